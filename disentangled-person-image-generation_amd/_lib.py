@@ -1,0 +1,127 @@
+"""ctypes binding of libdpig_hip.so (the C ABI declared in include/dpig_hip.h).
+
+The library is the product: there is NO fallback.  If the shared object is missing or a call
+returns a non-zero status a RuntimeError is raised (mirroring the reference's `raise Exception`
+convention, e.g. tflib/ops/deconv2d.py:38-39).
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdpig_hip.so")
+
+ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
+
+c_float_p = ctypes.c_void_p  # device pointers travel as integers
+
+
+class DpigConvDesc(ctypes.Structure):
+    _fields_ = [
+        ("N", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("C", ctypes.c_int32),
+        ("K", ctypes.c_int32), ("R", ctypes.c_int32), ("S", ctypes.c_int32), ("stride", ctypes.c_int32),
+        ("pad_t", ctypes.c_int32), ("pad_l", ctypes.c_int32),
+        ("ldx", ctypes.c_int32), ("ldy", ctypes.c_int32), ("ldres", ctypes.c_int32), ("ldmask", ctypes.c_int32),
+        ("act", ctypes.c_int32), ("alpha", ctypes.c_float),
+        ("upsample2x", ctypes.c_int32), ("split_k", ctypes.c_int32),
+    ]
+
+
+# every symbol include/dpig_hip.h declares: name -> (restype, argtypes)
+_vp, _i, _f, _i64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64, ctypes.c_size_t
+_dp = ctypes.POINTER(DpigConvDesc)
+SYMBOLS = {
+    "dpig_version": (_i, []),
+    "dpig_last_error": (ctypes.c_char_p, []),
+    "dpig_same_pad": (_i, [_i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
+    "dpig_conv2d_workspace_bytes": (_sz, [_dp, _i]),
+    "dpig_conv2d_fwd": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dpig_conv2d_dgrad": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dpig_conv2d_wgrad": (_i, [_dp, _vp, _vp, _vp, _f, _vp, _sz, _vp]),
+    "dpig_act_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _i, _i, _f, _vp]),
+    "dpig_colsum_workspace_bytes": (_sz, [_i64, _i]),
+    "dpig_colsum": (_i, [_vp, _i, _i64, _i, _vp, _f, _vp, _sz, _vp]),
+    "dpig_bn_workspace_bytes": (_sz, [_i64, _i]),
+    "dpig_bn_fwd": (_i, [_vp, _i, _i64, _i, _vp, _vp, _f, _i, _f, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "dpig_bn_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp, _vp, _vp, _i, _f, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "dpig_ln_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _i, _f, _vp, _vp, _vp, _vp]),
+    "dpig_ln_workspace_bytes": (_sz, [_i, _i, _i]),
+    "dpig_ln_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dpig_linear_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "dpig_linear_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
+    "dpig_linear_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "dpig_linear_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "dpig_crop_resize_fwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "dpig_crop_resize_bwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "dpig_upsample2x_fwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "dpig_upsample2x_bwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
+    "dpig_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _i, _f, _vp]),
+    "dpig_adam_multi": (_i, [_vp, _vp, _i, _i64, _vp, _f, _f, _f, _i, _f, _vp]),
+    "dpig_sce_mean": (_i, [_vp, _i, _f, _vp, _vp, _f, _vp]),
+    "dpig_l1_workspace_bytes": (_sz, [_i64]),
+    "dpig_l1_mean": (_i, [_vp, _vp, _i64, _vp, _vp, _f, _vp, _sz, _vp]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load (once) and return the ctypes handle.  Fails loudly when the extension is absent."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                "libdpig_hip.so not found at %s -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  There is no CPU fallback." % LIB_PATH)
+        h = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(h, name)  # AttributeError if the .so does not export a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = h
+    return _lib
+
+
+def check(rc, what=""):
+    if rc != 0:
+        msg = lib().dpig_last_error()
+        raise RuntimeError("libdpig_hip %s failed (%d): %s" % (what, rc, msg.decode() if msg else ""))
+
+
+def ptr(t):
+    """Device pointer of a tensor (or None)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+class _Workspace:
+    """Grow-only scratch buffer per device; the C ABI never allocates (SURVEY 8b ownership row)."""
+
+    def __init__(self):
+        self.buf = {}
+
+    def get(self, nbytes, device):
+        if nbytes == 0:
+            return None, 0
+        key = (device.type, device.index)
+        b = self.buf.get(key)
+        if b is None or b.numel() < nbytes:
+            # round up generously: reallocation is a sync point for the caching allocator
+            size = max(int(nbytes * 1.25), 64 << 20)
+            b = torch.empty(size, dtype=torch.uint8, device=device)
+            self.buf[key] = b
+        return b, b.numel()
+
+
+workspace = _Workspace()
+
+
+def same_pad(inp, k, stride):
+    """TF 'SAME': (out, pad_before) -- tflib/ops/conv2d.py:110 semantics (host-side mirror)."""
+    out = -(-inp // stride)
+    total = max((out - 1) * stride + k - inp, 0)
+    return out, total // 2

@@ -1,0 +1,677 @@
+// HBM-bound companions of the conv kernels: activation/bias gradients, batch norm, layer norm,
+// crop_and_resize, nearest upsample, TF-style Adam and the GAN/L1 losses.  All fp32, NHWC with
+// explicit row strides, float4 accesses wherever alignment allows, two-pass (deterministic)
+// reductions -- no atomics except the crop_and_resize scatter-add.
+#include "dpig_common.h"
+
+namespace dpig {
+
+char* err_buf() {
+    static thread_local char buf[512] = {0};
+    return buf;
+}
+int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err_buf(), 512, fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+static inline int cdivi(long a, long b) { return (int)((a + b - 1) / b); }
+static inline int grid_for(long n, int per_block = 256, int cap = 8 * kNumCU) {
+    int b = cdivi(n, per_block);
+    if (b > cap) b = cap;
+    return b < 1 ? 1 : b;
+}
+
+// ---------------------------------------------------------------------------------------------
+// elementwise activation backward: dz = dy * act'(y)
+// ---------------------------------------------------------------------------------------------
+template <bool VEC>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, int lddy,
+                                                      const float* __restrict__ y, int ldy,
+                                                      float* __restrict__ dz, int lddz, long rows, int cols,
+                                                      int act, float alpha) {
+    if (VEC) {
+        const int c4 = cols >> 2;
+        const long total = rows * c4;
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+            const long r = i / c4;
+            const int c = (int)(i - r * c4) * 4;
+            const float4 g = *reinterpret_cast<const float4*>(dy + r * lddy + c);
+            const float4 o = *reinterpret_cast<const float4*>(y + r * ldy + c);
+            float4 v;
+            v.x = g.x * act_grad(o.x, act, alpha);
+            v.y = g.y * act_grad(o.y, act, alpha);
+            v.z = g.z * act_grad(o.z, act, alpha);
+            v.w = g.w * act_grad(o.w, act, alpha);
+            *reinterpret_cast<float4*>(dz + r * lddz + c) = v;
+        }
+    } else {
+        const long total = rows * cols;
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+            const long r = i / cols;
+            const int c = (int)(i - r * cols);
+            dz[r * lddz + c] = dy[r * lddy + c] * act_grad(y[r * ldy + c], act, alpha);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// column reductions over a [rows, C] matrix.  Block = 64 columns x 4 row groups; grid.y row slabs.
+//   MODE 0: s0 = sum a
+//   MODE 1: s0 = sum (a - mean[c])^2
+//   MODE 2: dz = a*act'(y);  s0 = sum dz ; s1 = sum dz * (x - mean[c]) * rstd[c]          (BN bwd)
+//   MODE 3: as MODE 2 with per-sample statistics mean[r / P], rstd[r / P]                  (LN bwd)
+// partial layout: [slab][NOUT][C]
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void col_partial_kernel(const float* __restrict__ a, int lda,
+                                                          const float* __restrict__ x, int ldx,
+                                                          const float* __restrict__ y, int ldy,
+                                                          const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, long rows, int C,
+                                                          int P, int act, float alpha,
+                                                          float* __restrict__ partial) {
+    constexpr int NOUT = (MODE >= 2) ? 2 : 1;
+    __shared__ float red[NOUT][4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float s0 = 0.f, s1 = 0.f;
+    if (c < C) {
+        float mu = 0.f, rs = 0.f;
+        if (MODE == 1 || MODE == 2) mu = mean[c];
+        if (MODE == 2) rs = rstd[c];
+        for (long r = (long)blockIdx.y * 4 + rg; r < rows; r += (long)gridDim.y * 4) {
+            const float v = a[r * lda + c];
+            if (MODE == 0) {
+                s0 += v;
+            } else if (MODE == 1) {
+                const float d = v - mu;
+                s0 += d * d;
+            } else {
+                if (MODE == 3) { const long n = r / P; mu = mean[n]; rs = rstd[n]; }
+                const float dz = (act != DPIG_ACT_NONE) ? v * act_grad(y[r * ldy + c], act, alpha) : v;
+                s0 += dz;
+                s1 += dz * (x[r * ldx + c] - mu) * rs;
+            }
+        }
+    }
+    red[0][rg][cl] = s0;
+    if (NOUT == 2) red[NOUT - 1][rg][cl] = s1;
+    __syncthreads();
+    if (rg == 0 && c < C) {
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+            const float t = (red[o][0][cl] + red[o][1][cl]) + (red[o][2][cl] + red[o][3][cl]);
+            partial[((long)blockIdx.y * NOUT + o) * C + c] = t;
+        }
+    }
+}
+
+// out_o[c] = beta*out_o[c] + scale * sum_slab partial[slab][o][c]      (FIN 0)
+// out_0[c] = 1/sqrt(scale * sum + eps)                                  (FIN 1)
+template <int FIN>
+__global__ __launch_bounds__(256) void col_final_kernel(const float* __restrict__ partial, int nslab, int nout,
+                                                        int C, float* __restrict__ out0,
+                                                        float* __restrict__ out1, float scale, float beta,
+                                                        float eps) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    for (int o = 0; o < nout; ++o) {
+        float s = 0.f;
+        for (int b = 0; b < nslab; ++b) s += partial[((long)b * nout + o) * C + c];
+        float* out = (o == 0) ? out0 : out1;
+        if (!out) continue;
+        if (FIN == 1) out[c] = 1.0f / sqrtf(s * scale + eps);
+        else out[c] = ((beta != 0.f) ? beta * out[c] : 0.f) + s * scale;
+    }
+}
+
+static int slabs_for(long rows) {
+    long s = rows / 128;
+    if (s < 1) s = 1;
+    if (s > 256) s = 256;
+    return (int)s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// batch norm apply kernels
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, int ldx, long rows, int C,
+                                                       const float* __restrict__ scale,
+                                                       const float* __restrict__ offset,
+                                                       const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, int act, float alpha,
+                                                       float* __restrict__ y, int ldy) {
+    const long total = rows * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / C;
+        const int c = (int)(i - r * C);
+        const float v = (x[r * ldx + c] - mean[c]) * rstd[c] * scale[c] + offset[c];
+        y[r * ldy + c] = act_apply(v, act, alpha);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ dy, int lddy,
+                                                           const float* __restrict__ x, int ldx,
+                                                           const float* __restrict__ y, int ldy, long rows,
+                                                           int C, const float* __restrict__ scale,
+                                                           const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd,
+                                                           const float* __restrict__ dscale,
+                                                           const float* __restrict__ doffset, int act,
+                                                           float alpha, float* __restrict__ dx, int lddx) {
+    const long total = rows * C;
+    const float inv = 1.0f / (float)rows;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / C;
+        const int c = (int)(i - r * C);
+        float dz = dy[r * lddy + c];
+        if (act != DPIG_ACT_NONE) dz *= act_grad(y[r * ldy + c], act, alpha);
+        const float xh = (x[r * ldx + c] - mean[c]) * rstd[c];
+        dx[r * lddx + c] = scale[c] * rstd[c] * (dz - doffset[c] * inv - xh * dscale[c] * inv);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// layer norm: one 1024-thread workgroup per sample (N <= a few dozen, L = P*C <= ~1M)
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_1024(float v, float* red) {
+    v = wave_sum(v);
+    const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
+    __syncthreads();
+    if (l == 0) red[w] = v;
+    __syncthreads();
+    float t = (threadIdx.x < 16) ? red[threadIdx.x] : 0.f;
+    if (w == 0) {
+        t = wave_sum(t);
+        if (l == 0) red[16] = t;
+    }
+    __syncthreads();
+    return red[16];
+}
+
+__global__ __launch_bounds__(1024) void ln_fwd_kernel(const float* __restrict__ x, int P, int C,
+                                                      const float* __restrict__ scale,
+                                                      const float* __restrict__ offset, float eps, int act,
+                                                      float alpha, float* __restrict__ y,
+                                                      float* __restrict__ save_mean,
+                                                      float* __restrict__ save_rstd) {
+    __shared__ float red[17];
+    const long L = (long)P * C;
+    const float* xs = x + (long)blockIdx.x * L;
+    float* ys = y + (long)blockIdx.x * L;
+    float s = 0.f;
+    for (long i = threadIdx.x; i < L; i += 1024) s += xs[i];
+    const float mean = block_sum_1024(s, red) / (float)L;
+    float q = 0.f;
+    for (long i = threadIdx.x; i < L; i += 1024) { const float d = xs[i] - mean; q += d * d; }
+    const float var = block_sum_1024(q, red) / (float)L;
+    const float rstd = 1.0f / sqrtf(var + eps);
+    if (threadIdx.x == 0) { save_mean[blockIdx.x] = mean; save_rstd[blockIdx.x] = rstd; }
+    for (long i = threadIdx.x; i < L; i += 1024) {
+        const int c = (int)(i % C);
+        ys[i] = act_apply((xs[i] - mean) * rstd * scale[c] + offset[c], act, alpha);
+    }
+}
+
+__global__ __launch_bounds__(1024) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                      const float* __restrict__ y, int P, int C,
+                                                      const float* __restrict__ scale,
+                                                      const float* __restrict__ mean,
+                                                      const float* __restrict__ rstd, int act, float alpha,
+                                                      float* __restrict__ dx) {
+    __shared__ float red[17];
+    const long L = (long)P * C;
+    const long base = (long)blockIdx.x * L;
+    const float mu = mean[blockIdx.x], rs = rstd[blockIdx.x];
+    float s1 = 0.f, s2 = 0.f;
+    for (long i = threadIdx.x; i < L; i += 1024) {
+        const int c = (int)(i % C);
+        float dz = dy[base + i];
+        if (act != DPIG_ACT_NONE) dz *= act_grad(y[base + i], act, alpha);
+        const float g = dz * scale[c];
+        s1 += g;
+        s2 += g * (x[base + i] - mu) * rs;
+    }
+    const float S1 = block_sum_1024(s1, red) / (float)L;
+    const float S2 = block_sum_1024(s2, red) / (float)L;
+    for (long i = threadIdx.x; i < L; i += 1024) {
+        const int c = (int)(i % C);
+        float dz = dy[base + i];
+        if (act != DPIG_ACT_NONE) dz *= act_grad(y[base + i], act, alpha);
+        const float xh = (x[base + i] - mu) * rs;
+        dx[base + i] = rs * (dz * scale[c] - S1 - xh * S2);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// tf.image.crop_and_resize (bilinear, extrapolation_value 0) and its image gradient
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool crop_coord(float b1, float b2, int i, int crop, int size, float* pos) {
+    const float in = (crop > 1) ? b1 * (size - 1) + i * ((b2 - b1) * (size - 1) / (float)(crop - 1))
+                                : 0.5f * (b1 + b2) * (size - 1);
+    *pos = in;
+    return !(in < 0.f || in > (float)(size - 1));
+}
+
+__global__ __launch_bounds__(256) void crop_resize_fwd_kernel(const float* __restrict__ img, int H, int W, int C,
+                                                              const float* __restrict__ boxes,
+                                                              const int* __restrict__ box_ind, int nbox, int ch,
+                                                              int cw, float* __restrict__ out) {
+    const long total = (long)nbox * ch * cw * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long t = i / C;
+        const int j = (int)(t % cw); t /= cw;
+        const int ii = (int)(t % ch);
+        const int b = (int)(t / ch);
+        const float y1 = boxes[b * 4 + 0], x1 = boxes[b * 4 + 1], y2 = boxes[b * 4 + 2], x2 = boxes[b * 4 + 3];
+        float in_y, in_x;
+        const bool oky = crop_coord(y1, y2, ii, ch, H, &in_y);
+        const bool okx = crop_coord(x1, x2, j, cw, W, &in_x);
+        float v = 0.f;
+        if (oky && okx) {
+            const int ty = (int)floorf(in_y), by = (int)ceilf(in_y);
+            const int lx = (int)floorf(in_x), rx = (int)ceilf(in_x);
+            const float ly = in_y - ty, lxw = in_x - lx;
+            const float* base = img + (long)box_ind[b] * H * W * C + c;
+            const float tl = base[((long)ty * W + lx) * C], tr = base[((long)ty * W + rx) * C];
+            const float bl = base[((long)by * W + lx) * C], br = base[((long)by * W + rx) * C];
+            const float top = tl + (tr - tl) * lxw;
+            const float bot = bl + (br - bl) * lxw;
+            v = top + (bot - top) * ly;
+        }
+        out[i] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void crop_resize_bwd_kernel(const float* __restrict__ dout, int H, int W, int C,
+                                                              const float* __restrict__ boxes,
+                                                              const int* __restrict__ box_ind, int nbox, int ch,
+                                                              int cw, float* __restrict__ dimg) {
+    const long total = (long)nbox * ch * cw * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long t = i / C;
+        const int j = (int)(t % cw); t /= cw;
+        const int ii = (int)(t % ch);
+        const int b = (int)(t / ch);
+        const float y1 = boxes[b * 4 + 0], x1 = boxes[b * 4 + 1], y2 = boxes[b * 4 + 2], x2 = boxes[b * 4 + 3];
+        float in_y, in_x;
+        const bool oky = crop_coord(y1, y2, ii, ch, H, &in_y);
+        const bool okx = crop_coord(x1, x2, j, cw, W, &in_x);
+        if (!(oky && okx)) continue;
+        const int ty = (int)floorf(in_y), by = (int)ceilf(in_y);
+        const int lx = (int)floorf(in_x), rx = (int)ceilf(in_x);
+        const float ly = in_y - ty, lxw = in_x - lx;
+        const float g = dout[i];
+        float* base = dimg + (long)box_ind[b] * H * W * C + c;
+        const float dtop = (1.f - ly) * g, dbot = ly * g;
+        atomicAdd(&base[((long)ty * W + lx) * C], (1.f - lxw) * dtop);
+        atomicAdd(&base[((long)ty * W + rx) * C], lxw * dtop);
+        atomicAdd(&base[((long)by * W + lx) * C], (1.f - lxw) * dbot);
+        atomicAdd(&base[((long)by * W + rx) * C], lxw * dbot);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// nearest-neighbour 2x upsample (align_corners=False -> exact 2x2 replication) and its gradient
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* __restrict__ x, int N, int H, int W,
+                                                             int C, float* __restrict__ y) {
+    const long total = (long)N * 2 * H * 2 * W * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long t = i / C;
+        const int ox = (int)(t % (2 * W)); t /= (2 * W);
+        const int oy = (int)(t % (2 * H));
+        const long n = t / (2 * H);
+        y[i] = x[((n * H + (oy >> 1)) * W + (ox >> 1)) * C + c];
+    }
+}
+__global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ dy, int N, int H, int W,
+                                                             int C, float* __restrict__ dx) {
+    const long total = (long)N * H * W * C;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        long t = i / C;
+        const int ix = (int)(t % W); t /= W;
+        const int iy = (int)(t % H);
+        const long n = t / H;
+        const float* p = dy + ((n * 2 * H + 2 * iy) * (2L * W) + 2 * ix) * C + c;
+        dx[i] = (p[0] + p[C]) + (p[2L * W * C] + p[2L * W * C + C]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// TensorFlow Adam (epsilon outside the bias-corrected sqrt): trainer.py:137-140
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, float lr_t, float b1, float b2,
+                                         float eps) {
+    m = b1 * m + (1.f - b1) * g;
+    v = b2 * v + (1.f - b2) * g * g;
+    p -= lr_t * m / (sqrtf(v) + eps);
+}
+
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                   float* __restrict__ m, float* __restrict__ v, long n,
+                                                   const float* __restrict__ lr_dev, float b1, float b2,
+                                                   float eps, float corr, float gscale) {
+    const float lr_t = lr_dev[0] * corr;
+    const long n4 = n >> 2;
+    float4* p4 = reinterpret_cast<float4*>(p);
+    const float4* g4 = reinterpret_cast<const float4*>(g);
+    float4* m4 = reinterpret_cast<float4*>(m);
+    float4* v4 = reinterpret_cast<float4*>(v);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 pp = p4[i], mm = m4[i], vv = v4[i];
+        const float4 gg = g4[i];
+        adam_one(pp.x, gg.x * gscale, mm.x, vv.x, lr_t, b1, b2, eps);
+        adam_one(pp.y, gg.y * gscale, mm.y, vv.y, lr_t, b1, b2, eps);
+        adam_one(pp.z, gg.z * gscale, mm.z, vv.z, lr_t, b1, b2, eps);
+        adam_one(pp.w, gg.w * gscale, mm.w, vv.w, lr_t, b1, b2, eps);
+        p4[i] = pp; m4[i] = mm; v4[i] = vv;
+    }
+    // tail
+    for (long i = (n4 << 2) + (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        adam_one(p[i], g[i] * gscale, m[i], v[i], lr_t, b1, b2, eps);
+}
+
+__global__ __launch_bounds__(256) void adam_multi_kernel(const void* const* __restrict__ ptrs,
+                                                         const long* __restrict__ sizes,
+                                                         const float* __restrict__ lr_dev, float b1, float b2,
+                                                         float eps, float corr, float gscale) {
+    const int t = blockIdx.y;
+    const long n = sizes[t];
+    float* p = (float*)ptrs[4 * t + 0];
+    const float* g = (const float*)ptrs[4 * t + 1];
+    float* m = (float*)ptrs[4 * t + 2];
+    float* v = (float*)ptrs[4 * t + 3];
+    const float lr_t = lr_dev[0] * corr;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        adam_one(p[i], g[i] * gscale, m[i], v[i], lr_t, b1, b2, eps);
+}
+
+// ---------------------------------------------------------------------------------------------
+// losses
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void sce_mean_kernel(const float* __restrict__ x, int n, float label,
+                                                        float* __restrict__ out, float* __restrict__ dx,
+                                                        float scale) {
+    __shared__ float red[17];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float v = x[i];
+        // max(x,0) - x*z + log1p(exp(-|x|))   (tf.nn.sigmoid_cross_entropy_with_logits)
+        s += fmaxf(v, 0.f) - v * label + log1pf(expf(-fabsf(v)));
+        if (dx) {
+            const float sg = 1.f / (1.f + expf(-v));
+            dx[i] = scale * (sg - label) / (float)n;
+        }
+    }
+    const float t = block_sum_1024(s, red);
+    if (threadIdx.x == 0) out[0] = t / (float)n;
+}
+
+__global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
+                                                         long n, float* __restrict__ da, float gs,
+                                                         float* __restrict__ partial) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float d = a[i] - b[i];
+        s += fabsf(d);
+        if (da) da[i] = (d > 0.f) ? gs : ((d < 0.f) ? -gs : 0.f);
+    }
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+__global__ __launch_bounds__(256) void l1_final_kernel(const float* __restrict__ partial, int nb, float inv_n,
+                                                       float* __restrict__ out) {
+    __shared__ float red[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < nb; i += 256) s += partial[i];
+    s = wave_sum(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = ((red[0] + red[1]) + (red[2] + red[3])) * inv_n;
+}
+
+}  // namespace dpig
+
+using namespace dpig;
+
+// =================================================================================================
+// C ABI
+// =================================================================================================
+extern "C" int dpig_version(void) { return DPIG_VERSION; }
+extern "C" const char* dpig_last_error(void) { return err_buf(); }
+
+extern "C" int dpig_act_bwd(const float* dy, int lddy, const float* y, int ldy, float* dz, int lddz, int64_t rows,
+                            int cols, int act, float alpha, void* stream) {
+    if (!dy || !y || !dz) return fail(DPIG_EINVAL, "act_bwd: null pointer");
+    if (rows <= 0 || cols <= 0) return fail(DPIG_EINVAL, "act_bwd: empty");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool vec = aligned16(dy) && aligned16(y) && aligned16(dz) && cols % 4 == 0 && lddy % 4 == 0 &&
+                     ldy % 4 == 0 && lddz % 4 == 0;
+    if (vec)
+        hipLaunchKernelGGL((act_bwd_kernel<true>), dim3(grid_for(rows * (cols / 4))), dim3(256), 0, st, dy, lddy, y,
+                           ldy, dz, lddz, (long)rows, cols, act, alpha);
+    else
+        hipLaunchKernelGGL((act_bwd_kernel<false>), dim3(grid_for(rows * cols)), dim3(256), 0, st, dy, lddy, y, ldy,
+                           dz, lddz, (long)rows, cols, act, alpha);
+    return check_launch("act_bwd_kernel");
+}
+
+extern "C" size_t dpig_colsum_workspace_bytes(int64_t rows, int cols) {
+    return (size_t)slabs_for(rows) * 2 * cols * sizeof(float);
+}
+extern "C" int dpig_colsum(const float* a, int lda, int64_t rows, int cols, float* out, float beta, void* ws,
+                           size_t ws_bytes, void* stream) {
+    if (!a || !out) return fail(DPIG_EINVAL, "colsum: null pointer");
+    if (!ws || ws_bytes < dpig_colsum_workspace_bytes(rows, cols)) return fail(DPIG_ENOMEM, "colsum: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nslab = slabs_for(rows);
+    float* partial = static_cast<float*>(ws);
+    hipLaunchKernelGGL((col_partial_kernel<0>), dim3(cdivi(cols, 64), nslab), dim3(256), 0, st, a, lda, nullptr, 0,
+                       nullptr, 0, nullptr, nullptr, (long)rows, cols, 1, 0, 0.f, partial);
+    hipLaunchKernelGGL((col_final_kernel<0>), dim3(cdivi(cols, 256)), dim3(256), 0, st, partial, nslab, 1, cols, out,
+                       nullptr, 1.0f, beta, 0.f);
+    return check_launch("colsum");
+}
+
+extern "C" size_t dpig_bn_workspace_bytes(int64_t rows, int C) {
+    return (size_t)slabs_for(rows) * 2 * C * sizeof(float);
+}
+extern "C" int dpig_bn_fwd(const float* x, int ldx, int64_t rows, int C, const float* scale, const float* offset,
+                           float eps, int act, float alpha, float* y, int ldy, float* save_mean, float* save_rstd,
+                           void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !scale || !offset || !y || !save_mean || !save_rstd) return fail(DPIG_EINVAL, "bn_fwd: null pointer");
+    if (!ws || ws_bytes < dpig_bn_workspace_bytes(rows, C)) return fail(DPIG_ENOMEM, "bn_fwd: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nslab = slabs_for(rows);
+    float* partial = static_cast<float*>(ws);
+    const dim3 g1(cdivi(C, 64), nslab), g2(cdivi(C, 256));
+    hipLaunchKernelGGL((col_partial_kernel<0>), g1, dim3(256), 0, st, x, ldx, nullptr, 0, nullptr, 0, nullptr,
+                       nullptr, (long)rows, C, 1, 0, 0.f, partial);
+    hipLaunchKernelGGL((col_final_kernel<0>), g2, dim3(256), 0, st, partial, nslab, 1, C, save_mean, nullptr,
+                       1.0f / (float)rows, 0.f, 0.f);
+    hipLaunchKernelGGL((col_partial_kernel<1>), g1, dim3(256), 0, st, x, ldx, nullptr, 0, nullptr, 0, save_mean,
+                       nullptr, (long)rows, C, 1, 0, 0.f, partial);
+    hipLaunchKernelGGL((col_final_kernel<1>), g2, dim3(256), 0, st, partial, nslab, 1, C, save_rstd, nullptr,
+                       1.0f / (float)rows, 0.f, eps);
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(rows * C)), dim3(256), 0, st, x, ldx, (long)rows, C, scale,
+                       offset, save_mean, save_rstd, act, alpha, y, ldy);
+    return check_launch("bn_fwd");
+}
+
+extern "C" int dpig_bn_bwd(const float* dy, int lddy, const float* x, int ldx, const float* y, int ldy, int64_t rows,
+                           int C, const float* scale, const float* save_mean, const float* save_rstd, int act,
+                           float alpha, float* dx, int lddx, float* dscale, float* doffset, void* ws,
+                           size_t ws_bytes, void* stream) {
+    if (!dy || !x || !scale || !save_mean || !save_rstd || !dx || !dscale || !doffset)
+        return fail(DPIG_EINVAL, "bn_bwd: null pointer");
+    if (act != DPIG_ACT_NONE && !y) return fail(DPIG_EINVAL, "bn_bwd: activation output required");
+    if (!ws || ws_bytes < dpig_bn_workspace_bytes(rows, C)) return fail(DPIG_ENOMEM, "bn_bwd: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nslab = slabs_for(rows);
+    float* partial = static_cast<float*>(ws);
+    hipLaunchKernelGGL((col_partial_kernel<2>), dim3(cdivi(C, 64), nslab), dim3(256), 0, st, dy, lddy, x, ldx, y, ldy,
+                       save_mean, save_rstd, (long)rows, C, 1, act, alpha, partial);
+    hipLaunchKernelGGL((col_final_kernel<0>), dim3(cdivi(C, 256)), dim3(256), 0, st, partial, nslab, 2, C, doffset,
+                       dscale, 1.0f, 0.f, 0.f);
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * C)), dim3(256), 0, st, dy, lddy, x, ldx, y, ldy,
+                       (long)rows, C, scale, save_mean, save_rstd, dscale, doffset, act, alpha, dx, lddx);
+    return check_launch("bn_bwd");
+}
+
+extern "C" int dpig_ln_fwd(const float* x, int N, int P, int C, const float* scale, const float* offset, float eps,
+                           int act, float alpha, float* y, float* save_mean, float* save_rstd, void* stream) {
+    if (!x || !scale || !offset || !y || !save_mean || !save_rstd) return fail(DPIG_EINVAL, "ln_fwd: null pointer");
+    if (N <= 0 || P <= 0 || C <= 0) return fail(DPIG_EINVAL, "ln_fwd: empty");
+    hipLaunchKernelGGL(ln_fwd_kernel, dim3(N), dim3(1024), 0, static_cast<hipStream_t>(stream), x, P, C, scale, offset,
+                       eps, act, alpha, y, save_mean, save_rstd);
+    return check_launch("ln_fwd");
+}
+extern "C" size_t dpig_ln_workspace_bytes(int N, int P, int C) {
+    return (size_t)slabs_for((long)N * P) * 2 * C * sizeof(float);
+}
+extern "C" int dpig_ln_bwd(const float* dy, const float* x, const float* y, int N, int P, int C, const float* scale,
+                           const float* save_mean, const float* save_rstd, int act, float alpha, float* dx,
+                           float* dscale, float* doffset, void* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !x || !scale || !save_mean || !save_rstd || !dx || !dscale || !doffset)
+        return fail(DPIG_EINVAL, "ln_bwd: null pointer");
+    if (act != DPIG_ACT_NONE && !y) return fail(DPIG_EINVAL, "ln_bwd: activation output required");
+    if (!ws || ws_bytes < dpig_ln_workspace_bytes(N, P, C)) return fail(DPIG_ENOMEM, "ln_bwd: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const long rows = (long)N * P;
+    const int nslab = slabs_for(rows);
+    float* partial = static_cast<float*>(ws);
+    hipLaunchKernelGGL((col_partial_kernel<3>), dim3(cdivi(C, 64), nslab), dim3(256), 0, st, dy, C, x, C, y, C,
+                       save_mean, save_rstd, rows, C, P, act, alpha, partial);
+    hipLaunchKernelGGL((col_final_kernel<0>), dim3(cdivi(C, 256)), dim3(256), 0, st, partial, nslab, 2, C, doffset,
+                       dscale, 1.0f, 0.f, 0.f);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(N), dim3(1024), 0, st, dy, x, y, P, C, scale, save_mean, save_rstd, act,
+                       alpha, dx);
+    return check_launch("ln_bwd");
+}
+
+// ---- fully connected layers ride on the conv kernels (a [M,K] matrix is an M x 1 x 1 x K image) -
+static DpigConvDesc linear_desc(int M, int Kin, int Nout, int act, float alpha) {
+    DpigConvDesc d = {};
+    d.N = M; d.H = 1; d.W = 1; d.C = Kin; d.K = Nout; d.R = 1; d.S = 1; d.stride = 1;
+    d.pad_t = 0; d.pad_l = 0; d.ldx = Kin; d.ldy = Nout; d.ldres = 0; d.ldmask = 0;
+    d.act = act; d.alpha = alpha; d.upsample2x = 0; d.split_k = 0;
+    return d;
+}
+extern "C" size_t dpig_linear_workspace_bytes(int M, int Kin, int Nout, int which) {
+    DpigConvDesc d = linear_desc(M, Kin, Nout, 0, 0.f);
+    size_t b = dpig_conv2d_workspace_bytes(&d, which);
+    if (which == 2) {
+        const size_t c = dpig_colsum_workspace_bytes(M, Nout);
+        if (c > b) b = c;
+    }
+    return b;
+}
+extern "C" int dpig_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int Kin, int Nout,
+                               int act, float alpha, void* ws, size_t ws_bytes, void* stream) {
+    if (M <= 0 || Kin <= 0 || Nout <= 0) return fail(DPIG_EINVAL, "linear: non-positive dims");
+    DpigConvDesc d = linear_desc(M, Kin, Nout, act, alpha);
+    return dpig_conv2d_fwd(&d, x, w, bias, nullptr, y, ws, ws_bytes, stream);
+}
+extern "C" int dpig_linear_dgrad(const float* dy, const float* w, float* dx, int M, int Kin, int Nout, void* ws,
+                                 size_t ws_bytes, void* stream) {
+    if (M <= 0 || Kin <= 0 || Nout <= 0) return fail(DPIG_EINVAL, "linear: non-positive dims");
+    DpigConvDesc d = linear_desc(M, Kin, Nout, 0, 0.f);
+    return dpig_conv2d_dgrad(&d, dy, w, nullptr, nullptr, dx, ws, ws_bytes, stream);
+}
+extern "C" int dpig_linear_wgrad(const float* x, const float* dy, float* dw, float* db, int M, int Kin, int Nout,
+                                 void* ws, size_t ws_bytes, void* stream) {
+    if (M <= 0 || Kin <= 0 || Nout <= 0) return fail(DPIG_EINVAL, "linear: non-positive dims");
+    DpigConvDesc d = linear_desc(M, Kin, Nout, 0, 0.f);
+    int rc = dpig_conv2d_wgrad(&d, x, dy, dw, 0.f, ws, ws_bytes, stream);
+    if (rc) return rc;
+    if (db) rc = dpig_colsum(dy, Nout, M, Nout, db, 0.f, ws, ws_bytes, stream);
+    return rc;
+}
+
+extern "C" int dpig_crop_resize_fwd(const float* img, int N, int H, int W, int C, const float* boxes,
+                                    const int32_t* box_ind, int nbox, int ch, int cw, float* out, void* stream) {
+    if (!img || !boxes || !box_ind || !out) return fail(DPIG_EINVAL, "crop_resize: null pointer");
+    if (N <= 0 || nbox <= 0 || ch <= 0 || cw <= 0) return fail(DPIG_EINVAL, "crop_resize: empty");
+    hipLaunchKernelGGL(crop_resize_fwd_kernel, dim3(grid_for((long)nbox * ch * cw * C)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), img, H, W, C, boxes, box_ind, nbox, ch, cw, out);
+    return check_launch("crop_resize_fwd");
+}
+extern "C" int dpig_crop_resize_bwd(const float* dout, int N, int H, int W, int C, const float* boxes,
+                                    const int32_t* box_ind, int nbox, int ch, int cw, float* dimg, void* stream) {
+    if (!dout || !boxes || !box_ind || !dimg) return fail(DPIG_EINVAL, "crop_resize: null pointer");
+    if (N <= 0 || nbox <= 0 || ch <= 0 || cw <= 0) return fail(DPIG_EINVAL, "crop_resize: empty");
+    hipLaunchKernelGGL(crop_resize_bwd_kernel, dim3(grid_for((long)nbox * ch * cw * C)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), dout, H, W, C, boxes, box_ind, nbox, ch, cw, dimg);
+    return check_launch("crop_resize_bwd");
+}
+
+extern "C" int dpig_upsample2x_fwd(const float* x, int N, int H, int W, int C, float* y, void* stream) {
+    if (!x || !y) return fail(DPIG_EINVAL, "upsample2x: null pointer");
+    hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(grid_for((long)N * H * W * C * 4)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x, N, H, W, C, y);
+    return check_launch("upsample2x_fwd");
+}
+extern "C" int dpig_upsample2x_bwd(const float* dy, int N, int H, int W, int C, float* dx, void* stream) {
+    if (!dy || !dx) return fail(DPIG_EINVAL, "upsample2x: null pointer");
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3(grid_for((long)N * H * W * C)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), dy, N, H, W, C, dx);
+    return check_launch("upsample2x_bwd");
+}
+
+static float adam_corr(float b1, float b2, int step) {
+    // lr_t = lr * sqrt(1 - b2^t) / (1 - b1^t), t >= 1
+    const double t = (double)step;
+    return (float)(sqrt(1.0 - pow((double)b2, t)) / (1.0 - pow((double)b1, t)));
+}
+extern "C" int dpig_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev,
+                              float beta1, float beta2, float eps, int step, float grad_scale, void* stream) {
+    if (!p || !g || !m || !v || !lr_dev) return fail(DPIG_EINVAL, "adam: null pointer");
+    if (step < 1) return fail(DPIG_EINVAL, "adam: step must be >= 1");
+    if (!(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v))) return fail(DPIG_EALIGN, "adam: 16B alignment required");
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m,
+                       v, (long)n, lr_dev, beta1, beta2, eps, adam_corr(beta1, beta2, step), grad_scale);
+    return check_launch("adam");
+}
+extern "C" int dpig_adam_multi(const void* const* ptrs_dev, const int64_t* sizes_dev, int ntensors, int64_t max_size,
+                               const float* lr_dev, float beta1, float beta2, float eps, int step, float grad_scale,
+                               void* stream) {
+    if (!ptrs_dev || !sizes_dev || !lr_dev || ntensors <= 0) return fail(DPIG_EINVAL, "adam_multi: bad arguments");
+    if (step < 1) return fail(DPIG_EINVAL, "adam: step must be >= 1");
+    int bx = grid_for(max_size, 256, 512);
+    hipLaunchKernelGGL(adam_multi_kernel, dim3(bx, ntensors), dim3(256), 0, static_cast<hipStream_t>(stream), ptrs_dev,
+                       reinterpret_cast<const long*>(sizes_dev), lr_dev, beta1, beta2, eps,
+                       adam_corr(beta1, beta2, step), grad_scale);
+    return check_launch("adam_multi");
+}
+
+extern "C" int dpig_sce_mean(const float* logits, int n, float label, float* out, float* dlogits, float scale,
+                             void* stream) {
+    if (!logits || !out || n <= 0) return fail(DPIG_EINVAL, "sce: bad arguments");
+    hipLaunchKernelGGL(sce_mean_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), logits, n, label, out,
+                       dlogits, scale);
+    return check_launch("sce_mean");
+}
+extern "C" size_t dpig_l1_workspace_bytes(int64_t n) { return (size_t)grid_for(n, 1024, 1024) * sizeof(float); }
+extern "C" int dpig_l1_mean(const float* a, const float* b, int64_t n, float* out, float* da, float scale, void* ws,
+                            size_t ws_bytes, void* stream) {
+    if (!a || !b || !out || n <= 0) return fail(DPIG_EINVAL, "l1: bad arguments");
+    if (!ws || ws_bytes < dpig_l1_workspace_bytes(n)) return fail(DPIG_ENOMEM, "l1: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nb = grid_for(n, 1024, 1024);
+    float* partial = static_cast<float*>(ws);
+    hipLaunchKernelGGL(l1_partial_kernel, dim3(nb), dim3(256), 0, st, a, b, (long)n, da, scale / (float)n, partial);
+    hipLaunchKernelGGL(l1_final_kernel, dim3(1), dim3(256), 0, st, partial, nb, 1.0f / (float)n, out);
+    return check_launch("l1_mean");
+}

@@ -1,0 +1,356 @@
+"""Thin functional layer over the C ABI: torch tensors in, torch tensors out, no autograd.
+
+Every function launches hand-written gfx950 kernels from libdpig_hip.so on torch's current HIP
+stream.  Tensors are fp32 NHWC; a tensor may be a channel slice of a wider NHWC buffer (stride of
+the W axis = "ld"), which is how channel concats (models.py:524,560) cost nothing.
+"""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, DpigConvDesc, check, lib, ptr, stream_ptr, workspace
+
+
+def _require_gpu(t):
+    if not t.is_cuda:
+        raise RuntimeError("dpig HIP ops need device tensors (got %s): there is no CPU fallback" % t.device)
+    if t.dtype != torch.float32:
+        raise RuntimeError("dpig HIP ops are fp32 (got %s)" % t.dtype)
+
+
+def nhwc_ld(t):
+    """Channel stride of an NHWC tensor that is dense except for a channel slice; None if not."""
+    if t.dim() != 4:
+        return None
+    n, h, w, c = t.shape
+    s = t.stride()
+    if c > 1 and s[3] != 1:
+        return None
+    ld = s[2] if w > 1 else (s[1] // max(w, 1) if h > 1 else (s[0] // max(h * w, 1) if n > 1 else c))
+    if ld < c:
+        return None
+    if (w > 1 and s[2] != ld) or (h > 1 and s[1] != w * ld) or (n > 1 and s[0] != h * w * ld):
+        return None
+    return ld
+
+
+def as_nhwc(t):
+    """Return (tensor, ld) with tensor usable by the kernels (copy only if the layout is exotic)."""
+    ld = nhwc_ld(t)
+    if ld is None:
+        t = t.contiguous()
+        ld = t.shape[3]
+    return t, ld
+
+
+def _desc(N, H, W, C, K, R, S, stride, ldx, ldy, ldres=0, ldmask=0, act=ACT_NONE, alpha=0.2, upsample2x=False,
+          split_k=0):
+    d = DpigConvDesc()
+    d.N, d.H, d.W, d.C, d.K, d.R, d.S, d.stride = N, H, W, C, K, R, S, stride
+    d.pad_t, d.pad_l = -1, -1
+    d.ldx, d.ldy, d.ldres, d.ldmask = ldx, ldy, ldres, ldmask
+    d.act, d.alpha, d.upsample2x, d.split_k = act, alpha, int(upsample2x), split_k
+    return d
+
+
+def _ws(d, which, device):
+    nbytes = lib().dpig_conv2d_workspace_bytes(ctypes.byref(d), which)
+    buf, size = workspace.get(nbytes, device)
+    return buf, size
+
+
+def conv_out_hw(H, W, R, S, stride, upsample2x=False):
+    if upsample2x:
+        return 2 * H, 2 * W
+    return _lib.same_pad(H, R, stride)[0], _lib.same_pad(W, S, stride)[0]
+
+
+def conv2d_fwd(x, w, bias=None, stride=1, act=ACT_NONE, alpha=0.2, residual=None, out=None, upsample2x=False,
+               split_k=0):
+    """y = act(conv_SAME(x, w) + bias + residual); x NHWC, w HWIO.  `out` may be a channel slice."""
+    _require_gpu(x)
+    x, ldx = as_nhwc(x)
+    w = w.contiguous()
+    N, H, W, C = x.shape
+    R, S, Cw, K = w.shape
+    if Cw != C:
+        raise RuntimeError("conv2d: filter expects %d input channels, tensor has %d" % (Cw, C))
+    Ho, Wo = conv_out_hw(H, W, R, S, stride, upsample2x)
+    if out is None:
+        out = torch.empty((N, Ho, Wo, K), dtype=torch.float32, device=x.device)
+    ldy = nhwc_ld(out)
+    if ldy is None or tuple(out.shape) != (N, Ho, Wo, K):
+        raise RuntimeError("conv2d: bad output tensor")
+    ldres = 0
+    if residual is not None:
+        residual, ldres = as_nhwc(residual)
+    if bias is not None:
+        bias = bias.contiguous()
+    d = _desc(N, H, W, C, K, R, S, stride, ldx, ldy, ldres=ldres, act=act, alpha=alpha, upsample2x=upsample2x,
+              split_k=split_k)
+    wsb, wsn = _ws(d, 0, x.device)
+    check(lib().dpig_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(out), ptr(wsb), wsn,
+                                stream_ptr()), "conv2d_fwd")
+    return out
+
+
+def conv2d_dgrad(dy, w, in_shape, stride=1, accum=None, mask=None, act=ACT_NONE, alpha=0.2, out=None,
+                 upsample2x=False, split_k=0):
+    """dx = (conv_backward_data(dy, w) + accum) * act'(mask);  in_shape = (N,H,W,C) of the fwd input."""
+    _require_gpu(dy)
+    dy, ldy = as_nhwc(dy)
+    w = w.contiguous()
+    N, H, W, C = in_shape
+    R, S, Cw, K = w.shape
+    if Cw != C or dy.shape[3] != K:
+        raise RuntimeError("conv2d_dgrad: channel mismatch")
+    Ho, Wo = conv_out_hw(H, W, R, S, stride, upsample2x)
+    if tuple(dy.shape) != (N, Ho, Wo, K):
+        raise RuntimeError("conv2d_dgrad: dy shape %s, expected %s" % (tuple(dy.shape), (N, Ho, Wo, K)))
+    if out is None:
+        out = torch.empty((N, H, W, C), dtype=torch.float32, device=dy.device)
+    ldx = nhwc_ld(out)
+    if ldx is None or tuple(out.shape) != (N, H, W, C):
+        raise RuntimeError("conv2d_dgrad: bad output tensor")
+    ldres = ldmask = 0
+    if accum is not None:
+        accum, ldres = as_nhwc(accum)
+    if mask is not None:
+        mask, ldmask = as_nhwc(mask)
+    d = _desc(N, H, W, C, K, R, S, stride, ldx, ldy, ldres=ldres, ldmask=ldmask, act=act, alpha=alpha,
+              upsample2x=upsample2x, split_k=split_k)
+    wsb, wsn = _ws(d, 1, dy.device)
+    check(lib().dpig_conv2d_dgrad(ctypes.byref(d), ptr(dy), ptr(w), ptr(accum), ptr(mask), ptr(out), ptr(wsb), wsn,
+                                  stream_ptr()), "conv2d_dgrad")
+    return out
+
+
+def conv2d_wgrad(x, dy, wshape, stride=1, upsample2x=False, out=None, beta=0.0, split_k=0):
+    """dw[R,S,C,K] = conv_backward_filter(x, dy)."""
+    _require_gpu(x)
+    x, ldx = as_nhwc(x)
+    dy, ldy = as_nhwc(dy)
+    N, H, W, C = x.shape
+    R, S, Cw, K = wshape
+    if Cw != C or dy.shape[3] != K:
+        raise RuntimeError("conv2d_wgrad: channel mismatch")
+    if out is None:
+        out = torch.empty(tuple(wshape), dtype=torch.float32, device=x.device)
+        beta = 0.0
+    d = _desc(N, H, W, C, K, R, S, stride, ldx, ldy, upsample2x=upsample2x, split_k=split_k)
+    wsb, wsn = _ws(d, 2, x.device)
+    check(lib().dpig_conv2d_wgrad(ctypes.byref(d), ptr(x), ptr(dy), ptr(out), float(beta), ptr(wsb), wsn,
+                                  stream_ptr()), "conv2d_wgrad")
+    return out
+
+
+def _rows_ld(t):
+    """View an NHWC (or 2-D) tensor as [rows, cols] with row stride ld."""
+    if t.dim() == 2:
+        if t.stride(1) != 1 and t.shape[1] > 1:
+            t = t.contiguous()
+        return t, t.shape[0], t.shape[1], (t.stride(0) if t.shape[0] > 1 else t.shape[1])
+    t, ld = as_nhwc(t)
+    return t, t.shape[0] * t.shape[1] * t.shape[2], t.shape[3], ld
+
+
+def act_bwd(dy, y, act, alpha=0.2):
+    """dz = dy * act'(y) with y the activation output."""
+    _require_gpu(dy)
+    dy, rows, cols, lddy = _rows_ld(dy)
+    y, _, _, ldy = _rows_ld(y)
+    dz = torch.empty(dy.shape, dtype=torch.float32, device=dy.device)
+    check(lib().dpig_act_bwd(ptr(dy), lddy, ptr(y), ldy, ptr(dz), cols, rows, cols, act, alpha, stream_ptr()),
+          "act_bwd")
+    return dz
+
+
+def colsum(a, out=None, beta=0.0):
+    """Column sums of an NHWC / 2-D tensor viewed as [rows, C] (bias gradient)."""
+    _require_gpu(a)
+    a, rows, cols, lda = _rows_ld(a)
+    if out is None:
+        out = torch.empty(cols, dtype=torch.float32, device=a.device)
+        beta = 0.0
+    nbytes = lib().dpig_colsum_workspace_bytes(rows, cols)
+    wsb, wsn = workspace.get(nbytes, a.device)
+    check(lib().dpig_colsum(ptr(a), lda, rows, cols, ptr(out), float(beta), ptr(wsb), wsn, stream_ptr()), "colsum")
+    return out
+
+
+def bn_fwd(x, scale, offset, eps=1e-5, act=ACT_NONE, alpha=0.2):
+    """Training-mode batch norm over all but the last axis (+ fused activation)."""
+    _require_gpu(x)
+    x, rows, C, ldx = _rows_ld(x)
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    mean = torch.empty(C, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    wsb, wsn = workspace.get(lib().dpig_bn_workspace_bytes(rows, C), x.device)
+    check(lib().dpig_bn_fwd(ptr(x), ldx, rows, C, ptr(scale.contiguous()), ptr(offset.contiguous()), eps, act, alpha,
+                            ptr(y), C, ptr(mean), ptr(rstd), ptr(wsb), wsn, stream_ptr()), "bn_fwd")
+    return y, mean, rstd
+
+
+def bn_bwd(dy, x, y, scale, mean, rstd, act=ACT_NONE, alpha=0.2):
+    _require_gpu(dy)
+    dy, rows, C, lddy = _rows_ld(dy)
+    x, _, _, ldx = _rows_ld(x)
+    ldy = C
+    if y is not None:
+        y, _, _, ldy = _rows_ld(y)
+    dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    dscale = torch.empty(C, dtype=torch.float32, device=x.device)
+    doffset = torch.empty(C, dtype=torch.float32, device=x.device)
+    wsb, wsn = workspace.get(lib().dpig_bn_workspace_bytes(rows, C), x.device)
+    check(lib().dpig_bn_bwd(ptr(dy), lddy, ptr(x), ldx, ptr(y), ldy, rows, C, ptr(scale.contiguous()), ptr(mean),
+                            ptr(rstd), act, alpha, ptr(dx), C, ptr(dscale), ptr(doffset), ptr(wsb), wsn,
+                            stream_ptr()), "bn_bwd")
+    return dx, dscale, doffset
+
+
+def ln_fwd(x, scale, offset, eps=1e-5, act=ACT_NONE, alpha=0.2):
+    """Layer norm over (H,W,C) per sample; x NHWC dense."""
+    _require_gpu(x)
+    x = x.contiguous()
+    N, C = x.shape[0], x.shape[-1]
+    P = x.numel() // (N * C)
+    y = torch.empty_like(x)
+    mean = torch.empty(N, dtype=torch.float32, device=x.device)
+    rstd = torch.empty(N, dtype=torch.float32, device=x.device)
+    check(lib().dpig_ln_fwd(ptr(x), N, P, C, ptr(scale.contiguous()), ptr(offset.contiguous()), eps, act, alpha,
+                            ptr(y), ptr(mean), ptr(rstd), stream_ptr()), "ln_fwd")
+    return y, mean, rstd
+
+
+def ln_bwd(dy, x, y, scale, mean, rstd, act=ACT_NONE, alpha=0.2):
+    _require_gpu(dy)
+    dy = dy.contiguous()
+    x = x.contiguous()
+    if y is not None:
+        y = y.contiguous()
+    N, C = x.shape[0], x.shape[-1]
+    P = x.numel() // (N * C)
+    dx = torch.empty_like(x)
+    dscale = torch.empty(C, dtype=torch.float32, device=x.device)
+    doffset = torch.empty(C, dtype=torch.float32, device=x.device)
+    wsb, wsn = workspace.get(lib().dpig_ln_workspace_bytes(N, P, C), x.device)
+    check(lib().dpig_ln_bwd(ptr(dy), ptr(x), ptr(y), N, P, C, ptr(scale.contiguous()), ptr(mean), ptr(rstd), act,
+                            alpha, ptr(dx), ptr(dscale), ptr(doffset), ptr(wsb), wsn, stream_ptr()), "ln_bwd")
+    return dx, dscale, doffset
+
+
+def linear_fwd(x, w, bias=None, act=ACT_NONE, alpha=0.2):
+    _require_gpu(x)
+    x = x.contiguous()
+    w = w.contiguous()
+    M, Kin = x.shape
+    Nout = w.shape[1]
+    if w.shape[0] != Kin:
+        raise RuntimeError("linear: weight is %s, input has %d features" % (tuple(w.shape), Kin))
+    y = torch.empty((M, Nout), dtype=torch.float32, device=x.device)
+    wsb, wsn = workspace.get(lib().dpig_linear_workspace_bytes(M, Kin, Nout, 0), x.device)
+    check(lib().dpig_linear_fwd(ptr(x), ptr(w), ptr(bias.contiguous() if bias is not None else None), ptr(y), M, Kin,
+                                Nout, act, alpha, ptr(wsb), wsn, stream_ptr()), "linear_fwd")
+    return y
+
+
+def linear_dgrad(dy, w):
+    _require_gpu(dy)
+    dy = dy.contiguous()
+    w = w.contiguous()
+    M, Nout = dy.shape
+    Kin = w.shape[0]
+    dx = torch.empty((M, Kin), dtype=torch.float32, device=dy.device)
+    wsb, wsn = workspace.get(lib().dpig_linear_workspace_bytes(M, Kin, Nout, 1), dy.device)
+    check(lib().dpig_linear_dgrad(ptr(dy), ptr(w), ptr(dx), M, Kin, Nout, ptr(wsb), wsn, stream_ptr()),
+          "linear_dgrad")
+    return dx
+
+
+def linear_wgrad(x, dy, need_bias=True):
+    _require_gpu(x)
+    x = x.contiguous()
+    dy = dy.contiguous()
+    M, Kin = x.shape
+    Nout = dy.shape[1]
+    dw = torch.empty((Kin, Nout), dtype=torch.float32, device=x.device)
+    db = torch.empty(Nout, dtype=torch.float32, device=x.device) if need_bias else None
+    wsb, wsn = workspace.get(lib().dpig_linear_workspace_bytes(M, Kin, Nout, 2), x.device)
+    check(lib().dpig_linear_wgrad(ptr(x), ptr(dy), ptr(dw), ptr(db), M, Kin, Nout, ptr(wsb), wsn, stream_ptr()),
+          "linear_wgrad")
+    return dw, db
+
+
+def crop_resize_fwd(img, boxes, box_ind, ch, cw):
+    _require_gpu(img)
+    img = img.contiguous()
+    N, H, W, C = img.shape
+    boxes = boxes.contiguous().float()
+    box_ind = box_ind.contiguous().to(torch.int32)
+    nb = boxes.shape[0]
+    out = torch.empty((nb, ch, cw, C), dtype=torch.float32, device=img.device)
+    check(lib().dpig_crop_resize_fwd(ptr(img), N, H, W, C, ptr(boxes), ptr(box_ind), nb, ch, cw, ptr(out),
+                                     stream_ptr()), "crop_resize_fwd")
+    return out
+
+
+def crop_resize_bwd(dout, boxes, box_ind, img_shape):
+    _require_gpu(dout)
+    dout = dout.contiguous()
+    N, H, W, C = img_shape
+    boxes = boxes.contiguous().float()
+    box_ind = box_ind.contiguous().to(torch.int32)
+    nb, ch, cw, _ = dout.shape
+    dimg = torch.zeros(tuple(img_shape), dtype=torch.float32, device=dout.device)
+    check(lib().dpig_crop_resize_bwd(ptr(dout), N, H, W, C, ptr(boxes), ptr(box_ind), nb, ch, cw, ptr(dimg),
+                                     stream_ptr()), "crop_resize_bwd")
+    return dimg
+
+
+def upsample2x_fwd(x):
+    _require_gpu(x)
+    x = x.contiguous()
+    N, H, W, C = x.shape
+    y = torch.empty((N, 2 * H, 2 * W, C), dtype=torch.float32, device=x.device)
+    check(lib().dpig_upsample2x_fwd(ptr(x), N, H, W, C, ptr(y), stream_ptr()), "upsample2x_fwd")
+    return y
+
+
+def upsample2x_bwd(dy):
+    _require_gpu(dy)
+    dy = dy.contiguous()
+    N, H2, W2, C = dy.shape
+    dx = torch.empty((N, H2 // 2, W2 // 2, C), dtype=torch.float32, device=dy.device)
+    check(lib().dpig_upsample2x_bwd(ptr(dy), N, H2 // 2, W2 // 2, C, ptr(dx), stream_ptr()), "upsample2x_bwd")
+    return dx
+
+
+def adam_step(p, g, m, v, lr_dev, beta1, beta2, eps, step, grad_scale=1.0):
+    """In-place TF Adam on flat fp32 buffers; lr_dev is a 1-element device tensor."""
+    _require_gpu(p)
+    check(lib().dpig_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(lr_dev), beta1, beta2, eps, step,
+                               grad_scale, stream_ptr()), "adam_step")
+
+
+def sce_mean(logits, label, want_grad=False, scale=1.0):
+    _require_gpu(logits)
+    logits = logits.contiguous()
+    out = torch.empty(1, dtype=torch.float32, device=logits.device)
+    dl = torch.empty_like(logits) if want_grad else None
+    check(lib().dpig_sce_mean(ptr(logits), logits.numel(), float(label), ptr(out), ptr(dl), float(scale),
+                              stream_ptr()), "sce_mean")
+    return out, dl
+
+
+def l1_mean(a, b, want_grad=False, scale=1.0):
+    _require_gpu(a)
+    a = a.contiguous()
+    b = b.contiguous()
+    n = a.numel()
+    out = torch.empty(1, dtype=torch.float32, device=a.device)
+    da = torch.empty_like(a) if want_grad else None
+    wsb, wsn = workspace.get(lib().dpig_l1_workspace_bytes(n), a.device)
+    check(lib().dpig_l1_mean(ptr(a), ptr(b), n, ptr(out), ptr(da), float(scale), ptr(wsb), wsn, stream_ptr()),
+          "l1_mean")
+    return out, da

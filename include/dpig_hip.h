@@ -1,0 +1,171 @@
+/*
+ * dpig_hip.h -- C ABI of libdpig_hip.so, the MI355X (gfx950 / CDNA4) compute library behind the
+ * conv hot path of Disentangled-Person-Image-Generation (DPIG).
+ *
+ * Every entry point is `extern "C"`, takes plain device pointers + sizes + a HIP stream (passed as
+ * `void*`, i.e. a `hipStream_t`), never allocates, never synchronises, and returns an int status:
+ *   0 = DPIG_OK, negative = error (see dpig_last_error()).  All tensors are fp32, activations are
+ *   *physically* NHWC with an explicit channel stride (`ld*`, in elements) so that channel-concats
+ *   and slices are free views; filters are HWIO exactly as the reference stores them.
+ *
+ * Which reference interface each entry point replaces (paths relative to the reference repo):
+ *   dpig_conv2d_fwd      tf.nn.conv2d(SAME)+bias_add   tflib/ops/conv2d.py:106-120, and every
+ *                        slim.conv2d(...) of models.py:396-573 (bias + activation fused)
+ *   dpig_conv2d_dgrad    gradient of the above w.r.t. the input (TF autodiff; Optimizer.minimize
+ *                        trainer.py:137-140) and tf.nn.conv2d_transpose  tflib/ops/deconv2d.py:97-103
+ *   dpig_conv2d_wgrad    gradient w.r.t. the HWIO filter (TF autodiff, same call sites)
+ *   dpig_bn_*            tf.nn.fused_batch_norm(training)  tflib/ops/batchnorm.py:30 (+ its gradient)
+ *   dpig_ln_*            tf.nn.moments + batch_normalization  tflib/ops/layernorm.py:7-19 (+ grads)
+ *   dpig_linear_*        tf.matmul + bias_add  tflib/ops/linear.py:132-146, slim.fully_connected
+ *                        models.py:431,464,545,554 (+ grads)
+ *   dpig_crop_resize_*   tf.image.crop_and_resize  models.py:415 (+ gradient w.r.t. the image)
+ *   dpig_upsample2x_*    tf.image.resize_nearest_neighbor  utils.py:61-72 (+ gradient)
+ *   dpig_act_bwd/bias    the ReLU / LeakyReLU / bias_add gradients TF autodiff emits
+ *   dpig_adam_step       tf.train.AdamOptimizer  trainer.py:131-146
+ *   dpig_sce_* / l1      sigmoid_cross_entropy_with_logits / L1  trainer.py:238-245, 607, 623
+ */
+#ifndef DPIG_HIP_H
+#define DPIG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DPIG_OK 0
+#define DPIG_EINVAL (-22)     /* bad descriptor / unsupported shape */
+#define DPIG_EALIGN (-14)     /* misaligned pointer or stride */
+#define DPIG_ENOMEM (-12)     /* workspace too small */
+#define DPIG_ELAUNCH (-5)     /* HIP launch failure */
+
+#define DPIG_ACT_NONE 0
+#define DPIG_ACT_RELU 1
+#define DPIG_ACT_LRELU 2
+
+#define DPIG_VERSION 100
+
+/* Convolution problem, always described from the FORWARD op's point of view. */
+typedef struct DpigConvDesc {
+    int32_t N, H, W, C;   /* forward input x: N images of H x W x C                               */
+    int32_t K;            /* forward output channels                                              */
+    int32_t R, S;         /* filter height / width (HWIO filter [R][S][C][K])                     */
+    int32_t stride;       /* 1 or 2 (both spatial dims)                                           */
+    int32_t pad_t, pad_l; /* leading pads; pass -1 for TensorFlow 'SAME' (tflib conv2d.py:110)    */
+    int32_t ldx;          /* channel stride (elements) of x / dx buffers, >= C                    */
+    int32_t ldy;          /* channel stride of y / dy buffers, >= K                               */
+    int32_t ldres;        /* channel stride of the residual (fwd) / accumulate (dgrad) tensor     */
+    int32_t ldmask;       /* channel stride of the dgrad activation-mask tensor                   */
+    int32_t act;          /* fwd: activation after bias(+residual); dgrad: activation whose       */
+                          /*      derivative (taken at `mask`) multiplies dx                      */
+    float alpha;          /* LeakyReLU slope                                                      */
+    int32_t upsample2x;   /* 1: x is nearest-neighbour 2x-upsampled before a 1x1 conv             */
+                          /*    (models.py:569-570); computed at low resolution (exact commute)   */
+    int32_t split_k;      /* 0 = library heuristic, otherwise forced split count                  */
+} DpigConvDesc;
+
+int dpig_version(void);
+const char* dpig_last_error(void);
+
+/* TF 'SAME' geometry: out = ceil(in/stride), pad_before = floor(max((out-1)*stride+k-in,0)/2). */
+int dpig_same_pad(int in, int k, int stride, int* out, int* pad_before);
+
+/* Scratch requirement (bytes) of the three conv entry points for this descriptor.
+ * which: 0 fwd, 1 dgrad, 2 wgrad.  Returns 0 when no workspace is needed. */
+size_t dpig_conv2d_workspace_bytes(const DpigConvDesc* d, int which);
+
+/* y[N,Ho,Wo,K] = act(conv(x, w) + bias + residual).  bias / residual may be NULL.
+ * With upsample2x, y has spatial size (2H, 2W). */
+int dpig_conv2d_fwd(const DpigConvDesc* d, const float* x, const float* w, const float* bias,
+                    const float* residual, float* y, void* ws, size_t ws_bytes, void* stream);
+
+/* dx[N,H,W,C] = (conv_backward_data(dy, w) + accum) * act'(mask).  accum / mask may be NULL.
+ * Also the forward of tflib Deconv2D (stride-2 transposed conv). */
+int dpig_conv2d_dgrad(const DpigConvDesc* d, const float* dy, const float* w, const float* accum,
+                      const float* mask, float* dx, void* ws, size_t ws_bytes, void* stream);
+
+/* dw[R,S,C,K] = conv_backward_filter(x, dy).  beta = 0 overwrites, beta = 1 accumulates. */
+int dpig_conv2d_wgrad(const DpigConvDesc* d, const float* x, const float* dy, float* dw, float beta,
+                      void* ws, size_t ws_bytes, void* stream);
+
+/* ---- elementwise / reductions over a [rows, cols] fp32 matrix with row stride ld ------------- */
+
+/* dz = dy * act'(y)   (y = the activation OUTPUT; relu'/lrelu' decided by y > 0). */
+int dpig_act_bwd(const float* dy, int lddy, const float* y, int ldy, float* dz, int lddz, int64_t rows,
+                 int cols, int act, float alpha, void* stream);
+/* out[c] = beta*out[c] + sum_r a[r,c]   (bias gradient).  ws: dpig_colsum_workspace_bytes. */
+size_t dpig_colsum_workspace_bytes(int64_t rows, int cols);
+int dpig_colsum(const float* a, int lda, int64_t rows, int cols, float* out, float beta, void* ws,
+                size_t ws_bytes, void* stream);
+
+/* ---- batch norm (training mode, biased variance, eps inside sqrt; batchnorm.py:30) ----------- */
+/* x,y: [rows, C] (rows = N*H*W).  save_mean / save_rstd: [C].  Optional fused LeakyReLU/ReLU. */
+size_t dpig_bn_workspace_bytes(int64_t rows, int C);
+int dpig_bn_fwd(const float* x, int ldx, int64_t rows, int C, const float* scale, const float* offset,
+                float eps, int act, float alpha, float* y, int ldy, float* save_mean, float* save_rstd,
+                void* ws, size_t ws_bytes, void* stream);
+/* dy is the gradient w.r.t. the (activated) output y; y is needed only when act != NONE. */
+int dpig_bn_bwd(const float* dy, int lddy, const float* x, int ldx, const float* y, int ldy, int64_t rows,
+                int C, const float* scale, const float* save_mean, const float* save_rstd, int act,
+                float alpha, float* dx, int lddx, float* dscale, float* doffset, void* ws,
+                size_t ws_bytes, void* stream);
+
+/* ---- layer norm over (H,W,C) per sample, per-channel scale/offset (layernorm.py:6-20) -------- */
+/* x,y: [N, P, C] with P = H*W pixels, dense (ld == C). save_mean/save_rstd: [N]. */
+int dpig_ln_fwd(const float* x, int N, int P, int C, const float* scale, const float* offset, float eps,
+                int act, float alpha, float* y, float* save_mean, float* save_rstd, void* stream);
+size_t dpig_ln_workspace_bytes(int N, int P, int C);
+int dpig_ln_bwd(const float* dy, const float* x, const float* y, int N, int P, int C, const float* scale,
+                const float* save_mean, const float* save_rstd, int act, float alpha, float* dx,
+                float* dscale, float* doffset, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- fully connected (linear.py:132-146, slim.fully_connected) ------------------------------- */
+/* y[M,Nout] = act(x[M,Kin] @ w[Kin,Nout] + bias) */
+size_t dpig_linear_workspace_bytes(int M, int Kin, int Nout, int which);
+int dpig_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int Kin, int Nout,
+                    int act, float alpha, void* ws, size_t ws_bytes, void* stream);
+/* dx[M,Kin] = dy[M,Nout] @ w^T */
+int dpig_linear_dgrad(const float* dy, const float* w, float* dx, int M, int Kin, int Nout, void* ws,
+                      size_t ws_bytes, void* stream);
+/* dw[Kin,Nout] = x^T @ dy ; db[Nout] = colsum(dy) (db may be NULL) */
+int dpig_linear_wgrad(const float* x, const float* dy, float* dw, float* db, int M, int Kin, int Nout,
+                      void* ws, size_t ws_bytes, void* stream);
+
+/* ---- tf.image.crop_and_resize (bilinear, extrapolation 0) ------------------------------------ */
+/* img: [N,H,W,C] (ld = C); boxes: [nbox,4] normalised (y1,x1,y2,x2); box_ind: [nbox];
+ * out: [nbox, ch, cw, C]. */
+int dpig_crop_resize_fwd(const float* img, int N, int H, int W, int C, const float* boxes,
+                         const int32_t* box_ind, int nbox, int ch, int cw, float* out, void* stream);
+/* dimg must be zero-initialised by the caller (scatter-add). */
+int dpig_crop_resize_bwd(const float* dout, int N, int H, int W, int C, const float* boxes,
+                         const int32_t* box_ind, int nbox, int ch, int cw, float* dimg, void* stream);
+
+/* ---- nearest-neighbour 2x upsample (unfused form; utils.py:61-72) ---------------------------- */
+int dpig_upsample2x_fwd(const float* x, int N, int H, int W, int C, float* y, void* stream);
+int dpig_upsample2x_bwd(const float* dy, int N, int H, int W, int C, float* dx, void* stream);
+
+/* ---- TensorFlow-flavoured Adam on one flat tensor (trainer.py:137-140) ------------------------
+ * lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v updated in place; p -= lr_t*m/(sqrt(v)+eps).
+ * `lr` is read from device memory (the reference keeps g_lr in a tf.Variable, trainer.py:56-59). */
+int dpig_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev,
+                   float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+/* Multi-tensor form: ptrs[4*i+0..3] = {p, g, m, v} device pointers of tensor i, sizes[i] elements.
+ * `ptrs` and `sizes` are DEVICE arrays. */
+int dpig_adam_multi(const void* const* ptrs_dev, const int64_t* sizes_dev, int ntensors, int64_t max_size,
+                    const float* lr_dev, float beta1, float beta2, float eps, int step, float grad_scale,
+                    void* stream);
+
+/* ---- losses (trainer.py:238-245, 607, 623) --------------------------------------------------- */
+/* out[0] = mean_i sce(logits_i, label) ; dlogits_i = scale*(sigmoid(x_i)-label)/n (dlogits may be NULL) */
+int dpig_sce_mean(const float* logits, int n, float label, float* out, float* dlogits, float scale,
+                  void* stream);
+/* out[0] = mean |a-b| ; dgrad (may be NULL) = scale*sign(a-b)/n */
+size_t dpig_l1_workspace_bytes(int64_t n);
+int dpig_l1_mean(const float* a, const float* b, int64_t n, float* out, float* da, float scale, void* ws,
+                 size_t ws_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DPIG_HIP_H */

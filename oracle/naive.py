@@ -1,0 +1,202 @@
+"""Independent numpy restatement (explicit loops / einsum, float64) of the TF-1.4 kernels that the
+hot path reaches.  TEST INFRASTRUCTURE: its only job is to pin oracle/ops.py (two independent
+restatements of the published TensorFlow algorithms must agree) -- parity is otherwise unpinned
+because the reference ships no vectors (see oracle/__init__.py).
+
+Each function cites the reference call site it restates; the kernel arithmetic itself follows
+TensorFlow 1.4.1 (tensorflow/core/kernels/{conv_ops,crop_and_resize_op,resize_nearest_neighbor_op,
+fused_batch_norm_op}.cc and python/training/adam.py as published).
+"""
+import math
+
+import numpy as np
+
+
+def same_pad(inp, k, stride):
+    out = int(math.ceil(inp / float(stride)))
+    total = max((out - 1) * stride + k - inp, 0)
+    return out, total // 2
+
+
+def conv2d_same(x, w, b=None, stride=1):
+    """tflib/ops/conv2d.py:106-120 / slim.conv2d models.py:396: direct 7-loop definition."""
+    x = np.asarray(x, np.float64)
+    w = np.asarray(w, np.float64)
+    n, H, W, C = x.shape
+    R, S, _, K = w.shape
+    Ho, pt = same_pad(H, R, stride)
+    Wo, pl = same_pad(W, S, stride)
+    y = np.zeros((n, Ho, Wo, K))
+    for oy in range(Ho):
+        for ox in range(Wo):
+            acc = np.zeros((n, K))
+            for ky in range(R):
+                iy = oy * stride + ky - pt
+                if iy < 0 or iy >= H:
+                    continue
+                for kx in range(S):
+                    ix = ox * stride + kx - pl
+                    if ix < 0 or ix >= W:
+                        continue
+                    acc += x[:, iy, ix, :] @ w[ky, kx]
+            y[:, oy, ox, :] = acc
+    if b is not None:
+        y = y + np.asarray(b, np.float64)
+    return y
+
+
+def conv2d_same_dgrad(dy, w, in_shape, stride=1):
+    """Gradient of conv2d_same w.r.t. x (scatter form of the definition above)."""
+    dy = np.asarray(dy, np.float64)
+    w = np.asarray(w, np.float64)
+    n, H, W, C = in_shape
+    R, S, _, K = w.shape
+    Ho, pt = same_pad(H, R, stride)
+    Wo, pl = same_pad(W, S, stride)
+    dx = np.zeros((n, H, W, C))
+    for oy in range(Ho):
+        for ox in range(Wo):
+            for ky in range(R):
+                iy = oy * stride + ky - pt
+                if iy < 0 or iy >= H:
+                    continue
+                for kx in range(S):
+                    ix = ox * stride + kx - pl
+                    if ix < 0 or ix >= W:
+                        continue
+                    dx[:, iy, ix, :] += dy[:, oy, ox, :] @ w[ky, kx].T
+    return dx
+
+
+def conv2d_same_wgrad(x, dy, wshape, stride=1):
+    x = np.asarray(x, np.float64)
+    dy = np.asarray(dy, np.float64)
+    n, H, W, C = x.shape
+    R, S, _, K = wshape
+    Ho, pt = same_pad(H, R, stride)
+    Wo, pl = same_pad(W, S, stride)
+    dw = np.zeros((R, S, C, K))
+    for oy in range(Ho):
+        for ox in range(Wo):
+            for ky in range(R):
+                iy = oy * stride + ky - pt
+                if iy < 0 or iy >= H:
+                    continue
+                for kx in range(S):
+                    ix = ox * stride + kx - pl
+                    if ix < 0 or ix >= W:
+                        continue
+                    dw[ky, kx] += x[:, iy, ix, :].T @ dy[:, oy, ox, :]
+    return dw
+
+
+def batchnorm_train(x, scale, offset, eps=1e-5):
+    """tflib/ops/batchnorm.py:30 (fused_batch_norm, training): biased variance, eps in sqrt."""
+    x = np.asarray(x, np.float64)
+    C = x.shape[-1]
+    flat = x.reshape(-1, C)
+    mean = flat.sum(0) / flat.shape[0]
+    var = ((flat - mean) ** 2).sum(0) / flat.shape[0]
+    return (x - mean) / np.sqrt(var + eps) * scale + offset
+
+
+def layernorm(x, scale, offset, eps=1e-5):
+    """tflib/ops/layernorm.py:7-19 with axes (C,H,W) per sample (x NHWC here)."""
+    x = np.asarray(x, np.float64)
+    out = np.empty_like(x)
+    for i in range(x.shape[0]):
+        mu = x[i].mean()
+        var = ((x[i] - mu) ** 2).mean()
+        out[i] = (x[i] - mu) / math.sqrt(var + eps) * scale + offset
+    return out
+
+
+def upsample2x(x):
+    """utils.py:61-72: out[y,x] = in[min(floor(y*in/out), in-1)] with out = 2*in."""
+    x = np.asarray(x)
+    n, H, W, C = x.shape
+    y = np.empty((n, 2 * H, 2 * W, C), x.dtype)
+    for oy in range(2 * H):
+        for ox in range(2 * W):
+            y[:, oy, ox, :] = x[:, min(int(math.floor(oy * H / (2.0 * H))), H - 1),
+                                min(int(math.floor(ox * W / (2.0 * W))), W - 1), :]
+    return y
+
+
+def crop_and_resize(img, boxes, box_ind, ch, cw):
+    """models.py:415 -- tensorflow/core/kernels/crop_and_resize_op.cc (bilinear, extrapolation 0)."""
+    img = np.asarray(img, np.float64)
+    n, H, W, C = img.shape
+    nb = len(boxes)
+    out = np.zeros((nb, ch, cw, C))
+    for b in range(nb):
+        y1, x1, y2, x2 = [float(v) for v in boxes[b]]
+        bi = int(box_ind[b])
+        hs = (y2 - y1) * (H - 1) / (ch - 1) if ch > 1 else 0.0
+        ws = (x2 - x1) * (W - 1) / (cw - 1) if cw > 1 else 0.0
+        for i in range(ch):
+            in_y = y1 * (H - 1) + i * hs if ch > 1 else 0.5 * (y1 + y2) * (H - 1)
+            if in_y < 0 or in_y > H - 1:
+                continue
+            ty, by = int(math.floor(in_y)), int(math.ceil(in_y))
+            ly = in_y - ty
+            for j in range(cw):
+                in_x = x1 * (W - 1) + j * ws if cw > 1 else 0.5 * (x1 + x2) * (W - 1)
+                if in_x < 0 or in_x > W - 1:
+                    continue
+                lx_, rx = int(math.floor(in_x)), int(math.ceil(in_x))
+                lw = in_x - lx_
+                top = img[bi, ty, lx_] + (img[bi, ty, rx] - img[bi, ty, lx_]) * lw
+                bot = img[bi, by, lx_] + (img[bi, by, rx] - img[bi, by, lx_]) * lw
+                out[b, i, j] = top + (bot - top) * ly
+    return out
+
+
+def crop_and_resize_grad_image(dout, boxes, box_ind, img_shape):
+    """CropAndResizeGradImage: scatter the 4 bilinear weights."""
+    dout = np.asarray(dout, np.float64)
+    n, H, W, C = img_shape
+    nb, ch, cw, _ = dout.shape
+    dimg = np.zeros(img_shape)
+    for b in range(nb):
+        y1, x1, y2, x2 = [float(v) for v in boxes[b]]
+        bi = int(box_ind[b])
+        hs = (y2 - y1) * (H - 1) / (ch - 1) if ch > 1 else 0.0
+        ws = (x2 - x1) * (W - 1) / (cw - 1) if cw > 1 else 0.0
+        for i in range(ch):
+            in_y = y1 * (H - 1) + i * hs if ch > 1 else 0.5 * (y1 + y2) * (H - 1)
+            if in_y < 0 or in_y > H - 1:
+                continue
+            ty, by = int(math.floor(in_y)), int(math.ceil(in_y))
+            ly = in_y - ty
+            for j in range(cw):
+                in_x = x1 * (W - 1) + j * ws if cw > 1 else 0.5 * (x1 + x2) * (W - 1)
+                if in_x < 0 or in_x > W - 1:
+                    continue
+                lx_, rx = int(math.floor(in_x)), int(math.ceil(in_x))
+                lw = in_x - lx_
+                g = dout[b, i, j]
+                dimg[bi, ty, lx_] += (1 - ly) * (1 - lw) * g
+                dimg[bi, ty, rx] += (1 - ly) * lw * g
+                dimg[bi, by, lx_] += ly * (1 - lw) * g
+                dimg[bi, by, rx] += ly * lw * g
+    return dimg
+
+
+def sigmoid_cross_entropy_with_logits(x, z):
+    x = np.asarray(x, np.float64)
+    return np.maximum(x, 0) - x * z + np.log1p(np.exp(-np.abs(x)))
+
+
+def tf_adam(p, grads, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    """python/training/adam.py: sequence of updates for a list of gradients; returns final p."""
+    p = np.asarray(p, np.float64).copy()
+    m = np.zeros_like(p)
+    v = np.zeros_like(p)
+    for t, g in enumerate(grads, start=1):
+        g = np.asarray(g, np.float64)
+        lr_t = lr * math.sqrt(1 - beta2 ** t) / (1 - beta1 ** t)
+        m = beta1 * m + (1 - beta1) * g
+        v = beta2 * v + (1 - beta2) * g * g
+        p = p - lr_t * m / (np.sqrt(v) + eps)
+    return p

@@ -1,0 +1,142 @@
+"""Differentiable torch-CPU restatement of the TensorFlow-1.4 ops on the DPIG hot path.
+
+TEST INFRASTRUCTURE (see oracle/__init__.py) -- parity unpinned by the reference; pinned against
+oracle/naive.py and analytic KATs.  Activations are NHWC, filters HWIO, exactly as the reference
+generator (main.py:18 forces NHWC) and tflib store them.  Gradients come from torch autograd over
+these forward definitions (TF autodiff, trainer.py:137-140).
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+def same_pad(inp, k, stride):
+    """tf 'SAME' (tflib/ops/conv2d.py:110; slim.conv2d default): out=ceil(in/s),
+    pad_total=max((out-1)*s+k-in,0), pad_before=floor(pad_total/2), remainder after."""
+    out = -(-inp // stride)
+    total = max((out - 1) * stride + k - inp, 0)
+    return out, total // 2, total - total // 2
+
+
+def conv2d_same(x, w, b=None, stride=1):
+    """tf.nn.conv2d(x, w, [1,s,s,1], 'SAME') + bias_add.  x NHWC, w HWIO (cross-correlation).
+    Follows tflib/ops/conv2d.py:106-120 and slim.conv2d as used in models.py:396-573."""
+    kh, kw = w.shape[0], w.shape[1]
+    _, pt, pb = same_pad(x.shape[1], kh, stride)
+    _, pl, pr = same_pad(x.shape[2], kw, stride)
+    xn = x.permute(0, 3, 1, 2)
+    xn = F.pad(xn, (pl, pr, pt, pb))                 # asymmetric pad: torch's padding= is wrong for s=2
+    wn = w.permute(3, 2, 0, 1)                       # HWIO -> OIHW
+    y = F.conv2d(xn, wn, None, stride=stride)
+    y = y.permute(0, 2, 3, 1)
+    if b is not None:
+        y = y + b
+    return y
+
+
+def conv2d_transpose_same(x, w, b=None, stride=2):
+    """tf.nn.conv2d_transpose(x, w, out=[N,2H,2W,Cout], strides 2, 'SAME') + bias
+    (tflib/ops/deconv2d.py:89-112).  w is (k,k,Cout,Cin).  Defined as the gradient of
+    conv2d_same w.r.t. its input, which is TF's own definition of the op."""
+    n, h, wd, _ = x.shape
+    cout = w.shape[2]
+    ref = torch.zeros(n, h * stride, wd * stride, cout, dtype=x.dtype, requires_grad=True)
+    with torch.enable_grad():
+        y = conv2d_same(ref, w.detach() if not w.requires_grad else w, None, stride)
+    assert y.shape == x.shape, (y.shape, x.shape)
+    (out,) = torch.autograd.grad(y, ref, x, create_graph=x.requires_grad or w.requires_grad)
+    if b is not None:
+        out = out + b
+    return out
+
+
+def relu(x):
+    return torch.relu(x)
+
+
+def leaky_relu(x, alpha=0.2):
+    """wgan_gp.py:23-24: tf.maximum(alpha*x, x)."""
+    return torch.maximum(alpha * x, x)
+
+
+def batchnorm_train(x, scale, offset, eps=1e-5):
+    """tf.nn.fused_batch_norm training mode (tflib/ops/batchnorm.py:30): stats over N,H,W,
+    biased variance, eps inside the sqrt.  x is NHWC here (the reference passes NCHW)."""
+    mean = x.mean(dim=(0, 1, 2), keepdim=True)
+    var = ((x - mean) ** 2).mean(dim=(0, 1, 2), keepdim=True)
+    return (x - mean) / torch.sqrt(var + eps) * scale + offset
+
+
+def layernorm(x, scale, offset, eps=1e-5):
+    """tflib/ops/layernorm.py:6-20 with norm_axes [1,2,3]: per-sample moments over (C,H,W),
+    per-channel scale/offset.  x NHWC."""
+    mean = x.mean(dim=(1, 2, 3), keepdim=True)
+    var = ((x - mean) ** 2).mean(dim=(1, 2, 3), keepdim=True)
+    return (x - mean) / torch.sqrt(var + eps) * scale + offset
+
+
+def linear(x, w, b=None):
+    """tf.matmul + bias_add (tflib/ops/linear.py:132-146; slim.fully_connected)."""
+    y = x @ w
+    if b is not None:
+        y = y + b
+    return y
+
+
+def upsample2x(x):
+    """tf.image.resize_nearest_neighbor, align_corners=False, exact 2x (utils.py:61-72)."""
+    return x.repeat_interleave(2, dim=1).repeat_interleave(2, dim=2)
+
+
+def crop_and_resize(img, boxes, box_ind, crop_h, crop_w):
+    """tf.image.crop_and_resize, bilinear, extrapolation 0 (models.py:415).  img NHWC, boxes
+    [n,4] normalised (y1,x1,y2,x2).  Differentiable w.r.t. img only (TF gives no box grad here)."""
+    n, H, W, C = img.shape
+    nb = boxes.shape[0]
+    boxes = boxes.to(img.dtype)
+    y1, x1, y2, x2 = boxes[:, 0], boxes[:, 1], boxes[:, 2], boxes[:, 3]
+    ii = torch.arange(crop_h, dtype=img.dtype)
+    jj = torch.arange(crop_w, dtype=img.dtype)
+    if crop_h > 1:
+        in_y = y1[:, None] * (H - 1) + ii[None, :] * ((y2 - y1) * (H - 1) / (crop_h - 1))[:, None]
+    else:
+        in_y = (0.5 * (y1 + y2) * (H - 1))[:, None].expand(nb, 1)
+    if crop_w > 1:
+        in_x = x1[:, None] * (W - 1) + jj[None, :] * ((x2 - x1) * (W - 1) / (crop_w - 1))[:, None]
+    else:
+        in_x = (0.5 * (x1 + x2) * (W - 1))[:, None].expand(nb, 1)
+    oky = ~((in_y < 0) | (in_y > H - 1))
+    okx = ~((in_x < 0) | (in_x > W - 1))
+    ty = torch.floor(in_y).clamp(0, H - 1)
+    by = torch.ceil(in_y).clamp(0, H - 1)
+    lx = torch.floor(in_x).clamp(0, W - 1)
+    rx = torch.ceil(in_x).clamp(0, W - 1)
+    ly = (in_y - torch.floor(in_y))[:, :, None, None]
+    lw = (in_x - torch.floor(in_x))[:, None, :, None]
+    bi = box_ind.long()[:, None, None]
+    tyi, byi, lxi, rxi = ty.long(), by.long(), lx.long(), rx.long()
+    tl = img[bi, tyi[:, :, None], lxi[:, None, :]]
+    tr = img[bi, tyi[:, :, None], rxi[:, None, :]]
+    bl = img[bi, byi[:, :, None], lxi[:, None, :]]
+    br = img[bi, byi[:, :, None], rxi[:, None, :]]
+    top = tl + (tr - tl) * lw
+    bot = bl + (br - bl) * lw
+    out = top + (bot - top) * ly
+    ok = (oky[:, :, None] & okx[:, None, :])[..., None].to(img.dtype)
+    return out * ok
+
+
+def sigmoid_cross_entropy_with_logits(logits, labels):
+    """max(x,0) - x*z + log1p(exp(-|x|)) (trainer.py:239-243)."""
+    return torch.clamp(logits, min=0) - logits * labels + torch.log1p(torch.exp(-torch.abs(logits)))
+
+
+def tf_adam_step(p, g, m, v, lr, beta1, beta2, eps, t):
+    """tf.train.AdamOptimizer (trainer.py:137-140): lr_t = lr*sqrt(1-b2^t)/(1-b1^t);
+    epsilon OUTSIDE the bias-corrected sqrt.  Returns new (p, m, v)."""
+    lr_t = lr * math.sqrt(1.0 - beta2 ** t) / (1.0 - beta1 ** t)
+    m = beta1 * m + (1.0 - beta1) * g
+    v = beta2 * v + (1.0 - beta2) * g * g
+    p = p - lr_t * m / (torch.sqrt(v) + eps)
+    return p, m, v
