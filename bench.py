@@ -1,0 +1,182 @@
+#!/usr/bin/env python
+"""bench.py -- DPIG stage-I training throughput on MI355X (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W        (N>1: launched by torch.distributed.run)
+
+One "step" = one iteration of the reference training loop (trainer.py:336-347) in dcgan mode:
+g_optim on one synthetic batch + d_optim on another, Market-1501 128x64, bs=16 per GPU, fp32
+(BASELINE configs[1]); inputs are resident in HBM before the timed region.  Weak scaling: the
+per-GPU batch is fixed, gradients are all-reduced over RCCL each optimizer call.
+
+Prints ONE JSON line on rank 0 with the driver's contract plus
+  roofline     -- the dominant kernel (conv forward implicit GEMM), executed FLOPs per launch over its
+                  mean launch duration, HIP events on the launch stream, same steps as the timed ones
+  cpu_baseline -- the CPU oracle ("port" of the reference graph, torch-CPU fp32) timed on the host
+                  cores on a bounded sample (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+ALG_GFLOP_PER_IMG = 549.9         # stage-I Market G+D step, dense reference formulation
+
+
+def cpu_baseline(target_seconds=20.0):
+    """Time the oracle's G+D step (torch-CPU, fp32, all host cores) on a bounded sample."""
+    import torch
+    from dpig_amd import synthetic
+    from oracle import models as OM
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+
+    def one_step(B, seed):
+        P = OM.ParamStore(seed=1, dtype=torch.float32)
+        ob = OM.batch_to_torch(synthetic.make_batch(B, seed=seed), dtype=torch.float32)
+        t0 = time.time()
+        gl, _ = OM.stage1_g_loss(P, ob)
+        gn = OM.g_var_names(P)
+        torch.autograd.grad(gl, [P.p[n] for n in gn], allow_unused=True)
+        dl, _ = OM.stage1_d_loss(P, ob)
+        dn = OM.d_var_names(P)
+        torch.autograd.grad(dl, [P.p[n] for n in dn], allow_unused=True)
+        return time.time() - t0
+
+    t = one_step(1, 7)                       # B=1 probe (also pages torch's CPU kernels in)
+    B = 1
+    if t < target_seconds / 4:
+        B = max(1, min(4, int(target_seconds / (2 * t))))
+        t = one_step(B, 8)
+    return {"value": round(B / t, 4), "unit": "images/sec", "cores": cores, "kind": "port",
+            "sample": "1 G+D step (oracle graph, torch-CPU fp32, fwd+bwd, no optimizer) at bs=%d, %.1f s" % (B, t)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (BASELINE configs[1]: 16)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 or world > 1:
+        assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world)      # "nccl" IS RCCL on ROCm
+    dev = torch.device("cuda", local_rank)
+    torch.cuda.set_device(dev)
+
+    import __graft_entry__
+    if rank == 0:
+        __graft_entry__.build()
+    if world > 1:
+        dist.barrier()
+    from dpig_amd import hip_ops as H
+    from dpig_amd import synthetic
+    from dpig_amd.trainer import Config, DPIG_Encoder_GAN_BodyROI_FgBg
+
+    np.random.seed(0)                         # identical initial weights on every rank (+ broadcast)
+    B = args.batch
+    tr = DPIG_Encoder_GAN_BodyROI_FgBg(Config(batch_size=B), dev)
+    batch_g = synthetic.to_device(synthetic.make_batch(B, seed=100 + 2 * rank), dev)
+    batch_d = synthetic.to_device(synthetic.make_batch(B, seed=101 + 2 * rank), dev)
+    tr.init_net(batch_g)
+    tr.step = 1                               # steady state: g_optim is only skipped at step 0
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        tr.train_step(batch_g, batch_d)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = tr.train_step(batch_g, batch_d)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = t.item()
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * B * args.steps / elapsed
+
+    roofline = None
+    if rank == 0 and not args.no_roofline:
+        # instrumented replay of the same step: HIP events around every conv-forward launch
+        H.PROFILE = []
+        nrep = max(1, min(3, args.steps))
+        for _ in range(nrep):
+            tr.train_step(batch_g, batch_d)
+        torch.cuda.synchronize()
+        recs = [(k, f, e0.elapsed_time(e1) * 1e-3) for (k, f, e0, e1) in H.PROFILE]
+        H.PROFILE = None
+        fwd = [(f, t) for (k, f, t) in recs if k == "conv_fwd_mfma"]
+        nl = len(fwd)
+        flops = sum(f for f, _ in fwd)
+        secs = sum(t for _, t in fwd)
+        achieved = flops / secs / 1e12
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("conv_fwd_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "mfma", "kernel": "dpig::gather_gemm_kernel<false,true> (conv fwd, fp32 MFMA)",
+                    "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "launches_per_step": nl // nrep,
+                    "flops_per_launch": flops / nl, "avg_launch_us": round(secs / nl * 1e6, 2),
+                    "time_share_of_step": round(secs / nrep / (ms_per_step * 1e-3), 3)}
+        by = {}
+        for k, f, t in recs:
+            a = by.setdefault(k, [0, 0.0, 0.0])
+            a[0] += 1; a[1] += f; a[2] += t
+        roofline["per_kernel_class"] = {k: {"launches_per_step": v[0] // nrep, "ms_per_step": round(v[2] / nrep * 1e3, 3),
+                                            "tflops": round(v[1] / v[2] / 1e12, 2) if v[2] > 0 and v[1] > 0 else None}
+                                        for k, v in sorted(by.items())}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        cpu = cpu_baseline()
+
+    if rank == 0:
+        line = {
+            "metric": "training images/sec (G+D step) Market-1501 128x64 bs=16",
+            "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "Market-1501 128x64 stage-I (Fg/Bg/Pose enc + U-Net decoder + DCGAN D), "
+                                   "g_optim + d_optim per step, bs=%d per GPU, fp32" % B,
+                       "global_batch": world * B, "parallelism": "dp%d" % world},
+            "achieved_alg_tflops": round(ALG_GFLOP_PER_IMG * value / 1e3, 2),
+            "losses": {k: float(v) for k, v in out.items() if hasattr(v, "numel") and v.numel() == 1},
+            "roofline": roofline, "cpu_baseline": cpu,
+        }
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

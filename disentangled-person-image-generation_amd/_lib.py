@@ -24,7 +24,8 @@ class DpigConvDesc(ctypes.Structure):
         ("pad_t", ctypes.c_int32), ("pad_l", ctypes.c_int32),
         ("ldx", ctypes.c_int32), ("ldy", ctypes.c_int32), ("ldres", ctypes.c_int32), ("ldmask", ctypes.c_int32),
         ("act", ctypes.c_int32), ("alpha", ctypes.c_float),
-        ("upsample2x", ctypes.c_int32), ("split_k", ctypes.c_int32),
+        ("upsample2x", ctypes.c_int32), ("res_after_act", ctypes.c_int32), ("ldy2", ctypes.c_int32),
+        ("split_k", ctypes.c_int32),
     ]
 
 
@@ -36,9 +37,10 @@ SYMBOLS = {
     "dpig_last_error": (ctypes.c_char_p, []),
     "dpig_same_pad": (_i, [_i, _i, _i, ctypes.POINTER(_i), ctypes.POINTER(_i)]),
     "dpig_conv2d_workspace_bytes": (_sz, [_dp, _i]),
-    "dpig_conv2d_fwd": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dpig_conv2d_fwd": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dpig_conv2d_dgrad": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dpig_conv2d_wgrad": (_i, [_dp, _vp, _vp, _vp, _f, _vp, _sz, _vp]),
+    "dpig_act_fwd": (_i, [_vp, _i, _vp, _i, _i64, _i, _i, _f, _vp]),
     "dpig_act_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _i, _i, _f, _vp]),
     "dpig_colsum_workspace_bytes": (_sz, [_i64, _i]),
     "dpig_colsum": (_i, [_vp, _i, _i64, _i, _vp, _f, _vp, _sz, _vp]),
@@ -51,7 +53,7 @@ SYMBOLS = {
     "dpig_linear_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "dpig_linear_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
     "dpig_linear_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
-    "dpig_linear_wgrad": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
+    "dpig_linear_wgrad": (_i, [_vp, _vp, _vp, _f, _i, _i, _i, _vp, _sz, _vp]),
     "dpig_crop_resize_fwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "dpig_crop_resize_bwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "dpig_upsample2x_fwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),

@@ -1,0 +1,301 @@
+"""torch.autograd plumbing around the HIP kernels (hip_ops).  No arithmetic happens here: every
+forward/backward piece is a kernel of libdpig_hip.so; torch only records the graph and owns the
+memory.  The gradient definitions are the ones TF autodiff derives for the reference graph
+(trainer.py:137-140).
+"""
+import torch
+
+from . import hip_ops as H
+from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU
+
+
+def _sink(p, fn):
+    """Gradient delivery for a parameter.  If the optimizer registered a persistent gradient slice
+    on the parameter (`p._dpig_grad`, a view into its flat gradient buffer -- see trainer.FlatParams)
+    the kernel writes (first touch: beta=0) or accumulates (later touches: beta=1) straight into it
+    and autograd gets None: no AccumulateGrad copy, no zero-fill pass, and the flat buffer is what
+    RCCL all-reduces.  Otherwise the gradient is returned to autograd as usual."""
+    buf = getattr(p, "_dpig_grad", None)
+    if buf is None:
+        return fn(None, 0.0)
+    touched = p._dpig_touched
+    fn(buf, 1.0 if touched[0] else 0.0)
+    touched[0] = True
+    return None
+
+
+def _sink_small(p, g):
+    """Same contract as _sink for tiny per-channel gradients that a kernel already produced."""
+    buf = getattr(p, "_dpig_grad", None)
+    if buf is None:
+        return g
+    touched = p._dpig_touched
+    if touched[0]:
+        buf.add_(g.view_as(buf))
+    else:
+        buf.copy_(g.view_as(buf))
+    touched[0] = True
+    return None
+
+
+class _ConvFn(torch.autograd.Function):
+    """y = act(conv_SAME(x, w) + b)   [optionally on a nearest-2x-upsampled x, 1x1 only]."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stride, act, alpha, upsample2x):
+        y = H.conv2d_fwd(x, w, b, stride=stride, act=act, alpha=alpha, upsample2x=upsample2x)
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        ctx.cfg = (stride, act, alpha, upsample2x, b is not None)
+        ctx.b_ref = b
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        stride, act, alpha, up, has_b = ctx.cfg
+        dz = H.act_bwd(dy, y, act, alpha) if act != ACT_NONE else dy
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = H.conv2d_dgrad(dz, w, tuple(x.shape), stride=stride, upsample2x=up)
+        if ctx.needs_input_grad[1]:
+            dw = _sink(w, lambda o, beta: H.conv2d_wgrad(x, dz, tuple(w.shape), stride=stride, upsample2x=up,
+                                                         out=o, beta=beta))
+        if has_b and ctx.needs_input_grad[2]:
+            db = _sink(ctx.b_ref, lambda o, beta: H.colsum(dz, out=o, beta=beta))
+        return dx, dw, db, None, None, None, None
+
+
+def conv2d(x, w, b=None, stride=1, act=ACT_NONE, alpha=0.2, upsample2x=False):
+    return _ConvFn.apply(x, w, b, stride, act, alpha, upsample2x)
+
+
+class _ResBlockFn(torch.autograd.Function):
+    """The reference residual block (models.py:398-400, 425-427, 458-460, 534-536, 564-566):
+         c1 = relu(conv3x3(x0)+b1); c2 = relu(conv3x3(c1)+b2); out = c2 + x0
+    forward: 2 launches (the add rides in conv2's epilogue); backward: one act_bwd, then
+    dgrad(conv2) applies c1's ReLU mask and dgrad(conv1) adds the skip gradient in its epilogue."""
+
+    @staticmethod
+    def forward(ctx, x0, w1, b1, w2, b2):
+        c1 = H.conv2d_fwd(x0, w1, b1, act=ACT_RELU)
+        c2 = torch.empty_like(c1)
+        out = torch.empty_like(c1)
+        H.conv2d_fwd(c1, w2, b2, act=ACT_RELU, residual=x0, res_after_act=True, out=out, out_act=c2)
+        ctx.save_for_backward(x0, w1, w2, c1, c2)
+        ctx.b_refs = (b1, b2)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x0, w1, w2, c1, c2 = ctx.saved_tensors
+        b1, b2 = ctx.b_refs
+        dz2 = H.act_bwd(dout, c2, ACT_RELU)
+        dw2 = db2 = dw1 = db1 = None
+        if ctx.needs_input_grad[3]:
+            dw2 = _sink(w2, lambda o, beta: H.conv2d_wgrad(c1, dz2, tuple(w2.shape), out=o, beta=beta))
+        if ctx.needs_input_grad[4]:
+            db2 = _sink(b2, lambda o, beta: H.colsum(dz2, out=o, beta=beta))
+        dz1 = H.conv2d_dgrad(dz2, w2, tuple(c1.shape), mask=c1, act=ACT_RELU)
+        if ctx.needs_input_grad[1]:
+            dw1 = _sink(w1, lambda o, beta: H.conv2d_wgrad(x0, dz1, tuple(w1.shape), out=o, beta=beta))
+        if ctx.needs_input_grad[2]:
+            db1 = _sink(b1, lambda o, beta: H.colsum(dz1, out=o, beta=beta))
+        dx0 = None
+        if ctx.needs_input_grad[0]:
+            dx0 = H.conv2d_dgrad(dz1, w1, tuple(x0.shape), accum=dout)
+        return dx0, dw1, db1, dw2, db2
+
+
+def resblock(x0, w1, b1, w2, b2):
+    return _ResBlockFn.apply(x0, w1, b1, w2, b2)
+
+
+class _ActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, act, alpha):
+        y = H.act_fwd(x, act, alpha)
+        ctx.save_for_backward(y)
+        ctx.cfg = (act, alpha)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (y,) = ctx.saved_tensors
+        return H.act_bwd(dy, y, *ctx.cfg), None, None
+
+
+def activation(x, act, alpha=0.2):
+    return _ActFn.apply(x, act, alpha)
+
+
+class _DeconvFn(torch.autograd.Function):
+    """tf.nn.conv2d_transpose, stride 2, SAME (tflib/ops/deconv2d.py:97-103): y = F^T(x) where F is
+    the stride-2 SAME conv [N,2H,2W,Cout] -> [N,H,W,Cin] with the (k,k,Cout,Cin) filter read as HWIO."""
+
+    @staticmethod
+    def forward(ctx, x, w, b):
+        N, Hh, W, _ = x.shape
+        out_shape = (N, 2 * Hh, 2 * W, w.shape[2])
+        y = H.conv2d_dgrad(x, w, out_shape, stride=2)
+        if b is not None:
+            y = y + b          # bias_add on the small generator-side tensor (dormant path)
+        ctx.save_for_backward(x, w)
+        ctx.has_b = b is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        dx = H.conv2d_fwd(dy, w, None, stride=2) if ctx.needs_input_grad[0] else None
+        dw = H.conv2d_wgrad(dy, x, tuple(w.shape), stride=2) if ctx.needs_input_grad[1] else None
+        db = H.colsum(dy) if ctx.has_b and ctx.needs_input_grad[2] else None
+        return dx, dw, db
+
+
+def conv2d_transpose(x, w, b=None):
+    return _DeconvFn.apply(x, w, b)
+
+
+class _LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, b, act, alpha):
+        y = H.linear_fwd(x, w, b, act=act, alpha=alpha)
+        ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
+        ctx.cfg = (act, alpha, b is not None)
+        ctx.b_ref = b
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w, y = ctx.saved_tensors
+        act, alpha, has_b = ctx.cfg
+        dz = H.act_bwd(dy, y, act, alpha) if act != ACT_NONE else dy.contiguous()
+        dx = H.linear_dgrad(dz, w) if ctx.needs_input_grad[0] else None
+        dw = db = None
+        if ctx.needs_input_grad[1]:
+            dw = _sink(w, lambda o, beta: H.linear_wgrad(x, dz, out=o, beta=beta))
+        if has_b and ctx.needs_input_grad[2]:
+            db = _sink(ctx.b_ref, lambda o, beta: H.colsum(dz, out=o, beta=beta))
+        return dx, dw, db, None, None
+
+
+def linear(x, w, b=None, act=ACT_NONE, alpha=0.2):
+    return _LinearFn.apply(x, w, b, act, alpha)
+
+
+class _BatchNormFn(torch.autograd.Function):
+    """Training-mode BN over (N,H,W) of an NHWC tensor + fused activation (batchnorm.py:30)."""
+
+    @staticmethod
+    def forward(ctx, x, scale, offset, eps, act, alpha):
+        y, mean, rstd = H.bn_fwd(x, scale, offset, eps, act, alpha)
+        ctx.save_for_backward(x, scale, mean, rstd, y if act != ACT_NONE else None)
+        ctx.cfg = (act, alpha)
+        ctx.offset_ref = offset
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, scale, mean, rstd, y = ctx.saved_tensors
+        act, alpha = ctx.cfg
+        dx, dscale, doffset = H.bn_bwd(dy, x, y, scale, mean, rstd, act, alpha)
+        ds = _sink_small(scale, dscale) if ctx.needs_input_grad[1] else None
+        do = _sink_small(ctx.offset_ref, doffset) if ctx.needs_input_grad[2] else None
+        return dx, ds, do, None, None, None
+
+
+def batchnorm(x, scale, offset, eps=1e-5, act=ACT_NONE, alpha=0.2):
+    return _BatchNormFn.apply(x, scale, offset, eps, act, alpha)
+
+
+class _LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, scale, offset, eps, act, alpha):
+        y, mean, rstd = H.ln_fwd(x, scale, offset, eps, act, alpha)
+        ctx.save_for_backward(x, scale, mean, rstd, y if act != ACT_NONE else None)
+        ctx.cfg = (act, alpha)
+        ctx.offset_ref = offset
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, scale, mean, rstd, y = ctx.saved_tensors
+        act, alpha = ctx.cfg
+        dx, dscale, doffset = H.ln_bwd(dy, x, y, scale, mean, rstd, act, alpha)
+        ds = _sink_small(scale, dscale) if ctx.needs_input_grad[1] else None
+        do = _sink_small(ctx.offset_ref, doffset) if ctx.needs_input_grad[2] else None
+        return dx, ds, do, None, None, None
+
+
+def layernorm(x, scale, offset, eps=1e-5, act=ACT_NONE, alpha=0.2):
+    return _LayerNormFn.apply(x, scale, offset, eps, act, alpha)
+
+
+class _CropResizeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, img, boxes, box_ind, ch, cw):
+        out = H.crop_resize_fwd(img, boxes, box_ind, ch, cw)
+        ctx.save_for_backward(boxes, box_ind)
+        ctx.img_shape = tuple(img.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        boxes, box_ind = ctx.saved_tensors
+        return H.crop_resize_bwd(dout, boxes, box_ind, ctx.img_shape), None, None, None, None
+
+
+def crop_and_resize(img, boxes, box_ind, ch, cw):
+    return _CropResizeFn.apply(img, boxes, box_ind, ch, cw)
+
+
+class _Upsample2xFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return H.upsample2x_fwd(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return H.upsample2x_bwd(dy)
+
+
+def upsample2x(x):
+    return _Upsample2xFn.apply(x)
+
+
+class _SceMeanFn(torch.autograd.Function):
+    """mean(sigmoid_cross_entropy_with_logits(logits, label)) (trainer.py:239-243)."""
+
+    @staticmethod
+    def forward(ctx, logits, label):
+        out, dl = H.sce_mean(logits, label, want_grad=True, scale=1.0)
+        ctx.save_for_backward(dl)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g, None
+
+
+def sce_mean(logits, label):
+    return _SceMeanFn.apply(logits, float(label))
+
+
+class _L1MeanFn(torch.autograd.Function):
+    """mean(|a - b|) with gradient to a only (trainer.py:607: tf.reduce_mean(tf.abs(G - x)))."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        out, da = H.l1_mean(a, b, want_grad=True, scale=1.0)
+        ctx.save_for_backward(da)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (da,) = ctx.saved_tensors
+        return da * g, None
+
+
+def l1_mean(a, b):
+    return _L1MeanFn.apply(a, b)

@@ -32,6 +32,7 @@ struct GGParams {
     const float* A;       // gathered source activation (x for fwd, dy for dgrad)
     const float* B;       // HWIO filter
     float* D;             // destination activation
+    float* D2;            // optional second output: the activation BEFORE a post-activation residual add
     const float* bias;    // [Ncols] or null
     const float* res;     // residual / accumulate tensor (dest-shaped) or null
     const float* mask;    // activation-output tensor for act' (dest-shaped) or null
@@ -40,7 +41,8 @@ struct GGParams {
     int Hs, Ws, lda, Cs, sr;   // source spatial dims, channel stride, reduction channels, row->src stride
     int Ncols;            // GEMM N
     int Hd, Wd, ldd, dr, dpy, dpx;   // destination pixel = (r*dr+dpy, c*dr+dpx)
-    int ldres, ldmask;
+    int ldres, ldmask, ldd2;
+    int res_post;         // 1: D = act(v + bias) + res  (reference res-blocks, models.py:400,427,536,566)
     int ntaps, cchunks, ktiles, tiles_per_split, nsplit;
     int mtiles, ntiles;
     int act; float alpha;
@@ -68,12 +70,15 @@ __device__ __attribute__((noinline)) void epi_store(float* __restrict__ D, const
                                                     const float* __restrict__ res,
                                                     const float* __restrict__ mask, long pix, int col, float v,
                                                     int ldd, int ldres, int ldmask, int act, float alpha,
-                                                    int replicate, int Wd) {
+                                                    int replicate, int Wd, float* __restrict__ D2, int ldd2,
+                                                    int res_post) {
     if (bias) v += bias[col];
     if (!replicate) {
-        if (res) v += res[pix * ldres + col];
+        if (res && !res_post) v += res[pix * ldres + col];
         if (mask) v *= act_grad(mask[pix * ldmask + col], act, alpha);
         else v = act_apply(v, act, alpha);
+        if (D2) D2[pix * ldd2 + col] = v;
+        if (res && res_post) v += res[pix * ldres + col];
         D[pix * ldd + col] = v;
     } else {
         v = act_apply(v, act, alpha);
@@ -266,7 +271,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GGParams p) {
                 if (row < p.M && col < p.Ncols) {
                     if (p.nsplit > 1) p.partial[((long)split * p.M + row) * p.Ncols + col] = v;
                     else epi_store(p.D, p.bias, p.res, p.mask, pix, col, v, p.ldd, p.ldres, p.ldmask, p.act,
-                                   p.alpha, p.replicate, p.Wd);
+                                   p.alpha, p.replicate, p.Wd, p.D2, p.ldd2, p.res_post);
                 }
             }
         }
@@ -284,7 +289,7 @@ __global__ __launch_bounds__(256) void gather_gemm_reduce_kernel(const GGParams 
         const long pix = p.identity_rows ? (long)row
                                          : row_to_pix(row, p.HrWr, p.Wr, p.Hd, p.Wd, p.dr, p.dpy, p.dpx);
         epi_store(p.D, p.bias, p.res, p.mask, pix, col, v, p.ldd, p.ldres, p.ldmask, p.act, p.alpha, p.replicate,
-                  p.Wd);
+                  p.Wd, p.D2, p.ldd2, p.res_post);
     }
 }
 
@@ -621,7 +626,8 @@ extern "C" size_t dpig_conv2d_workspace_bytes(const DpigConvDesc* d, int which) 
 }
 
 extern "C" int dpig_conv2d_fwd(const DpigConvDesc* d, const float* x, const float* w, const float* bias,
-                               const float* residual, float* y, void* ws, size_t ws_bytes, void* stream) {
+                               const float* residual, float* y, float* y_act, void* ws, size_t ws_bytes,
+                               void* stream) {
     int pt, pl, Ho, Wo;
     int rc = resolve_desc(d, &pt, &pl, &Ho, &Wo);
     if (rc) return rc;
@@ -629,6 +635,9 @@ extern "C" int dpig_conv2d_fwd(const DpigConvDesc* d, const float* x, const floa
     if (d->upsample2x && residual) return fail(DPIG_EINVAL, "residual unsupported with upsample2x");
     GGParams p = {};
     p.A = x; p.B = w; p.D = y; p.bias = bias; p.res = residual; p.mask = nullptr;
+    p.D2 = y_act; p.ldd2 = d->ldy2; p.res_post = d->res_after_act;
+    if (y_act && d->ldy2 < d->K) return fail(DPIG_EINVAL, "ldy2 < K");
+    if (y_act && d->upsample2x) return fail(DPIG_EINVAL, "y_act unsupported with upsample2x");
     p.partial = static_cast<float*>(ws);
     Shape s = fwd_shape(d, Ho, Wo);
     p.M = (int)s.M;

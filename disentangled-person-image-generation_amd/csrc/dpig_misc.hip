@@ -58,6 +58,17 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
     }
 }
 
+// y = act(x) (stand-alone LeakyReLU / ReLU, wgan_gp.py:23-24) ------------------------------------
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* __restrict__ x, int ldx, float* __restrict__ y,
+                                                      int ldy, long rows, int cols, int act, float alpha) {
+    const long total = rows * cols;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / cols;
+        const int c = (int)(i - r * cols);
+        y[r * ldy + c] = act_apply(x[r * ldx + c], act, alpha);
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // column reductions over a [rows, C] matrix.  Block = 64 columns x 4 row groups; grid.y row slabs.
 //   MODE 0: s0 = sum a
@@ -468,6 +479,15 @@ extern "C" int dpig_act_bwd(const float* dy, int lddy, const float* y, int ldy, 
     return check_launch("act_bwd_kernel");
 }
 
+extern "C" int dpig_act_fwd(const float* x, int ldx, float* y, int ldy, int64_t rows, int cols, int act, float alpha,
+                            void* stream) {
+    if (!x || !y) return fail(DPIG_EINVAL, "act_fwd: null pointer");
+    if (rows <= 0 || cols <= 0) return fail(DPIG_EINVAL, "act_fwd: empty");
+    hipLaunchKernelGGL(act_fwd_kernel, dim3(grid_for(rows * cols)), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                       ldx, y, ldy, (long)rows, cols, act, alpha);
+    return check_launch("act_fwd_kernel");
+}
+
 extern "C" size_t dpig_colsum_workspace_bytes(int64_t rows, int cols) {
     return (size_t)slabs_for(rows) * 2 * cols * sizeof(float);
 }
@@ -571,18 +591,13 @@ static DpigConvDesc linear_desc(int M, int Kin, int Nout, int act, float alpha) 
 }
 extern "C" size_t dpig_linear_workspace_bytes(int M, int Kin, int Nout, int which) {
     DpigConvDesc d = linear_desc(M, Kin, Nout, 0, 0.f);
-    size_t b = dpig_conv2d_workspace_bytes(&d, which);
-    if (which == 2) {
-        const size_t c = dpig_colsum_workspace_bytes(M, Nout);
-        if (c > b) b = c;
-    }
-    return b;
+    return dpig_conv2d_workspace_bytes(&d, which);
 }
 extern "C" int dpig_linear_fwd(const float* x, const float* w, const float* bias, float* y, int M, int Kin, int Nout,
                                int act, float alpha, void* ws, size_t ws_bytes, void* stream) {
     if (M <= 0 || Kin <= 0 || Nout <= 0) return fail(DPIG_EINVAL, "linear: non-positive dims");
     DpigConvDesc d = linear_desc(M, Kin, Nout, act, alpha);
-    return dpig_conv2d_fwd(&d, x, w, bias, nullptr, y, ws, ws_bytes, stream);
+    return dpig_conv2d_fwd(&d, x, w, bias, nullptr, y, nullptr, ws, ws_bytes, stream);
 }
 extern "C" int dpig_linear_dgrad(const float* dy, const float* w, float* dx, int M, int Kin, int Nout, void* ws,
                                  size_t ws_bytes, void* stream) {
@@ -590,14 +605,11 @@ extern "C" int dpig_linear_dgrad(const float* dy, const float* w, float* dx, int
     DpigConvDesc d = linear_desc(M, Kin, Nout, 0, 0.f);
     return dpig_conv2d_dgrad(&d, dy, w, nullptr, nullptr, dx, ws, ws_bytes, stream);
 }
-extern "C" int dpig_linear_wgrad(const float* x, const float* dy, float* dw, float* db, int M, int Kin, int Nout,
+extern "C" int dpig_linear_wgrad(const float* x, const float* dy, float* dw, float beta, int M, int Kin, int Nout,
                                  void* ws, size_t ws_bytes, void* stream) {
     if (M <= 0 || Kin <= 0 || Nout <= 0) return fail(DPIG_EINVAL, "linear: non-positive dims");
     DpigConvDesc d = linear_desc(M, Kin, Nout, 0, 0.f);
-    int rc = dpig_conv2d_wgrad(&d, x, dy, dw, 0.f, ws, ws_bytes, stream);
-    if (rc) return rc;
-    if (db) rc = dpig_colsum(dy, Nout, M, Nout, db, 0.f, ws, ws_bytes, stream);
-    return rc;
+    return dpig_conv2d_wgrad(&d, x, dy, dw, beta, ws, ws_bytes, stream);
 }
 
 extern "C" int dpig_crop_resize_fwd(const float* img, int N, int H, int W, int C, const float* boxes,

@@ -12,6 +12,30 @@ from . import _lib
 from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU, DpigConvDesc, check, lib, ptr, stream_ptr, workspace
 
 
+# Optional per-launch timing (bench.py's roofline leg): when PROFILE is a list, every conv launch is
+# bracketed by HIP events recorded on the stream the kernel is launched on (torch's current stream)
+# and (class, executed FLOPs, start, end) is appended.  None = off (no overhead).
+PROFILE = None
+
+
+class _Timed(object):
+    def __init__(self, kind, flops):
+        self.kind, self.flops = kind, flops
+
+    def __enter__(self):
+        if PROFILE is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e1 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE is not None:
+            self.e1.record()
+            PROFILE.append((self.kind, self.flops, self.e0, self.e1))
+        return False
+
+
 def _require_gpu(t):
     if not t.is_cuda:
         raise RuntimeError("dpig HIP ops need device tensors (got %s): there is no CPU fallback" % t.device)
@@ -45,12 +69,13 @@ def as_nhwc(t):
 
 
 def _desc(N, H, W, C, K, R, S, stride, ldx, ldy, ldres=0, ldmask=0, act=ACT_NONE, alpha=0.2, upsample2x=False,
-          split_k=0):
+          split_k=0, res_after_act=False, ldy2=0):
     d = DpigConvDesc()
     d.N, d.H, d.W, d.C, d.K, d.R, d.S, d.stride = N, H, W, C, K, R, S, stride
     d.pad_t, d.pad_l = -1, -1
     d.ldx, d.ldy, d.ldres, d.ldmask = ldx, ldy, ldres, ldmask
     d.act, d.alpha, d.upsample2x, d.split_k = act, alpha, int(upsample2x), split_k
+    d.res_after_act, d.ldy2 = int(res_after_act), ldy2
     return d
 
 
@@ -67,8 +92,10 @@ def conv_out_hw(H, W, R, S, stride, upsample2x=False):
 
 
 def conv2d_fwd(x, w, bias=None, stride=1, act=ACT_NONE, alpha=0.2, residual=None, out=None, upsample2x=False,
-               split_k=0):
-    """y = act(conv_SAME(x, w) + bias + residual); x NHWC, w HWIO.  `out` may be a channel slice."""
+               split_k=0, res_after_act=False, out_act=None):
+    """y = act(conv_SAME(x, w) + bias + residual) (or act(..) + residual with res_after_act);
+    x NHWC, w HWIO.  `out` may be a channel slice.  `out_act` optionally receives the activation
+    output before a post-activation residual add."""
     _require_gpu(x)
     x, ldx = as_nhwc(x)
     w = w.contiguous()
@@ -87,11 +114,18 @@ def conv2d_fwd(x, w, bias=None, stride=1, act=ACT_NONE, alpha=0.2, residual=None
         residual, ldres = as_nhwc(residual)
     if bias is not None:
         bias = bias.contiguous()
+    ldy2 = 0
+    if out_act is not None:
+        ldy2 = nhwc_ld(out_act)
+        if ldy2 is None or tuple(out_act.shape) != (N, Ho, Wo, K):
+            raise RuntimeError("conv2d: bad out_act tensor")
     d = _desc(N, H, W, C, K, R, S, stride, ldx, ldy, ldres=ldres, act=act, alpha=alpha, upsample2x=upsample2x,
-              split_k=split_k)
+              split_k=split_k, res_after_act=res_after_act, ldy2=ldy2)
     wsb, wsn = _ws(d, 0, x.device)
-    check(lib().dpig_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(out), ptr(wsb), wsn,
-                                stream_ptr()), "conv2d_fwd")
+    mfma = (C % 4 == 0 and K % 4 == 0 and ldx % 4 == 0 and C >= 32 and K >= 32)
+    with _Timed("conv_fwd_mfma" if mfma else "conv_fwd_thin", 2.0 * N * H * W // (stride * stride) * K * R * S * C):
+        check(lib().dpig_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(out),
+                                    ptr(out_act), ptr(wsb), wsn, stream_ptr()), "conv2d_fwd")
     return out
 
 
@@ -121,8 +155,11 @@ def conv2d_dgrad(dy, w, in_shape, stride=1, accum=None, mask=None, act=ACT_NONE,
     d = _desc(N, H, W, C, K, R, S, stride, ldx, ldy, ldres=ldres, ldmask=ldmask, act=act, alpha=alpha,
               upsample2x=upsample2x, split_k=split_k)
     wsb, wsn = _ws(d, 1, dy.device)
-    check(lib().dpig_conv2d_dgrad(ctypes.byref(d), ptr(dy), ptr(w), ptr(accum), ptr(mask), ptr(out), ptr(wsb), wsn,
-                                  stream_ptr()), "conv2d_dgrad")
+    mfma = (C % 4 == 0 and K % 4 == 0 and ldy % 4 == 0 and C >= 32 and K >= 32)
+    with _Timed("conv_dgrad_mfma" if mfma else "conv_dgrad_thin",
+                2.0 * N * H * W // (stride * stride) * K * R * S * C):
+        check(lib().dpig_conv2d_dgrad(ctypes.byref(d), ptr(dy), ptr(w), ptr(accum), ptr(mask), ptr(out), ptr(wsb),
+                                      wsn, stream_ptr()), "conv2d_dgrad")
     return out
 
 
@@ -140,8 +177,11 @@ def conv2d_wgrad(x, dy, wshape, stride=1, upsample2x=False, out=None, beta=0.0, 
         beta = 0.0
     d = _desc(N, H, W, C, K, R, S, stride, ldx, ldy, upsample2x=upsample2x, split_k=split_k)
     wsb, wsn = _ws(d, 2, x.device)
-    check(lib().dpig_conv2d_wgrad(ctypes.byref(d), ptr(x), ptr(dy), ptr(out), float(beta), ptr(wsb), wsn,
-                                  stream_ptr()), "conv2d_wgrad")
+    mfma = (C % 4 == 0 and K % 4 == 0 and C >= 32 and K >= 32)
+    with _Timed("conv_wgrad_mfma" if mfma else "conv_wgrad_thin",
+                2.0 * N * H * W // (stride * stride) * K * R * S * C):
+        check(lib().dpig_conv2d_wgrad(ctypes.byref(d), ptr(x), ptr(dy), ptr(out), float(beta), ptr(wsb), wsn,
+                                      stream_ptr()), "conv2d_wgrad")
     return out
 
 
@@ -153,6 +193,15 @@ def _rows_ld(t):
         return t, t.shape[0], t.shape[1], (t.stride(0) if t.shape[0] > 1 else t.shape[1])
     t, ld = as_nhwc(t)
     return t, t.shape[0] * t.shape[1] * t.shape[2], t.shape[3], ld
+
+
+def act_fwd(x, act, alpha=0.2):
+    """y = act(x) elementwise."""
+    _require_gpu(x)
+    x, rows, cols, ldx = _rows_ld(x)
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    check(lib().dpig_act_fwd(ptr(x), ldx, ptr(y), cols, rows, cols, act, alpha, stream_ptr()), "act_fwd")
+    return y
 
 
 def act_bwd(dy, y, act, alpha=0.2):
@@ -268,18 +317,20 @@ def linear_dgrad(dy, w):
     return dx
 
 
-def linear_wgrad(x, dy, need_bias=True):
+def linear_wgrad(x, dy, out=None, beta=0.0):
+    """dw[Kin,Nout] = beta*dw + x^T @ dy."""
     _require_gpu(x)
     x = x.contiguous()
     dy = dy.contiguous()
     M, Kin = x.shape
     Nout = dy.shape[1]
-    dw = torch.empty((Kin, Nout), dtype=torch.float32, device=x.device)
-    db = torch.empty(Nout, dtype=torch.float32, device=x.device) if need_bias else None
+    if out is None:
+        out = torch.empty((Kin, Nout), dtype=torch.float32, device=x.device)
+        beta = 0.0
     wsb, wsn = workspace.get(lib().dpig_linear_workspace_bytes(M, Kin, Nout, 2), x.device)
-    check(lib().dpig_linear_wgrad(ptr(x), ptr(dy), ptr(dw), ptr(db), M, Kin, Nout, ptr(wsb), wsn, stream_ptr()),
-          "linear_wgrad")
-    return dw, db
+    check(lib().dpig_linear_wgrad(ptr(x), ptr(dy), ptr(out), float(beta), M, Kin, Nout, ptr(wsb), wsn,
+                                  stream_ptr()), "linear_wgrad")
+    return out
 
 
 def crop_resize_fwd(img, boxes, box_ind, ch, cw):

@@ -1,0 +1,238 @@
+"""Model builders of the DPIG hot path on the HIP kernels: same function names, argument meaning
+and return shapes as the reference `models.py` (file:line cited per function).  Pure functions
+`tensor(s) -> (tensor(s), var_list)`; variables are created on first call under TF-slim names.
+
+Activations are NHWC fp32 device tensors.  Differences from the reference are execution-only:
+the residual blocks are one fused op (slim.res_block), the 7 ROI crops are one launch, and the
+nearest-2x upsample is folded into the following 1x1 conv.  Arithmetic is unchanged.
+"""
+import numpy as np
+import torch
+
+from . import autograd as A
+from . import slim
+from .slim import fully_connected, variable_scope
+
+
+def relu(x):
+    return slim.relu(x)
+
+
+def LeakyReLU(x, alpha=0.3):
+    """models.py:137 (alpha 0.3; the trainers resolve LeakyReLU to wgan_gp's 0.2, SURVEY B-11)."""
+    return slim.leaky_relu(x, alpha)
+
+
+def reshape(x, h, w, c, data_format):
+    """utils.py:54-59."""
+    if data_format == 'NCHW':
+        return x.reshape(-1, c, h, w)
+    return x.reshape(-1, h, w, c)
+
+
+def _normalised_boxes(ROI_bboxs, bbox_num, img_H, img_W):
+    """models.py:405-413: pixel (y1,x1,y2,x2) -> /img_H, /img_W (division by H, not H-1), stacked
+    part-major ([part0: all images, part1: all images, ...]) like tf.concat(body_roi_list, axis=0)."""
+    b = ROI_bboxs[:, :bbox_num, :].to(torch.float32)
+    scale = torch.tensor([img_H, img_W, img_H, img_W], dtype=torch.float32, device=b.device)
+    b = b / scale
+    batch = b.shape[0]
+    boxes = b.permute(1, 0, 2).reshape(bbox_num * batch, 4).contiguous()
+    box_ind = torch.arange(batch, dtype=torch.int32, device=b.device).repeat(bbox_num)
+    return boxes, box_ind
+
+
+def _roi_tower(body_regions, z_num, repeat_num, hidden_num, data_format, activation_fn):
+    """Shared-weight tower on the stacked ROI crops (models.py:346-357 / 420-431)."""
+    for idx in range(repeat_num):
+        channel_num = hidden_num * (idx + 1)
+        body_regions = slim.res_block(body_regions, channel_num, 3, activation_fn=activation_fn,
+                                      data_format=data_format)
+        if idx < repeat_num - 1:
+            body_regions = slim.conv2d(body_regions, hidden_num * (idx + 2), 3, 2, activation_fn=activation_fn,
+                                       data_format=data_format)
+    body_regions = body_regions.reshape(body_regions.shape[0], -1)
+    return fully_connected(body_regions, z_num, activation_fn=None)
+
+
+def _apply_vis(body_regions, ROI_vis, bbox_num, z_num):
+    """models.py:359-368 / 433-442: split per part, multiply by the visibility flag, concat on -1."""
+    batch = ROI_vis.shape[0]
+    fea = body_regions.reshape(bbox_num, batch, z_num)
+    vis = ROI_vis[:, :bbox_num].to(torch.float32).t().reshape(bbox_num, batch, 1)
+    fea = fea * vis
+    fea_list = [fea[i] for i in range(bbox_num)]
+    return fea_list
+
+
+def GeneratorCNN_ID_Encoder_BodyROIVis(x, ROI_bboxs, ROI_vis, bbox_num, z_num, repeat_num, hidden_num, data_format,
+                                       activation_fn=relu, keep_part_prob=1.0, roi_size=48, reuse=False):
+    """Reference models.py:328-388 (DeepFashion appearance encoder)."""
+    with variable_scope("G_encoder", reuse=reuse) as vs:
+        batch_num = x.shape[0]
+        img_H, img_W = float(x.shape[1]), float(x.shape[2])
+        x = slim.conv2d(x, hidden_num, 3, 1, activation_fn=activation_fn, data_format=data_format)
+        x = slim.res_block(x, hidden_num, 3, activation_fn=activation_fn, data_format=data_format)
+
+        boxes, box_ind = _normalised_boxes(ROI_bboxs, bbox_num, img_H, img_W)
+        body_regions = A.crop_and_resize(x, boxes, box_ind, roi_size, roi_size)
+        body_regions = _roi_tower(body_regions, z_num, repeat_num, hidden_num, data_format, activation_fn)
+        fea_list = _apply_vis(body_regions, ROI_vis, bbox_num, z_num)
+        if keep_part_prob < 1.0:
+            for i in range(bbox_num):
+                keep = (torch.rand(batch_num, 1, device=x.device) < keep_part_prob).to(torch.float32)
+                fea_list[i] = fea_list[i] * keep
+        fea_all = torch.cat(fea_list, dim=-1)
+        variables = slim.get_variables(vs)
+    return fea_all, fea_list, variables
+
+
+def GeneratorCNN_ID_Encoder_BodyROIVis_FgBgFeaTwoBranch(x, fg_mask, ROI_bboxs, ROI_vis, bbox_num, z_num, repeat_num,
+                                                        hidden_num, data_format, activation_fn=relu,
+                                                        keep_part_prob=1.0, roi_size=48, reuse=False):
+    """Reference models.py:390-471 (Market-1501 Fg/Bg two-branch encoder)."""
+    with variable_scope("G_encoder", reuse=reuse) as vs:
+        batch_num = x.shape[0]
+        img_H, img_W = float(x.shape[1]), float(x.shape[2])
+        # Encoder stem
+        x = slim.conv2d(x, hidden_num, 3, 1, activation_fn=activation_fn, data_format=data_format)
+        x = slim.res_block(x, hidden_num, 3, activation_fn=activation_fn, data_format=data_format)
+
+        m = fg_mask.to(torch.float32)
+        x_fg = x * m
+        x_bg = x * (1.0 - m)
+
+        boxes, box_ind = _normalised_boxes(ROI_bboxs, bbox_num, img_H, img_W)
+        body_regions = A.crop_and_resize(x_fg, boxes, box_ind, roi_size, roi_size)
+        conv_fea_list = [body_regions, x_bg]
+
+        # Share weights for different body regions
+        body_regions = _roi_tower(body_regions, z_num, repeat_num, hidden_num, data_format, activation_fn)
+        fea_list = _apply_vis(body_regions, ROI_vis, bbox_num, z_num)
+        if keep_part_prob < 1.0:
+            for i in range(bbox_num):
+                keep = (torch.rand(batch_num, 1, device=x.device) < keep_part_prob).to(torch.float32)
+                fea_list[i] = fea_list[i] * keep
+
+        # Background branch
+        for idx in range(repeat_num):
+            channel_num = hidden_num * (idx + 1)
+            x_bg = slim.res_block(x_bg, channel_num, 3, activation_fn=activation_fn, data_format=data_format)
+            if idx < repeat_num - 1:
+                x_bg = slim.conv2d(x_bg, hidden_num * (idx + 2), 3, 2, activation_fn=activation_fn,
+                                   data_format=data_format)
+        x_bg = x_bg.reshape(x_bg.shape[0], -1)
+        x_bg = fully_connected(x_bg, z_num * 4, activation_fn=None)
+
+        fea_list.append(x_bg)
+        fea_all = torch.cat(fea_list, dim=-1)
+        variables = slim.get_variables(vs)
+    return fea_all, fea_list, conv_fea_list, variables
+
+
+def GaussianFCRes(z_shape, out_channel, repeat_num, hidden_num, data_format, mean=0.0, stddev=0.2,
+                  activation_fn=relu, reuse=False, z=None, device=None):
+    """Reference models.py:474-486."""
+    with variable_scope("G_FC", reuse=reuse) as vs:
+        if z is None:
+            z = torch.randn(tuple(z_shape), device=device) * stddev + mean
+        z = fully_connected(z, hidden_num, activation_fn=activation_fn)
+        for i in range(repeat_num):
+            res = z
+            z = fully_connected(z, hidden_num, activation_fn=activation_fn)
+            z = fully_connected(z, hidden_num, activation_fn=activation_fn)
+            z = res + z
+        out = fully_connected(z, out_channel, activation_fn=None)
+        variables = slim.get_variables(vs)
+    return out, variables
+
+
+def PoseEncoderFCRes(pose_rcv, z_num, repeat_num, hidden_num, data_format, activation_fn=relu, reuse=False):
+    """Reference models.py:488-499."""
+    with variable_scope("G_Pose_Encoder", reuse=reuse) as vs:
+        x = fully_connected(pose_rcv, hidden_num, activation_fn=activation_fn)
+        for i in range(repeat_num):
+            res = x
+            x = fully_connected(x, hidden_num, activation_fn=activation_fn)
+            x = fully_connected(x, hidden_num, activation_fn=activation_fn)
+            x = res + x
+        out = fully_connected(x, z_num, activation_fn=None)
+        variables = slim.get_variables(vs)
+    return out, variables
+
+
+class _BinaryRoundST(torch.autograd.Function):
+    """models.py:97-108: round() with a straight-through (identity) gradient."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return torch.round(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+def binaryRound(x):
+    return _BinaryRoundST.apply(x)
+
+
+def PoseDecoderFCRes(z, keypoint_num, repeat_num, hidden_num, data_format, activation_fn=relu, reuse=False):
+    """Reference models.py:501-515."""
+    with variable_scope("G_Pose_Decoder", reuse=reuse) as vs:
+        x = fully_connected(z, hidden_num, activation_fn=None)
+        for i in range(repeat_num):
+            res = x
+            x = fully_connected(x, hidden_num, activation_fn=activation_fn)
+            x = fully_connected(x, hidden_num, activation_fn=activation_fn)
+            x = res + x
+        re_pose_coord = fully_connected(x, keypoint_num * 2, activation_fn=None)
+        re_pose_visible = fully_connected(x, keypoint_num, activation_fn=torch.sigmoid)  # norm to (0, 1)
+        re_pose_visible = binaryRound(re_pose_visible)
+        variables = slim.get_variables(vs)
+    return re_pose_coord, re_pose_visible, variables
+
+
+def GeneratorCNN_ID_UAEAfterResidual(x, pose, input_channel, z_num, repeat_num, hidden_num, data_format,
+                                     activation_fn=relu, min_fea_map_H=8, noise_dim=0, reuse=False):
+    """Reference models.py:518-576 (U-Net style decoder G)."""
+    with variable_scope("G", reuse=reuse) as vs:
+        if pose is not None:
+            if data_format != 'NHWC':
+                raise Exception("only NHWC is supported (main.py:18)")
+            x = torch.cat([x, pose], dim=3)
+
+        # Encoder
+        encoder_layer_list = []
+        x = slim.conv2d(x, hidden_num, 3, 1, activation_fn=activation_fn, data_format=data_format)
+        for idx in range(repeat_num):
+            channel_num = hidden_num * (idx + 1)
+            x = slim.res_block(x, channel_num, 3, activation_fn=activation_fn, data_format=data_format)
+            encoder_layer_list.append(x)
+            if idx < repeat_num - 1:
+                x = slim.conv2d(x, hidden_num * (idx + 2), 3, 2, activation_fn=activation_fn,
+                                data_format=data_format)
+
+        x_shape = list(x.shape)
+        x = x.reshape(x_shape[0], int(np.prod(x_shape[1:])))
+        z = x = fully_connected(x, z_num, activation_fn=None)
+        if noise_dim > 0:
+            noise = torch.rand(z.shape[0], noise_dim, device=z.device) * 2.0 - 1.0
+            z = torch.cat([z, noise], dim=1)
+
+        # Decoder
+        x = fully_connected(z, x_shape[1] * x_shape[2] * hidden_num, activation_fn=None)
+        x = reshape(x, x_shape[1], x_shape[2], hidden_num, data_format)
+
+        for idx in range(repeat_num):
+            x = torch.cat([x, encoder_layer_list[repeat_num - 1 - idx]], dim=-1)
+            channel_num = x.shape[-1]
+            x = slim.res_block(x, channel_num, 3, activation_fn=activation_fn, data_format=data_format)
+            if idx < repeat_num - 1:
+                # x = upscale(x, 2, data_format); x = slim.conv2d(x, ..., 1, 1, ...)   (models.py:569-570)
+                x = slim.conv2d(x, hidden_num * (repeat_num - idx - 1), 1, 1, activation_fn=activation_fn,
+                                data_format=data_format, upsample2x=True)
+
+        out = slim.conv2d(x, input_channel, 3, 1, activation_fn=None, data_format=data_format)
+        variables = slim.get_variables(vs)
+    return out, z, variables

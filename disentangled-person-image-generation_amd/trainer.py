@@ -1,0 +1,276 @@
+"""Stage-I training step of DPIG on the HIP kernels, mirroring the reference `trainer.py`:
+`_gan_loss` (:217-252), `_getOptimizer` (:116-149), `_getDiscriminator` (:151-158),
+`DPIG_Encoder_GAN_BodyROI_FgBg.build_model` (:568-625) and the step order of `train()` (:336-347):
+one "G+D step" = g_optim on one batch (skipped at step 0) then d_optim x {1 (dcgan/lsgan) | 5}.
+
+Host code is graph wiring only: every tensor op on the hot path is a kernel of libdpig_hip.so.
+Parameters live in two flat HBM buffers (G-side = Encoder + ID_AE, D-side = Discriminator.*), the
+wgrad kernels write gradients straight into the matching flat gradient buffers, one Adam launch
+updates a whole side, and under data parallelism the flat gradient buffer is what RCCL
+all-reduces (bucketed slices of one allocation).
+"""
+import math
+
+import torch
+
+from . import autograd as A
+from . import hip_ops as H
+from . import models
+from . import slim
+from . import tflib as lib
+from .wgan_gp import WGAN_GP
+
+
+class FlatParams(object):
+    """Re-homes a list of parameters into one flat fp32 buffer + flat grad / Adam-moment buffers.
+
+    Each tensor starts on a 16-byte boundary so the kernels' float4 paths apply to every slice."""
+
+    def __init__(self, params):
+        seen, plist = set(), []
+        for p in params:
+            if isinstance(p, torch.nn.Parameter) and p.requires_grad and id(p) not in seen:
+                seen.add(id(p))
+                plist.append(p)
+        self.params = plist
+        dev = plist[0].device
+        offs, total = [], 0
+        for p in plist:
+            offs.append(total)
+            total += (p.numel() + 3) // 4 * 4
+        self.numel = total
+        self.flat = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grad = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.m = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.v = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.offsets = offs
+        for p, o in zip(plist, offs):
+            n = p.numel()
+            self.flat[o:o + n].copy_(p.data.reshape(-1))
+            p.data = self.flat[o:o + n].view(p.shape)
+            p._dpig_grad = self.grad[o:o + n].view(p.shape)
+            p._dpig_touched = [False]
+
+    def zero_grad(self):
+        """No memset: the first kernel that touches a slice overwrites it (beta = 0)."""
+        for p in self.params:
+            p._dpig_touched[0] = False
+            p.grad = None
+
+    def finalize(self):
+        """Parameters that received no gradient this step must contribute zeros."""
+        for p in self.params:
+            if not p._dpig_touched[0]:
+                if p.grad is not None:           # gradient came through plain autograd
+                    p._dpig_grad.copy_(p.grad)
+                    p.grad = None
+                else:
+                    p._dpig_grad.zero_()
+
+    def set_requires_grad(self, flag):
+        for p in self.params:
+            p.requires_grad_(flag)
+
+
+class TFAdam(object):
+    """tf.train.AdamOptimizer on a FlatParams (trainer.py:131-146): one fused kernel launch.
+    `lr` is a 1-element device tensor (the reference keeps it in a tf.Variable, :56-59)."""
+
+    def __init__(self, flat, lr_dev, beta1=0.9, beta2=0.999, eps=1e-8):
+        self.flat, self.lr, self.b1, self.b2, self.eps, self.t = flat, lr_dev, beta1, beta2, eps, 0
+
+    def step(self, grad_scale=1.0):
+        self.t += 1
+        f = self.flat
+        H.adam_step(f.flat, f.grad, f.m, f.v, self.lr, self.b1, self.b2, self.eps, self.t, grad_scale)
+
+
+class GradAllReduce(object):
+    """Data-parallel gradient exchange: sum-all-reduce of the flat gradient buffer over RCCL in
+    ~32 MB slices (xGMI is point-to-point: a few large collectives, not hundreds of small ones);
+    the 1/world factor is folded into the Adam kernel's grad_scale."""
+
+    def __init__(self, bucket_bytes=32 << 20):
+        import torch.distributed as dist
+        self.dist = dist
+        self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+        self.world = dist.get_world_size() if self.enabled else 1
+        self.bucket = bucket_bytes // 4
+
+    def __call__(self, flat_grad):
+        if not self.enabled:
+            return 1.0
+        n = flat_grad.numel()
+        handles = []
+        for o in range(0, n, self.bucket):
+            handles.append(self.dist.all_reduce(flat_grad[o:min(o + self.bucket, n)], async_op=True))
+        for h in handles:
+            h.wait()
+        return 1.0 / self.world
+
+    def broadcast(self, flat_params):
+        if self.enabled:
+            self.dist.broadcast(flat_params, src=0)
+
+
+def gan_loss(wgan_gp, disc_real, disc_fake):
+    """trainer.py:217-252 (`_gan_loss`), modes dcgan / wgan / lsgan.  Returns (gen_cost, disc_cost);
+    either input may be None when that side is not needed (TF prunes the unused branch)."""
+    mode = wgan_gp.MODE
+    gen_cost = disc_cost = None
+    if mode == 'dcgan':
+        if disc_fake is not None:
+            gen_cost = A.sce_mean(disc_fake, 1.0)
+        if disc_fake is not None and disc_real is not None:
+            disc_cost = (A.sce_mean(disc_fake, 0.0) + A.sce_mean(disc_real, 1.0)) / 2.
+    elif mode == 'wgan':
+        if disc_fake is not None:
+            gen_cost = -disc_fake.mean()
+        if disc_fake is not None and disc_real is not None:
+            disc_cost = disc_fake.mean() - disc_real.mean()
+    elif mode == 'lsgan':
+        if disc_fake is not None:
+            gen_cost = ((disc_fake - 1) ** 2).mean()
+        if disc_fake is not None and disc_real is not None:
+            disc_cost = (((disc_real - 1) ** 2).mean() + ((disc_fake - 0) ** 2).mean()) / 2.
+    elif mode == 'wgan-gp':
+        raise Exception("wgan-gp (gradient penalty) is not wired into the stage-I step yet")
+    else:
+        raise Exception()
+    return gen_cost, disc_cost
+
+
+class Config(object):
+    """The config.py flags the hot path reads (defaults = config.py / run_market_train.sh)."""
+
+    def __init__(self, **kw):
+        self.batch_size = 16
+        self.img_H, self.img_W = 128, 64
+        self.conv_hidden_num = 128       # config.py:23
+        self.z_num = 64
+        self.g_lr = 2e-5                 # run_market_train.sh:12
+        self.d_lr = 2e-5
+        self.lr_update_step = 50000
+        self.D_arch = 'DCGAN'
+        self.data_format = 'NHWC'        # main.py:18
+        self.__dict__.update(kw)
+        self.repeat_num = int(math.log2(self.img_H)) - 2    # trainer.py:75
+
+
+class DPIG_Encoder_GAN_BodyROI_FgBg(object):
+    """Reference trainer.py:567-625 (model 1) + the base-class loop :326-347."""
+
+    def __init__(self, config, device):
+        self.config = config
+        self.device = torch.device(device)
+        self.batch_size = config.batch_size
+        self.img_H, self.img_W, self.channel = config.img_H, config.img_W, 3
+        self.repeat_num, self.conv_hidden_num, self.z_num = config.repeat_num, config.conv_hidden_num, config.z_num
+        self.data_format = config.data_format
+        self.keypoint_num, self.part_num = 18, 7
+        lib.set_device(self.device)
+        self.g_lr = torch.full((1,), config.g_lr, dtype=torch.float32, device=self.device)
+        self.d_lr = torch.full((1,), config.d_lr, dtype=torch.float32, device=self.device)
+        # _define_input (trainer.py:254-259)
+        self.Generator_fn = models.GeneratorCNN_ID_UAEAfterResidual
+        self.wgan_gp = WGAN_GP(DATA_DIR='', MODE='dcgan', DIM=64, BATCH_SIZE=self.batch_size, ITERS=200000,
+                               LAMBDA=10, G_OUTPUT_DIM=self.img_H * self.img_W * 3)
+        self.Discriminator_fn = self._getDiscriminator(self.wgan_gp, arch=config.D_arch)
+        self.step = 0
+        self.built = False
+        self.allreduce = None
+
+    def _getDiscriminator(self, wgan_gp, arch='DCGAN'):
+        if 'DCGAN' == arch:
+            return wgan_gp.DCGANDiscriminator
+        elif 'FCDis' == arch:
+            return wgan_gp.FCDiscriminator
+        raise Exception('You must choose an architecture!')
+
+    # ---- graph pieces (build_model, trainer.py:568-607) ------------------------------------------
+    def encode(self, batch):
+        with slim.variable_scope("Encoder"):
+            embs, _, _, enc_var = models.GeneratorCNN_ID_Encoder_BodyROIVis_FgBgFeaTwoBranch(
+                batch["x"], batch["mask_r6"], batch["part_bbox"], batch["part_vis"], self.part_num, 32,
+                self.repeat_num, self.conv_hidden_num, self.data_format, activation_fn=slim.relu,
+                keep_part_prob=1.0, reuse=self.built)
+        return embs, enc_var
+
+    def generate(self, embs, pose):
+        # embs_rep: tile the [B,352] embedding over H x W (trainer.py:588-590)
+        B = embs.shape[0]
+        embs_rep = embs.reshape(B, 1, 1, -1).expand(B, self.img_H, self.img_W, embs.shape[1])
+        with slim.variable_scope("ID_AE"):
+            G, _, g_var = self.Generator_fn(embs_rep, pose, self.channel, self.z_num, self.repeat_num,
+                                            self.conv_hidden_num, self.data_format, activation_fn=slim.relu,
+                                            reuse=self.built)
+        return G, g_var
+
+    def discriminate(self, img_nhwc):
+        # tf.transpose(x, [0,3,1,2]) (trainer.py:601-602): a free view here
+        return self.Discriminator_fn(img_nhwc.permute(0, 3, 1, 2), input_dim=3)
+
+    def init_net(self, batch):
+        """Create every variable (one forward, like TF graph construction) and set up optimizers."""
+        with torch.no_grad():
+            embs, enc_var = self.encode(batch)
+            G, g_var = self.generate(embs, batch["pose"])
+            self.discriminate(batch["x"])
+        self.built = True
+        self.G_var = g_var + enc_var                       # trainer.py:596
+        self.D_var = lib.params_with_name('Discriminator.')  # trainer.py:603
+        self.G_flat = FlatParams(self.G_var)
+        self.D_flat = FlatParams(self.D_var)
+        # _getOptimizer, MODE == 'dcgan' (trainer.py:136-140): Adam(beta1=0.5), eps/beta2 TF defaults
+        self.g_opt = TFAdam(self.G_flat, self.g_lr, beta1=0.5, beta2=0.999, eps=1e-8)
+        self.d_opt = TFAdam(self.D_flat, self.d_lr, beta1=0.5, beta2=0.999, eps=1e-8)
+        self.allreduce = GradAllReduce()
+        self.allreduce.broadcast(self.G_flat.flat)
+        self.allreduce.broadcast(self.D_flat.flat)
+
+    # ---- the two optimizer ops -----------------------------------------------------------------
+    def g_optim(self, batch):
+        """sess.run(g_optim): fwd E,G,D(fake); g_loss = sce(D(G),1) + 20*L1; bwd D(dgrad only),G,E; Adam."""
+        self.G_flat.zero_grad()
+        self.D_flat.set_requires_grad(False)
+        embs, _ = self.encode(batch)
+        G, _ = self.generate(embs, batch["pose"])
+        D_z_neg = self.discriminate(G)
+        g_loss_only, _ = gan_loss(self.wgan_gp, None, D_z_neg)
+        L1Loss = A.l1_mean(G, batch["x"])
+        g_loss = g_loss_only + L1Loss * 20           # trainer.py:623
+        g_loss.backward()
+        self.D_flat.set_requires_grad(True)
+        self.G_flat.finalize()
+        scale = self.allreduce(self.G_flat.grad)
+        self.g_opt.step(scale)
+        return {"g_loss": g_loss.detach(), "L1Loss": L1Loss.detach(), "g_loss_only": g_loss_only.detach(), "G": G.detach()}
+
+    def d_optim(self, batch):
+        """sess.run(d_optim): fwd E,G (no grad), D(x), D(G); d_loss; bwd D; Adam(D)."""
+        self.D_flat.zero_grad()
+        with torch.no_grad():
+            embs, _ = self.encode(batch)
+            G, _ = self.generate(embs, batch["pose"])
+        D_z_pos = self.discriminate(batch["x"])
+        D_z_neg = self.discriminate(G)
+        _, d_loss = gan_loss(self.wgan_gp, D_z_pos, D_z_neg)
+        d_loss.backward()
+        self.D_flat.finalize()
+        scale = self.allreduce(self.D_flat.grad)
+        self.d_opt.step(scale)
+        return {"d_loss": d_loss.detach()}
+
+    def train_step(self, batch_g, batch_d):
+        """One iteration of the reference loop (trainer.py:336-347, 362-363)."""
+        out = {}
+        if self.step > 0:
+            out.update(self.g_optim(batch_g))
+        disc_iters = 1 if self.wgan_gp.MODE in ('dcgan', 'lsgan') else self.wgan_gp.CRITIC_ITERS
+        for _ in range(disc_iters):
+            out.update(self.d_optim(batch_d))
+        if self.step % self.config.lr_update_step == self.config.lr_update_step - 1:
+            self.g_lr.mul_(0.5)
+            self.d_lr.mul_(0.5)
+        self.step += 1
+        return out

@@ -62,6 +62,9 @@ typedef struct DpigConvDesc {
     float alpha;          /* LeakyReLU slope                                                      */
     int32_t upsample2x;   /* 1: x is nearest-neighbour 2x-upsampled before a 1x1 conv             */
                           /*    (models.py:569-570); computed at low resolution (exact commute)   */
+    int32_t res_after_act;/* fwd: 0: y = act(conv+bias+res); 1: y = act(conv+bias) + res, the     */
+                          /*      reference res-block order (models.py:398-400,425-427,534-536)   */
+    int32_t ldy2;         /* channel stride of the optional y_act output                          */
     int32_t split_k;      /* 0 = library heuristic, otherwise forced split count                  */
 } DpigConvDesc;
 
@@ -75,10 +78,13 @@ int dpig_same_pad(int in, int k, int stride, int* out, int* pad_before);
  * which: 0 fwd, 1 dgrad, 2 wgrad.  Returns 0 when no workspace is needed. */
 size_t dpig_conv2d_workspace_bytes(const DpigConvDesc* d, int which);
 
-/* y[N,Ho,Wo,K] = act(conv(x, w) + bias + residual).  bias / residual may be NULL.
+/* y[N,Ho,Wo,K] = act(conv(x, w) + bias + residual)  (or act(..)+residual, see res_after_act).
+ * bias / residual / y_act may be NULL.  y_act (optional) receives the activation output before a
+ * post-activation residual add (its sign is the ReLU mask the backward pass needs).
  * With upsample2x, y has spatial size (2H, 2W). */
 int dpig_conv2d_fwd(const DpigConvDesc* d, const float* x, const float* w, const float* bias,
-                    const float* residual, float* y, void* ws, size_t ws_bytes, void* stream);
+                    const float* residual, float* y, float* y_act, void* ws, size_t ws_bytes,
+                    void* stream);
 
 /* dx[N,H,W,C] = (conv_backward_data(dy, w) + accum) * act'(mask).  accum / mask may be NULL.
  * Also the forward of tflib Deconv2D (stride-2 transposed conv). */
@@ -91,6 +97,9 @@ int dpig_conv2d_wgrad(const DpigConvDesc* d, const float* x, const float* dy, fl
 
 /* ---- elementwise / reductions over a [rows, cols] fp32 matrix with row stride ld ------------- */
 
+/* y = act(x): stand-alone ReLU / LeakyReLU (wgan_gp.py:23-24 `tf.maximum(alpha*x, x)`). */
+int dpig_act_fwd(const float* x, int ldx, float* y, int ldy, int64_t rows, int cols, int act, float alpha,
+                 void* stream);
 /* dz = dy * act'(y)   (y = the activation OUTPUT; relu'/lrelu' decided by y > 0). */
 int dpig_act_bwd(const float* dy, int lddy, const float* y, int ldy, float* dz, int lddz, int64_t rows,
                  int cols, int act, float alpha, void* stream);
@@ -128,8 +137,8 @@ int dpig_linear_fwd(const float* x, const float* w, const float* bias, float* y,
 /* dx[M,Kin] = dy[M,Nout] @ w^T */
 int dpig_linear_dgrad(const float* dy, const float* w, float* dx, int M, int Kin, int Nout, void* ws,
                       size_t ws_bytes, void* stream);
-/* dw[Kin,Nout] = x^T @ dy ; db[Nout] = colsum(dy) (db may be NULL) */
-int dpig_linear_wgrad(const float* x, const float* dy, float* dw, float* db, int M, int Kin, int Nout,
+/* dw[Kin,Nout] = beta*dw + x^T @ dy   (the bias gradient is dpig_colsum(dy)) */
+int dpig_linear_wgrad(const float* x, const float* dy, float* dw, float beta, int M, int Kin, int Nout,
                       void* ws, size_t ws_bytes, void* stream);
 
 /* ---- tf.image.crop_and_resize (bilinear, extrapolation 0) ------------------------------------ */

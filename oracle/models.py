@@ -1,0 +1,345 @@
+"""CPU restatement (torch-CPU, differentiable) of the reference model graphs on the hot path.
+TEST INFRASTRUCTURE -- see oracle/__init__.py; parity unpinned by the reference.
+
+Layer for layer after the reference (each conv / add / concat is its own op, nothing fused):
+  encoder_fgbg      models.py:390-471   GeneratorCNN_ID_Encoder_BodyROIVis_FgBgFeaTwoBranch
+  encoder_roi       models.py:328-388   GeneratorCNN_ID_Encoder_BodyROIVis
+  generator_uae     models.py:518-576   GeneratorCNN_ID_UAEAfterResidual
+  dcgan_discriminator wgan_gp.py:407-440 (+ Batchnorm switch :34-40, LeakyReLU :23-24)
+  fc_discriminator  wgan_gp.py:399-405
+  gan_loss          trainer.py:217-252
+  stage1_*          trainer.py:568-625 build_model + :336-347 step order, Adam :136-140
+
+Variables are kept in a ParamStore under the TF-slim / tflib names so the
+same values can be loaded into the HIP implementation.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import ops as O
+
+
+class ParamStore(object):
+    """name -> torch tensor (requires_grad).  Creation order and init follow slim / tflib:
+    'xavier' = U(+-sqrt(6/(fan_in+fan_out))) (slim default), 'stdev' = U(+-s*sqrt(3)) (tflib
+    `uniform`, conv2d.py:55-60), 'he_lin' = tflib Linear 'he' (linear.py:71-75)."""
+
+    def __init__(self, seed=0, dtype=torch.float64):
+        self.rng = np.random.default_rng(seed)
+        self.dtype = dtype
+        self.p = {}
+        self.trainable = {}
+
+    def get(self, name, shape=None, kind="zeros", fan=None, stdev=None, trainable=True):
+        if name not in self.p:
+            if kind == "zeros":
+                v = np.zeros(shape)
+            elif kind == "ones":
+                v = np.ones(shape)
+            elif kind == "xavier":
+                lim = math.sqrt(6.0 / (fan[0] + fan[1]))
+                v = self.rng.uniform(-lim, lim, size=shape)
+            elif kind == "stdev":
+                v = self.rng.uniform(-stdev * math.sqrt(3), stdev * math.sqrt(3), size=shape)
+            else:
+                raise ValueError(kind)
+            v = v.astype(np.float32)            # initial values are fp32 like the reference's variables
+            t = torch.tensor(v, dtype=self.dtype, requires_grad=trainable)
+            self.p[name] = t
+            self.trainable[name] = trainable
+        return self.p[name]
+
+    def names_with(self, substr, trainable_only=True):
+        return [n for n in self.p if substr in n and (self.trainable[n] or not trainable_only)]
+
+    def state_numpy(self):
+        return {n: t.detach().to(torch.float32).numpy().copy() for n, t in self.p.items()}
+
+
+class _Scope(object):
+    """TF-slim variable naming: <path>/Conv[_k], <path>/fully_connected[_k] in creation order."""
+
+    def __init__(self, path):
+        self.path = path
+        self.count = {}
+
+    def uniq(self, default):
+        n = self.count.get(default, 0)
+        self.count[default] = n + 1
+        return "%s/%s" % (self.path, default if n == 0 else "%s_%d" % (default, n))
+
+
+def _conv(P, sc, x, cout, k, stride, act):
+    name = sc.uniq("Conv")
+    cin = x.shape[-1]
+    w = P.get(name + "/weights", (k, k, cin, cout), "xavier", fan=(k * k * cin, k * k * cout))
+    b = P.get(name + "/biases", (cout,), "zeros")
+    y = O.conv2d_same(x, w, b, stride)
+    return act(y) if act is not None else y
+
+
+def _fc(P, sc, x, cout, act):
+    name = sc.uniq("fully_connected")
+    cin = x.shape[-1]
+    w = P.get(name + "/weights", (cin, cout), "xavier", fan=(cin, cout))
+    b = P.get(name + "/biases", (cout,), "zeros")
+    y = O.linear(x, w, b)
+    return act(y) if act is not None else y
+
+
+def _tower(P, sc, x, z_out, repeat_num, hidden_num, act):
+    for idx in range(repeat_num):
+        channel_num = hidden_num * (idx + 1)
+        res = x
+        x = _conv(P, sc, x, channel_num, 3, 1, act)
+        x = _conv(P, sc, x, channel_num, 3, 1, act)
+        x = x + res
+        if idx < repeat_num - 1:
+            x = _conv(P, sc, x, hidden_num * (idx + 2), 3, 2, act)
+    x = x.reshape(x.shape[0], -1)            # NHWC flatten order (h, w, c)
+    return _fc(P, sc, x, z_out, None)
+
+
+def _crops(x, ROI_bboxs, bbox_num, roi_size):
+    B, H, W, _ = x.shape
+    rois = []
+    for i in range(bbox_num):
+        bbox = ROI_bboxs[:, i, :].to(x.dtype)
+        y1 = bbox[:, 0:1] / float(H)
+        x1 = bbox[:, 1:2] / float(W)
+        y2 = bbox[:, 2:3] / float(H)
+        x2 = bbox[:, 3:4] / float(W)
+        nb = torch.cat([y1, x1, y2, x2], dim=-1)
+        rois.append(O.crop_and_resize(x, nb, torch.arange(B), roi_size, roi_size))
+    return torch.cat(rois, dim=0)
+
+
+def encoder_fgbg(P, x, fg_mask, ROI_bboxs, ROI_vis, bbox_num=7, z_num=32, repeat_num=5, hidden_num=128,
+                 roi_size=48, scope="Encoder/G_encoder", taps=None):
+    """models.py:390-471."""
+    sc = _Scope(scope)
+    act = O.relu
+    B = x.shape[0]
+    x = _conv(P, sc, x, hidden_num, 3, 1, act)
+    res = x
+    x = _conv(P, sc, x, hidden_num, 3, 1, act)
+    x = _conv(P, sc, x, hidden_num, 3, 1, act)
+    x = x + res
+    if taps is not None:
+        taps["E.stem"] = x
+    m = fg_mask.to(x.dtype)
+    x_fg = x * m
+    x_bg = x * (1.0 - m)
+    body = _crops(x_fg, ROI_bboxs, bbox_num, roi_size)
+    if taps is not None:
+        taps["E.rois"] = body
+    body = _tower(P, sc, body, z_num, repeat_num, hidden_num, act)
+    fea_list = list(torch.split(body, B, dim=0))
+    for i in range(bbox_num):
+        fea_list[i] = fea_list[i] * ROI_vis[:, i:i + 1].to(x.dtype)
+    x_bg = _tower(P, sc, x_bg, z_num * 4, repeat_num, hidden_num, act)
+    fea_list.append(x_bg)
+    return torch.cat(fea_list, dim=-1)
+
+
+def encoder_roi(P, x, ROI_bboxs, ROI_vis, bbox_num=7, z_num=32, repeat_num=7, hidden_num=128, roi_size=64,
+                scope="Encoder/G_encoder"):
+    """models.py:328-388."""
+    sc = _Scope(scope)
+    act = O.relu
+    B = x.shape[0]
+    x = _conv(P, sc, x, hidden_num, 3, 1, act)
+    res = x
+    x = _conv(P, sc, x, hidden_num, 3, 1, act)
+    x = _conv(P, sc, x, hidden_num, 3, 1, act)
+    x = x + res
+    body = _crops(x, ROI_bboxs, bbox_num, roi_size)
+    body = _tower(P, sc, body, z_num, repeat_num, hidden_num, act)
+    fea_list = list(torch.split(body, B, dim=0))
+    for i in range(bbox_num):
+        fea_list[i] = fea_list[i] * ROI_vis[:, i:i + 1].to(x.dtype)
+    return torch.cat(fea_list, dim=-1)
+
+
+def generator_uae(P, x, pose, input_channel=3, z_num=64, repeat_num=5, hidden_num=128, scope="ID_AE/G",
+                  taps=None):
+    """models.py:518-576.  x = tiled embedding [B,H,W,E]."""
+    sc = _Scope(scope)
+    act = O.relu
+    if pose is not None:
+        x = torch.cat([x, pose], dim=3)
+    enc = []
+    x = _conv(P, sc, x, hidden_num, 3, 1, act)
+    if taps is not None:
+        taps["G.stem"] = x
+    for idx in range(repeat_num):
+        channel_num = hidden_num * (idx + 1)
+        res = x
+        x = _conv(P, sc, x, channel_num, 3, 1, act)
+        x = _conv(P, sc, x, channel_num, 3, 1, act)
+        x = x + res
+        enc.append(x)
+        if idx < repeat_num - 1:
+            x = _conv(P, sc, x, hidden_num * (idx + 2), 3, 2, act)
+    x_shape = list(x.shape)
+    x = x.reshape(x_shape[0], -1)
+    z = x = _fc(P, sc, x, z_num, None)
+    if taps is not None:
+        taps["G.z"] = z
+    x = _fc(P, sc, z, x_shape[1] * x_shape[2] * hidden_num, None)
+    x = x.reshape(-1, x_shape[1], x_shape[2], hidden_num)
+    for idx in range(repeat_num):
+        x = torch.cat([x, enc[repeat_num - 1 - idx]], dim=-1)
+        res = x
+        channel_num = x.shape[-1]
+        x = _conv(P, sc, x, channel_num, 3, 1, act)
+        x = _conv(P, sc, x, channel_num, 3, 1, act)
+        x = x + res
+        if taps is not None:
+            taps["G.dec%d" % idx] = x
+        if idx < repeat_num - 1:
+            x = O.upsample2x(x)
+            x = _conv(P, sc, x, hidden_num * (repeat_num - idx - 1), 1, 1, act)
+    out = _conv(P, sc, x, input_channel, 3, 1, None)
+    return out, z
+
+
+def dcgan_discriminator(P, img_nhwc, mode="dcgan", dim=64, name="", taps=None):
+    """wgan_gp.py:407-440 on NHWC data; the final flatten reproduces tf.reshape of the reference's
+    NCHW tensor (order c,h,w) including the hard-coded 8*4*8*dim width."""
+    def conv(nm, x, cin, cout):
+        w = P.get(nm + ".Filters", (5, 5, cin, cout), "stdev", stdev=0.02)
+        b = P.get(nm + ".Biases", (cout,), "zeros")
+        return O.conv2d_same(x, w, b, 2)
+
+    def norm(nm, x):
+        c = x.shape[-1]
+        offset = P.get(nm + ".offset", (c,), "zeros")
+        scale = P.get(nm + ".scale", (c,), "ones")
+        if mode == "wgan-gp":
+            return O.layernorm(x, scale, offset)
+        P.get(nm + ".moving_mean", (c,), "zeros", trainable=False)
+        P.get(nm + ".moving_variance", (c,), "ones", trainable=False)
+        return O.batchnorm_train(x, scale, offset)
+
+    pre = name + "Discriminator."
+    z1 = conv(pre + "1", img_nhwc, img_nhwc.shape[-1], dim)
+    o = O.leaky_relu(z1)
+    z2 = norm(pre + "BN2", conv(pre + "2", o, dim, 2 * dim))
+    o = O.leaky_relu(z2)
+    z3 = norm(pre + "BN3", conv(pre + "3", o, 2 * dim, 4 * dim))
+    o = O.leaky_relu(z3)
+    z4 = norm(pre + "BN4", conv(pre + "4", o, 4 * dim, 8 * dim))
+    o = O.leaky_relu(z4)
+    if taps is not None:
+        taps.update({"D.1pre": z1, "D.2pre": z2, "D.3pre": z3, "D.4pre": z4, "D.4": o})
+    o = o.permute(0, 3, 1, 2).reshape(-1, 8 * 4 * 8 * dim)
+    w = P.get(pre + "Output.W", (8 * 4 * 8 * dim, 1), "stdev", stdev=0.02)
+    b = P.get(pre + "Output.b", (1,), "zeros")
+    return O.linear(o, w, b).reshape(-1)
+
+
+def fc_discriminator(P, x, input_dim, fc_dim=512, n_layers=3, name=""):
+    """wgan_gp.py:399-405 with LeakyReLULayer :30-32 ('he' init: stdev sqrt(2/n_in))."""
+    def lin(nm, x, nin, nout, he=True):
+        sd = math.sqrt(2.0 / nin) if he else math.sqrt(2.0 / (nin + nout))
+        w = P.get(nm + ".W", (nin, nout), "stdev", stdev=sd)
+        b = P.get(nm + ".b", (nout,), "zeros")
+        return O.linear(x, w, b)
+    o = O.leaky_relu(lin(name + "Discriminator.Input.Linear", x, input_dim, fc_dim))
+    for i in range(n_layers):
+        o = O.leaky_relu(lin(name + "Discriminator.%d.Linear" % i, o, fc_dim, fc_dim))
+    return lin(name + "Discriminator.Out", o, fc_dim, 1, he=False).reshape(-1)
+
+
+def gan_loss(mode, disc_real, disc_fake):
+    """trainer.py:217-252 (dcgan / wgan / lsgan)."""
+    if mode == "dcgan":
+        gen = O.sigmoid_cross_entropy_with_logits(disc_fake, torch.ones_like(disc_fake)).mean()
+        dis = O.sigmoid_cross_entropy_with_logits(disc_fake, torch.zeros_like(disc_fake)).mean()
+        if disc_real is not None:
+            dis = dis + O.sigmoid_cross_entropy_with_logits(disc_real, torch.ones_like(disc_real)).mean()
+        dis = dis / 2.0
+    elif mode == "wgan":
+        gen = -disc_fake.mean()
+        dis = disc_fake.mean() - (disc_real.mean() if disc_real is not None else 0.0)
+    elif mode == "lsgan":
+        gen = ((disc_fake - 1) ** 2).mean()
+        dis = (((disc_real - 1) ** 2).mean() + (disc_fake ** 2).mean()) / 2.0
+    else:
+        raise ValueError(mode)
+    return gen, dis
+
+
+def stage1_forward(P, batch, hidden_num=128, z_num=64, repeat_num=5, taps=None):
+    """trainer.py:568-607: E -> tile -> G.  batch: dict of torch CPU tensors."""
+    x = batch["x"]
+    B, H, W, _ = x.shape
+    embs = encoder_fgbg(P, x, batch["mask_r6"], batch["part_bbox"], batch["part_vis"], 7, 32, repeat_num,
+                        hidden_num, taps=taps)
+    if taps is not None:
+        taps["embs"] = embs
+    embs_rep = embs.reshape(B, 1, 1, -1).expand(B, H, W, embs.shape[1])
+    G, z = generator_uae(P, embs_rep, batch["pose"], 3, z_num, repeat_num, hidden_num, taps=taps)
+    if taps is not None:
+        taps["G"] = G
+    return embs, G
+
+
+def stage1_g_loss(P, batch, **kw):
+    """g_loss = sce(D(G), 1) + 20 * mean|G - x|   (trainer.py:605-607, 623)."""
+    _, G = stage1_forward(P, batch, **kw)
+    d_fake = dcgan_discriminator(P, G, "dcgan")
+    g_only, _ = gan_loss("dcgan", None, d_fake)
+    l1 = (G - batch["x"]).abs().mean()
+    return g_only + 20.0 * l1, {"g_loss_only": g_only, "L1Loss": l1, "G": G, "D_z_neg": d_fake}
+
+
+def stage1_d_loss(P, batch, **kw):
+    """d_loss = (sce(D(G),0) + sce(D(x),1)) / 2 with D called separately on real and fake
+    (trainer.py:601-602: two independent BN statistic sets)."""
+    with torch.no_grad():
+        _, G = stage1_forward(P, batch, **kw)
+    d_real = dcgan_discriminator(P, batch["x"], "dcgan")
+    d_fake = dcgan_discriminator(P, G, "dcgan")
+    _, d = gan_loss("dcgan", d_real, d_fake)
+    return d, {"D_z_pos": d_real, "D_z_neg": d_fake}
+
+
+def g_var_names(P):
+    return [n for n in P.p if (n.startswith("Encoder/") or n.startswith("ID_AE/"))]
+
+
+def d_var_names(P):
+    return [n for n in P.p if "Discriminator." in n and P.trainable[n]]
+
+
+class OracleAdam(object):
+    """TF Adam over a name list of a ParamStore."""
+
+    def __init__(self, P, names, lr, beta1=0.5, beta2=0.999, eps=1e-8):
+        self.P, self.names, self.lr, self.b1, self.b2, self.eps, self.t = P, names, lr, beta1, beta2, eps, 0
+        self.m = {n: torch.zeros_like(P.p[n]) for n in names}
+        self.v = {n: torch.zeros_like(P.p[n]) for n in names}
+
+    def step(self, grads):
+        self.t += 1
+        with torch.no_grad():
+            for n in self.names:
+                g = grads.get(n)
+                if g is None:
+                    g = torch.zeros_like(self.P.p[n])
+                p, m, v = O.tf_adam_step(self.P.p[n], g, self.m[n], self.v[n], self.lr, self.b1, self.b2, self.eps,
+                                         self.t)
+                self.P.p[n].copy_(p)
+                self.m[n], self.v[n] = m, v
+
+
+def batch_to_torch(batch, dtype=torch.float64):
+    out = {}
+    for k, v in batch.items():
+        t = torch.as_tensor(v)
+        out[k] = t.to(dtype) if t.is_floating_point() else t
+    return out

@@ -1,0 +1,199 @@
+"""GPU parity of the non-conv kernels (through the C ABI) against the CPU oracle (fp64).
+Tolerance 2e-5 relative to max|ref| unless noted (fp32 kernels vs fp64 oracle)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+
+def _rand(shape, seed, lo=-1.0, hi=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(shape, generator=g, dtype=torch.float64) * (hi - lo) + lo
+
+
+def _close(got, ref, tol=TOL):
+    ref = ref.detach().double()
+    err = (got.detach().double().cpu() - ref).abs().max().item()
+    scale = max(ref.abs().max().item(), 1e-6)
+    assert err <= tol * scale, "max err %.3e vs scale %.3e" % (err, scale)
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 16, 128), (16, 8, 4, 512), (3, 5, 7, 20)])
+@pytest.mark.parametrize("act", [0, 2])
+def test_batchnorm_fwd_bwd(dev, shape, act):
+    import dpig_amd.hip_ops as H
+    from oracle import ops as O
+    C = shape[-1]
+    x = (_rand(shape, 1) * 3 + 0.7).requires_grad_(True)
+    scale = _rand((C,), 2, 0.5, 1.5).requires_grad_(True)
+    offset = _rand((C,), 3).requires_grad_(True)
+    y = O.batchnorm_train(x, scale, offset)
+    if act == 2:
+        y = O.leaky_relu(y, 0.2)
+    dy = _rand(shape, 4)
+    y.backward(dy)
+    xg = x.detach().float().to(dev)
+    yg, mean, rstd = H.bn_fwd(xg, scale.detach().float().to(dev), offset.detach().float().to(dev), 1e-5, act, 0.2)
+    _close(yg, y)
+    dx, ds, do = H.bn_bwd(dy.float().to(dev), xg, yg, scale.detach().float().to(dev), mean, rstd, act, 0.2)
+    _close(dx, x.grad, 5e-5)
+    _close(ds, scale.grad, 5e-5)
+    _close(do, offset.grad, 5e-5)
+
+
+@pytest.mark.parametrize("shape", [(2, 32, 16, 128), (4, 8, 4, 512), (3, 5, 7, 20)])
+def test_layernorm_fwd_bwd(dev, shape):
+    import dpig_amd.hip_ops as H
+    from oracle import ops as O
+    C = shape[-1]
+    x = (_rand(shape, 1) * 2 - 0.3).requires_grad_(True)
+    scale = _rand((C,), 2, 0.5, 1.5).requires_grad_(True)
+    offset = _rand((C,), 3).requires_grad_(True)
+    y = O.leaky_relu(O.layernorm(x, scale, offset), 0.2)
+    dy = _rand(shape, 4)
+    y.backward(dy)
+    xg = x.detach().float().to(dev)
+    yg, mean, rstd = H.ln_fwd(xg, scale.detach().float().to(dev), offset.detach().float().to(dev), 1e-5, 2, 0.2)
+    _close(yg, y)
+    dx, ds, do = H.ln_bwd(dy.float().to(dev), xg, yg, scale.detach().float().to(dev), mean, rstd, 2, 0.2)
+    _close(dx, x.grad, 5e-5)
+    _close(ds, scale.grad, 5e-5)
+    _close(do, offset.grad, 5e-5)
+
+
+@pytest.mark.parametrize("mkn", [(16, 20480, 128), (14, 5760, 32), (16, 64, 4096), (2, 16384, 1), (64, 224, 512),
+                                 (5, 37, 11)])
+def test_linear(dev, mkn):
+    import dpig_amd.hip_ops as H
+    M, K, N = mkn
+    x = _rand((M, K), 1).requires_grad_(True)
+    w = (_rand((K, N), 2) * 0.1).requires_grad_(True)
+    b = _rand((N,), 3)
+    y = torch.relu(x @ w + b)
+    dy = _rand((M, N), 4)
+    (x @ w + b).backward(dy)
+    yg = H.linear_fwd(x.detach().float().to(dev), w.detach().float().to(dev), b.float().to(dev), act=1)
+    _close(yg, y)
+    _close(H.linear_dgrad(dy.float().to(dev), w.detach().float().to(dev)), x.grad)
+    _close(H.linear_wgrad(x.detach().float().to(dev), dy.float().to(dev)), w.grad)
+
+
+def test_crop_and_resize(dev):
+    import dpig_amd.hip_ops as H
+    from oracle import ops as O
+    N, Hh, W, C = 3, 32, 16, 24
+    img = _rand((N, Hh, W, C), 1).requires_grad_(True)
+    # pixel boxes /H,/W (models.py:410-413), incl. the [0,0,1,1] sentinel and a box touching the border
+    px = torch.tensor([[0, 0, 1, 1], [3, 2, 20, 9], [10, 5, 31, 15], [0, 0, 31, 15], [7, 7, 8, 8], [5, 1, 30, 14]],
+                      dtype=torch.float64)
+    boxes = px / torch.tensor([Hh, W, Hh, W], dtype=torch.float64)
+    # one out-of-range box (extrapolation 0)
+    boxes = torch.cat([boxes, torch.tensor([[-0.2, 0.1, 1.3, 0.9]], dtype=torch.float64)])
+    box_ind = torch.tensor([0, 1, 2, 0, 1, 2, 1])
+    ref = O.crop_and_resize(img, boxes, box_ind, 12, 12)
+    dout = _rand(tuple(ref.shape), 2)
+    ref.backward(dout)
+    got = H.crop_resize_fwd(img.detach().float().to(dev), boxes.float().to(dev), box_ind.to(dev), 12, 12)
+    _close(got, ref)
+    dimg = H.crop_resize_bwd(dout.float().to(dev), boxes.float().to(dev), box_ind.to(dev), (N, Hh, W, C))
+    _close(dimg, img.grad, 5e-5)
+
+
+def test_upsample_act_colsum(dev):
+    import dpig_amd.hip_ops as H
+    from oracle import ops as O
+    x = _rand((2, 5, 3, 12), 1).requires_grad_(True)
+    y = O.upsample2x(x)
+    dy = _rand(tuple(y.shape), 2)
+    y.backward(dy)
+    _close(H.upsample2x_fwd(x.detach().float().to(dev)), y)
+    _close(H.upsample2x_bwd(dy.float().to(dev)), x.grad)
+    a = _rand((4, 6, 5, 36), 3)
+    yy = O.leaky_relu(a, 0.2)
+    _close(H.act_fwd(a.float().to(dev), 2, 0.2), yy)
+    g = _rand((4, 6, 5, 36), 4)
+    _close(H.act_bwd(g.float().to(dev), yy.float().to(dev), 2, 0.2), g * torch.where(yy > 0, 1.0, 0.2))
+    _close(H.colsum(a.float().to(dev)), a.reshape(-1, 36).sum(0))
+    big = _rand((16, 64, 32, 64), 5)
+    _close(H.colsum(big.float().to(dev)), big.reshape(-1, 64).sum(0), 1e-4)
+
+
+def test_losses(dev):
+    import dpig_amd.hip_ops as H
+    from oracle import ops as O
+    x = (_rand((37,), 1) * 6).requires_grad_(True)
+    for label in (0.0, 1.0):
+        x.grad = None
+        ref = O.sigmoid_cross_entropy_with_logits(x, torch.full_like(x, label)).mean()
+        ref.backward()
+        out, dl = H.sce_mean(x.detach().float().to(dev), label, want_grad=True, scale=1.0)
+        _close(out, ref.reshape(1))
+        _close(dl, x.grad)
+    a = _rand((2, 16, 8, 3), 2).requires_grad_(True)
+    b = _rand((2, 16, 8, 3), 3)
+    ref = (a - b).abs().mean()
+    ref.backward()
+    out, da = H.l1_mean(a.detach().float().to(dev), b.float().to(dev), want_grad=True, scale=1.0)
+    _close(out, ref.reshape(1))
+    _close(da, a.grad)
+
+
+def test_tf_adam(dev):
+    import dpig_amd.hip_ops as H
+    from oracle import naive
+    n = 1003
+    p0 = _rand((n,), 1).numpy()
+    grads = [_rand((n,), 10 + i).numpy() * 0.1 for i in range(3)]
+    ref = naive.tf_adam(p0, grads, lr=2e-3, beta1=0.5, beta2=0.999, eps=1e-8)
+    pad = (n + 3) // 4 * 4
+    p = torch.zeros(pad, device=dev); p[:n] = torch.tensor(p0, dtype=torch.float32)
+    m = torch.zeros(pad, device=dev); v = torch.zeros(pad, device=dev)
+    lr = torch.full((1,), 2e-3, device=dev)
+    for t, g in enumerate(grads, start=1):
+        gg = torch.zeros(pad, device=dev); gg[:n] = torch.tensor(g, dtype=torch.float32)
+        H.adam_step(p, gg, m, v, lr, 0.5, 0.999, 1e-8, t)
+    _close(p[:n], torch.tensor(ref), 1e-5)
+
+
+def test_tflib_ops_boundary(dev):
+    """The reference-signature ops: NCHW logical in/out, shared params by name, fused epilogues."""
+    import dpig_amd.tflib as lib
+    import dpig_amd.tflib.ops  # noqa
+    from oracle import ops as O
+    lib.delete_all_params()
+    lib.set_device(dev)
+    np.random.seed(5)
+    x = _rand((2, 16, 8, 6), 1)                       # NHWC
+    x_nchw = x.float().to(dev).permute(0, 3, 1, 2)    # logical NCHW view (trainer.py:601)
+    lib.ops.conv2d.set_weights_stdev(0.02)
+    y = lib.ops.conv2d.Conv2D('T.1', 6, 16, 5, x_nchw, stride=2)
+    lib.ops.conv2d.unset_weights_stdev()
+    assert tuple(y.shape) == (2, 16, 8, 4)
+    w = lib.param('T.1.Filters'); b = lib.param('T.1.Biases')
+    assert float(w.abs().max()) <= 0.02 * np.sqrt(3) + 1e-7
+    ref = O.conv2d_same(x, w.detach().double().cpu(), b.detach().double().cpu(), 2)
+    _close(y.permute(0, 2, 3, 1), ref)
+    y2 = lib.ops.conv2d.Conv2D('T.1', 6, 16, 5, x_nchw, stride=2)      # same name -> same weights
+    assert torch.equal(y, y2)
+    z = lib.ops.batchnorm.Batchnorm('T.BN', [0, 2, 3], y)
+    sc = lib.param('T.BN.scale'); of = lib.param('T.BN.offset')
+    _close(z.permute(0, 2, 3, 1), O.batchnorm_train(ref, sc.detach().double().cpu(), of.detach().double().cpu()), 1e-4)
+    assert 'T.BN.moving_mean' in lib._params and not lib.param('T.BN.moving_mean').requires_grad
+    ln = lib.ops.layernorm.Layernorm('T.LN', [1, 2, 3], y)
+    _close(ln.permute(0, 2, 3, 1), O.layernorm(ref, torch.ones(16, dtype=torch.float64), torch.zeros(16, dtype=torch.float64)), 1e-4)
+    flat = y.reshape(2, -1)                                           # logical (c,h,w) flatten
+    lin = lib.ops.linear.Linear('T.Out', 16 * 8 * 4, 3, flat)
+    wl = lib.param('T.Out.W').detach().double().cpu()
+    _close(lin, ref.permute(0, 3, 1, 2).reshape(2, -1) @ wl)
+    dc = lib.ops.deconv2d.Deconv2D('T.D', 16, 5, 5, y)
+    assert tuple(dc.shape) == (2, 5, 16, 8)
+    wd = lib.param('T.D.Filters').detach().double().cpu()
+    _close(dc.permute(0, 2, 3, 1), O.conv2d_transpose_same(ref, wd, None, 2), 1e-4)
+    with pytest.raises(Exception):
+        lib.ops.deconv2d.Deconv2D('T.D2', 16, 5, 5, y, mask_type=('a', 1))
+    with pytest.raises(Exception):
+        lib.ops.linear.Linear('T.bad', 4, 4, flat[:, :4], initialization='nope')
+    assert len(lib.params_with_name('T.')) == len([n for n in lib._params if 'T.' in n])
+    lib.delete_all_params()
