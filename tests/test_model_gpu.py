@@ -127,11 +127,14 @@ def test_g_and_d_gradients_and_adam_step(dev):
     dgrads = dict(zip(dnames, torch.autograd.grad(dl, [P.p[n] for n in dnames], allow_unused=True)))
     out = tr.d_optim(gb)
     assert abs(out["d_loss"].item() - dl.item()) < 1e-4 * abs(dl.item())
+    errs = {}
     for n in dnames:
         # the conv biases feeding a BatchNorm have an exactly-zero true gradient (BN removes the
         # mean): both sides hold round-off there, compare on an absolute floor instead
         got, ref = lib._params[n]._dpig_grad.double().cpu(), dgrads[n].double()
-        assert (got - ref).abs().max().item() < 3e-2 * max(ref.abs().max().item(), 1e-4), n
+        errs[n] = (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-4)
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    assert worst[0][1] < 3e-2, worst
 
 
 def test_train_step_order(dev):

@@ -1,0 +1,182 @@
+"""Pins the CPU oracle (oracle/ops.py, torch-CPU) -- the reference ships no golden vectors, so:
+  * every op is cross-checked against the independent numpy loop restatement oracle/naive.py;
+  * analytic known-answer tests nail the TF-1.4 semantics of SURVEY.md Appendix B.
+CPU only (runs in the not-gpu tier)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import naive
+from oracle import ops as O
+
+
+def rnd(shape, seed, scale=1.0):
+    return np.random.default_rng(seed).uniform(-1, 1, size=shape) * scale
+
+
+T = lambda a: torch.tensor(a, dtype=torch.float64)  # noqa: E731
+
+
+# ---- SAME padding (Appendix B-1) ------------------------------------------------------------------
+@pytest.mark.parametrize("inp,k,s,out,before,after", [
+    (128, 3, 1, 128, 1, 1), (128, 3, 2, 64, 0, 1), (64, 5, 2, 32, 1, 2), (7, 3, 2, 4, 1, 1),
+    (9, 5, 2, 5, 2, 2), (48, 3, 2, 24, 0, 1), (3, 3, 1, 3, 1, 1), (16, 1, 1, 16, 0, 0)])
+def test_same_pad_kat(inp, k, s, out, before, after):
+    assert O.same_pad(inp, k, s) == (out, before, after)
+    assert naive.same_pad(inp, k, s) == (out, before)
+
+
+# ---- conv2d ---------------------------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(2, 8, 6, 3, 5, 3, 1), (2, 8, 6, 4, 5, 3, 2), (1, 9, 7, 3, 4, 5, 2),
+                                   (2, 5, 5, 2, 3, 1, 1), (1, 7, 9, 3, 2, 3, 2)])
+def test_conv_matches_naive(shape):
+    N, H, W, C, K, k, s = shape
+    x, w, b = rnd((N, H, W, C), 1), rnd((k, k, C, K), 2), rnd((K,), 3)
+    got = O.conv2d_same(T(x), T(w), T(b), s).numpy()
+    np.testing.assert_allclose(got, naive.conv2d_same(x, w, b, s), rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("shape", [(2, 8, 6, 3, 5, 3, 1), (2, 8, 6, 4, 5, 3, 2), (1, 9, 7, 3, 4, 5, 2)])
+def test_conv_grads_match_naive(shape):
+    N, H, W, C, K, k, s = shape
+    x, w = T(rnd((N, H, W, C), 1)).requires_grad_(True), T(rnd((k, k, C, K), 2)).requires_grad_(True)
+    y = O.conv2d_same(x, w, None, s)
+    dy = rnd(tuple(y.shape), 3)
+    y.backward(T(dy))
+    np.testing.assert_allclose(x.grad.numpy(), naive.conv2d_same_dgrad(dy, w.detach().numpy(), (N, H, W, C), s),
+                               rtol=1e-11, atol=1e-12)
+    np.testing.assert_allclose(w.grad.numpy(), naive.conv2d_same_wgrad(x.detach().numpy(), dy, (k, k, C, K), s),
+                               rtol=1e-11, atol=1e-12)
+
+
+def test_conv_delta_image_is_flipped_kernel():
+    """Cross-correlation (Appendix B-2): a unit impulse at p paints w[ky,kx] at p-(ky-1, kx-1)."""
+    w = rnd((3, 3, 1, 1), 4)
+    x = np.zeros((1, 7, 7, 1)); x[0, 3, 3, 0] = 1.0
+    y = O.conv2d_same(T(x), T(w), None, 1).numpy()[0, :, :, 0]
+    np.testing.assert_allclose(y[2:5, 2:5], w[::-1, ::-1, 0, 0], atol=1e-15)
+
+
+def test_conv_constant_image_border_classes():
+    """Constant image through a SAME 3x3 conv: 9 border classes = sums over the valid taps
+    (the structure behind the G.stem collapse); stride 2 pads only bottom/right."""
+    w = rnd((3, 3, 1, 1), 5)[:, :, 0, 0]
+    y = O.conv2d_same(T(np.ones((1, 6, 6, 1))), T(w[:, :, None, None]), None, 1).numpy()[0, :, :, 0]
+    assert abs(y[2, 3] - w.sum()) < 1e-14
+    assert abs(y[0, 0] - w[1:, 1:].sum()) < 1e-14
+    assert abs(y[0, 3] - w[1:, :].sum()) < 1e-14
+    assert abs(y[5, 5] - w[:2, :2].sum()) < 1e-14
+    y2 = O.conv2d_same(T(np.ones((1, 6, 6, 1))), T(w[:, :, None, None]), None, 2).numpy()[0, :, :, 0]
+    assert y2.shape == (3, 3)
+    assert abs(y2[0, 0] - w.sum()) < 1e-14              # no top/left pad for even input (pad = (0,1))
+    assert abs(y2[2, 2] - w[:2, :2].sum()) < 1e-14
+
+
+def test_deconv_is_adjoint_of_strided_conv():
+    """tflib Deconv2D == conv2d_transpose == gradient of the stride-2 SAME conv: <F(u), v> = <u, F^T(v)>."""
+    wt = T(rnd((5, 5, 4, 3), 6))       # (k, k, Cout, Cin) as deconv2d.py:61-67
+    v = T(rnd((2, 4, 3, 3), 7))        # deconv input  [N,H,W,Cin]
+    u = T(rnd((2, 8, 6, 4), 8))        # deconv output-shaped
+    Fu = O.conv2d_same(u, wt, None, 2)
+    Ftv = O.conv2d_transpose_same(v, wt, None, 2)
+    assert tuple(Ftv.shape) == (2, 8, 6, 4)
+    assert abs((Fu * v).sum().item() - (u * Ftv).sum().item()) < 1e-10
+
+
+# ---- norms ----------------------------------------------------------------------------------------
+def test_batchnorm_matches_naive_and_kat():
+    x, sc, of = rnd((3, 4, 5, 6), 1, 2.0) + 0.5, rnd((6,), 2) + 1.5, rnd((6,), 3)
+    got = O.batchnorm_train(T(x), T(sc), T(of)).numpy()
+    np.testing.assert_allclose(got, naive.batchnorm_train(x, sc, of), rtol=1e-12, atol=1e-12)
+    # KAT: two values {0, 2} per channel -> mean 1, biased var 1 -> (x-1)/sqrt(1+1e-5)
+    xk = np.zeros((2, 1, 1, 1)); xk[1] = 2.0
+    yk = O.batchnorm_train(T(xk), T(np.ones(1)), T(np.zeros(1))).numpy().reshape(-1)
+    np.testing.assert_allclose(yk, np.array([-1.0, 1.0]) / math.sqrt(1 + 1e-5), rtol=1e-14)
+
+
+def test_layernorm_matches_naive():
+    x, sc, of = rnd((3, 4, 5, 6), 1, 2.0) - 0.2, rnd((6,), 2) + 1.5, rnd((6,), 3)
+    np.testing.assert_allclose(O.layernorm(T(x), T(sc), T(of)).numpy(), naive.layernorm(x, sc, of), rtol=1e-12,
+                               atol=1e-12)
+
+
+# ---- resize / crop --------------------------------------------------------------------------------
+def test_upsample_matches_naive():
+    x = rnd((2, 3, 4, 5), 1)
+    up = O.upsample2x(T(x)).numpy()
+    np.testing.assert_array_equal(up, naive.upsample2x(x))
+    assert up[0, 5, 7, 2] == x[0, 2, 3, 2]
+
+
+def test_crop_and_resize_matches_naive_incl_grad():
+    H, W = 16, 8
+    img = T(rnd((2, H, W, 3), 1)).requires_grad_(True)
+    px = np.array([[0, 0, 1, 1], [2, 1, 12, 6], [0, 0, 15, 7], [5, 5, 6, 6]], dtype=np.float64)
+    boxes = np.concatenate([px / np.array([H, W, H, W]), [[-0.3, 0.2, 1.2, 0.7]]])
+    ind = np.array([0, 1, 1, 0, 1])
+    out = O.crop_and_resize(img, T(boxes), torch.tensor(ind), 6, 5)
+    np.testing.assert_allclose(out.detach().numpy(), naive.crop_and_resize(img.detach().numpy(), boxes, ind, 6, 5),
+                               rtol=1e-12, atol=1e-13)
+    dout = rnd(tuple(out.shape), 2)
+    out.backward(T(dout))
+    np.testing.assert_allclose(img.grad.numpy(), naive.crop_and_resize_grad_image(dout, boxes, ind, (2, H, W, 3)),
+                               rtol=1e-11, atol=1e-13)
+    # KAT: the full-image box with crop == image size is the identity (y1=x1=0, y2=x2=1)
+    ident = O.crop_and_resize(img.detach(), T([[0, 0, 1, 1]]), torch.tensor([1]), H, W)
+    np.testing.assert_allclose(ident[0].numpy(), img.detach()[1].numpy(), atol=1e-13)
+    # the reference normalises by /H, /W (models.py:410-413): box [0,0,H,W]/[H,W] hits y2 = 1 exactly
+    # and everything outside [0, H-1] is extrapolated with 0
+    far = O.crop_and_resize(img.detach(), T([[1.5, 1.5, 2.0, 2.0]]), torch.tensor([0]), 3, 3)
+    assert float(far.abs().max()) == 0.0
+
+
+# ---- losses / optimizer ---------------------------------------------------------------------------
+def test_sigmoid_ce_kat():
+    x = T([0.0, 50.0, -50.0, 3.0])
+    np.testing.assert_allclose(O.sigmoid_cross_entropy_with_logits(x, torch.ones(4, dtype=torch.float64)).numpy(),
+                               [math.log(2), 0.0, 50.0, math.log1p(math.exp(-3.0))], atol=1e-12)
+    np.testing.assert_allclose(O.sigmoid_cross_entropy_with_logits(x, torch.zeros(4, dtype=torch.float64)).numpy(),
+                               naive.sigmoid_cross_entropy_with_logits(x.numpy(), 0.0), atol=1e-12)
+
+
+def test_tf_adam_closed_form():
+    """First TF-Adam step: m=(1-b1)g, v=(1-b2)g^2, lr_t=lr*sqrt(1-b2)/(1-b1) -> p - lr*g/(|g|+eps')
+    with eps' = eps/sqrt(1-b2): a sign step for |g| >> eps'."""
+    p, g = T([1.0, -2.0, 0.5]), T([0.3, -4.0, 1e-3])
+    lr, b1, b2, eps = 2e-5, 0.5, 0.999, 1e-8
+    p1, m1, v1 = O.tf_adam_step(p, g, torch.zeros_like(p), torch.zeros_like(p), lr, b1, b2, eps, 1)
+    expect = p - lr * g / (g.abs() + eps / math.sqrt(1 - b2))
+    np.testing.assert_allclose(p1.numpy(), expect.numpy(), rtol=1e-12)
+    # three steps against the independent numpy restatement
+    grads = [rnd((5,), 10 + i) for i in range(3)]
+    pp, mm, vv = T(np.ones(5)), torch.zeros(5, dtype=torch.float64), torch.zeros(5, dtype=torch.float64)
+    for t, gg in enumerate(grads, 1):
+        pp, mm, vv = O.tf_adam_step(pp, T(gg), mm, vv, 1e-3, 0.5, 0.999, 1e-8, t)
+    np.testing.assert_allclose(pp.numpy(), naive.tf_adam(np.ones(5), grads, 1e-3, 0.5, 0.999, 1e-8), rtol=1e-12)
+
+
+# ---- model-level structure (tiny widths, CPU) -----------------------------------------------------
+def test_oracle_model_shapes_names_and_losses():
+    from dpig_amd import synthetic
+    from oracle import models as OM
+    ob = OM.batch_to_torch(synthetic.make_batch(2, seed=1))
+    P = OM.ParamStore(seed=2)
+    gl, aux = OM.stage1_g_loss(P, ob, hidden_num=8, z_num=4)
+    dl, _ = OM.stage1_d_loss(P, ob, hidden_num=8, z_num=4)
+    assert tuple(aux["G"].shape) == (2, 128, 64, 3)
+    # SURVEY Appendix F creation order: stem Conv, Conv_1,_2; ROI tower Conv_3.._16 + fully_connected;
+    # Bg tower Conv_17.._30 + fully_connected_1; G: Conv.._29, fully_connected(_1)
+    names = list(P.p.keys())
+    assert names[0] == "Encoder/G_encoder/Conv/weights"
+    assert "Encoder/G_encoder/Conv_30/weights" in P.p and "Encoder/G_encoder/Conv_31/weights" not in P.p
+    assert "Encoder/G_encoder/fully_connected_1/weights" in P.p
+    assert "ID_AE/G/Conv_29/weights" in P.p and "ID_AE/G/Conv_30/weights" not in P.p
+    assert tuple(P.p["Encoder/G_encoder/fully_connected/weights"].shape) == (3 * 3 * 8 * 5, 32)
+    assert tuple(P.p["ID_AE/G/Conv/weights"].shape) == (3, 3, 352 + 18, 8)
+    assert tuple(P.p["Discriminator.Output.W"].shape) == (8 * 4 * 8 * 64, 1)
+    assert "Discriminator.BN2.moving_mean" in P.p and not P.trainable["Discriminator.BN2.moving_mean"]
+    assert torch.isfinite(gl) and torch.isfinite(dl)
+    # g_loss = sce(D(G),1) + 20*L1 (trainer.py:623)
+    assert abs(gl.item() - (aux["g_loss_only"].item() + 20 * aux["L1Loss"].item())) < 1e-12
