@@ -14,6 +14,16 @@ from . import slim
 from .slim import fully_connected, variable_scope
 
 
+# Optional activation taps for parity tests: set to a dict to have the builders record the tensors
+# named like the oracle's taps (E.stem, E.rois, G.stem, G.z, G.dec<i>).  None = off.
+TAPS = None
+
+
+def _tap(name, t):
+    if TAPS is not None:
+        TAPS[name] = t.detach()
+
+
 def relu(x):
     return slim.relu(x)
 
@@ -98,6 +108,7 @@ def GeneratorCNN_ID_Encoder_BodyROIVis_FgBgFeaTwoBranch(x, fg_mask, ROI_bboxs, R
         x = slim.conv2d(x, hidden_num, 3, 1, activation_fn=activation_fn, data_format=data_format)
         x = slim.res_block(x, hidden_num, 3, activation_fn=activation_fn, data_format=data_format)
 
+        _tap("E.stem", x)
         m = fg_mask.to(torch.float32)
         x_fg = x * m
         x_bg = x * (1.0 - m)
@@ -105,6 +116,7 @@ def GeneratorCNN_ID_Encoder_BodyROIVis_FgBgFeaTwoBranch(x, fg_mask, ROI_bboxs, R
         boxes, box_ind = _normalised_boxes(ROI_bboxs, bbox_num, img_H, img_W)
         body_regions = A.crop_and_resize(x_fg, boxes, box_ind, roi_size, roi_size)
         conv_fea_list = [body_regions, x_bg]
+        _tap("E.rois", body_regions)
 
         # Share weights for different body regions
         body_regions = _roi_tower(body_regions, z_num, repeat_num, hidden_num, data_format, activation_fn)
@@ -205,6 +217,7 @@ def GeneratorCNN_ID_UAEAfterResidual(x, pose, input_channel, z_num, repeat_num, 
         # Encoder
         encoder_layer_list = []
         x = slim.conv2d(x, hidden_num, 3, 1, activation_fn=activation_fn, data_format=data_format)
+        _tap("G.stem", x)
         for idx in range(repeat_num):
             channel_num = hidden_num * (idx + 1)
             x = slim.res_block(x, channel_num, 3, activation_fn=activation_fn, data_format=data_format)
@@ -216,6 +229,7 @@ def GeneratorCNN_ID_UAEAfterResidual(x, pose, input_channel, z_num, repeat_num, 
         x_shape = list(x.shape)
         x = x.reshape(x_shape[0], int(np.prod(x_shape[1:])))
         z = x = fully_connected(x, z_num, activation_fn=None)
+        _tap("G.z", z)
         if noise_dim > 0:
             noise = torch.rand(z.shape[0], noise_dim, device=z.device) * 2.0 - 1.0
             z = torch.cat([z, noise], dim=1)
@@ -228,6 +242,7 @@ def GeneratorCNN_ID_UAEAfterResidual(x, pose, input_channel, z_num, repeat_num, 
             x = torch.cat([x, encoder_layer_list[repeat_num - 1 - idx]], dim=-1)
             channel_num = x.shape[-1]
             x = slim.res_block(x, channel_num, 3, activation_fn=activation_fn, data_format=data_format)
+            _tap("G.dec%d" % idx, x)
             if idx < repeat_num - 1:
                 # x = upscale(x, 2, data_format); x = slim.conv2d(x, ..., 1, 1, ...)   (models.py:569-570)
                 x = slim.conv2d(x, hidden_num * (repeat_num - idx - 1), 1, 1, activation_fn=activation_fn,

@@ -132,7 +132,8 @@ def test_g_and_d_gradients_and_adam_step(dev):
         # the conv biases feeding a BatchNorm have an exactly-zero true gradient (BN removes the
         # mean): both sides hold round-off there, compare on an absolute floor instead
         got, ref = lib._params[n]._dpig_grad.double().cpu(), dgrads[n].double()
-        errs[n] = (got - ref).abs().max().item() / max(ref.abs().max().item(), 1e-4)
+        floor = 1e-3 if n in ("Discriminator.2.Biases", "Discriminator.3.Biases", "Discriminator.4.Biases") else 1e-6
+        errs[n] = (got - ref).abs().max().item() / max(ref.abs().max().item(), floor)
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
     assert worst[0][1] < 3e-2, worst
 
