@@ -52,6 +52,8 @@ struct GGParams {
     // tap t -> (a, b) = (t / tap_nb, t % tap_nb); source offset (oy0 + a*oys, ox0 + b*oxs);
     // filter slab w0 + a*wa + b*wb
     int tap_nb, oy0, oys, ox0, oxs, w0, wa, wb;
+    unsigned a_bytes, b_bytes;   // byte extents of A and B for the buffer descriptors
+    int vec_epi;          // 1: every epilogue operand is 16-byte addressable (float4 path)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -89,6 +91,36 @@ __device__ __attribute__((noinline)) void epi_store(float* __restrict__ D, const
     }
 }
 
+// ---- buffer-descriptor loads: 32-bit byte offsets, hardware bounds check -----------------------
+// Every gathered element is fetched with buffer_load through an SRD whose num_records is the exact
+// byte extent of the tensor.  A lane that must read a structural zero (padding halo, row >= M,
+// channel >= C) is simply given the offset OOB (> num_records): the hardware returns 0 -- no
+// branches, no 64-bit address math, no select after the load.
+typedef int v4i __attribute__((ext_vector_type(4)));
+constexpr unsigned OOB = 0x7fffffffu;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const float* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p), 0, (int)bytes, 0x00020000);
+}
+template <bool VEC>
+__device__ __forceinline__ float4 gload4(__amdgpu_buffer_rsrc_t r, unsigned off, bool ok, int first, int limit) {
+    // VEC: one 16-byte load (caller folded `first < limit` into ok); else 4 dword loads, element e valid
+    // iff first + e < limit
+    float4 v;
+    if (VEC) {
+        // NB: bit_cast the WHOLE vector; element-wise bit_casts of the builtin's result make hipcc
+        // (ROCm 7.2) emit a single dword load and splat it
+        const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)(ok ? off : OOB), 0, 0));
+        v.x = t.x; v.y = t.y; v.z = t.z; v.w = t.w;
+    } else {
+        v.x = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)((ok & (first + 0 < limit)) ? off + 0 : OOB), 0, 0));
+        v.y = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)((ok & (first + 1 < limit)) ? off + 4 : OOB), 0, 0));
+        v.z = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)((ok & (first + 2 < limit)) ? off + 8 : OOB), 0, 0));
+        v.w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)((ok & (first + 3 < limit)) ? off + 12 : OOB), 0, 0));
+    }
+    return v;
+}
+
 template <bool B_ROWK, bool VEC>
 __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GGParams p) {
     __shared__ __attribute__((aligned(16))) float smem[2][2 * TILE_FLOATS];
@@ -106,84 +138,93 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GGParams p) {
     const int kt_begin = split * p.tiles_per_split;
     const int kt_end = min(p.ktiles, kt_begin + p.tiles_per_split);
 
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes);
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.B, p.b_bytes);
+
     // ---- per-thread A rows (fixed for the whole k loop) --------------------------------------
     const int a_kq = tid & 7;
-    int a_base[4], a_iy0[4], a_ix0[4];
-    bool a_ok[4];
+    unsigned a_rowoff[4];
+    int a_iy0[4], a_ix0[4];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int m = m0 + (tid >> 3) + 32 * i;
-        a_ok[i] = m < p.M;
-        const int mm = a_ok[i] ? m : 0;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
         const int n = mm / p.HrWr;
         const int rem = mm - n * p.HrWr;
         const int r = rem / p.Wr;
         const int c = rem - r * p.Wr;
-        a_base[i] = n * p.Hs;
-        a_iy0[i] = r * p.sr;
+        a_iy0[i] = ok ? r * p.sr : -(1 << 24);      // a row beyond M fails every bounds test below
         a_ix0[i] = c * p.sr;
+        a_rowoff[i] = (unsigned)((((n * p.Hs + r * p.sr) * p.Ws + c * p.sr) * p.lda + a_kq * 4) * 4);
+    }
+    // ---- per-thread B offsets ------------------------------------------------------------------
+    unsigned b_off[4];
+    bool b_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (B_ROWK) {   // B[(wtap*Ncols + n)*Cs + k]: rows n, k contiguous (dgrad)
+            const int n = n0 + (tid >> 3) + 32 * i;
+            b_ok[i] = n < p.Ncols;
+            b_off[i] = (unsigned)((n * p.Cs + a_kq * 4) * 4);
+        } else {        // B[(wtap*Cs + k)*Ncols + n]: rows k, n contiguous (fwd)
+            const int nq = n0 + (tid & 31) * 4;
+            b_ok[i] = VEC ? (nq < p.Ncols) : true;
+            b_off[i] = (unsigned)((((tid >> 5) + 8 * i) * p.Ncols + nq) * 4);
+        }
     }
 
     float4 ra[4], rb[4];
 
-    auto load_tiles = [&](int kt) {
-        const int tap = kt / p.cchunks;
-        const int c0 = (kt - tap * p.cchunks) * BK;
-        const int ta = tap / p.tap_nb, tb = tap - ta * p.tap_nb;
-        const int oy = p.oy0 + ta * p.oys, ox = p.ox0 + tb * p.oxs, wt = p.w0 + ta * p.wa + tb * p.wb;
-        // A: 128 rows x 32 k, thread -> (row = tid/8 + 32 i, 4 consecutive k)
-        const int ck = c0 + a_kq * 4;
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int iy = a_iy0[i] + oy, ix = a_ix0[i] + ox;
-            const bool ok = a_ok[i] && (unsigned)iy < (unsigned)p.Hs && (unsigned)ix < (unsigned)p.Ws;
-            const long off = ((long)(a_base[i] + iy) * p.Ws + ix) * p.lda + ck;
-            if (VEC) {
-                ra[i] = (ok && ck < p.Cs) ? *reinterpret_cast<const float4*>(p.A + off)
-                                          : make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {
-                ra[i].x = (ok && ck + 0 < p.Cs) ? p.A[off + 0] : 0.f;
-                ra[i].y = (ok && ck + 1 < p.Cs) ? p.A[off + 1] : 0.f;
-                ra[i].z = (ok && ck + 2 < p.Cs) ? p.A[off + 2] : 0.f;
-                ra[i].w = (ok && ck + 3 < p.Cs) ? p.A[off + 3] : 0.f;
-            }
+    // k-tile cursor (tap row/col, channel chunk) advanced incrementally: no divisions in the loop
+    int cur_c0, cur_ta, cur_tb;
+    {
+        const int tap = kt_begin / p.cchunks;
+        cur_c0 = (kt_begin - tap * p.cchunks) * BK;
+        cur_ta = tap / p.tap_nb;
+        cur_tb = tap - cur_ta * p.tap_nb;
+    }
+
+    // The loader of one k-tile is cut into 4 parts (one A row + one B row each) so that the kernel can
+    // issue them between the MFMA groups of the previous tile instead of as one ~150-instruction
+    // block during which this wave feeds nothing to the matrix pipe.
+    int t_oy, t_ox, t_ck, t_c0;
+    unsigned t_sA, t_sB;
+    bool t_kok;
+    auto load_begin = [&]() {            // scalar work: advance the cursor, derive the tap's offsets
+        const int c0 = cur_c0, ta = cur_ta, tb = cur_tb;
+        cur_c0 += BK;
+        if (cur_c0 >= p.Cs) {
+            cur_c0 = 0;
+            if (++cur_tb == p.tap_nb) { cur_tb = 0; ++cur_ta; }
         }
+        const int wt = p.w0 + ta * p.wa + tb * p.wb;
+        t_oy = p.oy0 + ta * p.oys;
+        t_ox = p.ox0 + tb * p.oxs;
+        t_c0 = c0;
+        t_ck = c0 + a_kq * 4;
+        t_sA = (unsigned)(((t_oy * p.Ws + t_ox) * p.lda + c0) * 4);
+        t_kok = VEC ? (t_ck < p.Cs) : true;
+        t_sB = B_ROWK ? (unsigned)((wt * p.Ncols * p.Cs + c0) * 4) : (unsigned)(((wt * p.Cs + c0) * p.Ncols) * 4);
+    };
+    // `live` = false turns the part into loads of structural zeros (offset OOB): the steady-state loop
+    // stays branch-free, the last iteration just fetches nothing.
+    auto load_part = [&](int i, bool live) {
+        // bitwise & on purpose: short-circuit && compiles to exec-mask branches around each load
+        const bool ok = live & t_kok & ((unsigned)(a_iy0[i] + t_oy) < (unsigned)p.Hs) &
+                        ((unsigned)(a_ix0[i] + t_ox) < (unsigned)p.Ws);
+        ra[i] = gload4<VEC>(rsA, a_rowoff[i] + t_sA, ok, t_ck, p.Cs);
         if (B_ROWK) {
-            // B stored [(wtap*Ncols + n)*Cs + k]: rows n, k contiguous (dgrad)
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int n = n0 + (tid >> 3) + 32 * i;
-                const bool ok = n < p.Ncols;
-                const long off = ((long)wt * p.Ncols + n) * p.Cs + ck;
-                if (VEC) {
-                    rb[i] = (ok && ck < p.Cs) ? *reinterpret_cast<const float4*>(p.B + off)
-                                              : make_float4(0.f, 0.f, 0.f, 0.f);
-                } else {
-                    rb[i].x = (ok && ck + 0 < p.Cs) ? p.B[off + 0] : 0.f;
-                    rb[i].y = (ok && ck + 1 < p.Cs) ? p.B[off + 1] : 0.f;
-                    rb[i].z = (ok && ck + 2 < p.Cs) ? p.B[off + 2] : 0.f;
-                    rb[i].w = (ok && ck + 3 < p.Cs) ? p.B[off + 3] : 0.f;
-                }
-            }
+            rb[i] = gload4<VEC>(rsB, b_off[i] + t_sB, live & b_ok[i] & t_kok, t_ck, p.Cs);
         } else {
-            // B stored [(wtap*Cs + k)*Ncols + n]: rows k, n contiguous (fwd)
-            const int nq = n0 + (tid & 31) * 4;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int k = c0 + (tid >> 5) + 8 * i;
-                const bool ok = k < p.Cs;
-                const long off = ((long)wt * p.Cs + k) * p.Ncols + nq;
-                if (VEC) {
-                    rb[i] = (ok && nq < p.Ncols) ? *reinterpret_cast<const float4*>(p.B + off)
-                                                 : make_float4(0.f, 0.f, 0.f, 0.f);
-                } else {
-                    rb[i].x = (ok && nq + 0 < p.Ncols) ? p.B[off + 0] : 0.f;
-                    rb[i].y = (ok && nq + 1 < p.Ncols) ? p.B[off + 1] : 0.f;
-                    rb[i].z = (ok && nq + 2 < p.Ncols) ? p.B[off + 2] : 0.f;
-                    rb[i].w = (ok && nq + 3 < p.Ncols) ? p.B[off + 3] : 0.f;
-                }
-            }
+            rb[i] = gload4<VEC>(rsB, b_off[i] + t_sB, live & b_ok[i] & (t_c0 + (tid >> 5) + 8 * i < p.Cs),
+                                n0 + (tid & 31) * 4, p.Ncols);
         }
+    };
+    auto load_tiles = [&]() {
+        load_begin();
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_part(i, true);
     };
 
     auto store_tiles = [&](int buf) {
@@ -203,6 +244,21 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GGParams p) {
         }
     };
 
+    // LDS -> register fragments of k-step kk (8 k values: lane half h takes k = kk*8 + 4h + j)
+    auto load_frag = [&](const float* As, const float* Bs, int kk, float4 (&fa)[2], float4 (&fb)[2]) {
+        fa[0] = *reinterpret_cast<const float4*>(&As[(wm * 64 + l31) * LDR + kk * 8 + half * 4]);
+        fa[1] = *reinterpret_cast<const float4*>(&As[(wm * 64 + 32 + l31) * LDR + kk * 8 + half * 4]);
+        if (B_ROWK) {
+            fb[0] = *reinterpret_cast<const float4*>(&Bs[(wn * 64 + l31) * LDR + kk * 8 + half * 4]);
+            fb[1] = *reinterpret_cast<const float4*>(&Bs[(wn * 64 + 32 + l31) * LDR + kk * 8 + half * 4]);
+        } else {
+            const float* bp = &Bs[(kk * 8 + half * 4) * LDKN + wn * 64 + l31];
+            fb[0].x = bp[0 * LDKN]; fb[0].y = bp[1 * LDKN]; fb[0].z = bp[2 * LDKN]; fb[0].w = bp[3 * LDKN];
+            fb[1].x = bp[0 * LDKN + 32]; fb[1].y = bp[1 * LDKN + 32];
+            fb[1].z = bp[2 * LDKN + 32]; fb[1].w = bp[3 * LDKN + 32];
+        }
+    };
+
     f32x16 acc[2][2];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -212,31 +268,24 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GGParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     if (kt_begin < kt_end) {
-        load_tiles(kt_begin);
+        load_tiles();
         store_tiles(0);
         __syncthreads();
         int buf = 0;
+        float4 fa[2][2], fb[2][2];          // [k-step parity][32-row / 32-col block]
+        load_frag(smem[0], smem[0] + TILE_FLOATS, 0, fa[0], fb[0]);
         for (int kt = kt_begin; kt < kt_end; ++kt) {
             const bool more = (kt + 1) < kt_end;
-            if (more) load_tiles(kt + 1);
+            load_begin();
             const float* As = smem[buf];
             const float* Bs = smem[buf] + TILE_FLOATS;
 #pragma unroll
             for (int kk = 0; kk < BK / 8; ++kk) {
-                const float4 a0 =
-                    *reinterpret_cast<const float4*>(&As[(wm * 64 + l31) * LDR + kk * 8 + half * 4]);
-                const float4 a1 =
-                    *reinterpret_cast<const float4*>(&As[(wm * 64 + 32 + l31) * LDR + kk * 8 + half * 4]);
-                float4 b0, b1;
-                if (B_ROWK) {
-                    b0 = *reinterpret_cast<const float4*>(&Bs[(wn * 64 + l31) * LDR + kk * 8 + half * 4]);
-                    b1 = *reinterpret_cast<const float4*>(&Bs[(wn * 64 + 32 + l31) * LDR + kk * 8 + half * 4]);
-                } else {
-                    const float* bp = &Bs[(kk * 8 + half * 4) * LDKN + wn * 64 + l31];
-                    b0.x = bp[0 * LDKN]; b0.y = bp[1 * LDKN]; b0.z = bp[2 * LDKN]; b0.w = bp[3 * LDKN];
-                    b1.x = bp[0 * LDKN + 32]; b1.y = bp[1 * LDKN + 32];
-                    b1.z = bp[2 * LDKN + 32]; b1.w = bp[3 * LDKN + 32];
-                }
+                if (kk + 1 < BK / 8) load_frag(As, Bs, kk + 1, fa[(kk + 1) & 1], fb[(kk + 1) & 1]);
+                load_part(kk, more);               // HBM/L2 -> registers for tile t+1, between MFMA groups
+                __builtin_amdgcn_sched_barrier(0);  // keep the loads HERE: unpinned, hipcc sinks them to the
+                                                    // ds_writes below and exposes the whole memory latency
+                const float4 a0 = fa[kk & 1][0], a1 = fa[kk & 1][1], b0 = fb[kk & 1][0], b1 = fb[kk & 1][1];
                 const float av0[4] = {a0.x, a0.y, a0.z, a0.w};
                 const float av1[4] = {a1.x, a1.y, a1.z, a1.w};
                 const float bv0[4] = {b0.x, b0.y, b0.z, b0.w};
@@ -249,30 +298,91 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GGParams p) {
                     acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[j], bv1[j], acc[1][1], 0, 0, 0);
                 }
             }
-            if (more) store_tiles(buf ^ 1);
+            store_tiles(buf ^ 1);                  // (zeros after the last tile: nobody reads them)
             __syncthreads();
             buf ^= 1;
+            load_frag(smem[buf], smem[buf] + TILE_FLOATS, 0, fa[0], fb[0]);
         }
     }
 
     // ---- epilogue ------------------------------------------------------------------------------
+    // The accumulators go through LDS (the operand ring is dead now) so that every global access of
+    // the fused epilogue -- bias, residual, activation mask, the one or two outputs, split-K partials
+    // -- is a 16-byte, row-contiguous access issued 16 at a time, instead of 64 dependent 4-byte
+    // round trips per lane.
+    constexpr int LDC = BN + 4;
+    float* Cs = &smem[0][0];                       // 128 x 132 floats = 67.6 KB <= 73.7 KB
+    __syncthreads();                               // (the loop's last barrier already passed; cheap)
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
+    for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int row = m0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            long pix = row;
-            if (p.nsplit == 1 && !p.identity_rows && row < p.M)
-                pix = row_to_pix(row, p.HrWr, p.Wr, p.Hd, p.Wd, p.dr, p.dpy, p.dpx);
+        for (int r = 0; r < 16; ++r)
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                const int col = n0 + wn * 64 + nb * 32 + l31;
-                const float v = acc[mb][nb][r];
-                if (row < p.M && col < p.Ncols) {
-                    if (p.nsplit > 1) p.partial[((long)split * p.M + row) * p.Ncols + col] = v;
-                    else epi_store(p.D, p.bias, p.res, p.mask, pix, col, v, p.ldd, p.ldres, p.ldmask, p.act,
-                                   p.alpha, p.replicate, p.Wd, p.D2, p.ldd2, p.res_post);
+            for (int nb = 0; nb < 2; ++nb)
+                Cs[(wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDC + wn * 64 + nb * 32 + l31] =
+                    acc[mb][nb][r];
+    __syncthreads();
+
+    if (p.vec_epi) {
+        const int c = (tid & 31) * 4;
+        const int col = n0 + c;
+        if (col < p.Ncols) {
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias && p.nsplit == 1) bv = *reinterpret_cast<const float4*>(p.bias + col);
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int rl = (tid >> 5) + 8 * it;
+                const int row = m0 + rl;
+                if (row >= p.M) continue;
+                float4 v = *reinterpret_cast<const float4*>(&Cs[rl * LDC + c]);
+                if (p.nsplit > 1) {
+                    *reinterpret_cast<float4*>(&p.partial[((long)split * p.M + row) * p.Ncols + col]) = v;
+                    continue;
                 }
+                long pix = row;
+                if (!p.identity_rows) {
+                    const int n = row / p.HrWr;
+                    const int rem = row - n * p.HrWr;
+                    const int rr = rem / p.Wr;
+                    const int cc = rem - rr * p.Wr;
+                    pix = ((long)n * p.Hd + (rr * p.dr + p.dpy)) * p.Wd + (cc * p.dr + p.dpx);
+                }
+                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (p.res) rv = *reinterpret_cast<const float4*>(p.res + pix * p.ldres + col);
+                if (p.res && !p.res_post) { v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
+                if (p.mask) {
+                    const float4 mv = *reinterpret_cast<const float4*>(p.mask + pix * p.ldmask + col);
+                    v.x *= act_grad(mv.x, p.act, p.alpha); v.y *= act_grad(mv.y, p.act, p.alpha);
+                    v.z *= act_grad(mv.z, p.act, p.alpha); v.w *= act_grad(mv.w, p.act, p.alpha);
+                } else {
+                    v.x = act_apply(v.x, p.act, p.alpha); v.y = act_apply(v.y, p.act, p.alpha);
+                    v.z = act_apply(v.z, p.act, p.alpha); v.w = act_apply(v.w, p.act, p.alpha);
+                }
+                if (p.D2) *reinterpret_cast<float4*>(p.D2 + pix * p.ldd2 + col) = v;
+                if (p.res && p.res_post) { v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
+                *reinterpret_cast<float4*>(p.D + pix * p.ldd + col) = v;
+                if (p.replicate) {
+                    *reinterpret_cast<float4*>(p.D + (pix + 1) * p.ldd + col) = v;
+                    *reinterpret_cast<float4*>(p.D + (pix + p.Wd) * p.ldd + col) = v;
+                    *reinterpret_cast<float4*>(p.D + (pix + p.Wd + 1) * p.ldd + col) = v;
+                }
+            }
+        }
+    } else {
+        // generic scalar path (thin / unaligned layers)
+        for (int idx = tid; idx < BM * BN; idx += 256) {
+            const int rl = idx >> 7, cl = idx & 127;
+            const int row = m0 + rl, col = n0 + cl;
+            if (row >= p.M || col >= p.Ncols) continue;
+            const float v = Cs[rl * LDC + cl];
+            if (p.nsplit > 1) {
+                p.partial[((long)split * p.M + row) * p.Ncols + col] = v;
+            } else {
+                const long pix = p.identity_rows ? (long)row
+                                                 : row_to_pix(row, p.HrWr, p.Wr, p.Hd, p.Wd, p.dr, p.dpy, p.dpx);
+                epi_store(p.D, p.bias, p.res, p.mask, pix, col, v, p.ldd, p.ldres, p.ldmask, p.act, p.alpha,
+                          p.replicate, p.Wd, p.D2, p.ldd2, p.res_post);
             }
         }
     }
@@ -304,7 +414,15 @@ struct WGParams {
     int ktiles, tiles_per_split, nsplit, wrows;
     float beta;
     int S, pad_t, pad_l;   // tap t = ky*S + kx -> source offset (ky - pad_t, kx - pad_l), filter slab t
+    unsigned x_bytes, y_bytes;                     // buffer-descriptor extents
+    unsigned mul_howo, shr_howo, mul_wo, shr_wo;   // magic numbers: m / HoWo and rem / Wo without v_rcp
+    int vec_epi;                                   // 1: dw / partial rows are 16-byte addressable
 };
+
+// n / d for 0 <= n < 2^31 with a precomputed (mul, shr); mul == 0 encodes d == 1
+__device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned shr) {
+    return mul ? (int)(__umulhi((unsigned)n, mul) >> shr) : n;
+}
 
 template <bool VEC>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
@@ -328,6 +446,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
     const int kt_end = min(p.ktiles, kt_begin + p.tiles_per_split);
 
     const int q = (tid & 31) * 4;   // column quad inside the 128-wide tile (both operands)
+    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.X, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t rsY = make_rsrc(p.DY, p.y_bytes);
+    const bool cx_ok = VEC ? (ci0 + q < p.C) : true;
+    const bool cy_ok = VEC ? (co0 + q < p.K) : true;
     float4 ra[4], rb[4];
 
     auto load_tiles = [&](int kt) {
@@ -336,29 +458,17 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
             const int m = kt * BK + (tid >> 5) + 8 * i;
             const bool mok = m < p.Npix;
             const int mm = mok ? m : 0;
-            const int n = mm / p.HoWo;
+            const int n = fast_div(mm, p.mul_howo, p.shr_howo);
             const int rem = mm - n * p.HoWo;
-            const int oy = rem / p.Wo;
+            const int oy = fast_div(rem, p.mul_wo, p.shr_wo);
             const int ox = rem - oy * p.Wo;
-            const int iy = (oy * p.s + oyoff) >> p.shift, ix = (ox * p.s + oxoff) >> p.shift;
-            const bool ok = mok && (oy * p.s + oyoff) >= 0 && (ox * p.s + oxoff) >= 0 && iy < p.H && ix < p.W;
-            const long xoff = ((long)(n * p.H + iy) * p.W + ix) * p.ldx + ci0 + q;
-            const long yoff = (long)mm * p.ldy + co0 + q;
-            if (VEC) {
-                ra[i] = (ok && ci0 + q < p.C) ? *reinterpret_cast<const float4*>(p.X + xoff)
-                                              : make_float4(0.f, 0.f, 0.f, 0.f);
-                rb[i] = (mok && co0 + q < p.K) ? *reinterpret_cast<const float4*>(p.DY + yoff)
-                                               : make_float4(0.f, 0.f, 0.f, 0.f);
-            } else {
-                ra[i].x = (ok && ci0 + q + 0 < p.C) ? p.X[xoff + 0] : 0.f;
-                ra[i].y = (ok && ci0 + q + 1 < p.C) ? p.X[xoff + 1] : 0.f;
-                ra[i].z = (ok && ci0 + q + 2 < p.C) ? p.X[xoff + 2] : 0.f;
-                ra[i].w = (ok && ci0 + q + 3 < p.C) ? p.X[xoff + 3] : 0.f;
-                rb[i].x = (mok && co0 + q + 0 < p.K) ? p.DY[yoff + 0] : 0.f;
-                rb[i].y = (mok && co0 + q + 1 < p.K) ? p.DY[yoff + 1] : 0.f;
-                rb[i].z = (mok && co0 + q + 2 < p.K) ? p.DY[yoff + 2] : 0.f;
-                rb[i].w = (mok && co0 + q + 3 < p.K) ? p.DY[yoff + 3] : 0.f;
-            }
+            const int py = oy * p.s + oyoff, px = ox * p.s + oxoff;
+            const int iy = py >> p.shift, ix = px >> p.shift;
+            const bool ok = mok & (py >= 0) & (px >= 0) & (iy < p.H) & (ix < p.W);
+            const unsigned xoff = (unsigned)((((n * p.H + iy) * p.W + ix) * p.ldx + ci0 + q) * 4);
+            const unsigned yoff = (unsigned)((mm * p.ldy + co0 + q) * 4);
+            ra[i] = gload4<VEC>(rsX, xoff, ok & cx_ok, ci0 + q, p.C);
+            rb[i] = gload4<VEC>(rsY, yoff, mok & cy_ok, co0 + q, p.K);
         }
     };
     auto store_tiles = [&](int buf) {
@@ -379,11 +489,26 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    // LDS -> register fragments of k-step kk; both operands are k-major: lane half h takes k = kk*8+4h+j
+    auto load_frag = [&](const float* As, const float* Bs, int kk, float (&fa)[2][4], float (&fb)[2][4]) {
+        const float* ap = &As[(kk * 8 + half * 4) * LDKN + wm * 64 + l31];
+        const float* bp = &Bs[(kk * 8 + half * 4) * LDKN + wn * 64 + l31];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            fa[0][j] = ap[j * LDKN];
+            fa[1][j] = ap[j * LDKN + 32];
+            fb[0][j] = bp[j * LDKN];
+            fb[1][j] = bp[j * LDKN + 32];
+        }
+    };
+
     if (kt_begin < kt_end) {
         load_tiles(kt_begin);
         store_tiles(0);
         __syncthreads();
         int buf = 0;
+        float fa[2][2][4], fb[2][2][4];      // [k-step parity][32-row/col block][j]
+        load_frag(smem[0], smem[0] + BK * LDKN, 0, fa[0], fb[0]);
         for (int kt = kt_begin; kt < kt_end; ++kt) {
             const bool more = (kt + 1) < kt_end;
             if (more) load_tiles(kt + 1);
@@ -391,47 +516,63 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
             const float* Bs = smem[buf] + BK * LDKN;
 #pragma unroll
             for (int kk = 0; kk < BK / 8; ++kk) {
-                const float* ap = &As[(kk * 8 + half * 4) * LDKN + wm * 64 + l31];
-                const float* bp = &Bs[(kk * 8 + half * 4) * LDKN + wn * 64 + l31];
-                float av0[4], av1[4], bv0[4], bv1[4];
+                if (kk + 1 < BK / 8) load_frag(As, Bs, kk + 1, fa[(kk + 1) & 1], fb[(kk + 1) & 1]);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    av0[j] = ap[j * LDKN];
-                    av1[j] = ap[j * LDKN + 32];
-                    bv0[j] = bp[j * LDKN];
-                    bv1[j] = bp[j * LDKN + 32];
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[j], bv0[j], acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[j], bv1[j], acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[j], bv0[j], acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[j], bv1[j], acc[1][1], 0, 0, 0);
+                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][0][j], fb[kk & 1][0][j], acc[0][0], 0, 0, 0);
+                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][0][j], fb[kk & 1][1][j], acc[0][1], 0, 0, 0);
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][1][j], fb[kk & 1][0][j], acc[1][0], 0, 0, 0);
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][1][j], fb[kk & 1][1][j], acc[1][1], 0, 0, 0);
                 }
             }
             if (more) store_tiles(buf ^ 1);
             __syncthreads();
             buf ^= 1;
+            if (more) load_frag(smem[buf], smem[buf] + BK * LDKN, 0, fa[0], fb[0]);
         }
     }
 
-    // ---- epilogue: dw rows are (wtap*C + ci), cols co -------------------------------------------
+    // ---- epilogue: dw rows are (wtap*C + ci), cols co; staged through LDS for 16-byte stores ----
     const long wsize = (long)p.wrows * p.K;
+    float* Cs = &smem[0][0];                       // 128 x 128 floats = the whole 64 KB ring
+    __syncthreads();
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
+    for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ci = ci0 + wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        for (int r = 0; r < 16; ++r)
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
-                const int co = co0 + wn * 64 + nb * 32 + l31;
-                const float v = acc[mb][nb][r];
-                if (ci < p.C && co < p.K) {
-                    const long idx = ((long)wt * p.C + ci) * p.K + co;
-                    if (p.nsplit > 1) p.partial[(long)split * wsize + idx] = v;
-                    else p.DW[idx] = (p.beta != 0.f) ? p.beta * p.DW[idx] + v : v;
+            for (int nb = 0; nb < 2; ++nb)
+                Cs[(wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * BN + wn * 64 + nb * 32 + l31] =
+                    acc[mb][nb][r];
+    __syncthreads();
+    float* dst = (p.nsplit > 1) ? p.partial + (long)split * wsize : p.DW;
+    const float beta = (p.nsplit > 1) ? 0.f : p.beta;
+    if (p.vec_epi) {
+        const int c = (tid & 31) * 4;
+        const int co = co0 + c;
+        if (co < p.K) {
+#pragma unroll 4
+            for (int it = 0; it < 16; ++it) {
+                const int rl = (tid >> 5) + 8 * it;
+                const int ci = ci0 + rl;
+                if (ci >= p.C) continue;
+                float4 v = *reinterpret_cast<const float4*>(&Cs[rl * BN + c]);
+                float4* o = reinterpret_cast<float4*>(dst + ((long)wt * p.C + ci) * p.K + co);
+                if (beta != 0.f) {
+                    const float4 old = *o;
+                    v.x += beta * old.x; v.y += beta * old.y; v.z += beta * old.z; v.w += beta * old.w;
                 }
+                *o = v;
             }
+        }
+    } else {
+        for (int idx = tid; idx < BM * BN; idx += 256) {
+            const int rl = idx >> 7, cl = idx & 127;
+            const int ci = ci0 + rl, co = co0 + cl;
+            if (ci >= p.C || co >= p.K) continue;
+            const long o = ((long)wt * p.C + ci) * p.K + co;
+            const float v = Cs[rl * BN + cl];
+            dst[o] = (beta != 0.f) ? beta * dst[o] + v : v;
         }
     }
 }
@@ -469,6 +610,16 @@ __global__ __launch_bounds__(256) void splitk_sum_scalar_kernel(const float* __r
 // ================================================================================================
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// (mul, shr) such that n / d == umulhi(n, mul) >> shr for every 0 <= n < 2^31; d == 1 -> mul = 0
+static void find_divisor(int d, unsigned* mul, unsigned* shr) {
+    if (d == 1) { *mul = 0; *shr = 0; return; }
+    unsigned lg = 0;
+    while ((1u << lg) < (unsigned)d) ++lg;                 // ceil(log2 d)
+    const unsigned p = 31 + lg;
+    *mul = (unsigned)(((1ull << p) + (unsigned)d - 1) / (unsigned)d);
+    *shr = p - 32;
+}
+
 static int resolve_desc(const DpigConvDesc* d, int* pt, int* pl, int* Ho, int* Wo) {
     if (!d) return fail(DPIG_EINVAL, "null descriptor");
     if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->K <= 0) return fail(DPIG_EINVAL, "non-positive dims");
@@ -489,16 +640,29 @@ static int resolve_desc(const DpigConvDesc* d, int* pt, int* pl, int* Ho, int* W
     return DPIG_OK;
 }
 
+// Split-K plan.  The grid is tiles x splits workgroups of which 2 per CU are resident (512 slots):
+// pick the split count that best fills whole "rounds" of 512 slots, charged with the HBM round trip
+// of the fp32 partial sums (~120*s/K relative to the MFMA time of a K-deep reduction).
 static int choose_split(int tiles, int ktiles, int forced) {
     if (forced > 0) return forced < ktiles ? forced : (ktiles > 0 ? ktiles : 1);
     if (ktiles <= 0) return 1;
-    const int target = 2 * kNumCU;            // two resident workgroups per CU
-    if (tiles >= target / 2) return 1;        // >= 1 block per CU already: splitting only adds traffic
-    int s = cdiv(target, tiles);
-    const int max_by_k = ktiles / 4 > 0 ? ktiles / 4 : 1;   // keep >= 4 k-tiles per split
-    if (s > max_by_k) s = max_by_k;
-    if (s > 64) s = 64;
-    return s < 1 ? 1 : s;
+    const int slots = 2 * kNumCU;
+    const double kred = 32.0 * ktiles;
+    double best = -1.0;
+    int best_s = 1;
+    const int smax = ktiles / 2 > 0 ? (ktiles / 2 < 64 ? ktiles / 2 : 64) : 1;
+    for (int s = 1; s <= smax; ++s) {
+        const int tps = cdiv(ktiles, s);
+        const int sr = cdiv(ktiles, tps);                  // effective split count
+        if (sr != s) continue;
+        const long blocks = (long)tiles * s;
+        const long rounds = (blocks + slots - 1) / slots;
+        double eff = (double)blocks / (double)(rounds * slots);
+        if (rounds == 1 && blocks <= kNumCU) eff = 0.75 * (double)blocks / kNumCU;   // lone block per CU
+        const double score = eff / (s > 1 ? 1.0 + 120.0 * s / kred : 1.0);
+        if (score > best * 1.02) { best = score; best_s = s; }
+    }
+    return best_s;
 }
 
 struct Plan { int nsplit, tiles_per_split; };
@@ -514,8 +678,17 @@ static bool vec_ok(const void* a, const void* b, int lda, int Cs, int Ncols) {
     return aligned16(a) && aligned16(b) && (lda % 4 == 0) && (Cs % 4 == 0) && (Ncols % 4 == 0);
 }
 
-static int launch_gg(GGParams& p, bool b_rowk, hipStream_t st) {
+static int launch_gg(GGParams& p, bool b_rowk, int nimg, long filter_elems, hipStream_t st) {
     p.HrWr = p.Hr * p.Wr;
+    const long a_elems = ((long)nimg * p.Hs * p.Ws - 1) * p.lda + p.Cs;
+    if (a_elems * 4 >= 0x7fffffffL || filter_elems * 4 >= 0x7fffffffL)
+        return fail(DPIG_EINVAL, "tensor exceeds the 2 GiB buffer-descriptor range");
+    p.a_bytes = (unsigned)(a_elems * 4);
+    p.b_bytes = (unsigned)(filter_elems * 4);
+    p.vec_epi = (p.Ncols % 4 == 0) && (p.ldd % 4 == 0) && aligned16(p.D) &&
+                (!p.bias || aligned16(p.bias)) && (!p.res || (p.ldres % 4 == 0 && aligned16(p.res))) &&
+                (!p.mask || (p.ldmask % 4 == 0 && aligned16(p.mask))) &&
+                (!p.D2 || (p.ldd2 % 4 == 0 && aligned16(p.D2))) && (!p.partial || aligned16(p.partial));
     p.mtiles = cdiv(p.M, BM);
     p.ntiles = cdiv(p.Ncols, BN);
     p.cchunks = cdiv(p.Cs, BK);
@@ -657,7 +830,7 @@ extern "C" int dpig_conv2d_fwd(const DpigConvDesc* d, const float* x, const floa
     if (p.nsplit > 1 && ws_bytes < (size_t)p.nsplit * s.M * s.Ncols * sizeof(float))
         return fail(DPIG_ENOMEM, "conv fwd workspace too small: have %zu", ws_bytes);
     if (p.nsplit > 1 && !ws) return fail(DPIG_ENOMEM, "conv fwd needs a workspace");
-    return launch_gg(p, false, static_cast<hipStream_t>(stream));
+    return launch_gg(p, false, d->N, (long)d->R * d->S * d->C * d->K, static_cast<hipStream_t>(stream));
 }
 
 extern "C" int dpig_conv2d_dgrad(const DpigConvDesc* d, const float* dy, const float* w, const float* accum,
@@ -704,7 +877,7 @@ extern "C" int dpig_conv2d_dgrad(const DpigConvDesc* d, const float* dy, const f
             q.nsplit = pln.nsplit; q.tiles_per_split = pln.tiles_per_split;
             if (q.nsplit > 1 && (!ws || ws_bytes < (size_t)q.nsplit * q.M * q.Ncols * sizeof(float)))
                 return fail(DPIG_ENOMEM, "conv dgrad workspace too small: have %zu", ws_bytes);
-            rc = launch_gg(q, true, st);
+            rc = launch_gg(q, true, d->N, (long)d->R * d->S * d->C * d->K, st);
             if (rc) return rc;
         }
         return DPIG_OK;
@@ -713,7 +886,7 @@ extern "C" int dpig_conv2d_dgrad(const DpigConvDesc* d, const float* dy, const f
     p.nsplit = pln.nsplit; p.tiles_per_split = pln.tiles_per_split;
     if (p.nsplit > 1 && (!ws || ws_bytes < (size_t)p.nsplit * p.M * p.Ncols * sizeof(float)))
         return fail(DPIG_ENOMEM, "conv dgrad workspace too small: have %zu", ws_bytes);
-    return launch_gg(p, true, st);
+    return launch_gg(p, true, d->N, (long)d->R * d->S * d->C * d->K, st);
 }
 
 extern "C" int dpig_conv2d_wgrad(const DpigConvDesc* d, const float* x, const float* dy, float* dw, float beta,
@@ -736,6 +909,15 @@ extern "C" int dpig_conv2d_wgrad(const DpigConvDesc* d, const float* x, const fl
     }
     p.HoWo = p.Ho * p.Wo;
     p.Npix = d->N * p.HoWo;
+    {
+        const long xe = ((long)d->N * d->H * d->W - 1) * d->ldx + d->C;
+        const long ye = ((long)p.Npix - 1) * d->ldy + d->K;
+        if (xe * 4 >= 0x7fffffffL || ye * 4 >= 0x7fffffffL)
+            return fail(DPIG_EINVAL, "tensor exceeds the 2 GiB buffer-descriptor range");
+        p.x_bytes = (unsigned)(xe * 4); p.y_bytes = (unsigned)(ye * 4);
+        find_divisor(p.HoWo, &p.mul_howo, &p.shr_howo);
+        find_divisor(p.Wo, &p.mul_wo, &p.shr_wo);
+    }
     p.wrows = d->R * d->S * d->C;
     p.cblocks = cdiv(d->C, BM);
     p.ntiles = cdiv(d->K, BN);
@@ -748,6 +930,7 @@ extern "C" int dpig_conv2d_wgrad(const DpigConvDesc* d, const float* x, const fl
         return fail(DPIG_ENOMEM, "conv wgrad workspace too small: have %zu", ws_bytes);
     const bool vec = aligned16(x) && aligned16(dy) && (d->ldx % 4 == 0) && (d->ldy % 4 == 0) &&
                      (d->C % 4 == 0) && (d->K % 4 == 0);
+    p.vec_epi = (d->K % 4 == 0) && aligned16(dw) && (p.nsplit == 1 || aligned16(ws));
     dim3 grid(tiles, 1, p.nsplit), block(256);
     if (vec) hipLaunchKernelGGL((wgrad_kernel<true>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((wgrad_kernel<false>), grid, block, 0, st, p);
