@@ -25,7 +25,7 @@ class DpigConvDesc(ctypes.Structure):
         ("ldx", ctypes.c_int32), ("ldy", ctypes.c_int32), ("ldres", ctypes.c_int32), ("ldmask", ctypes.c_int32),
         ("act", ctypes.c_int32), ("alpha", ctypes.c_float),
         ("upsample2x", ctypes.c_int32), ("res_after_act", ctypes.c_int32), ("ldy2", ctypes.c_int32),
-        ("split_k", ctypes.c_int32),
+        ("res_class", ctypes.c_int32), ("split_k", ctypes.c_int32),
     ]
 
 
@@ -44,6 +44,8 @@ SYMBOLS = {
     "dpig_act_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _i, _i, _f, _vp]),
     "dpig_colsum_workspace_bytes": (_sz, [_i64, _i]),
     "dpig_colsum": (_i, [_vp, _i, _i64, _i, _vp, _f, _vp, _sz, _vp]),
+    "dpig_border_class_sum_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "dpig_border_class_sum": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "dpig_bn_workspace_bytes": (_sz, [_i64, _i]),
     "dpig_bn_fwd": (_i, [_vp, _i, _i64, _i, _vp, _vp, _f, _i, _f, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "dpig_bn_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp, _vp, _vp, _i, _f, _vp, _i, _vp, _vp, _vp, _sz, _vp]),

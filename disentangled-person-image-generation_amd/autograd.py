@@ -110,6 +110,74 @@ def resblock(x0, w1, b1, w2, b2):
     return _ResBlockFn.apply(x0, w1, b1, w2, b2)
 
 
+def _valid_taps(c):
+    """Filter rows/cols that see real data for border class c of a SAME 3x3 conv (pad 1)."""
+    return (slice(1, 3), slice(0, 3), slice(0, 2))[c]
+
+
+class _TiledEmbConvFn(torch.autograd.Function):
+    """First conv of the U-Net generator (models.py:520-528) on concat(tile(emb), pose):
+
+        y = relu(conv3x3_SAME(concat([emb broadcast over H x W, pose], -1), w) + b)
+
+    The reference materialises the [B,H,W,E] tiled embedding (trainer.py:588-590, 184 MB at B=16) and
+    convolves it densely (111.7 GFLOP).  Because those E input channels are spatially constant their
+    contribution to an output pixel only depends on which filter taps fall inside the image, i.e. on
+    the pixel's 3x3 border class:  contribution = emb[b] @ sum_{valid taps} w[tap,:E,:].
+    So: one [B,E]x[E,9K] GEMM gives the per-(image, class) vectors, a thin conv over the pose
+    channels adds them in its epilogue -- identical result, ~1/20 of the work.  The backward pass is
+    the exact transpose: per-class sums of dz, two small GEMMs, and the thin wgrad of the pose part."""
+
+    @staticmethod
+    def forward(ctx, emb, pose, w, b):
+        E = emb.shape[1]
+        K = w.shape[3]
+        we = w[:, :, :E, :]
+        wy = torch.stack([we[_valid_taps(c)].sum(0) for c in range(3)])                 # [cy, kx, E, K]
+        wc = torch.stack([wy[:, _valid_taps(c)].sum(1) for c in range(3)], dim=1)       # [cy, cx, E, K]
+        wmat = wc.permute(2, 0, 1, 3).reshape(E, 9 * K).contiguous()
+        e9 = H.linear_fwd(emb, wmat)                                                   # [B, 9K]
+        w_pose = w[:, :, E:, :].contiguous()
+        y = H.conv2d_fwd(pose, w_pose, b, act=ACT_RELU, residual=e9.view(-1, 9, K), res_class=True)
+        ctx.save_for_backward(emb, pose, w, wmat, y)
+        ctx.b_ref = b
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        emb, pose, w, wmat, y = ctx.saved_tensors
+        E, K = emb.shape[1], w.shape[3]
+        B = emb.shape[0]
+        dz = H.act_bwd(dy, y, ACT_RELU)
+        db = _sink(ctx.b_ref, lambda o, beta: H.colsum(dz, out=o, beta=beta)) if ctx.needs_input_grad[3] else None
+        z9 = H.border_class_sum(dz).view(B, 9 * K)
+        d_emb = H.linear_dgrad(z9, wmat) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[2]:
+            dwp = H.conv2d_wgrad(pose, dz, (3, 3, pose.shape[3], K))
+            dwc = H.linear_wgrad(emb, z9).view(E, 3, 3, K).permute(1, 2, 0, 3)          # [cy, cx, E, K]
+            # transpose of the class sums: tap ky receives every class whose valid set contains ky
+            dwy = torch.stack([dwc[1:].sum(0), dwc.sum(0), dwc[:2].sum(0)])              # [ky, cx, E, K]
+            dwe = torch.stack([dwy[:, 1:].sum(1), dwy.sum(1), dwy[:, :2].sum(1)], dim=1)  # [ky, kx, E, K]
+
+            def put(out, beta):
+                if out is None:
+                    return torch.cat([dwe, dwp], dim=2)
+                if beta == 0.0:
+                    out[:, :, :E, :].copy_(dwe)
+                    out[:, :, E:, :].copy_(dwp)
+                else:
+                    out[:, :, :E, :].add_(dwe)
+                    out[:, :, E:, :].add_(dwp)
+                return out
+            dw = _sink(w, put)
+        return d_emb, None, dw, db
+
+
+def tiled_emb_conv(emb, pose, w, b):
+    return _TiledEmbConvFn.apply(emb, pose, w, b)
+
+
 class _ActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, act, alpha):

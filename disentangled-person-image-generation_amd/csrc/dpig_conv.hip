@@ -43,6 +43,7 @@ struct GGParams {
     int Hd, Wd, ldd, dr, dpy, dpx;   // destination pixel = (r*dr+dpy, c*dr+dpx)
     int ldres, ldmask, ldd2;
     int res_post;         // 1: D = act(v + bias) + res  (reference res-blocks, models.py:400,427,536,566)
+    int res_class;        // 1: res is [images][9][Ncols], indexed by the 3x3 border class of the output pixel
     int ntaps, cchunks, ktiles, tiles_per_split, nsplit;
     int mtiles, ntiles;
     int act; float alpha;
@@ -73,14 +74,14 @@ __device__ __attribute__((noinline)) void epi_store(float* __restrict__ D, const
                                                     const float* __restrict__ mask, long pix, int col, float v,
                                                     int ldd, int ldres, int ldmask, int act, float alpha,
                                                     int replicate, int Wd, float* __restrict__ D2, int ldd2,
-                                                    int res_post) {
+                                                    int res_post, long rpix) {
     if (bias) v += bias[col];
     if (!replicate) {
-        if (res && !res_post) v += res[pix * ldres + col];
+        if (res && !res_post) v += res[rpix * ldres + col];
         if (mask) v *= act_grad(mask[pix * ldmask + col], act, alpha);
         else v = act_apply(v, act, alpha);
         if (D2) D2[pix * ldd2 + col] = v;
-        if (res && res_post) v += res[pix * ldres + col];
+        if (res && res_post) v += res[rpix * ldres + col];
         D[pix * ldd + col] = v;
     } else {
         v = act_apply(v, act, alpha);
@@ -119,6 +120,20 @@ __device__ __forceinline__ float4 gload4(__amdgpu_buffer_rsrc_t r, unsigned off,
         v.w = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(r, (int)((ok & (first + 3 < limit)) ? off + 12 : OOB), 0, 0));
     }
     return v;
+}
+
+// 3x3 border class of pixel (y, x) in an H x W image: (top|interior|bottom) x (left|interior|right).
+// A SAME 3x3 conv over a spatially constant input only depends on this class.
+__device__ __forceinline__ int border_class(int y, int x, int H, int W) {
+    const int cy = (y == 0) ? 0 : ((y == H - 1) ? 2 : 1);
+    const int cx = (x == 0) ? 0 : ((x == W - 1) ? 2 : 1);
+    return cy * 3 + cx;
+}
+__device__ __forceinline__ long class_row(int row, int HrWr, int Wr, int Hr) {
+    const int n = row / HrWr;
+    const int rem = row - n * HrWr;
+    const int y = rem / Wr;
+    return (long)n * 9 + border_class(y, rem - y * Wr, Hr, Wr);
 }
 
 template <bool B_ROWK, bool VEC>
@@ -349,7 +364,10 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GGParams p) {
                 }
                 v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
                 float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.res) rv = *reinterpret_cast<const float4*>(p.res + pix * p.ldres + col);
+                if (p.res) {
+                    const long rpix = p.res_class ? class_row(row, p.HrWr, p.Wr, p.Hr) : pix;
+                    rv = *reinterpret_cast<const float4*>(p.res + rpix * p.ldres + col);
+                }
                 if (p.res && !p.res_post) { v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
                 if (p.mask) {
                     const float4 mv = *reinterpret_cast<const float4*>(p.mask + pix * p.ldmask + col);
@@ -381,8 +399,9 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GGParams p) {
             } else {
                 const long pix = p.identity_rows ? (long)row
                                                  : row_to_pix(row, p.HrWr, p.Wr, p.Hd, p.Wd, p.dr, p.dpy, p.dpx);
+                const long rpix = (p.res && p.res_class) ? class_row(row, p.HrWr, p.Wr, p.Hr) : pix;
                 epi_store(p.D, p.bias, p.res, p.mask, pix, col, v, p.ldd, p.ldres, p.ldmask, p.act, p.alpha,
-                          p.replicate, p.Wd, p.D2, p.ldd2, p.res_post);
+                          p.replicate, p.Wd, p.D2, p.ldd2, p.res_post, rpix);
             }
         }
     }
@@ -398,8 +417,9 @@ __global__ __launch_bounds__(256) void gather_gemm_reduce_kernel(const GGParams 
         const int col = (int)(i - (long)row * p.Ncols);
         const long pix = p.identity_rows ? (long)row
                                          : row_to_pix(row, p.HrWr, p.Wr, p.Hd, p.Wd, p.dr, p.dpy, p.dpx);
+        const long rpix = (p.res && p.res_class) ? class_row(row, p.HrWr, p.Wr, p.Hr) : pix;
         epi_store(p.D, p.bias, p.res, p.mask, pix, col, v, p.ldd, p.ldres, p.ldmask, p.act, p.alpha, p.replicate,
-                  p.Wd, p.D2, p.ldd2, p.res_post);
+                  p.Wd, p.D2, p.ldd2, p.res_post, rpix);
     }
 }
 
@@ -809,6 +829,9 @@ extern "C" int dpig_conv2d_fwd(const DpigConvDesc* d, const float* x, const floa
     GGParams p = {};
     p.A = x; p.B = w; p.D = y; p.bias = bias; p.res = residual; p.mask = nullptr;
     p.D2 = y_act; p.ldd2 = d->ldy2; p.res_post = d->res_after_act;
+    p.res_class = (residual && d->res_class) ? 1 : 0;
+    if (p.res_class && (d->stride != 1 || d->upsample2x || d->H < 2 || d->W < 2))
+        return fail(DPIG_EINVAL, "res_class needs a stride-1 conv on an image of at least 2x2");
     if (y_act && d->ldy2 < d->K) return fail(DPIG_EINVAL, "ldy2 < K");
     if (y_act && d->upsample2x) return fail(DPIG_EINVAL, "y_act unsupported with upsample2x");
     p.partial = static_cast<float*>(ws);

@@ -123,18 +123,27 @@ __global__ __launch_bounds__(256) void col_partial_kernel(const float* __restric
 
 // out_o[c] = beta*out_o[c] + scale * sum_slab partial[slab][o][c]      (FIN 0)
 // out_0[c] = 1/sqrt(scale * sum + eps)                                  (FIN 1)
+// block = 64 columns x 4 slab groups (fixed summation order -> deterministic)
 template <int FIN>
 __global__ __launch_bounds__(256) void col_final_kernel(const float* __restrict__ partial, int nslab, int nout,
                                                         int C, float* __restrict__ out0,
                                                         float* __restrict__ out1, float scale, float beta,
                                                         float eps) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+    __shared__ float red[2][4][64];
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     for (int o = 0; o < nout; ++o) {
         float s = 0.f;
-        for (int b = 0; b < nslab; ++b) s += partial[((long)b * nout + o) * C + c];
+        if (c < C)
+            for (int b = g; b < nslab; b += 4) s += partial[((long)b * nout + o) * C + c];
+        red[o][g][cl] = s;
+    }
+    __syncthreads();
+    if (g != 0 || c >= C) return;
+    for (int o = 0; o < nout; ++o) {
         float* out = (o == 0) ? out0 : out1;
         if (!out) continue;
+        const float s = (red[o][0][cl] + red[o][1][cl]) + (red[o][2][cl] + red[o][3][cl]);
         if (FIN == 1) out[c] = 1.0f / sqrtf(s * scale + eps);
         else out[c] = ((beta != 0.f) ? beta * out[c] : 0.f) + s * scale;
     }
@@ -145,6 +154,55 @@ static int slabs_for(long rows) {
     if (s < 1) s = 1;
     if (s > 256) s = 256;
     return (int)s;
+}
+
+// ---------------------------------------------------------------------------------------------
+// per-image sums of a [N,H,W,C] tensor over the 9 border classes of a 3x3 SAME conv (the gradient
+// of the class-indexed residual of dpig_conv2d_fwd).  partial: [N][slab][9][C]
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void class_sum_partial_kernel(const float* __restrict__ a, int lda, int H, int W,
+                                                                int C, float* __restrict__ partial) {
+    __shared__ float red[9][4][64];
+    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    const int n = blockIdx.y, slab = blockIdx.z, nslab = gridDim.z;
+    float acc[9];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) acc[k] = 0.f;
+    if (c < C) {
+        const int P = H * W;
+        for (int pix = slab * 4 + rg; pix < P; pix += nslab * 4) {
+            const int y = pix / W, x = pix - y * W;
+            const int cy = (y == 0) ? 0 : ((y == H - 1) ? 2 : 1);
+            const int cx = (x == 0) ? 0 : ((x == W - 1) ? 2 : 1);
+            const int cls = cy * 3 + cx;
+            const float v = a[((long)n * P + pix) * lda + c];
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc[k] += (cls == k) ? v : 0.f;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) red[k][rg][cl] = acc[k];
+    __syncthreads();
+    if (rg == 0 && c < C) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k)
+            partial[(((long)n * nslab + slab) * 9 + k) * C + c] =
+                (red[k][0][cl] + red[k][1][cl]) + (red[k][2][cl] + red[k][3][cl]);
+    }
+}
+__global__ __launch_bounds__(256) void class_sum_final_kernel(const float* __restrict__ partial, int nslab, int C,
+                                                              long total, float* __restrict__ out) {
+    // out[(n*9 + k)*C + c] = sum_slab partial[((n*nslab + slab)*9 + k)*C + c]
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long nk = i / C;
+        const int c = (int)(i - nk * C);
+        const long n = nk / 9;
+        const int k = (int)(nk - n * 9);
+        float s = 0.f;
+        for (int b = 0; b < nslab; ++b) s += partial[((n * nslab + b) * 9 + k) * C + c];
+        out[i] = s;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -500,9 +558,34 @@ extern "C" int dpig_colsum(const float* a, int lda, int64_t rows, int cols, floa
     float* partial = static_cast<float*>(ws);
     hipLaunchKernelGGL((col_partial_kernel<0>), dim3(cdivi(cols, 64), nslab), dim3(256), 0, st, a, lda, nullptr, 0,
                        nullptr, 0, nullptr, nullptr, (long)rows, cols, 1, 0, 0.f, partial);
-    hipLaunchKernelGGL((col_final_kernel<0>), dim3(cdivi(cols, 256)), dim3(256), 0, st, partial, nslab, 1, cols, out,
+    hipLaunchKernelGGL((col_final_kernel<0>), dim3(cdivi(cols, 64)), dim3(256), 0, st, partial, nslab, 1, cols, out,
                        nullptr, 1.0f, beta, 0.f);
     return check_launch("colsum");
+}
+
+static int class_slabs(int N, int H, int W) {
+    int s = (H * W) / 256;
+    if (s < 1) s = 1;
+    if (s > 32) s = 32;
+    return s;
+}
+extern "C" size_t dpig_border_class_sum_workspace_bytes(int N, int H, int W, int C) {
+    return (size_t)N * class_slabs(N, H, W) * 9 * C * sizeof(float);
+}
+extern "C" int dpig_border_class_sum(const float* a, int lda, int N, int H, int W, int C, float* out, void* ws,
+                                     size_t ws_bytes, void* stream) {
+    if (!a || !out) return fail(DPIG_EINVAL, "border_class_sum: null pointer");
+    if (N <= 0 || H < 2 || W < 2 || C <= 0 || lda < C) return fail(DPIG_EINVAL, "border_class_sum: bad shape");
+    if (!ws || ws_bytes < dpig_border_class_sum_workspace_bytes(N, H, W, C))
+        return fail(DPIG_ENOMEM, "border_class_sum: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nslab = class_slabs(N, H, W);
+    float* partial = static_cast<float*>(ws);
+    hipLaunchKernelGGL(class_sum_partial_kernel, dim3(cdivi(C, 64), N, nslab), dim3(256), 0, st, a, lda, H, W, C,
+                       partial);
+    const long total = (long)N * 9 * C;
+    hipLaunchKernelGGL(class_sum_final_kernel, dim3(grid_for(total)), dim3(256), 0, st, partial, nslab, C, total, out);
+    return check_launch("border_class_sum");
 }
 
 extern "C" size_t dpig_bn_workspace_bytes(int64_t rows, int C) {
@@ -516,7 +599,7 @@ extern "C" int dpig_bn_fwd(const float* x, int ldx, int64_t rows, int C, const f
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nslab = slabs_for(rows);
     float* partial = static_cast<float*>(ws);
-    const dim3 g1(cdivi(C, 64), nslab), g2(cdivi(C, 256));
+    const dim3 g1(cdivi(C, 64), nslab), g2(cdivi(C, 64));
     hipLaunchKernelGGL((col_partial_kernel<0>), g1, dim3(256), 0, st, x, ldx, nullptr, 0, nullptr, 0, nullptr,
                        nullptr, (long)rows, C, 1, 0, 0.f, partial);
     hipLaunchKernelGGL((col_final_kernel<0>), g2, dim3(256), 0, st, partial, nslab, 1, C, save_mean, nullptr,
@@ -543,7 +626,7 @@ extern "C" int dpig_bn_bwd(const float* dy, int lddy, const float* x, int ldx, c
     float* partial = static_cast<float*>(ws);
     hipLaunchKernelGGL((col_partial_kernel<2>), dim3(cdivi(C, 64), nslab), dim3(256), 0, st, dy, lddy, x, ldx, y, ldy,
                        save_mean, save_rstd, (long)rows, C, 1, act, alpha, partial);
-    hipLaunchKernelGGL((col_final_kernel<0>), dim3(cdivi(C, 256)), dim3(256), 0, st, partial, nslab, 2, C, doffset,
+    hipLaunchKernelGGL((col_final_kernel<0>), dim3(cdivi(C, 64)), dim3(256), 0, st, partial, nslab, 2, C, doffset,
                        dscale, 1.0f, 0.f, 0.f);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * C)), dim3(256), 0, st, dy, lddy, x, ldx, y, ldy,
                        (long)rows, C, scale, save_mean, save_rstd, dscale, doffset, act, alpha, dx, lddx);
@@ -574,7 +657,7 @@ extern "C" int dpig_ln_bwd(const float* dy, const float* x, const float* y, int 
     float* partial = static_cast<float*>(ws);
     hipLaunchKernelGGL((col_partial_kernel<3>), dim3(cdivi(C, 64), nslab), dim3(256), 0, st, dy, C, x, C, y, C,
                        save_mean, save_rstd, rows, C, P, act, alpha, partial);
-    hipLaunchKernelGGL((col_final_kernel<0>), dim3(cdivi(C, 256)), dim3(256), 0, st, partial, nslab, 2, C, doffset,
+    hipLaunchKernelGGL((col_final_kernel<0>), dim3(cdivi(C, 64)), dim3(256), 0, st, partial, nslab, 2, C, doffset,
                        dscale, 1.0f, 0.f, 0.f);
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(N), dim3(1024), 0, st, dy, x, y, P, C, scale, save_mean, save_rstd, act,
                        alpha, dx);

@@ -69,13 +69,13 @@ def as_nhwc(t):
 
 
 def _desc(N, H, W, C, K, R, S, stride, ldx, ldy, ldres=0, ldmask=0, act=ACT_NONE, alpha=0.2, upsample2x=False,
-          split_k=0, res_after_act=False, ldy2=0):
+          split_k=0, res_after_act=False, ldy2=0, res_class=False):
     d = DpigConvDesc()
     d.N, d.H, d.W, d.C, d.K, d.R, d.S, d.stride = N, H, W, C, K, R, S, stride
     d.pad_t, d.pad_l = -1, -1
     d.ldx, d.ldy, d.ldres, d.ldmask = ldx, ldy, ldres, ldmask
     d.act, d.alpha, d.upsample2x, d.split_k = act, alpha, int(upsample2x), split_k
-    d.res_after_act, d.ldy2 = int(res_after_act), ldy2
+    d.res_after_act, d.ldy2, d.res_class = int(res_after_act), ldy2, int(res_class)
     return d
 
 
@@ -92,7 +92,7 @@ def conv_out_hw(H, W, R, S, stride, upsample2x=False):
 
 
 def conv2d_fwd(x, w, bias=None, stride=1, act=ACT_NONE, alpha=0.2, residual=None, out=None, upsample2x=False,
-               split_k=0, res_after_act=False, out_act=None):
+               split_k=0, res_after_act=False, out_act=None, res_class=False):
     """y = act(conv_SAME(x, w) + bias + residual) (or act(..) + residual with res_after_act);
     x NHWC, w HWIO.  `out` may be a channel slice.  `out_act` optionally receives the activation
     output before a post-activation residual add."""
@@ -111,7 +111,13 @@ def conv2d_fwd(x, w, bias=None, stride=1, act=ACT_NONE, alpha=0.2, residual=None
         raise RuntimeError("conv2d: bad output tensor")
     ldres = 0
     if residual is not None:
-        residual, ldres = as_nhwc(residual)
+        if res_class:          # [N, 9, K]: one row per (image, 3x3 border class)
+            residual = residual.contiguous()
+            if tuple(residual.shape) != (N, 9, K):
+                raise RuntimeError("conv2d: class residual must be [N, 9, K]")
+            ldres = K
+        else:
+            residual, ldres = as_nhwc(residual)
     if bias is not None:
         bias = bias.contiguous()
     ldy2 = 0
@@ -120,7 +126,7 @@ def conv2d_fwd(x, w, bias=None, stride=1, act=ACT_NONE, alpha=0.2, residual=None
         if ldy2 is None or tuple(out_act.shape) != (N, Ho, Wo, K):
             raise RuntimeError("conv2d: bad out_act tensor")
     d = _desc(N, H, W, C, K, R, S, stride, ldx, ldy, ldres=ldres, act=act, alpha=alpha, upsample2x=upsample2x,
-              split_k=split_k, res_after_act=res_after_act, ldy2=ldy2)
+              split_k=split_k, res_after_act=res_after_act, ldy2=ldy2, res_class=res_class)
     wsb, wsn = _ws(d, 0, x.device)
     mfma = (C % 4 == 0 and K % 4 == 0 and ldx % 4 == 0 and C >= 32 and K >= 32)
     with _Timed("conv_fwd_mfma" if mfma else "conv_fwd_thin", 2.0 * N * H * W // (stride * stride) * K * R * S * C):
@@ -225,6 +231,18 @@ def colsum(a, out=None, beta=0.0):
     nbytes = lib().dpig_colsum_workspace_bytes(rows, cols)
     wsb, wsn = workspace.get(nbytes, a.device)
     check(lib().dpig_colsum(ptr(a), lda, rows, cols, ptr(out), float(beta), ptr(wsb), wsn, stream_ptr()), "colsum")
+    return out
+
+
+def border_class_sum(a):
+    """[N,H,W,C] -> [N,9,C]: per-image sums over the 9 border classes of a SAME 3x3 conv."""
+    _require_gpu(a)
+    a, lda = as_nhwc(a)
+    N, Hh, W, C = a.shape
+    out = torch.empty((N, 9, C), dtype=torch.float32, device=a.device)
+    wsb, wsn = workspace.get(lib().dpig_border_class_sum_workspace_bytes(N, Hh, W, C), a.device)
+    check(lib().dpig_border_class_sum(ptr(a), lda, N, Hh, W, C, ptr(out), ptr(wsb), wsn, stream_ptr()),
+          "border_class_sum")
     return out
 
 

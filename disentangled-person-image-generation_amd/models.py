@@ -209,14 +209,20 @@ def GeneratorCNN_ID_UAEAfterResidual(x, pose, input_channel, z_num, repeat_num, 
                                      activation_fn=relu, min_fea_map_H=8, noise_dim=0, reuse=False):
     """Reference models.py:518-576 (U-Net style decoder G)."""
     with variable_scope("G", reuse=reuse) as vs:
-        if pose is not None:
-            if data_format != 'NHWC':
-                raise Exception("only NHWC is supported (main.py:18)")
-            x = torch.cat([x, pose], dim=3)
-
+        if data_format != 'NHWC':
+            raise Exception("only NHWC is supported (main.py:18)")
         # Encoder
         encoder_layer_list = []
-        x = slim.conv2d(x, hidden_num, 3, 1, activation_fn=activation_fn, data_format=data_format)
+        tiled = (pose is not None and x.dim() == 4 and x.stride(1) == 0 and x.stride(2) == 0 and
+                 x.shape[1] >= 2 and x.shape[2] >= 2 and activation_fn is slim.relu)
+        if tiled:
+            # x is a [B,E] embedding broadcast over H x W (trainer.py:588-590 embs_rep): the first conv
+            # collapses exactly to a small GEMM + a thin conv over the pose channels (SURVEY F7)
+            x = slim.conv2d_tiled_embedding(x[:, 0, 0, :], pose, hidden_num)
+        else:
+            if pose is not None:
+                x = torch.cat([x, pose], dim=3)
+            x = slim.conv2d(x, hidden_num, 3, 1, activation_fn=activation_fn, data_format=data_format)
         _tap("G.stem", x)
         for idx in range(repeat_num):
             channel_num = hidden_num * (idx + 1)

@@ -108,6 +108,16 @@ def conv2d(inputs, num_outputs, kernel_size, stride=1, activation_fn=relu, data_
     return foreign(y) if foreign is not None else y
 
 
+def conv2d_tiled_embedding(emb, pose, num_outputs, scope=None):
+    """slim.conv2d(concat([tile(emb), pose], -1), num_outputs, 3, 1, activation_fn=relu) -- same `Conv`
+    variables ([3,3,E+P,num_outputs] weights), evaluated without materialising the tiled embedding
+    (autograd._TiledEmbConvFn)."""
+    name = scope if scope is not None else _unique("Conv")
+    cin = emb.shape[-1] + pose.shape[-1]
+    w, b = _conv_vars(name, 3, cin, num_outputs)
+    return A.tiled_emb_conv(emb, pose, w, b)
+
+
 def res_block(inputs, channel_num, kernel_size=3, activation_fn=relu, data_format="NHWC"):
     """The three reference lines
             x = slim.conv2d(x, channel_num, 3, 1, activation_fn=...)

@@ -65,6 +65,10 @@ typedef struct DpigConvDesc {
     int32_t res_after_act;/* fwd: 0: y = act(conv+bias+res); 1: y = act(conv+bias) + res, the     */
                           /*      reference res-block order (models.py:398-400,425-427,534-536)   */
     int32_t ldy2;         /* channel stride of the optional y_act output                          */
+    int32_t res_class;    /* fwd: 1: `residual` is [N][9][K], indexed by the 3x3 border class of  */
+                          /*      the output pixel (top|mid|bottom x left|mid|right): the exact   */
+                          /*      contribution of spatially constant input channels to a SAME 3x3 */
+                          /*      conv -- the tiled embedding of trainer.py:588-590   */
     int32_t split_k;      /* 0 = library heuristic, otherwise forced split count                  */
 } DpigConvDesc;
 
@@ -107,6 +111,12 @@ int dpig_act_bwd(const float* dy, int lddy, const float* y, int ldy, float* dz, 
 size_t dpig_colsum_workspace_bytes(int64_t rows, int cols);
 int dpig_colsum(const float* a, int lda, int64_t rows, int cols, float* out, float beta, void* ws,
                 size_t ws_bytes, void* stream);
+
+/* out[N][9][C] = per-image sums of a[N,H,W,C] over the 9 border classes (gradient of the
+ * class-indexed residual above; the backward half of the tiled-embedding collapse). */
+size_t dpig_border_class_sum_workspace_bytes(int N, int H, int W, int C);
+int dpig_border_class_sum(const float* a, int lda, int N, int H, int W, int C, float* out, void* ws,
+                          size_t ws_bytes, void* stream);
 
 /* ---- batch norm (training mode, biased variance, eps inside sqrt; batchnorm.py:30) ----------- */
 /* x,y: [rows, C] (rows = N*H*W).  save_mean / save_rstd: [C].  Optional fused LeakyReLU/ReLU. */

@@ -177,3 +177,40 @@ def test_bad_descriptor_raises(dev):
     w7 = torch.zeros(7, 7, 8, 8, device=dev)
     with pytest.raises(RuntimeError):
         H.conv2d_fwd(x, w7)
+
+
+def test_tiled_embedding_conv_collapse(dev):
+    """G.stem (models.py:520-528): conv3x3(concat([tile(emb), pose])) == class-GEMM + thin pose conv,
+    forward and every gradient, against the dense oracle on the materialised tensor."""
+    import dpig_amd.autograd as A
+    from oracle import ops as O
+    B, Hh, W, E, P, K = 3, 10, 6, 44, 18, 32
+    emb = _rand((B, E), 1).requires_grad_(True)
+    pose = _rand((B, Hh, W, P), 2)
+    w = (_rand((3, 3, E + P, K), 3) * 0.2).requires_grad_(True)
+    b = _rand((K,), 4).requires_grad_(True)
+    x = torch.cat([emb.reshape(B, 1, 1, E).expand(B, Hh, W, E), pose], dim=3)
+    y = O.relu(O.conv2d_same(x, w, b, 1))
+    dy = _rand(tuple(y.shape), 5)
+    y.backward(dy)
+    ge = emb.detach().float().to(dev).requires_grad_(True)
+    gw = w.detach().float().to(dev).requires_grad_(True)
+    gb = b.detach().float().to(dev).requires_grad_(True)
+    gy = A.tiled_emb_conv(ge, pose.float().to(dev), gw, gb)
+    _close(gy, y)
+    gy.backward(dy.float().to(dev))
+    _close(ge.grad, emb.grad, 5e-5)
+    _close(gw.grad, w.grad, 5e-5)
+    _close(gb.grad, b.grad, 5e-5)
+
+
+def test_border_class_sum(dev):
+    import dpig_amd.hip_ops as H
+    a = _rand((2, 7, 5, 12), 1)
+    ref = torch.zeros(2, 9, 12, dtype=torch.float64)
+    for y in range(7):
+        for x in range(5):
+            cy = 0 if y == 0 else (2 if y == 6 else 1)
+            cx = 0 if x == 0 else (2 if x == 4 else 1)
+            ref[:, cy * 3 + cx] += a[:, y, x]
+    _close(H.border_class_sum(a.float().to(dev)), ref)
