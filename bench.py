@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (BASELINE configs[1]: 16)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly (no hipGraph replay)")
     args = ap.parse_args()
 
     import numpy as np
@@ -118,6 +119,8 @@ def main():
     batch_d = synthetic.to_device(synthetic.make_batch(B, seed=101 + 2 * rank), dev)
     tr.init_net(batch_g)
     tr.step = 1                               # steady state: g_optim is only skipped at step 0
+    if not args.no_graph:
+        tr.enable_graphs(batch_g, batch_d)    # fwd+bwd+all-reduce+Adam of each optimizer op = one hipGraph
 
     def sync():
         if world > 1:
@@ -144,9 +147,11 @@ def main():
         # instrumented replay of the same step: HIP events around every conv-forward launch
         H.PROFILE = []
         nrep = max(1, min(3, args.steps))
+        graphs, tr._graphs = tr._graphs, None          # eager launches so that each one can be bracketed
         for _ in range(nrep):
             tr.train_step(batch_g, batch_d)
         torch.cuda.synchronize()
+        tr._graphs = graphs
         recs = [(k, f, e0.elapsed_time(e1) * 1e-3) for (k, f, e0, e1) in H.PROFILE]
         H.PROFILE = None
         fwd = [(f, t) for (k, f, t) in recs if k == "conv_fwd_mfma"]

@@ -61,6 +61,7 @@ SYMBOLS = {
     "dpig_upsample2x_fwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "dpig_upsample2x_bwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "dpig_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _i, _f, _vp]),
+    "dpig_adam_step_dev": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _f, _f, _f, _f, _vp]),
     "dpig_adam_multi": (_i, [_vp, _vp, _i, _i64, _vp, _f, _f, _f, _i, _f, _vp]),
     "dpig_sce_mean": (_i, [_vp, _i, _f, _vp, _vp, _f, _vp]),
     "dpig_l1_workspace_bytes": (_sz, [_i64]),

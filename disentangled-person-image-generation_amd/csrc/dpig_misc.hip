@@ -428,8 +428,9 @@ __device__ __forceinline__ void adam_one(float& p, float g, float& m, float& v, 
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g,
                                                    float* __restrict__ m, float* __restrict__ v, long n,
                                                    const float* __restrict__ lr_dev, float b1, float b2,
-                                                   float eps, float corr, float gscale) {
-    const float lr_t = lr_dev[0] * corr;
+                                                   float eps, float corr, float gscale,
+                                                   const float* __restrict__ corr_dev) {
+    const float lr_t = lr_dev[0] * (corr_dev ? corr_dev[0] : corr);
     const long n4 = n >> 2;
     float4* p4 = reinterpret_cast<float4*>(p);
     const float4* g4 = reinterpret_cast<const float4*>(g);
@@ -736,8 +737,29 @@ extern "C" int dpig_adam_step(float* p, const float* g, float* m, float* v, int6
     if (step < 1) return fail(DPIG_EINVAL, "adam: step must be >= 1");
     if (!(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v))) return fail(DPIG_EALIGN, "adam: 16B alignment required");
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, m,
-                       v, (long)n, lr_dev, beta1, beta2, eps, adam_corr(beta1, beta2, step), grad_scale);
+                       v, (long)n, lr_dev, beta1, beta2, eps, adam_corr(beta1, beta2, step), grad_scale,
+                       (const float*)nullptr);
     return check_launch("adam");
+}
+
+// Graph-replayable form: the step counter and the bias correction live in device memory
+// (state_dev = {int32 t; float corr}); one tick kernel advances them, so a captured hipGraph replays
+// the right lr_t every step (a host-side `step` argument would be frozen into the graph).
+__global__ void adam_tick_kernel(int* __restrict__ state, float b1, float b2) {
+    const int t = state[0] + 1;
+    state[0] = t;
+    reinterpret_cast<float*>(state)[1] = (float)(sqrt(1.0 - pow((double)b2, (double)t)) / (1.0 - pow((double)b1, (double)t)));
+}
+extern "C" int dpig_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev,
+                                  void* state_dev, float beta1, float beta2, float eps, float grad_scale,
+                                  void* stream) {
+    if (!p || !g || !m || !v || !lr_dev || !state_dev) return fail(DPIG_EINVAL, "adam: null pointer");
+    if (!(aligned16(p) && aligned16(g) && aligned16(m) && aligned16(v))) return fail(DPIG_EALIGN, "adam: 16B alignment required");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(adam_tick_kernel, dim3(1), dim3(1), 0, st, static_cast<int*>(state_dev), beta1, beta2);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for(n / 4 + 1)), dim3(256), 0, st, p, g, m, v, (long)n, lr_dev, beta1,
+                       beta2, eps, 1.0f, grad_scale, reinterpret_cast<const float*>(state_dev) + 1);
+    return check_launch("adam_dev");
 }
 extern "C" int dpig_adam_multi(const void* const* ptrs_dev, const int64_t* sizes_dev, int ntensors, int64_t max_size,
                                const float* lr_dev, float beta1, float beta2, float eps, int step, float grad_scale,

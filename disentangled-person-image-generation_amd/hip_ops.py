@@ -402,6 +402,13 @@ def adam_step(p, g, m, v, lr_dev, beta1, beta2, eps, step, grad_scale=1.0):
                                grad_scale, stream_ptr()), "adam_step")
 
 
+def adam_step_dev(p, g, m, v, lr_dev, state_dev, beta1, beta2, eps, grad_scale=1.0):
+    """TF Adam with the step counter / bias correction in device memory (hipGraph-replayable)."""
+    _require_gpu(p)
+    check(lib().dpig_adam_step_dev(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(lr_dev), ptr(state_dev), beta1,
+                                   beta2, eps, grad_scale, stream_ptr()), "adam_step_dev")
+
+
 def sce_mean(logits, label, want_grad=False, scale=1.0):
     _require_gpu(logits)
     logits = logits.contiguous()

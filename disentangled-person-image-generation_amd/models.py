@@ -44,8 +44,8 @@ def _normalised_boxes(ROI_bboxs, bbox_num, img_H, img_W):
     """models.py:405-413: pixel (y1,x1,y2,x2) -> /img_H, /img_W (division by H, not H-1), stacked
     part-major ([part0: all images, part1: all images, ...]) like tf.concat(body_roi_list, axis=0)."""
     b = ROI_bboxs[:, :bbox_num, :].to(torch.float32)
-    scale = torch.tensor([img_H, img_W, img_H, img_W], dtype=torch.float32, device=b.device)
-    b = b / scale
+    # scalar divisions only (no host->device constant upload: the step must be hipGraph-capturable)
+    b = torch.stack([b[..., 0] / img_H, b[..., 1] / img_W, b[..., 2] / img_H, b[..., 3] / img_W], dim=-1)
     batch = b.shape[0]
     boxes = b.permute(1, 0, 2).reshape(bbox_num * batch, 4).contiguous()
     box_ind = torch.arange(batch, dtype=torch.int32, device=b.device).repeat(bbox_num)

@@ -78,11 +78,13 @@ class TFAdam(object):
 
     def __init__(self, flat, lr_dev, beta1=0.9, beta2=0.999, eps=1e-8):
         self.flat, self.lr, self.b1, self.b2, self.eps, self.t = flat, lr_dev, beta1, beta2, eps, 0
+        # {int32 t, float corr} on the device: the launch sequence is hipGraph-replayable
+        self.state = torch.zeros(2, dtype=torch.int32, device=flat.flat.device)
 
     def step(self, grad_scale=1.0):
-        self.t += 1
+        self.t += 1          # host mirror, bookkeeping only
         f = self.flat
-        H.adam_step(f.flat, f.grad, f.m, f.v, self.lr, self.b1, self.b2, self.eps, self.t, grad_scale)
+        H.adam_step_dev(f.flat, f.grad, f.m, f.v, self.lr, self.state, self.b1, self.b2, self.eps, grad_scale)
 
 
 class GradAllReduce(object):
@@ -101,6 +103,10 @@ class GradAllReduce(object):
         if not self.enabled:
             return 1.0
         n = flat_grad.numel()
+        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
+            for o in range(0, n, self.bucket):      # stream-ordered inside a graph capture
+                self.dist.all_reduce(flat_grad[o:min(o + self.bucket, n)])
+            return 1.0 / self.world
         handles = []
         for o in range(0, n, self.bucket):
             handles.append(self.dist.all_reduce(flat_grad[o:min(o + self.bucket, n)], async_op=True))
@@ -179,6 +185,7 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         self.step = 0
         self.built = False
         self.allreduce = None
+        self._graphs = None
 
     def _getDiscriminator(self, wgan_gp, arch='DCGAN'):
         if 'DCGAN' == arch:
@@ -228,8 +235,54 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         self.allreduce.broadcast(self.G_flat.flat)
         self.allreduce.broadcast(self.D_flat.flat)
 
-    # ---- the two optimizer ops -----------------------------------------------------------------
+    # ---- hipGraph capture of the two optimizer ops ----------------------------------------------
+    def enable_graphs(self, batch_g, batch_d, warmup=2):
+        """Capture g_optim and d_optim (fwd + bwd + all-reduce + Adam, ~900 launches) into two
+        hipGraphs.  Shapes are static, parameters/gradients/Adam state live at fixed addresses, the
+        Adam step counter is on the device, so one replay per optimizer call is the whole host cost.
+        Inputs are copied into static buffers; outputs are static tensors overwritten by each replay."""
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        self._static_g = {k: v.clone() for k, v in batch_g.items()}
+        self._static_d = {k: v.clone() for k, v in batch_d.items()}
+        with torch.cuda.stream(side):
+            for _ in range(warmup):                 # sizes the workspace, pages every kernel in
+                self._g_optim_eager(self._static_g)
+                self._d_optim_eager(self._static_d)
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        gg, gd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(gg):
+            out_g = self._g_optim_eager(self._static_g)
+        with torch.cuda.graph(gd, pool=gg.pool()):
+            out_d = self._d_optim_eager(self._static_d)
+        self._graphs = (gg, out_g, gd, out_d)
+        self.g_opt.t -= 1          # capturing recorded one step() each without executing it
+        self.d_opt.t -= 1
+
+    def _feed(self, static, batch):
+        for k, v in batch.items():
+            if static[k].data_ptr() != v.data_ptr():
+                static[k].copy_(v, non_blocking=True)
+
     def g_optim(self, batch):
+        if self._graphs is None:
+            return self._g_optim_eager(batch)
+        self._feed(self._static_g, batch)
+        self._graphs[0].replay()
+        self.g_opt.t += 1
+        return self._graphs[1]
+
+    def d_optim(self, batch):
+        if self._graphs is None:
+            return self._d_optim_eager(batch)
+        self._feed(self._static_d, batch)
+        self._graphs[2].replay()
+        self.d_opt.t += 1
+        return self._graphs[3]
+
+    # ---- the two optimizer ops -----------------------------------------------------------------
+    def _g_optim_eager(self, batch):
         """sess.run(g_optim): fwd E,G,D(fake); g_loss = sce(D(G),1) + 20*L1; bwd D(dgrad only),G,E; Adam."""
         self.G_flat.zero_grad()
         self.D_flat.set_requires_grad(False)
@@ -246,7 +299,7 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         self.g_opt.step(scale)
         return {"g_loss": g_loss.detach(), "L1Loss": L1Loss.detach(), "g_loss_only": g_loss_only.detach(), "G": G.detach()}
 
-    def d_optim(self, batch):
+    def _d_optim_eager(self, batch):
         """sess.run(d_optim): fwd E,G (no grad), D(x), D(G); d_loss; bwd D; Adam(D)."""
         self.D_flat.zero_grad()
         with torch.no_grad():

@@ -169,6 +169,11 @@ int dpig_upsample2x_bwd(const float* dy, int N, int H, int W, int C, float* dx, 
  * `lr` is read from device memory (the reference keeps g_lr in a tf.Variable, trainer.py:56-59). */
 int dpig_adam_step(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev,
                    float beta1, float beta2, float eps, int step, float grad_scale, void* stream);
+/* Same update with the step counter in device memory: state_dev = {int32 t; float corr}, zero-initialised
+ * by the caller; every call advances t and the bias correction on the device, so the launch sequence
+ * can be captured once in a hipGraph and replayed (a host `step` would be frozen into the graph). */
+int dpig_adam_step_dev(float* p, const float* g, float* m, float* v, int64_t n, const float* lr_dev,
+                       void* state_dev, float beta1, float beta2, float eps, float grad_scale, void* stream);
 /* Multi-tensor form: ptrs[4*i+0..3] = {p, g, m, v} device pointers of tensor i, sizes[i] elements.
  * `ptrs` and `sizes` are DEVICE arrays. */
 int dpig_adam_multi(const void* const* ptrs_dev, const int64_t* sizes_dev, int ntensors, int64_t max_size,
