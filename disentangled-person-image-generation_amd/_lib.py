@@ -63,6 +63,8 @@ SYMBOLS = {
     "dpig_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _i, _f, _vp]),
     "dpig_adam_step_dev": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _vp, _f, _f, _f, _f, _vp]),
     "dpig_adam_multi": (_i, [_vp, _vp, _i, _i64, _vp, _f, _f, _f, _i, _f, _vp]),
+    "dpig_rmsprop_step": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _vp]),
+    "dpig_clip": (_i, [_vp, _i64, _f, _f, _vp]),
     "dpig_sce_mean": (_i, [_vp, _i, _f, _vp, _vp, _f, _vp]),
     "dpig_l1_workspace_bytes": (_sz, [_i64]),
     "dpig_l1_mean": (_i, [_vp, _vp, _i64, _vp, _vp, _f, _vp, _sz, _vp]),

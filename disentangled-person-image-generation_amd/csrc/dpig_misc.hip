@@ -466,6 +466,30 @@ __global__ __launch_bounds__(256) void adam_multi_kernel(const void* const* __re
 }
 
 // ---------------------------------------------------------------------------------------------
+// tf.train.RMSPropOptimizer (trainer.py:119-122, wgan / lsgan modes): ms = d*ms + (1-d)*g^2;
+// mom = mu*mom + lr*g/sqrt(ms+eps); p -= mom.  (TF initialises ms to ONES, mom to zeros.)
+// and the WGAN weight clipping of trainer.py:124-128.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void rmsprop_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                      float* __restrict__ ms, float* __restrict__ mom, long n,
+                                                      const float* __restrict__ lr_dev, float decay, float mu,
+                                                      float eps, float gscale) {
+    const float lr = lr_dev[0];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float gg = g[i] * gscale;
+        const float m2 = decay * ms[i] + (1.f - decay) * gg * gg;
+        const float mo = mu * mom[i] + lr * gg / sqrtf(m2 + eps);
+        ms[i] = m2;
+        mom[i] = mo;
+        p[i] -= mo;
+    }
+}
+__global__ __launch_bounds__(256) void clip_kernel(float* __restrict__ p, long n, float lo, float hi) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        p[i] = fminf(fmaxf(p[i], lo), hi);
+}
+
+// ---------------------------------------------------------------------------------------------
 // losses
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void sce_mean_kernel(const float* __restrict__ x, int n, float label,
@@ -771,6 +795,19 @@ extern "C" int dpig_adam_multi(const void* const* ptrs_dev, const int64_t* sizes
                        reinterpret_cast<const long*>(sizes_dev), lr_dev, beta1, beta2, eps,
                        adam_corr(beta1, beta2, step), grad_scale);
     return check_launch("adam_multi");
+}
+
+extern "C" int dpig_rmsprop_step(float* p, const float* g, float* ms, float* mom, int64_t n, const float* lr_dev,
+                                 float decay, float momentum, float eps, float grad_scale, void* stream) {
+    if (!p || !g || !ms || !mom || !lr_dev || n <= 0) return fail(DPIG_EINVAL, "rmsprop: bad arguments");
+    hipLaunchKernelGGL(rmsprop_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), p, g, ms, mom,
+                       (long)n, lr_dev, decay, momentum, eps, grad_scale);
+    return check_launch("rmsprop");
+}
+extern "C" int dpig_clip(float* p, int64_t n, float lo, float hi, void* stream) {
+    if (!p || n <= 0 || !(lo <= hi)) return fail(DPIG_EINVAL, "clip: bad arguments");
+    hipLaunchKernelGGL(clip_kernel, dim3(grid_for(n)), dim3(256), 0, static_cast<hipStream_t>(stream), p, (long)n, lo, hi);
+    return check_launch("clip");
 }
 
 extern "C" int dpig_sce_mean(const float* logits, int n, float label, float* out, float* dlogits, float scale,

@@ -409,6 +409,19 @@ def adam_step_dev(p, g, m, v, lr_dev, state_dev, beta1, beta2, eps, grad_scale=1
                                    beta2, eps, grad_scale, stream_ptr()), "adam_step_dev")
 
 
+def rmsprop_step(p, g, ms, mom, lr_dev, decay=0.9, momentum=0.0, eps=1e-10, grad_scale=1.0):
+    """In-place tf.train.RMSPropOptimizer update on flat buffers."""
+    _require_gpu(p)
+    check(lib().dpig_rmsprop_step(ptr(p), ptr(g), ptr(ms), ptr(mom), p.numel(), ptr(lr_dev), decay, momentum, eps,
+                                  grad_scale, stream_ptr()), "rmsprop_step")
+
+
+def clip_(p, lo, hi):
+    """In-place clip_by_value (WGAN critic weight clipping, trainer.py:124-128)."""
+    _require_gpu(p)
+    check(lib().dpig_clip(ptr(p), p.numel(), float(lo), float(hi), stream_ptr()), "clip")
+
+
 def sce_mean(logits, label, want_grad=False, scale=1.0):
     _require_gpu(logits)
     logits = logits.contiguous()

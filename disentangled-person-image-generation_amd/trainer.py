@@ -87,6 +87,39 @@ class TFAdam(object):
         H.adam_step_dev(f.flat, f.grad, f.m, f.v, self.lr, self.state, self.b1, self.b2, self.eps, grad_scale)
 
 
+class TFRMSProp(object):
+    """tf.train.RMSPropOptimizer(lr) with TF's defaults decay=0.9, momentum=0, epsilon=1e-10 and TF's slot
+    initialisation (rms = ones, momentum = zeros) -- wgan / lsgan modes, trainer.py:119-122,142-146."""
+
+    def __init__(self, flat, lr_dev, decay=0.9, momentum=0.0, eps=1e-10):
+        self.flat, self.lr, self.decay, self.mu, self.eps, self.t = flat, lr_dev, decay, momentum, eps, 0
+        flat.m.fill_(1.0)      # `rms` slot
+        flat.v.zero_()         # `momentum` slot
+
+    def step(self, grad_scale=1.0):
+        self.t += 1
+        f = self.flat
+        H.rmsprop_step(f.flat, f.grad, f.m, f.v, self.lr, self.decay, self.mu, self.eps, grad_scale)
+
+
+def get_optimizers(wgan_gp, G_flat, D_flat, g_lr, d_lr):
+    """trainer.py:116-149 `_getOptimizer`: the optimizer pair each GAN mode trains with.  The wgan
+    weight clipping op of :124-128 is `clip_disc_weights` below."""
+    if wgan_gp.MODE in ('wgan', 'lsgan'):
+        return TFRMSProp(G_flat, g_lr), TFRMSProp(D_flat, d_lr)
+    elif wgan_gp.MODE == 'wgan-gp':
+        return (TFAdam(G_flat, g_lr, beta1=0.5, beta2=0.9, eps=1e-8), TFAdam(D_flat, d_lr, beta1=0.5, beta2=0.9, eps=1e-8))
+    elif wgan_gp.MODE == 'dcgan':
+        return (TFAdam(G_flat, g_lr, beta1=0.5, beta2=0.999, eps=1e-8), TFAdam(D_flat, d_lr, beta1=0.5, beta2=0.999, eps=1e-8))
+    raise Exception()
+
+
+def clip_disc_weights(D_flat, lo=-.01, hi=.01):
+    """trainer.py:124-128: clip every `Discriminator` parameter to [-0.01, 0.01] -- one launch on the flat buffer
+    (the 16-byte alignment padding between tensors is zero and stays zero)."""
+    H.clip_(D_flat.flat, lo, hi)
+
+
 class GradAllReduce(object):
     """Data-parallel gradient exchange: sum-all-reduce of the flat gradient buffer over RCCL in
     ~32 MB slices (xGMI is point-to-point: a few large collectives, not hundreds of small ones);
@@ -217,6 +250,12 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         # tf.transpose(x, [0,3,1,2]) (trainer.py:601-602): a free view here
         return self.Discriminator_fn(img_nhwc.permute(0, 3, 1, 2), input_dim=3)
 
+    def disc_pair(self, x, G, need_real=True):
+        """(D_z_pos, D_z_neg).  Model 1 calls D separately on real and fake (trainer.py:601-602): two
+        independent BatchNorm statistic sets; g_loss never needs the real pass (TF prunes it)."""
+        D_z_pos = self.discriminate(x) if need_real else None
+        return D_z_pos, self.discriminate(G)
+
     def init_net(self, batch):
         """Create every variable (one forward, like TF graph construction) and set up optimizers."""
         with torch.no_grad():
@@ -228,9 +267,7 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         self.D_var = lib.params_with_name('Discriminator.')  # trainer.py:603
         self.G_flat = FlatParams(self.G_var)
         self.D_flat = FlatParams(self.D_var)
-        # _getOptimizer, MODE == 'dcgan' (trainer.py:136-140): Adam(beta1=0.5), eps/beta2 TF defaults
-        self.g_opt = TFAdam(self.G_flat, self.g_lr, beta1=0.5, beta2=0.999, eps=1e-8)
-        self.d_opt = TFAdam(self.D_flat, self.d_lr, beta1=0.5, beta2=0.999, eps=1e-8)
+        self.g_opt, self.d_opt = get_optimizers(self.wgan_gp, self.G_flat, self.D_flat, self.g_lr, self.d_lr)
         self.allreduce = GradAllReduce()
         self.allreduce.broadcast(self.G_flat.flat)
         self.allreduce.broadcast(self.D_flat.flat)
@@ -288,7 +325,7 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         self.D_flat.set_requires_grad(False)
         embs, _ = self.encode(batch)
         G, _ = self.generate(embs, batch["pose"])
-        D_z_neg = self.discriminate(G)
+        _, D_z_neg = self.disc_pair(batch["x"], G, need_real=False)
         g_loss_only, _ = gan_loss(self.wgan_gp, None, D_z_neg)
         L1Loss = A.l1_mean(G, batch["x"])
         g_loss = g_loss_only + L1Loss * 20           # trainer.py:623
@@ -305,8 +342,7 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         with torch.no_grad():
             embs, _ = self.encode(batch)
             G, _ = self.generate(embs, batch["pose"])
-        D_z_pos = self.discriminate(batch["x"])
-        D_z_neg = self.discriminate(G)
+        D_z_pos, D_z_neg = self.disc_pair(batch["x"], G, need_real=True)
         _, d_loss = gan_loss(self.wgan_gp, D_z_pos, D_z_neg)
         d_loss.backward()
         self.D_flat.finalize()

@@ -180,6 +180,13 @@ int dpig_adam_multi(const void* const* ptrs_dev, const int64_t* sizes_dev, int n
                     const float* lr_dev, float beta1, float beta2, float eps, int step, float grad_scale,
                     void* stream);
 
+/* ---- TF RMSProp (trainer.py:119-122; wgan / lsgan modes) and WGAN weight clipping (:124-128) -------
+ * ms = decay*ms + (1-decay)*g^2; mom = momentum*mom + lr*g/sqrt(ms+eps); p -= mom.
+ * TF initialises the `rms` slot to ones and `momentum` to zeros (the caller owns the buffers). */
+int dpig_rmsprop_step(float* p, const float* g, float* ms, float* mom, int64_t n, const float* lr_dev,
+                      float decay, float momentum, float eps, float grad_scale, void* stream);
+int dpig_clip(float* p, int64_t n, float lo, float hi, void* stream);
+
 /* ---- losses (trainer.py:238-245, 607, 623) --------------------------------------------------- */
 /* out[0] = mean_i sce(logits_i, label) ; dlogits_i = scale*(sigmoid(x_i)-label)/n (dlogits may be NULL) */
 int dpig_sce_mean(const float* logits, int n, float label, float* out, float* dlogits, float scale,

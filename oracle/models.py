@@ -343,3 +343,46 @@ def batch_to_torch(batch, dtype=torch.float64):
         t = torch.as_tensor(v)
         out[k] = t.to(dtype) if t.is_floating_point() else t
     return out
+
+
+# ---- stage-II pieces (trainer.py:715-868) and the DeepFashion 256 variant (trainer_256.py:31-88) -------------
+def gaussian_fc_res(P, z, out_channel, repeat_num=4, hidden_num=512, scope="Gaussian_FC_Fg/G_FC", alpha=0.2):
+    """models.py:474-486 with the LeakyReLU(0.2) the stage-II trainer passes (trainer.py:753, B-11)."""
+    sc = _Scope(scope)
+    act = lambda t: O.leaky_relu(t, alpha)  # noqa: E731
+    z = _fc(P, sc, z, hidden_num, act)
+    for _ in range(repeat_num):
+        res = z
+        z = _fc(P, sc, z, hidden_num, act)
+        z = _fc(P, sc, z, hidden_num, act)
+        z = res + z
+    return _fc(P, sc, z, out_channel, None)
+
+
+def stage2_losses(P, real, z, side="Fg", hidden=512):
+    """wgan mode (trainer.py:218-220): g = -mean(D(fake)); d = mean(D(fake)) - mean(D(real))."""
+    fake = gaussian_fc_res(P, z, real.shape[1], 4, hidden, scope="Gaussian_FC_%s/G_FC" % side)
+    d_fake = fc_discriminator(P, fake, fake.shape[1], name="%s_FCDis_" % side)
+    d_real = fc_discriminator(P, real, real.shape[1], name="%s_FCDis_" % side)
+    return -d_fake.mean(), d_fake.mean() - d_real.mean(), fake
+
+
+def stage1_256_forward(P, batch, hidden_num=128, z_num=64, repeat_num=6):
+    """trainer_256.py:31-66: E = BodyROIVis(repeat_num+1, roi 64); G with repeat_num-1 levels; D on [x; G]."""
+    x = batch["x"]
+    B, H, W, _ = x.shape
+    embs = encoder_roi(P, x, batch["part_bbox"], batch["part_vis"], 7, 32, repeat_num + 1, hidden_num, roi_size=64)
+    embs_rep = embs.reshape(B, 1, 1, -1).expand(B, H, W, embs.shape[1])
+    G, _ = generator_uae(P, embs_rep, batch["pose"], 3, z_num, repeat_num - 1, hidden_num)
+    D_z = dcgan_discriminator(P, torch.cat([x, G], dim=0), "dcgan")
+    D_pos, D_neg = torch.split(D_z, D_z.shape[0] // 2)
+    g_only, d_loss = gan_loss("dcgan", D_pos, D_neg)
+    l1 = (G - x).abs().mean()
+    return {"embs": embs, "G": G, "D_z": D_z, "g_loss": g_only + 20.0 * l1, "d_loss": d_loss, "L1Loss": l1}
+
+
+def tf_rmsprop_step(p, g, ms, mom, lr, decay=0.9, momentum=0.0, eps=1e-10):
+    """tf.train.RMSPropOptimizer (rms slot initialised to ones): returns new (p, ms, mom)."""
+    ms = decay * ms + (1 - decay) * g * g
+    mom = momentum * mom + lr * g / torch.sqrt(ms + eps)
+    return p - mom, ms, mom

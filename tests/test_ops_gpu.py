@@ -197,3 +197,39 @@ def test_tflib_ops_boundary(dev):
         lib.ops.linear.Linear('T.bad', 4, 4, flat[:, :4], initialization='nope')
     assert len(lib.params_with_name('T.')) == len([n for n in lib._params if 'T.' in n])
     lib.delete_all_params()
+
+
+def test_rmsprop_and_clip(dev):
+    import dpig_amd.hip_ops as H
+    from oracle import models as OM
+    n = 777
+    p = _rand((n,), 1); g1 = _rand((n,), 2) * 0.3; g2 = _rand((n,), 3) * 0.3
+    rp, rms, rmom = p.clone(), torch.ones(n, dtype=torch.float64), torch.zeros(n, dtype=torch.float64)
+    for g in (g1, g2):
+        rp, rms, rmom = OM.tf_rmsprop_step(rp, g, rms, rmom, 2e-3)
+    gp = p.float().to(dev); ms = torch.ones(n, device=dev); mom = torch.zeros(n, device=dev)
+    lr = torch.full((1,), 2e-3, device=dev)
+    for g in (g1, g2):
+        H.rmsprop_step(gp, g.float().to(dev), ms, mom, lr)
+    _close(gp, rp, 1e-5)
+    H.clip_(gp, -0.01, 0.01)
+    _close(gp, rp.clamp(-0.01, 0.01), 1e-5)
+    assert float(gp.max()) <= 0.01 and float(gp.min()) >= -0.01
+
+
+def test_deconv_backward(dev):
+    """Deconv2D (conv2d_transpose) gradients: d/dx = F(dy), d/dw = wgrad_F(dy, x)."""
+    import dpig_amd.autograd as A
+    from oracle import ops as O
+    x = _rand((2, 4, 3, 8), 1).requires_grad_(True)
+    w = (_rand((5, 5, 6, 8), 2) * 0.2).requires_grad_(True)     # (k, k, Cout, Cin)
+    y = O.conv2d_transpose_same(x, w, None, 2)
+    dy = _rand(tuple(y.shape), 3)
+    y.backward(dy)
+    gx = x.detach().float().to(dev).requires_grad_(True)
+    gw = w.detach().float().to(dev).requires_grad_(True)
+    gy = A.conv2d_transpose(gx, gw, None)
+    _close(gy, y, 1e-4)
+    gy.backward(dy.float().to(dev))
+    _close(gx.grad, x.grad, 1e-4)
+    _close(gw.grad, w.grad, 1e-4)

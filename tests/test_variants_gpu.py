@@ -1,0 +1,142 @@
+"""Parity of the remaining model variants on the hot path against the CPU oracle (small widths):
+stage-II embedding GAN pieces (GaussianFCRes mapper + FC critic, wgan mode, RMSProp + clipping;
+trainer.py:715-868), the DeepFashion 256x256 stage-I graph (trainer_256.py:31-88: deeper ROI encoder,
+D on the concatenated pair with joint BatchNorm statistics, 8 logit rows per image), and the
+LayerNorm discriminator that MODE='wgan-gp' selects (wgan_gp.py:34-40)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(got, ref):
+    ref = ref.detach().double()
+    return (got.detach().double().cpu() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-12)
+
+
+def _load(P, dev):
+    import dpig_amd.tflib as lib
+    from dpig_amd import slim
+    lib.delete_all_params()
+    slim.reset_scopes()
+    lib.set_device(dev)
+    for n, v in P.state_numpy().items():
+        lib.param(n, v, trainable=P.trainable[n])
+
+
+def test_stage2_mapper_critic_wgan(dev):
+    import dpig_amd.tflib as lib
+    from dpig_amd import synthetic
+    from dpig_amd.trainer import Config
+    from dpig_amd.trainer_stage2 import DPIG_Encoder_subSampleAppNetFgBg_GAN_BodyROI
+    from oracle import models as OM
+    B, HID = 4, 8
+    g = torch.Generator().manual_seed(0)
+    P = OM.ParamStore(seed=5)
+    batch_np = synthetic.make_batch(B, seed=9)
+    ob = OM.batch_to_torch(batch_np)
+    with torch.no_grad():
+        embs = OM.encoder_fgbg(P, ob["x"], ob["mask_r6"], ob["part_bbox"], ob["part_vis"], 7, 32, 5, HID)
+    real = {"Fg": embs[:, :224], "Bg": embs[:, 224:]}
+    z = {"Fg": torch.randn(B, 224, generator=g, dtype=torch.float64) * 0.2,
+         "Bg": torch.randn(B, 128, generator=g, dtype=torch.float64) * 0.2}
+    ref = {}
+    for side, hid in (("Fg", 512), ("Bg", 256)):
+        ref[side] = OM.stage2_losses(P, real[side], z[side], side, hid)
+    _load(P, dev)
+    tr = DPIG_Encoder_subSampleAppNetFgBg_GAN_BodyROI(Config(batch_size=B, conv_hidden_num=HID, g_lr=1e-3, d_lr=1e-3), dev)
+    gb = synthetic.to_device(batch_np, dev)
+    tr.init_net(gb)
+    assert set(lib._params.keys()) == set(P.p.keys())
+    fg, bg, _ = tr.encode(gb)
+    assert _rel(torch.cat([fg, bg], 1), embs) < 1e-4
+    for side, key in (("fg", "Fg"), ("bg", "Bg")):
+        g_ref, d_ref, fake_ref = ref[key]
+        gnames = [n for n in P.p if n.startswith("Gaussian_FC_%s/" % key)]
+        dnames = [n for n in P.p if ("%s_FCDis_" % key) in n]
+        gg = dict(zip(gnames, torch.autograd.grad(g_ref, [P.p[n] for n in gnames], retain_graph=True)))
+        dg = dict(zip(dnames, torch.autograd.grad(d_ref, [P.p[n] for n in dnames])))
+        zz = z[key].float().to(dev)
+        d_loss = tr.d_optim_embs(side, gb, z=zz)               # critic first: mapper weights still the oracle's
+        assert abs(d_loss.item() - d_ref.item()) < 1e-4 * max(abs(d_ref.item()), 1e-3)
+        for n in dnames:
+            assert _rel(lib._params[n]._dpig_grad, dg[n]) < 2e-3, n
+        # RMSProp (rms slot = ones) + clip to +-0.01 (trainer.py:119-128)
+        for n in dnames:
+            p_new, _, _ = OM.tf_rmsprop_step(P.p[n].detach(), dg[n], torch.ones_like(dg[n]), torch.zeros_like(dg[n]), 1e-3)
+            assert (lib._params[n].detach().double().cpu() - p_new.clamp(-0.01, 0.01)).abs().max().item() < 2e-5, n
+        with torch.no_grad():                                   # restore the critic for the mapper check
+            for n in dnames:
+                lib._params[n].copy_(P.p[n].to(torch.float32))
+        g_loss = tr.g_optim_embs(side, z=zz)
+        assert abs(g_loss.item() - g_ref.item()) < 1e-4 * max(abs(g_ref.item()), 1e-3)
+        for n in gnames:
+            assert _rel(lib._params[n]._dpig_grad, gg[n]) < 2e-3, n
+    out = tr.train_step(gb)                # step 0: no mapper update, 5 clipped critic updates per side
+    assert "g_loss_embs_fg" not in out and "d_loss_embs_bg" in out
+    out = tr.train_step(gb)
+    assert "g_loss_embs_fg" in out and "g_loss_embs_bg" in out
+    assert tr.opts["fg"][1].t == 1 + 5 + 5 and tr.opts["fg"][0].t == 1 + 1
+    for _, df in tr.flats.values():
+        assert float(df.flat.abs().max()) <= 0.01 + 1e-9
+    lib.delete_all_params()
+
+
+def test_stage1_256_graph(dev):
+    """Model 101 at 256x256, width 8: activations, the 8-rows-per-image logits (F8), losses, one step."""
+    import dpig_amd.tflib as lib
+    from dpig_amd import synthetic
+    from dpig_amd.trainer import Config
+    from dpig_amd.trainer_256 import DPIG_Encoder_GAN_BodyROI_256
+    from oracle import models as OM
+    B, HID, ZN = 2, 8, 8
+    batch_np = synthetic.make_batch(B, img_H=256, img_W=256, seed=4)
+    ob = OM.batch_to_torch(batch_np)
+    P = OM.ParamStore(seed=6)
+    with torch.no_grad():
+        ref = OM.stage1_256_forward(P, ob, HID, ZN, 6)
+    _load(P, dev)
+    cfg = Config(batch_size=B, img_H=256, img_W=256, conv_hidden_num=HID, z_num=ZN)
+    assert cfg.repeat_num == 6
+    tr = DPIG_Encoder_GAN_BodyROI_256(cfg, dev)
+    gb = synthetic.to_device(batch_np, dev)
+    tr.init_net(gb)
+    assert set(lib._params.keys()) == set(P.p.keys())
+    with torch.no_grad():
+        embs, _ = tr.encode(gb)
+        G, _ = tr.generate(embs, gb["pose"])
+        D_pos, D_neg = tr.disc_pair(gb["x"], G)
+    assert tuple(embs.shape) == (B, 224) and tuple(D_pos.shape) == (8 * B,) and tuple(D_neg.shape) == (8 * B,)
+    assert _rel(embs, ref["embs"]) < 1e-4 and _rel(G, ref["G"]) < 1e-4
+    assert _rel(torch.cat([D_pos, D_neg]), ref["D_z"]) < 1e-3
+    o = tr.train_step(gb, gb)              # step 0: d_optim only
+    assert abs(o["d_loss"].item() - ref["d_loss"].item()) < 1e-3 * abs(ref["d_loss"].item())
+    o = tr.train_step(gb, gb)
+    assert torch.isfinite(o["g_loss"]) and torch.isfinite(o["d_loss"])
+    lib.delete_all_params()
+
+
+def test_layernorm_discriminator_wgan_gp_mode(dev):
+    """MODE='wgan-gp' swaps the discriminator's BatchNorm for LayerNorm (wgan_gp.py:34-40)."""
+    import dpig_amd.tflib as lib
+    from dpig_amd.wgan_gp import WGAN_GP
+    from oracle import models as OM
+    g = torch.Generator().manual_seed(1)
+    x = torch.rand(3, 128, 64, 3, generator=g, dtype=torch.float64) * 2 - 1
+    P = OM.ParamStore(seed=8)
+    xr = x.clone().requires_grad_(True)
+    ref = OM.dcgan_discriminator(P, xr, "wgan-gp")
+    names = OM.d_var_names(P)
+    grads = torch.autograd.grad(ref.sum(), [xr] + [P.p[n] for n in names])
+    _load(P, dev)
+    wg = WGAN_GP(MODE='wgan-gp', BATCH_SIZE=3)
+    xg = x.float().to(dev).requires_grad_(True)
+    out = wg.DCGANDiscriminator(xg.permute(0, 3, 1, 2), input_dim=3)
+    assert 'Discriminator.BN2.moving_mean' not in lib._params          # LayerNorm creates no moving stats
+    assert _rel(out, ref) < 1e-4
+    out.sum().backward()
+    assert _rel(xg.grad, grads[0]) < 2e-3
+    for n, gr in zip(names, grads[1:]):
+        assert _rel(lib._params[n].grad, gr) < 2e-3, n
+    lib.delete_all_params()
