@@ -52,6 +52,8 @@ SYMBOLS = {
     "dpig_ln_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _i, _f, _vp, _vp, _vp, _vp]),
     "dpig_ln_workspace_bytes": (_sz, [_i, _i, _i]),
     "dpig_ln_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dpig_ln_bwd2_workspace_bytes": (_sz, [_i, _i, _i]),
+    "dpig_ln_bwd2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dpig_linear_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "dpig_linear_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
     "dpig_linear_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),

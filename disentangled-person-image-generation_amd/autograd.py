@@ -38,6 +38,77 @@ def _sink_small(p, g):
     return None
 
 
+# ---- second-level functions: the backward passes themselves, differentiable once more -------------
+# Used only when a backward pass runs with create_graph=True (the WGAN-GP penalty is a function of
+# dD/dx, trainer.py:222-236).  LeakyReLU/ReLU are piecewise linear, so nothing flows through the masks;
+# the conv / linear backward-data ops are linear in (dz, w): their adjoints are the forward op and wgrad
+# (SURVEY Appendix E "up-sweep"); LayerNorm needs a genuine second-order kernel (dpig_ln_bwd2).
+class _ActBwdFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dy, y, act, alpha):
+        ctx.save_for_backward(y)
+        ctx.cfg = (act, alpha)
+        return H.act_bwd(dy, y, act, alpha)
+
+    @staticmethod
+    def backward(ctx, ddz):
+        (y,) = ctx.saved_tensors
+        return H.act_bwd(ddz, y, *ctx.cfg), None, None, None
+
+
+class _ConvDgradFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dz, w, in_shape, stride, upsample2x):
+        ctx.save_for_backward(dz, w)
+        ctx.cfg = (stride, upsample2x)
+        return H.conv2d_dgrad(dz, w, in_shape, stride=stride, upsample2x=upsample2x)
+
+    @staticmethod
+    def backward(ctx, ddx):
+        dz, w = ctx.saved_tensors
+        stride, up = ctx.cfg
+        d_dz = H.conv2d_fwd(ddx, w, None, stride=stride, upsample2x=up) if ctx.needs_input_grad[0] else None
+        d_w = None
+        if ctx.needs_input_grad[1]:
+            d_w = _sink(w, lambda o, beta: H.conv2d_wgrad(ddx, dz, tuple(w.shape), stride=stride, upsample2x=up,
+                                                          out=o, beta=beta))
+        return d_dz, d_w, None, None, None
+
+
+class _LinearDgradFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dz, w):
+        ctx.save_for_backward(dz, w)
+        return H.linear_dgrad(dz, w)
+
+    @staticmethod
+    def backward(ctx, ddx):
+        dz, w = ctx.saved_tensors
+        ddx = ddx.contiguous()
+        d_dz = H.linear_fwd(ddx, w) if ctx.needs_input_grad[0] else None
+        d_w = None
+        if ctx.needs_input_grad[1]:
+            d_w = _sink(w, lambda o, beta: H.linear_wgrad(ddx, dz, out=o, beta=beta))
+        return d_dz, d_w
+
+
+class _LNBwdFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dy, x, y, scale, mean, rstd, act, alpha):
+        ctx.save_for_backward(dy, x, y, scale, mean, rstd)
+        ctx.cfg = (act, alpha)
+        dx, _, _ = H.ln_bwd(dy, x, y, scale, mean, rstd, act, alpha)
+        return dx
+
+    @staticmethod
+    def backward(ctx, u):
+        dy, x, y, scale, mean, rstd = ctx.saved_tensors
+        act, alpha = ctx.cfg
+        d_dy, d_x, d_scale = H.ln_bwd2(u, dy, x, y, scale, mean, rstd, act, alpha)
+        ds = _sink_small(scale, d_scale) if ctx.needs_input_grad[3] else None
+        return d_dy, d_x, None, ds, None, None, None, None
+
+
 class _ConvFn(torch.autograd.Function):
     """y = act(conv_SAME(x, w) + b)   [optionally on a nearest-2x-upsampled x, 1x1 only]."""
 
@@ -53,10 +124,18 @@ class _ConvFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
         stride, act, alpha, up, has_b = ctx.cfg
-        dz = H.act_bwd(dy, y, act, alpha) if act != ACT_NONE else dy
+        second = torch.is_grad_enabled()       # backward under create_graph=True
+        if second:
+            dz = _ActBwdFn.apply(dy, y, act, alpha) if act != ACT_NONE else dy
+        else:
+            dz = H.act_bwd(dy, y, act, alpha) if act != ACT_NONE else dy
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
-            dx = H.conv2d_dgrad(dz, w, tuple(x.shape), stride=stride, upsample2x=up)
+            if second:
+                dx = _ConvDgradFn.apply(dz, w, tuple(x.shape), stride, up)
+                dz = dz.detach()
+            else:
+                dx = H.conv2d_dgrad(dz, w, tuple(x.shape), stride=stride, upsample2x=up)
         if ctx.needs_input_grad[1]:
             dw = _sink(w, lambda o, beta: H.conv2d_wgrad(x, dz, tuple(w.shape), stride=stride, upsample2x=up,
                                                          out=o, beta=beta))
@@ -189,6 +268,8 @@ class _ActFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         (y,) = ctx.saved_tensors
+        if torch.is_grad_enabled():
+            return _ActBwdFn.apply(dy, y, *ctx.cfg), None, None
         return H.act_bwd(dy, y, *ctx.cfg), None, None
 
 
@@ -237,8 +318,13 @@ class _LinearFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, w, y = ctx.saved_tensors
         act, alpha, has_b = ctx.cfg
-        dz = H.act_bwd(dy, y, act, alpha) if act != ACT_NONE else dy.contiguous()
-        dx = H.linear_dgrad(dz, w) if ctx.needs_input_grad[0] else None
+        if torch.is_grad_enabled():            # backward under create_graph=True
+            dz = _ActBwdFn.apply(dy, y, act, alpha) if act != ACT_NONE else dy.contiguous()
+            dx = _LinearDgradFn.apply(dz, w) if ctx.needs_input_grad[0] else None
+            dz = dz.detach()
+        else:
+            dz = H.act_bwd(dy, y, act, alpha) if act != ACT_NONE else dy.contiguous()
+            dx = H.linear_dgrad(dz, w) if ctx.needs_input_grad[0] else None
         dw = db = None
         if ctx.needs_input_grad[1]:
             dw = _sink(w, lambda o, beta: H.linear_wgrad(x, dz, out=o, beta=beta))
@@ -289,7 +375,13 @@ class _LayerNormFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, scale, mean, rstd, y = ctx.saved_tensors
         act, alpha = ctx.cfg
-        dx, dscale, doffset = H.ln_bwd(dy, x, y, scale, mean, rstd, act, alpha)
+        if torch.is_grad_enabled():            # backward under create_graph=True
+            dx = _LNBwdFn.apply(dy, x, y, scale, mean, rstd, act, alpha)
+            if not (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+                return dx, None, None, None, None, None
+            _, dscale, doffset = H.ln_bwd(dy.detach(), x, y, scale, mean, rstd, act, alpha)
+        else:
+            dx, dscale, doffset = H.ln_bwd(dy, x, y, scale, mean, rstd, act, alpha)
         ds = _sink_small(scale, dscale) if ctx.needs_input_grad[1] else None
         do = _sink_small(ctx.offset_ref, doffset) if ctx.needs_input_grad[2] else None
         return dx, ds, do, None, None, None

@@ -316,6 +316,69 @@ __global__ __launch_bounds__(1024) void ln_bwd_kernel(const float* __restrict__ 
     }
 }
 
+// Second-order LayerNorm: the backward of ln_bwd_kernel (needed by the WGAN-GP penalty, whose loss is a
+// function of dD/dx -- trainer.py:233-236; SURVEY Appendix E "down-sweep").  With g = dz*gamma,
+// dx = r*(g - mean(g) - xh*mean(g*xh)) and upstream u = dP/d(dx):
+//   dP/dg_i  = r*(u_i - mean(u) - xh_i*mean(u*xh))
+//   dP/dxh_i = -r*(mean(g*xh)*u_i + mean(u*xh)*g_i),   dP/dr = sum_i u_i*(g_i - mean(g) - xh_i*mean(g*xh))
+//   dP/dx_j  = r*(q_j - mean(q) - xh_j*mean(q*xh)) - (dP/dr)*r^2*xh_j/L          (q = dP/dxh)
+// gs = dP/dg * dz is written for the per-channel gamma gradient (column sum over samples).
+__global__ __launch_bounds__(1024) void ln_bwd2_kernel(const float* __restrict__ u, const float* __restrict__ dy,
+                                                       const float* __restrict__ x, const float* __restrict__ y,
+                                                       int P, int C, const float* __restrict__ scale,
+                                                       const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, int act, float alpha,
+                                                       float* __restrict__ d_dy, float* __restrict__ d_x,
+                                                       float* __restrict__ gs) {
+    __shared__ float red[17];
+    const long L = (long)P * C;
+    const long base = (long)blockIdx.x * L;
+    const float mu = mean[blockIdx.x], r = rstd[blockIdx.x];
+    const float invL = 1.0f / (float)L;
+    float su = 0.f, sux = 0.f, sg = 0.f, sgx = 0.f;
+    for (long i = threadIdx.x; i < L; i += 1024) {
+        const int c = (int)(i % C);
+        float dz = dy[base + i];
+        if (act != DPIG_ACT_NONE) dz *= act_grad(y[base + i], act, alpha);
+        const float g = dz * scale[c];
+        const float xh = (x[base + i] - mu) * r;
+        const float uu = u[base + i];
+        su += uu; sux += uu * xh; sg += g; sgx += g * xh;
+    }
+    const float mu_u = block_sum_1024(su, red) * invL;
+    const float cc = block_sum_1024(sux, red) * invL;
+    const float a = block_sum_1024(sg, red) * invL;
+    const float b = block_sum_1024(sgx, red) * invL;
+    float s1 = 0.f, sq = 0.f, sqx = 0.f;
+    for (long i = threadIdx.x; i < L; i += 1024) {
+        const int c = (int)(i % C);
+        float dz = dy[base + i];
+        if (act != DPIG_ACT_NONE) dz *= act_grad(y[base + i], act, alpha);
+        const float g = dz * scale[c];
+        const float xh = (x[base + i] - mu) * r;
+        const float uu = u[base + i];
+        const float q = -r * (b * uu + cc * g);
+        s1 += uu * (g - a - xh * b);
+        sq += q; sqx += q * xh;
+    }
+    const float U1 = block_sum_1024(s1, red);
+    const float mq = block_sum_1024(sq, red) * invL;
+    const float mqx = block_sum_1024(sqx, red) * invL;
+    for (long i = threadIdx.x; i < L; i += 1024) {
+        const int c = (int)(i % C);
+        const float ag = (act != DPIG_ACT_NONE) ? act_grad(y[base + i], act, alpha) : 1.f;
+        const float dz = dy[base + i] * ag;
+        const float g = dz * scale[c];
+        const float xh = (x[base + i] - mu) * r;
+        const float uu = u[base + i];
+        const float dg = r * (uu - mu_u - xh * cc);
+        const float q = -r * (b * uu + cc * g);
+        d_dy[base + i] = dg * scale[c] * ag;
+        d_x[base + i] = r * (q - mq - xh * mqx) - U1 * r * r * xh * invL;
+        gs[base + i] = dg * dz;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // tf.image.crop_and_resize (bilinear, extrapolation_value 0) and its image gradient
 // ---------------------------------------------------------------------------------------------
@@ -687,6 +750,26 @@ extern "C" int dpig_ln_bwd(const float* dy, const float* x, const float* y, int 
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(N), dim3(1024), 0, st, dy, x, y, P, C, scale, save_mean, save_rstd, act,
                        alpha, dx);
     return check_launch("ln_bwd");
+}
+
+extern "C" size_t dpig_ln_bwd2_workspace_bytes(int N, int P, int C) {
+    return (size_t)N * P * C * sizeof(float) + dpig_colsum_workspace_bytes((int64_t)N * P, C);
+}
+extern "C" int dpig_ln_bwd2(const float* u, const float* dy, const float* x, const float* y, int N, int P, int C,
+                            const float* scale, const float* save_mean, const float* save_rstd, int act, float alpha,
+                            float* d_dy, float* d_x, float* d_scale, void* ws, size_t ws_bytes, void* stream) {
+    if (!u || !dy || !x || !scale || !save_mean || !save_rstd || !d_dy || !d_x || !d_scale)
+        return fail(DPIG_EINVAL, "ln_bwd2: null pointer");
+    if (act != DPIG_ACT_NONE && !y) return fail(DPIG_EINVAL, "ln_bwd2: activation output required");
+    if (!ws || ws_bytes < dpig_ln_bwd2_workspace_bytes(N, P, C)) return fail(DPIG_ENOMEM, "ln_bwd2: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* gs = static_cast<float*>(ws);
+    hipLaunchKernelGGL(ln_bwd2_kernel, dim3(N), dim3(1024), 0, st, u, dy, x, y, P, C, scale, save_mean, save_rstd, act,
+                       alpha, d_dy, d_x, gs);
+    int rc = check_launch("ln_bwd2");
+    if (rc) return rc;
+    const size_t off = (size_t)N * P * C * sizeof(float);
+    return dpig_colsum(gs, C, (int64_t)N * P, C, d_scale, 0.f, static_cast<char*>(ws) + off, ws_bytes - off, stream);
 }
 
 // ---- fully connected layers ride on the conv kernels (a [M,K] matrix is an M x 1 x 1 x K image) -

@@ -307,6 +307,23 @@ def ln_bwd(dy, x, y, scale, mean, rstd, act=ACT_NONE, alpha=0.2):
     return dx, dscale, doffset
 
 
+def ln_bwd2(u, dy, x, y, scale, mean, rstd, act=ACT_NONE, alpha=0.2):
+    """Second-order LayerNorm: gradients of ln_bwd's dx w.r.t. (dy, x, scale) given u = dP/d(dx)."""
+    _require_gpu(u)
+    u = u.contiguous(); dy = dy.contiguous(); x = x.contiguous()
+    if y is not None:
+        y = y.contiguous()
+    N, C = x.shape[0], x.shape[-1]
+    P = x.numel() // (N * C)
+    d_dy = torch.empty_like(x)
+    d_x = torch.empty_like(x)
+    d_scale = torch.empty(C, dtype=torch.float32, device=x.device)
+    wsb, wsn = workspace.get(lib().dpig_ln_bwd2_workspace_bytes(N, P, C), x.device)
+    check(lib().dpig_ln_bwd2(ptr(u), ptr(dy), ptr(x), ptr(y), N, P, C, ptr(scale.contiguous()), ptr(mean), ptr(rstd),
+                             act, alpha, ptr(d_dy), ptr(d_x), ptr(d_scale), ptr(wsb), wsn, stream_ptr()), "ln_bwd2")
+    return d_dy, d_x, d_scale
+
+
 def linear_fwd(x, w, bias=None, act=ACT_NONE, alpha=0.2):
     _require_gpu(x)
     x = x.contiguous()

@@ -152,8 +152,24 @@ class GradAllReduce(object):
             self.dist.broadcast(flat_params, src=0)
 
 
-def gan_loss(wgan_gp, disc_real, disc_fake):
-    """trainer.py:217-252 (`_gan_loss`), modes dcgan / wgan / lsgan.  Returns (gen_cost, disc_cost);
+def gradient_penalty(Discriminator, real_data, fake_data, LAMBDA=10., alpha=None):
+    """trainer.py:222-236 / wgan_gp.py:605-619: LAMBDA * mean_b (||grad_xhat D(xhat)||_2 - 1)^2 with
+    xhat = real + alpha*(fake - real), alpha ~ U[0,1) per sample.  As written the reference only type-checks
+    for flat [B,D] inputs (SURVEY C-3); this is the canonical form (per-sample alpha, L2 norm over all
+    non-batch axes), identical on flat data.  The penalty's gradient w.r.t. the critic's parameters needs
+    the backward pass differentiated once more: every piece is a kernel (autograd second-level functions)."""
+    B = real_data.shape[0]
+    if alpha is None:
+        alpha = torch.rand([B] + [1] * (real_data.dim() - 1), device=real_data.device)
+    interpolates = (real_data + alpha * (fake_data - real_data)).detach().requires_grad_(True)
+    D_int = Discriminator(interpolates)
+    gradients = torch.autograd.grad(D_int.sum(), interpolates, create_graph=True)[0]
+    slopes = torch.sqrt((gradients * gradients).reshape(B, -1).sum(dim=1))
+    return LAMBDA * ((slopes - 1.) ** 2).mean()
+
+
+def gan_loss(wgan_gp, disc_real, disc_fake, Discriminator=None, real_data=None, fake_data=None, alpha=None):
+    """trainer.py:217-252 (`_gan_loss`), modes dcgan / wgan / wgan-gp / lsgan.  Returns (gen_cost, disc_cost);
     either input may be None when that side is not needed (TF prunes the unused branch)."""
     mode = wgan_gp.MODE
     gen_cost = disc_cost = None
@@ -173,7 +189,11 @@ def gan_loss(wgan_gp, disc_real, disc_fake):
         if disc_fake is not None and disc_real is not None:
             disc_cost = (((disc_real - 1) ** 2).mean() + ((disc_fake - 0) ** 2).mean()) / 2.
     elif mode == 'wgan-gp':
-        raise Exception("wgan-gp (gradient penalty) is not wired into the stage-I step yet")
+        if disc_fake is not None:
+            gen_cost = -disc_fake.mean()
+        if disc_fake is not None and disc_real is not None:
+            disc_cost = disc_fake.mean() - disc_real.mean()
+            disc_cost = disc_cost + gradient_penalty(Discriminator, real_data, fake_data, wgan_gp.LAMBDA, alpha)
     else:
         raise Exception()
     return gen_cost, disc_cost
@@ -191,6 +211,8 @@ class Config(object):
         self.d_lr = 2e-5
         self.lr_update_step = 50000
         self.D_arch = 'DCGAN'
+        self.gan_mode = 'dcgan'          # trainer.py:257 hard-codes MODE='dcgan' for stage I; 'wgan-gp' exercises
+                                         # the gradient-penalty branch the reference keeps dormant
         self.data_format = 'NHWC'        # main.py:18
         self.__dict__.update(kw)
         self.repeat_num = int(math.log2(self.img_H)) - 2    # trainer.py:75
@@ -212,7 +234,7 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         self.d_lr = torch.full((1,), config.d_lr, dtype=torch.float32, device=self.device)
         # _define_input (trainer.py:254-259)
         self.Generator_fn = models.GeneratorCNN_ID_UAEAfterResidual
-        self.wgan_gp = WGAN_GP(DATA_DIR='', MODE='dcgan', DIM=64, BATCH_SIZE=self.batch_size, ITERS=200000,
+        self.wgan_gp = WGAN_GP(DATA_DIR='', MODE=config.gan_mode, DIM=64, BATCH_SIZE=self.batch_size, ITERS=200000,
                                LAMBDA=10, G_OUTPUT_DIM=self.img_H * self.img_W * 3)
         self.Discriminator_fn = self._getDiscriminator(self.wgan_gp, arch=config.D_arch)
         self.step = 0
@@ -343,7 +365,8 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
             embs, _ = self.encode(batch)
             G, _ = self.generate(embs, batch["pose"])
         D_z_pos, D_z_neg = self.disc_pair(batch["x"], G, need_real=True)
-        _, d_loss = gan_loss(self.wgan_gp, D_z_pos, D_z_neg)
+        _, d_loss = gan_loss(self.wgan_gp, D_z_pos, D_z_neg, Discriminator=self.discriminate,
+                             real_data=batch["x"], fake_data=G)
         d_loss.backward()
         self.D_flat.finalize()
         scale = self.allreduce(self.D_flat.grad)
@@ -358,6 +381,8 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         disc_iters = 1 if self.wgan_gp.MODE in ('dcgan', 'lsgan') else self.wgan_gp.CRITIC_ITERS
         for _ in range(disc_iters):
             out.update(self.d_optim(batch_d))
+            if self.wgan_gp.MODE == 'wgan':
+                clip_disc_weights(self.D_flat)
         if self.step % self.config.lr_update_step == self.config.lr_update_step - 1:
             self.g_lr.mul_(0.5)
             self.d_lr.mul_(0.5)

@@ -100,7 +100,9 @@ class DPIG_Encoder_subSampleAppNetFgBg_GAN_BodyROI(object):
         real = fg if side == "fg" else bg
         with torch.no_grad():
             app, _ = self.mapper(side, self.dims[side], z=z)
-        _, d_loss = gan_loss(self.sides[side]["wg"], self.critic(side, real.contiguous()), self.critic(side, app))
+        real = real.contiguous()
+        _, d_loss = gan_loss(self.sides[side]["wg"], self.critic(side, real), self.critic(side, app),
+                             Discriminator=lambda t: self.critic(side, t), real_data=real, fake_data=app)
         d_loss.backward()
         df.finalize()
         self.opts[side][1].step(self.allreduce(df.grad))

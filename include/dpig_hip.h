@@ -139,6 +139,14 @@ int dpig_ln_bwd(const float* dy, const float* x, const float* y, int N, int P, i
                 const float* save_mean, const float* save_rstd, int act, float alpha, float* dx,
                 float* dscale, float* doffset, void* ws, size_t ws_bytes, void* stream);
 
+/* Second-order LayerNorm (gradient of dpig_ln_bwd's dx w.r.t. dy, x and scale), the piece of the WGAN-GP
+ * double backward (trainer.py:222-236) that does not reduce to the first-order kernels: with
+ * u = dPenalty/d(dx) it returns d_dy, d_x [N,P,C] and d_scale [C] (the offset has no second-order term). */
+size_t dpig_ln_bwd2_workspace_bytes(int N, int P, int C);
+int dpig_ln_bwd2(const float* u, const float* dy, const float* x, const float* y, int N, int P, int C,
+                 const float* scale, const float* save_mean, const float* save_rstd, int act, float alpha,
+                 float* d_dy, float* d_x, float* d_scale, void* ws, size_t ws_bytes, void* stream);
+
 /* ---- fully connected (linear.py:132-146, slim.fully_connected) ------------------------------- */
 /* y[M,Nout] = act(x[M,Kin] @ w[Kin,Nout] + bias) */
 size_t dpig_linear_workspace_bytes(int M, int Kin, int Nout, int which);

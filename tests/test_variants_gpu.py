@@ -140,3 +140,111 @@ def test_layernorm_discriminator_wgan_gp_mode(dev):
     for n, gr in zip(names, grads[1:]):
         assert _rel(lib._params[n].grad, gr) < 2e-3, n
     lib.delete_all_params()
+
+
+def test_second_order_layernorm_kernel(dev):
+    """dpig_ln_bwd2 against torch double backward of the oracle LayerNorm."""
+    import dpig_amd.hip_ops as H
+    from oracle import ops as O
+    g = torch.Generator().manual_seed(2)
+    shape = (3, 6, 5, 12)
+    x = (torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 0.4).requires_grad_(True)
+    sc = (torch.rand(12, generator=g, dtype=torch.float64) + 0.5).requires_grad_(True)
+    of = torch.zeros(12, dtype=torch.float64)
+    dy = (torch.rand(shape, generator=g, dtype=torch.float64) - 0.5).requires_grad_(True)
+    u = torch.rand(shape, generator=g, dtype=torch.float64) - 0.5
+    y = O.leaky_relu(O.layernorm(x, sc, of), 0.2)
+    (dx,) = torch.autograd.grad(y, x, dy, create_graph=True)
+    d_dy, d_x, d_sc = torch.autograd.grad((dx * u).sum(), [dy, x, sc])
+    xg = x.detach().float().to(dev)
+    yg, mean, rstd = H.ln_fwd(xg, sc.detach().float().to(dev), of.float().to(dev), 1e-5, 2, 0.2)
+    g_dy, g_x, g_sc = H.ln_bwd2(u.float().to(dev), dy.detach().float().to(dev), xg, yg, sc.detach().float().to(dev),
+                                mean, rstd, 2, 0.2)
+    assert _rel(g_dy, d_dy) < 5e-5 and _rel(g_x, d_x) < 5e-5 and _rel(g_sc, d_sc) < 5e-5
+
+
+@pytest.mark.parametrize("kind", ["image_ln_critic", "fc_critic"])
+def test_wgan_gp_gradient_penalty_double_backward(dev, kind):
+    """d(LAMBDA*GP)/d(theta_D) through conv5x5s2 / LayerNorm / LeakyReLU / Linear (image critic) and through
+    the FC critic, against torch's double backward of the oracle (same alpha)."""
+    import dpig_amd.tflib as lib
+    from dpig_amd.trainer import gradient_penalty
+    from dpig_amd.wgan_gp import WGAN_GP
+    from oracle import models as OM
+    g = torch.Generator().manual_seed(3)
+    P = OM.ParamStore(seed=9)
+    if kind == "image_ln_critic":
+        B = 2
+        real = torch.rand(B, 128, 64, 3, generator=g, dtype=torch.float64) * 2 - 1
+        fake = torch.rand(B, 128, 64, 3, generator=g, dtype=torch.float64) * 2 - 1
+        alpha = torch.rand(B, 1, 1, 1, generator=g, dtype=torch.float64)
+        D_o = lambda t: OM.dcgan_discriminator(P, t, "wgan-gp")                     # noqa: E731
+    else:
+        B = 6
+        real = torch.rand(B, 224, generator=g, dtype=torch.float64) - 0.5
+        fake = torch.rand(B, 224, generator=g, dtype=torch.float64) - 0.5
+        alpha = torch.rand(B, 1, generator=g, dtype=torch.float64)
+        D_o = lambda t: OM.fc_discriminator(P, t, 224, name="Fg_FCDis_")            # noqa: E731
+    xh = (real + alpha * (fake - real)).requires_grad_(True)
+    (gr,) = torch.autograd.grad(D_o(xh).sum(), xh, create_graph=True)
+    gp_ref = 10.0 * ((gr.reshape(B, -1).pow(2).sum(1).sqrt() - 1) ** 2).mean()
+    names = OM.d_var_names(P)
+    refs = dict(zip(names, torch.autograd.grad(gp_ref, [P.p[n] for n in names], allow_unused=True)))
+    _load(P, dev)
+    wg = WGAN_GP(MODE='wgan-gp', BATCH_SIZE=B)
+    if kind == "image_ln_critic":
+        D_h = lambda t: wg.DCGANDiscriminator(t.permute(0, 3, 1, 2), input_dim=3)   # noqa: E731
+    else:
+        D_h = lambda t: wg.FCDiscriminator(t, input_dim=224, name="Fg_FCDis_")      # noqa: E731
+    gp = gradient_penalty(D_h, real.float().to(dev), fake.float().to(dev), 10.0, alpha.float().to(dev))
+    assert abs(gp.item() - gp_ref.item()) < 1e-4 * abs(gp_ref.item())
+    gp.backward()
+    for n in names:
+        if refs[n] is None:
+            continue
+        got = lib._params[n].grad
+        assert got is not None, n
+        scale = max(refs[n].abs().max().item(), 1e-7)
+        assert (got.double().cpu() - refs[n]).abs().max().item() < 5e-3 * scale, n
+    lib.delete_all_params()
+
+
+def test_stage1_step_in_wgan_gp_mode(dev):
+    """The dormant MODE='wgan-gp' branch end to end (trainer.py:222-236, 131-135): LayerNorm critic,
+    5 critic iterations per step with the gradient penalty, Adam(beta1=.5, beta2=.9); d_loss matches the
+    oracle for the same alpha."""
+    import dpig_amd.tflib as lib
+    from dpig_amd import slim, synthetic
+    from dpig_amd.trainer import Config, DPIG_Encoder_GAN_BodyROI_FgBg, gan_loss
+    from oracle import models as OM
+    B, HID, ZN = 2, 8, 8
+    batch_np = synthetic.make_batch(B, seed=12)
+    ob = OM.batch_to_torch(batch_np)
+    P = OM.ParamStore(seed=13)
+    with torch.no_grad():
+        _, G_o = OM.stage1_forward(P, ob, hidden_num=HID, z_num=ZN)
+    g = torch.Generator().manual_seed(14)
+    alpha = torch.rand(B, 1, 1, 1, generator=g, dtype=torch.float64)
+    d_real = OM.dcgan_discriminator(P, ob["x"], "wgan-gp")
+    d_fake = OM.dcgan_discriminator(P, G_o, "wgan-gp")
+    xh = (ob["x"] + alpha * (G_o - ob["x"])).requires_grad_(True)
+    (gr,) = torch.autograd.grad(OM.dcgan_discriminator(P, xh, "wgan-gp").sum(), xh, create_graph=True)
+    d_ref = d_fake.mean() - d_real.mean() + 10.0 * ((gr.reshape(B, -1).pow(2).sum(1).sqrt() - 1) ** 2).mean()
+    _load(P, dev)
+    tr = DPIG_Encoder_GAN_BodyROI_FgBg(Config(batch_size=B, conv_hidden_num=HID, z_num=ZN, gan_mode='wgan-gp'), dev)
+    gb = synthetic.to_device(batch_np, dev)
+    tr.init_net(gb)
+    assert set(lib._params.keys()) == set(P.p.keys())
+    assert (tr.d_opt.b1, tr.d_opt.b2) == (0.5, 0.9)
+    with torch.no_grad():
+        embs, _ = tr.encode(gb)
+        G, _ = tr.generate(embs, gb["pose"])
+    D_pos, D_neg = tr.disc_pair(gb["x"], G)
+    _, d_loss = gan_loss(tr.wgan_gp, D_pos, D_neg, Discriminator=tr.discriminate, real_data=gb["x"], fake_data=G,
+                         alpha=alpha.float().to(dev))
+    assert abs(d_loss.item() - d_ref.item()) < 1e-3 * abs(d_ref.item())
+    o = tr.train_step(gb, gb)
+    assert tr.d_opt.t == 5 and torch.isfinite(o["d_loss"])
+    o = tr.train_step(gb, gb)
+    assert tr.g_opt.t == 1 and tr.d_opt.t == 10 and torch.isfinite(o["g_loss"])
+    lib.delete_all_params()
