@@ -152,7 +152,7 @@ def main():
             tr.train_step(batch_g, batch_d)
         torch.cuda.synchronize()
         tr._graphs = graphs
-        recs = [(k, f, e0.elapsed_time(e1) * 1e-3) for (k, f, e0, e1) in H.PROFILE]
+        recs = [(r[0], r[1], r[2].elapsed_time(r[3]) * 1e-3) for r in H.PROFILE]
         H.PROFILE = None
         fwd = [(f, t) for (k, f, t) in recs if k == "conv_fwd_mfma"]
         nl = len(fwd)

@@ -136,19 +136,26 @@ __device__ __forceinline__ long class_row(int row, int HrWr, int Wr, int Hr) {
     return (long)n * 9 + border_class(y, rem - y * Wr, Hr, Wr);
 }
 
-template <bool B_ROWK, bool VEC>
+// NARROW: 128 x 32 block tile (waves stacked 4 x 1, one 32x32 accumulator each) for GEMMs whose N is
+// at most 32 (Cout = 3 image conv, dgrad towards a 3-channel image, N = 1 logits): 4x fewer MFMAs than
+// masking a 128-wide tile down to 3 columns.
+template <bool B_ROWK, bool VEC, bool NARROW>
 __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GGParams p) {
+    constexpr int MB = NARROW ? 1 : 2;          // 32-row blocks per wave
+    constexpr int NB = NARROW ? 1 : 2;          // 32-col blocks per wave
+    constexpr int BNT = NARROW ? 32 : BN;       // block tile width
     __shared__ __attribute__((aligned(16))) float smem[2][2 * TILE_FLOATS];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wrow = NARROW ? wave * 32 : (wave >> 1) * 64;     // wave's first row / column in the tile
+    const int wcol = NARROW ? 0 : (wave & 1) * 64;
     const int l31 = lane & 31, half = lane >> 5;
 
     const int tile = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
     const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
-    const int m0 = mt * BM, n0 = nt * BN;
+    const int m0 = mt * BM, n0 = nt * BNT;
     const int split = blockIdx.z;
     const int kt_begin = split * p.tiles_per_split;
     const int kt_end = min(p.ktiles, kt_begin + p.tiles_per_split);
@@ -180,11 +187,11 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GGParams p) {
     for (int i = 0; i < 4; ++i) {
         if (B_ROWK) {   // B[(wtap*Ncols + n)*Cs + k]: rows n, k contiguous (dgrad)
             const int n = n0 + (tid >> 3) + 32 * i;
-            b_ok[i] = n < p.Ncols;
+            b_ok[i] = (n < p.Ncols) & ((tid >> 3) + 32 * i < BNT);
             b_off[i] = (unsigned)((n * p.Cs + a_kq * 4) * 4);
         } else {        // B[(wtap*Cs + k)*Ncols + n]: rows k, n contiguous (fwd)
             const int nq = n0 + (tid & 31) * 4;
-            b_ok[i] = VEC ? (nq < p.Ncols) : true;
+            b_ok[i] = (VEC ? (nq < p.Ncols) : true) & ((tid & 31) * 4 < BNT);
             b_off[i] = (unsigned)((((tid >> 5) + 8 * i) * p.Ncols + nq) * 4);
         }
     }
@@ -260,25 +267,26 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GGParams p) {
     };
 
     // LDS -> register fragments of k-step kk (8 k values: lane half h takes k = kk*8 + 4h + j)
-    auto load_frag = [&](const float* As, const float* Bs, int kk, float4 (&fa)[2], float4 (&fb)[2]) {
-        fa[0] = *reinterpret_cast<const float4*>(&As[(wm * 64 + l31) * LDR + kk * 8 + half * 4]);
-        fa[1] = *reinterpret_cast<const float4*>(&As[(wm * 64 + 32 + l31) * LDR + kk * 8 + half * 4]);
-        if (B_ROWK) {
-            fb[0] = *reinterpret_cast<const float4*>(&Bs[(wn * 64 + l31) * LDR + kk * 8 + half * 4]);
-            fb[1] = *reinterpret_cast<const float4*>(&Bs[(wn * 64 + 32 + l31) * LDR + kk * 8 + half * 4]);
-        } else {
-            const float* bp = &Bs[(kk * 8 + half * 4) * LDKN + wn * 64 + l31];
-            fb[0].x = bp[0 * LDKN]; fb[0].y = bp[1 * LDKN]; fb[0].z = bp[2 * LDKN]; fb[0].w = bp[3 * LDKN];
-            fb[1].x = bp[0 * LDKN + 32]; fb[1].y = bp[1 * LDKN + 32];
-            fb[1].z = bp[2 * LDKN + 32]; fb[1].w = bp[3 * LDKN + 32];
+    auto load_frag = [&](const float* As, const float* Bs, int kk, float4 (&fa)[MB], float4 (&fb)[NB]) {
+#pragma unroll
+        for (int mb = 0; mb < MB; ++mb)
+            fa[mb] = *reinterpret_cast<const float4*>(&As[(wrow + mb * 32 + l31) * LDR + kk * 8 + half * 4]);
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            if (B_ROWK) {
+                fb[nb] = *reinterpret_cast<const float4*>(&Bs[(wcol + nb * 32 + l31) * LDR + kk * 8 + half * 4]);
+            } else {
+                const float* bp = &Bs[(kk * 8 + half * 4) * LDKN + wcol + nb * 32 + l31];
+                fb[nb].x = bp[0 * LDKN]; fb[nb].y = bp[1 * LDKN]; fb[nb].z = bp[2 * LDKN]; fb[nb].w = bp[3 * LDKN];
+            }
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MB][NB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MB; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -287,7 +295,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GGParams p) {
         store_tiles(0);
         __syncthreads();
         int buf = 0;
-        float4 fa[2][2], fb[2][2];          // [k-step parity][32-row / 32-col block]
+        float4 fa[2][MB], fb[2][NB];        // [k-step parity][32-row / 32-col block]
         load_frag(smem[0], smem[0] + TILE_FLOATS, 0, fa[0], fb[0]);
         for (int kt = kt_begin; kt < kt_end; ++kt) {
             const bool more = (kt + 1) < kt_end;
@@ -300,18 +308,24 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GGParams p) {
                 load_part(kk, more);               // HBM/L2 -> registers for tile t+1, between MFMA groups
                 __builtin_amdgcn_sched_barrier(0);  // keep the loads HERE: unpinned, hipcc sinks them to the
                                                     // ds_writes below and exposes the whole memory latency
-                const float4 a0 = fa[kk & 1][0], a1 = fa[kk & 1][1], b0 = fb[kk & 1][0], b1 = fb[kk & 1][1];
-                const float av0[4] = {a0.x, a0.y, a0.z, a0.w};
-                const float av1[4] = {a1.x, a1.y, a1.z, a1.w};
-                const float bv0[4] = {b0.x, b0.y, b0.z, b0.w};
-                const float bv1[4] = {b1.x, b1.y, b1.z, b1.w};
+                float av[MB][4], bv[NB][4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[j], bv0[j], acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av0[j], bv1[j], acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[j], bv0[j], acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av1[j], bv1[j], acc[1][1], 0, 0, 0);
+                for (int mb = 0; mb < MB; ++mb) {
+                    const float4 t = fa[kk & 1][mb];
+                    av[mb][0] = t.x; av[mb][1] = t.y; av[mb][2] = t.z; av[mb][3] = t.w;
                 }
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const float4 t = fb[kk & 1][nb];
+                    bv[nb][0] = t.x; bv[nb][1] = t.y; bv[nb][2] = t.z; bv[nb][3] = t.w;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mb][j], bv[nb][j], acc[mb][nb], 0, 0, 0);
             }
             store_tiles(buf ^ 1);                  // (zeros after the last tile: nobody reads them)
             __syncthreads();
@@ -329,19 +343,18 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GGParams p) {
     float* Cs = &smem[0][0];                       // 128 x 132 floats = 67.6 KB <= 73.7 KB
     __syncthreads();                               // (the loop's last barrier already passed; cheap)
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
+    for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-                Cs[(wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDC + wn * 64 + nb * 32 + l31] =
-                    acc[mb][nb][r];
+            for (int nb = 0; nb < NB; ++nb)
+                Cs[(wrow + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDC + wcol + nb * 32 + l31] = acc[mb][nb][r];
     __syncthreads();
 
     if (p.vec_epi) {
         const int c = (tid & 31) * 4;
         const int col = n0 + c;
-        if (col < p.Ncols) {
+        if (col < p.Ncols && c < BNT) {
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p.bias && p.nsplit == 1) bv = *reinterpret_cast<const float4*>(p.bias + col);
 #pragma unroll 4
@@ -392,7 +405,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GGParams p) {
         for (int idx = tid; idx < BM * BN; idx += 256) {
             const int rl = idx >> 7, cl = idx & 127;
             const int row = m0 + rl, col = n0 + cl;
-            if (row >= p.M || col >= p.Ncols) continue;
+            if (row >= p.M || col >= p.Ncols || cl >= BNT) continue;
             const float v = Cs[rl * LDC + cl];
             if (p.nsplit > 1) {
                 p.partial[((long)split * p.M + row) * p.Ncols + col] = v;
@@ -444,22 +457,29 @@ __device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned shr) {
     return mul ? (int)(__umulhi((unsigned)n, mul) >> shr) : n;
 }
 
-template <bool VEC>
+// NARROW: 128 x 32 tile for Cout <= 32 (the 3-channel image conv).  FLAT: for thin inputs (Cin = 3 stems,
+// the 18-channel pose conv) the tile rows are the flattened (tap, ci) index instead of 128 channels of one
+// tap, so a 3-channel 5x5 filter gradient is 1 row tile instead of 25 tiles that are 98 % padding.
+template <bool VEC, bool NARROW, bool FLAT>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
+    constexpr int MB = NARROW ? 1 : 2;
+    constexpr int NB = NARROW ? 1 : 2;
+    constexpr int BNT = NARROW ? 32 : BN;
     __shared__ __attribute__((aligned(16))) float smem[2][2 * BK * LDKN];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wrow = NARROW ? wave * 32 : (wave >> 1) * 64;
+    const int wcol = NARROW ? 0 : (wave & 1) * 64;
     const int l31 = lane & 31, half = lane >> 5;
 
-    const int mtiles = p.ntaps * p.cblocks;
+    const int mtiles = FLAT ? (p.ntaps * p.C + BM - 1) / BM : p.ntaps * p.cblocks;
     const int tile = xcd_remap(blockIdx.x, mtiles * p.ntiles);
     const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
-    const int tap = mt / p.cblocks;
-    const int ci0 = (mt - tap * p.cblocks) * BM;
-    const int co0 = nt * BN;
+    const int tap = FLAT ? 0 : mt / p.cblocks;
+    const int ci0 = FLAT ? mt * BM : (mt - tap * p.cblocks) * BM;     // FLAT: first flattened (tap,ci) row
+    const int co0 = nt * BNT;
     const int oyoff = tap / p.S - p.pad_t, oxoff = tap % p.S - p.pad_l, wt = tap;
     const int split = blockIdx.z;
     const int kt_begin = split * p.tiles_per_split;
@@ -469,8 +489,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
     const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.X, p.x_bytes);
     const __amdgpu_buffer_rsrc_t rsY = make_rsrc(p.DY, p.y_bytes);
     const bool cx_ok = VEC ? (ci0 + q < p.C) : true;
-    const bool cy_ok = VEC ? (co0 + q < p.K) : true;
+    const bool cy_ok = (VEC ? (co0 + q < p.K) : true) & (q < BNT);
     float4 ra[4], rb[4];
+    // FLAT: this thread's 4 tile rows are 4 (tap, ci) pairs, fixed for the whole pixel loop
+    int f_oy[4], f_ox[4], f_ci[4];
+    bool f_ok[4];
+    if (FLAT) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int i = ci0 + q + e;
+            f_ok[e] = i < p.ntaps * p.C;
+            const int t = f_ok[e] ? i / p.C : 0;
+            f_ci[e] = f_ok[e] ? i - t * p.C : 0;
+            f_oy[e] = t / p.S - p.pad_t;
+            f_ox[e] = t % p.S - p.pad_l;
+        }
+    }
 
     auto load_tiles = [&](int kt) {
 #pragma unroll
@@ -482,13 +516,25 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
             const int rem = mm - n * p.HoWo;
             const int oy = fast_div(rem, p.mul_wo, p.shr_wo);
             const int ox = rem - oy * p.Wo;
-            const int py = oy * p.s + oyoff, px = ox * p.s + oxoff;
-            const int iy = py >> p.shift, ix = px >> p.shift;
-            const bool ok = mok & (py >= 0) & (px >= 0) & (iy < p.H) & (ix < p.W);
-            const unsigned xoff = (unsigned)((((n * p.H + iy) * p.W + ix) * p.ldx + ci0 + q) * 4);
             const unsigned yoff = (unsigned)((mm * p.ldy + co0 + q) * 4);
-            ra[i] = gload4<VEC>(rsX, xoff, ok & cx_ok, ci0 + q, p.C);
             rb[i] = gload4<VEC>(rsY, yoff, mok & cy_ok, co0 + q, p.K);
+            if (FLAT) {
+                float v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int py = oy * p.s + f_oy[e], px = ox * p.s + f_ox[e];
+                    const bool ok = mok & f_ok[e] & ((unsigned)py < (unsigned)p.H) & ((unsigned)px < (unsigned)p.W);
+                    const unsigned off = (unsigned)((((n * p.H + py) * p.W + px) * p.ldx + f_ci[e]) * 4);
+                    v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, (int)(ok ? off : OOB), 0, 0));
+                }
+                ra[i] = make_float4(v[0], v[1], v[2], v[3]);
+            } else {
+                const int py = oy * p.s + oyoff, px = ox * p.s + oxoff;
+                const int iy = py >> p.shift, ix = px >> p.shift;
+                const bool ok = mok & (py >= 0) & (px >= 0) & (iy < p.H) & (ix < p.W);
+                const unsigned xoff = (unsigned)((((n * p.H + iy) * p.W + ix) * p.ldx + ci0 + q) * 4);
+                ra[i] = gload4<VEC>(rsX, xoff, ok & cx_ok, ci0 + q, p.C);
+            }
         }
     };
     auto store_tiles = [&](int buf) {
@@ -501,24 +547,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
         }
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[MB][NB];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < MB; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // LDS -> register fragments of k-step kk; both operands are k-major: lane half h takes k = kk*8+4h+j
-    auto load_frag = [&](const float* As, const float* Bs, int kk, float (&fa)[2][4], float (&fb)[2][4]) {
-        const float* ap = &As[(kk * 8 + half * 4) * LDKN + wm * 64 + l31];
-        const float* bp = &Bs[(kk * 8 + half * 4) * LDKN + wn * 64 + l31];
+    auto load_frag = [&](const float* As, const float* Bs, int kk, float (&fa)[MB][4], float (&fb)[NB][4]) {
+        const float* ap = &As[(kk * 8 + half * 4) * LDKN + wrow + l31];
+        const float* bp = &Bs[(kk * 8 + half * 4) * LDKN + wcol + l31];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            fa[0][j] = ap[j * LDKN];
-            fa[1][j] = ap[j * LDKN + 32];
-            fb[0][j] = bp[j * LDKN];
-            fb[1][j] = bp[j * LDKN + 32];
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) fa[mb][j] = ap[j * LDKN + mb * 32];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) fb[nb][j] = bp[j * LDKN + nb * 32];
         }
     };
 
@@ -527,7 +573,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
         store_tiles(0);
         __syncthreads();
         int buf = 0;
-        float fa[2][2][4], fb[2][2][4];      // [k-step parity][32-row/col block][j]
+        float fa[2][MB][4], fb[2][NB][4];    // [k-step parity][32-row/col block][j]
         load_frag(smem[0], smem[0] + BK * LDKN, 0, fa[0], fb[0]);
         for (int kt = kt_begin; kt < kt_end; ++kt) {
             const bool more = (kt + 1) < kt_end;
@@ -538,12 +584,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
             for (int kk = 0; kk < BK / 8; ++kk) {
                 if (kk + 1 < BK / 8) load_frag(As, Bs, kk + 1, fa[(kk + 1) & 1], fb[(kk + 1) & 1]);
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][0][j], fb[kk & 1][0][j], acc[0][0], 0, 0, 0);
-                    acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][0][j], fb[kk & 1][1][j], acc[0][1], 0, 0, 0);
-                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][1][j], fb[kk & 1][0][j], acc[1][0], 0, 0, 0);
-                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][1][j], fb[kk & 1][1][j], acc[1][1], 0, 0, 0);
-                }
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][mb][j], fb[kk & 1][nb][j],
+                                                                               acc[mb][nb], 0, 0, 0);
             }
             if (more) store_tiles(buf ^ 1);
             __syncthreads();
@@ -557,25 +604,24 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
     float* Cs = &smem[0][0];                       // 128 x 128 floats = the whole 64 KB ring
     __syncthreads();
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb)
+    for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-                Cs[(wm * 64 + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * BN + wn * 64 + nb * 32 + l31] =
-                    acc[mb][nb][r];
+            for (int nb = 0; nb < NB; ++nb)
+                Cs[(wrow + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * BN + wcol + nb * 32 + l31] = acc[mb][nb][r];
     __syncthreads();
     float* dst = (p.nsplit > 1) ? p.partial + (long)split * wsize : p.DW;
     const float beta = (p.nsplit > 1) ? 0.f : p.beta;
     if (p.vec_epi) {
         const int c = (tid & 31) * 4;
         const int co = co0 + c;
-        if (co < p.K) {
+        if (co < p.K && c < BNT) {
 #pragma unroll 4
             for (int it = 0; it < 16; ++it) {
                 const int rl = (tid >> 5) + 8 * it;
-                const int ci = ci0 + rl;
-                if (ci >= p.C) continue;
+                const int ci = ci0 + rl;                       // FLAT: flattened (tap, ci) row
+                if (ci >= (FLAT ? p.ntaps * p.C : p.C)) continue;
                 float4 v = *reinterpret_cast<const float4*>(&Cs[rl * BN + c]);
                 float4* o = reinterpret_cast<float4*>(dst + ((long)wt * p.C + ci) * p.K + co);
                 if (beta != 0.f) {
@@ -589,7 +635,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
         for (int idx = tid; idx < BM * BN; idx += 256) {
             const int rl = idx >> 7, cl = idx & 127;
             const int ci = ci0 + rl, co = co0 + cl;
-            if (ci >= p.C || co >= p.K) continue;
+            if (ci >= (FLAT ? p.ntaps * p.C : p.C) || co >= p.K || cl >= BNT) continue;
             const long o = ((long)wt * p.C + ci) * p.K + co;
             const float v = Cs[rl * BN + cl];
             dst[o] = (beta != 0.f) ? beta * dst[o] + v : v;
@@ -709,19 +755,22 @@ static int launch_gg(GGParams& p, bool b_rowk, int nimg, long filter_elems, hipS
                 (!p.bias || aligned16(p.bias)) && (!p.res || (p.ldres % 4 == 0 && aligned16(p.res))) &&
                 (!p.mask || (p.ldmask % 4 == 0 && aligned16(p.mask))) &&
                 (!p.D2 || (p.ldd2 % 4 == 0 && aligned16(p.D2))) && (!p.partial || aligned16(p.partial));
+    const bool narrow = p.Ncols <= 32;
     p.mtiles = cdiv(p.M, BM);
-    p.ntiles = cdiv(p.Ncols, BN);
+    p.ntiles = cdiv(p.Ncols, narrow ? 32 : BN);
     p.cchunks = cdiv(p.Cs, BK);
     p.ktiles = p.ntaps * p.cchunks;
     bool vec = vec_ok(p.A, p.B, p.lda, p.Cs, p.Ncols);
     dim3 grid(p.mtiles * p.ntiles, 1, p.nsplit), block(256);
+#define DPIG_GG(BR, VE, NA) hipLaunchKernelGGL((gather_gemm_kernel<BR, VE, NA>), grid, block, 0, st, p)
     if (b_rowk) {
-        if (vec) hipLaunchKernelGGL((gather_gemm_kernel<true, true>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((gather_gemm_kernel<true, false>), grid, block, 0, st, p);
+        if (narrow) { if (vec) DPIG_GG(true, true, true); else DPIG_GG(true, false, true); }
+        else { if (vec) DPIG_GG(true, true, false); else DPIG_GG(true, false, false); }
     } else {
-        if (vec) hipLaunchKernelGGL((gather_gemm_kernel<false, true>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((gather_gemm_kernel<false, false>), grid, block, 0, st, p);
+        if (narrow) { if (vec) DPIG_GG(false, true, true); else DPIG_GG(false, false, true); }
+        else { if (vec) DPIG_GG(false, true, false); else DPIG_GG(false, false, false); }
     }
+#undef DPIG_GG
     int rc = check_launch("gather_gemm_kernel");
     if (rc) return rc;
     if (p.nsplit > 1) {
@@ -811,7 +860,9 @@ extern "C" size_t dpig_conv2d_workspace_bytes(const DpigConvDesc* d, int which) 
         return mx;
     } else if (which == 2) {
         const long Npix = (long)d->N * Ho * Wo * (d->upsample2x ? 4 : 1);
-        const int tiles = d->R * d->S * cdiv(d->C, BM) * cdiv(d->K, BN);
+        const bool flat = !d->upsample2x && d->C < 32 && d->R * d->S > 1;
+        const int tiles = (flat ? cdiv((long)d->R * d->S * d->C, BM) : d->R * d->S * cdiv(d->C, BM)) *
+                          cdiv(d->K, d->K <= 32 ? 32 : BN);
         Plan pln = plan_split(tiles, cdiv(Npix, BK), d->split_k);
         return pln.nsplit > 1 ? (size_t)pln.nsplit * d->R * d->S * d->C * d->K * sizeof(float) : 0;
     }
@@ -942,10 +993,12 @@ extern "C" int dpig_conv2d_wgrad(const DpigConvDesc* d, const float* x, const fl
         find_divisor(p.Wo, &p.mul_wo, &p.shr_wo);
     }
     p.wrows = d->R * d->S * d->C;
+    const bool narrow = d->K <= 32;
+    const bool flat = !d->upsample2x && d->C < 32 && d->R * d->S > 1;
     p.cblocks = cdiv(d->C, BM);
-    p.ntiles = cdiv(d->K, BN);
+    p.ntiles = cdiv(d->K, narrow ? 32 : BN);
     p.ktiles = cdiv(p.Npix, BK);
-    const int tiles = p.ntaps * p.cblocks * p.ntiles;
+    const int tiles = (flat ? cdiv((long)p.ntaps * d->C, BM) : p.ntaps * p.cblocks) * p.ntiles;
     Plan pln = plan_split(tiles, p.ktiles, d->split_k);
     p.nsplit = pln.nsplit; p.tiles_per_split = pln.tiles_per_split;
     const long wsize = (long)p.wrows * d->K;
@@ -955,8 +1008,11 @@ extern "C" int dpig_conv2d_wgrad(const DpigConvDesc* d, const float* x, const fl
                      (d->C % 4 == 0) && (d->K % 4 == 0);
     p.vec_epi = (d->K % 4 == 0) && aligned16(dw) && (p.nsplit == 1 || aligned16(ws));
     dim3 grid(tiles, 1, p.nsplit), block(256);
-    if (vec) hipLaunchKernelGGL((wgrad_kernel<true>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((wgrad_kernel<false>), grid, block, 0, st, p);
+#define DPIG_WG(VE, NA, FL) hipLaunchKernelGGL((wgrad_kernel<VE, NA, FL>), grid, block, 0, st, p)
+    if (flat) { if (narrow) DPIG_WG(false, true, true); else DPIG_WG(false, false, true); }
+    else if (narrow) { if (vec) DPIG_WG(true, true, false); else DPIG_WG(false, true, false); }
+    else { if (vec) DPIG_WG(true, false, false); else DPIG_WG(false, false, false); }
+#undef DPIG_WG
     rc = check_launch("wgrad_kernel");
     if (rc) return rc;
     if (p.nsplit > 1) {

@@ -19,8 +19,8 @@ PROFILE = None
 
 
 class _Timed(object):
-    def __init__(self, kind, flops):
-        self.kind, self.flops = kind, flops
+    def __init__(self, kind, flops, label=None):
+        self.kind, self.flops, self.label = kind, flops, label
 
     def __enter__(self):
         if PROFILE is not None:
@@ -32,7 +32,8 @@ class _Timed(object):
     def __exit__(self, *exc):
         if PROFILE is not None:
             self.e1.record()
-            PROFILE.append((self.kind, self.flops, self.e0, self.e1))
+            PROFILE.append((self.kind, self.flops, self.e0, self.e1) if self.label is None
+                           else (self.kind, self.flops, self.e0, self.e1, self.label))
         return False
 
 
@@ -129,7 +130,8 @@ def conv2d_fwd(x, w, bias=None, stride=1, act=ACT_NONE, alpha=0.2, residual=None
               split_k=split_k, res_after_act=res_after_act, ldy2=ldy2, res_class=res_class)
     wsb, wsn = _ws(d, 0, x.device)
     mfma = (C % 4 == 0 and K % 4 == 0 and ldx % 4 == 0 and C >= 32 and K >= 32)
-    with _Timed("conv_fwd_mfma" if mfma else "conv_fwd_thin", 2.0 * N * H * W // (stride * stride) * K * R * S * C):
+    with _Timed("conv_fwd_mfma" if mfma else "conv_fwd_thin", 2.0 * N * H * W // (stride * stride) * K * R * S * C,
+                (N, H, W, C, K, R, stride, int(upsample2x))):
         check(lib().dpig_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(out),
                                     ptr(out_act), ptr(wsb), wsn, stream_ptr()), "conv2d_fwd")
     return out
@@ -163,7 +165,7 @@ def conv2d_dgrad(dy, w, in_shape, stride=1, accum=None, mask=None, act=ACT_NONE,
     wsb, wsn = _ws(d, 1, dy.device)
     mfma = (C % 4 == 0 and K % 4 == 0 and ldy % 4 == 0 and C >= 32 and K >= 32)
     with _Timed("conv_dgrad_mfma" if mfma else "conv_dgrad_thin",
-                2.0 * N * H * W // (stride * stride) * K * R * S * C):
+                2.0 * N * H * W // (stride * stride) * K * R * S * C, (N, H, W, C, K, R, stride, int(upsample2x))):
         check(lib().dpig_conv2d_dgrad(ctypes.byref(d), ptr(dy), ptr(w), ptr(accum), ptr(mask), ptr(out), ptr(wsb),
                                       wsn, stream_ptr()), "conv2d_dgrad")
     return out
@@ -185,7 +187,7 @@ def conv2d_wgrad(x, dy, wshape, stride=1, upsample2x=False, out=None, beta=0.0, 
     wsb, wsn = _ws(d, 2, x.device)
     mfma = (C % 4 == 0 and K % 4 == 0 and C >= 32 and K >= 32)
     with _Timed("conv_wgrad_mfma" if mfma else "conv_wgrad_thin",
-                2.0 * N * H * W // (stride * stride) * K * R * S * C):
+                2.0 * N * H * W // (stride * stride) * K * R * S * C, (N, H, W, C, K, R, stride, int(upsample2x))):
         check(lib().dpig_conv2d_wgrad(ctypes.byref(d), ptr(x), ptr(dy), ptr(out), float(beta), ptr(wsb), wsn,
                                       stream_ptr()), "conv2d_wgrad")
     return out

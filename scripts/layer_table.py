@@ -1,0 +1,23 @@
+"""Per-layer-shape timing table of one stage-I step (eager, HIP events around every conv launch)."""
+import os, sys, collections
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from dpig_amd import hip_ops as H, synthetic
+from dpig_amd.trainer import Config, DPIG_Encoder_GAN_BodyROI_FgBg
+dev = torch.device("cuda:0"); np.random.seed(0)
+tr = DPIG_Encoder_GAN_BodyROI_FgBg(Config(batch_size=16), dev)
+b0 = synthetic.to_device(synthetic.make_batch(16, seed=1), dev); b1 = synthetic.to_device(synthetic.make_batch(16, seed=2), dev)
+tr.init_net(b0); tr.step = 1
+for _ in range(2): tr.train_step(b0, b1)
+torch.cuda.synchronize(); H.PROFILE = []
+e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True); e0.record()
+for _ in range(3): tr.train_step(b0, b1)
+e1.record(); torch.cuda.synchronize()
+recs = H.PROFILE; H.PROFILE = None
+agg = collections.OrderedDict()
+for k, f, a, b, lab in recs:
+    key = (k, lab); d = agg.setdefault(key, [0, 0.0, 0.0]); d[0] += 1; d[1] += f; d[2] += a.elapsed_time(b) * 1e-3
+tot = sum(v[2] for v in agg.values())
+print("step %.2f ms (instrumented); conv total %.2f ms" % (e0.elapsed_time(e1) / 3, tot / 3 * 1e3))
+for (k, lab), v in sorted(agg.items(), key=lambda kv: -kv[1][2])[:45]:
+    print("%-16s N%-3d %3dx%-3d C%-4d K%-4d k%d s%d u%d | n/step %4.1f  ms/step %6.3f  %6.1f TF" % ((k,) + lab + (v[0] / 3, v[2] / 3 * 1e3, v[1] / v[2] / 1e12)))

@@ -23,6 +23,10 @@ SHAPES = [
     (2, 16, 8, 256, 3, 3, 1),      # G.out: Cout=3
     (3, 6, 6, 96, 132, 1, 1),      # 1x1
     (1, 8, 4, 370, 128, 3, 1),     # G.stem: Cin=370 (not a multiple of 4)
+    (2, 16, 8, 18, 128, 3, 1),     # pose conv of the collapsed G.stem: flattened-(tap,ci) wgrad rows
+    (2, 16, 8, 3, 128, 3, 1),      # E.stem
+    (2, 8, 8, 64, 1, 1, 1),        # N = 1 (narrow tile)
+    (2, 8, 8, 20, 24, 3, 2),       # thin both ways, stride 2
 ]
 
 
