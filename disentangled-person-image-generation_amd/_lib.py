@@ -39,7 +39,7 @@ SYMBOLS = {
     "dpig_conv2d_workspace_bytes": (_sz, [_dp, _i]),
     "dpig_conv2d_fwd": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dpig_conv2d_dgrad": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "dpig_conv2d_wgrad": (_i, [_dp, _vp, _vp, _vp, _f, _vp, _sz, _vp]),
+    "dpig_conv2d_wgrad": (_i, [_dp, _vp, _vp, _vp, _f, _vp, _f, _vp, _sz, _vp]),
     "dpig_act_fwd": (_i, [_vp, _i, _vp, _i, _i64, _i, _i, _f, _vp]),
     "dpig_act_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _i, _i, _f, _vp]),
     "dpig_colsum_workspace_bytes": (_sz, [_i64, _i]),

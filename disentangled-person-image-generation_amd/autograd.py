@@ -24,6 +24,26 @@ def _sink(p, fn):
     return None
 
 
+def _sink_wgrad_bias(w, b, x, dz, stride=1, upsample2x=False, want_w=True, want_b=True):
+    """Filter gradient (+ bias gradient in the same launch when both go to flat sinks)."""
+    dw = db = None
+    wbuf = getattr(w, "_dpig_grad", None) if want_w else None
+    bbuf = getattr(b, "_dpig_grad", None) if (want_b and b is not None) else None
+    if wbuf is not None and bbuf is not None:
+        wt, bt = w._dpig_touched, b._dpig_touched
+        H.conv2d_wgrad(x, dz, tuple(w.shape), stride=stride, upsample2x=upsample2x, out=wbuf,
+                       beta=1.0 if wt[0] else 0.0, db=bbuf, db_beta=1.0 if bt[0] else 0.0)
+        wt[0] = True
+        bt[0] = True
+        return None, None
+    if want_w:
+        dw = _sink(w, lambda o, beta: H.conv2d_wgrad(x, dz, tuple(w.shape), stride=stride, upsample2x=upsample2x,
+                                                     out=o, beta=beta))
+    if want_b and b is not None:
+        db = _sink(b, lambda o, beta: H.colsum(dz, out=o, beta=beta))
+    return dw, db
+
+
 def _sink_small(p, g):
     """Same contract as _sink for tiny per-channel gradients that a kernel already produced."""
     buf = getattr(p, "_dpig_grad", None)
@@ -136,11 +156,8 @@ class _ConvFn(torch.autograd.Function):
                 dz = dz.detach()
             else:
                 dx = H.conv2d_dgrad(dz, w, tuple(x.shape), stride=stride, upsample2x=up)
-        if ctx.needs_input_grad[1]:
-            dw = _sink(w, lambda o, beta: H.conv2d_wgrad(x, dz, tuple(w.shape), stride=stride, upsample2x=up,
-                                                         out=o, beta=beta))
-        if has_b and ctx.needs_input_grad[2]:
-            db = _sink(ctx.b_ref, lambda o, beta: H.colsum(dz, out=o, beta=beta))
+        dw, db = _sink_wgrad_bias(w, ctx.b_ref, x, dz, stride, up, ctx.needs_input_grad[1],
+                                  has_b and ctx.needs_input_grad[2])
         return dx, dw, db, None, None, None, None
 
 
@@ -169,16 +186,9 @@ class _ResBlockFn(torch.autograd.Function):
         x0, w1, w2, c1, c2 = ctx.saved_tensors
         b1, b2 = ctx.b_refs
         dz2 = H.act_bwd(dout, c2, ACT_RELU)
-        dw2 = db2 = dw1 = db1 = None
-        if ctx.needs_input_grad[3]:
-            dw2 = _sink(w2, lambda o, beta: H.conv2d_wgrad(c1, dz2, tuple(w2.shape), out=o, beta=beta))
-        if ctx.needs_input_grad[4]:
-            db2 = _sink(b2, lambda o, beta: H.colsum(dz2, out=o, beta=beta))
+        dw2, db2 = _sink_wgrad_bias(w2, b2, c1, dz2, want_w=ctx.needs_input_grad[3], want_b=ctx.needs_input_grad[4])
         dz1 = H.conv2d_dgrad(dz2, w2, tuple(c1.shape), mask=c1, act=ACT_RELU)
-        if ctx.needs_input_grad[1]:
-            dw1 = _sink(w1, lambda o, beta: H.conv2d_wgrad(x0, dz1, tuple(w1.shape), out=o, beta=beta))
-        if ctx.needs_input_grad[2]:
-            db1 = _sink(b1, lambda o, beta: H.colsum(dz1, out=o, beta=beta))
+        dw1, db1 = _sink_wgrad_bias(w1, b1, x0, dz1, want_w=ctx.needs_input_grad[1], want_b=ctx.needs_input_grad[2])
         dx0 = None
         if ctx.needs_input_grad[0]:
             dx0 = H.conv2d_dgrad(dz1, w1, tuple(x0.shape), accum=dout)

@@ -136,6 +136,41 @@ __device__ __forceinline__ long class_row(int row, int HrWr, int Wr, int Hr) {
     return (long)n * 9 + border_class(y, rem - y * Wr, Hr, Wr);
 }
 
+// Fused epilogue on 4 consecutive columns of one output row (16-byte accesses throughout).
+__device__ __forceinline__ void epi_vec4(const GGParams& p, int row, int col, float4 v, float4 bv) {
+    long pix = row;
+    if (!p.identity_rows) {
+        const int n = row / p.HrWr;
+        const int rem = row - n * p.HrWr;
+        const int rr = rem / p.Wr;
+        const int cc = rem - rr * p.Wr;
+        pix = ((long)n * p.Hd + (rr * p.dr + p.dpy)) * p.Wd + (cc * p.dr + p.dpx);
+    }
+    v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+    float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.res) {
+        const long rpix = p.res_class ? class_row(row, p.HrWr, p.Wr, p.Hr) : pix;
+        rv = *reinterpret_cast<const float4*>(p.res + rpix * p.ldres + col);
+    }
+    if (p.res && !p.res_post) { v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
+    if (p.mask) {
+        const float4 mv = *reinterpret_cast<const float4*>(p.mask + pix * p.ldmask + col);
+        v.x *= act_grad(mv.x, p.act, p.alpha); v.y *= act_grad(mv.y, p.act, p.alpha);
+        v.z *= act_grad(mv.z, p.act, p.alpha); v.w *= act_grad(mv.w, p.act, p.alpha);
+    } else {
+        v.x = act_apply(v.x, p.act, p.alpha); v.y = act_apply(v.y, p.act, p.alpha);
+        v.z = act_apply(v.z, p.act, p.alpha); v.w = act_apply(v.w, p.act, p.alpha);
+    }
+    if (p.D2) *reinterpret_cast<float4*>(p.D2 + pix * p.ldd2 + col) = v;
+    if (p.res && p.res_post) { v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
+    *reinterpret_cast<float4*>(p.D + pix * p.ldd + col) = v;
+    if (p.replicate) {
+        *reinterpret_cast<float4*>(p.D + (pix + 1) * p.ldd + col) = v;
+        *reinterpret_cast<float4*>(p.D + (pix + p.Wd) * p.ldd + col) = v;
+        *reinterpret_cast<float4*>(p.D + (pix + p.Wd + 1) * p.ldd + col) = v;
+    }
+}
+
 // NARROW: 128 x 32 block tile (waves stacked 4 x 1, one 32x32 accumulator each) for GEMMs whose N is
 // at most 32 (Cout = 3 image conv, dgrad towards a 3-channel image, N = 1 logits): 4x fewer MFMAs than
 // masking a 128-wide tile down to 3 columns.
@@ -367,37 +402,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GGParams p) {
                     *reinterpret_cast<float4*>(&p.partial[((long)split * p.M + row) * p.Ncols + col]) = v;
                     continue;
                 }
-                long pix = row;
-                if (!p.identity_rows) {
-                    const int n = row / p.HrWr;
-                    const int rem = row - n * p.HrWr;
-                    const int rr = rem / p.Wr;
-                    const int cc = rem - rr * p.Wr;
-                    pix = ((long)n * p.Hd + (rr * p.dr + p.dpy)) * p.Wd + (cc * p.dr + p.dpx);
-                }
-                v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
-                float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (p.res) {
-                    const long rpix = p.res_class ? class_row(row, p.HrWr, p.Wr, p.Hr) : pix;
-                    rv = *reinterpret_cast<const float4*>(p.res + rpix * p.ldres + col);
-                }
-                if (p.res && !p.res_post) { v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
-                if (p.mask) {
-                    const float4 mv = *reinterpret_cast<const float4*>(p.mask + pix * p.ldmask + col);
-                    v.x *= act_grad(mv.x, p.act, p.alpha); v.y *= act_grad(mv.y, p.act, p.alpha);
-                    v.z *= act_grad(mv.z, p.act, p.alpha); v.w *= act_grad(mv.w, p.act, p.alpha);
-                } else {
-                    v.x = act_apply(v.x, p.act, p.alpha); v.y = act_apply(v.y, p.act, p.alpha);
-                    v.z = act_apply(v.z, p.act, p.alpha); v.w = act_apply(v.w, p.act, p.alpha);
-                }
-                if (p.D2) *reinterpret_cast<float4*>(p.D2 + pix * p.ldd2 + col) = v;
-                if (p.res && p.res_post) { v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
-                *reinterpret_cast<float4*>(p.D + pix * p.ldd + col) = v;
-                if (p.replicate) {
-                    *reinterpret_cast<float4*>(p.D + (pix + 1) * p.ldd + col) = v;
-                    *reinterpret_cast<float4*>(p.D + (pix + p.Wd) * p.ldd + col) = v;
-                    *reinterpret_cast<float4*>(p.D + (pix + p.Wd + 1) * p.ldd + col) = v;
-                }
+                epi_vec4(p, row, col, v, bv);
             }
         }
     } else {
@@ -423,6 +428,24 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GGParams p) {
 // split-K second pass: sum partials in split order (deterministic) and run the fused epilogue
 __global__ __launch_bounds__(256) void gather_gemm_reduce_kernel(const GGParams p) {
     const long total = (long)p.M * p.Ncols;
+    if (p.vec_epi) {
+        const int n4 = p.Ncols >> 2;
+        const long total4 = total >> 2;
+        const float4* p4 = reinterpret_cast<const float4*>(p.partial);
+        for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
+            float4 v = p4[i];
+            for (int s = 1; s < p.nsplit; ++s) {
+                const float4 t = p4[(long)s * total4 + i];
+                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            }
+            const int row = (int)(i / n4);
+            const int col = (int)(i - (long)row * n4) * 4;
+            float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + col);
+            epi_vec4(p, row, col, v, bv);
+        }
+        return;
+    }
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         float v = 0.f;
         for (int s = 0; s < p.nsplit; ++s) v += p.partial[(long)s * total + i];
@@ -450,6 +473,7 @@ struct WGParams {
     unsigned x_bytes, y_bytes;                     // buffer-descriptor extents
     unsigned mul_howo, shr_howo, mul_wo, shr_wo;   // magic numbers: m / HoWo and rem / Wo without v_rcp
     int vec_epi;                                   // 1: dw / partial rows are 16-byte addressable
+    float* DB; float* bias_partial; float beta_b;  // fused bias gradient: db[co] = sum_pixels dy[., co]
 };
 
 // n / d for 0 <= n < 2^31 with a precomputed (mul, shr); mul == 0 encodes d == 1
@@ -537,6 +561,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
             }
         }
     };
+    // fused bias gradient: the row-tile-0 workgroups also sum the dy tile they stage anyway
+    const bool do_bias = (p.DB != nullptr) && (mt == 0);
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
     auto store_tiles = [&](int buf) {
         float* As = smem[buf];
         float* Bs = smem[buf] + BK * LDKN;
@@ -544,6 +571,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
         for (int i = 0; i < 4; ++i) {
             *reinterpret_cast<float4*>(&As[((tid >> 5) + 8 * i) * LDKN + q]) = ra[i];
             *reinterpret_cast<float4*>(&Bs[((tid >> 5) + 8 * i) * LDKN + q]) = rb[i];
+            if (do_bias) { bsum.x += rb[i].x; bsum.y += rb[i].y; bsum.z += rb[i].z; bsum.w += rb[i].w; }
         }
     };
 
@@ -603,6 +631,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
     const long wsize = (long)p.wrows * p.K;
     float* Cs = &smem[0][0];                       // 128 x 128 floats = the whole 64 KB ring
     __syncthreads();
+    if (do_bias) {                                 // 8 thread rows x 128 columns -> 128 column sums
+        *reinterpret_cast<float4*>(&Cs[(tid >> 5) * BN + q]) = bsum;
+        __syncthreads();
+        if (tid < BNT) {
+            float v = 0.f;
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v += Cs[r * BN + tid];
+            const int co = co0 + tid;
+            if (co < p.K) {
+                if (p.nsplit > 1) p.bias_partial[(long)split * p.K + co] = v;
+                else p.DB[co] = (p.beta_b != 0.f) ? p.beta_b * p.DB[co] + v : v;
+            }
+        }
+        __syncthreads();
+    }
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -775,7 +818,7 @@ static int launch_gg(GGParams& p, bool b_rowk, int nimg, long filter_elems, hipS
     if (rc) return rc;
     if (p.nsplit > 1) {
         const long total = (long)p.M * p.Ncols;
-        int blocks = cdiv(total, 256);
+        int blocks = cdiv(p.vec_epi ? total / 4 : total, 256);
         if (blocks > 8 * kNumCU) blocks = 8 * kNumCU;
         hipLaunchKernelGGL(gather_gemm_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
         rc = check_launch("gather_gemm_reduce_kernel");
@@ -864,7 +907,7 @@ extern "C" size_t dpig_conv2d_workspace_bytes(const DpigConvDesc* d, int which) 
         const int tiles = (flat ? cdiv((long)d->R * d->S * d->C, BM) : d->R * d->S * cdiv(d->C, BM)) *
                           cdiv(d->K, d->K <= 32 ? 32 : BN);
         Plan pln = plan_split(tiles, cdiv(Npix, BK), d->split_k);
-        return pln.nsplit > 1 ? (size_t)pln.nsplit * d->R * d->S * d->C * d->K * sizeof(float) : 0;
+        return pln.nsplit > 1 ? (size_t)pln.nsplit * ((size_t)d->R * d->S * d->C * d->K + d->K) * sizeof(float) : 0;
     }
     return 0;
 }
@@ -964,7 +1007,7 @@ extern "C" int dpig_conv2d_dgrad(const DpigConvDesc* d, const float* dy, const f
 }
 
 extern "C" int dpig_conv2d_wgrad(const DpigConvDesc* d, const float* x, const float* dy, float* dw, float beta,
-                                 void* ws, size_t ws_bytes, void* stream) {
+                                 float* db, float beta_b, void* ws, size_t ws_bytes, void* stream) {
     int pt, pl, Ho, Wo;
     int rc = resolve_desc(d, &pt, &pl, &Ho, &Wo);
     if (rc) return rc;
@@ -1002,8 +1045,10 @@ extern "C" int dpig_conv2d_wgrad(const DpigConvDesc* d, const float* x, const fl
     Plan pln = plan_split(tiles, p.ktiles, d->split_k);
     p.nsplit = pln.nsplit; p.tiles_per_split = pln.tiles_per_split;
     const long wsize = (long)p.wrows * d->K;
-    if (p.nsplit > 1 && (!ws || ws_bytes < (size_t)p.nsplit * wsize * sizeof(float)))
+    if (p.nsplit > 1 && (!ws || ws_bytes < (size_t)p.nsplit * (wsize + d->K) * sizeof(float)))
         return fail(DPIG_ENOMEM, "conv wgrad workspace too small: have %zu", ws_bytes);
+    p.DB = db; p.beta_b = beta_b;
+    p.bias_partial = p.partial ? p.partial + (long)p.nsplit * wsize : nullptr;
     const bool vec = aligned16(x) && aligned16(dy) && (d->ldx % 4 == 0) && (d->ldy % 4 == 0) &&
                      (d->C % 4 == 0) && (d->K % 4 == 0);
     p.vec_epi = (d->K % 4 == 0) && aligned16(dw) && (p.nsplit == 1 || aligned16(ws));
@@ -1025,6 +1070,10 @@ extern "C" int dpig_conv2d_wgrad(const DpigConvDesc* d, const float* x, const fl
             int blocks = cdiv(wsize, 256);
             if (blocks > 8 * kNumCU) blocks = 8 * kNumCU;
             hipLaunchKernelGGL(splitk_sum_scalar_kernel, dim3(blocks), dim3(256), 0, st, p.partial, dw, wsize, p.nsplit, beta);
+        }
+        if (db) {
+            hipLaunchKernelGGL(splitk_sum_scalar_kernel, dim3(cdiv(d->K, 256)), dim3(256), 0, st, p.bias_partial, db,
+                               (long)d->K, p.nsplit, beta_b);
         }
         rc = check_launch("splitk_sum_kernel");
     }

@@ -800,7 +800,7 @@ extern "C" int dpig_linear_wgrad(const float* x, const float* dy, float* dw, flo
                                  void* ws, size_t ws_bytes, void* stream) {
     if (M <= 0 || Kin <= 0 || Nout <= 0) return fail(DPIG_EINVAL, "linear: non-positive dims");
     DpigConvDesc d = linear_desc(M, Kin, Nout, 0, 0.f);
-    return dpig_conv2d_wgrad(&d, x, dy, dw, beta, ws, ws_bytes, stream);
+    return dpig_conv2d_wgrad(&d, x, dy, dw, beta, nullptr, 0.f, ws, ws_bytes, stream);
 }
 
 extern "C" int dpig_crop_resize_fwd(const float* img, int N, int H, int W, int C, const float* boxes,

@@ -171,8 +171,9 @@ def conv2d_dgrad(dy, w, in_shape, stride=1, accum=None, mask=None, act=ACT_NONE,
     return out
 
 
-def conv2d_wgrad(x, dy, wshape, stride=1, upsample2x=False, out=None, beta=0.0, split_k=0):
-    """dw[R,S,C,K] = conv_backward_filter(x, dy)."""
+def conv2d_wgrad(x, dy, wshape, stride=1, upsample2x=False, out=None, beta=0.0, split_k=0, db=None, db_beta=0.0):
+    """dw[R,S,C,K] = beta*dw + conv_backward_filter(x, dy); with `db` ([K] tensor) the same launch also writes
+    the bias gradient db = db_beta*db + sum over pixels of dy."""
     _require_gpu(x)
     x, ldx = as_nhwc(x)
     dy, ldy = as_nhwc(dy)
@@ -188,8 +189,8 @@ def conv2d_wgrad(x, dy, wshape, stride=1, upsample2x=False, out=None, beta=0.0, 
     mfma = (C % 4 == 0 and K % 4 == 0 and C >= 32 and K >= 32)
     with _Timed("conv_wgrad_mfma" if mfma else "conv_wgrad_thin",
                 2.0 * N * H * W // (stride * stride) * K * R * S * C, (N, H, W, C, K, R, stride, int(upsample2x))):
-        check(lib().dpig_conv2d_wgrad(ctypes.byref(d), ptr(x), ptr(dy), ptr(out), float(beta), ptr(wsb), wsn,
-                                      stream_ptr()), "conv2d_wgrad")
+        check(lib().dpig_conv2d_wgrad(ctypes.byref(d), ptr(x), ptr(dy), ptr(out), float(beta), ptr(db),
+                                      float(db_beta), ptr(wsb), wsn, stream_ptr()), "conv2d_wgrad")
     return out
 
 

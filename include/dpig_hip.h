@@ -95,9 +95,11 @@ int dpig_conv2d_fwd(const DpigConvDesc* d, const float* x, const float* w, const
 int dpig_conv2d_dgrad(const DpigConvDesc* d, const float* dy, const float* w, const float* accum,
                       const float* mask, float* dx, void* ws, size_t ws_bytes, void* stream);
 
-/* dw[R,S,C,K] = conv_backward_filter(x, dy).  beta = 0 overwrites, beta = 1 accumulates. */
+/* dw[R,S,C,K] = beta*dw + conv_backward_filter(x, dy).  beta = 0 overwrites, beta = 1 accumulates.
+ * If db is not NULL the same launch also produces the bias gradient db[K] = beta_b*db + sum_pixels dy
+ * (TF's BiasAddGrad) from the dy tiles it stages anyway -- no extra pass over dy. */
 int dpig_conv2d_wgrad(const DpigConvDesc* d, const float* x, const float* dy, float* dw, float beta,
-                      void* ws, size_t ws_bytes, void* stream);
+                      float* db, float beta_b, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- elementwise / reductions over a [rows, cols] fp32 matrix with row stride ld ------------- */
 

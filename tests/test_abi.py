@@ -90,7 +90,7 @@ def test_bad_arguments_fail_loudly_without_touching_the_gpu(lib):
     d = _desc(lib, stride=3)
     assert h.dpig_conv2d_dgrad(ctypes.byref(d), 8, 8, None, None, 8, None, 0, None) == -22
     d = _desc(lib, ldx=4)
-    assert h.dpig_conv2d_wgrad(ctypes.byref(d), 8, 8, 8, 0.0, None, 0, None) == -22
+    assert h.dpig_conv2d_wgrad(ctypes.byref(d), 8, 8, 8, 0.0, None, 0.0, None, 0, None) == -22
     d = _desc(lib)        # needs a workspace (split-K) but none is given
     assert h.dpig_conv2d_fwd(ctypes.byref(d), 16, 16, None, None, 16, None, None, 0, None) == -12
     with pytest.raises(RuntimeError):

@@ -160,6 +160,28 @@ def test_conv_wgrad_split_and_beta(dev):
         _close(out, w.grad + base)
 
 
+@pytest.mark.parametrize("shape", [(4, 16, 8, 64, 128, 3, 1), (2, 16, 8, 3, 64, 5, 2), (2, 16, 8, 256, 3, 3, 1),
+                                   (2, 9, 7, 36, 40, 3, 2)])
+def test_wgrad_fused_bias_gradient(dev, shape):
+    """db = sum over pixels of dy comes out of the wgrad launch (split and unsplit, beta 0 / 1)."""
+    import dpig_amd.hip_ops as H
+    from oracle import ops as O
+    N, Hh, W, C, K, k, s = shape
+    x = _rand((N, Hh, W, C), 1)
+    w = (_rand((k, k, C, K), 2) * 0.2).requires_grad_(True)
+    b = _rand((K,), 3).requires_grad_(True)
+    y = O.conv2d_same(x, w, b, s)
+    dy = _rand(tuple(y.shape), 4)
+    y.backward(dy)
+    base = _rand((K,), 5)
+    for split in (0, 1, 3):
+        db = base.float().to(dev).clone()
+        dw = H.conv2d_wgrad(x.float().to(dev), dy.float().to(dev), (k, k, C, K), stride=s, split_k=split,
+                            out=torch.empty(k, k, C, K, device=dev), beta=0.0, db=db, db_beta=1.0)
+        _close(dw, w.grad)
+        _close(db, b.grad + base)
+
+
 def test_conv_large_decoder_shape(dev):
     """dec4-sized layer (Market B=2): checks the many-tile path against the oracle."""
     import dpig_amd.hip_ops as H
