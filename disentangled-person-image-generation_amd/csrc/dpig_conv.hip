@@ -55,6 +55,7 @@ struct GGParams {
     int tap_nb, oy0, oys, ox0, oxs, w0, wa, wb;
     unsigned a_bytes, b_bytes;   // byte extents of A and B for the buffer descriptors
     int vec_epi;          // 1: every epilogue operand is 16-byte addressable (float4 path)
+    int vec_a;            // 1: the gathered operand alone is 16-byte loadable (thin-N layers: B is not)
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -270,7 +271,8 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GGParams p) {
         // bitwise & on purpose: short-circuit && compiles to exec-mask branches around each load
         const bool ok = live & t_kok & ((unsigned)(a_iy0[i] + t_oy) < (unsigned)p.Hs) &
                         ((unsigned)(a_ix0[i] + t_ox) < (unsigned)p.Ws);
-        ra[i] = gload4<VEC>(rsA, a_rowoff[i] + t_sA, ok, t_ck, p.Cs);
+        if (VEC || p.vec_a) ra[i] = gload4<true>(rsA, a_rowoff[i] + t_sA, ok & (t_ck < p.Cs), t_ck, p.Cs);
+        else ra[i] = gload4<false>(rsA, a_rowoff[i] + t_sA, ok, t_ck, p.Cs);
         if (B_ROWK) {
             rb[i] = gload4<VEC>(rsB, b_off[i] + t_sB, live & b_ok[i] & t_kok, t_ck, p.Cs);
         } else {
@@ -474,6 +476,7 @@ struct WGParams {
     unsigned mul_howo, shr_howo, mul_wo, shr_wo;   // magic numbers: m / HoWo and rem / Wo without v_rcp
     int vec_epi;                                   // 1: dw / partial rows are 16-byte addressable
     float* DB; float* bias_partial; float beta_b;  // fused bias gradient: db[co] = sum_pixels dy[., co]
+    int vec_x;                                     // 1: x alone is 16-byte loadable (Cout = 3: dy is not)
 };
 
 // n / d for 0 <= n < 2^31 with a precomputed (mul, shr); mul == 0 encodes d == 1
@@ -557,7 +560,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
                 const int iy = py >> p.shift, ix = px >> p.shift;
                 const bool ok = mok & (py >= 0) & (px >= 0) & (iy < p.H) & (ix < p.W);
                 const unsigned xoff = (unsigned)((((n * p.H + iy) * p.W + ix) * p.ldx + ci0 + q) * 4);
-                ra[i] = gload4<VEC>(rsX, xoff, ok & cx_ok, ci0 + q, p.C);
+                if (VEC || p.vec_x) ra[i] = gload4<true>(rsX, xoff, ok & (ci0 + q < p.C), ci0 + q, p.C);
+                else ra[i] = gload4<false>(rsX, xoff, ok, ci0 + q, p.C);
             }
         }
     };
@@ -804,6 +808,7 @@ static int launch_gg(GGParams& p, bool b_rowk, int nimg, long filter_elems, hipS
     p.cchunks = cdiv(p.Cs, BK);
     p.ktiles = p.ntaps * p.cchunks;
     bool vec = vec_ok(p.A, p.B, p.lda, p.Cs, p.Ncols);
+    p.vec_a = aligned16(p.A) && (p.lda % 4 == 0) && (p.Cs % 4 == 0);
     dim3 grid(p.mtiles * p.ntiles, 1, p.nsplit), block(256);
 #define DPIG_GG(BR, VE, NA) hipLaunchKernelGGL((gather_gemm_kernel<BR, VE, NA>), grid, block, 0, st, p)
     if (b_rowk) {
@@ -1052,6 +1057,7 @@ extern "C" int dpig_conv2d_wgrad(const DpigConvDesc* d, const float* x, const fl
     const bool vec = aligned16(x) && aligned16(dy) && (d->ldx % 4 == 0) && (d->ldy % 4 == 0) &&
                      (d->C % 4 == 0) && (d->K % 4 == 0);
     p.vec_epi = (d->K % 4 == 0) && aligned16(dw) && (p.nsplit == 1 || aligned16(ws));
+    p.vec_x = aligned16(x) && (d->ldx % 4 == 0) && (d->C % 4 == 0);
     dim3 grid(tiles, 1, p.nsplit), block(256);
 #define DPIG_WG(VE, NA, FL) hipLaunchKernelGGL((wgrad_kernel<VE, NA, FL>), grid, block, 0, st, p)
     if (flat) { if (narrow) DPIG_WG(false, true, true); else DPIG_WG(false, false, true); }
