@@ -98,8 +98,11 @@ def main():
         assert world == args.gpus, "launch with torch.distributed.run --nproc-per-node %d" % args.gpus
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        ndev = torch.cuda.device_count()
+        local_rank = local_rank % max(ndev, 1)            # (only the 1-GPU gloo smoke test shares a device)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world)      # "nccl" IS RCCL on ROCm
+        backend = os.environ.get("DPIG_DIST_BACKEND", "nccl")             # "nccl" IS RCCL on ROCm
+        dist.init_process_group(backend, rank=rank, world_size=world)
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
 

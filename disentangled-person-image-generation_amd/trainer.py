@@ -136,10 +136,6 @@ class GradAllReduce(object):
         if not self.enabled:
             return 1.0
         n = flat_grad.numel()
-        if torch.cuda.is_available() and torch.cuda.is_current_stream_capturing():
-            for o in range(0, n, self.bucket):      # stream-ordered inside a graph capture
-                self.dist.all_reduce(flat_grad[o:min(o + self.bucket, n)])
-            return 1.0 / self.world
         handles = []
         for o in range(0, n, self.bucket):
             handles.append(self.dist.all_reduce(flat_grad[o:min(o + self.bucket, n)], async_op=True))
@@ -296,9 +292,11 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
 
     # ---- hipGraph capture of the two optimizer ops ----------------------------------------------
     def enable_graphs(self, batch_g, batch_d, warmup=2):
-        """Capture g_optim and d_optim (fwd + bwd + all-reduce + Adam, ~900 launches) into two
-        hipGraphs.  Shapes are static, parameters/gradients/Adam state live at fixed addresses, the
-        Adam step counter is on the device, so one replay per optimizer call is the whole host cost.
+        """Capture g_optim and d_optim into hipGraphs.  Shapes are static, parameters/gradients/Adam state
+        live at fixed addresses and the Adam step counter is on the device, so a replay is the whole host
+        cost of ~900 launches.  Single GPU: one graph per optimizer op (fwd + bwd + Adam).  Data parallel:
+        the graph stops after the backward pass; the RCCL all-reduce of the flat gradient buffer and the
+        Adam launch follow eagerly on the same stream (collectives are kept out of the capture).
         Inputs are copied into static buffers; outputs are static tensors overwritten by each replay."""
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
@@ -310,14 +308,16 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
                 self._d_optim_eager(self._static_d)
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
+        self._graph_update = not self.allreduce.enabled       # fold all-reduce + Adam into the graph?
         gg, gd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         with torch.cuda.graph(gg):
-            out_g = self._g_optim_eager(self._static_g)
+            out_g = self._g_optim_eager(self._static_g, update=self._graph_update)
         with torch.cuda.graph(gd, pool=gg.pool()):
-            out_d = self._d_optim_eager(self._static_d)
+            out_d = self._d_optim_eager(self._static_d, update=self._graph_update)
         self._graphs = (gg, out_g, gd, out_d)
-        self.g_opt.t -= 1          # capturing recorded one step() each without executing it
-        self.d_opt.t -= 1
+        if self._graph_update:
+            self.g_opt.t -= 1          # capturing recorded one step() each without executing it
+            self.d_opt.t -= 1
 
     def _feed(self, static, batch):
         for k, v in batch.items():
@@ -329,7 +329,10 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
             return self._g_optim_eager(batch)
         self._feed(self._static_g, batch)
         self._graphs[0].replay()
-        self.g_opt.t += 1
+        if self._graph_update:
+            self.g_opt.t += 1
+        else:
+            self.g_opt.step(self.allreduce(self.G_flat.grad))
         return self._graphs[1]
 
     def d_optim(self, batch):
@@ -337,11 +340,14 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
             return self._d_optim_eager(batch)
         self._feed(self._static_d, batch)
         self._graphs[2].replay()
-        self.d_opt.t += 1
+        if self._graph_update:
+            self.d_opt.t += 1
+        else:
+            self.d_opt.step(self.allreduce(self.D_flat.grad))
         return self._graphs[3]
 
     # ---- the two optimizer ops -----------------------------------------------------------------
-    def _g_optim_eager(self, batch):
+    def _g_optim_eager(self, batch, update=True):
         """sess.run(g_optim): fwd E,G,D(fake); g_loss = sce(D(G),1) + 20*L1; bwd D(dgrad only),G,E; Adam."""
         self.G_flat.zero_grad()
         self.D_flat.set_requires_grad(False)
@@ -354,11 +360,11 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         g_loss.backward()
         self.D_flat.set_requires_grad(True)
         self.G_flat.finalize()
-        scale = self.allreduce(self.G_flat.grad)
-        self.g_opt.step(scale)
+        if update:
+            self.g_opt.step(self.allreduce(self.G_flat.grad))
         return {"g_loss": g_loss.detach(), "L1Loss": L1Loss.detach(), "g_loss_only": g_loss_only.detach(), "G": G.detach()}
 
-    def _d_optim_eager(self, batch):
+    def _d_optim_eager(self, batch, update=True):
         """sess.run(d_optim): fwd E,G (no grad), D(x), D(G); d_loss; bwd D; Adam(D)."""
         self.D_flat.zero_grad()
         with torch.no_grad():
@@ -369,8 +375,8 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
                              real_data=batch["x"], fake_data=G)
         d_loss.backward()
         self.D_flat.finalize()
-        scale = self.allreduce(self.D_flat.grad)
-        self.d_opt.step(scale)
+        if update:
+            self.d_opt.step(self.allreduce(self.D_flat.grad))
         return {"d_loss": d_loss.detach()}
 
     def train_step(self, batch_g, batch_d):
