@@ -386,3 +386,31 @@ def tf_rmsprop_step(p, g, ms, mom, lr, decay=0.9, momentum=0.0, eps=1e-10):
     ms = decay * ms + (1 - decay) * g * g
     mom = momentum * mom + lr * g / torch.sqrt(ms + eps)
     return p - mom, ms, mom
+
+
+def pose_encoder_fc_res(P, pose_rcv, z_num=32, repeat_num=4, hidden_num=512, scope="PoseAE/G_Pose_Encoder", alpha=0.2):
+    """models.py:488-499 with the LeakyReLU(0.2) of trainer.py:647-648."""
+    sc = _Scope(scope)
+    act = lambda t: O.leaky_relu(t, alpha)  # noqa: E731
+    x = _fc(P, sc, pose_rcv, hidden_num, act)
+    for _ in range(repeat_num):
+        res = x
+        x = _fc(P, sc, x, hidden_num, act)
+        x = _fc(P, sc, x, hidden_num, act)
+        x = res + x
+    return _fc(P, sc, x, z_num, None)
+
+
+def pose_decoder_fc_res(P, z, keypoint_num=18, repeat_num=4, hidden_num=512, scope="PoseAE/G_Pose_Decoder", alpha=0.2):
+    """models.py:501-515: coords head linear, visibility head sigmoid + binaryRound (forward value = round)."""
+    sc = _Scope(scope)
+    act = lambda t: O.leaky_relu(t, alpha)  # noqa: E731
+    x = _fc(P, sc, z, hidden_num, None)
+    for _ in range(repeat_num):
+        res = x
+        x = _fc(P, sc, x, hidden_num, act)
+        x = _fc(P, sc, x, hidden_num, act)
+        x = res + x
+    coord = _fc(P, sc, x, keypoint_num * 2, None)
+    vis_prob = torch.sigmoid(_fc(P, sc, x, keypoint_num, None))
+    return coord, torch.round(vis_prob), vis_prob
