@@ -59,7 +59,8 @@ SYMBOLS = {
     "dpig_linear_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
     "dpig_linear_wgrad": (_i, [_vp, _vp, _vp, _f, _i, _i, _i, _vp, _sz, _vp]),
     "dpig_crop_resize_fwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
-    "dpig_crop_resize_bwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "dpig_crop_resize_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
+    "dpig_crop_resize_bwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "dpig_upsample2x_fwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "dpig_upsample2x_bwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "dpig_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _i, _f, _vp]),

@@ -691,8 +691,21 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
 }
 
 // out[i] = beta*out[i] + sum_s partial[s][i]   (n multiple of 4, 16B aligned)
+// The last block also folds the fused bias-gradient partials (bpart[s][co] -> db[co]) when db != nullptr,
+// so a split-K wgrad costs one reduce launch, not two.
+__device__ __forceinline__ void splitk_bias_tail(const float* __restrict__ bpart, float* __restrict__ db, int K,
+                                                 int nsplit, float beta_b) {
+    if (db == nullptr || blockIdx.x != gridDim.x - 1) return;
+    for (int co = threadIdx.x; co < K; co += blockDim.x) {
+        float v = 0.f;
+        for (int s = 0; s < nsplit; ++s) v += bpart[(long)s * K + co];
+        db[co] = (beta_b != 0.f) ? beta_b * db[co] + v : v;
+    }
+}
 __global__ __launch_bounds__(256) void splitk_sum_kernel(const float* __restrict__ partial, float* __restrict__ out,
-                                                          long n4, int nsplit, float beta) {
+                                                          long n4, int nsplit, float beta,
+                                                          const float* __restrict__ bpart, float* __restrict__ db,
+                                                          int K, float beta_b) {
     const float4* p4 = reinterpret_cast<const float4*>(partial);
     float4* o4 = reinterpret_cast<float4*>(out);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
@@ -707,15 +720,18 @@ __global__ __launch_bounds__(256) void splitk_sum_kernel(const float* __restrict
         }
         o4[i] = v;
     }
+    splitk_bias_tail(bpart, db, K, nsplit, beta_b);
 }
 __global__ __launch_bounds__(256) void splitk_sum_scalar_kernel(const float* __restrict__ partial,
                                                                  float* __restrict__ out, long n, int nsplit,
-                                                                 float beta) {
+                                                                 float beta, const float* __restrict__ bpart,
+                                                                 float* __restrict__ db, int K, float beta_b) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
         float v = 0.f;
         for (int s = 0; s < nsplit; ++s) v += partial[(long)s * n + i];
         out[i] = (beta != 0.f) ? beta * out[i] + v : v;
     }
+    splitk_bias_tail(bpart, db, K, nsplit, beta_b);
 }
 
 // ================================================================================================
@@ -1071,15 +1087,13 @@ extern "C" int dpig_conv2d_wgrad(const DpigConvDesc* d, const float* x, const fl
             const long n4 = wsize / 4;
             int blocks = cdiv(n4, 256);
             if (blocks > 8 * kNumCU) blocks = 8 * kNumCU;
-            hipLaunchKernelGGL(splitk_sum_kernel, dim3(blocks), dim3(256), 0, st, p.partial, dw, n4, p.nsplit, beta);
+            hipLaunchKernelGGL(splitk_sum_kernel, dim3(blocks), dim3(256), 0, st, p.partial, dw, n4, p.nsplit, beta,
+                               p.bias_partial, db, d->K, beta_b);
         } else {
             int blocks = cdiv(wsize, 256);
             if (blocks > 8 * kNumCU) blocks = 8 * kNumCU;
-            hipLaunchKernelGGL(splitk_sum_scalar_kernel, dim3(blocks), dim3(256), 0, st, p.partial, dw, wsize, p.nsplit, beta);
-        }
-        if (db) {
-            hipLaunchKernelGGL(splitk_sum_scalar_kernel, dim3(cdiv(d->K, 256)), dim3(256), 0, st, p.bias_partial, db,
-                               (long)d->K, p.nsplit, beta_b);
+            hipLaunchKernelGGL(splitk_sum_scalar_kernel, dim3(blocks), dim3(256), 0, st, p.partial, dw, wsize, p.nsplit,
+                               beta, p.bias_partial, db, d->K, beta_b);
         }
         rc = check_launch("splitk_sum_kernel");
     }

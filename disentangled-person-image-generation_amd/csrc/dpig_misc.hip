@@ -383,20 +383,26 @@ __global__ __launch_bounds__(1024) void ln_bwd2_kernel(const float* __restrict__
 // tf.image.crop_and_resize (bilinear, extrapolation_value 0) and its image gradient
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ bool crop_coord(float b1, float b2, int i, int crop, int size, float* pos) {
+    // no fma contraction: the forward and both backward passes must take bit-identical in/out-of-image
+    // decisions for a sample, whatever code surrounds the inlined expression (TF's CPU kernel does not fuse)
+#pragma clang fp contract(off)
     const float in = (crop > 1) ? b1 * (size - 1) + i * ((b2 - b1) * (size - 1) / (float)(crop - 1))
                                 : 0.5f * (b1 + b2) * (size - 1);
     *pos = in;
     return !(in < 0.f || in > (float)(size - 1));
 }
 
+// forward: one thread per (box, crop pixel, channel quad) -- 16-byte loads/stores when C % 4 == 0
+template <int V>
 __global__ __launch_bounds__(256) void crop_resize_fwd_kernel(const float* __restrict__ img, int H, int W, int C,
                                                               const float* __restrict__ boxes,
                                                               const int* __restrict__ box_ind, int nbox, int ch,
                                                               int cw, float* __restrict__ out) {
-    const long total = (long)nbox * ch * cw * C;
+    const int CV = C / V;
+    const long total = (long)nbox * ch * cw * CV;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        long t = i / C;
+        const int c = (int)(i % CV) * V;
+        long t = i / CV;
         const int j = (int)(t % cw); t /= cw;
         const int ii = (int)(t % ch);
         const int b = (int)(t / ch);
@@ -404,48 +410,142 @@ __global__ __launch_bounds__(256) void crop_resize_fwd_kernel(const float* __res
         float in_y, in_x;
         const bool oky = crop_coord(y1, y2, ii, ch, H, &in_y);
         const bool okx = crop_coord(x1, x2, j, cw, W, &in_x);
-        float v = 0.f;
+        float v[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) v[e] = 0.f;
         if (oky && okx) {
             const int ty = (int)floorf(in_y), by = (int)ceilf(in_y);
             const int lx = (int)floorf(in_x), rx = (int)ceilf(in_x);
             const float ly = in_y - ty, lxw = in_x - lx;
             const float* base = img + (long)box_ind[b] * H * W * C + c;
-            const float tl = base[((long)ty * W + lx) * C], tr = base[((long)ty * W + rx) * C];
-            const float bl = base[((long)by * W + lx) * C], br = base[((long)by * W + rx) * C];
-            const float top = tl + (tr - tl) * lxw;
-            const float bot = bl + (br - bl) * lxw;
-            v = top + (bot - top) * ly;
+            const float* ptl = base + ((long)ty * W + lx) * C;
+            const float* ptr_ = base + ((long)ty * W + rx) * C;
+            const float* pbl = base + ((long)by * W + lx) * C;
+            const float* pbr = base + ((long)by * W + rx) * C;
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                const float tl = ptl[e], tr = ptr_[e], bl = pbl[e], br = pbr[e];
+                const float top = tl + (tr - tl) * lxw;
+                const float bot = bl + (br - bl) * lxw;
+                v[e] = top + (bot - top) * ly;
+            }
         }
-        out[i] = v;
+        float* o = out + ((((long)b * ch + ii) * cw + j) * C + c);
+#pragma unroll
+        for (int e = 0; e < V; ++e) o[e] = v[e];
     }
 }
 
-__global__ __launch_bounds__(256) void crop_resize_bwd_kernel(const float* __restrict__ dout, int H, int W, int C,
-                                                              const float* __restrict__ boxes,
-                                                              const int* __restrict__ box_ind, int nbox, int ch,
-                                                              int cw, float* __restrict__ dimg) {
-    const long total = (long)nbox * ch * cw * C;
+// backward as two separable GATHER passes (deterministic: no atomics, fixed summation order).
+// A sample at continuous coordinate `in` scatters onto integer position p with the bilinear hat weight
+// max(0, 1-|in-p|) (floor gets 1-lerp, ceil gets lerp), and the 2-D weight is the product of the two 1-D
+// ones, so   dimg[n,y,x] = sum_{b: ind[b]=n} sum_i hat(in_y(b,i)-y) * ( sum_j hat(in_x(b,j)-x) * dout[b,i,j] ).
+// Pass X forms the bracket into tmp[b,i,x,:], pass Y finishes.  Out-of-image samples (extrapolation) carry no
+// gradient; crop_coord() reproduces the forward's decision bit for bit.  (TF: CropAndResizeGradImage.)
+__device__ __forceinline__ void crop_range(float b1, float b2, int crop, int size, int p, int* lo, int* hi) {
+    // sample indices whose coordinate can fall in (p-1, p+1); conservative by one on both sides
+    if (crop <= 1) { *lo = 0; *hi = 0; return; }
+    const float step = (b2 - b1) * (size - 1) / (float)(crop - 1);
+    const float org = b1 * (size - 1);
+    if (fabsf(step) < 1e-12f) { *lo = 0; *hi = crop - 1; return; }
+    float a = ((float)(p - 1) - org) / step, b = ((float)(p + 1) - org) / step;
+    if (a > b) { const float t = a; a = b; b = t; }
+    a = fmaxf(a, -2.f); b = fminf(b, (float)crop + 1.f);
+    const int l = (int)floorf(a) - 1, h = (int)ceilf(b) + 1;
+    *lo = l < 0 ? 0 : l;
+    *hi = h > crop - 1 ? crop - 1 : h;
+}
+template <int V>
+__global__ __launch_bounds__(256) void crop_bwd_x_kernel(const float* __restrict__ dout, int W, int C,
+                                                         const float* __restrict__ boxes, int nbox, int ch, int cw,
+                                                         float* __restrict__ tmp) {
+    const int CV = C / V;
+    const long total = (long)nbox * ch * W * CV;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % C);
-        long t = i / C;
-        const int j = (int)(t % cw); t /= cw;
-        const int ii = (int)(t % ch);
+        const int c = (int)(i % CV) * V;
+        long t = i / CV;
+        const int x = (int)(t % W); t /= W;                  // t = b*ch + ii
         const int b = (int)(t / ch);
-        const float y1 = boxes[b * 4 + 0], x1 = boxes[b * 4 + 1], y2 = boxes[b * 4 + 2], x2 = boxes[b * 4 + 3];
-        float in_y, in_x;
-        const bool oky = crop_coord(y1, y2, ii, ch, H, &in_y);
-        const bool okx = crop_coord(x1, x2, j, cw, W, &in_x);
-        if (!(oky && okx)) continue;
-        const int ty = (int)floorf(in_y), by = (int)ceilf(in_y);
-        const int lx = (int)floorf(in_x), rx = (int)ceilf(in_x);
-        const float ly = in_y - ty, lxw = in_x - lx;
-        const float g = dout[i];
-        float* base = dimg + (long)box_ind[b] * H * W * C + c;
-        const float dtop = (1.f - ly) * g, dbot = ly * g;
-        atomicAdd(&base[((long)ty * W + lx) * C], (1.f - lxw) * dtop);
-        atomicAdd(&base[((long)ty * W + rx) * C], lxw * dtop);
-        atomicAdd(&base[((long)by * W + lx) * C], (1.f - lxw) * dbot);
-        atomicAdd(&base[((long)by * W + rx) * C], lxw * dbot);
+        const float x1 = boxes[b * 4 + 1], x2 = boxes[b * 4 + 3];
+        int jlo, jhi;
+        crop_range(x1, x2, cw, W, x, &jlo, &jhi);
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = 0.f;
+        const float* g = dout + (t * cw) * C + c;
+        for (int j = jlo; j <= jhi; ++j) {
+            float in_x;
+            if (!crop_coord(x1, x2, j, cw, W, &in_x)) continue;
+            const float w = 1.f - fabsf(in_x - (float)x);
+            if (w <= 0.f) continue;
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[e] += w * g[(long)j * C + e];
+        }
+        float* o = tmp + (t * W + x) * C + c;
+#pragma unroll
+        for (int e = 0; e < V; ++e) o[e] = acc[e];
+    }
+}
+// pass Y: one thread per (image pixel, channel quad).  The boxes of the block's image(s) are first marked in an
+// LDS bitmask (atomicOr: order-free), then visited in increasing box order by every thread.
+template <int V>
+__global__ __launch_bounds__(256) void crop_bwd_y_kernel(const float* __restrict__ tmp, int N, int H, int W, int C,
+                                                         const float* __restrict__ boxes,
+                                                         const int* __restrict__ box_ind, int nbox, int ch,
+                                                         float* __restrict__ dimg) {
+    __shared__ unsigned s_mask[32];
+    const int CV = C / V;
+    const long per_img = (long)H * W * CV;
+    const long total = (long)N * per_img;
+    const long i0 = (long)blockIdx.x * blockDim.x;
+    const long i = i0 + threadIdx.x;
+    const bool live = i < total;
+    const long ic = live ? i : total - 1;
+    const int c = (int)(ic % CV) * V;
+    long t = ic / CV;
+    const int x = (int)(t % W); t /= W;
+    const int y = (int)(t % H);
+    const int n = (int)(t / H);
+    const int n_lo = (int)(i0 / per_img);
+    const long ilast = (i0 + blockDim.x - 1 < total) ? i0 + blockDim.x - 1 : total - 1;
+    const int n_hi = (int)(ilast / per_img);
+    float acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = 0.f;
+    for (int base = 0; base < nbox; base += 1024) {
+        if (threadIdx.x < 32) s_mask[threadIdx.x] = 0u;
+        __syncthreads();
+        for (int b = base + threadIdx.x; b < nbox && b < base + 1024; b += blockDim.x) {
+            const int ind = box_ind[b];
+            if (ind >= n_lo && ind <= n_hi) atomicOr(&s_mask[(b - base) >> 5], 1u << ((b - base) & 31));
+        }
+        __syncthreads();
+        for (int wd = 0; wd < 32; ++wd) {
+            unsigned m = s_mask[wd];
+            while (m) {
+                const int b = base + wd * 32 + (__ffs((int)m) - 1);
+                m &= m - 1;
+                if (box_ind[b] != n) continue;
+                const float y1 = boxes[b * 4 + 0], y2 = boxes[b * 4 + 2];
+                int ilo, ihi;
+                crop_range(y1, y2, ch, H, y, &ilo, &ihi);
+                const float* g = tmp + (((long)b * ch) * W + x) * C + c;
+                for (int ii = ilo; ii <= ihi; ++ii) {
+                    float in_y;
+                    if (!crop_coord(y1, y2, ii, ch, H, &in_y)) continue;
+                    const float w = 1.f - fabsf(in_y - (float)y);
+                    if (w <= 0.f) continue;
+#pragma unroll
+                    for (int e = 0; e < V; ++e) acc[e] += w * g[(long)ii * W * C + e];
+                }
+            }
+        }
+        __syncthreads();
+    }
+    if (live) {
+        float* o = dimg + (((long)n * H + y) * W + x) * C + c;
+#pragma unroll
+        for (int e = 0; e < V; ++e) o[e] = acc[e];
     }
 }
 
@@ -807,16 +907,39 @@ extern "C" int dpig_crop_resize_fwd(const float* img, int N, int H, int W, int C
                                     const int32_t* box_ind, int nbox, int ch, int cw, float* out, void* stream) {
     if (!img || !boxes || !box_ind || !out) return fail(DPIG_EINVAL, "crop_resize: null pointer");
     if (N <= 0 || nbox <= 0 || ch <= 0 || cw <= 0) return fail(DPIG_EINVAL, "crop_resize: empty");
-    hipLaunchKernelGGL(crop_resize_fwd_kernel, dim3(grid_for((long)nbox * ch * cw * C)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), img, H, W, C, boxes, box_ind, nbox, ch, cw, out);
+    if (C % 4 == 0 && aligned16(img) && aligned16(out))
+        hipLaunchKernelGGL((crop_resize_fwd_kernel<4>), dim3(grid_for((long)nbox * ch * cw * (C / 4))), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), img, H, W, C, boxes, box_ind, nbox, ch, cw, out);
+    else
+        hipLaunchKernelGGL((crop_resize_fwd_kernel<1>), dim3(grid_for((long)nbox * ch * cw * C)), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), img, H, W, C, boxes, box_ind, nbox, ch, cw, out);
     return check_launch("crop_resize_fwd");
 }
+extern "C" size_t dpig_crop_resize_bwd_workspace_bytes(int W, int C, int nbox, int ch) {
+    if (W <= 0 || C <= 0 || nbox <= 0 || ch <= 0) return 0;
+    return (size_t)nbox * ch * W * C * sizeof(float);
+}
 extern "C" int dpig_crop_resize_bwd(const float* dout, int N, int H, int W, int C, const float* boxes,
-                                    const int32_t* box_ind, int nbox, int ch, int cw, float* dimg, void* stream) {
+                                    const int32_t* box_ind, int nbox, int ch, int cw, float* dimg, void* ws,
+                                    size_t ws_bytes, void* stream) {
     if (!dout || !boxes || !box_ind || !dimg) return fail(DPIG_EINVAL, "crop_resize: null pointer");
     if (N <= 0 || nbox <= 0 || ch <= 0 || cw <= 0) return fail(DPIG_EINVAL, "crop_resize: empty");
-    hipLaunchKernelGGL(crop_resize_bwd_kernel, dim3(grid_for((long)nbox * ch * cw * C)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), dout, H, W, C, boxes, box_ind, nbox, ch, cw, dimg);
+    if (!ws || ws_bytes < dpig_crop_resize_bwd_workspace_bytes(W, C, nbox, ch))
+        return fail(DPIG_ENOMEM, "crop_resize_bwd workspace too small: have %zu", ws_bytes);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* tmp = static_cast<float*>(ws);
+    const bool v4 = (C % 4 == 0) && aligned16(dout) && aligned16(dimg) && aligned16(ws);
+    const long nx = (long)nbox * ch * W * (v4 ? C / 4 : C);
+    const long ny = (long)N * H * W * (v4 ? C / 4 : C);
+    if (ny > 256L * 0x7fffffffL) return fail(DPIG_EINVAL, "crop_resize_bwd: image too large");
+    const dim3 gy((unsigned)((ny + 255) / 256));
+    if (v4) {
+        hipLaunchKernelGGL((crop_bwd_x_kernel<4>), dim3(grid_for(nx)), dim3(256), 0, st, dout, W, C, boxes, nbox, ch, cw, tmp);
+        hipLaunchKernelGGL((crop_bwd_y_kernel<4>), gy, dim3(256), 0, st, tmp, N, H, W, C, boxes, box_ind, nbox, ch, dimg);
+    } else {
+        hipLaunchKernelGGL((crop_bwd_x_kernel<1>), dim3(grid_for(nx)), dim3(256), 0, st, dout, W, C, boxes, nbox, ch, cw, tmp);
+        hipLaunchKernelGGL((crop_bwd_y_kernel<1>), gy, dim3(256), 0, st, tmp, N, H, W, C, boxes, box_ind, nbox, ch, dimg);
+    }
     return check_launch("crop_resize_bwd");
 }
 

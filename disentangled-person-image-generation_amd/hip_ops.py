@@ -391,9 +391,10 @@ def crop_resize_bwd(dout, boxes, box_ind, img_shape):
     boxes = boxes.contiguous().float()
     box_ind = box_ind.contiguous().to(torch.int32)
     nb, ch, cw, _ = dout.shape
-    dimg = torch.zeros(tuple(img_shape), dtype=torch.float32, device=dout.device)
+    dimg = torch.empty(tuple(img_shape), dtype=torch.float32, device=dout.device)
+    wsb, wsn = workspace.get(lib().dpig_crop_resize_bwd_workspace_bytes(W, C, nb, ch), dout.device)
     check(lib().dpig_crop_resize_bwd(ptr(dout), N, H, W, C, ptr(boxes), ptr(box_ind), nb, ch, cw, ptr(dimg),
-                                     stream_ptr()), "crop_resize_bwd")
+                                     ptr(wsb), wsn, stream_ptr()), "crop_resize_bwd")
     return dimg
 
 

@@ -166,9 +166,12 @@ int dpig_linear_wgrad(const float* x, const float* dy, float* dw, float beta, in
  * out: [nbox, ch, cw, C]. */
 int dpig_crop_resize_fwd(const float* img, int N, int H, int W, int C, const float* boxes,
                          const int32_t* box_ind, int nbox, int ch, int cw, float* out, void* stream);
-/* dimg must be zero-initialised by the caller (scatter-add). */
+/* Image gradient (TF CropAndResizeGradImage) as two separable gather passes: deterministic, no atomics;
+ * dimg [N,H,W,C] is fully overwritten.  ws: dpig_crop_resize_bwd_workspace_bytes(W, C, nbox, ch) bytes. */
+size_t dpig_crop_resize_bwd_workspace_bytes(int W, int C, int nbox, int ch);
 int dpig_crop_resize_bwd(const float* dout, int N, int H, int W, int C, const float* boxes,
-                         const int32_t* box_ind, int nbox, int ch, int cw, float* dimg, void* stream);
+                         const int32_t* box_ind, int nbox, int ch, int cw, float* dimg, void* ws,
+                         size_t ws_bytes, void* stream);
 
 /* ---- nearest-neighbour 2x upsample (unfused form; utils.py:61-72) ---------------------------- */
 int dpig_upsample2x_fwd(const float* x, int N, int H, int W, int C, float* y, void* stream);

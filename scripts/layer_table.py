@@ -19,5 +19,9 @@ for k, f, a, b, lab in recs:
     key = (k, lab); d = agg.setdefault(key, [0, 0.0, 0.0]); d[0] += 1; d[1] += f; d[2] += a.elapsed_time(b) * 1e-3
 tot = sum(v[2] for v in agg.values())
 print("step %.2f ms (instrumented); conv total %.2f ms" % (e0.elapsed_time(e1) / 3, tot / 3 * 1e3))
-for (k, lab), v in sorted(agg.items(), key=lambda kv: -kv[1][2])[:45]:
-    print("%-16s N%-3d %3dx%-3d C%-4d K%-4d k%d s%d u%d | n/step %4.1f  ms/step %6.3f  %6.1f TF" % ((k,) + lab + (v[0] / 3, v[2] / 3 * 1e3, v[1] / v[2] / 1e12)))
+CEIL = 130e12   # what the pure-MFMA loop structure sustains
+tf = sum(v[1] for v in agg.values())
+print("executed %.2f TFLOP/step -> %.1f TF average; at %.0f TF everywhere: %.2f ms" % (tf / 3 / 1e12, tf / tot / 1e12, CEIL / 1e12, tf / 3 / CEIL * 1e3))
+lost = lambda v: (v[2] - v[1] / CEIL) / 3 * 1e3
+for (k, lab), v in sorted(agg.items(), key=lambda kv: -lost(kv[1])):
+    print("%-16s N%-3d %3dx%-3d C%-4d K%-4d k%d s%d u%d | n/step %4.1f  ms/step %6.3f  %6.1f TF  lost %6.3f ms" % ((k,) + lab + (v[0] / 3, v[2] / 3 * 1e3, v[1] / v[2] / 1e12, lost(v))))

@@ -101,6 +101,37 @@ def test_crop_and_resize(dev):
     _close(dimg, img.grad, 5e-5)
 
 
+@pytest.mark.parametrize("C", [128, 6])
+def test_crop_and_resize_roi_shapes(dev, C):
+    """ROI-tower shapes (models.py:410-415): 7 parts x B boxes, 48x48 crops of a 128x64 map; also degenerate
+    (zero-height), flipped (y2<y1) and partly outside boxes.  The backward is a gather: bitwise repeatable."""
+    import dpig_amd.hip_ops as H
+    from oracle import ops as O
+    B, Hh, W = 2, 128, 64
+    g = torch.Generator().manual_seed(5)
+    img = _rand((B, Hh, W, C), 3).requires_grad_(True)
+    y1 = torch.randint(0, 64, (7 * B,), generator=g).double()
+    x1 = torch.randint(0, 32, (7 * B,), generator=g).double()
+    hh = torch.randint(8, 64, (7 * B,), generator=g).double()
+    ww = torch.randint(8, 32, (7 * B,), generator=g).double()
+    px = torch.stack([y1, x1, y1 + hh, x1 + ww], 1)
+    px[0] = torch.tensor([0., 0., 1., 1.])          # invisible-part sentinel
+    px[1] = torch.tensor([20., 5., 20., 30.])       # zero height
+    px[2] = torch.tensor([90., 40., 30., 10.])      # flipped
+    px[3] = torch.tensor([100., 50., 160., 80.])    # runs off the image
+    boxes = px / torch.tensor([Hh, W, Hh, W], dtype=torch.float64)
+    box_ind = torch.arange(B).repeat(7)
+    ref = O.crop_and_resize(img, boxes, box_ind, 48, 48)
+    dout = _rand(tuple(ref.shape), 4)
+    ref.backward(dout)
+    bd, bi = boxes.float().to(dev), box_ind.to(dev)
+    _close(H.crop_resize_fwd(img.detach().float().to(dev), bd, bi, 48, 48), ref)
+    d1 = H.crop_resize_bwd(dout.float().to(dev), bd, bi, (B, Hh, W, C))
+    d2 = H.crop_resize_bwd(dout.float().to(dev), bd, bi, (B, Hh, W, C))
+    assert torch.equal(d1, d2)
+    _close(d1, img.grad, 1e-4)
+
+
 def test_upsample_act_colsum(dev):
     import dpig_amd.hip_ops as H
     from oracle import ops as O
