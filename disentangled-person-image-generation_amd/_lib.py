@@ -10,7 +10,7 @@ import os
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdpig_hip.so")
+LIB_PATH = os.environ.get("DPIG_LIB_PATH") or os.path.join(_HERE, "libdpig_hip.so")   # (override: A/B kernel experiments)
 
 ACT_NONE, ACT_RELU, ACT_LRELU = 0, 1, 2
 

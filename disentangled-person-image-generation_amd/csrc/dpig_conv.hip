@@ -18,7 +18,24 @@
 //
 // Reference semantics: tf.nn.conv2d 'SAME' (tflib/ops/conv2d.py:106-112), slim.conv2d
 // (models.py:396-573) and the gradients TF autodiff derives for them (trainer.py:137-140).
+#include <type_traits>
 #include "dpig_common.h"
+#ifndef DPIG_PIPE2
+#define DPIG_PIPE2 1
+#endif
+#ifdef DPIG_TRACE   // dev aid (never in the shipped build): s_memtime stamps of wave 0 of the first 512 workgroups
+__device__ unsigned long long dpig_trace_buf[512 * 256];
+__device__ unsigned long long dpig_trace_se[8192 * 4];     // start / end tick of every workgroup
+extern "C" int dpig_debug_trace_read_se(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dpig_trace_se), sizeof(unsigned long long) * n);
+}
+#define DPIG_STAMP(slot) do { if (trace_on && trace_n < 256 && ((slot) == 0 || (slot) >= 5)) dpig_trace_buf[blockIdx.x * 256 + trace_n++] = ((unsigned long long)(slot) << 56) | (__builtin_amdgcn_s_memtime() & 0x00ffffffffffffffull); } while (0)
+extern "C" int dpig_debug_trace_read(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dpig_trace_buf), sizeof(unsigned long long) * n);
+}
+#else
+#define DPIG_STAMP(slot) do { } while (0)
+#endif
 
 namespace dpig {
 
@@ -303,6 +320,15 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GGParams p) {
         }
     };
 
+    auto store_a = [&](int buf, int i) {
+        *reinterpret_cast<float4*>(&smem[buf][((tid >> 3) + 32 * i) * LDR + a_kq * 4]) = ra[i];
+    };
+    auto store_b = [&](int buf, int i) {
+        float* Bs = smem[buf] + TILE_FLOATS;
+        if (B_ROWK) *reinterpret_cast<float4*>(&Bs[((tid >> 3) + 32 * i) * LDR + a_kq * 4]) = rb[i];
+        else *reinterpret_cast<float4*>(&Bs[((tid >> 5) + 8 * i) * LDKN + (tid & 31) * 4]) = rb[i];
+    };
+
     // LDS -> register fragments of k-step kk (8 k values: lane half h takes k = kk*8 + 4h + j)
     auto load_frag = [&](const float* As, const float* Bs, int kk, float4 (&fa)[MB], float4 (&fb)[NB]) {
 #pragma unroll
@@ -327,6 +353,13 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GGParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+#ifdef DPIG_TRACE
+    const bool trace_on = ((int)blockIdx.x < 512) && (blockIdx.z == 0) && (tid == 0);
+    int trace_n = 0;
+    if (trace_on) dpig_trace_buf[blockIdx.x * 256 + trace_n++] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+    DPIG_STAMP(0);
+    if (tid == 0 && blockIdx.x < 8192 && blockIdx.z == 0) { dpig_trace_se[blockIdx.x * 4] = __builtin_amdgcn_s_memtime(); dpig_trace_se[blockIdx.x * 4 + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4); }
+#endif
     if (kt_begin < kt_end) {
         load_tiles();
         store_tiles(0);
@@ -339,6 +372,60 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GGParams p) {
             load_begin();
             const float* As = smem[buf];
             const float* Bs = smem[buf] + TILE_FLOATS;
+#if DPIG_PIPE2
+            DPIG_STAMP(1);
+            // Schedule of one k-tile = 4 groups (kk) of 4 quads (j) of 4 MFMAs.  The hand-over of tile t+1 is
+            // spread BEHIND this tile's MFMAs instead of sitting between two tiles: HBM/L2 loads are issued
+            // at the head of groups 0 and 1; the eight 16-byte LDS stores go one or two at a time after the
+            // quads of groups 2 and 3 (a ds_write_b128 occupies the store path ~13 cycles, an MFMA quad keeps
+            // the matrix pipe busy >= 256); the barrier and the first fragment reads of tile t+1 come before
+            // the LAST quad, which covers their latency.  With the whole hand-over after group 3 a wave feeds
+            // nothing to the matrix pipe for ~1700 cycles per tile (s_memtime trace), and since the two
+            // workgroups of a CU run the same code in phase nobody else does either.
+#pragma unroll
+            for (int kk = 0; kk < BK / 8; ++kk) {
+                if (kk + 1 < BK / 8) load_frag(As, Bs, kk + 1, fa[(kk + 1) & 1], fb[(kk + 1) & 1]);
+                if (kk < 2) { load_part(2 * kk, more); load_part(2 * kk + 1, more); }
+                __builtin_amdgcn_sched_barrier(0);  // keep the memory ops HERE, ahead of the MFMA group
+                float av[MB][4], bv[NB][4];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) {
+                    const float4 t = fa[kk & 1][mb];
+                    av[mb][0] = t.x; av[mb][1] = t.y; av[mb][2] = t.z; av[mb][3] = t.w;
+                }
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) {
+                    const float4 t = fb[kk & 1][nb];
+                    bv[nb][0] = t.x; bv[nb][1] = t.y; bv[nb][2] = t.z; bv[nb][3] = t.w;
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (kk == 3 && j == 3) {           // publish tile t+1, request its first fragments
+                        DPIG_STAMP(2);
+                        __syncthreads();
+                        DPIG_STAMP(4);
+                        load_frag(smem[buf ^ 1], smem[buf ^ 1] + TILE_FLOATS, 0, fa[0], fb[0]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mb][j], bv[nb][j], acc[mb][nb], 0, 0, 0);
+                    if (kk == 2) {                     // stores of parts 0,1: one per quad
+                        __builtin_amdgcn_sched_barrier(0);
+                        if ((j & 1) == 0) store_a(buf ^ 1, j >> 1); else store_b(buf ^ 1, j >> 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else if (kk == 3 && j < 2) {     // parts 2,3: two per quad, done two quads before the barrier
+                        __builtin_amdgcn_sched_barrier(0);
+                        store_a(buf ^ 1, 2 + j); store_b(buf ^ 1, 2 + j);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            buf ^= 1;
+#else
 #pragma unroll
             for (int kk = 0; kk < BK / 8; ++kk) {
                 if (kk + 1 < BK / 8) load_frag(As, Bs, kk + 1, fa[(kk + 1) & 1], fb[(kk + 1) & 1]);
@@ -368,9 +455,14 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GGParams p) {
             __syncthreads();
             buf ^= 1;
             load_frag(smem[buf], smem[buf] + TILE_FLOATS, 0, fa[0], fb[0]);
+#endif
         }
     }
 
+    DPIG_STAMP(5);
+#ifdef DPIG_TRACE
+    if (tid == 0 && blockIdx.x < 8192 && blockIdx.z == 0) dpig_trace_se[blockIdx.x * 4 + 1] = __builtin_amdgcn_s_memtime();
+#endif
     // ---- epilogue ------------------------------------------------------------------------------
     // The accumulators go through LDS (the operand ring is dead now) so that every global access of
     // the fused epilogue -- bias, residual, activation mask, the one or two outputs, split-K partials
@@ -379,6 +471,7 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GGParams p) {
     constexpr int LDC = BN + 4;
     float* Cs = &smem[0][0];                       // 128 x 132 floats = 67.6 KB <= 73.7 KB
     __syncthreads();                               // (the loop's last barrier already passed; cheap)
+    DPIG_STAMP(6);
 #pragma unroll
     for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
@@ -386,7 +479,9 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GGParams p) {
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb)
                 Cs[(wrow + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDC + wcol + nb * 32 + l31] = acc[mb][nb][r];
+    DPIG_STAMP(7);
     __syncthreads();
+    DPIG_STAMP(8);
 
     if (p.vec_epi) {
         const int c = (tid & 31) * 4;
@@ -394,19 +489,75 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GGParams p) {
         if (col < p.Ncols && c < BNT) {
             float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
             if (p.bias && p.nsplit == 1) bv = *reinterpret_cast<const float4*>(p.bias + col);
+            const int rl0 = tid >> 5;
+            if (p.nsplit > 1) {
+                float* pp = p.partial + ((long)split * p.M + m0 + rl0) * p.Ncols + col;
 #pragma unroll 4
-            for (int it = 0; it < 16; ++it) {
-                const int rl = (tid >> 5) + 8 * it;
-                const int row = m0 + rl;
-                if (row >= p.M) continue;
-                float4 v = *reinterpret_cast<const float4*>(&Cs[rl * LDC + c]);
-                if (p.nsplit > 1) {
-                    *reinterpret_cast<float4*>(&p.partial[((long)split * p.M + row) * p.Ncols + col]) = v;
-                    continue;
+                for (int it = 0; it < 16; ++it) {
+                    if (m0 + rl0 + 8 * it < p.M)
+                        *reinterpret_cast<float4*>(pp + (long)(8 * it) * p.Ncols) =
+                            *reinterpret_cast<const float4*>(&Cs[(rl0 + 8 * it) * LDC + c]);
                 }
-                epi_vec4(p, row, col, v, bv);
+            } else if (p.identity_rows && !p.res_class && !p.replicate) {
+                // Lean path for the common case (output row == pixel): no index arithmetic, no per-element
+                // switches -- one slope for all three activations, row pointers advancing by 8 rows.  The four
+                // flag combinations the model produces get their own straight-line loop body; the co-resident
+                // workgroup is streaming MFMAs meanwhile, and every scalar branch / VALU op issued here waits
+                // its turn behind them (the generic epilogue measured ~48k cycles per tile, 7 % of a
+                // 72-k-tile workgroup's life).
+                const float slope = (p.act == DPIG_ACT_NONE) ? 1.f : ((p.act == DPIG_ACT_RELU) ? 0.f : p.alpha);
+                auto run = [&](auto HAS_RES, auto RES_POST, auto HAS_MASK, auto HAS_D2) {
+                    const long r0 = (long)(m0 + rl0);
+                    float* dp = p.D + r0 * p.ldd + col;
+                    const float* rp = HAS_RES ? p.res + r0 * p.ldres + col : nullptr;
+                    const float* mp = HAS_MASK ? p.mask + r0 * p.ldmask + col : nullptr;
+                    float* d2 = HAS_D2 ? p.D2 + r0 * p.ldd2 + col : nullptr;
+#pragma unroll 4
+                    for (int it = 0; it < 16; ++it) {
+                        if (m0 + rl0 + 8 * it >= p.M) break;
+                        float4 v = *reinterpret_cast<const float4*>(&Cs[(rl0 + 8 * it) * LDC + c]);
+                        v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+                        float4 rv = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (HAS_RES) rv = *reinterpret_cast<const float4*>(rp + (long)(8 * it) * p.ldres);
+                        if (HAS_RES && !RES_POST) { v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
+                        if (HAS_MASK) {
+                            const float4 mv = *reinterpret_cast<const float4*>(mp + (long)(8 * it) * p.ldmask);
+                            v.x *= (mv.x > 0.f) ? 1.f : slope; v.y *= (mv.y > 0.f) ? 1.f : slope;
+                            v.z *= (mv.z > 0.f) ? 1.f : slope; v.w *= (mv.w > 0.f) ? 1.f : slope;
+                        } else {
+                            // (+0.f: RELU of a negative is +0 as with max(v, 0), not -0)
+                            v.x = (v.x > 0.f) ? v.x : (v.x * slope + 0.f); v.y = (v.y > 0.f) ? v.y : (v.y * slope + 0.f);
+                            v.z = (v.z > 0.f) ? v.z : (v.z * slope + 0.f); v.w = (v.w > 0.f) ? v.w : (v.w * slope + 0.f);
+                        }
+                        if (HAS_D2) *reinterpret_cast<float4*>(d2 + (long)(8 * it) * p.ldd2) = v;
+                        if (HAS_RES && RES_POST) { v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
+                        *reinterpret_cast<float4*>(dp + (long)(8 * it) * p.ldd) = v;
+                    }
+                };
+                using T = std::true_type; using F = std::false_type;
+                const bool hr = p.res != nullptr, hm = p.mask != nullptr, h2 = p.D2 != nullptr, rpost = p.res_post != 0;
+                if (!hr && !hm && !h2) run(F{}, F{}, F{}, F{});                 // bias + activation
+                else if (hr && !rpost && !hm && !h2) run(T{}, F{}, F{}, F{});   // + residual before the activation (dgrad accumulate)
+                else if (!hr && hm && !h2) run(F{}, F{}, T{}, F{});             // dgrad * activation mask
+                else if (hr && rpost && !hm && h2) run(T{}, T{}, F{}, T{});     // res-block tail: act -> D2, + skip -> D
+                else {
+#pragma unroll 2
+                    for (int it = 0; it < 16; ++it) {
+                        const int rl = rl0 + 8 * it;
+                        if (m0 + rl >= p.M) break;
+                        epi_vec4(p, m0 + rl, col, *reinterpret_cast<const float4*>(&Cs[rl * LDC + c]), bv);
+                    }
+                }
+            } else {
+#pragma unroll 2
+                for (int it = 0; it < 16; ++it) {
+                    const int rl = rl0 + 8 * it;
+                    if (m0 + rl >= p.M) break;
+                    epi_vec4(p, m0 + rl, col, *reinterpret_cast<const float4*>(&Cs[rl * LDC + c]), bv);
+                }
             }
         }
+        DPIG_STAMP(9);
     } else {
         // generic scalar path (thin / unaligned layers)
         for (int idx = tid; idx < BM * BN; idx += 256) {
@@ -425,6 +576,9 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GGParams p) {
             }
         }
     }
+#ifdef DPIG_TRACE
+    if (tid == 0 && blockIdx.x < 8192 && blockIdx.z == 0) dpig_trace_se[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime();
+#endif
 }
 
 // split-K second pass: sum partials in split order (deterministic) and run the fused epilogue
@@ -579,6 +733,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
         }
     };
 
+    auto store_a = [&](int buf, int i) {
+        *reinterpret_cast<float4*>(&smem[buf][((tid >> 5) + 8 * i) * LDKN + q]) = ra[i];
+    };
+    auto store_b = [&](int buf, int i) {
+        *reinterpret_cast<float4*>(&smem[buf][BK * LDKN + ((tid >> 5) + 8 * i) * LDKN + q]) = rb[i];
+        if (do_bias) { bsum.x += rb[i].x; bsum.y += rb[i].y; bsum.z += rb[i].z; bsum.w += rb[i].w; }
+    };
+
     f32x16 acc[MB][NB];
 #pragma unroll
     for (int i = 0; i < MB; ++i)
@@ -610,8 +772,43 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
         for (int kt = kt_begin; kt < kt_end; ++kt) {
             const bool more = (kt + 1) < kt_end;
             if (more) load_tiles(kt + 1);
+            __builtin_amdgcn_sched_barrier(0);
             const float* As = smem[buf];
             const float* Bs = smem[buf] + BK * LDKN;
+#if DPIG_PIPE2
+            // same hand-over schedule as gather_gemm_kernel: the LDS stores of tile t+1 ride behind the MFMA
+            // quads of groups 2 and 3, the barrier and the first fragment reads sit before the last quad
+#pragma unroll
+            for (int kk = 0; kk < BK / 8; ++kk) {
+                if (kk + 1 < BK / 8) load_frag(As, Bs, kk + 1, fa[(kk + 1) & 1], fb[(kk + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (kk == 3 && j == 3) {
+                        __syncthreads();
+                        if (more) load_frag(smem[buf ^ 1], smem[buf ^ 1] + BK * LDKN, 0, fa[0], fb[0]);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+                        for (int nb = 0; nb < NB; ++nb)
+                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][mb][j], fb[kk & 1][nb][j],
+                                                                               acc[mb][nb], 0, 0, 0);
+                    if (more && kk == 2) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if ((j & 1) == 0) store_a(buf ^ 1, j >> 1); else store_b(buf ^ 1, j >> 1);
+                        __builtin_amdgcn_sched_barrier(0);
+                    } else if (more && kk == 3 && j < 2) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        store_a(buf ^ 1, 2 + j); store_b(buf ^ 1, 2 + j);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            buf ^= 1;
+#else
 #pragma unroll
             for (int kk = 0; kk < BK / 8; ++kk) {
                 if (kk + 1 < BK / 8) load_frag(As, Bs, kk + 1, fa[(kk + 1) & 1], fb[(kk + 1) & 1]);
@@ -628,6 +825,7 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
             __syncthreads();
             buf ^= 1;
             if (more) load_frag(smem[buf], smem[buf] + BK * LDKN, 0, fa[0], fb[0]);
+#endif
         }
     }
 

@@ -33,8 +33,11 @@ for name, N, Hh, W, C, K, k, s in LAYERS:
     x = torch.randn(N, Hh, W, C, device=dev)
     w = torch.randn(k, k, C, K, device=dev) * 0.05
     b = torch.randn(K, device=dev)
+    if os.environ.get("ZERO"):      # DVFS probe: all-zero operands draw less power -> higher sustained clock
+        x.zero_(); w.zero_(); b.zero_()
     y = H.conv2d_fwd(x, w, b, stride=s, act=1)
     dy = torch.randn_like(y)
+    if os.environ.get("ZERO"): dy.zero_()
     flops = 2.0 * y.numel() * k * k * C
     tf = timeit(lambda: H.conv2d_fwd(x, w, b, stride=s, act=1))
     td = timeit(lambda: H.conv2d_dgrad(dy, w, (N, Hh, W, C), stride=s))
