@@ -631,6 +631,7 @@ struct WGParams {
     int vec_epi;                                   // 1: dw / partial rows are 16-byte addressable
     float* DB; float* bias_partial; float beta_b;  // fused bias gradient: db[co] = sum_pixels dy[., co]
     int vec_x;                                     // 1: x alone is 16-byte loadable (Cout = 3: dy is not)
+    int d32_oy, d32_ox;                            // S1: (row, col) advance of a pixel index step of BK = 32
 };
 
 // n / d for 0 <= n < 2^31 with a precomputed (mul, shr); mul == 0 encodes d == 1
@@ -641,7 +642,11 @@ __device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned shr) {
 // NARROW: 128 x 32 tile for Cout <= 32 (the 3-channel image conv).  FLAT: for thin inputs (Cin = 3 stems,
 // the 18-channel pose conv) the tile rows are the flattened (tap, ci) index instead of 128 channels of one
 // tap, so a 3-channel 5x5 filter gradient is 1 row tile instead of 25 tiles that are 98 % padding.
-template <bool VEC, bool NARROW, bool FLAT>
+// S1 (stride 1, SAME, 16-byte loadable): pixel m of dy pairs with pixel m + const of x, so both operands are
+// addressed as  per-thread constant voffset + per-k-tile SCALAR soffset; the only per-row vector work left is
+// the halo test on an incrementally advanced (oy, ox).  (The generic loader spends ~35 VALU per row per k-tile
+// on index arithmetic, which -- not the matrix pipe -- paced groups 0-1 of the k-loop: s_memtime trace.)
+template <bool VEC, bool NARROW, bool FLAT, bool S1 = false>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
     constexpr int MB = NARROW ? 1 : 2;
     constexpr int NB = NARROW ? 1 : 2;
@@ -687,37 +692,77 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
         }
     }
 
-    auto load_tiles = [&](int kt) {
+    // S1 loader state: (oy, ox) of this thread's 4 tile rows at the next k-tile to load, constant voffsets.
+    // The x descriptor starts `padpix` pixels BEFORE the tensor so that m + tap shift + padpix >= 0 always
+    // (soffset is unsigned); lanes whose tap falls outside the image get voffset = OOB and are never dereferenced.
+    int s_oy[4], s_ox[4];
+    unsigned s_xv[4], s_yv[4];
+    const int padpix = p.pad_t * p.W + p.pad_l;
+    const __amdgpu_buffer_rsrc_t rsXs = make_rsrc(p.X - (long)padpix * p.ldx, p.x_bytes + (unsigned)(padpix * p.ldx * 4));
+    if (S1) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int m = kt * BK + (tid >> 5) + 8 * i;
-            const bool mok = m < p.Npix;
-            const int mm = mok ? m : 0;
-            const int n = fast_div(mm, p.mul_howo, p.shr_howo);
-            const int rem = mm - n * p.HoWo;
-            const int oy = fast_div(rem, p.mul_wo, p.shr_wo);
-            const int ox = rem - oy * p.Wo;
-            const unsigned yoff = (unsigned)((mm * p.ldy + co0 + q) * 4);
-            rb[i] = gload4<VEC>(rsY, yoff, mok & cy_ok, co0 + q, p.K);
-            if (FLAT) {
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int py = oy * p.s + f_oy[e], px = ox * p.s + f_ox[e];
-                    const bool ok = mok & f_ok[e] & ((unsigned)py < (unsigned)p.H) & ((unsigned)px < (unsigned)p.W);
-                    const unsigned off = (unsigned)((((n * p.H + py) * p.W + px) * p.ldx + f_ci[e]) * 4);
-                    v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, (int)(ok ? off : OOB), 0, 0));
-                }
-                ra[i] = make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                const int py = oy * p.s + oyoff, px = ox * p.s + oxoff;
-                const int iy = py >> p.shift, ix = px >> p.shift;
-                const bool ok = mok & (py >= 0) & (px >= 0) & (iy < p.H) & (ix < p.W);
-                const unsigned xoff = (unsigned)((((n * p.H + iy) * p.W + ix) * p.ldx + ci0 + q) * 4);
-                if (VEC || p.vec_x) ra[i] = gload4<true>(rsX, xoff, ok & (ci0 + q < p.C), ci0 + q, p.C);
-                else ra[i] = gload4<false>(rsX, xoff, ok, ci0 + q, p.C);
-            }
+            const int r = (tid >> 5) + 8 * i;
+            const int m = kt_begin * BK + r;
+            const int n = fast_div(m, p.mul_howo, p.shr_howo);
+            const int rem = m - n * p.HoWo;
+            s_oy[i] = fast_div(rem, p.mul_wo, p.shr_wo);
+            s_ox[i] = rem - s_oy[i] * p.Wo;
+            s_xv[i] = cx_ok ? (unsigned)((r * p.ldx + ci0 + q) * 4) : OOB;
+            s_yv[i] = cy_ok ? (unsigned)((r * p.ldy + co0 + q) * 4) : OOB;
         }
+    }
+    // one quarter (tile rows i, i+8, ...: one 16-byte load per operand) of the loads of k-tile kt; `live` = false
+    // turns it into loads of structural zeros (OOB offset), so the steady-state loop stays branch-free.
+    // (S1: must be called exactly once per (kt, i), kt ascending -- it advances the row state.)
+    auto load_part = [&](int kt, int i, bool live) {
+        if (S1) {
+            const bool mok = live & ((tid >> 5) + 8 * i < p.Npix - kt * BK);
+            const bool ok = mok & ((unsigned)(s_oy[i] + oyoff) < (unsigned)p.H) & ((unsigned)(s_ox[i] + oxoff) < (unsigned)p.W);
+            const int sx = ((kt * BK + oyoff * p.W + oxoff + padpix) * p.ldx) * 4;
+            const int sy = (kt * BK * p.ldy) * 4;
+            const f32x4 ta = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsXs, (int)(ok ? s_xv[i] : OOB), sx, 0));
+            const f32x4 tb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsY, (int)(mok ? s_yv[i] : OOB), sy, 0));
+            ra[i] = make_float4(ta.x, ta.y, ta.z, ta.w);
+            rb[i] = make_float4(tb.x, tb.y, tb.z, tb.w);
+            s_ox[i] += p.d32_ox;
+            const bool c1 = s_ox[i] >= p.Wo;
+            s_ox[i] -= c1 ? p.Wo : 0;
+            s_oy[i] += p.d32_oy + (c1 ? 1 : 0);
+            s_oy[i] -= (s_oy[i] >= p.Ho) ? p.Ho : 0;
+            return;
+        }
+        const int m = kt * BK + (tid >> 5) + 8 * i;
+        const bool mok = live & (m < p.Npix);
+        const int mm = mok ? m : 0;
+        const int n = fast_div(mm, p.mul_howo, p.shr_howo);
+        const int rem = mm - n * p.HoWo;
+        const int oy = fast_div(rem, p.mul_wo, p.shr_wo);
+        const int ox = rem - oy * p.Wo;
+        const unsigned yoff = (unsigned)((mm * p.ldy + co0 + q) * 4);
+        rb[i] = gload4<VEC>(rsY, yoff, mok & cy_ok, co0 + q, p.K);
+        if (FLAT) {
+            float v[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int py = oy * p.s + f_oy[e], px = ox * p.s + f_ox[e];
+                const bool ok = mok & f_ok[e] & ((unsigned)py < (unsigned)p.H) & ((unsigned)px < (unsigned)p.W);
+                const unsigned off = (unsigned)((((n * p.H + py) * p.W + px) * p.ldx + f_ci[e]) * 4);
+                v[e] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsX, (int)(ok ? off : OOB), 0, 0));
+            }
+            ra[i] = make_float4(v[0], v[1], v[2], v[3]);
+        } else {
+            const int py = oy * p.s + oyoff, px = ox * p.s + oxoff;
+            const int iy = py >> p.shift, ix = px >> p.shift;
+            const bool ok = mok & (py >= 0) & (px >= 0) & (iy < p.H) & (ix < p.W);
+            const unsigned xoff = (unsigned)((((n * p.H + iy) * p.W + ix) * p.ldx + ci0 + q) * 4);
+            if (VEC || p.vec_x) ra[i] = gload4<true>(rsX, xoff, ok & (ci0 + q < p.C), ci0 + q, p.C);
+            else ra[i] = gload4<false>(rsX, xoff, ok, ci0 + q, p.C);
+        }
+    };
+    auto load_tiles = [&](int kt) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_part(kt, i, true);
     };
     // fused bias gradient: the row-tile-0 workgroups also sum the dy tile they stage anyway
     const bool do_bias = (p.DB != nullptr) && (mt == 0);
@@ -738,7 +783,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
     };
     auto store_b = [&](int buf, int i) {
         *reinterpret_cast<float4*>(&smem[buf][BK * LDKN + ((tid >> 5) + 8 * i) * LDKN + q]) = rb[i];
-        if (do_bias) { bsum.x += rb[i].x; bsum.y += rb[i].y; bsum.z += rb[i].z; bsum.w += rb[i].w; }
+        if (do_bias) {      // workgroup-uniform; the empty asm keeps it a real branch (if-converted it costs every
+            asm volatile("" ::: "memory");   // workgroup 4 adds + 4 selects per store, all but 1/mtiles for nothing)
+            bsum.x += rb[i].x; bsum.y += rb[i].y; bsum.z += rb[i].z; bsum.w += rb[i].w;
+        }
     };
 
     f32x16 acc[MB][NB];
@@ -762,6 +810,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
         }
     };
 
+#ifdef DPIG_TRACE
+    const bool trace_on = (blockIdx.x + gridDim.x * blockIdx.z == 3) && ((tid & 63) == 0);
+    int trace_n = 0;
+#undef DPIG_STAMP
+#define DPIG_STAMP(slot) do { if (trace_on && trace_n < 2000) dpig_trace_buf[(tid >> 6) * 2000 + trace_n++] = ((unsigned long long)(slot) << 56) | (__builtin_amdgcn_s_memtime() & 0x00ffffffffffffffull); } while (0)
+    DPIG_STAMP(0);
+#endif
     if (kt_begin < kt_end) {
         load_tiles(kt_begin);
         store_tiles(0);
@@ -771,8 +826,9 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
         load_frag(smem[0], smem[0] + BK * LDKN, 0, fa[0], fb[0]);
         for (int kt = kt_begin; kt < kt_end; ++kt) {
             const bool more = (kt + 1) < kt_end;
+#if !DPIG_PIPE2
             if (more) load_tiles(kt + 1);
-            __builtin_amdgcn_sched_barrier(0);
+#endif
             const float* As = smem[buf];
             const float* Bs = smem[buf] + BK * LDKN;
 #if DPIG_PIPE2
@@ -780,13 +836,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
             // quads of groups 2 and 3, the barrier and the first fragment reads sit before the last quad
 #pragma unroll
             for (int kk = 0; kk < BK / 8; ++kk) {
+                if (kk == 0) DPIG_STAMP(1);
+                if (kk == 2) DPIG_STAMP(3);
                 if (kk + 1 < BK / 8) load_frag(As, Bs, kk + 1, fa[(kk + 1) & 1], fb[(kk + 1) & 1]);
+                if (kk < 2) { load_part(kt + 1, 2 * kk, more); load_part(kt + 1, 2 * kk + 1, more); }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     if (kk == 3 && j == 3) {
+                        DPIG_STAMP(2);
                         __syncthreads();
-                        if (more) load_frag(smem[buf ^ 1], smem[buf ^ 1] + BK * LDKN, 0, fa[0], fb[0]);
+                        DPIG_STAMP(4);
+                        load_frag(smem[buf ^ 1], smem[buf ^ 1] + BK * LDKN, 0, fa[0], fb[0]);
                         __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma unroll
@@ -795,11 +856,11 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
                         for (int nb = 0; nb < NB; ++nb)
                             acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][mb][j], fb[kk & 1][nb][j],
                                                                                acc[mb][nb], 0, 0, 0);
-                    if (more && kk == 2) {
+                    if (kk == 2) {                     // (zeros after the last tile: nobody reads them)
                         __builtin_amdgcn_sched_barrier(0);
                         if ((j & 1) == 0) store_a(buf ^ 1, j >> 1); else store_b(buf ^ 1, j >> 1);
                         __builtin_amdgcn_sched_barrier(0);
-                    } else if (more && kk == 3 && j < 2) {
+                    } else if (kk == 3 && j < 2) {
                         __builtin_amdgcn_sched_barrier(0);
                         store_a(buf ^ 1, 2 + j); store_b(buf ^ 1, 2 + j);
                         __builtin_amdgcn_sched_barrier(0);
@@ -1272,10 +1333,15 @@ extern "C" int dpig_conv2d_wgrad(const DpigConvDesc* d, const float* x, const fl
                      (d->C % 4 == 0) && (d->K % 4 == 0);
     p.vec_epi = (d->K % 4 == 0) && aligned16(dw) && (p.nsplit == 1 || aligned16(ws));
     p.vec_x = aligned16(x) && (d->ldx % 4 == 0) && (d->C % 4 == 0);
+    p.d32_oy = (BK / p.Wo) % p.Ho;
+    p.d32_ox = BK % p.Wo;
+    const bool s1 = vec && !flat && !narrow && d->stride == 1 && !d->upsample2x && p.Ho == p.H && p.Wo == p.W &&
+                    p.pad_t >= 0 && p.pad_l >= 0 && ((long)p.x_bytes + (long)(p.pad_t * p.W + p.pad_l) * p.ldx * 4 < 0x7fffffffL);
     dim3 grid(tiles, 1, p.nsplit), block(256);
 #define DPIG_WG(VE, NA, FL) hipLaunchKernelGGL((wgrad_kernel<VE, NA, FL>), grid, block, 0, st, p)
     if (flat) { if (narrow) DPIG_WG(false, true, true); else DPIG_WG(false, false, true); }
     else if (narrow) { if (vec) DPIG_WG(true, true, false); else DPIG_WG(false, true, false); }
+    else if (s1) hipLaunchKernelGGL((wgrad_kernel<true, false, false, true>), grid, block, 0, st, p);
     else { if (vec) DPIG_WG(true, false, false); else DPIG_WG(false, false, false); }
 #undef DPIG_WG
     rc = check_launch("wgrad_kernel");
