@@ -20,6 +20,7 @@
 // (models.py:396-573) and the gradients TF autodiff derives for them (trainer.py:137-140).
 #include <type_traits>
 #include "dpig_common.h"
+#include "dpig_thin.h"
 #ifndef DPIG_PIPE2
 #define DPIG_PIPE2 1
 #endif
@@ -1182,6 +1183,8 @@ extern "C" size_t dpig_conv2d_workspace_bytes(const DpigConvDesc* d, int which) 
         }
         return mx;
     } else if (which == 2) {
+        const size_t thin = thin_wgrad_workspace_bytes(d, pt, pl);
+        if (thin) return thin;
         const long Npix = (long)d->N * Ho * Wo * (d->upsample2x ? 4 : 1);
         const bool flat = !d->upsample2x && d->C < 32 && d->R * d->S > 1;
         const int tiles = (flat ? cdiv((long)d->R * d->S * d->C, BM) : d->R * d->S * cdiv(d->C, BM)) *
@@ -1208,6 +1211,9 @@ extern "C" int dpig_conv2d_fwd(const DpigConvDesc* d, const float* x, const floa
         return fail(DPIG_EINVAL, "res_class needs a stride-1 conv on an image of at least 2x2");
     if (y_act && d->ldy2 < d->K) return fail(DPIG_EINVAL, "ldy2 < K");
     if (y_act && d->upsample2x) return fail(DPIG_EINVAL, "y_act unsupported with upsample2x");
+    if (residual && d->ldres < d->K) return fail(DPIG_EINVAL, "ldres < K");
+    rc = thin_fwd_try(d, pt, pl, x, w, bias, residual, y, y_act, static_cast<hipStream_t>(stream));
+    if (rc != 0) return rc < 0 ? rc : DPIG_OK;
     p.partial = static_cast<float*>(ws);
     Shape s = fwd_shape(d, Ho, Wo);
     p.M = (int)s.M;
@@ -1239,6 +1245,8 @@ extern "C" int dpig_conv2d_dgrad(const DpigConvDesc* d, const float* dy, const f
     if (accum && d->ldres < d->C) return fail(DPIG_EINVAL, "ldres < C");
     if (mask && d->ldmask < d->C) return fail(DPIG_EINVAL, "ldmask < C");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    rc = thin_dgrad_try(d, pt, pl, dy, w, accum, mask, dx, st);
+    if (rc != 0) return rc < 0 ? rc : DPIG_OK;
     GGParams p = {};
     p.A = dy; p.B = w; p.D = dx; p.bias = nullptr; p.res = accum; p.mask = mask;
     p.partial = static_cast<float*>(ws);
@@ -1293,6 +1301,8 @@ extern "C" int dpig_conv2d_wgrad(const DpigConvDesc* d, const float* x, const fl
     if (rc) return rc;
     if (!x || !dy || !dw) return fail(DPIG_EINVAL, "null tensor pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    rc = thin_wgrad_try(d, pt, pl, x, dy, dw, beta, db, beta_b, ws, ws_bytes, st);
+    if (rc != 0) return rc < 0 ? rc : DPIG_OK;
     WGParams p = {};
     p.X = x; p.DY = dy; p.DW = dw; p.partial = static_cast<float*>(ws);
     p.H = d->H; p.W = d->W; p.ldx = d->ldx; p.C = d->C; p.K = d->K; p.ldy = d->ldy;

@@ -1,0 +1,343 @@
+// dpig_thin.hip -- 3x3 stride-1 SAME convolutions with THREE output channels (the generator's image conv,
+// models.py:571-573: 256 -> 3 at full resolution), forward / dgrad / wgrad.
+//
+// As a GEMM this layer is [N*H*W, 9*C] x [9*C, 3]: on the 128x32 MFMA tile 29 of 32 columns are padding and the
+// launch is paced by its per-k-tile fixed costs (340 us for 1.8 GFLOP at B=16).  The layer is HBM-bound -- it
+// must stream the C-channel activation (134 MB) once -- so it runs on the vector ALUs instead:
+//
+//   * one wave walks a strip of one image row; lane l owns input channels 4l..4l+3 (16-byte accesses, C <= 256),
+//   * the lane's 9 x 4 x 3 filter coefficients live in registers (108 VGPRs),
+//   * the 3x3 input window slides along the row: 3 new 16-byte loads per pixel instead of 9,
+//   * fwd: the 3 per-lane partial sums are reduced across the wave with DPP row shifts / broadcasts;
+//     dgrad: the 27 dy values of the window are wave-uniform, every lane produces its own 4 dx channels;
+//     wgrad: every lane keeps its 108 partial filter gradients (+ the bias gradient) in registers over the strip,
+//     waves of a workgroup are summed through LDS in a fixed order and a second kernel sums the workgroups
+//     (deterministic: no atomics).
+//
+// Roofline: HBM.  Algorithmic bytes = 4*(N*H*W*C + N*H*W*3) per call (+ filter), i.e. 135.8 MB at B=16.
+#include <hip/hip_runtime.h>
+
+#include "dpig_common.h"
+#include "dpig_hip.h"
+#include "dpig_thin.h"
+
+namespace dpig {
+
+constexpr int TK = 3;        // output channels
+constexpr int XS = 32;       // pixels per strip
+constexpr int kWgradBlocks = 2 * kNumCU;   // persistent wgrad workgroups (4 waves each): two per CU
+typedef int v4i_t __attribute__((ext_vector_type(4)));
+
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_add(float v) {
+    const int t = __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, true);
+    return v + __builtin_bit_cast(float, t);
+}
+// sum over the 64 lanes, result valid in lane 63 (row_shr 1,2,4,8 = inclusive scan inside each row of 16,
+// row_bcast:15 folds rows 0->1 and 2->3, row_bcast:31 folds the lower half into the upper)
+__device__ __forceinline__ float reduce_to_lane63(float v) {
+    v = dpp_add<0x111, 0xf>(v);
+    v = dpp_add<0x112, 0xf>(v);
+    v = dpp_add<0x114, 0xf>(v);
+    v = dpp_add<0x118, 0xf>(v);
+    v = dpp_add<0x142, 0xa>(v);
+    v = dpp_add<0x143, 0xc>(v);
+    return v;
+}
+
+struct ThinParams {
+    const float* X; const float* W; const float* bias; const float* DY;
+    float* Y; float* DX; float* partial;
+    int N, H, Wd, C, ldx, ldy;          // ldy: row stride of the 3-channel tensor
+    int nstrips, nwaves;
+    unsigned x_bytes;
+    int act; float alpha;
+};
+
+__device__ __forceinline__ float4 ld16(__amdgpu_buffer_rsrc_t r, unsigned off) {
+    const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+constexpr unsigned OOBT = 0x7fffffffu;
+
+// filter coefficients of this lane's 4 channels: wr[tap][e][k] = w[(tap*C + 4*lane + e)*3 + k]
+__device__ __forceinline__ void load_filter(const float* __restrict__ w, int C, int lane, float (&wr)[9][4][TK]) {
+    const bool ok = lane * 4 < C;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int k = 0; k < TK; ++k) wr[t][e][k] = ok ? w[((long)t * C + lane * 4 + e) * TK + k] : 0.f;
+}
+
+// ---- forward ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void thin3_fwd_kernel(const ThinParams p) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (wv >= p.nwaves) return;
+    const int strip = wv % p.nstrips;
+    const int row = wv / p.nstrips;                 // n*H + y
+    const int y = row % p.H;
+    const int x0 = strip * XS;
+    const int x1 = min(p.Wd, x0 + XS);
+    float wr[9][4][TK];
+    load_filter(p.W, p.C, lane, wr);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, (int)p.x_bytes, 0x00020000);
+    const bool cok = lane * 4 < p.C;
+    // byte offset of pixel (row + dy, ix), or OOB when outside the image
+    auto off = [&](int dy, int ix) -> unsigned {
+        const bool ok = cok & ((unsigned)(y + dy) < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.Wd);
+        return ok ? (unsigned)((((long)(row + dy)) * p.Wd + ix) * p.ldx + lane * 4) * 4u : OOBT;
+    };
+    float4 win[3][3];                               // [column x-1, x, x+1][row y-1, y, y+1]
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { win[1][r] = ld16(rs, off(r - 1, x0 - 1)); win[2][r] = ld16(rs, off(r - 1, x0)); }
+    float b[TK];
+#pragma unroll
+    for (int k = 0; k < TK; ++k) b[k] = p.bias ? p.bias[k] : 0.f;
+    const float slope = (p.act == DPIG_ACT_NONE) ? 1.f : ((p.act == DPIG_ACT_RELU) ? 0.f : p.alpha);
+    for (int x = x0; x < x1; ++x) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { win[0][r] = win[1][r]; win[1][r] = win[2][r]; win[2][r] = ld16(rs, off(r - 1, x + 1)); }
+        float acc[TK];
+#pragma unroll
+        for (int k = 0; k < TK; ++k) acc[k] = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float4 v = win[kx][ky];
+                const int t = ky * 3 + kx;
+#pragma unroll
+                for (int k = 0; k < TK; ++k)
+                    acc[k] += v.x * wr[t][0][k] + v.y * wr[t][1][k] + v.z * wr[t][2][k] + v.w * wr[t][3][k];
+            }
+#pragma unroll
+        for (int k = 0; k < TK; ++k) acc[k] = reduce_to_lane63(acc[k]);
+        if (lane == 63) {
+            float* o = p.Y + ((long)row * p.Wd + x) * p.ldy;
+#pragma unroll
+            for (int k = 0; k < TK; ++k) {
+                const float v = acc[k] + b[k];
+                o[k] = (v > 0.f) ? v : (v * slope + 0.f);
+            }
+        }
+    }
+}
+
+// ---- dgrad: dx[p][c] = sum_{ky,kx,k} dy[p + (1-ky, 1-kx)][k] * w[ky][kx][c][k] --------------------------
+__global__ __launch_bounds__(256) void thin3_dgrad_kernel(const ThinParams p) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (wv >= p.nwaves) return;
+    const int strip = wv % p.nstrips;
+    const int row = wv / p.nstrips;
+    const int y = row % p.H;
+    const int x0 = strip * XS;
+    const int x1 = min(p.Wd, x0 + XS);
+    float wr[9][4][TK];
+    load_filter(p.W, p.C, lane, wr);
+    // window of dy: g[col][row][k], wave-uniform (scalar loads)
+    auto ldg = [&](int dyy, int ix, float (&g)[TK]) {
+        const bool ok = ((unsigned)(y + dyy) < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.Wd);
+        const float* s = p.DY + ((long)(row + dyy) * p.Wd + (ok ? ix : 0)) * p.ldy;
+#pragma unroll
+        for (int k = 0; k < TK; ++k) g[k] = ok ? s[k] : 0.f;
+    };
+    float g[3][3][TK];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) { ldg(r - 1, x0 - 1, g[1][r]); ldg(r - 1, x0, g[2][r]); }
+    const bool cok = lane * 4 < p.C;
+    for (int x = x0; x < x1; ++x) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+            for (int k = 0; k < TK; ++k) { g[0][r][k] = g[1][r][k]; g[1][r][k] = g[2][r][k]; }
+            ldg(r - 1, x + 1, g[2][r]);
+        }
+        float a[4] = {0.f, 0.f, 0.f, 0.f};
+        // output pixel (y, x) receives filter tap (ky, kx) from dy pixel (y + 1 - ky, x + 1 - kx)
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int t = ky * 3 + kx;
+#pragma unroll
+                for (int k = 0; k < TK; ++k) {
+                    const float gv = g[2 - kx][2 - ky][k];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) a[e] += gv * wr[t][e][k];
+                }
+            }
+        if (cok) *reinterpret_cast<float4*>(p.DX + ((long)row * p.Wd + x) * p.ldx + lane * 4) = make_float4(a[0], a[1], a[2], a[3]);
+    }
+}
+
+// ---- wgrad: dw[t][c][k] = sum_p x[p + tap t][c] * dy[p][k],  db[k] = sum_p dy[p][k] -------------------------
+// partial layout per workgroup: [9][C][3] filter gradient followed by [3] bias gradient
+__global__ __launch_bounds__(256) void thin3_wgrad_kernel(const ThinParams p) {
+    __shared__ float red[9 * 4 * TK + TK][64];
+    const int lane = threadIdx.x & 63;
+    const int wid = threadIdx.x >> 6;
+    float acc[9][4][TK];
+    float bs[TK];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+#pragma unroll
+            for (int k = 0; k < TK; ++k) acc[t][e][k] = 0.f;
+#pragma unroll
+    for (int k = 0; k < TK; ++k) bs[k] = 0.f;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, (int)p.x_bytes, 0x00020000);
+    const bool cok = lane * 4 < p.C;
+    // a wave owns the strips u = wave, wave + #waves, ... (fixed assignment -> fixed summation order)
+    for (int u = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wid); u < p.nwaves; u += gridDim.x * 4) {
+        const int strip = u % p.nstrips;
+        const int row = u / p.nstrips;
+        const int y = row % p.H;
+        const int x0 = strip * XS;
+        const int x1 = min(p.Wd, x0 + XS);
+        auto off = [&](int dy, int ix) -> unsigned {
+            const bool ok = cok & ((unsigned)(y + dy) < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.Wd);
+            return ok ? (unsigned)((((long)(row + dy)) * p.Wd + ix) * p.ldx + lane * 4) * 4u : OOBT;
+        };
+        float4 win[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) { win[1][r] = ld16(rs, off(r - 1, x0 - 1)); win[2][r] = ld16(rs, off(r - 1, x0)); }
+        for (int x = x0; x < x1; ++x) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) { win[0][r] = win[1][r]; win[1][r] = win[2][r]; win[2][r] = ld16(rs, off(r - 1, x + 1)); }
+            const float* s = p.DY + ((long)row * p.Wd + x) * p.ldy;
+            float g[TK];
+#pragma unroll
+            for (int k = 0; k < TK; ++k) { g[k] = s[k]; bs[k] += g[k]; }
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const float4 v = win[kx][ky];
+                    const int t = ky * 3 + kx;
+#pragma unroll
+                    for (int k = 0; k < TK; ++k) {
+                        acc[t][0][k] += v.x * g[k]; acc[t][1][k] += v.y * g[k];
+                        acc[t][2][k] += v.z * g[k]; acc[t][3][k] += v.w * g[k];
+                    }
+                }
+        }
+    }
+    // waves of the workgroup are added in wave order (fixed summation order)
+    for (int ph = 0; ph < 4; ++ph) {
+        if (wid == ph) {
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int k = 0; k < TK; ++k) {
+                        const int i = (t * 4 + e) * TK + k;
+                        red[i][lane] = (ph == 0) ? acc[t][e][k] : red[i][lane] + acc[t][e][k];
+                    }
+#pragma unroll
+            for (int k = 0; k < TK; ++k) red[108 + k][lane] = (ph == 0) ? bs[k] : red[108 + k][lane] + bs[k];
+        }
+        __syncthreads();
+    }
+    // write the workgroup's partial: dw[t][c = 4*lane + e][k]
+    float* out = p.partial + (long)blockIdx.x * (9 * p.C * TK + TK);
+    for (int i = threadIdx.x; i < 9 * p.C * TK; i += 256) {
+        const int k = i % TK;
+        const int c = (i / TK) % p.C;
+        const int t = i / (TK * p.C);
+        out[i] = red[(t * 4 + (c & 3)) * TK + k][c >> 2];
+    }
+    if (threadIdx.x < TK) out[9 * p.C * TK + threadIdx.x] = red[108 + threadIdx.x][0];   // bias: every lane saw the same dy
+}
+
+// dw = beta*dw + sum over workgroups (db likewise; may be null): 32 outputs x 8 slices of the workgroup list per
+// block, slices combined through LDS in slice order
+__global__ __launch_bounds__(256) void thin3_wgrad_reduce_kernel(const float* __restrict__ partial, int nblk, int wsize,
+                                                                 float* __restrict__ dw, float beta,
+                                                                 float* __restrict__ db, float beta_b) {
+    __shared__ float sm[8][32];
+    const int j = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + j;
+    const int n = wsize + TK;
+    float v = 0.f;
+    if (i < n)
+        for (int b = g; b < nblk; b += 8) v += partial[(long)b * n + i];
+    sm[g][j] = v;
+    __syncthreads();
+    if (g == 0 && i < n) {
+        float t = sm[0][j];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) t += sm[q][j];
+        if (i < wsize) dw[i] = (beta != 0.f) ? beta * dw[i] + t : t;
+        else if (db) db[i - wsize] = (beta_b != 0.f) ? beta_b * db[i - wsize] + t : t;
+    }
+}
+
+// ---- host side ---------------------------------------------------------------------------------------------
+static bool eligible(const DpigConvDesc* d, int pt, int pl) {
+    return d->K == TK && d->R == 3 && d->S == 3 && d->stride == 1 && !d->upsample2x && pt == 1 && pl == 1 &&
+           d->C % 4 == 0 && d->C >= 16 && d->C <= 256 && d->ldx % 4 == 0;
+}
+static bool fill(const DpigConvDesc* d, ThinParams* p) {
+    p->N = d->N; p->H = d->H; p->Wd = d->W; p->C = d->C; p->ldx = d->ldx; p->ldy = d->ldy;
+    p->nstrips = (d->W + XS - 1) / XS;
+    p->nwaves = d->N * d->H * p->nstrips;
+    const long xe = ((long)d->N * d->H * d->W - 1) * d->ldx + d->C;
+    if (xe * 4 >= 0x7fffffffL) return false;
+    p->x_bytes = (unsigned)(xe * 4);
+    p->act = d->act; p->alpha = d->alpha;
+    return true;
+}
+
+int thin_fwd_try(const DpigConvDesc* d, int pt, int pl, const float* x, const float* w, const float* bias,
+                 const float* residual, float* y, float* y_act, hipStream_t st) {
+    if (!eligible(d, pt, pl) || residual || y_act || !aligned16(x)) return 0;
+    ThinParams p = {};
+    if (!fill(d, &p)) return 0;
+    p.X = x; p.W = w; p.bias = bias; p.Y = y;
+    hipLaunchKernelGGL(thin3_fwd_kernel, dim3((p.nwaves + 3) / 4), dim3(256), 0, st, p);
+    const int rc = check_launch("thin3_fwd_kernel");
+    return rc ? rc : 1;
+}
+
+int thin_dgrad_try(const DpigConvDesc* d, int pt, int pl, const float* dy, const float* w, const float* accum,
+                   const float* mask, float* dx, hipStream_t st) {
+    if (!eligible(d, pt, pl) || accum || mask || !aligned16(dx)) return 0;
+    ThinParams p = {};
+    if (!fill(d, &p)) return 0;
+    p.DY = dy; p.W = w; p.DX = dx;
+    hipLaunchKernelGGL(thin3_dgrad_kernel, dim3((p.nwaves + 3) / 4), dim3(256), 0, st, p);
+    const int rc = check_launch("thin3_dgrad_kernel");
+    return rc ? rc : 1;
+}
+
+size_t thin_wgrad_workspace_bytes(const DpigConvDesc* d, int pt, int pl) {
+    if (!eligible(d, pt, pl)) return 0;
+    return (size_t)kWgradBlocks * (9 * (size_t)d->C * TK + TK) * sizeof(float);
+}
+
+int thin_wgrad_try(const DpigConvDesc* d, int pt, int pl, const float* x, const float* dy, float* dw, float beta,
+                   float* db, float beta_b, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!eligible(d, pt, pl) || !aligned16(x)) return 0;
+    ThinParams p = {};
+    if (!fill(d, &p)) return 0;
+    const size_t need = thin_wgrad_workspace_bytes(d, pt, pl);
+    if (!ws || ws_bytes < need) return fail(DPIG_ENOMEM, "conv wgrad workspace too small: have %zu", ws_bytes);
+    p.X = x; p.DY = dy; p.partial = static_cast<float*>(ws);
+    const int nblk = kWgradBlocks;
+    hipLaunchKernelGGL(thin3_wgrad_kernel, dim3(nblk), dim3(256), 0, st, p);
+    int rc = check_launch("thin3_wgrad_kernel");
+    if (rc) return rc;
+    const int wsize = 9 * d->C * TK;
+    hipLaunchKernelGGL(thin3_wgrad_reduce_kernel, dim3((wsize + TK + 31) / 32), dim3(256), 0, st, p.partial, nblk, wsize,
+                       dw, beta, db, beta_b);
+    rc = check_launch("thin3_wgrad_reduce_kernel");
+    return rc ? rc : 1;
+}
+
+}  // namespace dpig

@@ -27,6 +27,8 @@ SHAPES = [
     (2, 16, 8, 3, 128, 3, 1),      # E.stem
     (2, 8, 8, 64, 1, 1, 1),        # N = 1 (narrow tile)
     (2, 8, 8, 20, 24, 3, 2),       # thin both ways, stride 2
+    (2, 5, 40, 64, 3, 3, 1),       # Cout=3 vector-ALU path: two strips per row, the second one partial
+    (1, 3, 70, 20, 3, 3, 1),       # Cout=3, 5 active lanes, three strips
 ]
 
 
@@ -240,3 +242,30 @@ def test_border_class_sum(dev):
             cx = 0 if x == 0 else (2 if x == 4 else 1)
             ref[:, cy * 3 + cx] += a[:, y, x]
     _close(H.border_class_sum(a.float().to(dev)), ref)
+
+
+@pytest.mark.parametrize("act", [0, 1, 2])
+def test_thin_cout3_epilogue_and_accumulate(dev, act):
+    """The 3-output-channel image conv (vector-ALU kernels): fused bias + activation, wgrad with beta = 1 and the
+    bias gradient, bitwise repeatable (no atomics)."""
+    import dpig_amd.hip_ops as H
+    from oracle import ops as O
+    N, Hh, W, C, K = 3, 7, 33, 128, 3
+    x = _rand((N, Hh, W, C), 1)
+    w = (_rand((3, 3, C, K), 2) * 0.2).requires_grad_(True)
+    b = _rand((K,), 3).requires_grad_(True)
+    z = O.conv2d_same(x, w, b, 1)
+    ref = z if act == 0 else (torch.relu(z) if act == 1 else torch.where(z > 0, z, 0.2 * z))
+    got = H.conv2d_fwd(x.float().to(dev), w.detach().float().to(dev), b.detach().float().to(dev), act=act, alpha=0.2)
+    _close(got, ref)
+    dy = _rand(tuple(z.shape), 4)
+    z.backward(dy)
+    base_w, base_b = _rand((3, 3, C, K), 5), _rand((K,), 6)
+    outs = []
+    for _ in range(2):
+        dw = base_w.float().to(dev).clone(); db = base_b.float().to(dev).clone()
+        H.conv2d_wgrad(x.float().to(dev), dy.float().to(dev), (3, 3, C, K), out=dw, beta=1.0, db=db, db_beta=1.0)
+        outs.append((dw, db))
+    _close(outs[0][0], w.grad + base_w)
+    _close(outs[0][1], b.grad + base_b)
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
