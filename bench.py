@@ -27,6 +27,18 @@ PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32,
 ALG_GFLOP_PER_IMG = 549.9         # stage-I Market G+D step, dense reference formulation
 
 
+# name -> (trainer module, class, Config overrides, default per-GPU batch, description)
+WORKLOADS = {
+    "market128": ("trainer", "DPIG_Encoder_GAN_BodyROI_FgBg", {}, 16,
+                  "Market-1501 128x64 stage-I (Fg/Bg/Pose enc + U-Net decoder + DCGAN D), g_optim + d_optim per step"),
+    "market128-wgan-gp": ("trainer", "DPIG_Encoder_GAN_BodyROI_FgBg", {"gan_mode": "wgan-gp"}, 16,
+                          "Market-1501 128x64 stage-I with MODE='wgan-gp' (LayerNorm critic, gradient penalty, "
+                          "g_optim + 5 critic iterations per step, trainer.py:336-347)"),
+    "df256": ("trainer_256", "DPIG_Encoder_GAN_BodyROI_256", {"img_H": 256, "img_W": 256}, 8,
+              "DeepFashion 256x256 stage-I (trainer_256.py path), g_optim + d_optim per step"),
+}
+
+
 def cpu_baseline(target_seconds=20.0):
     """Time the oracle's G+D step (torch-CPU, fp32, all host cores) on a bounded sample."""
     import torch
@@ -81,10 +93,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="per-GPU batch (BASELINE configs[1]: 16)")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: 16 for Market, BASELINE configs[1]; 8 for df256)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly (no hipGraph replay)")
+    ap.add_argument("--workload", default="market128", choices=sorted(WORKLOADS),
+                    help="market128 = the BASELINE metric (configs[1]); the others are information lines for DESIGN.md")
     args = ap.parse_args()
 
     import numpy as np
@@ -113,13 +127,20 @@ def main():
         dist.barrier()
     from dpig_amd import hip_ops as H
     from dpig_amd import synthetic
-    from dpig_amd.trainer import Config, DPIG_Encoder_GAN_BodyROI_FgBg
+    import importlib
+    from dpig_amd.trainer import Config
+    wl_mod, wl_cls, wl_cfg, wl_batch, wl_desc = WORKLOADS[args.workload]
+    headline = args.workload == "market128"
+    if not headline:                          # information lines: no roofline / CPU legs, eager launches
+        args.no_roofline = args.no_cpu_baseline = True
+        args.no_graph = args.no_graph or args.workload != "df256"
 
     np.random.seed(0)                         # identical initial weights on every rank (+ broadcast)
-    B = args.batch
-    tr = DPIG_Encoder_GAN_BodyROI_FgBg(Config(batch_size=B), dev)
-    batch_g = synthetic.to_device(synthetic.make_batch(B, seed=100 + 2 * rank), dev)
-    batch_d = synthetic.to_device(synthetic.make_batch(B, seed=101 + 2 * rank), dev)
+    B = args.batch or wl_batch
+    cfg = Config(batch_size=B, **wl_cfg)
+    tr = getattr(importlib.import_module("dpig_amd." + wl_mod), wl_cls)(cfg, dev)
+    batch_g = synthetic.to_device(synthetic.make_batch(B, img_H=cfg.img_H, img_W=cfg.img_W, seed=100 + 2 * rank), dev)
+    batch_d = synthetic.to_device(synthetic.make_batch(B, img_H=cfg.img_H, img_W=cfg.img_W, seed=101 + 2 * rank), dev)
     tr.init_net(batch_g)
     tr.step = 1                               # steady state: g_optim is only skipped at step 0
     if not args.no_graph:
@@ -189,14 +210,14 @@ def main():
 
     if rank == 0:
         line = {
-            "metric": "training images/sec (G+D step) Market-1501 128x64 bs=16",
+            "metric": "training images/sec (G+D step) Market-1501 128x64 bs=16" if headline else
+                      "training images/sec (%s) [information line, not the BASELINE metric]" % args.workload,
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "Market-1501 128x64 stage-I (Fg/Bg/Pose enc + U-Net decoder + DCGAN D), "
-                                   "g_optim + d_optim per step, bs=%d per GPU, fp32" % B,
+            "config": {"workload": "%s, bs=%d per GPU, fp32" % (wl_desc, B),
                        "global_batch": world * B, "parallelism": "dp%d" % world},
-            "achieved_alg_tflops": round(ALG_GFLOP_PER_IMG * value / 1e3, 2),
+            "achieved_alg_tflops": round(ALG_GFLOP_PER_IMG * value / 1e3, 2) if headline else None,
             "losses": {k: float(v) for k, v in out.items() if hasattr(v, "numel") and v.numel() == 1},
             "roofline": roofline, "cpu_baseline": cpu,
         }
