@@ -49,6 +49,10 @@ SYMBOLS = {
     "dpig_bn_workspace_bytes": (_sz, [_i64, _i]),
     "dpig_bn_fwd": (_i, [_vp, _i, _i64, _i, _vp, _vp, _f, _i, _f, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "dpig_bn_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp, _vp, _vp, _i, _f, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "dpig_bn_sqdev": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _sz, _vp]),
+    "dpig_bn_apply": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _i, _vp]),
+    "dpig_bn_bwd_sums": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _sz, _vp]),
+    "dpig_bn_bwd_apply": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _vp, _i, _vp]),
     "dpig_ln_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _i, _f, _vp, _vp, _vp, _vp]),
     "dpig_ln_workspace_bytes": (_sz, [_i, _i, _i]),
     "dpig_ln_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),

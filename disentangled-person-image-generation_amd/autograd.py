@@ -368,7 +368,53 @@ class _BatchNormFn(torch.autograd.Function):
         return dx, ds, do, None, None, None
 
 
+class _SyncBatchNormFn(torch.autograd.Function):
+    """The same op with batch statistics over every data-parallel rank ("offer SyncBN"): three tiny
+    sum-all-reduces forward ([C] sums, [C] centred squares) / one backward ([2C]).  The returned scale / offset
+    gradients are the global sums divided by the world size, so that the trainer's gradient all-reduce
+    (sum over ranks, 1/world folded into Adam) reproduces exactly the single-process gradient."""
+
+    @staticmethod
+    def forward(ctx, x, scale, offset, eps, act, alpha, group):
+        import torch.distributed as dist
+        world = dist.get_world_size(group)
+        ar = lambda t: dist.all_reduce(t, group=group)
+        y, mean, rstd = H.bn_sync_fwd(x, scale, offset, eps, act, alpha, ar, world)
+        ctx.save_for_backward(x, scale, mean, rstd, y if act != ACT_NONE else None)
+        ctx.cfg = (act, alpha, group, world)
+        ctx.offset_ref = offset
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        import torch.distributed as dist
+        x, scale, mean, rstd, y = ctx.saved_tensors
+        act, alpha, group, world = ctx.cfg
+        ar = lambda t: dist.all_reduce(t, group=group)
+        dx, dscale, doffset = H.bn_sync_bwd(dy, x, y, scale, mean, rstd, act, alpha, ar, world)
+        # every rank back-propagates its LOCAL mean loss, i.e. world x its share of the global mean loss; the
+        # trainer then averages parameter gradients over ranks.  dx is consistent with that convention as it is;
+        # the scale / offset sums are already global, so each rank contributes sum / world.
+        dscale = dscale * (1.0 / world)
+        doffset = doffset * (1.0 / world)
+        ds = _sink_small(scale, dscale) if ctx.needs_input_grad[1] else None
+        do = _sink_small(ctx.offset_ref, doffset) if ctx.needs_input_grad[2] else None
+        return dx, ds, do, None, None, None, None
+
+
+_SYNC_BN_GROUP = [False, None]      # (enabled, process group)
+
+
+def set_sync_batchnorm(enabled, group=None):
+    """Use cross-rank batch statistics in every subsequent batchnorm() call (no-op without torch.distributed)."""
+    _SYNC_BN_GROUP[0], _SYNC_BN_GROUP[1] = bool(enabled), group
+
+
 def batchnorm(x, scale, offset, eps=1e-5, act=ACT_NONE, alpha=0.2):
+    if _SYNC_BN_GROUP[0]:
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(_SYNC_BN_GROUP[1]) > 1:
+            return _SyncBatchNormFn.apply(x, scale, offset, eps, act, alpha, _SYNC_BN_GROUP[1])
     return _BatchNormFn.apply(x, scale, offset, eps, act, alpha)
 
 

@@ -231,9 +231,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                            const float* __restrict__ rstd,
                                                            const float* __restrict__ dscale,
                                                            const float* __restrict__ doffset, int act,
-                                                           float alpha, float* __restrict__ dx, int lddx) {
-    const long total = rows * C;
-    const float inv = 1.0f / (float)rows;
+                                                           float alpha, float inv, float* __restrict__ dx, int lddx) {
+    const long total = rows * C;      // inv = 1 / (number of rows the statistics were taken over)
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long r = i / C;
         const int c = (int)(i - r * C);
@@ -817,8 +816,58 @@ extern "C" int dpig_bn_bwd(const float* dy, int lddy, const float* x, int ldx, c
     hipLaunchKernelGGL((col_final_kernel<0>), dim3(cdivi(C, 64)), dim3(256), 0, st, partial, nslab, 2, C, doffset,
                        dscale, 1.0f, 0.f, 0.f);
     hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * C)), dim3(256), 0, st, dy, lddy, x, ldx, y, ldy,
-                       (long)rows, C, scale, save_mean, save_rstd, dscale, doffset, act, alpha, dx, lddx);
+                       (long)rows, C, scale, save_mean, save_rstd, dscale, doffset, act, alpha, 1.0f / (float)rows, dx, lddx);
     return check_launch("bn_bwd");
+}
+
+// ---- staged form (synchronised BN over data-parallel ranks): the caller all-reduces the [C] vectors ----------
+extern "C" int dpig_bn_sqdev(const float* x, int ldx, int64_t rows, int C, const float* mean, float* sq_out,
+                             void* ws, size_t ws_bytes, void* stream) {
+    if (!x || !mean || !sq_out) return fail(DPIG_EINVAL, "bn_sqdev: null pointer");
+    if (!ws || ws_bytes < dpig_bn_workspace_bytes(rows, C)) return fail(DPIG_ENOMEM, "bn_sqdev: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nslab = slabs_for(rows);
+    float* partial = static_cast<float*>(ws);
+    hipLaunchKernelGGL((col_partial_kernel<1>), dim3(cdivi(C, 64), nslab), dim3(256), 0, st, x, ldx, nullptr, 0, nullptr, 0,
+                       mean, nullptr, (long)rows, C, 1, 0, 0.f, partial);
+    hipLaunchKernelGGL((col_final_kernel<0>), dim3(cdivi(C, 64)), dim3(256), 0, st, partial, nslab, 1, C, sq_out, nullptr,
+                       1.0f, 0.f, 0.f);
+    return check_launch("bn_sqdev");
+}
+extern "C" int dpig_bn_apply(const float* x, int ldx, int64_t rows, int C, const float* scale, const float* offset,
+                             const float* mean, const float* rstd, int act, float alpha, float* y, int ldy,
+                             void* stream) {
+    if (!x || !scale || !offset || !mean || !rstd || !y) return fail(DPIG_EINVAL, "bn_apply: null pointer");
+    hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(rows * C)), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx,
+                       (long)rows, C, scale, offset, mean, rstd, act, alpha, y, ldy);
+    return check_launch("bn_apply");
+}
+extern "C" int dpig_bn_bwd_sums(const float* dy, int lddy, const float* x, int ldx, const float* y, int ldy,
+                                int64_t rows, int C, const float* mean, const float* rstd, int act, float alpha,
+                                float* dscale, float* doffset, void* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !x || !mean || !rstd || !dscale || !doffset) return fail(DPIG_EINVAL, "bn_bwd_sums: null pointer");
+    if (act != DPIG_ACT_NONE && !y) return fail(DPIG_EINVAL, "bn_bwd_sums: activation output required");
+    if (!ws || ws_bytes < dpig_bn_workspace_bytes(rows, C)) return fail(DPIG_ENOMEM, "bn_bwd_sums: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nslab = slabs_for(rows);
+    float* partial = static_cast<float*>(ws);
+    hipLaunchKernelGGL((col_partial_kernel<2>), dim3(cdivi(C, 64), nslab), dim3(256), 0, st, dy, lddy, x, ldx, y, ldy,
+                       mean, rstd, (long)rows, C, 1, act, alpha, partial);
+    hipLaunchKernelGGL((col_final_kernel<0>), dim3(cdivi(C, 64)), dim3(256), 0, st, partial, nslab, 2, C, doffset,
+                       dscale, 1.0f, 0.f, 0.f);
+    return check_launch("bn_bwd_sums");
+}
+extern "C" int dpig_bn_bwd_apply(const float* dy, int lddy, const float* x, int ldx, const float* y, int ldy,
+                                 int64_t rows, int C, const float* scale, const float* mean, const float* rstd,
+                                 const float* dscale, const float* doffset, int act, float alpha, float inv_count,
+                                 float* dx, int lddx, void* stream) {
+    if (!dy || !x || !scale || !mean || !rstd || !dscale || !doffset || !dx)
+        return fail(DPIG_EINVAL, "bn_bwd_apply: null pointer");
+    if (act != DPIG_ACT_NONE && !y) return fail(DPIG_EINVAL, "bn_bwd_apply: activation output required");
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(rows * C)), dim3(256), 0, static_cast<hipStream_t>(stream), dy,
+                       lddy, x, ldx, y, ldy, (long)rows, C, scale, mean, rstd, dscale, doffset, act, alpha, inv_count,
+                       dx, lddx);
+    return check_launch("bn_bwd_apply");
 }
 
 extern "C" int dpig_ln_fwd(const float* x, int N, int P, int C, const float* scale, const float* offset, float eps,

@@ -279,6 +279,49 @@ def bn_bwd(dy, x, y, scale, mean, rstd, act=ACT_NONE, alpha=0.2):
     return dx, dscale, doffset
 
 
+def bn_sync_fwd(x, scale, offset, eps, act, alpha, allreduce, world):
+    """Batch norm with statistics over ALL data-parallel ranks (equal per-rank batches): `allreduce(t)`
+    sum-reduces a small device tensor in place.  Same two-pass arithmetic (mean, then centred second moment)
+    as the fused single-rank op.  Returns (y, mean, rstd)."""
+    _require_gpu(x)
+    x, rows, C, ldx = _rows_ld(x)
+    dev = x.device
+    n_total = float(rows) * world
+    s1 = colsum(x)
+    allreduce(s1)
+    mean = s1.mul_(1.0 / n_total)
+    sq = torch.empty(C, dtype=torch.float32, device=dev)
+    wsb, wsn = workspace.get(lib().dpig_bn_workspace_bytes(rows, C), dev)
+    check(lib().dpig_bn_sqdev(ptr(x), ldx, rows, C, ptr(mean), ptr(sq), ptr(wsb), wsn, stream_ptr()), "bn_sqdev")
+    allreduce(sq)
+    rstd = torch.rsqrt(sq.mul_(1.0 / n_total).add_(eps))
+    y = torch.empty(x.shape, dtype=torch.float32, device=dev)
+    check(lib().dpig_bn_apply(ptr(x), ldx, rows, C, ptr(scale.contiguous()), ptr(offset.contiguous()), ptr(mean),
+                              ptr(rstd), act, alpha, ptr(y), C, stream_ptr()), "bn_apply")
+    return y, mean, rstd
+
+
+def bn_sync_bwd(dy, x, y, scale, mean, rstd, act, alpha, allreduce, world):
+    """Returns dx and the GLOBAL (dscale, doffset) sums over all ranks."""
+    _require_gpu(dy)
+    dy, rows, C, lddy = _rows_ld(dy)
+    x, _, _, ldx = _rows_ld(x)
+    ldy = C
+    if y is not None:
+        y, _, _, ldy = _rows_ld(y)
+    dev = x.device
+    sums = torch.empty(2 * C, dtype=torch.float32, device=dev)        # [dscale | doffset]
+    wsb, wsn = workspace.get(lib().dpig_bn_workspace_bytes(rows, C), dev)
+    check(lib().dpig_bn_bwd_sums(ptr(dy), lddy, ptr(x), ldx, ptr(y), ldy, rows, C, ptr(mean), ptr(rstd), act, alpha,
+                                 ptr(sums), ptr(sums) + 4 * C, ptr(wsb), wsn, stream_ptr()), "bn_bwd_sums")
+    allreduce(sums)
+    dx = torch.empty(x.shape, dtype=torch.float32, device=dev)
+    check(lib().dpig_bn_bwd_apply(ptr(dy), lddy, ptr(x), ldx, ptr(y), ldy, rows, C, ptr(scale.contiguous()), ptr(mean),
+                                  ptr(rstd), ptr(sums), ptr(sums) + 4 * C, act, alpha, 1.0 / (float(rows) * world),
+                                  ptr(dx), C, stream_ptr()), "bn_bwd_apply")
+    return dx, sums[:C], sums[C:]
+
+
 def ln_fwd(x, scale, offset, eps=1e-5, act=ACT_NONE, alpha=0.2):
     """Layer norm over (H,W,C) per sample; x NHWC dense."""
     _require_gpu(x)

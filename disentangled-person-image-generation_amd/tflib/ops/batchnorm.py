@@ -8,6 +8,13 @@ from ..._lib import ACT_LRELU, ACT_NONE, ACT_RELU
 from ._layout import nchw_to_nhwc_view, nhwc_to_nchw_view
 
 
+def set_sync(enabled, group=None):
+    """Extension for data-parallel runs: take the batch statistics over all ranks of `group`.  The
+    reference is single-process; with this switch a world-size-N run at B/N per rank reproduces its batch-B
+    statistics exactly."""
+    A.set_sync_batchnorm(enabled, group)
+
+
 def Batchnorm(name, axes, inputs, is_training=None, stats_iter=None, update_moving_stats=True, fused=True,
               fused_act=None, alpha=0.2):
     """Training-mode batch norm with the reference's contract: with axes [0,2,3] (NCHW conv data) or

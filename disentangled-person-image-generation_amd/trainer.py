@@ -210,6 +210,7 @@ class Config(object):
         self.gan_mode = 'dcgan'          # trainer.py:257 hard-codes MODE='dcgan' for stage I; 'wgan-gp' exercises
                                          # the gradient-penalty branch the reference keeps dormant
         self.data_format = 'NHWC'        # main.py:18
+        self.sync_bn = False             # data parallel: D's BatchNorm statistics over all ranks
         self.__dict__.update(kw)
         self.repeat_num = int(math.log2(self.img_H)) - 2    # trainer.py:75
 
@@ -289,6 +290,7 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         self.allreduce = GradAllReduce()
         self.allreduce.broadcast(self.G_flat.flat)
         self.allreduce.broadcast(self.D_flat.flat)
+        lib.ops.batchnorm.set_sync(bool(getattr(self.config, "sync_bn", False)) and self.allreduce.enabled)
 
     # ---- hipGraph capture of the two optimizer ops ----------------------------------------------
     def enable_graphs(self, batch_g, batch_d, warmup=2):

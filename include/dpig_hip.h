@@ -132,6 +132,23 @@ int dpig_bn_bwd(const float* dy, int lddy, const float* x, int ldx, const float*
                 float alpha, float* dx, int lddx, float* dscale, float* doffset, void* ws,
                 size_t ws_bytes, void* stream);
 
+/* Staged form of the same op for synchronised batch statistics across data-parallel ranks: the
+ * caller sum-all-reduces the [C] vectors between the stages.
+ *   fwd: dpig_colsum(x) -> mean = sum/n_total; dpig_bn_sqdev(x, mean) -> rstd = rsqrt(sq/n_total + eps);
+ *        dpig_bn_apply.
+ *   bwd: dpig_bn_bwd_sums -> (dscale, doffset) summed over ranks; dpig_bn_bwd_apply with inv_count = 1/n_total. */
+int dpig_bn_sqdev(const float* x, int ldx, int64_t rows, int C, const float* mean, float* sq_out, void* ws,
+                  size_t ws_bytes, void* stream);
+int dpig_bn_apply(const float* x, int ldx, int64_t rows, int C, const float* scale, const float* offset,
+                  const float* mean, const float* rstd, int act, float alpha, float* y, int ldy, void* stream);
+int dpig_bn_bwd_sums(const float* dy, int lddy, const float* x, int ldx, const float* y, int ldy, int64_t rows,
+                     int C, const float* mean, const float* rstd, int act, float alpha, float* dscale,
+                     float* doffset, void* ws, size_t ws_bytes, void* stream);
+int dpig_bn_bwd_apply(const float* dy, int lddy, const float* x, int ldx, const float* y, int ldy, int64_t rows,
+                      int C, const float* scale, const float* mean, const float* rstd, const float* dscale,
+                      const float* doffset, int act, float alpha, float inv_count, float* dx, int lddx,
+                      void* stream);
+
 /* ---- layer norm over (H,W,C) per sample, per-channel scale/offset (layernorm.py:6-20) -------- */
 /* x,y: [N, P, C] with P = H*W pixels, dense (ld == C). save_mean/save_rstd: [N]. */
 int dpig_ln_fwd(const float* x, int N, int P, int C, const float* scale, const float* offset, float eps,
