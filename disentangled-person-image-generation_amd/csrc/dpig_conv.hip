@@ -1185,6 +1185,8 @@ extern "C" size_t dpig_conv2d_workspace_bytes(const DpigConvDesc* d, int which) 
     } else if (which == 2) {
         const size_t thin = thin_wgrad_workspace_bytes(d, pt, pl);
         if (thin) return thin;
+        const size_t fewc = fewc_wgrad_workspace_bytes(d);
+        if (fewc) return fewc;
         const long Npix = (long)d->N * Ho * Wo * (d->upsample2x ? 4 : 1);
         const bool flat = !d->upsample2x && d->C < 32 && d->R * d->S > 1;
         const int tiles = (flat ? cdiv((long)d->R * d->S * d->C, BM) : d->R * d->S * cdiv(d->C, BM)) *
@@ -1213,6 +1215,8 @@ extern "C" int dpig_conv2d_fwd(const DpigConvDesc* d, const float* x, const floa
     if (y_act && d->upsample2x) return fail(DPIG_EINVAL, "y_act unsupported with upsample2x");
     if (residual && d->ldres < d->K) return fail(DPIG_EINVAL, "ldres < K");
     rc = thin_fwd_try(d, pt, pl, x, w, bias, residual, y, y_act, static_cast<hipStream_t>(stream));
+    if (rc != 0) return rc < 0 ? rc : DPIG_OK;
+    rc = fewc_fwd_try(d, pt, pl, Ho, Wo, x, w, bias, residual, y, y_act, static_cast<hipStream_t>(stream));
     if (rc != 0) return rc < 0 ? rc : DPIG_OK;
     p.partial = static_cast<float*>(ws);
     Shape s = fwd_shape(d, Ho, Wo);
@@ -1246,6 +1250,8 @@ extern "C" int dpig_conv2d_dgrad(const DpigConvDesc* d, const float* dy, const f
     if (mask && d->ldmask < d->C) return fail(DPIG_EINVAL, "ldmask < C");
     hipStream_t st = static_cast<hipStream_t>(stream);
     rc = thin_dgrad_try(d, pt, pl, dy, w, accum, mask, dx, st);
+    if (rc != 0) return rc < 0 ? rc : DPIG_OK;
+    rc = fewc_dgrad_try(d, pt, pl, Ho, Wo, dy, w, accum, mask, dx, st);
     if (rc != 0) return rc < 0 ? rc : DPIG_OK;
     GGParams p = {};
     p.A = dy; p.B = w; p.D = dx; p.bias = nullptr; p.res = accum; p.mask = mask;
@@ -1302,6 +1308,8 @@ extern "C" int dpig_conv2d_wgrad(const DpigConvDesc* d, const float* x, const fl
     if (!x || !dy || !dw) return fail(DPIG_EINVAL, "null tensor pointer");
     hipStream_t st = static_cast<hipStream_t>(stream);
     rc = thin_wgrad_try(d, pt, pl, x, dy, dw, beta, db, beta_b, ws, ws_bytes, st);
+    if (rc != 0) return rc < 0 ? rc : DPIG_OK;
+    rc = fewc_wgrad_try(d, pt, pl, Ho, Wo, x, dy, dw, beta, db, beta_b, ws, ws_bytes, st);
     if (rc != 0) return rc < 0 ? rc : DPIG_OK;
     WGParams p = {};
     p.X = x; p.DY = dy; p.DW = dw; p.partial = static_cast<float*>(ws);

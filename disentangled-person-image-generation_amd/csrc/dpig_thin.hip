@@ -278,6 +278,193 @@ __global__ __launch_bounds__(256) void thin3_wgrad_reduce_kernel(const float* __
     }
 }
 
+// =============================================================================================================
+// THREE INPUT channels: the encoder stem (models.py:396, 3x3 s1, 3 -> 128) and the critic's first conv
+// (wgan_gp.py DCGANDiscriminator, 5x5 s2, 3 -> 64), forward / wgrad, and the 5x5 s2 dgrad towards the image.
+// GEMM-wise K = R*S*3 = 27 / 75: a fraction of one 32-deep k-tile; the layers are bound by streaming the
+// Cout-channel tensor.  Lanes own output-channel quads (fwd, wgrad) or single output channels (dgrad); the
+// 3-channel image rows a workgroup needs are staged in LDS with zero margins (no border branches), the filter
+// sits in LDS (fwd) or registers (dgrad); wgrad keeps R*S*3 (or one filter row of) float4 accumulators per lane.
+// =============================================================================================================
+struct FewCParams {
+    const float* X; const float* W; const float* bias; const float* DY;
+    float* Y; float* DX; float* partial;
+    int N, H, Wd, ldx;           // image [N,H,Wd,3], row stride ldx
+    int Ho, Wo, K, ldy;          // Cout tensor [N,Ho,Wo,K]
+    int pt, pl, act; float alpha;
+    int nrows;                   // N*Ho
+};
+constexpr int FC_MAXW = 264;     // widest staged image row (+ margins)
+
+// stage image row iy of image n into LDS as [ (Wd + S) * 3 ] with pl zero pixels in front: dst[(ix + pl) * 3 + c]
+template <int S>
+__device__ __forceinline__ void stage_row(const FewCParams& p, int n, int iy, float* dst) {
+    const int tot = (p.Wd + S) * 3;
+    const bool rok = (unsigned)iy < (unsigned)p.H;
+    for (int i = threadIdx.x; i < tot; i += blockDim.x) {
+        const int ix = i / 3 - p.pl, c = i - (i / 3) * 3;
+        const bool ok = rok & ((unsigned)ix < (unsigned)p.Wd);
+        dst[i] = ok ? p.X[(((long)n * p.H + iy) * p.Wd + ix) * p.ldx + c] : 0.f;
+    }
+}
+
+// ---- forward: one workgroup per output row; thread = (output-channel quad, pixel slot) ------------------------
+template <int R, int S, int ST>
+__global__ __launch_bounds__(256) void fewc_fwd_kernel(const FewCParams p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* wsm = sm;                                  // [R*S*3][K]
+    float* xrow = sm + R * S * 3 * p.K;               // [R][FC_MAXW*3]
+    const int row = blockIdx.x;                       // n*Ho + oy
+    const int n = row / p.Ho, oy = row - n * p.Ho;
+    for (int i = threadIdx.x * 4; i < R * S * 3 * p.K; i += 1024)
+        *reinterpret_cast<float4*>(&wsm[i]) = *reinterpret_cast<const float4*>(&p.W[i]);
+#pragma unroll
+    for (int r = 0; r < R; ++r) stage_row<S>(p, n, oy * ST - p.pt + r, xrow + r * FC_MAXW * 3);
+    __syncthreads();
+    const int LP = p.K >> 2;                          // lanes per pixel
+    const int kq = threadIdx.x % LP, slot = threadIdx.x / LP, nslots = 256 / LP;
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + kq * 4);
+    const float slope = (p.act == DPIG_ACT_NONE) ? 1.f : ((p.act == DPIG_ACT_RELU) ? 0.f : p.alpha);
+    for (int ox = slot; ox < p.Wo; ox += nslots) {
+        float4 a = bv;
+#pragma unroll
+        for (int r = 0; r < R; ++r) {
+            const float* xr = xrow + r * FC_MAXW * 3 + ox * ST * 3;       // (margin: ix + pl folded into staging)
+#pragma unroll
+            for (int sc = 0; sc < S * 3; ++sc) {
+                const float xv = xr[sc];
+                const float4 wv = *reinterpret_cast<const float4*>(&wsm[((r * S) * 3 + sc) * p.K + kq * 4]);
+                a.x += xv * wv.x; a.y += xv * wv.y; a.z += xv * wv.z; a.w += xv * wv.w;
+            }
+        }
+        a.x = (a.x > 0.f) ? a.x : (a.x * slope + 0.f); a.y = (a.y > 0.f) ? a.y : (a.y * slope + 0.f);
+        a.z = (a.z > 0.f) ? a.z : (a.z * slope + 0.f); a.w = (a.w > 0.f) ? a.w : (a.w * slope + 0.f);
+        *reinterpret_cast<float4*>(p.Y + ((long)row * p.Wo + ox) * p.ldy + kq * 4) = a;
+    }
+}
+
+// ---- wgrad: persistent workgroups over output rows; blockIdx.y = tap group (TG consecutive taps) ----------------
+// partial layout per workgroup (blockIdx.x): [R*S*3][K] filter gradient, then [K] bias gradient
+template <int R, int S, int ST, int TG>
+__global__ __launch_bounds__(256) void fewc_wgrad_kernel(const FewCParams p) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int RG = (TG + S - 1) / S;              // image rows a tap group touches (TG = S: 1, TG = R*S: R)
+    float* xrow = sm;                                 // [RG][FC_MAXW*3]
+    float* red = sm + RG * FC_MAXW * 3;               // [(TG*3 + 1)][K]
+    const int t0 = blockIdx.y * TG;                   // first tap of this group
+    const int r0 = t0 / S;                            // its filter row (groups are whole rows or everything)
+    const int LP = p.K >> 2;
+    const int kq = threadIdx.x % LP, slot = threadIdx.x / LP, nslots = 256 / LP;
+    float4 acc[TG * 3];
+    float4 bs = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int i = 0; i < TG * 3; ++i) acc[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int row = blockIdx.x; row < p.nrows; row += gridDim.x) {
+        const int n = row / p.Ho, oy = row - n * p.Ho;
+        __syncthreads();
+#pragma unroll
+        for (int r = 0; r < RG; ++r) stage_row<S>(p, n, oy * ST - p.pt + r0 + r, xrow + r * FC_MAXW * 3);
+        __syncthreads();
+        for (int ox = slot; ox < p.Wo; ox += nslots) {
+            const float4 g = *reinterpret_cast<const float4*>(p.DY + ((long)row * p.Wo + ox) * p.ldy + kq * 4);
+            bs.x += g.x; bs.y += g.y; bs.z += g.z; bs.w += g.w;
+#pragma unroll
+            for (int t = 0; t < TG; ++t) {
+                const float* xr = xrow + (t / S) * FC_MAXW * 3 + (ox * ST + (t % S)) * 3;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const float xv = xr[c];
+                    float4& a = acc[t * 3 + c];
+                    a.x += xv * g.x; a.y += xv * g.y; a.z += xv * g.z; a.w += xv * g.w;
+                }
+            }
+        }
+    }
+    // pixel slots are added in slot order (fixed summation order)
+    for (int ph = 0; ph < nslots; ++ph) {
+        __syncthreads();
+        if (slot == ph) {
+#pragma unroll
+            for (int i = 0; i < TG * 3; ++i) {
+                float4* d = reinterpret_cast<float4*>(&red[i * p.K + kq * 4]);
+                float4 v = acc[i];
+                if (ph) { const float4 o = *d; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+                *d = v;
+            }
+            float4* d = reinterpret_cast<float4*>(&red[TG * 3 * p.K + kq * 4]);
+            float4 v = bs;
+            if (ph) { const float4 o = *d; v.x += o.x; v.y += o.y; v.z += o.z; v.w += o.w; }
+            *d = v;
+        }
+    }
+    __syncthreads();
+    float* out = p.partial + (long)blockIdx.x * (R * S * 3 * p.K + p.K);
+    for (int i = threadIdx.x; i < TG * 3 * p.K; i += 256) out[t0 * 3 * p.K + i] = red[i];
+    if (blockIdx.y == 0)
+        for (int i = threadIdx.x; i < p.K; i += 256) out[R * S * 3 * p.K + i] = red[TG * 3 * p.K + i];
+}
+
+// dst = beta*dst + sum over workgroups, for the filter ([wsize]) and the bias ([K]) parts of the partials
+__global__ __launch_bounds__(256) void fewc_wgrad_reduce_kernel(const float* __restrict__ partial, int nblk, int wsize,
+                                                                int K, float* __restrict__ dw, float beta,
+                                                                float* __restrict__ db, float beta_b) {
+    __shared__ float smr[8][32];
+    const int j = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int i = blockIdx.x * 32 + j;
+    const int n = wsize + K;
+    float v = 0.f;
+    if (i < n)
+        for (int b = g; b < nblk; b += 8) v += partial[(long)b * n + i];
+    smr[g][j] = v;
+    __syncthreads();
+    if (g == 0 && i < n) {
+        float t = smr[0][j];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) t += smr[q][j];
+        if (i < wsize) dw[i] = (beta != 0.f) ? beta * dw[i] + t : t;
+        else if (db) db[i - wsize] = (beta_b != 0.f) ? beta_b * db[i - wsize] + t : t;
+    }
+}
+
+// ---- dgrad towards the 3-channel image: lane = output channel k (K <= 64), one wave per strip of image pixels --
+template <int R, int S, int ST>
+__global__ __launch_bounds__(256) void fewc_dgrad_kernel(const FewCParams p, int nstrips, int nwaves) {
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (wv >= nwaves) return;
+    const int strip = wv % nstrips;
+    const int row = wv / nstrips;                     // n*H + iy
+    const int n = row / p.H, iy = row - n * p.H;
+    const bool kok = lane < p.K;
+    float wr[R * S][3];                               // w[t][c][k = lane]
+#pragma unroll
+    for (int t = 0; t < R * S; ++t)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) wr[t][c] = kok ? p.W[((long)t * 3 + c) * p.K + lane] : 0.f;
+    const int x0 = strip * XS, x1 = min(p.Wd, x0 + XS);
+    for (int ix = x0; ix < x1; ++ix) {
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < R; ++ky) {
+            const int ty = iy + p.pt - ky;            // = oy * ST
+            if (ty < 0 || (ty % ST) != 0 || ty / ST >= p.Ho) continue;
+#pragma unroll
+            for (int kx = 0; kx < S; ++kx) {
+                const int tx = ix + p.pl - kx;
+                if (tx < 0 || (tx % ST) != 0 || tx / ST >= p.Wo) continue;
+                const float g = kok ? p.DY[(((long)n * p.Ho + ty / ST) * p.Wo + tx / ST) * p.ldy + lane] : 0.f;
+                a0 += g * wr[ky * S + kx][0]; a1 += g * wr[ky * S + kx][1]; a2 += g * wr[ky * S + kx][2];
+            }
+        }
+        a0 = reduce_to_lane63(a0); a1 = reduce_to_lane63(a1); a2 = reduce_to_lane63(a2);
+        if (lane == 63) {
+            float* o = p.DX + ((long)row * p.Wd + ix) * p.ldx;
+            o[0] = a0; o[1] = a1; o[2] = a2;
+        }
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------
 static bool eligible(const DpigConvDesc* d, int pt, int pl) {
     return d->K == TK && d->R == 3 && d->S == 3 && d->stride == 1 && !d->upsample2x && pt == 1 && pl == 1 &&
@@ -337,6 +524,80 @@ int thin_wgrad_try(const DpigConvDesc* d, int pt, int pl, const float* x, const 
     hipLaunchKernelGGL(thin3_wgrad_reduce_kernel, dim3((wsize + TK + 31) / 32), dim3(256), 0, st, p.partial, nblk, wsize,
                        dw, beta, db, beta_b);
     rc = check_launch("thin3_wgrad_reduce_kernel");
+    return rc ? rc : 1;
+}
+
+// ---- three-input-channel layers ---------------------------------------------------------------------------------
+static int fewc_kind(const DpigConvDesc* d) {        // 1: 3x3 s1, 2: 5x5 s2, 0: not eligible
+    if (d->C != 3 || d->upsample2x || d->W + 5 > FC_MAXW || d->K % 4 != 0 || d->ldy % 4 != 0) return 0;
+    const int lp = d->K / 4;
+    if (lp < 1 || lp > 64 || (lp & (lp - 1)) != 0) return 0;        // lanes per pixel: a power of two
+    if (d->R == 3 && d->S == 3 && d->stride == 1) return 1;
+    if (d->R == 5 && d->S == 5 && d->stride == 2) return 2;
+    return 0;
+}
+static void fewc_fill(const DpigConvDesc* d, int pt, int pl, int Ho, int Wo, FewCParams* p) {
+    p->N = d->N; p->H = d->H; p->Wd = d->W; p->ldx = d->ldx; p->Ho = Ho; p->Wo = Wo; p->K = d->K; p->ldy = d->ldy;
+    p->pt = pt; p->pl = pl; p->act = d->act; p->alpha = d->alpha; p->nrows = d->N * Ho;
+}
+constexpr int kFewCWgradBlocks = 2 * kNumCU;
+
+int fewc_fwd_try(const DpigConvDesc* d, int pt, int pl, int Ho, int Wo, const float* x, const float* w,
+                 const float* bias, const float* residual, float* y, float* y_act, hipStream_t st) {
+    const int kind = fewc_kind(d);
+    if (!kind || residual || y_act || !aligned16(w) || !aligned16(y) || (bias && !aligned16(bias))) return 0;
+    FewCParams p = {};
+    fewc_fill(d, pt, pl, Ho, Wo, &p);
+    p.X = x; p.W = w; p.bias = bias; p.Y = y;
+    const int R = kind == 1 ? 3 : 5;
+    const size_t lds = ((size_t)R * R * 3 * d->K + (size_t)R * FC_MAXW * 3) * sizeof(float);
+    if (kind == 1) hipLaunchKernelGGL((fewc_fwd_kernel<3, 3, 1>), dim3(p.nrows), dim3(256), lds, st, p);
+    else hipLaunchKernelGGL((fewc_fwd_kernel<5, 5, 2>), dim3(p.nrows), dim3(256), lds, st, p);
+    const int rc = check_launch("fewc_fwd_kernel");
+    return rc ? rc : 1;
+}
+
+size_t fewc_wgrad_workspace_bytes(const DpigConvDesc* d) {
+    if (!fewc_kind(d)) return 0;
+    return (size_t)kFewCWgradBlocks * ((size_t)d->R * d->S * 3 * d->K + d->K) * sizeof(float);
+}
+
+int fewc_wgrad_try(const DpigConvDesc* d, int pt, int pl, int Ho, int Wo, const float* x, const float* dy,
+                   float* dw, float beta, float* db, float beta_b, void* ws, size_t ws_bytes, hipStream_t st) {
+    const int kind = fewc_kind(d);
+    if (!kind || !aligned16(dy)) return 0;
+    const size_t need = fewc_wgrad_workspace_bytes(d);
+    if (!ws || ws_bytes < need) return fail(DPIG_ENOMEM, "conv wgrad workspace too small: have %zu", ws_bytes);
+    FewCParams p = {};
+    fewc_fill(d, pt, pl, Ho, Wo, &p);
+    p.X = x; p.DY = dy; p.partial = static_cast<float*>(ws);
+    const int nblk = p.nrows < kFewCWgradBlocks ? p.nrows : kFewCWgradBlocks;
+    if (kind == 1) {
+        const size_t lds = ((size_t)3 * FC_MAXW * 3 + (size_t)(27 + 1) * d->K) * sizeof(float);
+        hipLaunchKernelGGL((fewc_wgrad_kernel<3, 3, 1, 9>), dim3(nblk, 1), dim3(256), lds, st, p);
+    } else {
+        const size_t lds = ((size_t)1 * FC_MAXW * 3 + (size_t)(15 + 1) * d->K) * sizeof(float);
+        hipLaunchKernelGGL((fewc_wgrad_kernel<5, 5, 2, 5>), dim3(nblk, 5), dim3(256), lds, st, p);
+    }
+    int rc = check_launch("fewc_wgrad_kernel");
+    if (rc) return rc;
+    const int wsize = d->R * d->S * 3 * d->K;
+    hipLaunchKernelGGL(fewc_wgrad_reduce_kernel, dim3((wsize + d->K + 31) / 32), dim3(256), 0, st, p.partial, nblk, wsize,
+                       d->K, dw, beta, db, beta_b);
+    rc = check_launch("fewc_wgrad_reduce_kernel");
+    return rc ? rc : 1;
+}
+
+int fewc_dgrad_try(const DpigConvDesc* d, int pt, int pl, int Ho, int Wo, const float* dy, const float* w,
+                   const float* accum, const float* mask, float* dx, hipStream_t st) {
+    if (fewc_kind(d) != 2 || d->K > 64 || accum || mask) return 0;
+    FewCParams p = {};
+    fewc_fill(d, pt, pl, Ho, Wo, &p);
+    p.DY = dy; p.W = w; p.DX = dx;
+    const int nstrips = (d->W + XS - 1) / XS;
+    const int nwaves = d->N * d->H * nstrips;
+    hipLaunchKernelGGL((fewc_dgrad_kernel<5, 5, 2>), dim3((nwaves + 3) / 4), dim3(256), 0, st, p, nstrips, nwaves);
+    const int rc = check_launch("fewc_dgrad_kernel");
     return rc ? rc : 1;
 }
 

@@ -16,6 +16,7 @@ LAYERS = [
     ("roi b0 48x48 128->128 ", 112, 48, 48, 128, 128, 3, 1),
     ("roi dn 48x48 128->256 ", 112, 48, 48, 128, 256, 3, 2),
     ("roi b4 3x3 640->640   ", 112, 3, 3, 640, 640, 3, 1),
+    ("D.1    128x64 3->64   ", 16, 128, 64, 3, 64, 5, 2),
     ("D.2    64x32 64->128  ", 16, 64, 32, 64, 128, 5, 2),
     ("G.out  128x64 256->3  ", 16, 128, 64, 256, 3, 3, 1),
     ("E.stem 128x64 3->128  ", 16, 128, 64, 3, 128, 3, 1),

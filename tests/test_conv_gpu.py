@@ -29,6 +29,8 @@ SHAPES = [
     (2, 8, 8, 20, 24, 3, 2),       # thin both ways, stride 2
     (2, 5, 40, 64, 3, 3, 1),       # Cout=3 vector-ALU path: two strips per row, the second one partial
     (1, 3, 70, 20, 3, 3, 1),       # Cout=3, 5 active lanes, three strips
+    (1, 9, 70, 3, 32, 3, 1),       # Cin=3 vector-ALU path, 8 lanes per pixel, odd width
+    (2, 11, 37, 3, 16, 5, 2),      # Cin=3 5x5 s2, odd sizes (pad (1,2) / (2,2)), 4 lanes per pixel
 ]
 
 

@@ -34,7 +34,7 @@ def _worker(rank, world, port, q):
         ar.broadcast(fp.flat)
         fp.grad[:1000].copy_(torch.arange(1000, dtype=torch.float32) * (rank + 1))
         scale = ar(fp.grad)
-        q.put((rank, fp.flat[:1000].clone(), fp.grad[:1000].clone(), scale))
+        q.put((rank, fp.flat[:1000].detach().numpy().copy(), fp.grad[:1000].numpy().copy(), scale))   # by value
     finally:
         dist.destroy_process_group()
 
@@ -50,7 +50,7 @@ def test_bucketed_allreduce_and_broadcast_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, w0, g0, s0), (r1, w1, g1, s1) = res
+    (r0, w0, g0, s0), (r1, w1, g1, s1) = [(r, torch.from_numpy(w), torch.from_numpy(g), sc) for r, w, g, sc in res]
     assert torch.equal(w0, w1)                                           # broadcast from rank 0
     expect = torch.arange(1000, dtype=torch.float32) * 3.0               # (1 + 2) * arange
     assert torch.equal(g0, expect) and torch.equal(g1, expect)

@@ -58,7 +58,7 @@ def _op_worker(rank, world, port, q):
             yf = A.batchnorm(xf, scf, off, 1e-5, 2, 0.2)
             yf.backward(dy_full.to(dev))
             out.update(y_ref=yf.detach().cpu(), dx_ref=xf.grad.cpu(), ds_ref=scf.grad.cpu(), do_ref=off.grad.cpu())
-        q.put((rank, out))
+        q.put((rank, {k: v.numpy() for k, v in out.items()}))      # by value: the producer may exit first
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -71,7 +71,7 @@ def test_sync_batchnorm_op_matches_full_batch():
     procs = [ctx.Process(target=_op_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=240) for _ in range(world))
+    res = {r: {k: torch.from_numpy(v) for k, v in o.items()} for r, o in (q.get(timeout=240) for _ in range(world))}
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -104,7 +104,7 @@ def _train_worker(rank, world, port, q):
         out = tr.train_step(bg, bd)
         torch.cuda.synchronize()
         res = dict(d_loss=float(out["d_loss"]), g_loss=float(out["g_loss"]),
-                   D=tr.D_flat.flat.detach().cpu().clone(), G=tr.G_flat.flat.detach().cpu().clone())
+                   D=tr.D_flat.flat.detach().cpu().numpy().copy(), G=tr.G_flat.flat.detach().cpu().numpy().copy())
         q.put((rank, res))
         dist.barrier()
     finally:
@@ -123,6 +123,8 @@ def test_two_rank_step_with_sync_bn_matches_single_process(dev):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
+    for r in res:
+        res[r]["D"], res[r]["G"] = torch.from_numpy(res[r]["D"]), torch.from_numpy(res[r]["G"])
     assert torch.equal(res[0]["D"], res[1]["D"]) and torch.equal(res[0]["G"], res[1]["G"])   # replicas stay in sync
 
     from dpig_amd import slim, synthetic
