@@ -65,6 +65,9 @@ SYMBOLS = {
     "dpig_crop_resize_fwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "dpig_crop_resize_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "dpig_crop_resize_bwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "dpig_pose_points": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "dpig_pose_inflate": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
+    "dpig_pose_rasterize": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "dpig_upsample2x_fwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "dpig_upsample2x_bwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "dpig_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _i, _f, _vp]),

@@ -549,6 +549,73 @@ __global__ __launch_bounds__(256) void crop_bwd_y_kernel(const float* __restrict
 }
 
 // ---------------------------------------------------------------------------------------------
+// input pipeline: pose target maps (utils.py:237-318)
+// ---------------------------------------------------------------------------------------------
+// half-width of the inflate stencil at row distance |a| (a disc of radius 4): |b| <= kDiscHalf[|a|]
+__device__ __forceinline__ int disc_half(int a) {
+    const int aa = a < 0 ? -a : a;
+    return aa == 0 ? 4 : (aa <= 2 ? 3 : (aa == 3 ? 2 : (aa == 4 ? 0 : -1)));
+}
+__device__ __forceinline__ void keypoint_pixel(const float* __restrict__ rcv, int H, int W, int normalized, int* r,
+                                               int* c, float* v) {
+    float R = rcv[0], C = rcv[1];
+    if (normalized) {
+        R = fminf(fmaxf((R + 1.f) / 2.0f * (float)H, 0.f), (float)(H - 1));
+        C = fminf(fmaxf((C + 1.f) / 2.0f * (float)W, 0.f), (float)(W - 1));
+    }
+    *r = (int)R; *c = (int)C; *v = rcv[2];                // tf.to_int32 truncates
+}
+// MODE 0: single points (coord2channel_simple_rcv), MODE 1: points + disc (the chained pipeline)
+template <int MODE>
+__global__ __launch_bounds__(256) void pose_from_rcv_kernel(const float* __restrict__ rcv, int B, int K, int H, int W,
+                                                            int normalized, float* __restrict__ out, int ldo) {
+    const long total = (long)B * H * W * K;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K);
+        long t = i / K;
+        const int x = (int)(t % W); t /= W;
+        const int y = (int)(t % H);
+        const int b = (int)(t / H);
+        int r, c; float v;
+        keypoint_pixel(rcv + ((long)b * K + k) * 3, H, W, normalized, &r, &c, &v);
+        float o = -1.f;
+        if (MODE == 0) {
+            if ((unsigned)r < (unsigned)H && (unsigned)c < (unsigned)W && r == y && c == x) o = 2.f * v - 1.f;
+        } else {
+            const int a = r - y, bb = c - x;
+            const int hw = disc_half(a);
+            if ((unsigned)r < (unsigned)H && (unsigned)c < (unsigned)W && hw >= 0 && bb >= -hw && bb <= hw) {
+                const float hits = (a == 0 && bb == 0) ? 2.f : 1.f;      // the shift list contains (0,0) once more
+                o = fminf(v * hits, 1.f) * 2.f - 1.f;
+            }
+        }
+        out[((((long)b * H + y) * W + x)) * ldo + k] = o;
+    }
+}
+__global__ __launch_bounds__(256) void pose_inflate_kernel(const float* __restrict__ pose, int ldp, int B, int K, int H,
+                                                           int W, float* __restrict__ out, int ldo) {
+    const long total = (long)B * H * W * K;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int k = (int)(i % K);
+        long t = i / K;
+        const int x = (int)(t % W); t /= W;
+        const int y = (int)(t % H);
+        const int b = (int)(t / H);
+        const float* base = pose + ((long)b * H * W) * ldp + k;
+        float s = (base[((long)y * W + x) * ldp] + 1.f) * 0.5f;          // the unshifted map itself
+        for (int a = -4; a <= 4; ++a) {
+            const int yy = y + a, hw = disc_half(a);
+            if ((unsigned)yy >= (unsigned)H) continue;
+            for (int bb = -hw; bb <= hw; ++bb) {
+                const int xx = x + bb;
+                if ((unsigned)xx < (unsigned)W) s += (base[((long)yy * W + xx) * ldp] + 1.f) * 0.5f;
+            }
+        }
+        out[(((long)b * H + y) * W + x) * ldo + k] = fminf(s, 1.f) * 2.f - 1.f;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // nearest-neighbour 2x upsample (align_corners=False -> exact 2x2 replication) and its gradient
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* __restrict__ x, int N, int H, int W,
@@ -990,6 +1057,32 @@ extern "C" int dpig_crop_resize_bwd(const float* dout, int N, int H, int W, int 
         hipLaunchKernelGGL((crop_bwd_y_kernel<1>), gy, dim3(256), 0, st, tmp, N, H, W, C, boxes, box_ind, nbox, ch, dimg);
     }
     return check_launch("crop_resize_bwd");
+}
+
+extern "C" int dpig_pose_points(const float* rcv, int B, int K, int H, int W, int is_normalized, float* out, int ldo,
+                                void* stream) {
+    if (!rcv || !out) return fail(DPIG_EINVAL, "pose_points: null pointer");
+    if (B <= 0 || K <= 0 || H <= 0 || W <= 0 || ldo < K) return fail(DPIG_EINVAL, "pose_points: bad shape");
+    hipLaunchKernelGGL((pose_from_rcv_kernel<0>), dim3(grid_for((long)B * H * W * K)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), rcv, B, K, H, W, is_normalized, out, ldo);
+    return check_launch("pose_points");
+}
+extern "C" int dpig_pose_rasterize(const float* rcv, int B, int K, int H, int W, int is_normalized, float* out,
+                                   int ldo, void* stream) {
+    if (!rcv || !out) return fail(DPIG_EINVAL, "pose_rasterize: null pointer");
+    if (B <= 0 || K <= 0 || H <= 0 || W <= 0 || ldo < K) return fail(DPIG_EINVAL, "pose_rasterize: bad shape");
+    hipLaunchKernelGGL((pose_from_rcv_kernel<1>), dim3(grid_for((long)B * H * W * K)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), rcv, B, K, H, W, is_normalized, out, ldo);
+    return check_launch("pose_rasterize");
+}
+extern "C" int dpig_pose_inflate(const float* pose, int ldp, int B, int K, int H, int W, float* out, int ldo,
+                                 void* stream) {
+    if (!pose || !out) return fail(DPIG_EINVAL, "pose_inflate: null pointer");
+    if (B <= 0 || K <= 0 || H <= 0 || W <= 0 || ldo < K || ldp < K) return fail(DPIG_EINVAL, "pose_inflate: bad shape");
+    if (pose == out) return fail(DPIG_EINVAL, "pose_inflate: in-place not supported");
+    hipLaunchKernelGGL(pose_inflate_kernel, dim3(grid_for((long)B * H * W * K)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), pose, ldp, B, K, H, W, out, ldo);
+    return check_launch("pose_inflate");
 }
 
 extern "C" int dpig_upsample2x_fwd(const float* x, int N, int H, int W, int C, float* y, void* stream) {

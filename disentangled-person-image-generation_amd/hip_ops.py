@@ -441,6 +441,38 @@ def crop_resize_bwd(dout, boxes, box_ind, img_shape):
     return dimg
 
 
+def pose_points(rcv, H, W, keypoint_num=18, is_normalized=True):
+    """coord2channel_simple_rcv (utils.py:237-285) on the device: rcv [B, K*3] -> [B,H,W,K]."""
+    _require_gpu(rcv)
+    B = rcv.shape[0]
+    rcv = rcv.reshape(B, keypoint_num, 3).contiguous().float()
+    out = torch.empty((B, H, W, keypoint_num), dtype=torch.float32, device=rcv.device)
+    check(lib().dpig_pose_points(ptr(rcv), B, keypoint_num, H, W, int(bool(is_normalized)), ptr(out), keypoint_num,
+                                 stream_ptr()), "pose_points")
+    return out
+
+
+def pose_inflate(pose):
+    """tf_poseInflate (utils.py:287-318) on an NHWC [-1,1] map."""
+    _require_gpu(pose)
+    pose = pose.contiguous()
+    B, H, W, K = pose.shape
+    out = torch.empty_like(pose)
+    check(lib().dpig_pose_inflate(ptr(pose), K, B, K, H, W, ptr(out), K, stream_ptr()), "pose_inflate")
+    return out
+
+
+def pose_rasterize(rcv, H, W, keypoint_num=18, is_normalized=True):
+    """Both steps in one pass from the keypoint coordinates: each visible keypoint becomes a radius-4 disc."""
+    _require_gpu(rcv)
+    B = rcv.shape[0]
+    rcv = rcv.reshape(B, keypoint_num, 3).contiguous().float()
+    out = torch.empty((B, H, W, keypoint_num), dtype=torch.float32, device=rcv.device)
+    check(lib().dpig_pose_rasterize(ptr(rcv), B, keypoint_num, H, W, int(bool(is_normalized)), ptr(out), keypoint_num,
+                                    stream_ptr()), "pose_rasterize")
+    return out
+
+
 def upsample2x_fwd(x):
     _require_gpu(x)
     x = x.contiguous()

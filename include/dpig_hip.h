@@ -190,6 +190,18 @@ int dpig_crop_resize_bwd(const float* dout, int N, int H, int W, int C, const fl
                          const int32_t* box_ind, int nbox, int ch, int cw, float* dimg, void* ws,
                          size_t ws_bytes, void* stream);
 
+/* ---- input pipeline: pose target maps (utils.py:237-318) --------------------------------
+ * rcv: [B, K, 3] = (row, col, visibility) per keypoint, rows/cols in [-1,1] if is_normalized.  out: [B,H,W,K], ld = ldo.
+ * dpig_pose_points   = coord2channel_simple_rcv: 2v-1 at the clipped, truncated keypoint pixel, -1 elsewhere.
+ * dpig_pose_inflate  = tf_poseInflate on any [-1,1] map: the map plus its 49 zero-padded shifts (disc of radius 4),
+ *                      clipped at 1, back to [-1,1].
+ * dpig_pose_rasterize = the two chained in one pass straight from the coordinates (no intermediate map, no 49 shifts). */
+int dpig_pose_points(const float* rcv, int B, int K, int H, int W, int is_normalized, float* out, int ldo,
+                     void* stream);
+int dpig_pose_inflate(const float* pose, int ldp, int B, int K, int H, int W, float* out, int ldo, void* stream);
+int dpig_pose_rasterize(const float* rcv, int B, int K, int H, int W, int is_normalized, float* out, int ldo,
+                        void* stream);
+
 /* ---- nearest-neighbour 2x upsample (unfused form; utils.py:61-72) ---------------------------- */
 int dpig_upsample2x_fwd(const float* x, int N, int H, int W, int C, float* y, void* stream);
 int dpig_upsample2x_bwd(const float* dy, int N, int H, int W, int C, float* dx, void* stream);

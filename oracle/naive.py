@@ -200,3 +200,23 @@ def tf_adam(p, grads, lr, beta1=0.9, beta2=0.999, eps=1e-8):
         v = beta2 * v + (1 - beta2) * g * g
         p = p - lr_t * m / (np.sqrt(v) + eps)
     return p
+
+
+def pose_disc_map(rcv, keypoint_num, img_H, img_W, radius=4):
+    """Independent restatement of the pose target the input pipeline builds (utils.py:237-318 chained): the
+    reference's own numpy variant fills a Euclidean disc of `radius` around each visible keypoint
+    (py_poseInflate, utils.py:320-340); the 49-shift stencil of tf_poseInflate is exactly that disc for radius 4."""
+    B = rcv.shape[0]
+    rcv = np.asarray(rcv, dtype=np.float64).reshape(B, keypoint_num, 3)
+    out = -np.ones((B, img_H, img_W, keypoint_num))
+    for b in range(B):
+        for k in range(keypoint_num):
+            r = min(max((rcv[b, k, 0] + 1) / 2.0 * img_H, 0.0), img_H - 1.0)
+            c = min(max((rcv[b, k, 1] + 1) / 2.0 * img_W, 0.0), img_W - 1.0)
+            r, c, v = int(r), int(c), rcv[b, k, 2]
+            for i in range(-radius, radius + 1):
+                for j in range(-radius, radius + 1):
+                    if i * i + j * j <= radius * radius and 0 <= r + i < img_H and 0 <= c + j < img_W:
+                        hits = 2 if (i == 0 and j == 0) else 1          # the stencil visits the centre twice
+                        out[b, r + i, c + j, k] = min(v * hits, 1.0) * 2 - 1
+    return out

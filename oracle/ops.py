@@ -140,3 +140,39 @@ def tf_adam_step(p, g, m, v, lr, beta1, beta2, eps, t):
     v = beta2 * v + (1.0 - beta2) * g * g
     p = p - lr_t * m / (torch.sqrt(v) + eps)
     return p, m, v
+
+
+# ---- input-pipeline pose maps (utils.py:237-318) ----------------------------------------------------
+POSE_STENCIL = ([(a, 0) for a in (-4, 4)] + [(a, b) for a in (-3, 3) for b in range(-2, 3)] +
+                [(a, b) for a in (-2, 2) for b in range(-3, 4)] + [(a, b) for a in (-1, 1) for b in range(-3, 4)] +
+                [(0, b) for b in range(-4, 5)])          # the 49 (row, col) shifts of tf_poseInflate (utils.py:300-314)
+
+
+def coord2channel_simple_rcv(rcv, keypoint_num=18, is_normalized=True, img_H=128, img_W=64):
+    """utils.py:237-285: RCV [B, K*3] or [B,K,3] = (row, col, visibility) per keypoint -> [B,H,W,K] map that is
+    2*v-1 at the (clipped, truncated) keypoint pixel and -1 elsewhere.  scatter_nd ADDS duplicates; there are
+    none here (one update per (b,k))."""
+    B = rcv.shape[0]
+    rcv = rcv.reshape(B, keypoint_num, 3)
+    R, C, V = rcv[..., 0], rcv[..., 1], rcv[..., 2]
+    if is_normalized:
+        R = torch.clamp((R + 1) / 2.0 * img_H, min=0.0, max=float(img_H - 1))
+        C = torch.clamp((C + 1) / 2.0 * img_W, min=0.0, max=float(img_W - 1))
+    Ri, Ci = R.to(torch.int64), C.to(torch.int64)            # tf.to_int32 truncates
+    land = torch.zeros(B, img_H, img_W, keypoint_num, dtype=rcv.dtype)
+    bi = torch.arange(B)[:, None].expand(B, keypoint_num)
+    ki = torch.arange(keypoint_num)[None, :].expand(B, keypoint_num)
+    land.index_put_((bi, Ri, Ci, ki), torch.full((B, keypoint_num), 2.0, dtype=rcv.dtype), accumulate=True)
+    land = land * V[:, None, None, :]
+    return land - 1
+
+
+def tf_poseInflate(pose, keypoint_num=18, radius=4, img_H=128, img_W=64):
+    """utils.py:287-318: g=(pose+1)/2; g + sum of the 49 zero-padded shifts of g; min(.,1); back to [-1,1].
+    shift (a,b): result[i,j] = g[i+a, j+b] (pad_to_bounding_box by `radius`, crop at (a+radius, b+radius))."""
+    g = (pose + 1) / 2
+    pad = torch.nn.functional.pad(g, (0, 0, radius, radius, radius, radius))          # NHWC: pad W then H
+    out = g.clone()
+    for a, b in POSE_STENCIL:
+        out = out + pad[:, a + radius:a + radius + img_H, b + radius:b + radius + img_W, :]
+    return torch.clamp(out, max=1.0) * 2 - 1

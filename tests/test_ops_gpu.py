@@ -264,3 +264,35 @@ def test_deconv_backward(dev):
     gy.backward(dy.float().to(dev))
     _close(gx.grad, x.grad, 1e-4)
     _close(gw.grad, w.grad, 1e-4)
+
+
+@pytest.mark.parametrize("normalized", [True, False])
+def test_pose_maps(dev, normalized):
+    """coord2channel_simple_rcv / tf_poseInflate (utils.py:237-318) and the fused rasteriser."""
+    import dpig_amd.utils as U
+    from oracle import ops as O
+    rng = np.random.default_rng(9)
+    B, K, Hh, W = 4, 18, 128, 64
+    rcv = np.zeros((B, K, 3), dtype=np.float32)
+    if normalized:
+        rcv[..., 0] = rng.uniform(-1.1, 1.1, (B, K)); rcv[..., 1] = rng.uniform(-1.1, 1.1, (B, K))
+    else:
+        rcv[..., 0] = rng.integers(0, Hh, (B, K)); rcv[..., 1] = rng.integers(0, W, (B, K))
+    rcv[..., 2] = (rng.uniform(size=(B, K)) < 0.85)
+    rcv[0, 0] = (-1.0, -1.0, 1.0) if normalized else (0.0, 0.0, 1.0)
+    rcv[0, 1] = (1.0, 1.0, 1.0) if normalized else (Hh - 1.0, W - 1.0, 1.0)
+    rcv[1, 2, 2] = 0.5
+    t = torch.from_numpy(rcv.reshape(B, K * 3))
+    ref_pts = O.coord2channel_simple_rcv(t.double(), K, normalized, Hh, W)
+    ref = O.tf_poseInflate(ref_pts, K, 4, Hh, W)
+    pts = U.coord2channel_simple_rcv(t.to(dev), K, normalized, Hh, W)
+    assert torch.equal(pts.cpu().double(), ref_pts)
+    assert torch.equal(U.tf_poseInflate(pts, K, 4, Hh, W).cpu().double(), ref)
+    assert torch.equal(U.pose_target_from_rcv(t.to(dev), K, normalized, Hh, W).cpu().double(), ref)
+    # tf_poseInflate is defined on any [-1,1] map, not only on single points
+    dense = torch.from_numpy(rng.choice([-1.0, -0.5, 0.25, 1.0], size=(2, 20, 12, 5))).float()
+    _close(U.tf_poseInflate(dense.to(dev), 5, 4, 20, 12), O.tf_poseInflate(dense.double(), 5, 4, 20, 12), 1e-6)
+    if not normalized:                              # keypoints outside the image are dropped
+        rcv[2, 3] = (-3.0, 5.0, 1.0); rcv[2, 4] = (5.0, W + 2.0, 1.0)
+        out = U.pose_target_from_rcv(torch.from_numpy(rcv.reshape(B, K * 3)).to(dev), K, False, Hh, W)
+        assert float(out[2, :, :, 3].max()) == -1.0 and float(out[2, :, :, 4].max()) == -1.0

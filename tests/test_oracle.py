@@ -180,3 +180,35 @@ def test_oracle_model_shapes_names_and_losses():
     assert torch.isfinite(gl) and torch.isfinite(dl)
     # g_loss = sce(D(G),1) + 20*L1 (trainer.py:623)
     assert abs(gl.item() - (aux["g_loss_only"].item() + 20 * aux["L1Loss"].item())) < 1e-12
+
+
+@pytest.mark.parametrize("normalized", [True, False])
+def test_pose_maps_scatter_and_shifts_equal_disc(normalized):
+    """utils.py:237-318 restated two ways: scatter + 49 zero-padded shifts (oracle/ops.py) vs a Euclidean disc of
+    radius 4 per visible keypoint (oracle/naive.py, the reference's own numpy variant utils.py:320-340)."""
+    import numpy as np
+    import torch
+    from oracle import naive, ops
+    rng = np.random.default_rng(3)
+    B, K, Hh, W = 3, 18, 32, 16
+    rcv = np.zeros((B, K, 3))
+    if normalized:
+        rcv[..., 0] = rng.uniform(-1.2, 1.2, (B, K)); rcv[..., 1] = rng.uniform(-1.2, 1.2, (B, K))
+    else:
+        rcv[..., 0] = rng.integers(0, Hh, (B, K)); rcv[..., 1] = rng.integers(0, W, (B, K))
+    rcv[..., 2] = (rng.uniform(size=(B, K)) < 0.8).astype(np.float64)
+    rcv[0, 0] = (-1.0 if normalized else 0.0, -1.0 if normalized else 0.0, 1.0)          # corner keypoint
+    rcv[0, 1, 2] = 0.5                                                                    # fractional visibility
+    t = torch.from_numpy(rcv.reshape(B, K * 3))
+    if normalized:
+        pts = ops.coord2channel_simple_rcv(t, K, True, Hh, W)
+        want = naive.pose_disc_map(rcv, K, Hh, W)
+    else:
+        pts = ops.coord2channel_simple_rcv(t, K, False, Hh, W)
+        norm = rcv.copy()                          # the disc restatement takes normalised coordinates
+        norm[..., 0] = (rcv[..., 0] + 0.25) / Hh * 2 - 1
+        norm[..., 1] = (rcv[..., 1] + 0.25) / W * 2 - 1
+        want = naive.pose_disc_map(norm, K, Hh, W)
+    got = ops.tf_poseInflate(pts, K, 4, Hh, W).numpy()
+    assert np.array_equal(got, want)
+    assert ((pts.numpy() == -1) | (pts.numpy() == 2 * rcv[:, None, None, :, 2] - 1)).all()
