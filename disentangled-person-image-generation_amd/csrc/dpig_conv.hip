@@ -194,7 +194,7 @@ __device__ __forceinline__ void epi_vec4(const GGParams& p, int row, int col, fl
 // at most 32 (Cout = 3 image conv, dgrad towards a 3-channel image, N = 1 logits): 4x fewer MFMAs than
 // masking a 128-wide tile down to 3 columns.
 template <bool B_ROWK, bool VEC, bool NARROW>
-__global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GGParams p) {
+__device__ __forceinline__ void gather_gemm_body(const GGParams& p) {
     constexpr int MB = NARROW ? 1 : 2;          // 32-row blocks per wave
     constexpr int NB = NARROW ? 1 : 2;          // 32-col blocks per wave
     constexpr int BNT = NARROW ? 32 : BN;       // block tile width
@@ -582,8 +582,29 @@ __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GGParams p) {
 #endif
 }
 
+template <bool B_ROWK, bool VEC, bool NARROW>
+__global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GGParams p) {
+    gather_gemm_body<B_ROWK, VEC, NARROW>(p);
+}
+// Several independent problems of the same kernel variant in ONE launch (blockIdx.y picks the problem): the 4
+// output-parity classes of a stride-2 dgrad are 4 small GEMMs (a quarter of the pixels each, 4..9 of the 25 taps);
+// as 4 launches + 4 split-K reductions they were launch-bound (~13 us each, 31 TFLOP/s on the critic's layers).
+struct GGMulti { GGParams q[4]; };
+template <bool B_ROWK, bool VEC, bool NARROW>
+__global__ __launch_bounds__(256, 2) void gather_gemm_multi_kernel(const GGMulti m) {
+    const GGParams& p = m.q[blockIdx.y];
+    if ((int)blockIdx.x >= p.mtiles * p.ntiles || (int)blockIdx.z >= p.nsplit) return;
+    gather_gemm_body<B_ROWK, VEC, NARROW>(p);
+}
+
 // split-K second pass: sum partials in split order (deterministic) and run the fused epilogue
-__global__ __launch_bounds__(256) void gather_gemm_reduce_kernel(const GGParams p) {
+__device__ __forceinline__ void gather_gemm_reduce_body(const GGParams& p);
+__global__ __launch_bounds__(256) void gather_gemm_reduce_kernel(const GGParams p) { gather_gemm_reduce_body(p); }
+__global__ __launch_bounds__(256) void gather_gemm_reduce_multi_kernel(const GGMulti m) {
+    const GGParams& p = m.q[blockIdx.y];
+    if (p.nsplit > 1) gather_gemm_reduce_body(p);
+}
+__device__ __forceinline__ void gather_gemm_reduce_body(const GGParams& p) {
     const long total = (long)p.M * p.Ncols;
     if (p.vec_epi) {
         const int n4 = p.Ncols >> 2;
@@ -1067,7 +1088,8 @@ static bool vec_ok(const void* a, const void* b, int lda, int Cs, int Ncols) {
     return aligned16(a) && aligned16(b) && (lda % 4 == 0) && (Cs % 4 == 0) && (Ncols % 4 == 0);
 }
 
-static int launch_gg(GGParams& p, bool b_rowk, int nimg, long filter_elems, hipStream_t st) {
+// derived fields of one problem; *vec / *narrow select the kernel variant
+static int prepare_gg(GGParams& p, int nimg, long filter_elems, bool* vec, bool* narrow) {
     p.HrWr = p.Hr * p.Wr;
     const long a_elems = ((long)nimg * p.Hs * p.Ws - 1) * p.lda + p.Cs;
     if (a_elems * 4 >= 0x7fffffffL || filter_elems * 4 >= 0x7fffffffL)
@@ -1078,13 +1100,24 @@ static int launch_gg(GGParams& p, bool b_rowk, int nimg, long filter_elems, hipS
                 (!p.bias || aligned16(p.bias)) && (!p.res || (p.ldres % 4 == 0 && aligned16(p.res))) &&
                 (!p.mask || (p.ldmask % 4 == 0 && aligned16(p.mask))) &&
                 (!p.D2 || (p.ldd2 % 4 == 0 && aligned16(p.D2))) && (!p.partial || aligned16(p.partial));
-    const bool narrow = p.Ncols <= 32;
+    *narrow = p.Ncols <= 32;
     p.mtiles = cdiv(p.M, BM);
-    p.ntiles = cdiv(p.Ncols, narrow ? 32 : BN);
+    p.ntiles = cdiv(p.Ncols, *narrow ? 32 : BN);
     p.cchunks = cdiv(p.Cs, BK);
     p.ktiles = p.ntaps * p.cchunks;
-    bool vec = vec_ok(p.A, p.B, p.lda, p.Cs, p.Ncols);
+    *vec = vec_ok(p.A, p.B, p.lda, p.Cs, p.Ncols);
     p.vec_a = aligned16(p.A) && (p.lda % 4 == 0) && (p.Cs % 4 == 0);
+    return DPIG_OK;
+}
+static int reduce_blocks(const GGParams& p) {
+    const long total = (long)p.M * p.Ncols;
+    int blocks = cdiv(p.vec_epi ? total / 4 : total, 256);
+    return blocks > 8 * kNumCU ? 8 * kNumCU : blocks;
+}
+static int launch_gg(GGParams& p, bool b_rowk, int nimg, long filter_elems, hipStream_t st) {
+    bool vec, narrow;
+    int rc = prepare_gg(p, nimg, filter_elems, &vec, &narrow);
+    if (rc) return rc;
     dim3 grid(p.mtiles * p.ntiles, 1, p.nsplit), block(256);
 #define DPIG_GG(BR, VE, NA) hipLaunchKernelGGL((gather_gemm_kernel<BR, VE, NA>), grid, block, 0, st, p)
     if (b_rowk) {
@@ -1095,14 +1128,40 @@ static int launch_gg(GGParams& p, bool b_rowk, int nimg, long filter_elems, hipS
         else { if (vec) DPIG_GG(false, true, false); else DPIG_GG(false, false, false); }
     }
 #undef DPIG_GG
-    int rc = check_launch("gather_gemm_kernel");
+    rc = check_launch("gather_gemm_kernel");
     if (rc) return rc;
     if (p.nsplit > 1) {
-        const long total = (long)p.M * p.Ncols;
-        int blocks = cdiv(p.vec_epi ? total / 4 : total, 256);
-        if (blocks > 8 * kNumCU) blocks = 8 * kNumCU;
-        hipLaunchKernelGGL(gather_gemm_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+        hipLaunchKernelGGL(gather_gemm_reduce_kernel, dim3(reduce_blocks(p)), dim3(256), 0, st, p);
         rc = check_launch("gather_gemm_reduce_kernel");
+    }
+    return rc;
+}
+// n <= 4 problems of the same variant (dgrad: B is [N][K]) in one launch + at most one reduction launch
+static int launch_gg_multi(GGParams* q, int n, int nimg, long filter_elems, hipStream_t st) {
+    GGMulti m = {};
+    bool vec = false, narrow = false;
+    int max_tiles = 0, max_split = 1, max_red = 0;
+    for (int i = 0; i < n; ++i) {
+        bool v, na;
+        const int rc = prepare_gg(q[i], nimg, filter_elems, &v, &na);
+        if (rc) return rc;
+        if (i == 0) { vec = v; narrow = na; }
+        else if (v != vec || na != narrow) return fail(DPIG_EINVAL, "internal: multi-launch variants differ");
+        if (q[i].mtiles * q[i].ntiles > max_tiles) max_tiles = q[i].mtiles * q[i].ntiles;
+        if (q[i].nsplit > max_split) max_split = q[i].nsplit;
+        if (q[i].nsplit > 1 && reduce_blocks(q[i]) > max_red) max_red = reduce_blocks(q[i]);
+        m.q[i] = q[i];
+    }
+    dim3 grid(max_tiles, n, max_split), block(256);
+#define DPIG_GGM(VE, NA) hipLaunchKernelGGL((gather_gemm_multi_kernel<true, VE, NA>), grid, block, 0, st, m)
+    if (narrow) { if (vec) DPIG_GGM(true, true); else DPIG_GGM(false, true); }
+    else { if (vec) DPIG_GGM(true, false); else DPIG_GGM(false, false); }
+#undef DPIG_GGM
+    int rc = check_launch("gather_gemm_multi_kernel");
+    if (rc) return rc;
+    if (max_red > 0) {
+        hipLaunchKernelGGL(gather_gemm_reduce_multi_kernel, dim3(max_red, n), dim3(256), 0, st, m);
+        rc = check_launch("gather_gemm_reduce_multi_kernel");
     }
     return rc;
 }
@@ -1156,6 +1215,24 @@ static int build_dgrad_classes(const DpigConvDesc* d, int pt, int pl, DClass* cl
         }
     return nc;
 }
+// split plan of the parity classes when they share one launch: every class is planned against the TOTAL tile
+// count (that is what fills the machine); partial slabs are laid out back to back in the workspace
+struct S2Plan { int nc; DClass cls[4]; Plan pl[4]; long M[4]; size_t off[4]; size_t total; };
+static void plan_dgrad_s2(const DpigConvDesc* d, int pt, int pl, S2Plan* sp) {
+    sp->nc = build_dgrad_classes(d, pt, pl, sp->cls);
+    const int ntile_n = cdiv(d->C, d->C <= 32 ? 32 : BN);
+    int total_tiles = 0;
+    for (int i = 0; i < sp->nc; ++i) {
+        sp->M[i] = (long)d->N * sp->cls[i].Hr * sp->cls[i].Wr;
+        total_tiles += cdiv(sp->M[i], BM) * ntile_n;
+    }
+    sp->total = 0;
+    for (int i = 0; i < sp->nc; ++i) {
+        sp->pl[i] = plan_split(total_tiles, sp->cls[i].ntaps * cdiv(d->K, BK), d->split_k);
+        sp->off[i] = sp->total;
+        if (sp->pl[i].nsplit > 1) sp->total += (size_t)sp->pl[i].nsplit * sp->M[i] * d->C * sizeof(float);
+    }
+}
 }  // namespace dpig
 
 extern "C" size_t dpig_conv2d_workspace_bytes(const DpigConvDesc* d, int which) {
@@ -1172,16 +1249,9 @@ extern "C" size_t dpig_conv2d_workspace_bytes(const DpigConvDesc* d, int which) 
             Plan pln = plan_split(cdiv(M, BM) * cdiv(d->C, BN), ntaps * cdiv(d->K, BK), d->split_k);
             return pln.nsplit > 1 ? (size_t)pln.nsplit * M * d->C * sizeof(float) : 0;
         }
-        DClass cls[4];
-        const int nc = build_dgrad_classes(d, pt, pl, cls);
-        size_t mx = 0;
-        for (int i = 0; i < nc; ++i) {
-            const long M = (long)d->N * cls[i].Hr * cls[i].Wr;
-            Plan pln = plan_split(cdiv(M, BM) * cdiv(d->C, BN), cls[i].ntaps * cdiv(d->K, BK), d->split_k);
-            const size_t b = pln.nsplit > 1 ? (size_t)pln.nsplit * M * d->C * sizeof(float) : 0;
-            if (b > mx) mx = b;
-        }
-        return mx;
+        S2Plan sp;
+        plan_dgrad_s2(d, pt, pl, &sp);
+        return sp.total;
     } else if (which == 2) {
         const size_t thin = thin_wgrad_workspace_bytes(d, pt, pl);
         if (thin) return thin;
@@ -1273,25 +1343,26 @@ extern "C" int dpig_conv2d_dgrad(const DpigConvDesc* d, const float* dy, const f
         p.ntaps = d->R * d->S;
         p.tap_nb = d->S; p.oy0 = pt; p.oys = -1; p.ox0 = pl; p.oxs = -1; p.w0 = 0; p.wa = d->S; p.wb = 1;
     } else {
-        DClass cls[4];
-        const int nc = build_dgrad_classes(d, pt, pl, cls);
-        for (int i = 0; i < nc; ++i) {
-            GGParams q = p;
-            q.M = d->N * cls[i].Hr * cls[i].Wr; q.Hr = cls[i].Hr; q.Wr = cls[i].Wr;
+        S2Plan sp;
+        plan_dgrad_s2(d, pt, pl, &sp);
+        if (sp.total > 0 && (!ws || ws_bytes < sp.total))
+            return fail(DPIG_ENOMEM, "conv dgrad workspace too small: have %zu", ws_bytes);
+        GGParams qs[4];
+        for (int i = 0; i < sp.nc; ++i) {
+            const DClass& c = sp.cls[i];
+            GGParams& q = qs[i];
+            q = p;
+            q.M = (int)sp.M[i]; q.Hr = c.Hr; q.Wr = c.Wr;
             q.Hs = Ho; q.Ws = Wo; q.sr = 1;
-            q.dr = 2; q.dpy = cls[i].py; q.dpx = cls[i].px; q.identity_rows = 0;
-            q.ntaps = cls[i].ntaps;
-            q.tap_nb = cls[i].nkx > 0 ? cls[i].nkx : 1;
-            q.oy0 = cls[i].oy0; q.oys = -1; q.ox0 = cls[i].ox0; q.oxs = -1;
-            q.w0 = cls[i].ky0 * d->S + cls[i].kx0; q.wa = d->stride * d->S; q.wb = d->stride;
-            Plan pln = plan_split(cdiv(q.M, BM) * cdiv(q.Ncols, BN), q.ntaps * cdiv(q.Cs, BK), d->split_k);
-            q.nsplit = pln.nsplit; q.tiles_per_split = pln.tiles_per_split;
-            if (q.nsplit > 1 && (!ws || ws_bytes < (size_t)q.nsplit * q.M * q.Ncols * sizeof(float)))
-                return fail(DPIG_ENOMEM, "conv dgrad workspace too small: have %zu", ws_bytes);
-            rc = launch_gg(q, true, d->N, (long)d->R * d->S * d->C * d->K, st);
-            if (rc) return rc;
+            q.dr = 2; q.dpy = c.py; q.dpx = c.px; q.identity_rows = 0;
+            q.ntaps = c.ntaps;
+            q.tap_nb = c.nkx > 0 ? c.nkx : 1;
+            q.oy0 = c.oy0; q.oys = -1; q.ox0 = c.ox0; q.oxs = -1;
+            q.w0 = c.ky0 * d->S + c.kx0; q.wa = d->stride * d->S; q.wb = d->stride;
+            q.nsplit = sp.pl[i].nsplit; q.tiles_per_split = sp.pl[i].tiles_per_split;
+            q.partial = reinterpret_cast<float*>(static_cast<char*>(ws) + sp.off[i]);
         }
-        return DPIG_OK;
+        return launch_gg_multi(qs, sp.nc, d->N, (long)d->R * d->S * d->C * d->K, st);
     }
     Plan pln = plan_split(cdiv(p.M, BM) * cdiv(p.Ncols, BN), p.ntaps * cdiv(p.Cs, BK), d->split_k);
     p.nsplit = pln.nsplit; p.tiles_per_split = pln.tiles_per_split;
