@@ -167,8 +167,9 @@ def main():
     value = world * B * args.steps / elapsed
 
     roofline = None
-    if rank == 0 and not args.no_roofline:
-        # instrumented replay of the same step: HIP events around every conv-forward launch
+    if not args.no_roofline:
+        # instrumented replay of the same step: HIP events around every conv-forward launch.  EVERY rank replays
+        # (the steps contain the gradient all-reduce); rank 0's numbers are the ones reported.
         H.PROFILE = []
         nrep = max(1, min(3, args.steps))
         graphs, tr._graphs = tr._graphs, None          # eager launches so that each one can be bracketed

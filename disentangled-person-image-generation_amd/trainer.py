@@ -312,9 +312,10 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         torch.cuda.synchronize(self.device)
         self._graph_update = not self.allreduce.enabled       # fold all-reduce + Adam into the graph?
         gg, gd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(gg):
+        # thread_local: a process-group watchdog thread polling events must not invalidate the capture
+        with torch.cuda.graph(gg, capture_error_mode="thread_local"):
             out_g = self._g_optim_eager(self._static_g, update=self._graph_update)
-        with torch.cuda.graph(gd, pool=gg.pool()):
+        with torch.cuda.graph(gd, pool=gg.pool(), capture_error_mode="thread_local"):
             out_d = self._d_optim_eager(self._static_d, update=self._graph_update)
         self._graphs = (gg, out_g, gd, out_d)
         if self._graph_update:
