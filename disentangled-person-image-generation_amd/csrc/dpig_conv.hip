@@ -21,9 +21,6 @@
 #include <type_traits>
 #include "dpig_common.h"
 #include "dpig_thin.h"
-#ifndef DPIG_PIPE2
-#define DPIG_PIPE2 1
-#endif
 #ifdef DPIG_TRACE   // dev aid (never in the shipped build): s_memtime stamps of wave 0 of the first 512 workgroups
 __device__ unsigned long long dpig_trace_buf[512 * 256];
 __device__ unsigned long long dpig_trace_se[8192 * 4];     // start / end tick of every workgroup
@@ -373,7 +370,6 @@ __device__ __forceinline__ void gather_gemm_body(const GGParams& p) {
             load_begin();
             const float* As = smem[buf];
             const float* Bs = smem[buf] + TILE_FLOATS;
-#if DPIG_PIPE2
             DPIG_STAMP(1);
             // Schedule of one k-tile = 4 groups (kk) of 4 quads (j) of 4 MFMAs.  The hand-over of tile t+1 is
             // spread BEHIND this tile's MFMAs instead of sitting between two tiles: HBM/L2 loads are issued
@@ -426,37 +422,6 @@ __device__ __forceinline__ void gather_gemm_body(const GGParams& p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             buf ^= 1;
-#else
-#pragma unroll
-            for (int kk = 0; kk < BK / 8; ++kk) {
-                if (kk + 1 < BK / 8) load_frag(As, Bs, kk + 1, fa[(kk + 1) & 1], fb[(kk + 1) & 1]);
-                load_part(kk, more);               // HBM/L2 -> registers for tile t+1, between MFMA groups
-                __builtin_amdgcn_sched_barrier(0);  // keep the loads HERE: unpinned, hipcc sinks them to the
-                                                    // ds_writes below and exposes the whole memory latency
-                float av[MB][4], bv[NB][4];
-#pragma unroll
-                for (int mb = 0; mb < MB; ++mb) {
-                    const float4 t = fa[kk & 1][mb];
-                    av[mb][0] = t.x; av[mb][1] = t.y; av[mb][2] = t.z; av[mb][3] = t.w;
-                }
-#pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const float4 t = fb[kk & 1][nb];
-                    bv[nb][0] = t.x; bv[nb][1] = t.y; bv[nb][2] = t.z; bv[nb][3] = t.w;
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb)
-                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[mb][j], bv[nb][j], acc[mb][nb], 0, 0, 0);
-            }
-            store_tiles(buf ^ 1);                  // (zeros after the last tile: nobody reads them)
-            __syncthreads();
-            buf ^= 1;
-            load_frag(smem[buf], smem[buf] + TILE_FLOATS, 0, fa[0], fb[0]);
-#endif
         }
     }
 
@@ -848,12 +813,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
         load_frag(smem[0], smem[0] + BK * LDKN, 0, fa[0], fb[0]);
         for (int kt = kt_begin; kt < kt_end; ++kt) {
             const bool more = (kt + 1) < kt_end;
-#if !DPIG_PIPE2
-            if (more) load_tiles(kt + 1);
-#endif
             const float* As = smem[buf];
             const float* Bs = smem[buf] + BK * LDKN;
-#if DPIG_PIPE2
             // same hand-over schedule as gather_gemm_kernel: the LDS stores of tile t+1 ride behind the MFMA
             // quads of groups 2 and 3, the barrier and the first fragment reads sit before the last quad
 #pragma unroll
@@ -891,24 +852,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
                 __builtin_amdgcn_sched_barrier(0);
             }
             buf ^= 1;
-#else
-#pragma unroll
-            for (int kk = 0; kk < BK / 8; ++kk) {
-                if (kk + 1 < BK / 8) load_frag(As, Bs, kk + 1, fa[(kk + 1) & 1], fb[(kk + 1) & 1]);
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-                        for (int nb = 0; nb < NB; ++nb)
-                            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[kk & 1][mb][j], fb[kk & 1][nb][j],
-                                                                               acc[mb][nb], 0, 0, 0);
-            }
-            if (more) store_tiles(buf ^ 1);
-            __syncthreads();
-            buf ^= 1;
-            if (more) load_frag(smem[buf], smem[buf] + BK * LDKN, 0, fa[0], fb[0]);
-#endif
         }
     }
 
