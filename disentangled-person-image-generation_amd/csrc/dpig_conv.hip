@@ -807,22 +807,28 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
     if (kt_begin < kt_end) {
         load_tiles(kt_begin);
         store_tiles(0);
+        // The operands of this GEMM stream from HBM (a pixel is used by one k-tile), so a load needs a whole
+        // k-tile period to land: the registers of part i are re-loaded with tile t+2 right after the LDS stores
+        // that publish their tile t+1 contents (groups 2-3 of tile t), not at the head of tile t+1.  No second
+        // register set.  (With the loads at the heads of groups 0-1 the stores of groups 2-3 waited on vmcnt:
+        // 148 cycles per MFMA there in the s_memtime trace, against 92 in groups 0-1.)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) load_part(kt_begin + 1, i, kt_begin + 1 < kt_end);
         __syncthreads();
         int buf = 0;
         float fa[2][MB][4], fb[2][NB][4];    // [k-step parity][32-row/col block][j]
         load_frag(smem[0], smem[0] + BK * LDKN, 0, fa[0], fb[0]);
         for (int kt = kt_begin; kt < kt_end; ++kt) {
-            const bool more = (kt + 1) < kt_end;
+            const bool more2 = (kt + 2) < kt_end;
             const float* As = smem[buf];
             const float* Bs = smem[buf] + BK * LDKN;
-            // same hand-over schedule as gather_gemm_kernel: the LDS stores of tile t+1 ride behind the MFMA
-            // quads of groups 2 and 3, the barrier and the first fragment reads sit before the last quad
+            // hand-over schedule as in gather_gemm_kernel: the LDS stores of tile t+1 ride behind the MFMA quads of
+            // groups 2 and 3, the barrier and the first fragment reads sit before the last quad
 #pragma unroll
             for (int kk = 0; kk < BK / 8; ++kk) {
                 if (kk == 0) DPIG_STAMP(1);
                 if (kk == 2) DPIG_STAMP(3);
                 if (kk + 1 < BK / 8) load_frag(As, Bs, kk + 1, fa[(kk + 1) & 1], fb[(kk + 1) & 1]);
-                if (kk < 2) { load_part(kt + 1, 2 * kk, more); load_part(kt + 1, 2 * kk + 1, more); }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
@@ -841,11 +847,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
                                                                                acc[mb][nb], 0, 0, 0);
                     if (kk == 2) {                     // (zeros after the last tile: nobody reads them)
                         __builtin_amdgcn_sched_barrier(0);
-                        if ((j & 1) == 0) store_a(buf ^ 1, j >> 1); else store_b(buf ^ 1, j >> 1);
+                        if ((j & 1) == 0) store_a(buf ^ 1, j >> 1);
+                        else { store_b(buf ^ 1, j >> 1); load_part(kt + 2, j >> 1, more2); }
                         __builtin_amdgcn_sched_barrier(0);
                     } else if (kk == 3 && j < 2) {
                         __builtin_amdgcn_sched_barrier(0);
                         store_a(buf ^ 1, 2 + j); store_b(buf ^ 1, 2 + j);
+                        load_part(kt + 2, 2 + j, more2);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
