@@ -25,7 +25,7 @@ class DpigConvDesc(ctypes.Structure):
         ("ldx", ctypes.c_int32), ("ldy", ctypes.c_int32), ("ldres", ctypes.c_int32), ("ldmask", ctypes.c_int32),
         ("act", ctypes.c_int32), ("alpha", ctypes.c_float),
         ("upsample2x", ctypes.c_int32), ("res_after_act", ctypes.c_int32), ("ldy2", ctypes.c_int32),
-        ("res_class", ctypes.c_int32), ("split_k", ctypes.c_int32),
+        ("res_class", ctypes.c_int32), ("split_k", ctypes.c_int32), ("compute", ctypes.c_int32),
     ]
 
 

@@ -187,10 +187,142 @@ __device__ __forceinline__ void epi_vec4(const GGParams& p, int row, int col, fl
     }
 }
 
+// ---- bf16 matrix-pipe variant of the k loop (DpigConvDesc.compute = DPIG_COMPUTE_BF16; BASELINE configs 3-5) ----
+// Tensors stay fp32 in HBM; operands are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) on their way into LDS and fed
+// to v_mfma_f32_32x32x16_bf16 (fp32 accumulate, same accumulator layout as the fp32 MFMA, so the epilogue is
+// shared).  k-tile = 64: the same 73.7 KB LDS ring holds [128][64] bf16 per operand, rows padded to 144 bytes
+// (conflict-free ds_read_b128 fragments: lane = row, 8 consecutive k per lane).  The forward filter is k-major in
+// HBM ([k][n]); each thread loads an 8(k) x 4(n) patch and transposes it in registers into four 16-byte LDS rows.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack_bf16(float a, float b) {
+    bf16x2 v;
+    v[0] = (__bf16)a; v[1] = (__bf16)b;
+    return __builtin_bit_cast(unsigned, v);
+}
+constexpr int BKH = 64;              // k-tile of the bf16 loop
+constexpr int ROWB = 144;            // bytes per LDS row (64 bf16 + 16 pad)
+constexpr int TILEB = 128 * ROWB;    // one operand tile
+template <bool B_ROWK>
+__device__ __forceinline__ void gg_mainloop_bf16(const GGParams& p, char* lds, f32x16 (&acc)[2][2], int m0, int n0,
+                                                 int kt_begin, int kt_end, int tid, int wrow, int wcol, int l31,
+                                                 int half) {
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes);
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.B, p.b_bytes);
+    const int kq = tid & 15;                                  // 4-float k group of the row-major operands
+    unsigned a_rowoff[8];
+    int a_iy0[8], a_ix0[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int m = m0 + (tid >> 4) + 16 * i;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int n = mm / p.HrWr;
+        const int rem = mm - n * p.HrWr;
+        const int r = rem / p.Wr;
+        const int c = rem - r * p.Wr;
+        a_iy0[i] = ok ? r * p.sr : -(1 << 24);
+        a_ix0[i] = c * p.sr;
+        a_rowoff[i] = (unsigned)((((n * p.Hs + r * p.sr) * p.Ws + c * p.sr) * p.lda + kq * 4) * 4);
+    }
+    unsigned b_off[8];
+    bool b_ok[8];
+    const int nq = tid & 31, koct = tid >> 5;                 // fwd filter patch: 4 columns x 8 k rows
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        if (B_ROWK) {
+            const int n = n0 + (tid >> 4) + 16 * i;
+            b_ok[i] = n < p.Ncols;
+            b_off[i] = (unsigned)((n * p.Cs + kq * 4) * 4);
+        } else {
+            b_ok[i] = n0 + nq * 4 < p.Ncols;
+            b_off[i] = (unsigned)((((koct * 8 + i) * p.Ncols) + n0 + nq * 4) * 4);
+        }
+    }
+    int cur_c0, cur_ta, cur_tb;
+    {
+        const int tap = kt_begin / p.cchunks;
+        cur_c0 = (kt_begin - tap * p.cchunks) * BKH;
+        cur_ta = tap / p.tap_nb;
+        cur_tb = tap - cur_ta * p.tap_nb;
+    }
+    float4 ra[8], rb[8];
+    auto load_tile = [&](bool live) {
+        const int c0 = cur_c0, ta = cur_ta, tb = cur_tb;
+        cur_c0 += BKH;
+        if (cur_c0 >= p.Cs) {
+            cur_c0 = 0;
+            if (++cur_tb == p.tap_nb) { cur_tb = 0; ++cur_ta; }
+        }
+        const int wt = p.w0 + ta * p.wa + tb * p.wb;
+        const int t_oy = p.oy0 + ta * p.oys, t_ox = p.ox0 + tb * p.oxs;
+        const int t_ck = c0 + kq * 4;
+        const bool t_kok = t_ck < p.Cs;
+        const unsigned t_sA = (unsigned)(((t_oy * p.Ws + t_ox) * p.lda + c0) * 4);
+        const unsigned t_sB = B_ROWK ? (unsigned)((wt * p.Ncols * p.Cs + c0) * 4) : (unsigned)(((wt * p.Cs + c0) * p.Ncols) * 4);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const bool ok = live & t_kok & ((unsigned)(a_iy0[i] + t_oy) < (unsigned)p.Hs) &
+                            ((unsigned)(a_ix0[i] + t_ox) < (unsigned)p.Ws);
+            ra[i] = gload4<true>(rsA, a_rowoff[i] + t_sA, ok, t_ck, p.Cs);
+            if (B_ROWK) rb[i] = gload4<true>(rsB, b_off[i] + t_sB, live & b_ok[i] & t_kok, t_ck, p.Cs);
+            else rb[i] = gload4<true>(rsB, b_off[i] + t_sB, live & b_ok[i] & (c0 + koct * 8 + i < p.Cs), 0, 4);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char* As = lds + buf * 2 * TILEB;
+        char* Bs = As + TILEB;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const int r = (tid >> 4) + 16 * i;
+            *reinterpret_cast<uint2*>(As + r * ROWB + kq * 8) = make_uint2(pack_bf16(ra[i].x, ra[i].y), pack_bf16(ra[i].z, ra[i].w));
+            if (B_ROWK)
+                *reinterpret_cast<uint2*>(Bs + r * ROWB + kq * 8) = make_uint2(pack_bf16(rb[i].x, rb[i].y), pack_bf16(rb[i].z, rb[i].w));
+        }
+        if (!B_ROWK) {      // register transpose of the 8(k) x 4(n) patch -> 4 rows n of 8 consecutive k
+            char* d = Bs + (nq * 4) * ROWB + koct * 16;
+            *reinterpret_cast<uint4*>(d + 0 * ROWB) = make_uint4(pack_bf16(rb[0].x, rb[1].x), pack_bf16(rb[2].x, rb[3].x), pack_bf16(rb[4].x, rb[5].x), pack_bf16(rb[6].x, rb[7].x));
+            *reinterpret_cast<uint4*>(d + 1 * ROWB) = make_uint4(pack_bf16(rb[0].y, rb[1].y), pack_bf16(rb[2].y, rb[3].y), pack_bf16(rb[4].y, rb[5].y), pack_bf16(rb[6].y, rb[7].y));
+            *reinterpret_cast<uint4*>(d + 2 * ROWB) = make_uint4(pack_bf16(rb[0].z, rb[1].z), pack_bf16(rb[2].z, rb[3].z), pack_bf16(rb[4].z, rb[5].z), pack_bf16(rb[6].z, rb[7].z));
+            *reinterpret_cast<uint4*>(d + 3 * ROWB) = make_uint4(pack_bf16(rb[0].w, rb[1].w), pack_bf16(rb[2].w, rb[3].w), pack_bf16(rb[4].w, rb[5].w), pack_bf16(rb[6].w, rb[7].w));
+        }
+    };
+    if (kt_begin >= kt_end) return;
+    load_tile(true);
+    store_tile(0);
+    __syncthreads();
+    int buf = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const bool more = (kt + 1) < kt_end;
+        load_tile(more);                                   // tile t+1 in flight under this tile's MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        const char* As = lds + buf * 2 * TILEB;
+        const char* Bs = As + TILEB;
+#pragma unroll
+        for (int ks = 0; ks < BKH / 16; ++ks) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+                fa[mb] = *reinterpret_cast<const bf16x8*>(As + (wrow + mb * 32 + l31) * ROWB + ks * 32 + half * 16);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+                fb[nb] = *reinterpret_cast<const bf16x8*>(Bs + (wcol + nb * 32 + l31) * ROWB + ks * 32 + half * 16);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mb], fb[nb], acc[mb][nb], 0, 0, 0);
+        }
+        store_tile(buf ^ 1);                                // (zeros after the last tile: nobody reads them)
+        __syncthreads();
+        buf ^= 1;
+    }
+}
+
 // NARROW: 128 x 32 block tile (waves stacked 4 x 1, one 32x32 accumulator each) for GEMMs whose N is
 // at most 32 (Cout = 3 image conv, dgrad towards a 3-channel image, N = 1 logits): 4x fewer MFMAs than
 // masking a 128-wide tile down to 3 columns.
-template <bool B_ROWK, bool VEC, bool NARROW>
+template <bool B_ROWK, bool VEC, bool NARROW, bool BF16 = false>
 __device__ __forceinline__ void gather_gemm_body(const GGParams& p) {
     constexpr int MB = NARROW ? 1 : 2;          // 32-row blocks per wave
     constexpr int NB = NARROW ? 1 : 2;          // 32-col blocks per wave
@@ -211,6 +343,25 @@ __device__ __forceinline__ void gather_gemm_body(const GGParams& p) {
     const int kt_begin = split * p.tiles_per_split;
     const int kt_end = min(p.ktiles, kt_begin + p.tiles_per_split);
 
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#ifdef DPIG_TRACE
+    const bool trace_on = ((int)blockIdx.x < 512) && (blockIdx.z == 0) && (tid == 0);
+    int trace_n = 0;
+    if (trace_on) dpig_trace_buf[blockIdx.x * 256 + trace_n++] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
+    DPIG_STAMP(0);
+    if (tid == 0 && blockIdx.x < 8192 && blockIdx.z == 0) { dpig_trace_se[blockIdx.x * 4] = __builtin_amdgcn_s_memtime(); dpig_trace_se[blockIdx.x * 4 + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4); }
+#endif
+    if constexpr (BF16) {
+        static_assert(!NARROW && VEC, "the bf16 loop exists for the 128x128 tile, 16-byte loadable operands");
+        gg_mainloop_bf16<B_ROWK>(p, reinterpret_cast<char*>(&smem[0][0]), acc, m0, n0, kt_begin, kt_end, tid, wrow, wcol,
+                                 l31, half);
+    } else {
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes);
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.B, p.b_bytes);
 
@@ -343,21 +494,6 @@ __device__ __forceinline__ void gather_gemm_body(const GGParams& p) {
         }
     };
 
-    f32x16 acc[MB][NB];
-#pragma unroll
-    for (int i = 0; i < MB; ++i)
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-#ifdef DPIG_TRACE
-    const bool trace_on = ((int)blockIdx.x < 512) && (blockIdx.z == 0) && (tid == 0);
-    int trace_n = 0;
-    if (trace_on) dpig_trace_buf[blockIdx.x * 256 + trace_n++] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4);
-    DPIG_STAMP(0);
-    if (tid == 0 && blockIdx.x < 8192 && blockIdx.z == 0) { dpig_trace_se[blockIdx.x * 4] = __builtin_amdgcn_s_memtime(); dpig_trace_se[blockIdx.x * 4 + 2] = ((unsigned long long)__builtin_amdgcn_s_getreg((3 << 11) | (0 << 6) | 20) << 32) | __builtin_amdgcn_s_getreg((31 << 11) | (0 << 6) | 4); }
-#endif
     if (kt_begin < kt_end) {
         load_tiles();
         store_tiles(0);
@@ -424,6 +560,8 @@ __device__ __forceinline__ void gather_gemm_body(const GGParams& p) {
             buf ^= 1;
         }
     }
+
+    }   // fp32 k loop
 
     DPIG_STAMP(5);
 #ifdef DPIG_TRACE
@@ -547,19 +685,19 @@ __device__ __forceinline__ void gather_gemm_body(const GGParams& p) {
 #endif
 }
 
-template <bool B_ROWK, bool VEC, bool NARROW>
+template <bool B_ROWK, bool VEC, bool NARROW, bool BF16 = false>
 __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GGParams p) {
-    gather_gemm_body<B_ROWK, VEC, NARROW>(p);
+    gather_gemm_body<B_ROWK, VEC, NARROW, BF16>(p);
 }
 // Several independent problems of the same kernel variant in ONE launch (blockIdx.y picks the problem): the 4
 // output-parity classes of a stride-2 dgrad are 4 small GEMMs (a quarter of the pixels each, 4..9 of the 25 taps);
 // as 4 launches + 4 split-K reductions they were launch-bound (~13 us each, 31 TFLOP/s on the critic's layers).
 struct GGMulti { GGParams q[4]; };
-template <bool B_ROWK, bool VEC, bool NARROW>
+template <bool B_ROWK, bool VEC, bool NARROW, bool BF16 = false>
 __global__ __launch_bounds__(256, 2) void gather_gemm_multi_kernel(const GGMulti m) {
     const GGParams& p = m.q[blockIdx.y];
     if ((int)blockIdx.x >= p.mtiles * p.ntiles || (int)blockIdx.z >= p.nsplit) return;
-    gather_gemm_body<B_ROWK, VEC, NARROW>(p);
+    gather_gemm_body<B_ROWK, VEC, NARROW, BF16>(p);
 }
 
 // split-K second pass: sum partials in split order (deterministic) and run the fused epilogue
@@ -1039,8 +1177,14 @@ static bool vec_ok(const void* a, const void* b, int lda, int Cs, int Ncols) {
     return aligned16(a) && aligned16(b) && (lda % 4 == 0) && (Cs % 4 == 0) && (Ncols % 4 == 0);
 }
 
+// k-tile depth of the GEMM loop: 64 when the caller asked for the bf16 matrix pipe and the problem has the shape the
+// bf16 loop is written for (16-byte loadable operands, 128-wide tile), else 32 (fp32 MFMA)
+static int gg_bk(const DpigConvDesc* d, int lda, int Cs, int Ncols) {
+    return (d->compute == DPIG_COMPUTE_BF16 && lda % 4 == 0 && Cs % 4 == 0 && Ncols % 4 == 0 && Ncols > 32) ? BKH : BK;
+}
+
 // derived fields of one problem; *vec / *narrow select the kernel variant
-static int prepare_gg(GGParams& p, int nimg, long filter_elems, bool* vec, bool* narrow) {
+static int prepare_gg(GGParams& p, int nimg, long filter_elems, bool* vec, bool* narrow, bool bf16 = false) {
     p.HrWr = p.Hr * p.Wr;
     const long a_elems = ((long)nimg * p.Hs * p.Ws - 1) * p.lda + p.Cs;
     if (a_elems * 4 >= 0x7fffffffL || filter_elems * 4 >= 0x7fffffffL)
@@ -1054,7 +1198,7 @@ static int prepare_gg(GGParams& p, int nimg, long filter_elems, bool* vec, bool*
     *narrow = p.Ncols <= 32;
     p.mtiles = cdiv(p.M, BM);
     p.ntiles = cdiv(p.Ncols, *narrow ? 32 : BN);
-    p.cchunks = cdiv(p.Cs, BK);
+    p.cchunks = cdiv(p.Cs, bf16 ? BKH : BK);
     p.ktiles = p.ntaps * p.cchunks;
     *vec = vec_ok(p.A, p.B, p.lda, p.Cs, p.Ncols);
     p.vec_a = aligned16(p.A) && (p.lda % 4 == 0) && (p.Cs % 4 == 0);
@@ -1065,13 +1209,17 @@ static int reduce_blocks(const GGParams& p) {
     int blocks = cdiv(p.vec_epi ? total / 4 : total, 256);
     return blocks > 8 * kNumCU ? 8 * kNumCU : blocks;
 }
-static int launch_gg(GGParams& p, bool b_rowk, int nimg, long filter_elems, hipStream_t st) {
+static int launch_gg(GGParams& p, bool b_rowk, int nimg, long filter_elems, hipStream_t st, bool bf16 = false) {
     bool vec, narrow;
-    int rc = prepare_gg(p, nimg, filter_elems, &vec, &narrow);
+    int rc = prepare_gg(p, nimg, filter_elems, &vec, &narrow, bf16);
     if (rc) return rc;
     dim3 grid(p.mtiles * p.ntiles, 1, p.nsplit), block(256);
+    if (bf16 && (!vec || narrow)) return fail(DPIG_EINVAL, "internal: bf16 loop selected for an ineligible problem");
 #define DPIG_GG(BR, VE, NA) hipLaunchKernelGGL((gather_gemm_kernel<BR, VE, NA>), grid, block, 0, st, p)
-    if (b_rowk) {
+    if (bf16) {
+        if (b_rowk) hipLaunchKernelGGL((gather_gemm_kernel<true, true, false, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gather_gemm_kernel<false, true, false, true>), grid, block, 0, st, p);
+    } else if (b_rowk) {
         if (narrow) { if (vec) DPIG_GG(true, true, true); else DPIG_GG(true, false, true); }
         else { if (vec) DPIG_GG(true, true, false); else DPIG_GG(true, false, false); }
     } else {
@@ -1088,13 +1236,13 @@ static int launch_gg(GGParams& p, bool b_rowk, int nimg, long filter_elems, hipS
     return rc;
 }
 // n <= 4 problems of the same variant (dgrad: B is [N][K]) in one launch + at most one reduction launch
-static int launch_gg_multi(GGParams* q, int n, int nimg, long filter_elems, hipStream_t st) {
+static int launch_gg_multi(GGParams* q, int n, int nimg, long filter_elems, hipStream_t st, bool bf16 = false) {
     GGMulti m = {};
     bool vec = false, narrow = false;
     int max_tiles = 0, max_split = 1, max_red = 0;
     for (int i = 0; i < n; ++i) {
         bool v, na;
-        const int rc = prepare_gg(q[i], nimg, filter_elems, &v, &na);
+        const int rc = prepare_gg(q[i], nimg, filter_elems, &v, &na, bf16);
         if (rc) return rc;
         if (i == 0) { vec = v; narrow = na; }
         else if (v != vec || na != narrow) return fail(DPIG_EINVAL, "internal: multi-launch variants differ");
@@ -1104,8 +1252,10 @@ static int launch_gg_multi(GGParams* q, int n, int nimg, long filter_elems, hipS
         m.q[i] = q[i];
     }
     dim3 grid(max_tiles, n, max_split), block(256);
+    if (bf16 && (!vec || narrow)) return fail(DPIG_EINVAL, "internal: bf16 loop selected for an ineligible problem");
 #define DPIG_GGM(VE, NA) hipLaunchKernelGGL((gather_gemm_multi_kernel<true, VE, NA>), grid, block, 0, st, m)
-    if (narrow) { if (vec) DPIG_GGM(true, true); else DPIG_GGM(false, true); }
+    if (bf16) hipLaunchKernelGGL((gather_gemm_multi_kernel<true, true, false, true>), grid, block, 0, st, m);
+    else if (narrow) { if (vec) DPIG_GGM(true, true); else DPIG_GGM(false, true); }
     else { if (vec) DPIG_GGM(true, false); else DPIG_GGM(false, false); }
 #undef DPIG_GGM
     int rc = check_launch("gather_gemm_multi_kernel");
@@ -1119,11 +1269,11 @@ static int launch_gg_multi(GGParams* q, int n, int nimg, long filter_elems, hipS
 
 // number of (row tiles x col tiles) and k-tiles for each op, used by both the workspace query and the launch
 struct Shape { long M; int Ncols, ktiles; };
-static Shape fwd_shape(const DpigConvDesc* d, int Ho, int Wo) {
+static Shape fwd_shape(const DpigConvDesc* d, int Ho, int Wo, int bk = BK) {
     Shape s;
     s.M = d->upsample2x ? (long)d->N * d->H * d->W : (long)d->N * Ho * Wo;
     s.Ncols = d->K;
-    s.ktiles = d->R * d->S * cdiv(d->C, BK);
+    s.ktiles = d->R * d->S * cdiv(d->C, bk);
     return s;
 }
 
@@ -1169,7 +1319,7 @@ static int build_dgrad_classes(const DpigConvDesc* d, int pt, int pl, DClass* cl
 // split plan of the parity classes when they share one launch: every class is planned against the TOTAL tile
 // count (that is what fills the machine); partial slabs are laid out back to back in the workspace
 struct S2Plan { int nc; DClass cls[4]; Plan pl[4]; long M[4]; size_t off[4]; size_t total; };
-static void plan_dgrad_s2(const DpigConvDesc* d, int pt, int pl, S2Plan* sp) {
+static void plan_dgrad_s2(const DpigConvDesc* d, int pt, int pl, S2Plan* sp, int bk = BK) {
     sp->nc = build_dgrad_classes(d, pt, pl, sp->cls);
     const int ntile_n = cdiv(d->C, d->C <= 32 ? 32 : BN);
     int total_tiles = 0;
@@ -1179,7 +1329,7 @@ static void plan_dgrad_s2(const DpigConvDesc* d, int pt, int pl, S2Plan* sp) {
     }
     sp->total = 0;
     for (int i = 0; i < sp->nc; ++i) {
-        sp->pl[i] = plan_split(total_tiles, sp->cls[i].ntaps * cdiv(d->K, BK), d->split_k);
+        sp->pl[i] = plan_split(total_tiles, sp->cls[i].ntaps * cdiv(d->K, bk), d->split_k);
         sp->off[i] = sp->total;
         if (sp->pl[i].nsplit > 1) sp->total += (size_t)sp->pl[i].nsplit * sp->M[i] * d->C * sizeof(float);
     }
@@ -1189,20 +1339,33 @@ static void plan_dgrad_s2(const DpigConvDesc* d, int pt, int pl, S2Plan* sp) {
 extern "C" size_t dpig_conv2d_workspace_bytes(const DpigConvDesc* d, int which) {
     int pt, pl, Ho, Wo;
     if (resolve_desc(d, &pt, &pl, &Ho, &Wo)) return 0;
+    // (pointer alignment is not known here: when the bf16 loop may be chosen, size for the larger of the two plans)
     if (which == 0) {
-        Shape s = fwd_shape(d, Ho, Wo);
-        Plan pln = plan_split(cdiv(s.M, BM) * cdiv(s.Ncols, BN), s.ktiles, d->split_k);
-        return pln.nsplit > 1 ? (size_t)pln.nsplit * s.M * s.Ncols * sizeof(float) : 0;
-    } else if (which == 1) {
-        if (d->upsample2x || d->stride == 1) {
-            const long M = (long)d->N * d->H * d->W;
-            const int ntaps = d->upsample2x ? 4 : d->R * d->S;
-            Plan pln = plan_split(cdiv(M, BM) * cdiv(d->C, BN), ntaps * cdiv(d->K, BK), d->split_k);
-            return pln.nsplit > 1 ? (size_t)pln.nsplit * M * d->C * sizeof(float) : 0;
+        size_t best = 0;
+        for (int bk = BK; bk <= gg_bk(d, d->ldx, d->C, d->K); bk += BK) {
+            Shape s = fwd_shape(d, Ho, Wo, bk);
+            Plan pln = plan_split(cdiv(s.M, BM) * cdiv(s.Ncols, BN), s.ktiles, d->split_k);
+            const size_t b = pln.nsplit > 1 ? (size_t)pln.nsplit * s.M * s.Ncols * sizeof(float) : 0;
+            if (b > best) best = b;
         }
-        S2Plan sp;
-        plan_dgrad_s2(d, pt, pl, &sp);
-        return sp.total;
+        return best;
+    } else if (which == 1) {
+        size_t best = 0;
+        for (int bk = BK; bk <= gg_bk(d, d->ldy, d->K, d->C); bk += BK) {
+            size_t b;
+            if (d->upsample2x || d->stride == 1) {
+                const long M = (long)d->N * d->H * d->W;
+                const int ntaps = d->upsample2x ? 4 : d->R * d->S;
+                Plan pln = plan_split(cdiv(M, BM) * cdiv(d->C, BN), ntaps * cdiv(d->K, bk), d->split_k);
+                b = pln.nsplit > 1 ? (size_t)pln.nsplit * M * d->C * sizeof(float) : 0;
+            } else {
+                S2Plan sp;
+                plan_dgrad_s2(d, pt, pl, &sp, bk);
+                b = sp.total;
+            }
+            if (b > best) best = b;
+        }
+        return best;
     } else if (which == 2) {
         const size_t thin = thin_wgrad_workspace_bytes(d, pt, pl);
         if (thin) return thin;
@@ -1240,7 +1403,8 @@ extern "C" int dpig_conv2d_fwd(const DpigConvDesc* d, const float* x, const floa
     rc = fewc_fwd_try(d, pt, pl, Ho, Wo, x, w, bias, residual, y, y_act, static_cast<hipStream_t>(stream));
     if (rc != 0) return rc < 0 ? rc : DPIG_OK;
     p.partial = static_cast<float*>(ws);
-    Shape s = fwd_shape(d, Ho, Wo);
+    const bool bf16 = gg_bk(d, d->ldx, d->C, d->K) == BKH && aligned16(x) && aligned16(w);
+    Shape s = fwd_shape(d, Ho, Wo, bf16 ? BKH : BK);
     p.M = (int)s.M;
     p.Hr = d->upsample2x ? d->H : Ho; p.Wr = d->upsample2x ? d->W : Wo;
     p.Hs = d->H; p.Ws = d->W; p.lda = d->ldx; p.Cs = d->C; p.sr = d->stride;
@@ -1258,7 +1422,7 @@ extern "C" int dpig_conv2d_fwd(const DpigConvDesc* d, const float* x, const floa
     if (p.nsplit > 1 && ws_bytes < (size_t)p.nsplit * s.M * s.Ncols * sizeof(float))
         return fail(DPIG_ENOMEM, "conv fwd workspace too small: have %zu", ws_bytes);
     if (p.nsplit > 1 && !ws) return fail(DPIG_ENOMEM, "conv fwd needs a workspace");
-    return launch_gg(p, false, d->N, (long)d->R * d->S * d->C * d->K, static_cast<hipStream_t>(stream));
+    return launch_gg(p, false, d->N, (long)d->R * d->S * d->C * d->K, static_cast<hipStream_t>(stream), bf16);
 }
 
 extern "C" int dpig_conv2d_dgrad(const DpigConvDesc* d, const float* dy, const float* w, const float* accum,
@@ -1278,6 +1442,7 @@ extern "C" int dpig_conv2d_dgrad(const DpigConvDesc* d, const float* dy, const f
     p.A = dy; p.B = w; p.D = dx; p.bias = nullptr; p.res = accum; p.mask = mask;
     p.partial = static_cast<float*>(ws);
     p.lda = d->ldy; p.Cs = d->K; p.Ncols = d->C;
+    const bool bf16 = gg_bk(d, d->ldy, d->K, d->C) == BKH && aligned16(dy) && aligned16(w);
     p.Hd = d->H; p.Wd = d->W; p.ldd = d->ldx; p.ldres = d->ldres; p.ldmask = d->ldmask;
     p.act = mask ? d->act : DPIG_ACT_NONE; p.alpha = d->alpha; p.replicate = 0;
     if (d->upsample2x) {
@@ -1295,7 +1460,7 @@ extern "C" int dpig_conv2d_dgrad(const DpigConvDesc* d, const float* dy, const f
         p.tap_nb = d->S; p.oy0 = pt; p.oys = -1; p.ox0 = pl; p.oxs = -1; p.w0 = 0; p.wa = d->S; p.wb = 1;
     } else {
         S2Plan sp;
-        plan_dgrad_s2(d, pt, pl, &sp);
+        plan_dgrad_s2(d, pt, pl, &sp, bf16 ? BKH : BK);
         if (sp.total > 0 && (!ws || ws_bytes < sp.total))
             return fail(DPIG_ENOMEM, "conv dgrad workspace too small: have %zu", ws_bytes);
         GGParams qs[4];
@@ -1313,13 +1478,13 @@ extern "C" int dpig_conv2d_dgrad(const DpigConvDesc* d, const float* dy, const f
             q.nsplit = sp.pl[i].nsplit; q.tiles_per_split = sp.pl[i].tiles_per_split;
             q.partial = reinterpret_cast<float*>(static_cast<char*>(ws) + sp.off[i]);
         }
-        return launch_gg_multi(qs, sp.nc, d->N, (long)d->R * d->S * d->C * d->K, st);
+        return launch_gg_multi(qs, sp.nc, d->N, (long)d->R * d->S * d->C * d->K, st, bf16);
     }
-    Plan pln = plan_split(cdiv(p.M, BM) * cdiv(p.Ncols, BN), p.ntaps * cdiv(p.Cs, BK), d->split_k);
+    Plan pln = plan_split(cdiv(p.M, BM) * cdiv(p.Ncols, BN), p.ntaps * cdiv(p.Cs, bf16 ? BKH : BK), d->split_k);
     p.nsplit = pln.nsplit; p.tiles_per_split = pln.tiles_per_split;
     if (p.nsplit > 1 && (!ws || ws_bytes < (size_t)p.nsplit * p.M * p.Ncols * sizeof(float)))
         return fail(DPIG_ENOMEM, "conv dgrad workspace too small: have %zu", ws_bytes);
-    return launch_gg(p, true, d->N, (long)d->R * d->S * d->C * d->K, st);
+    return launch_gg(p, true, d->N, (long)d->R * d->S * d->C * d->K, st, bf16);
 }
 
 extern "C" int dpig_conv2d_wgrad(const DpigConvDesc* d, const float* x, const float* dy, float* dw, float beta,

@@ -69,9 +69,24 @@ def as_nhwc(t):
     return t, ld
 
 
+COMPUTE_F32, COMPUTE_BF16 = 0, 1
+_COMPUTE = [COMPUTE_F32]
+
+
+def set_compute(dtype):
+    """Matrix-pipe arithmetic of every subsequent conv launch: 'f32' (default; exact fp32 products) or 'bf16'
+    (operands rounded to bfloat16, fp32 accumulation, tensors unchanged in memory: DpigConvDesc.compute)."""
+    _COMPUTE[0] = {"f32": COMPUTE_F32, "fp32": COMPUTE_F32, "bf16": COMPUTE_BF16}[dtype]
+
+
+def get_compute():
+    return "bf16" if _COMPUTE[0] == COMPUTE_BF16 else "f32"
+
+
 def _desc(N, H, W, C, K, R, S, stride, ldx, ldy, ldres=0, ldmask=0, act=ACT_NONE, alpha=0.2, upsample2x=False,
           split_k=0, res_after_act=False, ldy2=0, res_class=False):
     d = DpigConvDesc()
+    d.compute = _COMPUTE[0]
     d.N, d.H, d.W, d.C, d.K, d.R, d.S, d.stride = N, H, W, C, K, R, S, stride
     d.pad_t, d.pad_l = -1, -1
     d.ldx, d.ldy, d.ldres, d.ldmask = ldx, ldy, ldres, ldmask

@@ -70,7 +70,15 @@ typedef struct DpigConvDesc {
                           /*      contribution of spatially constant input channels to a SAME 3x3 */
                           /*      conv -- the tiled embedding of trainer.py:588-590   */
     int32_t split_k;      /* 0 = library heuristic, otherwise forced split count                  */
+    int32_t compute;      /* DPIG_COMPUTE_F32 (default): fp32 MFMA, exact fp32 products.           */
+                          /* DPIG_COMPUTE_BF16: tensors stay fp32 in memory, GEMM operands are     */
+                          /* rounded to bfloat16 (round-to-nearest-even) and multiplied on the     */
+                          /* bf16 matrix pipe with fp32 accumulation (BASELINE configs 3-5);       */
+                          /* layers the bf16 loop is not written for (unaligned / fewer than 33    */
+                          /* output columns / C % 4 != 0) silently use the fp32 pipe.              */
 } DpigConvDesc;
+#define DPIG_COMPUTE_F32 0
+#define DPIG_COMPUTE_BF16 1
 
 int dpig_version(void);
 const char* dpig_last_error(void);

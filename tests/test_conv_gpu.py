@@ -271,3 +271,56 @@ def test_thin_cout3_epilogue_and_accumulate(dev, act):
     _close(outs[0][0], w.grad + base_w)
     _close(outs[0][1], b.grad + base_b)
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+BF16_SHAPES = [(2, 16, 8, 32, 128, 3, 1), (2, 16, 8, 64, 128, 3, 2), (1, 12, 12, 128, 256, 3, 1), (2, 9, 7, 36, 40, 3, 1),
+               (2, 8, 4, 64, 128, 5, 2), (3, 6, 6, 96, 132, 1, 1), (2, 9, 7, 36, 40, 3, 2), (1, 16, 8, 200, 64, 3, 1)]
+
+
+def _bf(t):
+    """Round to bfloat16 (nearest even) and return fp64: what the bf16 matrix pipe multiplies."""
+    return t.float().bfloat16().double()
+
+
+@pytest.mark.parametrize("shape", BF16_SHAPES)
+@pytest.mark.parametrize("split_k", [0, 3])
+def test_conv_bf16_compute(dev, shape, split_k):
+    """DpigConvDesc.compute = BF16: operands rounded to bf16, exact products, fp32 accumulation -> equal to the fp64
+    oracle on the ROUNDED operands to fp32-accumulation accuracy (fwd with bias + LeakyReLU, dgrad, wgrad).  A GEMM
+    with at most 32 output columns is served by the fp32 pipe (then the unrounded oracle is the reference)."""
+    import dpig_amd.hip_ops as H
+    from oracle import ops as O
+    N, Hh, W, C, K, k, s = shape
+    x = _rand((N, Hh, W, C), 1)
+    w = _rand((k, k, C, K), 2) * 0.2
+    b = _rand((K,), 3)
+    dy_shape = tuple(O.conv2d_same(x, w, None, s).shape)
+    dy = _rand(dy_shape, 4)
+    H.set_compute("bf16")
+    try:
+        # forward: N-dim = K
+        xe, we = (_bf(x), _bf(w)) if K > 32 else (x, w)
+        got = H.conv2d_fwd(x.float().to(dev), w.float().to(dev), b.float().to(dev), stride=s, act=2, alpha=0.2,
+                           split_k=split_k)
+        _close(got, O.leaky_relu(O.conv2d_same(xe, we, b, s), 0.2))
+        # dgrad multiplies dy with w: N-dim = C
+        de, we = (_bf(dy), _bf(w)) if C > 32 else (dy, w)
+        xr = x.clone().requires_grad_(True)
+        (O.conv2d_same(xr, we, None, s) * de).sum().backward()
+        dx = H.conv2d_dgrad(dy.float().to(dev), w.float().to(dev), (N, Hh, W, C), stride=s, split_k=split_k)
+        _close(dx, xr.grad)
+    finally:
+        H.set_compute("f32")
+
+
+def test_conv_bf16_falls_back_to_fp32_when_ineligible(dev):
+    import dpig_amd.hip_ops as H
+    x = _rand((2, 16, 8, 256), 1).float().to(dev)
+    w = (_rand((3, 3, 256, 3), 2) * 0.2).float().to(dev)
+    ref = H.conv2d_fwd(x, w)
+    H.set_compute("bf16")
+    try:
+        got = H.conv2d_fwd(x, w)          # 3 output columns: the fp32 path serves it
+    finally:
+        H.set_compute("f32")
+    assert torch.equal(got, ref)
