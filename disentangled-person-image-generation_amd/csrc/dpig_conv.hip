@@ -757,11 +757,106 @@ struct WGParams {
     float* DB; float* bias_partial; float beta_b;  // fused bias gradient: db[co] = sum_pixels dy[., co]
     int vec_x;                                     // 1: x alone is 16-byte loadable (Cout = 3: dy is not)
     int d32_oy, d32_ox;                            // S1: (row, col) advance of a pixel index step of BK = 32
+    int d64_oy, d64_ox;                            //     ... and of the bf16 loop's 64
 };
 
 // n / d for 0 <= n < 2^31 with a precomputed (mul, shr); mul == 0 encodes d == 1
 __device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned shr) {
     return mul ? (int)(__umulhi((unsigned)n, mul) >> shr) : n;
+}
+
+// bf16 matrix-pipe variant of the stride-1 wgrad pixel loop (see gg_mainloop_bf16 for the operand format).
+// Both operands are pixel-major in HBM ([pixel][channel]) while the MFMA wants 8 consecutive k (= pixels) per
+// lane: each thread loads an 8(pixel) x 4(channel) patch of x and of dy with the scalar-offset addressing of the
+// S1 loader and transposes it in registers into four 16-byte LDS rows per operand; fragments are then plain
+// ds_read_b128 (the fp32 loop needs 4-byte LDS reads here).  k-tile = 64 pixels.
+__device__ __forceinline__ void wg_mainloop_bf16(const WGParams& p, char* lds, f32x16 (&acc)[2][2], int ci0, int co0,
+                                                 int oyoff, int oxoff, int kt_begin, int kt_end, int tid, int wrow,
+                                                 int wcol, int l31, int half, bool do_bias, float4& bsum) {
+    const int cq = tid & 31, poct = tid >> 5;                  // 4 channels x 8 pixels per thread
+    const int padpix = p.pad_t * p.W + p.pad_l;
+    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.X - (long)padpix * p.ldx, p.x_bytes + (unsigned)(padpix * p.ldx * 4));
+    const __amdgpu_buffer_rsrc_t rsY = make_rsrc(p.DY, p.y_bytes);
+    const bool cx_ok = ci0 + cq * 4 < p.C, cy_ok = co0 + cq * 4 < p.K;
+    int s_oy[8], s_ox[8];
+    unsigned xv[8], yv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int r = poct * 8 + e;
+        const int m = kt_begin * BKH + r;
+        const int n = fast_div(m, p.mul_howo, p.shr_howo);
+        const int rem = m - n * p.HoWo;
+        s_oy[e] = fast_div(rem, p.mul_wo, p.shr_wo);
+        s_ox[e] = rem - s_oy[e] * p.Wo;
+        xv[e] = cx_ok ? (unsigned)((r * p.ldx + ci0 + cq * 4) * 4) : OOB;
+        yv[e] = cy_ok ? (unsigned)((r * p.ldy + co0 + cq * 4) * 4) : OOB;
+    }
+    float4 ra[8], rb[8];
+    auto load_tile = [&](int kt, bool live) {
+        const int sx = ((kt * BKH + oyoff * p.W + oxoff + padpix) * p.ldx) * 4;
+        const int sy = (kt * BKH * p.ldy) * 4;
+        const int left = p.Npix - kt * BKH;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool mok = live & (poct * 8 + e < left);
+            const bool ok = mok & ((unsigned)(s_oy[e] + oyoff) < (unsigned)p.H) & ((unsigned)(s_ox[e] + oxoff) < (unsigned)p.W);
+            const f32x4 ta = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)(ok ? xv[e] : OOB), sx, 0));
+            const f32x4 tb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsY, (int)(mok ? yv[e] : OOB), sy, 0));
+            ra[e] = make_float4(ta.x, ta.y, ta.z, ta.w);
+            rb[e] = make_float4(tb.x, tb.y, tb.z, tb.w);
+            s_ox[e] += p.d64_ox;
+            const bool c1 = s_ox[e] >= p.Wo;
+            s_ox[e] -= c1 ? p.Wo : 0;
+            s_oy[e] += p.d64_oy + (c1 ? 1 : 0);
+            s_oy[e] -= (s_oy[e] >= p.Ho) ? p.Ho : 0;
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char* da = lds + buf * 2 * TILEB + (cq * 4) * ROWB + poct * 16;
+        char* db = da + TILEB;
+        *reinterpret_cast<uint4*>(da + 0 * ROWB) = make_uint4(pack_bf16(ra[0].x, ra[1].x), pack_bf16(ra[2].x, ra[3].x), pack_bf16(ra[4].x, ra[5].x), pack_bf16(ra[6].x, ra[7].x));
+        *reinterpret_cast<uint4*>(da + 1 * ROWB) = make_uint4(pack_bf16(ra[0].y, ra[1].y), pack_bf16(ra[2].y, ra[3].y), pack_bf16(ra[4].y, ra[5].y), pack_bf16(ra[6].y, ra[7].y));
+        *reinterpret_cast<uint4*>(da + 2 * ROWB) = make_uint4(pack_bf16(ra[0].z, ra[1].z), pack_bf16(ra[2].z, ra[3].z), pack_bf16(ra[4].z, ra[5].z), pack_bf16(ra[6].z, ra[7].z));
+        *reinterpret_cast<uint4*>(da + 3 * ROWB) = make_uint4(pack_bf16(ra[0].w, ra[1].w), pack_bf16(ra[2].w, ra[3].w), pack_bf16(ra[4].w, ra[5].w), pack_bf16(ra[6].w, ra[7].w));
+        *reinterpret_cast<uint4*>(db + 0 * ROWB) = make_uint4(pack_bf16(rb[0].x, rb[1].x), pack_bf16(rb[2].x, rb[3].x), pack_bf16(rb[4].x, rb[5].x), pack_bf16(rb[6].x, rb[7].x));
+        *reinterpret_cast<uint4*>(db + 1 * ROWB) = make_uint4(pack_bf16(rb[0].y, rb[1].y), pack_bf16(rb[2].y, rb[3].y), pack_bf16(rb[4].y, rb[5].y), pack_bf16(rb[6].y, rb[7].y));
+        *reinterpret_cast<uint4*>(db + 2 * ROWB) = make_uint4(pack_bf16(rb[0].z, rb[1].z), pack_bf16(rb[2].z, rb[3].z), pack_bf16(rb[4].z, rb[5].z), pack_bf16(rb[6].z, rb[7].z));
+        *reinterpret_cast<uint4*>(db + 3 * ROWB) = make_uint4(pack_bf16(rb[0].w, rb[1].w), pack_bf16(rb[2].w, rb[3].w), pack_bf16(rb[4].w, rb[5].w), pack_bf16(rb[6].w, rb[7].w));
+        if (do_bias) {          // exact fp32 column sums of dy, as in the fp32 loop (workgroup-uniform branch)
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { bsum.x += rb[e].x; bsum.y += rb[e].y; bsum.z += rb[e].z; bsum.w += rb[e].w; }
+        }
+    };
+    if (kt_begin >= kt_end) return;
+    load_tile(kt_begin, true);
+    store_tile(0);
+    __syncthreads();
+    int buf = 0;
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        load_tile(kt + 1, (kt + 1) < kt_end);
+        __builtin_amdgcn_sched_barrier(0);
+        const char* As = lds + buf * 2 * TILEB;
+        const char* Bs = As + TILEB;
+#pragma unroll
+        for (int ks = 0; ks < BKH / 16; ++ks) {
+            bf16x8 fa[2], fb[2];
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+                fa[mb] = *reinterpret_cast<const bf16x8*>(As + (wrow + mb * 32 + l31) * ROWB + ks * 32 + half * 16);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+                fb[nb] = *reinterpret_cast<const bf16x8*>(Bs + (wcol + nb * 32 + l31) * ROWB + ks * 32 + half * 16);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mb], fb[nb], acc[mb][nb], 0, 0, 0);
+        }
+        store_tile(buf ^ 1);
+        __syncthreads();
+        buf ^= 1;
+    }
 }
 
 // NARROW: 128 x 32 tile for Cout <= 32 (the 3-channel image conv).  FLAT: for thin inputs (Cin = 3 stems,
@@ -771,12 +866,13 @@ __device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned shr) {
 // addressed as  per-thread constant voffset + per-k-tile SCALAR soffset; the only per-row vector work left is
 // the halo test on an incrementally advanced (oy, ox).  (The generic loader spends ~35 VALU per row per k-tile
 // on index arithmetic, which -- not the matrix pipe -- paced groups 0-1 of the k-loop: s_memtime trace.)
-template <bool VEC, bool NARROW, bool FLAT, bool S1 = false>
+template <bool VEC, bool NARROW, bool FLAT, bool S1 = false, bool BF16 = false>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
     constexpr int MB = NARROW ? 1 : 2;
     constexpr int NB = NARROW ? 1 : 2;
     constexpr int BNT = NARROW ? 32 : BN;
-    __shared__ __attribute__((aligned(16))) float smem[2][2 * BK * LDKN];
+    constexpr int SMEM_HALF = BF16 ? (2 * TILEB / 4) : (2 * BK * LDKN);      // floats per buffer of the operand ring
+    __shared__ __attribute__((aligned(16))) float smem[2][SMEM_HALF];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -801,6 +897,22 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
     const __amdgpu_buffer_rsrc_t rsY = make_rsrc(p.DY, p.y_bytes);
     const bool cx_ok = VEC ? (ci0 + q < p.C) : true;
     const bool cy_ok = (VEC ? (co0 + q < p.K) : true) & (q < BNT);
+    // fused bias gradient: the row-tile-0 workgroups also sum the dy tile they stage anyway
+    const bool do_bias = (p.DB != nullptr) && (mt == 0);
+    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
+    f32x16 acc[MB][NB];
+#pragma unroll
+    for (int i = 0; i < MB; ++i)
+#pragma unroll
+        for (int j = 0; j < NB; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if constexpr (BF16) {
+        static_assert(S1 && VEC && !NARROW && !FLAT, "the bf16 pixel loop exists for the stride-1 128x128 variant");
+        wg_mainloop_bf16(p, reinterpret_cast<char*>(&smem[0][0]), acc, ci0, co0, oyoff, oxoff, kt_begin, kt_end, tid,
+                         wrow, wcol, l31, half, do_bias, bsum);
+    } else {
     float4 ra[4], rb[4];
     // FLAT: this thread's 4 tile rows are 4 (tap, ci) pairs, fixed for the whole pixel loop
     int f_oy[4], f_ox[4], f_ci[4];
@@ -889,9 +1001,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) load_part(kt, i, true);
     };
-    // fused bias gradient: the row-tile-0 workgroups also sum the dy tile they stage anyway
-    const bool do_bias = (p.DB != nullptr) && (mt == 0);
-    float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
     auto store_tiles = [&](int buf) {
         float* As = smem[buf];
         float* Bs = smem[buf] + BK * LDKN;
@@ -913,14 +1022,6 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
             bsum.x += rb[i].x; bsum.y += rb[i].y; bsum.z += rb[i].z; bsum.w += rb[i].w;
         }
     };
-
-    f32x16 acc[MB][NB];
-#pragma unroll
-    for (int i = 0; i < MB; ++i)
-#pragma unroll
-        for (int j = 0; j < NB; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     // LDS -> register fragments of k-step kk; both operands are k-major: lane half h takes k = kk*8+4h+j
     auto load_frag = [&](const float* As, const float* Bs, int kk, float (&fa)[MB][4], float (&fb)[NB][4]) {
@@ -1000,6 +1101,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
             buf ^= 1;
         }
     }
+
+    }   // fp32 pixel loop
 
     // ---- epilogue: dw rows are (wtap*C + ci), cols co; staged through LDS for 16-byte stores ----
     const long wsize = (long)p.wrows * p.K;
@@ -1336,6 +1439,12 @@ static void plan_dgrad_s2(const DpigConvDesc* d, int pt, int pl, S2Plan* sp, int
 }
 }  // namespace dpig
 
+// shape conditions of the stride-1 SAME wgrad variant (pointer alignment is checked at launch)
+static bool wgrad_s1_shape(const DpigConvDesc* d, int pt, int pl, int Ho, int Wo) {
+    return d->stride == 1 && !d->upsample2x && d->K > 32 && !(d->C < 32 && d->R * d->S > 1) && Ho == d->H && Wo == d->W &&
+           pt >= 0 && pl >= 0 && d->ldx % 4 == 0 && d->ldy % 4 == 0 && d->C % 4 == 0 && d->K % 4 == 0;
+}
+
 extern "C" size_t dpig_conv2d_workspace_bytes(const DpigConvDesc* d, int which) {
     int pt, pl, Ho, Wo;
     if (resolve_desc(d, &pt, &pl, &Ho, &Wo)) return 0;
@@ -1375,8 +1484,14 @@ extern "C" size_t dpig_conv2d_workspace_bytes(const DpigConvDesc* d, int which) 
         const bool flat = !d->upsample2x && d->C < 32 && d->R * d->S > 1;
         const int tiles = (flat ? cdiv((long)d->R * d->S * d->C, BM) : d->R * d->S * cdiv(d->C, BM)) *
                           cdiv(d->K, d->K <= 32 ? 32 : BN);
-        Plan pln = plan_split(tiles, cdiv(Npix, BK), d->split_k);
-        return pln.nsplit > 1 ? (size_t)pln.nsplit * ((size_t)d->R * d->S * d->C * d->K + d->K) * sizeof(float) : 0;
+        size_t best = 0;
+        const int bkmax = (d->compute == DPIG_COMPUTE_BF16 && wgrad_s1_shape(d, pt, pl, Ho, Wo)) ? BKH : BK;
+        for (int bk = BK; bk <= bkmax; bk += BK) {
+            Plan pln = plan_split(tiles, cdiv(Npix, bk), d->split_k);
+            const size_t b = pln.nsplit > 1 ? (size_t)pln.nsplit * ((size_t)d->R * d->S * d->C * d->K + d->K) * sizeof(float) : 0;
+            if (b > best) best = b;
+        }
+        return best;
     }
     return 0;
 }
@@ -1523,9 +1638,14 @@ extern "C" int dpig_conv2d_wgrad(const DpigConvDesc* d, const float* x, const fl
     p.wrows = d->R * d->S * d->C;
     const bool narrow = d->K <= 32;
     const bool flat = !d->upsample2x && d->C < 32 && d->R * d->S > 1;
+    const bool vec = aligned16(x) && aligned16(dy) && (d->ldx % 4 == 0) && (d->ldy % 4 == 0) &&
+                     (d->C % 4 == 0) && (d->K % 4 == 0);
+    const bool s1 = vec && wgrad_s1_shape(d, pt, pl, Ho, Wo) &&
+                    ((long)p.x_bytes + (long)(p.pad_t * p.W + p.pad_l) * p.ldx * 4 < 0x7fffffffL);
+    const bool bf16 = s1 && d->compute == DPIG_COMPUTE_BF16;
     p.cblocks = cdiv(d->C, BM);
     p.ntiles = cdiv(d->K, narrow ? 32 : BN);
-    p.ktiles = cdiv(p.Npix, BK);
+    p.ktiles = cdiv(p.Npix, bf16 ? BKH : BK);
     const int tiles = (flat ? cdiv((long)p.ntaps * d->C, BM) : p.ntaps * p.cblocks) * p.ntiles;
     Plan pln = plan_split(tiles, p.ktiles, d->split_k);
     p.nsplit = pln.nsplit; p.tiles_per_split = pln.tiles_per_split;
@@ -1534,18 +1654,17 @@ extern "C" int dpig_conv2d_wgrad(const DpigConvDesc* d, const float* x, const fl
         return fail(DPIG_ENOMEM, "conv wgrad workspace too small: have %zu", ws_bytes);
     p.DB = db; p.beta_b = beta_b;
     p.bias_partial = p.partial ? p.partial + (long)p.nsplit * wsize : nullptr;
-    const bool vec = aligned16(x) && aligned16(dy) && (d->ldx % 4 == 0) && (d->ldy % 4 == 0) &&
-                     (d->C % 4 == 0) && (d->K % 4 == 0);
     p.vec_epi = (d->K % 4 == 0) && aligned16(dw) && (p.nsplit == 1 || aligned16(ws));
     p.vec_x = aligned16(x) && (d->ldx % 4 == 0) && (d->C % 4 == 0);
     p.d32_oy = (BK / p.Wo) % p.Ho;
     p.d32_ox = BK % p.Wo;
-    const bool s1 = vec && !flat && !narrow && d->stride == 1 && !d->upsample2x && p.Ho == p.H && p.Wo == p.W &&
-                    p.pad_t >= 0 && p.pad_l >= 0 && ((long)p.x_bytes + (long)(p.pad_t * p.W + p.pad_l) * p.ldx * 4 < 0x7fffffffL);
+    p.d64_oy = (BKH / p.Wo) % p.Ho;
+    p.d64_ox = BKH % p.Wo;
     dim3 grid(tiles, 1, p.nsplit), block(256);
 #define DPIG_WG(VE, NA, FL) hipLaunchKernelGGL((wgrad_kernel<VE, NA, FL>), grid, block, 0, st, p)
     if (flat) { if (narrow) DPIG_WG(false, true, true); else DPIG_WG(false, false, true); }
     else if (narrow) { if (vec) DPIG_WG(true, true, false); else DPIG_WG(false, true, false); }
+    else if (bf16) hipLaunchKernelGGL((wgrad_kernel<true, false, false, true, true>), grid, block, 0, st, p);
     else if (s1) hipLaunchKernelGGL((wgrad_kernel<true, false, false, true>), grid, block, 0, st, p);
     else { if (vec) DPIG_WG(true, false, false); else DPIG_WG(false, false, false); }
 #undef DPIG_WG

@@ -273,7 +273,7 @@ def test_thin_cout3_epilogue_and_accumulate(dev, act):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
-BF16_SHAPES = [(2, 16, 8, 32, 128, 3, 1), (2, 16, 8, 64, 128, 3, 2), (1, 12, 12, 128, 256, 3, 1), (2, 9, 7, 36, 40, 3, 1),
+BF16_SHAPES = [(2, 16, 8, 32, 128, 3, 1), (2, 24, 24, 128, 128, 3, 1), (3, 3, 3, 64, 64, 3, 1), (2, 16, 8, 64, 128, 3, 2), (1, 12, 12, 128, 256, 3, 1), (2, 9, 7, 36, 40, 3, 1),
                (2, 8, 4, 64, 128, 5, 2), (3, 6, 6, 96, 132, 1, 1), (2, 9, 7, 36, 40, 3, 2), (1, 16, 8, 200, 64, 3, 1)]
 
 
@@ -309,6 +309,17 @@ def test_conv_bf16_compute(dev, shape, split_k):
         (O.conv2d_same(xr, we, None, s) * de).sum().backward()
         dx = H.conv2d_dgrad(dy.float().to(dev), w.float().to(dev), (N, Hh, W, C), stride=s, split_k=split_k)
         _close(dx, xr.grad)
+        # wgrad multiplies x with dy (stride-1 layers with > 32 output channels); the bias gradient stays an exact
+        # fp32 column sum of dy
+        elig = s == 1 and K > 32 and not (C < 32 and k > 1)
+        xe, de = (_bf(x), _bf(dy)) if elig else (x, dy)
+        wr = w.clone().requires_grad_(True)
+        (O.conv2d_same(xe, wr, None, s) * de).sum().backward()
+        db = torch.zeros(K, device=dev)
+        dw = H.conv2d_wgrad(x.float().to(dev), dy.float().to(dev), (k, k, C, K), stride=s, split_k=split_k,
+                            out=torch.empty(k, k, C, K, device=dev), beta=0.0, db=db, db_beta=0.0)
+        _close(dw, wr.grad)
+        _close(db, dy.reshape(-1, K).sum(0))
     finally:
         H.set_compute("f32")
 
