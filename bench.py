@@ -97,6 +97,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly (no hipGraph replay)")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
+                    help="matrix-pipe arithmetic of the conv GEMMs; bf16 (fp32 tensors and accumulation) is an information "
+                         "line: the BASELINE metric is quoted at fp32")
     ap.add_argument("--workload", default="market128", choices=sorted(WORKLOADS),
                     help="market128 = the BASELINE metric (configs[1]); the others are information lines for DESIGN.md")
     args = ap.parse_args()
@@ -130,14 +133,14 @@ def main():
     import importlib
     from dpig_amd.trainer import Config
     wl_mod, wl_cls, wl_cfg, wl_batch, wl_desc = WORKLOADS[args.workload]
-    headline = args.workload == "market128"
+    headline = args.workload == "market128" and args.dtype == "f32"
     if not headline:                          # information lines: no roofline / CPU legs, eager launches
         args.no_roofline = args.no_cpu_baseline = True
-        args.no_graph = args.no_graph or args.workload != "df256"
+        args.no_graph = args.no_graph or args.workload == "market128-wgan-gp"
 
     np.random.seed(0)                         # identical initial weights on every rank (+ broadcast)
     B = args.batch or wl_batch
-    cfg = Config(batch_size=B, **wl_cfg)
+    cfg = Config(batch_size=B, compute_dtype=args.dtype, **wl_cfg)
     tr = getattr(importlib.import_module("dpig_amd." + wl_mod), wl_cls)(cfg, dev)
     batch_g = synthetic.to_device(synthetic.make_batch(B, img_H=cfg.img_H, img_W=cfg.img_W, seed=100 + 2 * rank), dev)
     batch_d = synthetic.to_device(synthetic.make_batch(B, img_H=cfg.img_H, img_W=cfg.img_W, seed=101 + 2 * rank), dev)
@@ -212,11 +215,11 @@ def main():
     if rank == 0:
         line = {
             "metric": "training images/sec (G+D step) Market-1501 128x64 bs=16" if headline else
-                      "training images/sec (%s) [information line, not the BASELINE metric]" % args.workload,
+                      "training images/sec (%s, %s) [information line, not the BASELINE metric]" % (args.workload, args.dtype),
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "%s, bs=%d per GPU, fp32" % (wl_desc, B),
+            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "%s, bs=%d per GPU, %s" % (wl_desc, B, "fp32" if args.dtype == "f32" else "bf16 matrix pipe on fp32 tensors"),
                        "global_batch": world * B, "parallelism": "dp%d" % world},
             "achieved_alg_tflops": round(ALG_GFLOP_PER_IMG * value / 1e3, 2) if headline else None,
             "losses": {k: float(v) for k, v in out.items() if hasattr(v, "numel") and v.numel() == 1},

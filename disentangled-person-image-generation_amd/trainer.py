@@ -211,6 +211,8 @@ class Config(object):
                                          # the gradient-penalty branch the reference keeps dormant
         self.data_format = 'NHWC'        # main.py:18
         self.sync_bn = False             # data parallel: D's BatchNorm statistics over all ranks
+        self.compute_dtype = 'f32'       # 'bf16': conv GEMMs on the bf16 matrix pipe (fp32 tensors / accumulation /
+                                         # master weights; BASELINE configs 3-5); 'f32' is the reference's arithmetic
         self.__dict__.update(kw)
         self.repeat_num = int(math.log2(self.img_H)) - 2    # trainer.py:75
 
@@ -277,6 +279,7 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
 
     def init_net(self, batch):
         """Create every variable (one forward, like TF graph construction) and set up optimizers."""
+        H.set_compute(getattr(self.config, "compute_dtype", "f32"))
         with torch.no_grad():
             embs, enc_var = self.encode(batch)
             G, g_var = self.generate(embs, batch["pose"])
@@ -352,6 +355,7 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
     # ---- the two optimizer ops -----------------------------------------------------------------
     def _g_optim_eager(self, batch, update=True):
         """sess.run(g_optim): fwd E,G,D(fake); g_loss = sce(D(G),1) + 20*L1; bwd D(dgrad only),G,E; Adam."""
+        H.set_compute(getattr(self.config, "compute_dtype", "f32"))
         self.G_flat.zero_grad()
         self.D_flat.set_requires_grad(False)
         embs, _ = self.encode(batch)
@@ -369,6 +373,7 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
 
     def _d_optim_eager(self, batch, update=True):
         """sess.run(d_optim): fwd E,G (no grad), D(x), D(G); d_loss; bwd D; Adam(D)."""
+        H.set_compute(getattr(self.config, "compute_dtype", "f32"))
         self.D_flat.zero_grad()
         with torch.no_grad():
             embs, _ = self.encode(batch)

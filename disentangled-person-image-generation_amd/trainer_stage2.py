@@ -17,6 +17,7 @@ import torch
 from . import models
 from . import slim
 from . import tflib as lib
+from . import hip_ops as H
 from .trainer import Config, FlatParams, GradAllReduce, clip_disc_weights, gan_loss, get_optimizers
 from .wgan_gp import WGAN_GP, LeakyReLU  # noqa: F401  (trainer.py:23 star-import: alpha 0.2)
 
@@ -43,6 +44,7 @@ class DPIG_Encoder_subSampleAppNetFgBg_GAN_BodyROI(object):
     # ---- graph pieces ------------------------------------------------------------------------------
     def encode(self, batch):
         """Frozen stage-I encoder (restored from --pretrained_path in the reference, trainer.py:180-183)."""
+        H.set_compute(getattr(self.config, "compute_dtype", "f32"))
         with torch.no_grad(), slim.variable_scope("Encoder"):
             embs, _, _, enc_var = models.GeneratorCNN_ID_Encoder_BodyROIVis_FgBgFeaTwoBranch(
                 batch["x"], batch["mask_r6"], batch["part_bbox"], batch["part_vis"], self.part_num, 32,

@@ -281,3 +281,48 @@ def test_pose_fc_autoencoder(dev):
         if grads[n] is not None:
             assert _rel(lib._params[n].grad, grads[n]) < 2e-3, n
     lib.delete_all_params()
+
+
+def test_stage1_bf16_compute_mode(dev):
+    """Config(compute_dtype='bf16') (BASELINE configs 3-5): conv GEMMs on the bf16 matrix pipe, fp32 tensors /
+    accumulation / master weights.  Embedding, generator output and losses stay within bf16 operand rounding of the
+    fp64 oracle (8 mantissa bits per operand, averaged over the reduction), a training step runs, and fp32 mode is
+    untouched afterwards."""
+    import dpig_amd.hip_ops as H
+    import dpig_amd.tflib as lib
+    from dpig_amd import slim, synthetic
+    from dpig_amd.trainer import Config, DPIG_Encoder_GAN_BodyROI_FgBg
+    from oracle import models as OM
+    lib.delete_all_params(); slim.reset_scopes()
+    B, HID, ZN = 2, 64, 16
+    np.random.seed(0)
+    batch_np = synthetic.make_batch(B, seed=31)
+    ob = OM.batch_to_torch(batch_np)
+    P = OM.ParamStore(seed=12)
+    with torch.no_grad():
+        OM.stage1_g_loss(P, ob, hidden_num=HID, z_num=ZN)
+        OM.stage1_d_loss(P, ob, hidden_num=HID, z_num=ZN)
+    lib.set_device(dev)
+    for n, v in P.state_numpy().items():
+        lib.param(n, v, trainable=P.trainable[n])
+    tr = DPIG_Encoder_GAN_BodyROI_FgBg(Config(batch_size=B, conv_hidden_num=HID, z_num=ZN, compute_dtype='bf16'), dev)
+    batch = synthetic.to_device(batch_np, dev)
+    try:
+        tr.init_net(batch)
+        assert H.get_compute() == "bf16"
+        with torch.no_grad():
+            embs_o, G_o = OM.stage1_forward(P, ob, hidden_num=HID, z_num=ZN)
+            embs, _ = tr.encode(batch)
+            G, _ = tr.generate(embs, batch["pose"])
+        rel = lambda a, b: (a.double().cpu() - b.double()).abs().max().item() / max(b.abs().max().item(), 1e-12)
+        assert 1e-6 < rel(embs, embs_o) < 3e-2          # (> 1e-6: the bf16 pipe really was used)
+        assert rel(G, G_o) < 5e-2
+        gl_o, _ = OM.stage1_g_loss(P, ob, hidden_num=HID, z_num=ZN)
+        tr.step = 1
+        w0 = tr.G_flat.flat.detach().clone()
+        out = tr.train_step(batch, batch)
+        assert abs(float(out["g_loss"]) - float(gl_o)) < 5e-2 * abs(float(gl_o))
+        assert all(np.isfinite(float(v)) for v in out.values() if hasattr(v, "numel") and v.numel() == 1)
+        assert float((tr.G_flat.flat - w0).abs().max()) > 0
+    finally:
+        H.set_compute("f32")
