@@ -757,7 +757,7 @@ struct WGParams {
     float* DB; float* bias_partial; float beta_b;  // fused bias gradient: db[co] = sum_pixels dy[., co]
     int vec_x;                                     // 1: x alone is 16-byte loadable (Cout = 3: dy is not)
     int d32_oy, d32_ox;                            // S1: (row, col) advance of a pixel index step of BK = 32
-    int d64_oy, d64_ox;                            //     ... and of the bf16 loop's 64
+    int d64_oy, d64_ox, d64_n;                     //     ... and of the bf16 loop's 64 (+ whole images, generic variant)
 };
 
 // n / d for 0 <= n < 2^31 with a precomputed (mul, shr); mul == 0 encodes d == 1
@@ -770,15 +770,16 @@ __device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned shr) {
 // lane: each thread loads an 8(pixel) x 4(channel) patch of x and of dy with the scalar-offset addressing of the
 // S1 loader and transposes it in registers into four 16-byte LDS rows per operand; fragments are then plain
 // ds_read_b128 (the fp32 loop needs 4-byte LDS reads here).  k-tile = 64 pixels.
+template <bool GEN>   // GEN: any stride / the upsampled 1x1 (x offset computed per pixel); else stride-1 SAME (scalar offsets)
 __device__ __forceinline__ void wg_mainloop_bf16(const WGParams& p, char* lds, f32x16 (&acc)[2][2], int ci0, int co0,
                                                  int oyoff, int oxoff, int kt_begin, int kt_end, int tid, int wrow,
                                                  int wcol, int l31, int half, bool do_bias, float4& bsum) {
     const int cq = tid & 31, poct = tid >> 5;                  // 4 channels x 8 pixels per thread
-    const int padpix = p.pad_t * p.W + p.pad_l;
+    const int padpix = GEN ? 0 : p.pad_t * p.W + p.pad_l;
     const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.X - (long)padpix * p.ldx, p.x_bytes + (unsigned)(padpix * p.ldx * 4));
     const __amdgpu_buffer_rsrc_t rsY = make_rsrc(p.DY, p.y_bytes);
     const bool cx_ok = ci0 + cq * 4 < p.C, cy_ok = co0 + cq * 4 < p.K;
-    int s_oy[8], s_ox[8];
+    int s_oy[8], s_ox[8], s_n[8];
     unsigned xv[8], yv[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -786,6 +787,7 @@ __device__ __forceinline__ void wg_mainloop_bf16(const WGParams& p, char* lds, f
         const int m = kt_begin * BKH + r;
         const int n = fast_div(m, p.mul_howo, p.shr_howo);
         const int rem = m - n * p.HoWo;
+        s_n[e] = n;
         s_oy[e] = fast_div(rem, p.mul_wo, p.shr_wo);
         s_ox[e] = rem - s_oy[e] * p.Wo;
         xv[e] = cx_ok ? (unsigned)((r * p.ldx + ci0 + cq * 4) * 4) : OOB;
@@ -799,8 +801,17 @@ __device__ __forceinline__ void wg_mainloop_bf16(const WGParams& p, char* lds, f
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const bool mok = live & (poct * 8 + e < left);
-            const bool ok = mok & ((unsigned)(s_oy[e] + oyoff) < (unsigned)p.H) & ((unsigned)(s_ox[e] + oxoff) < (unsigned)p.W);
-            const f32x4 ta = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)(ok ? xv[e] : OOB), sx, 0));
+            f32x4 ta;
+            if (GEN) {
+                const int py = s_oy[e] * p.s + oyoff, px = s_ox[e] * p.s + oxoff;
+                const int iy = py >> p.shift, ix = px >> p.shift;
+                const bool ok = mok & cx_ok & (py >= 0) & (px >= 0) & (iy < p.H) & (ix < p.W);
+                const unsigned xo = (unsigned)((((s_n[e] * p.H + iy) * p.W + ix) * p.ldx + ci0 + cq * 4) * 4);
+                ta = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)(ok ? xo : OOB), 0, 0));
+            } else {
+                const bool ok = mok & ((unsigned)(s_oy[e] + oyoff) < (unsigned)p.H) & ((unsigned)(s_ox[e] + oxoff) < (unsigned)p.W);
+                ta = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)(ok ? xv[e] : OOB), sx, 0));
+            }
             const f32x4 tb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsY, (int)(mok ? yv[e] : OOB), sy, 0));
             ra[e] = make_float4(ta.x, ta.y, ta.z, ta.w);
             rb[e] = make_float4(tb.x, tb.y, tb.z, tb.w);
@@ -808,7 +819,9 @@ __device__ __forceinline__ void wg_mainloop_bf16(const WGParams& p, char* lds, f
             const bool c1 = s_ox[e] >= p.Wo;
             s_ox[e] -= c1 ? p.Wo : 0;
             s_oy[e] += p.d64_oy + (c1 ? 1 : 0);
-            s_oy[e] -= (s_oy[e] >= p.Ho) ? p.Ho : 0;
+            const bool c2 = s_oy[e] >= p.Ho;
+            s_oy[e] -= c2 ? p.Ho : 0;
+            if (GEN) s_n[e] += p.d64_n + (c2 ? 1 : 0);
         }
     };
     auto store_tile = [&](int buf) {
@@ -909,8 +922,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     if constexpr (BF16) {
-        static_assert(S1 && VEC && !NARROW && !FLAT, "the bf16 pixel loop exists for the stride-1 128x128 variant");
-        wg_mainloop_bf16(p, reinterpret_cast<char*>(&smem[0][0]), acc, ci0, co0, oyoff, oxoff, kt_begin, kt_end, tid,
+        static_assert(VEC && !NARROW && !FLAT, "the bf16 pixel loop exists for the 16-byte loadable 128x128 variant");
+        wg_mainloop_bf16<!S1>(p, reinterpret_cast<char*>(&smem[0][0]), acc, ci0, co0, oyoff, oxoff, kt_begin, kt_end, tid,
                          wrow, wcol, l31, half, do_bias, bsum);
     } else {
     float4 ra[4], rb[4];
@@ -1485,7 +1498,8 @@ extern "C" size_t dpig_conv2d_workspace_bytes(const DpigConvDesc* d, int which) 
         const int tiles = (flat ? cdiv((long)d->R * d->S * d->C, BM) : d->R * d->S * cdiv(d->C, BM)) *
                           cdiv(d->K, d->K <= 32 ? 32 : BN);
         size_t best = 0;
-        const int bkmax = (d->compute == DPIG_COMPUTE_BF16 && wgrad_s1_shape(d, pt, pl, Ho, Wo)) ? BKH : BK;
+        const bool bf_shape = d->K > 32 && !flat && d->ldx % 4 == 0 && d->ldy % 4 == 0 && d->C % 4 == 0 && d->K % 4 == 0;
+        const int bkmax = (d->compute == DPIG_COMPUTE_BF16 && bf_shape) ? BKH : BK;
         for (int bk = BK; bk <= bkmax; bk += BK) {
             Plan pln = plan_split(tiles, cdiv(Npix, bk), d->split_k);
             const size_t b = pln.nsplit > 1 ? (size_t)pln.nsplit * ((size_t)d->R * d->S * d->C * d->K + d->K) * sizeof(float) : 0;
@@ -1642,7 +1656,7 @@ extern "C" int dpig_conv2d_wgrad(const DpigConvDesc* d, const float* x, const fl
                      (d->C % 4 == 0) && (d->K % 4 == 0);
     const bool s1 = vec && wgrad_s1_shape(d, pt, pl, Ho, Wo) &&
                     ((long)p.x_bytes + (long)(p.pad_t * p.W + p.pad_l) * p.ldx * 4 < 0x7fffffffL);
-    const bool bf16 = s1 && d->compute == DPIG_COMPUTE_BF16;
+    const bool bf16 = vec && !flat && !narrow && d->compute == DPIG_COMPUTE_BF16;
     p.cblocks = cdiv(d->C, BM);
     p.ntiles = cdiv(d->K, narrow ? 32 : BN);
     p.ktiles = cdiv(p.Npix, bf16 ? BKH : BK);
@@ -1658,13 +1672,15 @@ extern "C" int dpig_conv2d_wgrad(const DpigConvDesc* d, const float* x, const fl
     p.vec_x = aligned16(x) && (d->ldx % 4 == 0) && (d->C % 4 == 0);
     p.d32_oy = (BK / p.Wo) % p.Ho;
     p.d32_ox = BK % p.Wo;
-    p.d64_oy = (BKH / p.Wo) % p.Ho;
-    p.d64_ox = BKH % p.Wo;
+    p.d64_n = BKH / p.HoWo;
+    p.d64_oy = (BKH % p.HoWo) / p.Wo;
+    p.d64_ox = (BKH % p.HoWo) % p.Wo;
     dim3 grid(tiles, 1, p.nsplit), block(256);
 #define DPIG_WG(VE, NA, FL) hipLaunchKernelGGL((wgrad_kernel<VE, NA, FL>), grid, block, 0, st, p)
     if (flat) { if (narrow) DPIG_WG(false, true, true); else DPIG_WG(false, false, true); }
     else if (narrow) { if (vec) DPIG_WG(true, true, false); else DPIG_WG(false, true, false); }
-    else if (bf16) hipLaunchKernelGGL((wgrad_kernel<true, false, false, true, true>), grid, block, 0, st, p);
+    else if (bf16 && s1) hipLaunchKernelGGL((wgrad_kernel<true, false, false, true, true>), grid, block, 0, st, p);
+    else if (bf16) hipLaunchKernelGGL((wgrad_kernel<true, false, false, false, true>), grid, block, 0, st, p);
     else if (s1) hipLaunchKernelGGL((wgrad_kernel<true, false, false, true>), grid, block, 0, st, p);
     else { if (vec) DPIG_WG(true, false, false); else DPIG_WG(false, false, false); }
 #undef DPIG_WG

@@ -309,9 +309,9 @@ def test_conv_bf16_compute(dev, shape, split_k):
         (O.conv2d_same(xr, we, None, s) * de).sum().backward()
         dx = H.conv2d_dgrad(dy.float().to(dev), w.float().to(dev), (N, Hh, W, C), stride=s, split_k=split_k)
         _close(dx, xr.grad)
-        # wgrad multiplies x with dy (stride-1 layers with > 32 output channels); the bias gradient stays an exact
+        # wgrad multiplies x with dy (layers with > 32 output channels and >= 32 input channels); the bias gradient stays an exact
         # fp32 column sum of dy
-        elig = s == 1 and K > 32 and not (C < 32 and k > 1)
+        elig = K > 32 and not (C < 32 and k > 1)
         xe, de = (_bf(x), _bf(dy)) if elig else (x, dy)
         wr = w.clone().requires_grad_(True)
         (O.conv2d_same(xe, wr, None, s) * de).sum().backward()
@@ -320,6 +320,31 @@ def test_conv_bf16_compute(dev, shape, split_k):
                             out=torch.empty(k, k, C, K, device=dev), beta=0.0, db=db, db_beta=0.0)
         _close(dw, wr.grad)
         _close(db, dy.reshape(-1, K).sum(0))
+    finally:
+        H.set_compute("f32")
+
+
+def test_conv_upsample_fused_bf16(dev):
+    """The upsample-commuted 1x1 conv (fwd with 2x2 replication, 4-tap dgrad, source-shift wgrad) on the bf16 pipe."""
+    import dpig_amd.hip_ops as H
+    from oracle import ops as O
+    N, Hh, W, C, K = 2, 8, 4, 96, 64
+    x = _rand((N, Hh, W, C), 1)
+    w = _rand((1, 1, C, K), 2) * 0.3
+    b = _rand((K,), 3)
+    xb, wb = _bf(x), _bf(w)
+    ref = O.relu(O.conv2d_same(O.upsample2x(xb), wb, b, 1))
+    dy = _rand(tuple(ref.shape), 5)
+    dyb = _bf(dy)
+    H.set_compute("bf16")
+    try:
+        _close(H.conv2d_fwd(x.float().to(dev), w.float().to(dev), b.float().to(dev), act=1, upsample2x=True), ref)
+        xr = x.clone().requires_grad_(True)
+        (O.conv2d_same(O.upsample2x(xr), wb, None, 1) * dyb).sum().backward()
+        _close(H.conv2d_dgrad(dy.float().to(dev), w.float().to(dev), (N, Hh, W, C), upsample2x=True), xr.grad)
+        wr = w.clone().requires_grad_(True)
+        (O.conv2d_same(O.upsample2x(xb), wr, None, 1) * dyb).sum().backward()
+        _close(H.conv2d_wgrad(x.float().to(dev), dy.float().to(dev), (1, 1, C, K), upsample2x=True), wr.grad)
     finally:
         H.set_compute("f32")
 
