@@ -292,29 +292,41 @@ __device__ __forceinline__ void gg_mainloop_bf16(const GGParams& p, char* lds, f
     store_tile(0);
     __syncthreads();
     int buf = 0;
+    bf16x8 fa[2][2], fb[2][2];                              // [k-step parity][32-row / 32-col block]
+    auto load_frag = [&](int b, int ks, bf16x8 (&a)[2], bf16x8 (&bb)[2]) {
+        const char* As = lds + b * 2 * TILEB;
+        const char* Bs = As + TILEB;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+            a[mb] = *reinterpret_cast<const bf16x8*>(As + (wrow + mb * 32 + l31) * ROWB + ks * 32 + half * 16);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+            bb[nb] = *reinterpret_cast<const bf16x8*>(Bs + (wcol + nb * 32 + l31) * ROWB + ks * 32 + half * 16);
+    };
+    load_frag(0, 0, fa[0], fb[0]);
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const bool more = (kt + 1) < kt_end;
         load_tile(more);                                   // tile t+1 in flight under this tile's MFMAs
         __builtin_amdgcn_sched_barrier(0);
-        const char* As = lds + buf * 2 * TILEB;
-        const char* Bs = As + TILEB;
 #pragma unroll
         for (int ks = 0; ks < BKH / 16; ++ks) {
-            bf16x8 fa[2], fb[2];
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-                fa[mb] = *reinterpret_cast<const bf16x8*>(As + (wrow + mb * 32 + l31) * ROWB + ks * 32 + half * 16);
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-                fb[nb] = *reinterpret_cast<const bf16x8*>(Bs + (wcol + nb * 32 + l31) * ROWB + ks * 32 + half * 16);
+            if (ks + 1 < BKH / 16) {
+                load_frag(buf, ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);    // fragments of the next k-step
+            } else {
+                // last k-step: publish tile t+1 first (its loads have had three k-steps to land), then request the
+                // first fragments of t+1; the 4 MFMAs below cover the barrier and the LDS latency
+                store_tile(buf ^ 1);                        // (zeros after the last tile: nobody reads them)
+                __syncthreads();
+                load_frag(buf ^ 1, 0, fa[0], fb[0]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb)
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mb], fb[nb], acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][mb], fb[ks & 1][nb], acc[mb][nb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        store_tile(buf ^ 1);                                // (zeros after the last tile: nobody reads them)
-        __syncthreads();
         buf ^= 1;
     }
 }
@@ -846,28 +858,38 @@ __device__ __forceinline__ void wg_mainloop_bf16(const WGParams& p, char* lds, f
     store_tile(0);
     __syncthreads();
     int buf = 0;
+    bf16x8 fa[2][2], fb[2][2];
+    auto load_frag = [&](int b, int ks, bf16x8 (&a)[2], bf16x8 (&bb)[2]) {
+        const char* As = lds + b * 2 * TILEB;
+        const char* Bs = As + TILEB;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+            a[mb] = *reinterpret_cast<const bf16x8*>(As + (wrow + mb * 32 + l31) * ROWB + ks * 32 + half * 16);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+            bb[nb] = *reinterpret_cast<const bf16x8*>(Bs + (wcol + nb * 32 + l31) * ROWB + ks * 32 + half * 16);
+    };
+    load_frag(0, 0, fa[0], fb[0]);
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         load_tile(kt + 1, (kt + 1) < kt_end);
         __builtin_amdgcn_sched_barrier(0);
-        const char* As = lds + buf * 2 * TILEB;
-        const char* Bs = As + TILEB;
 #pragma unroll
         for (int ks = 0; ks < BKH / 16; ++ks) {
-            bf16x8 fa[2], fb[2];
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-                fa[mb] = *reinterpret_cast<const bf16x8*>(As + (wrow + mb * 32 + l31) * ROWB + ks * 32 + half * 16);
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
-                fb[nb] = *reinterpret_cast<const bf16x8*>(Bs + (wcol + nb * 32 + l31) * ROWB + ks * 32 + half * 16);
+            if (ks + 1 < BKH / 16) {
+                load_frag(buf, ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+            } else {                                       // same hand-over as gg_mainloop_bf16
+                store_tile(buf ^ 1);
+                __syncthreads();
+                load_frag(buf ^ 1, 0, fa[0], fb[0]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb)
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[mb], fb[nb], acc[mb][nb], 0, 0, 0);
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][mb], fb[ks & 1][nb], acc[mb][nb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        store_tile(buf ^ 1);
-        __syncthreads();
         buf ^= 1;
     }
 }
