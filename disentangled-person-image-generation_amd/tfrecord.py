@@ -1,0 +1,243 @@
+"""TensorFlow-free reader of the reference's training records (second half of the input-pipeline row).
+
+The reference feeds the trainer from TFRecord files of `tf.train.Example` protos written by
+`datasets/convert_market.py` and declared in `datasets/market1501.py:79-141`; decoding, batching and the pose-map
+rasterisation happen inside the TF graph (`trainer.py:537-564`).  This module restates the two public formats --
+the TFRecord framing (length, masked CRC32C of the length, payload, masked CRC32C of the payload) and the protobuf
+wire encoding of `Example{Features{map<string, Feature{BytesList|FloatList|Int64List}>}}` -- in plain Python/numpy,
+and assembles the batch dict the trainers consume (`synthetic.make_batch` has the same keys), with the pose maps
+rasterised on the device by `dpig_pose_rasterize`.
+
+Nothing here touches TensorFlow.  A writer is included so that tests (and users without the dataset) can
+produce records; files written by TensorFlow use exactly this framing and wire format.
+"""
+import io
+import struct
+
+import numpy as np
+
+# ---- CRC32C (Castagnoli), reflected, table driven; TFRecord masks it: rot-right 15, + 0xa282ead8 -----------------
+_POLY = 0x82F63B78
+_TABLE = []
+for _i in range(256):
+    _c = _i
+    for _ in range(8):
+        _c = (_c >> 1) ^ _POLY if _c & 1 else _c >> 1
+    _TABLE.append(_c)
+_TABLE = np.array(_TABLE, dtype=np.uint32)
+
+
+def crc32c(data):
+    crc = 0xFFFFFFFF
+    tab = _TABLE
+    for b in bytes(data):
+        crc = int(tab[(crc ^ b) & 0xFF]) ^ (crc >> 8)
+    return crc ^ 0xFFFFFFFF
+
+
+def masked_crc32c(data):
+    crc = crc32c(data)
+    return (((crc >> 15) | (crc << 17)) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+# ---- TFRecord framing ----------------------------------------------------------------------------------------
+def read_records(path_or_file, check_crc=True):
+    """Yield the payload of every record of a TFRecord file."""
+    f = open(path_or_file, "rb") if isinstance(path_or_file, str) else path_or_file
+    try:
+        while True:
+            head = f.read(12)
+            if not head:
+                return
+            if len(head) != 12:
+                raise IOError("truncated TFRecord header")
+            length, lcrc = struct.unpack("<QI", head)
+            if check_crc and masked_crc32c(head[:8]) != lcrc:
+                raise IOError("TFRecord length CRC mismatch")
+            data = f.read(length)
+            tail = f.read(4)
+            if len(data) != length or len(tail) != 4:
+                raise IOError("truncated TFRecord payload")
+            if check_crc and masked_crc32c(data) != struct.unpack("<I", tail)[0]:
+                raise IOError("TFRecord payload CRC mismatch")
+            yield data
+    finally:
+        if isinstance(path_or_file, str):
+            f.close()
+
+
+def write_records(path_or_file, payloads):
+    f = open(path_or_file, "wb") if isinstance(path_or_file, str) else path_or_file
+    try:
+        for data in payloads:
+            head = struct.pack("<Q", len(data))
+            f.write(head + struct.pack("<I", masked_crc32c(head)) + data + struct.pack("<I", masked_crc32c(data)))
+    finally:
+        if isinstance(path_or_file, str):
+            f.close()
+
+
+# ---- protobuf wire format (the subset tf.train.Example uses) ----------------------------------------------------
+def _varint(buf, pos):
+    out = shift = 0
+    while True:
+        b = buf[pos]
+        pos += 1
+        out |= (b & 0x7F) << shift
+        if not b & 0x80:
+            return out, pos
+        shift += 7
+
+
+def _fields(buf):
+    """Yield (field number, wire type, value) of one message; value is an int (varint / fixed) or a memoryview."""
+    pos, n = 0, len(buf)
+    while pos < n:
+        key, pos = _varint(buf, pos)
+        num, wt = key >> 3, key & 7
+        if wt == 0:
+            val, pos = _varint(buf, pos)
+        elif wt == 1:
+            val = bytes(buf[pos:pos + 8]); pos += 8
+        elif wt == 2:
+            ln, pos = _varint(buf, pos)
+            val = buf[pos:pos + ln]; pos += ln
+        elif wt == 5:
+            val = bytes(buf[pos:pos + 4]); pos += 4
+        else:
+            raise ValueError("unsupported protobuf wire type %d" % wt)
+        yield num, wt, val
+
+
+def _signed64(v):
+    return v - (1 << 64) if v >= (1 << 63) else v
+
+
+def parse_example(payload):
+    """tf.train.Example -> {name: list of bytes | np.float32 array | np.int64 array}."""
+    out = {}
+    buf = memoryview(payload)
+    for num, wt, features in _fields(buf):
+        if num != 1 or wt != 2:
+            continue
+        for fnum, fwt, entry in _fields(features):                 # map<string, Feature> entries
+            if fnum != 1 or fwt != 2:
+                continue
+            name, feat = None, None
+            for enum, ewt, val in _fields(entry):
+                if enum == 1:
+                    name = bytes(val).decode("utf-8")
+                elif enum == 2:
+                    feat = val
+            if name is None:
+                continue
+            value = []
+            for knum, kwt, lst in _fields(feat if feat is not None else b""):
+                if knum == 1:                                        # BytesList
+                    value = [bytes(v) for n_, w_, v in _fields(lst) if n_ == 1]
+                elif knum == 2:                                      # FloatList: packed or repeated fixed32
+                    vals = []
+                    for n_, w_, v in _fields(lst):
+                        if n_ != 1:
+                            continue
+                        vals.append(np.frombuffer(bytes(v), dtype="<f4") if w_ == 2 else np.frombuffer(v, dtype="<f4"))
+                    value = np.concatenate(vals).astype(np.float32) if vals else np.zeros(0, np.float32)
+                elif knum == 3:                                      # Int64List: packed or repeated varint
+                    vals = []
+                    for n_, w_, v in _fields(lst):
+                        if n_ != 1:
+                            continue
+                        if w_ == 2:
+                            pos, m = 0, len(v)
+                            while pos < m:
+                                x, pos = _varint(v, pos)
+                                vals.append(_signed64(x))
+                        else:
+                            vals.append(_signed64(v))
+                    value = np.array(vals, dtype=np.int64)
+            out[name] = value
+    return out
+
+
+def _enc_varint(v):
+    v &= (1 << 64) - 1
+    out = bytearray()
+    while True:
+        b = v & 0x7F
+        v >>= 7
+        out.append(b | (0x80 if v else 0))
+        if not v:
+            return bytes(out)
+
+
+def _ld(num, data):
+    return _enc_varint((num << 3) | 2) + _enc_varint(len(data)) + data
+
+
+def encode_example(features):
+    """{name: bytes | list of bytes | float array | int array} -> serialized tf.train.Example (packed lists)."""
+    entries = b""
+    for name in sorted(features):
+        v = features[name]
+        if isinstance(v, (bytes, bytearray)):
+            v = [bytes(v)]
+        if isinstance(v, list) and (not v or isinstance(v[0], (bytes, bytearray))):
+            feat = _ld(1, b"".join(_ld(1, bytes(b)) for b in v))
+        else:
+            a = np.asarray(v)
+            if a.dtype.kind == "f":
+                feat = _ld(2, _ld(1, a.astype("<f4").tobytes()))
+            else:
+                feat = _ld(3, _ld(1, b"".join(_enc_varint(int(x)) for x in a.reshape(-1))))
+        entries += _ld(1, _ld(1, name.encode("utf-8")) + _ld(2, feat))
+    return _ld(1, entries)
+
+
+# ---- the reference's record schema (datasets/market1501.py:79-141) -> trainer batch ---------------------------
+def decode_image(raw, fmt, H, W):
+    """`slim.tfexample_decoder.Image`: JPEG/PNG bytes -> uint8 [H,W,3] (format 'raw': the bytes are the pixels)."""
+    if fmt in ("raw", "RAW"):
+        return np.frombuffer(raw, dtype=np.uint8).reshape(H, W, 3)
+    from PIL import Image
+    img = np.asarray(Image.open(io.BytesIO(raw)).convert("RGB"))
+    if img.shape[:2] != (H, W):
+        raise ValueError("decoded image is %s, expected %s" % (img.shape[:2], (H, W)))
+    return img
+
+
+def decode_pair(example, which=0, img_H=128, img_W=64, part_indices=range(7)):
+    """One side (`which` = 0 source / 1 target) of a pair record as the arrays `_load_batch_pair_pose`
+    (trainer.py:537-564) produces, with the part selection of `build_model` (trainer.py:571-578)."""
+    s = str(which)
+    fmt = example.get("image_format", [b"jpg"])
+    fmt = (fmt[0] if len(fmt) else b"jpg").decode()
+    img = decode_image(example["image_raw_" + s][0], fmt, img_H, img_W)
+    nparts = len(example["part_vis_" + s])
+    bbox = np.asarray(example["part_bbox_" + s], dtype=np.int64).reshape(nparts, 4)
+    vis = np.asarray(example["part_vis_" + s], dtype=np.int64)
+    idx = list(part_indices)
+    return {
+        "x": (img.astype(np.float32) - 127.5) / 127.5,                                  # process_image(x, 127.5, 127.5)
+        "pose_rcv": np.asarray(example["pose_peaks_%s_rcv" % s], dtype=np.float32),
+        "mask_r6": np.asarray(example["pose_mask_r6_" + s], dtype=np.float32).reshape(img_H, img_W, 1),
+        "part_bbox": bbox[idx].astype(np.int32),
+        "part_vis": vis[idx].astype(np.float32),
+    }
+
+
+def batch_from_examples(examples, device, which=0, img_H=128, img_W=64, keypoint_num=18, part_indices=range(7)):
+    """Batch dict of device tensors with the keys of `synthetic.make_batch` / `synthetic.to_device`; the [B,H,W,18]
+    pose target is rasterised on the device from the (row, col, visibility) triplets (is_normalized=False,
+    trainer.py:556-560)."""
+    import torch
+    from . import utils
+    items = [decode_pair(e, which, img_H, img_W, part_indices) for e in examples]
+    stack = lambda k: torch.from_numpy(np.stack([it[k] for it in items]))
+    rcv = stack("pose_rcv").to(device)
+    return {
+        "x": stack("x").to(device),
+        "pose": utils.pose_target_from_rcv(rcv, keypoint_num, False, img_H, img_W),
+        "mask_r6": stack("mask_r6").to(device),
+        "part_bbox": stack("part_bbox").to(device),
+        "part_vis": stack("part_vis").to(device),
+    }

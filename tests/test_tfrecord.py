@@ -1,0 +1,128 @@
+"""TensorFlow-free reader of the reference's TFRecord / tf.train.Example training records:
+known-answer vectors of the public formats, round trips, and (GPU) a batch assembled from records."""
+import io
+import struct
+
+import numpy as np
+import pytest
+
+from dpig_amd import tfrecord as T
+
+
+def test_crc32c_known_answers():
+    # RFC 3720 (iSCSI) appendix B.4 test vectors of CRC32C
+    assert T.crc32c(b"123456789") == 0xE3069283
+    assert T.crc32c(bytes(32)) == 0x8A9136AA
+    assert T.crc32c(bytes([0xFF] * 32)) == 0x62A8AB43
+    assert T.crc32c(bytes(range(32))) == 0x46DD794E
+    assert T.crc32c(b"") == 0
+    # TFRecord masking: ((crc >> 15) | (crc << 17)) + 0xa282ead8 mod 2^32
+    crc = 0xE3069283
+    assert T.masked_crc32c(b"123456789") == ((((crc >> 15) | (crc << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def test_tfrecord_framing_roundtrip_and_corruption():
+    payloads = [b"", b"a", bytes(range(256)) * 5]
+    f = io.BytesIO()
+    T.write_records(f, payloads)
+    raw = f.getvalue()
+    assert len(raw) == sum(16 + len(p) for p in payloads)
+    assert struct.unpack("<Q", raw[:8])[0] == 0
+    assert list(T.read_records(io.BytesIO(raw))) == payloads
+    bad = bytearray(raw); bad[-6] ^= 1                       # flip a payload bit of the last record
+    with pytest.raises(IOError):
+        list(T.read_records(io.BytesIO(bytes(bad))))
+    assert len(list(T.read_records(io.BytesIO(bytes(bad)), check_crc=False))) == 3
+    with pytest.raises(IOError):
+        list(T.read_records(io.BytesIO(raw[:-3])))
+
+
+def test_example_wire_format_known_bytes():
+    """A hand-assembled tf.train.Example: Features{ 'a': Int64List[1, -1, 300] (packed), 'b': FloatList[0.5, -2]
+    (UNPACKED, one fixed32 per element), 'c': BytesList['xy', ''] }."""
+    int_list = bytes([0x0A, 0x0D, 0x01]) + bytes([0xFF] * 9 + [0x01]) + bytes([0xAC, 0x02])      # 1, -1, 300
+    feat_a = bytes([0x1A, len(int_list)]) + int_list
+    fl = bytes([0x0D]) + struct.pack("<f", 0.5) + bytes([0x0D]) + struct.pack("<f", -2.0)
+    feat_b = bytes([0x12, len(fl)]) + fl
+    bl = bytes([0x0A, 0x02]) + b"xy" + bytes([0x0A, 0x00])
+    feat_c = bytes([0x0A, len(bl)]) + bl
+    def entry(k, feat):
+        e = bytes([0x0A, len(k)]) + k + bytes([0x12, len(feat)]) + feat
+        return bytes([0x0A, len(e)]) + e
+    feats = entry(b"a", feat_a) + entry(b"b", feat_b) + entry(b"c", feat_c)
+    ex = T.parse_example(bytes([0x0A, len(feats)]) + feats)
+    assert ex["a"].tolist() == [1, -1, 300] and ex["a"].dtype == np.int64
+    assert ex["b"].tolist() == [0.5, -2.0] and ex["b"].dtype == np.float32
+    assert ex["c"] == [b"xy", b""]
+    # the module's own encoder (packed lists) parses back to the same values
+    back = T.parse_example(T.encode_example({"a": ex["a"], "b": ex["b"], "c": ex["c"]}))
+    assert back["a"].tolist() == [1, -1, 300] and back["b"].tolist() == [0.5, -2.0] and back["c"] == [b"xy", b""]
+
+
+def _pair_example(rng, H=128, W=64, nparts=37, fmt=b"raw"):
+    """A record with the schema of datasets/market1501.py:79-141 (the fields the stage-I trainer reads)."""
+    ex = {"image_format": [fmt], "label": np.array([1]), "image_height": np.array([H]), "image_width": np.array([W])}
+    truth = {}
+    for s in ("0", "1"):
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        rcv = np.zeros((18, 3), np.float32)
+        rcv[:, 0] = rng.integers(0, H, 18); rcv[:, 1] = rng.integers(0, W, 18); rcv[:, 2] = rng.uniform(size=18) < 0.85
+        mask = (rng.uniform(size=(H * W,)) < 0.35).astype(np.int64)
+        bbox = np.zeros((nparts, 4), np.int64)
+        bbox[:, 0] = rng.integers(0, H // 2, nparts); bbox[:, 1] = rng.integers(0, W // 2, nparts)
+        bbox[:, 2] = bbox[:, 0] + rng.integers(8, H // 2, nparts); bbox[:, 3] = bbox[:, 1] + rng.integers(8, W // 2, nparts)
+        vis = (rng.uniform(size=nparts) < 0.9).astype(np.int64)
+        ex.update({"image_raw_" + s: [img.tobytes()], "pose_peaks_%s_rcv" % s: rcv.reshape(-1),
+                   "pose_mask_r6_" + s: mask, "part_bbox_" + s: bbox.reshape(-1), "part_vis_" + s: vis})
+        truth[s] = dict(img=img, rcv=rcv, mask=mask, bbox=bbox, vis=vis)
+    return T.encode_example(ex), truth
+
+
+def test_decode_pair_record_schema():
+    rng = np.random.default_rng(5)
+    payload, truth = _pair_example(rng)
+    f = io.BytesIO(); T.write_records(f, [payload]); f.seek(0)
+    ex = T.parse_example(next(T.read_records(f)))
+    for which in (0, 1):
+        d = T.decode_pair(ex, which)
+        t = truth[str(which)]
+        assert np.array_equal(d["x"], (t["img"].astype(np.float32) - 127.5) / 127.5)
+        assert np.array_equal(d["pose_rcv"], t["rcv"].reshape(-1))
+        assert np.array_equal(d["mask_r6"][..., 0], t["mask"].reshape(128, 64))
+        assert np.array_equal(d["part_bbox"], t["bbox"][:7]) and np.array_equal(d["part_vis"], t["vis"][:7])
+
+
+def test_jpeg_image_field_is_decoded():
+    from PIL import Image
+    img = np.zeros((128, 64, 3), np.uint8); img[32:96, 16:48] = (200, 40, 90)
+    buf = io.BytesIO(); Image.fromarray(img).save(buf, format="PNG")           # lossless, so the pixels are exact
+    assert np.array_equal(T.decode_image(buf.getvalue(), "png", 128, 64), img)
+    buf = io.BytesIO(); Image.fromarray(img).save(buf, format="JPEG", quality=95)
+    dec = T.decode_image(buf.getvalue(), "jpg", 128, 64)
+    assert dec.shape == (128, 64, 3) and np.abs(dec.astype(int) - img.astype(int)).mean() < 3
+
+
+@pytest.mark.gpu
+def test_batch_from_records_feeds_the_trainer(dev):
+    """Records -> batch dict on the device (pose maps rasterised by dpig_pose_rasterize) -> one encoder forward."""
+    import torch
+    import dpig_amd.tflib as lib
+    from dpig_amd import slim
+    from dpig_amd.trainer import Config, DPIG_Encoder_GAN_BodyROI_FgBg
+    from oracle import ops as O
+    rng = np.random.default_rng(6)
+    recs = [_pair_example(rng) for _ in range(2)]
+    f = io.BytesIO(); T.write_records(f, [r[0] for r in recs]); f.seek(0)
+    exs = [T.parse_example(p) for p in T.read_records(f)]
+    batch = T.batch_from_examples(exs, dev, which=0)
+    assert tuple(batch["x"].shape) == (2, 128, 64, 3) and tuple(batch["pose"].shape) == (2, 128, 64, 18)
+    rcv = torch.from_numpy(np.stack([r[1]["0"]["rcv"].reshape(-1) for r in recs])).double()
+    ref = O.tf_poseInflate(O.coord2channel_simple_rcv(rcv, 18, False, 128, 64), 18, 4, 128, 64)
+    assert torch.equal(batch["pose"].cpu().double(), ref)
+    lib.delete_all_params(); slim.reset_scopes()
+    np.random.seed(0)
+    tr = DPIG_Encoder_GAN_BodyROI_FgBg(Config(batch_size=2, conv_hidden_num=16, z_num=8), dev)
+    tr.init_net(batch)
+    tr.step = 1
+    out = tr.train_step(batch, T.batch_from_examples(exs, dev, which=1))
+    assert all(np.isfinite(float(v)) for v in out.values() if hasattr(v, "numel") and v.numel() == 1)
