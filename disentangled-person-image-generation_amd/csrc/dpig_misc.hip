@@ -616,6 +616,85 @@ __global__ __launch_bounds__(256) void pose_inflate_kernel(const float* __restri
 }
 
 // ---------------------------------------------------------------------------------------------
+// SSIM of trainer.generate() (skimage compare_ssim on gray uint8 images), per image
+// ---------------------------------------------------------------------------------------------
+constexpr int kSsimBlocks = 16;      // workgroups per image in every stage
+__device__ __forceinline__ float gray_u8(const float* __restrict__ px) {
+    const float r = floorf(fminf(fmaxf(px[0], 0.f), 255.f)), g = floorf(fminf(fmaxf(px[1], 0.f), 255.f)),
+                b = floorf(fminf(fmaxf(px[2], 0.f), 255.f));          // clip, astype(uint8)
+    return (r * 0.2125f + g * 0.7154f + b * 0.0721f) * (1.0f / 255.0f);
+}
+__device__ __forceinline__ float block_reduce_256(float v, float* red, int op) {     // op 0 sum, 1 min, 2 max
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float t = __shfl_xor(v, o, 64);
+        v = op == 0 ? v + t : (op == 1 ? fminf(v, t) : fmaxf(v, t));
+    }
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = red[0];
+    for (int i = 1; i < 4; ++i) r = op == 0 ? r + red[i] : (op == 1 ? fminf(r, red[i]) : fmaxf(r, red[i]));
+    return r;
+}
+// stage 1: gray maps ga, gb [B][H*W] and per-workgroup (min, max) of gb
+__global__ __launch_bounds__(256) void ssim_gray_kernel(const float* __restrict__ a, const float* __restrict__ b, int HW,
+                                                        float* __restrict__ ga, float* __restrict__ gb,
+                                                        float* __restrict__ mm) {
+    __shared__ float red[4];
+    const int img = blockIdx.y;
+    float lo = 3.4e38f, hi = -3.4e38f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < HW; i += gridDim.x * 256) {
+        const long o = (long)img * HW + i;
+        const float x = gray_u8(a + o * 3), y = gray_u8(b + o * 3);
+        ga[o] = x; gb[o] = y;
+        lo = fminf(lo, y); hi = fmaxf(hi, y);
+    }
+    lo = block_reduce_256(lo, red, 1);
+    hi = block_reduce_256(hi, red, 2);
+    if (threadIdx.x == 0) { mm[(img * gridDim.x + blockIdx.x) * 2] = lo; mm[(img * gridDim.x + blockIdx.x) * 2 + 1] = hi; }
+}
+// stage 2: SSIM of every 7x7 window, per-workgroup partial sums
+__global__ __launch_bounds__(256) void ssim_map_kernel(const float* __restrict__ ga, const float* __restrict__ gb, int H,
+                                                       int W, const float* __restrict__ mm, int nmm,
+                                                       float* __restrict__ part) {
+    __shared__ float red[4];
+    const int img = blockIdx.y;
+    float lo = 3.4e38f, hi = -3.4e38f;
+    for (int i = 0; i < nmm; ++i) { lo = fminf(lo, mm[(img * nmm + i) * 2]); hi = fmaxf(hi, mm[(img * nmm + i) * 2 + 1]); }
+    const float R = hi - lo;
+    const float C1 = (0.01f * R) * (0.01f * R), C2 = (0.03f * R) * (0.03f * R);
+    const int Hv = H - 6, Wv = W - 6;
+    const float* A = ga + (long)img * H * W;
+    const float* Bm = gb + (long)img * H * W;
+    float sum = 0.f;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < Hv * Wv; i += gridDim.x * 256) {
+        const int y = i / Wv, x = i - y * Wv;
+        float sx = 0.f, sy = 0.f, sxx = 0.f, syy = 0.f, sxy = 0.f;
+        for (int dy = 0; dy < 7; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 7; ++dx) {
+                const float u = A[(y + dy) * W + x + dx], v = Bm[(y + dy) * W + x + dx];
+                sx += u; sy += v; sxx += u * u; syy += v * v; sxy += u * v;
+            }
+        const float n = 49.f, ux = sx / n, uy = sy / n;
+        const float cn = n / (n - 1.f);
+        const float vx = cn * (sxx / n - ux * ux), vy = cn * (syy / n - uy * uy), vxy = cn * (sxy / n - ux * uy);
+        sum += ((2.f * ux * uy + C1) * (2.f * vxy + C2)) / ((ux * ux + uy * uy + C1) * (vx + vy + C2));
+    }
+    sum = block_reduce_256(sum, red, 0);
+    if (threadIdx.x == 0) part[img * gridDim.x + blockIdx.x] = sum;
+}
+__global__ void ssim_final_kernel(const float* __restrict__ part, int npart, int B, float inv_count,
+                                  float* __restrict__ out) {
+    const int img = blockIdx.x * blockDim.x + threadIdx.x;
+    if (img >= B) return;
+    float s = 0.f;
+    for (int i = 0; i < npart; ++i) s += part[img * npart + i];
+    out[img] = s * inv_count;
+}
+
+// ---------------------------------------------------------------------------------------------
 // nearest-neighbour 2x upsample (align_corners=False -> exact 2x2 replication) and its gradient
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* __restrict__ x, int N, int H, int W,
@@ -1083,6 +1162,27 @@ extern "C" int dpig_pose_inflate(const float* pose, int ldp, int B, int K, int H
     hipLaunchKernelGGL(pose_inflate_kernel, dim3(grid_for((long)B * H * W * K)), dim3(256), 0,
                        static_cast<hipStream_t>(stream), pose, ldp, B, K, H, W, out, ldo);
     return check_launch("pose_inflate");
+}
+
+extern "C" size_t dpig_ssim_workspace_bytes(int B, int H, int W) {
+    if (B <= 0 || H < 7 || W < 7) return 0;
+    return ((size_t)2 * B * H * W + (size_t)3 * B * kSsimBlocks) * sizeof(float);
+}
+extern "C" int dpig_ssim_gray_u8(const float* a, const float* b, int B, int H, int W, float* out, void* ws,
+                                 size_t ws_bytes, void* stream) {
+    if (!a || !b || !out) return fail(DPIG_EINVAL, "ssim: null pointer");
+    if (B <= 0 || H < 7 || W < 7) return fail(DPIG_EINVAL, "ssim: images must be at least 7x7");
+    if (!ws || ws_bytes < dpig_ssim_workspace_bytes(B, H, W)) return fail(DPIG_ENOMEM, "ssim: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    float* ga = static_cast<float*>(ws);
+    float* gb = ga + (size_t)B * H * W;
+    float* mm = gb + (size_t)B * H * W;
+    float* part = mm + (size_t)2 * B * kSsimBlocks;
+    hipLaunchKernelGGL(ssim_gray_kernel, dim3(kSsimBlocks, B), dim3(256), 0, st, a, b, H * W, ga, gb, mm);
+    hipLaunchKernelGGL(ssim_map_kernel, dim3(kSsimBlocks, B), dim3(256), 0, st, ga, gb, H, W, mm, kSsimBlocks, part);
+    hipLaunchKernelGGL(ssim_final_kernel, dim3((B + 63) / 64), dim3(64), 0, st, part, kSsimBlocks, B,
+                       1.0f / (float)((H - 6) * (W - 6)), out);
+    return check_launch("ssim");
 }
 
 extern "C" int dpig_upsample2x_fwd(const float* x, int N, int H, int W, int C, float* y, void* stream) {

@@ -488,6 +488,20 @@ def pose_rasterize(rcv, H, W, keypoint_num=18, is_normalized=True):
     return out
 
 
+def ssim_gray_u8(a255, b255):
+    """Per-image SSIM of two [B,H,W,3] batches of 0..255 pixel values, as skimage.compare_ssim gives it on the gray
+    uint8 images (trainer.py:516-521): returns [B]."""
+    _require_gpu(a255)
+    a255, b255 = a255.contiguous().float(), b255.contiguous().float()
+    B, Hh, W, C = a255.shape
+    if C != 3 or tuple(b255.shape) != tuple(a255.shape):
+        raise RuntimeError("ssim_gray_u8 expects two [B,H,W,3] tensors")
+    out = torch.empty(B, dtype=torch.float32, device=a255.device)
+    wsb, wsn = workspace.get(lib().dpig_ssim_workspace_bytes(B, Hh, W), a255.device)
+    check(lib().dpig_ssim_gray_u8(ptr(a255), ptr(b255), B, Hh, W, ptr(out), ptr(wsb), wsn, stream_ptr()), "ssim_gray_u8")
+    return out
+
+
 def upsample2x_fwd(x):
     _require_gpu(x)
     x = x.contiguous()

@@ -23,3 +23,10 @@ def tf_poseInflate(G_pose, keypoint_num, radius=4, img_H=128, img_W=64):
 
 def pose_target_from_rcv(RCV, keypoint_num=18, is_normalized=False, img_H=128, img_W=64):
     return H.pose_rasterize(RCV, img_H, img_W, keypoint_num, is_normalized)
+
+
+def ssim_G_x(G_255, x_pm1):
+    """The SSIM list of `trainer.generate()` (trainer.py:516-521) on the device: G holds 0..255 pixel values (the
+    denormalised generator output), x the [-1,1] input batch; returns the per-image SSIM tensor [B] (the reference
+    logs its mean).  Replaces skimage's CPU rgb2gray + compare_ssim."""
+    return H.ssim_gray_u8(G_255, (x_pm1 + 1) * 127.5)

@@ -210,6 +210,15 @@ int dpig_pose_inflate(const float* pose, int ldp, int B, int K, int H, int W, fl
 int dpig_pose_rasterize(const float* rcv, int B, int K, int H, int W, int is_normalized, float* out, int ldo,
                         void* stream);
 
+/* ---- evaluation metric of trainer.generate() / score.py (trainer.py:516-521) -------------------
+ * SSIM as skimage.measure.compare_ssim computes it on gray uint8 images: a, b: [B,H,W,3] fp32 pixel values
+ * (ld 3); each is clipped to [0,255], truncated to uint8, converted to gray ((0.2125,0.7154,0.0721)/255), 7x7
+ * uniform window, sample covariance, data_range = max - min of b's gray image (per image), mean over the windows
+ * fully inside the image.  out[B].  H, W >= 7. */
+size_t dpig_ssim_workspace_bytes(int B, int H, int W);
+int dpig_ssim_gray_u8(const float* a, const float* b, int B, int H, int W, float* out, void* ws, size_t ws_bytes,
+                      void* stream);
+
 /* ---- nearest-neighbour 2x upsample (unfused form; utils.py:61-72) ---------------------------- */
 int dpig_upsample2x_fwd(const float* x, int N, int H, int W, int C, float* y, void* stream);
 int dpig_upsample2x_bwd(const float* dy, int N, int H, int W, int C, float* dx, void* stream);

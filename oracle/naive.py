@@ -220,3 +220,20 @@ def pose_disc_map(rcv, keypoint_num, img_H, img_W, radius=4):
                         hits = 2 if (i == 0 and j == 0) else 1          # the stencil visits the centre twice
                         out[b, r + i, c + j, k] = min(v * hits, 1.0) * 2 - 1
     return out
+
+
+def ssim_window_loops(X, Y, data_range, win=7, K1=0.01, K2=0.03):
+    """Independent loop restatement of the windowed SSIM (Wang et al. 2004) as skimage evaluates it: for every window
+    fully inside the image, unbiased variances / covariance of the 49 samples."""
+    X = np.asarray(X, dtype=np.float64); Y = np.asarray(Y, dtype=np.float64)
+    H, W = X.shape
+    C1, C2 = (K1 * data_range) ** 2, (K2 * data_range) ** 2
+    tot, cnt = 0.0, 0
+    for i in range(H - win + 1):
+        for j in range(W - win + 1):
+            a = X[i:i + win, j:j + win].ravel(); b = Y[i:i + win, j:j + win].ravel()
+            ma, mb = a.mean(), b.mean()
+            va, vb = a.var(ddof=1), b.var(ddof=1)
+            cab = ((a - ma) * (b - mb)).sum() / (a.size - 1)
+            tot += ((2 * ma * mb + C1) * (2 * cab + C2)) / ((ma * ma + mb * mb + C1) * (va + vb + C2)); cnt += 1
+    return tot / cnt

@@ -176,3 +176,39 @@ def tf_poseInflate(pose, keypoint_num=18, radius=4, img_H=128, img_W=64):
     for a, b in POSE_STENCIL:
         out = out + pad[:, a + radius:a + radius + img_H, b + radius:b + radius + img_W, :]
     return torch.clamp(out, max=1.0) * 2 - 1
+
+
+# ---- evaluation metric of trainer.generate() / score.py: skimage compare_ssim on gray uint8 images ----------------
+def rgb2gray_u8(img_u8):
+    """skimage.color.rgb2gray on a uint8 RGB image: float64 in [0,1], weights (0.2125, 0.7154, 0.0721)."""
+    import numpy as np
+    x = np.asarray(img_u8, dtype=np.float64) / 255.0
+    return x[..., 0] * 0.2125 + x[..., 1] * 0.7154 + x[..., 2] * 0.0721
+
+
+def ssim_skimage(X, Y, data_range, win_size=7, K1=0.01, K2=0.03):
+    """skimage.measure.compare_ssim(X, Y, data_range=..., multichannel=False) with its defaults (trainer.py:516-521):
+    7x7 uniform window, sample covariance (NP/(NP-1)), mean of the SSIM map cropped by (win-1)/2 on every side."""
+    import numpy as np
+    from scipy.ndimage import uniform_filter
+    X = np.asarray(X, dtype=np.float64); Y = np.asarray(Y, dtype=np.float64)
+    NP = win_size ** 2
+    cov_norm = NP / (NP - 1.0)
+    ux, uy = uniform_filter(X, size=win_size), uniform_filter(Y, size=win_size)
+    uxx, uyy, uxy = uniform_filter(X * X, size=win_size), uniform_filter(Y * Y, size=win_size), uniform_filter(X * Y, size=win_size)
+    vx, vy, vxy = cov_norm * (uxx - ux * ux), cov_norm * (uyy - uy * uy), cov_norm * (uxy - ux * uy)
+    C1, C2 = (K1 * data_range) ** 2, (K2 * data_range) ** 2
+    S = ((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux ** 2 + uy ** 2 + C1) * (vx + vy + C2))
+    pad = (win_size - 1) // 2
+    return float(S[pad:-pad, pad:-pad].mean())
+
+
+def ssim_G_x(G_255, x_pm1):
+    """The per-image SSIM list of trainer.generate() (trainer.py:516-521): G in 0..255 floats, x in [-1,1]."""
+    import numpy as np
+    out = []
+    for i in range(G_255.shape[0]):
+        g = rgb2gray_u8(np.clip(np.asarray(G_255[i]), 0, 255).astype(np.uint8))
+        x = rgb2gray_u8(np.clip((np.asarray(x_pm1[i]) + 1) * 127.5, 0, 255).astype(np.uint8))
+        out.append(ssim_skimage(g, x, data_range=x.max() - x.min()))
+    return np.array(out)

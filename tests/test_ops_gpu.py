@@ -296,3 +296,23 @@ def test_pose_maps(dev, normalized):
         rcv[2, 3] = (-3.0, 5.0, 1.0); rcv[2, 4] = (5.0, W + 2.0, 1.0)
         out = U.pose_target_from_rcv(torch.from_numpy(rcv.reshape(B, K * 3)).to(dev), K, False, Hh, W)
         assert float(out[2, :, :, 3].max()) == -1.0 and float(out[2, :, :, 4].max()) == -1.0
+
+
+def test_ssim_metric(dev):
+    """the SSIM trainer.generate() logs (skimage on gray uint8 images) computed on the device."""
+    import dpig_amd.utils as U
+    from oracle import ops as O
+    rng = np.random.default_rng(4)
+    B, Hh, W = 5, 128, 64
+    x = rng.uniform(-1, 1, (B, Hh, W, 3)).astype(np.float32)
+    G = np.clip((x + 1) * 127.5 + rng.normal(0, 25, x.shape), -20, 280).astype(np.float32)     # incl. values to clip
+    G[0] = (x[0] + 1) * 127.5                                                                   # identical image -> 1
+    x[1, 40:60, 10:30] = 0.3                                                                     # a flat patch
+    ref = O.ssim_G_x(G, x)
+    got = U.ssim_G_x(torch.from_numpy(G).to(dev), torch.from_numpy(x).to(dev)).cpu().numpy()
+    assert np.abs(got - ref).max() < 2e-4, (got, ref)
+    assert abs(got[0] - 1.0) < 1e-5
+    small = rng.uniform(0, 255, (2, 7, 9, 3)).astype(np.float32)                                 # minimum size: 1x3 windows
+    ref2 = O.ssim_G_x(small, small[::-1] / 127.5 - 1)
+    got2 = U.ssim_G_x(torch.from_numpy(small).to(dev), torch.from_numpy(small[::-1].copy() / 127.5 - 1).to(dev)).cpu().numpy()
+    assert np.abs(got2 - ref2).max() < 2e-4

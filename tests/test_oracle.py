@@ -212,3 +212,18 @@ def test_pose_maps_scatter_and_shifts_equal_disc(normalized):
     got = ops.tf_poseInflate(pts, K, 4, Hh, W).numpy()
     assert np.array_equal(got, want)
     assert ((pts.numpy() == -1) | (pts.numpy() == 2 * rcv[:, None, None, :, 2] - 1)).all()
+
+
+def test_ssim_skimage_restatement_equals_window_loops():
+    """trainer.py:516-521 metric: the scipy uniform_filter restatement of skimage.compare_ssim vs explicit 7x7 window
+    loops with unbiased (co)variances; identical images give exactly 1."""
+    import numpy as np
+    from oracle import naive, ops
+    rng = np.random.default_rng(2)
+    a = rng.integers(0, 256, (20, 15, 3), dtype=np.uint8)
+    b = np.clip(a.astype(int) + rng.integers(-40, 41, a.shape), 0, 255).astype(np.uint8)
+    ga, gb = ops.rgb2gray_u8(a), ops.rgb2gray_u8(b)
+    R = gb.max() - gb.min()
+    assert abs(ops.ssim_skimage(ga, gb, R) - naive.ssim_window_loops(ga, gb, R)) < 1e-12
+    assert abs(ops.ssim_skimage(ga, ga, R) - 1.0) < 1e-12
+    assert 0.0 <= gb.min() and gb.max() <= 1.0
