@@ -326,3 +326,51 @@ def test_stage1_bf16_compute_mode(dev):
         assert float((tr.G_flat.flat - w0).abs().max()) > 0
     finally:
         H.set_compute("f32")
+
+
+def test_inference_harness(dev):
+    """SURVEY 8f-3 (tester.py:256-417): with sampling off the harness reproduces the trainer's generator path
+    (same variables, pose maps rasterised from the keypoints) and the critic score; with sampling on it draws
+    appearance / pose from the FC mappers; outputs are denormalised images with an SSIM against the input."""
+    import dpig_amd.tflib as lib
+    from dpig_amd import slim, synthetic
+    from dpig_amd.tester import DPIG_FourNetsFgBg_testOnly
+    from dpig_amd.trainer import Config, DPIG_Encoder_GAN_BodyROI_FgBg
+    from oracle import ops as O
+    lib.delete_all_params(); slim.reset_scopes()
+    B = 2
+    np.random.seed(1)
+    cfg = Config(batch_size=B, conv_hidden_num=16, z_num=8)
+    tr = DPIG_Encoder_GAN_BodyROI_FgBg(cfg, dev)
+    batch = synthetic.to_device(synthetic.make_batch(B, seed=41), dev)
+    tr.init_net(batch)
+    rng = np.random.default_rng(7)
+    rcv = np.zeros((B, 18, 3), np.float32)
+    rcv[..., 0] = rng.integers(4, 124, (B, 18)); rcv[..., 1] = rng.integers(4, 60, (B, 18)); rcv[..., 2] = 1.0
+    rcv_t = torch.from_numpy(rcv.reshape(B, -1)).to(dev)
+    # the trainer's path on the pose map of exactly these keypoints
+    pose_map = O.tf_poseInflate(O.coord2channel_simple_rcv(torch.from_numpy(rcv.reshape(B, -1)).double(), 18, False, 128, 64),
+                                18, 4, 128, 64).float().to(dev)
+    with torch.no_grad():
+        embs, _ = tr.encode(batch)
+        G_ref, _ = tr.generate(embs, pose_map)
+        score_ref = tr.discriminate(G_ref)
+    te = DPIG_FourNetsFgBg_testOnly(cfg, dev)
+    te.built = False
+    # the Encoder / ID_AE variables exist already (created by the trainer): reuse them, create the samplers
+    slim.reset_scopes()
+    out = te.run(batch, rcv_t)
+    assert torch.equal(out["pose_map"], pose_map)
+    assert torch.allclose(out["G"], torch.clamp((G_ref + 1) * 127.5, 0, 255), atol=1e-3)
+    assert torch.allclose(out["G_dis_score"], score_ref.reshape(B, -1).mean(1), atol=1e-4)
+    assert float(out["reconstruct_loss"]) == 0.0 and tuple(out["ssim_G_x"].shape) == (B,)
+    # sampling on: fixed noise makes it repeatable; one foreground for the whole batch
+    ts = DPIG_FourNetsFgBg_testOnly(cfg, dev, sample_app=True, sample_pose=True, one_app_per_batch=True)
+    ts.built = True                                   # every variable exists now
+    z_fg, z_bg = torch.randn(B, 224, device=dev) * 0.2, torch.randn(B, 128, device=dev) * 0.2
+    o1 = ts.run(batch, rcv_t, z_fg=z_fg, z_bg=z_bg)
+    o2 = ts.run(batch, rcv_t, z_fg=z_fg, z_bg=z_bg)
+    assert torch.equal(o1["G"], o2["G"]) and torch.isfinite(o1["G"]).all()
+    assert torch.equal(o1["embs"][0, :224], o1["embs"][1, :224]) and not torch.equal(o1["embs"][0, 224:], o1["embs"][1, 224:])
+    assert float(o1["G"].min()) >= 0.0 and float(o1["G"].max()) <= 255.0
+    assert set(np.unique(o1["G_pose_rcv"][..., 2].cpu().numpy())) <= {0.0, 1.0}       # binaryRound visibilities
