@@ -727,7 +727,8 @@ __device__ __forceinline__ void gather_gemm_reduce_body(const GGParams& p) {
         const float4* p4 = reinterpret_cast<const float4*>(p.partial);
         for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
             float4 v = p4[i];
-            for (int s = 1; s < p.nsplit; ++s) {
+#pragma unroll 4
+            for (int s = 1; s < p.nsplit; ++s) {       // (unrolled: several 16-byte loads in flight per lane)
                 const float4 t = p4[(long)s * total4 + i];
                 v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
             }
@@ -1218,6 +1219,7 @@ __global__ __launch_bounds__(256) void splitk_sum_kernel(const float* __restrict
     float4* o4 = reinterpret_cast<float4*>(out);
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
         for (int s = 0; s < nsplit; ++s) {
             const float4 t = p4[(long)s * n4 + i];
             v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
