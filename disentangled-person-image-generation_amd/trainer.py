@@ -57,9 +57,9 @@ class FlatParams(object):
             p._dpig_touched[0] = False
             p.grad = None
 
-    def finalize(self):
-        """Parameters that received no gradient this step must contribute zeros."""
-        for p in self.params:
+    def finalize(self, lo=0, hi=None):
+        """Parameters (of the index range [lo, hi)) that received no gradient this step must contribute zeros."""
+        for p in self.params[lo:hi]:
             if not p._dpig_touched[0]:
                 if p.grad is not None:           # gradient came through plain autograd
                     p._dpig_grad.copy_(p.grad)
@@ -143,6 +143,19 @@ class GradAllReduce(object):
             h.wait()
         return 1.0 / self.world
 
+    def start(self, flat_grad):
+        """Launch the bucketed all-reduce of a slice asynchronously (RCCL runs it on its own stream, ordered after the
+        work already queued on the current stream) and return the handles; `finish` waits for them."""
+        if not self.enabled:
+            return []
+        n = flat_grad.numel()
+        return [self.dist.all_reduce(flat_grad[o:min(o + self.bucket, n)], async_op=True) for o in range(0, n, self.bucket)]
+
+    def finish(self, handles):
+        for h in handles:
+            h.wait()
+        return 1.0 / self.world if self.enabled else 1.0
+
     def broadcast(self, flat_params):
         if self.enabled:
             self.dist.broadcast(flat_params, src=0)
@@ -211,6 +224,9 @@ class Config(object):
                                          # the gradient-penalty branch the reference keeps dormant
         self.data_format = 'NHWC'        # main.py:18
         self.sync_bn = False             # data parallel: D's BatchNorm statistics over all ranks
+        self.split_backward = None       # None: in data-parallel runs only.  The generator-side backward runs in two
+                                         # stages (decoder+critic, then encoder) so that the decoder half of the
+                                         # gradient all-reduce overlaps the encoder's backward pass
         self.compute_dtype = 'f32'       # 'bf16': conv GEMMs on the bf16 matrix pipe (fp32 tensors / accumulation /
                                          # master weights; BASELINE configs 3-5); 'f32' is the reference's arithmetic
         self.__dict__.update(kw)
@@ -289,6 +305,10 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         self.D_var = lib.params_with_name('Discriminator.')  # trainer.py:603
         self.G_flat = FlatParams(self.G_var)
         self.D_flat = FlatParams(self.D_var)
+        dec_ids = set(id(p) for p in g_var)
+        self._n_dec = sum(1 for p in self.G_flat.params if id(p) in dec_ids)        # decoder params come first
+        assert all(id(p) in dec_ids for p in self.G_flat.params[:self._n_dec])
+        self._enc_off = self.G_flat.offsets[self._n_dec] if self._n_dec < len(self.G_flat.params) else self.G_flat.numel
         self.g_opt, self.d_opt = get_optimizers(self.wgan_gp, self.G_flat, self.D_flat, self.g_lr, self.d_lr)
         self.allreduce = GradAllReduce()
         self.allreduce.broadcast(self.G_flat.flat)
@@ -313,11 +333,24 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
                 self._d_optim_eager(self._static_d)
         torch.cuda.current_stream(self.device).wait_stream(side)
         torch.cuda.synchronize(self.device)
-        self._graph_update = not self.allreduce.enabled       # fold all-reduce + Adam into the graph?
+        self._graph_update = not (self.allreduce.enabled or self._split())   # fold all-reduce + Adam into the graph?
         gg, gd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
         # thread_local: a process-group watchdog thread polling events must not invalidate the capture
-        with torch.cuda.graph(gg, capture_error_mode="thread_local"):
-            out_g = self._g_optim_eager(self._static_g, update=self._graph_update)
+        self._gg2 = None
+        if self._split():
+            # two graphs for g_optim: [forward + critic/decoder backward] and [encoder backward]; the all-reduce of
+            # the decoder slice is launched between the two replays and overlaps the second one
+            with torch.cuda.graph(gg, capture_error_mode="thread_local"):
+                g_loss, embs, out_g = self._g_forward(self._static_g)
+                d_embs = self._g_backward_decoder(g_loss, embs)
+            self._gg2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self._gg2, pool=gg.pool(), capture_error_mode="thread_local"):
+                self._g_backward_encoder(embs, d_embs)
+            self._keep = (g_loss, embs, d_embs)
+            del g_loss, embs, d_embs
+        else:
+            with torch.cuda.graph(gg, capture_error_mode="thread_local"):
+                out_g = self._g_optim_eager(self._static_g, update=self._graph_update)
         with torch.cuda.graph(gd, pool=gg.pool(), capture_error_mode="thread_local"):
             out_d = self._d_optim_eager(self._static_d, update=self._graph_update)
         self._graphs = (gg, out_g, gd, out_d)
@@ -335,7 +368,12 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
             return self._g_optim_eager(batch)
         self._feed(self._static_g, batch)
         self._graphs[0].replay()
-        if self._graph_update:
+        if self._gg2 is not None:
+            h = self.allreduce.start(self.G_flat.grad[:self._enc_off])
+            self._gg2.replay()
+            h += self.allreduce.start(self.G_flat.grad[self._enc_off:])
+            self.g_opt.step(self.allreduce.finish(h))
+        elif self._graph_update:
             self.g_opt.t += 1
         else:
             self.g_opt.step(self.allreduce(self.G_flat.grad))
@@ -353,8 +391,11 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         return self._graphs[3]
 
     # ---- the two optimizer ops -----------------------------------------------------------------
-    def _g_optim_eager(self, batch, update=True):
-        """sess.run(g_optim): fwd E,G,D(fake); g_loss = sce(D(G),1) + 20*L1; bwd D(dgrad only),G,E; Adam."""
+    def _split(self):
+        sb = getattr(self.config, "split_backward", None)
+        return self.allreduce.enabled if sb is None else bool(sb)
+
+    def _g_forward(self, batch):
         H.set_compute(getattr(self.config, "compute_dtype", "f32"))
         self.G_flat.zero_grad()
         self.D_flat.set_requires_grad(False)
@@ -364,12 +405,54 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         g_loss_only, _ = gan_loss(self.wgan_gp, None, D_z_neg)
         L1Loss = A.l1_mean(G, batch["x"])
         g_loss = g_loss_only + L1Loss * 20           # trainer.py:623
-        g_loss.backward()
+        out = {"g_loss": g_loss.detach(), "L1Loss": L1Loss.detach(), "g_loss_only": g_loss_only.detach(), "G": G.detach()}
+        return g_loss, embs, out
+
+    def _sunk_or_copy(self, params, grads):
+        """Gradients our kernels wrote into the flat buffer come back as None; anything plain autograd produced is
+        copied into its slice."""
+        for p, g in zip(params, grads):
+            if g is not None:
+                if p._dpig_touched[0]:
+                    p._dpig_grad.add_(g)
+                else:
+                    p._dpig_grad.copy_(g)
+                p._dpig_touched[0] = True
+
+    def _g_backward_decoder(self, g_loss, embs):
+        """Stage 1: critic (dgrad only) + generator, down to the embedding; the decoder slice of the flat gradient
+        is complete afterwards."""
+        dec = self.G_flat.params[:self._n_dec]
+        res = torch.autograd.grad(g_loss, [embs] + dec, allow_unused=True)
+        self._sunk_or_copy(dec, res[1:])
         self.D_flat.set_requires_grad(True)
-        self.G_flat.finalize()
-        if update:
-            self.g_opt.step(self.allreduce(self.G_flat.grad))
-        return {"g_loss": g_loss.detach(), "L1Loss": L1Loss.detach(), "g_loss_only": g_loss_only.detach(), "G": G.detach()}
+        self.G_flat.finalize(0, self._n_dec)
+        return res[0]
+
+    def _g_backward_encoder(self, embs, d_embs):
+        """Stage 2: the encoder, from the embedding gradient."""
+        enc = self.G_flat.params[self._n_dec:]
+        res = torch.autograd.grad(embs, enc, grad_outputs=d_embs, allow_unused=True)
+        self._sunk_or_copy(enc, res)
+        self.G_flat.finalize(self._n_dec, None)
+
+    def _g_optim_eager(self, batch, update=True):
+        """sess.run(g_optim): fwd E,G,D(fake); g_loss = sce(D(G),1) + 20*L1; bwd D(dgrad only),G,E; Adam."""
+        g_loss, embs, out = self._g_forward(batch)
+        if self._split():
+            d_embs = self._g_backward_decoder(g_loss, embs)
+            h = self.allreduce.start(self.G_flat.grad[:self._enc_off]) if update else []
+            self._g_backward_encoder(embs, d_embs)
+            if update:
+                h += self.allreduce.start(self.G_flat.grad[self._enc_off:])
+                self.g_opt.step(self.allreduce.finish(h))
+        else:
+            g_loss.backward()
+            self.D_flat.set_requires_grad(True)
+            self.G_flat.finalize()
+            if update:
+                self.g_opt.step(self.allreduce(self.G_flat.grad))
+        return out
 
     def _d_optim_eager(self, batch, update=True):
         """sess.run(d_optim): fwd E,G (no grad), D(x), D(G); d_loss; bwd D; Adam(D)."""

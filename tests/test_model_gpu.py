@@ -179,3 +179,35 @@ def test_hipgraph_replay_matches_eager(dev):
     lr = 2e-3
     assert (g0 - g1).abs().max().item() <= 6 * lr and (g0 - g1).abs().mean().item() < 0.05 * lr
     assert (d0 - d1).abs().max().item() <= 6 * lr and (d0 - d1).abs().mean().item() < 0.05 * lr
+
+
+def test_split_backward_equals_full_backward(dev):
+    """The data-parallel schedule of g_optim (critic + decoder backward, [all-reduce of the decoder slice], encoder
+    backward) produces bit-identical gradients to one backward pass, eagerly and as two replayed hipGraphs."""
+    import dpig_amd.tflib as lib
+    tr, gb, P, ob, OM = _setup(dev)
+    assert 0 < tr._n_dec < len(tr.G_flat.params) and 0 < tr._enc_off < tr.G_flat.numel
+    grads = lambda: [p._dpig_grad.clone() for p in tr.G_flat.params]       # (the flat buffer also has alignment padding)
+    same = lambda a, b: all(torch.equal(x, y) for x, y in zip(a, b))
+    tr.config.split_backward = False
+    tr._g_optim_eager(gb, update=False)
+    ref = grads()
+    assert sum(float(g.abs().sum()) for g in ref[:tr._n_dec]) > 0 and sum(float(g.abs().sum()) for g in ref[tr._n_dec:]) > 0
+    tr.config.split_backward = True
+    tr.G_flat.grad.fill_(7.0)                       # stale garbage must be overwritten
+    tr._g_optim_eager(gb, update=False)
+    assert same(grads(), ref)
+    # graphs: forced split -> two graphs for g_optim, optimizer launches stay eager
+    w0, d0 = tr.G_flat.flat.clone(), tr.D_flat.flat.clone()
+    tr.enable_graphs(gb, gb, warmup=1)
+    assert tr._gg2 is not None and not tr._graph_update
+    for fl, s0 in zip((tr.G_flat, tr.D_flat), (w0, d0)):
+        fl.flat.copy_(s0); fl.m.zero_(); fl.v.zero_()
+    for opt in (tr.g_opt, tr.d_opt):
+        opt.state.zero_(); opt.t = 0
+    tr.G_flat.grad.fill_(7.0)
+    tr.g_optim(gb)
+    torch.cuda.synchronize()
+    assert same(grads(), ref)
+    assert float((tr.G_flat.flat - w0).abs().max()) > 0
+    lib.delete_all_params()
