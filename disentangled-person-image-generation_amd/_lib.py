@@ -70,6 +70,8 @@ SYMBOLS = {
     "dpig_pose_rasterize": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "dpig_ssim_workspace_bytes": (_sz, [_i, _i, _i]),
     "dpig_ssim_gray_u8": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "dpig_gp_interpolate": (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp]),
+    "dpig_gp_penalty": (_i, [_vp, _i, _i64, _f, _vp, _vp, _vp, _vp]),
     "dpig_upsample2x_fwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "dpig_upsample2x_bwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "dpig_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _i, _f, _vp]),

@@ -402,6 +402,26 @@ class _SyncBatchNormFn(torch.autograd.Function):
         return dx, ds, do, None, None, None, None
 
 
+class _GPPenaltyFn(torch.autograd.Function):
+    """LAMBDA * mean_b (||g_b||_2 - 1)^2 of the critic's input gradient g (trainer.py:233-236): the value and its
+    derivative w.r.t. g -- the seed of the double-backward sweep -- come out of one pass over g."""
+
+    @staticmethod
+    def forward(ctx, g, lam):
+        pen, dg, _ = H.gp_penalty(g, lam)
+        ctx.save_for_backward(dg)
+        return pen.reshape(())
+
+    @staticmethod
+    def backward(ctx, dout):
+        (dg,) = ctx.saved_tensors
+        return dg * dout, None
+
+
+def gp_penalty(g, lam):
+    return _GPPenaltyFn.apply(g, lam)
+
+
 _SYNC_BN_GROUP = [False, None]      # (enabled, process group)
 
 

@@ -695,6 +695,40 @@ __global__ void ssim_final_kernel(const float* __restrict__ part, int npart, int
 }
 
 // ---------------------------------------------------------------------------------------------
+// WGAN-GP gradient penalty: interpolation, and penalty + double-backward seed in one pass
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gp_interpolate_kernel(const float* __restrict__ real, const float* __restrict__ fake,
+                                                             const float* __restrict__ alpha, long D, long total,
+                                                             float* __restrict__ xhat) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const float a = alpha[i / D];
+        const float r = real[i];
+        xhat[i] = r + a * (fake[i] - r);
+    }
+}
+// one workgroup per sample: slope = ||g_b||, then dg_b = coef * g_b with coef = lambda*2*(slope-1)/(B*slope)
+__global__ __launch_bounds__(256) void gp_penalty_kernel(const float* __restrict__ g, int B, long D, float lambda,
+                                                         float* __restrict__ dg, float* __restrict__ slopes) {
+    __shared__ float red[4];
+    const int b = blockIdx.x;
+    const float* gb = g + (long)b * D;
+    float s = 0.f;
+    for (long i = threadIdx.x; i < D; i += 256) { const float v = gb[i]; s += v * v; }
+    s = block_reduce_256(s, red, 0);
+    const float slope = sqrtf(s);
+    if (threadIdx.x == 0) slopes[b] = slope;
+    const float coef = slope > 0.f ? lambda * 2.f * (slope - 1.f) / ((float)B * slope) : 0.f;
+    float* db = dg + (long)b * D;
+    for (long i = threadIdx.x; i < D; i += 256) db[i] = coef * gb[i];
+}
+__global__ void gp_final_kernel(const float* __restrict__ slopes, int B, float lambda, float* __restrict__ penalty) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) { const float d = slopes[b] - 1.f; s += d * d; }       // fixed order
+    penalty[0] = lambda * s / (float)B;
+}
+
+// ---------------------------------------------------------------------------------------------
 // nearest-neighbour 2x upsample (align_corners=False -> exact 2x2 replication) and its gradient
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void upsample2x_fwd_kernel(const float* __restrict__ x, int N, int H, int W,
@@ -1183,6 +1217,24 @@ extern "C" int dpig_ssim_gray_u8(const float* a, const float* b, int B, int H, i
     hipLaunchKernelGGL(ssim_final_kernel, dim3((B + 63) / 64), dim3(64), 0, st, part, kSsimBlocks, B,
                        1.0f / (float)((H - 6) * (W - 6)), out);
     return check_launch("ssim");
+}
+
+extern "C" int dpig_gp_interpolate(const float* real, const float* fake, const float* alpha, int B, int64_t D,
+                                   float* xhat, void* stream) {
+    if (!real || !fake || !alpha || !xhat) return fail(DPIG_EINVAL, "gp_interpolate: null pointer");
+    if (B <= 0 || D <= 0) return fail(DPIG_EINVAL, "gp_interpolate: empty");
+    hipLaunchKernelGGL(gp_interpolate_kernel, dim3(grid_for((long)B * D)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       real, fake, alpha, (long)D, (long)B * D, xhat);
+    return check_launch("gp_interpolate");
+}
+extern "C" int dpig_gp_penalty(const float* g, int B, int64_t D, float lambda, float* penalty, float* dg, float* slopes,
+                               void* stream) {
+    if (!g || !penalty || !dg || !slopes) return fail(DPIG_EINVAL, "gp_penalty: null pointer");
+    if (B <= 0 || D <= 0) return fail(DPIG_EINVAL, "gp_penalty: empty");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(gp_penalty_kernel, dim3(B), dim3(256), 0, st, g, B, (long)D, lambda, dg, slopes);
+    hipLaunchKernelGGL(gp_final_kernel, dim3(1), dim3(64), 0, st, slopes, B, lambda, penalty);
+    return check_launch("gp_penalty");
 }
 
 extern "C" int dpig_upsample2x_fwd(const float* x, int N, int H, int W, int C, float* y, void* stream) {

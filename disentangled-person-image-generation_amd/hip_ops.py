@@ -502,6 +502,30 @@ def ssim_gray_u8(a255, b255):
     return out
 
 
+def gp_interpolate(real, fake, alpha):
+    """xhat = real + alpha[b] * (fake - real), alpha: [B]."""
+    _require_gpu(real)
+    real, fake = real.contiguous(), fake.contiguous()
+    B = real.shape[0]
+    out = torch.empty_like(real)
+    check(lib().dpig_gp_interpolate(ptr(real), ptr(fake), ptr(alpha.contiguous().reshape(-1).float()), B, real.numel() // B,
+                                    ptr(out), stream_ptr()), "gp_interpolate")
+    return out
+
+
+def gp_penalty(g, lam):
+    """(penalty [1], dpenalty/dg, slopes [B]) of lambda * mean_b (||g_b|| - 1)^2 for g [B, ...]."""
+    _require_gpu(g)
+    g = g.contiguous()
+    B = g.shape[0]
+    pen = torch.empty(1, dtype=torch.float32, device=g.device)
+    dg = torch.empty_like(g)
+    slopes = torch.empty(B, dtype=torch.float32, device=g.device)
+    check(lib().dpig_gp_penalty(ptr(g), B, g.numel() // B, float(lam), ptr(pen), ptr(dg), ptr(slopes), stream_ptr()),
+          "gp_penalty")
+    return pen, dg, slopes
+
+
 def upsample2x_fwd(x):
     _require_gpu(x)
     x = x.contiguous()

@@ -166,15 +166,16 @@ def gradient_penalty(Discriminator, real_data, fake_data, LAMBDA=10., alpha=None
     xhat = real + alpha*(fake - real), alpha ~ U[0,1) per sample.  As written the reference only type-checks
     for flat [B,D] inputs (SURVEY C-3); this is the canonical form (per-sample alpha, L2 norm over all
     non-batch axes), identical on flat data.  The penalty's gradient w.r.t. the critic's parameters needs
-    the backward pass differentiated once more: every piece is a kernel (autograd second-level functions)."""
+    the backward pass differentiated once more: every piece is a kernel (autograd second-level functions); the
+    interpolation is one launch, the norm / penalty / seed-of-the-second-sweep another (`dpig_gp_penalty`)."""
     B = real_data.shape[0]
     if alpha is None:
         alpha = torch.rand([B] + [1] * (real_data.dim() - 1), device=real_data.device)
-    interpolates = (real_data + alpha * (fake_data - real_data)).detach().requires_grad_(True)
+    interpolates = H.gp_interpolate(real_data.detach(), fake_data.detach(), alpha.reshape(B)).requires_grad_(True)
     D_int = Discriminator(interpolates)
     gradients = torch.autograd.grad(D_int.sum(), interpolates, create_graph=True)[0]
-    slopes = torch.sqrt((gradients * gradients).reshape(B, -1).sum(dim=1))
-    return LAMBDA * ((slopes - 1.) ** 2).mean()
+    # penalty value + its derivative w.r.t. `gradients` (the seed of the second sweep) in one fused pass
+    return A.gp_penalty(gradients, LAMBDA)
 
 
 def gan_loss(wgan_gp, disc_real, disc_fake, Discriminator=None, real_data=None, fake_data=None, alpha=None):

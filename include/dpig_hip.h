@@ -219,6 +219,17 @@ size_t dpig_ssim_workspace_bytes(int B, int H, int W);
 int dpig_ssim_gray_u8(const float* a, const float* b, int B, int H, int W, float* out, void* ws, size_t ws_bytes,
                       void* stream);
 
+/* ---- WGAN-GP gradient-penalty term (trainer.py:222-236, wgan_gp.py:605-619) --------------------------------
+ * dpig_gp_interpolate: xhat[b,:] = real[b,:] + alpha[b] * (fake[b,:] - real[b,:]),  tensors [B, D] dense.
+ * dpig_gp_penalty: given g = grad_xhat D(xhat) [B, D]:  slope_b = ||g[b,:]||_2,
+ *     *penalty = lambda * mean_b (slope_b - 1)^2   and   dg[b,:] = lambda * 2 (slope_b - 1) / (B * slope_b) * g[b,:]
+ *   (the derivative of the penalty w.r.t. g: the seed of the double-backward sweep through the critic), in one
+ *   pass over g + a [B]-sized finalisation; slopes: [B] scratch/output.  A zero slope yields dg = 0. */
+int dpig_gp_interpolate(const float* real, const float* fake, const float* alpha, int B, int64_t D, float* xhat,
+                        void* stream);
+int dpig_gp_penalty(const float* g, int B, int64_t D, float lambda, float* penalty, float* dg, float* slopes,
+                    void* stream);
+
 /* ---- nearest-neighbour 2x upsample (unfused form; utils.py:61-72) ---------------------------- */
 int dpig_upsample2x_fwd(const float* x, int N, int H, int W, int C, float* y, void* stream);
 int dpig_upsample2x_bwd(const float* dy, int N, int H, int W, int C, float* dx, void* stream);

@@ -316,3 +316,22 @@ def test_ssim_metric(dev):
     ref2 = O.ssim_G_x(small, small[::-1] / 127.5 - 1)
     got2 = U.ssim_G_x(torch.from_numpy(small).to(dev), torch.from_numpy(small[::-1].copy() / 127.5 - 1).to(dev)).cpu().numpy()
     assert np.abs(got2 - ref2).max() < 2e-4
+
+
+def test_gp_penalty_fused(dev):
+    """trainer.py:222-236: interpolation, and LAMBDA*mean((||g||-1)^2) with its derivative w.r.t. g in one pass."""
+    import dpig_amd.hip_ops as H
+    B, shape = 5, (5, 8, 4, 3)
+    real, fake = _rand(shape, 1), _rand(shape, 2)
+    alpha = _rand((B,), 3, 0.0, 1.0)
+    xh = H.gp_interpolate(real.float().to(dev), fake.float().to(dev), alpha.float().to(dev))
+    _close(xh, real + alpha.reshape(B, 1, 1, 1) * (fake - real))
+    g = (_rand(shape, 4) * 0.3).requires_grad_(True)
+    slopes = torch.sqrt((g * g).reshape(B, -1).sum(1))
+    pen = 10.0 * ((slopes - 1.0) ** 2).mean()
+    pen.backward()
+    p, dg, sl = H.gp_penalty(g.detach().float().to(dev), 10.0)
+    _close(p, pen.reshape(1)); _close(dg, g.grad); _close(sl, slopes)
+    z = torch.zeros(2, 7, device=dev)                       # zero slope: no NaN
+    p0, dg0, _ = H.gp_penalty(z, 10.0)
+    assert float(p0) == 10.0 and float(dg0.abs().max()) == 0.0
