@@ -1,0 +1,98 @@
+"""Size-independent properties of the conv kernels at BASELINE configs[1] sizes (Market 128x64, B=16), where the
+fp64 oracle is too slow to be the reference:
+
+  * adjointness   <conv(x; w), dy> = <x, dgrad(dy; w)> = <w, wgrad(x, dy)>   (the three kernels are one bilinear form),
+  * linearity     conv(a x1 + x2) = a conv(x1) + conv(x2),
+  * a spatially constant input gives the 9 border-class values of sum-over-valid-taps(w) (analytic),
+  * bit-for-bit repeatability (no atomics anywhere on the path).
+
+Dot products are accumulated in fp64 on the device; tolerances are fp32 round-off over the 1e7..1e8-term sums."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+# (name, N, H, W, C, K, k, stride, upsample)
+LAYERS = [
+    ("dec4 3x3", 16, 128, 64, 256, 256, 3, 1, False),
+    ("enc down 3x3 s2", 16, 128, 64, 128, 256, 3, 2, False),
+    ("roi tower 48x48", 112, 48, 48, 128, 128, 3, 1, False),
+    ("dec up 1x1 on 2x-upsampled", 16, 64, 32, 512, 128, 1, 1, True),
+    ("critic 5x5 s2", 16, 64, 32, 64, 128, 5, 2, False),
+    ("image conv 256->3", 16, 128, 64, 256, 3, 3, 1, False),
+    ("stem 3->128", 16, 128, 64, 3, 128, 3, 1, False),
+]
+
+
+def _dot(a, b):
+    return float((a.double() * b.double()).sum())
+
+
+@pytest.mark.parametrize("layer", LAYERS, ids=[l[0] for l in LAYERS])
+def test_adjoint_identities_and_linearity(dev, layer):
+    import dpig_amd.hip_ops as H
+    _, N, Hh, W, C, K, k, s, up = layer
+    g = torch.Generator(device=dev).manual_seed(1)
+    x = torch.randn(N, Hh, W, C, device=dev, generator=g)
+    x2 = torch.randn(N, Hh, W, C, device=dev, generator=g)
+    w = torch.randn(k, k, C, K, device=dev, generator=g) * 0.05
+    y = H.conv2d_fwd(x, w, None, stride=s, upsample2x=up)
+    dy = torch.randn(y.shape, device=dev, generator=g)
+    dx = H.conv2d_dgrad(dy, w, (N, Hh, W, C), stride=s, upsample2x=up)
+    dw = H.conv2d_wgrad(x, dy, (k, k, C, K), stride=s, upsample2x=up)
+    a, b, c = _dot(y, dy), _dot(x, dx), _dot(w, dw)
+    scale = (float((y.double() ** 2).sum()) * float((dy.double() ** 2).sum())) ** 0.5
+    assert abs(a - b) <= 2e-6 * scale and abs(a - c) <= 2e-6 * scale, (a, b, c, scale)
+    # linearity in the input
+    y12 = H.conv2d_fwd(0.5 * x + x2, w, None, stride=s, upsample2x=up)
+    y2 = H.conv2d_fwd(x2, w, None, stride=s, upsample2x=up)
+    err = float((y12 - (0.5 * y + y2)).abs().max())
+    assert err <= 2e-5 * float(y12.abs().max()), err
+    # repeatability
+    assert torch.equal(H.conv2d_fwd(x, w, None, stride=s, upsample2x=up), y)
+    assert torch.equal(H.conv2d_dgrad(dy, w, (N, Hh, W, C), stride=s, upsample2x=up), dx)
+    assert torch.equal(H.conv2d_wgrad(x, dy, (k, k, C, K), stride=s, upsample2x=up), dw)
+
+
+def test_constant_input_gives_border_classes(dev):
+    """SAME 3x3 conv of an all-ones image: every output pixel equals the sum of the filter taps that fall inside the
+    image, i.e. one of 9 values per output channel (what the tiled-embedding collapse relies on)."""
+    import dpig_amd.hip_ops as H
+    N, Hh, W, C, K = 16, 128, 64, 128, 128
+    g = torch.Generator(device=dev).manual_seed(2)
+    w = torch.randn(3, 3, C, K, device=dev, generator=g) * 0.05
+    y = H.conv2d_fwd(torch.ones(N, Hh, W, C, device=dev), w, None)
+    ws = w.double().sum(2)                                           # [3,3,K]
+    rows = {0: ws[1:].sum(0), 1: ws.sum(0), 2: ws[:2].sum(0)}       # top / interior / bottom: valid filter rows
+    for cy, yy in ((0, 0), (1, Hh // 2), (2, Hh - 1)):
+        for cx, xx in ((0, 0), (1, W // 2), (2, W - 1)):
+            r = rows[cy]
+            want = (r[1:].sum(0), r.sum(0), r[:2].sum(0))[cx]
+            got = y[:, yy, xx, :].double()
+            assert float((got - want).abs().max()) <= 2e-5 * float(want.abs().max())
+    inner = y[:, 1:-1, 1:-1, :]
+    assert float((inner - inner[:1, :1, :1, :]).abs().max()) <= 1e-5 * float(inner.abs().max())
+
+
+def test_bf16_mode_adjointness_full_size(dev):
+    """bf16 matrix-pipe mode at full size: fwd / dgrad / wgrad still describe one bilinear form on the ROUNDED operands:
+    <conv(bf(x); bf(w)), bf(dy)> computed three ways (feeding already-rounded tensors makes the kernels' own rounding
+    the identity)."""
+    import dpig_amd.hip_ops as H
+    N, Hh, W, C, K = 16, 128, 64, 256, 256
+    g = torch.Generator(device=dev).manual_seed(3)
+    bf = lambda t: t.bfloat16().float()
+    x, w = bf(torch.randn(N, Hh, W, C, device=dev, generator=g)), bf(torch.randn(3, 3, C, K, device=dev, generator=g) * 0.05)
+    dy = bf(torch.randn(N, Hh, W, K, device=dev, generator=g))
+    H.set_compute("bf16")
+    try:
+        y = H.conv2d_fwd(x, w, None)
+        dx = H.conv2d_dgrad(dy, w, (N, Hh, W, C))
+        dw = H.conv2d_wgrad(x, dy, (3, 3, C, K))
+    finally:
+        H.set_compute("f32")
+    a, b, c = _dot(y, dy), _dot(x, dx), _dot(w, dw)
+    scale = (float((y.double() ** 2).sum()) * float((dy.double() ** 2).sum())) ** 0.5
+    assert abs(a - b) <= 2e-6 * scale and abs(a - c) <= 2e-6 * scale, (a, b, c, scale)
+    yf = H.conv2d_fwd(x, w, None)                    # fp32 pipe on the same (bf16-representable) operands: same products
+    assert float((y - yf).abs().max()) <= 2e-5 * float(yf.abs().max())
