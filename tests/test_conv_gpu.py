@@ -360,3 +360,38 @@ def test_conv_bf16_falls_back_to_fp32_when_ineligible(dev):
     finally:
         H.set_compute("f32")
     assert torch.equal(got, ref)
+
+
+def test_edge_cases_empty_huge_and_misaligned(dev):
+    """Empty batches and > 2 GiB tensors are refused with a status (nothing is launched); operands that are not
+    16-byte aligned take the dword-load variants and still give the right answer."""
+    import ctypes
+    import dpig_amd.hip_ops as H
+    from dpig_amd._lib import lib
+    from oracle import ops as O
+    x = torch.zeros(1, 4, 4, 8, device=dev)
+    w = torch.zeros(3, 3, 8, 8, device=dev)
+    with pytest.raises(RuntimeError):
+        H.conv2d_fwd(torch.zeros(0, 4, 4, 8, device=dev), w)
+    # a descriptor that claims 16 x 4096 x 4096 x 64 floats (16 GiB) on a tiny allocation: refused before any launch
+    d = H._desc(16, 4096, 4096, 64, 64, 3, 3, 1, 64, 64)
+    y = torch.zeros(16, device=dev)
+    rc = lib().dpig_conv2d_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), None, None, 0, None)
+    assert rc != 0 and b"exceeds" in lib().dpig_last_error()
+    d = H._desc(8, 1024, 1024, 64, 64, 3, 3, 1, 64, 64)          # 2 GiB: past the 32-bit buffer-descriptor range
+    rc = lib().dpig_conv2d_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), None, None, 0, None)
+    assert rc != 0 and b"exceeds" in lib().dpig_last_error()
+    # misaligned views (offset by one float) of x, w and the output
+    N, Hh, W, C, K = 2, 9, 7, 36, 40
+    xs = torch.zeros(N * Hh * W * C + 1, device=dev); ws = torch.zeros(9 * C * K + 1, device=dev)
+    xr, wr = _rand((N, Hh, W, C), 1), _rand((3, 3, C, K), 2) * 0.2
+    xs[1:].copy_(xr.float().reshape(-1)); ws[1:].copy_(wr.float().reshape(-1))
+    xv, wv = xs[1:].view(N, Hh, W, C), ws[1:].view(3, 3, C, K)
+    assert xv.data_ptr() % 16 != 0 and wv.data_ptr() % 16 != 0
+    ref = O.conv2d_same(xr, wr, None, 1)
+    _close(H.conv2d_fwd(xv, wv), ref)
+    dy = _rand(tuple(ref.shape), 3)
+    xg = xr.clone().requires_grad_(True); wg = wr.clone().requires_grad_(True)
+    O.conv2d_same(xg, wg, None, 1).backward(dy)
+    _close(H.conv2d_dgrad(dy.float().to(dev), wv, (N, Hh, W, C)), xg.grad)
+    _close(H.conv2d_wgrad(xv, dy.float().to(dev), (3, 3, C, K)), wg.grad)
