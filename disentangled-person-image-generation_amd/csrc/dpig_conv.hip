@@ -71,6 +71,7 @@ struct GGParams {
     unsigned a_bytes, b_bytes;   // byte extents of A and B for the buffer descriptors
     int vec_epi;          // 1: every epilogue operand is 16-byte addressable (float4 path)
     int vec_a;            // 1: the gathered operand alone is 16-byte loadable (thin-N layers: B is not)
+    unsigned mul_hrwr, shr_hrwr, mul_wr, shr_wr;   // magic numbers: row / (Hr*Wr) and rem / Wr without v_rcp sequences
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -106,6 +107,11 @@ __device__ __attribute__((noinline)) void epi_store(float* __restrict__ D, const
         D[(pix + Wd) * ldd + col] = v;
         D[(pix + Wd + 1) * ldd + col] = v;
     }
+}
+
+// n / d for 0 <= n < 2^31 with a precomputed (mul, shr); mul == 0 encodes d == 1
+__device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned shr) {
+    return mul ? (int)(__umulhi((unsigned)n, mul) >> shr) : n;
 }
 
 // ---- buffer-descriptor loads: 32-bit byte offsets, hardware bounds check -----------------------
@@ -217,9 +223,9 @@ __device__ __forceinline__ void gg_mainloop_bf16(const GGParams& p, char* lds, f
         const int m = m0 + (tid >> 4) + 16 * i;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
-        const int n = mm / p.HrWr;
+        const int n = fast_div(mm, p.mul_hrwr, p.shr_hrwr);
         const int rem = mm - n * p.HrWr;
-        const int r = rem / p.Wr;
+        const int r = fast_div(rem, p.mul_wr, p.shr_wr);
         const int c = rem - r * p.Wr;
         a_iy0[i] = ok ? r * p.sr : -(1 << 24);
         a_ix0[i] = c * p.sr;
@@ -386,9 +392,9 @@ __device__ __forceinline__ void gather_gemm_body(const GGParams& p) {
         const int m = m0 + (tid >> 3) + 32 * i;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
-        const int n = mm / p.HrWr;
+        const int n = fast_div(mm, p.mul_hrwr, p.shr_hrwr);
         const int rem = mm - n * p.HrWr;
-        const int r = rem / p.Wr;
+        const int r = fast_div(rem, p.mul_wr, p.shr_wr);
         const int c = rem - r * p.Wr;
         a_iy0[i] = ok ? r * p.sr : -(1 << 24);      // a row beyond M fails every bounds test below
         a_ix0[i] = c * p.sr;
@@ -773,10 +779,6 @@ struct WGParams {
     int d64_oy, d64_ox, d64_n;                     //     ... and of the bf16 loop's 64 (+ whole images, generic variant)
 };
 
-// n / d for 0 <= n < 2^31 with a precomputed (mul, shr); mul == 0 encodes d == 1
-__device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned shr) {
-    return mul ? (int)(__umulhi((unsigned)n, mul) >> shr) : n;
-}
 
 // bf16 matrix-pipe variant of the stride-1 wgrad pixel loop (see gg_mainloop_bf16 for the operand format).
 // Both operands are pixel-major in HBM ([pixel][channel]) while the MFMA wants 8 consecutive k (= pixels) per
@@ -1326,6 +1328,8 @@ static int gg_bk(const DpigConvDesc* d, int lda, int Cs, int Ncols) {
 // derived fields of one problem; *vec / *narrow select the kernel variant
 static int prepare_gg(GGParams& p, int nimg, long filter_elems, bool* vec, bool* narrow, bool bf16 = false) {
     p.HrWr = p.Hr * p.Wr;
+    find_divisor(p.HrWr, &p.mul_hrwr, &p.shr_hrwr);
+    find_divisor(p.Wr, &p.mul_wr, &p.shr_wr);
     const long a_elems = ((long)nimg * p.Hs * p.Ws - 1) * p.lda + p.Cs;
     if (a_elems * 4 >= 0x7fffffffL || filter_elems * 4 >= 0x7fffffffL)
         return fail(DPIG_EINVAL, "tensor exceeds the 2 GiB buffer-descriptor range");
