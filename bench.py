@@ -194,7 +194,7 @@ def main():
                 traffic = json.load(open(tpath)).get("conv_fwd_hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"bound": "mfma", "kernel": "dpig::gather_gemm_kernel<false, true, false> (conv fwd implicit GEMM, fp32 MFMA)",
+        roofline = {"bound": "mfma", "kernel": "dpig::gather_gemm_kernel<false, true, false, false> (conv fwd implicit GEMM, fp32 MFMA)",
                     "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
                     "launches_per_step": nl // nrep,
