@@ -34,6 +34,9 @@ WORKLOADS = {
     "market128-wgan-gp": ("trainer", "DPIG_Encoder_GAN_BodyROI_FgBg", {"gan_mode": "wgan-gp"}, 16,
                           "Market-1501 128x64 stage-I with MODE='wgan-gp' (LayerNorm critic, gradient penalty, "
                           "g_optim + 5 critic iterations per step, trainer.py:336-347)"),
+    "market128-stage2": ("trainer_stage2", "DPIG_Encoder_subSampleAppNetFgBg_GAN_BodyROI", {}, 64,
+                         "Market-1501 128x64 stage-II embedding GAN (model 3: frozen encoder forward x10 per step + "
+                         "Gaussian FC mappers / FC critics, MODE='wgan', 5 critic iterations per side)"),
     "df256": ("trainer_256", "DPIG_Encoder_GAN_BodyROI_256", {"img_H": 256, "img_W": 256}, 8,
               "DeepFashion 256x256 stage-I (trainer_256.py path), g_optim + d_optim per step"),
 }
@@ -136,7 +139,7 @@ def main():
     headline = args.workload == "market128" and args.dtype == "f32"
     if not headline:                          # information lines: no roofline / CPU legs, eager launches
         args.no_roofline = args.no_cpu_baseline = True
-        args.no_graph = args.no_graph or args.workload == "market128-wgan-gp"
+        args.no_graph = args.no_graph or args.workload in ("market128-wgan-gp", "market128-stage2")
 
     np.random.seed(0)                         # identical initial weights on every rank (+ broadcast)
     B = args.batch or wl_batch
@@ -154,12 +157,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    step_fn = (lambda: tr.train_step(batch_g)) if args.workload == "market128-stage2" else (lambda: tr.train_step(batch_g, batch_d))
     for _ in range(args.warmup):
-        tr.train_step(batch_g, batch_d)
+        step_fn()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        out = tr.train_step(batch_g, batch_d)
+        out = step_fn()
     sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
