@@ -1,99 +1,64 @@
-"""tflib.ops.conv2d drop-in (reference tflib/ops/conv2d.py:6-123)."""
+"""tflib.ops.conv2d drop-in: `Conv2D(name, input_dim, output_dim, filter_size, inputs, ...)` on logical-NCHW
+tensors with the reference's signature and variable names (`<name>.Filters` HWIO, `<name>.Biases`, `<name>.g`;
+reference tflib/ops/conv2d.py:20-123): SAME padding, stride 1 or 2, optional PixelCNN mask and weight norm,
+computed by `dpig_conv2d_*`."""
 import numpy as np
 import torch
 
 from ... import autograd as A
 from ... import tflib as lib
 from ..._lib import ACT_LRELU, ACT_NONE, ACT_RELU
+from . import _init
 from ._layout import nchw_to_nhwc_view, nhwc_to_nchw_view
 
-_default_weightnorm = False
+_SW = _init.Switches()
+_ACT = {None: ACT_NONE, 'relu': ACT_RELU, 'lrelu': ACT_LRELU}
 
 
 def enable_default_weightnorm():
-    global _default_weightnorm
-    _default_weightnorm = True
-
-
-_weights_stdev = None
+    _SW.weightnorm = True
 
 
 def set_weights_stdev(weights_stdev):
-    global _weights_stdev
-    _weights_stdev = weights_stdev
+    _SW.stdev = weights_stdev
 
 
 def unset_weights_stdev():
-    global _weights_stdev
-    _weights_stdev = None
+    _SW.stdev = None
+
+
+def _pixelcnn_mask(kind, groups, k, cin, cout):
+    """Causal filter mask of PixelCNN type 'a' / 'b' (conv2d.py:40-58): nothing below the centre row or right of the
+    centre tap; at the centre, channel group i of the input may feed group j of the output only if i < j ('a') or
+    i <= j ('b')."""
+    m = np.ones((k, k, cin, cout), dtype='float32')
+    c = k // 2
+    m[c + 1:] = 0.
+    m[c, c + 1:] = 0.
+    for i in range(groups):
+        for j in range(groups):
+            if i > j or (kind == 'a' and i == j):
+                m[c, c, i::groups, j::groups] = 0.
+    return m
 
 
 def Conv2D(name, input_dim, output_dim, filter_size, inputs, he_init=True, mask_type=None, stride=1,
            weightnorm=None, biases=True, gain=1., fused_act=None, alpha=0.2):
-    """
-    inputs: tensor of shape (batch size, num channels, height, width)
-    mask_type: one of None, 'a', 'b'
-
-    returns: tensor of shape (batch size, num channels, height, width)
-
-    Same signature and semantics as the reference (conv2d.py:20): SAME padding, HWIO filter
-    `<name>.Filters` initialised uniform(+-stdev*sqrt(3)), optional weight-norm `<name>.g`,
-    PixelCNN mask, bias `<name>.Biases`.  Extension (keyword-only in spirit): `fused_act` in
-    {None,'relu','lrelu'} fuses the activation the caller would apply next into the conv epilogue.
-    """
-    mask = None
+    """inputs / result: (batch, channels, height, width).  mask_type: None or ('a'|'b', n_channel_groups).
+    `fused_act` in {None,'relu','lrelu'} (extension) folds the caller's next activation into the conv epilogue."""
+    k = filter_size
+    fan_in, fan_out = input_dim * k ** 2, output_dim * k ** 2 / (stride ** 2)
+    if mask_type is not None:                      # roughly half of the taps are masked away
+        fan_in, fan_out = fan_in / 2., fan_out / 2.
+    fresh = None
+    if name + '.Filters' not in lib._params:
+        fresh = _init.conv_filter_values(_SW, (k, k, input_dim, output_dim), fan_in, fan_out, he_init, gain)
+    filters = lib.param(name + '.Filters', fresh)
+    if _SW.weightnorm if weightnorm is None else weightnorm:
+        filters = _init.weight_normalised(name, filters, fresh, reduce_axes=(0, 1, 2))
     if mask_type is not None:
-        mask_type, mask_n_channels = mask_type
-        mask = np.ones((filter_size, filter_size, input_dim, output_dim), dtype='float32')
-        center = filter_size // 2
-        # Mask out future locations; filter shape is (height, width, input channels, output channels)
-        mask[center + 1:, :, :, :] = 0.
-        mask[center, center + 1:, :, :] = 0.
-        # Mask out future channels
-        for i in range(mask_n_channels):
-            for j in range(mask_n_channels):
-                if (mask_type == 'a' and i >= j) or (mask_type == 'b' and i > j):
-                    mask[center, center, i::mask_n_channels, j::mask_n_channels] = 0.
-
-    def uniform(stdev, size):
-        return np.random.uniform(low=-stdev * np.sqrt(3), high=stdev * np.sqrt(3), size=size).astype('float32')
-
-    fan_in = input_dim * filter_size ** 2
-    fan_out = output_dim * filter_size ** 2 / (stride ** 2)
-    if mask_type is not None:  # only approximately correct
-        fan_in /= 2.
-        fan_out /= 2.
-    if he_init:
-        filters_stdev = np.sqrt(4. / (fan_in + fan_out))
-    else:  # Normalized init (Glorot & Bengio)
-        filters_stdev = np.sqrt(2. / (fan_in + fan_out))
-
-    if name + '.Filters' in lib._params:
-        filter_values = None
-    elif _weights_stdev is not None:
-        filter_values = uniform(_weights_stdev, (filter_size, filter_size, input_dim, output_dim))
-    else:
-        filter_values = uniform(filters_stdev, (filter_size, filter_size, input_dim, output_dim))
-    if filter_values is not None:
-        filter_values *= gain
-    filters = lib.param(name + '.Filters', filter_values)
-
-    if weightnorm is None:
-        weightnorm = _default_weightnorm
-    if weightnorm:
-        if name + '.g' in lib._params:
-            target_norms = lib.param(name + '.g')
-        else:
-            init = filter_values if filter_values is not None else filters.detach().cpu().numpy()
-            target_norms = lib.param(name + '.g', np.sqrt(np.sum(np.square(init), axis=(0, 1, 2))))
-        norms = torch.sqrt(torch.sum(filters * filters, dim=(0, 1, 2)))
-        filters = filters * (target_norms / norms)
-    if mask is not None:
-        filters = filters * torch.as_tensor(mask, device=filters.device)
-
-    _biases = lib.param(name + '.Biases', np.zeros(output_dim, dtype='float32')) if biases else None
-
-    act = {None: ACT_NONE, 'relu': ACT_RELU, 'lrelu': ACT_LRELU}[fused_act]
-    x = nchw_to_nhwc_view(inputs)
-    y = A.conv2d(x, filters, _biases, stride=stride, act=act, alpha=alpha)
+        filters = filters * torch.as_tensor(_pixelcnn_mask(mask_type[0], mask_type[1], k, input_dim, output_dim),
+                                            device=filters.device)
+    bias = _init.zero_bias(name + '.Biases', output_dim) if biases else None
+    y = A.conv2d(nchw_to_nhwc_view(inputs), filters, bias, stride=stride, act=_ACT[fused_act], alpha=alpha)
     return nhwc_to_nchw_view(y)
