@@ -4,7 +4,7 @@
  *
  * Every entry point is `extern "C"`, takes plain device pointers + sizes + a HIP stream (passed as
  * `void*`, i.e. a `hipStream_t`), never allocates, never synchronises, and returns an int status:
- *   0 = DPIG_OK, negative = error (see dpig_last_error()).  All tensors are fp32, activations are
+ *   0 = DPIG_OK, negative = error (see dpig_last_error()).  All tensors are fp32 in memory, activations are
  *   *physically* NHWC with an explicit channel stride (`ld*`, in elements) so that channel-concats
  *   and slices are free views; filters are HWIO exactly as the reference stores them.
  *
@@ -23,6 +23,13 @@
  *   dpig_act_bwd/bias    the ReLU / LeakyReLU / bias_add gradients TF autodiff emits
  *   dpig_adam_step       tf.train.AdamOptimizer  trainer.py:131-146
  *   dpig_sce_* / l1      sigmoid_cross_entropy_with_logits / L1  trainer.py:238-245, 607, 623
+ *   dpig_rmsprop_step / dpig_clip   tf.train.RMSPropOptimizer + clip_by_value (wgan mode)  trainer.py:119-128
+ *   dpig_gp_*            the WGAN-GP penalty term around tf.gradients  trainer.py:222-236
+ *   dpig_bn_sqdev/apply/bwd_sums/bwd_apply   the same batch norm in stages, for statistics over data-parallel ranks
+ *   dpig_pose_*          coord2channel_simple_rcv + tf_poseInflate of the input pipeline  utils.py:237-318
+ *   dpig_ssim_gray_u8    skimage rgb2gray + compare_ssim of trainer.generate() / score.py  trainer.py:516-521
+ * DpigConvDesc.compute selects the matrix-pipe arithmetic of the three conv entry points (fp32, or bf16 operands with
+ * fp32 accumulation on unchanged fp32 tensors).
  */
 #ifndef DPIG_HIP_H
 #define DPIG_HIP_H
