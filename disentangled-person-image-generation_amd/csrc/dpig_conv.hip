@@ -920,13 +920,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
     const int l31 = lane & 31, half = lane >> 5;
 
     const int mtiles = FLAT ? (p.ntaps * p.C + BM - 1) / BM : p.ntaps * p.cblocks;
-    const int tile = xcd_remap(blockIdx.x, mtiles * p.ntiles);
+    // The (tile, split) pairs are remapped as ONE list with the tile index fastest: the workgroups an XCD receives
+    // (linear id % 8) then cover whole pixel ranges -- all taps / channel blocks of one split -- so the dy tile and the
+    // overlapping x tiles of a pixel range are fetched into that XCD's L2 once instead of once per XCD.
+    const int ntl = mtiles * p.ntiles;
+    const int item = xcd_remap((int)(blockIdx.x + gridDim.x * blockIdx.z), ntl * (int)gridDim.z);
+    const int split = item / ntl;
+    const int tile = item - split * ntl;
     const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
     const int tap = FLAT ? 0 : mt / p.cblocks;
     const int ci0 = FLAT ? mt * BM : (mt - tap * p.cblocks) * BM;     // FLAT: first flattened (tap,ci) row
     const int co0 = nt * BNT;
     const int oyoff = tap / p.S - p.pad_t, oxoff = tap % p.S - p.pad_l, wt = tap;
-    const int split = blockIdx.z;
     const int kt_begin = split * p.tiles_per_split;
     const int kt_end = min(p.ktiles, kt_begin + p.tiles_per_split);
 
