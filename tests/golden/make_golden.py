@@ -7,6 +7,7 @@ regenerated bit-identically from seeds (dpig_amd.synthetic.make_batch(seed) and
 oracle.models.ParamStore(seed), numpy Generator streams), only expected outputs are committed.
 
     python tests/golden/make_golden.py            (~5 min on 8 cores)
+    python tests/golden/make_golden.py --small    the width-16 model (seconds): the fixture the CPU suite re-derives
 """
 import os
 import sys
@@ -34,9 +35,37 @@ def subsample(t, n=4096):
     return f[::step][:n].to(torch.float64).numpy().copy()
 
 
+def small_outputs():
+    """Width-16 / z-8 model, same seeds: forward values, losses and two kink-robust gradient vectors.  Shared by the
+    generator (--small) and tests/test_oracle.py::test_oracle_reproduces_small_golden."""
+    ob = OM.batch_to_torch(synthetic.make_batch(B, seed=BATCH_SEED))
+    P = OM.ParamStore(seed=PARAM_SEED)
+    embs, G = OM.stage1_forward(P, ob, hidden_num=16, z_num=8)
+    d_fake = OM.dcgan_discriminator(P, G, "dcgan")
+    d_real = OM.dcgan_discriminator(P, ob["x"], "dcgan")
+    g_only, d_loss = OM.gan_loss("dcgan", d_real, d_fake)
+    l1 = (G - ob["x"]).abs().mean()
+    gen = torch.Generator().manual_seed(READOUT_SEED)
+    r = torch.randn(tuple(G.shape), generator=gen, dtype=torch.float64)
+    names = ["Encoder/G_encoder/Conv/weights", "ID_AE/G/Conv/weights"]
+    grads = torch.autograd.grad((G * r).sum(), [P.p[n] for n in names])
+    out = {"embs": embs.detach().numpy(), "G": subsample(G, 8192), "d_real": d_real.detach().numpy(),
+           "d_fake": d_fake.detach().numpy(), "g_loss": np.array((g_only + 20.0 * l1).item()),
+           "L1Loss": np.array(l1.item()), "d_loss": np.array(d_loss.item())}
+    for n, g in zip(names, grads):
+        out["grad/" + n] = subsample(g)
+    return out
+
+
 def main():
     torch.set_num_threads(os.cpu_count() or 1)
     t0 = time.time()
+    if "--small" in sys.argv:
+        out = small_outputs()
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stage1_market_b2_w16.npz")
+        np.savez_compressed(path, **out)
+        print("wrote %s (%.0f KB) in %.1fs" % (path, os.path.getsize(path) / 1024.0, time.time() - t0))
+        return
     ob = OM.batch_to_torch(synthetic.make_batch(B, seed=BATCH_SEED))
     P = OM.ParamStore(seed=PARAM_SEED)
     taps = {}

@@ -227,3 +227,22 @@ def test_ssim_skimage_restatement_equals_window_loops():
     assert abs(ops.ssim_skimage(ga, gb, R) - naive.ssim_window_loops(ga, gb, R)) < 1e-12
     assert abs(ops.ssim_skimage(ga, ga, R) - 1.0) < 1e-12
     assert 0.0 <= gb.min() and gb.max() <= 1.0
+
+
+def test_oracle_reproduces_small_golden():
+    """The committed width-16 golden vectors (tests/golden/stage1_market_b2_w16.npz, written by
+    `make_golden.py --small`) are re-derived from seeds by today's oracle: any change of the oracle's arithmetic, of
+    the synthetic inputs or of the parameter initialisation shows up here, on the CPU, in seconds."""
+    import importlib.util
+    import os
+    import numpy as np
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(here, "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    want = np.load(os.path.join(here, "golden", "stage1_market_b2_w16.npz"))
+    got = mg.small_outputs()
+    assert set(got.keys()) == set(want.keys())
+    for k in want.keys():
+        scale = max(float(np.abs(want[k]).max()), 1e-12)
+        assert float(np.abs(np.asarray(got[k]) - want[k]).max()) <= 1e-9 * scale, k
