@@ -266,6 +266,24 @@ def test_deconv_backward(dev):
     _close(gw.grad, w.grad, 1e-4)
 
 
+def test_pose_maps_equal_reference_rasteriser(dev):
+    """The device rasteriser against maps produced by the reference's own numpy code (utils.py py_poseInflate, the
+    function tester.py:399-400 calls; fixture tests/golden/pose_reference.npz, generated by make_pose_golden.py)."""
+    import os
+    import dpig_amd.utils as U
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pose_reference.npz"))
+    for name in ("pixel_128x64", "normalized_128x64", "normalized_256x256"):
+        rcv = z[name + "/rcv"].astype(np.float32)
+        norm, Hh, W = (int(v) for v in z[name + "/meta"])
+        B, K = rcv.shape[:2]
+        want = np.unpackbits(z[name + "/bits"])[:B * Hh * W * K].reshape(B, Hh, W, K).astype(np.float32) * 2 - 1
+        t = torch.from_numpy(rcv.reshape(B, K * 3)).to(dev)
+        fused = U.pose_target_from_rcv(t, K, bool(norm), Hh, W)
+        assert torch.equal(fused.cpu(), torch.from_numpy(want)), name
+        chained = U.tf_poseInflate(U.coord2channel_simple_rcv(t, K, bool(norm), Hh, W), K, 4, Hh, W)
+        assert torch.equal(chained.cpu(), torch.from_numpy(want)), name
+
+
 @pytest.mark.parametrize("normalized", [True, False])
 def test_pose_maps(dev, normalized):
     """coord2channel_simple_rcv / tf_poseInflate (utils.py:237-318) and the fused rasteriser."""

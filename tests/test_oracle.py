@@ -246,3 +246,35 @@ def test_oracle_reproduces_small_golden():
     for k in want.keys():
         scale = max(float(np.abs(want[k]).max()), 1e-12)
         assert float(np.abs(np.asarray(got[k]) - want[k]).max()) <= 1e-9 * scale, k
+
+
+# ---- pinned against the reference's own python: tests/golden/pose_reference.npz holds outputs of utils.py
+#      py_poseInflate / _getSparsePose / _sparse2dense, executed from the reference's text by make_pose_golden.py -------
+def _pose_reference_cases():
+    import os
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "pose_reference.npz"))
+    for name in ("pixel_128x64", "normalized_128x64", "normalized_256x256"):
+        rcv = z[name + "/rcv"]
+        norm, H, W = (int(v) for v in z[name + "/meta"])
+        n = rcv.shape[0] * H * W * rcv.shape[1]
+        want = np.unpackbits(z[name + "/bits"])[:n].reshape(rcv.shape[0], H, W, rcv.shape[1]).astype(bool)
+        yield name, z, rcv, bool(norm), H, W, want
+
+
+def test_pose_oracle_equals_reference_py_poseInflate():
+    """The TF-graph pose pipeline as restated in oracle/ops.py (coord2channel_simple_rcv -> tf_poseInflate,
+    utils.py:237-318) produces exactly the maps the reference's numpy rasteriser py_poseInflate (utils.py:320-347)
+    produced for the same keypoints; for pixel coordinates also the dataset converter's 'Solid' channels."""
+    seen = 0
+    for name, z, rcv, norm, H, W, want in _pose_reference_cases():
+        B, K = rcv.shape[:2]
+        t = torch.from_numpy(rcv.reshape(B, K * 3)).double()
+        got = O.tf_poseInflate(O.coord2channel_simple_rcv(t, K, norm, H, W), K, 4, H, W).numpy()
+        assert set(np.unique(got)) <= {-1.0, 1.0}
+        assert np.array_equal(got > 0, want), name
+        assert want.any(axis=(1, 2)).sum() == int((rcv[..., 2] != 0).sum())       # one disc per visible keypoint
+        if name == "pixel_128x64":
+            solid = np.unpackbits(z[name + "/solid_bits"])[:want.size].reshape(want.shape).astype(bool)
+            assert np.array_equal(solid, want)
+        seen += 1
+    assert seen == 3
