@@ -110,3 +110,55 @@ def test_product_path_has_no_cpu_fallback(lib):
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle", src, flags=re.M), f
+
+
+# ---- property tests of the host-side planning code (pure host functions of the library; no GPU) ------------------
+from hypothesis import given, settings, strategies as st   # noqa: E402
+
+
+@settings(max_examples=300, deadline=None)
+@given(st.integers(1, 4096), st.integers(1, 7), st.integers(1, 2))
+def test_same_pad_equals_the_oracle_formula(inp, k, s):
+    from dpig_amd import _lib
+    from oracle import ops as O
+    o, p = ctypes.c_int(), ctypes.c_int()
+    assert _lib.lib().dpig_same_pad(inp, k, s, ctypes.byref(o), ctypes.byref(p)) == 0
+    eo, before, after = O.same_pad(inp, k, s)
+    assert (o.value, p.value) == (eo, before) and before <= after <= before + 1
+
+
+_dims = st.tuples(st.integers(1, 32), st.sampled_from([3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 128]),
+                  st.sampled_from([3, 4, 6, 8, 12, 16, 24, 32, 48, 64]), st.sampled_from([3, 18, 32, 64, 128, 256, 640, 1024]),
+                  st.sampled_from([3, 32, 64, 128, 256, 640, 1024]), st.sampled_from([1, 3, 5]), st.sampled_from([1, 2]),
+                  st.sampled_from([0, 1]))
+
+
+@settings(max_examples=200, deadline=None)
+@given(_dims)
+def test_workspace_plan_invariants(dims):
+    """For any layer shape: the query is total (no crash, 0 for bad descriptors), forcing split_k=1 on the GEMM
+    kernels needs no workspace, and an automatic plan asks for a whole number of partial-sum slabs, at most 64."""
+    from dpig_amd import _lib
+    N, H, W, C, K, k, s, compute = dims
+    h = _lib.lib()
+    d = _lib.DpigConvDesc()
+    for name, v in dict(N=N, H=H, W=W, C=C, K=K, R=k, S=k, stride=s, pad_t=-1, pad_l=-1, ldx=C, ldy=K,
+                        compute=compute).items():
+        setattr(d, name, v)
+    Ho, Wo = -(-H // s), -(-W // s)
+    slab = {0: N * Ho * Wo * K * 4, 1: N * H * W * C * 4, 2: (k * k * C * K + K) * 4}
+    thin = C <= 4 or K <= 4 or (C == 18 and k == 3)              # vector-ALU kernels have their own (small) workspaces
+    for which in (0, 1, 2):
+        auto = h.dpig_conv2d_workspace_bytes(ctypes.byref(d), which)
+        assert 0 <= auto < (1 << 40)
+        if not thin and auto:
+            if which == 1 and s == 2:                              # parity classes: slabs of the class sizes, same bound
+                assert auto <= 64 * slab[1]
+            else:
+                assert auto % slab[which] == 0 and auto // slab[which] <= 64, (which, auto, slab[which])
+        d.split_k = 1
+        if not thin:
+            assert h.dpig_conv2d_workspace_bytes(ctypes.byref(d), which) == 0
+        d.split_k = 0
+    d.stride = 3
+    assert h.dpig_conv2d_workspace_bytes(ctypes.byref(d), 0) == 0
