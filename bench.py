@@ -103,13 +103,14 @@ def main():
     ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
                     help="matrix-pipe arithmetic of the conv GEMMs; bf16 (fp32 tensors and accumulation) is an information "
                          "line: the BASELINE metric is quoted at fp32")
-    ap.add_argument("--host-input", nargs="?", const="prefetch", default=None, choices=["prefetch", "serial", "keypoints", "keypoints-serial"],
+    ap.add_argument("--host-input", nargs="?", const="prefetch", default=None, choices=["prefetch", "serial", "keypoints", "keypoints-serial", "keypoints-packed", "packed"],
                     help="information line: both batches start every step in pinned HOST memory, so the timed region "
                          "includes their PCIe upload (the BASELINE value is quoted with inputs resident in HBM). "
                          "'prefetch' uploads on a copy stream one step ahead (dpig_amd.prefetch), 'serial' on the compute stream, "
                          "'keypoints' = prefetch of the 18 (row, col, visibility) triplets instead of the dense pose maps, "
                          "rasterised on the device (what tfrecord.batch_from_examples feeds); 'keypoints-serial' = the same upload on "
-                         "the compute stream, no second queue")
+                         "the compute stream, no second queue; 'packed' / 'keypoints-packed' = prefetch with the batch packed "
+                         "into one pinned buffer and moved by one copy")
     ap.add_argument("--workload", default="market128", choices=sorted(WORKLOADS),
                     help="market128 = the BASELINE metric (configs[1]); the others are information lines for DESIGN.md")
     args = ap.parse_args()
@@ -165,7 +166,7 @@ def main():
     if args.host_input:                       # the replayed graphs read their own static buffers; _feed copies into them
         batch_g = {k: v.cpu().pin_memory() for k, v in batch_g.items()}
         batch_d = {k: v.cpu().pin_memory() for k, v in batch_d.items()}
-        if args.host_input in ("prefetch", "keypoints", "keypoints-serial"):
+        if args.host_input != "serial":
             import itertools
             from dpig_amd import utils
             from dpig_amd.prefetch import DevicePrefetcher
@@ -187,14 +188,15 @@ def main():
                     while True:
                         yield {k: v.to(dev, non_blocking=True) for k, v in host.items()}
                 batch_g, batch_d = sparse(batch_g, 1), sparse(batch_d, 2)
-                if args.host_input == "keypoints":
-                    feed_g = rasterised(DevicePrefetcher(itertools.repeat(batch_g), dev))
-                    feed_d = rasterised(DevicePrefetcher(itertools.repeat(batch_d), dev))
+                if args.host_input != "keypoints-serial":
+                    pk = args.host_input.endswith("packed")
+                    feed_g = rasterised(DevicePrefetcher(itertools.repeat(batch_g), dev, packed=pk))
+                    feed_d = rasterised(DevicePrefetcher(itertools.repeat(batch_d), dev, packed=pk))
                 else:
                     feed_g, feed_d = rasterised(uploaded(batch_g)), rasterised(uploaded(batch_d))
             else:
-                feed_g = DevicePrefetcher(itertools.repeat(batch_g), dev)
-                feed_d = DevicePrefetcher(itertools.repeat(batch_d), dev)
+                feed_g = DevicePrefetcher(itertools.repeat(batch_g), dev, packed=args.host_input == "packed")
+                feed_d = DevicePrefetcher(itertools.repeat(batch_d), dev, packed=args.host_input == "packed")
 
     def sync():
         if world > 1:

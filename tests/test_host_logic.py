@@ -117,3 +117,20 @@ def test_config_matches_reference_defaults():
     c = Config()
     assert (c.batch_size, c.img_H, c.img_W, c.conv_hidden_num, c.z_num, c.repeat_num) == (16, 128, 64, 128, 64, 5)
     assert Config(img_H=256, img_W=256).repeat_num == 6
+
+
+def test_packed_batch_layout_round_trip():
+    """prefetch.PackedLayout: fields 256-byte aligned inside one flat buffer, views carry dtype and shape, a batch of a
+    different structure is not mistaken for the same layout."""
+    import torch
+    from dpig_amd.prefetch import PackedLayout
+    b = {"x": torch.randn(4, 33, 17, 3), "ids": torch.randint(0, 1 << 30, (4, 7), dtype=torch.int32),
+         "vis": torch.rand(4, 7), "empty": torch.zeros(0, 3)}
+    L = PackedLayout(b)
+    assert all(off % 256 == 0 for _, _, _, off, _ in L.fields) and L.nbytes % 256 == 0
+    flat = torch.full((L.nbytes,), 0xAB, dtype=torch.uint8)
+    L.pack(b, flat)
+    out = L.views(flat.clone())
+    assert all(out[k].dtype == b[k].dtype and torch.equal(out[k], b[k]) for k in b)
+    assert L.matches(b) and not L.matches({k: v for k, v in b.items() if k != "vis"})
+    assert not L.matches(dict(b, x=b["x"].double()))

@@ -17,12 +17,13 @@ def _host_batches(n, seed=0):
     return out
 
 
+@pytest.mark.parametrize("packed", [False, True])
 @pytest.mark.parametrize("depth", [1, 2, 3])
-def test_order_values_and_exhaustion(depth):
+def test_order_values_and_exhaustion(depth, packed):
     from dpig_amd.prefetch import DevicePrefetcher
     host = _host_batches(7)
     got = []
-    for b in DevicePrefetcher(host, "cuda:0", depth=depth):
+    for b in DevicePrefetcher(host, "cuda:0", depth=depth, packed=packed):
         assert b["x"].is_cuda and b["ids"].dtype == torch.int32
         got.append({k: v.clone() for k, v in b.items()})
     assert len(got) == len(host)
@@ -31,12 +32,13 @@ def test_order_values_and_exhaustion(depth):
             assert torch.equal(g[k].cpu(), h[k])
 
 
-def test_slow_consumer_never_sees_a_recycled_slot():
+@pytest.mark.parametrize("packed", [False, True])
+def test_slow_consumer_never_sees_a_recycled_slot(packed):
     from dpig_amd.prefetch import DevicePrefetcher
     host = _host_batches(12, seed=3)
     big = torch.randn(4096, 4096, device="cuda:0")
     got = []
-    for b in DevicePrefetcher(host, "cuda:0", depth=1):
+    for b in DevicePrefetcher(host, "cuda:0", depth=1, packed=packed):
         for _ in range(6):                      # keep the compute stream busy well past the next uploads
             big = torch.tanh(big @ big * 1e-2)
         got.append(b["x"] + 0)                  # read the slot late on the compute stream
@@ -64,7 +66,7 @@ def test_trainer_step_through_prefetcher_matches_resident_batch():
         if fed:
             hg = {k: v.cpu().pin_memory() for k, v in bg.items()}
             hd = {k: v.cpu().pin_memory() for k, v in bd.items()}
-            fg, fd = DevicePrefetcher([hg, hg], dev), DevicePrefetcher([hd, hd], dev)
+            fg, fd = DevicePrefetcher([hg, hg], dev), DevicePrefetcher([hd, hd], dev, packed=True)
             outs = [tr.train_step(next(fg), next(fd)) for _ in range(2)]
         else:
             outs = [tr.train_step(bg, bd) for _ in range(2)]
