@@ -53,6 +53,14 @@ class DPIG_FourNetsFgBg_testOnly(object):
     def run(self, batch, pose_rcv, z_fg=None, z_bg=None, z_pose=None):
         """batch: dict with x, mask_r6, part_bbox, part_vis (as the trainers take); pose_rcv: [B, 18*3] pixel
         coordinates + visibility.  z_*: optional fixed noise for the Gaussian mappers (else drawn on the device)."""
+        if not self.built:
+            from . import tfckpt
+            if tfckpt.wants_restore(self.config):        # tester.py:17-64: build the graph, then restore into it
+                self._forward(batch, pose_rcv, z_fg, z_bg, z_pose)
+                tfckpt.restore_from_config(self.config)
+        return self._forward(batch, pose_rcv, z_fg, z_bg, z_pose)
+
+    def _forward(self, batch, pose_rcv, z_fg=None, z_bg=None, z_pose=None):
         H.set_compute(getattr(self.config, "compute_dtype", "f32"))
         B, K = self.batch_size, self.keypoint_num
         reuse = self.built

@@ -27,12 +27,60 @@ for _i in range(256):
 _TABLE = np.array(_TABLE, dtype=np.uint32)
 
 
-def crc32c(data):
+def _crc32c_scalar(data):
     crc = 0xFFFFFFFF
     tab = _TABLE
     for b in bytes(data):
         crc = int(tab[(crc ^ b) & 0xFF]) ^ (crc >> 8)
     return crc ^ 0xFFFFFFFF
+
+
+# The register update is linear over GF(2) in (state, data): the CRC of a long message is assembled from the raw
+# (zero-initialised) registers of equal-length chunks, all advanced together one byte per numpy step, and the
+# "append n zero bytes" operator Z_n (a 32x32 bit matrix, here 32 column words) that shifts an earlier register past
+# the bytes that follow it.  Leading zero bytes leave a zero register at zero, so the front is padded for free.
+def _gf2_apply(cols, v):
+    out, i = 0, 0
+    while v:
+        if v & 1:
+            out ^= cols[i]
+        v >>= 1
+        i += 1
+    return out
+
+
+def _zeros_operator(nbytes):
+    """Columns of Z_n: register -> register after n zero bytes."""
+    result = [1 << i for i in range(32)]                                       # identity
+    power = [int(_TABLE[(1 << i) & 0xFF]) ^ ((1 << i) >> 8) for i in range(32)]  # one zero byte
+    while nbytes:
+        if nbytes & 1:
+            result = [_gf2_apply(power, c) for c in result]
+        power = [_gf2_apply(power, c) for c in power]
+        nbytes >>= 1
+    return result
+
+
+def crc32c(data):
+    """CRC-32C (Castagnoli) of a bytes-like object; large inputs take the chunk-parallel numpy path."""
+    a = np.frombuffer(data, dtype=np.uint8) if not isinstance(data, np.ndarray) else data.reshape(-1).view(np.uint8)
+    n = a.size
+    if n < 2048:
+        return _crc32c_scalar(a.tobytes())
+    m = int(min(65536, max(64, n // 512)))                  # chunks advanced in lock step
+    L = -(-n // m)
+    padded = np.zeros(m * L, dtype=np.uint8)
+    padded[m * L - n:] = a
+    cols = np.ascontiguousarray(padded.reshape(m, L).T)     # [L, m]: byte i of every chunk is contiguous
+    state = np.zeros(m, dtype=np.uint32)
+    tab = _TABLE
+    for i in range(L):
+        state = tab[(state ^ cols[i]) & 0xFF] ^ (state >> 8)
+    zl = _zeros_operator(L)
+    acc = 0
+    for r in state.tolist():
+        acc = _gf2_apply(zl, acc) ^ r
+    return (_gf2_apply(_zeros_operator(n), 0xFFFFFFFF) ^ acc) ^ 0xFFFFFFFF
 
 
 def masked_crc32c(data):

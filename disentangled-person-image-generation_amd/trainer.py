@@ -230,6 +230,10 @@ class Config(object):
                                          # gradient all-reduce overlaps the encoder's backward pass
         self.compute_dtype = 'f32'       # 'bf16': conv GEMMs on the bf16 matrix pipe (fp32 tensors / accumulation /
                                          # master weights; BASELINE configs 3-5); 'f32' is the reference's arithmetic
+        self.pretrained_path = None      # V2 checkpoint prefixes (trainer.py:180-212): 'Encoder' + 'ID_AE' variables,
+        self.pretrained_poseAE_path = None   # the 'PoseAE' variables,
+        self.ckpt_path = None            # every variable of the model
+        self.model_dir = None            # where save_checkpoint() writes model.ckpt-<step>
         self.__dict__.update(kw)
         self.repeat_num = int(math.log2(self.img_H)) - 2    # trainer.py:75
 
@@ -302,6 +306,7 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
             G, g_var = self.generate(embs, batch["pose"])
             self.discriminate(batch["x"])
         self.built = True
+        self.restore_from_config()
         self.G_var = g_var + enc_var                       # trainer.py:596
         self.D_var = lib.params_with_name('Discriminator.')  # trainer.py:603
         self.G_flat = FlatParams(self.G_var)
@@ -315,6 +320,24 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         self.allreduce.broadcast(self.G_flat.flat)
         self.allreduce.broadcast(self.D_flat.flat)
         lib.ops.batchnorm.set_sync(bool(getattr(self.config, "sync_bn", False)) and self.allreduce.enabled)
+
+    # ---- checkpoints (trainer.py:180-212 restores, :366 saves; TF V2 bundle format, tfckpt.py) ----------------
+    def restore_from_config(self):
+        """The three restores of the reference's init_net, in its order; in place, so flat buffers / graphs survive."""
+        from . import tfckpt
+        return tfckpt.restore_from_config(self.config)
+
+    def save_checkpoint(self, model_dir=None):
+        """`saver.save(sess, model_dir/model.ckpt, global_step=step)`: every variable + the `step` counter."""
+        import os
+        import numpy as np
+        from . import tfckpt
+        model_dir = model_dir or getattr(self.config, "model_dir", None)
+        if not model_dir:
+            raise Exception("save_checkpoint: no model_dir")
+        prefix = os.path.join(model_dir, "model.ckpt-%d" % self.step)
+        tfckpt.save(prefix, extra={"step": np.array(self.step, dtype=np.int32)})
+        return prefix
 
     # ---- hipGraph capture of the two optimizer ops ----------------------------------------------
     def enable_graphs(self, batch_g, batch_d, warmup=2):

@@ -77,6 +77,8 @@ class DPIG_Encoder_subSampleAppNetFgBg_GAN_BodyROI(object):
             self.flats[side] = (gf, df)
             self.opts[side] = get_optimizers(self.sides[side]["wg"], gf, df, self.g_lr, self.d_lr)
         self.built = True
+        from . import tfckpt
+        tfckpt.restore_from_config(self.config)      # the frozen stage-I encoder comes from `pretrained_path` (trainer.py:180-183)
         self.allreduce = GradAllReduce()
         for gf, df in self.flats.values():
             self.allreduce.broadcast(gf.flat)

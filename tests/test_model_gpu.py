@@ -211,3 +211,45 @@ def test_split_backward_equals_full_backward(dev):
     assert same(grads(), ref)
     assert float((tr.G_flat.flat - w0).abs().max()) > 0
     lib.delete_all_params()
+
+
+def test_checkpoint_save_restore_round_trip(dev, tmp_path):
+    """trainer.py:366 / :180-212 through the TF-free V2 checkpoint code (tfckpt.py): a saved model restores in place
+    into a trained trainer (flat buffers keep their addresses) and into a freshly built one via Config.ckpt_path."""
+    import dpig_amd.tflib as lib
+    from dpig_amd import slim, tfckpt
+    from dpig_amd.trainer import Config, DPIG_Encoder_GAN_BodyROI_FgBg
+    tr, gb, P, ob, OM = _setup(dev)
+
+    def outputs(t):
+        with torch.no_grad():
+            embs, _ = t.encode(gb)
+            G, _ = t.generate(embs, gb["pose"])
+            return G.clone(), t.discriminate(G).clone()
+
+    tr.step = 1
+    tr.train_step(gb, gb)
+    G0, D0 = outputs(tr)
+    prefix = tr.save_checkpoint(str(tmp_path))
+    assert prefix.endswith("model.ckpt-2") and tfckpt.latest_checkpoint(str(tmp_path)) == prefix
+    listed = {n: s for n, s, _ in tfckpt.list_variables(prefix)}
+    assert int(tfckpt.load_checkpoint(prefix, ["step"])["step"]) == 2
+    assert all(tuple(p.shape) == listed[n] for n, p in lib._params.items())
+    flat_ptr = tr.G_flat.flat.data_ptr()
+    tr.G_flat.flat.add_(0.05)
+    tr.D_flat.flat.mul_(0.5)
+    G1, _ = outputs(tr)
+    assert not torch.equal(G1, G0)
+    assert len(tfckpt.restore(prefix)) == len(lib._params)
+    G2, D2 = outputs(tr)
+    assert torch.equal(G2, G0) and torch.equal(D2, D0) and tr.G_flat.flat.data_ptr() == flat_ptr
+    # a fresh process-like start: new registry, random init, restore through the config
+    lib.delete_all_params()
+    slim.reset_scopes()
+    np.random.seed(123)
+    cfg = Config(batch_size=2, conv_hidden_num=HID, z_num=ZNUM, ckpt_path=prefix)
+    tr2 = DPIG_Encoder_GAN_BodyROI_FgBg(cfg, dev)
+    tr2.init_net(gb)
+    G3, D3 = outputs(tr2)
+    assert torch.equal(G3, G0) and torch.equal(D3, D0)
+    lib.delete_all_params()

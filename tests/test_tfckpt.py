@@ -1,0 +1,193 @@
+"""TF V2 checkpoint reader / writer (dpig_amd/tfckpt.py): the table and bundle formats against
+hand-assembled bytes, round trips, corruption detection, and the Saver-like restore into the tflib registry.
+No TensorFlow-written file exists in this environment (the module's header says "unpinned"); what can be checked
+independently of the writer is checked here against bytes laid out by hand from the format descriptions."""
+import os
+import struct
+
+import numpy as np
+import pytest
+
+from dpig_amd import tfckpt as C
+from dpig_amd.tfrecord import masked_crc32c
+
+
+def _v(n):                                    # protobuf / leveldb varint, written out independently of the module
+    out = bytearray()
+    while True:
+        b = n & 0x7F
+        n >>= 7
+        out.append(b | (0x80 if n else 0))
+        if not n:
+            return bytes(out)
+
+
+def _trailer(block, ctype=0):
+    return bytes([ctype]) + struct.pack("<I", masked_crc32c(block + bytes([ctype])))
+
+
+def test_hand_assembled_table_and_bundle(tmp_path):
+    """A complete checkpoint laid out by hand: one fp32 [2,3] variable 'a/w' and one int64 scalar 'step'."""
+    w = np.arange(6, dtype="<f4").reshape(2, 3) - 2.5
+    step = np.array(1234567890123, dtype="<i8")
+    data = w.tobytes() + step.tobytes()
+    prefix = str(tmp_path / "model.ckpt-7")
+    open(prefix + ".data-00000-of-00001", "wb").write(data)
+    # BundleHeaderProto: num_shards(1)=1, version(3){producer(1)=1}
+    header = b"\x08\x01" + b"\x1a\x02\x08\x01"
+    # BundleEntryProto: dtype(1), shape(2){dim(2){size(1)}}, offset(4), size(5), crc32c(6, fixed32)
+    e_w = (b"\x08\x01" + b"\x12\x08" + b"\x12\x02\x08\x02" + b"\x12\x02\x08\x03" + b"\x28\x18" +
+           b"\x35" + struct.pack("<I", masked_crc32c(w.tobytes())))
+    e_s = (b"\x08\x09" + b"\x12\x00" + b"\x20\x18" + b"\x28\x08" + b"\x35" + struct.pack("<I", masked_crc32c(step.tobytes())))
+    # data block: 3 entries, restart interval 16 -> one restart; (shared, non_shared, value_len, key delta, value)
+    blk = b""
+    for shared, key, val in ((0, b"", header), (0, b"a/w", e_w), (0, b"step", e_s)):
+        blk += _v(shared) + _v(len(key)) + _v(len(val)) + key + val
+    blk += struct.pack("<I", 0) + struct.pack("<I", 1)
+    f = blk + _trailer(blk)
+    meta = struct.pack("<I", 0) + struct.pack("<I", 1)                       # empty block
+    meta_off = len(f)
+    f += meta + _trailer(meta)
+    handle = _v(0) + _v(len(blk))
+    idx = _v(0) + _v(4) + _v(len(handle)) + b"step" + handle + struct.pack("<I", 0) + struct.pack("<I", 1)
+    idx_off = len(f)
+    f += idx + _trailer(idx)
+    footer = _v(meta_off) + _v(len(meta)) + _v(idx_off) + _v(len(idx))
+    footer += b"\x00" * (40 - len(footer)) + bytes.fromhex("57fb808b247547db")   # magic, little endian
+    open(prefix + ".index", "wb").write(f + footer)
+
+    assert C.list_variables(prefix) == [("a/w", (2, 3), np.float32), ("step", (), np.int64)]
+    got = C.load_checkpoint(prefix)
+    assert got["a/w"].dtype == np.float32 and np.array_equal(got["a/w"], w)
+    assert got["step"].shape == () and int(got["step"]) == 1234567890123
+    # the writer lays the same two variables out to the same bytes
+    p2 = str(tmp_path / "again")
+    C.save_checkpoint(p2, {"step": step, "a/w": w})
+    assert open(p2 + ".data-00000-of-00001", "rb").read() == data
+    assert open(p2 + ".index", "rb").read() == f + footer
+
+
+def test_prefix_compression_restarts_and_many_blocks(tmp_path):
+    rng = np.random.RandomState(0)
+    keys = sorted({("scope%d/layer_%03d/%s" % (i % 7, i, s)).encode() for i in range(400) for s in ("weights", "biases")})
+    items = [(k, bytes(rng.randint(0, 256, rng.randint(0, 40)).astype(np.uint8))) for k in keys]
+    for bs in (64, 700, C.BLOCK_SIZE):
+        path = str(tmp_path / ("t%d" % bs))
+        C.write_table(path, items, block_size=bs)
+        assert C.read_table(path) == items
+    # a block with shared prefixes, assembled by hand: 'abc' -> 'abd' (shared 2) -> 'abde' (shared 3)
+    blk = (_v(0) + _v(3) + _v(1) + b"abc" + b"1") + (_v(2) + _v(1) + _v(1) + b"d" + b"2") + (_v(3) + _v(1) + _v(0) + b"e")
+    blk += struct.pack("<I", 0) + struct.pack("<I", 1)
+    assert list(C.block_entries(blk)) == [(b"abc", b"1"), (b"abd", b"2"), (b"abde", b"")]
+    with pytest.raises(ValueError):
+        C.write_table(str(tmp_path / "bad"), [(b"b", b""), (b"a", b"")])
+
+
+def test_snappy_block_known_answer(tmp_path):
+    # 11 bytes: literal 'abc', then an overlapping copy (offset 3, length 8); then a 2-byte-offset copy form
+    assert C.snappy_decompress(b"\x0b" + b"\x08abc" + b"\x11\x03") == b"abcabcabcab"
+    assert C.snappy_decompress(b"\x08" + b"\x0cabcd" + b"\x0e\x04\x00") == b"abcdabcd"
+    long_lit = bytes(range(70))
+    assert C.snappy_decompress(b"\x46" + b"\xf0\x45" + long_lit) == long_lit          # literal length in one extra byte
+    with pytest.raises(IOError):
+        C.snappy_decompress(b"\x05" + b"\x08abc")
+    # a table whose data block is snappy-compressed (type byte 1) is read through the decoder
+    blk = _v(0) + _v(0) + _v(6) + b"\x08\x01\x1a\x02\x08\x01" + struct.pack("<I", 0) + struct.pack("<I", 1)
+    comp = _v(len(blk)) + bytes([(len(blk) - 1) << 2]) + blk                          # one literal
+    f = comp + _trailer(comp, 1)
+    meta = struct.pack("<I", 0) + struct.pack("<I", 1)
+    mo = len(f); f += meta + _trailer(meta)
+    h = _v(0) + _v(len(comp))
+    idx = _v(0) + _v(0) + _v(len(h)) + h + struct.pack("<I", 0) + struct.pack("<I", 1)
+    io_ = len(f); f += idx + _trailer(idx)
+    foot = _v(mo) + _v(len(meta)) + _v(io_) + _v(len(idx))
+    foot += b"\x00" * (40 - len(foot)) + struct.pack("<Q", C.TABLE_MAGIC)
+    path = str(tmp_path / "snappy.index")
+    open(path, "wb").write(f + foot)
+    assert C.read_table(path) == [(b"", b"\x08\x01\x1a\x02\x08\x01")]
+
+
+def test_round_trip_dtypes_shapes_and_corruption(tmp_path):
+    rng = np.random.RandomState(1)
+    tensors = {"Encoder/G_encoder/Conv/weights": rng.randn(3, 3, 21, 16).astype(np.float32),
+               "Discriminator.1.Filters": rng.randn(5, 5, 3, 8).astype(np.float32),
+               "Discriminator.BN2.moving_mean": np.zeros(8, np.float32),
+               "beta1_power": np.array(0.5, np.float32), "step": np.array(41, np.int32),
+               "empty": np.zeros((0, 4), np.float32), "ids": rng.randint(-5, 5, (4, 2)).astype(np.int64),
+               "half": rng.randn(7).astype(np.float16), "flag": np.array([True, False]), "d": rng.randn(2, 2)}
+    prefix = str(tmp_path / "sub" / "model.ckpt-41")
+    C.save_checkpoint(prefix, tensors)
+    listed = {n: (s, d) for n, s, d in C.list_variables(prefix)}
+    assert set(listed) == set(tensors) and listed["empty"] == ((0, 4), np.float32) and listed["step"] == ((), np.int32)
+    got = C.load_checkpoint(prefix)
+    for n, a in tensors.items():
+        assert got[n].dtype == a.dtype and got[n].shape == a.shape and np.array_equal(got[n], a), n
+    assert set(C.load_checkpoint(prefix, names=["step", "ids"])) == {"step", "ids"}
+    assert set(C.load_checkpoint(prefix, names=lambda n: n.startswith("Discriminator."))) == {
+        "Discriminator.1.Filters", "Discriminator.BN2.moving_mean"}
+    assert C.latest_checkpoint(str(tmp_path / "sub")) == prefix and C.latest_checkpoint(str(tmp_path)) is None
+    # a flipped data byte / index byte / magic is detected
+    dpath, ipath = prefix + ".data-00000-of-00001", prefix + ".index"
+    raw = bytearray(open(dpath, "rb").read()); raw[100] ^= 1; open(dpath, "wb").write(bytes(raw))
+    with pytest.raises(IOError, match="CRC"):
+        C.load_checkpoint(prefix)
+    assert "step" in C.load_checkpoint(prefix, verify=False)
+    raw[100] ^= 1; open(dpath, "wb").write(bytes(raw))
+    idx = bytearray(open(ipath, "rb").read()); idx[10] ^= 0x40; open(ipath, "wb").write(bytes(idx))
+    with pytest.raises(IOError, match="CRC"):
+        C.list_variables(prefix)
+    idx[10] ^= 0x40; idx[-1] ^= 1; open(ipath, "wb").write(bytes(idx))
+    with pytest.raises(IOError, match="magic"):
+        C.list_variables(prefix)
+    idx[-1] ^= 1; open(ipath, "wb").write(bytes(idx[:-3]))
+    with pytest.raises(IOError):
+        C.list_variables(prefix)
+
+
+def test_saver_like_restore_into_the_registry(tmp_path):
+    """trainer.py:180-212: partial restores by scope, the full restore, strictness."""
+    import torch
+    import dpig_amd.tflib as lib
+    lib.delete_all_params()
+    lib.set_device("cpu")
+    try:
+        rng = np.random.RandomState(2)
+        names = {"Encoder/G_encoder/Conv/weights": (3, 3, 4, 8), "Encoder/G_encoder/Conv/biases": (8,),
+                 "ID_AE/G/Conv/weights": (3, 3, 8, 8), "PoseAE/G_Pose_Encoder/fully_connected/weights": (54, 16),
+                 "Discriminator.1.Filters": (5, 5, 3, 8), "Discriminator.BN2.moving_mean": (8,)}
+        saved = {}
+        for n, sh in names.items():
+            saved[n] = rng.randn(*sh).astype(np.float32)
+            lib.param(n, saved[n], trainable="moving" not in n)
+        prefix = str(tmp_path / "model.ckpt-3")
+        assert C.save(prefix, extra={"step": np.array(3, np.int32)}) == sorted(list(names) + ["step"])
+        flat_alias = lib._params["ID_AE/G/Conv/weights"].data           # in-place copy must keep this storage
+        for p in lib._params.values():
+            p.data.fill_(7.0)
+        done = C.restore(prefix, scopes=["Encoder", "ID_AE"])
+        assert sorted(done) == sorted(n for n in names if n.startswith(("Encoder", "ID_AE")))
+        assert np.array_equal(flat_alias.numpy(), saved["ID_AE/G/Conv/weights"])
+        assert float(lib._params["Discriminator.1.Filters"].detach().min()) == 7.0 == float(
+            lib._params["PoseAE/G_Pose_Encoder/fully_connected/weights"].detach().max())
+
+        class Cfg(object):
+            pretrained_path = None
+            pretrained_poseAE_path = prefix
+            ckpt_path = None
+        assert C.wants_restore(Cfg) and C.restore_from_config(Cfg) == ["PoseAE/G_Pose_Encoder/fully_connected/weights"]
+        assert len(C.restore(prefix)) == len(names)
+        for n in names:
+            assert np.array_equal(lib._params[n].detach().numpy(), saved[n])
+        # a variable the checkpoint lacks: error like Saver.restore, unless not strict
+        lib.param("Encoder/G_encoder/Conv_1/weights", np.zeros((3, 3, 8, 8), np.float32))
+        with pytest.raises(Exception, match="lacks"):
+            C.restore(prefix, scopes=["Encoder"])
+        assert len(C.restore(prefix, scopes=["Encoder"], strict=False)) == 2
+        lib._params.pop("Encoder/G_encoder/Conv_1/weights")
+        lib._params.pop("Discriminator.1.Filters")
+        lib.param("Discriminator.1.Filters", np.zeros((5, 5, 3, 16), np.float32))
+        with pytest.raises(Exception, match="shape"):
+            C.restore(prefix)
+    finally:
+        lib.delete_all_params()
+        lib.set_device(None)

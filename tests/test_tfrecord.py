@@ -21,6 +21,19 @@ def test_crc32c_known_answers():
     assert T.masked_crc32c(b"123456789") == ((((crc >> 15) | (crc << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
 
 
+def test_crc32c_chunk_parallel_path_equals_the_byte_loop():
+    """Inputs of 2 KB and more take the numpy path (equal-length chunks advanced in lock step, registers combined with
+    the GF(2) "append n zero bytes" operator); it must agree with the byte-at-a-time table loop."""
+    rng = np.random.RandomState(0)
+    for n in (2047, 2048, 2049, 4097, 65536, 100003, 300001):
+        d = rng.randint(0, 256, n).astype(np.uint8).tobytes()
+        assert T.crc32c(d) == T._crc32c_scalar(d), n
+    for d in (bytes(5000), b"\xff" * 7001, bytes(3000) + b"abc", b"abc" + bytes(3000)):
+        assert T.crc32c(d) == T._crc32c_scalar(d)
+    a = rng.randn(33, 77).astype(np.float32)
+    assert T.crc32c(a) == T._crc32c_scalar(a.tobytes())              # arrays are read through their bytes
+
+
 def test_tfrecord_framing_roundtrip_and_corruption():
     payloads = [b"", b"a", bytes(range(256)) * 5]
     f = io.BytesIO()
