@@ -5,7 +5,6 @@ import ctypes
 import os
 import re
 import subprocess
-import sys
 
 import pytest
 

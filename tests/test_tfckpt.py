@@ -2,7 +2,6 @@
 hand-assembled bytes, round trips, corruption detection, and the Saver-like restore into the tflib registry.
 No TensorFlow-written file exists in this environment (the module's header says "unpinned"); what can be checked
 independently of the writer is checked here against bytes laid out by hand from the format descriptions."""
-import os
 import struct
 
 import numpy as np
@@ -146,7 +145,6 @@ def test_round_trip_dtypes_shapes_and_corruption(tmp_path):
 
 def test_saver_like_restore_into_the_registry(tmp_path):
     """trainer.py:180-212: partial restores by scope, the full restore, strictness."""
-    import torch
     import dpig_amd.tflib as lib
     lib.delete_all_params()
     lib.set_device("cpu")
