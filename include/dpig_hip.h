@@ -97,7 +97,8 @@ int dpig_same_pad(int in, int k, int stride, int* out, int* pad_before);
  * which: 0 fwd, 1 dgrad, 2 wgrad.  Returns 0 when no workspace is needed. */
 size_t dpig_conv2d_workspace_bytes(const DpigConvDesc* d, int which);
 
-/* y[N,Ho,Wo,K] = act(conv(x, w) + bias + residual)  (or act(..)+residual, see res_after_act).
+/* Replaces tf.nn.conv2d('SAME') + bias_add (+ ReLU) of tflib/ops/conv2d.py:106-120 and slim.conv2d, models.py:396-573.
+ * y[N,Ho,Wo,K] = act(conv(x, w) + bias + residual)  (or act(..)+residual, see res_after_act).
  * bias / residual / y_act may be NULL.  y_act (optional) receives the activation output before a
  * post-activation residual add (its sign is the ReLU mask the backward pass needs).
  * With upsample2x, y has spatial size (2H, 2W). */
@@ -105,12 +106,14 @@ int dpig_conv2d_fwd(const DpigConvDesc* d, const float* x, const float* w, const
                     const float* residual, float* y, float* y_act, void* ws, size_t ws_bytes,
                     void* stream);
 
-/* dx[N,H,W,C] = (conv_backward_data(dy, w) + accum) * act'(mask).  accum / mask may be NULL.
- * Also the forward of tflib Deconv2D (stride-2 transposed conv). */
+/* Replaces Conv2DBackpropInput: the input gradient TF autodiff emits for the convs above (Optimizer.minimize,
+ * trainer.py:137-140) and the forward of tf.nn.conv2d_transpose, tflib/ops/deconv2d.py:97-103.
+ * dx[N,H,W,C] = (conv_backward_data(dy, w) + accum) * act'(mask).  accum / mask may be NULL. */
 int dpig_conv2d_dgrad(const DpigConvDesc* d, const float* dy, const float* w, const float* accum,
                       const float* mask, float* dx, void* ws, size_t ws_bytes, void* stream);
 
-/* dw[R,S,C,K] = beta*dw + conv_backward_filter(x, dy).  beta = 0 overwrites, beta = 1 accumulates.
+/* Replaces Conv2DBackpropFilter + BiasAddGrad of the same call sites (trainer.py:137-140).
+ * dw[R,S,C,K] = beta*dw + conv_backward_filter(x, dy).  beta = 0 overwrites, beta = 1 accumulates.
  * If db is not NULL the same launch also produces the bias gradient db[K] = beta_b*db + sum_pixels dy
  * (TF's BiasAddGrad) from the dy tiles it stages anyway -- no extra pass over dy. */
 int dpig_conv2d_wgrad(const DpigConvDesc* d, const float* x, const float* dy, float* dw, float beta,
@@ -121,16 +124,17 @@ int dpig_conv2d_wgrad(const DpigConvDesc* d, const float* x, const float* dy, fl
 /* y = act(x): stand-alone ReLU / LeakyReLU (wgan_gp.py:23-24 `tf.maximum(alpha*x, x)`). */
 int dpig_act_fwd(const float* x, int ldx, float* y, int ldy, int64_t rows, int cols, int act, float alpha,
                  void* stream);
-/* dz = dy * act'(y)   (y = the activation OUTPUT; relu'/lrelu' decided by y > 0). */
+/* dz = dy * act'(y)   (y = the activation OUTPUT; relu'/lrelu' decided by y > 0): ReluGrad / the gradient of
+ * wgan_gp.py:23-24's maximum, as TF autodiff emits them. */
 int dpig_act_bwd(const float* dy, int lddy, const float* y, int ldy, float* dz, int lddz, int64_t rows,
                  int cols, int act, float alpha, void* stream);
-/* out[c] = beta*out[c] + sum_r a[r,c]   (bias gradient).  ws: dpig_colsum_workspace_bytes. */
+/* out[c] = beta*out[c] + sum_r a[r,c]   (BiasAddGrad of conv2d.py:118-120 / linear.py:142-146).  ws: dpig_colsum_workspace_bytes. */
 size_t dpig_colsum_workspace_bytes(int64_t rows, int cols);
 int dpig_colsum(const float* a, int lda, int64_t rows, int cols, float* out, float beta, void* ws,
                 size_t ws_bytes, void* stream);
 
 /* out[N][9][C] = per-image sums of a[N,H,W,C] over the 9 border classes (gradient of the
- * class-indexed residual above; the backward half of the tiled-embedding collapse). */
+ * class-indexed residual above; the backward half of the tiled-embedding collapse, trainer.py:588-590 + models.py:520-528). */
 size_t dpig_border_class_sum_workspace_bytes(int N, int H, int W, int C);
 int dpig_border_class_sum(const float* a, int lda, int N, int H, int W, int C, float* out, void* ws,
                           size_t ws_bytes, void* stream);
@@ -193,7 +197,7 @@ int dpig_linear_dgrad(const float* dy, const float* w, float* dx, int M, int Kin
 int dpig_linear_wgrad(const float* x, const float* dy, float* dw, float beta, int M, int Kin, int Nout,
                       void* ws, size_t ws_bytes, void* stream);
 
-/* ---- tf.image.crop_and_resize (bilinear, extrapolation 0) ------------------------------------ */
+/* ---- tf.image.crop_and_resize (bilinear, extrapolation 0; models.py:415) ------------------------ */
 /* img: [N,H,W,C] (ld = C); boxes: [nbox,4] normalised (y1,x1,y2,x2); box_ind: [nbox];
  * out: [nbox, ch, cw, C]. */
 int dpig_crop_resize_fwd(const float* img, int N, int H, int W, int C, const float* boxes,
