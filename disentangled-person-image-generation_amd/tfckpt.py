@@ -23,6 +23,8 @@ snappy framing) are asserted there.
 `restore(prefix, scopes)` / `save(prefix)` move values between a checkpoint and the `tflib` parameter registry,
 whose names are the reference's variable names (`Encoder/G_encoder/Conv/weights`, `Discriminator.1.Filters`, ...;
 SURVEY Appendix F), filters HWIO and FC weights [in, out] exactly as TF stores them.
+Optimizer slots (`<var>/Adam`, `<var>/Adam_1`, `beta1_power`, ...) are neither written nor restored: entries of a
+TF checkpoint that the registry does not know are ignored, and a restored model continues with fresh moments.
 """
 import os
 import struct
