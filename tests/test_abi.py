@@ -5,6 +5,7 @@ import ctypes
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
@@ -161,3 +162,12 @@ def test_workspace_plan_invariants(dims):
         d.split_k = 0
     d.stride = 3
     assert h.dpig_conv2d_workspace_bytes(ctypes.byref(d), 0) == 0
+
+
+def test_missing_library_is_a_loud_error(tmp_path):
+    """No .so, no product: the binding raises (and names the build command) instead of computing some other way."""
+    env = dict(os.environ, DPIG_LIB_PATH=str(tmp_path / "absent.so"), PYTHONPATH=ROOT)
+    code = ("from dpig_amd import _lib\n"
+            "try:\n    _lib.lib()\nexcept RuntimeError as e:\n    print('RuntimeError', 'g.build()' in str(e))\n")
+    out = subprocess.check_output([sys.executable, "-c", code], env=env, cwd=ROOT).decode()
+    assert out.strip() == "RuntimeError True"
