@@ -189,3 +189,35 @@ def test_saver_like_restore_into_the_registry(tmp_path):
     finally:
         lib.delete_all_params()
         lib.set_device(None)
+
+
+# ---- generated cases --------------------------------------------------------------------------------------------
+from hypothesis import given, settings, strategies as st   # noqa: E402
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.dictionaries(st.binary(min_size=1, max_size=24), st.binary(max_size=64), max_size=60),
+       st.sampled_from([32, 200, 4096]))
+def test_table_round_trip_generated(tmp_path_factory, kv, block_size):
+    items = sorted(kv.items())
+    path = str(tmp_path_factory.mktemp("tbl") / "t")
+    C.write_table(path, items, block_size=block_size)
+    assert C.read_table(path) == items
+
+
+_names = st.text(alphabet="abcXYZ019_./", min_size=1, max_size=20)
+_arrays = st.one_of(
+    st.tuples(st.sampled_from(["<f4", "<f8", "<i4", "<i8", "<f2", "u1"]),
+              st.lists(st.integers(0, 5), max_size=3)).map(
+        lambda t: (np.arange(int(np.prod(t[1])) if t[1] else 1).reshape(t[1]) * 3 - 7).astype(t[0])))
+
+
+@settings(max_examples=40, deadline=None)
+@given(st.dictionaries(_names, _arrays, max_size=12))
+def test_bundle_round_trip_generated(tmp_path_factory, tensors):
+    prefix = str(tmp_path_factory.mktemp("ck") / "m.ckpt")
+    C.save_checkpoint(prefix, tensors, update_state_file=False)
+    got = C.load_checkpoint(prefix)
+    assert set(got) == set(tensors)
+    for n, a in tensors.items():
+        assert got[n].dtype == a.dtype and got[n].shape == a.shape and np.array_equal(got[n], a)

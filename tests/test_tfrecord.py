@@ -139,3 +139,29 @@ def test_batch_from_records_feeds_the_trainer(dev):
     tr.step = 1
     out = tr.train_step(batch, T.batch_from_examples(exs, dev, which=1))
     assert all(np.isfinite(float(v)) for v in out.values() if hasattr(v, "numel") and v.numel() == 1)
+
+
+from hypothesis import given, settings, strategies as st   # noqa: E402
+
+_feature = st.one_of(st.lists(st.binary(max_size=20), max_size=3),
+                     st.lists(st.floats(-1e6, 1e6, width=32), max_size=6).map(lambda v: np.array(v, np.float32)),
+                     st.lists(st.integers(-(1 << 62), 1 << 62), max_size=6).map(lambda v: np.array(v, np.int64)))
+
+
+@settings(max_examples=80, deadline=None)
+@given(st.lists(st.dictionaries(st.text(alphabet="abc_019", min_size=1, max_size=12), _feature, max_size=6), max_size=4))
+def test_example_and_framing_round_trip_generated(examples):
+    """encode_example -> write_records -> read_records -> parse_example returns what went in (bytes lists, float32 and
+    int64 arrays incl. negative values and empty lists)."""
+    buf = io.BytesIO()
+    T.write_records(buf, [T.encode_example(e) for e in examples])
+    buf.seek(0)
+    got = [T.parse_example(p) for p in T.read_records(buf)]
+    assert len(got) == len(examples)
+    for g, e in zip(got, examples):
+        assert set(g) == set(e)
+        for k, v in e.items():
+            if isinstance(v, list):
+                assert list(g[k]) == v
+            else:
+                assert np.array_equal(np.asarray(g[k]), v) and (len(v) == 0 or np.asarray(g[k]).dtype == v.dtype)
