@@ -278,3 +278,22 @@ def test_pose_oracle_equals_reference_py_poseInflate():
             assert np.array_equal(solid, want)
         seen += 1
     assert seen == 3
+
+
+@pytest.mark.skipif(not __import__("os").path.exists("/root/reference/utils.py"), reason="the reference tree is not mounted")
+def test_pose_fixture_is_what_the_reference_code_produces_today():
+    """Where the reference is mounted (the build container, not the GPU box): re-run its four pose functions from
+    their source text and compare with the committed fixture, so neither the fixture nor the generator can drift."""
+    import importlib.util
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_pose_golden", os.path.join(here, "golden", "make_pose_golden.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    f = gen.reference_functions()
+    seen = 0
+    for name, z, rcv, norm, H, W, want in _pose_reference_cases():
+        dense = f["py_poseInflate"](rcv.copy(), is_normalized=norm, radius=4, img_H=H, img_W=W)
+        assert np.array_equal(dense > 0, want), name
+        seen += 1
+    assert seen == 3
