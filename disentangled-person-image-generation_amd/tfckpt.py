@@ -23,8 +23,9 @@ snappy framing) are asserted there.
 `restore(prefix, scopes)` / `save(prefix)` move values between a checkpoint and the `tflib` parameter registry,
 whose names are the reference's variable names (`Encoder/G_encoder/Conv/weights`, `Discriminator.1.Filters`, ...;
 SURVEY Appendix F), filters HWIO and FC weights [in, out] exactly as TF stores them.
-Optimizer slots (`<var>/Adam`, `<var>/Adam_1`, `beta1_power`, ...) are neither written nor restored: entries of a
-TF checkpoint that the registry does not know are ignored, and a restored model continues with fresh moments.
+`restore` / `save` move VARIABLES; entries of a checkpoint that the registry does not know are ignored.  Optimizer slots
+(`<var>/Adam`, `<var>/Adam_1`, `beta1_power`, ...) are the trainer's business: `trainer.optimizer_slots` /
+`load_optimizer_slots`, switched on by `save_checkpoint(include_optimizer=True)` and `Config.restore_optimizer`.
 """
 import os
 import struct

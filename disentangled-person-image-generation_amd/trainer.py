@@ -114,6 +114,54 @@ def get_optimizers(wgan_gp, G_flat, D_flat, g_lr, d_lr):
     raise Exception()
 
 
+def optimizer_slots(flat, opt, ordinal=0):
+    """The optimizer state of one FlatParams under the names tf.train.Saver gives it: per variable `<var>/Adam` (m) and
+    `<var>/Adam_1` (v), or `<var>/RMSProp` (rms) and `<var>/RMSProp_1` (momentum); for Adam also the bias-correction
+    powers `beta1_power`, `beta2_power` (suffix `_<ordinal>` for every optimizer after the first one built: the
+    generator's is built first, trainer.py:116-149).  TF stores beta^(t+1) after t steps (the power is multiplied
+    AFTER each update)."""
+    import numpy as np
+    kind = "Adam" if isinstance(opt, TFAdam) else "RMSProp"
+    out = {}
+    for p, o in zip(flat.params, flat.offsets):
+        n = p.numel()
+        out["%s/%s" % (p.dpig_name, kind)] = flat.m[o:o + n].reshape(p.shape).detach().cpu().numpy().copy()
+        out["%s/%s_1" % (p.dpig_name, kind)] = flat.v[o:o + n].reshape(p.shape).detach().cpu().numpy().copy()
+    if kind == "Adam":
+        t = int(opt.state[0])                    # the device counter is the truth (graph replays advance it)
+        sfx = "" if ordinal == 0 else "_%d" % ordinal
+        out["beta1_power" + sfx] = np.array(opt.b1 ** (t + 1), dtype=np.float32)
+        out["beta2_power" + sfx] = np.array(opt.b2 ** (t + 1), dtype=np.float32)
+    return out
+
+
+def load_optimizer_slots(flat, opt, values, ordinal=0):
+    """Inverse of `optimizer_slots` from a {name: array} dict (e.g. tfckpt.load_checkpoint).  All or nothing: returns
+    False, touching nothing, when any slot of this optimizer is missing or mis-shaped."""
+    import math
+    import numpy as np
+    kind = "Adam" if isinstance(opt, TFAdam) else "RMSProp"
+    sfx = "" if ordinal == 0 else "_%d" % ordinal
+    need = [("%s/%s" % (p.dpig_name, kind), "%s/%s_1" % (p.dpig_name, kind)) for p in flat.params]
+    for p, (a, b) in zip(flat.params, need):
+        if a not in values or b not in values or tuple(values[a].shape) != tuple(p.shape) or tuple(values[b].shape) != tuple(p.shape):
+            return False
+    if kind == "Adam" and ("beta1_power" + sfx) not in values:
+        return False
+    with torch.no_grad():
+        for p, o, (a, b) in zip(flat.params, flat.offsets, need):
+            n = p.numel()
+            flat.m[o:o + n].copy_(torch.from_numpy(np.array(values[a], dtype=np.float32).reshape(-1)).to(flat.m.device))
+            flat.v[o:o + n].copy_(torch.from_numpy(np.array(values[b], dtype=np.float32).reshape(-1)).to(flat.v.device))
+        if kind == "Adam":
+            power = float(values["beta1_power" + sfx])
+            t = max(0, int(round(math.log(power) / math.log(opt.b1))) - 1) if 0.0 < power < 1.0 else 0
+            opt.t = t
+            opt.state.zero_()
+            opt.state[0] = t                     # the tick kernel recomputes the correction from t + 1
+    return True
+
+
 def clip_disc_weights(D_flat, lo=-.01, hi=.01):
     """trainer.py:124-128: clip every `Discriminator` parameter to [-0.01, 0.01] -- one launch on the flat buffer
     (the 16-byte alignment padding between tensors is zero and stays zero)."""
@@ -233,6 +281,7 @@ class Config(object):
         self.pretrained_path = None      # V2 checkpoint prefixes (trainer.py:180-212): 'Encoder' + 'ID_AE' variables,
         self.pretrained_poseAE_path = None   # the 'PoseAE' variables,
         self.ckpt_path = None            # every variable of the model
+        self.restore_optimizer = False   # with ckpt_path: also the Adam / RMSProp slots, if the checkpoint holds them
         self.model_dir = None            # where save_checkpoint() writes model.ckpt-<step>
         self.__dict__.update(kw)
         self.repeat_num = int(math.log2(self.img_H)) - 2    # trainer.py:75
@@ -320,6 +369,8 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         self.allreduce.broadcast(self.G_flat.flat)
         self.allreduce.broadcast(self.D_flat.flat)
         lib.ops.batchnorm.set_sync(bool(getattr(self.config, "sync_bn", False)) and self.allreduce.enabled)
+        if getattr(self.config, "ckpt_path", None) and getattr(self.config, "restore_optimizer", False):
+            self.restore_optimizer(self.config.ckpt_path)
 
     # ---- checkpoints (trainer.py:180-212 restores, :366 saves; TF V2 bundle format, tfckpt.py) ----------------
     def restore_from_config(self):
@@ -327,8 +378,18 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         from . import tfckpt
         return tfckpt.restore_from_config(self.config)
 
-    def save_checkpoint(self, model_dir=None):
-        """`saver.save(sess, model_dir/model.ckpt, global_step=step)`: every variable + the `step` counter."""
+    def restore_optimizer(self, prefix):
+        """The optimizer slots of a full checkpoint (a `tf.train.Saver()` holds them beside the variables).  Returns
+        (generator restored, critic restored)."""
+        from . import tfckpt
+        values = tfckpt.load_checkpoint(prefix, names=lambda n: n.rsplit("/", 1)[-1].startswith(("Adam", "RMSProp"))
+                                        or n.startswith(("beta1_power", "beta2_power")))
+        return (load_optimizer_slots(self.G_flat, self.g_opt, values, 0),
+                load_optimizer_slots(self.D_flat, self.d_opt, values, 1))
+
+    def save_checkpoint(self, model_dir=None, include_optimizer=False):
+        """`saver.save(sess, model_dir/model.ckpt, global_step=step)`: every variable + the `step` counter, and with
+        `include_optimizer` the Adam / RMSProp slots under TF's names (what the reference's full Saver writes)."""
         import os
         import numpy as np
         from . import tfckpt
@@ -336,7 +397,11 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         if not model_dir:
             raise Exception("save_checkpoint: no model_dir")
         prefix = os.path.join(model_dir, "model.ckpt-%d" % self.step)
-        tfckpt.save(prefix, extra={"step": np.array(self.step, dtype=np.int32)})
+        extra = {"step": np.array(self.step, dtype=np.int32)}
+        if include_optimizer:
+            extra.update(optimizer_slots(self.G_flat, self.g_opt, 0))
+            extra.update(optimizer_slots(self.D_flat, self.d_opt, 1))
+        tfckpt.save(prefix, extra=extra)
         return prefix
 
     # ---- hipGraph capture of the two optimizer ops ----------------------------------------------

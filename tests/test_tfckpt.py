@@ -221,3 +221,46 @@ def test_bundle_round_trip_generated(tmp_path_factory, tensors):
     assert set(got) == set(tensors)
     for n, a in tensors.items():
         assert got[n].dtype == a.dtype and got[n].shape == a.shape and np.array_equal(got[n], a)
+
+
+def test_optimizer_slots_round_trip_under_tf_names(tmp_path):
+    """trainer.optimizer_slots / load_optimizer_slots: Adam moments as `<var>/Adam`, `<var>/Adam_1`, the powers as
+    beta^(t+1) under `beta1_power[_k]`; RMSProp as `<var>/RMSProp`, `<var>/RMSProp_1`; all-or-nothing restore."""
+    import torch
+    import dpig_amd.tflib as lib
+    from dpig_amd.trainer import FlatParams, TFAdam, TFRMSProp, load_optimizer_slots, optimizer_slots
+    lib.delete_all_params()
+    lib.set_device("cpu")
+    try:
+        rng = np.random.RandomState(5)
+        shapes = {"ID_AE/G/Conv/weights": (3, 3, 2, 5), "ID_AE/G/Conv/biases": (5,), "ID_AE/G/fully_connected/weights": (7, 3)}
+        params = [lib.param(n, rng.randn(*sh).astype(np.float32)) for n, sh in shapes.items()]
+        flat = FlatParams(params)
+        lr = torch.tensor([1e-3])
+        opt = TFAdam(flat, lr, beta1=0.5, beta2=0.999)
+        flat.m.normal_(); flat.v.uniform_()
+        opt.state[0] = 7; opt.t = 7
+        slots = optimizer_slots(flat, opt, ordinal=1)
+        assert set(slots) == {n + s for n in shapes for s in ("/Adam", "/Adam_1")} | {"beta1_power_1", "beta2_power_1"}
+        assert abs(float(slots["beta1_power_1"]) - 0.5 ** 8) < 1e-9 and abs(float(slots["beta2_power_1"]) - 0.999 ** 8) < 1e-7
+        prefix = str(tmp_path / "model.ckpt-7")
+        C.save(prefix, extra=slots)
+        values = C.load_checkpoint(prefix)
+        want_m = {n: slots[n + "/Adam"].copy() for n in shapes}
+        want_v = {n: slots[n + "/Adam_1"].copy() for n in shapes}
+        flat.m.zero_(); flat.v.zero_(); opt.state.zero_(); opt.t = 0
+        assert not load_optimizer_slots(flat, opt, values, ordinal=0)          # the generator's powers are not in there
+        assert float(flat.m.abs().sum()) == 0.0
+        assert not load_optimizer_slots(flat, opt, {k: v for k, v in values.items() if k != "ID_AE/G/Conv/biases/Adam_1"}, 1)
+        assert load_optimizer_slots(flat, opt, values, ordinal=1)
+        for p, o in zip(flat.params, flat.offsets):
+            n = p.numel()
+            assert np.array_equal(flat.m[o:o + n].numpy().reshape(p.shape), want_m[p.dpig_name])
+            assert np.array_equal(flat.v[o:o + n].numpy().reshape(p.shape), want_v[p.dpig_name])
+        assert opt.t == 7 and int(opt.state[0]) == 7 and int(opt.state[1]) == 0
+        ropt = TFRMSProp(flat, lr)
+        names = set(optimizer_slots(flat, ropt))
+        assert names == {n + s for n in shapes for s in ("/RMSProp", "/RMSProp_1")}
+    finally:
+        lib.delete_all_params()
+        lib.set_device(None)
