@@ -253,3 +253,32 @@ def test_checkpoint_save_restore_round_trip(dev, tmp_path):
     G3, D3 = outputs(tr2)
     assert torch.equal(G3, G0) and torch.equal(D3, D0)
     lib.delete_all_params()
+
+
+def test_checkpoint_resume_with_optimizer_slots(dev, tmp_path):
+    """A run saved with its Adam slots and resumed through Config(ckpt_path, restore_optimizer) takes the same next step
+    as the run that never stopped (weights, moments and the device step counter all restored)."""
+    import dpig_amd.tflib as lib
+    from dpig_amd import slim, tfckpt
+    from dpig_amd.trainer import Config, DPIG_Encoder_GAN_BodyROI_FgBg
+    tr, gb, P, ob, OM = _setup(dev)
+    tr.step = 1
+    tr.train_step(gb, gb)
+    tr.train_step(gb, gb)
+    prefix = tr.save_checkpoint(str(tmp_path), include_optimizer=True)
+    names = {n for n, _, _ in tfckpt.list_variables(prefix)}
+    assert {"beta1_power", "beta2_power", "beta1_power_1", "beta2_power_1", "Discriminator.1.Filters/Adam",
+            "ID_AE/G/Conv/weights/Adam_1"} <= names
+    tr.train_step(gb, gb)
+    want_g, want_d = tr.G_flat.flat.clone(), tr.D_flat.flat.clone()
+    lib.delete_all_params()
+    slim.reset_scopes()
+    np.random.seed(99)
+    cfg = Config(batch_size=2, conv_hidden_num=HID, z_num=ZNUM, g_lr=2e-3, d_lr=2e-3, ckpt_path=prefix, restore_optimizer=True)
+    tr2 = DPIG_Encoder_GAN_BodyROI_FgBg(cfg, dev)
+    tr2.init_net(gb)
+    assert tr2.g_opt.t == 2 and int(tr2.g_opt.state[0]) == 2 and int(tr2.d_opt.state[0]) == 2
+    tr2.step = 3
+    tr2.train_step(gb, gb)
+    assert torch.equal(tr2.G_flat.flat, want_g) and torch.equal(tr2.D_flat.flat, want_d)
+    lib.delete_all_params()
