@@ -40,6 +40,16 @@ SYMBOLS = {
     "dpig_conv2d_fwd": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dpig_conv2d_dgrad": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dpig_conv2d_wgrad": (_i, [_dp, _vp, _vp, _vp, _f, _vp, _f, _vp, _sz, _vp]),
+    "dpig_conv2d_bf16_supported": (_i, [_dp, _i]),
+    "dpig_conv2d_bf16_workspace_bytes": (_sz, [_dp, _i]),
+    "dpig_conv2d_fwd_bf16": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dpig_conv2d_dgrad_bf16": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dpig_conv2d_wgrad_bf16": (_i, [_dp, _vp, _vp, _vp, _f, _vp, _f, _vp, _sz, _vp]),
+    "dpig_cvt_f32_to_bf16": (_i, [_vp, _i, _vp, _i, _i64, _i, _vp]),
+    "dpig_cvt_bf16_to_f32": (_i, [_vp, _i, _vp, _i, _i64, _i, _vp]),
+    "dpig_act_fwd_bf16": (_i, [_vp, _i, _vp, _i, _i64, _i, _i, _f, _vp]),
+    "dpig_act_bwd_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _i, _i, _f, _vp]),
+    "dpig_filter_shadow_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "dpig_act_fwd": (_i, [_vp, _i, _vp, _i, _i64, _i, _i, _f, _vp]),
     "dpig_act_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _i, _i, _f, _vp]),
     "dpig_colsum_workspace_bytes": (_sz, [_i64, _i]),

@@ -9,6 +9,24 @@ from . import hip_ops as H
 from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU
 
 
+# The WGAN-GP penalty needs dD(xhat)/dxhat with create_graph=True (trainer.py:233).  torch hands every custom Function of
+# that first-level sweep needs_input_grad = True for its parameters whatever `inputs=` says, so without this switch the
+# sweep would also deliver d(sum D(xhat))/dtheta into the critic's gradient slices -- a term d_loss does not contain.
+_PARAM_GRADS_OFF = [False]
+
+
+class no_param_grads(object):
+    """Context: backward passes run inside deliver no parameter gradients (input gradients only)."""
+
+    def __enter__(self):
+        self.saved = _PARAM_GRADS_OFF[0]
+        _PARAM_GRADS_OFF[0] = True
+
+    def __exit__(self, *exc):
+        _PARAM_GRADS_OFF[0] = self.saved
+        return False
+
+
 def _sink(p, fn):
     """Gradient delivery for a parameter.  If the optimizer registered a persistent gradient slice
     on the parameter (`p._dpig_grad`, a view into its flat gradient buffer -- see trainer.FlatParams)
@@ -156,6 +174,8 @@ class _ConvFn(torch.autograd.Function):
                 dz = dz.detach()
             else:
                 dx = H.conv2d_dgrad(dz, w, tuple(x.shape), stride=stride, upsample2x=up)
+        if _PARAM_GRADS_OFF[0]:
+            return dx, None, None, None, None, None, None
         dw, db = _sink_wgrad_bias(w, ctx.b_ref, x, dz, stride, up, ctx.needs_input_grad[1],
                                   has_b and ctx.needs_input_grad[2])
         return dx, dw, db, None, None, None, None
@@ -237,7 +257,7 @@ class _TiledEmbConvFn(torch.autograd.Function):
         emb, pose, w, wmat, y = ctx.saved_tensors
         E, K = emb.shape[1], w.shape[3]
         B = emb.shape[0]
-        dz = H.act_bwd(dy, y, ACT_RELU)
+        dz = H.to_f32(H.act_bwd(dy, y, ACT_RELU))       # ('bf16' mode: the three consumers below are fp32 kernels)
         db = _sink(ctx.b_ref, lambda o, beta: H.colsum(dz, out=o, beta=beta)) if ctx.needs_input_grad[3] else None
         z9 = H.border_class_sum(dz).view(B, 9 * K)
         d_emb = H.linear_dgrad(z9, wmat) if ctx.needs_input_grad[0] else None
@@ -336,10 +356,12 @@ class _LinearFn(torch.autograd.Function):
             dz = H.act_bwd(dy, y, act, alpha) if act != ACT_NONE else dy.contiguous()
             dx = H.linear_dgrad(dz, w) if ctx.needs_input_grad[0] else None
         dw = db = None
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and not _PARAM_GRADS_OFF[0]:
             dw = _sink(w, lambda o, beta: H.linear_wgrad(x, dz, out=o, beta=beta))
-        if has_b and ctx.needs_input_grad[2]:
+        if has_b and ctx.needs_input_grad[2] and not _PARAM_GRADS_OFF[0]:
             db = _sink(ctx.b_ref, lambda o, beta: H.colsum(dz, out=o, beta=beta))
+        if dx is not None and dx.dtype != x.dtype:
+            dx = H.to_bf16(dx) if x.dtype == H.BF16 else H.to_f32(dx)
         return dx, dw, db, None, None
 
 
@@ -363,6 +385,8 @@ class _BatchNormFn(torch.autograd.Function):
         x, scale, mean, rstd, y = ctx.saved_tensors
         act, alpha = ctx.cfg
         dx, dscale, doffset = H.bn_bwd(dy, x, y, scale, mean, rstd, act, alpha)
+        if _PARAM_GRADS_OFF[0]:
+            return dx, None, None, None, None, None
         ds = _sink_small(scale, dscale) if ctx.needs_input_grad[1] else None
         do = _sink_small(ctx.offset_ref, doffset) if ctx.needs_input_grad[2] else None
         return dx, ds, do, None, None, None
@@ -453,7 +477,7 @@ class _LayerNormFn(torch.autograd.Function):
         act, alpha = ctx.cfg
         if torch.is_grad_enabled():            # backward under create_graph=True
             dx = _LNBwdFn.apply(dy, x, y, scale, mean, rstd, act, alpha)
-            if not (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
+            if _PARAM_GRADS_OFF[0] or not (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):
                 return dx, None, None, None, None, None
             _, dscale, doffset = H.ln_bwd(dy.detach(), x, y, scale, mean, rstd, act, alpha)
         else:

@@ -21,6 +21,7 @@
 #include <type_traits>
 #include "dpig_common.h"
 #include "dpig_thin.h"
+#include "dpig_conv_plan.h"
 #ifdef DPIG_TRACE   // dev aid (never in the shipped build): s_memtime stamps of wave 0 of the first 512 workgroups
 __device__ unsigned long long dpig_trace_buf[512 * 256];
 __device__ unsigned long long dpig_trace_se[8192 * 4];     // start / end tick of every workgroup
@@ -41,7 +42,6 @@ constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int LDR = BK + 4;        // row-major [row][k] LDS stride (floats): 16B aligned, conflict-free b128
 constexpr int LDKN = BN;           // k-major  [k][col] LDS stride
 constexpr int TILE_FLOATS = BM * LDR;   // 4608 floats >= 32*128
-constexpr int MAX_TAPS = 25;
 
 struct GGParams {
     const float* A;       // gathered source activation (x for fwd, dy for dgrad)
@@ -1254,72 +1254,6 @@ __global__ __launch_bounds__(256) void splitk_sum_scalar_kernel(const float* __r
 // ================================================================================================
 // host side
 // ================================================================================================
-static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
-
-// (mul, shr) such that n / d == umulhi(n, mul) >> shr for every 0 <= n < 2^31; d == 1 -> mul = 0
-static void find_divisor(int d, unsigned* mul, unsigned* shr) {
-    if (d == 1) { *mul = 0; *shr = 0; return; }
-    unsigned lg = 0;
-    while ((1u << lg) < (unsigned)d) ++lg;                 // ceil(log2 d)
-    const unsigned p = 31 + lg;
-    *mul = (unsigned)(((1ull << p) + (unsigned)d - 1) / (unsigned)d);
-    *shr = p - 32;
-}
-
-static int resolve_desc(const DpigConvDesc* d, int* pt, int* pl, int* Ho, int* Wo) {
-    if (!d) return fail(DPIG_EINVAL, "null descriptor");
-    if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->K <= 0) return fail(DPIG_EINVAL, "non-positive dims");
-    if (d->R <= 0 || d->S <= 0 || d->R * d->S > MAX_TAPS) return fail(DPIG_EINVAL, "filter %dx%d unsupported", d->R, d->S);
-    if (d->stride != 1 && d->stride != 2) return fail(DPIG_EINVAL, "stride %d unsupported", d->stride);
-    if (d->ldx < d->C || d->ldy < d->K) return fail(DPIG_EINVAL, "channel stride smaller than channel count");
-    if (d->act < 0 || d->act > DPIG_ACT_LRELU) return fail(DPIG_EINVAL, "bad activation %d", d->act);
-    if (d->upsample2x && (d->R != 1 || d->S != 1 || d->stride != 1))
-        return fail(DPIG_EINVAL, "upsample2x fusion needs a 1x1 stride-1 conv");
-    int ho, wo, a, b;
-    dpig_same_pad(d->H, d->R, d->stride, &ho, &a);
-    dpig_same_pad(d->W, d->S, d->stride, &wo, &b);
-    if (d->pad_t >= 0) { a = d->pad_t; }
-    if (d->pad_l >= 0) { b = d->pad_l; }
-    *pt = a; *pl = b; *Ho = ho; *Wo = wo;
-    if ((long)d->N * d->H * d->W * d->ldx >= (1L << 31) || (long)d->N * ho * wo * d->ldy * (d->upsample2x ? 4 : 1) >= (1L << 31))
-        return fail(DPIG_EINVAL, "tensor exceeds 2^31 elements");
-    return DPIG_OK;
-}
-
-// Split-K plan.  The grid is tiles x splits workgroups of which 2 per CU are resident (512 slots):
-// pick the split count that best fills whole "rounds" of 512 slots, charged with the HBM round trip
-// of the fp32 partial sums (~120*s/K relative to the MFMA time of a K-deep reduction).
-static int choose_split(int tiles, int ktiles, int forced) {
-    if (forced > 0) return forced < ktiles ? forced : (ktiles > 0 ? ktiles : 1);
-    if (ktiles <= 0) return 1;
-    const int slots = 2 * kNumCU;
-    const double kred = 32.0 * ktiles;
-    double best = -1.0;
-    int best_s = 1;
-    const int smax = ktiles / 2 > 0 ? (ktiles / 2 < 64 ? ktiles / 2 : 64) : 1;
-    for (int s = 1; s <= smax; ++s) {
-        const int tps = cdiv(ktiles, s);
-        const int sr = cdiv(ktiles, tps);                  // effective split count
-        if (sr != s) continue;
-        const long blocks = (long)tiles * s;
-        const long rounds = (blocks + slots - 1) / slots;
-        double eff = (double)blocks / (double)(rounds * slots);
-        if (rounds == 1 && blocks <= kNumCU) eff = 0.75 * (double)blocks / kNumCU;   // lone block per CU
-        const double score = eff / (s > 1 ? 1.0 + 120.0 * s / kred : 1.0);
-        if (score > best * 1.02) { best = score; best_s = s; }
-    }
-    return best_s;
-}
-
-struct Plan { int nsplit, tiles_per_split; };
-static Plan plan_split(int tiles, int ktiles, int forced) {
-    Plan pl;
-    pl.nsplit = choose_split(tiles, ktiles, forced);
-    pl.tiles_per_split = cdiv(ktiles > 0 ? ktiles : 1, pl.nsplit);
-    pl.nsplit = cdiv(ktiles > 0 ? ktiles : 1, pl.tiles_per_split);   // drop empty splits
-    return pl;
-}
-
 static bool vec_ok(const void* a, const void* b, int lda, int Cs, int Ncols) {
     return aligned16(a) && aligned16(b) && (lda % 4 == 0) && (Cs % 4 == 0) && (Ncols % 4 == 0);
 }
@@ -1438,52 +1372,6 @@ extern "C" int dpig_same_pad(int in, int k, int stride, int* out, int* pad_befor
     if (pad_before) *pad_before = total / 2;
     return DPIG_OK;
 }
-
-// dgrad stride-2 parity class geometry
-namespace dpig {
-struct DClass { int py, px, Hr, Wr, ntaps, nky, nkx, ky0, kx0, oy0, ox0; };
-static int build_dgrad_classes(const DpigConvDesc* d, int pt, int pl, DClass* cls) {
-    int nc = 0;
-    const int s = d->stride;
-    for (int py = 0; py < s; ++py)
-        for (int px = 0; px < s; ++px) {
-            DClass& c = cls[nc];
-            c.py = py; c.px = px;
-            c.Hr = (d->H - py + s - 1) / s;
-            c.Wr = (d->W - px + s - 1) / s;
-            c.ntaps = 0;
-            if (c.Hr <= 0 || c.Wr <= 0) continue;
-            // valid filter rows: ky = ky0 + s*a with (py + pt - ky) divisible by s
-            c.ky0 = ((py + pt) % s + s) % s;
-            c.kx0 = ((px + pl) % s + s) % s;
-            c.nky = c.ky0 < d->R ? (d->R - c.ky0 + s - 1) / s : 0;
-            c.nkx = c.kx0 < d->S ? (d->S - c.kx0 + s - 1) / s : 0;
-            c.oy0 = (py + pt - c.ky0) / s;     // exact; a-th valid row has offset oy0 - a
-            c.ox0 = (px + pl - c.kx0) / s;
-            c.ntaps = c.nky * c.nkx;
-            ++nc;
-        }
-    return nc;
-}
-// split plan of the parity classes when they share one launch: every class is planned against the TOTAL tile
-// count (that is what fills the machine); partial slabs are laid out back to back in the workspace
-struct S2Plan { int nc; DClass cls[4]; Plan pl[4]; long M[4]; size_t off[4]; size_t total; };
-static void plan_dgrad_s2(const DpigConvDesc* d, int pt, int pl, S2Plan* sp, int bk = BK) {
-    sp->nc = build_dgrad_classes(d, pt, pl, sp->cls);
-    const int ntile_n = cdiv(d->C, d->C <= 32 ? 32 : BN);
-    int total_tiles = 0;
-    for (int i = 0; i < sp->nc; ++i) {
-        sp->M[i] = (long)d->N * sp->cls[i].Hr * sp->cls[i].Wr;
-        total_tiles += cdiv(sp->M[i], BM) * ntile_n;
-    }
-    sp->total = 0;
-    for (int i = 0; i < sp->nc; ++i) {
-        sp->pl[i] = plan_split(total_tiles, sp->cls[i].ntaps * cdiv(d->K, bk), d->split_k);
-        sp->off[i] = sp->total;
-        if (sp->pl[i].nsplit > 1) sp->total += (size_t)sp->pl[i].nsplit * sp->M[i] * d->C * sizeof(float);
-    }
-}
-}  // namespace dpig
 
 // shape conditions of the stride-1 SAME wgrad variant (pointer alignment is checked at launch)
 static bool wgrad_s1_shape(const DpigConvDesc* d, int pt, int pl, int Ho, int Wo) {

@@ -1,0 +1,1123 @@
+// bf16-STORAGE convolution family for gfx950 (MI355X): activations, activation gradients and the filter shadows are
+// bfloat16 in HBM, products run on v_mfma_f32_32x32x16_bf16 (dense peak 2.5 PFLOP/s), accumulation, bias, residual
+// adds and every epilogue are fp32, filter gradients are written in fp32 (BASELINE configs 3-5: "bf16").
+//
+//   fwd    y  = act(conv(x, w) + bias + residual)     B = filter shadow  [tap][Cout][Cin]  (rows = GEMM N, k contiguous)
+//   dgrad  dx = (conv^T(dy, w) + accum) * act'(mask)  B = filter shadow  [tap][Cin][Cout]  (the HWIO layout itself)
+//   wgrad  dw = x^T (*) dy   (fp32 out)               both operands pixel-major; fragments by ds_read_b64_tr_b16
+//
+// What differs from the fp32 family (dpig_conv.hip), and why:
+//  * operand tiles go HBM/L2 -> LDS by LDS-DMA (global_load_lds / buffer_load ... lds, 16 bytes per lane): no staging
+//    registers, no ds_write pass, no conversions in the loop.  The DMA writes LDS lane-linearly (wave base + 16 * lane)
+//    while the SOURCE address is per lane, so the implicit-GEMM gather (pixel + filter tap, zero halo) and the
+//    bank-conflict swizzle are both expressed on the source side: lane l of a DMA instruction fills LDS row l / 8, slot
+//    l % 8 and fetches the row's 16-byte chunk  slot ^ ((row >> 1) & 7).  A 128-byte row (64 bf16 of k) is fetched by
+//    8 neighbouring lanes in permuted order: still one full line per row.
+//  * fragments are ds_read_b128 (8 consecutive k per lane) at slot chunk ^ ((row >> 1) & 7): the 16 lanes of every
+//    ds_read_b128 group hit 16 different 16-byte bank groups (conflict-free without padding, which LDS-DMA forbids).
+//  * block tile 128 x 128 x 64, 4 waves (2 x 2) of 64 x 64, two 32 KB LDS stages, one barrier per k-tile, 2 workgroups
+//    per CU; the DMA of k-tile t+1 is in flight under the 16 MFMAs per wave of k-tile t.
+// Layer shapes the loops are not written for (fewer than 32 in/out channels, channel counts not multiples of 8) are not
+// accepted here (dpig_conv2d_bf16_supported); the host converts those few thin layers and runs them on the fp32 kernels.
+//
+// Reference semantics as in dpig_conv.hip: tf.nn.conv2d 'SAME' (tflib/ops/conv2d.py:106-112), slim.conv2d
+// (models.py:396-573) and the gradients TF autodiff derives for them (trainer.py:137-140).
+#include <stdlib.h>
+#include <string.h>
+#include <type_traits>
+#include "dpig_common.h"
+#include "dpig_conv_plan.h"
+
+namespace dpig {
+namespace bfk {
+
+typedef unsigned short bf16_t;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+constexpr int TM = 128, TN = 128, TK = 64;
+constexpr int ROWB = 128;                 // bytes of one LDS row: 64 bf16 of k, unpadded (LDS-DMA images are lane-linear)
+constexpr int TILE_B = TM * ROWB;         // one operand tile: 16 KB
+constexpr int STAGE_B = 2 * TILE_B;       // A + B: 32 KB
+constexpr int LDC = TN + 4;               // fp32 accumulator staging stride of the epilogue
+constexpr int SMEM_BYTES = TM * LDC * 4;  // 67584 >= 2 stages (65536); 2 workgroups per CU = 132 KB of 160 KB
+constexpr unsigned OOB = 0x7fffffffu;
+// split-K partial sums cost relatively more than on the fp32 pipe (the products are ~8x faster, HBM is not)
+constexpr double kSplitPenalty = 700.0;
+
+// 16 zero bytes: where the flat LDS-DMA form reads structural zeros (halo, rows >= M, channels >= C) from
+__device__ __attribute__((aligned(16))) unsigned g_zero16[4];
+
+struct BGParams {
+    const bf16_t* A;      // gathered source activation (x for fwd, dy for dgrad)
+    const bf16_t* B;      // filter shadow, [wtap][Ncols][Cs]
+    bf16_t* D;            // destination activation
+    bf16_t* D2;           // optional second output: the activation BEFORE a post-activation residual add
+    const float* bias;    // [Ncols] fp32 or null
+    const bf16_t* res;    // residual / accumulate tensor (dest-shaped) or null
+    const float* res_cls; // class-indexed residual [images][9][Ncols] fp32 (tiled-embedding collapse) or null
+    const bf16_t* mask;   // activation-output tensor for act' (dest-shaped) or null
+    float* partial;       // split-K workspace [nsplit][M][Ncols]
+    int M, Hr, Wr, HrWr;
+    int Hs, Ws, lda, Cs, sr;
+    int Ncols;
+    int Hd, Wd, ldd, dr, dpy, dpx;
+    int ldres, ldmask, ldd2;
+    int res_post;
+    int ntaps, cchunks, ktiles, tiles_per_split, nsplit;
+    int mtiles, ntiles;
+    int act; float alpha;
+    int replicate, identity_rows;
+    int tap_nb, oy0, oys, ox0, oxs, w0, wa, wb;     // affine tap family, as GGParams in dpig_conv.hip
+    unsigned a_bytes, b_bytes;
+    unsigned mul_hrwr, shr_hrwr, mul_wr, shr_wr;
+};
+
+__device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned shr) {
+    return mul ? (int)(__umulhi((unsigned)n, mul) >> shr) : n;
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+// 16 bytes per lane, HBM/L2 -> LDS.  `lds_dst` is wave-uniform; lane l lands at lds_dst + 16 * l.  A lane with
+// ok == false delivers zeros: out-of-range offset (buffer form, hardware bounds check) or the zero page (flat form).
+template <bool DMA_BUF>
+__device__ __forceinline__ void dma16(const void* base, __amdgpu_buffer_rsrc_t rs, bool ok, int off, char* lds_dst) {
+    if constexpr (DMA_BUF) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)lds_dst, 16, ok ? off : (int)OOB, 0, 0, 0);
+    } else {
+        const char* src = ok ? reinterpret_cast<const char*>(base) + (long)off : reinterpret_cast<const char*>(g_zero16);
+        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)lds_dst, 16, 0, 0);
+    }
+}
+
+__device__ __forceinline__ void unpack8(uint4 u, float (&v)[8]) {
+    v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+    v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+    v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
+    v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+}
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pack2(float a, float b) {      // round-to-nearest-even (v_cvt_pk_bf16_f32)
+    bf16x2 v;
+    v[0] = (__bf16)a; v[1] = (__bf16)b;
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ uint4 pack8(const float (&v)[8]) {
+    return make_uint4(pack2(v[0], v[1]), pack2(v[2], v[3]), pack2(v[4], v[5]), pack2(v[6], v[7]));
+}
+__device__ __forceinline__ int border_class(int y, int x, int H, int W) {
+    const int cy = (y == 0) ? 0 : ((y == H - 1) ? 2 : 1);
+    const int cx = (x == 0) ? 0 : ((x == W - 1) ? 2 : 1);
+    return cy * 3 + cx;
+}
+
+// Fused epilogue on 8 consecutive columns of one GEMM row (16-byte bf16 accesses; fp32 arithmetic).
+__device__ __forceinline__ void epi8(const BGParams& p, int row, int col, float (&v)[8], const float (&bv)[8]) {
+    long pix = row;
+    long crow = 0;
+    if (!p.identity_rows || p.res_cls) {
+        const int n = row / p.HrWr;
+        const int rem = row - n * p.HrWr;
+        const int rr = rem / p.Wr;
+        const int cc = rem - rr * p.Wr;
+        if (!p.identity_rows) pix = ((long)n * p.Hd + (rr * p.dr + p.dpy)) * p.Wd + (cc * p.dr + p.dpx);
+        crow = (long)n * 9 + border_class(rr, cc, p.Hr, p.Wr);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += bv[e];
+    float rv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) rv[e] = 0.f;
+    if (p.res_cls) {
+        const float4 r0 = *reinterpret_cast<const float4*>(p.res_cls + crow * p.ldres + col);
+        const float4 r1 = *reinterpret_cast<const float4*>(p.res_cls + crow * p.ldres + col + 4);
+        rv[0] = r0.x; rv[1] = r0.y; rv[2] = r0.z; rv[3] = r0.w; rv[4] = r1.x; rv[5] = r1.y; rv[6] = r1.z; rv[7] = r1.w;
+    } else if (p.res) {
+        unpack8(*reinterpret_cast<const uint4*>(p.res + pix * p.ldres + col), rv);
+    }
+    const bool has_res = p.res || p.res_cls;
+    if (has_res && !p.res_post) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+    }
+    if (p.mask) {
+        float mv[8];
+        unpack8(*reinterpret_cast<const uint4*>(p.mask + pix * p.ldmask + col), mv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= act_grad(mv[e], p.act, p.alpha);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = act_apply(v[e], p.act, p.alpha);
+    }
+    if (p.D2) {
+        const uint4 o2 = pack8(v);
+        *reinterpret_cast<uint4*>(p.D2 + pix * p.ldd2 + col) = o2;
+        if (has_res && p.res_post) {       // the sum is formed from the STORED (rounded) activation: out = c2 + skip
+            unpack8(o2, v);
+        }
+    }
+    if (has_res && p.res_post) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+    }
+    const uint4 o = pack8(v);
+    *reinterpret_cast<uint4*>(p.D + pix * p.ldd + col) = o;
+    if (p.replicate) {
+        *reinterpret_cast<uint4*>(p.D + (pix + 1) * p.ldd + col) = o;
+        *reinterpret_cast<uint4*>(p.D + (pix + p.Wd) * p.ldd + col) = o;
+        *reinterpret_cast<uint4*>(p.D + (pix + p.Wd + 1) * p.ldd + col) = o;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// gather-GEMM: D[M x Ncols] = gather(A)[M x K] * B^T, K = taps x channels
+template <bool DMA_BUF>
+__device__ __forceinline__ void bg_body(const BGParams& p) {
+    __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];     // the ONLY LDS object (two would make hipcc
+                                                                       // drain the DMA queue before every ds_read)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wrow = (wave >> 1) * 64, wcol = (wave & 1) * 64;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    const int tile = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
+    const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+    const int m0 = mt * TM, n0 = nt * TN;
+    const int split = blockIdx.z;
+    const int kt_begin = split * p.tiles_per_split;
+    const int kt_end = min(p.ktiles, kt_begin + p.tiles_per_split);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes);
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.B, p.b_bytes);
+
+    // ---- DMA roles: instruction j of this wave fills tile rows 32j + 8*wave .. +7; lane -> (row, slot) -------------
+    const int lrow = 8 * wave + (lane >> 3);                   // (+ 32 j)
+    const int chunk = (lane & 7) ^ ((lrow >> 1) & 7);          // the row's 16-byte chunk this lane fetches
+    int a_off[4], a_iy0[4], a_ix0[4], b_off[4];
+    bool b_ok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + lrow + 32 * j;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int n = fast_div(mm, p.mul_hrwr, p.shr_hrwr);
+        const int rem = mm - n * p.HrWr;
+        const int r = fast_div(rem, p.mul_wr, p.shr_wr);
+        const int c = rem - r * p.Wr;
+        a_iy0[j] = ok ? r * p.sr : -(1 << 24);                 // a row beyond M fails every bounds test
+        a_ix0[j] = c * p.sr;
+        a_off[j] = ((((n * p.Hs + r * p.sr) * p.Ws + c * p.sr) * p.lda) + chunk * 8) * 2;
+        const int nn = n0 + lrow + 32 * j;
+        b_ok[j] = nn < p.Ncols;
+        b_off[j] = (nn * p.Cs + chunk * 8) * 2;
+    }
+    int cur_c0, cur_ta, cur_tb;
+    {
+        const int tap = kt_begin / p.cchunks;
+        cur_c0 = (kt_begin - tap * p.cchunks) * TK;
+        cur_ta = tap / p.tap_nb;
+        cur_tb = tap - cur_ta * p.tap_nb;
+    }
+    auto issue = [&](int stage) {
+        const int c0 = cur_c0, ta = cur_ta, tb = cur_tb;
+        cur_c0 += TK;
+        if (cur_c0 >= p.Cs) {
+            cur_c0 = 0;
+            if (++cur_tb == p.tap_nb) { cur_tb = 0; ++cur_ta; }
+        }
+        const int wt = p.w0 + ta * p.wa + tb * p.wb;
+        const int t_oy = p.oy0 + ta * p.oys, t_ox = p.ox0 + tb * p.oxs;
+        const bool kok = c0 + chunk * 8 < p.Cs;
+        const int t_sA = ((t_oy * p.Ws + t_ox) * p.lda + c0) * 2;
+        const int t_sB = (wt * p.Ncols * p.Cs + c0) * 2;
+        char* dst = smem + stage * STAGE_B + (8 * wave) * ROWB;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // bitwise & on purpose: && would become exec-mask branches around each DMA
+            const bool ok = kok & ((unsigned)(a_iy0[j] + t_oy) < (unsigned)p.Hs) & ((unsigned)(a_ix0[j] + t_ox) < (unsigned)p.Ws);
+            dma16<DMA_BUF>(p.A, rsA, ok, a_off[j] + t_sA, dst + 32 * j * ROWB);
+            dma16<DMA_BUF>(p.B, rsB, b_ok[j] & kok, b_off[j] + t_sB, dst + TILE_B + 32 * j * ROWB);
+        }
+    };
+
+    // ---- fragment addresses: row = wave row/col + 32 mb + l31, 8 consecutive k = chunk 2 ks + half -----------------
+    const int fsw = (l31 >> 1) & 7;
+    const char* fa_base = smem + (wrow + l31) * ROWB;
+    const char* fb_base = smem + TILE_B + (wcol + l31) * ROWB;
+    int so[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) so[ks] = ((2 * ks + half) ^ fsw) * 16;
+
+    bf16x8 fa[2][2], fb[2][2];                     // [k-step parity][32-row / 32-col block]
+    auto load_frag = [&](int stage, int ks, bf16x8 (&a)[2], bf16x8 (&b)[2]) {
+        const char* ab = fa_base + stage * STAGE_B;
+        const char* bb = fb_base + stage * STAGE_B;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) a[mb] = *reinterpret_cast<const bf16x8*>(ab + mb * 32 * ROWB + so[ks]);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) b[nb] = *reinterpret_cast<const bf16x8*>(bb + nb * 32 * ROWB + so[ks]);
+    };
+    // One k-tile: the first fragments are requested right behind the barrier, the DMA of the NEXT tile (address
+    // arithmetic + 8 LDS-DMA instructions) is issued under their latency, the fragments of k-step ks+1 are read under the
+    // MFMAs of ks.  The stage the DMA fills was last read before the barrier every wave has passed.
+    auto ktile = [&](int stage, bool more) {
+        load_frag(stage, 0, fa[0], fb[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) issue(stage ^ 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks + 1 < 4) load_frag(stage, ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][mb], fb[ks & 1][nb], acc[mb][nb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+
+    if (kt_begin < kt_end) {
+        issue(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int kt = kt_begin;
+        // two k-tiles per trip so that the LDS stage is a compile-time constant
+        for (; kt + 1 < kt_end; kt += 2) {
+            ktile(0, true);
+            ktile(1, kt + 2 < kt_end);
+        }
+        if (kt < kt_end) ktile(0, false);
+    }
+
+    // ---- epilogue: accumulators -> LDS (fp32) -> 16-byte row-contiguous global accesses -------------------------
+    float* Cs = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+                Cs[(wrow + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDC + wcol + nb * 32 + l31] = acc[mb][nb][r];
+    __syncthreads();
+
+    const int c = (tid & 15) * 8;
+    const int col = n0 + c;
+    const int rl0 = tid >> 4;
+    if (col >= p.Ncols) return;
+    if (p.nsplit > 1) {
+        float* pp = p.partial + ((long)split * p.M + m0 + rl0) * p.Ncols + col;
+#pragma unroll 4
+        for (int it = 0; it < 8; ++it) {
+            if (m0 + rl0 + 16 * it < p.M) {
+                *reinterpret_cast<float4*>(pp + (long)(16 * it) * p.Ncols) = *reinterpret_cast<const float4*>(&Cs[(rl0 + 16 * it) * LDC + c]);
+                *reinterpret_cast<float4*>(pp + (long)(16 * it) * p.Ncols + 4) = *reinterpret_cast<const float4*>(&Cs[(rl0 + 16 * it) * LDC + c + 4]);
+            }
+        }
+        return;
+    }
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+    if (p.bias) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + col);
+        const float4 b1 = *reinterpret_cast<const float4*>(p.bias + col + 4);
+        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+    }
+    auto load_c = [&](int rl, float (&v)[8]) {
+        const float4 v0 = *reinterpret_cast<const float4*>(&Cs[rl * LDC + c]);
+        const float4 v1 = *reinterpret_cast<const float4*>(&Cs[rl * LDC + c + 4]);
+        v[0] = v0.x; v[1] = v0.y; v[2] = v0.z; v[3] = v0.w; v[4] = v1.x; v[5] = v1.y; v[6] = v1.z; v[7] = v1.w;
+    };
+    if (p.identity_rows && !p.res_cls && !p.replicate) {
+        // lean bodies for the flag combinations the models produce (one slope for all three activations, row pointers
+        // advancing by 16 rows, no per-element switches): the co-resident workgroup is streaming MFMAs meanwhile
+        const float slope = (p.act == DPIG_ACT_NONE) ? 1.f : ((p.act == DPIG_ACT_RELU) ? 0.f : p.alpha);
+        auto run = [&](auto HAS_RES, auto RES_POST, auto HAS_MASK, auto HAS_D2) {
+            const long r0 = (long)(m0 + rl0);
+            bf16_t* dp = p.D + r0 * p.ldd + col;
+            const bf16_t* rp = HAS_RES ? p.res + r0 * p.ldres + col : nullptr;
+            const bf16_t* mp = HAS_MASK ? p.mask + r0 * p.ldmask + col : nullptr;
+            bf16_t* d2 = HAS_D2 ? p.D2 + r0 * p.ldd2 + col : nullptr;
+#pragma unroll 2
+            for (int it = 0; it < 8; ++it) {
+                if (m0 + rl0 + 16 * it >= p.M) break;
+                float v[8], rv[8];
+                load_c(rl0 + 16 * it, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += bv[e];
+                if (HAS_RES) unpack8(*reinterpret_cast<const uint4*>(rp + (long)(16 * it) * p.ldres), rv);
+                if (HAS_RES && !RES_POST) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += rv[e];
+                }
+                if (HAS_MASK) {
+                    float mv[8];
+                    unpack8(*reinterpret_cast<const uint4*>(mp + (long)(16 * it) * p.ldmask), mv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] *= (mv[e] > 0.f) ? 1.f : slope;
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (v[e] > 0.f) ? v[e] : (v[e] * slope + 0.f);
+                }
+                if (HAS_D2) {
+                    const uint4 o2 = pack8(v);
+                    *reinterpret_cast<uint4*>(d2 + (long)(16 * it) * p.ldd2) = o2;
+                    if (HAS_RES && RES_POST) unpack8(o2, v);
+                }
+                if (HAS_RES && RES_POST) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] += rv[e];
+                }
+                *reinterpret_cast<uint4*>(dp + (long)(16 * it) * p.ldd) = pack8(v);
+            }
+        };
+        using T = std::true_type; using F = std::false_type;
+        const bool hr = p.res != nullptr, hm = p.mask != nullptr, h2 = p.D2 != nullptr, rpost = p.res_post != 0;
+        if (!hr && !hm && !h2) { run(F{}, F{}, F{}, F{}); return; }                 // bias + activation
+        if (hr && !rpost && !hm && !h2) { run(T{}, F{}, F{}, F{}); return; }        // + residual before the activation
+        if (!hr && hm && !h2) { run(F{}, F{}, T{}, F{}); return; }                  // dgrad * activation mask
+        if (hr && rpost && !hm && h2) { run(T{}, T{}, F{}, T{}); return; }          // res-block tail
+    }
+#pragma unroll 2
+    for (int it = 0; it < 8; ++it) {
+        const int rl = rl0 + 16 * it;
+        if (m0 + rl >= p.M) break;
+        float v[8];
+        load_c(rl, v);
+        epi8(p, m0 + rl, col, v, bv);
+    }
+}
+
+template <bool DMA_BUF>
+__global__ __launch_bounds__(256, 2) void bg_kernel(const BGParams p) { bg_body<DMA_BUF>(p); }
+
+struct BGMulti { BGParams q[4]; };
+template <bool DMA_BUF>
+__global__ __launch_bounds__(256, 2) void bg_multi_kernel(const BGMulti m) {
+    const BGParams& p = m.q[blockIdx.y];
+    if ((int)blockIdx.x >= p.mtiles * p.ntiles || (int)blockIdx.z >= p.nsplit) return;
+    bg_body<DMA_BUF>(p);
+}
+
+// split-K second pass: sum the fp32 partials in split order (deterministic), run the fused epilogue, write bf16
+__device__ __forceinline__ void bg_reduce_body(const BGParams& p) {
+    const int n8 = p.Ncols >> 3;
+    const long total8 = (long)p.M * n8;
+    const long total = (long)p.M * p.Ncols;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total8; i += (long)gridDim.x * blockDim.x) {
+        const float4* p4 = reinterpret_cast<const float4*>(p.partial) + 2 * i;
+        float4 a = p4[0], b = p4[1];
+#pragma unroll 4
+        for (int s = 1; s < p.nsplit; ++s) {
+            const float4 t0 = p4[(long)s * (total >> 2)], t1 = p4[(long)s * (total >> 2) + 1];
+            a.x += t0.x; a.y += t0.y; a.z += t0.z; a.w += t0.w;
+            b.x += t1.x; b.y += t1.y; b.z += t1.z; b.w += t1.w;
+        }
+        const int row = (int)(i / n8);
+        const int col = (int)(i - (long)row * n8) * 8;
+        float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        float bv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) bv[e] = p.bias ? p.bias[col + e] : 0.f;
+        epi8(p, row, col, v, bv);
+    }
+}
+__global__ __launch_bounds__(256) void bg_reduce_kernel(const BGParams p) { bg_reduce_body(p); }
+__global__ __launch_bounds__(256) void bg_reduce_multi_kernel(const BGMulti m) {
+    const BGParams& p = m.q[blockIdx.y];
+    if (p.nsplit > 1) bg_reduce_body(p);
+}
+
+// ------------------------------------------------------------------------------------------------
+// wgrad: dw[(tap, ci), co] = sum over output pixels m of x[src(m, tap), ci] * dy[m, co]   (fp32 result)
+// GEMM rows = ci (128 per workgroup), columns = co (128), reduction = pixels (64 per k-tile).  Both operands are
+// pixel-major in HBM ([pixel][channel]) while an MFMA lane wants 8 consecutive k (= pixels) of ONE channel: the tiles
+// are staged as they are ([64 pixels][128 channels], one 256-byte row per pixel = 16 DMA granules of 8 channels) and
+// the fragments are read with ds_read_b64_tr_b16, which hands each lane 4 consecutive pixels of its channel out of a
+// [4 pixels][16 channels] block (the transpose happens inside the LDS read).  Granule g of pixel row r sits at slot
+// g ^ ((r & 3) << 2): the 32 lanes served together (4 pixels x 4 granules) then cover all 64 banks once.
+struct BWParams {
+    const bf16_t* X; const bf16_t* DY; float* DW; float* partial;
+    int Npix, Ho, Wo, HoWo;
+    int H, W, ldx, C, shift, s;
+    int K, ldy;
+    int ntaps, cblocks, ntiles;
+    int ktiles, tiles_per_split, nsplit, wrows;
+    float beta;
+    int S, pad_t, pad_l;
+    unsigned x_bytes, y_bytes;
+    unsigned mul_howo, shr_howo, mul_wo, shr_wo;
+    float* DB; float* bias_partial; float beta_b;
+    int d64_oy, d64_ox, d64_n;
+};
+constexpr int WROWB = 256;                // bytes of one pixel row of a wgrad operand tile (128 channels)
+constexpr int WTILE_B = TK * WROWB;       // 16 KB
+constexpr int WSTAGE_B = 2 * WTILE_B;
+constexpr int WSMEM_BYTES = 2 * WSTAGE_B; // 64 KB = the [128][128] fp32 staging of the epilogue
+
+template <bool DMA_BUF>
+__global__ __launch_bounds__(256, 2) void bw_kernel(const BWParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[WSMEM_BYTES];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wrow = (wave >> 1) * 64, wcol = (wave & 1) * 64;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    const int mtiles = p.ntaps * p.cblocks;
+    const int ntl = mtiles * p.ntiles;
+    // (tile, split) pairs remapped as one list, tile fastest: an XCD receives whole pixel ranges (see dpig_conv.hip)
+    const int item = xcd_remap((int)(blockIdx.x + gridDim.x * blockIdx.z), ntl * (int)gridDim.z);
+    const int split = item / ntl;
+    const int tile = item - split * ntl;
+    const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+    const int tap = mt / p.cblocks;
+    const int ci0 = (mt - tap * p.cblocks) * TM;
+    const int co0 = nt * TN;
+    const int oyoff = tap / p.S - p.pad_t, oxoff = tap % p.S - p.pad_l;
+    const int kt_begin = split * p.tiles_per_split;
+    const int kt_end = min(p.ktiles, kt_begin + p.tiles_per_split);
+    const bool do_bias = (p.DB != nullptr) && (mt == 0);
+
+    f32x16 acc[2][2];
+    f32x16 accb[2];                         // bias gradient: ones x dy on the matrix pipe (rows all equal)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        acc[0][0][r] = 0.f; acc[0][1][r] = 0.f; acc[1][0][r] = 0.f; acc[1][1][r] = 0.f;
+        accb[0][r] = 0.f; accb[1][r] = 0.f;
+    }
+    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.X, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t rsY = make_rsrc(p.DY, p.y_bytes);
+
+    // ---- DMA roles: instruction j of this wave fills pixel rows 16j + 4*wave .. +3 (1 KB); lane -> (pixel, slot) ---
+    const int prow = 4 * wave + (lane >> 4);                   // (+ 16 j); (prow & 3) == lane >> 4
+    const int gran = (lane & 15) ^ ((lane >> 4) << 2);         // the 8-channel granule this lane fetches
+    const bool cx_ok = ci0 + gran * 8 < p.C, cy_ok = co0 + gran * 8 < p.K;
+    int s_oy[4], s_ox[4], s_n[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = kt_begin * TK + prow + 16 * j;
+        const int n = fast_div(m, p.mul_howo, p.shr_howo);
+        const int rem = m - n * p.HoWo;
+        s_n[j] = n;
+        s_oy[j] = fast_div(rem, p.mul_wo, p.shr_wo);
+        s_ox[j] = rem - s_oy[j] * p.Wo;
+    }
+    auto issue = [&](int kt, int stage) {
+        char* dst = smem + stage * WSTAGE_B + (4 * wave) * WROWB;
+        const int left = p.Npix - kt * TK;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = prow + 16 * j;
+            const bool mok = r < left;
+            const int py = s_oy[j] * p.s + oyoff, px = s_ox[j] * p.s + oxoff;
+            const int iy = py >> p.shift, ix = px >> p.shift;
+            const bool ok = mok & cx_ok & (py >= 0) & (px >= 0) & (iy < p.H) & (ix < p.W);
+            const int xo = ((((s_n[j] * p.H + iy) * p.W + ix) * p.ldx) + ci0 + gran * 8) * 2;
+            const int yo = (((kt * TK + r) * p.ldy) + co0 + gran * 8) * 2;
+            dma16<DMA_BUF>(p.X, rsX, ok, xo, dst + 16 * j * WROWB);
+            dma16<DMA_BUF>(p.DY, rsY, mok & cy_ok, yo, dst + WTILE_B + 16 * j * WROWB);
+            // advance this row's pixel by one k-tile (64 pixels)
+            s_ox[j] += p.d64_ox;
+            const bool c1 = s_ox[j] >= p.Wo;
+            s_ox[j] -= c1 ? p.Wo : 0;
+            s_oy[j] += p.d64_oy + (c1 ? 1 : 0);
+            const bool c2 = s_oy[j] >= p.Ho;
+            s_oy[j] -= c2 ? p.Ho : 0;
+            s_n[j] += p.d64_n + (c2 ? 1 : 0);
+        }
+    };
+
+    // ---- transposed fragment reads.  One ds_read_b64_tr_b16 serves a [4 pixels][16 channels] block per 16 lanes: lane
+    // q of the group supplies the 8-byte address of pixel q / 4, channels 4 (q % 4) .. +3 and receives the 4 pixels of
+    // channel q.  Two reads (pixels kb .. kb+3 and kb+4 .. kb+7) make the 8 consecutive k of a 32x32x16 fragment.
+    const int q = lane & 15;
+    const int cgrp = (lane >> 4) & 1;                          // which 16 of the fragment's 32 channels
+    const int pq = q >> 2;                                     // pixel (0..3) whose address this lane supplies
+    // per-lane base addresses (operand tile offset, stage, k-step and the +4 pixel step are compile-time immediates)
+    const char* pa[2];
+    const char* pb[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        const int ca = wrow + b * 32 + cgrp * 16 + (q & 3) * 4;       // first of this lane's 4 address channels
+        const int cb = wcol + b * 32 + cgrp * 16 + (q & 3) * 4;
+        // granule = chan / 8, swizzled by the pixel row: every pixel read below is 4 t + pq, so (pixel & 3) == pq
+        pa[b] = smem + (half * 8 + pq) * WROWB + (((ca >> 3) ^ (pq << 2)) * 16) + (ca & 7) * 2;
+        pb[b] = smem + WTILE_B + (half * 8 + pq) * WROWB + (((cb >> 3) ^ (pq << 2)) * 16) + (cb & 7) * 2;
+    }
+    auto tr_read = [&](const char* a) -> s16x4 {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a);
+    };
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    // One k-tile.  ALL 32 transposed reads of the tile are requested first and the DMA of the next tile is issued behind
+    // them: hipcc treats the tr-read intrinsic as possibly aliasing a pending LDS-DMA and puts `s_waitcnt vmcnt(0)` in
+    // front of the first tr read that follows a DMA in program order -- with the DMA issued last that wait is the one
+    // the tile's own barrier needed anyway, and the DMA stays in flight under the 16 MFMAs.
+    auto ktile = [&](int kt, int stage, bool more) {
+        bf16x8 fa[4][2], fb[4][2];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {                       // k-step ks: pixels 16 ks + 8 half .. + 7 of the tile
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int o = stage * WSTAGE_B + ks * 16 * WROWB;
+                const s16x4 a0 = tr_read(pa[b] + o), a1 = tr_read(pa[b] + o + 4 * WROWB);
+                const s16x4 b0 = tr_read(pb[b] + o), b1 = tr_read(pb[b] + o + 4 * WROWB);
+                const s16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+                const s16x8 bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                fa[ks][b] = __builtin_bit_cast(bf16x8, av);
+                fb[ks][b] = __builtin_bit_cast(bf16x8, bv);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) issue(kt + 1, stage ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][mb], fb[ks][nb], acc[mb][nb], 0, 0, 0);
+            if (do_bias) {                                     // workgroup-uniform
+                const s16x8 one8 = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+                const bf16x8 ones = __builtin_bit_cast(bf16x8, one8);
+                accb[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, fb[ks][0], accb[0], 0, 0, 0);
+                accb[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, fb[ks][1], accb[1], 0, 0, 0);
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+
+    if (kt_begin < kt_end) {
+        issue(kt_begin, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int kt = kt_begin;
+        for (; kt + 1 < kt_end; kt += 2) {
+            ktile(kt, 0, true);
+            ktile(kt + 1, 1, kt + 2 < kt_end);
+        }
+        if (kt < kt_end) ktile(kt, 0, false);
+    }
+
+    // ---- epilogue ------------------------------------------------------------------------------------------------
+    const long wsize = (long)p.wrows * p.K;
+    float* Cs = reinterpret_cast<float*>(smem);        // [128][128] fp32 = the whole 64 KB
+    if (do_bias && wrow == 0 && l31 < 32 && half == 0) {
+        // row 0 of the ones x dy product: accumulator register 0 of lanes 0..31 (half 0) holds (row 0, column l31)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int co = co0 + wcol + nb * 32 + l31;
+            if (co < p.K) {
+                const float v = accb[nb][0];
+                if (p.nsplit > 1) p.bias_partial[(long)split * p.K + co] = v;
+                else p.DB[co] = (p.beta_b != 0.f) ? p.beta_b * p.DB[co] + v : v;
+            }
+        }
+    }
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+                Cs[(wrow + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * TN + wcol + nb * 32 + l31] = acc[mb][nb][r];
+    __syncthreads();
+    float* dst = (p.nsplit > 1) ? p.partial + (long)split * wsize : p.DW;
+    const float beta = (p.nsplit > 1) ? 0.f : p.beta;
+    const int c = (tid & 31) * 4;
+    const int co = co0 + c;
+    if (co < p.K) {
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int rl = (tid >> 5) + 8 * it;
+            const int ci = ci0 + rl;
+            if (ci >= p.C) continue;
+            float4 v = *reinterpret_cast<const float4*>(&Cs[rl * TN + c]);
+            float4* o = reinterpret_cast<float4*>(dst + ((long)tap * p.C + ci) * p.K + co);
+            if (beta != 0.f) {
+                const float4 old = *o;
+                v.x += beta * old.x; v.y += beta * old.y; v.z += beta * old.z; v.w += beta * old.w;
+            }
+            *o = v;
+        }
+    }
+}
+
+// out[i] = beta*out[i] + sum_s partial[s][i]; the last block folds the bias-gradient partials
+__global__ __launch_bounds__(256) void bw_splitk_sum_kernel(const float* __restrict__ partial, float* __restrict__ out,
+                                                             long n4, int nsplit, float beta,
+                                                             const float* __restrict__ bpart, float* __restrict__ db,
+                                                             int K, float beta_b) {
+    const float4* p4 = reinterpret_cast<const float4*>(partial);
+    float4* o4 = reinterpret_cast<float4*>(out);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (int s = 0; s < nsplit; ++s) {
+            const float4 t = p4[(long)s * n4 + i];
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        if (beta != 0.f) {
+            const float4 o = o4[i];
+            v.x += beta * o.x; v.y += beta * o.y; v.z += beta * o.z; v.w += beta * o.w;
+        }
+        o4[i] = v;
+    }
+    if (db != nullptr && blockIdx.x == gridDim.x - 1) {
+        for (int co = threadIdx.x; co < K; co += blockDim.x) {
+            float v = 0.f;
+            for (int s = 0; s < nsplit; ++s) v += bpart[(long)s * K + co];
+            db[co] = (beta_b != 0.f) ? beta_b * db[co] + v : v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// conversions and filter shadows
+template <int TO_BF16>
+__global__ __launch_bounds__(256) void cvt_kernel(const void* __restrict__ in, int ldi, void* __restrict__ out, int ldo,
+                                                  long rows, int cols) {
+    const int c4 = cols >> 2;     // cols % 4 == 0 on this path
+    const long total = rows * c4;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / c4;
+        const int c = (int)(i - r * c4) * 4;
+        if (TO_BF16) {
+            const float4 v = *reinterpret_cast<const float4*>(static_cast<const float*>(in) + r * ldi + c);
+            *reinterpret_cast<uint2*>(static_cast<bf16_t*>(out) + r * ldo + c) = make_uint2(pack2(v.x, v.y), pack2(v.z, v.w));
+        } else {
+            const uint2 u = *reinterpret_cast<const uint2*>(static_cast<const bf16_t*>(in) + r * ldi + c);
+            *reinterpret_cast<float4*>(static_cast<float*>(out) + r * ldo + c) =
+                make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                            __uint_as_float(u.y & 0xffff0000u));
+        }
+    }
+}
+template <int TO_BF16>
+__global__ __launch_bounds__(256) void cvt_scalar_kernel(const void* __restrict__ in, int ldi, void* __restrict__ out,
+                                                         int ldo, long rows, int cols) {
+    const long total = rows * cols;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / cols;
+        const int c = (int)(i - r * cols);
+        if (TO_BF16) {
+            const __bf16 b = (__bf16)static_cast<const float*>(in)[r * ldi + c];
+            static_cast<bf16_t*>(out)[r * ldo + c] = __builtin_bit_cast(bf16_t, b);
+        } else {
+            static_cast<float*>(out)[r * ldo + c] = __uint_as_float((unsigned)static_cast<const bf16_t*>(in)[r * ldi + c] << 16);
+        }
+    }
+}
+
+// dz = dy * act'(y)  /  y = act(x) on bf16 tensors (8 elements = 16 bytes per access; cols % 8 == 0)
+template <int BWD>
+__global__ __launch_bounds__(256) void act_bf16_kernel(const bf16_t* __restrict__ a, int lda, const bf16_t* __restrict__ y,
+                                                       int ldy, bf16_t* __restrict__ o, int ldo, long rows, int cols,
+                                                       int act, float alpha) {
+    const int c8 = cols >> 3;
+    const long total = rows * c8;
+    const float slope = (act == DPIG_ACT_NONE) ? 1.f : ((act == DPIG_ACT_RELU) ? 0.f : alpha);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / c8;
+        const int c = (int)(i - r * c8) * 8;
+        float v[8];
+        unpack8(*reinterpret_cast<const uint4*>(a + r * lda + c), v);
+        if (BWD) {
+            float m[8];
+            unpack8(*reinterpret_cast<const uint4*>(y + r * ldy + c), m);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] *= (m[e] > 0.f) ? 1.f : slope;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (v[e] > 0.f) ? v[e] : (v[e] * slope + 0.f);
+        }
+        *reinterpret_cast<uint4*>(o + r * ldo + c) = pack8(v);
+    }
+}
+
+// w [taps][C][K] fp32 -> plain [taps][C][K] bf16 and transposed [taps][K][C] bf16 (either may be null): 32 x 32 tiles
+// through LDS so that both the read and the transposed write are row-contiguous
+__global__ __launch_bounds__(256) void shadow_kernel(const float* __restrict__ w, bf16_t* __restrict__ plain,
+                                                     bf16_t* __restrict__ trans, int C, int K) {
+    __shared__ float t[32][33];
+    const int tap = blockIdx.z;
+    const int c0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;           // 32 x 8
+    const float* wt = w + (long)tap * C * K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, k = k0 + tx;
+        float v = 0.f;
+        if (c < C && k < K) {
+            v = wt[(long)c * K + k];
+            if (plain) { const __bf16 b = (__bf16)v; plain[(long)tap * C * K + (long)c * K + k] = __builtin_bit_cast(bf16_t, b); }
+        }
+        t[ty + 8 * i][tx] = v;
+    }
+    __syncthreads();
+    if (trans) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int k = k0 + ty + 8 * i, c = c0 + tx;
+            if (c < C && k < K) {
+                const __bf16 b = (__bf16)t[tx][ty + 8 * i];
+                trans[(long)tap * C * K + (long)k * C + c] = __builtin_bit_cast(bf16_t, b);
+            }
+        }
+    }
+}
+
+// ================================================================================================
+// host side
+// ================================================================================================
+static int dma_mode() {          // 1: buffer_load ... lds (hardware bounds check), 0: global_load_lds + zero page
+    static int mode = -1;
+    if (mode < 0) {
+        const char* e = getenv("DPIG_BF16_DMA");
+        mode = (e && !strcmp(e, "flat")) ? 0 : 1;
+    }
+    return mode;
+}
+
+static bool shape_ok(const DpigConvDesc* d) {
+    return d->C % 8 == 0 && d->K % 8 == 0 && d->C >= 32 && d->K >= 32 && d->ldx % 8 == 0 && d->ldy % 8 == 0;
+}
+
+static int prepare_bg(BGParams& p, int nimg, long filter_elems) {
+    p.HrWr = p.Hr * p.Wr;
+    find_divisor(p.HrWr, &p.mul_hrwr, &p.shr_hrwr);
+    find_divisor(p.Wr, &p.mul_wr, &p.shr_wr);
+    const long a_elems = ((long)nimg * p.Hs * p.Ws - 1) * p.lda + p.Cs;
+    if (a_elems * 2 >= 0x7fffffffL || filter_elems * 2 >= 0x7fffffffL)
+        return fail(DPIG_EINVAL, "tensor exceeds the 2 GiB offset range of one launch");
+    p.a_bytes = (unsigned)(a_elems * 2);
+    p.b_bytes = (unsigned)(filter_elems * 2);
+    const bool al = aligned16(p.A) && aligned16(p.B) && aligned16(p.D) && (!p.D2 || aligned16(p.D2)) &&
+                    (!p.bias || aligned16(p.bias)) && (!p.res || aligned16(p.res)) && (!p.res_cls || aligned16(p.res_cls)) &&
+                    (!p.mask || aligned16(p.mask)) && (!p.partial || aligned16(p.partial));
+    const bool ld = (p.lda % 8 == 0) && (p.ldd % 8 == 0) && (!p.D2 || p.ldd2 % 8 == 0) && (!p.res || p.ldres % 8 == 0) &&
+                    (!p.res_cls || p.ldres % 4 == 0) && (!p.mask || p.ldmask % 8 == 0) && (p.Cs % 8 == 0) && (p.Ncols % 8 == 0);
+    if (!al || !ld) return fail(DPIG_EALIGN, "bf16 conv: pointers must be 16-byte aligned, channel counts / strides multiples of 8");
+    p.mtiles = cdiv(p.M, TM);
+    p.ntiles = cdiv(p.Ncols, TN);
+    p.cchunks = cdiv(p.Cs, TK);
+    p.ktiles = p.ntaps * p.cchunks;
+    return DPIG_OK;
+}
+static int reduce_blocks(const BGParams& p) {
+    const long total8 = (long)p.M * p.Ncols / 8;
+    int blocks = cdiv(total8, 256);
+    return blocks > 8 * kNumCU ? 8 * kNumCU : blocks;
+}
+static int launch_bg(BGParams& p, int nimg, long filter_elems, hipStream_t st) {
+    int rc = prepare_bg(p, nimg, filter_elems);
+    if (rc) return rc;
+    dim3 grid(p.mtiles * p.ntiles, 1, p.nsplit), block(256);
+    if (dma_mode()) hipLaunchKernelGGL((bg_kernel<true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((bg_kernel<false>), grid, block, 0, st, p);
+    rc = check_launch("bg_kernel");
+    if (rc) return rc;
+    if (p.nsplit > 1) {
+        hipLaunchKernelGGL(bg_reduce_kernel, dim3(reduce_blocks(p)), dim3(256), 0, st, p);
+        rc = check_launch("bg_reduce_kernel");
+    }
+    return rc;
+}
+static int launch_bg_multi(BGParams* q, int n, int nimg, long filter_elems, hipStream_t st) {
+    BGMulti m = {};
+    int max_tiles = 0, max_split = 1, max_red = 0;
+    for (int i = 0; i < n; ++i) {
+        const int rc = prepare_bg(q[i], nimg, filter_elems);
+        if (rc) return rc;
+        if (q[i].mtiles * q[i].ntiles > max_tiles) max_tiles = q[i].mtiles * q[i].ntiles;
+        if (q[i].nsplit > max_split) max_split = q[i].nsplit;
+        if (q[i].nsplit > 1 && reduce_blocks(q[i]) > max_red) max_red = reduce_blocks(q[i]);
+        m.q[i] = q[i];
+    }
+    dim3 grid(max_tiles, n, max_split), block(256);
+    if (dma_mode()) hipLaunchKernelGGL((bg_multi_kernel<true>), grid, block, 0, st, m);
+    else hipLaunchKernelGGL((bg_multi_kernel<false>), grid, block, 0, st, m);
+    int rc = check_launch("bg_multi_kernel");
+    if (rc) return rc;
+    if (max_red > 0) {
+        hipLaunchKernelGGL(bg_reduce_multi_kernel, dim3(max_red, n), dim3(256), 0, st, m);
+        rc = check_launch("bg_reduce_multi_kernel");
+    }
+    return rc;
+}
+
+static void plan_s2(const DpigConvDesc* d, int pt, int pl, S2Plan* sp) { plan_dgrad_s2(d, pt, pl, sp, TK, kSplitPenalty); }
+
+}  // namespace bfk
+}  // namespace dpig
+
+using namespace dpig;
+using namespace dpig::bfk;
+
+extern "C" int dpig_conv2d_bf16_supported(const DpigConvDesc* d, int which) {
+    int pt, pl, Ho, Wo;
+    if (resolve_desc(d, &pt, &pl, &Ho, &Wo)) return 0;
+    (void)which;
+    return shape_ok(d) ? 1 : 0;
+}
+
+extern "C" size_t dpig_conv2d_bf16_workspace_bytes(const DpigConvDesc* d, int which) {
+    int pt, pl, Ho, Wo;
+    if (resolve_desc(d, &pt, &pl, &Ho, &Wo) || !shape_ok(d)) return 0;
+    if (which == 0) {
+        const long M = d->upsample2x ? (long)d->N * d->H * d->W : (long)d->N * Ho * Wo;
+        Plan pln = plan_split(cdiv(M, TM) * cdiv(d->K, TN), d->R * d->S * cdiv(d->C, TK), d->split_k, TK, kSplitPenalty);
+        return pln.nsplit > 1 ? (size_t)pln.nsplit * M * d->K * sizeof(float) : 0;
+    } else if (which == 1) {
+        if (d->upsample2x || d->stride == 1) {
+            const long M = (long)d->N * d->H * d->W;
+            const int ntaps = d->upsample2x ? 4 : d->R * d->S;
+            Plan pln = plan_split(cdiv(M, TM) * cdiv(d->C, TN), ntaps * cdiv(d->K, TK), d->split_k, TK, kSplitPenalty);
+            return pln.nsplit > 1 ? (size_t)pln.nsplit * M * d->C * sizeof(float) : 0;
+        }
+        S2Plan sp;
+        plan_s2(d, pt, pl, &sp);
+        return sp.total;
+    } else if (which == 2) {
+        const long Npix = (long)d->N * Ho * Wo * (d->upsample2x ? 4 : 1);
+        const int tiles = (d->upsample2x ? 1 : d->R * d->S) * cdiv(d->C, TM) * cdiv(d->K, TN);
+        Plan pln = plan_split(tiles, cdiv(Npix, TK), d->split_k, TK, kSplitPenalty);
+        return pln.nsplit > 1 ? (size_t)pln.nsplit * ((size_t)d->R * d->S * d->C * d->K + d->K) * sizeof(float) : 0;
+    }
+    return 0;
+}
+
+extern "C" int dpig_conv2d_fwd_bf16(const DpigConvDesc* d, const uint16_t* x, const uint16_t* w_t, const float* bias,
+                                    const uint16_t* residual, const float* residual_class, uint16_t* y, uint16_t* y_act,
+                                    void* ws, size_t ws_bytes, void* stream) {
+    int pt, pl, Ho, Wo;
+    int rc = resolve_desc(d, &pt, &pl, &Ho, &Wo);
+    if (rc) return rc;
+    if (!x || !w_t || !y) return fail(DPIG_EINVAL, "null tensor pointer");
+    if (!shape_ok(d)) return fail(DPIG_EINVAL, "bf16 conv needs >= 32 channels in multiples of 8 on both sides");
+    if (residual && residual_class) return fail(DPIG_EINVAL, "residual and residual_class are exclusive");
+    if (d->upsample2x && (residual || residual_class || y_act)) return fail(DPIG_EINVAL, "residual / y_act unsupported with upsample2x");
+    if (residual_class && (d->stride != 1 || d->H < 2 || d->W < 2))
+        return fail(DPIG_EINVAL, "res_class needs a stride-1 conv on an image of at least 2x2");
+    if (y_act && d->ldy2 < d->K) return fail(DPIG_EINVAL, "ldy2 < K");
+    if ((residual || residual_class) && d->ldres < d->K) return fail(DPIG_EINVAL, "ldres < K");
+    BGParams p = {};
+    p.A = x; p.B = w_t; p.D = y; p.bias = bias; p.res = residual; p.res_cls = residual_class; p.mask = nullptr;
+    p.D2 = y_act; p.ldd2 = d->ldy2; p.res_post = d->res_after_act;
+    p.partial = static_cast<float*>(ws);
+    p.M = d->upsample2x ? d->N * d->H * d->W : d->N * Ho * Wo;
+    p.Hr = d->upsample2x ? d->H : Ho; p.Wr = d->upsample2x ? d->W : Wo;
+    p.Hs = d->H; p.Ws = d->W; p.lda = d->ldx; p.Cs = d->C; p.sr = d->stride;
+    p.Ncols = d->K;
+    if (d->upsample2x) { p.Hd = 2 * d->H; p.Wd = 2 * d->W; p.dr = 2; p.replicate = 1; }
+    else { p.Hd = Ho; p.Wd = Wo; p.dr = 1; p.replicate = 0; }
+    p.dpy = 0; p.dpx = 0; p.ldd = d->ldy; p.ldres = d->ldres; p.ldmask = 0;
+    p.identity_rows = d->upsample2x ? 0 : 1;
+    p.act = d->act; p.alpha = d->alpha;
+    p.ntaps = d->R * d->S;
+    p.tap_nb = d->S; p.oy0 = -pt; p.oys = 1; p.ox0 = -pl; p.oxs = 1; p.w0 = 0; p.wa = d->S; p.wb = 1;
+    Plan pln = plan_split(cdiv(p.M, TM) * cdiv(p.Ncols, TN), p.ntaps * cdiv(p.Cs, TK), d->split_k, TK, kSplitPenalty);
+    p.nsplit = pln.nsplit; p.tiles_per_split = pln.tiles_per_split;
+    if (p.nsplit > 1 && (!ws || ws_bytes < (size_t)p.nsplit * p.M * p.Ncols * sizeof(float)))
+        return fail(DPIG_ENOMEM, "bf16 conv fwd workspace too small: have %zu", ws_bytes);
+    return launch_bg(p, d->N, (long)d->R * d->S * d->C * d->K, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int dpig_conv2d_dgrad_bf16(const DpigConvDesc* d, const uint16_t* dy, const uint16_t* w, const uint16_t* accum,
+                                      const uint16_t* mask, uint16_t* dx, void* ws, size_t ws_bytes, void* stream) {
+    int pt, pl, Ho, Wo;
+    int rc = resolve_desc(d, &pt, &pl, &Ho, &Wo);
+    if (rc) return rc;
+    if (!dy || !w || !dx) return fail(DPIG_EINVAL, "null tensor pointer");
+    if (!shape_ok(d)) return fail(DPIG_EINVAL, "bf16 conv needs >= 32 channels in multiples of 8 on both sides");
+    if (accum && d->ldres < d->C) return fail(DPIG_EINVAL, "ldres < C");
+    if (mask && d->ldmask < d->C) return fail(DPIG_EINVAL, "ldmask < C");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    BGParams p = {};
+    p.A = dy; p.B = w; p.D = dx; p.bias = nullptr; p.res = accum; p.mask = mask;
+    p.partial = static_cast<float*>(ws);
+    p.lda = d->ldy; p.Cs = d->K; p.Ncols = d->C;
+    p.Hd = d->H; p.Wd = d->W; p.ldd = d->ldx; p.ldres = d->ldres; p.ldmask = d->ldmask;
+    p.act = mask ? d->act : DPIG_ACT_NONE; p.alpha = d->alpha; p.replicate = 0;
+    const long felems = (long)d->R * d->S * d->C * d->K;
+    if (d->upsample2x) {
+        p.M = d->N * d->H * d->W; p.Hr = d->H; p.Wr = d->W;
+        p.Hs = 2 * d->H; p.Ws = 2 * d->W; p.sr = 2;
+        p.dr = 1; p.identity_rows = 1;
+        p.ntaps = 4;
+        p.tap_nb = 2; p.oy0 = 0; p.oys = 1; p.ox0 = 0; p.oxs = 1; p.w0 = 0; p.wa = 0; p.wb = 0;
+    } else if (d->stride == 1) {
+        p.M = d->N * d->H * d->W; p.Hr = d->H; p.Wr = d->W;
+        p.Hs = Ho; p.Ws = Wo; p.sr = 1;
+        p.dr = 1; p.identity_rows = 1;
+        p.ntaps = d->R * d->S;
+        p.tap_nb = d->S; p.oy0 = pt; p.oys = -1; p.ox0 = pl; p.oxs = -1; p.w0 = 0; p.wa = d->S; p.wb = 1;
+    } else {
+        S2Plan sp;
+        plan_s2(d, pt, pl, &sp);
+        if (sp.total > 0 && (!ws || ws_bytes < sp.total))
+            return fail(DPIG_ENOMEM, "bf16 conv dgrad workspace too small: have %zu", ws_bytes);
+        BGParams qs[4];
+        for (int i = 0; i < sp.nc; ++i) {
+            const DClass& c = sp.cls[i];
+            BGParams& q = qs[i];
+            q = p;
+            q.M = (int)sp.M[i]; q.Hr = c.Hr; q.Wr = c.Wr;
+            q.Hs = Ho; q.Ws = Wo; q.sr = 1;
+            q.dr = 2; q.dpy = c.py; q.dpx = c.px; q.identity_rows = 0;
+            q.ntaps = c.ntaps;
+            q.tap_nb = c.nkx > 0 ? c.nkx : 1;
+            q.oy0 = c.oy0; q.oys = -1; q.ox0 = c.ox0; q.oxs = -1;
+            q.w0 = c.ky0 * d->S + c.kx0; q.wa = d->stride * d->S; q.wb = d->stride;
+            q.nsplit = sp.pl[i].nsplit; q.tiles_per_split = sp.pl[i].tiles_per_split;
+            q.partial = reinterpret_cast<float*>(static_cast<char*>(ws) + sp.off[i]);
+        }
+        return launch_bg_multi(qs, sp.nc, d->N, felems, st);
+    }
+    Plan pln = plan_split(cdiv(p.M, TM) * cdiv(p.Ncols, TN), p.ntaps * cdiv(p.Cs, TK), d->split_k, TK, kSplitPenalty);
+    p.nsplit = pln.nsplit; p.tiles_per_split = pln.tiles_per_split;
+    if (p.nsplit > 1 && (!ws || ws_bytes < (size_t)p.nsplit * p.M * p.Ncols * sizeof(float)))
+        return fail(DPIG_ENOMEM, "bf16 conv dgrad workspace too small: have %zu", ws_bytes);
+    return launch_bg(p, d->N, felems, st);
+}
+
+extern "C" int dpig_conv2d_wgrad_bf16(const DpigConvDesc* d, const uint16_t* x, const uint16_t* dy, float* dw, float beta,
+                                      float* db, float beta_b, void* ws, size_t ws_bytes, void* stream) {
+    int pt, pl, Ho, Wo;
+    int rc = resolve_desc(d, &pt, &pl, &Ho, &Wo);
+    if (rc) return rc;
+    if (!x || !dy || !dw) return fail(DPIG_EINVAL, "null tensor pointer");
+    if (!shape_ok(d)) return fail(DPIG_EINVAL, "bf16 conv needs >= 32 channels in multiples of 8 on both sides");
+    if (!aligned16(x) || !aligned16(dy) || !aligned16(dw) || (ws && !aligned16(ws)))
+        return fail(DPIG_EALIGN, "bf16 wgrad: pointers must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    BWParams p = {};
+    p.X = x; p.DY = dy; p.DW = dw; p.partial = static_cast<float*>(ws);
+    p.H = d->H; p.W = d->W; p.ldx = d->ldx; p.C = d->C; p.K = d->K; p.ldy = d->ldy;
+    p.beta = beta;
+    if (d->upsample2x) {
+        p.Ho = 2 * d->H; p.Wo = 2 * d->W; p.shift = 1; p.s = 1;
+        p.ntaps = 1; p.S = 1; p.pad_t = 0; p.pad_l = 0;
+    } else {
+        p.Ho = Ho; p.Wo = Wo; p.shift = 0; p.s = d->stride;
+        p.ntaps = d->R * d->S; p.S = d->S; p.pad_t = pt; p.pad_l = pl;
+    }
+    p.HoWo = p.Ho * p.Wo;
+    p.Npix = d->N * p.HoWo;
+    const long xe = ((long)d->N * d->H * d->W - 1) * d->ldx + d->C;
+    const long ye = ((long)p.Npix - 1) * d->ldy + d->K;
+    if (xe * 2 >= 0x7fffffffL || ye * 2 >= 0x7fffffffL)
+        return fail(DPIG_EINVAL, "tensor exceeds the 2 GiB offset range of one launch");
+    p.x_bytes = (unsigned)(xe * 2); p.y_bytes = (unsigned)(ye * 2);
+    find_divisor(p.HoWo, &p.mul_howo, &p.shr_howo);
+    find_divisor(p.Wo, &p.mul_wo, &p.shr_wo);
+    p.wrows = d->R * d->S * d->C;
+    p.cblocks = cdiv(d->C, TM);
+    p.ntiles = cdiv(d->K, TN);
+    p.ktiles = cdiv(p.Npix, TK);
+    const int tiles = p.ntaps * p.cblocks * p.ntiles;
+    Plan pln = plan_split(tiles, p.ktiles, d->split_k, TK, kSplitPenalty);
+    p.nsplit = pln.nsplit; p.tiles_per_split = pln.tiles_per_split;
+    const long wsize = (long)p.wrows * d->K;
+    if (p.nsplit > 1 && (!ws || ws_bytes < (size_t)p.nsplit * (wsize + d->K) * sizeof(float)))
+        return fail(DPIG_ENOMEM, "bf16 conv wgrad workspace too small: have %zu", ws_bytes);
+    p.DB = db; p.beta_b = beta_b;
+    p.bias_partial = p.partial ? p.partial + (long)p.nsplit * wsize : nullptr;
+    p.d64_n = TK / p.HoWo;
+    p.d64_oy = (TK % p.HoWo) / p.Wo;
+    p.d64_ox = (TK % p.HoWo) % p.Wo;
+    dim3 grid(tiles, 1, p.nsplit), block(256);
+    if (dma_mode()) hipLaunchKernelGGL((bw_kernel<true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((bw_kernel<false>), grid, block, 0, st, p);
+    rc = check_launch("bw_kernel");
+    if (rc) return rc;
+    if (p.nsplit > 1) {
+        const long n4 = wsize / 4;
+        int blocks = cdiv(n4, 256);
+        if (blocks > 8 * kNumCU) blocks = 8 * kNumCU;
+        hipLaunchKernelGGL(bw_splitk_sum_kernel, dim3(blocks), dim3(256), 0, st, p.partial, dw, n4, p.nsplit, beta,
+                           p.bias_partial, db, d->K, beta_b);
+        rc = check_launch("bw_splitk_sum_kernel");
+    }
+    return rc;
+}
+
+extern "C" int dpig_cvt_f32_to_bf16(const float* in, int ldi, uint16_t* out, int ldo, int64_t rows, int cols, void* stream) {
+    if (!in || !out || rows < 0 || cols <= 0 || ldi < cols || ldo < cols) return fail(DPIG_EINVAL, "cvt: bad arguments");
+    if (rows == 0) return DPIG_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool vec = (cols % 4 == 0) && (ldi % 4 == 0) && (ldo % 4 == 0) && aligned16(in) && ((reinterpret_cast<uintptr_t>(out) & 7u) == 0);
+    const long total = vec ? rows * (cols / 4) : rows * (long)cols;
+    int blocks = cdiv(total, 256);
+    if (blocks > 16 * kNumCU) blocks = 16 * kNumCU;
+    if (vec) hipLaunchKernelGGL((cvt_kernel<1>), dim3(blocks), dim3(256), 0, st, in, ldi, out, ldo, (long)rows, cols);
+    else hipLaunchKernelGGL((cvt_scalar_kernel<1>), dim3(blocks), dim3(256), 0, st, in, ldi, out, ldo, (long)rows, cols);
+    return check_launch("cvt_f32_to_bf16");
+}
+
+extern "C" int dpig_cvt_bf16_to_f32(const uint16_t* in, int ldi, float* out, int ldo, int64_t rows, int cols, void* stream) {
+    if (!in || !out || rows < 0 || cols <= 0 || ldi < cols || ldo < cols) return fail(DPIG_EINVAL, "cvt: bad arguments");
+    if (rows == 0) return DPIG_OK;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool vec = (cols % 4 == 0) && (ldi % 4 == 0) && (ldo % 4 == 0) && aligned16(out) && ((reinterpret_cast<uintptr_t>(in) & 7u) == 0);
+    const long total = vec ? rows * (cols / 4) : rows * (long)cols;
+    int blocks = cdiv(total, 256);
+    if (blocks > 16 * kNumCU) blocks = 16 * kNumCU;
+    if (vec) hipLaunchKernelGGL((cvt_kernel<0>), dim3(blocks), dim3(256), 0, st, in, ldi, out, ldo, (long)rows, cols);
+    else hipLaunchKernelGGL((cvt_scalar_kernel<0>), dim3(blocks), dim3(256), 0, st, in, ldi, out, ldo, (long)rows, cols);
+    return check_launch("cvt_bf16_to_f32");
+}
+
+extern "C" int dpig_filter_shadow_bf16(const float* w, uint16_t* plain, uint16_t* transposed, int taps, int C, int K,
+                                       void* stream) {
+    if (!w || taps <= 0 || C <= 0 || K <= 0) return fail(DPIG_EINVAL, "filter shadow: bad arguments");
+    if (!plain && !transposed) return DPIG_OK;
+    dim3 grid(cdiv(K, 32), cdiv(C, 32), taps);
+    hipLaunchKernelGGL(shadow_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), w, plain, transposed, C, K);
+    return check_launch("filter_shadow_bf16");
+}
+
+static int act_bf16_args(const void* a, int lda, const void* o, int ldo, int64_t rows, int cols) {
+    if (!a || !o || rows < 0 || cols <= 0) return fail(DPIG_EINVAL, "act_bf16: bad arguments");
+    if (cols % 8 || lda % 8 || ldo % 8 || !aligned16(a) || !aligned16(o))
+        return fail(DPIG_EALIGN, "act_bf16: 16-byte aligned tensors with channel counts / strides in multiples of 8");
+    return DPIG_OK;
+}
+extern "C" int dpig_act_fwd_bf16(const uint16_t* x, int ldx, uint16_t* y, int ldy, int64_t rows, int cols, int act,
+                                 float alpha, void* stream) {
+    int rc = act_bf16_args(x, ldx, y, ldy, rows, cols);
+    if (rc || rows == 0) return rc;
+    int blocks = cdiv(rows * (cols / 8), 256);
+    if (blocks > 16 * kNumCU) blocks = 16 * kNumCU;
+    hipLaunchKernelGGL((act_bf16_kernel<0>), dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx,
+                       (const bf16_t*)nullptr, 0, y, ldy, (long)rows, cols, act, alpha);
+    return check_launch("act_fwd_bf16");
+}
+extern "C" int dpig_act_bwd_bf16(const uint16_t* dy, int lddy, const uint16_t* y, int ldy, uint16_t* dz, int lddz,
+                                 int64_t rows, int cols, int act, float alpha, void* stream) {
+    int rc = act_bf16_args(dy, lddy, dz, lddz, rows, cols);
+    if (rc || rows == 0) return rc;
+    if (!y || ldy % 8 || !aligned16(y)) return fail(DPIG_EALIGN, "act_bwd_bf16: bad activation tensor");
+    int blocks = cdiv(rows * (cols / 8), 256);
+    if (blocks > 16 * kNumCU) blocks = 16 * kNumCU;
+    hipLaunchKernelGGL((act_bf16_kernel<1>), dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), dy, lddy, y,
+                       ldy, dz, lddz, (long)rows, cols, act, alpha);
+    return check_launch("act_bwd_bf16");
+}

@@ -1,8 +1,17 @@
 """Thin functional layer over the C ABI: torch tensors in, torch tensors out, no autograd.
 
 Every function launches hand-written gfx950 kernels from libdpig_hip.so on torch's current HIP
-stream.  Tensors are fp32 NHWC; a tensor may be a channel slice of a wider NHWC buffer (stride of
+stream.  Tensors are NHWC; a tensor may be a channel slice of a wider NHWC buffer (stride of
 the W axis = "ld"), which is how channel concats (models.py:524,560) cost nothing.
+
+Arithmetic modes (`set_compute`):
+  'f32'    the reference's arithmetic: fp32 tensors, exact fp32 products (BASELINE configs 1-2);
+  'bf16'   bf16 STORAGE (BASELINE configs 3-5): activations and their gradients are torch.bfloat16 tensors, conv
+           filters are read from bf16 shadows of the fp32 masters, products run on the bf16 matrix pipe, every
+           accumulation / bias / residual / normalisation is fp32, parameter gradients and the optimizer stay fp32.
+           Ops whose kernels exist in fp32 only (thin 3-channel convs, norms, FC layers, crops) convert at their
+           boundary (`to_f32` / `to_bf16` kernels); a tensor is stored as bf16 iff its channel count is a multiple of 8;
+  'bf16c'  round 1's intermediate mode: fp32 tensors, conv operands rounded to bf16 on their way into LDS.
 """
 import ctypes
 
@@ -37,11 +46,22 @@ class _Timed(object):
         return False
 
 
+BF16 = torch.bfloat16
+F32 = torch.float32
+
+
 def _require_gpu(t):
     if not t.is_cuda:
         raise RuntimeError("dpig HIP ops need device tensors (got %s): there is no CPU fallback" % t.device)
     if t.dtype != torch.float32:
         raise RuntimeError("dpig HIP ops are fp32 (got %s)" % t.dtype)
+
+
+def _require_dev(t):
+    if not t.is_cuda:
+        raise RuntimeError("dpig HIP ops need device tensors (got %s): there is no CPU fallback" % t.device)
+    if t.dtype not in (F32, BF16):
+        raise RuntimeError("dpig HIP ops take fp32 or bf16 tensors (got %s)" % t.dtype)
 
 
 def nhwc_ld(t):
@@ -70,17 +90,133 @@ def as_nhwc(t):
 
 
 COMPUTE_F32, COMPUTE_BF16 = 0, 1
-_COMPUTE = [COMPUTE_F32]
+_COMPUTE = [COMPUTE_F32]      # DpigConvDesc.compute of the fp32-tensor entry points
+_STORE_BF16 = [False]         # 'bf16' mode: activations stored as bf16
 
 
 def set_compute(dtype):
-    """Matrix-pipe arithmetic of every subsequent conv launch: 'f32' (default; exact fp32 products) or 'bf16'
-    (operands rounded to bfloat16, fp32 accumulation, tensors unchanged in memory: DpigConvDesc.compute)."""
-    _COMPUTE[0] = {"f32": COMPUTE_F32, "fp32": COMPUTE_F32, "bf16": COMPUTE_BF16}[dtype]
+    """Arithmetic of every subsequent launch (module docstring): 'f32' | 'bf16' (storage) | 'bf16c' (fp32 tensors,
+    bf16 matrix pipe)."""
+    mode = {"f32": "f32", "fp32": "f32", "bf16": "bf16", "bf16c": "bf16c"}[dtype]
+    _COMPUTE[0] = COMPUTE_BF16 if mode == "bf16c" else COMPUTE_F32
+    _STORE_BF16[0] = mode == "bf16"
 
 
 def get_compute():
-    return "bf16" if _COMPUTE[0] == COMPUTE_BF16 else "f32"
+    return "bf16" if _STORE_BF16[0] else ("bf16c" if _COMPUTE[0] == COMPUTE_BF16 else "f32")
+
+
+def storable_bf16(channels):
+    """A tensor is kept in bf16 iff 16-byte accesses fall on channel-vector boundaries."""
+    return channels % 8 == 0
+
+
+def _as_rows(t):
+    """(tensor, rows, cols, ld) view of an NHWC / 2-D / 1-D tensor for the row-strided elementwise kernels."""
+    if t.dim() == 4:
+        t, ld = as_nhwc(t)
+        return t, t.shape[0] * t.shape[1] * t.shape[2], t.shape[3], ld
+    if t.dim() == 2 and (t.stride(1) == 1 or t.shape[1] == 1) and (t.shape[0] <= 1 or t.stride(0) >= t.shape[1]):
+        return t, t.shape[0], t.shape[1], (t.stride(0) if t.shape[0] > 1 else t.shape[1])
+    t = t.contiguous()
+    n = t.numel()
+    cols = t.shape[-1] if t.dim() >= 1 and t.shape[-1] > 0 else 1
+    return t, n // max(cols, 1), cols, cols
+
+
+def to_f32(t):
+    """bf16 -> fp32 copy (exact) through dpig_cvt_bf16_to_f32; fp32 tensors pass through."""
+    if t is None or t.dtype == F32:
+        return t
+    _require_dev(t)
+    t, rows, cols, ld = _as_rows(t)
+    out = torch.empty(t.shape, dtype=F32, device=t.device)
+    if t.numel():
+        check(lib().dpig_cvt_bf16_to_f32(ptr(t), ld, ptr(out), cols, rows, cols, stream_ptr()), "cvt_bf16_to_f32")
+    return out
+
+
+def to_bf16(t, out=None):
+    """fp32 -> bf16 copy (round-to-nearest-even) through dpig_cvt_f32_to_bf16; bf16 tensors pass through."""
+    if t is None or (t.dtype == BF16 and out is None):
+        return t
+    _require_dev(t)
+    if t.dtype == BF16:
+        out.copy_(t)
+        return out
+    t, rows, cols, ld = _as_rows(t)
+    if out is None:
+        out = torch.empty(t.shape, dtype=BF16, device=t.device)
+        ldo = cols
+    else:
+        _, _, _, ldo = _as_rows(out)
+    if t.numel():
+        check(lib().dpig_cvt_f32_to_bf16(ptr(t), ld, ptr(out), ldo, rows, cols, stream_ptr()), "cvt_f32_to_bf16")
+    return out
+
+
+def _like_input(y32, ref):
+    """Give an fp32 result the storage type of the activation it derives from."""
+    if ref.dtype == BF16 and y32 is not None and y32.dtype == F32 and storable_bf16(y32.shape[-1]):
+        return to_bf16(y32)
+    return y32
+
+
+def filter_shadows(w, want_plain=True, want_t=True):
+    """bf16 shadows of an fp32 HWIO filter: (plain [R,S,C,K], transposed [R,S,K,C]).  Parameters owned by a
+    trainer carry persistent shadows refreshed after every optimizer step (`w._dpig_shadow`, trainer.FlatParams);
+    any other tensor gets them made on the spot."""
+    sh = getattr(w, "_dpig_shadow", None)
+    if sh is not None:
+        return sh
+    w = w.contiguous()
+    R, S, C, K = w.shape
+    plain = torch.empty((R, S, C, K), dtype=BF16, device=w.device) if want_plain else None
+    trans = torch.empty((R, S, K, C), dtype=BF16, device=w.device) if want_t else None
+    check(lib().dpig_filter_shadow_bf16(ptr(w), ptr(plain), ptr(trans), R * S, C, K, stream_ptr()), "filter_shadow")
+    return plain, trans
+
+
+class FilterShadows(object):
+    """Persistent bf16 shadows (plain HWIO + per-tap transposed) of every conv filter in `params` that the bf16 kernels
+    accept, in ONE allocation; attached to the parameters as `_dpig_shadow`.  `refresh()` re-derives them from the fp32
+    masters (one small launch per filter; call it after anything that changes the weights)."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.dim() == 4 and _bf16_conv_ok(p.shape[2], p.shape[3])]
+        total = sum((p.numel() + 7) // 8 * 8 for p in self.params)
+        self.numel = total
+        if not self.params:
+            return
+        dev = self.params[0].device
+        self.buf = torch.empty(2 * total, dtype=BF16, device=dev)
+        off = 0
+        for p in self.params:
+            R, S, C, K = p.shape
+            n = p.numel()
+            p._dpig_shadow = (self.buf[off:off + n].view(R, S, C, K), self.buf[total + off:total + off + n].view(R, S, K, C))
+            off += (n + 7) // 8 * 8
+        self.refresh()
+
+    def refresh(self):
+        for p in self.params:
+            plain, trans = p._dpig_shadow
+            R, S, C, K = p.shape
+            check(lib().dpig_filter_shadow_bf16(ptr(p.data), ptr(plain), ptr(trans), R * S, C, K, stream_ptr()),
+                  "filter_shadow")
+
+    def detach(self):
+        for p in self.params:
+            if hasattr(p, "_dpig_shadow"):
+                del p._dpig_shadow
+
+
+def _bf16_conv_ok(C, K, *lds):
+    return C % 8 == 0 and K % 8 == 0 and C >= 32 and K >= 32 and all(ld % 8 == 0 for ld in lds)
+
+
+def _al16(*ts):
+    return all(t is None or t.data_ptr() % 16 == 0 for t in ts)
 
 
 def _desc(N, H, W, C, K, R, S, stride, ldx, ldy, ldres=0, ldmask=0, act=ACT_NONE, alpha=0.2, upsample2x=False,
@@ -112,6 +248,9 @@ def conv2d_fwd(x, w, bias=None, stride=1, act=ACT_NONE, alpha=0.2, residual=None
     """y = act(conv_SAME(x, w) + bias + residual) (or act(..) + residual with res_after_act);
     x NHWC, w HWIO.  `out` may be a channel slice.  `out_act` optionally receives the activation
     output before a post-activation residual add."""
+    if _STORE_BF16[0] or x.dtype == BF16:
+        return _conv2d_fwd_bf16(x, w, bias, stride, act, alpha, residual, out, upsample2x, split_k, res_after_act,
+                                out_act, res_class)
     _require_gpu(x)
     x, ldx = as_nhwc(x)
     w = w.contiguous()
@@ -155,6 +294,8 @@ def conv2d_fwd(x, w, bias=None, stride=1, act=ACT_NONE, alpha=0.2, residual=None
 def conv2d_dgrad(dy, w, in_shape, stride=1, accum=None, mask=None, act=ACT_NONE, alpha=0.2, out=None,
                  upsample2x=False, split_k=0):
     """dx = (conv_backward_data(dy, w) + accum) * act'(mask);  in_shape = (N,H,W,C) of the fwd input."""
+    if _STORE_BF16[0] or dy.dtype == BF16:
+        return _conv2d_dgrad_bf16(dy, w, in_shape, stride, accum, mask, act, alpha, out, upsample2x, split_k)
     _require_gpu(dy)
     dy, ldy = as_nhwc(dy)
     w = w.contiguous()
@@ -189,6 +330,8 @@ def conv2d_dgrad(dy, w, in_shape, stride=1, accum=None, mask=None, act=ACT_NONE,
 def conv2d_wgrad(x, dy, wshape, stride=1, upsample2x=False, out=None, beta=0.0, split_k=0, db=None, db_beta=0.0):
     """dw[R,S,C,K] = beta*dw + conv_backward_filter(x, dy); with `db` ([K] tensor) the same launch also writes
     the bias gradient db = db_beta*db + sum over pixels of dy."""
+    if x.dtype == BF16 or dy.dtype == BF16:
+        return _conv2d_wgrad_bf16(x, dy, wshape, stride, upsample2x, out, beta, split_k, db, db_beta)
     _require_gpu(x)
     x, ldx = as_nhwc(x)
     dy, ldy = as_nhwc(dy)
@@ -209,6 +352,148 @@ def conv2d_wgrad(x, dy, wshape, stride=1, upsample2x=False, out=None, beta=0.0, 
     return out
 
 
+# ---- bf16-storage convolutions ('bf16' mode) ---------------------------------------------------------------------
+def _f32_mode():
+    """Context: run the fp32-tensor entry points with exact fp32 products (the thin-layer fall-back of 'bf16' mode)."""
+    class _Ctx(object):
+        def __enter__(self):
+            self.saved = (_COMPUTE[0], _STORE_BF16[0])
+            _COMPUTE[0], _STORE_BF16[0] = COMPUTE_F32, False
+
+        def __exit__(self, *exc):
+            _COMPUTE[0], _STORE_BF16[0] = self.saved
+            return False
+    return _Ctx()
+
+
+def _ws_bf16(d, which, device):
+    nbytes = lib().dpig_conv2d_bf16_workspace_bytes(ctypes.byref(d), which)
+    return workspace.get(nbytes, device)
+
+
+def _conv2d_fwd_bf16(x, w, bias, stride, act, alpha, residual, out, upsample2x, split_k, res_after_act, out_act,
+                     res_class):
+    _require_dev(x)
+    N, H, W, C = x.shape
+    R, S, Cw, K = w.shape
+    if Cw != C:
+        raise RuntimeError("conv2d: filter expects %d input channels, tensor has %d" % (Cw, C))
+    Ho, Wo = conv_out_hw(H, W, R, S, stride, upsample2x)
+    if _bf16_conv_ok(C, K):
+        x = to_bf16(x)
+        x, ldx = as_nhwc(x)
+        if out is None:
+            out = torch.empty((N, Ho, Wo, K), dtype=BF16, device=x.device)
+        ldy = nhwc_ld(out)
+        if ldy is None or tuple(out.shape) != (N, Ho, Wo, K) or out.dtype != BF16:
+            raise RuntimeError("conv2d: bad output tensor")
+        ldres, res_b, res_c = 0, None, None
+        if residual is not None:
+            if res_class:
+                res_c = to_f32(residual).contiguous()
+                if tuple(res_c.shape) != (N, 9, K):
+                    raise RuntimeError("conv2d: class residual must be [N, 9, K]")
+                ldres = K
+            else:
+                res_b, ldres = as_nhwc(to_bf16(residual))
+        ldy2 = 0
+        if out_act is not None:
+            ldy2 = nhwc_ld(out_act)
+            if ldy2 is None or tuple(out_act.shape) != (N, Ho, Wo, K) or out_act.dtype != BF16:
+                raise RuntimeError("conv2d: bad out_act tensor")
+        if _bf16_conv_ok(C, K, ldx, ldy, ldres if res_b is not None else 8, ldy2 if out_act is not None else 8) and \
+                _al16(x, out, res_b, out_act):
+            _, w_t = filter_shadows(w, want_plain=False)
+            if bias is not None:
+                bias = bias.contiguous()
+            d = _desc(N, H, W, C, K, R, S, stride, ldx, ldy, ldres=ldres, act=act, alpha=alpha, upsample2x=upsample2x,
+                      split_k=split_k, res_after_act=res_after_act, ldy2=ldy2, res_class=res_class)
+            wsb, wsn = _ws_bf16(d, 0, x.device)
+            with _Timed("conv_fwd_bf16", 2.0 * N * H * W // (stride * stride) * K * R * S * C,
+                        (N, H, W, C, K, R, stride, int(upsample2x))):
+                check(lib().dpig_conv2d_fwd_bf16(ctypes.byref(d), ptr(x), ptr(w_t), ptr(bias), ptr(res_b), ptr(res_c),
+                                                 ptr(out), ptr(out_act), ptr(wsb), wsn, stream_ptr()), "conv2d_fwd_bf16")
+            return out
+    # thin layer (3-channel image side, 18-channel pose, ...): fp32 kernels between conversions
+    with _f32_mode():
+        o32 = torch.empty((N, Ho, Wo, K), dtype=F32, device=x.device)
+        a32 = torch.empty((N, Ho, Wo, K), dtype=F32, device=x.device) if out_act is not None else None
+        conv2d_fwd(to_f32(x), w, bias, stride=stride, act=act, alpha=alpha, residual=to_f32(residual), out=o32,
+                   upsample2x=upsample2x, split_k=split_k, res_after_act=res_after_act, out_act=a32, res_class=res_class)
+    if out_act is not None:
+        to_bf16(a32, out=out_act) if out_act.dtype == BF16 else out_act.copy_(a32)
+    if out is not None:
+        to_bf16(o32, out=out) if out.dtype == BF16 else out.copy_(o32)
+        return out
+    return to_bf16(o32) if storable_bf16(K) else o32
+
+
+def _conv2d_dgrad_bf16(dy, w, in_shape, stride, accum, mask, act, alpha, out, upsample2x, split_k):
+    _require_dev(dy)
+    N, H, W, C = in_shape
+    R, S, Cw, K = w.shape
+    if Cw != C or dy.shape[3] != K:
+        raise RuntimeError("conv2d_dgrad: channel mismatch")
+    Ho, Wo = conv_out_hw(H, W, R, S, stride, upsample2x)
+    if tuple(dy.shape) != (N, Ho, Wo, K):
+        raise RuntimeError("conv2d_dgrad: dy shape %s, expected %s" % (tuple(dy.shape), (N, Ho, Wo, K)))
+    if _bf16_conv_ok(C, K):
+        dy, ldy = as_nhwc(to_bf16(dy))
+        if out is None:
+            out = torch.empty((N, H, W, C), dtype=BF16, device=dy.device)
+        ldx = nhwc_ld(out)
+        if ldx is None or tuple(out.shape) != (N, H, W, C) or out.dtype != BF16:
+            raise RuntimeError("conv2d_dgrad: bad output tensor")
+        ldres = ldmask = 0
+        if accum is not None:
+            accum, ldres = as_nhwc(to_bf16(accum))
+        if mask is not None:
+            mask, ldmask = as_nhwc(to_bf16(mask))
+        if _bf16_conv_ok(C, K, ldx, ldy, ldres or 8, ldmask or 8) and _al16(dy, out, accum, mask):
+            w_p, _ = filter_shadows(w, want_t=False)
+            d = _desc(N, H, W, C, K, R, S, stride, ldx, ldy, ldres=ldres, ldmask=ldmask, act=act, alpha=alpha,
+                      upsample2x=upsample2x, split_k=split_k)
+            wsb, wsn = _ws_bf16(d, 1, dy.device)
+            with _Timed("conv_dgrad_bf16", 2.0 * N * H * W // (stride * stride) * K * R * S * C,
+                        (N, H, W, C, K, R, stride, int(upsample2x))):
+                check(lib().dpig_conv2d_dgrad_bf16(ctypes.byref(d), ptr(dy), ptr(w_p), ptr(accum), ptr(mask), ptr(out),
+                                                   ptr(wsb), wsn, stream_ptr()), "conv2d_dgrad_bf16")
+            return out
+    with _f32_mode():
+        o32 = torch.empty((N, H, W, C), dtype=F32, device=dy.device)
+        conv2d_dgrad(to_f32(dy), w, in_shape, stride=stride, accum=to_f32(accum), mask=to_f32(mask), act=act,
+                     alpha=alpha, out=o32, upsample2x=upsample2x, split_k=split_k)
+    if out is not None:
+        to_bf16(o32, out=out) if out.dtype == BF16 else out.copy_(o32)
+        return out
+    return to_bf16(o32) if storable_bf16(C) else o32
+
+
+def _conv2d_wgrad_bf16(x, dy, wshape, stride, upsample2x, out, beta, split_k, db, db_beta):
+    _require_dev(x)
+    N, H, W, C = x.shape
+    R, S, Cw, K = wshape
+    if Cw != C or dy.shape[3] != K:
+        raise RuntimeError("conv2d_wgrad: channel mismatch")
+    if out is None:
+        out = torch.empty(tuple(wshape), dtype=F32, device=x.device)
+        beta = 0.0
+    if _bf16_conv_ok(C, K):
+        xb, ldx = as_nhwc(to_bf16(x))
+        dyb, ldy = as_nhwc(to_bf16(dy))
+        if _bf16_conv_ok(C, K, ldx, ldy) and _al16(xb, dyb, out) and out.is_contiguous():
+            d = _desc(N, H, W, C, K, R, S, stride, ldx, ldy, upsample2x=upsample2x, split_k=split_k)
+            wsb, wsn = _ws_bf16(d, 2, x.device)
+            with _Timed("conv_wgrad_bf16", 2.0 * N * H * W // (stride * stride) * K * R * S * C,
+                        (N, H, W, C, K, R, stride, int(upsample2x))):
+                check(lib().dpig_conv2d_wgrad_bf16(ctypes.byref(d), ptr(xb), ptr(dyb), ptr(out), float(beta), ptr(db),
+                                                   float(db_beta), ptr(wsb), wsn, stream_ptr()), "conv2d_wgrad_bf16")
+            return out
+    with _f32_mode():
+        return conv2d_wgrad(to_f32(x), to_f32(dy), wshape, stride=stride, upsample2x=upsample2x, out=out, beta=beta,
+                            split_k=split_k, db=db, db_beta=db_beta)
+
+
 def _rows_ld(t):
     """View an NHWC (or 2-D) tensor as [rows, cols] with row stride ld."""
     if t.dim() == 2:
@@ -221,6 +506,14 @@ def _rows_ld(t):
 
 def act_fwd(x, act, alpha=0.2):
     """y = act(x) elementwise."""
+    if x.dtype == BF16:
+        _require_dev(x)
+        x, rows, cols, ldx = _rows_ld(x)
+        if cols % 8 == 0 and ldx % 8 == 0 and _al16(x):
+            y = torch.empty(x.shape, dtype=BF16, device=x.device)
+            check(lib().dpig_act_fwd_bf16(ptr(x), ldx, ptr(y), cols, rows, cols, act, alpha, stream_ptr()), "act_fwd_bf16")
+            return y
+        return _like_input(act_fwd(to_f32(x), act, alpha), x)
     _require_gpu(x)
     x, rows, cols, ldx = _rows_ld(x)
     y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
@@ -230,6 +523,17 @@ def act_fwd(x, act, alpha=0.2):
 
 def act_bwd(dy, y, act, alpha=0.2):
     """dz = dy * act'(y) with y the activation output."""
+    if dy.dtype == BF16 or y.dtype == BF16:
+        _require_dev(dy)
+        if dy.dtype == BF16 and y.dtype == BF16:
+            dy, rows, cols, lddy = _rows_ld(dy)
+            y, _, _, ldy = _rows_ld(y)
+            if cols % 8 == 0 and lddy % 8 == 0 and ldy % 8 == 0 and _al16(dy, y):
+                dz = torch.empty(dy.shape, dtype=BF16, device=dy.device)
+                check(lib().dpig_act_bwd_bf16(ptr(dy), lddy, ptr(y), ldy, ptr(dz), cols, rows, cols, act, alpha,
+                                              stream_ptr()), "act_bwd_bf16")
+                return dz
+        return _like_input(act_bwd(to_f32(dy), to_f32(y), act, alpha), y)
     _require_gpu(dy)
     dy, rows, cols, lddy = _rows_ld(dy)
     y, _, _, ldy = _rows_ld(y)
@@ -241,6 +545,7 @@ def act_bwd(dy, y, act, alpha=0.2):
 
 def colsum(a, out=None, beta=0.0):
     """Column sums of an NHWC / 2-D tensor viewed as [rows, C] (bias gradient)."""
+    a = to_f32(a)
     _require_gpu(a)
     a, rows, cols, lda = _rows_ld(a)
     if out is None:
@@ -254,6 +559,7 @@ def colsum(a, out=None, beta=0.0):
 
 def border_class_sum(a):
     """[N,H,W,C] -> [N,9,C]: per-image sums over the 9 border classes of a SAME 3x3 conv."""
+    a = to_f32(a)
     _require_gpu(a)
     a, lda = as_nhwc(a)
     N, Hh, W, C = a.shape
@@ -266,6 +572,9 @@ def border_class_sum(a):
 
 def bn_fwd(x, scale, offset, eps=1e-5, act=ACT_NONE, alpha=0.2):
     """Training-mode batch norm over all but the last axis (+ fused activation)."""
+    if x.dtype == BF16:
+        y, mean, rstd = bn_fwd(to_f32(x), scale, offset, eps, act, alpha)
+        return to_bf16(y), mean, rstd
     _require_gpu(x)
     x, rows, C, ldx = _rows_ld(x)
     y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
@@ -278,6 +587,9 @@ def bn_fwd(x, scale, offset, eps=1e-5, act=ACT_NONE, alpha=0.2):
 
 
 def bn_bwd(dy, x, y, scale, mean, rstd, act=ACT_NONE, alpha=0.2):
+    if BF16 in (dy.dtype, x.dtype) or (y is not None and y.dtype == BF16):
+        dx, dscale, doffset = bn_bwd(to_f32(dy), to_f32(x), to_f32(y), scale, mean, rstd, act, alpha)
+        return _like_input(dx, x), dscale, doffset
     _require_gpu(dy)
     dy, rows, C, lddy = _rows_ld(dy)
     x, _, _, ldx = _rows_ld(x)
@@ -298,6 +610,9 @@ def bn_sync_fwd(x, scale, offset, eps, act, alpha, allreduce, world):
     """Batch norm with statistics over ALL data-parallel ranks (equal per-rank batches): `allreduce(t)`
     sum-reduces a small device tensor in place.  Same two-pass arithmetic (mean, then centred second moment)
     as the fused single-rank op.  Returns (y, mean, rstd)."""
+    if x.dtype == BF16:
+        y, mean, rstd = bn_sync_fwd(to_f32(x), scale, offset, eps, act, alpha, allreduce, world)
+        return to_bf16(y), mean, rstd
     _require_gpu(x)
     x, rows, C, ldx = _rows_ld(x)
     dev = x.device
@@ -318,6 +633,9 @@ def bn_sync_fwd(x, scale, offset, eps, act, alpha, allreduce, world):
 
 def bn_sync_bwd(dy, x, y, scale, mean, rstd, act, alpha, allreduce, world):
     """Returns dx and the GLOBAL (dscale, doffset) sums over all ranks."""
+    if BF16 in (dy.dtype, x.dtype) or (y is not None and y.dtype == BF16):
+        dx, a, b = bn_sync_bwd(to_f32(dy), to_f32(x), to_f32(y), scale, mean, rstd, act, alpha, allreduce, world)
+        return _like_input(dx, x), a, b
     _require_gpu(dy)
     dy, rows, C, lddy = _rows_ld(dy)
     x, _, _, ldx = _rows_ld(x)
@@ -339,6 +657,9 @@ def bn_sync_bwd(dy, x, y, scale, mean, rstd, act, alpha, allreduce, world):
 
 def ln_fwd(x, scale, offset, eps=1e-5, act=ACT_NONE, alpha=0.2):
     """Layer norm over (H,W,C) per sample; x NHWC dense."""
+    if x.dtype == BF16:
+        y, mean, rstd = ln_fwd(to_f32(x), scale, offset, eps, act, alpha)
+        return to_bf16(y), mean, rstd
     _require_gpu(x)
     x = x.contiguous()
     N, C = x.shape[0], x.shape[-1]
@@ -352,6 +673,9 @@ def ln_fwd(x, scale, offset, eps=1e-5, act=ACT_NONE, alpha=0.2):
 
 
 def ln_bwd(dy, x, y, scale, mean, rstd, act=ACT_NONE, alpha=0.2):
+    if BF16 in (dy.dtype, x.dtype) or (y is not None and y.dtype == BF16):
+        dx, dscale, doffset = ln_bwd(to_f32(dy), to_f32(x), to_f32(y), scale, mean, rstd, act, alpha)
+        return _like_input(dx, x), dscale, doffset
     _require_gpu(dy)
     dy = dy.contiguous()
     x = x.contiguous()
@@ -370,6 +694,9 @@ def ln_bwd(dy, x, y, scale, mean, rstd, act=ACT_NONE, alpha=0.2):
 
 def ln_bwd2(u, dy, x, y, scale, mean, rstd, act=ACT_NONE, alpha=0.2):
     """Second-order LayerNorm: gradients of ln_bwd's dx w.r.t. (dy, x, scale) given u = dP/d(dx)."""
+    if BF16 in (u.dtype, dy.dtype, x.dtype) or (y is not None and y.dtype == BF16):
+        d_dy, d_x, d_scale = ln_bwd2(to_f32(u), to_f32(dy), to_f32(x), to_f32(y), scale, mean, rstd, act, alpha)
+        return _like_input(d_dy, x), _like_input(d_x, x), d_scale
     _require_gpu(u)
     u = u.contiguous(); dy = dy.contiguous(); x = x.contiguous()
     if y is not None:
@@ -386,6 +713,8 @@ def ln_bwd2(u, dy, x, y, scale, mean, rstd, act=ACT_NONE, alpha=0.2):
 
 
 def linear_fwd(x, w, bias=None, act=ACT_NONE, alpha=0.2):
+    if x.dtype == BF16:        # FC layers: fp32 kernels on fp32 weights; the output follows the input's storage type
+        return _like_input(linear_fwd(to_f32(x), w, bias, act, alpha), x)
     _require_gpu(x)
     x = x.contiguous()
     w = w.contiguous()
@@ -401,6 +730,8 @@ def linear_fwd(x, w, bias=None, act=ACT_NONE, alpha=0.2):
 
 
 def linear_dgrad(dy, w):
+    if dy.dtype == BF16:
+        return _like_input(linear_dgrad(to_f32(dy), w), dy)
     _require_gpu(dy)
     dy = dy.contiguous()
     w = w.contiguous()
@@ -415,6 +746,7 @@ def linear_dgrad(dy, w):
 
 def linear_wgrad(x, dy, out=None, beta=0.0):
     """dw[Kin,Nout] = beta*dw + x^T @ dy."""
+    x, dy = to_f32(x), to_f32(dy)
     _require_gpu(x)
     x = x.contiguous()
     dy = dy.contiguous()
@@ -430,6 +762,8 @@ def linear_wgrad(x, dy, out=None, beta=0.0):
 
 
 def crop_resize_fwd(img, boxes, box_ind, ch, cw):
+    if img.dtype == BF16:
+        return _like_input(crop_resize_fwd(to_f32(img), boxes, box_ind, ch, cw), img)
     _require_gpu(img)
     img = img.contiguous()
     N, H, W, C = img.shape
@@ -443,6 +777,8 @@ def crop_resize_fwd(img, boxes, box_ind, ch, cw):
 
 
 def crop_resize_bwd(dout, boxes, box_ind, img_shape):
+    if dout.dtype == BF16:
+        return _like_input(crop_resize_bwd(to_f32(dout), boxes, box_ind, img_shape), dout)
     _require_gpu(dout)
     dout = dout.contiguous()
     N, H, W, C = img_shape
@@ -504,6 +840,7 @@ def ssim_gray_u8(a255, b255):
 
 def gp_interpolate(real, fake, alpha):
     """xhat = real + alpha[b] * (fake - real), alpha: [B]."""
+    real, fake = to_f32(real), to_f32(fake)
     _require_gpu(real)
     real, fake = real.contiguous(), fake.contiguous()
     B = real.shape[0]
@@ -515,6 +852,7 @@ def gp_interpolate(real, fake, alpha):
 
 def gp_penalty(g, lam):
     """(penalty [1], dpenalty/dg, slopes [B]) of lambda * mean_b (||g_b|| - 1)^2 for g [B, ...]."""
+    g = to_f32(g)
     _require_gpu(g)
     g = g.contiguous()
     B = g.shape[0]
@@ -527,6 +865,8 @@ def gp_penalty(g, lam):
 
 
 def upsample2x_fwd(x):
+    if x.dtype == BF16:
+        return _like_input(upsample2x_fwd(to_f32(x)), x)
     _require_gpu(x)
     x = x.contiguous()
     N, H, W, C = x.shape
@@ -536,6 +876,8 @@ def upsample2x_fwd(x):
 
 
 def upsample2x_bwd(dy):
+    if dy.dtype == BF16:
+        return _like_input(upsample2x_bwd(to_f32(dy)), dy)
     _require_gpu(dy)
     dy = dy.contiguous()
     N, H2, W2, C = dy.shape
@@ -572,6 +914,7 @@ def clip_(p, lo, hi):
 
 
 def sce_mean(logits, label, want_grad=False, scale=1.0):
+    logits = to_f32(logits)
     _require_gpu(logits)
     logits = logits.contiguous()
     out = torch.empty(1, dtype=torch.float32, device=logits.device)
@@ -582,6 +925,7 @@ def sce_mean(logits, label, want_grad=False, scale=1.0):
 
 
 def l1_mean(a, b, want_grad=False, scale=1.0):
+    a, b = to_f32(a), to_f32(b)
     _require_gpu(a)
     a = a.contiguous()
     b = b.contiguous()

@@ -109,7 +109,7 @@ def GeneratorCNN_ID_Encoder_BodyROIVis_FgBgFeaTwoBranch(x, fg_mask, ROI_bboxs, R
         x = slim.res_block(x, hidden_num, 3, activation_fn=activation_fn, data_format=data_format)
 
         _tap("E.stem", x)
-        m = fg_mask.to(torch.float32)
+        m = fg_mask.to(x.dtype)        # (bf16 storage mode: keep the product in the activation's type)
         x_fg = x * m
         x_bg = x * (1.0 - m)
 

@@ -51,6 +51,16 @@ class FlatParams(object):
             p._dpig_grad = self.grad[o:o + n].view(p.shape)
             p._dpig_touched = [False]
 
+    def enable_bf16_shadows(self):
+        """'bf16' mode: persistent bf16 shadows of the conv filters (hip_ops.FilterShadows), refreshed after every
+        optimizer step from the fp32 masters this object owns."""
+        self.shadows = H.FilterShadows(self.params)
+
+    def refresh_shadows(self):
+        sh = getattr(self, "shadows", None)
+        if sh is not None:
+            sh.refresh()
+
     def zero_grad(self):
         """No memset: the first kernel that touches a slice overwrites it (beta = 0)."""
         for p in self.params:
@@ -85,6 +95,7 @@ class TFAdam(object):
         self.t += 1          # host mirror, bookkeeping only
         f = self.flat
         H.adam_step_dev(f.flat, f.grad, f.m, f.v, self.lr, self.state, self.b1, self.b2, self.eps, grad_scale)
+        f.refresh_shadows()
 
 
 class TFRMSProp(object):
@@ -100,6 +111,7 @@ class TFRMSProp(object):
         self.t += 1
         f = self.flat
         H.rmsprop_step(f.flat, f.grad, f.m, f.v, self.lr, self.decay, self.mu, self.eps, grad_scale)
+        f.refresh_shadows()
 
 
 def get_optimizers(wgan_gp, G_flat, D_flat, g_lr, d_lr):
@@ -166,6 +178,7 @@ def clip_disc_weights(D_flat, lo=-.01, hi=.01):
     """trainer.py:124-128: clip every `Discriminator` parameter to [-0.01, 0.01] -- one launch on the flat buffer
     (the 16-byte alignment padding between tensors is zero and stays zero)."""
     H.clip_(D_flat.flat, lo, hi)
+    D_flat.refresh_shadows()
 
 
 class GradAllReduce(object):
@@ -221,7 +234,8 @@ def gradient_penalty(Discriminator, real_data, fake_data, LAMBDA=10., alpha=None
         alpha = torch.rand([B] + [1] * (real_data.dim() - 1), device=real_data.device)
     interpolates = H.gp_interpolate(real_data.detach(), fake_data.detach(), alpha.reshape(B)).requires_grad_(True)
     D_int = Discriminator(interpolates)
-    gradients = torch.autograd.grad(D_int.sum(), interpolates, create_graph=True)[0]
+    with A.no_param_grads():      # d(sum D(xhat))/dtheta is not part of the loss: input gradient only
+        gradients = torch.autograd.grad(D_int.sum(), interpolates, create_graph=True)[0]
     # penalty value + its derivative w.r.t. `gradients` (the seed of the second sweep) in one fused pass
     return A.gp_penalty(gradients, LAMBDA)
 
@@ -276,8 +290,10 @@ class Config(object):
         self.split_backward = None       # None: in data-parallel runs only.  The generator-side backward runs in two
                                          # stages (decoder+critic, then encoder) so that the decoder half of the
                                          # gradient all-reduce overlaps the encoder's backward pass
-        self.compute_dtype = 'f32'       # 'bf16': conv GEMMs on the bf16 matrix pipe (fp32 tensors / accumulation /
-                                         # master weights; BASELINE configs 3-5); 'f32' is the reference's arithmetic
+        self.compute_dtype = 'f32'       # 'f32' is the reference's arithmetic.  'bf16' (BASELINE configs 3-5):
+                                         # activations / their gradients / filter shadows stored as bf16, bf16 matrix
+                                         # pipe, fp32 accumulation, master weights, gradients and optimizer.  'bf16c':
+                                         # fp32 tensors, conv operands rounded to bf16 (hip_ops module docstring)
         self.pretrained_path = None      # V2 checkpoint prefixes (trainer.py:180-212): 'Encoder' + 'ID_AE' variables,
         self.pretrained_poseAE_path = None   # the 'PoseAE' variables,
         self.ckpt_path = None            # every variable of the model
@@ -368,9 +384,17 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         self.allreduce = GradAllReduce()
         self.allreduce.broadcast(self.G_flat.flat)
         self.allreduce.broadcast(self.D_flat.flat)
+        if getattr(self.config, "compute_dtype", "f32") == "bf16":
+            self.G_flat.enable_bf16_shadows()
+            self.D_flat.enable_bf16_shadows()
         lib.ops.batchnorm.set_sync(bool(getattr(self.config, "sync_bn", False)) and self.allreduce.enabled)
         if getattr(self.config, "ckpt_path", None) and getattr(self.config, "restore_optimizer", False):
             self.restore_optimizer(self.config.ckpt_path)
+
+    def refresh_shadows(self):
+        """After writing parameter values from outside the optimizer ('bf16' mode): re-derive the bf16 filter shadows."""
+        self.G_flat.refresh_shadows()
+        self.D_flat.refresh_shadows()
 
     # ---- checkpoints (trainer.py:180-212 restores, :366 saves; TF V2 bundle format, tfckpt.py) ----------------
     def restore_from_config(self):

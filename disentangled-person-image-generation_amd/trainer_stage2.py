@@ -83,6 +83,9 @@ class DPIG_Encoder_subSampleAppNetFgBg_GAN_BodyROI(object):
         for gf, df in self.flats.values():
             self.allreduce.broadcast(gf.flat)
             self.allreduce.broadcast(df.flat)
+        if getattr(self.config, "compute_dtype", "f32") == "bf16":
+            # the frozen encoder's filters: bf16 shadows made once (the FC mappers / critics run on fp32 weights)
+            self.encoder_shadows = H.FilterShadows(self.Encoder_var)
 
     # ---- optimizer ops -------------------------------------------------------------------------------
     def g_optim_embs(self, side, z=None):

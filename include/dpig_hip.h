@@ -51,7 +51,7 @@ extern "C" {
 #define DPIG_ACT_RELU 1
 #define DPIG_ACT_LRELU 2
 
-#define DPIG_VERSION 100
+#define DPIG_VERSION 200
 
 /* Convolution problem, always described from the FORWARD op's point of view. */
 typedef struct DpigConvDesc {
@@ -118,6 +118,44 @@ int dpig_conv2d_dgrad(const DpigConvDesc* d, const float* dy, const float* w, co
  * (TF's BiasAddGrad) from the dy tiles it stages anyway -- no extra pass over dy. */
 int dpig_conv2d_wgrad(const DpigConvDesc* d, const float* x, const float* dy, float* dw, float beta,
                       float* db, float beta_b, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- bf16-STORAGE convolution family (BASELINE configs 3-5; csrc/dpig_conv_bf16.hip) ---------------------------
+ * Same three operations as dpig_conv2d_{fwd,dgrad,wgrad} (same reference call sites: tflib/ops/conv2d.py:106-120,
+ * slim.conv2d of models.py:396-573 and the gradients TF autodiff derives, trainer.py:137-140) on tensors stored as
+ * bfloat16 (uint16_t bit patterns, round-to-nearest-even): activations and activation gradients NHWC bf16 with a
+ * channel stride; products on the bf16 matrix pipe; accumulation, bias, residual adds, activation and every epilogue
+ * in fp32; the filter gradient is written in fp32 (the master weights and the optimizer stay fp32).
+ * Filters are read from bf16 SHADOWS of the fp32 HWIO master (dpig_filter_shadow_bf16):
+ *   forward  w_t   [R][S][K][C]  (per tap transposed: the GEMM's reduction index contiguous)
+ *   dgrad    w     [R][S][C][K]  (the HWIO layout itself)
+ * Accepted shapes: C, K >= 32 and multiples of 8, ldx / ldy / ldres / ldmask / ldy2 multiples of 8, every pointer
+ * 16-byte aligned (dpig_conv2d_bf16_supported); the few thin layers outside that run on the fp32 entry points
+ * between dpig_cvt_* calls.  `compute` of the descriptor is ignored. */
+int dpig_conv2d_bf16_supported(const DpigConvDesc* d, int which);
+size_t dpig_conv2d_bf16_workspace_bytes(const DpigConvDesc* d, int which);
+/* residual (bf16, y-shaped) and residual_class (fp32 [N][9][K], see DpigConvDesc.res_class) are exclusive.  With a
+ * post-activation residual and y_act, y = bf16(float(y_act) + residual): the sum is formed from the stored activation. */
+int dpig_conv2d_fwd_bf16(const DpigConvDesc* d, const uint16_t* x, const uint16_t* w_t, const float* bias,
+                         const uint16_t* residual, const float* residual_class, uint16_t* y, uint16_t* y_act,
+                         void* ws, size_t ws_bytes, void* stream);
+int dpig_conv2d_dgrad_bf16(const DpigConvDesc* d, const uint16_t* dy, const uint16_t* w, const uint16_t* accum,
+                           const uint16_t* mask, uint16_t* dx, void* ws, size_t ws_bytes, void* stream);
+/* dw (fp32, [R][S][C][K]) = beta*dw + conv_backward_filter(x, dy); db (fp32, optional) = beta_b*db + sum_pixels dy,
+ * accumulated in fp32 on the matrix pipe from the dy tiles the launch stages anyway. */
+int dpig_conv2d_wgrad_bf16(const DpigConvDesc* d, const uint16_t* x, const uint16_t* dy, float* dw, float beta,
+                           float* db, float beta_b, void* ws, size_t ws_bytes, void* stream);
+/* [rows, cols] matrices with row strides (elements): fp32 <-> bf16 (round-to-nearest-even / exact widening). */
+int dpig_cvt_f32_to_bf16(const float* in, int ldi, uint16_t* out, int ldo, int64_t rows, int cols, void* stream);
+int dpig_cvt_bf16_to_f32(const uint16_t* in, int ldi, float* out, int ldo, int64_t rows, int cols, void* stream);
+/* y = act(x) / dz = dy * act'(y) on bf16 [rows, cols] matrices (cols and strides multiples of 8): dpig_act_fwd / _bwd. */
+int dpig_act_fwd_bf16(const uint16_t* x, int ldx, uint16_t* y, int ldy, int64_t rows, int cols, int act, float alpha,
+                      void* stream);
+int dpig_act_bwd_bf16(const uint16_t* dy, int lddy, const uint16_t* y, int ldy, uint16_t* dz, int lddz, int64_t rows,
+                      int cols, int act, float alpha, void* stream);
+/* bf16 shadows of an fp32 HWIO filter w[taps][C][K]: plain [taps][C][K] and / or transposed [taps][K][C]
+ * (either output may be NULL); refreshed after every optimizer step. */
+int dpig_filter_shadow_bf16(const float* w, uint16_t* plain, uint16_t* transposed, int taps, int C, int K,
+                            void* stream);
 
 /* ---- elementwise / reductions over a [rows, cols] fp32 matrix with row stride ld ------------- */
 

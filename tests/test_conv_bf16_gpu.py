@@ -1,0 +1,239 @@
+"""GPU parity of the bf16-STORAGE conv family (dpig_conv2d_*_bf16, through the C ABI) against the CPU oracle (fp64).
+
+Operands are bf16 in HBM, so the oracle is evaluated on the bf16-ROUNDED operands: products of bf16 numbers are exact
+in fp32 and the kernels accumulate in fp32, hence
+  * fp32 results (wgrad, bias gradient) must match at the fp32 kernels' bar, 2e-5 * max|ref|;
+  * bf16 results (fwd, dgrad) must match to within the final rounding to bf16: |err| <= 2^-8 |ref| + 2e-5 max|ref|
+    elementwise (half an ulp is 2^-9 |ref|).
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+# (N, H, W, C, K, k, stride): every shape the bf16 loops accept (C, K >= 32, multiples of 8)
+SHAPES = [
+    (2, 16, 8, 64, 128, 3, 1),     # decoder-style 3x3 s1, one k-chunk per tap
+    (2, 16, 8, 128, 64, 3, 2),     # encoder down conv (TF pad (0,1)), two k-chunks per tap
+    (1, 12, 12, 128, 256, 3, 1),   # ragged M (144 rows), 2 n-tiles
+    (2, 9, 7, 40, 48, 3, 1),       # odd sizes, partial tiles in every dim, C not a multiple of the 64-deep k-tile
+    (2, 9, 7, 40, 48, 3, 2),       # odd input with stride 2 (pad (1,1))
+    (2, 8, 4, 64, 128, 5, 2),      # D.2-style 5x5 s2 (pad (1,2))
+    (3, 6, 6, 96, 136, 1, 1),      # 1x1, K not a multiple of 128
+    (1, 8, 4, 200, 128, 3, 1),     # C = 3 k-chunks + a 8-channel tail
+    (2, 3, 3, 640, 64, 3, 1),      # 3x3 image (ROI tower tail): every tap is mostly halo
+]
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1) * scale
+
+
+def _r(t):
+    """round to bf16 (RNE) and back to fp64: what the device tensors hold"""
+    return t.float().to(BF).double()
+
+
+def _close_f32(got, ref, tol=2e-5):
+    ref = ref.double()
+    err = (got.double().cpu() - ref).abs().max().item()
+    scale = max(ref.abs().max().item(), 1e-6)
+    assert err <= tol * scale, "max err %.3e vs scale %.3e" % (err, scale)
+
+
+def _close_bf16(got, ref):
+    assert got.dtype == BF
+    ref = ref.double()
+    err = (got.double().cpu() - ref).abs()
+    bound = ref.abs() * 2.0 ** -8 + 2e-5 * max(ref.abs().max().item(), 1e-6)
+    bad = (err > bound)
+    assert not bad.any(), "%d elements off; worst err %.3e (ref scale %.3e)" % (int(bad.sum()), err.max().item(), ref.abs().max().item())
+
+
+def test_conversions_are_rne_and_exact(dev):
+    import dpig_amd.hip_ops as H
+    x = _rand((3, 5, 7, 24), 1, 3.0).float()
+    x.view(-1)[:4] = torch.tensor([1.00390625, 1.01171875, -0.0, 3.3895314e38])   # ties-to-even cases, -0, near max
+    xb = H.to_bf16(x.to(dev))
+    assert xb.dtype == BF and torch.equal(xb.cpu(), x.to(BF))
+    assert torch.equal(H.to_f32(xb).cpu(), x.to(BF).float())
+    # channel slice (row stride > cols) and a width that is not a multiple of 4
+    big = x.to(dev)
+    assert torch.equal(H.to_bf16(big[..., 8:16]).cpu(), x[..., 8:16].to(BF))
+    odd = _rand((11, 13), 2).float()
+    assert torch.equal(H.to_bf16(odd.to(dev)).cpu(), odd.to(BF))
+    assert torch.equal(H.to_f32(odd.to(BF).to(dev)).cpu(), odd.to(BF).float())
+
+
+def test_filter_shadows(dev):
+    import dpig_amd.hip_ops as H
+    w = _rand((3, 3, 40, 72), 3).float()
+    plain, trans = H.filter_shadows(w.to(dev))
+    assert torch.equal(plain.cpu(), w.to(BF))
+    assert torch.equal(trans.cpu(), w.permute(0, 1, 3, 2).contiguous().to(BF))
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+@pytest.mark.parametrize("split_k", [0, 3])
+def test_fwd(dev, shape, split_k):
+    import dpig_amd.hip_ops as H
+    from oracle import ops as O
+    N, Hh, W, C, K, k, s = shape
+    x = _rand((N, Hh, W, C), 1)
+    w = _rand((k, k, C, K), 2, 0.2)
+    b = _rand((K,), 3)
+    ref = O.leaky_relu(O.conv2d_same(_r(x), _r(w), b.float().double(), s), 0.2)
+    got = H.conv2d_fwd(x.float().to(dev).to(BF), w.float().to(dev), b.float().to(dev), stride=s, act=2, alpha=0.2,
+                       split_k=split_k)
+    _close_bf16(got, ref)
+
+
+def test_fwd_fused_epilogues(dev):
+    import dpig_amd.hip_ops as H
+    from oracle import ops as O
+    N, Hh, W, C, K = 2, 16, 8, 64, 64
+    x = _rand((N, Hh, W, C), 1)
+    w = _rand((3, 3, C, K), 2, 0.2)
+    b = _rand((K,), 3)
+    res = _rand((N, Hh, W, K), 4)
+    xd, wd, bd, rd = x.float().to(dev).to(BF), w.float().to(dev), b.float().to(dev), res.float().to(dev).to(BF)
+    conv = O.conv2d_same(_r(x), _r(w), b.float().double(), 1)
+    # residual before the activation
+    _close_bf16(H.conv2d_fwd(xd, wd, bd, act=1, residual=rd), O.relu(conv + _r(res)))
+    # the res-block tail: act -> out_act, (stored act) + skip -> out
+    out, out_act = torch.empty((N, Hh, W, K), dtype=BF, device=dev), torch.empty((N, Hh, W, K), dtype=BF, device=dev)
+    H.conv2d_fwd(xd, wd, bd, act=1, residual=rd, res_after_act=True, out=out, out_act=out_act)
+    _close_bf16(out_act, O.relu(conv))
+    assert torch.equal(out.cpu(), (out_act.float() + rd.float()).to(BF).cpu())      # exactly bf16(float(c2) + skip)
+    # split-K goes through the reduction kernel's epilogue
+    out2, act2 = torch.empty_like(out), torch.empty_like(out)
+    H.conv2d_fwd(xd, wd, bd, act=1, residual=rd, res_after_act=True, out=out2, out_act=act2, split_k=3)
+    _close_bf16(act2, O.relu(conv))
+    assert torch.equal(out2.cpu(), (act2.float() + rd.float()).to(BF).cpu())
+    # class-indexed residual (the tiled-embedding collapse, fp32 [N, 9, K])
+    e9 = _rand((N, 9, K), 5).float()
+    yy, xx = torch.meshgrid(torch.arange(Hh), torch.arange(W), indexing="ij")
+    cls = torch.where(yy == 0, 0, torch.where(yy == Hh - 1, 2, 1)) * 3 + torch.where(xx == 0, 0, torch.where(xx == W - 1, 2, 1))
+    ref = O.relu(conv + e9.double()[:, cls.reshape(-1), :].reshape(N, Hh, W, K))
+    _close_bf16(H.conv2d_fwd(xd, wd, bd, act=1, residual=e9.to(dev), res_class=True), ref)
+
+
+def test_channel_slices_and_upsample(dev):
+    import dpig_amd.hip_ops as H
+    from oracle import ops as O
+    N, Hh, W, C, K = 2, 8, 4, 64, 128
+    xbig = _rand((N, Hh, W, 96), 1)
+    w = _rand((3, 3, C, K), 2, 0.2)
+    ref = O.conv2d_same(_r(xbig[..., 32:96]), _r(w), None, 1)
+    xg = xbig.float().to(dev).to(BF)
+    ybig = torch.full((N, Hh, W, 192), 7.0, device=dev, dtype=BF)
+    H.conv2d_fwd(xg[..., 32:96], w.float().to(dev), None, out=ybig[..., 64:192])
+    _close_bf16(ybig[..., 64:192], ref)
+    assert (ybig[..., :64] == 7.0).all()
+    # nearest-2x upsample + 1x1 conv + bias + relu, computed at low resolution and replicated
+    C, K = 96, 64
+    x = _rand((N, Hh, W, C), 3)
+    w1 = _rand((1, 1, C, K), 4, 0.3)
+    b = _rand((K,), 5)
+    ref = O.relu(O.conv2d_same(O.upsample2x(_r(x)), _r(w1), b.float().double(), 1))
+    got = H.conv2d_fwd(x.float().to(dev).to(BF), w1.float().to(dev), b.float().to(dev), act=1, upsample2x=True)
+    _close_bf16(got, ref)
+    dy = _rand(tuple(ref.shape), 6)
+    xr = _r(x).requires_grad_(True)
+    wr = _r(w1).requires_grad_(True)
+    O.conv2d_same(O.upsample2x(xr), wr, None, 1).backward(_r(dy))
+    dyd = dy.float().to(dev).to(BF)
+    _close_bf16(H.conv2d_dgrad(dyd, w1.float().to(dev), (N, Hh, W, C), upsample2x=True), xr.grad)
+    _close_f32(H.conv2d_wgrad(x.float().to(dev).to(BF), dyd, (1, 1, C, K), upsample2x=True), wr.grad)
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_dgrad_wgrad(dev, shape):
+    import dpig_amd.hip_ops as H
+    from oracle import ops as O
+    N, Hh, W, C, K, k, s = shape
+    x = _rand((N, Hh, W, C), 1)
+    w = _rand((k, k, C, K), 2, 0.2)
+    xr = _r(x).requires_grad_(True)
+    wr = _r(w).requires_grad_(True)
+    y = O.conv2d_same(xr, wr, None, s)
+    dy = _rand(tuple(y.shape), 3)
+    y.backward(_r(dy))
+    xd, dyd, wd = x.float().to(dev).to(BF), dy.float().to(dev).to(BF), w.float().to(dev)
+    _close_bf16(H.conv2d_dgrad(dyd, wd, (N, Hh, W, C), stride=s), xr.grad)
+    db = torch.empty(K, device=dev)
+    dw = torch.empty((k, k, C, K), device=dev)
+    H.conv2d_wgrad(xd, dyd, (k, k, C, K), stride=s, out=dw, beta=0.0, db=db, db_beta=0.0)
+    _close_f32(dw, wr.grad)
+    _close_f32(db, _r(dy).sum((0, 1, 2)))
+
+
+def test_dgrad_mask_accum_and_wgrad_split_beta(dev):
+    import dpig_amd.hip_ops as H
+    from oracle import ops as O
+    N, Hh, W, C, K = 2, 16, 8, 64, 128
+    x = _rand((N, Hh, W, C), 1)
+    w = _rand((3, 3, C, K), 2, 0.2)
+    dy = _rand((N, Hh, W, K), 3)
+    acc = _rand((N, Hh, W, C), 4)
+    m = _rand((N, Hh, W, C), 5)
+    xr = _r(x).requires_grad_(True)
+    wr = _r(w).requires_grad_(True)
+    O.conv2d_same(xr, wr, None, 1).backward(_r(dy))
+    dyd, wd = dy.float().to(dev).to(BF), w.float().to(dev)
+    got = H.conv2d_dgrad(dyd, wd, (N, Hh, W, C), accum=acc.float().to(dev).to(BF), mask=m.float().to(dev).to(BF), act=2,
+                         alpha=0.2)
+    ref = (xr.grad + _r(acc)) * torch.where(_r(m) > 0, 1.0, 0.2)
+    _close_bf16(got, ref)
+    for split in (0, 1, 5):
+        dw = torch.full((3, 3, C, K), 2.0, device=dev)
+        db = torch.full((K,), 3.0, device=dev)
+        H.conv2d_wgrad(x.float().to(dev).to(BF), dyd, (3, 3, C, K), out=dw, beta=1.0, split_k=split, db=db, db_beta=1.0)
+        _close_f32(dw, wr.grad + 2.0)
+        _close_f32(db, _r(dy).sum((0, 1, 2)) + 3.0)
+
+
+def test_thin_layers_take_the_fp32_kernels_between_conversions(dev):
+    """3-channel image convs, the 18-channel pose conv: outside the bf16 loops; 'bf16' mode converts at their boundary
+    and stores the result as bf16 iff its channel count is a multiple of 8."""
+    import dpig_amd.hip_ops as H
+    from oracle import ops as O
+    H.set_compute("bf16")
+    try:
+        x = _rand((2, 16, 8, 3), 1)
+        w = _rand((3, 3, 3, 128), 2, 0.2)
+        got = H.conv2d_fwd(x.float().to(dev), w.float().to(dev), None, act=1)
+        assert got.dtype == BF
+        _close_bf16(got, O.relu(O.conv2d_same(x.float().double(), w.float().double(), None, 1)))
+        x2 = _rand((2, 16, 8, 256), 3)
+        w2 = _rand((3, 3, 256, 3), 4, 0.2)
+        got = H.conv2d_fwd(x2.float().to(dev).to(BF), w2.float().to(dev), None)
+        assert got.dtype == torch.float32                    # the image stays fp32
+        _close_f32(got, O.conv2d_same(_r(x2), w2.float().double(), None, 1))
+        dy = _rand((2, 16, 8, 3), 5)
+        dx = H.conv2d_dgrad(dy.float().to(dev), w2.float().to(dev), (2, 16, 8, 256))
+        assert dx.dtype == BF
+        dw = H.conv2d_wgrad(x2.float().to(dev).to(BF), dy.float().to(dev), (3, 3, 256, 3))
+        assert dw.dtype == torch.float32
+    finally:
+        H.set_compute("f32")
+
+
+def test_bad_arguments(dev):
+    import ctypes
+    from dpig_amd import _lib
+    h = _lib.lib()
+    d = _lib.DpigConvDesc()
+    for k, v in dict(N=1, H=8, W=8, C=64, K=64, R=3, S=3, stride=1, pad_t=-1, pad_l=-1, ldx=64, ldy=64).items():
+        setattr(d, k, v)
+    assert h.dpig_conv2d_bf16_supported(ctypes.byref(d), 0) == 1
+    d.C = d.ldx = 36
+    assert h.dpig_conv2d_bf16_supported(ctypes.byref(d), 0) == 0
+    assert h.dpig_conv2d_fwd_bf16(ctypes.byref(d), 16, 16, None, None, None, 16, None, None, 0, None) == -22
+    d.C = d.ldx = 64
+    assert h.dpig_conv2d_fwd_bf16(ctypes.byref(d), 16, 18, None, None, None, 16, None, None, 0, None) == -14   # misaligned
+    assert h.dpig_conv2d_fwd_bf16(ctypes.byref(d), None, 16, None, None, None, 16, None, None, 0, None) == -22

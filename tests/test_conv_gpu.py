@@ -296,7 +296,7 @@ def test_conv_bf16_compute(dev, shape, split_k):
     b = _rand((K,), 3)
     dy_shape = tuple(O.conv2d_same(x, w, None, s).shape)
     dy = _rand(dy_shape, 4)
-    H.set_compute("bf16")
+    H.set_compute("bf16c")
     try:
         # forward: N-dim = K
         xe, we = (_bf(x), _bf(w)) if K > 32 else (x, w)
@@ -336,7 +336,7 @@ def test_conv_upsample_fused_bf16(dev):
     ref = O.relu(O.conv2d_same(O.upsample2x(xb), wb, b, 1))
     dy = _rand(tuple(ref.shape), 5)
     dyb = _bf(dy)
-    H.set_compute("bf16")
+    H.set_compute("bf16c")
     try:
         _close(H.conv2d_fwd(x.float().to(dev), w.float().to(dev), b.float().to(dev), act=1, upsample2x=True), ref)
         xr = x.clone().requires_grad_(True)
@@ -354,7 +354,7 @@ def test_conv_bf16_falls_back_to_fp32_when_ineligible(dev):
     x = _rand((2, 16, 8, 256), 1).float().to(dev)
     w = (_rand((3, 3, 256, 3), 2) * 0.2).float().to(dev)
     ref = H.conv2d_fwd(x, w)
-    H.set_compute("bf16")
+    H.set_compute("bf16c")
     try:
         got = H.conv2d_fwd(x, w)          # 3 output columns: the fp32 path serves it
     finally:

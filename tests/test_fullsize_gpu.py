@@ -84,7 +84,7 @@ def test_bf16_mode_adjointness_full_size(dev):
     bf = lambda t: t.bfloat16().float()
     x, w = bf(torch.randn(N, Hh, W, C, device=dev, generator=g)), bf(torch.randn(3, 3, C, K, device=dev, generator=g) * 0.05)
     dy = bf(torch.randn(N, Hh, W, K, device=dev, generator=g))
-    H.set_compute("bf16")
+    H.set_compute("bf16c")
     try:
         y = H.conv2d_fwd(x, w, None)
         dx = H.conv2d_dgrad(dy, w, (N, Hh, W, C))

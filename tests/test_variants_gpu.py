@@ -305,11 +305,11 @@ def test_stage1_bf16_compute_mode(dev):
     lib.set_device(dev)
     for n, v in P.state_numpy().items():
         lib.param(n, v, trainable=P.trainable[n])
-    tr = DPIG_Encoder_GAN_BodyROI_FgBg(Config(batch_size=B, conv_hidden_num=HID, z_num=ZN, compute_dtype='bf16'), dev)
+    tr = DPIG_Encoder_GAN_BodyROI_FgBg(Config(batch_size=B, conv_hidden_num=HID, z_num=ZN, compute_dtype='bf16c'), dev)
     batch = synthetic.to_device(batch_np, dev)
     try:
         tr.init_net(batch)
-        assert H.get_compute() == "bf16"
+        assert H.get_compute() == "bf16c"
         with torch.no_grad():
             embs_o, G_o = OM.stage1_forward(P, ob, hidden_num=HID, z_num=ZN)
             embs, _ = tr.encode(batch)
