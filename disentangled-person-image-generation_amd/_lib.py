@@ -45,8 +45,12 @@ SYMBOLS = {
     "dpig_conv2d_fwd_bf16": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dpig_conv2d_dgrad_bf16": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dpig_conv2d_wgrad_bf16": (_i, [_dp, _vp, _vp, _vp, _f, _vp, _f, _vp, _sz, _vp]),
+    "dpig_conv2d_fwd_thin_bf16": (_i, [_dp, _vp, _vp, _vp, _vp, _vp]),
+    "dpig_conv2d_dgrad_thin_bf16": (_i, [_dp, _vp, _vp, _vp, _vp]),
+    "dpig_conv2d_wgrad_thin_bf16": (_i, [_dp, _vp, _vp, _vp, _f, _vp, _f, _vp, _sz, _vp]),
     "dpig_cvt_f32_to_bf16": (_i, [_vp, _i, _vp, _i, _i64, _i, _vp]),
     "dpig_cvt_bf16_to_f32": (_i, [_vp, _i, _vp, _i, _i64, _i, _vp]),
+    "dpig_cvt_f32_to_bf16_pad": (_i, [_vp, _i, _i, _vp, _i, _i, _i64, _vp]),
     "dpig_act_fwd_bf16": (_i, [_vp, _i, _vp, _i, _i64, _i, _i, _f, _vp]),
     "dpig_act_bwd_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _i, _i, _f, _vp]),
     "dpig_filter_shadow_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
@@ -56,6 +60,7 @@ SYMBOLS = {
     "dpig_colsum": (_i, [_vp, _i, _i64, _i, _vp, _f, _vp, _sz, _vp]),
     "dpig_border_class_sum_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "dpig_border_class_sum": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "dpig_border_class_sum_bf16": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "dpig_bn_workspace_bytes": (_sz, [_i64, _i]),
     "dpig_bn_fwd": (_i, [_vp, _i, _i64, _i, _vp, _vp, _f, _i, _f, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "dpig_bn_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp, _vp, _vp, _i, _f, _vp, _i, _vp, _vp, _vp, _sz, _vp]),

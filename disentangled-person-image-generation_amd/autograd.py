@@ -245,11 +245,21 @@ class _TiledEmbConvFn(torch.autograd.Function):
         wy = torch.stack([we[_valid_taps(c)].sum(0) for c in range(3)])                 # [cy, kx, E, K]
         wc = torch.stack([wy[:, _valid_taps(c)].sum(1) for c in range(3)], dim=1)       # [cy, cx, E, K]
         wmat = wc.permute(2, 0, 1, 3).reshape(E, 9 * K).contiguous()
-        e9 = H.linear_fwd(emb, wmat)                                                   # [B, 9K]
-        w_pose = w[:, :, E:, :].contiguous()
+        e9 = H.linear_fwd(H.to_f32(emb), wmat)                                         # [B, 9K]
+        P = pose.shape[3]
+        ctx.padded = H.get_compute() == "bf16" and K % 8 == 0 and P < 32
+        if ctx.padded:
+            # 'bf16' mode: the pose channels are widened to 32 (zeros) so that this conv runs on the bf16 matrix-pipe
+            # loop like every other layer (the filter rows of the padding channels are zero: same result)
+            pose = H.pad_channels_bf16(H.to_f32(pose), 32)
+            w_pose = torch.zeros((3, 3, 32, K), dtype=w.dtype, device=w.device)
+            w_pose[:, :, :P, :] = w[:, :, E:, :]
+        else:
+            w_pose = w[:, :, E:, :].contiguous()
         y = H.conv2d_fwd(pose, w_pose, b, act=ACT_RELU, residual=e9.view(-1, 9, K), res_class=True)
         ctx.save_for_backward(emb, pose, w, wmat, y)
         ctx.b_ref = b
+        ctx.P = P
         return y
 
     @staticmethod
@@ -257,14 +267,19 @@ class _TiledEmbConvFn(torch.autograd.Function):
         emb, pose, w, wmat, y = ctx.saved_tensors
         E, K = emb.shape[1], w.shape[3]
         B = emb.shape[0]
-        dz = H.to_f32(H.act_bwd(dy, y, ACT_RELU))       # ('bf16' mode: the three consumers below are fp32 kernels)
-        db = _sink(ctx.b_ref, lambda o, beta: H.colsum(dz, out=o, beta=beta)) if ctx.needs_input_grad[3] else None
-        z9 = H.border_class_sum(dz).view(B, 9 * K)
+        dz = H.act_bwd(dy, y, ACT_RELU)
+        z9 = H.border_class_sum(dz)                                                    # [B, 9, K] fp32
+        db = None
+        if ctx.needs_input_grad[3]:            # every pixel belongs to exactly one class: the bias gradient is their sum
+            db = _sink_small(ctx.b_ref, z9.sum((0, 1)))
+        z9 = z9.view(B, 9 * K)
         d_emb = H.linear_dgrad(z9, wmat) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[2]:
             dwp = H.conv2d_wgrad(pose, dz, (3, 3, pose.shape[3], K))
-            dwc = H.linear_wgrad(emb, z9).view(E, 3, 3, K).permute(1, 2, 0, 3)          # [cy, cx, E, K]
+            if ctx.padded:
+                dwp = dwp[:, :, :ctx.P, :]
+            dwc = H.linear_wgrad(H.to_f32(emb), z9).view(E, 3, 3, K).permute(1, 2, 0, 3)          # [cy, cx, E, K]
             # transpose of the class sums: tap ky receives every class whose valid set contains ky
             dwy = torch.stack([dwc[1:].sum(0), dwc.sum(0), dwc[:2].sum(0)])              # [ky, cx, E, K]
             dwe = torch.stack([dwy[:, 1:].sum(1), dwy.sum(1), dwy[:, :2].sum(1)], dim=1)  # [ky, kx, E, K]
@@ -280,6 +295,8 @@ class _TiledEmbConvFn(torch.autograd.Function):
                     out[:, :, E:, :].add_(dwp)
                 return out
             dw = _sink(w, put)
+        if d_emb is not None and d_emb.dtype != emb.dtype:
+            d_emb = H.to_bf16(d_emb) if emb.dtype == H.BF16 else H.to_f32(d_emb)
         return d_emb, None, dw, db
 
 

@@ -27,6 +27,7 @@
 #include <type_traits>
 #include "dpig_common.h"
 #include "dpig_conv_plan.h"
+#include "dpig_thin.h"
 
 namespace dpig {
 namespace bfk {
@@ -752,6 +753,22 @@ __global__ __launch_bounds__(256) void act_bf16_kernel(const bf16_t* __restrict_
     }
 }
 
+// out[r][0..cols_out) = bf16(in[r][0..cols_in)) followed by zeros: channel padding of a thin input (the 18 pose channels
+// -> 32) so that its conv runs on the bf16 matrix-pipe loop; cols_out % 8 == 0
+__global__ __launch_bounds__(256) void cvt_pad_kernel(const float* __restrict__ in, int ldi, int cols_in,
+                                                      bf16_t* __restrict__ out, int ldo, int cols_out, long rows) {
+    const int c8 = cols_out >> 3;
+    const long total = rows * c8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / c8;
+        const int c = (int)(i - r * c8) * 8;
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (c + e < cols_in) ? in[r * ldi + c + e] : 0.f;
+        *reinterpret_cast<uint4*>(out + r * ldo + c) = pack8(v);
+    }
+}
+
 // w [taps][C][K] fp32 -> plain [taps][C][K] bf16 and transposed [taps][K][C] bf16 (either may be null): 32 x 32 tiles
 // through LDS so that both the read and the transposed write are row-contiguous
 __global__ __launch_bounds__(256) void shadow_kernel(const float* __restrict__ w, bf16_t* __restrict__ plain,
@@ -1120,4 +1137,66 @@ extern "C" int dpig_act_bwd_bf16(const uint16_t* dy, int lddy, const uint16_t* y
     hipLaunchKernelGGL((act_bf16_kernel<1>), dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), dy, lddy, y,
                        ldy, dz, lddz, (long)rows, cols, act, alpha);
     return check_launch("act_bwd_bf16");
+}
+
+// ---- thin layers of 'bf16' mode: the vector-ALU kernels of dpig_thin.hip with their WIDE tensor stored as bf16 ----------
+// K == 3 (the generator's image conv, 3x3 s1): x / dx bf16 [.., C], y / dy fp32 [.., 3].
+// C == 3 (encoder stem 3x3 s1, critic conv1 5x5 s2): x / dx fp32 image, y / dy bf16 [.., K].
+static int thin_kind(const DpigConvDesc* d) { return d->K == 3 ? 1 : (d->C == 3 ? 2 : 0); }
+
+extern "C" int dpig_conv2d_fwd_thin_bf16(const DpigConvDesc* d, const void* x, const float* w, const float* bias, void* y,
+                                         void* stream) {
+    int pt, pl, Ho, Wo;
+    int rc = resolve_desc(d, &pt, &pl, &Ho, &Wo);
+    if (rc) return rc;
+    if (!x || !w || !y) return fail(DPIG_EINVAL, "null tensor pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int kind = thin_kind(d);
+    if (kind == 1) rc = thin_fwd_try(d, pt, pl, x, w, bias, nullptr, static_cast<float*>(y), nullptr, st, true);
+    else if (kind == 2) rc = fewc_fwd_try(d, pt, pl, Ho, Wo, static_cast<const float*>(x), w, bias, nullptr, y, nullptr, st, true);
+    else rc = 0;
+    if (rc == 0) return fail(DPIG_EINVAL, "not a thin layer the vector-ALU kernels accept");
+    return rc < 0 ? rc : DPIG_OK;
+}
+
+extern "C" int dpig_conv2d_dgrad_thin_bf16(const DpigConvDesc* d, const void* dy, const float* w, void* dx, void* stream) {
+    int pt, pl, Ho, Wo;
+    int rc = resolve_desc(d, &pt, &pl, &Ho, &Wo);
+    if (rc) return rc;
+    if (!dy || !w || !dx) return fail(DPIG_EINVAL, "null tensor pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int kind = thin_kind(d);
+    if (kind == 1) rc = thin_dgrad_try(d, pt, pl, static_cast<const float*>(dy), w, nullptr, nullptr, dx, st, true);
+    else if (kind == 2) rc = fewc_dgrad_try(d, pt, pl, Ho, Wo, dy, w, nullptr, nullptr, static_cast<float*>(dx), st, true);
+    else rc = 0;
+    if (rc == 0) return fail(DPIG_EINVAL, "not a thin layer the vector-ALU kernels accept");
+    return rc < 0 ? rc : DPIG_OK;
+}
+
+extern "C" int dpig_conv2d_wgrad_thin_bf16(const DpigConvDesc* d, const void* x, const void* dy, float* dw, float beta,
+                                           float* db, float beta_b, void* ws, size_t ws_bytes, void* stream) {
+    int pt, pl, Ho, Wo;
+    int rc = resolve_desc(d, &pt, &pl, &Ho, &Wo);
+    if (rc) return rc;
+    if (!x || !dy || !dw) return fail(DPIG_EINVAL, "null tensor pointer");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int kind = thin_kind(d);
+    if (kind == 1) rc = thin_wgrad_try(d, pt, pl, x, static_cast<const float*>(dy), dw, beta, db, beta_b, ws, ws_bytes, st, true);
+    else if (kind == 2) rc = fewc_wgrad_try(d, pt, pl, Ho, Wo, static_cast<const float*>(x), dy, dw, beta, db, beta_b, ws, ws_bytes, st, true);
+    else rc = 0;
+    if (rc == 0) return fail(DPIG_EINVAL, "not a thin layer the vector-ALU kernels accept");
+    return rc < 0 ? rc : DPIG_OK;
+}
+
+extern "C" int dpig_cvt_f32_to_bf16_pad(const float* in, int ldi, int cols_in, uint16_t* out, int ldo, int cols_out,
+                                        int64_t rows, void* stream) {
+    if (!in || !out || rows < 0 || cols_in <= 0 || cols_out < cols_in || ldi < cols_in || ldo < cols_out)
+        return fail(DPIG_EINVAL, "cvt_pad: bad arguments");
+    if (cols_out % 8 || ldo % 8 || !aligned16(out)) return fail(DPIG_EALIGN, "cvt_pad: output rows must be 16-byte vectors");
+    if (rows == 0) return DPIG_OK;
+    int blocks = cdiv(rows * (cols_out / 8), 256);
+    if (blocks > 16 * kNumCU) blocks = 16 * kNumCU;
+    hipLaunchKernelGGL(cvt_pad_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), in, ldi, cols_in, out,
+                       ldo, cols_out, (long)rows);
+    return check_launch("cvt_f32_to_bf16_pad");
 }

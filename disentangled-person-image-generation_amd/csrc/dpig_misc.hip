@@ -160,7 +160,10 @@ static int slabs_for(long rows) {
 // per-image sums of a [N,H,W,C] tensor over the 9 border classes of a 3x3 SAME conv (the gradient
 // of the class-indexed residual of dpig_conv2d_fwd).  partial: [N][slab][9][C]
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void class_sum_partial_kernel(const float* __restrict__ a, int lda, int H, int W,
+__device__ __forceinline__ float ld_elem(const float* a, long i) { return a[i]; }
+__device__ __forceinline__ float ld_elem(const unsigned short* a, long i) { return __uint_as_float((unsigned)a[i] << 16); }   // bf16
+template <typename T>
+__global__ __launch_bounds__(256) void class_sum_partial_kernel(const T* __restrict__ a, int lda, int H, int W,
                                                                 int C, float* __restrict__ partial) {
     __shared__ float red[9][4][64];
     const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(256) void class_sum_partial_kernel(const float* __r
             const int cy = (y == 0) ? 0 : ((y == H - 1) ? 2 : 1);
             const int cx = (x == 0) ? 0 : ((x == W - 1) ? 2 : 1);
             const int cls = cy * 3 + cx;
-            const float v = a[((long)n * P + pix) * lda + c];
+            const float v = ld_elem(a, ((long)n * P + pix) * lda + c);
 #pragma unroll
             for (int k = 0; k < 9; ++k) acc[k] += (cls == k) ? v : 0.f;
         }
@@ -939,8 +942,9 @@ static int class_slabs(int N, int H, int W) {
 extern "C" size_t dpig_border_class_sum_workspace_bytes(int N, int H, int W, int C) {
     return (size_t)N * class_slabs(N, H, W) * 9 * C * sizeof(float);
 }
-extern "C" int dpig_border_class_sum(const float* a, int lda, int N, int H, int W, int C, float* out, void* ws,
-                                     size_t ws_bytes, void* stream) {
+template <typename T>
+static int border_class_sum_impl(const T* a, int lda, int N, int H, int W, int C, float* out, void* ws, size_t ws_bytes,
+                                 void* stream) {
     if (!a || !out) return fail(DPIG_EINVAL, "border_class_sum: null pointer");
     if (N <= 0 || H < 2 || W < 2 || C <= 0 || lda < C) return fail(DPIG_EINVAL, "border_class_sum: bad shape");
     if (!ws || ws_bytes < dpig_border_class_sum_workspace_bytes(N, H, W, C))
@@ -948,11 +952,19 @@ extern "C" int dpig_border_class_sum(const float* a, int lda, int N, int H, int 
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nslab = class_slabs(N, H, W);
     float* partial = static_cast<float*>(ws);
-    hipLaunchKernelGGL(class_sum_partial_kernel, dim3(cdivi(C, 64), N, nslab), dim3(256), 0, st, a, lda, H, W, C,
+    hipLaunchKernelGGL(class_sum_partial_kernel<T>, dim3(cdivi(C, 64), N, nslab), dim3(256), 0, st, a, lda, H, W, C,
                        partial);
     const long total = (long)N * 9 * C;
     hipLaunchKernelGGL(class_sum_final_kernel, dim3(grid_for(total)), dim3(256), 0, st, partial, nslab, C, total, out);
     return check_launch("border_class_sum");
+}
+extern "C" int dpig_border_class_sum(const float* a, int lda, int N, int H, int W, int C, float* out, void* ws,
+                                     size_t ws_bytes, void* stream) {
+    return border_class_sum_impl<float>(a, lda, N, H, W, C, out, ws, ws_bytes, stream);
+}
+extern "C" int dpig_border_class_sum_bf16(const uint16_t* a, int lda, int N, int H, int W, int C, float* out, void* ws,
+                                          size_t ws_bytes, void* stream) {
+    return border_class_sum_impl<unsigned short>(a, lda, N, H, W, C, out, ws, ws_bytes, stream);
 }
 
 extern "C" size_t dpig_bn_workspace_bytes(int64_t rows, int C) {

@@ -46,17 +46,33 @@ __device__ __forceinline__ float reduce_to_lane63(float v) {
 }
 
 struct ThinParams {
-    const float* X; const float* W; const float* bias; const float* DY;
-    float* Y; float* DX; float* partial;
+    const void* X;               // the C-channel tensor: fp32, or bf16 in the WB kernel variants ('bf16' storage mode)
+    const float* W; const float* bias; const float* DY;
+    float* Y; void* DX; float* partial;
     int N, H, Wd, C, ldx, ldy;          // ldy: row stride of the 3-channel tensor
     int nstrips, nwaves;
     unsigned x_bytes;
     int act; float alpha;
 };
 
+// 4 consecutive channels of the wide tensor: 16 bytes of fp32 or (WB) 8 bytes of bf16, widened exactly
+template <bool WB>
 __device__ __forceinline__ float4 ld16(__amdgpu_buffer_rsrc_t r, unsigned off) {
-    const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
-    return make_float4(t.x, t.y, t.z, t.w);
+    if constexpr (WB) {
+        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+        const u32x2 t = __builtin_bit_cast(u32x2, __builtin_amdgcn_raw_buffer_load_b64(r, (int)off, 0, 0));
+        return make_float4(__uint_as_float(t.x << 16), __uint_as_float(t.x & 0xffff0000u), __uint_as_float(t.y << 16),
+                           __uint_as_float(t.y & 0xffff0000u));
+    } else {
+        const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 0));
+        return make_float4(t.x, t.y, t.z, t.w);
+    }
+}
+typedef __bf16 thin_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned thin_pack2(float a, float b) {
+    thin_bf16x2 v;
+    v[0] = (__bf16)a; v[1] = (__bf16)b;
+    return __builtin_bit_cast(unsigned, v);
 }
 constexpr unsigned OOBT = 0x7fffffffu;
 
@@ -72,7 +88,9 @@ __device__ __forceinline__ void load_filter(const float* __restrict__ w, int C, 
 }
 
 // ---- forward ---------------------------------------------------------------------------------------------
+template <bool WB>
 __global__ __launch_bounds__(256) void thin3_fwd_kernel(const ThinParams p) {
+    constexpr unsigned ES = WB ? 2u : 4u;          // bytes per element of the wide tensor
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
     if (wv >= p.nwaves) return;
@@ -83,23 +101,23 @@ __global__ __launch_bounds__(256) void thin3_fwd_kernel(const ThinParams p) {
     const int x1 = min(p.Wd, x0 + XS);
     float wr[9][4][TK];
     load_filter(p.W, p.C, lane, wr);
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.X), 0, (int)p.x_bytes, 0x00020000);
     const bool cok = lane * 4 < p.C;
     // byte offset of pixel (row + dy, ix), or OOB when outside the image
     auto off = [&](int dy, int ix) -> unsigned {
         const bool ok = cok & ((unsigned)(y + dy) < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.Wd);
-        return ok ? (unsigned)((((long)(row + dy)) * p.Wd + ix) * p.ldx + lane * 4) * 4u : OOBT;
+        return ok ? (unsigned)((((long)(row + dy)) * p.Wd + ix) * p.ldx + lane * 4) * ES : OOBT;
     };
     float4 win[3][3];                               // [column x-1, x, x+1][row y-1, y, y+1]
 #pragma unroll
-    for (int r = 0; r < 3; ++r) { win[1][r] = ld16(rs, off(r - 1, x0 - 1)); win[2][r] = ld16(rs, off(r - 1, x0)); }
+    for (int r = 0; r < 3; ++r) { win[1][r] = ld16<WB>(rs, off(r - 1, x0 - 1)); win[2][r] = ld16<WB>(rs, off(r - 1, x0)); }
     float b[TK];
 #pragma unroll
     for (int k = 0; k < TK; ++k) b[k] = p.bias ? p.bias[k] : 0.f;
     const float slope = (p.act == DPIG_ACT_NONE) ? 1.f : ((p.act == DPIG_ACT_RELU) ? 0.f : p.alpha);
     for (int x = x0; x < x1; ++x) {
 #pragma unroll
-        for (int r = 0; r < 3; ++r) { win[0][r] = win[1][r]; win[1][r] = win[2][r]; win[2][r] = ld16(rs, off(r - 1, x + 1)); }
+        for (int r = 0; r < 3; ++r) { win[0][r] = win[1][r]; win[1][r] = win[2][r]; win[2][r] = ld16<WB>(rs, off(r - 1, x + 1)); }
         float acc[TK];
 #pragma unroll
         for (int k = 0; k < TK; ++k) acc[k] = 0.f;
@@ -127,6 +145,7 @@ __global__ __launch_bounds__(256) void thin3_fwd_kernel(const ThinParams p) {
 }
 
 // ---- dgrad: dx[p][c] = sum_{ky,kx,k} dy[p + (1-ky, 1-kx)][k] * w[ky][kx][c][k] --------------------------
+template <bool WB>
 __global__ __launch_bounds__(256) void thin3_dgrad_kernel(const ThinParams p) {
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -170,13 +189,19 @@ __global__ __launch_bounds__(256) void thin3_dgrad_kernel(const ThinParams p) {
                     for (int e = 0; e < 4; ++e) a[e] += gv * wr[t][e][k];
                 }
             }
-        if (cok) *reinterpret_cast<float4*>(p.DX + ((long)row * p.Wd + x) * p.ldx + lane * 4) = make_float4(a[0], a[1], a[2], a[3]);
+        if (cok) {
+            const long o = ((long)row * p.Wd + x) * p.ldx + lane * 4;
+            if constexpr (WB) *reinterpret_cast<uint2*>(static_cast<unsigned short*>(p.DX) + o) = make_uint2(thin_pack2(a[0], a[1]), thin_pack2(a[2], a[3]));
+            else *reinterpret_cast<float4*>(static_cast<float*>(p.DX) + o) = make_float4(a[0], a[1], a[2], a[3]);
+        }
     }
 }
 
 // ---- wgrad: dw[t][c][k] = sum_p x[p + tap t][c] * dy[p][k],  db[k] = sum_p dy[p][k] -------------------------
 // partial layout per workgroup: [9][C][3] filter gradient followed by [3] bias gradient
+template <bool WB>
 __global__ __launch_bounds__(256) void thin3_wgrad_kernel(const ThinParams p) {
+    constexpr unsigned ES = WB ? 2u : 4u;
     __shared__ float red[9 * 4 * TK + TK][64];
     const int lane = threadIdx.x & 63;
     const int wid = threadIdx.x >> 6;
@@ -190,7 +215,7 @@ __global__ __launch_bounds__(256) void thin3_wgrad_kernel(const ThinParams p) {
             for (int k = 0; k < TK; ++k) acc[t][e][k] = 0.f;
 #pragma unroll
     for (int k = 0; k < TK; ++k) bs[k] = 0.f;
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.X), 0, (int)p.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.X), 0, (int)p.x_bytes, 0x00020000);
     const bool cok = lane * 4 < p.C;
     // a wave owns the strips u = wave, wave + #waves, ... (fixed assignment -> fixed summation order)
     for (int u = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + wid); u < p.nwaves; u += gridDim.x * 4) {
@@ -201,14 +226,14 @@ __global__ __launch_bounds__(256) void thin3_wgrad_kernel(const ThinParams p) {
         const int x1 = min(p.Wd, x0 + XS);
         auto off = [&](int dy, int ix) -> unsigned {
             const bool ok = cok & ((unsigned)(y + dy) < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.Wd);
-            return ok ? (unsigned)((((long)(row + dy)) * p.Wd + ix) * p.ldx + lane * 4) * 4u : OOBT;
+            return ok ? (unsigned)((((long)(row + dy)) * p.Wd + ix) * p.ldx + lane * 4) * ES : OOBT;
         };
         float4 win[3][3];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) { win[1][r] = ld16(rs, off(r - 1, x0 - 1)); win[2][r] = ld16(rs, off(r - 1, x0)); }
+        for (int r = 0; r < 3; ++r) { win[1][r] = ld16<WB>(rs, off(r - 1, x0 - 1)); win[2][r] = ld16<WB>(rs, off(r - 1, x0)); }
         for (int x = x0; x < x1; ++x) {
 #pragma unroll
-            for (int r = 0; r < 3; ++r) { win[0][r] = win[1][r]; win[1][r] = win[2][r]; win[2][r] = ld16(rs, off(r - 1, x + 1)); }
+            for (int r = 0; r < 3; ++r) { win[0][r] = win[1][r]; win[1][r] = win[2][r]; win[2][r] = ld16<WB>(rs, off(r - 1, x + 1)); }
             const float* s = p.DY + ((long)row * p.Wd + x) * p.ldy;
             float g[TK];
 #pragma unroll
@@ -287,8 +312,9 @@ __global__ __launch_bounds__(256) void thin3_wgrad_reduce_kernel(const float* __
 // sits in LDS (fwd) or registers (dgrad); wgrad keeps R*S*3 (or one filter row of) float4 accumulators per lane.
 // =============================================================================================================
 struct FewCParams {
-    const float* X; const float* W; const float* bias; const float* DY;
-    float* Y; float* DX; float* partial;
+    const float* X; const float* W; const float* bias;
+    const void* DY; void* Y;     // the K-channel tensor: fp32, or bf16 in the WB kernel variants
+    float* DX; float* partial;
     int N, H, Wd, ldx;           // image [N,H,Wd,3], row stride ldx
     int Ho, Wo, K, ldy;          // Cout tensor [N,Ho,Wo,K]
     int pt, pl, act; float alpha;
@@ -309,7 +335,18 @@ __device__ __forceinline__ void stage_row(const FewCParams& p, int n, int iy, fl
 }
 
 // ---- forward: one workgroup per output row; thread = (output-channel quad, pixel slot) ------------------------
-template <int R, int S, int ST>
+// 4 consecutive channels of the wide (K-channel) tensor at element offset o
+template <bool WB>
+__device__ __forceinline__ float4 fewc_ld4(const void* base, long o) {
+    if constexpr (WB) {
+        const uint2 u = *reinterpret_cast<const uint2*>(static_cast<const unsigned short*>(base) + o);
+        return make_float4(__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16),
+                           __uint_as_float(u.y & 0xffff0000u));
+    } else {
+        return *reinterpret_cast<const float4*>(static_cast<const float*>(base) + o);
+    }
+}
+template <int R, int S, int ST, bool WB>
 __global__ __launch_bounds__(256) void fewc_fwd_kernel(const FewCParams p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float* wsm = sm;                                  // [R*S*3][K]
@@ -340,13 +377,15 @@ __global__ __launch_bounds__(256) void fewc_fwd_kernel(const FewCParams p) {
         }
         a.x = (a.x > 0.f) ? a.x : (a.x * slope + 0.f); a.y = (a.y > 0.f) ? a.y : (a.y * slope + 0.f);
         a.z = (a.z > 0.f) ? a.z : (a.z * slope + 0.f); a.w = (a.w > 0.f) ? a.w : (a.w * slope + 0.f);
-        *reinterpret_cast<float4*>(p.Y + ((long)row * p.Wo + ox) * p.ldy + kq * 4) = a;
+        const long o = ((long)row * p.Wo + ox) * p.ldy + kq * 4;
+        if constexpr (WB) *reinterpret_cast<uint2*>(static_cast<unsigned short*>(p.Y) + o) = make_uint2(thin_pack2(a.x, a.y), thin_pack2(a.z, a.w));
+        else *reinterpret_cast<float4*>(static_cast<float*>(p.Y) + o) = a;
     }
 }
 
 // ---- wgrad: persistent workgroups over output rows; blockIdx.y = tap group (TG consecutive taps) ----------------
 // partial layout per workgroup (blockIdx.x): [R*S*3][K] filter gradient, then [K] bias gradient
-template <int R, int S, int ST, int TG>
+template <int R, int S, int ST, int TG, bool WB>
 __global__ __launch_bounds__(256) void fewc_wgrad_kernel(const FewCParams p) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int RG = (TG + S - 1) / S;              // image rows a tap group touches (TG = S: 1, TG = R*S: R)
@@ -367,7 +406,7 @@ __global__ __launch_bounds__(256) void fewc_wgrad_kernel(const FewCParams p) {
         for (int r = 0; r < RG; ++r) stage_row<S>(p, n, oy * ST - p.pt + r0 + r, xrow + r * FC_MAXW * 3);
         __syncthreads();
         for (int ox = slot; ox < p.Wo; ox += nslots) {
-            const float4 g = *reinterpret_cast<const float4*>(p.DY + ((long)row * p.Wo + ox) * p.ldy + kq * 4);
+            const float4 g = fewc_ld4<WB>(p.DY, ((long)row * p.Wo + ox) * p.ldy + kq * 4);
             bs.x += g.x; bs.y += g.y; bs.z += g.z; bs.w += g.w;
 #pragma unroll
             for (int t = 0; t < TG; ++t) {
@@ -428,7 +467,7 @@ __global__ __launch_bounds__(256) void fewc_wgrad_reduce_kernel(const float* __r
 }
 
 // ---- dgrad towards the 3-channel image: lane = output channel k (K <= 64), one wave per strip of image pixels --
-template <int R, int S, int ST>
+template <int R, int S, int ST, bool WB>
 __global__ __launch_bounds__(256) void fewc_dgrad_kernel(const FewCParams p, int nstrips, int nwaves) {
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
@@ -453,7 +492,9 @@ __global__ __launch_bounds__(256) void fewc_dgrad_kernel(const FewCParams p, int
             for (int kx = 0; kx < S; ++kx) {
                 const int tx = ix + p.pl - kx;
                 if (tx < 0 || (tx % ST) != 0 || tx / ST >= p.Wo) continue;
-                const float g = kok ? p.DY[(((long)n * p.Ho + ty / ST) * p.Wo + tx / ST) * p.ldy + lane] : 0.f;
+                const long go = (((long)n * p.Ho + ty / ST) * p.Wo + tx / ST) * p.ldy + lane;
+                const float g = !kok ? 0.f : (WB ? __uint_as_float((unsigned)static_cast<const unsigned short*>(p.DY)[go] << 16)
+                                                 : static_cast<const float*>(p.DY)[go]);
                 a0 += g * wr[ky * S + kx][0]; a1 += g * wr[ky * S + kx][1]; a2 += g * wr[ky * S + kx][2];
             }
         }
@@ -470,35 +511,38 @@ static bool eligible(const DpigConvDesc* d, int pt, int pl) {
     return d->K == TK && d->R == 3 && d->S == 3 && d->stride == 1 && !d->upsample2x && pt == 1 && pl == 1 &&
            d->C % 4 == 0 && d->C >= 16 && d->C <= 256 && d->ldx % 4 == 0;
 }
-static bool fill(const DpigConvDesc* d, ThinParams* p) {
+static bool fill(const DpigConvDesc* d, ThinParams* p, bool wb) {
     p->N = d->N; p->H = d->H; p->Wd = d->W; p->C = d->C; p->ldx = d->ldx; p->ldy = d->ldy;
     p->nstrips = (d->W + XS - 1) / XS;
     p->nwaves = d->N * d->H * p->nstrips;
     const long xe = ((long)d->N * d->H * d->W - 1) * d->ldx + d->C;
-    if (xe * 4 >= 0x7fffffffL) return false;
-    p->x_bytes = (unsigned)(xe * 4);
+    const long es = wb ? 2 : 4;
+    if (xe * es >= 0x7fffffffL) return false;
+    p->x_bytes = (unsigned)(xe * es);
     p->act = d->act; p->alpha = d->alpha;
     return true;
 }
 
-int thin_fwd_try(const DpigConvDesc* d, int pt, int pl, const float* x, const float* w, const float* bias,
-                 const float* residual, float* y, float* y_act, hipStream_t st) {
+int thin_fwd_try(const DpigConvDesc* d, int pt, int pl, const void* x, const float* w, const float* bias,
+                 const float* residual, float* y, float* y_act, hipStream_t st, bool wide_bf16) {
     if (!eligible(d, pt, pl) || residual || y_act || !aligned16(x)) return 0;
     ThinParams p = {};
-    if (!fill(d, &p)) return 0;
+    if (!fill(d, &p, wide_bf16)) return 0;
     p.X = x; p.W = w; p.bias = bias; p.Y = y;
-    hipLaunchKernelGGL(thin3_fwd_kernel, dim3((p.nwaves + 3) / 4), dim3(256), 0, st, p);
+    if (wide_bf16) hipLaunchKernelGGL(thin3_fwd_kernel<true>, dim3((p.nwaves + 3) / 4), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(thin3_fwd_kernel<false>, dim3((p.nwaves + 3) / 4), dim3(256), 0, st, p);
     const int rc = check_launch("thin3_fwd_kernel");
     return rc ? rc : 1;
 }
 
 int thin_dgrad_try(const DpigConvDesc* d, int pt, int pl, const float* dy, const float* w, const float* accum,
-                   const float* mask, float* dx, hipStream_t st) {
+                   const float* mask, void* dx, hipStream_t st, bool wide_bf16) {
     if (!eligible(d, pt, pl) || accum || mask || !aligned16(dx)) return 0;
     ThinParams p = {};
-    if (!fill(d, &p)) return 0;
+    if (!fill(d, &p, wide_bf16)) return 0;
     p.DY = dy; p.W = w; p.DX = dx;
-    hipLaunchKernelGGL(thin3_dgrad_kernel, dim3((p.nwaves + 3) / 4), dim3(256), 0, st, p);
+    if (wide_bf16) hipLaunchKernelGGL(thin3_dgrad_kernel<true>, dim3((p.nwaves + 3) / 4), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(thin3_dgrad_kernel<false>, dim3((p.nwaves + 3) / 4), dim3(256), 0, st, p);
     const int rc = check_launch("thin3_dgrad_kernel");
     return rc ? rc : 1;
 }
@@ -508,16 +552,17 @@ size_t thin_wgrad_workspace_bytes(const DpigConvDesc* d, int pt, int pl) {
     return (size_t)kWgradBlocks * (9 * (size_t)d->C * TK + TK) * sizeof(float);
 }
 
-int thin_wgrad_try(const DpigConvDesc* d, int pt, int pl, const float* x, const float* dy, float* dw, float beta,
-                   float* db, float beta_b, void* ws, size_t ws_bytes, hipStream_t st) {
+int thin_wgrad_try(const DpigConvDesc* d, int pt, int pl, const void* x, const float* dy, float* dw, float beta,
+                   float* db, float beta_b, void* ws, size_t ws_bytes, hipStream_t st, bool wide_bf16) {
     if (!eligible(d, pt, pl) || !aligned16(x)) return 0;
     ThinParams p = {};
-    if (!fill(d, &p)) return 0;
+    if (!fill(d, &p, wide_bf16)) return 0;
     const size_t need = thin_wgrad_workspace_bytes(d, pt, pl);
     if (!ws || ws_bytes < need) return fail(DPIG_ENOMEM, "conv wgrad workspace too small: have %zu", ws_bytes);
     p.X = x; p.DY = dy; p.partial = static_cast<float*>(ws);
     const int nblk = kWgradBlocks;
-    hipLaunchKernelGGL(thin3_wgrad_kernel, dim3(nblk), dim3(256), 0, st, p);
+    if (wide_bf16) hipLaunchKernelGGL(thin3_wgrad_kernel<true>, dim3(nblk), dim3(256), 0, st, p);
+    else hipLaunchKernelGGL(thin3_wgrad_kernel<false>, dim3(nblk), dim3(256), 0, st, p);
     int rc = check_launch("thin3_wgrad_kernel");
     if (rc) return rc;
     const int wsize = 9 * d->C * TK;
@@ -543,7 +588,7 @@ static void fewc_fill(const DpigConvDesc* d, int pt, int pl, int Ho, int Wo, Few
 constexpr int kFewCWgradBlocks = 2 * kNumCU;
 
 int fewc_fwd_try(const DpigConvDesc* d, int pt, int pl, int Ho, int Wo, const float* x, const float* w,
-                 const float* bias, const float* residual, float* y, float* y_act, hipStream_t st) {
+                 const float* bias, const float* residual, void* y, float* y_act, hipStream_t st, bool wide_bf16) {
     const int kind = fewc_kind(d);
     if (!kind || residual || y_act || !aligned16(w) || !aligned16(y) || (bias && !aligned16(bias))) return 0;
     FewCParams p = {};
@@ -551,8 +596,13 @@ int fewc_fwd_try(const DpigConvDesc* d, int pt, int pl, int Ho, int Wo, const fl
     p.X = x; p.W = w; p.bias = bias; p.Y = y;
     const int R = kind == 1 ? 3 : 5;
     const size_t lds = ((size_t)R * R * 3 * d->K + (size_t)R * FC_MAXW * 3) * sizeof(float);
-    if (kind == 1) hipLaunchKernelGGL((fewc_fwd_kernel<3, 3, 1>), dim3(p.nrows), dim3(256), lds, st, p);
-    else hipLaunchKernelGGL((fewc_fwd_kernel<5, 5, 2>), dim3(p.nrows), dim3(256), lds, st, p);
+    if (kind == 1) {
+        if (wide_bf16) hipLaunchKernelGGL((fewc_fwd_kernel<3, 3, 1, true>), dim3(p.nrows), dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((fewc_fwd_kernel<3, 3, 1, false>), dim3(p.nrows), dim3(256), lds, st, p);
+    } else {
+        if (wide_bf16) hipLaunchKernelGGL((fewc_fwd_kernel<5, 5, 2, true>), dim3(p.nrows), dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((fewc_fwd_kernel<5, 5, 2, false>), dim3(p.nrows), dim3(256), lds, st, p);
+    }
     const int rc = check_launch("fewc_fwd_kernel");
     return rc ? rc : 1;
 }
@@ -562,8 +612,9 @@ size_t fewc_wgrad_workspace_bytes(const DpigConvDesc* d) {
     return (size_t)kFewCWgradBlocks * ((size_t)d->R * d->S * 3 * d->K + d->K) * sizeof(float);
 }
 
-int fewc_wgrad_try(const DpigConvDesc* d, int pt, int pl, int Ho, int Wo, const float* x, const float* dy,
-                   float* dw, float beta, float* db, float beta_b, void* ws, size_t ws_bytes, hipStream_t st) {
+int fewc_wgrad_try(const DpigConvDesc* d, int pt, int pl, int Ho, int Wo, const float* x, const void* dy,
+                   float* dw, float beta, float* db, float beta_b, void* ws, size_t ws_bytes, hipStream_t st,
+                   bool wide_bf16) {
     const int kind = fewc_kind(d);
     if (!kind || !aligned16(dy)) return 0;
     const size_t need = fewc_wgrad_workspace_bytes(d);
@@ -574,10 +625,12 @@ int fewc_wgrad_try(const DpigConvDesc* d, int pt, int pl, int Ho, int Wo, const 
     const int nblk = p.nrows < kFewCWgradBlocks ? p.nrows : kFewCWgradBlocks;
     if (kind == 1) {
         const size_t lds = ((size_t)3 * FC_MAXW * 3 + (size_t)(27 + 1) * d->K) * sizeof(float);
-        hipLaunchKernelGGL((fewc_wgrad_kernel<3, 3, 1, 9>), dim3(nblk, 1), dim3(256), lds, st, p);
+        if (wide_bf16) hipLaunchKernelGGL((fewc_wgrad_kernel<3, 3, 1, 9, true>), dim3(nblk, 1), dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((fewc_wgrad_kernel<3, 3, 1, 9, false>), dim3(nblk, 1), dim3(256), lds, st, p);
     } else {
         const size_t lds = ((size_t)1 * FC_MAXW * 3 + (size_t)(15 + 1) * d->K) * sizeof(float);
-        hipLaunchKernelGGL((fewc_wgrad_kernel<5, 5, 2, 5>), dim3(nblk, 5), dim3(256), lds, st, p);
+        if (wide_bf16) hipLaunchKernelGGL((fewc_wgrad_kernel<5, 5, 2, 5, true>), dim3(nblk, 5), dim3(256), lds, st, p);
+        else hipLaunchKernelGGL((fewc_wgrad_kernel<5, 5, 2, 5, false>), dim3(nblk, 5), dim3(256), lds, st, p);
     }
     int rc = check_launch("fewc_wgrad_kernel");
     if (rc) return rc;
@@ -588,15 +641,16 @@ int fewc_wgrad_try(const DpigConvDesc* d, int pt, int pl, int Ho, int Wo, const 
     return rc ? rc : 1;
 }
 
-int fewc_dgrad_try(const DpigConvDesc* d, int pt, int pl, int Ho, int Wo, const float* dy, const float* w,
-                   const float* accum, const float* mask, float* dx, hipStream_t st) {
+int fewc_dgrad_try(const DpigConvDesc* d, int pt, int pl, int Ho, int Wo, const void* dy, const float* w,
+                   const float* accum, const float* mask, float* dx, hipStream_t st, bool wide_bf16) {
     if (fewc_kind(d) != 2 || d->K > 64 || accum || mask) return 0;
     FewCParams p = {};
     fewc_fill(d, pt, pl, Ho, Wo, &p);
     p.DY = dy; p.W = w; p.DX = dx;
     const int nstrips = (d->W + XS - 1) / XS;
     const int nwaves = d->N * d->H * nstrips;
-    hipLaunchKernelGGL((fewc_dgrad_kernel<5, 5, 2>), dim3((nwaves + 3) / 4), dim3(256), 0, st, p, nstrips, nwaves);
+    if (wide_bf16) hipLaunchKernelGGL((fewc_dgrad_kernel<5, 5, 2, true>), dim3((nwaves + 3) / 4), dim3(256), 0, st, p, nstrips, nwaves);
+    else hipLaunchKernelGGL((fewc_dgrad_kernel<5, 5, 2, false>), dim3((nwaves + 3) / 4), dim3(256), 0, st, p, nstrips, nwaves);
     const int rc = check_launch("fewc_dgrad_kernel");
     return rc ? rc : 1;
 }

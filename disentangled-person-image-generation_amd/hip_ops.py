@@ -215,6 +215,17 @@ def _bf16_conv_ok(C, K, *lds):
     return C % 8 == 0 and K % 8 == 0 and C >= 32 and K >= 32 and all(ld % 8 == 0 for ld in lds)
 
 
+def _thin_ok(C, K, ld_wide, R, S, stride, *tensors):
+    """Host-side mirror of the vector-ALU kernels' shape conditions (dpig_thin.hip `eligible` / `fewc_kind`)."""
+    if not _al16(*tensors):
+        return False
+    if K == 3:
+        return R == 3 and S == 3 and stride == 1 and C % 4 == 0 and 16 <= C <= 256 and ld_wide % 4 == 0
+    lp = K // 4
+    return C == 3 and K % 4 == 0 and 1 <= lp <= 64 and (lp & (lp - 1)) == 0 and \
+        ((R, S, stride) == (3, 3, 1) or (R, S, stride) == (5, 5, 2))
+
+
 def _al16(*ts):
     return all(t is None or t.data_ptr() % 16 == 0 for t in ts)
 
@@ -414,7 +425,19 @@ def _conv2d_fwd_bf16(x, w, bias, stride, act, alpha, residual, out, upsample2x, 
                 check(lib().dpig_conv2d_fwd_bf16(ctypes.byref(d), ptr(x), ptr(w_t), ptr(bias), ptr(res_b), ptr(res_c),
                                                  ptr(out), ptr(out_act), ptr(wsb), wsn, stream_ptr()), "conv2d_fwd_bf16")
             return out
-    # thin layer (3-channel image side, 18-channel pose, ...): fp32 kernels between conversions
+    # thin layers: 3 output channels (x bf16 -> fp32 image) / 3 input channels (fp32 image -> bf16): vector-ALU kernels
+    # that read / write the wide tensor as bf16 directly
+    if out is None and out_act is None and residual is None and not upsample2x and (K == 3 or C == 3):
+        xt = to_bf16(x) if K == 3 else to_f32(x)
+        xt, ldx = as_nhwc(xt)
+        y = torch.empty((N, Ho, Wo, K), dtype=F32 if K == 3 else BF16, device=x.device)
+        d = _desc(N, H, W, C, K, R, S, stride, ldx, K, act=act, alpha=alpha)
+        wc = w.contiguous()
+        rc = lib().dpig_conv2d_fwd_thin_bf16(ctypes.byref(d), ptr(xt), ptr(wc), ptr(bias.contiguous() if bias is not None else None),
+                                             ptr(y), stream_ptr()) if _thin_ok(C, K, ldx, R, S, stride, xt, y, wc) else -22
+        if rc == 0:
+            return y
+    # anything else (18-channel pose conv, ...): fp32 kernels between conversions
     with _f32_mode():
         o32 = torch.empty((N, Ho, Wo, K), dtype=F32, device=x.device)
         a32 = torch.empty((N, Ho, Wo, K), dtype=F32, device=x.device) if out_act is not None else None
@@ -459,6 +482,16 @@ def _conv2d_dgrad_bf16(dy, w, in_shape, stride, accum, mask, act, alpha, out, up
                 check(lib().dpig_conv2d_dgrad_bf16(ctypes.byref(d), ptr(dy), ptr(w_p), ptr(accum), ptr(mask), ptr(out),
                                                    ptr(wsb), wsn, stream_ptr()), "conv2d_dgrad_bf16")
             return out
+    if out is None and accum is None and mask is None and not upsample2x and (K == 3 or (C == 3 and R == 5 and stride == 2)):
+        dyt = to_f32(dy) if K == 3 else to_bf16(dy)
+        dyt, ldy = as_nhwc(dyt)
+        dx = torch.empty((N, H, W, C), dtype=BF16 if K == 3 else F32, device=dy.device)
+        d = _desc(N, H, W, C, K, R, S, stride, C, ldy)
+        wc = w.contiguous()
+        rc = lib().dpig_conv2d_dgrad_thin_bf16(ctypes.byref(d), ptr(dyt), ptr(wc), ptr(dx), stream_ptr()) \
+            if _thin_ok(C, K, C, R, S, stride, dyt, dx, wc) and (K != 3 or ldy == 3) else -22
+        if rc == 0:
+            return dx
     with _f32_mode():
         o32 = torch.empty((N, H, W, C), dtype=F32, device=dy.device)
         conv2d_dgrad(to_f32(dy), w, in_shape, stride=stride, accum=to_f32(accum), mask=to_f32(mask), act=act,
@@ -489,6 +522,18 @@ def _conv2d_wgrad_bf16(x, dy, wshape, stride, upsample2x, out, beta, split_k, db
                 check(lib().dpig_conv2d_wgrad_bf16(ctypes.byref(d), ptr(xb), ptr(dyb), ptr(out), float(beta), ptr(db),
                                                    float(db_beta), ptr(wsb), wsn, stream_ptr()), "conv2d_wgrad_bf16")
             return out
+    if not upsample2x and (K == 3 or C == 3) and out.is_contiguous():
+        xt = to_bf16(x) if K == 3 else to_f32(x)
+        dyt = to_f32(dy) if K == 3 else to_bf16(dy)
+        xt, ldx = as_nhwc(xt)
+        dyt, ldy = as_nhwc(dyt)
+        d = _desc(N, H, W, C, K, R, S, stride, ldx, ldy)
+        if _thin_ok(C, K, ldx, R, S, stride, xt, dyt, out) and (K != 3 or ldy == 3):
+            wsb, wsn = _ws(d, 2, x.device)
+            rc = lib().dpig_conv2d_wgrad_thin_bf16(ctypes.byref(d), ptr(xt), ptr(dyt), ptr(out), float(beta), ptr(db),
+                                                   float(db_beta), ptr(wsb), wsn, stream_ptr())
+            if rc == 0:
+                return out
     with _f32_mode():
         return conv2d_wgrad(to_f32(x), to_f32(dy), wshape, stride=stride, upsample2x=upsample2x, out=out, beta=beta,
                             split_k=split_k, db=db, db_beta=db_beta)
@@ -558,15 +603,25 @@ def colsum(a, out=None, beta=0.0):
 
 
 def border_class_sum(a):
-    """[N,H,W,C] -> [N,9,C]: per-image sums over the 9 border classes of a SAME 3x3 conv."""
-    a = to_f32(a)
-    _require_gpu(a)
+    """[N,H,W,C] -> [N,9,C]: per-image sums over the 9 border classes of a SAME 3x3 conv (fp32 result; the input may
+    be a bf16 tensor)."""
+    _require_dev(a)
     a, lda = as_nhwc(a)
     N, Hh, W, C = a.shape
     out = torch.empty((N, 9, C), dtype=torch.float32, device=a.device)
     wsb, wsn = workspace.get(lib().dpig_border_class_sum_workspace_bytes(N, Hh, W, C), a.device)
-    check(lib().dpig_border_class_sum(ptr(a), lda, N, Hh, W, C, ptr(out), ptr(wsb), wsn, stream_ptr()),
-          "border_class_sum")
+    fn = lib().dpig_border_class_sum_bf16 if a.dtype == BF16 else lib().dpig_border_class_sum
+    check(fn(ptr(a), lda, N, Hh, W, C, ptr(out), ptr(wsb), wsn, stream_ptr()), "border_class_sum")
+    return out
+
+
+def pad_channels_bf16(x, cols_out):
+    """fp32 [N,H,W,C] -> bf16 [N,H,W,cols_out] with zero channels appended (cols_out a multiple of 8)."""
+    _require_gpu(x)
+    x, ld = as_nhwc(x)
+    N, Hh, W, C = x.shape
+    out = torch.empty((N, Hh, W, cols_out), dtype=BF16, device=x.device)
+    check(lib().dpig_cvt_f32_to_bf16_pad(ptr(x), ld, C, ptr(out), cols_out, cols_out, N * Hh * W, stream_ptr()), "cvt_pad")
     return out
 
 

@@ -144,9 +144,24 @@ int dpig_conv2d_dgrad_bf16(const DpigConvDesc* d, const uint16_t* dy, const uint
  * accumulated in fp32 on the matrix pipe from the dy tiles the launch stages anyway. */
 int dpig_conv2d_wgrad_bf16(const DpigConvDesc* d, const uint16_t* x, const uint16_t* dy, float* dw, float beta,
                            float* db, float beta_b, void* ws, size_t ws_bytes, void* stream);
+/* The thin layers of 'bf16' mode on the vector-ALU kernels (csrc/dpig_thin.hip) with their WIDE tensor stored as bf16;
+ * the 3-channel image side, the fp32 HWIO filter and the filter gradient stay fp32:
+ *   K == 3 (3x3 s1, the generator's image conv models.py:573):        x / dx bf16 [.., C],   y / dy fp32 [.., 3]
+ *   C == 3 (3x3 s1 encoder stem models.py:396, 5x5 s2 critic conv1):  x / dx fp32 [.., 3],   y / dy bf16 [.., K]
+ * (dgrad towards the image exists for the 5x5 s2 layer only).  DPIG_EINVAL for any other layer.  wgrad workspace:
+ * dpig_conv2d_workspace_bytes(d, 2). */
+int dpig_conv2d_fwd_thin_bf16(const DpigConvDesc* d, const void* x, const float* w, const float* bias, void* y,
+                              void* stream);
+int dpig_conv2d_dgrad_thin_bf16(const DpigConvDesc* d, const void* dy, const float* w, void* dx, void* stream);
+int dpig_conv2d_wgrad_thin_bf16(const DpigConvDesc* d, const void* x, const void* dy, float* dw, float beta, float* db,
+                                float beta_b, void* ws, size_t ws_bytes, void* stream);
 /* [rows, cols] matrices with row strides (elements): fp32 <-> bf16 (round-to-nearest-even / exact widening). */
 int dpig_cvt_f32_to_bf16(const float* in, int ldi, uint16_t* out, int ldo, int64_t rows, int cols, void* stream);
 int dpig_cvt_bf16_to_f32(const uint16_t* in, int ldi, float* out, int ldo, int64_t rows, int cols, void* stream);
+/* out[r][0..cols_out) = bf16(in[r][0..cols_in)), zero-padded: widens a thin input (the 18 pose channels of
+ * models.py:520-528 -> 32) so that its conv runs on the bf16 matrix-pipe loop with a zero-padded filter. */
+int dpig_cvt_f32_to_bf16_pad(const float* in, int ldi, int cols_in, uint16_t* out, int ldo, int cols_out, int64_t rows,
+                             void* stream);
 /* y = act(x) / dz = dy * act'(y) on bf16 [rows, cols] matrices (cols and strides multiples of 8): dpig_act_fwd / _bwd. */
 int dpig_act_fwd_bf16(const uint16_t* x, int ldx, uint16_t* y, int ldy, int64_t rows, int cols, int act, float alpha,
                       void* stream);
@@ -176,6 +191,10 @@ int dpig_colsum(const float* a, int lda, int64_t rows, int cols, float* out, flo
 size_t dpig_border_class_sum_workspace_bytes(int N, int H, int W, int C);
 int dpig_border_class_sum(const float* a, int lda, int N, int H, int W, int C, float* out, void* ws,
                           size_t ws_bytes, void* stream);
+
+/* The same sums of a bf16 tensor ('bf16' storage mode), accumulated and returned in fp32. */
+int dpig_border_class_sum_bf16(const uint16_t* a, int lda, int N, int H, int W, int C, float* out, void* ws,
+                               size_t ws_bytes, void* stream);
 
 /* ---- batch norm (training mode, biased variance, eps inside sqrt; batchnorm.py:30) ----------- */
 /* x,y: [rows, C] (rows = N*H*W).  save_mean / save_rstd: [C].  Optional fused LeakyReLU/ReLU. */

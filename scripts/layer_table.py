@@ -4,9 +4,18 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from dpig_amd import hip_ops as H, synthetic
 from dpig_amd.trainer import Config, DPIG_Encoder_GAN_BodyROI_FgBg
+from dpig_amd.trainer_256 import DPIG_Encoder_GAN_BodyROI_256
 dev = torch.device("cuda:0"); np.random.seed(0)
-tr = DPIG_Encoder_GAN_BodyROI_FgBg(Config(batch_size=16, compute_dtype=os.environ.get('DPIG_DTYPE', 'f32')), dev)
-b0 = synthetic.to_device(synthetic.make_batch(16, seed=1), dev); b1 = synthetic.to_device(synthetic.make_batch(16, seed=2), dev)
+DT = os.environ.get('DPIG_DTYPE', 'f32')
+if os.environ.get('DPIG_WORKLOAD', 'market128') == 'df256':      # DPIG_WORKLOAD=df256 DPIG_DTYPE=bf16 python scripts/layer_table.py
+    B = 8
+    tr = DPIG_Encoder_GAN_BodyROI_256(Config(batch_size=B, img_H=256, img_W=256, compute_dtype=DT), dev)
+    mk = lambda seed: synthetic.to_device(synthetic.make_batch(B, img_H=256, img_W=256, seed=seed), dev)
+else:
+    B = 16
+    tr = DPIG_Encoder_GAN_BodyROI_FgBg(Config(batch_size=B, compute_dtype=DT), dev)
+    mk = lambda seed: synthetic.to_device(synthetic.make_batch(B, seed=seed), dev)
+b0, b1 = mk(1), mk(2)
 tr.init_net(b0); tr.step = 1
 for _ in range(2): tr.train_step(b0, b1)
 torch.cuda.synchronize(); H.PROFILE = []
@@ -19,7 +28,7 @@ for k, f, a, b, lab in recs:
     key = (k, lab); d = agg.setdefault(key, [0, 0.0, 0.0]); d[0] += 1; d[1] += f; d[2] += a.elapsed_time(b) * 1e-3
 tot = sum(v[2] for v in agg.values())
 print("step %.2f ms (instrumented); conv total %.2f ms" % (e0.elapsed_time(e1) / 3, tot / 3 * 1e3))
-CEIL = 130e12 if os.environ.get('DPIG_DTYPE', 'f32') == 'f32' else 600e12   # reference rate for the 'lost' column
+CEIL = {'f32': 130e12, 'bf16c': 600e12, 'bf16': 1000e12}[DT]   # reference rate for the 'lost' column
 tf = sum(v[1] for v in agg.values())
 print("executed %.2f TFLOP/step -> %.1f TF average; at %.0f TF everywhere: %.2f ms" % (tf / 3 / 1e12, tf / tot / 1e12, CEIL / 1e12, tf / 3 / CEIL * 1e3))
 lost = lambda v: (v[2] - v[1] / CEIL) / 3 * 1e3

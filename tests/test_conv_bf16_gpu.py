@@ -197,28 +197,50 @@ def test_dgrad_mask_accum_and_wgrad_split_beta(dev):
         _close_f32(db, _r(dy).sum((0, 1, 2)) + 3.0)
 
 
-def test_thin_layers_take_the_fp32_kernels_between_conversions(dev):
-    """3-channel image convs, the 18-channel pose conv: outside the bf16 loops; 'bf16' mode converts at their boundary
-    and stores the result as bf16 iff its channel count is a multiple of 8."""
+@pytest.mark.parametrize("layer", [(2, 16, 40, 256, 3, 3, 1), (2, 16, 40, 3, 128, 3, 1), (2, 16, 40, 3, 64, 5, 2),
+                                   (2, 16, 8, 18, 128, 3, 1)])
+def test_thin_layers(dev, layer):
+    """3 output channels (x bf16 -> fp32 image), 3 input channels (fp32 image -> bf16): the vector-ALU kernels read /
+    write the wide tensor as bf16 directly (dpig_conv2d_*_thin_bf16).  Anything else outside the bf16 loops (the
+    18-channel pose conv) runs on the fp32 kernels between conversions.  A result is stored as bf16 iff its channel count
+    is a multiple of 8."""
     import dpig_amd.hip_ops as H
     from oracle import ops as O
+    N, Hh, W, C, K, k, s = layer
     H.set_compute("bf16")
     try:
-        x = _rand((2, 16, 8, 3), 1)
-        w = _rand((3, 3, 3, 128), 2, 0.2)
-        got = H.conv2d_fwd(x.float().to(dev), w.float().to(dev), None, act=1)
-        assert got.dtype == BF
-        _close_bf16(got, O.relu(O.conv2d_same(x.float().double(), w.float().double(), None, 1)))
-        x2 = _rand((2, 16, 8, 256), 3)
-        w2 = _rand((3, 3, 256, 3), 4, 0.2)
-        got = H.conv2d_fwd(x2.float().to(dev).to(BF), w2.float().to(dev), None)
-        assert got.dtype == torch.float32                    # the image stays fp32
-        _close_f32(got, O.conv2d_same(_r(x2), w2.float().double(), None, 1))
-        dy = _rand((2, 16, 8, 3), 5)
-        dx = H.conv2d_dgrad(dy.float().to(dev), w2.float().to(dev), (2, 16, 8, 256))
-        assert dx.dtype == BF
-        dw = H.conv2d_wgrad(x2.float().to(dev).to(BF), dy.float().to(dev), (3, 3, 256, 3))
-        assert dw.dtype == torch.float32
+        x = _rand((N, Hh, W, C), 1)
+        w = _rand((k, k, C, K), 2, 0.2)
+        b = _rand((K,), 3)
+        xs = _r(x) if C % 8 == 0 else x.float().double()          # what the device tensor holds
+        xd = x.float().to(dev).to(BF) if C % 8 == 0 else x.float().to(dev)
+        xr = xs.clone().requires_grad_(True)
+        wr = w.float().double().requires_grad_(True)
+        y = O.conv2d_same(xr, wr, b.float().double(), s)
+        got = H.conv2d_fwd(xd, w.float().to(dev), b.float().to(dev), stride=s)
+        if K % 8 == 0:
+            assert got.dtype == BF
+            _close_bf16(got, y.detach())
+        else:
+            assert got.dtype == torch.float32                    # the image stays fp32
+            _close_f32(got, y.detach())
+        dy = _rand(tuple(y.shape), 5)
+        dys = _r(dy) if K % 8 == 0 else dy.float().double()
+        dyd = dy.float().to(dev).to(BF) if K % 8 == 0 else dy.float().to(dev)
+        y.backward(dys)
+        if C != 3 or k == 5:                                      # (no gradient towards the image through the 3x3 stem)
+            dx = H.conv2d_dgrad(dyd, w.float().to(dev), (N, Hh, W, C), stride=s)
+            if C % 8 == 0:
+                assert dx.dtype == BF
+                _close_bf16(dx, xr.grad)
+            else:
+                assert dx.dtype == torch.float32
+                _close_f32(dx, xr.grad)
+        dw = torch.full((k, k, C, K), 2.0, device=dev)
+        db = torch.full((K,), 3.0, device=dev)
+        H.conv2d_wgrad(xd, dyd, (k, k, C, K), stride=s, out=dw, beta=1.0, db=db, db_beta=1.0)
+        _close_f32(dw, wr.grad + 2.0)
+        _close_f32(db, dys.sum((0, 1, 2)) + 3.0)
     finally:
         H.set_compute("f32")
 

@@ -328,6 +328,77 @@ def test_stage1_bf16_compute_mode(dev):
         H.set_compute("f32")
 
 
+@pytest.mark.parametrize("model", ["market", "df256"])
+def test_stage1_bf16_storage_mode(dev, model):
+    """Config(compute_dtype='bf16') (BASELINE configs 3-5): activations, their gradients and the filter shadows stored
+    as bf16, bf16 matrix pipe, fp32 accumulation / master weights / gradients / optimizer.  Against the fp64 oracle on the
+    UNROUNDED weights: embedding, generator output and losses within bf16 storage rounding (8 mantissa bits per stored
+    activation, over a ~40-layer graph); a training step moves the fp32 masters and refreshes the shadows; the fp32 mode is
+    untouched afterwards.  model 'df256' is the trainer_256.py graph (BASELINE configs[3])."""
+    import dpig_amd.hip_ops as H
+    import dpig_amd.tflib as lib
+    from dpig_amd import slim, synthetic
+    from dpig_amd.trainer import Config, DPIG_Encoder_GAN_BodyROI_FgBg
+    from dpig_amd.trainer_256 import DPIG_Encoder_GAN_BodyROI_256
+    from oracle import models as OM
+    lib.delete_all_params(); slim.reset_scopes()
+    np.random.seed(0)
+    if model == "market":
+        B, HID, ZN, Hh, Ww = 2, 64, 16, 128, 64
+        cls, kw = DPIG_Encoder_GAN_BodyROI_FgBg, {}
+    else:
+        B, HID, ZN, Hh, Ww = 2, 32, 16, 256, 256
+        cls, kw = DPIG_Encoder_GAN_BodyROI_256, {"img_H": 256, "img_W": 256}
+    batch_np = synthetic.make_batch(B, img_H=Hh, img_W=Ww, seed=31)
+    ob = OM.batch_to_torch(batch_np)
+    P = OM.ParamStore(seed=12)
+    with torch.no_grad():
+        if model == "market":
+            embs_o, G_o = OM.stage1_forward(P, ob, hidden_num=HID, z_num=ZN)
+            gl_o = OM.stage1_g_loss(P, ob, hidden_num=HID, z_num=ZN)[0]
+            dl_o = OM.stage1_d_loss(P, ob, hidden_num=HID, z_num=ZN)[0]
+        else:
+            ref = OM.stage1_256_forward(P, ob, HID, ZN, 6)
+            embs_o, G_o, gl_o, dl_o = ref["embs"], ref["G"], ref["g_loss"], ref["d_loss"]
+    lib.set_device(dev)
+    for n, v in P.state_numpy().items():
+        lib.param(n, v, trainable=P.trainable[n])
+    tr = cls(Config(batch_size=B, conv_hidden_num=HID, z_num=ZN, compute_dtype='bf16', **kw), dev)
+    batch = synthetic.to_device(batch_np, dev)
+    try:
+        tr.init_net(batch)
+        assert H.get_compute() == "bf16"
+        assert set(lib._params.keys()) == set(P.p.keys())
+        assert len(tr.G_flat.shadows.params) > 20 and len(tr.D_flat.shadows.params) == 3
+        with torch.no_grad():
+            embs, _ = tr.encode(batch)
+            G, _ = tr.generate(embs, batch["pose"])
+        assert G.dtype == torch.float32                         # the 3-channel image stays fp32
+        rel = lambda a, b: (a.double().cpu() - b.double()).abs().max().item() / max(b.abs().max().item(), 1e-12)
+        e_embs, e_G = rel(embs, embs_o), rel(G, G_o)
+        print("bf16 storage (%s): embedding rel err %.3e, G rel err %.3e" % (model, e_embs, e_G))
+        assert 1e-5 < e_embs < 6e-2
+        assert e_G < 8e-2
+        tr.step = 1
+        w0 = tr.G_flat.flat.detach().clone()
+        sh0 = tr.G_flat.shadows.buf.detach().clone()
+        d0 = tr._d_optim_eager(batch, update=False)         # (before the generator moves: the oracle's weights)
+        assert abs(float(d0["d_loss"]) - float(dl_o)) < 8e-2 * abs(float(dl_o))
+        out = tr.train_step(batch, batch)
+        assert abs(float(out["g_loss"]) - float(gl_o)) < 5e-2 * abs(float(gl_o))
+        assert all(np.isfinite(float(v)) for v in out.values() if hasattr(v, "numel") and v.numel() == 1)
+        assert float((tr.G_flat.flat - w0).abs().max()) > 0
+        assert tr.G_flat.grad.dtype == torch.float32 and bool(torch.isfinite(tr.G_flat.grad).all())
+        # the shadows follow the masters: plain shadow == bf16(master) for every conv filter
+        assert not torch.equal(tr.G_flat.shadows.buf, sh0)
+        for p in tr.G_flat.shadows.params[:4]:
+            assert torch.equal(p._dpig_shadow[0], p.data.to(torch.bfloat16))
+            assert torch.equal(p._dpig_shadow[1], p.data.permute(0, 1, 3, 2).contiguous().to(torch.bfloat16))
+    finally:
+        H.set_compute("f32")
+        lib.delete_all_params(); slim.reset_scopes()
+
+
 def test_inference_harness(dev):
     """SURVEY 8f-3 (tester.py:256-417): with sampling off the harness reproduces the trainer's generator path
     (same variables, pose maps rasterised from the keypoints) and the critic score; with sampling on it draws
