@@ -53,6 +53,7 @@ SYMBOLS = {
     "dpig_cvt_f32_to_bf16_pad": (_i, [_vp, _i, _i, _vp, _i, _i, _i64, _vp]),
     "dpig_act_fwd_bf16": (_i, [_vp, _i, _vp, _i, _i64, _i, _i, _f, _vp]),
     "dpig_act_bwd_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _i, _i, _f, _vp]),
+    "dpig_filter_shadow_bf16_multi": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "dpig_filter_shadow_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     "dpig_act_fwd": (_i, [_vp, _i, _vp, _i, _i64, _i, _i, _f, _vp]),
     "dpig_act_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _i, _i, _f, _vp]),
@@ -80,6 +81,8 @@ SYMBOLS = {
     "dpig_crop_resize_fwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
     "dpig_crop_resize_bwd_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "dpig_crop_resize_bwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    "dpig_crop_resize_fwd_bf16": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp]),
+    "dpig_crop_resize_bwd_bf16": (_i, [_vp, _i, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "dpig_pose_points": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "dpig_pose_inflate": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),
     "dpig_pose_rasterize": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _i, _vp]),

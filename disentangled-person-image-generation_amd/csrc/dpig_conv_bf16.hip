@@ -48,9 +48,6 @@ constexpr unsigned OOB = 0x7fffffffu;
 // split-K partial sums cost relatively more than on the fp32 pipe (the products are ~8x faster, HBM is not)
 constexpr double kSplitPenalty = 700.0;
 
-// 16 zero bytes: where the flat LDS-DMA form reads structural zeros (halo, rows >= M, channels >= C) from
-__device__ __attribute__((aligned(16))) unsigned g_zero16[4];
-
 struct BGParams {
     const bf16_t* A;      // gathered source activation (x for fwd, dy for dgrad)
     const bf16_t* B;      // filter shadow, [wtap][Ncols][Cs]
@@ -82,16 +79,12 @@ __device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned shr) {
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
 }
-// 16 bytes per lane, HBM/L2 -> LDS.  `lds_dst` is wave-uniform; lane l lands at lds_dst + 16 * l.  A lane with
-// ok == false delivers zeros: out-of-range offset (buffer form, hardware bounds check) or the zero page (flat form).
-template <bool DMA_BUF>
-__device__ __forceinline__ void dma16(const void* base, __amdgpu_buffer_rsrc_t rs, bool ok, int off, char* lds_dst) {
-    if constexpr (DMA_BUF) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)lds_dst, 16, ok ? off : (int)OOB, 0, 0, 0);
-    } else {
-        const char* src = ok ? reinterpret_cast<const char*>(base) + (long)off : reinterpret_cast<const char*>(g_zero16);
-        __builtin_amdgcn_global_load_lds((glb_void*)src, (lds_void*)lds_dst, 16, 0, 0);
-    }
+// 16 bytes per lane, HBM/L2 -> LDS (buffer_load_dwordx4 ... lds).  `lds_dst` is wave-uniform; lane l lands at
+// lds_dst + 16 * l.  The source is descriptor base + voff (per lane) + soff (scalar); a lane whose voff is OOB fails the
+// hardware bounds check and delivers zeros (halo, rows >= M, channels >= C: scripts/ubench/lds_probe.hip).  (The flat
+// global_load_lds form with a zero page measured 13 % slower and was dropped.)
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t rs, int voff, int soff, char* lds_dst) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)lds_dst, 16, voff, soff, 0, 0);
 }
 
 __device__ __forceinline__ void unpack8(uint4 u, float (&v)[8]) {
@@ -173,139 +166,9 @@ __device__ __forceinline__ void epi8(const BGParams& p, int row, int col, float 
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// gather-GEMM: D[M x Ncols] = gather(A)[M x K] * B^T, K = taps x channels
-template <bool DMA_BUF>
-__device__ __forceinline__ void bg_body(const BGParams& p) {
-    __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];     // the ONLY LDS object (two would make hipcc
-                                                                       // drain the DMA queue before every ds_read)
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wrow = (wave >> 1) * 64, wcol = (wave & 1) * 64;
-    const int l31 = lane & 31, half = lane >> 5;
-
-    const int tile = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
-    const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
-    const int m0 = mt * TM, n0 = nt * TN;
-    const int split = blockIdx.z;
-    const int kt_begin = split * p.tiles_per_split;
-    const int kt_end = min(p.ktiles, kt_begin + p.tiles_per_split);
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes);
-    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.B, p.b_bytes);
-
-    // ---- DMA roles: instruction j of this wave fills tile rows 32j + 8*wave .. +7; lane -> (row, slot) -------------
-    const int lrow = 8 * wave + (lane >> 3);                   // (+ 32 j)
-    const int chunk = (lane & 7) ^ ((lrow >> 1) & 7);          // the row's 16-byte chunk this lane fetches
-    int a_off[4], a_iy0[4], a_ix0[4], b_off[4];
-    bool b_ok[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = m0 + lrow + 32 * j;
-        const bool ok = m < p.M;
-        const int mm = ok ? m : 0;
-        const int n = fast_div(mm, p.mul_hrwr, p.shr_hrwr);
-        const int rem = mm - n * p.HrWr;
-        const int r = fast_div(rem, p.mul_wr, p.shr_wr);
-        const int c = rem - r * p.Wr;
-        a_iy0[j] = ok ? r * p.sr : -(1 << 24);                 // a row beyond M fails every bounds test
-        a_ix0[j] = c * p.sr;
-        a_off[j] = ((((n * p.Hs + r * p.sr) * p.Ws + c * p.sr) * p.lda) + chunk * 8) * 2;
-        const int nn = n0 + lrow + 32 * j;
-        b_ok[j] = nn < p.Ncols;
-        b_off[j] = (nn * p.Cs + chunk * 8) * 2;
-    }
-    int cur_c0, cur_ta, cur_tb;
-    {
-        const int tap = kt_begin / p.cchunks;
-        cur_c0 = (kt_begin - tap * p.cchunks) * TK;
-        cur_ta = tap / p.tap_nb;
-        cur_tb = tap - cur_ta * p.tap_nb;
-    }
-    auto issue = [&](int stage) {
-        const int c0 = cur_c0, ta = cur_ta, tb = cur_tb;
-        cur_c0 += TK;
-        if (cur_c0 >= p.Cs) {
-            cur_c0 = 0;
-            if (++cur_tb == p.tap_nb) { cur_tb = 0; ++cur_ta; }
-        }
-        const int wt = p.w0 + ta * p.wa + tb * p.wb;
-        const int t_oy = p.oy0 + ta * p.oys, t_ox = p.ox0 + tb * p.oxs;
-        const bool kok = c0 + chunk * 8 < p.Cs;
-        const int t_sA = ((t_oy * p.Ws + t_ox) * p.lda + c0) * 2;
-        const int t_sB = (wt * p.Ncols * p.Cs + c0) * 2;
-        char* dst = smem + stage * STAGE_B + (8 * wave) * ROWB;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            // bitwise & on purpose: && would become exec-mask branches around each DMA
-            const bool ok = kok & ((unsigned)(a_iy0[j] + t_oy) < (unsigned)p.Hs) & ((unsigned)(a_ix0[j] + t_ox) < (unsigned)p.Ws);
-            dma16<DMA_BUF>(p.A, rsA, ok, a_off[j] + t_sA, dst + 32 * j * ROWB);
-            dma16<DMA_BUF>(p.B, rsB, b_ok[j] & kok, b_off[j] + t_sB, dst + TILE_B + 32 * j * ROWB);
-        }
-    };
-
-    // ---- fragment addresses: row = wave row/col + 32 mb + l31, 8 consecutive k = chunk 2 ks + half -----------------
-    const int fsw = (l31 >> 1) & 7;
-    const char* fa_base = smem + (wrow + l31) * ROWB;
-    const char* fb_base = smem + TILE_B + (wcol + l31) * ROWB;
-    int so[4];
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) so[ks] = ((2 * ks + half) ^ fsw) * 16;
-
-    bf16x8 fa[2][2], fb[2][2];                     // [k-step parity][32-row / 32-col block]
-    auto load_frag = [&](int stage, int ks, bf16x8 (&a)[2], bf16x8 (&b)[2]) {
-        const char* ab = fa_base + stage * STAGE_B;
-        const char* bb = fb_base + stage * STAGE_B;
-#pragma unroll
-        for (int mb = 0; mb < 2; ++mb) a[mb] = *reinterpret_cast<const bf16x8*>(ab + mb * 32 * ROWB + so[ks]);
-#pragma unroll
-        for (int nb = 0; nb < 2; ++nb) b[nb] = *reinterpret_cast<const bf16x8*>(bb + nb * 32 * ROWB + so[ks]);
-    };
-    // One k-tile: the first fragments are requested right behind the barrier, the DMA of the NEXT tile (address
-    // arithmetic + 8 LDS-DMA instructions) is issued under their latency, the fragments of k-step ks+1 are read under the
-    // MFMAs of ks.  The stage the DMA fills was last read before the barrier every wave has passed.
-    auto ktile = [&](int stage, bool more) {
-        load_frag(stage, 0, fa[0], fb[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (more) issue(stage ^ 1);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            if (ks + 1 < 4) load_frag(stage, ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int mb = 0; mb < 2; ++mb)
-#pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
-                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][mb], fb[ks & 1][nb], acc[mb][nb], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-    };
-
-    if (kt_begin < kt_end) {
-        issue(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        int kt = kt_begin;
-        // two k-tiles per trip so that the LDS stage is a compile-time constant
-        for (; kt + 1 < kt_end; kt += 2) {
-            ktile(0, true);
-            ktile(1, kt + 2 < kt_end);
-        }
-        if (kt < kt_end) ktile(0, false);
-    }
-
-    // ---- epilogue: accumulators -> LDS (fp32) -> 16-byte row-contiguous global accesses -------------------------
+// ---- epilogue shared by the k-loop variants: accumulators -> LDS (fp32) -> 16-byte row-contiguous global accesses ----
+__device__ __forceinline__ void bg_epilogue(const BGParams& p, char* smem, f32x16 (&acc)[2][2], int m0, int n0, int split,
+                                            int tid, int wrow, int wcol, int l31, int half) {
     float* Cs = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
@@ -404,15 +267,165 @@ __device__ __forceinline__ void bg_body(const BGParams& p) {
     }
 }
 
-template <bool DMA_BUF>
-__global__ __launch_bounds__(256, 2) void bg_kernel(const BGParams p) { bg_body<DMA_BUF>(p); }
+// ------------------------------------------------------------------------------------------------
+// gather-GEMM: D[M x Ncols] = gather(A)[M x K] * B^T, K = taps x channels
+__device__ __forceinline__ void bg_body(const BGParams& p) {
+    __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];     // the ONLY LDS object (two would make hipcc
+                                                                       // drain the DMA queue before every ds_read)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wrow = (wave >> 1) * 64, wcol = (wave & 1) * 64;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    const int tile = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
+    const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+    const int m0 = mt * TM, n0 = nt * TN;
+    const int split = blockIdx.z;
+    const int kt_begin = split * p.tiles_per_split;
+    const int kt_end = min(p.ktiles, kt_begin + p.tiles_per_split);
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes);
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.B, p.b_bytes);
+
+    // ---- DMA roles: instruction j of this wave fills tile rows 32j + 8*wave .. +7; lane -> (row, slot) -------------
+    // Per-lane work is kept OUT of the k-tile loop (the loop is issue-bound: 16 MFMAs of 32 cycles per k-tile leave ~500
+    // cycles for everything else): the halo test and the tap's pixel shift are folded into a per-lane offset once per
+    // TAP (a_voff, OOB when the tap falls outside the image for this row); the channel chunk of a k-tile is a SCALAR
+    // offset of the DMA instruction, as is the whole filter-slab offset of the B operand.
+    const int lrow = 8 * wave + (lane >> 3);                   // (+ 32 j)
+    const int chunk = (lane & 7) ^ ((lrow >> 1) & 7);          // the row's 16-byte chunk this lane fetches
+    int a_base[4], a_iy0[4], a_ix0[4], a_voff[4], b_voff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int m = m0 + lrow + 32 * j;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int n = fast_div(mm, p.mul_hrwr, p.shr_hrwr);
+        const int rem = mm - n * p.HrWr;
+        const int r = fast_div(rem, p.mul_wr, p.shr_wr);
+        const int c = rem - r * p.Wr;
+        a_iy0[j] = ok ? r * p.sr : -(1 << 24);                 // a row beyond M fails every bounds test
+        a_ix0[j] = c * p.sr;
+        a_base[j] = ((((n * p.Hs + r * p.sr) * p.Ws + c * p.sr) * p.lda) + chunk * 8) * 2;
+        const int nn = n0 + lrow + 32 * j;
+        b_voff[j] = (nn < p.Ncols) ? (nn * p.Cs + chunk * 8) * 2 : (int)OOB;
+    }
+    const bool ktail = (p.Cs & (TK - 1)) != 0;                 // the last channel chunk of a tap is partial (uniform)
+    int cur_c0, cur_ta, cur_tb, tap_sB = 0;
+    {
+        const int tap = kt_begin / p.cchunks;
+        cur_c0 = (kt_begin - tap * p.cchunks) * TK;
+        cur_ta = tap / p.tap_nb;
+        cur_tb = tap - cur_ta * p.tap_nb;
+    }
+    auto enter_tap = [&]() {
+        const int t_oy = p.oy0 + cur_ta * p.oys, t_ox = p.ox0 + cur_tb * p.oxs;
+        const int shift = ((t_oy * p.Ws + t_ox) * p.lda) * 2;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            // bitwise & on purpose: && would become exec-mask branches
+            const bool ok = ((unsigned)(a_iy0[j] + t_oy) < (unsigned)p.Hs) & ((unsigned)(a_ix0[j] + t_ox) < (unsigned)p.Ws);
+            a_voff[j] = ok ? a_base[j] + shift : (int)OOB;
+        }
+        tap_sB = ((p.w0 + cur_ta * p.wa + cur_tb * p.wb) * p.Ncols * p.Cs) * 2;
+    };
+    enter_tap();
+    auto issue = [&](int stage) {
+        const int c0 = cur_c0;
+        char* dst = smem + stage * STAGE_B + (8 * wave) * ROWB;
+        if (ktail) {
+            const bool kok = c0 + chunk * 8 < p.Cs;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                dma16(rsA, kok ? a_voff[j] : (int)OOB, c0 * 2, dst + 32 * j * ROWB);
+                dma16(rsB, kok ? b_voff[j] : (int)OOB, tap_sB + c0 * 2, dst + TILE_B + 32 * j * ROWB);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                dma16(rsA, a_voff[j], c0 * 2, dst + 32 * j * ROWB);
+                dma16(rsB, b_voff[j], tap_sB + c0 * 2, dst + TILE_B + 32 * j * ROWB);
+            }
+        }
+        cur_c0 += TK;
+        if (cur_c0 >= p.Cs) {                                  // next tap (uniform branch)
+            cur_c0 = 0;
+            if (++cur_tb == p.tap_nb) { cur_tb = 0; ++cur_ta; }
+            enter_tap();
+        }
+    };
+
+    // ---- fragment addresses: row = wave row/col + 32 mb + l31, 8 consecutive k = chunk 2 ks + half -----------------
+    const int fsw = (l31 >> 1) & 7;
+    const char* fa_base = smem + (wrow + l31) * ROWB;
+    const char* fb_base = smem + TILE_B + (wcol + l31) * ROWB;
+    int so[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) so[ks] = ((2 * ks + half) ^ fsw) * 16;
+
+    bf16x8 fa[2][2], fb[2][2];                     // [k-step parity][32-row / 32-col block]
+    auto load_frag = [&](int stage, int ks, bf16x8 (&a)[2], bf16x8 (&b)[2]) {
+        const char* ab = fa_base + stage * STAGE_B;
+        const char* bb = fb_base + stage * STAGE_B;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) a[mb] = *reinterpret_cast<const bf16x8*>(ab + mb * 32 * ROWB + so[ks]);
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) b[nb] = *reinterpret_cast<const bf16x8*>(bb + nb * 32 * ROWB + so[ks]);
+    };
+    // One k-tile: the first fragments are requested right behind the barrier, the DMA of the NEXT tile (address
+    // arithmetic + 8 LDS-DMA instructions) is issued under their latency, the fragments of k-step ks+1 are read under the
+    // MFMAs of ks.  The stage the DMA fills was last read before the barrier every wave has passed.
+    auto ktile = [&](int stage, bool more) {
+        load_frag(stage, 0, fa[0], fb[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) issue(stage ^ 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks + 1 < 4) load_frag(stage, ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][mb], fb[ks & 1][nb], acc[mb][nb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+
+    if (kt_begin < kt_end) {
+        issue(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int kt = kt_begin;
+        // two k-tiles per trip so that the LDS stage is a compile-time constant
+        for (; kt + 1 < kt_end; kt += 2) {
+            ktile(0, true);
+            ktile(1, kt + 2 < kt_end);
+        }
+        if (kt < kt_end) ktile(0, false);
+    }
+
+    bg_epilogue(p, smem, acc, m0, n0, split, tid, wrow, wcol, l31, half);
+}
+
+__global__ __launch_bounds__(256, 2) void bg_kernel(const BGParams p) { bg_body(p); }
 
 struct BGMulti { BGParams q[4]; };
-template <bool DMA_BUF>
 __global__ __launch_bounds__(256, 2) void bg_multi_kernel(const BGMulti m) {
     const BGParams& p = m.q[blockIdx.y];
     if ((int)blockIdx.x >= p.mtiles * p.ntiles || (int)blockIdx.z >= p.nsplit) return;
-    bg_body<DMA_BUF>(p);
+    bg_body(p);
 }
 
 // split-K second pass: sum the fp32 partials in split order (deterministic), run the fused epilogue, write bf16
@@ -471,7 +484,7 @@ constexpr int WTILE_B = TK * WROWB;       // 16 KB
 constexpr int WSTAGE_B = 2 * WTILE_B;
 constexpr int WSMEM_BYTES = 2 * WSTAGE_B; // 64 KB = the [128][128] fp32 staging of the epilogue
 
-template <bool DMA_BUF>
+template <bool S1>   // S1: stride-1 SAME layer -- output pixel m pairs with input pixel m + const
 __global__ __launch_bounds__(256, 2) void bw_kernel(const BWParams p) {
     __shared__ __attribute__((aligned(16))) char smem[WSMEM_BYTES];
     const int tid = threadIdx.x;
@@ -502,37 +515,51 @@ __global__ __launch_bounds__(256, 2) void bw_kernel(const BWParams p) {
         acc[0][0][r] = 0.f; acc[0][1][r] = 0.f; acc[1][0][r] = 0.f; acc[1][1][r] = 0.f;
         accb[0][r] = 0.f; accb[1][r] = 0.f;
     }
-    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.X, p.x_bytes);
+    // S1: the x descriptor starts `padpix` pixels BEFORE the tensor so that the scalar pixel offset m + tap shift + padpix is
+    // never negative; lanes whose tap falls outside the image carry voffset = OOB and are never dereferenced
+    const int padpix = S1 ? p.pad_t * p.W + p.pad_l : 0;
+    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.X - (long)padpix * p.ldx, p.x_bytes + (unsigned)(padpix * p.ldx * 2));
     const __amdgpu_buffer_rsrc_t rsY = make_rsrc(p.DY, p.y_bytes);
 
     // ---- DMA roles: instruction j of this wave fills pixel rows 16j + 4*wave .. +3 (1 KB); lane -> (pixel, slot) ---
+    // dy: per-lane constant offset + SCALAR k-tile offset; pixels >= Npix lie beyond the descriptor (zeros for free).
+    // x (S1): likewise, plus the halo test on an incrementally advanced (oy, ox); other layers (stride 2, the upsampled
+    // 1x1) compute the source pixel per row.
     const int prow = 4 * wave + (lane >> 4);                   // (+ 16 j); (prow & 3) == lane >> 4
     const int gran = (lane & 15) ^ ((lane >> 4) << 2);         // the 8-channel granule this lane fetches
     const bool cx_ok = ci0 + gran * 8 < p.C, cy_ok = co0 + gran * 8 < p.K;
-    int s_oy[4], s_ox[4], s_n[4];
+    int s_oy[4], s_ox[4], s_n[4], y_voff[4], x_voff[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        const int m = kt_begin * TK + prow + 16 * j;
+        const int r = prow + 16 * j;
+        const int m = kt_begin * TK + r;
         const int n = fast_div(m, p.mul_howo, p.shr_howo);
         const int rem = m - n * p.HoWo;
         s_n[j] = n;
         s_oy[j] = fast_div(rem, p.mul_wo, p.shr_wo);
         s_ox[j] = rem - s_oy[j] * p.Wo;
+        y_voff[j] = cy_ok ? (r * p.ldy + co0 + gran * 8) * 2 : (int)OOB;
+        x_voff[j] = cx_ok ? (r * p.ldx + ci0 + gran * 8) * 2 : (int)OOB;
     }
     auto issue = [&](int kt, int stage) {
         char* dst = smem + stage * WSTAGE_B + (4 * wave) * WROWB;
         const int left = p.Npix - kt * TK;
+        const int sy = (kt * TK * p.ldy) * 2;
+        const int sx = S1 ? ((kt * TK + oyoff * p.W + oxoff + padpix) * p.ldx) * 2 : 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int r = prow + 16 * j;
-            const bool mok = r < left;
-            const int py = s_oy[j] * p.s + oyoff, px = s_ox[j] * p.s + oxoff;
-            const int iy = py >> p.shift, ix = px >> p.shift;
-            const bool ok = mok & cx_ok & (py >= 0) & (px >= 0) & (iy < p.H) & (ix < p.W);
-            const int xo = ((((s_n[j] * p.H + iy) * p.W + ix) * p.ldx) + ci0 + gran * 8) * 2;
-            const int yo = (((kt * TK + r) * p.ldy) + co0 + gran * 8) * 2;
-            dma16<DMA_BUF>(p.X, rsX, ok, xo, dst + 16 * j * WROWB);
-            dma16<DMA_BUF>(p.DY, rsY, mok & cy_ok, yo, dst + WTILE_B + 16 * j * WROWB);
+            if (S1) {
+                const bool ok = (r < left) & ((unsigned)(s_oy[j] + oyoff) < (unsigned)p.H) & ((unsigned)(s_ox[j] + oxoff) < (unsigned)p.W);
+                dma16(rsX, ok ? x_voff[j] : (int)OOB, sx, dst + 16 * j * WROWB);
+            } else {
+                const int py = s_oy[j] * p.s + oyoff, px = s_ox[j] * p.s + oxoff;
+                const int iy = py >> p.shift, ix = px >> p.shift;
+                const bool ok = (r < left) & cx_ok & (py >= 0) & (px >= 0) & (iy < p.H) & (ix < p.W);
+                const int xo = ((((s_n[j] * p.H + iy) * p.W + ix) * p.ldx) + ci0 + gran * 8) * 2;
+                dma16(rsX, ok ? xo : (int)OOB, 0, dst + 16 * j * WROWB);
+            }
+            dma16(rsY, y_voff[j], sy, dst + WTILE_B + 16 * j * WROWB);
             // advance this row's pixel by one k-tile (64 pixels)
             s_ox[j] += p.d64_ox;
             const bool c1 = s_ox[j] >= p.Wo;
@@ -540,7 +567,7 @@ __global__ __launch_bounds__(256, 2) void bw_kernel(const BWParams p) {
             s_oy[j] += p.d64_oy + (c1 ? 1 : 0);
             const bool c2 = s_oy[j] >= p.Ho;
             s_oy[j] -= c2 ? p.Ho : 0;
-            s_n[j] += p.d64_n + (c2 ? 1 : 0);
+            if (!S1) s_n[j] += p.d64_n + (c2 ? 1 : 0);
         }
     };
 
@@ -801,17 +828,56 @@ __global__ __launch_bounds__(256) void shadow_kernel(const float* __restrict__ w
     }
 }
 
+// All filter shadows of one parameter set in ONE launch: table row t = {src offset (floats from `base`), destination
+// offset (elements from plain_base / trans_base), taps, C, K, first tile}; block b handles 32 x 32 tile b.
+struct ShadowRow { long src, dst, taps, C, K, tile0; };
+__global__ __launch_bounds__(256) void shadow_multi_kernel(const float* __restrict__ base, bf16_t* __restrict__ plain_base,
+                                                           bf16_t* __restrict__ trans_base,
+                                                           const ShadowRow* __restrict__ table, int ntensors) {
+    __shared__ float t[32][33];
+    const int b = blockIdx.x;
+    int lo = 0, hi = ntensors - 1;                      // last row with tile0 <= b (uniform: scalar loads)
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) >> 1;
+        if (table[mid].tile0 <= b) lo = mid; else hi = mid - 1;
+    }
+    const ShadowRow r = table[lo];
+    const int C = (int)r.C, K = (int)r.K;
+    const int tk = (K + 31) >> 5, tc = (C + 31) >> 5;
+    int local = b - (int)r.tile0;
+    const int tap = local / (tk * tc);
+    local -= tap * tk * tc;
+    const int c0 = (local / tk) * 32, k0 = (local % tk) * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* wt = base + r.src + (long)tap * C * K;
+    bf16_t* plain = plain_base + r.dst + (long)tap * C * K;
+    bf16_t* trans = trans_base + r.dst + (long)tap * C * K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = c0 + ty + 8 * i, k = k0 + tx;
+        float v = 0.f;
+        if (c < C && k < K) {
+            v = wt[(long)c * K + k];
+            const __bf16 bb = (__bf16)v;
+            plain[(long)c * K + k] = __builtin_bit_cast(bf16_t, bb);
+        }
+        t[ty + 8 * i][tx] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int k = k0 + ty + 8 * i, c = c0 + tx;
+        if (c < C && k < K) {
+            const __bf16 bb = (__bf16)t[tx][ty + 8 * i];
+            trans[(long)k * C + c] = __builtin_bit_cast(bf16_t, bb);
+        }
+    }
+}
+
 // ================================================================================================
 // host side
 // ================================================================================================
-static int dma_mode() {          // 1: buffer_load ... lds (hardware bounds check), 0: global_load_lds + zero page
-    static int mode = -1;
-    if (mode < 0) {
-        const char* e = getenv("DPIG_BF16_DMA");
-        mode = (e && !strcmp(e, "flat")) ? 0 : 1;
-    }
-    return mode;
-}
+static int gtk() { return TK; }      // k-tile depth of fwd / dgrad
 
 static bool shape_ok(const DpigConvDesc* d) {
     return d->C % 8 == 0 && d->K % 8 == 0 && d->C >= 32 && d->K >= 32 && d->ldx % 8 == 0 && d->ldy % 8 == 0;
@@ -834,7 +900,7 @@ static int prepare_bg(BGParams& p, int nimg, long filter_elems) {
     if (!al || !ld) return fail(DPIG_EALIGN, "bf16 conv: pointers must be 16-byte aligned, channel counts / strides multiples of 8");
     p.mtiles = cdiv(p.M, TM);
     p.ntiles = cdiv(p.Ncols, TN);
-    p.cchunks = cdiv(p.Cs, TK);
+    p.cchunks = cdiv(p.Cs, gtk());
     p.ktiles = p.ntaps * p.cchunks;
     return DPIG_OK;
 }
@@ -847,8 +913,7 @@ static int launch_bg(BGParams& p, int nimg, long filter_elems, hipStream_t st) {
     int rc = prepare_bg(p, nimg, filter_elems);
     if (rc) return rc;
     dim3 grid(p.mtiles * p.ntiles, 1, p.nsplit), block(256);
-    if (dma_mode()) hipLaunchKernelGGL((bg_kernel<true>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((bg_kernel<false>), grid, block, 0, st, p);
+    hipLaunchKernelGGL(bg_kernel, grid, block, 0, st, p);
     rc = check_launch("bg_kernel");
     if (rc) return rc;
     if (p.nsplit > 1) {
@@ -869,8 +934,7 @@ static int launch_bg_multi(BGParams* q, int n, int nimg, long filter_elems, hipS
         m.q[i] = q[i];
     }
     dim3 grid(max_tiles, n, max_split), block(256);
-    if (dma_mode()) hipLaunchKernelGGL((bg_multi_kernel<true>), grid, block, 0, st, m);
-    else hipLaunchKernelGGL((bg_multi_kernel<false>), grid, block, 0, st, m);
+    hipLaunchKernelGGL(bg_multi_kernel, grid, block, 0, st, m);
     int rc = check_launch("bg_multi_kernel");
     if (rc) return rc;
     if (max_red > 0) {
@@ -880,7 +944,7 @@ static int launch_bg_multi(BGParams* q, int n, int nimg, long filter_elems, hipS
     return rc;
 }
 
-static void plan_s2(const DpigConvDesc* d, int pt, int pl, S2Plan* sp) { plan_dgrad_s2(d, pt, pl, sp, TK, kSplitPenalty); }
+static void plan_s2(const DpigConvDesc* d, int pt, int pl, S2Plan* sp) { plan_dgrad_s2(d, pt, pl, sp, gtk(), kSplitPenalty); }
 
 }  // namespace bfk
 }  // namespace dpig
@@ -900,13 +964,13 @@ extern "C" size_t dpig_conv2d_bf16_workspace_bytes(const DpigConvDesc* d, int wh
     if (resolve_desc(d, &pt, &pl, &Ho, &Wo) || !shape_ok(d)) return 0;
     if (which == 0) {
         const long M = d->upsample2x ? (long)d->N * d->H * d->W : (long)d->N * Ho * Wo;
-        Plan pln = plan_split(cdiv(M, TM) * cdiv(d->K, TN), d->R * d->S * cdiv(d->C, TK), d->split_k, TK, kSplitPenalty);
+        Plan pln = plan_split(cdiv(M, TM) * cdiv(d->K, TN), d->R * d->S * cdiv(d->C, gtk()), d->split_k, gtk(), kSplitPenalty);
         return pln.nsplit > 1 ? (size_t)pln.nsplit * M * d->K * sizeof(float) : 0;
     } else if (which == 1) {
         if (d->upsample2x || d->stride == 1) {
             const long M = (long)d->N * d->H * d->W;
             const int ntaps = d->upsample2x ? 4 : d->R * d->S;
-            Plan pln = plan_split(cdiv(M, TM) * cdiv(d->C, TN), ntaps * cdiv(d->K, TK), d->split_k, TK, kSplitPenalty);
+            Plan pln = plan_split(cdiv(M, TM) * cdiv(d->C, TN), ntaps * cdiv(d->K, gtk()), d->split_k, gtk(), kSplitPenalty);
             return pln.nsplit > 1 ? (size_t)pln.nsplit * M * d->C * sizeof(float) : 0;
         }
         S2Plan sp;
@@ -950,7 +1014,7 @@ extern "C" int dpig_conv2d_fwd_bf16(const DpigConvDesc* d, const uint16_t* x, co
     p.act = d->act; p.alpha = d->alpha;
     p.ntaps = d->R * d->S;
     p.tap_nb = d->S; p.oy0 = -pt; p.oys = 1; p.ox0 = -pl; p.oxs = 1; p.w0 = 0; p.wa = d->S; p.wb = 1;
-    Plan pln = plan_split(cdiv(p.M, TM) * cdiv(p.Ncols, TN), p.ntaps * cdiv(p.Cs, TK), d->split_k, TK, kSplitPenalty);
+    Plan pln = plan_split(cdiv(p.M, TM) * cdiv(p.Ncols, TN), p.ntaps * cdiv(p.Cs, gtk()), d->split_k, gtk(), kSplitPenalty);
     p.nsplit = pln.nsplit; p.tiles_per_split = pln.tiles_per_split;
     if (p.nsplit > 1 && (!ws || ws_bytes < (size_t)p.nsplit * p.M * p.Ncols * sizeof(float)))
         return fail(DPIG_ENOMEM, "bf16 conv fwd workspace too small: have %zu", ws_bytes);
@@ -1008,7 +1072,7 @@ extern "C" int dpig_conv2d_dgrad_bf16(const DpigConvDesc* d, const uint16_t* dy,
         }
         return launch_bg_multi(qs, sp.nc, d->N, felems, st);
     }
-    Plan pln = plan_split(cdiv(p.M, TM) * cdiv(p.Ncols, TN), p.ntaps * cdiv(p.Cs, TK), d->split_k, TK, kSplitPenalty);
+    Plan pln = plan_split(cdiv(p.M, TM) * cdiv(p.Ncols, TN), p.ntaps * cdiv(p.Cs, gtk()), d->split_k, gtk(), kSplitPenalty);
     p.nsplit = pln.nsplit; p.tiles_per_split = pln.tiles_per_split;
     if (p.nsplit > 1 && (!ws || ws_bytes < (size_t)p.nsplit * p.M * p.Ncols * sizeof(float)))
         return fail(DPIG_ENOMEM, "bf16 conv dgrad workspace too small: have %zu", ws_bytes);
@@ -1061,7 +1125,9 @@ extern "C" int dpig_conv2d_wgrad_bf16(const DpigConvDesc* d, const uint16_t* x, 
     p.d64_oy = (TK % p.HoWo) / p.Wo;
     p.d64_ox = (TK % p.HoWo) % p.Wo;
     dim3 grid(tiles, 1, p.nsplit), block(256);
-    if (dma_mode()) hipLaunchKernelGGL((bw_kernel<true>), grid, block, 0, st, p);
+    const bool s1 = !d->upsample2x && d->stride == 1 && Ho == d->H && Wo == d->W && pt >= 0 && pl >= 0 &&
+                    ((long)p.x_bytes + (long)(pt * d->W + pl) * d->ldx * 2 < 0x7fffffffL);
+    if (s1) hipLaunchKernelGGL((bw_kernel<true>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((bw_kernel<false>), grid, block, 0, st, p);
     rc = check_launch("bw_kernel");
     if (rc) return rc;
@@ -1199,4 +1265,13 @@ extern "C" int dpig_cvt_f32_to_bf16_pad(const float* in, int ldi, int cols_in, u
     hipLaunchKernelGGL(cvt_pad_kernel, dim3(blocks), dim3(256), 0, static_cast<hipStream_t>(stream), in, ldi, cols_in, out,
                        ldo, cols_out, (long)rows);
     return check_launch("cvt_f32_to_bf16_pad");
+}
+
+extern "C" int dpig_filter_shadow_bf16_multi(const float* base, uint16_t* plain_base, uint16_t* trans_base,
+                                             const int64_t* table_dev, int ntensors, int total_tiles, void* stream) {
+    if (!base || !plain_base || !trans_base || !table_dev || ntensors <= 0 || total_tiles <= 0)
+        return fail(DPIG_EINVAL, "filter shadow (multi): bad arguments");
+    hipLaunchKernelGGL(shadow_multi_kernel, dim3(total_tiles), dim3(256), 0, static_cast<hipStream_t>(stream), base,
+                       plain_base, trans_base, reinterpret_cast<const ShadowRow*>(table_dev), ntensors);
+    return check_launch("filter_shadow_bf16_multi");
 }

@@ -395,11 +395,16 @@ __device__ __forceinline__ bool crop_coord(float b1, float b2, int i, int crop, 
 }
 
 // forward: one thread per (box, crop pixel, channel quad) -- 16-byte loads/stores when C % 4 == 0
-template <int V>
-__global__ __launch_bounds__(256) void crop_resize_fwd_kernel(const float* __restrict__ img, int H, int W, int C,
+__device__ __forceinline__ void st_elem(float* a, long i, float v) { a[i] = v; }
+__device__ __forceinline__ void st_elem(unsigned short* a, long i, float v) {      // bf16, round-to-nearest-even
+    const __bf16 b = (__bf16)v;
+    a[i] = __builtin_bit_cast(unsigned short, b);
+}
+template <int V, typename T>
+__global__ __launch_bounds__(256) void crop_resize_fwd_kernel(const T* __restrict__ img, int H, int W, int C,
                                                               const float* __restrict__ boxes,
                                                               const int* __restrict__ box_ind, int nbox, int ch,
-                                                              int cw, float* __restrict__ out) {
+                                                              int cw, T* __restrict__ out) {
     const int CV = C / V;
     const long total = (long)nbox * ch * cw * CV;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -419,22 +424,22 @@ __global__ __launch_bounds__(256) void crop_resize_fwd_kernel(const float* __res
             const int ty = (int)floorf(in_y), by = (int)ceilf(in_y);
             const int lx = (int)floorf(in_x), rx = (int)ceilf(in_x);
             const float ly = in_y - ty, lxw = in_x - lx;
-            const float* base = img + (long)box_ind[b] * H * W * C + c;
-            const float* ptl = base + ((long)ty * W + lx) * C;
-            const float* ptr_ = base + ((long)ty * W + rx) * C;
-            const float* pbl = base + ((long)by * W + lx) * C;
-            const float* pbr = base + ((long)by * W + rx) * C;
+            const T* base = img + (long)box_ind[b] * H * W * C + c;
+            const T* ptl = base + ((long)ty * W + lx) * C;
+            const T* ptr_ = base + ((long)ty * W + rx) * C;
+            const T* pbl = base + ((long)by * W + lx) * C;
+            const T* pbr = base + ((long)by * W + rx) * C;
 #pragma unroll
             for (int e = 0; e < V; ++e) {
-                const float tl = ptl[e], tr = ptr_[e], bl = pbl[e], br = pbr[e];
+                const float tl = ld_elem(ptl, e), tr = ld_elem(ptr_, e), bl = ld_elem(pbl, e), br = ld_elem(pbr, e);
                 const float top = tl + (tr - tl) * lxw;
                 const float bot = bl + (br - bl) * lxw;
                 v[e] = top + (bot - top) * ly;
             }
         }
-        float* o = out + ((((long)b * ch + ii) * cw + j) * C + c);
+        T* o = out + ((((long)b * ch + ii) * cw + j) * C + c);
 #pragma unroll
-        for (int e = 0; e < V; ++e) o[e] = v[e];
+        for (int e = 0; e < V; ++e) st_elem(o, e, v[e]);
     }
 }
 
@@ -457,8 +462,8 @@ __device__ __forceinline__ void crop_range(float b1, float b2, int crop, int siz
     *lo = l < 0 ? 0 : l;
     *hi = h > crop - 1 ? crop - 1 : h;
 }
-template <int V>
-__global__ __launch_bounds__(256) void crop_bwd_x_kernel(const float* __restrict__ dout, int W, int C,
+template <int V, typename T>
+__global__ __launch_bounds__(256) void crop_bwd_x_kernel(const T* __restrict__ dout, int W, int C,
                                                          const float* __restrict__ boxes, int nbox, int ch, int cw,
                                                          float* __restrict__ tmp) {
     const int CV = C / V;
@@ -474,14 +479,14 @@ __global__ __launch_bounds__(256) void crop_bwd_x_kernel(const float* __restrict
         float acc[V];
 #pragma unroll
         for (int e = 0; e < V; ++e) acc[e] = 0.f;
-        const float* g = dout + (t * cw) * C + c;
+        const T* g = dout + (t * cw) * C + c;
         for (int j = jlo; j <= jhi; ++j) {
             float in_x;
             if (!crop_coord(x1, x2, j, cw, W, &in_x)) continue;
             const float w = 1.f - fabsf(in_x - (float)x);
             if (w <= 0.f) continue;
 #pragma unroll
-            for (int e = 0; e < V; ++e) acc[e] += w * g[(long)j * C + e];
+            for (int e = 0; e < V; ++e) acc[e] += w * ld_elem(g, (long)j * C + e);
         }
         float* o = tmp + (t * W + x) * C + c;
 #pragma unroll
@@ -490,11 +495,11 @@ __global__ __launch_bounds__(256) void crop_bwd_x_kernel(const float* __restrict
 }
 // pass Y: one thread per (image pixel, channel quad).  The boxes of the block's image(s) are first marked in an
 // LDS bitmask (atomicOr: order-free), then visited in increasing box order by every thread.
-template <int V>
+template <int V, typename T>
 __global__ __launch_bounds__(256) void crop_bwd_y_kernel(const float* __restrict__ tmp, int N, int H, int W, int C,
                                                          const float* __restrict__ boxes,
                                                          const int* __restrict__ box_ind, int nbox, int ch,
-                                                         float* __restrict__ dimg) {
+                                                         T* __restrict__ dimg) {
     __shared__ unsigned s_mask[32];
     const int CV = C / V;
     const long per_img = (long)H * W * CV;
@@ -545,9 +550,9 @@ __global__ __launch_bounds__(256) void crop_bwd_y_kernel(const float* __restrict
         __syncthreads();
     }
     if (live) {
-        float* o = dimg + (((long)n * H + y) * W + x) * C + c;
+        T* o = dimg + (((long)n * H + y) * W + x) * C + c;
 #pragma unroll
-        for (int e = 0; e < V; ++e) o[e] = acc[e];
+        for (int e = 0; e < V; ++e) st_elem(o, e, acc[e]);
     }
 }
 
@@ -1144,25 +1149,34 @@ extern "C" int dpig_linear_wgrad(const float* x, const float* dy, float* dw, flo
     return dpig_conv2d_wgrad(&d, x, dy, dw, beta, nullptr, 0.f, ws, ws_bytes, stream);
 }
 
-extern "C" int dpig_crop_resize_fwd(const float* img, int N, int H, int W, int C, const float* boxes,
-                                    const int32_t* box_ind, int nbox, int ch, int cw, float* out, void* stream) {
+template <typename T>
+static int crop_resize_fwd_impl(const T* img, int N, int H, int W, int C, const float* boxes, const int32_t* box_ind,
+                                int nbox, int ch, int cw, T* out, void* stream) {
     if (!img || !boxes || !box_ind || !out) return fail(DPIG_EINVAL, "crop_resize: null pointer");
     if (N <= 0 || nbox <= 0 || ch <= 0 || cw <= 0) return fail(DPIG_EINVAL, "crop_resize: empty");
     if (C % 4 == 0 && aligned16(img) && aligned16(out))
-        hipLaunchKernelGGL((crop_resize_fwd_kernel<4>), dim3(grid_for((long)nbox * ch * cw * (C / 4))), dim3(256), 0,
+        hipLaunchKernelGGL((crop_resize_fwd_kernel<4, T>), dim3(grid_for((long)nbox * ch * cw * (C / 4))), dim3(256), 0,
                            static_cast<hipStream_t>(stream), img, H, W, C, boxes, box_ind, nbox, ch, cw, out);
     else
-        hipLaunchKernelGGL((crop_resize_fwd_kernel<1>), dim3(grid_for((long)nbox * ch * cw * C)), dim3(256), 0,
+        hipLaunchKernelGGL((crop_resize_fwd_kernel<1, T>), dim3(grid_for((long)nbox * ch * cw * C)), dim3(256), 0,
                            static_cast<hipStream_t>(stream), img, H, W, C, boxes, box_ind, nbox, ch, cw, out);
     return check_launch("crop_resize_fwd");
+}
+extern "C" int dpig_crop_resize_fwd(const float* img, int N, int H, int W, int C, const float* boxes,
+                                    const int32_t* box_ind, int nbox, int ch, int cw, float* out, void* stream) {
+    return crop_resize_fwd_impl<float>(img, N, H, W, C, boxes, box_ind, nbox, ch, cw, out, stream);
+}
+extern "C" int dpig_crop_resize_fwd_bf16(const uint16_t* img, int N, int H, int W, int C, const float* boxes,
+                                         const int32_t* box_ind, int nbox, int ch, int cw, uint16_t* out, void* stream) {
+    return crop_resize_fwd_impl<unsigned short>(img, N, H, W, C, boxes, box_ind, nbox, ch, cw, out, stream);
 }
 extern "C" size_t dpig_crop_resize_bwd_workspace_bytes(int W, int C, int nbox, int ch) {
     if (W <= 0 || C <= 0 || nbox <= 0 || ch <= 0) return 0;
     return (size_t)nbox * ch * W * C * sizeof(float);
 }
-extern "C" int dpig_crop_resize_bwd(const float* dout, int N, int H, int W, int C, const float* boxes,
-                                    const int32_t* box_ind, int nbox, int ch, int cw, float* dimg, void* ws,
-                                    size_t ws_bytes, void* stream) {
+template <typename T>
+static int crop_resize_bwd_impl(const T* dout, int N, int H, int W, int C, const float* boxes, const int32_t* box_ind,
+                                int nbox, int ch, int cw, T* dimg, void* ws, size_t ws_bytes, void* stream) {
     if (!dout || !boxes || !box_ind || !dimg) return fail(DPIG_EINVAL, "crop_resize: null pointer");
     if (N <= 0 || nbox <= 0 || ch <= 0 || cw <= 0) return fail(DPIG_EINVAL, "crop_resize: empty");
     if (!ws || ws_bytes < dpig_crop_resize_bwd_workspace_bytes(W, C, nbox, ch))
@@ -1175,13 +1189,23 @@ extern "C" int dpig_crop_resize_bwd(const float* dout, int N, int H, int W, int 
     if (ny > 256L * 0x7fffffffL) return fail(DPIG_EINVAL, "crop_resize_bwd: image too large");
     const dim3 gy((unsigned)((ny + 255) / 256));
     if (v4) {
-        hipLaunchKernelGGL((crop_bwd_x_kernel<4>), dim3(grid_for(nx)), dim3(256), 0, st, dout, W, C, boxes, nbox, ch, cw, tmp);
-        hipLaunchKernelGGL((crop_bwd_y_kernel<4>), gy, dim3(256), 0, st, tmp, N, H, W, C, boxes, box_ind, nbox, ch, dimg);
+        hipLaunchKernelGGL((crop_bwd_x_kernel<4, T>), dim3(grid_for(nx)), dim3(256), 0, st, dout, W, C, boxes, nbox, ch, cw, tmp);
+        hipLaunchKernelGGL((crop_bwd_y_kernel<4, T>), gy, dim3(256), 0, st, tmp, N, H, W, C, boxes, box_ind, nbox, ch, dimg);
     } else {
-        hipLaunchKernelGGL((crop_bwd_x_kernel<1>), dim3(grid_for(nx)), dim3(256), 0, st, dout, W, C, boxes, nbox, ch, cw, tmp);
-        hipLaunchKernelGGL((crop_bwd_y_kernel<1>), gy, dim3(256), 0, st, tmp, N, H, W, C, boxes, box_ind, nbox, ch, dimg);
+        hipLaunchKernelGGL((crop_bwd_x_kernel<1, T>), dim3(grid_for(nx)), dim3(256), 0, st, dout, W, C, boxes, nbox, ch, cw, tmp);
+        hipLaunchKernelGGL((crop_bwd_y_kernel<1, T>), gy, dim3(256), 0, st, tmp, N, H, W, C, boxes, box_ind, nbox, ch, dimg);
     }
     return check_launch("crop_resize_bwd");
+}
+extern "C" int dpig_crop_resize_bwd(const float* dout, int N, int H, int W, int C, const float* boxes,
+                                    const int32_t* box_ind, int nbox, int ch, int cw, float* dimg, void* ws,
+                                    size_t ws_bytes, void* stream) {
+    return crop_resize_bwd_impl<float>(dout, N, H, W, C, boxes, box_ind, nbox, ch, cw, dimg, ws, ws_bytes, stream);
+}
+extern "C" int dpig_crop_resize_bwd_bf16(const uint16_t* dout, int N, int H, int W, int C, const float* boxes,
+                                         const int32_t* box_ind, int nbox, int ch, int cw, uint16_t* dimg, void* ws,
+                                         size_t ws_bytes, void* stream) {
+    return crop_resize_bwd_impl<unsigned short>(dout, N, H, W, C, boxes, box_ind, nbox, ch, cw, dimg, ws, ws_bytes, stream);
 }
 
 extern "C" int dpig_pose_points(const float* rcv, int B, int K, int H, int W, int is_normalized, float* out, int ldo,

@@ -180,25 +180,44 @@ def filter_shadows(w, want_plain=True, want_t=True):
 class FilterShadows(object):
     """Persistent bf16 shadows (plain HWIO + per-tap transposed) of every conv filter in `params` that the bf16 kernels
     accept, in ONE allocation; attached to the parameters as `_dpig_shadow`.  `refresh()` re-derives them from the fp32
-    masters (one small launch per filter; call it after anything that changes the weights)."""
+    masters (call it after anything that changes the weights): one launch for the whole set when the masters are slices
+    of one flat buffer (`flat`, trainer.FlatParams), else one small launch per filter."""
 
-    def __init__(self, params):
+    def __init__(self, params, flat=None):
         self.params = [p for p in params if p.dim() == 4 and _bf16_conv_ok(p.shape[2], p.shape[3])]
         total = sum((p.numel() + 7) // 8 * 8 for p in self.params)
         self.numel = total
+        self.flat = None
         if not self.params:
             return
         dev = self.params[0].device
         self.buf = torch.empty(2 * total, dtype=BF16, device=dev)
-        off = 0
+        off, rows, tiles = 0, [], 0
         for p in self.params:
             R, S, C, K = p.shape
             n = p.numel()
             p._dpig_shadow = (self.buf[off:off + n].view(R, S, C, K), self.buf[total + off:total + off + n].view(R, S, K, C))
+            if flat is not None:
+                src = (p.data_ptr() - flat.data_ptr()) // 4
+                if not (0 <= src and src + n <= flat.numel() and p.is_contiguous()):
+                    flat = None
+                else:
+                    rows.append([src, off, R * S, C, K, tiles])
+                    tiles += R * S * ((C + 31) // 32) * ((K + 31) // 32)
             off += (n + 7) // 8 * 8
+        if flat is not None:
+            self.flat, self.ntiles = flat, tiles
+            self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
         self.refresh()
 
     def refresh(self):
+        if not self.params:
+            return
+        if self.flat is not None:
+            check(lib().dpig_filter_shadow_bf16_multi(ptr(self.flat), ptr(self.buf), ptr(self.buf) + 2 * self.numel,
+                                                      ptr(self.table), len(self.params), self.ntiles, stream_ptr()),
+                  "filter_shadow_multi")
+            return
         for p in self.params:
             plain, trans = p._dpig_shadow
             R, S, C, K = p.shape
@@ -817,33 +836,30 @@ def linear_wgrad(x, dy, out=None, beta=0.0):
 
 
 def crop_resize_fwd(img, boxes, box_ind, ch, cw):
-    if img.dtype == BF16:
-        return _like_input(crop_resize_fwd(to_f32(img), boxes, box_ind, ch, cw), img)
-    _require_gpu(img)
+    _require_dev(img)
     img = img.contiguous()
     N, H, W, C = img.shape
     boxes = boxes.contiguous().float()
     box_ind = box_ind.contiguous().to(torch.int32)
     nb = boxes.shape[0]
-    out = torch.empty((nb, ch, cw, C), dtype=torch.float32, device=img.device)
-    check(lib().dpig_crop_resize_fwd(ptr(img), N, H, W, C, ptr(boxes), ptr(box_ind), nb, ch, cw, ptr(out),
-                                     stream_ptr()), "crop_resize_fwd")
+    out = torch.empty((nb, ch, cw, C), dtype=img.dtype, device=img.device)
+    fn = lib().dpig_crop_resize_fwd_bf16 if img.dtype == BF16 else lib().dpig_crop_resize_fwd
+    check(fn(ptr(img), N, H, W, C, ptr(boxes), ptr(box_ind), nb, ch, cw, ptr(out), stream_ptr()), "crop_resize_fwd")
     return out
 
 
 def crop_resize_bwd(dout, boxes, box_ind, img_shape):
-    if dout.dtype == BF16:
-        return _like_input(crop_resize_bwd(to_f32(dout), boxes, box_ind, img_shape), dout)
-    _require_gpu(dout)
+    _require_dev(dout)
     dout = dout.contiguous()
     N, H, W, C = img_shape
     boxes = boxes.contiguous().float()
     box_ind = box_ind.contiguous().to(torch.int32)
     nb, ch, cw, _ = dout.shape
-    dimg = torch.empty(tuple(img_shape), dtype=torch.float32, device=dout.device)
+    dimg = torch.empty(tuple(img_shape), dtype=dout.dtype, device=dout.device)
     wsb, wsn = workspace.get(lib().dpig_crop_resize_bwd_workspace_bytes(W, C, nb, ch), dout.device)
-    check(lib().dpig_crop_resize_bwd(ptr(dout), N, H, W, C, ptr(boxes), ptr(box_ind), nb, ch, cw, ptr(dimg),
-                                     ptr(wsb), wsn, stream_ptr()), "crop_resize_bwd")
+    fn = lib().dpig_crop_resize_bwd_bf16 if dout.dtype == BF16 else lib().dpig_crop_resize_bwd
+    check(fn(ptr(dout), N, H, W, C, ptr(boxes), ptr(box_ind), nb, ch, cw, ptr(dimg), ptr(wsb), wsn, stream_ptr()),
+          "crop_resize_bwd")
     return dimg
 
 

@@ -54,7 +54,7 @@ class FlatParams(object):
     def enable_bf16_shadows(self):
         """'bf16' mode: persistent bf16 shadows of the conv filters (hip_ops.FilterShadows), refreshed after every
         optimizer step from the fp32 masters this object owns."""
-        self.shadows = H.FilterShadows(self.params)
+        self.shadows = H.FilterShadows(self.params, flat=self.flat)
 
     def refresh_shadows(self):
         sh = getattr(self, "shadows", None)

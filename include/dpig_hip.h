@@ -171,6 +171,11 @@ int dpig_act_bwd_bf16(const uint16_t* dy, int lddy, const uint16_t* y, int ldy, 
  * (either output may be NULL); refreshed after every optimizer step. */
 int dpig_filter_shadow_bf16(const float* w, uint16_t* plain, uint16_t* transposed, int taps, int C, int K,
                             void* stream);
+/* The shadows of MANY filters in one launch.  table_dev: device array of ntensors rows of six int64
+ * {src offset in floats from `base`, destination offset in elements from plain_base / trans_base, taps, C, K, first
+ * tile}, rows ordered by first tile; tiles are 32 x 32 (per filter taps * ceil(C/32) * ceil(K/32)), total_tiles their sum. */
+int dpig_filter_shadow_bf16_multi(const float* base, uint16_t* plain_base, uint16_t* trans_base,
+                                  const int64_t* table_dev, int ntensors, int total_tiles, void* stream);
 
 /* ---- elementwise / reductions over a [rows, cols] fp32 matrix with row stride ld ------------- */
 
@@ -265,6 +270,14 @@ size_t dpig_crop_resize_bwd_workspace_bytes(int W, int C, int nbox, int ch);
 int dpig_crop_resize_bwd(const float* dout, int N, int H, int W, int C, const float* boxes,
                          const int32_t* box_ind, int nbox, int ch, int cw, float* dimg, void* ws,
                          size_t ws_bytes, void* stream);
+
+/* The same two ops on bf16 tensors ('bf16' storage mode): bilinear weights and sums in fp32 (the separable backward's
+ * intermediate stays fp32), inputs / results bf16. */
+int dpig_crop_resize_fwd_bf16(const uint16_t* img, int N, int H, int W, int C, const float* boxes,
+                              const int32_t* box_ind, int nbox, int ch, int cw, uint16_t* out, void* stream);
+int dpig_crop_resize_bwd_bf16(const uint16_t* dout, int N, int H, int W, int C, const float* boxes,
+                              const int32_t* box_ind, int nbox, int ch, int cw, uint16_t* dimg, void* ws,
+                              size_t ws_bytes, void* stream);
 
 /* ---- input pipeline: pose target maps (utils.py:237-318) --------------------------------
  * rcv: [B, K, 3] = (row, col, visibility) per keypoint, rows/cols in [-1,1] if is_normalized.  out: [B,H,W,K], ld = ldo.

@@ -19,7 +19,8 @@ for k, a in agg.items():
     gui = a["GRBM_GUI_ACTIVE"] / 8.0
     wc = max(a["SQ_WAVE_CYCLES"], 1.0)
     rows.append((a["SQ_VALU_MFMA_BUSY_CYCLES"], short(k), cnt[k], a["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0 / gui,
-                 a["SQ_ACTIVE_INST_ANY"] / wc, a["SQ_WAIT_INST_ANY"] / wc, a["SQ_WAIT_ANY"] / wc))
+                 a["SQ_ACTIVE_INST_ANY"] / wc, a["SQ_WAIT_INST_ANY"] / wc, a["SQ_WAIT_ANY"] / wc,
+                 a.get("SQ_WAIT_INST_LDS", 0.0) / wc, a.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(a.get("SQ_LDS_IDX_ACTIVE", 0.0), 1.0)))
 rows.sort(reverse=True)
 with open(os.path.join(root, "profiles", tag + "_pmc_mfma.md"), "w") as f:
     f.write("# Matrix-pipe utilisation from rocprofv3 PMC counters: %s\n\n" % tag)
@@ -28,7 +29,7 @@ with open(os.path.join(root, "profiles", tag + "_pmc_mfma.md"), "w") as f:
             "(own pass, no other trace domains).  MfmaUtil = MFMA busy cycles / (1024 SIMDs x shader cycles per XCD); the wave-cycle\n"
             "split says where a resident wave spends its time (issuing, stalled at issue = mostly behind the matrix pipe, parked on\n"
             "s_waitcnt / s_barrier).\n\n")
-    f.write("| kernel | launches | MfmaUtil | wave cycles: issuing | issue-stalled | parked |\n|---|---|---|---|---|---|\n")
-    for _, k, n, u, ai, wi, wa in rows:
-        f.write("| `%s` | %d | %.1f %% | %.1f %% | %.1f %% | %.1f %% |\n" % (k, n, 100 * u, 100 * ai, 100 * wi, 100 * wa))
+    f.write("| kernel | launches | MfmaUtil | wave cycles: issuing | issue-stalled | parked | (LDS-issue-stalled) | LDS conflict cycles / LDS active |\n|---|---|---|---|---|---|---|---|\n")
+    for _, k, n, u, ai, wi, wa, wl, bc in rows:
+        f.write("| `%s` | %d | %.1f %% | %.1f %% | %.1f %% | %.1f %% | %.1f %% | %.2f |\n" % (k, n, 100 * u, 100 * ai, 100 * wi, 100 * wa, 100 * wl, bc))
 print("ok", len(rows))

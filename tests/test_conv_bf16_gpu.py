@@ -245,6 +245,32 @@ def test_thin_layers(dev, layer):
         H.set_compute("f32")
 
 
+def test_crop_resize_and_border_sums_on_bf16_tensors(dev):
+    """tf.image.crop_and_resize (models.py:415) forward / image gradient and the border-class sums with bf16 storage."""
+    import dpig_amd.hip_ops as H
+    from oracle import ops as O
+    N, Hh, W, C = 2, 32, 16, 16
+    img = _rand((N, Hh, W, C), 1)
+    boxes = torch.tensor([[0.1, 0.2, 0.8, 0.9], [0.0, 0.0, 1.0, 1.0], [-0.2, 0.3, 0.6, 1.2], [0.5, 0.5, 0.5, 0.5]], dtype=torch.float64)
+    ind = torch.tensor([0, 1, 1, 0], dtype=torch.int64)
+    xr = _r(img).requires_grad_(True)
+    ref = O.crop_and_resize(xr, boxes, ind, 12, 12)
+    got = H.crop_resize_fwd(img.float().to(dev).to(BF), boxes.float().to(dev), ind.to(dev), 12, 12)
+    _close_bf16(got, ref.detach())
+    dout = _rand(tuple(ref.shape), 2)
+    ref.backward(_r(dout))
+    dimg = H.crop_resize_bwd(dout.float().to(dev).to(BF), boxes.float().to(dev), ind.to(dev), (N, Hh, W, C))
+    _close_bf16(dimg, xr.grad)
+    z = _rand((N, Hh, W, 72), 3)
+    s32 = H.border_class_sum(_r(z).float().to(dev))
+    sbf = H.border_class_sum(z.float().to(dev).to(BF))
+    assert sbf.dtype == torch.float32
+    _close_f32(sbf, s32.double().cpu(), 1e-6)
+    xp = _rand((N, Hh, W, 18), 4).float()
+    pad = H.pad_channels_bf16(xp.to(dev), 32)
+    assert torch.equal(pad[..., :18].cpu(), xp.to(BF)) and bool((pad[..., 18:] == 0).all())
+
+
 def test_bad_arguments(dev):
     import ctypes
     from dpig_amd import _lib
