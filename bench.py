@@ -91,6 +91,35 @@ def cpu_baseline(target_seconds=20.0):
                       "optimizer) at bs=%d on %d threads of %d logical CPUs: %.1f s" % (reps, B, cores, ncpu, t)}
 
 
+INFO_RUNS = [   # (key, BASELINE config it informs, bench.py arguments)
+    ("df256_bf16", "configs[3]: DeepFashion 256x256 (trainer_256.py path) bs=8 bf16 on 1 MI355X",
+     ["--workload", "df256", "--dtype", "bf16", "--steps", "8", "--warmup", "2"]),
+    ("market128_stage2_bf16", "configs[2]: Market-1501 stage-II adversarial sampling bs=64 bf16 (this GPU's share of the job)",
+     ["--workload", "market128-stage2", "--dtype", "bf16", "--steps", "3", "--warmup", "1"]),
+    ("market128_bf16", "configs[1]'s graph in bf16", ["--workload", "market128", "--dtype", "bf16", "--steps", "10", "--warmup", "2"]),
+    ("market128_wgan_gp_f32", "configs[1] with MODE='wgan-gp' (LayerNorm critic, gradient penalty, 5 critic iterations per step)",
+     ["--workload", "market128-wgan-gp", "--steps", "5", "--warmup", "2"]),
+]
+
+
+def info_lines():
+    """The other BASELINE configurations that fit one GPU, each measured by this same script in a sub-process (fresh
+    parameter registry, same kernels) AFTER the headline's timed region: {key: {value, unit, ms_per_step, config, informs}}."""
+    import subprocess
+    out = {}
+    for key, informs, extra in INFO_RUNS:
+        try:
+            r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-info-lines"] + extra,
+                               capture_output=True, text=True, timeout=300)
+            js = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            d = json.loads(js[-1])
+            out[key] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"],
+                        "steps": d["steps"], "warmup": d["warmup"], "config": d["config"], "informs": informs}
+        except Exception as e:          # an information line must never take the headline down
+            out[key] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -100,9 +129,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly (no hipGraph replay)")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16"],
-                    help="matrix-pipe arithmetic of the conv GEMMs; bf16 (fp32 tensors and accumulation) is an information "
-                         "line: the BASELINE metric is quoted at fp32")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "bf16c"],
+                    help="f32 = the BASELINE metric's arithmetic.  bf16 (information lines; BASELINE configs 3-5): activations, "
+                         "their gradients and the filter shadows stored as bf16, bf16 matrix pipe, fp32 accumulation / master "
+                         "weights / gradients / optimizer.  bf16c: round 1's intermediate mode (fp32 tensors, bf16 pipe)")
+    ap.add_argument("--no-info-lines", action="store_true",
+                    help="headline run only: skip the information lines (df256 / stage-II / Market in bf16, Market wgan-gp) that "
+                         "are measured in sub-processes after the headline and embedded under `info_lines`")
     ap.add_argument("--host-input", nargs="?", const="prefetch", default=None, choices=["prefetch", "serial", "keypoints", "keypoints-serial", "keypoints-packed", "packed"],
                     help="information line: both batches start every step in pinned HOST memory, so the timed region "
                          "includes their PCIe upload (the BASELINE value is quoted with inputs resident in HBM). "
@@ -275,12 +308,14 @@ def main():
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "%s, bs=%d per GPU, %s" % (wl_desc, B, "fp32" if args.dtype == "f32" else "bf16 matrix pipe on fp32 tensors"),
+            "config": {"workload": "%s, bs=%d per GPU, %s" % (wl_desc, B, {"f32": "fp32", "bf16": "bf16 storage (activations, their gradients, filter shadows) + bf16 matrix pipe; fp32 accumulation, master weights, gradients and optimizer", "bf16c": "bf16 matrix pipe on fp32 tensors"}[args.dtype]),
                        "global_batch": world * B, "parallelism": "dp%d" % world},
             "achieved_alg_tflops": round(ALG_GFLOP_PER_IMG * value / 1e3, 2) if headline else None,
             "losses": {k: float(v) for k, v in out.items() if hasattr(v, "numel") and v.numel() == 1},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if headline and world == 1 and not args.no_info_lines:
+            line["info_lines"] = info_lines()
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

@@ -96,3 +96,56 @@ def test_bf16_mode_adjointness_full_size(dev):
     assert abs(a - b) <= 2e-6 * scale and abs(a - c) <= 2e-6 * scale, (a, b, c, scale)
     yf = H.conv2d_fwd(x, w, None)                    # fp32 pipe on the same (bf16-representable) operands: same products
     assert float((y - yf).abs().max()) <= 2e-5 * float(yf.abs().max())
+
+
+# BASELINE configs[3] / [4] (DeepFashion 256x256, B=8) and configs[2] (Market stage-II, B=64: 448 ROI crops) layer shapes
+BF16_LAYERS = [
+    ("df dec4 3x3 256ch @256x256", 8, 256, 256, 256, 256, 3, 1, False),
+    ("df E.res 3x3 128ch @256x256", 8, 256, 256, 128, 128, 3, 1, False),
+    ("df dec3 3x3 512ch @128x128", 8, 128, 128, 512, 512, 3, 1, False),
+    ("df roi tower N=56 64x64x128", 56, 64, 64, 128, 128, 3, 1, False),
+    ("df roi down 3x3 s2", 56, 64, 64, 128, 256, 3, 2, False),
+    ("df dec up 1x1 on 2x-upsampled", 8, 128, 128, 512, 256, 1, 1, True),
+    ("df critic 5x5 s2 on the [x;G] pair", 16, 128, 128, 64, 128, 5, 2, False),
+    ("stage-II roi tower N=448 48x48x128", 448, 48, 48, 128, 128, 3, 1, False),
+    ("stage-II roi tower N=448 12x12x384", 448, 12, 12, 384, 384, 3, 1, False),
+]
+
+
+@pytest.mark.parametrize("layer", BF16_LAYERS, ids=[l[0] for l in BF16_LAYERS])
+def test_bf16_storage_full_size_layers(dev, layer):
+    """The bf16-STORAGE kernels (dpig_conv2d_*_bf16) at the sizes of BASELINE configs 2-4, where the fp64 oracle is too
+    slow: products of bf16 numbers are exact in fp32 and both families accumulate in fp32, so on the same bf16-valued
+    operands the bf16 kernels must reproduce the (oracle-verified) fp32 kernels -- the filter gradient to fp32 round-off,
+    activations to the final rounding to bf16 -- and fwd / dgrad / wgrad must still be one bilinear form.  Bit-for-bit
+    repeatable."""
+    import dpig_amd.hip_ops as H
+    _, N, Hh, W, C, K, k, s, up = layer
+    BF = torch.bfloat16
+    g = torch.Generator(device=dev).manual_seed(4)
+    xb = torch.randn(N, Hh, W, C, device=dev, generator=g).to(BF)
+    w = (torch.randn(k, k, C, K, device=dev, generator=g) * 0.05).to(BF).float()      # bf16-representable master
+    yb = H.conv2d_fwd(xb, w, None, stride=s, upsample2x=up)
+    assert yb.dtype == BF
+    dyb = torch.randn(yb.shape, device=dev, generator=g).to(BF)
+    dxb = H.conv2d_dgrad(dyb, w, (N, Hh, W, C), stride=s, upsample2x=up)
+    dw = H.conv2d_wgrad(xb, dyb, (k, k, C, K), stride=s, upsample2x=up)
+    assert dxb.dtype == BF and dw.dtype == torch.float32
+    x32, dy32 = xb.float(), dyb.float()
+    y32 = H.conv2d_fwd(x32, w, None, stride=s, upsample2x=up)
+    dx32 = H.conv2d_dgrad(dy32, w, (N, Hh, W, C), stride=s, upsample2x=up)
+    dw32 = H.conv2d_wgrad(x32, dy32, (k, k, C, K), stride=s, upsample2x=up)
+
+    def close_bf16(got, ref):
+        err = (got.float() - ref).abs()
+        bound = ref.abs() * 2.0 ** -8 + 2e-5 * float(ref.abs().max())
+        assert not bool((err > bound).any()), float((err - bound).max())
+    close_bf16(yb, y32)
+    close_bf16(dxb, dx32)
+    assert float((dw - dw32).abs().max()) <= 2e-5 * float(dw32.abs().max())
+    a, b, c = _dot(yb, dyb), _dot(xb, dxb), _dot(w, dw)
+    scale = (float((yb.double() ** 2).sum()) * float((dyb.double() ** 2).sum())) ** 0.5
+    assert abs(a - c) <= 2e-5 * scale and abs(b - c) <= 2e-5 * scale, (a, b, c, scale)
+    assert torch.equal(H.conv2d_fwd(xb, w, None, stride=s, upsample2x=up), yb)
+    assert torch.equal(H.conv2d_dgrad(dyb, w, (N, Hh, W, C), stride=s, upsample2x=up), dxb)
+    assert torch.equal(H.conv2d_wgrad(xb, dyb, (k, k, C, K), stride=s, upsample2x=up), dw)
