@@ -98,6 +98,7 @@ SYMBOLS = {
     "dpig_rmsprop_step": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _vp]),
     "dpig_clip": (_i, [_vp, _i64, _f, _f, _vp]),
     "dpig_sce_mean": (_i, [_vp, _i, _f, _vp, _vp, _f, _vp]),
+    "dpig_logit_mean": (_i, [_vp, _i, _i, _f, _vp, _vp, _f, _vp]),
     "dpig_l1_workspace_bytes": (_sz, [_i64]),
     "dpig_l1_mean": (_i, [_vp, _vp, _i64, _vp, _vp, _f, _vp, _sz, _vp]),
 }
@@ -142,6 +143,13 @@ class _Workspace:
 
     def __init__(self):
         self.buf = {}
+        self.pinned = False      # a captured hipGraph has the buffer's address baked in (split-K partials, ...)
+        self.retired = []
+
+    def pin(self):
+        """Called once a graph has been captured: from now on a buffer that has to grow is RETIRED, not freed -- graph
+        replays keep writing to the old address, which must not be handed to anybody else by the caching allocator."""
+        self.pinned = True
 
     def get(self, nbytes, device):
         if nbytes == 0:
@@ -149,6 +157,8 @@ class _Workspace:
         key = (device.type, device.index)
         b = self.buf.get(key)
         if b is None or b.numel() < nbytes:
+            if b is not None and self.pinned:
+                self.retired.append(b)
             # round up generously: reallocation is a sync point for the caching allocator
             size = max(int(nbytes * 1.25), 64 << 20)
             b = torch.empty(size, dtype=torch.uint8, device=device)

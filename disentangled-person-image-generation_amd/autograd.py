@@ -559,6 +559,29 @@ def sce_mean(logits, label):
     return _SceMeanFn.apply(logits, float(label))
 
 
+class _LogitMeanFn(torch.autograd.Function):
+    """mean(x) / mean((x - target)^2) over a logit vector (trainer.py:218-220 wgan, :246-248 lsgan)."""
+
+    @staticmethod
+    def forward(ctx, logits, squared, target):
+        out, dl = H.logit_mean(logits, squared, target, want_grad=True, scale=1.0)
+        ctx.save_for_backward(dl)
+        return out.reshape(())
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return dl * g, None, None
+
+
+def logit_mean(logits):
+    return _LogitMeanFn.apply(logits, False, 0.0)
+
+
+def logit_sq_mean(logits, target):
+    return _LogitMeanFn.apply(logits, True, float(target))
+
+
 class _L1MeanFn(torch.autograd.Function):
     """mean(|a - b|) with gradient to a only (trainer.py:607: tf.reduce_mean(tf.abs(G - x)))."""
 

@@ -860,6 +860,21 @@ __global__ __launch_bounds__(1024) void sce_mean_kernel(const float* __restrict_
     if (threadIdx.x == 0) out[0] = t / (float)n;
 }
 
+// wgan / lsgan critic-output losses (trainer.py:218-220, 246-248): mean(x) or mean((x - target)^2) of a logit vector,
+// and the gradient scale * d(mean)/dx
+__global__ __launch_bounds__(1024) void logit_mean_kernel(const float* __restrict__ x, int n, int squared, float target,
+                                                          float* __restrict__ out, float* __restrict__ dx, float scale) {
+    __shared__ float red[17];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 1024) {
+        const float v = x[i] - (squared ? target : 0.f);
+        s += squared ? v * v : v;
+        if (dx) dx[i] = scale * (squared ? 2.f * v : 1.f) / (float)n;
+    }
+    const float t = block_sum_1024(s, red);
+    if (threadIdx.x == 0) out[0] = t / (float)n;
+}
+
 __global__ __launch_bounds__(256) void l1_partial_kernel(const float* __restrict__ a, const float* __restrict__ b,
                                                          long n, float* __restrict__ da, float gs,
                                                          float* __restrict__ partial) {
@@ -1352,6 +1367,13 @@ extern "C" int dpig_sce_mean(const float* logits, int n, float label, float* out
     hipLaunchKernelGGL(sce_mean_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), logits, n, label, out,
                        dlogits, scale);
     return check_launch("sce_mean");
+}
+extern "C" int dpig_logit_mean(const float* logits, int n, int squared, float target, float* out, float* dlogits,
+                               float scale, void* stream) {
+    if (!logits || !out || n <= 0) return fail(DPIG_EINVAL, "logit_mean: bad arguments");
+    hipLaunchKernelGGL(logit_mean_kernel, dim3(1), dim3(1024), 0, static_cast<hipStream_t>(stream), logits, n, squared,
+                       target, out, dlogits, scale);
+    return check_launch("logit_mean");
 }
 extern "C" size_t dpig_l1_workspace_bytes(int64_t n) { return (size_t)grid_for(n, 1024, 1024) * sizeof(float); }
 extern "C" int dpig_l1_mean(const float* a, const float* b, int64_t n, float* out, float* da, float scale, void* ws,

@@ -995,6 +995,18 @@ def sce_mean(logits, label, want_grad=False, scale=1.0):
     return out, dl
 
 
+def logit_mean(logits, squared=False, target=0.0, want_grad=False, scale=1.0):
+    """mean(x) or mean((x - target)^2) of a logit vector (+ its gradient): the wgan / lsgan loss terms."""
+    logits = to_f32(logits)
+    _require_gpu(logits)
+    logits = logits.contiguous()
+    out = torch.empty(1, dtype=torch.float32, device=logits.device)
+    dl = torch.empty_like(logits) if want_grad else None
+    check(lib().dpig_logit_mean(ptr(logits), logits.numel(), int(bool(squared)), float(target), ptr(out), ptr(dl),
+                                float(scale), stream_ptr()), "logit_mean")
+    return out, dl
+
+
 def l1_mean(a, b, want_grad=False, scale=1.0):
     a, b = to_f32(a), to_f32(b)
     _require_gpu(a)

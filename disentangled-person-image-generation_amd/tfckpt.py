@@ -360,19 +360,25 @@ def restore(prefix, scopes=None, strict=True, verify=True):
     from . import tflib as lib
     targets = [n for n in lib._params if _in_scopes(n, scopes)]
     have = {n: (shape, dt) for n, shape, dt in list_variables(prefix)}
-    missing = [n for n in targets if n not in have]
+    # checkpoint key of a registry name: the name TensorFlow gives the variable (tflib ops create theirs inside
+    # tf.name_scope(name): `Discriminator.1/Discriminator.1.Filters`); the bare registry name is accepted too
+    key = {}
+    for n in targets:
+        k = lib.tf_variable_name(n)
+        key[n] = k if k in have else (n if n in have else None)
+    missing = [n for n in targets if key[n] is None]
     if missing and strict:
-        raise Exception("checkpoint %s lacks %d variable(s), e.g. %s" % (prefix, len(missing), missing[0]))
-    names = [n for n in targets if n in have]
-    bad = [n for n in names if tuple(have[n][0]) != tuple(lib._params[n].shape)]
+        raise Exception("checkpoint %s lacks %d variable(s), e.g. %s" % (prefix, len(missing), lib.tf_variable_name(missing[0])))
+    names = [n for n in targets if key[n] is not None]
+    bad = [n for n in names if tuple(have[key[n]][0]) != tuple(lib._params[n].shape)]
     if bad:
         raise Exception("checkpoint %s: shape of %s is %s, the model's is %s" % (
-            prefix, bad[0], have[bad[0]][0], tuple(lib._params[bad[0]].shape)))
-    values = load_checkpoint(prefix, names, verify)
+            prefix, key[bad[0]], have[key[bad[0]]][0], tuple(lib._params[bad[0]].shape)))
+    values = load_checkpoint(prefix, [key[n] for n in names], verify)
     with torch.no_grad():
         for n in names:
             p = lib._params[n]
-            v = np.array(values[n], dtype=np.float32, order="C")
+            v = np.array(values[key[n]], dtype=np.float32, order="C")
             p.data.copy_(torch.from_numpy(v.reshape(-1)).to(p.device).reshape(p.shape))
     return names
 
@@ -401,7 +407,7 @@ def save(prefix, scopes=None, extra=None):
     """`tf.train.Saver(...).save(sess, prefix)`: the registry's variables (of `scopes`) as a V2 checkpoint; `extra`
     adds further named arrays (e.g. a global step)."""
     from . import tflib as lib
-    tensors = {n: p.detach().cpu().numpy() for n, p in lib._params.items() if _in_scopes(n, scopes)}
+    tensors = {lib.tf_variable_name(n): p.detach().cpu().numpy() for n, p in lib._params.items() if _in_scopes(n, scopes)}
     if extra:
         tensors.update(extra)
     save_checkpoint(prefix, tensors)

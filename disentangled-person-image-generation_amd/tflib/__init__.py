@@ -54,6 +54,23 @@ def param(name, *args, **kwargs):
     return result
 
 
+# The reference's Conv2D / Deconv2D / Linear create their tf.Variable(name=...) INSIDE `with tf.name_scope(name)`
+# (tflib/ops/conv2d.py:27,88; linear.py:37,108; deconv2d.py:36,71), so the graph -- and therefore every checkpoint a
+# `tf.train.Saver()` writes -- knows them as `<op name>/<op name>.<suffix>` (e.g. `Discriminator.1/Discriminator.1.Filters`,
+# `Fg_FCDis_Discriminator.Input.Linear/Fg_FCDis_Discriminator.Input.Linear.W`).  Batchnorm / Layernorm parameters
+# (batchnorm.py:23-27, layernorm.py:12-13) are created outside any name scope and keep their registry name.
+_TF_SCOPED_SUFFIXES = ('.Filters', '.Biases', '.g', '.W', '.b')
+
+
+def tf_variable_name(name):
+    """Registry name -> the variable name TensorFlow stores it under (checkpoint key; slots append `/Adam` etc.)."""
+    if '/' not in name:
+        for sfx in _TF_SCOPED_SUFFIXES:
+            if name.endswith(sfx) and len(name) > len(sfx):
+                return name[:-len(sfx)] + '/' + name
+    return name
+
+
 def params_with_name(name):
     return [p for n, p in _params.items() if name in n]
 

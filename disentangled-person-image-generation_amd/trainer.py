@@ -137,14 +137,38 @@ def optimizer_slots(flat, opt, ordinal=0):
     out = {}
     for p, o in zip(flat.params, flat.offsets):
         n = p.numel()
-        out["%s/%s" % (p.dpig_name, kind)] = flat.m[o:o + n].reshape(p.shape).detach().cpu().numpy().copy()
-        out["%s/%s_1" % (p.dpig_name, kind)] = flat.v[o:o + n].reshape(p.shape).detach().cpu().numpy().copy()
+        tfn = lib.tf_variable_name(p.dpig_name)
+        out["%s/%s" % (tfn, kind)] = flat.m[o:o + n].reshape(p.shape).detach().cpu().numpy().copy()
+        out["%s/%s_1" % (tfn, kind)] = flat.v[o:o + n].reshape(p.shape).detach().cpu().numpy().copy()
     if kind == "Adam":
         t = int(opt.state[0])                    # the device counter is the truth (graph replays advance it)
         sfx = "" if ordinal == 0 else "_%d" % ordinal
         out["beta1_power" + sfx] = np.array(opt.b1 ** (t + 1), dtype=np.float32)
         out["beta2_power" + sfx] = np.array(opt.b2 ** (t + 1), dtype=np.float32)
+        # the float32 powers underflow (0.5^150 = 0): the exact step count rides along under a name of our own, which
+        # TensorFlow ignores on restore
+        out[ADAM_STEP_KEY + sfx] = np.array(t, dtype=np.int64)
     return out
+
+
+ADAM_STEP_KEY = "dpig_amd/adam_step"
+
+
+def adam_step_from_powers(values, opt, sfx=""):
+    """Number of Adam updates behind a checkpoint.  Exact when our own step key is present; otherwise from TensorFlow's
+    beta powers (beta^(t+1) after t updates): beta2's first (it decays slowest), then beta1's; when BOTH have underflowed
+    to 0 in float32 the bias correction has long converged to 1, which any large t reproduces."""
+    import math
+    if (ADAM_STEP_KEY + sfx) in values:
+        return int(values[ADAM_STEP_KEY + sfx])
+    for key, beta in (("beta2_power" + sfx, opt.b2), ("beta1_power" + sfx, opt.b1)):
+        if key in values:
+            power = float(values[key])
+            if 0.0 < power < 1.0:
+                return max(0, int(round(math.log(power) / math.log(beta))) - 1)
+            if power >= 1.0:
+                return 0
+    return 10 ** 7
 
 
 def load_optimizer_slots(flat, opt, values, ordinal=0):
@@ -154,7 +178,8 @@ def load_optimizer_slots(flat, opt, values, ordinal=0):
     import numpy as np
     kind = "Adam" if isinstance(opt, TFAdam) else "RMSProp"
     sfx = "" if ordinal == 0 else "_%d" % ordinal
-    need = [("%s/%s" % (p.dpig_name, kind), "%s/%s_1" % (p.dpig_name, kind)) for p in flat.params]
+    need = [("%s/%s" % (lib.tf_variable_name(p.dpig_name), kind), "%s/%s_1" % (lib.tf_variable_name(p.dpig_name), kind))
+            for p in flat.params]
     for p, (a, b) in zip(flat.params, need):
         if a not in values or b not in values or tuple(values[a].shape) != tuple(p.shape) or tuple(values[b].shape) != tuple(p.shape):
             return False
@@ -166,8 +191,7 @@ def load_optimizer_slots(flat, opt, values, ordinal=0):
             flat.m[o:o + n].copy_(torch.from_numpy(np.array(values[a], dtype=np.float32).reshape(-1)).to(flat.m.device))
             flat.v[o:o + n].copy_(torch.from_numpy(np.array(values[b], dtype=np.float32).reshape(-1)).to(flat.v.device))
         if kind == "Adam":
-            power = float(values["beta1_power" + sfx])
-            t = max(0, int(round(math.log(power) / math.log(opt.b1))) - 1) if 0.0 < power < 1.0 else 0
+            t = adam_step_from_powers(values, opt, sfx)
             opt.t = t
             opt.state.zero_()
             opt.state[0] = t                     # the tick kernel recomputes the correction from t + 1
@@ -252,19 +276,19 @@ def gan_loss(wgan_gp, disc_real, disc_fake, Discriminator=None, real_data=None, 
             disc_cost = (A.sce_mean(disc_fake, 0.0) + A.sce_mean(disc_real, 1.0)) / 2.
     elif mode == 'wgan':
         if disc_fake is not None:
-            gen_cost = -disc_fake.mean()
+            gen_cost = -A.logit_mean(disc_fake)
         if disc_fake is not None and disc_real is not None:
-            disc_cost = disc_fake.mean() - disc_real.mean()
+            disc_cost = A.logit_mean(disc_fake) - A.logit_mean(disc_real)
     elif mode == 'lsgan':
         if disc_fake is not None:
-            gen_cost = ((disc_fake - 1) ** 2).mean()
+            gen_cost = A.logit_sq_mean(disc_fake, 1.0)
         if disc_fake is not None and disc_real is not None:
-            disc_cost = (((disc_real - 1) ** 2).mean() + ((disc_fake - 0) ** 2).mean()) / 2.
+            disc_cost = (A.logit_sq_mean(disc_real, 1.0) + A.logit_sq_mean(disc_fake, 0.0)) / 2.
     elif mode == 'wgan-gp':
         if disc_fake is not None:
-            gen_cost = -disc_fake.mean()
+            gen_cost = -A.logit_mean(disc_fake)
         if disc_fake is not None and disc_real is not None:
-            disc_cost = disc_fake.mean() - disc_real.mean()
+            disc_cost = A.logit_mean(disc_fake) - A.logit_mean(disc_real)
             disc_cost = disc_cost + gradient_penalty(Discriminator, real_data, fake_data, wgan_gp.LAMBDA, alpha)
     else:
         raise Exception()
@@ -388,8 +412,13 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
             self.G_flat.enable_bf16_shadows()
             self.D_flat.enable_bf16_shadows()
         lib.ops.batchnorm.set_sync(bool(getattr(self.config, "sync_bn", False)) and self.allreduce.enabled)
-        if getattr(self.config, "ckpt_path", None) and getattr(self.config, "restore_optimizer", False):
-            self.restore_optimizer(self.config.ckpt_path)
+        if getattr(self.config, "ckpt_path", None):
+            self.restore_counters(self.config.ckpt_path)
+            if getattr(self.config, "restore_optimizer", False):
+                ok = self.restore_optimizer(self.config.ckpt_path)
+                if not all(ok):
+                    raise Exception("Config.restore_optimizer: checkpoint %s holds no complete set of %s slots" % (
+                        self.config.ckpt_path, " / ".join(n for n, o in zip(("generator", "critic"), ok) if not o)))
 
     def refresh_shadows(self):
         """After writing parameter values from outside the optimizer ('bf16' mode): re-derive the bf16 filter shadows."""
@@ -402,12 +431,29 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         from . import tfckpt
         return tfckpt.restore_from_config(self.config)
 
+    def restore_counters(self, prefix):
+        """`step`, `g_lr`, `d_lr` of a full checkpoint (trainer.py:47,54-59: tf.Variables the reference's Saver stores
+        and restores with everything else): a resumed run continues the step count and the halved learning rates."""
+        from . import tfckpt
+        have = set(n for n, _, _ in tfckpt.list_variables(prefix))
+        want = [n for n in ("step", "g_lr", "d_lr") if n in have]
+        if not want:
+            return []
+        v = tfckpt.load_checkpoint(prefix, want)
+        if "step" in v:
+            self.step = int(v["step"])
+        if "g_lr" in v:
+            self.g_lr.fill_(float(v["g_lr"]))
+        if "d_lr" in v:
+            self.d_lr.fill_(float(v["d_lr"]))
+        return want
+
     def restore_optimizer(self, prefix):
         """The optimizer slots of a full checkpoint (a `tf.train.Saver()` holds them beside the variables).  Returns
         (generator restored, critic restored)."""
         from . import tfckpt
         values = tfckpt.load_checkpoint(prefix, names=lambda n: n.rsplit("/", 1)[-1].startswith(("Adam", "RMSProp"))
-                                        or n.startswith(("beta1_power", "beta2_power")))
+                                        or n.startswith(("beta1_power", "beta2_power", ADAM_STEP_KEY)))
         return (load_optimizer_slots(self.G_flat, self.g_opt, values, 0),
                 load_optimizer_slots(self.D_flat, self.d_opt, values, 1))
 
@@ -421,7 +467,9 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         if not model_dir:
             raise Exception("save_checkpoint: no model_dir")
         prefix = os.path.join(model_dir, "model.ckpt-%d" % self.step)
-        extra = {"step": np.array(self.step, dtype=np.int32)}
+        extra = {"step": np.array(self.step, dtype=np.int32),                   # trainer.py:47
+                 "g_lr": np.array(float(self.g_lr), dtype=np.float32),          # trainer.py:54-55
+                 "d_lr": np.array(float(self.d_lr), dtype=np.float32)}
         if include_optimizer:
             extra.update(optimizer_slots(self.G_flat, self.g_opt, 0))
             extra.update(optimizer_slots(self.D_flat, self.d_opt, 1))
@@ -440,11 +488,27 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         side.wait_stream(torch.cuda.current_stream(self.device))
         self._static_g = {k: v.clone() for k, v in batch_g.items()}
         self._static_d = {k: v.clone() for k, v in batch_d.items()}
+        # The warm-up (sizes the workspace, pages every kernel in) runs real optimizer steps: weights, optimizer slots
+        # and step counters are put back afterwards, so enabling graphs does not move the training trajectory (nor
+        # advance a restored checkpoint's Adam state).
+        snap = [(f.flat.clone(), f.m.clone(), f.v.clone()) for f in (self.G_flat, self.D_flat)]
+        osnap = [(getattr(o, "state", None), o.t) for o in (self.g_opt, self.d_opt)]
+        osnap = [(s.clone() if s is not None else None, t) for s, t in osnap]
         with torch.cuda.stream(side):
-            for _ in range(warmup):                 # sizes the workspace, pages every kernel in
+            for _ in range(warmup):
                 self._g_optim_eager(self._static_g)
                 self._d_optim_eager(self._static_d)
         torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        with torch.no_grad():
+            for f, (w, m, v) in zip((self.G_flat, self.D_flat), snap):
+                f.flat.copy_(w); f.m.copy_(m); f.v.copy_(v)
+                f.refresh_shadows()
+            for o, (st, t) in zip((self.g_opt, self.d_opt), osnap):
+                if st is not None:
+                    o.state.copy_(st)
+                o.t = t
+        del snap
         torch.cuda.synchronize(self.device)
         self._graph_update = not (self.allreduce.enabled or self._split())   # fold all-reduce + Adam into the graph?
         gg, gd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
@@ -467,6 +531,8 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         with torch.cuda.graph(gd, pool=gg.pool(), capture_error_mode="thread_local"):
             out_d = self._d_optim_eager(self._static_d, update=self._graph_update)
         self._graphs = (gg, out_g, gd, out_d)
+        from ._lib import workspace
+        workspace.pin()            # the graphs hold the workspace address: a later, larger request must not free it
         if self._graph_update:
             self.g_opt.t -= 1          # capturing recorded one step() each without executing it
             self.d_opt.t -= 1
@@ -576,7 +642,7 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
             G, _ = self.generate(embs, batch["pose"])
         D_z_pos, D_z_neg = self.disc_pair(batch["x"], G, need_real=True)
         _, d_loss = gan_loss(self.wgan_gp, D_z_pos, D_z_neg, Discriminator=self.discriminate,
-                             real_data=batch["x"], fake_data=G)
+                             real_data=batch["x"], fake_data=G, alpha=getattr(self, "gp_alpha", None))   # (tests pin alpha)
         d_loss.backward()
         self.D_flat.finalize()
         if update:

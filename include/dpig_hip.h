@@ -342,6 +342,10 @@ int dpig_clip(float* p, int64_t n, float lo, float hi, void* stream);
 /* out[0] = mean_i sce(logits_i, label) ; dlogits_i = scale*(sigmoid(x_i)-label)/n (dlogits may be NULL) */
 int dpig_sce_mean(const float* logits, int n, float label, float* out, float* dlogits, float scale,
                   void* stream);
+/* The critic-output terms of the wgan / wgan-gp and lsgan losses (trainer.py:218-220, 246-248):
+ * out[0] = mean_i x_i (squared = 0) or mean_i (x_i - target)^2 (squared = 1); dlogits (may be NULL) = scale * d out / dx_i */
+int dpig_logit_mean(const float* logits, int n, int squared, float target, float* out, float* dlogits, float scale,
+                    void* stream);
 /* out[0] = mean |a-b| ; dgrad (may be NULL) = scale*sign(a-b)/n */
 size_t dpig_l1_workspace_bytes(int64_t n);
 int dpig_l1_mean(const float* a, const float* b, int64_t n, float* out, float* da, float scale, void* ws,

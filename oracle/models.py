@@ -337,6 +337,25 @@ class OracleAdam(object):
                 self.m[n], self.v[n] = m, v
 
 
+def gradient_penalty(D, real, fake, alpha, lam=10.0):
+    """trainer.py:222-236 / wgan_gp.py:605-619 in the canonical form (per-sample alpha, L2 norm over all non-batch axes;
+    SURVEY C-3):  lam * mean_b (|| d D(xhat_b) / d xhat_b ||_2 - 1)^2,  xhat = real + alpha (fake - real).  Differentiable
+    w.r.t. the critic's parameters (create_graph)."""
+    B = real.shape[0]
+    xh = (real + alpha.reshape([B] + [1] * (real.dim() - 1)) * (fake - real)).detach().requires_grad_(True)
+    (g,) = torch.autograd.grad(D(xh).sum(), xh, create_graph=True)
+    return lam * ((g.reshape(B, -1).pow(2).sum(1).sqrt() - 1.0) ** 2).mean()
+
+
+def gan_losses(mode, D, real, fake, alpha=None, lam=10.0):
+    """`_gan_loss` for all four modes (trainer.py:217-252): (gen_cost, disc_cost)."""
+    d_real, d_fake = D(real), D(fake)
+    if mode == "wgan-gp":
+        gen, dis = gan_loss("wgan", d_real, d_fake)
+        return gen, dis + gradient_penalty(D, real, fake, alpha, lam)
+    return gan_loss(mode, d_real, d_fake)
+
+
 def batch_to_torch(batch, dtype=torch.float64):
     out = {}
     for k, v in batch.items():

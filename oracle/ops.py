@@ -27,7 +27,7 @@ def conv2d_same(x, w, b=None, stride=1):
     _, pl, pr = same_pad(x.shape[2], kw, stride)
     xn = x.permute(0, 3, 1, 2)
     xn = F.pad(xn, (pl, pr, pt, pb))                 # asymmetric pad: torch's padding= is wrong for s=2
-    wn = w.permute(3, 2, 0, 1)                       # HWIO -> OIHW
+    wn = w.permute(3, 2, 0, 1).contiguous()          # HWIO -> OIHW (contiguous: torch-CPU's backward wants it for 1-pixel shapes)
     y = F.conv2d(xn, wn, None, stride=stride)
     y = y.permute(0, 2, 3, 1)
     if b is not None:

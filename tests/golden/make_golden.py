@@ -8,6 +8,9 @@ oracle.models.ParamStore(seed), numpy Generator streams), only expected outputs 
 
     python tests/golden/make_golden.py            (~5 min on 8 cores)
     python tests/golden/make_golden.py --small    the width-16 model (seconds): the fixture the CPU suite re-derives
+    python tests/golden/make_golden.py --modes    modes_w32.npz: the four `_gan_loss` modes (wgan-gp incl. the critic's
+                                                  gradients), weights after two TF-Adam iterations, model 101
+                                                  (trainer_256.py) and the stage-II losses at width 32 (~2 min)
 """
 import os
 import sys
@@ -57,9 +60,99 @@ def small_outputs():
     return out
 
 
+# ---- fixtures for the other modes / models ---------------------------------------------------------------
+MODES_W, MODES_Z = 32, 16            # width of the mode fixtures
+ALPHA_SEED, Z_SEED = 24, 25
+D_GRAD_PARAMS = ["Discriminator.1.Filters", "Discriminator.3.Filters", "Discriminator.BN3.scale", "Discriminator.4.Biases",
+                 "Discriminator.Output.W"]
+ADAM_PARAMS = ["Encoder/G_encoder/Conv_2/weights", "ID_AE/G/Conv_20/weights", "ID_AE/G/fully_connected/weights",
+               "Discriminator.2.Filters", "Discriminator.BN4.scale"]
+
+
+def mode_outputs(which=("losses", "adam", "df256", "stage2")):
+    """Expected outputs of the oracle for: the four GAN modes of `_gan_loss` on the Market stage-I graph (width 32;
+    wgan-gp with its LayerNorm critic, the penalty and the critic's parameter gradients of d_loss), the weights after the
+    first two iterations of the training loop in dcgan mode (TF-Adam), model 101 (trainer_256.py graph, width 32) and the
+    stage-II wgan losses.  Inputs / weights / alpha / z all come from seeds.  Shared by the generator (--modes) and by
+    tests/test_oracle.py, which re-derives the cheap parts."""
+    out = {"meta": np.array([BATCH_SEED, PARAM_SEED, ALPHA_SEED, Z_SEED, B, MODES_W, MODES_Z])}
+    ob = OM.batch_to_torch(synthetic.make_batch(B, seed=BATCH_SEED))
+    kw = dict(hidden_num=MODES_W, z_num=MODES_Z)
+    gen = torch.Generator().manual_seed(ALPHA_SEED)
+    alpha = torch.rand(B, generator=gen, dtype=torch.float64)
+    if "losses" in which:
+        for mode in ("dcgan", "wgan", "lsgan", "wgan-gp"):
+            P = OM.ParamStore(seed=PARAM_SEED)
+            with torch.no_grad():
+                _, G = OM.stage1_forward(P, ob, **kw)
+            D = lambda t, m=("wgan-gp" if mode == "wgan-gp" else "dcgan"): OM.dcgan_discriminator(P, t, m)   # noqa: E731
+            g_only, d_loss = OM.gan_losses(mode, D, ob["x"], G, alpha)
+            out["loss/%s/g_loss_only" % mode] = np.array(g_only.item())
+            out["loss/%s/d_loss" % mode] = np.array(d_loss.item())
+            if mode == "dcgan":
+                out["G"] = subsample(G, 8192)
+            if mode == "wgan-gp":
+                out["loss/wgan-gp/penalty"] = np.array(OM.gradient_penalty(D, ob["x"], G, alpha).item())
+                grads = torch.autograd.grad(d_loss, [P.p[n] for n in D_GRAD_PARAMS])
+                for n, g in zip(D_GRAD_PARAMS, grads):
+                    out["dgrad/wgan-gp/" + n] = subsample(g)
+    if "adam" in which:
+        # trainer.py:336-347 from step 0: [d_optim], [g_optim, d_optim]; lr 1e-3 so that two steps are visible
+        P = OM.ParamStore(seed=PARAM_SEED)
+        OM.stage1_g_loss(P, ob, **kw)
+        OM.stage1_d_loss(P, ob, **kw)
+        gn, dn = OM.g_var_names(P), OM.d_var_names(P)
+        gopt, dopt = OM.OracleAdam(P, gn, 1e-3), OM.OracleAdam(P, dn, 1e-3)
+
+        def d_step():
+            dl, _ = OM.stage1_d_loss(P, ob, **kw)
+            dopt.step(dict(zip(dn, torch.autograd.grad(dl, [P.p[n] for n in dn], allow_unused=True))))
+            return dl.item()
+
+        def g_step():
+            gl, _ = OM.stage1_g_loss(P, ob, **kw)
+            gopt.step(dict(zip(gn, torch.autograd.grad(gl, [P.p[n] for n in gn], allow_unused=True))))
+            return gl.item()
+        out["adam/d_loss0"] = np.array(d_step())
+        out["adam/g_loss1"] = np.array(g_step())
+        out["adam/d_loss1"] = np.array(d_step())
+        for n in ADAM_PARAMS:
+            out["adam/w2/" + n] = subsample(P.p[n])
+    if "df256" in which:
+        ob256 = OM.batch_to_torch(synthetic.make_batch(B, img_H=256, img_W=256, seed=BATCH_SEED))
+        P = OM.ParamStore(seed=PARAM_SEED)
+        with torch.no_grad():
+            ref = OM.stage1_256_forward(P, ob256, MODES_W, MODES_Z, 6)
+        out["df256/embs"] = ref["embs"].numpy()
+        out["df256/G"] = subsample(ref["G"], 8192)
+        out["df256/D_z"] = ref["D_z"].numpy()
+        for k in ("g_loss", "d_loss", "L1Loss"):
+            out["df256/" + k] = np.array(ref[k].item())
+    if "stage2" in which:
+        P = OM.ParamStore(seed=PARAM_SEED)
+        with torch.no_grad():
+            embs = OM.encoder_fgbg(P, ob["x"], ob["mask_r6"], ob["part_bbox"], ob["part_vis"], 7, 32, 5, MODES_W)
+        gz = torch.Generator().manual_seed(Z_SEED)
+        for side, hid, sl in (("Fg", 512, slice(0, 224)), ("Bg", 256, slice(224, None))):
+            real = embs[:, sl]
+            z = torch.randn(B, real.shape[1], generator=gz, dtype=torch.float64) * 0.2
+            g_ref, d_ref, fake = OM.stage2_losses(P, real, z, side, hid)
+            out["stage2/%s/g_loss" % side] = np.array(g_ref.item())
+            out["stage2/%s/d_loss" % side] = np.array(d_ref.item())
+            out["stage2/%s/fake" % side] = fake.detach().numpy()
+        out["stage2/embs"] = embs.numpy()
+    return out
+
+
 def main():
     torch.set_num_threads(os.cpu_count() or 1)
     t0 = time.time()
+    if "--modes" in sys.argv:
+        out = mode_outputs()
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "modes_w32.npz")
+        np.savez_compressed(path, **{k: (v.astype(np.float64) if v.dtype.kind == "f" else v) for k, v in out.items()})
+        print("wrote %s (%.0f KB) in %.1fs" % (path, os.path.getsize(path) / 1024.0, time.time() - t0))
+        return
     if "--small" in sys.argv:
         out = small_outputs()
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stage1_market_b2_w16.npz")

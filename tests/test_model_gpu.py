@@ -157,13 +157,14 @@ def test_hipgraph_replay_matches_eager(dev):
     for use_graph in (False, True):
         tr, gb, P, ob, OM = _setup(dev)
         if use_graph:
-            # capture warm-up runs real steps; rewind weights/moments/counters afterwards
+            # the capture warm-up runs real optimizer steps and must put everything back: same weights, empty Adam
+            # slots, step counters at zero (a run -- or a restored checkpoint -- is not moved by enabling graphs)
             snap = [t.clone() for t in (tr.G_flat.flat, tr.D_flat.flat)]
             tr.enable_graphs(gb, gb, warmup=1)
             for fl, s0 in zip((tr.G_flat, tr.D_flat), snap):
-                fl.flat.copy_(s0); fl.m.zero_(); fl.v.zero_()
+                assert torch.equal(fl.flat, s0) and float(fl.m.abs().sum()) == 0.0 and float(fl.v.abs().sum()) == 0.0
             for opt in (tr.g_opt, tr.d_opt):
-                opt.state.zero_(); opt.t = 0
+                assert int(opt.state[0]) == 0 and opt.t == 0
         for _ in range(3):
             out = tr.train_step(gb, gb)
         torch.cuda.synchronize()

@@ -171,6 +171,32 @@ def test_losses(dev):
     _close(da, a.grad)
 
 
+def test_wgan_and_lsgan_loss_terms(dev):
+    """trainer.py:218-220 (wgan: +-mean D) and :246-248 (lsgan: mean (D - 1)^2, mean D^2) with their gradients, and
+    `gan_loss` in the four modes against the oracle's restatement."""
+    import dpig_amd.autograd as A
+    from dpig_amd.trainer import gan_loss
+    from dpig_amd.wgan_gp import WGAN_GP
+    from oracle import models as OM
+    g = torch.Generator().manual_seed(7)
+    real = (torch.rand(37, generator=g, dtype=torch.float64) * 6 - 3)
+    fake = (torch.rand(37, generator=g, dtype=torch.float64) * 6 - 3)
+    for mode in ("wgan", "lsgan", "dcgan"):
+        rr, ff = real.clone().requires_grad_(True), fake.clone().requires_grad_(True)
+        g_ref, d_ref = OM.gan_loss(mode, rr, ff)
+        gr, gf = torch.autograd.grad(d_ref, [rr, ff])
+        rg, fg = real.float().to(dev).requires_grad_(True), fake.float().to(dev).requires_grad_(True)
+        g_got, d_got = gan_loss(WGAN_GP(MODE=mode), rg, fg)
+        assert abs(g_got.item() - g_ref.item()) < 1e-5 * max(1.0, abs(g_ref.item()))
+        assert abs(d_got.item() - d_ref.item()) < 1e-5 * max(1.0, abs(d_ref.item()))
+        d_got.backward()
+        assert (rg.grad.double().cpu() - gr).abs().max().item() < 1e-6
+        assert (fg.grad.double().cpu() - gf).abs().max().item() < 1e-6
+    x = real.float().to(dev).requires_grad_(True)
+    (A.logit_sq_mean(x, 1.0) * 3.0).backward()
+    assert (x.grad.double().cpu() - 3.0 * 2.0 * (real - 1.0) / 37).abs().max().item() < 1e-6
+
+
 def test_tf_adam(dev):
     import dpig_amd.hip_ops as H
     from oracle import naive

@@ -3,6 +3,7 @@
   * analytic known-answer tests nail the TF-1.4 semantics of SURVEY.md Appendix B.
 CPU only (runs in the not-gpu tier)."""
 import math
+import os
 
 import numpy as np
 import pytest
@@ -297,3 +298,79 @@ def test_pose_fixture_is_what_the_reference_code_produces_today():
         assert np.array_equal(dense > 0, want), name
         seen += 1
     assert seen == 3
+
+
+def test_oracle_reproduces_mode_goldens():
+    """tests/golden/modes_w32.npz (the four `_gan_loss` modes incl. the wgan-gp penalty and the critic's gradients, the
+    weights after two TF-Adam iterations of the training loop, model 101 and the stage-II losses; `make_golden.py
+    --modes`) re-derived from seeds by today's oracle: the fixture the GPU box compares against cannot drift from the
+    restatement it was made with."""
+    import importlib.util
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(here, "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    gold = np.load(os.path.join(here, "golden", "modes_w32.npz"))
+    got = mg.mode_outputs()
+    assert set(got) == set(gold.files)
+    for k in gold.files:
+        ref = gold[k]
+        scale = max(float(np.abs(ref).max()), 1e-12)
+        assert np.abs(np.asarray(got[k], dtype=np.float64) - ref).max() <= 1e-7 * scale, k
+    # sanity of what the fixture pins: the penalty is part of the wgan-gp critic loss, lsgan differs from dcgan
+    assert float(gold["loss/wgan-gp/penalty"]) > 0
+    assert abs(float(gold["loss/lsgan/d_loss"]) - float(gold["loss/dcgan/d_loss"])) > 1e-3
+
+
+# ---- generated shapes: oracle/ops.py (torch, differentiable) against oracle/naive.py (numpy loops) ------------------------
+# SURVEY 8c-1: with no reference vectors, each TF-1.4 op is pinned by two independently written restatements agreeing
+# on hypothesis-drawn shapes -- asymmetric SAME pads at both strides and all three kernel sizes, degenerate sizes
+# (1-pixel images, kernels larger than the image), ragged crops and out-of-image boxes.
+from hypothesis import given, settings, strategies as st   # noqa: E402
+
+_conv_shapes = st.tuples(st.integers(1, 2), st.integers(1, 9), st.integers(1, 9), st.integers(1, 4), st.integers(1, 4),
+                         st.sampled_from([1, 3, 5]), st.sampled_from([1, 2]))
+
+
+@settings(max_examples=40, deadline=None)
+@given(_conv_shapes, st.integers(0, 2 ** 31 - 1))
+def test_generated_conv_shapes_fwd_dgrad_wgrad(shape, seed):
+    N, H, W, C, K, k, s = shape
+    x, w, b = rnd((N, H, W, C), seed), rnd((k, k, C, K), seed + 1), rnd((K,), seed + 2)
+    xt, wt = T(x).requires_grad_(True), T(w).requires_grad_(True)
+    y = O.conv2d_same(xt, wt, T(b), s)
+    ref = naive.conv2d_same(x, w, b, s)
+    assert y.shape == ref.shape == (N, -(-H // s), -(-W // s), K)
+    assert np.abs(y.detach().numpy() - ref).max() < 1e-12
+    dy = rnd(ref.shape, seed + 3)
+    y.backward(T(dy))
+    assert np.abs(xt.grad.numpy() - naive.conv2d_same_dgrad(dy, w, x.shape, s)).max() < 1e-12
+    assert np.abs(wt.grad.numpy() - naive.conv2d_same_wgrad(x, dy, w.shape, s)).max() < 1e-12
+
+
+@settings(max_examples=25, deadline=None)
+@given(st.tuples(st.integers(1, 3), st.integers(1, 6), st.integers(1, 6), st.integers(1, 5)), st.integers(0, 2 ** 31 - 1))
+def test_generated_norm_and_upsample_shapes(shape, seed):
+    x, sc, of = rnd(shape, seed), rnd((shape[3],), seed + 1) + 1.5, rnd((shape[3],), seed + 2)
+    assert np.abs(O.batchnorm_train(T(x), T(sc), T(of)).numpy() - naive.batchnorm_train(x, sc, of)).max() < 1e-10
+    assert np.abs(O.layernorm(T(x), T(sc), T(of)).numpy() - naive.layernorm(x, sc, of)).max() < 1e-10
+    assert np.array_equal(O.upsample2x(T(x)).numpy(), naive.upsample2x(x))
+
+
+@settings(max_examples=25, deadline=None)
+@given(st.tuples(st.integers(1, 2), st.integers(2, 9), st.integers(2, 9), st.integers(1, 3)), st.integers(1, 5), st.integers(1, 6),
+       st.integers(1, 6), st.integers(0, 2 ** 31 - 1))
+def test_generated_crop_and_resize_shapes_incl_grad(shape, nbox, ch, cw, seed):
+    N, H, W, C = shape
+    rng = np.random.default_rng(seed)
+    img = rnd(shape, seed)
+    y1, x1 = rng.uniform(-0.3, 0.9, nbox), rng.uniform(-0.3, 0.9, nbox)
+    boxes = np.stack([y1, x1, y1 + rng.uniform(0.0, 0.8, nbox), x1 + rng.uniform(0.0, 0.8, nbox)], axis=1)   # some reach outside [0,1]
+    ind = rng.integers(0, N, nbox)
+    it = T(img).requires_grad_(True)
+    out = O.crop_and_resize(it, T(boxes), torch.tensor(ind), ch, cw)
+    ref = naive.crop_and_resize(img, boxes, ind, ch, cw)
+    assert np.abs(out.detach().numpy() - ref).max() < 1e-12
+    dout = rnd(ref.shape, seed + 1)
+    out.backward(T(dout))
+    assert np.abs(it.grad.numpy() - naive.crop_and_resize_grad_image(dout, boxes, ind, img.shape)).max() < 1e-12

@@ -158,7 +158,11 @@ def test_saver_like_restore_into_the_registry(tmp_path):
             saved[n] = rng.randn(*sh).astype(np.float32)
             lib.param(n, saved[n], trainable="moving" not in n)
         prefix = str(tmp_path / "model.ckpt-3")
-        assert C.save(prefix, extra={"step": np.array(3, np.int32)}) == sorted(list(names) + ["step"])
+        # tflib conv / linear variables are stored under the name TensorFlow gives them: created inside
+        # tf.name_scope(name) (reference tflib/ops/conv2d.py:27,88) -> `Discriminator.1/Discriminator.1.Filters`
+        keys = [lib.tf_variable_name(n) for n in names]
+        assert "Discriminator.1/Discriminator.1.Filters" in keys and "Discriminator.BN2.moving_mean" in keys
+        assert C.save(prefix, extra={"step": np.array(3, np.int32)}) == sorted(keys + ["step"])
         flat_alias = lib._params["ID_AE/G/Conv/weights"].data           # in-place copy must keep this storage
         for p in lib._params.values():
             p.data.fill_(7.0)
@@ -223,6 +227,28 @@ def test_bundle_round_trip_generated(tmp_path_factory, tensors):
         assert got[n].dtype == a.dtype and got[n].shape == a.shape and np.array_equal(got[n], a)
 
 
+def test_tf_variable_names_of_the_full_model_key_list():
+    """The checkpoint keys of every variable of model 1 as a `tf.train.Saver()` of the reference names them (SURVEY
+    Appendix F): slim variables under their scopes, tflib conv / linear variables inside the name scope of their op,
+    BatchNorm parameters bare; Adam slots and the optimizer's powers on top."""
+    import dpig_amd.tflib as lib
+    cases = {
+        "Encoder/G_encoder/Conv_3/weights": "Encoder/G_encoder/Conv_3/weights",
+        "ID_AE/G/fully_connected_1/biases": "ID_AE/G/fully_connected_1/biases",
+        "Discriminator.1.Filters": "Discriminator.1/Discriminator.1.Filters",
+        "Discriminator.4.Biases": "Discriminator.4/Discriminator.4.Biases",
+        "Discriminator.Output.W": "Discriminator.Output/Discriminator.Output.W",
+        "Discriminator.Output.b": "Discriminator.Output/Discriminator.Output.b",
+        "Discriminator.BN2.offset": "Discriminator.BN2.offset",
+        "Discriminator.BN3.moving_variance": "Discriminator.BN3.moving_variance",
+        "Fg_FCDis_Discriminator.Input.Linear.W": "Fg_FCDis_Discriminator.Input.Linear/Fg_FCDis_Discriminator.Input.Linear.W",
+        "Bg_FCDis_Discriminator.2.Linear.b": "Bg_FCDis_Discriminator.2.Linear/Bg_FCDis_Discriminator.2.Linear.b",
+        "Generator.5.g": "Generator.5/Generator.5.g",
+    }
+    for reg, tfn in cases.items():
+        assert lib.tf_variable_name(reg) == tfn
+
+
 def test_optimizer_slots_round_trip_under_tf_names(tmp_path):
     """trainer.optimizer_slots / load_optimizer_slots: Adam moments as `<var>/Adam`, `<var>/Adam_1`, the powers as
     beta^(t+1) under `beta1_power[_k]`; RMSProp as `<var>/RMSProp`, `<var>/RMSProp_1`; all-or-nothing restore."""
@@ -241,7 +267,8 @@ def test_optimizer_slots_round_trip_under_tf_names(tmp_path):
         flat.m.normal_(); flat.v.uniform_()
         opt.state[0] = 7; opt.t = 7
         slots = optimizer_slots(flat, opt, ordinal=1)
-        assert set(slots) == {n + s for n in shapes for s in ("/Adam", "/Adam_1")} | {"beta1_power_1", "beta2_power_1"}
+        assert set(slots) == {n + s for n in shapes for s in ("/Adam", "/Adam_1")} | {"beta1_power_1", "beta2_power_1",
+                                                                                     "dpig_amd/adam_step_1"}
         assert abs(float(slots["beta1_power_1"]) - 0.5 ** 8) < 1e-9 and abs(float(slots["beta2_power_1"]) - 0.999 ** 8) < 1e-7
         prefix = str(tmp_path / "model.ckpt-7")
         C.save(prefix, extra=slots)
@@ -258,6 +285,19 @@ def test_optimizer_slots_round_trip_under_tf_names(tmp_path):
             assert np.array_equal(flat.m[o:o + n].numpy().reshape(p.shape), want_m[p.dpig_name])
             assert np.array_equal(flat.v[o:o + n].numpy().reshape(p.shape), want_v[p.dpig_name])
         assert opt.t == 7 and int(opt.state[0]) == 7 and int(opt.state[1]) == 0
+        # a TensorFlow-written checkpoint has no step key: t comes from the powers -- beta2's, because beta1 = 0.5
+        # underflows float32 after ~150 updates (0.5^151 == 0.0f) while 0.999^(t+1) stays representable
+        tfv = {k: v for k, v in values.items() if not k.startswith("dpig_amd/")}
+        assert load_optimizer_slots(flat, opt, tfv, ordinal=1) and opt.t == 7
+        for t in (149, 150, 5000, 60000):
+            tfv["beta1_power_1"] = np.float32(0.5 ** (t + 1))
+            tfv["beta2_power_1"] = np.float32(0.999 ** (t + 1))
+            assert load_optimizer_slots(flat, opt, tfv, ordinal=1)
+            assert abs(opt.t - t) <= max(1, t // 2000), (t, opt.t)       # (float32 power: exact to ~1e-7 relative)
+        assert float(np.float32(0.5 ** 151)) == 0.0
+        tfv["beta1_power_1"] = np.float32(0.0)
+        tfv["beta2_power_1"] = np.float32(0.0)                 # both underflowed: bias correction == 1 from here on
+        assert load_optimizer_slots(flat, opt, tfv, ordinal=1) and opt.t >= 10 ** 6
         ropt = TFRMSProp(flat, lr)
         names = set(optimizer_slots(flat, ropt))
         assert names == {n + s for n in shapes for s in ("/RMSProp", "/RMSProp_1")}
