@@ -235,7 +235,8 @@ def test_checkpoint_save_restore_round_trip(dev, tmp_path):
     assert prefix.endswith("model.ckpt-2") and tfckpt.latest_checkpoint(str(tmp_path)) == prefix
     listed = {n: s for n, s, _ in tfckpt.list_variables(prefix)}
     assert int(tfckpt.load_checkpoint(prefix, ["step"])["step"]) == 2
-    assert all(tuple(p.shape) == listed[n] for n, p in lib._params.items())
+    assert all(tuple(p.shape) == listed[lib.tf_variable_name(n)] for n, p in lib._params.items())
+    assert "Discriminator.1/Discriminator.1.Filters" in listed and "g_lr" in listed and "d_lr" in listed
     flat_ptr = tr.G_flat.flat.data_ptr()
     tr.G_flat.flat.add_(0.05)
     tr.D_flat.flat.mul_(0.5)
@@ -268,7 +269,7 @@ def test_checkpoint_resume_with_optimizer_slots(dev, tmp_path):
     tr.train_step(gb, gb)
     prefix = tr.save_checkpoint(str(tmp_path), include_optimizer=True)
     names = {n for n, _, _ in tfckpt.list_variables(prefix)}
-    assert {"beta1_power", "beta2_power", "beta1_power_1", "beta2_power_1", "Discriminator.1.Filters/Adam",
+    assert {"beta1_power", "beta2_power", "beta1_power_1", "beta2_power_1", "Discriminator.1/Discriminator.1.Filters/Adam",
             "ID_AE/G/Conv/weights/Adam_1"} <= names
     tr.train_step(gb, gb)
     want_g, want_d = tr.G_flat.flat.clone(), tr.D_flat.flat.clone()
@@ -279,7 +280,7 @@ def test_checkpoint_resume_with_optimizer_slots(dev, tmp_path):
     tr2 = DPIG_Encoder_GAN_BodyROI_FgBg(cfg, dev)
     tr2.init_net(gb)
     assert tr2.g_opt.t == 2 and int(tr2.g_opt.state[0]) == 2 and int(tr2.d_opt.state[0]) == 2
-    tr2.step = 3
+    assert tr2.step == 3                      # the `step` variable of the checkpoint (trainer.py:47) came back too
     tr2.train_step(gb, gb)
     assert torch.equal(tr2.G_flat.flat, want_g) and torch.equal(tr2.D_flat.flat, want_d)
     lib.delete_all_params()
