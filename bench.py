@@ -180,7 +180,7 @@ def main():
     headline = args.workload == "market128" and args.dtype == "f32" and not args.host_input
     if not headline:                          # information lines: no roofline / CPU legs, eager launches
         args.no_roofline = args.no_cpu_baseline = True
-        args.no_graph = args.no_graph or args.workload in ("market128-wgan-gp", "market128-stage2")
+        args.no_graph = args.no_graph or args.workload in ("market128-stage2",)
 
     np.random.seed(0)                         # identical initial weights on every rank (+ broadcast)
     B = args.batch or wl_batch
@@ -240,6 +240,11 @@ def main():
     get_d = (lambda: next(feed_d)) if feed_d is not None else (lambda: batch_d)
     if args.workload == "market128-stage2":
         step_fn = lambda: tr.train_step(get_g())
+    elif args.workload == "market128-wgan-gp" and feed_d is None:
+        # every critic iteration of a step dequeues its own batch (trainer.py:340-345, 553-555): 5 distinct resident batches
+        critic_batches = [batch_d] + [synthetic.to_device(synthetic.make_batch(B, img_H=cfg.img_H, img_W=cfg.img_W,
+                                                                             seed=300 + 10 * rank + i), dev) for i in range(4)]
+        step_fn = lambda: tr.train_step(get_g(), critic_batches)
     else:
         step_fn = lambda: tr.train_step(get_g(), get_d())
     for _ in range(args.warmup):

@@ -124,15 +124,22 @@ def _as_rows(t):
     return t, n // max(cols, 1), cols, cols
 
 
-def to_f32(t):
-    """bf16 -> fp32 copy (exact) through dpig_cvt_bf16_to_f32; fp32 tensors pass through."""
-    if t is None or t.dtype == F32:
+def to_f32(t, out=None):
+    """bf16 -> fp32 copy (exact) through dpig_cvt_bf16_to_f32; fp32 tensors pass through (or are copied into `out`)."""
+    if t is None or (t.dtype == F32 and out is None):
         return t
     _require_dev(t)
+    if t.dtype == F32:
+        out.copy_(t)
+        return out
     t, rows, cols, ld = _as_rows(t)
-    out = torch.empty(t.shape, dtype=F32, device=t.device)
+    if out is None:
+        out = torch.empty(t.shape, dtype=F32, device=t.device)
+        ldo = cols
+    else:
+        _, _, _, ldo = _as_rows(out)
     if t.numel():
-        check(lib().dpig_cvt_bf16_to_f32(ptr(t), ld, ptr(out), cols, rows, cols, stream_ptr()), "cvt_bf16_to_f32")
+        check(lib().dpig_cvt_bf16_to_f32(ptr(t), ld, ptr(out), ldo, rows, cols, stream_ptr()), "cvt_bf16_to_f32")
     return out
 
 

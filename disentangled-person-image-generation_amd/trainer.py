@@ -206,27 +206,38 @@ def clip_disc_weights(D_flat, lo=-.01, hi=.01):
 
 
 class GradAllReduce(object):
-    """Data-parallel gradient exchange: sum-all-reduce of the flat gradient buffer over RCCL in
-    ~32 MB slices (xGMI is point-to-point: a few large collectives, not hundreds of small ones);
-    the 1/world factor is folded into the Adam kernel's grad_scale."""
+    """Data-parallel gradient exchange: sum-all-reduce of the flat gradient buffer over RCCL in ~32 MB slices (xGMI is
+    point-to-point: a few large collectives, not hundreds of small ones); the 1/world factor is folded into the Adam
+    kernel's grad_scale.
 
-    def __init__(self, bucket_bytes=32 << 20):
+    `compress='bf16'` ('bf16' storage mode): the slice is rounded to bf16 into a persistent staging buffer
+    (dpig_cvt_f32_to_bf16), all-reduced there -- half the bytes on every xGMI link -- and widened back into the fp32
+    gradient buffer Adam reads (dpig_cvt_bf16_to_f32).  `codec` = (encode(src_f32, dst_bf16), decode(src_bf16, dst_f32))
+    replaces the two kernels (the gloo test on CPU tensors)."""
+
+    def __init__(self, bucket_bytes=32 << 20, compress=None, codec=None):
         import torch.distributed as dist
         self.dist = dist
         self.enabled = dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
         self.world = dist.get_world_size() if self.enabled else 1
-        self.bucket = bucket_bytes // 4
+        self.compress = compress if compress in (None, 'bf16') else None
+        self.bucket = bucket_bytes // (2 if self.compress else 4)
+        self.codec = codec or (lambda s, d: H.to_bf16(s, out=d), lambda s, d: H.to_f32(s, out=d))
+        self._stage = {}
+
+    def _staging(self, t):
+        """bf16 twin of the flat buffer `t` is a slice of (same offsets), allocated once per flat buffer."""
+        base = t._base if t._base is not None else t
+        key = (base.data_ptr(), base.numel())
+        if key not in self._stage:
+            self._stage[key] = torch.empty(base.numel(), dtype=torch.bfloat16, device=base.device)
+        off = (t.data_ptr() - base.data_ptr()) // 4
+        return self._stage[key][off:off + t.numel()]
 
     def __call__(self, flat_grad):
         if not self.enabled:
             return 1.0
-        n = flat_grad.numel()
-        handles = []
-        for o in range(0, n, self.bucket):
-            handles.append(self.dist.all_reduce(flat_grad[o:min(o + self.bucket, n)], async_op=True))
-        for h in handles:
-            h.wait()
-        return 1.0 / self.world
+        return self.finish(self.start(flat_grad))
 
     def start(self, flat_grad):
         """Launch the bucketed all-reduce of a slice asynchronously (RCCL runs it on its own stream, ordered after the
@@ -234,11 +245,26 @@ class GradAllReduce(object):
         if not self.enabled:
             return []
         n = flat_grad.numel()
-        return [self.dist.all_reduce(flat_grad[o:min(o + self.bucket, n)], async_op=True) for o in range(0, n, self.bucket)]
+        if n == 0:
+            return []
+        buf = flat_grad
+        pending = None
+        if self.compress:
+            buf = self._staging(flat_grad)
+            self.codec[0](flat_grad, buf)
+            pending = (buf, flat_grad)
+        hs = [(self.dist.all_reduce(buf[o:min(o + self.bucket, n)], async_op=True), None) for o in range(0, n, self.bucket)]
+        if pending is not None:
+            hs.append((None, pending))
+        return hs
 
     def finish(self, handles):
-        for h in handles:
-            h.wait()
+        for h, _ in handles:
+            if h is not None:
+                h.wait()
+        for _, pending in handles:
+            if pending is not None:
+                self.codec[1](pending[0], pending[1])
         return 1.0 / self.world if self.enabled else 1.0
 
     def broadcast(self, flat_params):
@@ -311,6 +337,8 @@ class Config(object):
                                          # the gradient-penalty branch the reference keeps dormant
         self.data_format = 'NHWC'        # main.py:18
         self.sync_bn = False             # data parallel: D's BatchNorm statistics over all ranks
+        self.grad_exchange = None        # None: 'bf16' in 'bf16' mode, fp32 otherwise.  'bf16' = the gradient all-reduce moves
+                                         # bf16 (half the xGMI bytes; fp32 gradients and optimizer unchanged); 'f32' forces fp32
         self.split_backward = None       # None: in data-parallel runs only.  The generator-side backward runs in two
                                          # stages (decoder+critic, then encoder) so that the decoder half of the
                                          # gradient all-reduce overlaps the encoder's backward pass
@@ -405,7 +433,10 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         assert all(id(p) in dec_ids for p in self.G_flat.params[:self._n_dec])
         self._enc_off = self.G_flat.offsets[self._n_dec] if self._n_dec < len(self.G_flat.params) else self.G_flat.numel
         self.g_opt, self.d_opt = get_optimizers(self.wgan_gp, self.G_flat, self.D_flat, self.g_lr, self.d_lr)
-        self.allreduce = GradAllReduce()
+        gx = getattr(self.config, "grad_exchange", None)
+        if gx is None:
+            gx = 'bf16' if getattr(self.config, "compute_dtype", "f32") == "bf16" else 'f32'
+        self.allreduce = GradAllReduce(compress='bf16' if gx == 'bf16' else None)
         self.allreduce.broadcast(self.G_flat.flat)
         self.allreduce.broadcast(self.D_flat.flat)
         if getattr(self.config, "compute_dtype", "f32") == "bf16":
@@ -650,13 +681,17 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         return {"d_loss": d_loss.detach()}
 
     def train_step(self, batch_g, batch_d):
-        """One iteration of the reference loop (trainer.py:336-347, 362-363)."""
+        """One iteration of the reference loop (trainer.py:336-347, 362-363).  `batch_d` is one batch, or a sequence of
+        batches: every `sess.run(d_optim)` of the reference dequeues a fresh batch (trainer.py:340-345, 553-555), so in
+        the wgan / wgan-gp modes the CRITIC_ITERS critic updates of a step see CRITIC_ITERS different batches (a single
+        batch is reused for all of them)."""
         out = {}
         if self.step > 0:
             out.update(self.g_optim(batch_g))
         disc_iters = 1 if self.wgan_gp.MODE in ('dcgan', 'lsgan') else self.wgan_gp.CRITIC_ITERS
-        for _ in range(disc_iters):
-            out.update(self.d_optim(batch_d))
+        many = isinstance(batch_d, (list, tuple))
+        for i in range(disc_iters):
+            out.update(self.d_optim(batch_d[i % len(batch_d)] if many else batch_d))
             if self.wgan_gp.MODE == 'wgan':
                 clip_disc_weights(self.D_flat)
         if self.step % self.config.lr_update_step == self.config.lr_update_step - 1:

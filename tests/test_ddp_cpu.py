@@ -34,7 +34,17 @@ def _worker(rank, world, port, q):
         ar.broadcast(fp.flat)
         fp.grad[:1000].copy_(torch.arange(1000, dtype=torch.float32) * (rank + 1))
         scale = ar(fp.grad)
-        q.put((rank, fp.flat[:1000].detach().numpy().copy(), fp.grad[:1000].numpy().copy(), scale))   # by value
+        exact = fp.grad[:1000].numpy().copy()
+        # bf16 exchange ('bf16' mode): staged through a persistent bf16 twin of the flat buffer, two overlapping slices
+        # in flight at once (the decoder / encoder halves of the generator-side update), widened back into the fp32 buffer
+        enc = lambda s, d: d.copy_(s.to(torch.bfloat16))
+        dec = lambda s, d: d.copy_(s.float())
+        arc = GradAllReduce(bucket_bytes=512, compress='bf16', codec=(enc, dec))
+        fp.grad[:1000].copy_(torch.arange(1000, dtype=torch.float32) * 0.37 * (rank + 1))
+        h = arc.start(fp.grad[:600])
+        h += arc.start(fp.grad[600:])
+        scale_c = arc.finish(h)
+        q.put((rank, fp.flat[:1000].detach().numpy().copy(), exact, scale, fp.grad[:1000].numpy().copy(), scale_c))   # by value
     finally:
         dist.destroy_process_group()
 
@@ -50,11 +60,17 @@ def test_bucketed_allreduce_and_broadcast_world2():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (r0, w0, g0, s0), (r1, w1, g1, s1) = [(r, torch.from_numpy(w), torch.from_numpy(g), sc) for r, w, g, sc in res]
+    (r0, w0, g0, s0, c0, sc0), (r1, w1, g1, s1, c1, sc1) = [(r, torch.from_numpy(w), torch.from_numpy(g), sc, torch.from_numpy(c), scc)
+                                                              for r, w, g, sc, c, scc in res]
     assert torch.equal(w0, w1)                                           # broadcast from rank 0
     expect = torch.arange(1000, dtype=torch.float32) * 3.0               # (1 + 2) * arange
     assert torch.equal(g0, expect) and torch.equal(g1, expect)
     assert s0 == s1 == 0.5                                               # mean = sum * 1/world in Adam
+    # bf16 exchange: every rank ends with the same bf16-valued sums, within bf16 rounding of the exact sum
+    a = torch.arange(1000, dtype=torch.float32) * 0.37
+    want = (a.to(torch.bfloat16) + (2 * a).to(torch.bfloat16)).float()
+    assert torch.equal(c0, c1) and sc0 == sc1 == 0.5
+    assert (c0 - 3 * a).abs().max() <= 2.0 ** -7 * (3 * a).abs().max() and (c0 - want).abs().max() <= 2.0 ** -7 * want.abs().max()
 
 
 def test_allreduce_is_identity_without_process_group():

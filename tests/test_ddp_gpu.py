@@ -1,0 +1,111 @@
+"""Data parallelism end to end on the GPU box: two ranks x B=2 must take the step one process takes on the
+concatenated batch of 4.  MODE='wgan-gp' is used because its critic normalises per sample (LayerNorm, wgan_gp.py:34-38): no
+cross-sample coupling, so the equality holds without SyncBN (with the dcgan critic's BatchNorm the per-rank statistics differ
+from the batch-4 ones: tests/test_syncbn_gpu.py covers that case).  The generator-side backward runs in its two stages with
+the decoder slice's all-reduce in flight under the encoder's backward (trainer._g_backward_decoder / _encoder); the second
+case moves the gradients as bf16 ('bf16' mode's exchange).  Both ranks share the one GPU and talk over gloo (production:
+RCCL, same code)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+B, HID, ZN, LR = 4, 16, 8, 2e-4
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _alpha():
+    return torch.rand(B, generator=torch.Generator().manual_seed(5))
+
+
+def _worker(rank, world, port, q, exchange):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.path.insert(0, ROOT)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from dpig_amd import synthetic
+        from dpig_amd.trainer import Config, DPIG_Encoder_GAN_BodyROI_FgBg
+        dev = torch.device("cuda:0")
+        half = B // world
+        pick = lambda b: {k: v[rank * half:(rank + 1) * half] for k, v in b.items()}
+        np.random.seed(0)
+        tr = DPIG_Encoder_GAN_BodyROI_FgBg(Config(batch_size=half, conv_hidden_num=HID, z_num=ZN, gan_mode='wgan-gp', g_lr=LR,
+                                                  d_lr=LR, grad_exchange=exchange), dev)
+        bg = synthetic.to_device(pick(synthetic.make_batch(B, seed=21)), dev)
+        bd = synthetic.to_device(pick(synthetic.make_batch(B, seed=22)), dev)
+        tr.init_net(bg)
+        assert tr.allreduce.enabled and tr._split() and tr.allreduce.compress == (None if exchange == 'f32' else 'bf16')
+        tr.gp_alpha = _alpha()[rank * half:(rank + 1) * half].to(dev)
+        og = tr.g_optim(bg)
+        od = tr.d_optim(bd)
+        torch.cuda.synchronize()
+        q.put((rank, dict(d_loss=float(od["d_loss"]), g_loss=float(og["g_loss"]),
+                          D=tr.D_flat.flat.detach().cpu().numpy().copy(), G=tr.G_flat.flat.detach().cpu().numpy().copy())))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("exchange", ["f32", "bf16"])
+def test_two_rank_step_equals_single_process_on_the_concatenated_batch(dev, exchange):
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in res:
+        res[r]["D"], res[r]["G"] = torch.from_numpy(res[r]["D"]), torch.from_numpy(res[r]["G"])
+    assert torch.equal(res[0]["D"], res[1]["D"]) and torch.equal(res[0]["G"], res[1]["G"])   # replicas stay in sync
+
+    from dpig_amd import slim, synthetic
+    import dpig_amd.tflib as lib
+    from dpig_amd.trainer import Config, DPIG_Encoder_GAN_BodyROI_FgBg
+    lib.delete_all_params()
+    slim.reset_scopes()
+    np.random.seed(0)
+    tr = DPIG_Encoder_GAN_BodyROI_FgBg(Config(batch_size=B, conv_hidden_num=HID, z_num=ZN, gan_mode='wgan-gp', g_lr=LR, d_lr=LR), dev)
+    bg = synthetic.to_device(synthetic.make_batch(B, seed=21), dev)
+    bd = synthetic.to_device(synthetic.make_batch(B, seed=22), dev)
+    tr.init_net(bg)
+    tr.gp_alpha = _alpha().to(dev)
+    D0, G0 = tr.D_flat.flat.detach().cpu().clone(), tr.G_flat.flat.detach().cpu().clone()
+    og = tr.g_optim(bg)
+    od = tr.d_optim(bd)
+    torch.cuda.synchronize()
+    # each rank reports the mean over its half: their average is the batch-4 mean
+    d_loss = 0.5 * (res[0]["d_loss"] + res[1]["d_loss"])
+    g_loss = 0.5 * (res[0]["g_loss"] + res[1]["g_loss"])
+    assert abs(d_loss - float(od["d_loss"])) < 2e-4 * max(1.0, abs(float(od["d_loss"])))
+    assert abs(g_loss - float(og["g_loss"])) < 2e-4 * max(1.0, abs(float(og["g_loss"])))
+    # Adam's first step moves every weight by ~lr*sign(g): compare the updates where the gradient is not at the rounding
+    # floor (same criterion as tests/test_syncbn_gpu.py); the bf16 exchange rounds the summed gradient to 8 bits, which
+    # only flips signs of gradients that are ~0 relative to their neighbours
+    need = 0.97 if exchange == "f32" else 0.93
+    for name, new, old, ref in (("D", res[0]["D"], D0, tr.D_flat.flat.detach().cpu()),
+                                ("G", res[0]["G"], G0, tr.G_flat.flat.detach().cpu())):
+        close = ((new - old) - (ref - old)).abs() <= 0.05 * LR
+        assert close.float().mean() > need, (name, exchange, close.float().mean())
+    lib.delete_all_params()
+    slim.reset_scopes()
