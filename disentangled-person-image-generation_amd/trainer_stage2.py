@@ -1,4 +1,8 @@
-"""Stage-II appearance-embedding GAN (model 3), mirroring the reference
+"""Stage-II trainers, mirroring the reference `trainer.py`: the appearance-embedding GAN (model 3, below), the pose
+auto-encoder (model 2, `DPIG_PoseRCV_AE_BodyROI`, :626-713) and the pose-embedding GAN (model 4,
+`DPIG_subnetSamplePoseRCV_GAN_BodyROI`, :868-1040) at the end of this file.
+
+Stage-II appearance-embedding GAN (model 3), mirroring the reference
 `DPIG_Encoder_subSampleAppNetFgBg_GAN_BodyROI` (`trainer.py:715-868`):
 
   * the stage-I encoder E is frozen and only runs forward (`:727-741`) -> real embeddings fg [B,224], bg [B,128];
@@ -132,3 +136,205 @@ class DPIG_Encoder_subSampleAppNetFgBg_GAN_BodyROI(object):
             self.d_lr.mul_(0.5)
         self.step += 1
         return out
+
+
+# ======================================================================================================================
+# pose branch of stage II
+# ======================================================================================================================
+def normalise_pose_rcv(pose_rcv, keypoint_num, img_H, img_W):
+    """trainer.py:639-644: (row, col, visibility) pixel triplets -> rows / cols in [-1, 1], flattened [B, 3 K]."""
+    B = pose_rcv.shape[0]
+    p = pose_rcv.reshape(B, keypoint_num, 3).to(torch.float32)
+    R = p[..., 0:1] / float(img_H) * 2.0 - 1
+    C = p[..., 1:2] / float(img_W) * 2.0 - 1
+    return torch.cat([R, C, p[..., 2:3]], dim=-1).reshape(B, -1)
+
+
+class DPIG_PoseRCV_AE_BodyROI(object):
+    """Model 2 (trainer.py:626-713): the pose auto-encoder.  PoseEncoderFCRes (54 -> 32) and PoseDecoderFCRes (32 ->
+    36 coordinates + 18 visibilities through sigmoid / binaryRound, straight-through gradient) under scope `PoseAE`;
+    reconstruct_loss = mean((pose_rcv_norm - G_pose_rcv)^2); Adam(g_lr, beta1 = 0.5) on 20 x that loss over both nets
+    (`_define_loss_optim` :665-667); the loop runs g_optim from step 1 on (:678-680)."""
+
+    def __init__(self, config, device):
+        from .trainer import TFAdam
+        self.config = config
+        self.device = torch.device(device)
+        self.batch_size = config.batch_size
+        self.img_H, self.img_W = config.img_H, config.img_W
+        self.data_format = config.data_format
+        self.keypoint_num = 18
+        self.sample_pose = bool(getattr(config, "sample_pose", False))
+        lib.set_device(self.device)
+        self.g_lr = torch.full((1,), config.g_lr, dtype=torch.float32, device=self.device)
+        self.d_lr = torch.full((1,), config.d_lr, dtype=torch.float32, device=self.device)
+        self._Adam = TFAdam
+        self.step = 0
+        self.built = False
+
+    def autoencode(self, pose_rcv):
+        """-> (pose_rcv_norm [B,54], pose_embs [B,32], G_pose_rcv [B,18,3], variables)."""
+        from . import autograd as A  # noqa: F401
+        B = pose_rcv.shape[0]
+        with slim.variable_scope("PoseAE"):
+            pose_rcv_norm = normalise_pose_rcv(pose_rcv, self.keypoint_num, self.img_H, self.img_W)
+            pose_embs, enc_var = models.PoseEncoderFCRes(pose_rcv_norm, z_num=32, repeat_num=4, hidden_num=512,
+                                                         data_format=self.data_format, activation_fn=slim.leaky_relu,
+                                                         reuse=self.built)
+            if self.sample_pose:                   # sampling new poses at test time (trainer.py:649-650)
+                pose_embs = torch.randn(tuple(pose_embs.shape), device=pose_embs.device) * 0.2
+            coord, visible, dec_var = models.PoseDecoderFCRes(pose_embs, self.keypoint_num, repeat_num=4, hidden_num=512,
+                                                              data_format=self.data_format, activation_fn=slim.leaky_relu,
+                                                              reuse=self.built)
+        G_pose_rcv = torch.cat([coord.reshape(B, self.keypoint_num, 2), visible.unsqueeze(-1)], dim=-1)
+        return pose_rcv_norm, pose_embs, G_pose_rcv, enc_var + dec_var
+
+    def reconstruct_loss(self, pose_rcv_norm, G_pose_rcv):
+        from . import autograd as A
+        diff = (pose_rcv_norm.reshape(-1) - G_pose_rcv.reshape(-1)).contiguous()
+        return A.logit_sq_mean(diff, 0.0)          # mean of squares: one reduction kernel
+
+    def init_net(self, batch):
+        with torch.no_grad():
+            _, _, _, var = self.autoencode(batch["pose_rcv"])
+        self.built = True
+        from . import tfckpt
+        tfckpt.restore_from_config(self.config)
+        self.G_var_pose = var
+        self.G_flat = FlatParams(var)
+        self.g_opt = self._Adam(self.G_flat, self.g_lr, beta1=0.5)      # tf.train.AdamOptimizer(lr, beta1=0.5): beta2 0.999
+        self.allreduce = GradAllReduce()
+        self.allreduce.broadcast(self.G_flat.flat)
+
+    def g_optim(self, batch):
+        self.G_flat.zero_grad()
+        norm, _, G_pose_rcv, _ = self.autoencode(batch["pose_rcv"])
+        loss = self.reconstruct_loss(norm, G_pose_rcv)
+        (loss * 20).backward()
+        self.G_flat.finalize()
+        self.g_opt.step(self.allreduce(self.G_flat.grad))
+        return {"reconstruct_loss": loss.detach(), "G_pose_rcv": G_pose_rcv.detach()}
+
+    def train_step(self, batch):
+        out = {}
+        if self.step > 0:
+            out.update(self.g_optim(batch))
+        else:
+            with torch.no_grad():
+                norm, _, G_pose_rcv, _ = self.autoencode(batch["pose_rcv"])
+                out["reconstruct_loss"] = self.reconstruct_loss(norm, G_pose_rcv)
+        if self.step % self.config.lr_update_step == self.config.lr_update_step - 1:
+            self.g_lr.mul_(0.5)
+            self.d_lr.mul_(0.5)
+        self.step += 1
+        return out
+
+    def G_pose(self, G_pose_rcv):
+        """`coord2channel_simple_rcv` of the decoded keypoints (trainer.py:657): the [B,H,W,18] point maps."""
+        from . import utils
+        return utils.coord2channel_simple_rcv(G_pose_rcv.reshape(G_pose_rcv.shape[0], -1), self.keypoint_num, True,
+                                              self.img_H, self.img_W)
+
+
+class DPIG_subnetSamplePoseRCV_GAN_BodyROI(DPIG_PoseRCV_AE_BodyROI):
+    """Model 4 (trainer.py:868-1040): the pose-embedding GAN.  The pose encoder of the auto-encoder (scope `PoseAE`,
+    frozen: restored from `pretrained_poseAE_path`) turns real poses into embeddings [B,32]; a GaussianFCRes mapper under
+    `PoseGaussian` turns z ~ N(0, 0.2) into fake ones; the critic `Pose_emb_Discriminator.*` (FCDiscriminator) sees the
+    PAIR [real; fake] in one call (:907-909); MODE='wgan' (:873): g = -mean D(fake), d = mean D(fake) - mean D(real),
+    RMSProp, critic clipped to +-0.01 after each of its 5 updates per step (:962-973).  The pose decoder maps the sampled
+    embedding to keypoints (`sample`), which the stage-I generator turns into a person (tester.py)."""
+
+    def __init__(self, config, device):
+        super(DPIG_subnetSamplePoseRCV_GAN_BodyROI, self).__init__(config, device)
+        self.wgan_gp_encoder = WGAN_GP(DATA_DIR='', MODE='wgan', DIM=64, BATCH_SIZE=self.batch_size, ITERS=200000, LAMBDA=10,
+                                       G_OUTPUT_DIM=self.keypoint_num * 3)
+
+    def encode_pose(self, pose_rcv):
+        with torch.no_grad(), slim.variable_scope("PoseAE"):
+            norm = normalise_pose_rcv(pose_rcv, self.keypoint_num, self.img_H, self.img_W)
+            embs, enc_var = models.PoseEncoderFCRes(norm, z_num=32, repeat_num=4, hidden_num=512, data_format=self.data_format,
+                                                    activation_fn=slim.leaky_relu, reuse=self.built)
+        return embs, enc_var
+
+    def mapper(self, z=None):
+        with slim.variable_scope("PoseGaussian"):
+            return models.GaussianFCRes([self.batch_size, 32], 32, repeat_num=4, hidden_num=512, data_format=self.data_format,
+                                        activation_fn=slim.leaky_relu, z=z, device=self.device, reuse=self.built)
+
+    def decode_pose(self, embs):
+        with torch.no_grad(), slim.variable_scope("PoseAE"):
+            coord, visible, dec_var = models.PoseDecoderFCRes(embs, self.keypoint_num, repeat_num=4, hidden_num=512,
+                                                              data_format=self.data_format, activation_fn=slim.leaky_relu,
+                                                              reuse=self.built)
+        B = embs.shape[0]
+        return torch.cat([coord.reshape(B, self.keypoint_num, 2), visible.unsqueeze(-1)], dim=-1), dec_var
+
+    def critic_pair(self, real, fake):
+        pair = torch.cat([real, fake], dim=0)                  # trainer.py:907-910
+        D_z = self.wgan_gp_encoder.FCDiscriminator(pair, input_dim=pair.shape[-1], FC_DIM=512, n_layers=3, name='Pose_emb_')
+        return torch.split(D_z, D_z.shape[0] // 2)
+
+    def init_net(self, batch):
+        real, self.G_var_encoder = self.encode_pose(batch["pose_rcv"])
+        with torch.no_grad():
+            fake, g_var = self.mapper()
+            _, self.G_var_decoder = self.decode_pose(fake)
+            self.critic_pair(real, fake)
+        self.built = True
+        from . import tfckpt
+        tfckpt.restore_from_config(self.config)
+        self.G_var_embs = g_var
+        self.D_var_embs = lib.params_with_name('Pose_emb_Discriminator.')
+        self.G_flat, self.D_flat = FlatParams(self.G_var_embs), FlatParams(self.D_var_embs)
+        self.g_opt, self.d_opt = get_optimizers(self.wgan_gp_encoder, self.G_flat, self.D_flat, self.g_lr, self.d_lr)
+        self.allreduce = GradAllReduce()
+        self.allreduce.broadcast(self.G_flat.flat)
+        self.allreduce.broadcast(self.D_flat.flat)
+
+    def g_optim_embs(self, batch, z=None):
+        self.G_flat.zero_grad()
+        self.D_flat.set_requires_grad(False)
+        real, _ = self.encode_pose(batch["pose_rcv"])
+        fake, _ = self.mapper(z)
+        _, D_neg = self.critic_pair(real, fake)
+        g_loss, _ = gan_loss(self.wgan_gp_encoder, None, D_neg)
+        g_loss.backward()
+        self.D_flat.set_requires_grad(True)
+        self.G_flat.finalize()
+        self.g_opt.step(self.allreduce(self.G_flat.grad))
+        return g_loss.detach()
+
+    def d_optim_embs(self, batch, z=None):
+        self.D_flat.zero_grad()
+        real, _ = self.encode_pose(batch["pose_rcv"])
+        with torch.no_grad():
+            fake, _ = self.mapper(z)
+        D_pos, D_neg = self.critic_pair(real, fake)
+        _, d_loss = gan_loss(self.wgan_gp_encoder, D_pos, D_neg)
+        d_loss.backward()
+        self.D_flat.finalize()
+        self.d_opt.step(self.allreduce(self.D_flat.grad))
+        if self.wgan_gp_encoder.MODE == 'wgan':
+            clip_disc_weights(self.D_flat)
+        return d_loss.detach()
+
+    def train_step(self, batch):
+        """trainer.py:962-973."""
+        out = {}
+        if self.step > 0:
+            out["g_loss_embs"] = self.g_optim_embs(batch)
+        iters = 1 if self.wgan_gp_encoder.MODE in ('dcgan', 'lsgan') else self.wgan_gp_encoder.CRITIC_ITERS
+        for _ in range(iters):
+            out["d_loss_embs"] = self.d_optim_embs(batch)
+        if self.step % self.config.lr_update_step == self.config.lr_update_step - 1:
+            self.g_lr.mul_(0.5)
+            self.d_lr.mul_(0.5)
+        self.step += 1
+        return out
+
+    def sample(self, z=None):
+        """G_pose_rcv of a sampled embedding (trainer.py:895-902): [B,18,3] normalised (row, col, visibility)."""
+        with torch.no_grad():
+            fake, _ = self.mapper(z)
+            rcv, _ = self.decode_pose(fake)
+        return rcv

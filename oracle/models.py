@@ -433,3 +433,33 @@ def pose_decoder_fc_res(P, z, keypoint_num=18, repeat_num=4, hidden_num=512, sco
     coord = _fc(P, sc, x, keypoint_num * 2, None)
     vis_prob = torch.sigmoid(_fc(P, sc, x, keypoint_num, None))
     return coord, torch.round(vis_prob), vis_prob
+
+
+def normalise_pose_rcv(pose_rcv, keypoint_num=18, img_H=128, img_W=64):
+    """trainer.py:639-644."""
+    B = pose_rcv.shape[0]
+    p = pose_rcv.reshape(B, keypoint_num, 3)
+    return torch.cat([p[..., 0:1] / float(img_H) * 2.0 - 1, p[..., 1:2] / float(img_W) * 2.0 - 1, p[..., 2:3]], dim=-1).reshape(B, -1)
+
+
+def pose_ae_loss(P, pose_rcv, img_H=128, img_W=64):
+    """Model 2 (trainer.py:636-661): reconstruct_loss = mean((pose_rcv_norm - G_pose_rcv)^2) with the visibility head's
+    binaryRound as a straight-through op (models.py:97-108: forward round, gradient of the identity)."""
+    B = pose_rcv.shape[0]
+    norm = normalise_pose_rcv(pose_rcv, 18, img_H, img_W)
+    z = pose_encoder_fc_res(P, norm)
+    coord, vis_round, vis_prob = pose_decoder_fc_res(P, z)
+    vis_st = vis_prob + (vis_round - vis_prob).detach()        # straight-through
+    G_pose_rcv = torch.cat([coord.reshape(B, 18, 2), vis_st.unsqueeze(-1)], dim=-1)
+    return ((norm.reshape(B, 18, 3) - G_pose_rcv) ** 2).mean(), z, G_pose_rcv
+
+
+def pose_gan_losses(P, pose_rcv, z, img_H=128, img_W=64):
+    """Model 4 (trainer.py:878-911): wgan losses of the pose-embedding GAN, critic on the pair [real; fake]."""
+    norm = normalise_pose_rcv(pose_rcv, 18, img_H, img_W)
+    real = pose_encoder_fc_res(P, norm).detach()
+    fake = gaussian_fc_res(P, z, 32, 4, 512, scope="PoseGaussian/G_FC")
+    coord, vis_round, _ = pose_decoder_fc_res(P, fake.detach())
+    D_z = fc_discriminator(P, torch.cat([real, fake], 0), 32, name="Pose_emb_")
+    d_real, d_fake = torch.split(D_z, D_z.shape[0] // 2)
+    return -d_fake.mean(), d_fake.mean() - d_real.mean(), fake, real

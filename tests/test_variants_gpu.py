@@ -328,6 +328,106 @@ def test_stage1_bf16_compute_mode(dev):
         H.set_compute("f32")
 
 
+def _pose_rcv(B, seed):
+    g = torch.Generator().manual_seed(seed)
+    r = torch.rand(B, 18, 1, generator=g, dtype=torch.float64) * 127
+    c = torch.rand(B, 18, 1, generator=g, dtype=torch.float64) * 63
+    v = (torch.rand(B, 18, 1, generator=g, dtype=torch.float64) < 0.85).double()
+    return torch.cat([r, c, v], -1).reshape(B, 54)
+
+
+def test_stage2_pose_autoencoder_trainer(dev):
+    """Model 2 (trainer.py:626-713): reconstruction loss of the pose auto-encoder, its gradients (x20, straight-through
+    visibility head) and one TF-Adam(beta1=0.5) step against the oracle."""
+    import dpig_amd.tflib as lib
+    from dpig_amd import slim
+    from dpig_amd.trainer import Config
+    from dpig_amd.trainer_stage2 import DPIG_PoseRCV_AE_BodyROI
+    from oracle import models as OM
+    from oracle import ops as O
+    lib.delete_all_params(); slim.reset_scopes()
+    B, LR = 6, 1e-3
+    rcv = _pose_rcv(B, 3)
+    P = OM.ParamStore(seed=16)
+    loss_o, z_o, G_o = OM.pose_ae_loss(P, rcv)
+    names = list(P.p.keys())
+    grads = dict(zip(names, torch.autograd.grad(loss_o * 20, [P.p[n] for n in names], allow_unused=True)))
+    _load(P, dev)
+    tr = DPIG_PoseRCV_AE_BodyROI(Config(batch_size=B, g_lr=LR), dev)
+    batch = {"pose_rcv": rcv.float().to(dev)}
+    tr.init_net(batch)
+    assert set(lib._params.keys()) == set(P.p.keys()) and len(tr.G_var_pose) == len(names)
+    assert (tr.g_opt.b1, tr.g_opt.b2) == (0.5, 0.999)
+    o0 = tr.train_step(batch)                       # step 0: no update (trainer.py:678-680)
+    assert tr.g_opt.t == 0 and abs(float(o0["reconstruct_loss"]) - loss_o.item()) < 1e-5 * loss_o.item()
+    o1 = tr.train_step(batch)
+    assert tr.g_opt.t == 1 and abs(float(o1["reconstruct_loss"]) - loss_o.item()) < 1e-5 * loss_o.item()
+    assert _rel(o1["G_pose_rcv"], G_o.detach()) < 1e-4
+    for n in names:
+        if grads[n] is None:
+            continue
+        assert _rel(lib._params[n]._dpig_grad, grads[n]) < 2e-3, n
+        p_new, _, _ = O.tf_adam_step(P.p[n].detach(), grads[n], torch.zeros_like(grads[n]), torch.zeros_like(grads[n]), LR, 0.5,
+                                     0.999, 1e-8, 1)
+        big = grads[n].abs() > 1e-3 * grads[n].abs().max()      # (sign-like first step: skip gradients at the rounding floor)
+        assert ((lib._params[n].detach().double().cpu() - p_new).abs()[big]).max().item() < 0.02 * LR, n
+    maps = tr.G_pose(o1["G_pose_rcv"])
+    assert tuple(maps.shape) == (B, 128, 64, 18)
+    lib.delete_all_params(); slim.reset_scopes()
+
+
+def test_stage2_pose_embedding_gan_trainer(dev):
+    """Model 4 (trainer.py:868-1040): frozen pose encoder -> real embeddings, PoseGaussian mapper, critic on the pair
+    [real; fake], wgan losses, RMSProp + clip, loop order; sampled poses decode to keypoints."""
+    import dpig_amd.tflib as lib
+    from dpig_amd import slim
+    from dpig_amd.trainer import Config
+    from dpig_amd.trainer_stage2 import DPIG_subnetSamplePoseRCV_GAN_BodyROI
+    from oracle import models as OM
+    lib.delete_all_params(); slim.reset_scopes()
+    B, LR = 6, 1e-3
+    rcv = _pose_rcv(B, 4)
+    g = torch.Generator().manual_seed(9)
+    z = torch.randn(B, 32, generator=g, dtype=torch.float64) * 0.2
+    P = OM.ParamStore(seed=17)
+    g_ref, d_ref, fake_o, real_o = OM.pose_gan_losses(P, rcv, z)
+    gnames = [n for n in P.p if n.startswith("PoseGaussian/")]
+    dnames = [n for n in P.p if "Pose_emb_Discriminator." in n]
+    gg = dict(zip(gnames, torch.autograd.grad(g_ref, [P.p[n] for n in gnames], retain_graph=True)))
+    dg = dict(zip(dnames, torch.autograd.grad(d_ref, [P.p[n] for n in dnames])))
+    _load(P, dev)
+    tr = DPIG_subnetSamplePoseRCV_GAN_BodyROI(Config(batch_size=B, g_lr=LR, d_lr=LR), dev)
+    batch = {"pose_rcv": rcv.float().to(dev)}
+    tr.init_net(batch)
+    assert set(lib._params.keys()) == set(P.p.keys())
+    assert sorted(p.dpig_name for p in tr.G_flat.params) == sorted(gnames) and sorted(p.dpig_name for p in tr.D_flat.params) == sorted(dnames)
+    zz = z.float().to(dev)
+    real, _ = tr.encode_pose(batch["pose_rcv"])
+    assert _rel(real, real_o) < 1e-4
+    d_loss = tr.d_optim_embs(batch, z=zz)
+    assert abs(d_loss.item() - d_ref.item()) < 1e-4 * max(abs(d_ref.item()), 1e-3)
+    for n in dnames:
+        assert _rel(lib._params[n]._dpig_grad, dg[n]) < 2e-3, n
+        p_new, _, _ = OM.tf_rmsprop_step(P.p[n].detach(), dg[n], torch.ones_like(dg[n]), torch.zeros_like(dg[n]), LR)
+        assert (lib._params[n].detach().double().cpu() - p_new.clamp(-0.01, 0.01)).abs().max().item() < 2e-5, n
+    with torch.no_grad():
+        for n in dnames:
+            lib._params[n].copy_(P.p[n].to(torch.float32))
+    g_loss = tr.g_optim_embs(batch, z=zz)
+    assert abs(g_loss.item() - g_ref.item()) < 1e-4 * max(abs(g_ref.item()), 1e-3)
+    for n in gnames:
+        assert _rel(lib._params[n]._dpig_grad, gg[n]) < 2e-3, n
+    t_g, t_d = tr.g_opt.t, tr.d_opt.t
+    out = tr.train_step(batch)                      # step 0: 5 clipped critic updates, no mapper update
+    assert "g_loss_embs" not in out and tr.d_opt.t == t_d + 5 and tr.g_opt.t == t_g
+    out = tr.train_step(batch)
+    assert "g_loss_embs" in out and tr.g_opt.t == t_g + 1 and tr.d_opt.t == t_d + 10
+    assert float(tr.D_flat.flat.abs().max()) <= 0.01 + 1e-9
+    rcv_s = tr.sample(zz)
+    assert tuple(rcv_s.shape) == (B, 18, 3) and set(rcv_s[..., 2].unique().tolist()) <= {0.0, 1.0}
+    lib.delete_all_params(); slim.reset_scopes()
+
+
 @pytest.mark.parametrize("model", ["market", "df256"])
 def test_stage1_bf16_storage_mode(dev, model):
     """Config(compute_dtype='bf16') (BASELINE configs 3-5): activations, their gradients and the filter shadows stored
