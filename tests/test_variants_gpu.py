@@ -545,3 +545,51 @@ def test_inference_harness(dev):
     assert torch.equal(o1["embs"][0, :224], o1["embs"][1, :224]) and not torch.equal(o1["embs"][0, 224:], o1["embs"][1, 224:])
     assert float(o1["G"].min()) >= 0.0 and float(o1["G"].max()) <= 255.0
     assert set(np.unique(o1["G_pose_rcv"][..., 2].cpu().numpy())) <= {0.0, 1.0}       # binaryRound visibilities
+
+
+def test_inference_harness_against_oracle(dev):
+    """tester.py:256-417 with every sampler on (appearance from the two Gaussian mappers, pose from the PoseGaussian
+    mapper through the pose decoder), fixed noise: the harness's embedding, decoded keypoints, rasterised pose maps,
+    generated image and critic score against the ORACLE's graph of the same chain (not against the trainer's own path)."""
+    import dpig_amd.tflib as lib
+    from dpig_amd import slim, synthetic
+    from dpig_amd.tester import DPIG_FourNetsFgBg_testOnly
+    from dpig_amd.trainer import Config
+    from oracle import models as OM
+    from oracle import ops as O
+    lib.delete_all_params(); slim.reset_scopes()
+    B, HID, ZN = 2, 16, 8
+    batch_np = synthetic.make_batch(B, seed=43)
+    ob = OM.batch_to_torch(batch_np)
+    rcv = _pose_rcv(B, 6)
+    g = torch.Generator().manual_seed(10)
+    z_fg = torch.randn(B, 224, generator=g, dtype=torch.float64) * 0.2
+    z_bg = torch.randn(B, 128, generator=g, dtype=torch.float64) * 0.2
+    z_pose = torch.randn(B, 32, generator=g, dtype=torch.float64) * 0.2
+    P = OM.ParamStore(seed=18)
+    with torch.no_grad():
+        norm = OM.normalise_pose_rcv(rcv)
+        OM.pose_encoder_fc_res(P, norm)                                          # (exists in the graph; unused when sampling)
+        pose_e = OM.gaussian_fc_res(P, z_pose, 32, 4, 512, scope="PoseGaussian/G_FC")
+        coord, vis, _ = OM.pose_decoder_fc_res(P, pose_e)
+        G_pose_rcv = torch.cat([coord.reshape(B, 18, 2), vis.unsqueeze(-1)], -1)
+        pose_map = O.tf_poseInflate(O.coord2channel_simple_rcv(G_pose_rcv.reshape(B, -1), 18, True, 128, 64), 18, 4, 128, 64)
+        OM.encoder_fgbg(P, ob["x"], ob["mask_r6"], ob["part_bbox"], ob["part_vis"], 7, 32, 5, HID)
+        fg = OM.gaussian_fc_res(P, z_fg, 224, 4, 512, scope="Gaussian_FC_Fg/G_FC")
+        bg = OM.gaussian_fc_res(P, z_bg, 128, 4, 256, scope="Gaussian_FC_Bg/G_FC")
+        embs = torch.cat([fg, bg], -1)
+        embs_rep = embs.reshape(B, 1, 1, -1).expand(B, 128, 64, embs.shape[1])
+        G, _ = OM.generator_uae(P, embs_rep, pose_map, 3, ZN, 5, HID)
+        score = OM.dcgan_discriminator(P, G, "dcgan")
+    _load(P, dev)
+    te = DPIG_FourNetsFgBg_testOnly(Config(batch_size=B, conv_hidden_num=HID, z_num=ZN), dev, sample_app=True, sample_pose=True,
+                                    sample_pose_embedding=True)
+    out = te.run(synthetic.to_device(batch_np, dev), rcv.float().to(dev), z_fg=z_fg.float().to(dev), z_bg=z_bg.float().to(dev),
+                 z_pose=z_pose.float().to(dev))
+    assert set(lib._params.keys()) == set(P.p.keys())
+    assert _rel(out["embs"], embs) < 1e-4
+    assert _rel(out["G_pose_rcv"][..., :2], G_pose_rcv[..., :2]) < 1e-4 and torch.equal(out["G_pose_rcv"][..., 2].cpu().double(), G_pose_rcv[..., 2])
+    assert torch.equal(out["pose_map"].cpu().double(), pose_map)
+    assert (out["G"].double().cpu() - torch.clamp((G + 1) * 127.5, 0, 255)).abs().max().item() < 1e-3 * 255
+    assert _rel(out["G_dis_score"], score.reshape(B, -1).mean(1)) < 1e-3
+    lib.delete_all_params(); slim.reset_scopes()
