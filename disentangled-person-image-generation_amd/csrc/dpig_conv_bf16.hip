@@ -29,6 +29,16 @@
 #include "dpig_conv_plan.h"
 #include "dpig_thin.h"
 
+#ifdef DPIG_TRACE   // dev aid (scripts/ubench/trace_bf16.py; never in the shipped build): s_memtime stamps of one lane per wave
+__device__ unsigned long long dpig_bf_trace[256 * 4 * 160];
+extern "C" int dpig_debug_bf_trace_read(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dpig_bf_trace), sizeof(unsigned long long) * n);
+}
+#define BF_STAMP(slot) do { if (trace_on && trace_n < 160) dpig_bf_trace[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 160 + trace_n++] = ((unsigned long long)(slot) << 56) | (__builtin_amdgcn_s_memtime() & 0x00ffffffffffffffull); } while (0)
+#else
+#define BF_STAMP(slot) do { } while (0)
+#endif
+
 namespace dpig {
 namespace bfk {
 
@@ -71,6 +81,7 @@ struct BGParams {
     int tap_nb, oy0, oys, ox0, oxs, w0, wa, wb;     // affine tap family, as GGParams in dpig_conv.hip
     unsigned a_bytes, b_bytes;
     unsigned mul_hrwr, shr_hrwr, mul_wr, shr_wr;
+    int tiles_x, tiles_y;  // bh_kernel: 2-D output patches per image
 };
 
 __device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned shr) {
@@ -167,8 +178,11 @@ __device__ __forceinline__ void epi8(const BGParams& p, int row, int col, float 
 }
 
 // ---- epilogue shared by the k-loop variants: accumulators -> LDS (fp32) -> 16-byte row-contiguous global accesses ----
+// `rowof(rl)` maps tile row rl (0..127) to the GEMM row it holds, or -1 when the tile row is padding: m0 + rl for the
+// linear row tiles of bg_kernel, the NHW pixel index of the 2-D patch position for the halo tiles of bh_kernel.
+template <typename RowOf>
 __device__ __forceinline__ void bg_epilogue(const BGParams& p, char* smem, f32x16 (&acc)[2][2], int m0, int n0, int split,
-                                            int tid, int wrow, int wcol, int l31, int half) {
+                                            int tid, int wrow, int wcol, int l31, int half, RowOf rowof) {
     float* Cs = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
@@ -212,26 +226,26 @@ __device__ __forceinline__ void bg_epilogue(const BGParams& p, char* smem, f32x1
         // advancing by 16 rows, no per-element switches): the co-resident workgroup is streaming MFMAs meanwhile
         const float slope = (p.act == DPIG_ACT_NONE) ? 1.f : ((p.act == DPIG_ACT_RELU) ? 0.f : p.alpha);
         auto run = [&](auto HAS_RES, auto RES_POST, auto HAS_MASK, auto HAS_D2) {
-            const long r0 = (long)(m0 + rl0);
-            bf16_t* dp = p.D + r0 * p.ldd + col;
-            const bf16_t* rp = HAS_RES ? p.res + r0 * p.ldres + col : nullptr;
-            const bf16_t* mp = HAS_MASK ? p.mask + r0 * p.ldmask + col : nullptr;
-            bf16_t* d2 = HAS_D2 ? p.D2 + r0 * p.ldd2 + col : nullptr;
 #pragma unroll 2
             for (int it = 0; it < 8; ++it) {
-                if (m0 + rl0 + 16 * it >= p.M) break;
+                const long r0 = rowof(rl0 + 16 * it);
+                if (r0 < 0) continue;
+                bf16_t* dp = p.D + r0 * p.ldd + col;
+                const bf16_t* rp = HAS_RES ? p.res + r0 * p.ldres + col : nullptr;
+                const bf16_t* mp = HAS_MASK ? p.mask + r0 * p.ldmask + col : nullptr;
+                bf16_t* d2 = HAS_D2 ? p.D2 + r0 * p.ldd2 + col : nullptr;
                 float v[8], rv[8];
                 load_c(rl0 + 16 * it, v);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += bv[e];
-                if (HAS_RES) unpack8(*reinterpret_cast<const uint4*>(rp + (long)(16 * it) * p.ldres), rv);
+                if (HAS_RES) unpack8(*reinterpret_cast<const uint4*>(rp), rv);
                 if (HAS_RES && !RES_POST) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += rv[e];
                 }
                 if (HAS_MASK) {
                     float mv[8];
-                    unpack8(*reinterpret_cast<const uint4*>(mp + (long)(16 * it) * p.ldmask), mv);
+                    unpack8(*reinterpret_cast<const uint4*>(mp), mv);
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] *= (mv[e] > 0.f) ? 1.f : slope;
                 } else {
@@ -240,14 +254,14 @@ __device__ __forceinline__ void bg_epilogue(const BGParams& p, char* smem, f32x1
                 }
                 if (HAS_D2) {
                     const uint4 o2 = pack8(v);
-                    *reinterpret_cast<uint4*>(d2 + (long)(16 * it) * p.ldd2) = o2;
+                    *reinterpret_cast<uint4*>(d2) = o2;
                     if (HAS_RES && RES_POST) unpack8(o2, v);
                 }
                 if (HAS_RES && RES_POST) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) v[e] += rv[e];
                 }
-                *reinterpret_cast<uint4*>(dp + (long)(16 * it) * p.ldd) = pack8(v);
+                *reinterpret_cast<uint4*>(dp) = pack8(v);
             }
         };
         using T = std::true_type; using F = std::false_type;
@@ -260,10 +274,11 @@ __device__ __forceinline__ void bg_epilogue(const BGParams& p, char* smem, f32x1
 #pragma unroll 2
     for (int it = 0; it < 8; ++it) {
         const int rl = rl0 + 16 * it;
-        if (m0 + rl >= p.M) break;
+        const int row = rowof(rl);
+        if (row < 0) continue;
         float v[8];
         load_c(rl, v);
-        epi8(p, m0 + rl, col, v, bv);
+        epi8(p, row, col, v, bv);
     }
 }
 
@@ -277,6 +292,13 @@ __device__ __forceinline__ void bg_body(const BGParams& p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wrow = (wave >> 1) * 64, wcol = (wave & 1) * 64;
     const int l31 = lane & 31, half = lane >> 5;
+#ifdef DPIG_KO_DMA
+    int ko_n = 0;
+#endif
+#ifdef DPIG_TRACE
+    const bool trace_on = ((int)blockIdx.x < 256) && (blockIdx.z == 0) && (lane == 0);
+    int trace_n = 0;
+#endif
 
     const int tile = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
     const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
@@ -376,33 +398,53 @@ __device__ __forceinline__ void bg_body(const BGParams& p) {
     auto load_frag = [&](int stage, int ks, bf16x8 (&a)[2], bf16x8 (&b)[2]) {
         const char* ab = fa_base + stage * STAGE_B;
         const char* bb = fb_base + stage * STAGE_B;
+#ifdef DPIG_KO_LDS      // knock-out experiment (scripts/ubench/knockout.sh): half the fragment reads, wrong results
+        a[0] = *reinterpret_cast<const bf16x8*>(ab + so[ks]); a[1] = a[0];
+        b[0] = *reinterpret_cast<const bf16x8*>(bb + so[ks]); b[1] = b[0];
+#else
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) a[mb] = *reinterpret_cast<const bf16x8*>(ab + mb * 32 * ROWB + so[ks]);
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) b[nb] = *reinterpret_cast<const bf16x8*>(bb + nb * 32 * ROWB + so[ks]);
+#endif
     };
     // One k-tile: the first fragments are requested right behind the barrier, the DMA of the NEXT tile (address
     // arithmetic + 8 LDS-DMA instructions) is issued under their latency, the fragments of k-step ks+1 are read under the
     // MFMAs of ks.  The stage the DMA fills was last read before the barrier every wave has passed.
     auto ktile = [&](int stage, bool more) {
+        BF_STAMP(1);
         load_frag(stage, 0, fa[0], fb[0]);
         __builtin_amdgcn_sched_barrier(0);
+#ifdef DPIG_KO_DMA      // knock-out: only the first tiles are fetched
+        if (more && ko_n++ < 1) issue(stage ^ 1);
+#else
         if (more) issue(stage ^ 1);
+#endif
+        BF_STAMP(2);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             if (ks + 1 < 4) load_frag(stage, ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
+#ifdef DPIG_KO_MFMA     // knock-out: one MFMA instead of four per k-step
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][0] + fa[ks & 1][1], fb[ks & 1][0] + fb[ks & 1][1], acc[0][0], 0, 0, 0);
+#else
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb)
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][mb], fb[ks & 1][nb], acc[mb][nb], 0, 0, 0);
+#endif
             __builtin_amdgcn_sched_barrier(0);
         }
+        BF_STAMP(3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        BF_STAMP(4);
+#ifndef DPIG_KO_BAR     // knock-out: no workgroup barrier per k-tile (races)
         __syncthreads();
+#endif
     };
 
+    BF_STAMP(0);
     if (kt_begin < kt_end) {
         issue(0);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -416,7 +458,10 @@ __device__ __forceinline__ void bg_body(const BGParams& p) {
         if (kt < kt_end) ktile(0, false);
     }
 
-    bg_epilogue(p, smem, acc, m0, n0, split, tid, wrow, wcol, l31, half);
+    BF_STAMP(5);
+    bg_epilogue(p, smem, acc, m0, n0, split, tid, wrow, wcol, l31, half,
+                [&](int rl) { return (m0 + rl < p.M) ? m0 + rl : -1; });
+    BF_STAMP(6);
 }
 
 __global__ __launch_bounds__(256, 2) void bg_kernel(const BGParams p) { bg_body(p); }
@@ -426,6 +471,169 @@ __global__ __launch_bounds__(256, 2) void bg_multi_kernel(const BGMulti m) {
     const BGParams& p = m.q[blockIdx.y];
     if ((int)blockIdx.x >= p.mtiles * p.ntiles || (int)blockIdx.z >= p.nsplit) return;
     bg_body(p);
+}
+
+// ------------------------------------------------------------------------------------------------
+// 3x3 stride-1 SAME convolutions (forward, and the stride-1 dgrad = the same window with flipped taps): ~90 % of the
+// model's FLOPs.  bg_kernel re-fetches its A tile for each of the 9 taps -- 9 x 16 KB per 64-channel chunk -- and measures
+// L2 -> LDS bound (the L2 serves ~60 % of its peak request rate while the matrix pipe is ~50 % busy).  Here the 128 output
+// pixels of a workgroup are a 2-D patch (8 x 16 or 16 x 8) of ONE image and the input patch WITH ITS HALO ((8+2) x (16+2)
+// = 180 pixels x 64 channels = 23 KB) is staged once per channel chunk; the 9 taps read shifted windows of it straight
+// into MFMA A fragments (an address offset per tap), only the 16 KB filter tile streams per (tap, chunk): L2 -> LDS bytes
+// per chunk 288 KB -> 167 KB, DMA instructions 288 -> 167.  The halo of the NEXT chunk is fetched one 1 KB piece per
+// wave per tap under taps 0..5 of the current chunk, so the per-tile DMA load stays even (18.6 KB).
+// LDS: 2 halo buffers (184 pixel rows of 128 B) + 2 filter tiles = 79872 B; two workgroups per CU.
+// Bank conflicts: pixel (hy, hx) of the halo keeps its 16-byte chunk c at slot c ^ ((hx >> 1) + (TW / 2) hy) & 7: the 16
+// lanes of a ds_read_b128 group (consecutive hx of one or two patch rows) then hit 16 different 16-byte bank groups
+// for every tap shift.
+template <int TWL>   // log2 of the patch width: 4 (8 rows x 16) or 3 (16 rows x 8)
+__global__ __launch_bounds__(256, 2) void bh_kernel(const BGParams p) {
+    constexpr int TW = 1 << TWL, TH = TM / TW, P = TW + 2, NPIX = (TH + 2) * P;       // 180 halo pixels
+    constexpr int HROWS = 184, HALO_B = HROWS * ROWB;                                 // 23 DMA pieces of 8 pixels
+    constexpr int HSMEM = 2 * HALO_B + 2 * TILE_B;                                    // 79872
+    static_assert(NPIX <= HROWS && HSMEM >= SMEM_BYTES, "LDS plan");
+    __shared__ __attribute__((aligned(16))) char smem[HSMEM];
+    char* const bbuf = smem + 2 * HALO_B;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wrow = (wave >> 1) * 64, wcol = (wave & 1) * 64;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    const int tile = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
+    const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+    const int n0 = nt * TN;
+    const int per_img = p.tiles_x * p.tiles_y;
+    const int img = mt / per_img;
+    const int trem = mt - img * per_img;
+    const int tyi = trem / p.tiles_x;
+    const int y0 = tyi * TH, x0 = (trem - tyi * p.tiles_x) * TW;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes);
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.B, p.b_bytes);
+    const bool ktail = (p.Cs & (TK - 1)) != 0;
+
+    // ---- halo DMA roles: piece i = wave + 4 q (q = 0..5, i < 23) covers halo pixels 8 i .. 8 i + 7; lane -> (pixel, slot)
+    int h_voff[6], h_gran[6];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        const int hp = 8 * (wave + 4 * q) + (lane >> 3);
+        const int hy = hp / P, hx = hp - hy * P;
+        const int y = y0 - 1 + hy, x = x0 - 1 + hx;
+        const bool ok = (hp < NPIX) & ((unsigned)y < (unsigned)p.Hs) & ((unsigned)x < (unsigned)p.Ws);
+        const int g = (lane & 7) ^ (((hx >> 1) + (TW / 2) * hy) & 7);
+        h_gran[q] = g;
+        h_voff[q] = ok ? ((((img * p.Hs + y) * p.Ws + x) * p.lda) + g * 8) * 2 : (int)OOB;
+    }
+    auto issue_halo = [&](int q, int buf, int c0) {            // piece (wave + 4 q) of the chunk starting at channel c0
+        if (wave + 4 * q >= 23) return;                        // (wave-uniform)
+        int v = h_voff[q];
+        if (ktail) v = (c0 + h_gran[q] * 8 < p.Cs) ? v : (int)OOB;
+        dma16(rsA, v, c0 * 2, smem + buf * HALO_B + (wave + 4 * q) * 8 * ROWB);
+    };
+    // ---- filter DMA roles (as bg_kernel): instruction j fills tile rows 32 j + 8 wave .. +7 ------------------------
+    const int lrow = 8 * wave + (lane >> 3);
+    const int chunk = (lane & 7) ^ ((lrow >> 1) & 7);
+    int b_voff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int nn = n0 + lrow + 32 * j;
+        b_voff[j] = (nn < p.Ncols) ? (nn * p.Cs + chunk * 8) * 2 : (int)OOB;
+    }
+    auto issue_b = [&](int stage, int tap, int c0) {
+        const int ta = tap / 3, tb = tap - ta * 3;
+        const int sB = ((p.w0 + ta * p.wa + tb * p.wb) * p.Ncols * p.Cs + c0) * 2;
+        char* dst = bbuf + stage * TILE_B + (8 * wave) * ROWB;
+        const bool kok = !ktail | (c0 + chunk * 8 < p.Cs);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dma16(rsB, kok ? b_voff[j] : (int)OOB, sB, dst + 32 * j * ROWB);
+    };
+
+    // ---- fragment addressing ---------------------------------------------------------------------------------------
+    int f_ty[2], f_tx[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        const int r = wrow + mb * 32 + l31;
+        f_ty[mb] = r >> TWL;
+        f_tx[mb] = r & (TW - 1);
+    }
+    const int fsw = (l31 >> 1) & 7;
+    const char* fb_base = bbuf + (wcol + l31) * ROWB;
+    int sob[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) sob[ks] = ((2 * ks + half) ^ fsw) * 16;
+
+    bf16x8 fa[2][2], fb[2][2];
+    const int nch = p.cchunks;
+    const int ktiles = 9 * nch;
+    // one k-tile = (chunk c, tap): A fragments from the resident halo of chunk c shifted by the tap, B from bbuf[stage]
+    auto ktile = [&](int kt, int stage) {
+        const int c = kt / 9, tap = kt - c * 9;
+        const int ta = tap / 3, tb = tap - ta * 3;
+        const int dyy = 1 + p.oy0 + ta * p.oys, dxx = 1 + p.ox0 + tb * p.oxs;       // halo shift of this tap (0..2)
+        const char* hb = smem + (c & 1) * HALO_B;
+        const char* bb = fb_base + stage * TILE_B;
+        const char* abase[2];
+        int sw[2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            const int hy = f_ty[mb] + dyy, hx = f_tx[mb] + dxx;
+            abase[mb] = hb + (hy * P + hx) * ROWB;
+            sw[mb] = ((hx >> 1) + (TW / 2) * hy) & 7;
+        }
+        auto load_frag = [&](int ks, bf16x8 (&a)[2], bf16x8 (&b)[2]) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb) a[mb] = *reinterpret_cast<const bf16x8*>(abase[mb] + (((2 * ks + half) ^ sw[mb]) << 4));
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) b[nb] = *reinterpret_cast<const bf16x8*>(bb + nb * 32 * ROWB + sob[ks]);
+        };
+        load_frag(0, fa[0], fb[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (kt + 1 < ktiles) {
+            const int kn = kt + 1, cn = kn / 9;
+            issue_b(stage ^ 1, kn - cn * 9, cn * TK);
+        }
+        if (tap < 6 && c + 1 < nch) issue_halo(tap, (c + 1) & 1, (c + 1) * TK);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks + 1 < 4) load_frag(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][mb], fb[ks & 1][nb], acc[mb][nb], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+
+#pragma unroll
+    for (int q = 0; q < 6; ++q) issue_halo(q, 0, 0);
+    issue_b(0, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int kt = 0;
+    for (; kt + 1 < ktiles; kt += 2) {
+        ktile(kt, 0);
+        ktile(kt + 1, 1);
+    }
+    if (kt < ktiles) ktile(kt, 0);
+
+    bg_epilogue(p, smem, acc, 0, n0, 0, tid, wrow, wcol, l31, half, [&](int rl) {
+        const int y = y0 + (rl >> TWL), x = x0 + (rl & (TW - 1));
+        return (y < p.Hs && x < p.Ws) ? (img * p.Hs + y) * p.Ws + x : -1;
+    });
 }
 
 // split-K second pass: sum the fp32 partials in split order (deterministic), run the fused epilogue, write bf16
@@ -909,9 +1117,44 @@ static int reduce_blocks(const BGParams& p) {
     int blocks = cdiv(total8, 256);
     return blocks > 8 * kNumCU ? 8 * kNumCU : blocks;
 }
+// 2-D patch plan of the halo kernel: returns log2(patch width) (4 or 3) or 0 when the layer should stay on bg_kernel
+// (not a 3x3 stride-1 window on a same-size grid, too small to fill the chip without split-K, or patches would be
+// mostly padding).  DPIG_BF16_HALO=0 disables it (A/B measurements).
+static int halo_plan(const BGParams& p, int nimg, int* tx, int* ty) {
+    static int enabled = -1;
+    if (enabled < 0) { const char* e = getenv("DPIG_BF16_HALO"); enabled = (e && !strcmp(e, "0")) ? 0 : 1; }
+    if (!enabled || p.ntaps != 9 || p.tap_nb != 3 || p.sr != 1 || !p.identity_rows || p.replicate) return 0;
+    if (p.Hr != p.Hs || p.Wr != p.Ws || p.oys * p.oys != 1 || p.oxs * p.oxs != 1) return 0;
+    if (1 + p.oy0 < 0 || 1 + p.oy0 + 2 * p.oys < 0 || 1 + p.oy0 > 2 || 1 + p.oy0 + 2 * p.oys > 2) return 0;
+    if (1 + p.ox0 < 0 || 1 + p.ox0 + 2 * p.oxs < 0 || 1 + p.ox0 > 2 || 1 + p.ox0 + 2 * p.oxs > 2) return 0;
+    int best = 0;
+    double best_u = 0.0;
+    for (int twl = 4; twl >= 3; --twl) {
+        const int tw = 1 << twl, th = TM / tw;
+        const int nx = cdiv(p.Ws, tw), ny = cdiv(p.Hs, th);
+        const double u = (double)p.Hs * p.Ws / ((double)nx * tw * ny * th);
+        if (u > best_u + 1e-9) { best_u = u; best = twl; *tx = nx; *ty = ny; }
+    }
+    if (best_u < 0.74) return 0;
+    const long tiles = (long)nimg * (*tx) * (*ty) * cdiv(p.Ncols, TN);
+    if (tiles < 2 * kNumCU) return 0;                          // small layers: bg_kernel with split-K fills the chip
+    return best;
+}
+
 static int launch_bg(BGParams& p, int nimg, long filter_elems, hipStream_t st) {
     int rc = prepare_bg(p, nimg, filter_elems);
     if (rc) return rc;
+    int tx = 0, ty = 0;
+    const int twl = halo_plan(p, nimg, &tx, &ty);
+    if (twl) {
+        p.tiles_x = tx; p.tiles_y = ty;
+        p.mtiles = nimg * tx * ty;
+        p.nsplit = 1; p.tiles_per_split = p.ktiles;
+        dim3 hgrid(p.mtiles * p.ntiles), hblock(256);
+        if (twl == 4) hipLaunchKernelGGL((bh_kernel<4>), hgrid, hblock, 0, st, p);
+        else hipLaunchKernelGGL((bh_kernel<3>), hgrid, hblock, 0, st, p);
+        return check_launch("bh_kernel");
+    }
     dim3 grid(p.mtiles * p.ntiles, 1, p.nsplit), block(256);
     hipLaunchKernelGGL(bg_kernel, grid, block, 0, st, p);
     rc = check_launch("bg_kernel");

