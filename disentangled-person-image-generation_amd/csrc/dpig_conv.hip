@@ -337,11 +337,179 @@ __device__ __forceinline__ void gg_mainloop_bf16(const GGParams& p, char* lds, f
     }
 }
 
+// ---- split-bf16 variant of the k loop (DpigConvDesc.compute = DPIG_COMPUTE_BF16X3): fp32 accuracy class on the bf16 pipe ----
+// Tensors stay fp32 in HBM.  On its way into LDS every operand value v is split into two bf16 terms, hi = bf16(v) and
+// lo = bf16(v - hi) (v - hi is exact in fp32; hi + lo carries 16 significand bits, |v - hi - lo| <= 2^-18 |v|), and each
+// 16-deep k-step issues THREE v_mfma_f32_32x32x16_bf16 into the same fp32 accumulator: a_hi b_lo + a_lo b_hi + a_hi b_hi
+// (the a_lo b_lo term, <= 2^-18 of the product, is dropped).  Products of bf16 numbers are exact in fp32, so the result
+// differs from the fp32 pipe's by the operand truncation only: measured <= 5e-6 max|ref| on random-sign data (tests hold
+// it to the same 2e-5 max|ref| bar as the exact path) at 3/16 of the fp32 pipe's matrix cycles per flop.
+// k-tile = 32 (the fp32 loop's: same split-K plans, same workspace); an LDS row is [32 hi | 32 lo] bf16 = 128 B + 16 pad,
+// i.e. the ROWB / TILEB image of the bf16 loop, fragments are ds_read_b128 (8 consecutive k per lane) from either half.
+constexpr int BKS = 32;
+__device__ __forceinline__ void split_pair(float a, float b, unsigned& hi, unsigned& lo) {
+    hi = pack_bf16(a, b);
+    lo = pack_bf16(a - __uint_as_float(hi << 16), b - __uint_as_float(hi & 0xffff0000u));
+}
+__device__ __forceinline__ void split_store4(char* dst, float a, float b, float c, float d) {   // 4 consecutive k of one row
+    unsigned h0, l0, h1, l1;
+    split_pair(a, b, h0, l0);
+    split_pair(c, d, h1, l1);
+    *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
+    *reinterpret_cast<uint2*>(dst + 64) = make_uint2(l0, l1);
+}
+struct SplitFrag { bf16x8 ah[2], al[2], bh[2], bl[2]; };
+__device__ __forceinline__ void split_load_frag(const char* As, const char* Bs, int ks, int wrow, int wcol, int l31, int half,
+                                                SplitFrag& f) {
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        const char* a = As + (wrow + mb * 32 + l31) * ROWB + ks * 32 + half * 16;
+        f.ah[mb] = *reinterpret_cast<const bf16x8*>(a);
+        f.al[mb] = *reinterpret_cast<const bf16x8*>(a + 64);
+    }
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const char* b = Bs + (wcol + nb * 32 + l31) * ROWB + ks * 32 + half * 16;
+        f.bh[nb] = *reinterpret_cast<const bf16x8*>(b);
+        f.bl[nb] = *reinterpret_cast<const bf16x8*>(b + 64);
+    }
+}
+__device__ __forceinline__ void split_mfma(const SplitFrag& f, f32x16 (&acc)[2][2]) {
+    // the two cross terms first, the leading term last; the same accumulator is touched every 4th instruction
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mb], f.bl[nb], acc[mb][nb], 0, 0, 0);
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al[mb], f.bh[nb], acc[mb][nb], 0, 0, 0);
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+            acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mb], f.bh[nb], acc[mb][nb], 0, 0, 0);
+}
+template <bool B_ROWK>
+__device__ __forceinline__ void gg_mainloop_split(const GGParams& p, char* lds, f32x16 (&acc)[2][2], int m0, int n0,
+                                                  int kt_begin, int kt_end, int tid, int wrow, int wcol, int l31,
+                                                  int half) {
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes);
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.B, p.b_bytes);
+    const int kq = tid & 7;                                   // 4-float k group of the row-major operands
+    unsigned a_rowoff[4];
+    int a_iy0[4], a_ix0[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int m = m0 + (tid >> 3) + 32 * i;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int n = fast_div(mm, p.mul_hrwr, p.shr_hrwr);
+        const int rem = mm - n * p.HrWr;
+        const int r = fast_div(rem, p.mul_wr, p.shr_wr);
+        const int c = rem - r * p.Wr;
+        a_iy0[i] = ok ? r * p.sr : -(1 << 24);
+        a_ix0[i] = c * p.sr;
+        a_rowoff[i] = (unsigned)((((n * p.Hs + r * p.sr) * p.Ws + c * p.sr) * p.lda + kq * 4) * 4);
+    }
+    unsigned b_off[4];
+    bool b_ok[4];
+    const int nq = tid & 31, kgrp = tid >> 5;                 // fwd filter patch: 4 columns x 4 k rows
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        if (B_ROWK) {
+            const int n = n0 + (tid >> 3) + 32 * i;
+            b_ok[i] = n < p.Ncols;
+            b_off[i] = (unsigned)((n * p.Cs + kq * 4) * 4);
+        } else {
+            b_ok[i] = n0 + nq * 4 < p.Ncols;
+            b_off[i] = (unsigned)((((kgrp * 4 + i) * p.Ncols) + n0 + nq * 4) * 4);
+        }
+    }
+    int cur_c0, cur_ta, cur_tb;
+    {
+        const int tap = kt_begin / p.cchunks;
+        cur_c0 = (kt_begin - tap * p.cchunks) * BKS;
+        cur_ta = tap / p.tap_nb;
+        cur_tb = tap - cur_ta * p.tap_nb;
+    }
+    float4 ra[4], rb[4];
+    auto load_tile = [&](bool live) {
+        const int c0 = cur_c0, ta = cur_ta, tb = cur_tb;
+        cur_c0 += BKS;
+        if (cur_c0 >= p.Cs) {
+            cur_c0 = 0;
+            if (++cur_tb == p.tap_nb) { cur_tb = 0; ++cur_ta; }
+        }
+        const int wt = p.w0 + ta * p.wa + tb * p.wb;
+        const int t_oy = p.oy0 + ta * p.oys, t_ox = p.ox0 + tb * p.oxs;
+        const int t_ck = c0 + kq * 4;
+        const bool t_kok = t_ck < p.Cs;
+        const unsigned t_sA = (unsigned)(((t_oy * p.Ws + t_ox) * p.lda + c0) * 4);
+        const unsigned t_sB = B_ROWK ? (unsigned)((wt * p.Ncols * p.Cs + c0) * 4) : (unsigned)(((wt * p.Cs + c0) * p.Ncols) * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = live & t_kok & ((unsigned)(a_iy0[i] + t_oy) < (unsigned)p.Hs) &
+                            ((unsigned)(a_ix0[i] + t_ox) < (unsigned)p.Ws);
+            ra[i] = gload4<true>(rsA, a_rowoff[i] + t_sA, ok, t_ck, p.Cs);
+            if (B_ROWK) rb[i] = gload4<true>(rsB, b_off[i] + t_sB, live & b_ok[i] & t_kok, t_ck, p.Cs);
+            else rb[i] = gload4<true>(rsB, b_off[i] + t_sB, live & b_ok[i] & (c0 + kgrp * 4 + i < p.Cs), 0, 4);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char* As = lds + buf * 2 * TILEB;
+        char* Bs = As + TILEB;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = (tid >> 3) + 32 * i;
+            split_store4(As + r * ROWB + kq * 8, ra[i].x, ra[i].y, ra[i].z, ra[i].w);
+            if (B_ROWK) split_store4(Bs + r * ROWB + kq * 8, rb[i].x, rb[i].y, rb[i].z, rb[i].w);
+        }
+        if (!B_ROWK) {      // register transpose of the 4(k) x 4(n) patch -> 4 rows n of 4 consecutive k
+            char* d = Bs + (nq * 4) * ROWB + kgrp * 8;
+            split_store4(d + 0 * ROWB, rb[0].x, rb[1].x, rb[2].x, rb[3].x);
+            split_store4(d + 1 * ROWB, rb[0].y, rb[1].y, rb[2].y, rb[3].y);
+            split_store4(d + 2 * ROWB, rb[0].z, rb[1].z, rb[2].z, rb[3].z);
+            split_store4(d + 3 * ROWB, rb[0].w, rb[1].w, rb[2].w, rb[3].w);
+        }
+    };
+    if (kt_begin >= kt_end) return;
+    load_tile(true);
+    store_tile(0);
+    __syncthreads();
+    int buf = 0;
+    SplitFrag f0, f1;
+    split_load_frag(lds, lds + TILEB, 0, wrow, wcol, l31, half, f0);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const bool more = (kt + 1) < kt_end;
+        const char* As = lds + buf * 2 * TILEB;
+        load_tile(more);                                   // tile t+1 in flight under this tile's 24 MFMAs
+        __builtin_amdgcn_sched_barrier(0);
+        split_load_frag(As, As + TILEB, 1, wrow, wcol, l31, half, f1);
+        __builtin_amdgcn_sched_barrier(0);
+        split_mfma(f0, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        // second k-step: publish tile t+1 first, then request its first fragments; the 12 MFMAs below cover the barrier
+        // and the LDS latency (zeros after the last tile: nobody reads them)
+        store_tile(buf ^ 1);
+        __syncthreads();
+        split_load_frag(lds + (buf ^ 1) * 2 * TILEB, lds + (buf ^ 1) * 2 * TILEB + TILEB, 0, wrow, wcol, l31, half, f0);
+        __builtin_amdgcn_sched_barrier(0);
+        split_mfma(f1, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        buf ^= 1;
+    }
+}
+
 // NARROW: 128 x 32 block tile (waves stacked 4 x 1, one 32x32 accumulator each) for GEMMs whose N is
 // at most 32 (Cout = 3 image conv, dgrad towards a 3-channel image, N = 1 logits): 4x fewer MFMAs than
 // masking a 128-wide tile down to 3 columns.
-template <bool B_ROWK, bool VEC, bool NARROW, bool BF16 = false>
+// PIPE: 0 fp32 MFMA (exact), 1 bf16 (operands rounded), 2 split-bf16 (three MFMAs per product block)
+template <bool B_ROWK, bool VEC, bool NARROW, int PIPE = 0>
 __device__ __forceinline__ void gather_gemm_body(const GGParams& p) {
+    constexpr bool BF16 = PIPE == 1;
     constexpr int MB = NARROW ? 1 : 2;          // 32-row blocks per wave
     constexpr int NB = NARROW ? 1 : 2;          // 32-col blocks per wave
     constexpr int BNT = NARROW ? 32 : BN;       // block tile width
@@ -379,6 +547,10 @@ __device__ __forceinline__ void gather_gemm_body(const GGParams& p) {
         static_assert(!NARROW && VEC, "the bf16 loop exists for the 128x128 tile, 16-byte loadable operands");
         gg_mainloop_bf16<B_ROWK>(p, reinterpret_cast<char*>(&smem[0][0]), acc, m0, n0, kt_begin, kt_end, tid, wrow, wcol,
                                  l31, half);
+    } else if constexpr (PIPE == 2) {
+        static_assert(!NARROW && VEC, "the split-bf16 loop exists for the 128x128 tile, 16-byte loadable operands");
+        gg_mainloop_split<B_ROWK>(p, reinterpret_cast<char*>(&smem[0][0]), acc, m0, n0, kt_begin, kt_end, tid, wrow, wcol,
+                                  l31, half);
     } else {
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes);
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.B, p.b_bytes);
@@ -703,19 +875,19 @@ __device__ __forceinline__ void gather_gemm_body(const GGParams& p) {
 #endif
 }
 
-template <bool B_ROWK, bool VEC, bool NARROW, bool BF16 = false>
+template <bool B_ROWK, bool VEC, bool NARROW, int PIPE = 0>
 __global__ __launch_bounds__(256, 2) void gather_gemm_kernel(const GGParams p) {
-    gather_gemm_body<B_ROWK, VEC, NARROW, BF16>(p);
+    gather_gemm_body<B_ROWK, VEC, NARROW, PIPE>(p);
 }
 // Several independent problems of the same kernel variant in ONE launch (blockIdx.y picks the problem): the 4
 // output-parity classes of a stride-2 dgrad are 4 small GEMMs (a quarter of the pixels each, 4..9 of the 25 taps);
 // as 4 launches + 4 split-K reductions they were launch-bound (~13 us each, 31 TFLOP/s on the critic's layers).
 struct GGMulti { GGParams q[4]; };
-template <bool B_ROWK, bool VEC, bool NARROW, bool BF16 = false>
+template <bool B_ROWK, bool VEC, bool NARROW, int PIPE = 0>
 __global__ __launch_bounds__(256, 2) void gather_gemm_multi_kernel(const GGMulti m) {
     const GGParams& p = m.q[blockIdx.y];
     if ((int)blockIdx.x >= p.mtiles * p.ntiles || (int)blockIdx.z >= p.nsplit) return;
-    gather_gemm_body<B_ROWK, VEC, NARROW, BF16>(p);
+    gather_gemm_body<B_ROWK, VEC, NARROW, PIPE>(p);
 }
 
 // split-K second pass: sum partials in split order (deterministic) and run the fused epilogue
@@ -777,6 +949,7 @@ struct WGParams {
     int vec_x;                                     // 1: x alone is 16-byte loadable (Cout = 3: dy is not)
     int d32_oy, d32_ox;                            // S1: (row, col) advance of a pixel index step of BK = 32
     int d64_oy, d64_ox, d64_n;                     //     ... and of the bf16 loop's 64 (+ whole images, generic variant)
+    int d32g_oy, d32g_ox, d32g_n;                  //     ... and of the split-bf16 loop's 32, in the bf16 loop's (n, oy, ox) form
 };
 
 
@@ -897,6 +1070,105 @@ __device__ __forceinline__ void wg_mainloop_bf16(const WGParams& p, char* lds, f
     }
 }
 
+// split-bf16 variant of the wgrad pixel loop (see gg_mainloop_split for the operand format): k-tile = 32 pixels, each
+// thread loads a 4(pixel) x 4(channel) patch of x and of dy and transposes it in registers into four LDS rows of
+// [4 hi | ... | 4 lo] per operand.  The bias gradient stays an exact fp32 column sum.
+template <bool GEN>
+__device__ __forceinline__ void wg_mainloop_split(const WGParams& p, char* lds, f32x16 (&acc)[2][2], int ci0, int co0,
+                                                  int oyoff, int oxoff, int kt_begin, int kt_end, int tid, int wrow,
+                                                  int wcol, int l31, int half, bool do_bias, float4& bsum) {
+    const int cq = tid & 31, pquad = tid >> 5;                 // 4 channels x 4 pixels per thread
+    const int padpix = GEN ? 0 : p.pad_t * p.W + p.pad_l;
+    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.X - (long)padpix * p.ldx, p.x_bytes + (unsigned)(padpix * p.ldx * 4));
+    const __amdgpu_buffer_rsrc_t rsY = make_rsrc(p.DY, p.y_bytes);
+    const bool cx_ok = ci0 + cq * 4 < p.C, cy_ok = co0 + cq * 4 < p.K;
+    int s_oy[4], s_ox[4], s_n[4];
+    unsigned xv[4], yv[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const int r = pquad * 4 + e;
+        const int m = kt_begin * BKS + r;
+        const int n = fast_div(m, p.mul_howo, p.shr_howo);
+        const int rem = m - n * p.HoWo;
+        s_n[e] = n;
+        s_oy[e] = fast_div(rem, p.mul_wo, p.shr_wo);
+        s_ox[e] = rem - s_oy[e] * p.Wo;
+        xv[e] = cx_ok ? (unsigned)((r * p.ldx + ci0 + cq * 4) * 4) : OOB;
+        yv[e] = cy_ok ? (unsigned)((r * p.ldy + co0 + cq * 4) * 4) : OOB;
+    }
+    float4 ra[4], rb[4];
+    auto load_tile = [&](int kt, bool live) {
+        const int sx = ((kt * BKS + oyoff * p.W + oxoff + padpix) * p.ldx) * 4;
+        const int sy = (kt * BKS * p.ldy) * 4;
+        const int left = p.Npix - kt * BKS;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const bool mok = live & (pquad * 4 + e < left);
+            f32x4 ta;
+            if (GEN) {
+                const int py = s_oy[e] * p.s + oyoff, px = s_ox[e] * p.s + oxoff;
+                const int iy = py >> p.shift, ix = px >> p.shift;
+                const bool ok = mok & cx_ok & (py >= 0) & (px >= 0) & (iy < p.H) & (ix < p.W);
+                const unsigned xo = (unsigned)((((s_n[e] * p.H + iy) * p.W + ix) * p.ldx + ci0 + cq * 4) * 4);
+                ta = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)(ok ? xo : OOB), 0, 0));
+            } else {
+                const bool ok = mok & ((unsigned)(s_oy[e] + oyoff) < (unsigned)p.H) & ((unsigned)(s_ox[e] + oxoff) < (unsigned)p.W);
+                ta = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, (int)(ok ? xv[e] : OOB), sx, 0));
+            }
+            const f32x4 tb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsY, (int)(mok ? yv[e] : OOB), sy, 0));
+            ra[e] = make_float4(ta.x, ta.y, ta.z, ta.w);
+            rb[e] = make_float4(tb.x, tb.y, tb.z, tb.w);
+            s_ox[e] += p.d32g_ox;
+            const bool c1 = s_ox[e] >= p.Wo;
+            s_ox[e] -= c1 ? p.Wo : 0;
+            s_oy[e] += p.d32g_oy + (c1 ? 1 : 0);
+            const bool c2 = s_oy[e] >= p.Ho;
+            s_oy[e] -= c2 ? p.Ho : 0;
+            if (GEN) s_n[e] += p.d32g_n + (c2 ? 1 : 0);
+        }
+    };
+    auto store_tile = [&](int buf) {
+        char* da = lds + buf * 2 * TILEB + (cq * 4) * ROWB + pquad * 8;
+        char* db = da + TILEB;
+        split_store4(da + 0 * ROWB, ra[0].x, ra[1].x, ra[2].x, ra[3].x);
+        split_store4(da + 1 * ROWB, ra[0].y, ra[1].y, ra[2].y, ra[3].y);
+        split_store4(da + 2 * ROWB, ra[0].z, ra[1].z, ra[2].z, ra[3].z);
+        split_store4(da + 3 * ROWB, ra[0].w, ra[1].w, ra[2].w, ra[3].w);
+        split_store4(db + 0 * ROWB, rb[0].x, rb[1].x, rb[2].x, rb[3].x);
+        split_store4(db + 1 * ROWB, rb[0].y, rb[1].y, rb[2].y, rb[3].y);
+        split_store4(db + 2 * ROWB, rb[0].z, rb[1].z, rb[2].z, rb[3].z);
+        split_store4(db + 3 * ROWB, rb[0].w, rb[1].w, rb[2].w, rb[3].w);
+        if (do_bias) {          // exact fp32 column sums of dy, as in the fp32 loop (workgroup-uniform branch)
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { bsum.x += rb[e].x; bsum.y += rb[e].y; bsum.z += rb[e].z; bsum.w += rb[e].w; }
+        }
+    };
+    if (kt_begin >= kt_end) return;
+    load_tile(kt_begin, true);
+    store_tile(0);
+    __syncthreads();
+    int buf = 0;
+    SplitFrag f0, f1;
+    split_load_frag(lds, lds + TILEB, 0, wrow, wcol, l31, half, f0);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const char* As = lds + buf * 2 * TILEB;
+        load_tile(kt + 1, (kt + 1) < kt_end);
+        __builtin_amdgcn_sched_barrier(0);
+        split_load_frag(As, As + TILEB, 1, wrow, wcol, l31, half, f1);
+        __builtin_amdgcn_sched_barrier(0);
+        split_mfma(f0, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        store_tile(buf ^ 1);                               // same hand-over as gg_mainloop_split
+        __syncthreads();
+        split_load_frag(lds + (buf ^ 1) * 2 * TILEB, lds + (buf ^ 1) * 2 * TILEB + TILEB, 0, wrow, wcol, l31, half, f0);
+        __builtin_amdgcn_sched_barrier(0);
+        split_mfma(f1, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        buf ^= 1;
+    }
+}
+
 // NARROW: 128 x 32 tile for Cout <= 32 (the 3-channel image conv).  FLAT: for thin inputs (Cin = 3 stems,
 // the 18-channel pose conv) the tile rows are the flattened (tap, ci) index instead of 128 channels of one
 // tap, so a 3-channel 5x5 filter gradient is 1 row tile instead of 25 tiles that are 98 % padding.
@@ -904,8 +1176,9 @@ __device__ __forceinline__ void wg_mainloop_bf16(const WGParams& p, char* lds, f
 // addressed as  per-thread constant voffset + per-k-tile SCALAR soffset; the only per-row vector work left is
 // the halo test on an incrementally advanced (oy, ox).  (The generic loader spends ~35 VALU per row per k-tile
 // on index arithmetic, which -- not the matrix pipe -- paced groups 0-1 of the k-loop: s_memtime trace.)
-template <bool VEC, bool NARROW, bool FLAT, bool S1 = false, bool BF16 = false>
+template <bool VEC, bool NARROW, bool FLAT, bool S1 = false, int PIPE = 0>
 __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
+    constexpr bool BF16 = PIPE != 0;         // both bf16-pipe loops use the [128][ROWB] LDS image
     constexpr int MB = NARROW ? 1 : 2;
     constexpr int NB = NARROW ? 1 : 2;
     constexpr int BNT = NARROW ? 32 : BN;
@@ -951,10 +1224,14 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WGParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    if constexpr (BF16) {
+    if constexpr (PIPE == 1) {
         static_assert(VEC && !NARROW && !FLAT, "the bf16 pixel loop exists for the 16-byte loadable 128x128 variant");
         wg_mainloop_bf16<!S1>(p, reinterpret_cast<char*>(&smem[0][0]), acc, ci0, co0, oyoff, oxoff, kt_begin, kt_end, tid,
                          wrow, wcol, l31, half, do_bias, bsum);
+    } else if constexpr (PIPE == 2) {
+        static_assert(VEC && !NARROW && !FLAT, "the split-bf16 pixel loop exists for the 16-byte loadable 128x128 variant");
+        wg_mainloop_split<!S1>(p, reinterpret_cast<char*>(&smem[0][0]), acc, ci0, co0, oyoff, oxoff, kt_begin, kt_end, tid,
+                          wrow, wcol, l31, half, do_bias, bsum);
     } else {
     float4 ra[4], rb[4];
     // FLAT: this thread's 4 tile rows are 4 (tap, ci) pairs, fixed for the whole pixel loop
@@ -1263,9 +1540,16 @@ static bool vec_ok(const void* a, const void* b, int lda, int Cs, int Ncols) {
 static int gg_bk(const DpigConvDesc* d, int lda, int Cs, int Ncols) {
     return (d->compute == DPIG_COMPUTE_BF16 && lda % 4 == 0 && Cs % 4 == 0 && Ncols % 4 == 0 && Ncols > 32) ? BKH : BK;
 }
+// matrix pipe of the GEMM loop (the PIPE template argument): the bf16 and split-bf16 loops need the same shape; the split
+// loop keeps the fp32 loop's k-tile, so every plan / workspace size of the exact path holds for it
+static int gg_pipe(const DpigConvDesc* d, int lda, int Cs, int Ncols, const void* a, const void* b) {
+    if (d->compute == DPIG_COMPUTE_F32) return 0;
+    const bool shape = lda % 4 == 0 && Cs % 4 == 0 && Ncols % 4 == 0 && Ncols > 32 && aligned16(a) && aligned16(b);
+    return shape ? (d->compute == DPIG_COMPUTE_BF16X3 ? 2 : 1) : 0;
+}
 
 // derived fields of one problem; *vec / *narrow select the kernel variant
-static int prepare_gg(GGParams& p, int nimg, long filter_elems, bool* vec, bool* narrow, bool bf16 = false) {
+static int prepare_gg(GGParams& p, int nimg, long filter_elems, bool* vec, bool* narrow, int pipe = 0) {
     p.HrWr = p.Hr * p.Wr;
     find_divisor(p.HrWr, &p.mul_hrwr, &p.shr_hrwr);
     find_divisor(p.Wr, &p.mul_wr, &p.shr_wr);
@@ -1281,7 +1565,7 @@ static int prepare_gg(GGParams& p, int nimg, long filter_elems, bool* vec, bool*
     *narrow = p.Ncols <= 32;
     p.mtiles = cdiv(p.M, BM);
     p.ntiles = cdiv(p.Ncols, *narrow ? 32 : BN);
-    p.cchunks = cdiv(p.Cs, bf16 ? BKH : BK);
+    p.cchunks = cdiv(p.Cs, pipe == 1 ? BKH : BK);
     p.ktiles = p.ntaps * p.cchunks;
     *vec = vec_ok(p.A, p.B, p.lda, p.Cs, p.Ncols);
     p.vec_a = aligned16(p.A) && (p.lda % 4 == 0) && (p.Cs % 4 == 0);
@@ -1292,16 +1576,19 @@ static int reduce_blocks(const GGParams& p) {
     int blocks = cdiv(p.vec_epi ? total / 4 : total, 256);
     return blocks > 8 * kNumCU ? 8 * kNumCU : blocks;
 }
-static int launch_gg(GGParams& p, bool b_rowk, int nimg, long filter_elems, hipStream_t st, bool bf16 = false) {
+static int launch_gg(GGParams& p, bool b_rowk, int nimg, long filter_elems, hipStream_t st, int pipe = 0) {
     bool vec, narrow;
-    int rc = prepare_gg(p, nimg, filter_elems, &vec, &narrow, bf16);
+    int rc = prepare_gg(p, nimg, filter_elems, &vec, &narrow, pipe);
     if (rc) return rc;
     dim3 grid(p.mtiles * p.ntiles, 1, p.nsplit), block(256);
-    if (bf16 && (!vec || narrow)) return fail(DPIG_EINVAL, "internal: bf16 loop selected for an ineligible problem");
+    if (pipe && (!vec || narrow)) return fail(DPIG_EINVAL, "internal: bf16 loop selected for an ineligible problem");
 #define DPIG_GG(BR, VE, NA) hipLaunchKernelGGL((gather_gemm_kernel<BR, VE, NA>), grid, block, 0, st, p)
-    if (bf16) {
-        if (b_rowk) hipLaunchKernelGGL((gather_gemm_kernel<true, true, false, true>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((gather_gemm_kernel<false, true, false, true>), grid, block, 0, st, p);
+    if (pipe == 1) {
+        if (b_rowk) hipLaunchKernelGGL((gather_gemm_kernel<true, true, false, 1>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gather_gemm_kernel<false, true, false, 1>), grid, block, 0, st, p);
+    } else if (pipe == 2) {
+        if (b_rowk) hipLaunchKernelGGL((gather_gemm_kernel<true, true, false, 2>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((gather_gemm_kernel<false, true, false, 2>), grid, block, 0, st, p);
     } else if (b_rowk) {
         if (narrow) { if (vec) DPIG_GG(true, true, true); else DPIG_GG(true, false, true); }
         else { if (vec) DPIG_GG(true, true, false); else DPIG_GG(true, false, false); }
@@ -1319,13 +1606,13 @@ static int launch_gg(GGParams& p, bool b_rowk, int nimg, long filter_elems, hipS
     return rc;
 }
 // n <= 4 problems of the same variant (dgrad: B is [N][K]) in one launch + at most one reduction launch
-static int launch_gg_multi(GGParams* q, int n, int nimg, long filter_elems, hipStream_t st, bool bf16 = false) {
+static int launch_gg_multi(GGParams* q, int n, int nimg, long filter_elems, hipStream_t st, int pipe = 0) {
     GGMulti m = {};
     bool vec = false, narrow = false;
     int max_tiles = 0, max_split = 1, max_red = 0;
     for (int i = 0; i < n; ++i) {
         bool v, na;
-        const int rc = prepare_gg(q[i], nimg, filter_elems, &v, &na, bf16);
+        const int rc = prepare_gg(q[i], nimg, filter_elems, &v, &na, pipe);
         if (rc) return rc;
         if (i == 0) { vec = v; narrow = na; }
         else if (v != vec || na != narrow) return fail(DPIG_EINVAL, "internal: multi-launch variants differ");
@@ -1335,9 +1622,10 @@ static int launch_gg_multi(GGParams* q, int n, int nimg, long filter_elems, hipS
         m.q[i] = q[i];
     }
     dim3 grid(max_tiles, n, max_split), block(256);
-    if (bf16 && (!vec || narrow)) return fail(DPIG_EINVAL, "internal: bf16 loop selected for an ineligible problem");
+    if (pipe && (!vec || narrow)) return fail(DPIG_EINVAL, "internal: bf16 loop selected for an ineligible problem");
 #define DPIG_GGM(VE, NA) hipLaunchKernelGGL((gather_gemm_multi_kernel<true, VE, NA>), grid, block, 0, st, m)
-    if (bf16) hipLaunchKernelGGL((gather_gemm_multi_kernel<true, true, false, true>), grid, block, 0, st, m);
+    if (pipe == 1) hipLaunchKernelGGL((gather_gemm_multi_kernel<true, true, false, 1>), grid, block, 0, st, m);
+    else if (pipe == 2) hipLaunchKernelGGL((gather_gemm_multi_kernel<true, true, false, 2>), grid, block, 0, st, m);
     else if (narrow) { if (vec) DPIG_GGM(true, true); else DPIG_GGM(false, true); }
     else { if (vec) DPIG_GGM(true, false); else DPIG_GGM(false, false); }
 #undef DPIG_GGM
@@ -1453,7 +1741,8 @@ extern "C" int dpig_conv2d_fwd(const DpigConvDesc* d, const float* x, const floa
     rc = fewc_fwd_try(d, pt, pl, Ho, Wo, x, w, bias, residual, y, y_act, static_cast<hipStream_t>(stream));
     if (rc != 0) return rc < 0 ? rc : DPIG_OK;
     p.partial = static_cast<float*>(ws);
-    const bool bf16 = gg_bk(d, d->ldx, d->C, d->K) == BKH && aligned16(x) && aligned16(w);
+    const int pipe = gg_pipe(d, d->ldx, d->C, d->K, x, w);
+    const bool bf16 = pipe == 1;
     Shape s = fwd_shape(d, Ho, Wo, bf16 ? BKH : BK);
     p.M = (int)s.M;
     p.Hr = d->upsample2x ? d->H : Ho; p.Wr = d->upsample2x ? d->W : Wo;
@@ -1472,7 +1761,7 @@ extern "C" int dpig_conv2d_fwd(const DpigConvDesc* d, const float* x, const floa
     if (p.nsplit > 1 && ws_bytes < (size_t)p.nsplit * s.M * s.Ncols * sizeof(float))
         return fail(DPIG_ENOMEM, "conv fwd workspace too small: have %zu", ws_bytes);
     if (p.nsplit > 1 && !ws) return fail(DPIG_ENOMEM, "conv fwd needs a workspace");
-    return launch_gg(p, false, d->N, (long)d->R * d->S * d->C * d->K, static_cast<hipStream_t>(stream), bf16);
+    return launch_gg(p, false, d->N, (long)d->R * d->S * d->C * d->K, static_cast<hipStream_t>(stream), pipe);
 }
 
 extern "C" int dpig_conv2d_dgrad(const DpigConvDesc* d, const float* dy, const float* w, const float* accum,
@@ -1492,7 +1781,8 @@ extern "C" int dpig_conv2d_dgrad(const DpigConvDesc* d, const float* dy, const f
     p.A = dy; p.B = w; p.D = dx; p.bias = nullptr; p.res = accum; p.mask = mask;
     p.partial = static_cast<float*>(ws);
     p.lda = d->ldy; p.Cs = d->K; p.Ncols = d->C;
-    const bool bf16 = gg_bk(d, d->ldy, d->K, d->C) == BKH && aligned16(dy) && aligned16(w);
+    const int pipe = gg_pipe(d, d->ldy, d->K, d->C, dy, w);
+    const bool bf16 = pipe == 1;
     p.Hd = d->H; p.Wd = d->W; p.ldd = d->ldx; p.ldres = d->ldres; p.ldmask = d->ldmask;
     p.act = mask ? d->act : DPIG_ACT_NONE; p.alpha = d->alpha; p.replicate = 0;
     if (d->upsample2x) {
@@ -1528,13 +1818,13 @@ extern "C" int dpig_conv2d_dgrad(const DpigConvDesc* d, const float* dy, const f
             q.nsplit = sp.pl[i].nsplit; q.tiles_per_split = sp.pl[i].tiles_per_split;
             q.partial = reinterpret_cast<float*>(static_cast<char*>(ws) + sp.off[i]);
         }
-        return launch_gg_multi(qs, sp.nc, d->N, (long)d->R * d->S * d->C * d->K, st, bf16);
+        return launch_gg_multi(qs, sp.nc, d->N, (long)d->R * d->S * d->C * d->K, st, pipe);
     }
     Plan pln = plan_split(cdiv(p.M, BM) * cdiv(p.Ncols, BN), p.ntaps * cdiv(p.Cs, bf16 ? BKH : BK), d->split_k);
     p.nsplit = pln.nsplit; p.tiles_per_split = pln.tiles_per_split;
     if (p.nsplit > 1 && (!ws || ws_bytes < (size_t)p.nsplit * p.M * p.Ncols * sizeof(float)))
         return fail(DPIG_ENOMEM, "conv dgrad workspace too small: have %zu", ws_bytes);
-    return launch_gg(p, true, d->N, (long)d->R * d->S * d->C * d->K, st, bf16);
+    return launch_gg(p, true, d->N, (long)d->R * d->S * d->C * d->K, st, pipe);
 }
 
 extern "C" int dpig_conv2d_wgrad(const DpigConvDesc* d, const float* x, const float* dy, float* dw, float beta,
@@ -1578,6 +1868,7 @@ extern "C" int dpig_conv2d_wgrad(const DpigConvDesc* d, const float* x, const fl
     const bool s1 = vec && wgrad_s1_shape(d, pt, pl, Ho, Wo) &&
                     ((long)p.x_bytes + (long)(p.pad_t * p.W + p.pad_l) * p.ldx * 4 < 0x7fffffffL);
     const bool bf16 = vec && !flat && !narrow && d->compute == DPIG_COMPUTE_BF16;
+    const bool split3 = vec && !flat && !narrow && d->compute == DPIG_COMPUTE_BF16X3;
     p.cblocks = cdiv(d->C, BM);
     p.ntiles = cdiv(d->K, narrow ? 32 : BN);
     p.ktiles = cdiv(p.Npix, bf16 ? BKH : BK);
@@ -1596,12 +1887,17 @@ extern "C" int dpig_conv2d_wgrad(const DpigConvDesc* d, const float* x, const fl
     p.d64_n = BKH / p.HoWo;
     p.d64_oy = (BKH % p.HoWo) / p.Wo;
     p.d64_ox = (BKH % p.HoWo) % p.Wo;
+    p.d32g_n = BKS / p.HoWo;
+    p.d32g_oy = (BKS % p.HoWo) / p.Wo;
+    p.d32g_ox = (BKS % p.HoWo) % p.Wo;
     dim3 grid(tiles, 1, p.nsplit), block(256);
 #define DPIG_WG(VE, NA, FL) hipLaunchKernelGGL((wgrad_kernel<VE, NA, FL>), grid, block, 0, st, p)
     if (flat) { if (narrow) DPIG_WG(false, true, true); else DPIG_WG(false, false, true); }
     else if (narrow) { if (vec) DPIG_WG(true, true, false); else DPIG_WG(false, true, false); }
-    else if (bf16 && s1) hipLaunchKernelGGL((wgrad_kernel<true, false, false, true, true>), grid, block, 0, st, p);
-    else if (bf16) hipLaunchKernelGGL((wgrad_kernel<true, false, false, false, true>), grid, block, 0, st, p);
+    else if (bf16 && s1) hipLaunchKernelGGL((wgrad_kernel<true, false, false, true, 1>), grid, block, 0, st, p);
+    else if (bf16) hipLaunchKernelGGL((wgrad_kernel<true, false, false, false, 1>), grid, block, 0, st, p);
+    else if (split3 && s1) hipLaunchKernelGGL((wgrad_kernel<true, false, false, true, 2>), grid, block, 0, st, p);
+    else if (split3) hipLaunchKernelGGL((wgrad_kernel<true, false, false, false, 2>), grid, block, 0, st, p);
     else if (s1) hipLaunchKernelGGL((wgrad_kernel<true, false, false, true>), grid, block, 0, st, p);
     else { if (vec) DPIG_WG(true, false, false); else DPIG_WG(false, false, false); }
 #undef DPIG_WG

@@ -11,7 +11,10 @@ Arithmetic modes (`set_compute`):
            accumulation / bias / residual / normalisation is fp32, parameter gradients and the optimizer stay fp32.
            Ops whose kernels exist in fp32 only (thin 3-channel convs, norms, FC layers, crops) convert at their
            boundary (`to_f32` / `to_bf16` kernels); a tensor is stored as bf16 iff its channel count is a multiple of 8;
-  'bf16c'  round 1's intermediate mode: fp32 tensors, conv operands rounded to bf16 on their way into LDS.
+  'bf16c'  round 1's intermediate mode: fp32 tensors, conv operands rounded to bf16 on their way into LDS;
+  'bf16x3' fp32 tensors, fp32 accuracy class on the bf16 pipe: conv operands are split into two bf16 terms on their way
+           into LDS and every product block is three bf16 MFMAs (DPIG_COMPUTE_BF16X3, include/dpig_hip.h).  An opt-in
+           mode, held to the exact path's kernel bar (2e-5 max|ref|); 'f32' stays the exact-products default.
 """
 import ctypes
 
@@ -89,21 +92,21 @@ def as_nhwc(t):
     return t, ld
 
 
-COMPUTE_F32, COMPUTE_BF16 = 0, 1
+COMPUTE_F32, COMPUTE_BF16, COMPUTE_BF16X3 = 0, 1, 2
 _COMPUTE = [COMPUTE_F32]      # DpigConvDesc.compute of the fp32-tensor entry points
 _STORE_BF16 = [False]         # 'bf16' mode: activations stored as bf16
 
 
 def set_compute(dtype):
     """Arithmetic of every subsequent launch (module docstring): 'f32' | 'bf16' (storage) | 'bf16c' (fp32 tensors,
-    bf16 matrix pipe)."""
-    mode = {"f32": "f32", "fp32": "f32", "bf16": "bf16", "bf16c": "bf16c"}[dtype]
-    _COMPUTE[0] = COMPUTE_BF16 if mode == "bf16c" else COMPUTE_F32
+    bf16 matrix pipe) | 'bf16x3' (fp32 tensors, split-bf16 products)."""
+    mode = {"f32": "f32", "fp32": "f32", "bf16": "bf16", "bf16c": "bf16c", "bf16x3": "bf16x3"}[dtype]
+    _COMPUTE[0] = {"bf16c": COMPUTE_BF16, "bf16x3": COMPUTE_BF16X3}.get(mode, COMPUTE_F32)
     _STORE_BF16[0] = mode == "bf16"
 
 
 def get_compute():
-    return "bf16" if _STORE_BF16[0] else ("bf16c" if _COMPUTE[0] == COMPUTE_BF16 else "f32")
+    return "bf16" if _STORE_BF16[0] else {COMPUTE_BF16: "bf16c", COMPUTE_BF16X3: "bf16x3"}.get(_COMPUTE[0], "f32")
 
 
 def storable_bf16(channels):

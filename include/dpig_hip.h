@@ -86,6 +86,11 @@ typedef struct DpigConvDesc {
 } DpigConvDesc;
 #define DPIG_COMPUTE_F32 0
 #define DPIG_COMPUTE_BF16 1
+#define DPIG_COMPUTE_BF16X3 2   /* tensors stay fp32; every operand is split into two bf16 terms (hi + lo, 16     */
+                                /* significand bits) on its way into LDS and each product block is three bf16     */
+                                /* MFMAs (hi*lo + lo*hi + hi*hi) into the fp32 accumulator: the fp32 accuracy     */
+                                /* class (<= 2e-5 max|ref|, the exact path's own test bar) at bf16-pipe speed.    */
+                                /* Applies where DPIG_COMPUTE_BF16 does; other shapes run the exact fp32 kernels. */
 
 int dpig_version(void);
 const char* dpig_last_error(void);

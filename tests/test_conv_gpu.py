@@ -349,6 +349,75 @@ def test_conv_upsample_fused_bf16(dev):
         H.set_compute("f32")
 
 
+@pytest.mark.parametrize("shape", BF16_SHAPES)
+@pytest.mark.parametrize("split_k", [0, 3])
+def test_conv_split_bf16_compute(dev, shape, split_k):
+    """DpigConvDesc.compute = BF16X3 (set_compute('bf16x3')): fp32 tensors, every operand split into two bf16 terms, three
+    bf16 MFMAs per product block.  Held to the SAME bar as the exact fp32 kernels (TOL x max|ref| against the fp64 oracle
+    on the UNROUNDED operands): forward with bias + LeakyReLU, dgrad, wgrad with the fused bias gradient."""
+    import dpig_amd.hip_ops as H
+    from oracle import ops as O
+    N, Hh, W, C, K, k, s = shape
+    x = _rand((N, Hh, W, C), 1)
+    w = _rand((k, k, C, K), 2) * 0.2
+    b = _rand((K,), 3)
+    ref = O.conv2d_same(x, w, b, s)
+    dy = _rand(tuple(ref.shape), 4)
+    H.set_compute("bf16x3")
+    try:
+        assert H.get_compute() == "bf16x3"
+        got = H.conv2d_fwd(x.float().to(dev), w.float().to(dev), b.float().to(dev), stride=s, act=2, alpha=0.2, split_k=split_k)
+        _close(got, O.leaky_relu(ref, 0.2))
+        xr = x.clone().requires_grad_(True)
+        wr = w.clone().requires_grad_(True)
+        (O.conv2d_same(xr, wr, None, s) * dy).sum().backward()
+        dx = H.conv2d_dgrad(dy.float().to(dev), w.float().to(dev), (N, Hh, W, C), stride=s, split_k=split_k)
+        _close(dx, xr.grad)
+        db = torch.zeros(K, device=dev)
+        dw = H.conv2d_wgrad(x.float().to(dev), dy.float().to(dev), (k, k, C, K), stride=s, split_k=split_k,
+                            out=torch.empty(k, k, C, K, device=dev), beta=0.0, db=db, db_beta=0.0)
+        _close(dw, wr.grad)
+        _close(db, dy.reshape(-1, K).sum(0))
+    finally:
+        H.set_compute("f32")
+
+
+def test_conv_split_bf16_epilogues_and_upsample(dev):
+    """Split-bf16 pipe with the fused epilogues the model uses: residual add + ReLU with the pre-activation kept, masked dgrad
+    accumulation, and the upsample-commuted 1x1 conv (2x2 replication fwd, 4-tap dgrad, source-shift wgrad)."""
+    import dpig_amd.hip_ops as H
+    from oracle import ops as O
+    N, Hh, W, C, K = 2, 12, 10, 64, 64
+    x = _rand((N, Hh, W, C), 1)
+    w = _rand((3, 3, C, K), 2) * 0.2
+    b = _rand((K,), 3)
+    res = _rand((N, Hh, W, K), 4)
+    pre = O.conv2d_same(x, w, b, 1) + res
+    dy = _rand(tuple(pre.shape), 5)
+    acc = _rand((N, Hh, W, C), 6)
+    H.set_compute("bf16x3")
+    try:
+        y = H.conv2d_fwd(x.float().to(dev), w.float().to(dev), b.float().to(dev), act=1, residual=res.float().to(dev))
+        _close(y, O.relu(pre))
+        xr = x.clone().requires_grad_(True)
+        (O.conv2d_same(xr, w, None, 1) * dy).sum().backward()
+        dx = H.conv2d_dgrad(dy.float().to(dev), w.float().to(dev), (N, Hh, W, C), accum=acc.float().to(dev))
+        _close(dx, xr.grad + acc)
+        Cu, Ku = 96, 64
+        xu = _rand((N, 8, 4, Cu), 7)
+        wu = _rand((1, 1, Cu, Ku), 8) * 0.3
+        refu = O.relu(O.conv2d_same(O.upsample2x(xu), wu, b, 1))
+        dyu = _rand(tuple(refu.shape), 9)
+        _close(H.conv2d_fwd(xu.float().to(dev), wu.float().to(dev), b.float().to(dev), act=1, upsample2x=True), refu)
+        xr = xu.clone().requires_grad_(True)
+        wr = wu.clone().requires_grad_(True)
+        (O.conv2d_same(O.upsample2x(xr), wr, None, 1) * dyu).sum().backward()
+        _close(H.conv2d_dgrad(dyu.float().to(dev), wu.float().to(dev), (N, 8, 4, Cu), upsample2x=True), xr.grad)
+        _close(H.conv2d_wgrad(xu.float().to(dev), dyu.float().to(dev), (1, 1, Cu, Ku), upsample2x=True), wr.grad)
+    finally:
+        H.set_compute("f32")
+
+
 def test_conv_bf16_falls_back_to_fp32_when_ineligible(dev):
     import dpig_amd.hip_ops as H
     x = _rand((2, 16, 8, 256), 1).float().to(dev)
