@@ -358,18 +358,26 @@ __device__ __forceinline__ void split_store4(char* dst, float a, float b, float 
     *reinterpret_cast<uint2*>(dst) = make_uint2(h0, h1);
     *reinterpret_cast<uint2*>(dst + 64) = make_uint2(l0, l1);
 }
+// An operand that reaches LDS through the register transpose (the forward filter, both wgrad operands) is written by 32 lanes
+// that hold 32 different 4-row groups at ONE k position: with plain rows their 8-byte stores fall on 4 bank groups
+// (8-way conflict).  Those tiles keep the 16-byte granule g of row r at position g ^ ((r >> 4) & 3) (2-way); SWA / SWB
+// tell the fragment reads which operand is stored that way.
+__device__ __forceinline__ int split_tslot(int slot8, int rowquad) { return slot8 ^ (((rowquad >> 2) & 3) << 1); }
 struct SplitFrag { bf16x8 ah[2], al[2], bh[2], bl[2]; };
+template <bool SWA, bool SWB>
 __device__ __forceinline__ void split_load_frag(const char* As, const char* Bs, int ks, int wrow, int wcol, int l31, int half,
                                                 SplitFrag& f) {
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
-        const char* a = As + (wrow + mb * 32 + l31) * ROWB + ks * 32 + half * 16;
+        const int g = (ks * 2 + half) ^ (SWA ? ((2 * mb + (l31 >> 4)) & 3) : 0);     // wrow, wcol are multiples of 64
+        const char* a = As + (wrow + mb * 32 + l31) * ROWB + g * 16;
         f.ah[mb] = *reinterpret_cast<const bf16x8*>(a);
         f.al[mb] = *reinterpret_cast<const bf16x8*>(a + 64);
     }
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
-        const char* b = Bs + (wcol + nb * 32 + l31) * ROWB + ks * 32 + half * 16;
+        const int g = (ks * 2 + half) ^ (SWB ? ((2 * nb + (l31 >> 4)) & 3) : 0);
+        const char* b = Bs + (wcol + nb * 32 + l31) * ROWB + g * 16;
         f.bh[nb] = *reinterpret_cast<const bf16x8*>(b);
         f.bl[nb] = *reinterpret_cast<const bf16x8*>(b + 64);
     }
@@ -468,7 +476,7 @@ __device__ __forceinline__ void gg_mainloop_split(const GGParams& p, char* lds, 
             if (B_ROWK) split_store4(Bs + r * ROWB + kq * 8, rb[i].x, rb[i].y, rb[i].z, rb[i].w);
         }
         if (!B_ROWK) {      // register transpose of the 4(k) x 4(n) patch -> 4 rows n of 4 consecutive k
-            char* d = Bs + (nq * 4) * ROWB + kgrp * 8;
+            char* d = Bs + (nq * 4) * ROWB + split_tslot(kgrp, nq) * 8;
             split_store4(d + 0 * ROWB, rb[0].x, rb[1].x, rb[2].x, rb[3].x);
             split_store4(d + 1 * ROWB, rb[0].y, rb[1].y, rb[2].y, rb[3].y);
             split_store4(d + 2 * ROWB, rb[0].z, rb[1].z, rb[2].z, rb[3].z);
@@ -481,13 +489,13 @@ __device__ __forceinline__ void gg_mainloop_split(const GGParams& p, char* lds, 
     __syncthreads();
     int buf = 0;
     SplitFrag f0, f1;
-    split_load_frag(lds, lds + TILEB, 0, wrow, wcol, l31, half, f0);
+    split_load_frag<false, !B_ROWK>(lds, lds + TILEB, 0, wrow, wcol, l31, half, f0);
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const bool more = (kt + 1) < kt_end;
         const char* As = lds + buf * 2 * TILEB;
         load_tile(more);                                   // tile t+1 in flight under this tile's 24 MFMAs
         __builtin_amdgcn_sched_barrier(0);
-        split_load_frag(As, As + TILEB, 1, wrow, wcol, l31, half, f1);
+        split_load_frag<false, !B_ROWK>(As, As + TILEB, 1, wrow, wcol, l31, half, f1);
         __builtin_amdgcn_sched_barrier(0);
         split_mfma(f0, acc);
         __builtin_amdgcn_sched_barrier(0);
@@ -495,7 +503,7 @@ __device__ __forceinline__ void gg_mainloop_split(const GGParams& p, char* lds, 
         // and the LDS latency (zeros after the last tile: nobody reads them)
         store_tile(buf ^ 1);
         __syncthreads();
-        split_load_frag(lds + (buf ^ 1) * 2 * TILEB, lds + (buf ^ 1) * 2 * TILEB + TILEB, 0, wrow, wcol, l31, half, f0);
+        split_load_frag<false, !B_ROWK>(lds + (buf ^ 1) * 2 * TILEB, lds + (buf ^ 1) * 2 * TILEB + TILEB, 0, wrow, wcol, l31, half, f0);
         __builtin_amdgcn_sched_barrier(0);
         split_mfma(f1, acc);
         __builtin_amdgcn_sched_barrier(0);
@@ -1128,7 +1136,7 @@ __device__ __forceinline__ void wg_mainloop_split(const WGParams& p, char* lds, 
         }
     };
     auto store_tile = [&](int buf) {
-        char* da = lds + buf * 2 * TILEB + (cq * 4) * ROWB + pquad * 8;
+        char* da = lds + buf * 2 * TILEB + (cq * 4) * ROWB + split_tslot(pquad, cq) * 8;
         char* db = da + TILEB;
         split_store4(da + 0 * ROWB, ra[0].x, ra[1].x, ra[2].x, ra[3].x);
         split_store4(da + 1 * ROWB, ra[0].y, ra[1].y, ra[2].y, ra[3].y);
@@ -1150,18 +1158,18 @@ __device__ __forceinline__ void wg_mainloop_split(const WGParams& p, char* lds, 
     __syncthreads();
     int buf = 0;
     SplitFrag f0, f1;
-    split_load_frag(lds, lds + TILEB, 0, wrow, wcol, l31, half, f0);
+    split_load_frag<true, true>(lds, lds + TILEB, 0, wrow, wcol, l31, half, f0);
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const char* As = lds + buf * 2 * TILEB;
         load_tile(kt + 1, (kt + 1) < kt_end);
         __builtin_amdgcn_sched_barrier(0);
-        split_load_frag(As, As + TILEB, 1, wrow, wcol, l31, half, f1);
+        split_load_frag<true, true>(As, As + TILEB, 1, wrow, wcol, l31, half, f1);
         __builtin_amdgcn_sched_barrier(0);
         split_mfma(f0, acc);
         __builtin_amdgcn_sched_barrier(0);
         store_tile(buf ^ 1);                               // same hand-over as gg_mainloop_split
         __syncthreads();
-        split_load_frag(lds + (buf ^ 1) * 2 * TILEB, lds + (buf ^ 1) * 2 * TILEB + TILEB, 0, wrow, wcol, l31, half, f0);
+        split_load_frag<true, true>(lds + (buf ^ 1) * 2 * TILEB, lds + (buf ^ 1) * 2 * TILEB + TILEB, 0, wrow, wcol, l31, half, f0);
         __builtin_amdgcn_sched_barrier(0);
         split_mfma(f1, acc);
         __builtin_amdgcn_sched_barrier(0);
