@@ -1675,7 +1675,7 @@ static bool wgrad_s1_shape(const DpigConvDesc* d, int pt, int pl, int Ho, int Wo
            pt >= 0 && pl >= 0 && d->ldx % 4 == 0 && d->ldy % 4 == 0 && d->C % 4 == 0 && d->K % 4 == 0;
 }
 
-extern "C" size_t dpig_conv2d_workspace_bytes(const DpigConvDesc* d, int which) {
+static size_t conv2d_workspace_bytes_one(const DpigConvDesc* d, int which) {
     int pt, pl, Ho, Wo;
     if (resolve_desc(d, &pt, &pl, &Ho, &Wo)) return 0;
     // (pointer alignment is not known here: when the bf16 loop may be chosen, size for the larger of the two plans)
@@ -1727,9 +1727,85 @@ extern "C" size_t dpig_conv2d_workspace_bytes(const DpigConvDesc* d, int which) 
     return 0;
 }
 
+// ---- entry points: one launch, or runs of whole images when a tensor exceeds one launch's 2 GiB range (dpig_conv_plan.h) ----
+static int conv2d_fwd_one(const DpigConvDesc* d, const float* x, const float* w, const float* bias,
+                          const float* residual, float* y, float* y_act, void* ws, size_t ws_bytes, void* stream);
+static int conv2d_dgrad_one(const DpigConvDesc* d, const float* dy, const float* w, const float* accum,
+                            const float* mask, float* dx, void* ws, size_t ws_bytes, void* stream);
+static int conv2d_wgrad_one(const DpigConvDesc* d, const float* x, const float* dy, float* dw, float beta,
+                            float* db, float beta_b, void* ws, size_t ws_bytes, void* stream);
+
+extern "C" size_t dpig_conv2d_workspace_bytes(const DpigConvDesc* d, int which) {
+    const int per = images_per_launch(d, 4);
+    if (!d || per <= 0 || per >= d->N) return conv2d_workspace_bytes_one(d, which);
+    DpigConvDesc c = *d;                         // the full runs and the remainder plan their split-K separately
+    c.N = per;
+    size_t best = conv2d_workspace_bytes_one(&c, which);
+    if (d->N % per) {
+        c.N = d->N % per;
+        const size_t b = conv2d_workspace_bytes_one(&c, which);
+        if (b > best) best = b;
+    }
+    return best;
+}
+
 extern "C" int dpig_conv2d_fwd(const DpigConvDesc* d, const float* x, const float* w, const float* bias,
                                const float* residual, float* y, float* y_act, void* ws, size_t ws_bytes,
                                void* stream) {
+    const int per = images_per_launch(d, 4);
+    if (d && per == 0) return fail(DPIG_EINVAL, "one image exceeds the 2 GiB range of a launch");
+    if (!d || per >= d->N || !x || !y) return conv2d_fwd_one(d, x, w, bias, residual, y, y_act, ws, ws_bytes, stream);
+    long xpix, ypix;
+    image_pixels(d, &xpix, &ypix);
+    for (int n0 = 0; n0 < d->N; n0 += per) {
+        DpigConvDesc c = *d;
+        c.N = d->N - n0 < per ? d->N - n0 : per;
+        const float* r = !residual ? nullptr : residual + (d->res_class ? (long)n0 * 9 * d->ldres : (long)n0 * ypix * d->ldres);
+        const int rc = conv2d_fwd_one(&c, x + (long)n0 * xpix * d->ldx, w, bias, r, y + (long)n0 * ypix * d->ldy,
+                                      y_act ? y_act + (long)n0 * ypix * d->ldy2 : nullptr, ws, ws_bytes, stream);
+        if (rc) return rc;
+    }
+    return DPIG_OK;
+}
+
+extern "C" int dpig_conv2d_dgrad(const DpigConvDesc* d, const float* dy, const float* w, const float* accum,
+                                 const float* mask, float* dx, void* ws, size_t ws_bytes, void* stream) {
+    const int per = images_per_launch(d, 4);
+    if (d && per == 0) return fail(DPIG_EINVAL, "one image exceeds the 2 GiB range of a launch");
+    if (!d || per >= d->N || !dy || !dx) return conv2d_dgrad_one(d, dy, w, accum, mask, dx, ws, ws_bytes, stream);
+    long xpix, ypix;
+    image_pixels(d, &xpix, &ypix);
+    for (int n0 = 0; n0 < d->N; n0 += per) {
+        DpigConvDesc c = *d;
+        c.N = d->N - n0 < per ? d->N - n0 : per;
+        const int rc = conv2d_dgrad_one(&c, dy + (long)n0 * ypix * d->ldy, w, accum ? accum + (long)n0 * xpix * d->ldres : nullptr,
+                                        mask ? mask + (long)n0 * xpix * d->ldmask : nullptr, dx + (long)n0 * xpix * d->ldx, ws,
+                                        ws_bytes, stream);
+        if (rc) return rc;
+    }
+    return DPIG_OK;
+}
+
+extern "C" int dpig_conv2d_wgrad(const DpigConvDesc* d, const float* x, const float* dy, float* dw, float beta,
+                                 float* db, float beta_b, void* ws, size_t ws_bytes, void* stream) {
+    const int per = images_per_launch(d, 4);
+    if (d && per == 0) return fail(DPIG_EINVAL, "one image exceeds the 2 GiB range of a launch");
+    if (!d || per >= d->N || !x || !dy) return conv2d_wgrad_one(d, x, dy, dw, beta, db, beta_b, ws, ws_bytes, stream);
+    long xpix, ypix;
+    image_pixels(d, &xpix, &ypix);
+    for (int n0 = 0; n0 < d->N; n0 += per) {     // image runs accumulate in order: same result on every call
+        DpigConvDesc c = *d;
+        c.N = d->N - n0 < per ? d->N - n0 : per;
+        const int rc = conv2d_wgrad_one(&c, x + (long)n0 * xpix * d->ldx, dy + (long)n0 * ypix * d->ldy, dw, n0 ? 1.0f : beta, db,
+                                        n0 ? 1.0f : beta_b, ws, ws_bytes, stream);
+        if (rc) return rc;
+    }
+    return DPIG_OK;
+}
+
+static int conv2d_fwd_one(const DpigConvDesc* d, const float* x, const float* w, const float* bias,
+                          const float* residual, float* y, float* y_act, void* ws, size_t ws_bytes,
+                          void* stream) {
     int pt, pl, Ho, Wo;
     int rc = resolve_desc(d, &pt, &pl, &Ho, &Wo);
     if (rc) return rc;
@@ -1772,8 +1848,8 @@ extern "C" int dpig_conv2d_fwd(const DpigConvDesc* d, const float* x, const floa
     return launch_gg(p, false, d->N, (long)d->R * d->S * d->C * d->K, static_cast<hipStream_t>(stream), pipe);
 }
 
-extern "C" int dpig_conv2d_dgrad(const DpigConvDesc* d, const float* dy, const float* w, const float* accum,
-                                 const float* mask, float* dx, void* ws, size_t ws_bytes, void* stream) {
+static int conv2d_dgrad_one(const DpigConvDesc* d, const float* dy, const float* w, const float* accum,
+                            const float* mask, float* dx, void* ws, size_t ws_bytes, void* stream) {
     int pt, pl, Ho, Wo;
     int rc = resolve_desc(d, &pt, &pl, &Ho, &Wo);
     if (rc) return rc;
@@ -1835,8 +1911,8 @@ extern "C" int dpig_conv2d_dgrad(const DpigConvDesc* d, const float* dy, const f
     return launch_gg(p, true, d->N, (long)d->R * d->S * d->C * d->K, st, pipe);
 }
 
-extern "C" int dpig_conv2d_wgrad(const DpigConvDesc* d, const float* x, const float* dy, float* dw, float beta,
-                                 float* db, float beta_b, void* ws, size_t ws_bytes, void* stream) {
+static int conv2d_wgrad_one(const DpigConvDesc* d, const float* x, const float* dy, float* dw, float beta,
+                            float* db, float beta_b, void* ws, size_t ws_bytes, void* stream) {
     int pt, pl, Ho, Wo;
     int rc = resolve_desc(d, &pt, &pl, &Ho, &Wo);
     if (rc) return rc;

@@ -1202,7 +1202,7 @@ extern "C" int dpig_conv2d_bf16_supported(const DpigConvDesc* d, int which) {
     return shape_ok(d) ? 1 : 0;
 }
 
-extern "C" size_t dpig_conv2d_bf16_workspace_bytes(const DpigConvDesc* d, int which) {
+static size_t bf16_workspace_bytes_one(const DpigConvDesc* d, int which) {
     int pt, pl, Ho, Wo;
     if (resolve_desc(d, &pt, &pl, &Ho, &Wo) || !shape_ok(d)) return 0;
     if (which == 0) {
@@ -1228,9 +1228,86 @@ extern "C" size_t dpig_conv2d_bf16_workspace_bytes(const DpigConvDesc* d, int wh
     return 0;
 }
 
+// ---- entry points: one launch, or runs of whole images when a tensor exceeds one launch's 2 GiB range (dpig_conv_plan.h) ----
+static int fwd_bf16_one(const DpigConvDesc* d, const uint16_t* x, const uint16_t* w_t, const float* bias,
+                        const uint16_t* residual, const float* residual_class, uint16_t* y, uint16_t* y_act, void* ws,
+                        size_t ws_bytes, void* stream);
+static int dgrad_bf16_one(const DpigConvDesc* d, const uint16_t* dy, const uint16_t* w, const uint16_t* accum,
+                          const uint16_t* mask, uint16_t* dx, void* ws, size_t ws_bytes, void* stream);
+static int wgrad_bf16_one(const DpigConvDesc* d, const uint16_t* x, const uint16_t* dy, float* dw, float beta, float* db,
+                          float beta_b, void* ws, size_t ws_bytes, void* stream);
+
+extern "C" size_t dpig_conv2d_bf16_workspace_bytes(const DpigConvDesc* d, int which) {
+    const int per = images_per_launch(d, 2);
+    if (!d || per <= 0 || per >= d->N) return bf16_workspace_bytes_one(d, which);
+    DpigConvDesc c = *d;
+    c.N = per;
+    size_t best = bf16_workspace_bytes_one(&c, which);
+    if (d->N % per) {
+        c.N = d->N % per;
+        const size_t b = bf16_workspace_bytes_one(&c, which);
+        if (b > best) best = b;
+    }
+    return best;
+}
+
 extern "C" int dpig_conv2d_fwd_bf16(const DpigConvDesc* d, const uint16_t* x, const uint16_t* w_t, const float* bias,
                                     const uint16_t* residual, const float* residual_class, uint16_t* y, uint16_t* y_act,
                                     void* ws, size_t ws_bytes, void* stream) {
+    const int per = images_per_launch(d, 2);
+    if (d && per == 0) return fail(DPIG_EINVAL, "one image exceeds the 2 GiB range of a launch");
+    if (!d || per >= d->N || !x || !y) return fwd_bf16_one(d, x, w_t, bias, residual, residual_class, y, y_act, ws, ws_bytes, stream);
+    long xpix, ypix;
+    image_pixels(d, &xpix, &ypix);
+    for (int n0 = 0; n0 < d->N; n0 += per) {
+        DpigConvDesc c = *d;
+        c.N = d->N - n0 < per ? d->N - n0 : per;
+        const int rc = fwd_bf16_one(&c, x + (long)n0 * xpix * d->ldx, w_t, bias, residual ? residual + (long)n0 * ypix * d->ldres : nullptr,
+                                    residual_class ? residual_class + (long)n0 * 9 * d->ldres : nullptr, y + (long)n0 * ypix * d->ldy,
+                                    y_act ? y_act + (long)n0 * ypix * d->ldy2 : nullptr, ws, ws_bytes, stream);
+        if (rc) return rc;
+    }
+    return DPIG_OK;
+}
+
+extern "C" int dpig_conv2d_dgrad_bf16(const DpigConvDesc* d, const uint16_t* dy, const uint16_t* w, const uint16_t* accum,
+                                      const uint16_t* mask, uint16_t* dx, void* ws, size_t ws_bytes, void* stream) {
+    const int per = images_per_launch(d, 2);
+    if (d && per == 0) return fail(DPIG_EINVAL, "one image exceeds the 2 GiB range of a launch");
+    if (!d || per >= d->N || !dy || !dx) return dgrad_bf16_one(d, dy, w, accum, mask, dx, ws, ws_bytes, stream);
+    long xpix, ypix;
+    image_pixels(d, &xpix, &ypix);
+    for (int n0 = 0; n0 < d->N; n0 += per) {
+        DpigConvDesc c = *d;
+        c.N = d->N - n0 < per ? d->N - n0 : per;
+        const int rc = dgrad_bf16_one(&c, dy + (long)n0 * ypix * d->ldy, w, accum ? accum + (long)n0 * xpix * d->ldres : nullptr,
+                                      mask ? mask + (long)n0 * xpix * d->ldmask : nullptr, dx + (long)n0 * xpix * d->ldx, ws, ws_bytes,
+                                      stream);
+        if (rc) return rc;
+    }
+    return DPIG_OK;
+}
+
+extern "C" int dpig_conv2d_wgrad_bf16(const DpigConvDesc* d, const uint16_t* x, const uint16_t* dy, float* dw, float beta,
+                                      float* db, float beta_b, void* ws, size_t ws_bytes, void* stream) {
+    const int per = images_per_launch(d, 2);
+    if (d && per == 0) return fail(DPIG_EINVAL, "one image exceeds the 2 GiB range of a launch");
+    if (!d || per >= d->N || !x || !dy) return wgrad_bf16_one(d, x, dy, dw, beta, db, beta_b, ws, ws_bytes, stream);
+    long xpix, ypix;
+    image_pixels(d, &xpix, &ypix);
+    for (int n0 = 0; n0 < d->N; n0 += per) {     // image runs accumulate in order: same result on every call
+        DpigConvDesc c = *d;
+        c.N = d->N - n0 < per ? d->N - n0 : per;
+        const int rc = wgrad_bf16_one(&c, x + (long)n0 * xpix * d->ldx, dy + (long)n0 * ypix * d->ldy, dw, n0 ? 1.0f : beta, db,
+                                      n0 ? 1.0f : beta_b, ws, ws_bytes, stream);
+        if (rc) return rc;
+    }
+    return DPIG_OK;
+}
+
+static int fwd_bf16_one(const DpigConvDesc* d, const uint16_t* x, const uint16_t* w_t, const float* bias,
+                        const uint16_t* residual, const float* residual_class, uint16_t* y, uint16_t* y_act,
+                        void* ws, size_t ws_bytes, void* stream) {
     int pt, pl, Ho, Wo;
     int rc = resolve_desc(d, &pt, &pl, &Ho, &Wo);
     if (rc) return rc;
@@ -1264,8 +1341,8 @@ extern "C" int dpig_conv2d_fwd_bf16(const DpigConvDesc* d, const uint16_t* x, co
     return launch_bg(p, d->N, (long)d->R * d->S * d->C * d->K, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int dpig_conv2d_dgrad_bf16(const DpigConvDesc* d, const uint16_t* dy, const uint16_t* w, const uint16_t* accum,
-                                      const uint16_t* mask, uint16_t* dx, void* ws, size_t ws_bytes, void* stream) {
+static int dgrad_bf16_one(const DpigConvDesc* d, const uint16_t* dy, const uint16_t* w, const uint16_t* accum,
+                          const uint16_t* mask, uint16_t* dx, void* ws, size_t ws_bytes, void* stream) {
     int pt, pl, Ho, Wo;
     int rc = resolve_desc(d, &pt, &pl, &Ho, &Wo);
     if (rc) return rc;
@@ -1322,8 +1399,8 @@ extern "C" int dpig_conv2d_dgrad_bf16(const DpigConvDesc* d, const uint16_t* dy,
     return launch_bg(p, d->N, felems, st);
 }
 
-extern "C" int dpig_conv2d_wgrad_bf16(const DpigConvDesc* d, const uint16_t* x, const uint16_t* dy, float* dw, float beta,
-                                      float* db, float beta_b, void* ws, size_t ws_bytes, void* stream) {
+static int wgrad_bf16_one(const DpigConvDesc* d, const uint16_t* x, const uint16_t* dy, float* dw, float beta,
+                          float* db, float beta_b, void* ws, size_t ws_bytes, void* stream) {
     int pt, pl, Ho, Wo;
     int rc = resolve_desc(d, &pt, &pl, &Ho, &Wo);
     if (rc) return rc;

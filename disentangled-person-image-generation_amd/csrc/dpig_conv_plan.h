@@ -121,4 +121,35 @@ static inline void plan_dgrad_s2(const DpigConvDesc* d, int pt, int pl, S2Plan* 
     }
 }
 
+// ---- batches beyond one launch's address range ---------------------------------------------------------------------------
+// A launch addresses every tensor through ONE buffer descriptor and 32-bit offsets, so it must see less than 2 GiB of each
+// operand.  Larger batches are cut into runs of whole images: independent launches for forward / dgrad, accumulated in image
+// order (beta = 1 after the first run: deterministic) for wgrad.  Returns the images per launch (>= N: one launch), or 0 when
+// a single image is already too large.  `es` = bytes per activation element (4, or 2 for the bf16-storage entry points).
+static inline int images_per_launch(const DpigConvDesc* d, long es) {
+    if (!d || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->R <= 0 || d->S <= 0 || (d->stride != 1 && d->stride != 2)) return d ? d->N : 1;
+    int ho, wo;
+    dpig_same_pad(d->H, d->R, d->stride, &ho, nullptr);
+    dpig_same_pad(d->W, d->S, d->stride, &wo, nullptr);
+    const long xpix = (long)d->H * d->W, ypix = d->upsample2x ? 4 * xpix : (long)ho * wo;
+    long ldx = d->ldx, ldy = d->ldy;            // aux tensors ride on either pixel set: residual / accum, mask, second output
+    if (d->ldres > ldx) ldx = d->ldres;
+    if (d->ldmask > ldx) ldx = d->ldmask;
+    if (d->ldres > ldy) ldy = d->ldres;
+    if (d->ldy2 > ldy) ldy = d->ldy2;
+    if (ldx <= 0 || ldy <= 0) return d->N;
+    const long per = (xpix * ldx > ypix * ldy ? xpix * ldx : ypix * ldy) * es;
+    const long lim = 0x7f000000L;               // 2 GiB minus room for the halo offsets folded into the descriptors
+    const long n = lim / per;
+    return n <= 0 ? 0 : (n >= d->N ? d->N : (int)n);
+}
+// per-image element strides of the tensors of one conv (x-side pixels, y-side pixels)
+static inline void image_pixels(const DpigConvDesc* d, long* xpix, long* ypix) {
+    int ho, wo;
+    dpig_same_pad(d->H, d->R, d->stride, &ho, nullptr);
+    dpig_same_pad(d->W, d->S, d->stride, &wo, nullptr);
+    *xpix = (long)d->H * d->W;
+    *ypix = d->upsample2x ? 4 * *xpix : (long)ho * wo;
+}
+
 }  // namespace dpig

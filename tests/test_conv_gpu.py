@@ -432,8 +432,9 @@ def test_conv_bf16_falls_back_to_fp32_when_ineligible(dev):
 
 
 def test_edge_cases_empty_huge_and_misaligned(dev):
-    """Empty batches and > 2 GiB tensors are refused with a status (nothing is launched); operands that are not
-    16-byte aligned take the dword-load variants and still give the right answer."""
+    """Empty batches and single images beyond a launch's 2 GiB range are refused with a status (nothing is launched);
+    operands that are not 16-byte aligned take the dword-load variants and still give the right answer.  (Batches beyond
+    2 GiB are served in runs of whole images: test_batches_beyond_two_gib.)"""
     import ctypes
     import dpig_amd.hip_ops as H
     from dpig_amd._lib import lib
@@ -442,12 +443,9 @@ def test_edge_cases_empty_huge_and_misaligned(dev):
     w = torch.zeros(3, 3, 8, 8, device=dev)
     with pytest.raises(RuntimeError):
         H.conv2d_fwd(torch.zeros(0, 4, 4, 8, device=dev), w)
-    # a descriptor that claims 16 x 4096 x 4096 x 64 floats (16 GiB) on a tiny allocation: refused before any launch
+    # a descriptor whose every IMAGE is 4096 x 4096 x 64 floats (4 GiB), on a tiny allocation: refused before any launch
     d = H._desc(16, 4096, 4096, 64, 64, 3, 3, 1, 64, 64)
     y = torch.zeros(16, device=dev)
-    rc = lib().dpig_conv2d_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), None, None, 0, None)
-    assert rc != 0 and b"exceeds" in lib().dpig_last_error()
-    d = H._desc(8, 1024, 1024, 64, 64, 3, 3, 1, 64, 64)          # 2 GiB: past the 32-bit buffer-descriptor range
     rc = lib().dpig_conv2d_fwd(ctypes.byref(d), x.data_ptr(), w.data_ptr(), None, None, y.data_ptr(), None, None, 0, None)
     assert rc != 0 and b"exceeds" in lib().dpig_last_error()
     # misaligned views (offset by one float) of x, w and the output
@@ -464,3 +462,45 @@ def test_edge_cases_empty_huge_and_misaligned(dev):
     O.conv2d_same(xg, wg, None, 1).backward(dy)
     _close(H.conv2d_dgrad(dy.float().to(dev), wv, (N, Hh, W, C)), xg.grad)
     _close(H.conv2d_wgrad(xv, dy.float().to(dev), (3, 3, C, K)), wg.grad)
+
+
+@pytest.mark.parametrize("storage", ["f32", "bf16"])
+def test_batches_beyond_two_gib(dev, storage):
+    """A launch addresses each tensor through one buffer descriptor (< 2 GiB).  Bigger batches are cut into runs of whole
+    images by the entry points themselves (forward / dgrad: independent runs; wgrad: runs accumulated in image order).
+    x is 2.4 GiB here; every image of the big call must equal the same kernel run on that image alone, the filter gradient
+    the sum over three sub-batches that each fit one launch, and the call is repeatable bit for bit."""
+    import dpig_amd.hip_ops as H
+    bf = storage == "bf16"
+    N, Hh, W, C, K = (72, 128, 128, 1024, 64) if bf else (72, 128, 128, 512, 64)
+    g = torch.Generator(device=dev).manual_seed(8)
+    dt = torch.bfloat16 if bf else torch.float32
+    x = torch.empty(N, Hh, W, C, device=dev, dtype=dt)
+    for n in range(0, N, 8):                                   # (randn of 2.4 GiB in one piece would need a 2x temporary)
+        x[n:n + 8] = torch.randn(min(8, N - n), Hh, W, C, device=dev, generator=g).to(dt)
+    assert x.numel() * x.element_size() > 2 ** 31
+    w = torch.randn(3, 3, C, K, device=dev, generator=g) * 0.05
+    b = torch.randn(K, device=dev, generator=g)
+    y = H.conv2d_fwd(x, w, b, act=1)
+    assert torch.equal(H.conv2d_fwd(x, w, b, act=1), y)
+    tol = (2.0 ** -7 if bf else 2e-5)
+    for n in (0, 17, 62, 63, 71):                               # 63 images per launch here: both sides of the run boundary
+        yn = H.conv2d_fwd(x[n:n + 1], w, b, act=1)
+        assert float((y[n:n + 1].float() - yn.float()).abs().max()) <= tol * float(yn.float().abs().max()), n
+    dy = torch.randn(N, Hh, W, K, device=dev, generator=g).to(dt)
+    dx = H.conv2d_dgrad(dy, w, (N, Hh, W, C))
+    for n in (0, 62, 63, 71):
+        dn = H.conv2d_dgrad(dy[n:n + 1], w, (1, Hh, W, C))
+        assert float((dx[n:n + 1].float() - dn.float()).abs().max()) <= tol * float(dn.float().abs().max()), n
+    del dx
+    db = torch.zeros(K, device=dev)
+    dw = H.conv2d_wgrad(x, dy, (3, 3, C, K), out=torch.empty(3, 3, C, K, device=dev), beta=0.0, db=db, db_beta=0.0)
+    ref = torch.zeros_like(dw); refb = torch.zeros_like(db)
+    for n0 in range(0, N, 24):
+        dbp = torch.zeros(K, device=dev)
+        ref += H.conv2d_wgrad(x[n0:n0 + 24], dy[n0:n0 + 24], (3, 3, C, K), out=torch.empty(3, 3, C, K, device=dev), beta=0.0, db=dbp, db_beta=0.0)
+        refb += dbp
+    assert float((dw - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    assert float((db - refb).abs().max()) <= 2e-5 * float(refb.abs().max())
+    dw2 = H.conv2d_wgrad(x, dy, (3, 3, C, K), out=torch.empty(3, 3, C, K, device=dev), beta=0.0)
+    assert torch.equal(dw2, dw)
