@@ -151,8 +151,13 @@ class _ConvFn(torch.autograd.Function):
     """y = act(conv_SAME(x, w) + b)   [optionally on a nearest-2x-upsampled x, 1x1 only]."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, act, alpha, upsample2x):
-        y = H.conv2d_fwd(x, w, b, stride=stride, act=act, alpha=alpha, upsample2x=upsample2x)
+    def forward(ctx, x, w, b, stride, act, alpha, upsample2x, stats_box=None):
+        if stats_box is not None and act == ACT_NONE and not upsample2x:
+            # the caller's next op is a batch norm: let the conv epilogue leave the per-tile statistics (None when it cannot)
+            y, st = H.conv2d_fwd_stats(x, w, b, stride=stride)
+            stats_box.append(st)
+        else:
+            y = H.conv2d_fwd(x, w, b, stride=stride, act=act, alpha=alpha, upsample2x=upsample2x)
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         ctx.cfg = (stride, act, alpha, upsample2x, b is not None)
         ctx.b_ref = b
@@ -175,14 +180,22 @@ class _ConvFn(torch.autograd.Function):
             else:
                 dx = H.conv2d_dgrad(dz, w, tuple(x.shape), stride=stride, upsample2x=up)
         if _PARAM_GRADS_OFF[0]:
-            return dx, None, None, None, None, None, None
+            return dx, None, None, None, None, None, None, None
         dw, db = _sink_wgrad_bias(w, ctx.b_ref, x, dz, stride, up, ctx.needs_input_grad[1],
                                   has_b and ctx.needs_input_grad[2])
-        return dx, dw, db, None, None, None, None
+        return dx, dw, db, None, None, None, None, None
 
 
-def conv2d(x, w, b=None, stride=1, act=ACT_NONE, alpha=0.2, upsample2x=False):
-    return _ConvFn.apply(x, w, b, stride, act, alpha, upsample2x)
+def conv2d(x, w, b=None, stride=1, act=ACT_NONE, alpha=0.2, upsample2x=False, bn_stats=False):
+    """`bn_stats=True` (the next op is a training-mode batch norm over this output): the result carries `_dpig_bnstats`, the
+    conv epilogue's per-tile statistics, when the launch plan allows it (hip_ops.conv2d_fwd_stats)."""
+    if not bn_stats:
+        return _ConvFn.apply(x, w, b, stride, act, alpha, upsample2x)
+    box = []
+    y = _ConvFn.apply(x, w, b, stride, act, alpha, upsample2x, box)
+    if box and box[0] is not None:
+        y._dpig_bnstats = box[0]
+    return y
 
 
 class _ResBlockFn(torch.autograd.Function):
@@ -390,8 +403,8 @@ class _BatchNormFn(torch.autograd.Function):
     """Training-mode BN over (N,H,W) of an NHWC tensor + fused activation (batchnorm.py:30)."""
 
     @staticmethod
-    def forward(ctx, x, scale, offset, eps, act, alpha):
-        y, mean, rstd = H.bn_fwd(x, scale, offset, eps, act, alpha)
+    def forward(ctx, x, scale, offset, eps, act, alpha, stats=None):
+        y, mean, rstd = H.bn_fwd(x, scale, offset, eps, act, alpha, stats=stats)
         ctx.save_for_backward(x, scale, mean, rstd, y if act != ACT_NONE else None)
         ctx.cfg = (act, alpha)
         ctx.offset_ref = offset
@@ -403,10 +416,10 @@ class _BatchNormFn(torch.autograd.Function):
         act, alpha = ctx.cfg
         dx, dscale, doffset = H.bn_bwd(dy, x, y, scale, mean, rstd, act, alpha)
         if _PARAM_GRADS_OFF[0]:
-            return dx, None, None, None, None, None
+            return dx, None, None, None, None, None, None
         ds = _sink_small(scale, dscale) if ctx.needs_input_grad[1] else None
         do = _sink_small(ctx.offset_ref, doffset) if ctx.needs_input_grad[2] else None
-        return dx, ds, do, None, None, None
+        return dx, ds, do, None, None, None, None
 
 
 class _SyncBatchNormFn(torch.autograd.Function):
@@ -471,12 +484,13 @@ def set_sync_batchnorm(enabled, group=None):
     _SYNC_BN_GROUP[0], _SYNC_BN_GROUP[1] = bool(enabled), group
 
 
-def batchnorm(x, scale, offset, eps=1e-5, act=ACT_NONE, alpha=0.2):
+def batchnorm(x, scale, offset, eps=1e-5, act=ACT_NONE, alpha=0.2, stats=None):
+    """`stats`: the `_dpig_bnstats` a `conv2d(..., bn_stats=True)` attached to x (ignored with cross-rank statistics)."""
     if _SYNC_BN_GROUP[0]:
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(_SYNC_BN_GROUP[1]) > 1:
             return _SyncBatchNormFn.apply(x, scale, offset, eps, act, alpha, _SYNC_BN_GROUP[1])
-    return _BatchNormFn.apply(x, scale, offset, eps, act, alpha)
+    return _BatchNormFn.apply(x, scale, offset, eps, act, alpha, stats)
 
 
 class _LayerNormFn(torch.autograd.Function):

@@ -52,6 +52,7 @@ struct GGParams {
     const float* res;     // residual / accumulate tensor (dest-shaped) or null
     const float* mask;    // activation-output tensor for act' (dest-shaped) or null
     float* partial;       // split-K workspace [nsplit][M][Ncols]
+    float* stats;         // BN partial statistics [mtiles][2][Ncols] of v + bias (sum, centred squares per row tile) or null
     int M, Hr, Wr, HrWr;  // row grid (rows = images x Hr x Wr)
     int Hs, Ws, lda, Cs, sr;   // source spatial dims, channel stride, reduction channels, row->src stride
     int Ncols;            // GEMM N
@@ -878,6 +879,63 @@ __device__ __forceinline__ void gather_gemm_body(const GGParams& p) {
             }
         }
     }
+    // ---- batch-norm partial statistics of this row tile (tflib/ops/batchnorm.py:30 after conv2d.py:106-120) -------------
+    // The tile is still in LDS: per column its sum and the sum of squared deviations from the TILE's own mean (two passes over
+    // LDS, so no E[x^2] - E[x]^2 cancellation); dpig_bn_stats_finalize merges the tiles pairwise-exactly (Chan et al.) in
+    // tile order.  Only launched un-split with the float4 epilogue on 128-wide tiles (launch_gg checks).
+    if constexpr (!NARROW) {
+    if (p.stats) {
+        const int c = (tid & 31) * 4, col = n0 + c, rl0 = tid >> 5;
+        const bool cok = col < p.Ncols;
+        const int nrows = min(BM, p.M - m0);
+        float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias && cok) bv = *reinterpret_cast<const float4*>(p.bias + col);
+        float* red = Cs + BM * LDC;                 // 8 x 128 floats behind the staged tile
+        float4 sm = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int rl = rl0 + 8 * it;
+            if (rl < nrows) {
+                const float4 v = *reinterpret_cast<const float4*>(&Cs[rl * LDC + c]);
+                sm.x += v.x + bv.x; sm.y += v.y + bv.y; sm.z += v.z + bv.z; sm.w += v.w + bv.w;
+            }
+        }
+        *reinterpret_cast<float4*>(&red[rl0 * BN + c]) = sm;
+        __syncthreads();
+        float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const float4 t = *reinterpret_cast<const float4*>(&red[g * BN + c]);
+            tot.x += t.x; tot.y += t.y; tot.z += t.z; tot.w += t.w;
+        }
+        const float inv = 1.0f / (float)nrows;
+        const float4 mean = make_float4(tot.x * inv, tot.y * inv, tot.z * inv, tot.w * inv);
+        __syncthreads();
+        float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int rl = rl0 + 8 * it;
+            if (rl < nrows) {
+                const float4 v = *reinterpret_cast<const float4*>(&Cs[rl * LDC + c]);
+                const float dx = v.x + bv.x - mean.x, dy = v.y + bv.y - mean.y, dz = v.z + bv.z - mean.z, dw = v.w + bv.w - mean.w;
+                q.x += dx * dx; q.y += dy * dy; q.z += dz * dz; q.w += dw * dw;
+            }
+        }
+        *reinterpret_cast<float4*>(&red[rl0 * BN + c]) = q;
+        __syncthreads();
+        if (rl0 == 0 && cok) {
+            float4 qt = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int g = 0; g < 8; ++g) {
+                const float4 t = *reinterpret_cast<const float4*>(&red[g * BN + c]);
+                qt.x += t.x; qt.y += t.y; qt.z += t.z; qt.w += t.w;
+            }
+            float* o = p.stats + (long)mt * 2 * p.Ncols + col;
+            *reinterpret_cast<float4*>(o) = tot;
+            *reinterpret_cast<float4*>(o + p.Ncols) = qt;
+        }
+    }
+    }
 #ifdef DPIG_TRACE
     if (tid == 0 && blockIdx.x < 8192 && blockIdx.z == 0) dpig_trace_se[blockIdx.x * 4 + 3] = __builtin_amdgcn_s_memtime();
 #endif
@@ -1590,6 +1648,8 @@ static int launch_gg(GGParams& p, bool b_rowk, int nimg, long filter_elems, hipS
     if (rc) return rc;
     dim3 grid(p.mtiles * p.ntiles, 1, p.nsplit), block(256);
     if (pipe && (!vec || narrow)) return fail(DPIG_EINVAL, "internal: bf16 loop selected for an ineligible problem");
+    if (p.stats && (p.nsplit != 1 || !p.vec_epi || narrow || !aligned16(p.stats)))
+        return fail(DPIG_EINVAL, "conv fwd with BN statistics needs an un-split plan, 16-byte aligned operands and more than 32 output channels");
 #define DPIG_GG(BR, VE, NA) hipLaunchKernelGGL((gather_gemm_kernel<BR, VE, NA>), grid, block, 0, st, p)
     if (pipe == 1) {
         if (b_rowk) hipLaunchKernelGGL((gather_gemm_kernel<true, true, false, 1>), grid, block, 0, st, p);
@@ -1729,7 +1789,8 @@ static size_t conv2d_workspace_bytes_one(const DpigConvDesc* d, int which) {
 
 // ---- entry points: one launch, or runs of whole images when a tensor exceeds one launch's 2 GiB range (dpig_conv_plan.h) ----
 static int conv2d_fwd_one(const DpigConvDesc* d, const float* x, const float* w, const float* bias,
-                          const float* residual, float* y, float* y_act, void* ws, size_t ws_bytes, void* stream);
+                          const float* residual, float* y, float* y_act, void* ws, size_t ws_bytes, void* stream,
+                          float* stats = nullptr);
 static int conv2d_dgrad_one(const DpigConvDesc* d, const float* dy, const float* w, const float* accum,
                             const float* mask, float* dx, void* ws, size_t ws_bytes, void* stream);
 static int conv2d_wgrad_one(const DpigConvDesc* d, const float* x, const float* dy, float* dw, float beta,
@@ -1766,6 +1827,27 @@ extern "C" int dpig_conv2d_fwd(const DpigConvDesc* d, const float* x, const floa
         if (rc) return rc;
     }
     return DPIG_OK;
+}
+
+// Forward conv (+ bias) that also leaves the batch-norm partial statistics of its output: row tiles of 128 output pixels,
+// stats[tile][0][K] = sum, stats[tile][1][K] = sum of squared deviations from the tile's mean.  The tile count is 0 when this
+// problem's plan cannot carry them (split-K, <= 32 output channels, the upsample fusion, a batch served in several runs):
+// the caller then runs dpig_bn_fwd's own statistics passes.
+extern "C" int dpig_conv2d_bn_stats_tiles(const DpigConvDesc* d) {
+    int pt, pl, Ho, Wo;
+    if (resolve_desc(d, &pt, &pl, &Ho, &Wo)) return 0;
+    if (d->upsample2x || d->K <= 32 || d->K % 4 || d->ldy % 4 || d->act != DPIG_ACT_NONE || images_per_launch(d, 4) < d->N) return 0;
+    const int bk = gg_bk(d, d->ldx, d->C, d->K);
+    Shape s = fwd_shape(d, Ho, Wo, bk);
+    Plan pln = plan_split(cdiv(s.M, BM) * cdiv(s.Ncols, BN), s.ktiles, d->split_k);
+    return pln.nsplit == 1 ? (int)cdiv(s.M, BM) : 0;
+}
+extern "C" int dpig_conv2d_fwd_stats(const DpigConvDesc* d, const float* x, const float* w, const float* bias, float* y,
+                                     float* stats, void* stream) {
+    if (!stats) return fail(DPIG_EINVAL, "conv fwd with BN statistics: null statistics buffer");
+    if (dpig_conv2d_bn_stats_tiles(d) <= 0)
+        return fail(DPIG_EINVAL, "conv fwd with BN statistics: this problem's plan cannot carry them (dpig_conv2d_bn_stats_tiles == 0)");
+    return conv2d_fwd_one(d, x, w, bias, nullptr, y, nullptr, nullptr, 0, stream, stats);
 }
 
 extern "C" int dpig_conv2d_dgrad(const DpigConvDesc* d, const float* dy, const float* w, const float* accum,
@@ -1805,7 +1887,7 @@ extern "C" int dpig_conv2d_wgrad(const DpigConvDesc* d, const float* x, const fl
 
 static int conv2d_fwd_one(const DpigConvDesc* d, const float* x, const float* w, const float* bias,
                           const float* residual, float* y, float* y_act, void* ws, size_t ws_bytes,
-                          void* stream) {
+                          void* stream, float* stats) {
     int pt, pl, Ho, Wo;
     int rc = resolve_desc(d, &pt, &pl, &Ho, &Wo);
     if (rc) return rc;
@@ -1820,11 +1902,14 @@ static int conv2d_fwd_one(const DpigConvDesc* d, const float* x, const float* w,
     if (y_act && d->ldy2 < d->K) return fail(DPIG_EINVAL, "ldy2 < K");
     if (y_act && d->upsample2x) return fail(DPIG_EINVAL, "y_act unsupported with upsample2x");
     if (residual && d->ldres < d->K) return fail(DPIG_EINVAL, "ldres < K");
-    rc = thin_fwd_try(d, pt, pl, x, w, bias, residual, y, y_act, static_cast<hipStream_t>(stream));
-    if (rc != 0) return rc < 0 ? rc : DPIG_OK;
-    rc = fewc_fwd_try(d, pt, pl, Ho, Wo, x, w, bias, residual, y, y_act, static_cast<hipStream_t>(stream));
-    if (rc != 0) return rc < 0 ? rc : DPIG_OK;
+    if (!stats) {
+        rc = thin_fwd_try(d, pt, pl, x, w, bias, residual, y, y_act, static_cast<hipStream_t>(stream));
+        if (rc != 0) return rc < 0 ? rc : DPIG_OK;
+        rc = fewc_fwd_try(d, pt, pl, Ho, Wo, x, w, bias, residual, y, y_act, static_cast<hipStream_t>(stream));
+        if (rc != 0) return rc < 0 ? rc : DPIG_OK;
+    }
     p.partial = static_cast<float*>(ws);
+    p.stats = stats;
     const int pipe = gg_pipe(d, d->ldx, d->C, d->K, x, w);
     const bool bf16 = pipe == 1;
     Shape s = fwd_shape(d, Ho, Wo, bf16 ? BKH : BK);

@@ -1032,6 +1032,56 @@ extern "C" int dpig_bn_bwd(const float* dy, int lddy, const float* x, int ldx, c
     return check_launch("bn_bwd");
 }
 
+// ---- statistics left by the producing conv's epilogue (dpig_conv2d_fwd_stats) -------------------------------------------
+// stats[tile][0][C] = sum over the tile's rows, stats[tile][1][C] = sum of squared deviations from the tile's own mean; tiles
+// hold `rows_per_tile` rows (the last one the remainder).  Merged with the exact pairwise update (Chan, Golub, LeVeque):
+// 4 lanes per column take every 4th tile in order, then the 4 partial results are merged in lane order -- fixed order,
+// no atomics.  mean and rstd = 1/sqrt(biased variance + eps) are what dpig_bn_apply / dpig_bn_bwd expect.
+__global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ stats, int tiles, long rows,
+                                                                int rows_per_tile, int C, float eps,
+                                                                float* __restrict__ mean_out, float* __restrict__ rstd_out) {
+    __shared__ float sn[4][64], sm[4][64], sq[4][64];
+    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    if (c < C) {
+        for (int t = g; t < tiles; t += 4) {
+            const long left = rows - (long)t * rows_per_tile;
+            const float nb = (float)(left < rows_per_tile ? left : rows_per_tile);
+            const float mb = stats[((long)t * 2) * C + c] / nb, qb = stats[((long)t * 2 + 1) * C + c];
+            const float nt = n + nb, delta = mb - mean;
+            mean += delta * (nb / nt);
+            m2 += qb + delta * delta * (n * nb / nt);
+            n = nt;
+        }
+    }
+    sn[g][cl] = n; sm[g][cl] = mean; sq[g][cl] = m2;
+    __syncthreads();
+    if (g == 0 && c < C) {
+        for (int k = 1; k < 4; ++k) {
+            const float nb = sn[k][cl];
+            if (nb > 0.f) {
+                const float nt = n + nb, delta = sm[k][cl] - mean;
+                mean += delta * (nb / nt);
+                m2 += sq[k][cl] + delta * delta * (n * nb / nt);
+                n = nt;
+            }
+        }
+        mean_out[c] = mean;
+        rstd_out[c] = 1.0f / sqrtf(m2 / n + eps);
+    }
+}
+extern "C" int dpig_bn_stats_finalize(const float* stats, int tiles, int64_t rows, int rows_per_tile, int C, float eps,
+                                      float* mean, float* rstd, void* stream) {
+    if (!stats || !mean || !rstd) return fail(DPIG_EINVAL, "bn_stats_finalize: null pointer");
+    if (tiles <= 0 || rows <= 0 || rows_per_tile <= 0 || C <= 0 || (long)tiles * rows_per_tile < rows ||
+        (long)(tiles - 1) * rows_per_tile >= rows)
+        return fail(DPIG_EINVAL, "bn_stats_finalize: %d tiles of %d rows do not cover %ld rows", tiles, rows_per_tile, (long)rows);
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdivi(C, 64)), dim3(256), 0, static_cast<hipStream_t>(stream), stats,
+                       tiles, (long)rows, rows_per_tile, C, eps, mean, rstd);
+    return check_launch("bn_stats_finalize");
+}
+
 // ---- staged form (synchronised BN over data-parallel ranks): the caller all-reduces the [C] vectors ----------
 extern "C" int dpig_bn_sqdev(const float* x, int ldx, int64_t rows, int C, const float* mean, float* sq_out,
                              void* ws, size_t ws_bytes, void* stream) {

@@ -331,6 +331,34 @@ def conv2d_fwd(x, w, bias=None, stride=1, act=ACT_NONE, alpha=0.2, residual=None
     return out
 
 
+def conv2d_fwd_stats(x, w, bias=None, stride=1, split_k=0):
+    """y = conv_SAME(x, w) + bias together with the batch-norm partial statistics of y, left by the conv's epilogue
+    (dpig_conv2d_fwd_stats): returns (y, stats) with stats = (float tensor [tiles, 2, K], rows per tile), or (y, None) when
+    this problem's plan cannot carry them (split-K, thin layers, bf16 storage) -- `bn_fwd(y, ..., stats=stats)` accepts both."""
+    if _STORE_BF16[0] or x.dtype == BF16:
+        return conv2d_fwd(x, w, bias, stride=stride, split_k=split_k), None
+    _require_gpu(x)
+    x, ldx = as_nhwc(x)
+    w = w.contiguous()
+    N, H, W, C = x.shape
+    R, S, Cw, K = w.shape
+    if Cw != C:
+        raise RuntimeError("conv2d: filter expects %d input channels, tensor has %d" % (Cw, C))
+    Ho, Wo = conv_out_hw(H, W, R, S, stride, False)
+    d = _desc(N, H, W, C, K, R, S, stride, ldx, K, split_k=split_k)
+    tiles = lib().dpig_conv2d_bn_stats_tiles(ctypes.byref(d))
+    if tiles <= 0:
+        return conv2d_fwd(x, w, bias, stride=stride, split_k=split_k), None
+    out = torch.empty((N, Ho, Wo, K), dtype=torch.float32, device=x.device)
+    stats = torch.empty((tiles, 2, K), dtype=torch.float32, device=x.device)
+    if bias is not None:
+        bias = bias.contiguous()
+    with _Timed("conv_fwd_mfma", 2.0 * N * H * W // (stride * stride) * K * R * S * C, (N, H, W, C, K, R, stride, 0)):
+        check(lib().dpig_conv2d_fwd_stats(ctypes.byref(d), ptr(x), ptr(w), ptr(bias), ptr(out), ptr(stats), stream_ptr()),
+              "conv2d_fwd_stats")
+    return out, (stats, 128)
+
+
 def conv2d_dgrad(dy, w, in_shape, stride=1, accum=None, mask=None, act=ACT_NONE, alpha=0.2, out=None,
                  upsample2x=False, split_k=0):
     """dx = (conv_backward_data(dy, w) + accum) * act'(mask);  in_shape = (N,H,W,C) of the fwd input."""
@@ -654,8 +682,9 @@ def pad_channels_bf16(x, cols_out):
     return out
 
 
-def bn_fwd(x, scale, offset, eps=1e-5, act=ACT_NONE, alpha=0.2):
-    """Training-mode batch norm over all but the last axis (+ fused activation)."""
+def bn_fwd(x, scale, offset, eps=1e-5, act=ACT_NONE, alpha=0.2, stats=None):
+    """Training-mode batch norm over all but the last axis (+ fused activation).  `stats` = what `conv2d_fwd_stats` returned
+    for x: the statistics passes are replaced by one merge of the producing conv's per-tile partials."""
     if x.dtype == BF16:
         y, mean, rstd = bn_fwd(to_f32(x), scale, offset, eps, act, alpha)
         return to_bf16(y), mean, rstd
@@ -664,6 +693,15 @@ def bn_fwd(x, scale, offset, eps=1e-5, act=ACT_NONE, alpha=0.2):
     y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
     mean = torch.empty(C, dtype=torch.float32, device=x.device)
     rstd = torch.empty(C, dtype=torch.float32, device=x.device)
+    if stats is not None:
+        st, rpt = stats
+        if st.shape[2] != C or st.shape[0] != (rows + rpt - 1) // rpt:
+            raise RuntimeError("bn_fwd: the statistics do not belong to this tensor")
+        check(lib().dpig_bn_stats_finalize(ptr(st), st.shape[0], rows, rpt, C, eps, ptr(mean), ptr(rstd), stream_ptr()),
+              "bn_stats_finalize")
+        check(lib().dpig_bn_apply(ptr(x), ldx, rows, C, ptr(scale.contiguous()), ptr(offset.contiguous()), ptr(mean), ptr(rstd),
+                                  act, alpha, ptr(y), C, stream_ptr()), "bn_apply")
+        return y, mean, rstd
     wsb, wsn = workspace.get(lib().dpig_bn_workspace_bytes(rows, C), x.device)
     check(lib().dpig_bn_fwd(ptr(x), ldx, rows, C, ptr(scale.contiguous()), ptr(offset.contiguous()), eps, act, alpha,
                             ptr(y), C, ptr(mean), ptr(rstd), ptr(wsb), wsn, stream_ptr()), "bn_fwd")

@@ -34,7 +34,8 @@ def Batchnorm(name, axes, inputs, is_training=None, stats_iter=None, update_movi
 
         x = nchw_to_nhwc_view(inputs)
         if is_training is None or bool(is_training):
-            y = A.batchnorm(x, scale, offset, 1e-5, act, alpha)
+            # statistics already left by the producing Conv2D(..., bn_stats=True), if its launch plan could carry them
+            y = A.batchnorm(x, scale, offset, 1e-5, act, alpha, stats=getattr(inputs, '_dpig_bnstats', None))
             if is_training is not None and update_moving_stats:
                 # batchnorm.py:57-68: running average with weight 1/(stats_iter+1); TF's returned
                 # batch_var is Bessel-corrected

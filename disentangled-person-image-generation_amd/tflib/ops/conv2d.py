@@ -43,9 +43,11 @@ def _pixelcnn_mask(kind, groups, k, cin, cout):
 
 
 def Conv2D(name, input_dim, output_dim, filter_size, inputs, he_init=True, mask_type=None, stride=1,
-           weightnorm=None, biases=True, gain=1., fused_act=None, alpha=0.2):
+           weightnorm=None, biases=True, gain=1., fused_act=None, alpha=0.2, bn_stats=False):
     """inputs / result: (batch, channels, height, width).  mask_type: None or ('a'|'b', n_channel_groups).
-    `fused_act` in {None,'relu','lrelu'} (extension) folds the caller's next activation into the conv epilogue."""
+    `fused_act` in {None,'relu','lrelu'} (extension) folds the caller's next activation into the conv epilogue.
+    `bn_stats=True` (extension): the caller's next op is `Batchnorm` over this output -- the conv epilogue leaves the batch
+    statistics with the result (`_dpig_bnstats`) so that Batchnorm skips its own statistics passes."""
     k = filter_size
     fan_in, fan_out = input_dim * k ** 2, output_dim * k ** 2 / (stride ** 2)
     if mask_type is not None:                      # roughly half of the taps are masked away
@@ -60,5 +62,9 @@ def Conv2D(name, input_dim, output_dim, filter_size, inputs, he_init=True, mask_
         filters = filters * torch.as_tensor(_pixelcnn_mask(mask_type[0], mask_type[1], k, input_dim, output_dim),
                                             device=filters.device)
     bias = _init.zero_bias(name + '.Biases', output_dim) if biases else None
-    y = A.conv2d(nchw_to_nhwc_view(inputs), filters, bias, stride=stride, act=_ACT[fused_act], alpha=alpha)
-    return nhwc_to_nchw_view(y)
+    y = A.conv2d(nchw_to_nhwc_view(inputs), filters, bias, stride=stride, act=_ACT[fused_act], alpha=alpha,
+                 bn_stats=bn_stats and fused_act is None)
+    out = nhwc_to_nchw_view(y)
+    if getattr(y, '_dpig_bnstats', None) is not None:
+        out._dpig_bnstats = y._dpig_bnstats
+    return out

@@ -72,6 +72,9 @@ class WGAN_GP(object):
         def post(o):
             return o if fuse is not None else nonlinearity(o)
 
+        # a BatchNorm (not the wgan-gp LayerNorm) follows the conv: let the conv epilogue carry the batch statistics
+        bn_stats = bool(bn) and self.MODE != 'wgan-gp'
+
         lib.ops.conv2d.set_weights_stdev(0.02)
         lib.ops.deconv2d.set_weights_stdev(0.02)
         lib.ops.linear.set_weights_stdev(0.02)
@@ -80,19 +83,19 @@ class WGAN_GP(object):
         output = post(output)
 
         output = lib.ops.conv2d.Conv2D(name + 'Discriminator.2', dim, 2 * dim, 5, output, stride=2,
-                                       fused_act=None if bn else fuse)
+                                       fused_act=None if bn else fuse, bn_stats=bn_stats)
         if bn:
             output = Batchnorm(name + 'Discriminator.BN2', [0, 2, 3], output, self.MODE, fused_act=fuse)
         output = post(output)
 
         output = lib.ops.conv2d.Conv2D(name + 'Discriminator.3', 2 * dim, 4 * dim, 5, output, stride=2,
-                                       fused_act=None if bn else fuse)
+                                       fused_act=None if bn else fuse, bn_stats=bn_stats)
         if bn:
             output = Batchnorm(name + 'Discriminator.BN3', [0, 2, 3], output, self.MODE, fused_act=fuse)
         output = post(output)
 
         output = lib.ops.conv2d.Conv2D(name + 'Discriminator.4', 4 * dim, 8 * dim, 5, output, stride=2,
-                                       fused_act=None if bn else fuse)
+                                       fused_act=None if bn else fuse, bn_stats=bn_stats)
         if bn:
             output = Batchnorm(name + 'Discriminator.BN4', [0, 2, 3], output, self.MODE, fused_act=fuse)
         output = post(output)

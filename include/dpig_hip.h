@@ -51,7 +51,7 @@ extern "C" {
 #define DPIG_ACT_RELU 1
 #define DPIG_ACT_LRELU 2
 
-#define DPIG_VERSION 200
+#define DPIG_VERSION 210
 
 /* Convolution problem, always described from the FORWARD op's point of view. */
 typedef struct DpigConvDesc {
@@ -205,6 +205,19 @@ int dpig_border_class_sum(const float* a, int lda, int N, int H, int W, int C, f
 /* The same sums of a bf16 tensor ('bf16' storage mode), accumulated and returned in fp32. */
 int dpig_border_class_sum_bf16(const uint16_t* a, int lda, int N, int H, int W, int C, float* out, void* ws,
                                size_t ws_bytes, void* stream);
+
+/* Batch-norm statistics carried by the producing conv (conv2d.py:106-120 followed by batchnorm.py:30): the forward conv
+ * (+ bias, no activation) also writes, per row tile of 128 output pixels, the column sums and the sums of squared deviations
+ * from the tile's mean; dpig_bn_stats_finalize merges them (fixed order, exact pairwise update) into the batch mean and
+ * rstd = 1/sqrt(biased variance + eps), after which dpig_bn_apply normalises.  One pass over the conv output instead of
+ * three.  dpig_conv2d_bn_stats_tiles(d) = number of row tiles = leading dimension of `stats` ([tiles][2][K] floats), or 0
+ * when this problem's plan cannot carry the statistics (split-K, K <= 32, upsample fusion, a batch served in several
+ * launches): callers then use dpig_bn_fwd. */
+int dpig_conv2d_bn_stats_tiles(const DpigConvDesc* d);
+int dpig_conv2d_fwd_stats(const DpigConvDesc* d, const float* x, const float* w, const float* bias, float* y, float* stats,
+                          void* stream);
+int dpig_bn_stats_finalize(const float* stats, int tiles, int64_t rows, int rows_per_tile, int C, float eps, float* mean,
+                           float* rstd, void* stream);
 
 /* ---- batch norm (training mode, biased variance, eps inside sqrt; batchnorm.py:30) ----------- */
 /* x,y: [rows, C] (rows = N*H*W).  save_mean / save_rstd: [C].  Optional fused LeakyReLU/ReLU. */

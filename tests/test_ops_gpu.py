@@ -43,6 +43,83 @@ def test_batchnorm_fwd_bwd(dev, shape, act):
     _close(do, offset.grad, 5e-5)
 
 
+@pytest.mark.parametrize("shape", [(3, 20, 20, 64, 128, 5, 2), (2, 17, 9, 32, 136, 3, 1), (1, 8, 8, 64, 64, 5, 2)])
+@pytest.mark.parametrize("compute", ["f32", "bf16x3"])
+def test_conv_epilogue_bn_statistics(dev, shape, compute):
+    """conv2d.py:106-120 followed by batchnorm.py:30 with the statistics carried by the conv's epilogue
+    (dpig_conv2d_fwd_stats -> dpig_bn_stats_finalize -> dpig_bn_apply): conv + bias, batch mean, rstd and the normalised
+    LeakyReLU output against the fp64 oracle conv -> batchnorm_train chain; a large offset in the bias makes a one-pass
+    E[x^2]-E[x]^2 lose ~4 digits (the per-tile centred sums do not); ragged last row tile; bit-for-bit repeatable.
+    With the heuristic split-K plan (few row tiles) the statistics are not offered and bn_fwd runs its own passes."""
+    import dpig_amd.hip_ops as H
+    from oracle import ops as O
+    N, Hh, W, C, K, k, s = shape
+    x = _rand((N, Hh, W, C), 1)
+    w = _rand((k, k, C, K), 2) * 0.1
+    b = _rand((K,), 3) * 0.5 + 40.0
+    scale = _rand((K,), 4, 0.5, 1.5)
+    offset = _rand((K,), 5)
+    pre = O.conv2d_same(x, w, b, s)
+    ref = O.leaky_relu(O.batchnorm_train(pre, scale, offset), 0.2)
+    xg, wg, bg = x.float().to(dev), w.float().to(dev), b.float().to(dev)
+    H.set_compute(compute)
+    try:
+        y, st = H.conv2d_fwd_stats(xg, wg, bg, stride=s, split_k=1)
+        assert st is not None and st[0].shape == ((pre.numel() // K + 127) // 128, 2, K)
+        _close(y, pre)
+        out, mean, rstd = H.bn_fwd(y, scale.float().to(dev), offset.float().to(dev), 1e-5, 2, 0.2, stats=st)
+        rows = pre.reshape(-1, K)
+        _close(mean, rows.mean(0), 1e-6)
+        _close(rstd, 1.0 / torch.sqrt(rows.var(0, unbiased=False) + 1e-5), 2e-5 if compute == "f32" else 1e-4)
+        _close(out, ref, 2e-5 if compute == "f32" else 1e-4)
+        out2, mean2, rstd2 = H.bn_fwd(y, scale.float().to(dev), offset.float().to(dev), 1e-5, 2, 0.2)     # the op's own passes
+        assert float((mean2 - mean).abs().max()) <= 1e-6 * float(mean.abs().max())
+        assert float((rstd2 - rstd).abs().max()) <= 1e-5 * float(rstd.abs().max())
+        y_b, st_b = H.conv2d_fwd_stats(xg, wg, bg, stride=s, split_k=1)
+        assert torch.equal(y_b, y) and torch.equal(st_b[0], st[0])
+        y_h, st_h = H.conv2d_fwd_stats(xg, wg, bg, stride=s)            # heuristic plan: split-K on these few tiles
+        if st_h is None:
+            _close(y_h, pre)
+    finally:
+        H.set_compute("f32")
+
+
+def test_discriminator_uses_conv_epilogue_bn_statistics(dev):
+    """DCGANDiscriminator (wgan_gp.py:407-440) in BatchNorm mode asks its convs for the statistics; on a batch large enough
+    for un-split plans the fused path must give the logits (and input gradient) of the path with separate statistics passes."""
+    import dpig_amd.hip_ops as H
+    import dpig_amd.tflib as lib
+    from dpig_amd import slim
+    from dpig_amd.wgan_gp import WGAN_GP
+    lib.delete_all_params(); slim.reset_scopes()
+    lib.set_device(dev)
+    wg = WGAN_GP(MODE='dcgan', DIM=32, BATCH_SIZE=16)
+    # DeepFashion-sized critic input (trainer_256.py): Discriminator.2 writes 16 x 64 x 64 = 65536 rows = 512 row tiles
+    x = torch.randn(16, 3, 256, 256, device=dev, generator=torch.Generator(device=dev).manual_seed(1)).requires_grad_(True)
+    calls = []
+    orig = H.conv2d_fwd_stats
+
+    def spy(*a, **k):
+        r = orig(*a, **k)
+        calls.append(r[1] is not None)
+        return r
+    H.conv2d_fwd_stats = spy
+    try:
+        out = wg.DCGANDiscriminator(x, dim=32)
+        g, = torch.autograd.grad(out.sum(), x)
+    finally:
+        H.conv2d_fwd_stats = orig
+    assert len(calls) == 3 and any(calls), calls          # the three BN-fed convs asked; at least the largest carried them
+    H.conv2d_fwd_stats = lambda xx, w, b=None, stride=1, split_k=0: (H.conv2d_fwd(xx, w, b, stride=stride, split_k=split_k), None)
+    try:
+        out0 = wg.DCGANDiscriminator(x, dim=32)
+        g0, = torch.autograd.grad(out0.sum(), x)
+    finally:
+        H.conv2d_fwd_stats = orig
+    assert float((out - out0).abs().max()) <= 1e-4 * float(out0.abs().max())
+    assert float((g - g0).abs().max()) <= 1e-3 * float(g0.abs().max())
+
+
 @pytest.mark.parametrize("shape", [(2, 32, 16, 128), (4, 8, 4, 512), (3, 5, 7, 20)])
 def test_layernorm_fwd_bwd(dev, shape):
     import dpig_amd.hip_ops as H
