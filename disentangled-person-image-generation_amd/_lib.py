@@ -55,6 +55,10 @@ SYMBOLS = {
     "dpig_act_bwd_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _i, _i, _f, _vp]),
     "dpig_filter_shadow_bf16_multi": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp]),
     "dpig_filter_shadow_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    "dpig_filter_shadow_split": (_i, [_vp, _vp, _vp, _i64, _i, _i, _i, _vp]),
+    "dpig_filter_shadow_split_multi": (_i, [_vp, _vp, _vp, _i64, _vp, _i, _i, _vp]),
+    "dpig_conv2d_fwd_x3": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dpig_conv2d_dgrad_x3": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dpig_act_fwd": (_i, [_vp, _i, _vp, _i, _i64, _i, _i, _f, _vp]),
     "dpig_act_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _i, _i, _f, _vp]),
     "dpig_colsum_workspace_bytes": (_sz, [_i64, _i]),
@@ -62,8 +66,8 @@ SYMBOLS = {
     "dpig_border_class_sum_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "dpig_border_class_sum": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "dpig_border_class_sum_bf16": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
-    "dpig_conv2d_bn_stats_tiles": (_i, [_vp]),
-    "dpig_conv2d_fwd_stats": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dpig_conv2d_bn_stats_tiles": (_i, [_dp]),
+    "dpig_conv2d_fwd_stats": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dpig_bn_stats_finalize": (_i, [_vp, _i, _i64, _i, _i, _f, _vp, _vp, _vp]),
     "dpig_bn_workspace_bytes": (_sz, [_i64, _i]),
     "dpig_bn_fwd": (_i, [_vp, _i, _i64, _i, _vp, _vp, _f, _i, _f, _vp, _i, _vp, _vp, _vp, _sz, _vp]),

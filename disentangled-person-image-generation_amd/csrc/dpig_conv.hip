@@ -53,6 +53,8 @@ struct GGParams {
     const float* mask;    // activation-output tensor for act' (dest-shaped) or null
     float* partial;       // split-K workspace [nsplit][M][Ncols]
     float* stats;         // BN partial statistics [mtiles][2][Ncols] of v + bias (sum, centred squares per row tile) or null
+    const unsigned short* Bs_hi;   // PIPE 3: bf16 hi plane of the filter's split shadow, rows n, k contiguous; the lo plane
+    unsigned bs_lo_off, bs_bytes;  //         starts bs_lo_off bytes behind it; bs_bytes = extent of hi..lo for the descriptor
     int M, Hr, Wr, HrWr;  // row grid (rows = images x Hr x Wr)
     int Hs, Ws, lda, Cs, sr;   // source spatial dims, channel stride, reduction channels, row->src stride
     int Ncols;            // GEMM N
@@ -365,7 +367,7 @@ __device__ __forceinline__ void split_store4(char* dst, float a, float b, float 
 // tell the fragment reads which operand is stored that way.
 __device__ __forceinline__ int split_tslot(int slot8, int rowquad) { return slot8 ^ (((rowquad >> 2) & 3) << 1); }
 struct SplitFrag { bf16x8 ah[2], al[2], bh[2], bl[2]; };
-template <bool SWA, bool SWB>
+template <bool SWA, bool SWB, bool BDMA = false>
 __device__ __forceinline__ void split_load_frag(const char* As, const char* Bs, int ks, int wrow, int wcol, int l31, int half,
                                                 SplitFrag& f) {
 #pragma unroll
@@ -377,10 +379,17 @@ __device__ __forceinline__ void split_load_frag(const char* As, const char* Bs, 
     }
 #pragma unroll
     for (int nb = 0; nb < 2; ++nb) {
-        const int g = (ks * 2 + half) ^ (SWB ? ((2 * nb + (l31 >> 4)) & 3) : 0);
-        const char* b = Bs + (wcol + nb * 32 + l31) * ROWB + g * 16;
-        f.bh[nb] = *reinterpret_cast<const bf16x8*>(b);
-        f.bl[nb] = *reinterpret_cast<const bf16x8*>(b + 64);
+        if (BDMA) {          // LDS-DMA image: 128-byte rows, slot = granule ^ ((row >> 1) & 7); the lo granule is 4 slots away
+            const int slot = (ks * 2 + half) ^ ((l31 >> 1) & 7);
+            const char* b = Bs + (wcol + nb * 32 + l31) * 128;
+            f.bh[nb] = *reinterpret_cast<const bf16x8*>(b + slot * 16);
+            f.bl[nb] = *reinterpret_cast<const bf16x8*>(b + (slot ^ 4) * 16);
+        } else {
+            const int g = (ks * 2 + half) ^ (SWB ? ((2 * nb + (l31 >> 4)) & 3) : 0);
+            const char* b = Bs + (wcol + nb * 32 + l31) * ROWB + g * 16;
+            f.bh[nb] = *reinterpret_cast<const bf16x8*>(b);
+            f.bl[nb] = *reinterpret_cast<const bf16x8*>(b + 64);
+        }
     }
 }
 __device__ __forceinline__ void split_mfma(const SplitFrag& f, f32x16 (&acc)[2][2]) {
@@ -401,12 +410,21 @@ __device__ __forceinline__ void split_mfma(const SplitFrag& f, f32x16 (&acc)[2][
         for (int nb = 0; nb < 2; ++nb)
             acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah[mb], f.bh[nb], acc[mb][nb], 0, 0, 0);
 }
-template <bool B_ROWK>
+// B_DMA (PIPE 3): the FILTER operand's split is taken out of the loop.  Its hi / lo bf16 planes are precomputed once per
+// optimizer step (dpig_filter_shadow_split*: rows n, k contiguous -- the transposed shadow for forward, the plain one for
+// dgrad, so both are the B_ROWK form) and each wave fills its share of the [128][32 hi | 32 lo] tile with four 1-KB LDS-DMA
+// pieces: no VGPRs, no VALU, no ds_write for B (a knock-out build with a free filter operand measured +31 % on forward /
+// dgrad).  The DMA image is lane-linear, so the B tile has unpadded 128-byte rows and the bank-conflict swizzle lives in the
+// SOURCE address: 16-byte slot s of row r holds granule s ^ ((r >> 1) & 7) (0-3 = hi k-granules, 4-7 = lo).
+typedef __attribute__((address_space(3))) void lds_void_t;
+template <bool B_ROWK, bool B_DMA = false>
 __device__ __forceinline__ void gg_mainloop_split(const GGParams& p, char* lds, f32x16 (&acc)[2][2], int m0, int n0,
                                                   int kt_begin, int kt_end, int tid, int wrow, int wcol, int l31,
                                                   int half) {
+    static_assert(!B_DMA || B_ROWK, "split shadows are stored rows n, k contiguous");
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes);
-    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.B, p.b_bytes);
+    const __amdgpu_buffer_rsrc_t rsB = B_DMA ? __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.Bs_hi), 0, (int)p.bs_bytes, 0x00020000)
+                                             : make_rsrc(p.B, p.b_bytes);
     const int kq = tid & 7;                                   // 4-float k group of the row-major operands
     unsigned a_rowoff[4];
     int a_iy0[4], a_ix0[4];
@@ -426,9 +444,17 @@ __device__ __forceinline__ void gg_mainloop_split(const GGParams& p, char* lds, 
     unsigned b_off[4];
     bool b_ok[4];
     const int nq = tid & 31, kgrp = tid >> 5;                 // fwd filter patch: 4 columns x 4 k rows
+    int d_kk[4] = {0, 0, 0, 0};                               // B_DMA: this lane's k-granule start inside a tile, per piece
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-        if (B_ROWK) {
+        if (B_DMA) {            // piece 4 wave + i = tile rows 8 piece .. + 7; lane -> (row, 16-byte slot)
+            const int lane = tid & 63;
+            const int r = ((tid >> 6) * 4 + i) * 8 + (lane >> 3);
+            const int gs = (lane & 7) ^ ((r >> 1) & 7);
+            d_kk[i] = (gs & 3) * 8;
+            b_ok[i] = n0 + r < p.Ncols;
+            b_off[i] = (unsigned)(((n0 + r) * p.Cs + d_kk[i]) * 2) + ((gs >> 2) ? p.bs_lo_off : 0u);
+        } else if (B_ROWK) {
             const int n = n0 + (tid >> 3) + 32 * i;
             b_ok[i] = n < p.Ncols;
             b_off[i] = (unsigned)((n * p.Cs + kq * 4) * 4);
@@ -445,7 +471,11 @@ __device__ __forceinline__ void gg_mainloop_split(const GGParams& p, char* lds, 
         cur_tb = tap - cur_ta * p.tap_nb;
     }
     float4 ra[4], rb[4];
-    auto load_tile = [&](bool live) {
+#ifdef DPIG_KO_SPLITB
+    bool ko_first = true;
+#endif
+    const int dma_wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    auto load_tile = [&](bool live, int bufn) {
         const int c0 = cur_c0, ta = cur_ta, tb = cur_tb;
         cur_c0 += BKS;
         if (cur_c0 >= p.Cs) {
@@ -457,14 +487,30 @@ __device__ __forceinline__ void gg_mainloop_split(const GGParams& p, char* lds, 
         const int t_ck = c0 + kq * 4;
         const bool t_kok = t_ck < p.Cs;
         const unsigned t_sA = (unsigned)(((t_oy * p.Ws + t_ox) * p.lda + c0) * 4);
-        const unsigned t_sB = B_ROWK ? (unsigned)((wt * p.Ncols * p.Cs + c0) * 4) : (unsigned)(((wt * p.Cs + c0) * p.Ncols) * 4);
+        const unsigned t_sB = B_DMA ? (unsigned)((wt * p.Ncols * p.Cs + c0) * 2)
+                                    : (B_ROWK ? (unsigned)((wt * p.Ncols * p.Cs + c0) * 4) : (unsigned)(((wt * p.Cs + c0) * p.Ncols) * 4));
+        if (B_DMA) {             // the next tile's filter rows go straight into its LDS buffer (nobody reads it any more)
+            char* bdst = lds + bufn * 2 * TILEB + TILEB + dma_wave * 4096;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = live & b_ok[i] & (c0 + d_kk[i] < p.Cs);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(bdst + i * 1024), 16, (int)(ok ? b_off[i] : OOB), (int)t_sB, 0, 0);
+            }
+        }
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool ok = live & t_kok & ((unsigned)(a_iy0[i] + t_oy) < (unsigned)p.Hs) &
                             ((unsigned)(a_ix0[i] + t_ox) < (unsigned)p.Ws);
             ra[i] = gload4<true>(rsA, a_rowoff[i] + t_sA, ok, t_ck, p.Cs);
+            if (B_DMA) continue;
+#ifdef DPIG_KO_SPLITB   // knock-out experiment: the filter operand costs nothing after the first tile (results wrong)
+            if (ko_first) {
+#endif
             if (B_ROWK) rb[i] = gload4<true>(rsB, b_off[i] + t_sB, live & b_ok[i] & t_kok, t_ck, p.Cs);
             else rb[i] = gload4<true>(rsB, b_off[i] + t_sB, live & b_ok[i] & (c0 + kgrp * 4 + i < p.Cs), 0, 4);
+#ifdef DPIG_KO_SPLITB
+            }
+#endif
         }
     };
     auto store_tile = [&](int buf) {
@@ -474,8 +520,15 @@ __device__ __forceinline__ void gg_mainloop_split(const GGParams& p, char* lds, 
         for (int i = 0; i < 4; ++i) {
             const int r = (tid >> 3) + 32 * i;
             split_store4(As + r * ROWB + kq * 8, ra[i].x, ra[i].y, ra[i].z, ra[i].w);
-            if (B_ROWK) split_store4(Bs + r * ROWB + kq * 8, rb[i].x, rb[i].y, rb[i].z, rb[i].w);
+#ifdef DPIG_KO_SPLITB
+            if (ko_first)
+#endif
+            if (B_ROWK && !B_DMA) split_store4(Bs + r * ROWB + kq * 8, rb[i].x, rb[i].y, rb[i].z, rb[i].w);
         }
+        if (B_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA pieces have landed before the barrier
+#ifdef DPIG_KO_SPLITB
+        if (ko_first)
+#endif
         if (!B_ROWK) {      // register transpose of the 4(k) x 4(n) patch -> 4 rows n of 4 consecutive k
             char* d = Bs + (nq * 4) * ROWB + split_tslot(kgrp, nq) * 8;
             split_store4(d + 0 * ROWB, rb[0].x, rb[1].x, rb[2].x, rb[3].x);
@@ -485,18 +538,22 @@ __device__ __forceinline__ void gg_mainloop_split(const GGParams& p, char* lds, 
         }
     };
     if (kt_begin >= kt_end) return;
-    load_tile(true);
+    load_tile(true, 0);
     store_tile(0);
+#ifdef DPIG_KO_SPLITB
+    store_tile(1);
+    ko_first = false;
+#endif
     __syncthreads();
     int buf = 0;
     SplitFrag f0, f1;
-    split_load_frag<false, !B_ROWK>(lds, lds + TILEB, 0, wrow, wcol, l31, half, f0);
+    split_load_frag<false, !B_ROWK, B_DMA>(lds, lds + TILEB, 0, wrow, wcol, l31, half, f0);
     for (int kt = kt_begin; kt < kt_end; ++kt) {
         const bool more = (kt + 1) < kt_end;
         const char* As = lds + buf * 2 * TILEB;
-        load_tile(more);                                   // tile t+1 in flight under this tile's 24 MFMAs
+        load_tile(more, buf ^ 1);                          // tile t+1 in flight under this tile's 24 MFMAs
         __builtin_amdgcn_sched_barrier(0);
-        split_load_frag<false, !B_ROWK>(As, As + TILEB, 1, wrow, wcol, l31, half, f1);
+        split_load_frag<false, !B_ROWK, B_DMA>(As, As + TILEB, 1, wrow, wcol, l31, half, f1);
         __builtin_amdgcn_sched_barrier(0);
         split_mfma(f0, acc);
         __builtin_amdgcn_sched_barrier(0);
@@ -504,7 +561,7 @@ __device__ __forceinline__ void gg_mainloop_split(const GGParams& p, char* lds, 
         // and the LDS latency (zeros after the last tile: nobody reads them)
         store_tile(buf ^ 1);
         __syncthreads();
-        split_load_frag<false, !B_ROWK>(lds + (buf ^ 1) * 2 * TILEB, lds + (buf ^ 1) * 2 * TILEB + TILEB, 0, wrow, wcol, l31, half, f0);
+        split_load_frag<false, !B_ROWK, B_DMA>(lds + (buf ^ 1) * 2 * TILEB, lds + (buf ^ 1) * 2 * TILEB + TILEB, 0, wrow, wcol, l31, half, f0);
         __builtin_amdgcn_sched_barrier(0);
         split_mfma(f1, acc);
         __builtin_amdgcn_sched_barrier(0);
@@ -515,7 +572,8 @@ __device__ __forceinline__ void gg_mainloop_split(const GGParams& p, char* lds, 
 // NARROW: 128 x 32 block tile (waves stacked 4 x 1, one 32x32 accumulator each) for GEMMs whose N is
 // at most 32 (Cout = 3 image conv, dgrad towards a 3-channel image, N = 1 logits): 4x fewer MFMAs than
 // masking a 128-wide tile down to 3 columns.
-// PIPE: 0 fp32 MFMA (exact), 1 bf16 (operands rounded), 2 split-bf16 (three MFMAs per product block)
+// PIPE: 0 fp32 MFMA (exact), 1 bf16 (operands rounded), 2 split-bf16 (three MFMAs per product block), 3 = 2 with the filter
+// operand from precomputed hi / lo shadows by LDS-DMA
 template <bool B_ROWK, bool VEC, bool NARROW, int PIPE = 0>
 __device__ __forceinline__ void gather_gemm_body(const GGParams& p) {
     constexpr bool BF16 = PIPE == 1;
@@ -560,6 +618,10 @@ __device__ __forceinline__ void gather_gemm_body(const GGParams& p) {
         static_assert(!NARROW && VEC, "the split-bf16 loop exists for the 128x128 tile, 16-byte loadable operands");
         gg_mainloop_split<B_ROWK>(p, reinterpret_cast<char*>(&smem[0][0]), acc, m0, n0, kt_begin, kt_end, tid, wrow, wcol,
                                   l31, half);
+    } else if constexpr (PIPE == 3) {
+        static_assert(!NARROW && VEC && B_ROWK, "split-bf16 with filter shadows: 128x128 tile, filter rows n / k contiguous");
+        gg_mainloop_split<true, true>(p, reinterpret_cast<char*>(&smem[0][0]), acc, m0, n0, kt_begin, kt_end, tid, wrow, wcol,
+                                      l31, half);
     } else {
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes);
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.B, p.b_bytes);
@@ -1657,6 +1719,8 @@ static int launch_gg(GGParams& p, bool b_rowk, int nimg, long filter_elems, hipS
     } else if (pipe == 2) {
         if (b_rowk) hipLaunchKernelGGL((gather_gemm_kernel<true, true, false, 2>), grid, block, 0, st, p);
         else hipLaunchKernelGGL((gather_gemm_kernel<false, true, false, 2>), grid, block, 0, st, p);
+    } else if (pipe == 3) {
+        hipLaunchKernelGGL((gather_gemm_kernel<true, true, false, 3>), grid, block, 0, st, p);
     } else if (b_rowk) {
         if (narrow) { if (vec) DPIG_GG(true, true, true); else DPIG_GG(true, false, true); }
         else { if (vec) DPIG_GG(true, true, false); else DPIG_GG(true, false, false); }
@@ -1694,6 +1758,7 @@ static int launch_gg_multi(GGParams* q, int n, int nimg, long filter_elems, hipS
 #define DPIG_GGM(VE, NA) hipLaunchKernelGGL((gather_gemm_multi_kernel<true, VE, NA>), grid, block, 0, st, m)
     if (pipe == 1) hipLaunchKernelGGL((gather_gemm_multi_kernel<true, true, false, 1>), grid, block, 0, st, m);
     else if (pipe == 2) hipLaunchKernelGGL((gather_gemm_multi_kernel<true, true, false, 2>), grid, block, 0, st, m);
+    else if (pipe == 3) hipLaunchKernelGGL((gather_gemm_multi_kernel<true, true, false, 3>), grid, block, 0, st, m);
     else if (narrow) { if (vec) DPIG_GGM(true, true); else DPIG_GGM(false, true); }
     else { if (vec) DPIG_GGM(true, false); else DPIG_GGM(false, false); }
 #undef DPIG_GGM
@@ -1788,11 +1853,21 @@ static size_t conv2d_workspace_bytes_one(const DpigConvDesc* d, int which) {
 }
 
 // ---- entry points: one launch, or runs of whole images when a tensor exceeds one launch's 2 GiB range (dpig_conv_plan.h) ----
+// hi / lo bf16 planes of a filter's split shadow (rows n, k contiguous); null hi = none
+struct SplitShadow { const unsigned short* hi; const unsigned short* lo; };
 static int conv2d_fwd_one(const DpigConvDesc* d, const float* x, const float* w, const float* bias,
                           const float* residual, float* y, float* y_act, void* ws, size_t ws_bytes, void* stream,
-                          float* stats = nullptr);
+                          float* stats = nullptr, SplitShadow sh = SplitShadow{nullptr, nullptr});
 static int conv2d_dgrad_one(const DpigConvDesc* d, const float* dy, const float* w, const float* accum,
-                            const float* mask, float* dx, void* ws, size_t ws_bytes, void* stream);
+                            const float* mask, float* dx, void* ws, size_t ws_bytes, void* stream,
+                            SplitShadow sh = SplitShadow{nullptr, nullptr});
+// PIPE 3 is PIPE 2 with the filter from its split shadow: same shapes, plus 16-byte k-granules and one descriptor over both planes
+static bool shadow_usable(const DpigConvDesc* d, int pipe, int Cs, long filter_elems, SplitShadow sh) {
+    if (pipe != 2 || !sh.hi || !sh.lo || Cs % 8 || !aligned16(sh.hi) || !aligned16(sh.lo)) return false;
+    const long off = reinterpret_cast<const char*>(sh.lo) - reinterpret_cast<const char*>(sh.hi);
+    (void)d;
+    return off > 0 && off + filter_elems * 2 < 0x7fffffffL;
+}
 static int conv2d_wgrad_one(const DpigConvDesc* d, const float* x, const float* dy, float* dw, float beta,
                             float* db, float beta_b, void* ws, size_t ws_bytes, void* stream);
 
@@ -1824,6 +1899,49 @@ extern "C" int dpig_conv2d_fwd(const DpigConvDesc* d, const float* x, const floa
         const float* r = !residual ? nullptr : residual + (d->res_class ? (long)n0 * 9 * d->ldres : (long)n0 * ypix * d->ldres);
         const int rc = conv2d_fwd_one(&c, x + (long)n0 * xpix * d->ldx, w, bias, r, y + (long)n0 * ypix * d->ldy,
                                       y_act ? y_act + (long)n0 * ypix * d->ldy2 : nullptr, ws, ws_bytes, stream);
+        if (rc) return rc;
+    }
+    return DPIG_OK;
+}
+
+// DPIG_COMPUTE_BF16X3 with the filter's two-term split precomputed (dpig_filter_shadow_split*): `w` is still the fp32 filter
+// (used when a layer cannot take the shadow path: thin layers, <= 32 output columns, C or K not a multiple of 8), w_*_hi / _lo
+// the bf16 planes -- transposed [R,S,K,C] for forward, plain [R,S,C,K] for dgrad.  Results equal dpig_conv2d_fwd / _dgrad
+// with compute = DPIG_COMPUTE_BF16X3 bit for bit (same products, same order).
+extern "C" int dpig_conv2d_fwd_x3(const DpigConvDesc* d, const float* x, const float* w, const uint16_t* w_t_hi,
+                                  const uint16_t* w_t_lo, const float* bias, const float* residual, float* y, float* y_act,
+                                  void* ws, size_t ws_bytes, void* stream) {
+    const int per = images_per_launch(d, 4);
+    if (d && per == 0) return fail(DPIG_EINVAL, "one image exceeds the 2 GiB range of a launch");
+    const SplitShadow sh{w_t_hi, w_t_lo};
+    if (!d || per >= d->N || !x || !y) return conv2d_fwd_one(d, x, w, bias, residual, y, y_act, ws, ws_bytes, stream, nullptr, sh);
+    long xpix, ypix;
+    image_pixels(d, &xpix, &ypix);
+    for (int n0 = 0; n0 < d->N; n0 += per) {
+        DpigConvDesc c = *d;
+        c.N = d->N - n0 < per ? d->N - n0 : per;
+        const float* r = !residual ? nullptr : residual + (d->res_class ? (long)n0 * 9 * d->ldres : (long)n0 * ypix * d->ldres);
+        const int rc = conv2d_fwd_one(&c, x + (long)n0 * xpix * d->ldx, w, bias, r, y + (long)n0 * ypix * d->ldy,
+                                      y_act ? y_act + (long)n0 * ypix * d->ldy2 : nullptr, ws, ws_bytes, stream, nullptr, sh);
+        if (rc) return rc;
+    }
+    return DPIG_OK;
+}
+extern "C" int dpig_conv2d_dgrad_x3(const DpigConvDesc* d, const float* dy, const float* w, const uint16_t* w_hi,
+                                    const uint16_t* w_lo, const float* accum, const float* mask, float* dx, void* ws,
+                                    size_t ws_bytes, void* stream) {
+    const int per = images_per_launch(d, 4);
+    if (d && per == 0) return fail(DPIG_EINVAL, "one image exceeds the 2 GiB range of a launch");
+    const SplitShadow sh{w_hi, w_lo};
+    if (!d || per >= d->N || !dy || !dx) return conv2d_dgrad_one(d, dy, w, accum, mask, dx, ws, ws_bytes, stream, sh);
+    long xpix, ypix;
+    image_pixels(d, &xpix, &ypix);
+    for (int n0 = 0; n0 < d->N; n0 += per) {
+        DpigConvDesc c = *d;
+        c.N = d->N - n0 < per ? d->N - n0 : per;
+        const int rc = conv2d_dgrad_one(&c, dy + (long)n0 * ypix * d->ldy, w, accum ? accum + (long)n0 * xpix * d->ldres : nullptr,
+                                        mask ? mask + (long)n0 * xpix * d->ldmask : nullptr, dx + (long)n0 * xpix * d->ldx, ws,
+                                        ws_bytes, stream, sh);
         if (rc) return rc;
     }
     return DPIG_OK;
@@ -1887,7 +2005,7 @@ extern "C" int dpig_conv2d_wgrad(const DpigConvDesc* d, const float* x, const fl
 
 static int conv2d_fwd_one(const DpigConvDesc* d, const float* x, const float* w, const float* bias,
                           const float* residual, float* y, float* y_act, void* ws, size_t ws_bytes,
-                          void* stream, float* stats) {
+                          void* stream, float* stats, SplitShadow sh) {
     int pt, pl, Ho, Wo;
     int rc = resolve_desc(d, &pt, &pl, &Ho, &Wo);
     if (rc) return rc;
@@ -1930,11 +2048,17 @@ static int conv2d_fwd_one(const DpigConvDesc* d, const float* x, const float* w,
     if (p.nsplit > 1 && ws_bytes < (size_t)p.nsplit * s.M * s.Ncols * sizeof(float))
         return fail(DPIG_ENOMEM, "conv fwd workspace too small: have %zu", ws_bytes);
     if (p.nsplit > 1 && !ws) return fail(DPIG_ENOMEM, "conv fwd needs a workspace");
+    if (shadow_usable(d, pipe, d->C, (long)d->R * d->S * d->C * d->K, sh)) {     // transposed shadow [tap][K][C]: the B_ROWK form
+        p.Bs_hi = sh.hi;
+        p.bs_lo_off = (unsigned)(reinterpret_cast<const char*>(sh.lo) - reinterpret_cast<const char*>(sh.hi));
+        p.bs_bytes = p.bs_lo_off + (unsigned)((long)d->R * d->S * d->C * d->K * 2);
+        return launch_gg(p, true, d->N, (long)d->R * d->S * d->C * d->K, static_cast<hipStream_t>(stream), 3);
+    }
     return launch_gg(p, false, d->N, (long)d->R * d->S * d->C * d->K, static_cast<hipStream_t>(stream), pipe);
 }
 
 static int conv2d_dgrad_one(const DpigConvDesc* d, const float* dy, const float* w, const float* accum,
-                            const float* mask, float* dx, void* ws, size_t ws_bytes, void* stream) {
+                            const float* mask, float* dx, void* ws, size_t ws_bytes, void* stream, SplitShadow sh) {
     int pt, pl, Ho, Wo;
     int rc = resolve_desc(d, &pt, &pl, &Ho, &Wo);
     if (rc) return rc;
@@ -1950,8 +2074,14 @@ static int conv2d_dgrad_one(const DpigConvDesc* d, const float* dy, const float*
     p.A = dy; p.B = w; p.D = dx; p.bias = nullptr; p.res = accum; p.mask = mask;
     p.partial = static_cast<float*>(ws);
     p.lda = d->ldy; p.Cs = d->K; p.Ncols = d->C;
-    const int pipe = gg_pipe(d, d->ldy, d->K, d->C, dy, w);
+    int pipe = gg_pipe(d, d->ldy, d->K, d->C, dy, w);
     const bool bf16 = pipe == 1;
+    if (shadow_usable(d, pipe, d->K, (long)d->R * d->S * d->C * d->K, sh)) {        // plain shadow [tap][C][K]
+        pipe = 3;
+        p.Bs_hi = sh.hi;
+        p.bs_lo_off = (unsigned)(reinterpret_cast<const char*>(sh.lo) - reinterpret_cast<const char*>(sh.hi));
+        p.bs_bytes = p.bs_lo_off + (unsigned)((long)d->R * d->S * d->C * d->K * 2);
+    }
     p.Hd = d->H; p.Wd = d->W; p.ldd = d->ldx; p.ldres = d->ldres; p.ldmask = d->ldmask;
     p.act = mask ? d->act : DPIG_ACT_NONE; p.alpha = d->alpha; p.replicate = 0;
     if (d->upsample2x) {

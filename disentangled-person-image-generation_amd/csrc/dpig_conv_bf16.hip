@@ -1006,8 +1006,16 @@ __global__ __launch_bounds__(256) void cvt_pad_kernel(const float* __restrict__ 
 
 // w [taps][C][K] fp32 -> plain [taps][C][K] bf16 and transposed [taps][K][C] bf16 (either may be null): 32 x 32 tiles
 // through LDS so that both the read and the transposed write are row-contiguous
+// lo_off != 0 (split shadows for DPIG_COMPUTE_BF16X3): the value's second bf16 term, bf16(v - float(bf16(v))), is written
+// lo_off elements behind the first one in either layout -- the same two roundings the split k-loop applies in registers.
+__device__ __forceinline__ bf16_t bf_hi(float v) { const __bf16 b = (__bf16)v; return __builtin_bit_cast(bf16_t, b); }
+__device__ __forceinline__ bf16_t bf_lo(float v) {
+    const __bf16 b = (__bf16)v;
+    const __bf16 l = (__bf16)(v - (float)b);
+    return __builtin_bit_cast(bf16_t, l);
+}
 __global__ __launch_bounds__(256) void shadow_kernel(const float* __restrict__ w, bf16_t* __restrict__ plain,
-                                                     bf16_t* __restrict__ trans, int C, int K) {
+                                                     bf16_t* __restrict__ trans, int C, int K, long lo_off) {
     __shared__ float t[32][33];
     const int tap = blockIdx.z;
     const int c0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
@@ -1019,7 +1027,10 @@ __global__ __launch_bounds__(256) void shadow_kernel(const float* __restrict__ w
         float v = 0.f;
         if (c < C && k < K) {
             v = wt[(long)c * K + k];
-            if (plain) { const __bf16 b = (__bf16)v; plain[(long)tap * C * K + (long)c * K + k] = __builtin_bit_cast(bf16_t, b); }
+            if (plain) {
+                plain[(long)tap * C * K + (long)c * K + k] = bf_hi(v);
+                if (lo_off) plain[lo_off + (long)tap * C * K + (long)c * K + k] = bf_lo(v);
+            }
         }
         t[ty + 8 * i][tx] = v;
     }
@@ -1029,8 +1040,8 @@ __global__ __launch_bounds__(256) void shadow_kernel(const float* __restrict__ w
         for (int i = 0; i < 4; ++i) {
             const int k = k0 + ty + 8 * i, c = c0 + tx;
             if (c < C && k < K) {
-                const __bf16 b = (__bf16)t[tx][ty + 8 * i];
-                trans[(long)tap * C * K + (long)k * C + c] = __builtin_bit_cast(bf16_t, b);
+                trans[(long)tap * C * K + (long)k * C + c] = bf_hi(t[tx][ty + 8 * i]);
+                if (lo_off) trans[lo_off + (long)tap * C * K + (long)k * C + c] = bf_lo(t[tx][ty + 8 * i]);
             }
         }
     }
@@ -1041,7 +1052,7 @@ __global__ __launch_bounds__(256) void shadow_kernel(const float* __restrict__ w
 struct ShadowRow { long src, dst, taps, C, K, tile0; };
 __global__ __launch_bounds__(256) void shadow_multi_kernel(const float* __restrict__ base, bf16_t* __restrict__ plain_base,
                                                            bf16_t* __restrict__ trans_base,
-                                                           const ShadowRow* __restrict__ table, int ntensors) {
+                                                           const ShadowRow* __restrict__ table, int ntensors, long lo_off) {
     __shared__ float t[32][33];
     const int b = blockIdx.x;
     int lo = 0, hi = ntensors - 1;                      // last row with tile0 <= b (uniform: scalar loads)
@@ -1066,8 +1077,8 @@ __global__ __launch_bounds__(256) void shadow_multi_kernel(const float* __restri
         float v = 0.f;
         if (c < C && k < K) {
             v = wt[(long)c * K + k];
-            const __bf16 bb = (__bf16)v;
-            plain[(long)c * K + k] = __builtin_bit_cast(bf16_t, bb);
+            plain[(long)c * K + k] = bf_hi(v);
+            if (lo_off) plain[lo_off + (long)c * K + k] = bf_lo(v);
         }
         t[ty + 8 * i][tx] = v;
     }
@@ -1076,8 +1087,8 @@ __global__ __launch_bounds__(256) void shadow_multi_kernel(const float* __restri
     for (int i = 0; i < 4; ++i) {
         const int k = k0 + ty + 8 * i, c = c0 + tx;
         if (c < C && k < K) {
-            const __bf16 bb = (__bf16)t[tx][ty + 8 * i];
-            trans[(long)k * C + c] = __builtin_bit_cast(bf16_t, bb);
+            trans[(long)k * C + c] = bf_hi(t[tx][ty + 8 * i]);
+            if (lo_off) trans[lo_off + (long)k * C + c] = bf_lo(t[tx][ty + 8 * i]);
         }
     }
 }
@@ -1493,8 +1504,26 @@ extern "C" int dpig_filter_shadow_bf16(const float* w, uint16_t* plain, uint16_t
     if (!w || taps <= 0 || C <= 0 || K <= 0) return fail(DPIG_EINVAL, "filter shadow: bad arguments");
     if (!plain && !transposed) return DPIG_OK;
     dim3 grid(cdiv(K, 32), cdiv(C, 32), taps);
-    hipLaunchKernelGGL(shadow_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), w, plain, transposed, C, K);
+    hipLaunchKernelGGL(shadow_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), w, plain, transposed, C, K, 0L);
     return check_launch("filter_shadow_bf16");
+}
+// Split shadows for DPIG_COMPUTE_BF16X3 (dpig_conv2d_fwd_x3 / _dgrad_x3): hi planes at `plain_hi` / `trans_hi`, the lo planes
+// lo_off ELEMENTS behind each (one allocation per layout, so that one buffer descriptor spans both planes).
+extern "C" int dpig_filter_shadow_split(const float* w, uint16_t* plain_hi, uint16_t* trans_hi, int64_t lo_off, int taps, int C,
+                                        int K, void* stream) {
+    if (!w || taps <= 0 || C <= 0 || K <= 0 || lo_off < (int64_t)taps * C * K) return fail(DPIG_EINVAL, "filter shadow (split): bad arguments");
+    if (!plain_hi && !trans_hi) return DPIG_OK;
+    dim3 grid(cdiv(K, 32), cdiv(C, 32), taps);
+    hipLaunchKernelGGL(shadow_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), w, plain_hi, trans_hi, C, K, (long)lo_off);
+    return check_launch("filter_shadow_split");
+}
+extern "C" int dpig_filter_shadow_split_multi(const float* base, uint16_t* plain_base, uint16_t* trans_base, int64_t lo_off,
+                                              const int64_t* table_dev, int ntensors, int total_tiles, void* stream) {
+    if (!base || !plain_base || !trans_base || !table_dev || ntensors <= 0 || total_tiles <= 0 || lo_off <= 0)
+        return fail(DPIG_EINVAL, "filter shadow (split, multi): bad arguments");
+    hipLaunchKernelGGL(shadow_multi_kernel, dim3(total_tiles), dim3(256), 0, static_cast<hipStream_t>(stream), base,
+                       plain_base, trans_base, reinterpret_cast<const ShadowRow*>(table_dev), ntensors, (long)lo_off);
+    return check_launch("filter_shadow_split_multi");
 }
 
 static int act_bf16_args(const void* a, int lda, const void* o, int ldo, int64_t rows, int cols) {
@@ -1592,6 +1621,6 @@ extern "C" int dpig_filter_shadow_bf16_multi(const float* base, uint16_t* plain_
     if (!base || !plain_base || !trans_base || !table_dev || ntensors <= 0 || total_tiles <= 0)
         return fail(DPIG_EINVAL, "filter shadow (multi): bad arguments");
     hipLaunchKernelGGL(shadow_multi_kernel, dim3(total_tiles), dim3(256), 0, static_cast<hipStream_t>(stream), base,
-                       plain_base, trans_base, reinterpret_cast<const ShadowRow*>(table_dev), ntensors);
+                       plain_base, trans_base, reinterpret_cast<const ShadowRow*>(table_dev), ntensors, 0L);
     return check_launch("filter_shadow_bf16_multi");
 }

@@ -193,7 +193,10 @@ class FilterShadows(object):
     masters (call it after anything that changes the weights): one launch for the whole set when the masters are slices
     of one flat buffer (`flat`, trainer.FlatParams), else one small launch per filter."""
 
-    def __init__(self, params, flat=None):
+    def __init__(self, params, flat=None, split=False):
+        """split=True: the two-term (hi, lo) shadows of the 'bf16x3' mode, attached as `_dpig_shadow_x3` =
+        (plain_hi, trans_hi, plain_lo, trans_lo); buffer layout [plain hi | plain lo | trans hi | trans lo]."""
+        self.split = bool(split)
         self.params = [p for p in params if p.dim() == 4 and _bf16_conv_ok(p.shape[2], p.shape[3])]
         total = sum((p.numel() + 7) // 8 * 8 for p in self.params)
         self.numel = total
@@ -201,12 +204,20 @@ class FilterShadows(object):
         if not self.params:
             return
         dev = self.params[0].device
-        self.buf = torch.empty(2 * total, dtype=BF16, device=dev)
+        planes = 2 if self.split else 1
+        self.buf = torch.empty(2 * planes * total, dtype=BF16, device=dev)
+        self.trans_off = planes * total                  # element offset of the transposed layout; lo planes `total` behind hi
         off, rows, tiles = 0, [], 0
         for p in self.params:
             R, S, C, K = p.shape
             n = p.numel()
-            p._dpig_shadow = (self.buf[off:off + n].view(R, S, C, K), self.buf[total + off:total + off + n].view(R, S, K, C))
+            t0 = self.trans_off
+            if self.split:
+                p._dpig_shadow_x3 = (self.buf[off:off + n].view(R, S, C, K), self.buf[t0 + off:t0 + off + n].view(R, S, K, C),
+                                     self.buf[total + off:total + off + n].view(R, S, C, K),
+                                     self.buf[t0 + total + off:t0 + total + off + n].view(R, S, K, C))
+            else:
+                p._dpig_shadow = (self.buf[off:off + n].view(R, S, C, K), self.buf[t0 + off:t0 + off + n].view(R, S, K, C))
             if flat is not None:
                 src = (p.data_ptr() - flat.data_ptr()) // 4
                 if not (0 <= src and src + n <= flat.numel() and p.is_contiguous()):
@@ -224,20 +235,31 @@ class FilterShadows(object):
         if not self.params:
             return
         if self.flat is not None:
-            check(lib().dpig_filter_shadow_bf16_multi(ptr(self.flat), ptr(self.buf), ptr(self.buf) + 2 * self.numel,
-                                                      ptr(self.table), len(self.params), self.ntiles, stream_ptr()),
-                  "filter_shadow_multi")
+            if self.split:
+                check(lib().dpig_filter_shadow_split_multi(ptr(self.flat), ptr(self.buf), ptr(self.buf) + 2 * self.trans_off,
+                                                           self.numel, ptr(self.table), len(self.params), self.ntiles,
+                                                           stream_ptr()), "filter_shadow_split_multi")
+            else:
+                check(lib().dpig_filter_shadow_bf16_multi(ptr(self.flat), ptr(self.buf), ptr(self.buf) + 2 * self.trans_off,
+                                                          ptr(self.table), len(self.params), self.ntiles, stream_ptr()),
+                      "filter_shadow_multi")
             return
         for p in self.params:
-            plain, trans = p._dpig_shadow
             R, S, C, K = p.shape
-            check(lib().dpig_filter_shadow_bf16(ptr(p.data), ptr(plain), ptr(trans), R * S, C, K, stream_ptr()),
-                  "filter_shadow")
+            if self.split:
+                plain, trans = p._dpig_shadow_x3[:2]
+                check(lib().dpig_filter_shadow_split(ptr(p.data), ptr(plain), ptr(trans), self.numel, R * S, C, K, stream_ptr()),
+                      "filter_shadow_split")
+            else:
+                plain, trans = p._dpig_shadow
+                check(lib().dpig_filter_shadow_bf16(ptr(p.data), ptr(plain), ptr(trans), R * S, C, K, stream_ptr()),
+                      "filter_shadow")
 
     def detach(self):
         for p in self.params:
-            if hasattr(p, "_dpig_shadow"):
-                del p._dpig_shadow
+            for a in ("_dpig_shadow", "_dpig_shadow_x3"):
+                if hasattr(p, a):
+                    delattr(p, a)
 
 
 def _bf16_conv_ok(C, K, *lds):
@@ -326,8 +348,13 @@ def conv2d_fwd(x, w, bias=None, stride=1, act=ACT_NONE, alpha=0.2, residual=None
     mfma = (C % 4 == 0 and K % 4 == 0 and ldx % 4 == 0 and C >= 32 and K >= 32)
     with _Timed("conv_fwd_mfma" if mfma else "conv_fwd_thin", 2.0 * N * H * W // (stride * stride) * K * R * S * C,
                 (N, H, W, C, K, R, stride, int(upsample2x))):
-        check(lib().dpig_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(out),
-                                    ptr(out_act), ptr(wsb), wsn, stream_ptr()), "conv2d_fwd")
+        sh = getattr(w, "_dpig_shadow_x3", None) if _COMPUTE[0] == COMPUTE_BF16X3 else None
+        if sh is not None:           # the filter's two bf16 terms are kept ready (FilterShadows(split=True))
+            check(lib().dpig_conv2d_fwd_x3(ctypes.byref(d), ptr(x), ptr(w), ptr(sh[1]), ptr(sh[3]), ptr(bias), ptr(residual),
+                                           ptr(out), ptr(out_act), ptr(wsb), wsn, stream_ptr()), "conv2d_fwd_x3")
+        else:
+            check(lib().dpig_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(out),
+                                        ptr(out_act), ptr(wsb), wsn, stream_ptr()), "conv2d_fwd")
     return out
 
 
@@ -390,8 +417,13 @@ def conv2d_dgrad(dy, w, in_shape, stride=1, accum=None, mask=None, act=ACT_NONE,
     mfma = (C % 4 == 0 and K % 4 == 0 and ldy % 4 == 0 and C >= 32 and K >= 32)
     with _Timed("conv_dgrad_mfma" if mfma else "conv_dgrad_thin",
                 2.0 * N * H * W // (stride * stride) * K * R * S * C, (N, H, W, C, K, R, stride, int(upsample2x))):
-        check(lib().dpig_conv2d_dgrad(ctypes.byref(d), ptr(dy), ptr(w), ptr(accum), ptr(mask), ptr(out), ptr(wsb),
-                                      wsn, stream_ptr()), "conv2d_dgrad")
+        sh = getattr(w, "_dpig_shadow_x3", None) if _COMPUTE[0] == COMPUTE_BF16X3 else None
+        if sh is not None:
+            check(lib().dpig_conv2d_dgrad_x3(ctypes.byref(d), ptr(dy), ptr(w), ptr(sh[0]), ptr(sh[2]), ptr(accum), ptr(mask),
+                                             ptr(out), ptr(wsb), wsn, stream_ptr()), "conv2d_dgrad_x3")
+        else:
+            check(lib().dpig_conv2d_dgrad(ctypes.byref(d), ptr(dy), ptr(w), ptr(accum), ptr(mask), ptr(out), ptr(wsb),
+                                          wsn, stream_ptr()), "conv2d_dgrad")
     return out
 
 

@@ -51,10 +51,10 @@ class FlatParams(object):
             p._dpig_grad = self.grad[o:o + n].view(p.shape)
             p._dpig_touched = [False]
 
-    def enable_bf16_shadows(self):
+    def enable_bf16_shadows(self, split=False):
         """'bf16' mode: persistent bf16 shadows of the conv filters (hip_ops.FilterShadows), refreshed after every
-        optimizer step from the fp32 masters this object owns."""
-        self.shadows = H.FilterShadows(self.params, flat=self.flat)
+        optimizer step from the fp32 masters this object owns.  split=True ('bf16x3' mode): the two-term shadows."""
+        self.shadows = H.FilterShadows(self.params, flat=self.flat, split=split)
 
     def refresh_shadows(self):
         sh = getattr(self, "shadows", None)
@@ -439,9 +439,10 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         self.allreduce = GradAllReduce(compress='bf16' if gx == 'bf16' else None)
         self.allreduce.broadcast(self.G_flat.flat)
         self.allreduce.broadcast(self.D_flat.flat)
-        if getattr(self.config, "compute_dtype", "f32") == "bf16":
-            self.G_flat.enable_bf16_shadows()
-            self.D_flat.enable_bf16_shadows()
+        if getattr(self.config, "compute_dtype", "f32") in ("bf16", "bf16x3"):
+            split = self.config.compute_dtype == "bf16x3"
+            self.G_flat.enable_bf16_shadows(split)
+            self.D_flat.enable_bf16_shadows(split)
         lib.ops.batchnorm.set_sync(bool(getattr(self.config, "sync_bn", False)) and self.allreduce.enabled)
         if getattr(self.config, "ckpt_path", None):
             self.restore_counters(self.config.ckpt_path)

@@ -87,9 +87,9 @@ class DPIG_Encoder_subSampleAppNetFgBg_GAN_BodyROI(object):
         for gf, df in self.flats.values():
             self.allreduce.broadcast(gf.flat)
             self.allreduce.broadcast(df.flat)
-        if getattr(self.config, "compute_dtype", "f32") == "bf16":
+        if getattr(self.config, "compute_dtype", "f32") in ("bf16", "bf16x3"):
             # the frozen encoder's filters: bf16 shadows made once (the FC mappers / critics run on fp32 weights)
-            self.encoder_shadows = H.FilterShadows(self.Encoder_var)
+            self.encoder_shadows = H.FilterShadows(self.Encoder_var, split=self.config.compute_dtype == "bf16x3")
 
     # ---- optimizer ops -------------------------------------------------------------------------------
     def g_optim_embs(self, side, z=None):

@@ -51,7 +51,7 @@ extern "C" {
 #define DPIG_ACT_RELU 1
 #define DPIG_ACT_LRELU 2
 
-#define DPIG_VERSION 210
+#define DPIG_VERSION 220
 
 /* Convolution problem, always described from the FORWARD op's point of view. */
 typedef struct DpigConvDesc {
@@ -181,6 +181,22 @@ int dpig_filter_shadow_bf16(const float* w, uint16_t* plain, uint16_t* transpose
  * tile}, rows ordered by first tile; tiles are 32 x 32 (per filter taps * ceil(C/32) * ceil(K/32)), total_tiles their sum. */
 int dpig_filter_shadow_bf16_multi(const float* base, uint16_t* plain_base, uint16_t* trans_base,
                                   const int64_t* table_dev, int ntensors, int total_tiles, void* stream);
+
+/* ---- DPIG_COMPUTE_BF16X3 with the filter's split taken out of the k-loop ------------------------------------------------
+ * dpig_filter_shadow_split*: from the fp32 HWIO master, hi = bf16(w) and lo = bf16(w - hi) in both layouts (plain [R,S,C,K],
+ * per-tap transposed [R,S,K,C]); the lo plane of a layout sits lo_off ELEMENTS behind its hi plane (same allocation).  Call
+ * after every optimizer step (the _multi form: all filters of a flat parameter buffer in one launch, table rows as for
+ * dpig_filter_shadow_bf16_multi).  dpig_conv2d_fwd_x3 / _dgrad_x3 = dpig_conv2d_fwd / _dgrad with compute = BF16X3, reading
+ * the filter's two terms from those planes by LDS-DMA where the layer allows (else from `w`): same results bit for bit. */
+int dpig_filter_shadow_split(const float* w, uint16_t* plain_hi, uint16_t* trans_hi, int64_t lo_off, int taps, int C, int K,
+                             void* stream);
+int dpig_filter_shadow_split_multi(const float* base, uint16_t* plain_base, uint16_t* trans_base, int64_t lo_off,
+                                   const int64_t* table_dev, int ntensors, int total_tiles, void* stream);
+int dpig_conv2d_fwd_x3(const DpigConvDesc* d, const float* x, const float* w, const uint16_t* w_t_hi, const uint16_t* w_t_lo,
+                       const float* bias, const float* residual, float* y, float* y_act, void* ws, size_t ws_bytes,
+                       void* stream);
+int dpig_conv2d_dgrad_x3(const DpigConvDesc* d, const float* dy, const float* w, const uint16_t* w_hi, const uint16_t* w_lo,
+                         const float* accum, const float* mask, float* dx, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- elementwise / reductions over a [rows, cols] fp32 matrix with row stride ld ------------- */
 

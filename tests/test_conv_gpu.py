@@ -418,6 +418,38 @@ def test_conv_split_bf16_epilogues_and_upsample(dev):
         H.set_compute("f32")
 
 
+@pytest.mark.parametrize("shape", [(2, 24, 24, 128, 128, 3, 1), (2, 16, 8, 64, 128, 3, 2), (2, 8, 4, 64, 128, 5, 2), (3, 6, 6, 96, 136, 1, 1),
+                                   (1, 16, 8, 200, 64, 3, 1), (2, 9, 7, 36, 40, 3, 1)])
+def test_conv_split_bf16_filter_shadows(dev, shape):
+    """dpig_conv2d_fwd_x3 / _dgrad_x3: the filter's hi / lo terms come from precomputed shadows by LDS-DMA instead of being
+    split in the k-loop.  Same two roundings, same products, same order => bit-identical to the in-loop split, for the plain
+    and split-K plans, the stride-2 dgrad classes and (36 channels: not a multiple of 8) the fallback to the fp32 filter."""
+    import dpig_amd.hip_ops as H
+    N, Hh, W, C, K, k, s = shape
+    x = _rand((N, Hh, W, C), 1).float().to(dev)
+    w = (_rand((k, k, C, K), 2) * 0.2).float().to(dev)
+    b = _rand((K,), 3).float().to(dev)
+    H.set_compute("bf16x3")
+    try:
+        for sk in (0, 3):
+            y0 = H.conv2d_fwd(x, w, b, stride=s, act=2, alpha=0.2, split_k=sk)
+            dy = torch.randn(y0.shape, device=dev, generator=torch.Generator(device=dev).manual_seed(4))
+            dx0 = H.conv2d_dgrad(dy, w, (N, Hh, W, C), stride=s, split_k=sk)
+            sh = H.FilterShadows([w], split=True)
+            if C % 8 or K % 8:                                  # no 16-byte k-granules: no shadows, the fp32 filter is split in the loop
+                assert not hasattr(w, "_dpig_shadow_x3")
+            else:
+                hi, lo = w._dpig_shadow_x3[0].float(), w._dpig_shadow_x3[2].float()
+                assert torch.equal(hi, w.bfloat16().float()) and torch.equal(lo, (w - hi).bfloat16().float())
+                assert torch.equal(w._dpig_shadow_x3[1].float(), hi.permute(0, 1, 3, 2)) and torch.equal(w._dpig_shadow_x3[3].float(), lo.permute(0, 1, 3, 2))
+            y1 = H.conv2d_fwd(x, w, b, stride=s, act=2, alpha=0.2, split_k=sk)
+            dx1 = H.conv2d_dgrad(dy, w, (N, Hh, W, C), stride=s, split_k=sk)
+            sh.detach()
+            assert torch.equal(y1, y0) and torch.equal(dx1, dx0), (sk, float((y1 - y0).abs().max()), float((dx1 - dx0).abs().max()))
+    finally:
+        H.set_compute("f32")
+
+
 def test_conv_bf16_falls_back_to_fp32_when_ineligible(dev):
     import dpig_amd.hip_ops as H
     x = _rand((2, 16, 8, 256), 1).float().to(dev)
