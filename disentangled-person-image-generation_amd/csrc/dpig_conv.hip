@@ -475,28 +475,26 @@ __device__ __forceinline__ void gg_mainloop_split(const GGParams& p, char* lds, 
     bool ko_first = true;
 #endif
     const int dma_wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    auto load_tile = [&](bool live, int bufn) {
-        const int c0 = cur_c0, ta = cur_ta, tb = cur_tb;
-        cur_c0 += BKS;
-        if (cur_c0 >= p.Cs) {
-            cur_c0 = 0;
-            if (++cur_tb == p.tap_nb) { cur_tb = 0; ++cur_ta; }
+    // The register-staged operand(s) and the DMA'd filter tile of the SAME k-tile are requested at different moments (below),
+    // so each keeps its own (tap, channel-chunk) cursor.
+    struct Cursor { int c0, ta, tb; };
+    Cursor curA = {cur_c0, cur_ta, cur_tb}, curB = curA;
+    auto advance = [&](Cursor& c) {
+        c.c0 += BKS;
+        if (c.c0 >= p.Cs) {
+            c.c0 = 0;
+            if (++c.tb == p.tap_nb) { c.tb = 0; ++c.ta; }
         }
+    };
+    auto load_regs = [&](bool live) {                       // global -> VGPRs: A, and B unless it is DMA'd
+        const int c0 = curA.c0, ta = curA.ta, tb = curA.tb;
+        advance(curA);
         const int wt = p.w0 + ta * p.wa + tb * p.wb;
         const int t_oy = p.oy0 + ta * p.oys, t_ox = p.ox0 + tb * p.oxs;
         const int t_ck = c0 + kq * 4;
         const bool t_kok = t_ck < p.Cs;
         const unsigned t_sA = (unsigned)(((t_oy * p.Ws + t_ox) * p.lda + c0) * 4);
-        const unsigned t_sB = B_DMA ? (unsigned)((wt * p.Ncols * p.Cs + c0) * 2)
-                                    : (B_ROWK ? (unsigned)((wt * p.Ncols * p.Cs + c0) * 4) : (unsigned)(((wt * p.Cs + c0) * p.Ncols) * 4));
-        if (B_DMA) {             // the next tile's filter rows go straight into its LDS buffer (nobody reads it any more)
-            char* bdst = lds + bufn * 2 * TILEB + TILEB + dma_wave * 4096;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool ok = live & b_ok[i] & (c0 + d_kk[i] < p.Cs);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(bdst + i * 1024), 16, (int)(ok ? b_off[i] : OOB), (int)t_sB, 0, 0);
-            }
-        }
+        const unsigned t_sB = B_ROWK ? (unsigned)((wt * p.Ncols * p.Cs + c0) * 4) : (unsigned)(((wt * p.Cs + c0) * p.Ncols) * 4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const bool ok = live & t_kok & ((unsigned)(a_iy0[i] + t_oy) < (unsigned)p.Hs) &
@@ -513,6 +511,18 @@ __device__ __forceinline__ void gg_mainloop_split(const GGParams& p, char* lds, 
 #endif
         }
     };
+    auto dma_b = [&](bool live, int bufn) {                 // B_DMA: four 1-KB pieces of the filter tile straight into LDS
+        const int c0 = curB.c0;
+        const int wt = p.w0 + curB.ta * p.wa + curB.tb * p.wb;
+        advance(curB);
+        const unsigned t_sB = (unsigned)((wt * p.Ncols * p.Cs + c0) * 2);
+        char* bdst = lds + bufn * 2 * TILEB + TILEB + dma_wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = live & b_ok[i] & (c0 + d_kk[i] < p.Cs);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(bdst + i * 1024), 16, (int)(ok ? b_off[i] : OOB), (int)t_sB, 0, 0);
+        }
+    };
     auto store_tile = [&](int buf) {
         char* As = lds + buf * 2 * TILEB;
         char* Bs = As + TILEB;
@@ -525,7 +535,6 @@ __device__ __forceinline__ void gg_mainloop_split(const GGParams& p, char* lds, 
 #endif
             if (B_ROWK && !B_DMA) split_store4(Bs + r * ROWB + kq * 8, rb[i].x, rb[i].y, rb[i].z, rb[i].w);
         }
-        if (B_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's DMA pieces have landed before the barrier
 #ifdef DPIG_KO_SPLITB
         if (ko_first)
 #endif
@@ -538,35 +547,47 @@ __device__ __forceinline__ void gg_mainloop_split(const GGParams& p, char* lds, 
         }
     };
     if (kt_begin >= kt_end) return;
-    load_tile(true, 0);
+    // Pipeline: a k-tile's operands are requested a FULL tile period before they are published: right behind the barrier in
+    // the middle of tile t (which retires the LDS buffer the filter DMA of tile t+2 lands in) and consumed by the store in
+    // the middle of tile t+1.  (Requested at the head of tile t and consumed in its middle, i.e. 12 MFMAs later, the loads
+    // were still on their way: the wait at the store was the longest segment of the loop.)  Nothing is in flight at a
+    // barrier: the store has consumed the register loads, and the DMA pieces, issued before them, return before them.
+    if (B_DMA) dma_b(true, 0);
+    load_regs(true);
     store_tile(0);
 #ifdef DPIG_KO_SPLITB
     store_tile(1);
     ko_first = false;
 #endif
+    if (B_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+    if (B_DMA) dma_b(kt_begin + 1 < kt_end, 1);
+    load_regs(kt_begin + 1 < kt_end);
     int buf = 0;
     SplitFrag f0, f1;
     split_load_frag<false, !B_ROWK, B_DMA>(lds, lds + TILEB, 0, wrow, wcol, l31, half, f0);
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const bool more = (kt + 1) < kt_end;
+        const bool more2 = (kt + 2) < kt_end;
         const char* As = lds + buf * 2 * TILEB;
-        load_tile(more, buf ^ 1);                          // tile t+1 in flight under this tile's 24 MFMAs
-        __builtin_amdgcn_sched_barrier(0);
         split_load_frag<false, !B_ROWK, B_DMA>(As, As + TILEB, 1, wrow, wcol, l31, half, f1);
         __builtin_amdgcn_sched_barrier(0);
         split_mfma(f0, acc);
         __builtin_amdgcn_sched_barrier(0);
-        // second k-step: publish tile t+1 first, then request its first fragments; the 12 MFMAs below cover the barrier
-        // and the LDS latency (zeros after the last tile: nobody reads them)
+        // second k-step: publish tile t+1 (requested a tile ago), retire buffer t behind the barrier, request tile t+2 (its
+        // filter DMA lands in buffer t); the 12 MFMAs below cover the barrier and the LDS latency (zeros after the last
+        // tile: nobody reads them)
         store_tile(buf ^ 1);
+        if (B_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
+        if (B_DMA) dma_b(more2, buf);
+        load_regs(more2);
         split_load_frag<false, !B_ROWK, B_DMA>(lds + (buf ^ 1) * 2 * TILEB, lds + (buf ^ 1) * 2 * TILEB + TILEB, 0, wrow, wcol, l31, half, f0);
         __builtin_amdgcn_sched_barrier(0);
         split_mfma(f1, acc);
         __builtin_amdgcn_sched_barrier(0);
         buf ^= 1;
     }
+    if (B_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (dead pieces of the tiles past the end)
 }
 
 // NARROW: 128 x 32 block tile (waves stacked 4 x 1, one 32x32 accumulator each) for GEMMs whose N is
@@ -1717,6 +1738,8 @@ static int launch_gg(GGParams& p, bool b_rowk, int nimg, long filter_elems, hipS
         if (b_rowk) hipLaunchKernelGGL((gather_gemm_kernel<true, true, false, 1>), grid, block, 0, st, p);
         else hipLaunchKernelGGL((gather_gemm_kernel<false, true, false, 1>), grid, block, 0, st, p);
     } else if (pipe == 2) {
+        static const bool dbg = getenv("DPIG_DEBUG_PIPE2") != nullptr;       // which layers split the filter in the loop
+        if (dbg) fprintf(stderr, "[dpig] pipe 2 %s: M %d Ncols %d Cs %d taps %d nsplit %d\n", b_rowk ? "dgrad" : "fwd", p.M, p.Ncols, p.Cs, p.ntaps, p.nsplit);
         if (b_rowk) hipLaunchKernelGGL((gather_gemm_kernel<true, true, false, 2>), grid, block, 0, st, p);
         else hipLaunchKernelGGL((gather_gemm_kernel<false, true, false, 2>), grid, block, 0, st, p);
     } else if (pipe == 3) {
