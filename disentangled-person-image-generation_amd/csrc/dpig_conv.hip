@@ -1689,6 +1689,12 @@ static bool vec_ok(const void* a, const void* b, int lda, int Cs, int Ncols) {
 static int gg_bk(const DpigConvDesc* d, int lda, int Cs, int Ncols) {
     return (d->compute == DPIG_COMPUTE_BF16 && lda % 4 == 0 && Cs % 4 == 0 && Ncols % 4 == 0 && Ncols > 32) ? BKH : BK;
 }
+// What a split-K partial-sum round trip costs relative to a k-tile, for choose_split: the split-bf16 k-tile runs ~2.4x
+// faster than the exact fp32 one while the fp32 partials cost the same, so splitting pays later there.
+static double split_pen(const DpigConvDesc* d) {
+    static const double x3 = getenv("DPIG_X3_SPLIT_PEN") ? atof(getenv("DPIG_X3_SPLIT_PEN")) : 120.0;
+    return d->compute == DPIG_COMPUTE_BF16X3 ? x3 : 120.0;
+}
 // matrix pipe of the GEMM loop (the PIPE template argument): the bf16 and split-bf16 loops need the same shape; the split
 // loop keeps the fp32 loop's k-tile, so every plan / workspace size of the exact path holds for it
 static int gg_pipe(const DpigConvDesc* d, int lda, int Cs, int Ncols, const void* a, const void* b) {
@@ -1831,7 +1837,7 @@ static size_t conv2d_workspace_bytes_one(const DpigConvDesc* d, int which) {
         size_t best = 0;
         for (int bk = BK; bk <= gg_bk(d, d->ldx, d->C, d->K); bk += BK) {
             Shape s = fwd_shape(d, Ho, Wo, bk);
-            Plan pln = plan_split(cdiv(s.M, BM) * cdiv(s.Ncols, BN), s.ktiles, d->split_k);
+            Plan pln = plan_split(cdiv(s.M, BM) * cdiv(s.Ncols, BN), s.ktiles, d->split_k, 32, split_pen(d));
             const size_t b = pln.nsplit > 1 ? (size_t)pln.nsplit * s.M * s.Ncols * sizeof(float) : 0;
             if (b > best) best = b;
         }
@@ -1843,11 +1849,11 @@ static size_t conv2d_workspace_bytes_one(const DpigConvDesc* d, int which) {
             if (d->upsample2x || d->stride == 1) {
                 const long M = (long)d->N * d->H * d->W;
                 const int ntaps = d->upsample2x ? 4 : d->R * d->S;
-                Plan pln = plan_split(cdiv(M, BM) * cdiv(d->C, BN), ntaps * cdiv(d->K, bk), d->split_k);
+                Plan pln = plan_split(cdiv(M, BM) * cdiv(d->C, BN), ntaps * cdiv(d->K, bk), d->split_k, 32, split_pen(d));
                 b = pln.nsplit > 1 ? (size_t)pln.nsplit * M * d->C * sizeof(float) : 0;
             } else {
                 S2Plan sp;
-                plan_dgrad_s2(d, pt, pl, &sp, bk);
+                plan_dgrad_s2(d, pt, pl, &sp, bk, split_pen(d));
                 b = sp.total;
             }
             if (b > best) best = b;
@@ -1866,7 +1872,7 @@ static size_t conv2d_workspace_bytes_one(const DpigConvDesc* d, int which) {
         const bool bf_shape = d->K > 32 && !flat && d->ldx % 4 == 0 && d->ldy % 4 == 0 && d->C % 4 == 0 && d->K % 4 == 0;
         const int bkmax = (d->compute == DPIG_COMPUTE_BF16 && bf_shape) ? BKH : BK;
         for (int bk = BK; bk <= bkmax; bk += BK) {
-            Plan pln = plan_split(tiles, cdiv(Npix, bk), d->split_k);
+            Plan pln = plan_split(tiles, cdiv(Npix, bk), d->split_k, 32, split_pen(d));
             const size_t b = pln.nsplit > 1 ? (size_t)pln.nsplit * ((size_t)d->R * d->S * d->C * d->K + d->K) * sizeof(float) : 0;
             if (b > best) best = b;
         }
@@ -1980,7 +1986,7 @@ extern "C" int dpig_conv2d_bn_stats_tiles(const DpigConvDesc* d) {
     if (d->upsample2x || d->K <= 32 || d->K % 4 || d->ldy % 4 || d->act != DPIG_ACT_NONE || images_per_launch(d, 4) < d->N) return 0;
     const int bk = gg_bk(d, d->ldx, d->C, d->K);
     Shape s = fwd_shape(d, Ho, Wo, bk);
-    Plan pln = plan_split(cdiv(s.M, BM) * cdiv(s.Ncols, BN), s.ktiles, d->split_k);
+    Plan pln = plan_split(cdiv(s.M, BM) * cdiv(s.Ncols, BN), s.ktiles, d->split_k, 32, split_pen(d));
     return pln.nsplit == 1 ? (int)cdiv(s.M, BM) : 0;
 }
 extern "C" int dpig_conv2d_fwd_stats(const DpigConvDesc* d, const float* x, const float* w, const float* bias, float* y,
@@ -2066,7 +2072,7 @@ static int conv2d_fwd_one(const DpigConvDesc* d, const float* x, const float* w,
     if (residual && d->ldres < d->K) return fail(DPIG_EINVAL, "ldres < K");
     p.ntaps = d->R * d->S;
     p.tap_nb = d->S; p.oy0 = -pt; p.oys = 1; p.ox0 = -pl; p.oxs = 1; p.w0 = 0; p.wa = d->S; p.wb = 1;
-    Plan pln = plan_split(cdiv(s.M, BM) * cdiv(s.Ncols, BN), s.ktiles, d->split_k);
+    Plan pln = plan_split(cdiv(s.M, BM) * cdiv(s.Ncols, BN), s.ktiles, d->split_k, 32, split_pen(d));
     p.nsplit = pln.nsplit; p.tiles_per_split = pln.tiles_per_split;
     if (p.nsplit > 1 && ws_bytes < (size_t)p.nsplit * s.M * s.Ncols * sizeof(float))
         return fail(DPIG_ENOMEM, "conv fwd workspace too small: have %zu", ws_bytes);
@@ -2122,7 +2128,7 @@ static int conv2d_dgrad_one(const DpigConvDesc* d, const float* dy, const float*
         p.tap_nb = d->S; p.oy0 = pt; p.oys = -1; p.ox0 = pl; p.oxs = -1; p.w0 = 0; p.wa = d->S; p.wb = 1;
     } else {
         S2Plan sp;
-        plan_dgrad_s2(d, pt, pl, &sp, bf16 ? BKH : BK);
+        plan_dgrad_s2(d, pt, pl, &sp, bf16 ? BKH : BK, split_pen(d));
         if (sp.total > 0 && (!ws || ws_bytes < sp.total))
             return fail(DPIG_ENOMEM, "conv dgrad workspace too small: have %zu", ws_bytes);
         GGParams qs[4];
@@ -2142,7 +2148,7 @@ static int conv2d_dgrad_one(const DpigConvDesc* d, const float* dy, const float*
         }
         return launch_gg_multi(qs, sp.nc, d->N, (long)d->R * d->S * d->C * d->K, st, pipe);
     }
-    Plan pln = plan_split(cdiv(p.M, BM) * cdiv(p.Ncols, BN), p.ntaps * cdiv(p.Cs, bf16 ? BKH : BK), d->split_k);
+    Plan pln = plan_split(cdiv(p.M, BM) * cdiv(p.Ncols, BN), p.ntaps * cdiv(p.Cs, bf16 ? BKH : BK), d->split_k, 32, split_pen(d));
     p.nsplit = pln.nsplit; p.tiles_per_split = pln.tiles_per_split;
     if (p.nsplit > 1 && (!ws || ws_bytes < (size_t)p.nsplit * p.M * p.Ncols * sizeof(float)))
         return fail(DPIG_ENOMEM, "conv dgrad workspace too small: have %zu", ws_bytes);
@@ -2195,7 +2201,7 @@ static int conv2d_wgrad_one(const DpigConvDesc* d, const float* x, const float* 
     p.ntiles = cdiv(d->K, narrow ? 32 : BN);
     p.ktiles = cdiv(p.Npix, bf16 ? BKH : BK);
     const int tiles = (flat ? cdiv((long)p.ntaps * d->C, BM) : p.ntaps * p.cblocks) * p.ntiles;
-    Plan pln = plan_split(tiles, p.ktiles, d->split_k);
+    Plan pln = plan_split(tiles, p.ktiles, d->split_k, 32, split_pen(d));
     p.nsplit = pln.nsplit; p.tiles_per_split = pln.tiles_per_split;
     const long wsize = (long)p.wrows * d->K;
     if (p.nsplit > 1 && (!ws || ws_bytes < (size_t)p.nsplit * (wsize + d->K) * sizeof(float)))
