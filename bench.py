@@ -285,16 +285,18 @@ def main():
         flops = sum(f for f, _ in fwd)
         secs = sum(t for _, t in fwd)
         achieved = flops / secs / 1e12
-        traffic = None
+        traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("conv_fwd_hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                traffic = tj.get("conv_fwd_hbm_bytes_per_launch")
+                traffic_src = "static: FETCH_SIZE / WRITE_SIZE passes of this command under rocprofv3 (%s), not re-measured in this run" % tj.get("source")
             except Exception:
                 traffic = None
-        roofline = {"bound": "mfma", "kernel": "dpig::gather_gemm_kernel<false, true, false, false> (conv fwd implicit GEMM, fp32 MFMA)",
+        roofline = {"bound": "mfma", "kernel": "dpig::gather_gemm_kernel<false, true, false, 0> (conv fwd implicit GEMM, fp32 MFMA)",
                     "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic,
+                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "launches_per_step": nl // nrep,
                     "flops_per_launch": flops / nl, "avg_launch_us": round(secs / nl * 1e6, 2),
                     "time_share_of_step": round(secs / nrep / (ms_per_step * 1e-3), 3)}

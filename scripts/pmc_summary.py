@@ -31,9 +31,9 @@ with open(os.path.join(root, "profiles", tag + "_pmc_traffic.md"), "w") as fh:
         fh.write("| `%s` | %d | %.0f | %.2f | %.2f | %.2f |\n" % (short(k), n, raw / 1024.0, rd / 1e6, wr / 1e6, tot / 1e6))
 js = {}
 for k, n, raw, rd, wr, tot in rows:
-    if "gather_gemm_kernel<false, true, false, false>" in k: js["conv_fwd_hbm_bytes_per_launch"] = round(tot)
-    if "gather_gemm_kernel<true, true, false, false>" in k: js["conv_dgrad_hbm_bytes_per_launch"] = round(tot)
-    if "wgrad_kernel<true, false, false, true, false>" in k: js["conv_wgrad_hbm_bytes_per_launch"] = round(tot)
+    if "gather_gemm_kernel<false, true, false, 0>" in k: js["conv_fwd_hbm_bytes_per_launch"] = round(tot)
+    if "gather_gemm_kernel<true, true, false, 0>" in k: js["conv_dgrad_hbm_bytes_per_launch"] = round(tot)
+    if "wgrad_kernel<true, false, false, true, 0>" in k: js["conv_wgrad_hbm_bytes_per_launch"] = round(tot)
 js["source"] = "profiles/%s_pmc_traffic.md" % tag
 json.dump(js, open(os.path.join(root, "profiles", "roofline_traffic.json"), "w"), indent=1)
 print(js)
