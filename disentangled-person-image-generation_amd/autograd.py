@@ -151,13 +151,14 @@ class _ConvFn(torch.autograd.Function):
     """y = act(conv_SAME(x, w) + b)   [optionally on a nearest-2x-upsampled x, 1x1 only]."""
 
     @staticmethod
-    def forward(ctx, x, w, b, stride, act, alpha, upsample2x, stats_box=None):
+    def forward(ctx, x, w, b, stride, act, alpha, upsample2x, stats_box=None, out=None):
         if stats_box is not None and act == ACT_NONE and not upsample2x:
             # the caller's next op is a batch norm: let the conv epilogue leave the per-tile statistics (None when it cannot)
             y, st = H.conv2d_fwd_stats(x, w, b, stride=stride)
             stats_box.append(st)
         else:
-            y = H.conv2d_fwd(x, w, b, stride=stride, act=act, alpha=alpha, upsample2x=upsample2x)
+            y = H.conv2d_fwd(x, w, b, stride=stride, act=act, alpha=alpha, upsample2x=upsample2x,
+                             out=out.t if out is not None else None)
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         ctx.cfg = (stride, act, alpha, upsample2x, b is not None)
         ctx.b_ref = b
@@ -180,16 +181,19 @@ class _ConvFn(torch.autograd.Function):
             else:
                 dx = H.conv2d_dgrad(dz, w, tuple(x.shape), stride=stride, upsample2x=up)
         if _PARAM_GRADS_OFF[0]:
-            return dx, None, None, None, None, None, None, None
+            return dx, None, None, None, None, None, None, None, None
         dw, db = _sink_wgrad_bias(w, ctx.b_ref, x, dz, stride, up, ctx.needs_input_grad[1],
                                   has_b and ctx.needs_input_grad[2])
-        return dx, dw, db, None, None, None, None, None
+        return dx, dw, db, None, None, None, None, None, None
 
 
-def conv2d(x, w, b=None, stride=1, act=ACT_NONE, alpha=0.2, upsample2x=False, bn_stats=False):
+def conv2d(x, w, b=None, stride=1, act=ACT_NONE, alpha=0.2, upsample2x=False, bn_stats=False, out=None):
     """`bn_stats=True` (the next op is a training-mode batch norm over this output): the result carries `_dpig_bnstats`, the
-    conv epilogue's per-tile statistics, when the launch plan allows it (hip_ops.conv2d_fwd_stats)."""
+    conv epilogue's per-tile statistics, when the launch plan allows it (hip_ops.conv2d_fwd_stats).
+    `out`: a channel slice of a wider NHWC buffer to write the result into (see `join_channels`)."""
     if not bn_stats:
+        if out is not None:
+            return _ConvFn.apply(x, w, b, stride, act, alpha, upsample2x, None, _Out(out))
         return _ConvFn.apply(x, w, b, stride, act, alpha, upsample2x)
     box = []
     y = _ConvFn.apply(x, w, b, stride, act, alpha, upsample2x, box)
@@ -205,10 +209,10 @@ class _ResBlockFn(torch.autograd.Function):
     dgrad(conv2) applies c1's ReLU mask and dgrad(conv1) adds the skip gradient in its epilogue."""
 
     @staticmethod
-    def forward(ctx, x0, w1, b1, w2, b2):
+    def forward(ctx, x0, w1, b1, w2, b2, out=None):
         c1 = H.conv2d_fwd(x0, w1, b1, act=ACT_RELU)
         c2 = torch.empty_like(c1)
-        out = torch.empty_like(c1)
+        out = torch.empty_like(c1) if out is None else out.t
         H.conv2d_fwd(c1, w2, b2, act=ACT_RELU, residual=x0, res_after_act=True, out=out, out_act=c2)
         ctx.save_for_backward(x0, w1, w2, c1, c2)
         ctx.b_refs = (b1, b2)
@@ -225,11 +229,79 @@ class _ResBlockFn(torch.autograd.Function):
         dx0 = None
         if ctx.needs_input_grad[0]:
             dx0 = H.conv2d_dgrad(dz1, w1, tuple(x0.shape), accum=dout)
-        return dx0, dw1, db1, dw2, db2
+        return dx0, dw1, db1, dw2, db2, None
 
 
-def resblock(x0, w1, b1, w2, b2):
+def resblock(x0, w1, b1, w2, b2, out=None):
+    """`out`: a channel slice of a wider NHWC buffer to write the block's output into (see `join_channels`)."""
+    if out is not None:
+        return _ResBlockFn.apply(x0, w1, b1, w2, b2, _Out(out))
     return _ResBlockFn.apply(x0, w1, b1, w2, b2)
+
+
+class _Out(object):
+    """Carrier of an `out=` tensor through Function.apply: not a Tensor argument, so autograd neither treats it as an input
+    nor the returned tensor as "an input returned as is"."""
+
+    def __init__(self, t):
+        self.t = t
+
+
+class _PlaceFn(torch.autograd.Function):
+    """Copy x into a channel slice of a wider buffer (identity for autograd)."""
+
+    @staticmethod
+    def forward(ctx, x, out):
+        out.t.copy_(x)
+        return out.t
+
+    @staticmethod
+    def backward(ctx, d):
+        return d, None
+
+
+def place(x, out):
+    return _PlaceFn.apply(x, _Out(out))
+
+
+def _alias(storage_of, offset, size, stride):
+    """A tensor over the same memory that is NOT an autograd view of anything (own version counter, no base)."""
+    return torch.empty(0, dtype=storage_of.dtype, device=storage_of.device).set_(storage_of.untyped_storage(), offset, size, stride)
+
+
+class _JoinFn(torch.autograd.Function):
+    """tf.concat([a, b], axis=3) (models.py:560) of two tensors that ALREADY are adjacent channel slices of one NHWC buffer
+    (their producers were given `out=` slices): the result is that buffer -- no copy; the gradient splits into two views."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.c1 = a.shape[3]
+        N, Hh, W, C1 = a.shape
+        return _alias(a, a.storage_offset(), (N, Hh, W, C1 + b.shape[3]), a.stride())
+
+    @staticmethod
+    def backward(ctx, d):
+        return d[..., :ctx.c1], d[..., ctx.c1:]
+
+
+def channel_slices(N, Hh, W, c1, c2, dtype, device):
+    """One NHWC buffer of c1 + c2 channels and its two channel slices (for `out=` of the two producers of a concat)."""
+    buf = torch.empty((N, Hh, W, c1 + c2), dtype=dtype, device=device)
+    C = c1 + c2
+    st = (Hh * W * C, W * C, C, 1)
+    return _alias(buf, 0, (N, Hh, W, c1), st), _alias(buf, c1, (N, Hh, W, c2), st)
+
+
+def join_channels(a, b):
+    """concat([a, b], channel axis): free when a and b are adjacent slices of one buffer (`channel_slices`), else a copy."""
+    adjacent = (a.dim() == 4 and b.dim() == 4 and a.dtype == b.dtype and a.shape[:3] == b.shape[:3] and
+                a.stride() == b.stride() and a.stride(3) == 1 and a.stride(2) == a.shape[3] + b.shape[3] and
+                a.stride(1) == a.shape[2] * a.stride(2) and a.stride(0) == a.shape[1] * a.stride(1) and
+                a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() and
+                b.storage_offset() == a.storage_offset() + a.shape[3])
+    if adjacent:
+        return _JoinFn.apply(a, b)
+    return torch.cat([a, b], dim=3)
 
 
 def _valid_taps(c):

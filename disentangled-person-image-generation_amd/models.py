@@ -6,6 +6,8 @@ Activations are NHWC fp32 device tensors.  Differences from the reference are ex
 the residual blocks are one fused op (slim.res_block), the 7 ROI crops are one launch, and the
 nearest-2x upsample is folded into the following 1x1 conv.  Arithmetic is unchanged.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -224,9 +226,21 @@ def GeneratorCNN_ID_UAEAfterResidual(x, pose, input_channel, z_num, repeat_num, 
                 x = torch.cat([x, pose], dim=3)
             x = slim.conv2d(x, hidden_num, 3, 1, activation_fn=activation_fn, data_format=data_format)
         _tap("G.stem", x)
+        # The decoder's tf.concat([x, skip], 3) (models.py:560) is made free: each encoder block writes its output straight
+        # into the upper channel slice of the buffer the decoder stage will read, and the decoder's producer (the upsampled
+        # 1x1 conv of the stage before) writes the lower slice -- A.join_channels then hands out the buffer itself.
+        placed = activation_fn is slim.relu and not os.environ.get('DPIG_NO_PLACED_CONCAT')
+        dec_slices = []
         for idx in range(repeat_num):
             channel_num = hidden_num * (idx + 1)
-            x = slim.res_block(x, channel_num, 3, activation_fn=activation_fn, data_format=data_format)
+            out_slice = None
+            if placed and x.shape[-1] == channel_num:
+                c_dec = channel_num if idx < repeat_num - 1 else hidden_num
+                lo, out_slice = A.channel_slices(x.shape[0], x.shape[1], x.shape[2], c_dec, channel_num, x.dtype, x.device)
+                dec_slices.append(lo)
+            else:
+                dec_slices.append(None)
+            x = slim.res_block(x, channel_num, 3, activation_fn=activation_fn, data_format=data_format, out=out_slice)
             encoder_layer_list.append(x)
             if idx < repeat_num - 1:
                 x = slim.conv2d(x, hidden_num * (idx + 2), 3, 2, activation_fn=activation_fn,
@@ -243,16 +257,22 @@ def GeneratorCNN_ID_UAEAfterResidual(x, pose, input_channel, z_num, repeat_num, 
         # Decoder
         x = fully_connected(z, x_shape[1] * x_shape[2] * hidden_num, activation_fn=None)
         x = reshape(x, x_shape[1], x_shape[2], hidden_num, data_format)
+        lo = dec_slices[repeat_num - 1]
+        if lo is not None and lo.shape == x.shape and lo.dtype == x.dtype:
+            x = A.place(x, lo)                   # (the 8x4 map out of the FC layer: a tiny copy into its slice)
 
         for idx in range(repeat_num):
-            x = torch.cat([x, encoder_layer_list[repeat_num - 1 - idx]], dim=-1)
+            x = A.join_channels(x, encoder_layer_list[repeat_num - 1 - idx])
             channel_num = x.shape[-1]
             x = slim.res_block(x, channel_num, 3, activation_fn=activation_fn, data_format=data_format)
             _tap("G.dec%d" % idx, x)
             if idx < repeat_num - 1:
                 # x = upscale(x, 2, data_format); x = slim.conv2d(x, ..., 1, 1, ...)   (models.py:569-570)
-                x = slim.conv2d(x, hidden_num * (repeat_num - idx - 1), 1, 1, activation_fn=activation_fn,
-                                data_format=data_format, upsample2x=True)
+                c_up = hidden_num * (repeat_num - idx - 1)
+                lo = dec_slices[repeat_num - 2 - idx]
+                if lo is not None and not (lo.shape[-1] == c_up and lo.shape[1] == 2 * x.shape[1] and lo.dtype == x.dtype):
+                    lo = None
+                x = slim.conv2d(x, c_up, 1, 1, activation_fn=activation_fn, data_format=data_format, upsample2x=True, out=lo)
 
         out = slim.conv2d(x, input_channel, 3, 1, activation_fn=None, data_format=data_format)
         variables = slim.get_variables(vs)

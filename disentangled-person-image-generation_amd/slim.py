@@ -94,7 +94,7 @@ def _conv_vars(scope, k, cin, cout):
 
 
 def conv2d(inputs, num_outputs, kernel_size, stride=1, activation_fn=relu, data_format="NHWC", scope=None,
-           upsample2x=False):
+           upsample2x=False, out=None):
     """slim.conv2d(x, num_outputs, k, s, activation_fn=..., data_format=...) on NHWC tensors.
     `upsample2x=True` (extension) means "the input is utils.upscale(x, 2)": the nearest-neighbour
     upsample of models.py:569 is folded into the 1x1 conv (exact: the two ops commute)."""
@@ -104,7 +104,7 @@ def conv2d(inputs, num_outputs, kernel_size, stride=1, activation_fn=relu, data_
     cin = inputs.shape[-1]
     w, b = _conv_vars(name, kernel_size, cin, num_outputs)
     act, foreign = _act_code(activation_fn)
-    y = A.conv2d(inputs, w, b, stride=stride, act=act, upsample2x=upsample2x)
+    y = A.conv2d(inputs, w, b, stride=stride, act=act, upsample2x=upsample2x, out=out if foreign is None else None)
     return foreign(y) if foreign is not None else y
 
 
@@ -118,7 +118,7 @@ def conv2d_tiled_embedding(emb, pose, num_outputs, scope=None):
     return A.tiled_emb_conv(emb, pose, w, b)
 
 
-def res_block(inputs, channel_num, kernel_size=3, activation_fn=relu, data_format="NHWC"):
+def res_block(inputs, channel_num, kernel_size=3, activation_fn=relu, data_format="NHWC", out=None):
     """The three reference lines
             x = slim.conv2d(x, channel_num, 3, 1, activation_fn=...)
             x = slim.conv2d(x, channel_num, 3, 1, activation_fn=...)
@@ -135,7 +135,7 @@ def res_block(inputs, channel_num, kernel_size=3, activation_fn=relu, data_forma
     w2, b2 = _conv_vars(n2, kernel_size, channel_num, channel_num)
     act, foreign = _act_code(activation_fn)
     if act == ACT_RELU and cin == channel_num and foreign is None:
-        return A.resblock(inputs, w1, b1, w2, b2)
+        return A.resblock(inputs, w1, b1, w2, b2, out=out)      # `out` (extension): a channel slice to write the result into
     x = A.conv2d(inputs, w1, b1, act=act)
     x = foreign(x) if foreign is not None else x
     x = A.conv2d(x, w2, b2, act=act)
