@@ -536,3 +536,40 @@ def test_batches_beyond_two_gib(dev, storage):
     assert float((db - refb).abs().max()) <= 2e-5 * float(refb.abs().max())
     dw2 = H.conv2d_wgrad(x, dy, (3, 3, C, K), out=torch.empty(3, 3, C, K, device=dev), beta=0.0)
     assert torch.equal(dw2, dw)
+
+
+def test_round2_entry_points_refuse_bad_arguments(dev):
+    """Status codes (never a launch) of the entry points added in round 2: statistics-carrying forward on a plan that cannot
+    carry them, a statistics merge whose tile count does not cover the rows, split shadows with a lo plane inside the hi
+    plane; and the shadow-fed x3 forward without shadows simply splits the fp32 filter in the loop."""
+    import ctypes
+    import dpig_amd.hip_ops as H
+    from dpig_amd._lib import lib, ptr, stream_ptr
+    x = torch.randn(1, 8, 8, 64, device=dev)
+    w = torch.randn(3, 3, 64, 64, device=dev) * 0.1
+    y = torch.empty(1, 8, 8, 64, device=dev)
+    st = torch.empty(1, 2, 64, device=dev)
+    d = H._desc(1, 8, 8, 64, 64, 3, 3, 1, 64, 64)
+    assert lib().dpig_conv2d_bn_stats_tiles(ctypes.byref(d)) == 0            # 1 row tile: the heuristic plan is split-K
+    assert lib().dpig_conv2d_fwd_stats(ctypes.byref(d), ptr(x), ptr(w), None, ptr(y), ptr(st), stream_ptr()) != 0
+    assert b"statistics" in lib().dpig_last_error()
+    d1 = H._desc(1, 8, 8, 64, 64, 3, 3, 1, 64, 64, split_k=1)
+    assert lib().dpig_conv2d_bn_stats_tiles(ctypes.byref(d1)) == 1
+    assert lib().dpig_conv2d_fwd_stats(ctypes.byref(d1), ptr(x), ptr(w), None, ptr(y), None, stream_ptr()) != 0
+    m = torch.empty(64, device=dev)
+    assert lib().dpig_bn_stats_finalize(ptr(st), 1, 64, 128, 64, 1e-5, ptr(m), ptr(m), stream_ptr()) == 0
+    assert lib().dpig_bn_stats_finalize(ptr(st), 1, 200, 128, 64, 1e-5, ptr(m), ptr(m), stream_ptr()) != 0    # 2 tiles needed
+    assert lib().dpig_bn_stats_finalize(ptr(st), 2, 64, 128, 64, 1e-5, ptr(m), ptr(m), stream_ptr()) != 0     # 1 tile too many
+    sh = torch.empty(4 * w.numel(), dtype=torch.bfloat16, device=dev)
+    assert lib().dpig_filter_shadow_split(ptr(w), ptr(sh), None, w.numel() - 8, 9, 64, 64, stream_ptr()) != 0  # planes overlap
+    assert lib().dpig_filter_shadow_split(ptr(w), ptr(sh), None, w.numel(), 9, 64, 64, stream_ptr()) == 0
+    H.set_compute("bf16x3")
+    try:
+        d2 = H._desc(1, 8, 8, 64, 64, 3, 3, 1, 64, 64)
+        ref = H.conv2d_fwd(x, w)
+        ws, wn = H._ws(d2, 0, dev)
+        assert lib().dpig_conv2d_fwd_x3(ctypes.byref(d2), ptr(x), ptr(w), None, None, None, None, ptr(y), None, ptr(ws), wn,
+                                        stream_ptr()) == 0
+        assert torch.equal(y, ref)
+    finally:
+        H.set_compute("f32")
