@@ -158,7 +158,7 @@ class _ConvFn(torch.autograd.Function):
             stats_box.append(st)
         else:
             y = H.conv2d_fwd(x, w, b, stride=stride, act=act, alpha=alpha, upsample2x=upsample2x,
-                             out=out.t if out is not None else None)
+                             out=out.t if out is not None else None, emit32=True)      # (a conv's output mostly feeds a conv)
         ctx.save_for_backward(x, w, y if act != ACT_NONE else None)
         ctx.cfg = (stride, act, alpha, upsample2x, b is not None)
         ctx.b_ref = b
@@ -210,10 +210,10 @@ class _ResBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x0, w1, b1, w2, b2, out=None):
-        c1 = H.conv2d_fwd(x0, w1, b1, act=ACT_RELU)
+        c1 = H.conv2d_fwd(x0, w1, b1, act=ACT_RELU, emit32=True)
         c2 = torch.empty_like(c1)
         out = torch.empty_like(c1) if out is None else out.t
-        H.conv2d_fwd(c1, w2, b2, act=ACT_RELU, residual=x0, res_after_act=True, out=out, out_act=c2)
+        H.conv2d_fwd(c1, w2, b2, act=ACT_RELU, residual=x0, res_after_act=True, out=out, out_act=c2, emit32=True)
         ctx.save_for_backward(x0, w1, w2, c1, c2)
         ctx.b_refs = (b1, b2)
         return out
@@ -224,7 +224,7 @@ class _ResBlockFn(torch.autograd.Function):
         b1, b2 = ctx.b_refs
         dz2 = H.act_bwd(dout, c2, ACT_RELU)
         dw2, db2 = _sink_wgrad_bias(w2, b2, c1, dz2, want_w=ctx.needs_input_grad[3], want_b=ctx.needs_input_grad[4])
-        dz1 = H.conv2d_dgrad(dz2, w2, tuple(c1.shape), mask=c1, act=ACT_RELU)
+        dz1 = H.conv2d_dgrad(dz2, w2, tuple(c1.shape), mask=c1, act=ACT_RELU, emit32=True)    # feeds dgrad(conv1)
         dw1, db1 = _sink_wgrad_bias(w1, b1, x0, dz1, want_w=ctx.needs_input_grad[1], want_b=ctx.needs_input_grad[2])
         dx0 = None
         if ctx.needs_input_grad[0]:

@@ -55,6 +55,11 @@ struct GGParams {
     float* stats;         // BN partial statistics [mtiles][2][Ncols] of v + bias (sum, centred squares per row tile) or null
     const unsigned short* Bs_hi;   // PIPE 3: bf16 hi plane of the filter's split shadow, rows n, k contiguous; the lo plane
     unsigned bs_lo_off, bs_bytes;  //         starts bs_lo_off bytes behind it; bs_bytes = extent of hi..lo for the descriptor
+    const unsigned short* As32;    // PIPE 4: the gathered activation in split32 layout [pixel][chunk][32 hi | 32 lo] (dpig_split32)
+    unsigned as_bytes;
+    int a_nchunk;                  //         32-channel chunks per pixel
+    unsigned short* D32;           // split32 image of D, written by the float4 epilogue (x3 mode: the next conv DMAs it) or null
+    int d_nchunk;
     int M, Hr, Wr, HrWr;  // row grid (rows = images x Hr x Wr)
     int Hs, Ws, lda, Cs, sr;   // source spatial dims, channel stride, reduction channels, row->src stride
     int Ncols;            // GEMM N
@@ -162,6 +167,18 @@ __device__ __forceinline__ long class_row(int row, int HrWr, int Wr, int Hr) {
 }
 
 // Fused epilogue on 4 consecutive columns of one output row (16-byte accesses throughout).
+// The value's two bf16 terms as the split k-loops round them (hi = bf16(v), lo = bf16(v - hi)), 4 channels of one pixel into
+// its split32 image [pixel][chunk][32 hi | 32 lo]: what dpig_split32 would write for D, without reading D again.
+__device__ __forceinline__ void store_s32(const GGParams& p, long pix, int col, float4 v) {
+    typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+    b2 h0, h1, l0, l1;
+    h0[0] = (__bf16)v.x; h0[1] = (__bf16)v.y; h1[0] = (__bf16)v.z; h1[1] = (__bf16)v.w;
+    l0[0] = (__bf16)(v.x - (float)h0[0]); l0[1] = (__bf16)(v.y - (float)h0[1]);
+    l1[0] = (__bf16)(v.z - (float)h1[0]); l1[1] = (__bf16)(v.w - (float)h1[1]);
+    unsigned short* o = p.D32 + (pix * p.d_nchunk + (col >> 5)) * 64 + (col & 31);
+    *reinterpret_cast<uint2*>(o) = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
+    *reinterpret_cast<uint2*>(o + 32) = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
+}
 __device__ __forceinline__ void epi_vec4(const GGParams& p, int row, int col, float4 v, float4 bv) {
     long pix = row;
     if (!p.identity_rows) {
@@ -189,6 +206,7 @@ __device__ __forceinline__ void epi_vec4(const GGParams& p, int row, int col, fl
     if (p.D2) *reinterpret_cast<float4*>(p.D2 + pix * p.ldd2 + col) = v;
     if (p.res && p.res_post) { v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
     *reinterpret_cast<float4*>(p.D + pix * p.ldd + col) = v;
+    if (p.D32) store_s32(p, pix, col, v);
     if (p.replicate) {
         *reinterpret_cast<float4*>(p.D + (pix + 1) * p.ldd + col) = v;
         *reinterpret_cast<float4*>(p.D + (pix + p.Wd) * p.ldd + col) = v;
@@ -590,11 +608,124 @@ __device__ __forceinline__ void gg_mainloop_split(const GGParams& p, char* lds, 
     if (B_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // (dead pieces of the tiles past the end)
 }
 
+// ---- PIPE 4: split-bf16 with BOTH operands by LDS-DMA ---------------------------------------------------------------------
+// The activation's two-term split is taken out of the loop as well: dpig_split32 writes it once per tensor as
+// [pixel][32-channel chunk][32 hi | 32 lo] bf16 (4 bytes per element, like the fp32 tensor it mirrors; zero-padded to whole
+// chunks), so that one 128-byte tile row is ONE contiguous 128-byte read and a k-tile (tap, chunk) is a scalar offset.  The
+// k-loop then is the bf16-storage loop (dpig_conv_bf16.hip) with three MFMAs per fragment pair: eight 1-KB DMA pieces per wave
+// per k-tile, no operand ever in a VGPR, 24 MFMAs.  Both tile images have unpadded 128-byte rows, 16-byte slot s of row r
+// holding granule s ^ ((r >> 1) & 7) (source-side swizzle: zero LDS bank conflicts).  Same roundings, products and order as
+// the in-loop split => bit-identical results.
+__device__ __forceinline__ void gg_mainloop_x3dma(const GGParams& p, char* lds, f32x16 (&acc)[2][2], int m0, int n0,
+                                                  int kt_begin, int kt_end, int tid, int wrow, int wcol, int l31, int half) {
+    constexpr int IMG = 128 * 128;           // one operand image
+    constexpr int STG = 2 * IMG;             // a stage: A image, B image
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.As32), 0, (int)p.as_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned short*>(p.Bs_hi), 0, (int)p.bs_bytes, 0x00020000);
+    int a_base[4], a_iy0[4], a_ix0[4], a_voff[4], d_kk[4];
+    unsigned b_off[4];
+    bool b_ok[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {            // piece 4 wave + i = tile rows 8 piece .. + 7; lane -> (row, 16-byte slot)
+        const int r = (wave * 4 + i) * 8 + (lane >> 3);
+        const int gs = (lane & 7) ^ ((r >> 1) & 7);
+        const int m = m0 + r;
+        const bool ok = m < p.M;
+        const int mm = ok ? m : 0;
+        const int n = fast_div(mm, p.mul_hrwr, p.shr_hrwr);
+        const int rem = mm - n * p.HrWr;
+        const int rr = fast_div(rem, p.mul_wr, p.shr_wr);
+        const int c = rem - rr * p.Wr;
+        a_iy0[i] = ok ? rr * p.sr : -(1 << 24);                // a row beyond M fails every bounds test
+        a_ix0[i] = c * p.sr;
+        a_base[i] = (((n * p.Hs + rr * p.sr) * p.Ws + c * p.sr) * p.a_nchunk) * 128 + gs * 16;
+        d_kk[i] = (gs & 3) * 8;
+        b_ok[i] = n0 + r < p.Ncols;
+        b_off[i] = (unsigned)(((n0 + r) * p.Cs + d_kk[i]) * 2) + ((gs >> 2) ? p.bs_lo_off : 0u);
+    }
+    int cur_c0, cur_ta, cur_tb, tap_sB = 0;
+    {
+        const int tap = kt_begin / p.cchunks;
+        cur_c0 = (kt_begin - tap * p.cchunks) * BKS;
+        cur_ta = tap / p.tap_nb;
+        cur_tb = tap - cur_ta * p.tap_nb;
+    }
+    auto enter_tap = [&]() {                 // per TAP: the halo test and the tap's pixel shift, folded into one offset per piece
+        const int t_oy = p.oy0 + cur_ta * p.oys, t_ox = p.ox0 + cur_tb * p.oxs;
+        const int shift = ((t_oy * p.Ws + t_ox) * p.a_nchunk) * 128;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool ok = ((unsigned)(a_iy0[i] + t_oy) < (unsigned)p.Hs) & ((unsigned)(a_ix0[i] + t_ox) < (unsigned)p.Ws);
+            a_voff[i] = ok ? a_base[i] + shift : (int)OOB;
+        }
+        tap_sB = ((p.w0 + cur_ta * p.wa + cur_tb * p.wb) * p.Ncols * p.Cs) * 2;
+    };
+    enter_tap();
+    auto issue = [&](int stage) {
+        const int c0 = cur_c0;
+        char* dst = lds + stage * STG + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void_t*)(dst + i * 1024), 16, a_voff[i], (c0 >> 5) * 128, 0, 0);
+            const bool kok = b_ok[i] & (c0 + d_kk[i] < p.Cs);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsB, (lds_void_t*)(dst + IMG + i * 1024), 16, (int)(kok ? b_off[i] : OOB), tap_sB + c0 * 2, 0, 0);
+        }
+        cur_c0 += BKS;
+        if (cur_c0 >= p.Cs) {                                  // next tap (uniform branch)
+            cur_c0 = 0;
+            if (++cur_tb == p.tap_nb) { cur_tb = 0; ++cur_ta; }
+            enter_tap();
+        }
+    };
+    const int fsw = (l31 >> 1) & 7;
+    auto load_frag = [&](int stage, int ks, SplitFrag& f) {
+        const int slot = (ks * 2 + half) ^ fsw;
+        const char* ab = lds + stage * STG + (wrow + l31) * 128;
+        const char* bb = lds + stage * STG + IMG + (wcol + l31) * 128;
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+            f.ah[mb] = *reinterpret_cast<const bf16x8*>(ab + mb * 32 * 128 + slot * 16);
+            f.al[mb] = *reinterpret_cast<const bf16x8*>(ab + mb * 32 * 128 + (slot ^ 4) * 16);
+        }
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            f.bh[nb] = *reinterpret_cast<const bf16x8*>(bb + nb * 32 * 128 + slot * 16);
+            f.bl[nb] = *reinterpret_cast<const bf16x8*>(bb + nb * 32 * 128 + (slot ^ 4) * 16);
+        }
+    };
+    SplitFrag f0, f1;
+    auto ktile = [&](int stage, bool more) {
+        load_frag(stage, 0, f0);
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) issue(stage ^ 1);          // the stage it fills was last read before the barrier every wave has passed
+        load_frag(stage, 1, f1);
+        __builtin_amdgcn_sched_barrier(0);
+        split_mfma(f0, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        split_mfma(f1, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+    if (kt_begin >= kt_end) return;
+    issue(0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    int kt = kt_begin;
+    for (; kt + 1 < kt_end; kt += 2) {       // two k-tiles per trip: the LDS stage is a compile-time constant
+        ktile(0, true);
+        ktile(1, kt + 2 < kt_end);
+    }
+    if (kt < kt_end) ktile(0, false);
+}
+
 // NARROW: 128 x 32 block tile (waves stacked 4 x 1, one 32x32 accumulator each) for GEMMs whose N is
 // at most 32 (Cout = 3 image conv, dgrad towards a 3-channel image, N = 1 logits): 4x fewer MFMAs than
 // masking a 128-wide tile down to 3 columns.
 // PIPE: 0 fp32 MFMA (exact), 1 bf16 (operands rounded), 2 split-bf16 (three MFMAs per product block), 3 = 2 with the filter
-// operand from precomputed hi / lo shadows by LDS-DMA
+// operand from precomputed hi / lo shadows by LDS-DMA, 4 = 3 with the activation from its split32 image by LDS-DMA too
 template <bool B_ROWK, bool VEC, bool NARROW, int PIPE = 0>
 __device__ __forceinline__ void gather_gemm_body(const GGParams& p) {
     constexpr bool BF16 = PIPE == 1;
@@ -643,6 +774,9 @@ __device__ __forceinline__ void gather_gemm_body(const GGParams& p) {
         static_assert(!NARROW && VEC && B_ROWK, "split-bf16 with filter shadows: 128x128 tile, filter rows n / k contiguous");
         gg_mainloop_split<true, true>(p, reinterpret_cast<char*>(&smem[0][0]), acc, m0, n0, kt_begin, kt_end, tid, wrow, wcol,
                                       l31, half);
+    } else if constexpr (PIPE == 4) {
+        static_assert(!NARROW && VEC && B_ROWK, "split-bf16 with both operands by DMA: 128x128 tile, filter rows n / k contiguous");
+        gg_mainloop_x3dma(p, reinterpret_cast<char*>(&smem[0][0]), acc, m0, n0, kt_begin, kt_end, tid, wrow, wcol, l31, half);
     } else {
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes);
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.B, p.b_bytes);
@@ -918,6 +1052,7 @@ __device__ __forceinline__ void gather_gemm_body(const GGParams& p) {
                         if (HAS_D2) *reinterpret_cast<float4*>(d2 + (long)(8 * it) * p.ldd2) = v;
                         if (HAS_RES && RES_POST) { v.x += rv.x; v.y += rv.y; v.z += rv.z; v.w += rv.w; }
                         *reinterpret_cast<float4*>(dp + (long)(8 * it) * p.ldd) = v;
+                        if (p.D32) store_s32(p, r0 + 8 * it, col, v);
                     }
                 };
                 using T = std::true_type; using F = std::false_type;
@@ -1737,6 +1872,7 @@ static int launch_gg(GGParams& p, bool b_rowk, int nimg, long filter_elems, hipS
     if (rc) return rc;
     dim3 grid(p.mtiles * p.ntiles, 1, p.nsplit), block(256);
     if (pipe && (!vec || narrow)) return fail(DPIG_EINVAL, "internal: bf16 loop selected for an ineligible problem");
+    if (!p.vec_epi || narrow || p.nsplit != 1 || p.replicate) p.D32 = nullptr;      // only the un-split float4 epilogue writes the image
     if (p.stats && (p.nsplit != 1 || !p.vec_epi || narrow || !aligned16(p.stats)))
         return fail(DPIG_EINVAL, "conv fwd with BN statistics needs an un-split plan, 16-byte aligned operands and more than 32 output channels");
 #define DPIG_GG(BR, VE, NA) hipLaunchKernelGGL((gather_gemm_kernel<BR, VE, NA>), grid, block, 0, st, p)
@@ -1750,6 +1886,8 @@ static int launch_gg(GGParams& p, bool b_rowk, int nimg, long filter_elems, hipS
         else hipLaunchKernelGGL((gather_gemm_kernel<false, true, false, 2>), grid, block, 0, st, p);
     } else if (pipe == 3) {
         hipLaunchKernelGGL((gather_gemm_kernel<true, true, false, 3>), grid, block, 0, st, p);
+    } else if (pipe == 4) {
+        hipLaunchKernelGGL((gather_gemm_kernel<true, true, false, 4>), grid, block, 0, st, p);
     } else if (b_rowk) {
         if (narrow) { if (vec) DPIG_GG(true, true, true); else DPIG_GG(true, false, true); }
         else { if (vec) DPIG_GG(true, true, false); else DPIG_GG(true, false, false); }
@@ -1788,6 +1926,7 @@ static int launch_gg_multi(GGParams* q, int n, int nimg, long filter_elems, hipS
     if (pipe == 1) hipLaunchKernelGGL((gather_gemm_multi_kernel<true, true, false, 1>), grid, block, 0, st, m);
     else if (pipe == 2) hipLaunchKernelGGL((gather_gemm_multi_kernel<true, true, false, 2>), grid, block, 0, st, m);
     else if (pipe == 3) hipLaunchKernelGGL((gather_gemm_multi_kernel<true, true, false, 3>), grid, block, 0, st, m);
+    else if (pipe == 4) hipLaunchKernelGGL((gather_gemm_multi_kernel<true, true, false, 4>), grid, block, 0, st, m);
     else if (narrow) { if (vec) DPIG_GGM(true, true); else DPIG_GGM(false, true); }
     else { if (vec) DPIG_GGM(true, false); else DPIG_GGM(false, false); }
 #undef DPIG_GGM
@@ -1883,19 +2022,31 @@ static size_t conv2d_workspace_bytes_one(const DpigConvDesc* d, int which) {
 
 // ---- entry points: one launch, or runs of whole images when a tensor exceeds one launch's 2 GiB range (dpig_conv_plan.h) ----
 // hi / lo bf16 planes of a filter's split shadow (rows n, k contiguous); null hi = none
-struct SplitShadow { const unsigned short* hi; const unsigned short* lo; };
+struct SplitShadow {
+    const unsigned short* hi; const unsigned short* lo;
+    const unsigned short* a32;     // the gathered activation in split32 layout (dpig_split32) or null
+    unsigned short* out32;         // where to leave the OUTPUT's split32 image (or null); *wrote says whether it was written
+    int* wrote;
+};
 static int conv2d_fwd_one(const DpigConvDesc* d, const float* x, const float* w, const float* bias,
                           const float* residual, float* y, float* y_act, void* ws, size_t ws_bytes, void* stream,
-                          float* stats = nullptr, SplitShadow sh = SplitShadow{nullptr, nullptr});
+                          float* stats = nullptr, SplitShadow sh = SplitShadow{nullptr, nullptr, nullptr, nullptr, nullptr});
 static int conv2d_dgrad_one(const DpigConvDesc* d, const float* dy, const float* w, const float* accum,
                             const float* mask, float* dx, void* ws, size_t ws_bytes, void* stream,
-                            SplitShadow sh = SplitShadow{nullptr, nullptr});
+                            SplitShadow sh = SplitShadow{nullptr, nullptr, nullptr, nullptr, nullptr});
 // PIPE 3 is PIPE 2 with the filter from its split shadow: same shapes, plus 16-byte k-granules and one descriptor over both planes
 static bool shadow_usable(const DpigConvDesc* d, int pipe, int Cs, long filter_elems, SplitShadow sh) {
     if (pipe != 2 || !sh.hi || !sh.lo || Cs % 8 || !aligned16(sh.hi) || !aligned16(sh.lo)) return false;
     const long off = reinterpret_cast<const char*>(sh.lo) - reinterpret_cast<const char*>(sh.hi);
     (void)d;
     return off > 0 && off + filter_elems * 2 < 0x7fffffffL;
+}
+// PIPE 4 on top of PIPE 3: the gathered activation's split32 image ([pixel][chunk][32 hi | 32 lo]) inside one descriptor
+static bool split32_usable(GGParams& p, SplitShadow sh, long pixels, int channels) {
+    const long bytes = pixels * cdiv(channels, 32) * 128;
+    if (!sh.a32 || !aligned16(sh.a32) || bytes >= 0x7fffffffL) return false;
+    p.As32 = sh.a32; p.as_bytes = (unsigned)bytes; p.a_nchunk = cdiv(channels, 32);
+    return true;
 }
 static int conv2d_wgrad_one(const DpigConvDesc* d, const float* x, const float* dy, float* dw, float beta,
                             float* db, float beta_b, void* ws, size_t ws_bytes, void* stream);
@@ -1937,12 +2088,15 @@ extern "C" int dpig_conv2d_fwd(const DpigConvDesc* d, const float* x, const floa
 // (used when a layer cannot take the shadow path: thin layers, <= 32 output columns, C or K not a multiple of 8), w_*_hi / _lo
 // the bf16 planes -- transposed [R,S,K,C] for forward, plain [R,S,C,K] for dgrad.  Results equal dpig_conv2d_fwd / _dgrad
 // with compute = DPIG_COMPUTE_BF16X3 bit for bit (same products, same order).
-extern "C" int dpig_conv2d_fwd_x3(const DpigConvDesc* d, const float* x, const float* w, const uint16_t* w_t_hi,
-                                  const uint16_t* w_t_lo, const float* bias, const float* residual, float* y, float* y_act,
-                                  void* ws, size_t ws_bytes, void* stream) {
+extern "C" int dpig_conv2d_fwd_x3(const DpigConvDesc* d, const float* x, const uint16_t* x32, const float* w,
+                                  const uint16_t* w_t_hi, const uint16_t* w_t_lo, const float* bias, const float* residual,
+                                  float* y, float* y_act, uint16_t* y32, int* y32_written, void* ws, size_t ws_bytes,
+                                  void* stream) {
     const int per = images_per_launch(d, 4);
     if (d && per == 0) return fail(DPIG_EINVAL, "one image exceeds the 2 GiB range of a launch");
-    const SplitShadow sh{w_t_hi, w_t_lo};
+    if (y32_written) *y32_written = 0;
+    SplitShadow sh{w_t_hi, w_t_lo, x32, y32, y32_written};
+    if (d && per < d->N) { sh.a32 = nullptr; sh.out32 = nullptr; sh.wrote = nullptr; }   // (batches served in several runs: no images)
     if (!d || per >= d->N || !x || !y) return conv2d_fwd_one(d, x, w, bias, residual, y, y_act, ws, ws_bytes, stream, nullptr, sh);
     long xpix, ypix;
     image_pixels(d, &xpix, &ypix);
@@ -1956,12 +2110,14 @@ extern "C" int dpig_conv2d_fwd_x3(const DpigConvDesc* d, const float* x, const f
     }
     return DPIG_OK;
 }
-extern "C" int dpig_conv2d_dgrad_x3(const DpigConvDesc* d, const float* dy, const float* w, const uint16_t* w_hi,
-                                    const uint16_t* w_lo, const float* accum, const float* mask, float* dx, void* ws,
-                                    size_t ws_bytes, void* stream) {
+extern "C" int dpig_conv2d_dgrad_x3(const DpigConvDesc* d, const float* dy, const uint16_t* dy32, const float* w,
+                                    const uint16_t* w_hi, const uint16_t* w_lo, const float* accum, const float* mask,
+                                    float* dx, uint16_t* dx32, int* dx32_written, void* ws, size_t ws_bytes, void* stream) {
     const int per = images_per_launch(d, 4);
     if (d && per == 0) return fail(DPIG_EINVAL, "one image exceeds the 2 GiB range of a launch");
-    const SplitShadow sh{w_hi, w_lo};
+    if (dx32_written) *dx32_written = 0;
+    SplitShadow sh{w_hi, w_lo, dy32, dx32, dx32_written};
+    if (d && per < d->N) { sh.a32 = nullptr; sh.out32 = nullptr; sh.wrote = nullptr; }
     if (!d || per >= d->N || !dy || !dx) return conv2d_dgrad_one(d, dy, w, accum, mask, dx, ws, ws_bytes, stream, sh);
     long xpix, ypix;
     image_pixels(d, &xpix, &ypix);
@@ -2077,13 +2233,18 @@ static int conv2d_fwd_one(const DpigConvDesc* d, const float* x, const float* w,
     if (p.nsplit > 1 && ws_bytes < (size_t)p.nsplit * s.M * s.Ncols * sizeof(float))
         return fail(DPIG_ENOMEM, "conv fwd workspace too small: have %zu", ws_bytes);
     if (p.nsplit > 1 && !ws) return fail(DPIG_ENOMEM, "conv fwd needs a workspace");
+    if (sh.out32 && !d->upsample2x && d->K % 32 == 0 && aligned16(sh.out32)) { p.D32 = sh.out32; p.d_nchunk = d->K / 32; }
     if (shadow_usable(d, pipe, d->C, (long)d->R * d->S * d->C * d->K, sh)) {     // transposed shadow [tap][K][C]: the B_ROWK form
         p.Bs_hi = sh.hi;
         p.bs_lo_off = (unsigned)(reinterpret_cast<const char*>(sh.lo) - reinterpret_cast<const char*>(sh.hi));
         p.bs_bytes = p.bs_lo_off + (unsigned)((long)d->R * d->S * d->C * d->K * 2);
-        return launch_gg(p, true, d->N, (long)d->R * d->S * d->C * d->K, static_cast<hipStream_t>(stream), 3);
+        const int pp = split32_usable(p, sh, (long)d->N * d->H * d->W, d->C) ? 4 : 3;
+        rc = launch_gg(p, true, d->N, (long)d->R * d->S * d->C * d->K, static_cast<hipStream_t>(stream), pp);
+    } else {
+        rc = launch_gg(p, false, d->N, (long)d->R * d->S * d->C * d->K, static_cast<hipStream_t>(stream), pipe);
     }
-    return launch_gg(p, false, d->N, (long)d->R * d->S * d->C * d->K, static_cast<hipStream_t>(stream), pipe);
+    if (sh.wrote) *sh.wrote = (rc == DPIG_OK && p.D32) ? 1 : 0;
+    return rc;
 }
 
 static int conv2d_dgrad_one(const DpigConvDesc* d, const float* dy, const float* w, const float* accum,
@@ -2110,6 +2271,7 @@ static int conv2d_dgrad_one(const DpigConvDesc* d, const float* dy, const float*
         p.Bs_hi = sh.hi;
         p.bs_lo_off = (unsigned)(reinterpret_cast<const char*>(sh.lo) - reinterpret_cast<const char*>(sh.hi));
         p.bs_bytes = p.bs_lo_off + (unsigned)((long)d->R * d->S * d->C * d->K * 2);
+        if (split32_usable(p, sh, (long)d->N * Ho * Wo * (d->upsample2x ? 4 : 1), d->K)) pipe = 4;
     }
     p.Hd = d->H; p.Wd = d->W; p.ldd = d->ldx; p.ldres = d->ldres; p.ldmask = d->ldmask;
     p.act = mask ? d->act : DPIG_ACT_NONE; p.alpha = d->alpha; p.replicate = 0;
@@ -2152,7 +2314,11 @@ static int conv2d_dgrad_one(const DpigConvDesc* d, const float* dy, const float*
     p.nsplit = pln.nsplit; p.tiles_per_split = pln.tiles_per_split;
     if (p.nsplit > 1 && (!ws || ws_bytes < (size_t)p.nsplit * p.M * p.Ncols * sizeof(float)))
         return fail(DPIG_ENOMEM, "conv dgrad workspace too small: have %zu", ws_bytes);
-    return launch_gg(p, true, d->N, (long)d->R * d->S * d->C * d->K, st, pipe);
+    // (stride 1 and the upsample fusion only: the stride-2 classes above are separate problems that may split differently)
+    if (sh.out32 && d->C % 32 == 0 && aligned16(sh.out32)) { p.D32 = sh.out32; p.d_nchunk = d->C / 32; }
+    rc = launch_gg(p, true, d->N, (long)d->R * d->S * d->C * d->K, st, pipe);
+    if (sh.wrote) *sh.wrote = (rc == DPIG_OK && p.D32) ? 1 : 0;
+    return rc;
 }
 
 static int conv2d_wgrad_one(const DpigConvDesc* d, const float* x, const float* dy, float* dw, float beta,

@@ -1507,6 +1507,47 @@ extern "C" int dpig_filter_shadow_bf16(const float* w, uint16_t* plain, uint16_t
     hipLaunchKernelGGL(shadow_kernel, grid, dim3(256), 0, static_cast<hipStream_t>(stream), w, plain, transposed, C, K, 0L);
     return check_launch("filter_shadow_bf16");
 }
+// split32 image of an fp32 activation for the split-bf16 k-loop with both operands by DMA (dpig_conv.hip, PIPE 4):
+// out[row][chunk][0..31] = bf16(x), out[row][chunk][32..63] = bf16(x - bf16(x)) for the chunk's 32 channels (zeros past C).
+// One thread per 8 channels: two 16-byte loads, two 16-byte stores.
+__global__ __launch_bounds__(256) void split32_kernel(const float* __restrict__ x, int ldx, long rows, int C, int nchunk,
+                                                      bf16_t* __restrict__ out) {
+    const long total = rows * nchunk * 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long row = i / (nchunk * 4);
+        const int rem = (int)(i - row * (nchunk * 4));
+        const int chunk = rem >> 2, g = rem & 3;
+        const int c0 = chunk * 32 + g * 8;
+        float v[8];
+        if (c0 + 8 <= C) {
+            const float4 a = *reinterpret_cast<const float4*>(x + row * ldx + c0);
+            const float4 b = *reinterpret_cast<const float4*>(x + row * ldx + c0 + 4);
+            v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] = (c0 + e < C) ? x[row * ldx + c0 + e] : 0.f;
+        }
+        unsigned short h[8], l[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { h[e] = bf_hi(v[e]); l[e] = bf_lo(v[e]); }
+        bf16_t* o = out + (row * nchunk + chunk) * 64 + g * 8;
+        *reinterpret_cast<uint4*>(o) = make_uint4(h[0] | ((unsigned)h[1] << 16), h[2] | ((unsigned)h[3] << 16), h[4] | ((unsigned)h[5] << 16), h[6] | ((unsigned)h[7] << 16));
+        *reinterpret_cast<uint4*>(o + 32) = make_uint4(l[0] | ((unsigned)l[1] << 16), l[2] | ((unsigned)l[3] << 16), l[4] | ((unsigned)l[5] << 16), l[6] | ((unsigned)l[7] << 16));
+    }
+}
+extern "C" size_t dpig_split32_bytes(int64_t rows, int C) { return (rows > 0 && C > 0) ? (size_t)rows * ((C + 31) / 32) * 128 : 0; }
+extern "C" int dpig_split32(const float* x, int ldx, int64_t rows, int C, uint16_t* out, void* stream) {
+    if (!x || !out || rows <= 0 || C <= 0 || ldx < C) return fail(DPIG_EINVAL, "split32: bad arguments");
+    if ((ldx % 4) || !aligned16(x) || !aligned16(out) || (C % 4)) return fail(DPIG_EINVAL, "split32: operands must be 16-byte addressable");
+    const int nchunk = (C + 31) / 32;
+    const long total = (long)rows * nchunk * 4;
+    long blocks = (total + 255) / 256;
+    if (blocks > 16 * 256) blocks = 16 * 256;
+    hipLaunchKernelGGL(split32_kernel, dim3((unsigned)blocks), dim3(256), 0, static_cast<hipStream_t>(stream), x, ldx, (long)rows, C,
+                       nchunk, out);
+    return check_launch("split32");
+}
+
 // Split shadows for DPIG_COMPUTE_BF16X3 (dpig_conv2d_fwd_x3 / _dgrad_x3): hi planes at `plain_hi` / `trans_hi`, the lo planes
 // lo_off ELEMENTS behind each (one allocation per layout, so that one buffer descriptor spans both planes).
 extern "C" int dpig_filter_shadow_split(const float* w, uint16_t* plain_hi, uint16_t* trans_hi, int64_t lo_off, int taps, int C,

@@ -17,6 +17,7 @@ Arithmetic modes (`set_compute`):
            mode, held to the exact path's kernel bar (2e-5 max|ref|); 'f32' stays the exact-products default.
 """
 import ctypes
+import os
 
 import torch
 
@@ -305,8 +306,12 @@ def conv_out_hw(H, W, R, S, stride, upsample2x=False):
     return _lib.same_pad(H, R, stride)[0], _lib.same_pad(W, S, stride)[0]
 
 
+X3_EMIT = [int(os.environ.get('DPIG_X3_EMIT', '1'))]    # 0: never let an epilogue leave its output's split32 image; 1: where the
+                                                          # caller says the output feeds another conv (`emit32`); 2: always
+
+
 def conv2d_fwd(x, w, bias=None, stride=1, act=ACT_NONE, alpha=0.2, residual=None, out=None, upsample2x=False,
-               split_k=0, res_after_act=False, out_act=None, res_class=False):
+               split_k=0, res_after_act=False, out_act=None, res_class=False, emit32=False):
     """y = act(conv_SAME(x, w) + bias + residual) (or act(..) + residual with res_after_act);
     x NHWC, w HWIO.  `out` may be a channel slice.  `out_act` optionally receives the activation
     output before a post-activation residual add."""
@@ -350,12 +355,59 @@ def conv2d_fwd(x, w, bias=None, stride=1, act=ACT_NONE, alpha=0.2, residual=None
                 (N, H, W, C, K, R, stride, int(upsample2x))):
         sh = getattr(w, "_dpig_shadow_x3", None) if _COMPUTE[0] == COMPUTE_BF16X3 else None
         if sh is not None:           # the filter's two bf16 terms are kept ready (FilterShadows(split=True))
-            check(lib().dpig_conv2d_fwd_x3(ctypes.byref(d), ptr(x), ptr(w), ptr(sh[1]), ptr(sh[3]), ptr(bias), ptr(residual),
-                                           ptr(out), ptr(out_act), ptr(wsb), wsn, stream_ptr()), "conv2d_fwd_x3")
+            x32 = split32(x, R * S * ((K + 127) // 128)) if mfma else None
+            y32, wrote = _image_room(N, Ho, Wo, K, x.device) if (mfma and not upsample2x and X3_EMIT[0] > (0 if emit32 else 1)) else (None, None)
+            check(lib().dpig_conv2d_fwd_x3(ctypes.byref(d), ptr(x), ptr(x32), ptr(w), ptr(sh[1]), ptr(sh[3]), ptr(bias),
+                                           ptr(residual), ptr(out), ptr(out_act), ptr(y32),
+                                           ctypes.byref(wrote) if wrote is not None else None, ptr(wsb), wsn, stream_ptr()),
+                  "conv2d_fwd_x3")
+            if wrote is not None and wrote.value:
+                out._dpig_s32 = y32        # the epilogue left the output's split32 image: the next conv of the chain DMAs it
         else:
             check(lib().dpig_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(out),
                                         ptr(out_act), ptr(wsb), wsn, stream_ptr()), "conv2d_fwd")
     return out
+
+
+# 'bf16x3' mode: also give the forward / dgrad kernels the ACTIVATION's two-term split as a ready image (both operands by DMA,
+# PIPE 4).  Measured: the kernels gain 17 % (335 -> 395-405 effective TFLOP/s) but every image costs a pass over its tensor
+# (dpig_split32) or wider epilogue stores (emission), and with ONE consumer per image the step comes out even (-1.8 ... +1.4 %
+# same-box A/B).  Off by default until wgrad consumes the same images; DPIG_X3_PLANES=1 turns it on.
+X3_PLANES = [os.environ.get('DPIG_X3_PLANES', '0') != '0']
+
+
+def split32(t, reuse=1):
+    """The two-term bf16 split of an fp32 NHWC activation in the layout the DMA-fed split k-loop reads
+    ([N,H,W,chunks,64]: 32 hi | 32 lo per 32-channel chunk; dpig_split32), made once per tensor and kept on it
+    (`_dpig_s32`: the forward input is needed again by wgrad-side consumers, dy by dgrad).  Returns None when it would not pay:
+    the image costs a read and a write of the tensor, so a consumer that gathers each element fewer than 4 times
+    (`reuse` = taps x column tiles) splits it in its k-loop instead -- unless the image already exists."""
+    if not X3_PLANES[0] or t.dtype != torch.float32:
+        return None
+    s32 = getattr(t, "_dpig_s32", None)
+    if s32 is not None:
+        return s32
+    ld = nhwc_ld(t)
+    N, Hh, W, C = t.shape
+    if reuse < 4 or ld is None or C % 4 or ld % 4 or t.data_ptr() % 16:
+        return None
+    nchunk = (C + 31) // 32
+    if N * Hh * W * nchunk * 128 >= 2 ** 31 - 1:
+        return None
+    s32 = torch.empty((N, Hh, W, nchunk, 64), dtype=BF16, device=t.device)
+    check(lib().dpig_split32(ptr(t), ld, N * Hh * W, C, ptr(s32), stream_ptr()), "split32")
+    try:
+        t._dpig_s32 = s32
+    except Exception:
+        pass
+    return s32
+
+
+def _image_room(N, Hh, W, C, device):
+    """Room for a conv output's split32 image (written by the epilogue when the launch allows it) + the flag that says so."""
+    if not X3_PLANES[0] or C % 32 or N * Hh * W * (C // 32) * 128 >= 2 ** 31 - 1:
+        return None, None
+    return torch.empty((N, Hh, W, C // 32, 64), dtype=BF16, device=device), ctypes.c_int(0)
 
 
 def conv2d_fwd_stats(x, w, bias=None, stride=1, split_k=0):
@@ -387,7 +439,7 @@ def conv2d_fwd_stats(x, w, bias=None, stride=1, split_k=0):
 
 
 def conv2d_dgrad(dy, w, in_shape, stride=1, accum=None, mask=None, act=ACT_NONE, alpha=0.2, out=None,
-                 upsample2x=False, split_k=0):
+                 upsample2x=False, split_k=0, emit32=False):
     """dx = (conv_backward_data(dy, w) + accum) * act'(mask);  in_shape = (N,H,W,C) of the fwd input."""
     if _STORE_BF16[0] or dy.dtype == BF16:
         return _conv2d_dgrad_bf16(dy, w, in_shape, stride, accum, mask, act, alpha, out, upsample2x, split_k)
@@ -419,8 +471,14 @@ def conv2d_dgrad(dy, w, in_shape, stride=1, accum=None, mask=None, act=ACT_NONE,
                 2.0 * N * H * W // (stride * stride) * K * R * S * C, (N, H, W, C, K, R, stride, int(upsample2x))):
         sh = getattr(w, "_dpig_shadow_x3", None) if _COMPUTE[0] == COMPUTE_BF16X3 else None
         if sh is not None:
-            check(lib().dpig_conv2d_dgrad_x3(ctypes.byref(d), ptr(dy), ptr(w), ptr(sh[0]), ptr(sh[2]), ptr(accum), ptr(mask),
-                                             ptr(out), ptr(wsb), wsn, stream_ptr()), "conv2d_dgrad_x3")
+            taps_hit = 4 if upsample2x else (R * S if stride == 1 else max(1, R * S // (stride * stride)))
+            dy32 = split32(dy, taps_hit * ((C + 127) // 128)) if mfma else None
+            dx32, wrote = _image_room(N, H, W, C, dy.device) if (mfma and stride == 1 and X3_EMIT[0] > (0 if emit32 else 1)) else (None, None)
+            check(lib().dpig_conv2d_dgrad_x3(ctypes.byref(d), ptr(dy), ptr(dy32), ptr(w), ptr(sh[0]), ptr(sh[2]), ptr(accum),
+                                             ptr(mask), ptr(out), ptr(dx32), ctypes.byref(wrote) if wrote is not None else None,
+                                             ptr(wsb), wsn, stream_ptr()), "conv2d_dgrad_x3")
+            if wrote is not None and wrote.value:
+                out._dpig_s32 = dx32
         else:
             check(lib().dpig_conv2d_dgrad(ctypes.byref(d), ptr(dy), ptr(w), ptr(accum), ptr(mask), ptr(out), ptr(wsb),
                                           wsn, stream_ptr()), "conv2d_dgrad")

@@ -51,7 +51,7 @@ extern "C" {
 #define DPIG_ACT_RELU 1
 #define DPIG_ACT_LRELU 2
 
-#define DPIG_VERSION 220
+#define DPIG_VERSION 240
 
 /* Convolution problem, always described from the FORWARD op's point of view. */
 typedef struct DpigConvDesc {
@@ -192,11 +192,20 @@ int dpig_filter_shadow_split(const float* w, uint16_t* plain_hi, uint16_t* trans
                              void* stream);
 int dpig_filter_shadow_split_multi(const float* base, uint16_t* plain_base, uint16_t* trans_base, int64_t lo_off,
                                    const int64_t* table_dev, int ntensors, int total_tiles, void* stream);
-int dpig_conv2d_fwd_x3(const DpigConvDesc* d, const float* x, const float* w, const uint16_t* w_t_hi, const uint16_t* w_t_lo,
-                       const float* bias, const float* residual, float* y, float* y_act, void* ws, size_t ws_bytes,
-                       void* stream);
-int dpig_conv2d_dgrad_x3(const DpigConvDesc* d, const float* dy, const float* w, const uint16_t* w_hi, const uint16_t* w_lo,
-                         const float* accum, const float* mask, float* dx, void* ws, size_t ws_bytes, void* stream);
+int dpig_conv2d_fwd_x3(const DpigConvDesc* d, const float* x, const uint16_t* x32, const float* w, const uint16_t* w_t_hi,
+                       const uint16_t* w_t_lo, const float* bias, const float* residual, float* y, float* y_act,
+                       uint16_t* y32, int* y32_written, void* ws, size_t ws_bytes, void* stream);
+int dpig_conv2d_dgrad_x3(const DpigConvDesc* d, const float* dy, const uint16_t* dy32, const float* w, const uint16_t* w_hi,
+                         const uint16_t* w_lo, const float* accum, const float* mask, float* dx, uint16_t* dx32,
+                         int* dx32_written, void* ws, size_t ws_bytes, void* stream);
+/* x32 / dy32 (optional, may be null): the gathered activation's own two-term split, written once per tensor by dpig_split32 as
+ * [pixel][32-channel chunk][32 hi | 32 lo] bf16 (dpig_split32_bytes(rows, C) bytes, rows = N*H*W of that tensor, contiguous).
+ * With it BOTH operands reach LDS by DMA and no operand passes through registers; results stay bit-identical.
+ * y32 / dx32 (optional): room for the OUTPUT's split32 image; the float4 epilogue of an un-split launch writes it beside the
+ * fp32 output (no second pass over it) and sets *written = 1 -- the next conv of the chain takes it as its x32 / dy32;
+ * *written = 0 (split-K plan, thin layer, channel count not a multiple of 32, stride-2 dgrad): make it with dpig_split32. */
+size_t dpig_split32_bytes(int64_t rows, int C);
+int dpig_split32(const float* x, int ldx, int64_t rows, int C, uint16_t* out, void* stream);
 
 /* ---- elementwise / reductions over a [rows, cols] fp32 matrix with row stride ld ------------- */
 

@@ -63,13 +63,15 @@ for (tag, N, Hh, W, C, K, k, s) in (LAYERS[:4] + LAYERS[9:11] if quick else LAYE
     if "--x3" in sys.argv:                   # fp32 tensors: exact fp32 pipe next to the split-bf16 pipe (effective TF/s)
         if hasattr(w, "_dpig_shadow"): del w._dpig_shadow
         dy32 = dy.float()
-        for mode in ("f32", "bf16x3", "bf16x3+shadows"):
+        for mode in ("f32", "bf16x3", "bf16x3+shadows", "bf16x3+shadows+planes"):
             H.set_compute(mode.split("+")[0])
             shx = H.FilterShadows([w], split=True) if "+" in mode else None      # persistent two-term shadows, as in a trainer
+            H.X3_PLANES[0] = mode.endswith("planes")      # + the activation's split32 image (made once, outside the timed calls)
             tf = timeit(lambda: H.conv2d_fwd(x, w, b, stride=s, act=1, upsample2x=up)); td = timeit(lambda: H.conv2d_dgrad(dy32, w, (N, Hh, W, C), stride=s, upsample2x=up))
             tw = timeit(lambda: H.conv2d_wgrad(x, dy32, (k, k, C, K), stride=s, upsample2x=up, out=dw))
             line += "  || %s fwd %6.1f dgrad %6.1f wgrad %6.1f TF" % (mode, fl / tf / 1e12, fl / td / 1e12, fl / tw / 1e12)
             if shx is not None: shx.detach()
+        H.X3_PLANES[0] = False
         H.set_compute("f32")
     print(line, flush=True)
     del x, xb, y, dy, w, dw

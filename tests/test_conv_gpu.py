@@ -430,6 +430,8 @@ def test_conv_split_bf16_filter_shadows(dev, shape):
     w = (_rand((k, k, C, K), 2) * 0.2).float().to(dev)
     b = _rand((K,), 3).float().to(dev)
     H.set_compute("bf16x3")
+    planes_default, emit_default = H.X3_PLANES[0], H.X3_EMIT[0]
+    H.X3_EMIT[0] = 2                                            # let every eligible epilogue leave its output's image
     try:
         for sk in (0, 3):
             y0 = H.conv2d_fwd(x, w, b, stride=s, act=2, alpha=0.2, split_k=sk)
@@ -442,11 +444,29 @@ def test_conv_split_bf16_filter_shadows(dev, shape):
                 hi, lo = w._dpig_shadow_x3[0].float(), w._dpig_shadow_x3[2].float()
                 assert torch.equal(hi, w.bfloat16().float()) and torch.equal(lo, (w - hi).bfloat16().float())
                 assert torch.equal(w._dpig_shadow_x3[1].float(), hi.permute(0, 1, 3, 2)) and torch.equal(w._dpig_shadow_x3[3].float(), lo.permute(0, 1, 3, 2))
-            y1 = H.conv2d_fwd(x, w, b, stride=s, act=2, alpha=0.2, split_k=sk)
-            dx1 = H.conv2d_dgrad(dy, w, (N, Hh, W, C), stride=s, split_k=sk)
+            for planes in (False, True):                        # filter shadows alone; + the activation's split32 image (both by DMA)
+                H.X3_PLANES[0] = planes
+                for t in (x, dy):
+                    if hasattr(t, "_dpig_s32"):
+                        del t._dpig_s32
+                y1 = H.conv2d_fwd(x, w, b, stride=s, act=2, alpha=0.2, split_k=sk)
+                dx1 = H.conv2d_dgrad(dy, w, (N, Hh, W, C), stride=s, split_k=sk)
+                if planes and not (C % 8 or K % 8) and k > 1:
+                    assert hasattr(x, "_dpig_s32")              # the image was made (and is kept for the tensor's next consumer)
+                    s32 = x._dpig_s32.float()
+                    xp = torch.nn.functional.pad(x, (0, s32.shape[3] * 32 - C)).reshape(N, Hh, W, -1, 32)
+                    assert torch.equal(s32[..., :32], xp.bfloat16().float()) and torch.equal(s32[..., 32:], (xp - s32[..., :32]).bfloat16().float())
+                assert torch.equal(y1, y0) and torch.equal(dx1, dx0), (sk, planes, float((y1 - y0).abs().max()), float((dx1 - dx0).abs().max()))
+                for t in (y1, dx1):                            # an image the epilogue left equals the one dpig_split32 makes
+                    img = getattr(t, "_dpig_s32", None)
+                    if img is not None:
+                        assert planes
+                        del t._dpig_s32
+                        assert torch.equal(H.split32(t, 99), img)
+            H.X3_PLANES[0] = planes_default
             sh.detach()
-            assert torch.equal(y1, y0) and torch.equal(dx1, dx0), (sk, float((y1 - y0).abs().max()), float((dx1 - dx0).abs().max()))
     finally:
+        H.X3_PLANES[0], H.X3_EMIT[0] = planes_default, emit_default
         H.set_compute("f32")
 
 
@@ -568,8 +588,8 @@ def test_round2_entry_points_refuse_bad_arguments(dev):
         d2 = H._desc(1, 8, 8, 64, 64, 3, 3, 1, 64, 64)
         ref = H.conv2d_fwd(x, w)
         ws, wn = H._ws(d2, 0, dev)
-        assert lib().dpig_conv2d_fwd_x3(ctypes.byref(d2), ptr(x), ptr(w), None, None, None, None, ptr(y), None, ptr(ws), wn,
-                                        stream_ptr()) == 0
+        assert lib().dpig_conv2d_fwd_x3(ctypes.byref(d2), ptr(x), None, ptr(w), None, None, None, None, ptr(y), None, None, None,
+                                        ptr(ws), wn, stream_ptr()) == 0
         assert torch.equal(y, ref)
     finally:
         H.set_compute("f32")
