@@ -2188,6 +2188,24 @@ extern "C" int dpig_conv2d_wgrad(const DpigConvDesc* d, const float* x, const fl
     return DPIG_OK;
 }
 
+// DPIG_COMPUTE_BF16X3 filter gradient from the split32 images of x and dy (dpig_split32, or left by the producing epilogues):
+// both operands by LDS-DMA, transposed on their way out of LDS (bw3_kernel, dpig_conv_bf16.hip).  dw is bit-identical to
+// dpig_conv2d_wgrad's; db sums dy to its 16 split bits instead of the fp32 values.  Null images, or a layer the kernel does
+// not serve (thin layers, <= 32 output channels, a batch served in several runs), run dpig_conv2d_wgrad on x / dy.
+extern "C" int dpig_conv2d_wgrad_x3(const DpigConvDesc* d, const float* x, const uint16_t* x32, const float* dy,
+                                    const uint16_t* dy32, float* dw, float beta, float* db, float beta_b, void* ws,
+                                    size_t ws_bytes, void* stream) {
+    if (d && x32 && dy32 && dw && d->compute == DPIG_COMPUTE_BF16X3 && images_per_launch(d, 4) >= d->N) {
+        int pt, pl, Ho, Wo;
+        int rc = resolve_desc(d, &pt, &pl, &Ho, &Wo);
+        if (rc) return rc;
+        rc = wgrad_x3_try(d, pt, pl, Ho, Wo, x32, dy32, dw, beta, db, beta_b, ws, ws_bytes, static_cast<hipStream_t>(stream),
+                          split_pen(d));
+        if (rc != 0) return rc < 0 ? rc : DPIG_OK;
+    }
+    return dpig_conv2d_wgrad(d, x, dy, dw, beta, db, beta_b, ws, ws_bytes, stream);
+}
+
 static int conv2d_fwd_one(const DpigConvDesc* d, const float* x, const float* w, const float* bias,
                           const float* residual, float* y, float* y_act, void* ws, size_t ws_bytes,
                           void* stream, float* stats, SplitShadow sh) {

@@ -896,6 +896,243 @@ __global__ __launch_bounds__(256, 2) void bw_kernel(const BWParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Split-bf16 filter gradient with BOTH operands from their split32 images (dpig_split32: [pixel][32-channel chunk][32 hi |
+// 32 lo]) -- DPIG_COMPUTE_BF16X3's wgrad without the register path.  x and dy are the images the forward / dgrad launches of
+// the same layer already consumed, so this kernel adds no pass over the tensors.  Structure = bw_kernel (LDS-DMA tiles as
+// they lie in memory, pixel-major; ds_read_b64_tr_b16 hands each lane 4 consecutive pixels of its channel) with three MFMAs
+// per fragment pair in the order of the in-loop split (x_hi dy_lo + x_lo dy_hi + x_hi dy_hi per 16-pixel step) and the same
+// k-tile (32 pixels): the filter gradient is bit-identical to wgrad_kernel<..., PIPE 2>'s.  The bias gradient is ones x
+// (dy_hi + dy_lo) on the matrix pipe (dy to 16 significand bits; the register path sums the fp32 dy).
+// A pixel of an operand tile is 512 B = 4 chunks x [32 hi | 32 lo]; granule (16 B) g of pixel r is kept at g ^ swz(r & 3),
+// swz = ((r & 1) << 1) | ((r & 2) << 2): the four pixels a transposed read touches then hit four different 32-byte windows.
+struct BW3Params {
+    const bf16_t* X32; const bf16_t* DY32; float* DW; float* partial;
+    int Npix, Ho, Wo, HoWo;
+    int H, W, C, K, shift, s, nchx, nchy;
+    int ntaps, cblocks, ntiles;
+    int ktiles, tiles_per_split, nsplit, wrows;
+    float beta;
+    int S, pad_t, pad_l;
+    unsigned x_bytes, y_bytes;
+    unsigned mul_howo, shr_howo, mul_wo, shr_wo;
+    float* DB; float* bias_partial; float beta_b;
+    int d32_oy, d32_ox, d32_n;
+};
+constexpr int W3_TK = 32;
+constexpr int W3_PIX_B = 512;
+constexpr int W3_TILE_B = W3_TK * W3_PIX_B;      // 16 KB
+constexpr int W3_STAGE_B = 2 * W3_TILE_B;
+constexpr int W3_SMEM = 2 * W3_STAGE_B;          // 64 KB = the [128][128] fp32 staging of the epilogue
+
+template <bool S1>
+__global__ __launch_bounds__(256, 2) void bw3_kernel(const BW3Params p) {
+    __shared__ __attribute__((aligned(16))) char smem[W3_SMEM];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wrow = (wave >> 1) * 64, wcol = (wave & 1) * 64;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    const int mtiles = p.ntaps * p.cblocks;
+    const int ntl = mtiles * p.ntiles;
+    const int item = xcd_remap((int)(blockIdx.x + gridDim.x * blockIdx.z), ntl * (int)gridDim.z);
+    const int split = item / ntl;
+    const int tile = item - split * ntl;
+    const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+    const int tap = mt / p.cblocks;
+    const int ci0 = (mt - tap * p.cblocks) * TM;
+    const int co0 = nt * TN;
+    const int oyoff = tap / p.S - p.pad_t, oxoff = tap % p.S - p.pad_l;
+    const int kt_begin = split * p.tiles_per_split;
+    const int kt_end = min(p.ktiles, kt_begin + p.tiles_per_split);
+    const bool do_bias = (p.DB != nullptr) && (mt == 0);
+
+    f32x16 acc[2][2];
+    f32x16 accb[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        acc[0][0][r] = 0.f; acc[0][1][r] = 0.f; acc[1][0][r] = 0.f; acc[1][1][r] = 0.f;
+        accb[0][r] = 0.f; accb[1][r] = 0.f;
+    }
+    const int xrow = p.nchx * 128, yrow = p.nchy * 128;        // bytes per pixel of the images
+    const int padpix = S1 ? p.pad_t * p.W + p.pad_l : 0;
+    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.X32 - (long)padpix * (xrow / 2), p.x_bytes + (unsigned)(padpix * xrow));
+    const __amdgpu_buffer_rsrc_t rsY = make_rsrc(p.DY32, p.y_bytes);
+
+    // ---- DMA roles: piece 4 wave + j = tile pixels 2 piece, 2 piece + 1 (1 KB); lane -> (pixel, physical granule) ----
+    const int pp = lane >> 5, pgn = lane & 31;
+    int s_oy[4], s_ox[4], s_n[4], y_voff[4], x_voff[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (4 * wave + j) * 2 + pp;
+        const int lg = pgn ^ (((r & 1) << 1) | ((r & 2) << 2));            // the logical granule this lane fetches
+        const bool cx_ok = (ci0 >> 5) + (lg >> 3) < p.nchx, cy_ok = (co0 >> 5) + (lg >> 3) < p.nchy;
+        const int m = kt_begin * W3_TK + r;
+        const int n = fast_div(m, p.mul_howo, p.shr_howo);
+        const int rem = m - n * p.HoWo;
+        s_n[j] = n;
+        s_oy[j] = fast_div(rem, p.mul_wo, p.shr_wo);
+        s_ox[j] = rem - s_oy[j] * p.Wo;
+        y_voff[j] = cy_ok ? r * yrow + (co0 >> 5) * 128 + lg * 16 : (int)OOB;
+        x_voff[j] = cx_ok ? (S1 ? r * xrow : 0) + (ci0 >> 5) * 128 + lg * 16 : (int)OOB;
+    }
+    auto issue = [&](int kt, int stage) {
+        char* dst = smem + stage * W3_STAGE_B + (4 * wave) * 1024;
+        const int left = p.Npix - kt * W3_TK;
+        const int sy = kt * W3_TK * yrow;
+        const int sx = S1 ? (kt * W3_TK + oyoff * p.W + oxoff + padpix) * xrow : 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = (4 * wave + j) * 2 + pp;
+            if (S1) {
+                const bool ok = (r < left) & ((unsigned)(s_oy[j] + oyoff) < (unsigned)p.H) & ((unsigned)(s_ox[j] + oxoff) < (unsigned)p.W);
+                dma16(rsX, ok ? x_voff[j] : (int)OOB, sx, dst + j * 1024);
+            } else {
+                const int py = s_oy[j] * p.s + oyoff, px = s_ox[j] * p.s + oxoff;
+                const int iy = py >> p.shift, ix = px >> p.shift;
+                const bool ok = (r < left) & (x_voff[j] != (int)OOB) & (py >= 0) & (px >= 0) & (iy < p.H) & (ix < p.W);
+                const int xo = ((s_n[j] * p.H + iy) * p.W + ix) * xrow + x_voff[j];
+                dma16(rsX, ok ? xo : (int)OOB, 0, dst + j * 1024);
+            }
+            dma16(rsY, (r < left) ? y_voff[j] : (int)OOB, sy, dst + W3_TILE_B + j * 1024);
+            s_ox[j] += p.d32_ox;                              // advance this row's pixel by one k-tile (32 pixels)
+            const bool c1 = s_ox[j] >= p.Wo;
+            s_ox[j] -= c1 ? p.Wo : 0;
+            s_oy[j] += p.d32_oy + (c1 ? 1 : 0);
+            const bool c2 = s_oy[j] >= p.Ho;
+            s_oy[j] -= c2 ? p.Ho : 0;
+            if (!S1) s_n[j] += p.d32_n + (c2 ? 1 : 0);
+        }
+    };
+
+    // ---- transposed fragment reads (see bw_kernel): lane q of a 16-lane group supplies the 8-byte address of pixel q / 4,
+    // channels 4 (q % 4) .. +3 of the group's 16 channels and receives the 4 pixels of channel q --------------------------
+    const int q = lane & 15;
+    const int cgrp = (lane >> 4) & 1;
+    const int pq = q >> 2;
+    const int swz = ((pq & 1) << 1) | ((pq & 2) << 2);
+    const char* pa[2][2];                    // [32-channel block = chunk][hi / lo]
+    const char* pb[2][2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int ga = ((wrow >> 5) + b) * 8 + h * 4 + cgrp * 2 + ((q & 3) >> 1);
+            const int gb = ((wcol >> 5) + b) * 8 + h * 4 + cgrp * 2 + ((q & 3) >> 1);
+            pa[b][h] = smem + (half * 8 + pq) * W3_PIX_B + ((ga ^ swz) * 16) + (q & 1) * 8;
+            pb[b][h] = smem + W3_TILE_B + (half * 8 + pq) * W3_PIX_B + ((gb ^ swz) * 16) + (q & 1) * 8;
+        }
+    auto tr_read = [&](const char* a) -> s16x4 {
+        return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a);
+    };
+    typedef short s16x8 __attribute__((ext_vector_type(8)));
+    auto frag = [&](const char* a) -> bf16x8 {
+        const s16x4 v0 = tr_read(a), v1 = tr_read(a + 4 * W3_PIX_B);
+        const s16x8 v = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+        return __builtin_bit_cast(bf16x8, v);
+    };
+    // One k-tile: all 32 transposed reads first, the DMA of the next tile behind them (hipcc puts a vmcnt(0) in front of the
+    // first tr read that follows a DMA), then the 24 MFMAs.
+    auto ktile = [&](int kt, int stage, bool more) {
+        bf16x8 ah[2][2], al[2][2], bh[2][2], bl[2][2];         // [k-step][block]
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int o = stage * W3_STAGE_B + ks * 16 * W3_PIX_B;
+                ah[ks][b] = frag(pa[b][0] + o); al[ks][b] = frag(pa[b][1] + o);
+                bh[ks][b] = frag(pb[b][0] + o); bl[ks][b] = frag(pb[b][1] + o);
+            }
+        __builtin_amdgcn_sched_barrier(0);
+        if (more) issue(kt + 1, stage ^ 1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][mb], bl[ks][nb], acc[mb][nb], 0, 0, 0);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[ks][mb], bh[ks][nb], acc[mb][nb], 0, 0, 0);
+#pragma unroll
+            for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[ks][mb], bh[ks][nb], acc[mb][nb], 0, 0, 0);
+            if (do_bias) {                                     // workgroup-uniform
+                const s16x8 one8 = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
+                const bf16x8 ones = __builtin_bit_cast(bf16x8, one8);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    accb[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bl[ks][nb], accb[nb], 0, 0, 0);
+                    accb[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, bh[ks][nb], accb[nb], 0, 0, 0);
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+
+    if (kt_begin < kt_end) {
+        issue(kt_begin, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int kt = kt_begin;
+        for (; kt + 1 < kt_end; kt += 2) {
+            ktile(kt, 0, true);
+            ktile(kt + 1, 1, kt + 2 < kt_end);
+        }
+        if (kt < kt_end) ktile(kt, 0, false);
+    }
+
+    // ---- epilogue (as bw_kernel) ------------------------------------------------------------------------------------
+    const long wsize = (long)p.wrows * p.K;
+    float* Cs = reinterpret_cast<float*>(smem);
+    if (do_bias && wrow == 0 && half == 0) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            const int co = co0 + wcol + nb * 32 + l31;
+            if (co < p.K) {
+                const float v = accb[nb][0];
+                if (p.nsplit > 1) p.bias_partial[(long)split * p.K + co] = v;
+                else p.DB[co] = (p.beta_b != 0.f) ? p.beta_b * p.DB[co] + v : v;
+            }
+        }
+    }
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+                Cs[(wrow + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * TN + wcol + nb * 32 + l31] = acc[mb][nb][r];
+    __syncthreads();
+    float* dst = (p.nsplit > 1) ? p.partial + (long)split * wsize : p.DW;
+    const float beta = (p.nsplit > 1) ? 0.f : p.beta;
+    const int c = (tid & 31) * 4;
+    const int co = co0 + c;
+    if (co < p.K) {
+#pragma unroll 4
+        for (int it = 0; it < 16; ++it) {
+            const int rl = (tid >> 5) + 8 * it;
+            const int ci = ci0 + rl;
+            if (ci >= p.C) continue;
+            float4 v = *reinterpret_cast<const float4*>(&Cs[rl * TN + c]);
+            float4* o = reinterpret_cast<float4*>(dst + ((long)tap * p.C + ci) * p.K + co);
+            if (beta != 0.f) {
+                const float4 old = *o;
+                v.x += beta * old.x; v.y += beta * old.y; v.z += beta * old.z; v.w += beta * old.w;
+            }
+            *o = v;
+        }
+    }
+}
+
 // out[i] = beta*out[i] + sum_s partial[s][i]; the last block folds the bias-gradient partials
 __global__ __launch_bounds__(256) void bw_splitk_sum_kernel(const float* __restrict__ partial, float* __restrict__ out,
                                                              long n4, int nsplit, float beta,
@@ -1547,6 +1784,68 @@ extern "C" int dpig_split32(const float* x, int ldx, int64_t rows, int C, uint16
                        nchunk, out);
     return check_launch("split32");
 }
+
+// Host side of bw3_kernel for dpig_conv2d_wgrad_x3 (dpig_conv.hip): 1 = launched, 0 = not this layer's case (the caller runs
+// the register-path kernel on the fp32 tensors), < 0 = error.  The split-K plan is the fp32 kernel's (k-tile 32, `pen`).
+namespace dpig {
+int wgrad_x3_try(const DpigConvDesc* d, int pt, int pl, int Ho, int Wo, const uint16_t* x32, const uint16_t* dy32, float* dw,
+                 float beta, float* db, float beta_b, void* ws, size_t ws_bytes, hipStream_t st, double pen) {
+    using namespace bfk;
+    if (!x32 || !dy32 || d->C < 32 || d->K <= 32 || d->C % 4 || d->K % 4) return 0;
+    if (!aligned16(x32) || !aligned16(dy32) || !aligned16(dw) || (ws && !aligned16(ws))) return 0;
+    BW3Params p = {};
+    p.X32 = x32; p.DY32 = dy32; p.DW = dw; p.partial = static_cast<float*>(ws);
+    p.H = d->H; p.W = d->W; p.C = d->C; p.K = d->K; p.nchx = cdiv(d->C, 32); p.nchy = cdiv(d->K, 32);
+    p.beta = beta;
+    if (d->upsample2x) {
+        p.Ho = 2 * d->H; p.Wo = 2 * d->W; p.shift = 1; p.s = 1;
+        p.ntaps = 1; p.S = 1; p.pad_t = 0; p.pad_l = 0;
+    } else {
+        p.Ho = Ho; p.Wo = Wo; p.shift = 0; p.s = d->stride;
+        p.ntaps = d->R * d->S; p.S = d->S; p.pad_t = pt; p.pad_l = pl;
+    }
+    p.HoWo = p.Ho * p.Wo;
+    p.Npix = d->N * p.HoWo;
+    const long xb = (long)d->N * d->H * d->W * p.nchx * 128, yb = (long)p.Npix * p.nchy * 128;
+    const long padb = (long)(pt > 0 ? pt : 0) * d->W * p.nchx * 128 + (long)(pl > 0 ? pl : 0) * p.nchx * 128;
+    if (xb + padb >= 0x7fffffffL || yb >= 0x7fffffffL) return 0;
+    p.x_bytes = (unsigned)xb; p.y_bytes = (unsigned)yb;
+    find_divisor(p.HoWo, &p.mul_howo, &p.shr_howo);
+    find_divisor(p.Wo, &p.mul_wo, &p.shr_wo);
+    p.wrows = d->R * d->S * d->C;
+    p.cblocks = cdiv(d->C, TM);
+    p.ntiles = cdiv(d->K, TN);
+    p.ktiles = cdiv(p.Npix, W3_TK);
+    const int tiles = p.ntaps * p.cblocks * p.ntiles;
+    Plan pln = plan_split(tiles, p.ktiles, d->split_k, 32, pen);
+    p.nsplit = pln.nsplit; p.tiles_per_split = pln.tiles_per_split;
+    const long wsize = (long)p.wrows * d->K;
+    if (p.nsplit > 1 && (!ws || ws_bytes < (size_t)p.nsplit * (wsize + d->K) * sizeof(float)))
+        return fail(DPIG_ENOMEM, "conv wgrad workspace too small: have %zu", ws_bytes);
+    if (p.nsplit > 1 && (wsize % 4)) return 0;
+    p.DB = db; p.beta_b = beta_b;
+    p.bias_partial = p.partial ? p.partial + (long)p.nsplit * wsize : nullptr;
+    p.d32_n = W3_TK / p.HoWo;
+    p.d32_oy = (W3_TK % p.HoWo) / p.Wo;
+    p.d32_ox = (W3_TK % p.HoWo) % p.Wo;
+    dim3 grid(tiles, 1, p.nsplit), block(256);
+    const bool s1 = !d->upsample2x && d->stride == 1 && Ho == d->H && Wo == d->W && pt >= 0 && pl >= 0;
+    if (s1) hipLaunchKernelGGL((bw3_kernel<true>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((bw3_kernel<false>), grid, block, 0, st, p);
+    int rc = check_launch("bw3_kernel");
+    if (rc) return rc;
+    if (p.nsplit > 1) {
+        const long n4 = wsize / 4;
+        int blocks = cdiv(n4, 256);
+        if (blocks > 8 * kNumCU) blocks = 8 * kNumCU;
+        hipLaunchKernelGGL(bw_splitk_sum_kernel, dim3(blocks), dim3(256), 0, st, p.partial, dw, n4, p.nsplit, beta,
+                           p.bias_partial, db, d->K, beta_b);
+        rc = check_launch("bw_splitk_sum_kernel");
+        if (rc) return rc;
+    }
+    return 1;
+}
+}  // namespace dpig
 
 // Split shadows for DPIG_COMPUTE_BF16X3 (dpig_conv2d_fwd_x3 / _dgrad_x3): hi planes at `plain_hi` / `trans_hi`, the lo planes
 // lo_off ELEMENTS behind each (one allocation per layout, so that one buffer descriptor spans both planes).

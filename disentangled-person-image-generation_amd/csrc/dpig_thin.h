@@ -26,4 +26,7 @@ int fewc_wgrad_try(const DpigConvDesc* d, int pt, int pl, int Ho, int Wo, const 
                    bool wide_bf16 = false);
 int fewc_dgrad_try(const DpigConvDesc* d, int pt, int pl, int Ho, int Wo, const void* dy, const float* w,
                    const float* accum, const float* mask, float* dx, hipStream_t st, bool wide_bf16 = false);
+// dpig_conv_bf16.hip: split-bf16 filter gradient from the split32 images of x and dy (both operands by LDS-DMA)
+int wgrad_x3_try(const DpigConvDesc* d, int pt, int pl, int Ho, int Wo, const uint16_t* x32, const uint16_t* dy32, float* dw,
+                 float beta, float* db, float beta_b, void* ws, size_t ws_bytes, hipStream_t st, double pen);
 }  // namespace dpig

@@ -369,11 +369,12 @@ def conv2d_fwd(x, w, bias=None, stride=1, act=ACT_NONE, alpha=0.2, residual=None
     return out
 
 
-# 'bf16x3' mode: also give the forward / dgrad kernels the ACTIVATION's two-term split as a ready image (both operands by DMA,
-# PIPE 4).  Measured: the kernels gain 17 % (335 -> 395-405 effective TFLOP/s) but every image costs a pass over its tensor
-# (dpig_split32) or wider epilogue stores (emission), and with ONE consumer per image the step comes out even (-1.8 ... +1.4 %
-# same-box A/B).  Off by default until wgrad consumes the same images; DPIG_X3_PLANES=1 turns it on.
-X3_PLANES = [os.environ.get('DPIG_X3_PLANES', '0') != '0']
+# 'bf16x3' mode: give the conv kernels the ACTIVATIONS' two-term splits as ready images too (dpig_split32 layout), so that
+# forward, dgrad and wgrad take BOTH operands by LDS-DMA (PIPE 4, bw3_kernel).  An image costs a pass over its tensor (or
+# wider epilogue stores when the producing conv leaves it), and has two consumers (x: forward + wgrad, dy: dgrad + wgrad).
+# Measured, same-box A/B: kernels +17 % (fwd / dgrad) and +45 % (wgrad), Market step 452 -> 488 img/s.  DPIG_X3_PLANES=0
+# turns it off (every activation is then split in the k-loops' registers).
+X3_PLANES = [os.environ.get('DPIG_X3_PLANES', '1') != '0']
 
 
 def split32(t, reuse=1):
@@ -505,8 +506,17 @@ def conv2d_wgrad(x, dy, wshape, stride=1, upsample2x=False, out=None, beta=0.0, 
     mfma = (C % 4 == 0 and K % 4 == 0 and C >= 32 and K >= 32)
     with _Timed("conv_wgrad_mfma" if mfma else "conv_wgrad_thin",
                 2.0 * N * H * W // (stride * stride) * K * R * S * C, (N, H, W, C, K, R, stride, int(upsample2x))):
-        check(lib().dpig_conv2d_wgrad(ctypes.byref(d), ptr(x), ptr(dy), ptr(out), float(beta), ptr(db),
-                                      float(db_beta), ptr(wsb), wsn, stream_ptr()), "conv2d_wgrad")
+        x32 = dy32 = None
+        if mfma and _COMPUTE[0] == COMPUTE_BF16X3 and X3_PLANES[0] and K > 32:
+            # the images the forward / dgrad launches of this layer left on the tensors (made now if they did not)
+            x32 = split32(x, R * S * ((K + 127) // 128))
+            dy32 = split32(dy, R * S * ((C + 127) // 128)) if x32 is not None else None
+        if x32 is not None and dy32 is not None:
+            check(lib().dpig_conv2d_wgrad_x3(ctypes.byref(d), ptr(x), ptr(x32), ptr(dy), ptr(dy32), ptr(out), float(beta), ptr(db),
+                                             float(db_beta), ptr(wsb), wsn, stream_ptr()), "conv2d_wgrad_x3")
+        else:
+            check(lib().dpig_conv2d_wgrad(ctypes.byref(d), ptr(x), ptr(dy), ptr(out), float(beta), ptr(db),
+                                          float(db_beta), ptr(wsb), wsn, stream_ptr()), "conv2d_wgrad")
     return out
 
 

@@ -51,7 +51,7 @@ extern "C" {
 #define DPIG_ACT_RELU 1
 #define DPIG_ACT_LRELU 2
 
-#define DPIG_VERSION 240
+#define DPIG_VERSION 250
 
 /* Convolution problem, always described from the FORWARD op's point of view. */
 typedef struct DpigConvDesc {
@@ -204,6 +204,11 @@ int dpig_conv2d_dgrad_x3(const DpigConvDesc* d, const float* dy, const uint16_t*
  * y32 / dx32 (optional): room for the OUTPUT's split32 image; the float4 epilogue of an un-split launch writes it beside the
  * fp32 output (no second pass over it) and sets *written = 1 -- the next conv of the chain takes it as its x32 / dy32;
  * *written = 0 (split-K plan, thin layer, channel count not a multiple of 32, stride-2 dgrad): make it with dpig_split32. */
+/* Filter gradient of the same mode from the two images (x32 of the forward input, dy32 of the output gradient): both operands
+ * by LDS-DMA, no pass over the fp32 tensors; dw bit-identical to dpig_conv2d_wgrad's, db summed from dy's 16 split bits.
+ * Null images / layers it does not serve run dpig_conv2d_wgrad(d, x, dy, ...). */
+int dpig_conv2d_wgrad_x3(const DpigConvDesc* d, const float* x, const uint16_t* x32, const float* dy, const uint16_t* dy32,
+                         float* dw, float beta, float* db, float beta_b, void* ws, size_t ws_bytes, void* stream);
 size_t dpig_split32_bytes(int64_t rows, int C);
 int dpig_split32(const float* x, int ldx, int64_t rows, int C, uint16_t* out, void* stream);
 

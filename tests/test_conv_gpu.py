@@ -457,6 +457,14 @@ def test_conv_split_bf16_filter_shadows(dev, shape):
                     xp = torch.nn.functional.pad(x, (0, s32.shape[3] * 32 - C)).reshape(N, Hh, W, -1, 32)
                     assert torch.equal(s32[..., :32], xp.bfloat16().float()) and torch.equal(s32[..., 32:], (xp - s32[..., :32]).bfloat16().float())
                 assert torch.equal(y1, y0) and torch.equal(dx1, dx0), (sk, planes, float((y1 - y0).abs().max()), float((dx1 - dx0).abs().max()))
+                dbw = torch.zeros(K, device=dev)
+                dw1 = H.conv2d_wgrad(x, dy, (k, k, C, K), stride=s, split_k=sk, out=torch.empty(k, k, C, K, device=dev), beta=0.0,
+                                     db=dbw, db_beta=0.0)
+                if not planes:
+                    dw0, db0 = dw1, dbw                        # the register path (fp32 tensors split in the loop)
+                else:                                          # both operands from their images: dw bit for bit, db to dy's 16 bits
+                    assert torch.equal(dw1, dw0), (sk, float((dw1 - dw0).abs().max()))
+                    assert float((dbw - db0).abs().max()) <= 2e-5 * float(db0.abs().max())
                 for t in (y1, dx1):                            # an image the epilogue left equals the one dpig_split32 makes
                     img = getattr(t, "_dpig_s32", None)
                     if img is not None:
