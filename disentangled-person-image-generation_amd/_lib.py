@@ -60,6 +60,7 @@ SYMBOLS = {
     "dpig_conv2d_fwd_x3": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dpig_conv2d_dgrad_x3": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dpig_conv2d_wgrad_x3": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _f, _vp, _f, _vp, _sz, _vp]),
+    "dpig_act_bwd_s32": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _i, _i, _f, _vp, _vp]),
     "dpig_split32_bytes": (_sz, [_i64, _i]),
     "dpig_split32": (_i, [_vp, _i, _i64, _i, _vp, _vp]),
     "dpig_act_fwd": (_i, [_vp, _i, _vp, _i, _i64, _i, _i, _f, _vp]),

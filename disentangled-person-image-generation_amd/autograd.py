@@ -172,7 +172,7 @@ class _ConvFn(torch.autograd.Function):
         if second:
             dz = _ActBwdFn.apply(dy, y, act, alpha) if act != ACT_NONE else dy
         else:
-            dz = H.act_bwd(dy, y, act, alpha) if act != ACT_NONE else dy
+            dz = H.act_bwd(dy, y, act, alpha, emit32=True) if act != ACT_NONE else dy
         dx = dw = db = None
         if ctx.needs_input_grad[0]:
             if second:
@@ -222,7 +222,7 @@ class _ResBlockFn(torch.autograd.Function):
     def backward(ctx, dout):
         x0, w1, w2, c1, c2 = ctx.saved_tensors
         b1, b2 = ctx.b_refs
-        dz2 = H.act_bwd(dout, c2, ACT_RELU)
+        dz2 = H.act_bwd(dout, c2, ACT_RELU, emit32=True)
         dw2, db2 = _sink_wgrad_bias(w2, b2, c1, dz2, want_w=ctx.needs_input_grad[3], want_b=ctx.needs_input_grad[4])
         dz1 = H.conv2d_dgrad(dz2, w2, tuple(c1.shape), mask=c1, act=ACT_RELU, emit32=True)    # feeds dgrad(conv1)
         dw1, db1 = _sink_wgrad_bias(w1, b1, x0, dz1, want_w=ctx.needs_input_grad[1], want_b=ctx.needs_input_grad[2])

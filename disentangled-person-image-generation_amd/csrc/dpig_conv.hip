@@ -1872,7 +1872,8 @@ static int launch_gg(GGParams& p, bool b_rowk, int nimg, long filter_elems, hipS
     if (rc) return rc;
     dim3 grid(p.mtiles * p.ntiles, 1, p.nsplit), block(256);
     if (pipe && (!vec || narrow)) return fail(DPIG_EINVAL, "internal: bf16 loop selected for an ineligible problem");
-    if (!p.vec_epi || narrow || p.nsplit != 1 || p.replicate) p.D32 = nullptr;      // only the un-split float4 epilogue writes the image
+    if (!p.vec_epi || narrow || p.replicate) p.D32 = nullptr;      // the float4 epilogue (in the kernel, or in the split-K
+                                                                   // reduction pass) is what writes the image
     if (p.stats && (p.nsplit != 1 || !p.vec_epi || narrow || !aligned16(p.stats)))
         return fail(DPIG_EINVAL, "conv fwd with BN statistics needs an un-split plan, 16-byte aligned operands and more than 32 output channels");
 #define DPIG_GG(BR, VE, NA) hipLaunchKernelGGL((gather_gemm_kernel<BR, VE, NA>), grid, block, 0, st, p)

@@ -32,7 +32,7 @@ template <bool VEC>
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ dy, int lddy,
                                                       const float* __restrict__ y, int ldy,
                                                       float* __restrict__ dz, int lddz, long rows, int cols,
-                                                      int act, float alpha) {
+                                                      int act, float alpha, unsigned short* __restrict__ dz32 = nullptr) {
     if (VEC) {
         const int c4 = cols >> 2;
         const long total = rows * c4;
@@ -47,6 +47,16 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ 
             v.z = g.z * act_grad(o.z, act, alpha);
             v.w = g.w * act_grad(o.w, act, alpha);
             *reinterpret_cast<float4*>(dz + r * lddz + c) = v;
+            if (dz32) {     // the result's split32 image for the split-bf16 conv kernels ([row][chunk][32 hi | 32 lo], cols % 32 == 0)
+                typedef __bf16 b2 __attribute__((ext_vector_type(2)));
+                b2 h0, h1, l0, l1;
+                h0[0] = (__bf16)v.x; h0[1] = (__bf16)v.y; h1[0] = (__bf16)v.z; h1[1] = (__bf16)v.w;
+                l0[0] = (__bf16)(v.x - (float)h0[0]); l0[1] = (__bf16)(v.y - (float)h0[1]);
+                l1[0] = (__bf16)(v.z - (float)h1[0]); l1[1] = (__bf16)(v.w - (float)h1[1]);
+                unsigned short* o = dz32 + (r * (cols >> 5) + (c >> 5)) * 64 + (c & 31);
+                *reinterpret_cast<uint2*>(o) = make_uint2(__builtin_bit_cast(unsigned, h0), __builtin_bit_cast(unsigned, h1));
+                *reinterpret_cast<uint2*>(o + 32) = make_uint2(__builtin_bit_cast(unsigned, l0), __builtin_bit_cast(unsigned, l1));
+            }
         }
     } else {
         const long total = rows * cols;
@@ -924,6 +934,19 @@ extern "C" int dpig_act_bwd(const float* dy, int lddy, const float* y, int ldy, 
     else
         hipLaunchKernelGGL((act_bwd_kernel<false>), dim3(grid_for(rows * cols)), dim3(256), 0, st, dy, lddy, y, ldy,
                            dz, lddz, (long)rows, cols, act, alpha);
+    return check_launch("act_bwd_kernel");
+}
+
+// dpig_act_bwd that also leaves dz's split32 image (dpig_split32 layout) for the split-bf16 conv kernels that read dz next
+extern "C" int dpig_act_bwd_s32(const float* dy, int lddy, const float* y, int ldy, float* dz, int lddz, int64_t rows, int cols,
+                                int act, float alpha, uint16_t* dz32, void* stream) {
+    if (!dy || !y || !dz || !dz32) return fail(DPIG_EINVAL, "act_bwd_s32: null pointer");
+    if (rows <= 0 || cols <= 0) return fail(DPIG_EINVAL, "act_bwd_s32: empty");
+    if ((cols % 32) || (lddy % 4) || (ldy % 4) || (lddz % 4) || ((uintptr_t)dy % 16) || ((uintptr_t)y % 16) || ((uintptr_t)dz % 16) ||
+        ((uintptr_t)dz32 % 16))
+        return fail(DPIG_EINVAL, "act_bwd_s32: needs a multiple of 32 columns and 16-byte addressable rows");
+    hipLaunchKernelGGL((act_bwd_kernel<true>), dim3(grid_for(rows * (cols / 4))), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       dy, lddy, y, ldy, dz, lddz, (long)rows, cols, act, alpha, dz32);
     return check_launch("act_bwd_kernel");
 }
 

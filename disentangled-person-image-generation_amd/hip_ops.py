@@ -723,8 +723,9 @@ def act_fwd(x, act, alpha=0.2):
     return y
 
 
-def act_bwd(dy, y, act, alpha=0.2):
-    """dz = dy * act'(y) with y the activation output."""
+def act_bwd(dy, y, act, alpha=0.2, emit32=False):
+    """dz = dy * act'(y) with y the activation output.  `emit32`: dz feeds conv kernels next ('bf16x3' mode: also leave its
+    split32 image)."""
     if dy.dtype == BF16 or y.dtype == BF16:
         _require_dev(dy)
         if dy.dtype == BF16 and y.dtype == BF16:
@@ -740,6 +741,14 @@ def act_bwd(dy, y, act, alpha=0.2):
     dy, rows, cols, lddy = _rows_ld(dy)
     y, _, _, ldy = _rows_ld(y)
     dz = torch.empty(dy.shape, dtype=torch.float32, device=dy.device)
+    if (emit32 and _COMPUTE[0] == COMPUTE_BF16X3 and X3_PLANES[0] and X3_EMIT[0] and dz.dim() == 4 and cols % 32 == 0 and
+            lddy % 4 == 0 and ldy % 4 == 0 and _al16(dy, y) and rows * cols * 4 < 2 ** 31 - 1):
+        # dz feeds split-bf16 convs next (wgrad and dgrad of the layer): leave its split32 image in the same pass
+        dz32 = torch.empty(tuple(dz.shape[:3]) + (cols // 32, 64), dtype=BF16, device=dz.device)
+        check(lib().dpig_act_bwd_s32(ptr(dy), lddy, ptr(y), ldy, ptr(dz), cols, rows, cols, act, alpha, ptr(dz32), stream_ptr()),
+              "act_bwd_s32")
+        dz._dpig_s32 = dz32
+        return dz
     check(lib().dpig_act_bwd(ptr(dy), lddy, ptr(y), ldy, ptr(dz), cols, rows, cols, act, alpha, stream_ptr()),
           "act_bwd")
     return dz

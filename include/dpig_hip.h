@@ -51,7 +51,7 @@ extern "C" {
 #define DPIG_ACT_RELU 1
 #define DPIG_ACT_LRELU 2
 
-#define DPIG_VERSION 250
+#define DPIG_VERSION 260
 
 /* Convolution problem, always described from the FORWARD op's point of view. */
 typedef struct DpigConvDesc {
@@ -209,6 +209,9 @@ int dpig_conv2d_dgrad_x3(const DpigConvDesc* d, const float* dy, const uint16_t*
  * Null images / layers it does not serve run dpig_conv2d_wgrad(d, x, dy, ...). */
 int dpig_conv2d_wgrad_x3(const DpigConvDesc* d, const float* x, const uint16_t* x32, const float* dy, const uint16_t* dy32,
                          float* dw, float beta, float* db, float beta_b, void* ws, size_t ws_bytes, void* stream);
+/* dpig_act_bwd that also leaves dz's split32 image (cols % 32 == 0, 16-byte addressable rows). */
+int dpig_act_bwd_s32(const float* dy, int lddy, const float* y, int ldy, float* dz, int lddz, int64_t rows, int cols, int act,
+                     float alpha, uint16_t* dz32, void* stream);
 size_t dpig_split32_bytes(int64_t rows, int C);
 int dpig_split32(const float* x, int ldx, int64_t rows, int C, uint16_t* out, void* stream);
 
