@@ -73,6 +73,8 @@ SYMBOLS = {
     "dpig_conv2d_bn_stats_tiles": (_i, [_dp]),
     "dpig_conv2d_fwd_stats": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dpig_bn_stats_finalize": (_i, [_vp, _i, _i64, _i, _i, _f, _vp, _vp, _vp]),
+    "dpig_conv2d_bf16_bn_stats_tiles": (_i, [_dp]),
+    "dpig_conv2d_fwd_bf16_stats": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dpig_bn_workspace_bytes": (_sz, [_i64, _i]),
     "dpig_bn_fwd": (_i, [_vp, _i, _i64, _i, _vp, _vp, _f, _i, _f, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "dpig_bn_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp, _vp, _vp, _i, _f, _vp, _i, _vp, _vp, _vp, _sz, _vp]),

@@ -53,7 +53,8 @@ constexpr int ROWB = 128;                 // bytes of one LDS row: 64 bf16 of k,
 constexpr int TILE_B = TM * ROWB;         // one operand tile: 16 KB
 constexpr int STAGE_B = 2 * TILE_B;       // A + B: 32 KB
 constexpr int LDC = TN + 4;               // fp32 accumulator staging stride of the epilogue
-constexpr int SMEM_BYTES = TM * LDC * 4;  // 67584 >= 2 stages (65536); 2 workgroups per CU = 132 KB of 160 KB
+constexpr int STATS_RED_BYTES = 16 * TN * 4;                 // scratch of the BN-statistics epilogue: 16 row groups x 128 columns
+constexpr int SMEM_BYTES = TM * LDC * 4 + STATS_RED_BYTES;   // 67584 (>= 2 stages = 65536) + 8192; 2 workgroups per CU = 148 KB of 160 KB
 constexpr unsigned OOB = 0x7fffffffu;
 // split-K partial sums cost relatively more than on the fp32 pipe (the products are ~8x faster, HBM is not)
 constexpr double kSplitPenalty = 700.0;
@@ -68,6 +69,7 @@ struct BGParams {
     const float* res_cls; // class-indexed residual [images][9][Ncols] fp32 (tiled-embedding collapse) or null
     const bf16_t* mask;   // activation-output tensor for act' (dest-shaped) or null
     float* partial;       // split-K workspace [nsplit][M][Ncols]
+    float* stats;         // BN partial statistics [mtiles][2][Ncols] of acc + bias (sum, centred squares per row tile) or null
     int M, Hr, Wr, HrWr;
     int Hs, Ws, lda, Cs, sr;
     int Ncols;
@@ -196,6 +198,55 @@ __device__ __forceinline__ void bg_epilogue(const BGParams& p, char* smem, f32x1
     const int c = (tid & 15) * 8;
     const int col = n0 + c;
     const int rl0 = tid >> 4;
+    // ---- batch-norm partial statistics of this row tile (as dpig_conv.hip's: per column the sum and the sum of squared
+    // deviations from the TILE's mean, from the fp32 accumulators + bias, before the output is rounded to bf16).  Only set by
+    // dpig_conv2d_fwd_bf16_stats: un-split bg_kernel launch, rows m0 .. m0 + 127 are pixels m0 .. (every thread takes part).
+    if (p.stats) {
+        const bool cok = col < p.Ncols;
+        const int nrows = min(TM, p.M - m0);
+        float b8[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) b8[e] = (p.bias && cok) ? p.bias[col + e] : 0.f;
+        float* red = Cs + TM * LDC;
+        float sm[8], q8[8], tot[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { sm[e] = 0.f; q8[e] = 0.f; tot[e] = 0.f; }
+        for (int it = 0; it < 8; ++it) {
+            const int rl = rl0 + 16 * it;
+            if (rl < nrows) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sm[e] += Cs[rl * LDC + c + e] + b8[e];
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[rl0 * TN + c + e] = sm[e];
+        __syncthreads();
+        for (int g = 0; g < 16; ++g)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) tot[e] += red[g * TN + c + e];
+        const float inv = 1.0f / (float)nrows;
+        __syncthreads();
+        for (int it = 0; it < 8; ++it) {
+            const int rl = rl0 + 16 * it;
+            if (rl < nrows) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float dv = Cs[rl * LDC + c + e] + b8[e] - tot[e] * inv; q8[e] += dv * dv; }
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) red[rl0 * TN + c + e] = q8[e];
+        __syncthreads();
+        if (rl0 == 0 && cok) {
+            float* o = p.stats + ((long)(m0 / TM) * 2) * p.Ncols + col;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                float qt = 0.f;
+                for (int g = 0; g < 16; ++g) qt += red[g * TN + c + e];
+                o[e] = tot[e];
+                o[p.Ncols + e] = qt;
+            }
+        }
+    }
     if (col >= p.Ncols) return;
     if (p.nsplit > 1) {
         float* pp = p.partial + ((long)split * p.M + m0 + rl0) * p.Ncols + col;
@@ -1393,7 +1444,9 @@ static int launch_bg(BGParams& p, int nimg, long filter_elems, hipStream_t st) {
     int rc = prepare_bg(p, nimg, filter_elems);
     if (rc) return rc;
     int tx = 0, ty = 0;
-    const int twl = halo_plan(p, nimg, &tx, &ty);
+    if (p.stats && (p.nsplit != 1 || !p.identity_rows || p.replicate || !aligned16(p.stats)))
+        return fail(DPIG_EINVAL, "bf16 conv fwd with BN statistics needs an un-split plan");
+    const int twl = p.stats ? 0 : halo_plan(p, nimg, &tx, &ty);
     if (twl) {
         p.tiles_x = tx; p.tiles_y = ty;
         p.mtiles = nimg * tx * ty;
@@ -1479,7 +1532,7 @@ static size_t bf16_workspace_bytes_one(const DpigConvDesc* d, int which) {
 // ---- entry points: one launch, or runs of whole images when a tensor exceeds one launch's 2 GiB range (dpig_conv_plan.h) ----
 static int fwd_bf16_one(const DpigConvDesc* d, const uint16_t* x, const uint16_t* w_t, const float* bias,
                         const uint16_t* residual, const float* residual_class, uint16_t* y, uint16_t* y_act, void* ws,
-                        size_t ws_bytes, void* stream);
+                        size_t ws_bytes, void* stream, float* stats = nullptr);
 static int dgrad_bf16_one(const DpigConvDesc* d, const uint16_t* dy, const uint16_t* w, const uint16_t* accum,
                           const uint16_t* mask, uint16_t* dx, void* ws, size_t ws_bytes, void* stream);
 static int wgrad_bf16_one(const DpigConvDesc* d, const uint16_t* x, const uint16_t* dy, float* dw, float beta, float* db,
@@ -1553,9 +1606,27 @@ extern "C" int dpig_conv2d_wgrad_bf16(const DpigConvDesc* d, const uint16_t* x, 
     return DPIG_OK;
 }
 
+// Forward conv (+ bias) on bf16 tensors that also leaves the batch-norm partial statistics of its output (see
+// dpig_conv2d_fwd_stats; merged by dpig_bn_stats_finalize).  Tile count 0: this problem's plan cannot carry them.
+extern "C" int dpig_conv2d_bf16_bn_stats_tiles(const DpigConvDesc* d) {
+    int pt, pl, Ho, Wo;
+    if (resolve_desc(d, &pt, &pl, &Ho, &Wo) || !shape_ok(d)) return 0;
+    if (d->upsample2x || d->act != DPIG_ACT_NONE || images_per_launch(d, 2) < d->N) return 0;
+    const long M = (long)d->N * Ho * Wo;
+    Plan pln = plan_split(cdiv(M, TM) * cdiv(d->K, TN), d->R * d->S * cdiv(d->C, gtk()), d->split_k, gtk(), kSplitPenalty);
+    return pln.nsplit == 1 ? (int)cdiv(M, TM) : 0;
+}
+extern "C" int dpig_conv2d_fwd_bf16_stats(const DpigConvDesc* d, const uint16_t* x, const uint16_t* w_t, const float* bias,
+                                          uint16_t* y, float* stats, void* stream) {
+    if (!stats) return fail(DPIG_EINVAL, "bf16 conv fwd with BN statistics: null statistics buffer");
+    if (dpig_conv2d_bf16_bn_stats_tiles(d) <= 0)
+        return fail(DPIG_EINVAL, "bf16 conv fwd with BN statistics: this problem's plan cannot carry them");
+    return fwd_bf16_one(d, x, w_t, bias, nullptr, nullptr, y, nullptr, nullptr, 0, stream, stats);
+}
+
 static int fwd_bf16_one(const DpigConvDesc* d, const uint16_t* x, const uint16_t* w_t, const float* bias,
                         const uint16_t* residual, const float* residual_class, uint16_t* y, uint16_t* y_act,
-                        void* ws, size_t ws_bytes, void* stream) {
+                        void* ws, size_t ws_bytes, void* stream, float* stats) {
     int pt, pl, Ho, Wo;
     int rc = resolve_desc(d, &pt, &pl, &Ho, &Wo);
     if (rc) return rc;
@@ -1571,6 +1642,7 @@ static int fwd_bf16_one(const DpigConvDesc* d, const uint16_t* x, const uint16_t
     p.A = x; p.B = w_t; p.D = y; p.bias = bias; p.res = residual; p.res_cls = residual_class; p.mask = nullptr;
     p.D2 = y_act; p.ldd2 = d->ldy2; p.res_post = d->res_after_act;
     p.partial = static_cast<float*>(ws);
+    p.stats = stats;
     p.M = d->upsample2x ? d->N * d->H * d->W : d->N * Ho * Wo;
     p.Hr = d->upsample2x ? d->H : Ho; p.Wr = d->upsample2x ? d->W : Wo;
     p.Hs = d->H; p.Ws = d->W; p.lda = d->ldx; p.Cs = d->C; p.sr = d->stride;

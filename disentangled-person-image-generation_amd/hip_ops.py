@@ -416,6 +416,24 @@ def conv2d_fwd_stats(x, w, bias=None, stride=1, split_k=0):
     (dpig_conv2d_fwd_stats): returns (y, stats) with stats = (float tensor [tiles, 2, K], rows per tile), or (y, None) when
     this problem's plan cannot carry them (split-K, thin layers, bf16 storage) -- `bn_fwd(y, ..., stats=stats)` accepts both."""
     if _STORE_BF16[0] or x.dtype == BF16:
+        _require_dev(x)
+        N, H, W, C = x.shape
+        R, S, Cw, K = w.shape
+        if Cw == C and _bf16_conv_ok(C, K):
+            xb, ldx = as_nhwc(to_bf16(x))
+            if _bf16_conv_ok(C, K, ldx) and _al16(xb):
+                d = _desc(N, H, W, C, K, R, S, stride, ldx, K, split_k=split_k)
+                tiles = lib().dpig_conv2d_bf16_bn_stats_tiles(ctypes.byref(d))
+                if tiles > 0:
+                    Ho, Wo = conv_out_hw(H, W, R, S, stride, False)
+                    _, w_t = filter_shadows(w, want_plain=False)
+                    out = torch.empty((N, Ho, Wo, K), dtype=BF16, device=x.device)
+                    stats = torch.empty((tiles, 2, K), dtype=torch.float32, device=x.device)
+                    with _Timed("conv_fwd_bf16", 2.0 * N * H * W // (stride * stride) * K * R * S * C, (N, H, W, C, K, R, stride, 0)):
+                        check(lib().dpig_conv2d_fwd_bf16_stats(ctypes.byref(d), ptr(xb), ptr(w_t),
+                                                               ptr(bias.contiguous() if bias is not None else None), ptr(out),
+                                                               ptr(stats), stream_ptr()), "conv2d_fwd_bf16_stats")
+                    return out, (stats, 128)
         return conv2d_fwd(x, w, bias, stride=stride, split_k=split_k), None
     _require_gpu(x)
     x, ldx = as_nhwc(x)
@@ -795,7 +813,7 @@ def bn_fwd(x, scale, offset, eps=1e-5, act=ACT_NONE, alpha=0.2, stats=None):
     """Training-mode batch norm over all but the last axis (+ fused activation).  `stats` = what `conv2d_fwd_stats` returned
     for x: the statistics passes are replaced by one merge of the producing conv's per-tile partials."""
     if x.dtype == BF16:
-        y, mean, rstd = bn_fwd(to_f32(x), scale, offset, eps, act, alpha)
+        y, mean, rstd = bn_fwd(to_f32(x), scale, offset, eps, act, alpha, stats=stats)
         return to_bf16(y), mean, rstd
     _require_gpu(x)
     x, rows, C, ldx = _rows_ld(x)

@@ -51,7 +51,7 @@ extern "C" {
 #define DPIG_ACT_RELU 1
 #define DPIG_ACT_LRELU 2
 
-#define DPIG_VERSION 260
+#define DPIG_VERSION 270
 
 /* Convolution problem, always described from the FORWARD op's point of view. */
 typedef struct DpigConvDesc {
@@ -249,6 +249,10 @@ int dpig_border_class_sum_bf16(const uint16_t* a, int lda, int N, int H, int W, 
 int dpig_conv2d_bn_stats_tiles(const DpigConvDesc* d);
 int dpig_conv2d_fwd_stats(const DpigConvDesc* d, const float* x, const float* w, const float* bias, float* y, float* stats,
                           void* stream);
+/* the same for bf16 activations (statistics from the fp32 accumulators + bias, before y is rounded to bf16) */
+int dpig_conv2d_bf16_bn_stats_tiles(const DpigConvDesc* d);
+int dpig_conv2d_fwd_bf16_stats(const DpigConvDesc* d, const uint16_t* x, const uint16_t* w_t, const float* bias, uint16_t* y,
+                               float* stats, void* stream);
 int dpig_bn_stats_finalize(const float* stats, int tiles, int64_t rows, int rows_per_tile, int C, float eps, float* mean,
                            float* rstd, void* stream);
 

@@ -317,3 +317,36 @@ def test_bad_arguments(dev):
     d.C = d.ldx = 64
     assert h.dpig_conv2d_fwd_bf16(ctypes.byref(d), 16, 18, None, None, None, 16, None, None, 0, None) == -14   # misaligned
     assert h.dpig_conv2d_fwd_bf16(ctypes.byref(d), None, 16, None, None, None, 16, None, None, 0, None) == -22
+
+
+@pytest.mark.parametrize("shape", [(3, 20, 20, 64, 128, 5, 2), (2, 17, 9, 32, 136, 3, 1)])
+def test_bf16_conv_epilogue_bn_statistics(dev, shape):
+    """dpig_conv2d_fwd_bf16_stats: the bf16-storage forward conv leaves the batch-norm partial statistics of its output (from
+    the fp32 accumulators + bias, before y is rounded to bf16); merged by dpig_bn_stats_finalize they give the batch mean and
+    rstd of the fp64 oracle conv on the bf16-ROUNDED operands, and bn_fwd(..., stats=) the normalised LeakyReLU output."""
+    import dpig_amd.hip_ops as H
+    from oracle import ops as O
+    N, Hh, W, C, K, k, s = shape
+    g = torch.Generator().manual_seed(7)
+    bf = lambda t: t.float().bfloat16().double()
+    x = bf(torch.randn(N, Hh, W, C, generator=g, dtype=torch.float64))
+    w = bf(torch.randn(k, k, C, K, generator=g, dtype=torch.float64) * 0.1)
+    b = torch.randn(K, generator=g, dtype=torch.float64) * 0.5 + 8.0
+    scale = torch.rand(K, generator=g, dtype=torch.float64) + 0.5
+    offset = torch.randn(K, generator=g, dtype=torch.float64)
+    pre = O.conv2d_same(x, w, b, s)
+    rows = pre.reshape(-1, K)
+    xg, wg, bg = x.float().to(dev).bfloat16(), w.float().to(dev), b.float().to(dev)
+    y, st = H.conv2d_fwd_stats(xg, wg, bg, stride=s, split_k=1)
+    assert y.dtype == torch.bfloat16 and st is not None and st[0].shape == ((rows.shape[0] + 127) // 128, 2, K)
+    err = (y.float().cpu().double() - pre).abs()
+    assert not bool((err > pre.abs() * 2.0 ** -8 + 1e-4 * float(pre.abs().max())).any())
+    out, mean, rstd = H.bn_fwd(y, scale.float().to(dev), offset.float().to(dev), 1e-5, 2, 0.2, stats=st)
+    assert float((mean.cpu().double() - rows.mean(0)).abs().max()) <= 1e-5 * float(rows.mean(0).abs().max())
+    ref_rstd = 1.0 / torch.sqrt(rows.var(0, unbiased=False) + 1e-5)
+    assert float((rstd.cpu().double() - ref_rstd).abs().max()) <= 1e-4 * float(ref_rstd.abs().max())
+    ref = O.leaky_relu(O.batchnorm_train(pre, scale, offset), 0.2)
+    assert out.dtype == torch.bfloat16
+    assert float((out.float().cpu().double() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())      # bf16 y, bf16 result
+    y2, st2 = H.conv2d_fwd_stats(xg, wg, bg, stride=s, split_k=1)
+    assert torch.equal(y2, y) and torch.equal(st2[0], st[0])
