@@ -1058,17 +1058,19 @@ extern "C" int dpig_bn_bwd(const float* dy, int lddy, const float* x, int ldx, c
 // ---- statistics left by the producing conv's epilogue (dpig_conv2d_fwd_stats) -------------------------------------------
 // stats[tile][0][C] = sum over the tile's rows, stats[tile][1][C] = sum of squared deviations from the tile's own mean; tiles
 // hold `rows_per_tile` rows (the last one the remainder).  Merged with the exact pairwise update (Chan, Golub, LeVeque):
-// 4 lanes per column take every 4th tile in order, then the 4 partial results are merged in lane order -- fixed order,
+// 16 lanes per column take every 16th tile in order, then the 16 partial results are merged in lane order -- fixed order,
 // no atomics.  mean and rstd = 1/sqrt(biased variance + eps) are what dpig_bn_apply / dpig_bn_bwd expect.
 __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __restrict__ stats, int tiles, long rows,
                                                                 int rows_per_tile, int C, float eps,
                                                                 float* __restrict__ mean_out, float* __restrict__ rstd_out) {
-    __shared__ float sn[4][64], sm[4][64], sq[4][64];
-    const int cl = threadIdx.x & 63, g = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    // 16 columns per block, 16 lanes per column: lane g takes tiles g, g + 16, ... in order (the loads of a tile do not
+    // depend on the running merge, so they pipeline), then the 16 partial results are merged in lane order
+    __shared__ float sn[16][16], sm[16][16], sq[16][16];
+    const int cl = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     float n = 0.f, mean = 0.f, m2 = 0.f;
     if (c < C) {
-        for (int t = g; t < tiles; t += 4) {
+        for (int t = g; t < tiles; t += 16) {
             const long left = rows - (long)t * rows_per_tile;
             const float nb = (float)(left < rows_per_tile ? left : rows_per_tile);
             const float mb = stats[((long)t * 2) * C + c] / nb, qb = stats[((long)t * 2 + 1) * C + c];
@@ -1081,7 +1083,7 @@ __global__ __launch_bounds__(256) void bn_stats_finalize_kernel(const float* __r
     sn[g][cl] = n; sm[g][cl] = mean; sq[g][cl] = m2;
     __syncthreads();
     if (g == 0 && c < C) {
-        for (int k = 1; k < 4; ++k) {
+        for (int k = 1; k < 16; ++k) {
             const float nb = sn[k][cl];
             if (nb > 0.f) {
                 const float nt = n + nb, delta = sm[k][cl] - mean;
@@ -1100,7 +1102,7 @@ extern "C" int dpig_bn_stats_finalize(const float* stats, int tiles, int64_t row
     if (tiles <= 0 || rows <= 0 || rows_per_tile <= 0 || C <= 0 || (long)tiles * rows_per_tile < rows ||
         (long)(tiles - 1) * rows_per_tile >= rows)
         return fail(DPIG_EINVAL, "bn_stats_finalize: %d tiles of %d rows do not cover %ld rows", tiles, rows_per_tile, (long)rows);
-    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdivi(C, 64)), dim3(256), 0, static_cast<hipStream_t>(stream), stats,
+    hipLaunchKernelGGL(bn_stats_finalize_kernel, dim3(cdivi(C, 16)), dim3(256), 0, static_cast<hipStream_t>(stream), stats,
                        tiles, (long)rows, rows_per_tile, C, eps, mean, rstd);
     return check_launch("bn_stats_finalize");
 }
