@@ -106,6 +106,8 @@ INFO_RUNS = [   # (key, BASELINE config it informs, bench.py arguments)
     ("market128_split_bf16", "configs[1] (the headline workload) with the conv products on the bf16 pipe as two-term splits of the fp32 "
      "operands (DPIG_COMPUTE_BF16X3: fp32 tensors, <= 2e-5 max|ref| per kernel); the headline itself stays exact fp32",
      ["--workload", "market128", "--dtype", "bf16x3", "--steps", "10", "--warmup", "2"]),
+    ("df256_split_bf16", "configs[3]'s graph (DeepFashion 256x256 bs=8) with fp32 tensors and split-bf16 conv products",
+     ["--workload", "df256", "--dtype", "bf16x3", "--steps", "4", "--warmup", "2"]),
     ("market128_wgan_gp_f32", "configs[1] with MODE='wgan-gp' (LayerNorm critic, gradient penalty, 5 critic iterations per step)",
      ["--workload", "market128-wgan-gp", "--steps", "5", "--warmup", "2"]),
 ]
