@@ -1,0 +1,450 @@
+// bf16-STORAGE gather-GEMM, large-tile form: 8 waves per workgroup, ONE workgroup per CU, block tile 256 x 256 x 64
+// (bq_kernel<2, 4>) or 512 x 128 x 64 (bq_kernel<4, 2>, for 128-column layers), every wave a 128 x 64 sub-tile =
+// 4 x 2 accumulators of v_mfma_f32_32x32x16_bf16.  Same problem abstraction as bg_kernel (dpig_conv_bf16.hip): rows =
+// output pixels, k = (filter tap, 64-channel chunk), A gathered per tap with the halo as out-of-range DMA lanes, B = the
+// filter shadow; forward 3x3 / 5x5 / 1x1 and the stride-1 dgrad run on it (tflib/ops/conv2d.py:106-112, models.py:396-573).
+//
+// Why: at 128 x 128 a wave must issue 8 LDS-DMA pieces per 16 MFMAs and the k-loop is bound by their issue cost and
+// landing latency (profiles/r02_bf16_kloop_timeline_knockout.md).  Here a wave issues 8 (10) pieces per 32 MFMAs and
+// nothing in the loop ever waits for the DMA queue to drain:
+//  * two LDS slots (k-tiles t, t+1) of [A tile | B tile], rows of 128 B = 64 bf16 of k, lane-linear DMA images with the
+//    bank swizzle on the SOURCE side (slot s of row r holds chunk s ^ ((r >> 1) & 7)), fragments by ds_read_b128;
+//  * a k-tile is FOUR phases, one 64 x 32 accumulator quadrant (8 MFMAs) each:
+//        P1  read B[nb0] (4) + A[mh0] (8)   stage UB1(t+1)   MFMA (mh0, nb0)
+//        P2  read B[nb1] (4)                stage UA1(t+1)   MFMA (mh0, nb1)
+//        P3  read A[mh1] (8)                stage UA0(t+2)   MFMA (mh1, nb1)
+//        P4  --                             stage UB0(t+2)   MFMA (mh1, nb0)
+//    a staging unit Uxh = the rows the waves read in ONE phase: UA0 = rows wr*128 + 0..63 of every wave row, UA1 = rows
+//    wr*128 + 64..127, UB0 / UB1 = columns wc*64 + 0..31 / 32..63 of every wave column;
+//  * a phase is   { ds_reads ; DMA issue ; s_waitcnt vmcnt(N) ; s_barrier ; 8 MFMAs at s_setprio 1 ; s_barrier }
+//    with RAW barriers (no fence: an LDS-DMA is a pending LDS write, __syncthreads() would drain it) and the two wave
+//    groups (waves 0-3 / 4-7 = the two waves of each SIMD) staggered by one barrier, so that one wave of every SIMD is in
+//    its MFMA cluster while its partner reads fragments and issues DMA ("ping-pong");
+//  * hazards, by construction of the table above (p = phase count, b = barrier count; group 0 runs L(p) in
+//    [b(2p-2), b(2p-1)] and M(p) in [b(2p-1), b(2p)], group 1 one barrier later):
+//      RAW  a unit is read one phase AFTER the phase whose counted vmcnt retires it: every wave waits for ITS pieces
+//           before the first barrier of phase r, readers start behind that barrier in phase r + 1.  N = 2 (NA + NB)
+//           pieces = the four units issued after the one being retired;
+//      WAR  a unit is re-staged >= 2 phases after its last read: the readers' fragments have returned (their MFMA
+//           cluster consumed them) before the barrier that precedes the issuing phase of either group;
+//    past the last k-tile the same DMA instructions are issued with out-of-range offsets (zero fill of a free unit), so
+//    the counts stay uniform; the queue is drained once, before the epilogue reuses the LDS.
+// Epilogue: the 256 KB of accumulators go through LDS in four passes (one 32-row block of every wave per pass) into the
+// same fused row-contiguous epilogue as the 128 x 128 kernels (bias, activation, residual before / after, second
+// output, dgrad mask).
+#include <stdlib.h>
+#include <string.h>
+#include <type_traits>
+#include "dpig_bf16_common.h"
+#include "dpig_conv_plan.h"
+
+namespace dpig {
+namespace bfk {
+
+template <int WM, int WN>
+struct QGeom {
+    static constexpr int BM = WM * 128, BN = WN * 64;
+    static constexpr int ASLOT = 128 * ROWB, BSLOT = 64 * ROWB;     // one slot of one wave row / wave column: 16 KB / 8 KB
+    static constexpr int B_OFF = WM * 2 * ASLOT;                     // B region behind the A region
+    static constexpr int SMEM = B_OFF + WN * 2 * BSLOT;
+    static constexpr int NA = WM;              // DMA pieces per wave per A unit (WM * 64 rows / 8 rows / 8 waves)
+    static constexpr int NB = WN / 2;          // per B unit
+    static constexpr int VMC = 2 * (NA + NB);  // pieces left in flight by the per-phase wait
+    static constexpr int LDCQ = BN + 4;        // fp32 staging stride of the epilogue
+    static constexpr int RP = WM * 32;         // staged rows per epilogue pass
+    static_assert(WM * WN == 8 && (WN == 2 || WN == 4), "8 waves");
+    static_assert(RP * LDCQ * 4 <= SMEM && SMEM <= 163840, "LDS plan");
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+typedef __attribute__((address_space(3))) char lds_char;
+__device__ __forceinline__ void dma16l(__amdgpu_buffer_rsrc_t rs, int voff, int soff, lds_char* lds_dst) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)lds_dst, 16, voff, soff, 0, 0);
+}
+
+__device__ __forceinline__ void q_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// one output row segment of 8 columns: the flag combinations the models produce as straight-line bodies, the rest by epi8
+template <bool HAS_RES, bool RES_POST, bool HAS_MASK, bool HAS_D2>
+__device__ __forceinline__ void q_row8(const BGParams& p, long r0, int col, float (&v)[8], const float (&bv)[8], float slope) {
+    bf16_t* dp = p.D + r0 * p.ldd + col;
+    float rv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] += bv[e];
+    if (HAS_RES) unpack8(*reinterpret_cast<const uint4*>(p.res + r0 * p.ldres + col), rv);
+    if (HAS_RES && !RES_POST) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+    }
+    if (HAS_MASK) {
+        float mv[8];
+        unpack8(*reinterpret_cast<const uint4*>(p.mask + r0 * p.ldmask + col), mv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= (mv[e] > 0.f) ? 1.f : slope;
+    } else {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = (v[e] > 0.f) ? v[e] : (v[e] * slope + 0.f);
+    }
+    if (HAS_D2) {
+        const uint4 o2 = pack8(v);
+        *reinterpret_cast<uint4*>(p.D2 + r0 * p.ldd2 + col) = o2;
+        if (HAS_RES && RES_POST) unpack8(o2, v);     // the sum is formed from the STORED (rounded) activation
+    }
+    if (HAS_RES && RES_POST) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+    }
+    *reinterpret_cast<uint4*>(dp) = pack8(v);
+}
+
+template <int WM, int WN>
+__global__ __launch_bounds__(512, 2) void bq_kernel(const BGParams p) {
+    using G = QGeom<WM, WN>;
+    __shared__ __attribute__((aligned(16))) char smem[G::SMEM];        // the ONLY LDS object
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave / WN, wc = wave % WN;
+    const int grp = wave >> 2;                                         // waves w and w + 4 share a SIMD
+    const int l31 = lane & 31, half = lane >> 5;
+
+    const int tile = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
+    const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+    const int m0 = mt * G::BM, n0 = nt * G::BN;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes);
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.B, p.b_bytes);
+
+    // ---- LDS plan: A region = [wave row][slot][128 rows x 128 B], B region = [wave column][slot][64 rows x 128 B]: the
+    // slot is ONE address bit (G::ASLOT / G::BSLOT), so the k-loop has a single body and toggles its addresses by XOR, and
+    // every fragment offset is a 16-bit immediate of 8 address registers.
+    // ---- DMA roles.  A unit h, piece j of this wave: rows h*64 + 8*wave .. +7 of wave row j; B unit h, piece j: columns
+    // h*32 + 8*(wave & 3) .. +7 of wave column (wave >> 2) + 2j.  lane -> (row = lane >> 3, 16-byte slot = lane & 7).
+    const int prow = lane >> 3;
+    int a_base[2][G::NA], a_yx[2][G::NA], a_voff[2][G::NA], b_voff[2][G::NB];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int j = 0; j < G::NA; ++j) {
+            const int trow = j * 128 + h * 64 + 8 * wave + prow;
+            const int chunk = (lane & 7) ^ ((trow >> 1) & 7);
+            const int m = m0 + trow;
+            const bool ok = m < p.M;
+            const int mm = ok ? m : 0;
+            const int n = fast_div(mm, p.mul_hrwr, p.shr_hrwr);
+            const int rem = mm - n * p.HrWr;
+            const int r = fast_div(rem, p.mul_wr, p.shr_wr);
+            const int c = rem - r * p.Wr;
+            const int iy0 = ok ? r * p.sr : -16384;                   // a row beyond M fails every bounds test
+            a_yx[h][j] = (int)(((unsigned)iy0 << 16) | ((unsigned)(c * p.sr) & 0xffffu));
+            a_base[h][j] = ((((n * p.Hs + r * p.sr) * p.Ws + c * p.sr) * p.lda) + chunk * 8) * 2;
+        }
+#pragma unroll
+        for (int j = 0; j < G::NB; ++j) {
+            const int tcol = ((wave >> 2) + 2 * j) * 64 + h * 32 + 8 * (wave & 3) + prow;
+            const int chunk = (lane & 7) ^ ((tcol >> 1) & 7);
+            const int nn = n0 + tcol;
+            b_voff[h][j] = (nn < p.Ncols) ? (nn * p.Cs + chunk * 8) * 2 : (int)OOB;
+        }
+    }
+    // ---- staging cursor (scalar state, advanced incrementally): the k-tile whose units are being issued ----------
+    const int kt_begin = blockIdx.z * p.tiles_per_split;
+    const int nkt = min(p.ktiles, kt_begin + p.tiles_per_split) - kt_begin;
+    int st_left = nkt, st_tb, st_oy, st_ox, st_kA, st_kB;           // st_kA / st_kB: scalar byte offsets of the DMA
+    {
+        const int tap = kt_begin / p.cchunks;
+        const int c0 = (kt_begin - tap * p.cchunks) * TK;
+        const int ta = tap / p.tap_nb;
+        st_tb = tap - ta * p.tap_nb;
+        st_oy = p.oy0 + ta * p.oys;
+        st_ox = p.ox0 + st_tb * p.oxs;
+        st_kA = c0 * 2;
+        st_kB = ((p.w0 + ta * p.wa + st_tb * p.wb) * p.Ncols * p.Cs + c0) * 2;
+    }
+    const int cs2 = p.Cs * 2;
+    int st_cleft = cs2 - st_kA;                                       // bytes of k left in this tap's channel run
+    auto enter_tap = [&]() {
+        const int shift = ((st_oy * p.Ws + st_ox) * p.lda) * 2;
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < G::NA; ++j) {
+                const int iy = (a_yx[h][j] >> 16) + st_oy;
+                const int ix = (int)(short)(a_yx[h][j] & 0xffff) + st_ox;
+                const bool ok = ((unsigned)iy < (unsigned)p.Hs) & ((unsigned)ix < (unsigned)p.Ws);
+                a_voff[h][j] = ok ? a_base[h][j] + shift : (int)OOB;
+            }
+    };
+    int st_dead = 0;                                                   // 0, or OOB once no k-tile is left: OR-ed into every offset
+    auto advance = [&]() {                                             // cursor -> next k-tile (all branches uniform)
+        --st_left;
+        st_kA += TK * 2;
+        st_kB += TK * 2;
+        st_cleft -= TK * 2;
+        if (st_left <= 0) {
+            st_dead = (int)OOB;                                        // every further piece is a zero fill of a free unit
+        } else if (st_cleft <= 0) {                                    // next tap
+            st_kA = 0;
+            st_cleft = cs2;
+            const int nc2 = p.Ncols * cs2;
+            if (++st_tb == p.tap_nb) {
+                st_tb = 0;
+                st_oy += p.oys;
+                st_ox = p.ox0;
+                st_kB += (p.wa - (p.tap_nb - 1) * p.wb) * nc2 - cs2;
+            } else {
+                st_ox += p.oxs;
+                st_kB += p.wb * nc2 - cs2;
+            }
+            enter_tap();
+        }
+    };
+    // LDS destinations of this wave's pieces: one scalar base per region, the slot toggled by XOR, the rest immediates
+    lds_char* const L = (lds_char*)smem;                               // LDS-address-space view of the one LDS object
+    int dA = (8 * wave) * ROWB;                                        // byte offsets in L of the CURRENT slot
+    int dB = G::B_OFF + (wave >> 2) * (2 * G::BSLOT) + (8 * (wave & 3)) * ROWB;
+    int sA = G::ASLOT, sB = G::BSLOT;                                  // current slot -> other slot (sign flips per k-tile)
+    auto issueA = [&](int other, auto H) {                             // `other`: literal 0 / 1 = current / other slot
+        constexpr int h = decltype(H)::value;
+        const int d = (other ? dA + sA : dA) + h * 64 * ROWB;
+#pragma unroll
+        for (int j = 0; j < G::NA; ++j) dma16l(rsA, a_voff[h][j] | st_dead, st_kA, L + (d + j * 2 * G::ASLOT));
+    };
+    auto issueB = [&](int other, auto H) {
+        constexpr int h = decltype(H)::value;
+        const int d = (other ? dB + sB : dB) + h * 32 * ROWB;
+#pragma unroll
+        for (int j = 0; j < G::NB; ++j) dma16l(rsB, b_voff[h][j] | st_dead, st_kB, L + (d + j * 4 * G::BSLOT));
+    };
+
+    // ---- fragment addresses: A row = l31 (+ mb*32) of wave row wr, B column = l31 (+ nb*32) of wave column wc, 8 consecutive
+    // k = chunk 2 ks + half at slot chunk ^ ((row >> 1) & 7) ------------------------------------------------------------
+    const int fsw = (l31 >> 1) & 7;
+    int fa[4], fb[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+        const int so = ((2 * ks + half) ^ fsw) * 16;
+        fa[ks] = wr * (2 * G::ASLOT) + l31 * ROWB + so;
+        fb[ks] = G::B_OFF + wc * (2 * G::BSLOT) + l31 * ROWB + so;
+    }
+    auto lds16 = [&](int off) -> bf16x8 { return *(const __attribute__((address_space(3))) bf16x8*)(L + off); };
+
+    bf16x8 fA[2][4], fB0[4], fB1[4];
+    auto rdA = [&](auto MH) {
+        constexpr int mh = decltype(MH)::value;
+#pragma unroll
+        for (int mbi = 0; mbi < 2; ++mbi)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) fA[mbi][ks] = lds16(fa[ks] + (mh * 64 + mbi * 32) * ROWB);
+    };
+    auto rdB = [&](auto NBK, bf16x8 (&f)[4]) {
+        constexpr int nb = decltype(NBK)::value;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) f[ks] = lds16(fb[ks] + nb * 32 * ROWB);
+    };
+    auto mma = [&](auto MH, auto NBK, const bf16x8 (&fbv)[4]) {
+        constexpr int mh = decltype(MH)::value, nb = decltype(NBK)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int mbi = 0; mbi < 2; ++mbi)
+                acc[2 * mh + mbi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fA[mbi][ks], fbv[ks], acc[2 * mh + mbi][nb], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    // ---- prologue: k-tile 0 complete + UA0 / UB0 of k-tile 1 in flight ------------------------------------------------
+    enter_tap();
+    issueA(0, I0{});
+    issueB(0, I0{});
+    issueB(0, I1{});
+    issueA(0, I1{});
+    advance();
+    issueA(1, I0{});
+    issueB(1, I0{});
+    wait_vm<G::NA + G::NB>();
+    q_barrier();
+    if (grp == 1) q_barrier();                       // stagger: this group runs one barrier behind
+    for (int t = 0; t < nkt; ++t) {
+        // P1
+        rdB(I0{}, fB0);
+        __builtin_amdgcn_sched_barrier(0);
+        rdA(I0{});
+        __builtin_amdgcn_sched_barrier(0);
+        issueB(1, I1{});
+        wait_vm<G::VMC>();
+        q_barrier();
+        mma(I0{}, I0{}, fB0);
+        q_barrier();
+        // P2
+        rdB(I1{}, fB1);
+        __builtin_amdgcn_sched_barrier(0);
+        issueA(1, I1{});
+        advance();
+        wait_vm<G::VMC>();
+        q_barrier();
+        mma(I0{}, I1{}, fB1);
+        q_barrier();
+        // P3
+        rdA(I1{});
+        __builtin_amdgcn_sched_barrier(0);
+        issueA(0, I0{});
+        q_barrier();
+        mma(I1{}, I1{}, fB1);
+        q_barrier();
+        // P4
+        issueB(0, I0{});
+        wait_vm<G::VMC>();
+        q_barrier();
+        mma(I1{}, I0{}, fB0);
+        q_barrier();
+        // the other slot becomes the current one
+        dA += sA;
+        dB += sB;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) { fa[ks] += sA; fb[ks] += sB; }
+        sA = -sA;
+        sB = -sB;
+    }
+    if (grp == 0) q_barrier();
+    wait_vm<0>();                                    // zero fills issued past the last k-tile: drain before reusing the LDS
+    __syncthreads();
+
+    // ---- epilogue: four passes, pass mb stages rows wr*128 + mb*32 .. +31 of every wave row ---------------------------
+    float* Cs = reinterpret_cast<float*>(smem);
+    constexpr int TPR = G::BN / 8, RPS = 512 / TPR;   // threads per staged row, rows per sweep
+    const int c = (tid % TPR) * 8;
+    const int col = n0 + c;
+    const int rl0 = tid / TPR;
+    const bool cok = col < p.Ncols;
+    float bv[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+    if (p.bias && cok) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + col);
+        const float4 b1 = *reinterpret_cast<const float4*>(p.bias + col + 4);
+        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+    }
+    const bool lean = p.identity_rows && !p.res_cls && !p.replicate && p.nsplit == 1;
+    const bool hr = p.res != nullptr, hm = p.mask != nullptr, h2 = p.D2 != nullptr, rpost = p.res_post != 0;
+    const int kind = !lean ? 0 : ((!hr && !hm && !h2) ? 1 : ((hr && !rpost && !hm && !h2) ? 2 : ((!hr && hm && !h2) ? 3 : ((hr && rpost && !hm && h2) ? 4 : ((hr && !rpost && hm && !h2) ? 5 : 0)))));
+    const float slope = (p.act == DPIG_ACT_NONE) ? 1.f : ((p.act == DPIG_ACT_RELU) ? 0.f : p.alpha);
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        if (mb) __syncthreads();
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+                Cs[(wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * G::LDCQ + wc * 64 + nb * 32 + l31] = acc[mb][nb][r];
+        __syncthreads();
+        if (!cok) continue;
+#pragma unroll 2
+        for (int it = 0; it < G::RP / RPS; ++it) {
+            const int rl = rl0 + RPS * it;
+            const int row = m0 + (rl >> 5) * 128 + mb * 32 + (rl & 31);
+            if (row >= p.M) continue;
+            const float4 v0 = *reinterpret_cast<const float4*>(&Cs[rl * G::LDCQ + c]);
+            const float4 v1 = *reinterpret_cast<const float4*>(&Cs[rl * G::LDCQ + c + 4]);
+            if (p.nsplit > 1) {
+                float* pp = p.partial + ((long)blockIdx.z * p.M + row) * p.Ncols + col;
+                *reinterpret_cast<float4*>(pp) = v0;
+                *reinterpret_cast<float4*>(pp + 4) = v1;
+                continue;
+            }
+            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            switch (kind) {                                           // workgroup-uniform
+                case 1: q_row8<false, false, false, false>(p, row, col, v, bv, slope); break;   // bias + activation
+                case 2: q_row8<true, false, false, false>(p, row, col, v, bv, slope); break;    // + residual before the activation
+                case 3: q_row8<false, false, true, false>(p, row, col, v, bv, slope); break;    // dgrad * activation mask
+                case 4: q_row8<true, true, false, true>(p, row, col, v, bv, slope); break;      // res-block tail
+                case 5: q_row8<true, false, true, false>(p, row, col, v, bv, slope); break;     // (dgrad + accum) * mask
+                default: epi8(p, row, col, v, bv); break;
+            }
+        }
+    }
+}
+
+// ================================================================================================
+// host side
+// ================================================================================================
+static int g_q_mode = -1;      // 0 off, 1 automatic, 2 whenever the layer is legal for the kernel (tests)
+static int g_q_variant = 0;    // 0 automatic, 1 = 256 x 256, 2 = 512 x 128 (measurements)
+static double g_q_mineff = 0.8;
+
+static void q_init() {
+    if (g_q_mode >= 0) return;
+    const char* e = getenv("DPIG_BF16_Q");
+    g_q_mode = e ? atoi(e) : 1;
+    const char* v = getenv("DPIG_BF16_Q_VARIANT");
+    g_q_variant = v ? atoi(v) : 0;
+    const char* m = getenv("DPIG_BF16_Q_MINEFF");
+    if (m) g_q_mineff = atof(m);
+}
+
+// Fraction of the launched MFMA work that is real when `tiles` tiles of bm x bn run one per CU in whole rounds.
+static double q_eff(long M, long N, int bm, int bn) {
+    const long tiles = (long)cdiv(M, bm) * cdiv(N, bn);
+    const long rounds = (tiles + kNumCU - 1) / kNumCU;
+    return (double)M * (double)N / ((double)rounds * kNumCU * bm * bn);
+}
+
+// 1 = launched on the large-tile kernel, 0 = not this layer's case (the caller continues with the 128 x 128 kernels), < 0 = error
+int bq_try(BGParams& p, hipStream_t st) {
+    q_init();
+    if (!g_q_mode) return 0;
+    if (p.stats || (p.Cs % TK) || p.Hs >= 16384 || p.Ws >= 16384) return 0;
+    const int ktiles = p.ntaps * (p.Cs / TK);
+    if (ktiles < 2) return 0;
+    const double e1 = q_eff(p.M, p.Ncols, 256, 256), e2 = q_eff(p.M, p.Ncols, 512, 128);
+    int variant = g_q_variant ? g_q_variant : (e2 > e1 * 1.05 ? 2 : 1);
+    if (g_q_mode == 1) {
+        if (p.nsplit > 1) return 0;                      // the split-K plan of the 128 x 128 family wins on small layers
+        if ((variant == 1 ? e1 : e2) < g_q_mineff) return 0;
+    }
+    const int bm = variant == 1 ? 256 : 512, bn = variant == 1 ? 256 : 128;
+    BGParams q = p;
+    q.mtiles = cdiv(p.M, bm);
+    q.ntiles = cdiv(p.Ncols, bn);
+    q.cchunks = p.Cs / TK;
+    q.ktiles = ktiles;
+    q.nsplit = 1;
+    q.tiles_per_split = ktiles;
+    dim3 grid(q.mtiles * q.ntiles, 1, 1), block(512);
+    if (variant == 1) hipLaunchKernelGGL((bq_kernel<2, 4>), grid, block, 0, st, q);
+    else hipLaunchKernelGGL((bq_kernel<4, 2>), grid, block, 0, st, q);
+    const int rc = check_launch("bq_kernel");
+    return rc ? rc : 1;
+}
+
+}  // namespace bfk
+}  // namespace dpig
+
+// Large-tile kernel selection (0 = never, 1 = automatic [default; DPIG_BF16_Q], 2 = whenever legal) and tile variant
+// (0 = automatic, 1 = 256 x 256, 2 = 512 x 128): for tests and measurements.
+extern "C" int dpig_conv_bf16_set_large_tile(int mode, int variant) {
+    if (mode < 0 || mode > 2 || variant < 0 || variant > 2) return dpig::fail(DPIG_EINVAL, "large-tile mode / variant out of range");
+    dpig::bfk::q_init();
+    dpig::bfk::g_q_mode = mode;
+    dpig::bfk::g_q_variant = variant;
+    return DPIG_OK;
+}

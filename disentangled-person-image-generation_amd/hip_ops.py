@@ -539,6 +539,12 @@ def conv2d_wgrad(x, dy, wshape, stride=1, upsample2x=False, out=None, beta=0.0, 
 
 
 # ---- bf16-storage convolutions ('bf16' mode) ---------------------------------------------------------------------
+def set_large_tile(mode=1, variant=0):
+    """Tile family of the bf16-storage forward / dgrad convs (dpig_conv_bf16_set_large_tile): mode 0 = 128 x 128 kernels
+    only, 1 = automatic, 2 = the 8-wave large-tile kernels wherever legal; variant 0 = automatic, 1 = 256 x 256, 2 = 512 x 128."""
+    check(lib().dpig_conv_bf16_set_large_tile(int(mode), int(variant)), "conv_bf16_set_large_tile")
+
+
 def _f32_mode():
     """Context: run the fp32-tensor entry points with exact fp32 products (the thin-layer fall-back of 'bf16' mode)."""
     class _Ctx(object):

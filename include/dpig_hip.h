@@ -149,6 +149,12 @@ int dpig_conv2d_dgrad_bf16(const DpigConvDesc* d, const uint16_t* dy, const uint
  * accumulated in fp32 on the matrix pipe from the dy tiles the launch stages anyway. */
 int dpig_conv2d_wgrad_bf16(const DpigConvDesc* d, const uint16_t* x, const uint16_t* dy, float* dw, float beta,
                            float* db, float beta_b, void* ws, size_t ws_bytes, void* stream);
+/* Tile family of dpig_conv2d_fwd_bf16 / _dgrad_bf16 (csrc/dpig_conv_bf16_q.hip): large layers run on 8-wave workgroups
+ * with 256 x 256 or 512 x 128 block tiles (one workgroup per CU, counted-vmcnt LDS-DMA pipeline), the rest on the
+ * 128 x 128 kernels.  mode 0 = 128 x 128 only, 1 = automatic (default; environment DPIG_BF16_Q), 2 = large tiles whenever
+ * the layer is legal for them (channel count a multiple of 64; tests).  variant 0 = automatic, 1 = 256 x 256, 2 = 512 x 128.
+ * Results do not depend on the choice beyond fp32 summation order.  Process-wide; not stream-ordered. */
+int dpig_conv_bf16_set_large_tile(int mode, int variant);
 /* The thin layers of 'bf16' mode on the vector-ALU kernels (csrc/dpig_thin.hip) with their WIDE tensor stored as bf16;
  * the 3-channel image side, the fp32 HWIO filter and the filter gradient stay fp32:
  *   K == 3 (3x3 s1, the generator's image conv models.py:573):        x / dx bf16 [.., C],   y / dy fp32 [.., 3]

@@ -1,0 +1,160 @@
+"""GPU parity of the large-tile bf16-storage gather-GEMM (csrc/dpig_conv_bf16_q.hip: 8-wave workgroups, 256 x 256 and
+512 x 128 block tiles, counted-vmcnt LDS-DMA pipeline across raw barriers) through dpig_conv2d_fwd_bf16 / _dgrad_bf16.
+
+The kernels are forced (dpig_conv_bf16_set_large_tile(2, variant)) onto small layers so that every structural edge is hit
+against the fp64 oracle on the bf16-rounded operands: partial row tiles, partial column tiles, odd and even k-tile counts,
+two k-tiles only, halo taps, stride 2, 5x5, 1x1, every fused epilogue (lean bodies and the generic one).  At BASELINE
+sizes the result must equal the 128 x 128 kernels' bit for bit (same products, same k order, fp32 accumulation) and must
+be repeatable launch after launch (the DMA pipeline's hazards are timing dependent, a race would show up as a difference).
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1) * scale
+
+
+def _r(t):
+    return t.float().to(BF).double()
+
+
+def _close_bf16(got, ref):
+    assert got.dtype == BF
+    ref = ref.double()
+    err = (got.double().cpu() - ref).abs()
+    bound = ref.abs() * 2.0 ** -8 + 2e-5 * max(ref.abs().max().item(), 1e-6)
+    bad = err > bound
+    assert not bad.any(), "%d elements off; worst err %.3e (ref scale %.3e)" % (int(bad.sum()), err.max().item(), ref.abs().max().item())
+
+
+@pytest.fixture(params=[1, 2], ids=["256x256", "512x128"])
+def large_tile(request):
+    import dpig_amd.hip_ops as H
+    H.set_large_tile(2, request.param)
+    yield request.param
+    H.set_large_tile(1, 0)
+
+
+# (N, H, W, C, K, k, stride)
+FWD_SHAPES = [
+    (3, 24, 20, 128, 192, 3, 1),    # 1440 rows (partial row tile both variants), 18 k-tiles
+    (2, 16, 12, 64, 264, 3, 1),     # 264 columns: a partial column tile of 8; 9 k-tiles (odd)
+    (2, 33, 17, 64, 128, 5, 2),     # 5x5 stride 2 (TF pads (1,2) / (2,2)), 25 k-tiles
+    (2, 16, 16, 192, 64, 1, 1),     # 1x1: 3 k-tiles
+    (1, 16, 16, 128, 64, 1, 1),     # 1x1: exactly 2 k-tiles (prologue + one loop trip + drain)
+    (2, 9, 7, 64, 72, 3, 2),        # odd input, stride 2, tiny M (126 rows)
+    (5, 3, 3, 640, 64, 3, 1),       # 3x3 image: every tap is mostly halo, 90 k-tiles
+]
+
+
+@pytest.mark.parametrize("shape", FWD_SHAPES)
+def test_forward_against_oracle(dev, large_tile, shape):
+    import dpig_amd.hip_ops as H
+    from oracle import ops as O
+    N, Hh, W, C, K, k, s = shape
+    x = _rand((N, Hh, W, C), 1)
+    w = _rand((k, k, C, K), 2, 0.2)
+    b = _rand((K,), 3)
+    ref = O.leaky_relu(O.conv2d_same(_r(x), _r(w), b.float().double(), s), 0.2)
+    got = H.conv2d_fwd(x.float().to(dev).to(BF), w.float().to(dev), b.float().to(dev), stride=s, act=2, alpha=0.2)
+    _close_bf16(got, ref)
+
+
+def test_fused_epilogues(dev, large_tile):
+    import dpig_amd.hip_ops as H
+    from oracle import ops as O
+    N, Hh, W, C, K = 3, 24, 20, 128, 192
+    x = _rand((N, Hh, W, C), 1)
+    w = _rand((3, 3, C, K), 2, 0.2)
+    b = _rand((K,), 3)
+    res = _rand((N, Hh, W, K), 4)
+    xd, wd, bd, rd = x.float().to(dev).to(BF), w.float().to(dev), b.float().to(dev), res.float().to(dev).to(BF)
+    xr = _r(x).requires_grad_(True)
+    conv0 = O.conv2d_same(xr, _r(w), None, 1)
+    conv = conv0.detach() + b.float().double()
+    # no bias, no activation
+    _close_bf16(H.conv2d_fwd(xd, wd, None), conv0.detach())
+    # residual before the activation
+    _close_bf16(H.conv2d_fwd(xd, wd, bd, act=1, residual=rd), O.relu(conv + _r(res)))
+    # the res-block tail: act -> out_act, (stored act) + skip -> out
+    out, out_act = torch.empty((N, Hh, W, K), dtype=BF, device=dev), torch.empty((N, Hh, W, K), dtype=BF, device=dev)
+    H.conv2d_fwd(xd, wd, bd, act=1, residual=rd, res_after_act=True, out=out, out_act=out_act)
+    _close_bf16(out_act, O.relu(conv))
+    assert torch.equal(out.cpu(), (out_act.float() + rd.float()).to(BF).cpu())
+    # post-activation residual WITHOUT the second output (generic epilogue body)
+    _close_bf16(H.conv2d_fwd(xd, wd, bd, act=1, residual=rd, res_after_act=True), O.relu(conv) + _r(res))
+    # class-indexed residual (tiled-embedding collapse, fp32 [N, 9, K]; generic body)
+    e9 = _rand((N, 9, K), 5).float()
+    yy, xx = torch.meshgrid(torch.arange(Hh), torch.arange(W), indexing="ij")
+    cls = torch.where(yy == 0, 0, torch.where(yy == Hh - 1, 2, 1)) * 3 + torch.where(xx == 0, 0, torch.where(xx == W - 1, 2, 1))
+    ref = O.relu(conv + e9.double()[:, cls.reshape(-1), :].reshape(N, Hh, W, K))
+    _close_bf16(H.conv2d_fwd(xd, wd, bd, act=1, residual=e9.to(dev), res_class=True), ref)
+    # channel slices of wider buffers on both sides
+    xbig = torch.zeros((N, Hh, W, C + 64), dtype=BF, device=dev)
+    xbig[..., 64:] = xd
+    ybig = torch.full((N, Hh, W, K + 64), 7.0, dtype=BF, device=dev)
+    H.conv2d_fwd(xbig[..., 64:], wd, bd, act=1, out=ybig[..., :K])
+    _close_bf16(ybig[..., :K], O.relu(conv))
+    assert (ybig[..., K:] == 7.0).all()
+    # stride-1 dgrad: plain, * mask, (+ accum) * mask   (Cs = K = 192, columns = C = 128)
+    dy = _rand((N, Hh, W, K), 6)
+    conv0.backward(_r(dy))
+    dyd = dy.float().to(dev).to(BF)
+    acc, m = _rand((N, Hh, W, C), 7), _rand((N, Hh, W, C), 8)
+    ad, md = acc.float().to(dev).to(BF), m.float().to(dev).to(BF)
+    _close_bf16(H.conv2d_dgrad(dyd, wd, (N, Hh, W, C)), xr.grad)
+    _close_bf16(H.conv2d_dgrad(dyd, wd, (N, Hh, W, C), mask=md, act=1), xr.grad * (_r(m) > 0))
+    _close_bf16(H.conv2d_dgrad(dyd, wd, (N, Hh, W, C), accum=ad, mask=md, act=2, alpha=0.2),
+                (xr.grad + _r(acc)) * torch.where(_r(m) > 0, 1.0, 0.2))
+    _close_bf16(H.conv2d_dgrad(dyd, wd, (N, Hh, W, C), accum=ad), xr.grad + _r(acc))
+
+
+def test_upsampled_1x1(dev, large_tile):
+    """nearest-2x upsample + 1x1 conv computed at low resolution with the 2 x 2 replicating epilogue (models.py:569-570)."""
+    import dpig_amd.hip_ops as H
+    from oracle import ops as O
+    N, Hh, W, C, K = 2, 12, 10, 128, 64
+    x = _rand((N, Hh, W, C), 3)
+    w1 = _rand((1, 1, C, K), 4, 0.3)
+    b = _rand((K,), 5)
+    ref = O.relu(O.conv2d_same(O.upsample2x(_r(x)), _r(w1), b.float().double(), 1))
+    got = H.conv2d_fwd(x.float().to(dev).to(BF), w1.float().to(dev), b.float().to(dev), act=1, upsample2x=True)
+    _close_bf16(got, ref)
+
+
+@pytest.mark.parametrize("layer", [(8, 128, 128, 256, 256), (8, 256, 256, 128, 128), (16, 128, 64, 256, 256),
+                                   (8, 64, 64, 768, 768), (56, 64, 64, 128, 128)])
+def test_full_size_layers_equal_the_128_tile_kernels_bit_for_bit(dev, layer):
+    """BASELINE configs[1]/[3] layer sizes (3x3 stride 1).  Both tile families form the same bf16 products and add them in
+    the same k order in fp32, so forward (+ bias + ReLU) and dgrad (* mask) must agree BIT FOR BIT, for both large-tile
+    variants, and every launch of the large-tile kernel must reproduce itself (five launches)."""
+    import dpig_amd.hip_ops as H
+    N, Hh, W, C, K = layer
+    g = torch.Generator(device="cpu").manual_seed(11)
+    x = (torch.rand((N, Hh, W, C), generator=g) * 2 - 1).to(dev).to(BF)
+    w = ((torch.rand((3, 3, C, K), generator=g) * 2 - 1) * 0.05).to(dev)
+    b = (torch.rand((K,), generator=g) * 2 - 1).to(dev)
+    dy = (torch.rand((N, Hh, W, K), generator=g) * 2 - 1).to(dev).to(BF)
+    m = (torch.rand((N, Hh, W, C), generator=g) * 2 - 1).to(dev).to(BF)
+    w._dpig_shadow = H.filter_shadows(w)
+    try:
+        H.set_large_tile(0, 0)
+        y0 = H.conv2d_fwd(x, w, b, act=1)
+        dx0 = H.conv2d_dgrad(dy, w, (N, Hh, W, C), mask=m, act=1)
+        for variant in (1, 2):
+            H.set_large_tile(2, variant)
+            for rep in range(5):
+                y = H.conv2d_fwd(x, w, b, act=1)
+                dx = H.conv2d_dgrad(dy, w, (N, Hh, W, C), mask=m, act=1)
+                assert torch.equal(y, y0), "forward differs (variant %d, launch %d): %d elements" % (
+                    variant, rep, int((y != y0).sum()))
+                assert torch.equal(dx, dx0), "dgrad differs (variant %d, launch %d): %d elements" % (
+                    variant, rep, int((dx != dx0).sum()))
+    finally:
+        H.set_large_tile(1, 0)
