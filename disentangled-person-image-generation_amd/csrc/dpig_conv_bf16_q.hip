@@ -9,34 +9,52 @@
 // nothing in the loop ever waits for the DMA queue to drain:
 //  * two LDS slots (k-tiles t, t+1) of [A tile | B tile], rows of 128 B = 64 bf16 of k, lane-linear DMA images with the
 //    bank swizzle on the SOURCE side (slot s of row r holds chunk s ^ ((r >> 1) & 7)), fragments by ds_read_b128;
-//  * a k-tile is FOUR phases, one 64 x 32 accumulator quadrant (8 MFMAs) each:
-//        P1  read B[nb0] (4) + A[mh0] (8)   stage UB1(t+1)   MFMA (mh0, nb0)
-//        P2  read B[nb1] (4)                stage UA1(t+1)   MFMA (mh0, nb1)
-//        P3  read A[mh1] (8)                stage UA0(t+2)   MFMA (mh1, nb1)
-//        P4  --                             stage UB0(t+2)   MFMA (mh1, nb0)
-//    a staging unit Uxh = the rows the waves read in ONE phase: UA0 = rows wr*128 + 0..63 of every wave row, UA1 = rows
-//    wr*128 + 64..127, UB0 / UB1 = columns wc*64 + 0..31 / 32..63 of every wave column;
-//  * a phase is   { ds_reads ; DMA issue ; s_waitcnt vmcnt(N) ; s_barrier ; 8 MFMAs at s_setprio 1 ; s_barrier }
-//    with RAW barriers (no fence: an LDS-DMA is a pending LDS write, __syncthreads() would drain it) and the two wave
-//    groups (waves 0-3 / 4-7 = the two waves of each SIMD) staggered by one barrier, so that one wave of every SIMD is in
-//    its MFMA cluster while its partner reads fragments and issues DMA ("ping-pong");
-//  * hazards, by construction of the table above (p = phase count, b = barrier count; group 0 runs L(p) in
-//    [b(2p-2), b(2p-1)] and M(p) in [b(2p-1), b(2p)], group 1 one barrier later):
+//  * a k-tile is TWO phases of 16 MFMAs (a 64 x 64 half of the wave's accumulators) each:
+//        PA  read B[nb0], B[nb1] (8) + A[mh0] (8)   stage UA1(t+1)                  MFMA (mh0, nb0), (mh0, nb1)
+//        PB  read A[mh1] (8)                        stage UA0, UB0, UB1 of (t+2)    MFMA (mh1, nb0), (mh1, nb1)
+//    a staging unit = the rows the waves read in ONE phase: UA0 = rows 0..63 of every wave row's 128, UA1 = rows
+//    64..127, UB0 / UB1 = columns 0..31 / 32..63 of every wave column's 64;
+//  * a phase is   { ds_reads ; DMA issue ; s_waitcnt vmcnt(N) ; s_waitcnt lgkmcnt(0) ; s_barrier ; 16 MFMAs at
+//    s_setprio 1 ; s_barrier }   with RAW barriers (no fence: an LDS-DMA is a pending LDS write, __syncthreads() would
+//    drain it) and the two wave groups (waves 0-3 / 4-7 = the two waves of each SIMD) staggered by one barrier, so that
+//    one wave of every SIMD is in its MFMA cluster while its partner reads fragments and issues DMA ("ping-pong").
+//    Measured on this kernel (scripts/ubench/knockout_q.sh): each barrier interval costs ~120-140 cycles on top of its
+//    MFMA cluster whatever the cluster's length, so the clusters are 16 MFMAs (512 cycles), not 8; removing the barriers
+//    altogether is SLOWER (the groups stop being complementary); the counted waits cost nothing;
+//  * hazards (p = phase count, b = barrier count; group 0 runs L(p) in [b(2p-2), b(2p-1)] and M(p) in [b(2p-1), b(2p)],
+//    group 1 one barrier later):
 //      RAW  a unit is read one phase AFTER the phase whose counted vmcnt retires it: every wave waits for ITS pieces
 //           before the first barrier of phase r, readers start behind that barrier in phase r + 1.  N = 2 (NA + NB)
-//           pieces = the four units issued after the one being retired;
-//      WAR  a unit is re-staged >= 2 phases after its last read: the readers' fragments have returned (their MFMA
-//           cluster consumed them) before the barrier that precedes the issuing phase of either group;
+//           pieces = the units issued after the one being retired (UA1(t) is retired in PA(t) behind {UA0, UB0, UB1}
+//           (t+1) and UA1(t+1); {UA0, UB0, UB1}(t+1) in PB(t) behind UA1(t+1) and the three units of t+2);
+//      WAR  a unit is re-staged ONE phase after its last read: the reading wave's lgkmcnt(0) sits before the first
+//           barrier of its phase, and both groups' issuing phases lie behind that barrier (a phase's DMA issue follows
+//           the other group's first barrier of the previous phase);
 //    past the last k-tile the same DMA instructions are issued with out-of-range offsets (zero fill of a free unit), so
 //    the counts stay uniform; the queue is drained once, before the epilogue reuses the LDS.
-// Epilogue: the 256 KB of accumulators go through LDS in four passes (one 32-row block of every wave per pass) into the
-// same fused row-contiguous epilogue as the 128 x 128 kernels (bias, activation, residual before / after, second
-// output, dgrad mask).
+// Epilogue: the MFMAs are fed filter-fragment first, so the accumulators hold D^T and each wave transposes its own 128 x 64
+// sub-tile through 8.5 KB of LDS of its own (no workgroup barrier) into the fused row-contiguous epilogue of the family
+// (bias, activation, residual before / after, second output, dgrad mask); the rare flag combinations (class-indexed
+// residual, 2 x 2 replication) go through the generic per-element epilogue behind workgroup barriers.
 #include <stdlib.h>
 #include <string.h>
 #include <type_traits>
 #include "dpig_bf16_common.h"
 #include "dpig_conv_plan.h"
+
+#ifdef DPIG_TRACE   // dev aid (scripts/ubench/trace_q.py; never in the shipped build): s_memtime segment sums per wave
+__device__ unsigned long long dpig_bq_prof[256 * 8 * 16];
+extern "C" int dpig_debug_bq_prof_read(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(dpig_bq_prof), sizeof(unsigned long long) * n);
+}
+#define QT_DECL unsigned long long qt_last = 0, qt_sum[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; const unsigned long long qt_begin = __builtin_amdgcn_s_memtime();
+#define QT_START() do { qt_last = __builtin_amdgcn_s_memtime(); } while (0)
+#define QT_SEG(i) do { const unsigned long long qt_now = __builtin_amdgcn_s_memtime(); qt_sum[i] += qt_now - qt_last; qt_last = qt_now; } while (0)
+#else
+#define QT_DECL
+#define QT_START() do { } while (0)
+#define QT_SEG(i) do { } while (0)
+#endif
 
 namespace dpig {
 namespace bfk {
@@ -58,6 +76,15 @@ struct QGeom {
 
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+// Knock-out builds (scripts/ubench/knockout_q.sh; dev aid, never in the shipped library, results wrong by construction):
+// DPIG_QKO_WAIT no counted vmcnt in the loop, _DMA no LDS-DMA in the loop, _LDS no fragment reads in the loop, _BAR no
+// barriers in the loop, _MFMA one MFMA per phase, _EPI no epilogue, _PRIO no s_setprio.
+template <int N>
+__device__ __forceinline__ void loop_wait_vm() {
+#if !defined(DPIG_QKO_WAIT) && !defined(DPIG_QKO_DMA)
+    wait_vm<N>();
+#endif
+}
 
 typedef __attribute__((address_space(3))) char lds_char;
 __device__ __forceinline__ void dma16l(__amdgpu_buffer_rsrc_t rs, int voff, int soff, lds_char* lds_dst) {
@@ -69,38 +96,89 @@ __device__ __forceinline__ void q_barrier() {
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
 }
+__device__ __forceinline__ void loop_barrier() {
+#ifdef DPIG_QKO_BAR
+    __builtin_amdgcn_sched_barrier(0);
+#else
+    q_barrier();
+#endif
+}
 
-// one output row segment of 8 columns: the flag combinations the models produce as straight-line bodies, the rest by epi8
+// ---- wave-private epilogue ---------------------------------------------------------------------------------------------
+// The k-loop feeds the filter fragment as the MFMA's FIRST operand, so an accumulator block holds D^T: lane (l31, half)
+// owns output PIXEL l31 of its 32-pixel block and the channels 8q + 4*half + 0..3 (q = 0..3) of its 32-channel block --
+// four runs of 4 consecutive fp32 = four 16-byte LDS stores per block instead of sixteen 4-byte ones.  Each wave
+// transposes its own 32 pixels x 64 channels (8.5 KB of LDS of its own; the LDS executes one wave's instructions in order,
+// so no barrier and no cross-wave wait), then lane -> (pixel = 8 i + lane / 8, 8 consecutive channels = lane % 8) applies
+// bias / residual / activation (mask) / second output with 16-byte accesses: 8 lanes cover one pixel's 128 contiguous
+// bytes, an instruction covers 8 full lines.  (Measured alternatives: staging the whole tile as fp32 rows behind
+// workgroup barriers with 4-byte LDS stores cost 13 % of a 256 x 256 x 2304 tile; a register-only epilogue with
+// v_permlane32_swap + per-pixel 16-byte stores is address-coalescer bound: 32 segments per instruction.)
+constexpr int WEP_ROW = 64 * 4 + 16;              // bytes per staged pixel row (+16: the 8 lanes of a store group hit 8 bank groups)
+constexpr int WEP_BYTES = 32 * WEP_ROW;           // per wave
 template <bool HAS_RES, bool RES_POST, bool HAS_MASK, bool HAS_D2>
-__device__ __forceinline__ void q_row8(const BGParams& p, long r0, int col, float (&v)[8], const float (&bv)[8], float slope) {
-    bf16_t* dp = p.D + r0 * p.ldd + col;
-    float rv[8];
+__device__ __forceinline__ void q_epilogue_wave(const BGParams& p, f32x16 (&acc)[4][2], lds_char* W, int row_base, int cb0,
+                                                int lane, float slope) {
+    const int l31 = lane & 31, half = lane >> 5;
+    const int c8 = (lane & 7) * 8, prow = lane >> 3;
+    const int col = cb0 + c8;
+    const bool cok = col < p.Ncols;
+    float bv[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) v[e] += bv[e];
-    if (HAS_RES) unpack8(*reinterpret_cast<const uint4*>(p.res + r0 * p.ldres + col), rv);
-    if (HAS_RES && !RES_POST) {
-#pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+    for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+    if (p.bias && cok) {
+        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + col);
+        const float4 b1 = *reinterpret_cast<const float4*>(p.bias + col + 4);
+        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
     }
-    if (HAS_MASK) {
-        float mv[8];
-        unpack8(*reinterpret_cast<const uint4*>(p.mask + r0 * p.ldmask + col), mv);
+    typedef __attribute__((address_space(3))) f32x4 lds_f4;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] *= (mv[e] > 0.f) ? 1.f : slope;
-    } else {
+    for (int mb = 0; mb < 4; ++mb) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] = (v[e] > 0.f) ? v[e] : (v[e] * slope + 0.f);
-    }
-    if (HAS_D2) {
-        const uint4 o2 = pack8(v);
-        *reinterpret_cast<uint4*>(p.D2 + r0 * p.ldd2 + col) = o2;
-        if (HAS_RES && RES_POST) unpack8(o2, v);     // the sum is formed from the STORED (rounded) activation
-    }
-    if (HAS_RES && RES_POST) {
+        for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-        for (int e = 0; e < 8; ++e) v[e] += rv[e];
+            for (int q = 0; q < 4; ++q)
+                *(lds_f4*)(W + l31 * WEP_ROW + (nb * 32 + 8 * q + 4 * half) * 4) =
+                    f32x4{acc[mb][nb][4 * q], acc[mb][nb][4 * q + 1], acc[mb][nb][4 * q + 2], acc[mb][nb][4 * q + 3]};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int px = 8 * i + prow;
+            const f32x4 v0 = *(const lds_f4*)(W + px * WEP_ROW + c8 * 4);
+            const f32x4 v1 = *(const lds_f4*)(W + px * WEP_ROW + c8 * 4 + 16);
+            const long r0 = row_base + mb * 32 + px;
+            if (!cok || r0 >= p.M) continue;
+            float v[8] = {v0[0] + bv[0], v0[1] + bv[1], v0[2] + bv[2], v0[3] + bv[3], v1[0] + bv[4], v1[1] + bv[5], v1[2] + bv[6], v1[3] + bv[7]};
+            float rv[8];
+            if (HAS_RES) unpack8(*reinterpret_cast<const uint4*>(p.res + r0 * p.ldres + col), rv);
+            if (HAS_RES && !RES_POST) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += rv[e];
+            }
+            if (HAS_MASK) {
+                float mv[8];
+                unpack8(*reinterpret_cast<const uint4*>(p.mask + r0 * p.ldmask + col), mv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] *= (mv[e] > 0.f) ? 1.f : slope;
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] = (v[e] > 0.f) ? v[e] : (v[e] * slope + 0.f);
+            }
+            if (HAS_D2) {
+                const uint4 o2 = pack8(v);
+                *reinterpret_cast<uint4*>(p.D2 + r0 * p.ldd2 + col) = o2;
+                if (HAS_RES && RES_POST) unpack8(o2, v);             // the sum is formed from the STORED (rounded) activation
+            }
+            if (HAS_RES && RES_POST) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) v[e] += rv[e];
+            }
+#ifdef DPIG_QKO_STORE
+            { const uint4 o = pack8(v); if (o.x == 0x12345678u && o.y == 0x9abcdef0u) *reinterpret_cast<uint4*>(p.D + r0 * p.ldd + col) = o; }
+#else
+            *reinterpret_cast<uint4*>(p.D + r0 * p.ldd + col) = pack8(v);
+#endif
+        }
     }
-    *reinterpret_cast<uint4*>(dp) = pack8(v);
 }
 
 template <int WM, int WN>
@@ -259,20 +337,37 @@ __global__ __launch_bounds__(512, 2) void bq_kernel(const BGParams p) {
     auto mma = [&](auto MH, auto NBK, const bf16x8 (&fbv)[4]) {
         constexpr int mh = decltype(MH)::value, nb = decltype(NBK)::value;
         __builtin_amdgcn_sched_barrier(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_sched_barrier(0);
+#ifndef DPIG_QKO_PRIO
         __builtin_amdgcn_s_setprio(1);
+#endif
+#ifdef DPIG_QKO_MFMA
+        acc[2 * mh][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fbv[0], fA[0][0], acc[2 * mh][nb], 0, 0, 0);
+#else
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int mbi = 0; mbi < 2; ++mbi)
-                acc[2 * mh + mbi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fA[mbi][ks], fbv[ks], acc[2 * mh + mbi][nb], 0, 0, 0);
+                acc[2 * mh + mbi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fbv[ks], fA[mbi][ks], acc[2 * mh + mbi][nb], 0, 0, 0);
+#endif
+#ifndef DPIG_QKO_PRIO
         __builtin_amdgcn_s_setprio(0);
+#endif
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
 
-    // ---- prologue: k-tile 0 complete + UA0 / UB0 of k-tile 1 in flight ------------------------------------------------
+#ifdef DPIG_QKO_LDS
+#define LRD(x) do { } while (0)
+#else
+#define LRD(x) x
+#endif
+#ifdef DPIG_QKO_DMA
+#define LDMA(x) do { } while (0)
+#else
+#define LDMA(x) x
+#endif
+    QT_DECL
+    // ---- prologue: k-tile 0 complete + {UA0, UB0, UB1} of k-tile 1 in flight ------------------------------------------
     enter_tap();
     issueA(0, I0{});
     issueB(0, I0{});
@@ -281,42 +376,54 @@ __global__ __launch_bounds__(512, 2) void bq_kernel(const BGParams p) {
     advance();
     issueA(1, I0{});
     issueB(1, I0{});
-    wait_vm<G::NA + G::NB>();
+    issueB(1, I1{});
+    wait_vm<G::NA + 2 * G::NB>();
     q_barrier();
+#ifdef DPIG_QKO_LDS
+    rdB(I0{}, fB0); rdB(I1{}, fB1); rdA(I0{});
+#endif
     if (grp == 1) q_barrier();                       // stagger: this group runs one barrier behind
     for (int t = 0; t < nkt; ++t) {
-        // P1
-        rdB(I0{}, fB0);
+        // PA: rows mh0 x all 64 columns
+        QT_START();
+        LRD(rdB(I0{}, fB0));
+        LRD(rdB(I1{}, fB1));
         __builtin_amdgcn_sched_barrier(0);
-        rdA(I0{});
+        LRD(rdA(I0{}));
         __builtin_amdgcn_sched_barrier(0);
-        issueB(1, I1{});
-        wait_vm<G::VMC>();
-        q_barrier();
+        LDMA(issueA(1, I1{}));
+        QT_SEG(0);                                                   // issue of 16 reads + NA pieces
+        loop_wait_vm<G::VMC>();
+        QT_SEG(1);                                                   // counted vmcnt
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // fragments home BEFORE the barrier (WAR rule above)
+        QT_SEG(2);                                                   // fragments home
+        loop_barrier();
+        QT_SEG(3);                                                   // first barrier
         mma(I0{}, I0{}, fB0);
-        q_barrier();
-        // P2
-        rdB(I1{}, fB1);
-        __builtin_amdgcn_sched_barrier(0);
-        issueA(1, I1{});
-        advance();
-        wait_vm<G::VMC>();
-        q_barrier();
         mma(I0{}, I1{}, fB1);
-        q_barrier();
-        // P3
-        rdA(I1{});
+        QT_SEG(4);                                                   // 16 MFMAs issued
+        loop_barrier();
+        QT_SEG(5);                                                   // second barrier
+        // PB: rows mh1
+        LRD(rdA(I1{}));
         __builtin_amdgcn_sched_barrier(0);
-        issueA(0, I0{});
-        q_barrier();
-        mma(I1{}, I1{}, fB1);
-        q_barrier();
-        // P4
-        issueB(0, I0{});
-        wait_vm<G::VMC>();
-        q_barrier();
+        advance();
+        LDMA(issueA(0, I0{}));
+        LDMA(issueB(0, I0{}));
+        LDMA(issueB(0, I1{}));
+        QT_SEG(6);                                                   // issue of 8 reads + cursor + NA + 2 NB pieces
+        loop_wait_vm<G::VMC>();
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        QT_SEG(7);                                                   // vmcnt + fragments home
+        loop_barrier();
+        QT_SEG(3);
         mma(I1{}, I0{}, fB0);
-        q_barrier();
+        mma(I1{}, I1{}, fB1);
+        QT_SEG(4);
+        loop_barrier();
+        QT_SEG(5);
         // the other slot becomes the current one
         dA += sA;
         dB += sB;
@@ -325,63 +432,99 @@ __global__ __launch_bounds__(512, 2) void bq_kernel(const BGParams p) {
         sA = -sA;
         sB = -sB;
     }
+#undef LRD
+#undef LDMA
     if (grp == 0) q_barrier();
     wait_vm<0>();                                    // zero fills issued past the last k-tile: drain before reusing the LDS
     __syncthreads();
+#ifdef DPIG_TRACE
+    const unsigned long long qt_loop_end = __builtin_amdgcn_s_memtime();
+#endif
 
     // ---- epilogue: four passes, pass mb stages rows wr*128 + mb*32 .. +31 of every wave row ---------------------------
-    float* Cs = reinterpret_cast<float*>(smem);
-    constexpr int TPR = G::BN / 8, RPS = 512 / TPR;   // threads per staged row, rows per sweep
-    const int c = (tid % TPR) * 8;
-    const int col = n0 + c;
-    const int rl0 = tid / TPR;
-    const bool cok = col < p.Ncols;
-    float bv[8];
+#ifdef DPIG_QKO_EPI
+    if (p.M > 0) {      // keep the accumulators live, store nothing
+        float z = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) bv[e] = 0.f;
-    if (p.bias && cok) {
-        const float4 b0 = *reinterpret_cast<const float4*>(p.bias + col);
-        const float4 b1 = *reinterpret_cast<const float4*>(p.bias + col + 4);
-        bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) z += acc[i][j][0] + acc[i][j][15];
+        if (z == 1.2345e-30f) p.D[0] = 0;
+        return;
     }
+#endif
     const bool lean = p.identity_rows && !p.res_cls && !p.replicate && p.nsplit == 1;
     const bool hr = p.res != nullptr, hm = p.mask != nullptr, h2 = p.D2 != nullptr, rpost = p.res_post != 0;
     const int kind = !lean ? 0 : ((!hr && !hm && !h2) ? 1 : ((hr && !rpost && !hm && !h2) ? 2 : ((!hr && hm && !h2) ? 3 : ((hr && rpost && !hm && h2) ? 4 : ((hr && !rpost && hm && !h2) ? 5 : 0)))));
     const float slope = (p.act == DPIG_ACT_NONE) ? 1.f : ((p.act == DPIG_ACT_RELU) ? 0.f : p.alpha);
+#ifndef DPIG_QKO_REGEPI
+    if (kind) {                                                       // (workgroup-uniform) the flag combinations the models produce
+        const int row_base = m0 + wr * 128, cb0 = n0 + wc * 64;
+        lds_char* W = (lds_char*)smem + wave * WEP_BYTES;             // this wave's own staging rows
+        switch (kind) {
+            case 1: q_epilogue_wave<false, false, false, false>(p, acc, W, row_base, cb0, lane, slope); break;   // bias + activation
+            case 2: q_epilogue_wave<true, false, false, false>(p, acc, W, row_base, cb0, lane, slope); break;    // + residual before the activation
+            case 3: q_epilogue_wave<false, false, true, false>(p, acc, W, row_base, cb0, lane, slope); break;    // dgrad * activation mask
+            case 4: q_epilogue_wave<true, true, false, true>(p, acc, W, row_base, cb0, lane, slope); break;      // res-block tail
+            default: q_epilogue_wave<true, false, true, false>(p, acc, W, row_base, cb0, lane, slope); break;    // (dgrad + accum) * mask
+        }
+    } else
+#endif
+    {
+        // every other combination (class-indexed residual, 2 x 2 replication, split-K partials, ...): four passes through LDS,
+        // pass mb stages the mb-th 32-pixel block of every wave as fp32 rows, then epi8 on 8 consecutive columns per thread
+        float* Cs = reinterpret_cast<float*>(smem);
+        constexpr int TPR = G::BN / 8, RPS = 512 / TPR;               // threads per staged row, rows per sweep
+        const int c = (tid % TPR) * 8;
+        const int col = n0 + c;
+        const int rl0 = tid / TPR;
+        const bool cok = col < p.Ncols;
+        float bv[8];
 #pragma unroll
-    for (int mb = 0; mb < 4; ++mb) {
-        if (mb) __syncthreads();
+        for (int e = 0; e < 8; ++e) bv[e] = 0.f;
+        if (p.bias && cok) {
+            const float4 b0 = *reinterpret_cast<const float4*>(p.bias + col);
+            const float4 b1 = *reinterpret_cast<const float4*>(p.bias + col + 4);
+            bv[0] = b0.x; bv[1] = b0.y; bv[2] = b0.z; bv[3] = b0.w; bv[4] = b1.x; bv[5] = b1.y; bv[6] = b1.z; bv[7] = b1.w;
+        }
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
+        for (int mb = 0; mb < 4; ++mb) {
+            if (mb) __syncthreads();
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
-                Cs[(wr * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * G::LDCQ + wc * 64 + nb * 32 + l31] = acc[mb][nb][r];
-        __syncthreads();
-        if (!cok) continue;
+#pragma unroll
+                for (int q = 0; q < 4; ++q)                           // (transposed accumulators: 4 consecutive channels per run)
+                    *reinterpret_cast<float4*>(&Cs[(wr * 32 + l31) * G::LDCQ + wc * 64 + nb * 32 + 8 * q + 4 * half]) =
+                        make_float4(acc[mb][nb][4 * q], acc[mb][nb][4 * q + 1], acc[mb][nb][4 * q + 2], acc[mb][nb][4 * q + 3]);
+            __syncthreads();
+            if (!cok) continue;
 #pragma unroll 2
-        for (int it = 0; it < G::RP / RPS; ++it) {
-            const int rl = rl0 + RPS * it;
-            const int row = m0 + (rl >> 5) * 128 + mb * 32 + (rl & 31);
-            if (row >= p.M) continue;
-            const float4 v0 = *reinterpret_cast<const float4*>(&Cs[rl * G::LDCQ + c]);
-            const float4 v1 = *reinterpret_cast<const float4*>(&Cs[rl * G::LDCQ + c + 4]);
-            if (p.nsplit > 1) {
-                float* pp = p.partial + ((long)blockIdx.z * p.M + row) * p.Ncols + col;
-                *reinterpret_cast<float4*>(pp) = v0;
-                *reinterpret_cast<float4*>(pp + 4) = v1;
-                continue;
-            }
-            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            switch (kind) {                                           // workgroup-uniform
-                case 1: q_row8<false, false, false, false>(p, row, col, v, bv, slope); break;   // bias + activation
-                case 2: q_row8<true, false, false, false>(p, row, col, v, bv, slope); break;    // + residual before the activation
-                case 3: q_row8<false, false, true, false>(p, row, col, v, bv, slope); break;    // dgrad * activation mask
-                case 4: q_row8<true, true, false, true>(p, row, col, v, bv, slope); break;      // res-block tail
-                case 5: q_row8<true, false, true, false>(p, row, col, v, bv, slope); break;     // (dgrad + accum) * mask
-                default: epi8(p, row, col, v, bv); break;
+            for (int it = 0; it < G::RP / RPS; ++it) {
+                const int rl = rl0 + RPS * it;
+                const int row = m0 + (rl >> 5) * 128 + mb * 32 + (rl & 31);
+                if (row >= p.M) continue;
+                const float4 v0 = *reinterpret_cast<const float4*>(&Cs[rl * G::LDCQ + c]);
+                const float4 v1 = *reinterpret_cast<const float4*>(&Cs[rl * G::LDCQ + c + 4]);
+                if (p.nsplit > 1) {
+                    float* pp = p.partial + ((long)blockIdx.z * p.M + row) * p.Ncols + col;
+                    *reinterpret_cast<float4*>(pp) = v0;
+                    *reinterpret_cast<float4*>(pp + 4) = v1;
+                    continue;
+                }
+                float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                epi8(p, row, col, v, bv);
             }
         }
     }
+#ifdef DPIG_TRACE
+    if ((int)blockIdx.x < 256 && lane == 0) {
+        unsigned long long* o = dpig_bq_prof + ((int)blockIdx.x * 8 + wave) * 16;
+        for (int i = 0; i < 8; ++i) o[i] = qt_sum[i];
+        o[8] = (unsigned long long)nkt;
+        o[9] = qt_loop_end - qt_begin;                               // prologue + k-loop
+        o[10] = __builtin_amdgcn_s_memtime() - qt_loop_end;          // epilogue
+    }
+#endif
 }
 
 // ================================================================================================
@@ -389,7 +532,7 @@ __global__ __launch_bounds__(512, 2) void bq_kernel(const BGParams p) {
 // ================================================================================================
 static int g_q_mode = -1;      // 0 off, 1 automatic, 2 whenever the layer is legal for the kernel (tests)
 static int g_q_variant = 0;    // 0 automatic, 1 = 256 x 256, 2 = 512 x 128 (measurements)
-static double g_q_mineff = 0.8;
+static double g_q_mineff = 1.04;     // required advantage over the 128 x 128 family's fill (DPIG_BF16_Q_MINEFF)
 
 static void q_init() {
     if (g_q_mode >= 0) return;
@@ -401,11 +544,11 @@ static void q_init() {
     if (m) g_q_mineff = atof(m);
 }
 
-// Fraction of the launched MFMA work that is real when `tiles` tiles of bm x bn run one per CU in whole rounds.
-static double q_eff(long M, long N, int bm, int bn) {
+// Fraction of the launched MFMA work that is real when the tiles of bm x bn run `slots` at a time in whole rounds.
+static double q_eff(long M, long N, int bm, int bn, int slots) {
     const long tiles = (long)cdiv(M, bm) * cdiv(N, bn);
-    const long rounds = (tiles + kNumCU - 1) / kNumCU;
-    return (double)M * (double)N / ((double)rounds * kNumCU * bm * bn);
+    const long rounds = (tiles + slots - 1) / slots;
+    return (double)M * (double)N / ((double)rounds * slots * bm * bn);
 }
 
 // 1 = launched on the large-tile kernel, 0 = not this layer's case (the caller continues with the 128 x 128 kernels), < 0 = error
@@ -415,11 +558,16 @@ int bq_try(BGParams& p, hipStream_t st) {
     if (p.stats || (p.Cs % TK) || p.Hs >= 16384 || p.Ws >= 16384) return 0;
     const int ktiles = p.ntaps * (p.Cs / TK);
     if (ktiles < 2) return 0;
-    const double e1 = q_eff(p.M, p.Ncols, 256, 256), e2 = q_eff(p.M, p.Ncols, 512, 128);
-    int variant = g_q_variant ? g_q_variant : (e2 > e1 * 1.05 ? 2 : 1);
+    // Selection (automatic mode), from the A/B of scripts/bench_conv_bf16q.py (profiles/r03_conv_bf16_tile_ab.txt): a full
+    // CU runs the 256 x 256 kernel ~1.15x and the 512 x 128 kernel ~1.04x as fast as two 128 x 128 workgroups; what decides
+    // is how well each tile grid fills whole rounds of the chip (256 slots here, 512 there).
+    const double e1 = q_eff(p.M, p.Ncols, 256, 256, kNumCU) * 1.15, e2 = q_eff(p.M, p.Ncols, 512, 128, kNumCU) * 1.04;
+    int variant = g_q_variant ? g_q_variant : (e2 > e1 ? 2 : 1);
     if (g_q_mode == 1) {
         if (p.nsplit > 1) return 0;                      // the split-K plan of the 128 x 128 family wins on small layers
-        if ((variant == 1 ? e1 : e2) < g_q_mineff) return 0;
+        const double e0 = q_eff(p.M, p.Ncols, 128, 128, 2 * kNumCU);
+        if ((variant == 1 ? e1 : e2) < e0 * g_q_mineff) return 0;
+        if (variant == 2 && p.Ncols <= 128 && (long)cdiv(p.M, 512) < 3 * kNumCU) return 0;   // 128-column layers: a wash below 3 rounds
     }
     const int bm = variant == 1 ? 256 : 512, bn = variant == 1 ? 256 : 128;
     BGParams q = p;
