@@ -144,6 +144,29 @@ __device__ __forceinline__ void epi8(const BGParams& p, int row, int col, float 
     }
 }
 
+// wgrad problem: dw[(tap, ci), co] = sum over output pixels of x[src(pixel, tap), ci] * dy[pixel, co]
+struct BWParams {
+    const bf16_t* X; const bf16_t* DY; float* DW; float* partial;
+    int Npix, Ho, Wo, HoWo;
+    int H, W, ldx, C, shift, s;
+    int K, ldy;
+    int ntaps, cblocks, ntiles;
+    int ktiles, tiles_per_split, nsplit, wrows;
+    float beta;
+    int S, pad_t, pad_l;
+    unsigned x_bytes, y_bytes;
+    unsigned mul_howo, shr_howo, mul_wo, shr_wo;
+    float* DB; float* bias_partial; float beta_b;
+    int d64_oy, d64_ox, d64_n;
+    int q_mtiles, q_ntiles;   // bwq_kernel: item tiles x column tiles
+};
+
+// dpig_conv_bf16_wq.hip, the large-tile (8-wave) wgrad of stride-1 SAME layers: bwq_choose = the variant (1: 2 items x 256
+// co, 2: 4 items x 128 co) the selection rule picks or 0; bwq_plan = its tile grid and split; bwq_try launches (1 / < 0)
+int bwq_choose(int ntaps, int C, int K, long npix, int forced_split);
+double bwq_plan(int ntaps, int C, int K, long npix, int variant, int forced_split, int* mtiles, int* ntiles, int* nsplit, int* tps);
+int bwq_try(BWParams& p, int variant, hipStream_t st);
+
 // dpig_conv_bf16_q.hip: 1 = launched on the large-tile (8-wave) kernel, 0 = not this layer's case, < 0 = error
 int bq_try(BGParams& p, hipStream_t st);
 

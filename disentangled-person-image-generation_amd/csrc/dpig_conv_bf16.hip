@@ -589,20 +589,6 @@ __global__ __launch_bounds__(256) void bg_reduce_multi_kernel(const BGMulti m) {
 // the fragments are read with ds_read_b64_tr_b16, which hands each lane 4 consecutive pixels of its channel out of a
 // [4 pixels][16 channels] block (the transpose happens inside the LDS read).  Granule g of pixel row r sits at slot
 // g ^ ((r & 3) << 2): the 32 lanes served together (4 pixels x 4 granules) then cover all 64 banks once.
-struct BWParams {
-    const bf16_t* X; const bf16_t* DY; float* DW; float* partial;
-    int Npix, Ho, Wo, HoWo;
-    int H, W, ldx, C, shift, s;
-    int K, ldy;
-    int ntaps, cblocks, ntiles;
-    int ktiles, tiles_per_split, nsplit, wrows;
-    float beta;
-    int S, pad_t, pad_l;
-    unsigned x_bytes, y_bytes;
-    unsigned mul_howo, shr_howo, mul_wo, shr_wo;
-    float* DB; float* bias_partial; float beta_b;
-    int d64_oy, d64_ox, d64_n;
-};
 constexpr int WROWB = 256;                // bytes of one pixel row of a wgrad operand tile (128 channels)
 constexpr int WTILE_B = TK * WROWB;       // 16 KB
 constexpr int WSTAGE_B = 2 * WTILE_B;
@@ -1372,6 +1358,13 @@ extern "C" int dpig_conv2d_bf16_supported(const DpigConvDesc* d, int which) {
     return shape_ok(d) ? 1 : 0;
 }
 
+// stride-1 SAME layer whose padded pixel offsets stay inside one buffer descriptor: output pixel m pairs with input pixel m + const
+static bool wgrad_is_s1(const DpigConvDesc* d, int pt, int pl, int Ho, int Wo) {
+    const long xe = ((long)d->N * d->H * d->W - 1) * d->ldx + d->C;
+    return !d->upsample2x && d->stride == 1 && Ho == d->H && Wo == d->W && pt >= 0 && pl >= 0 &&
+           (xe * 2 + (long)(pt * d->W + pl) * d->ldx * 2 < 0x7fffffffL);
+}
+
 static size_t bf16_workspace_bytes_one(const DpigConvDesc* d, int which) {
     int pt, pl, Ho, Wo;
     if (resolve_desc(d, &pt, &pl, &Ho, &Wo) || !shape_ok(d)) return 0;
@@ -1393,7 +1386,13 @@ static size_t bf16_workspace_bytes_one(const DpigConvDesc* d, int which) {
         const long Npix = (long)d->N * Ho * Wo * (d->upsample2x ? 4 : 1);
         const int tiles = (d->upsample2x ? 1 : d->R * d->S) * cdiv(d->C, TM) * cdiv(d->K, TN);
         Plan pln = plan_split(tiles, cdiv(Npix, TK), d->split_k, TK, kSplitPenalty);
-        return pln.nsplit > 1 ? (size_t)pln.nsplit * ((size_t)d->R * d->S * d->C * d->K + d->K) * sizeof(float) : 0;
+        int nsplit = pln.nsplit;
+        if (wgrad_is_s1(d, pt, pl, Ho, Wo)) {                    // the large-tile kernel splits deeper (fewer, larger tiles)
+            const int v = bwq_choose(d->R * d->S, d->C, d->K, Npix, d->split_k);
+            int a, b, s, t;
+            if (v) { bwq_plan(d->R * d->S, d->C, d->K, Npix, v, d->split_k, &a, &b, &s, &t); nsplit = s; }
+        }
+        return nsplit > 1 ? (size_t)nsplit * ((size_t)d->R * d->S * d->C * d->K + d->K) * sizeof(float) : 0;
     }
     return 0;
 }
@@ -1625,6 +1624,9 @@ static int wgrad_bf16_one(const DpigConvDesc* d, const uint16_t* x, const uint16
     const int tiles = p.ntaps * p.cblocks * p.ntiles;
     Plan pln = plan_split(tiles, p.ktiles, d->split_k, TK, kSplitPenalty);
     p.nsplit = pln.nsplit; p.tiles_per_split = pln.tiles_per_split;
+    const bool s1 = wgrad_is_s1(d, pt, pl, Ho, Wo);
+    const int qv = s1 ? bwq_choose(p.ntaps, d->C, d->K, p.Npix, d->split_k) : 0;      // large-tile kernel (dpig_conv_bf16_wq.hip)?
+    if (qv) bwq_plan(p.ntaps, d->C, d->K, p.Npix, qv, d->split_k, &p.q_mtiles, &p.q_ntiles, &p.nsplit, &p.tiles_per_split);
     const long wsize = (long)p.wrows * d->K;
     if (p.nsplit > 1 && (!ws || ws_bytes < (size_t)p.nsplit * (wsize + d->K) * sizeof(float)))
         return fail(DPIG_ENOMEM, "bf16 conv wgrad workspace too small: have %zu", ws_bytes);
@@ -1634,12 +1636,16 @@ static int wgrad_bf16_one(const DpigConvDesc* d, const uint16_t* x, const uint16
     p.d64_oy = (TK % p.HoWo) / p.Wo;
     p.d64_ox = (TK % p.HoWo) % p.Wo;
     dim3 grid(tiles, 1, p.nsplit), block(256);
-    const bool s1 = !d->upsample2x && d->stride == 1 && Ho == d->H && Wo == d->W && pt >= 0 && pl >= 0 &&
-                    ((long)p.x_bytes + (long)(pt * d->W + pl) * d->ldx * 2 < 0x7fffffffL);
-    if (s1) hipLaunchKernelGGL((bw_kernel<true>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((bw_kernel<false>), grid, block, 0, st, p);
-    rc = check_launch("bw_kernel");
-    if (rc) return rc;
+    if (qv) {
+        rc = bwq_try(p, qv, st);
+        if (rc < 0) return rc;
+        rc = DPIG_OK;
+    } else {
+        if (s1) hipLaunchKernelGGL((bw_kernel<true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((bw_kernel<false>), grid, block, 0, st, p);
+        rc = check_launch("bw_kernel");
+        if (rc) return rc;
+    }
     if (p.nsplit > 1) {
         const long n4 = wsize / 4;
         int blocks = cdiv(n4, 256);

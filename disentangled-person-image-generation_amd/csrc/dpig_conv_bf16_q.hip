@@ -567,7 +567,7 @@ int bq_try(BGParams& p, hipStream_t st) {
         if (p.nsplit > 1) return 0;                      // the split-K plan of the 128 x 128 family wins on small layers
         const double e0 = q_eff(p.M, p.Ncols, 128, 128, 2 * kNumCU);
         if ((variant == 1 ? e1 : e2) < e0 * g_q_mineff) return 0;
-        if (variant == 2 && p.Ncols <= 128 && (long)cdiv(p.M, 512) < 3 * kNumCU) return 0;   // 128-column layers: a wash below 3 rounds
+        if (variant == 2 && p.Ncols <= 128 && q_eff(p.M, p.Ncols, 512, 128, kNumCU) < 0.95) return 0;   // 128-column layers: only on full rounds
     }
     const int bm = variant == 1 ? 256 : 512, bn = variant == 1 ? 256 : 128;
     BGParams q = p;

@@ -545,6 +545,11 @@ def set_large_tile(mode=1, variant=0):
     check(lib().dpig_conv_bf16_set_large_tile(int(mode), int(variant)), "conv_bf16_set_large_tile")
 
 
+def set_large_tile_wgrad(mode=1, variant=0):
+    """The same switch for the bf16-storage filter gradient (dpig_conv_bf16_set_large_tile_wgrad)."""
+    check(lib().dpig_conv_bf16_set_large_tile_wgrad(int(mode), int(variant)), "conv_bf16_set_large_tile_wgrad")
+
+
 def _f32_mode():
     """Context: run the fp32-tensor entry points with exact fp32 products (the thin-layer fall-back of 'bf16' mode)."""
     class _Ctx(object):

@@ -155,6 +155,9 @@ int dpig_conv2d_wgrad_bf16(const DpigConvDesc* d, const uint16_t* x, const uint1
  * the layer is legal for them (channel count a multiple of 64; tests).  variant 0 = automatic, 1 = 256 x 256, 2 = 512 x 128.
  * Results do not depend on the choice beyond fp32 summation order.  Process-wide; not stream-ordered. */
 int dpig_conv_bf16_set_large_tile(int mode, int variant);
+/* The same switch for dpig_conv2d_wgrad_bf16 (csrc/dpig_conv_bf16_wq.hip: stride-1 SAME layers; variant 1 = 2 (tap, 128-ci)
+ * items x 256 co per workgroup, 2 = 4 items x 128 co; environment DPIG_BF16_WQ).  The workspace query follows the setting. */
+int dpig_conv_bf16_set_large_tile_wgrad(int mode, int variant);
 /* The thin layers of 'bf16' mode on the vector-ALU kernels (csrc/dpig_thin.hip) with their WIDE tensor stored as bf16;
  * the 3-channel image side, the fp32 HWIO filter and the filter gradient stay fp32:
  *   K == 3 (3x3 s1, the generator's image conv models.py:573):        x / dx bf16 [.., C],   y / dy fp32 [.., 3]

@@ -44,17 +44,21 @@ for (tag, N, Hh, W, C, K) in (LAYERS[:4] + LAYERS[11:13] if quick else LAYERS):
     m = torch.randn(N, Hh, W, C, device=dev).to(BF)
     fl = 2.0 * N * Hh * W * K * 9 * C
     w._dpig_shadow = H.filter_shadows(w)
-    res = {name: ([], []) for name, _, _ in MODES}
+    res = {name: ([], [], []) for name, _, _ in MODES}
+    dw = torch.empty((3, 3, C, K), device=dev)
     for r in range(rounds):
         for name, mode, var in MODES:
             H.set_large_tile(mode, var)
             res[name][0].append(timeit(lambda: H.conv2d_fwd(x, w, b, act=1)))
             res[name][1].append(timeit(lambda: H.conv2d_dgrad(dy, w, (N, Hh, W, C), mask=m, act=1)))
+            H.set_large_tile_wgrad(mode, var)
+            res[name][2].append(timeit(lambda: H.conv2d_wgrad(x, dy, (3, 3, C, K), out=dw)))
     H.set_large_tile(1, 0)
+    H.set_large_tile_wgrad(1, 0)
     line = tag
     for name, _, _ in MODES:
-        tf = sorted(res[name][0])[rounds // 2]; td = sorted(res[name][1])[rounds // 2]
-        line += " | %s fwd %6.1f TF dgrad %6.1f TF" % (name, fl / tf / 1e12, fl / td / 1e12)
+        tf = sorted(res[name][0])[rounds // 2]; td = sorted(res[name][1])[rounds // 2]; tw = sorted(res[name][2])[rounds // 2]
+        line += " | %s fwd %6.1f dgrad %6.1f wgrad %6.1f" % (name, fl / tf / 1e12, fl / td / 1e12, fl / tw / 1e12)
     print(line, flush=True)
     del x, dy, m, w
     torch.cuda.empty_cache()

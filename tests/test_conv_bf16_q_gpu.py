@@ -194,3 +194,81 @@ def test_equals_the_tap_major_128_tile_kernel_bit_for_bit(dev):
             assert torch.equal(H.conv2d_dgrad(dy, w, (N, Hh, W, C), mask=m, act=1), dx0)
     finally:
         H.set_large_tile(1, 0)
+
+
+# ---- filter gradient on the large-tile kernel (csrc/dpig_conv_bf16_wq.hip) --------------------------------------------------
+@pytest.fixture(params=[1, 2], ids=["2x256", "4x128"])
+def large_tile_wgrad(request):
+    import dpig_amd.hip_ops as H
+    H.set_large_tile_wgrad(2, request.param)
+    yield request.param
+    H.set_large_tile_wgrad(1, 0)
+
+
+def _close_f32(got, ref, tol=2e-5):
+    ref = ref.double()
+    err = (got.double().cpu() - ref).abs().max().item()
+    scale = max(ref.abs().max().item(), 1e-6)
+    assert err <= tol * scale, "max err %.3e vs scale %.3e" % (err, scale)
+
+
+WGRAD_SHAPES = [
+    (3, 24, 20, 128, 192, 3),    # 1440 pixels (22.5 k-tiles), 9 items: a half-empty item tile / a partial column tile
+    (2, 16, 12, 64, 264, 3),     # 64 input channels (half an item), 264 output channels
+    (2, 16, 16, 192, 64, 1),     # 1x1: one tap, two channel blocks
+    (5, 3, 3, 640, 64, 3),       # 45 pixels: one partial k-tile, images smaller than a k-tile, every tap mostly halo
+    (1, 40, 40, 256, 256, 3),    # 25 k-tiles
+]
+
+
+@pytest.mark.parametrize("shape", WGRAD_SHAPES)
+@pytest.mark.parametrize("split_k", [0, 3])
+def test_wgrad_against_oracle(dev, large_tile_wgrad, shape, split_k):
+    import dpig_amd.hip_ops as H
+    from oracle import ops as O
+    N, Hh, W, C, K, k = shape
+    x = _rand((N, Hh, W, C), 1)
+    w = _rand((k, k, C, K), 2, 0.2)
+    xr = _r(x)
+    wr = _r(w).requires_grad_(True)
+    y = O.conv2d_same(xr, wr, None, 1)
+    dy = _rand(tuple(y.shape), 3)
+    y.backward(_r(dy))
+    xd, dyd = x.float().to(dev).to(BF), dy.float().to(dev).to(BF)
+    dw = torch.full((k, k, C, K), 2.0, device=dev)
+    db = torch.full((K,), 3.0, device=dev)
+    H.conv2d_wgrad(xd, dyd, (k, k, C, K), out=dw, beta=1.0, split_k=split_k, db=db, db_beta=1.0)
+    _close_f32(dw, wr.grad + 2.0)
+    _close_f32(db, _r(dy).sum((0, 1, 2)) + 3.0)
+    dw0 = torch.empty((k, k, C, K), device=dev)
+    H.conv2d_wgrad(xd, dyd, (k, k, C, K), out=dw0, beta=0.0, split_k=split_k)
+    _close_f32(dw0, wr.grad)
+
+
+@pytest.mark.parametrize("layer", [(8, 128, 128, 256, 256), (8, 64, 64, 768, 768), (16, 64, 32, 512, 512), (8, 64, 64, 384, 384)])
+def test_wgrad_full_size_repeats_and_agrees(dev, layer):
+    """BASELINE layer sizes: the large-tile filter gradient reproduces itself bit for bit launch after launch and agrees with
+    the 128 x 128 kernel (another split of the pixel range: another fp32 summation order) to fp32 round-off."""
+    import dpig_amd.hip_ops as H
+    N, Hh, W, C, K = layer
+    x, w, b, dy, m = _full_size_operands(dev, N, Hh, W, C, K)
+    try:
+        H.set_large_tile_wgrad(0, 0)
+        dw0 = torch.empty((3, 3, C, K), device=dev)
+        db0 = torch.empty((K,), device=dev)
+        H.conv2d_wgrad(x, dy, (3, 3, C, K), out=dw0, db=db0)
+        scale = dw0.abs().max().item()
+        for variant in (1, 2):
+            H.set_large_tile_wgrad(2, variant)
+            ref = None
+            for rep in range(3):
+                dw = torch.empty((3, 3, C, K), device=dev)
+                db = torch.empty((K,), device=dev)
+                H.conv2d_wgrad(x, dy, (3, 3, C, K), out=dw, db=db)
+                if ref is None:
+                    ref = (dw, db)
+                assert torch.equal(dw, ref[0]) and torch.equal(db, ref[1]), "launch %d differs (variant %d)" % (rep, variant)
+            assert (ref[0] - dw0).abs().max().item() <= 2e-5 * scale
+            assert (ref[1] - db0).abs().max().item() <= 2e-5 * db0.abs().max().item()
+    finally:
+        H.set_large_tile_wgrad(1, 0)
