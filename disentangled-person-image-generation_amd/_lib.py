@@ -112,6 +112,15 @@ SYMBOLS = {
     "dpig_adam_multi": (_i, [_vp, _vp, _i, _i64, _vp, _f, _f, _f, _i, _f, _vp]),
     "dpig_rmsprop_step": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _f, _vp]),
     "dpig_clip": (_i, [_vp, _i64, _f, _f, _vp]),
+    "dpig_mask_split_fwd": (_i, [_vp, _i, _vp, _i64, _i, _vp, _i, _vp, _i, _i, _vp]),
+    "dpig_mask_split_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i64, _i, _vp, _i, _i, _vp]),
+    "dpig_roi_boxes": (_i, [_vp, _i, _i, _i, _i, _f, _f, _vp, _vp, _vp]),
+    "dpig_vis_concat_fwd": (_i, [_vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),
+    "dpig_vis_concat_bwd": (_i, [_vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp]),
+    "dpig_emb_class_weights_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp]),
+    "dpig_emb_class_weights_bwd": (_i, [_vp, _i, _i, _i, _vp, _f, _vp]),
+    "dpig_axpby3d": (_i, [_vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i, _f, _vp]),
+    "dpig_transpose12": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "dpig_sce_mean": (_i, [_vp, _i, _f, _vp, _vp, _f, _vp]),
     "dpig_logit_mean": (_i, [_vp, _i, _i, _f, _vp, _vp, _f, _vp]),
     "dpig_l1_workspace_bytes": (_sz, [_i64]),

@@ -326,10 +326,7 @@ class _TiledEmbConvFn(torch.autograd.Function):
     def forward(ctx, emb, pose, w, b):
         E = emb.shape[1]
         K = w.shape[3]
-        we = w[:, :, :E, :]
-        wy = torch.stack([we[_valid_taps(c)].sum(0) for c in range(3)])                 # [cy, kx, E, K]
-        wc = torch.stack([wy[:, _valid_taps(c)].sum(1) for c in range(3)], dim=1)       # [cy, cx, E, K]
-        wmat = wc.permute(2, 0, 1, 3).reshape(E, 9 * K).contiguous()
+        wmat = H.emb_class_weights_fwd(w, E)                                           # [E, 9K]: per-border-class tap sums
         e9 = H.linear_fwd(H.to_f32(emb), wmat)                                         # [B, 9K]
         P = pose.shape[3]
         ctx.padded = H.get_compute() == "bf16" and K % 8 == 0 and P < 32
@@ -356,28 +353,21 @@ class _TiledEmbConvFn(torch.autograd.Function):
         z9 = H.border_class_sum(dz)                                                    # [B, 9, K] fp32
         db = None
         if ctx.needs_input_grad[3]:            # every pixel belongs to exactly one class: the bias gradient is their sum
-            db = _sink_small(ctx.b_ref, z9.sum((0, 1)))
+            db = _sink(ctx.b_ref, lambda o, beta: H.colsum(z9.view(B * 9, K), out=o, beta=beta))
         z9 = z9.view(B, 9 * K)
         d_emb = H.linear_dgrad(z9, wmat) if ctx.needs_input_grad[0] else None
         dw = None
         if ctx.needs_input_grad[2]:
-            dwp = H.conv2d_wgrad(pose, dz, (3, 3, pose.shape[3], K))
-            if ctx.padded:
-                dwp = dwp[:, :, :ctx.P, :]
-            dwc = H.linear_wgrad(H.to_f32(emb), z9).view(E, 3, 3, K).permute(1, 2, 0, 3)          # [cy, cx, E, K]
-            # transpose of the class sums: tap ky receives every class whose valid set contains ky
-            dwy = torch.stack([dwc[1:].sum(0), dwc.sum(0), dwc[:2].sum(0)])              # [ky, cx, E, K]
-            dwe = torch.stack([dwy[:, 1:].sum(1), dwy.sum(1), dwy[:, :2].sum(1)], dim=1)  # [ky, kx, E, K]
+            dwp = H.conv2d_wgrad(pose, dz, (3, 3, pose.shape[3], K))                   # [3, 3, P (padded), K]
+            dwc = H.linear_wgrad(H.to_f32(emb), z9)                                    # [E, 9K]: gradient of the class sums
+            P = ctx.P
 
             def put(out, beta):
                 if out is None:
-                    return torch.cat([dwe, dwp], dim=2)
-                if beta == 0.0:
-                    out[:, :, :E, :].copy_(dwe)
-                    out[:, :, E:, :].copy_(dwp)
-                else:
-                    out[:, :, :E, :].add_(dwe)
-                    out[:, :, E:, :].add_(dwp)
+                    out = torch.empty((3, 3, E + P, K), dtype=torch.float32, device=dwc.device)
+                    beta = 0.0
+                H.emb_class_weights_bwd(dwc, E, out, beta)                             # the transposed class sums -> taps
+                H.axpby3d(dwp.view(9, dwp.shape[2], K)[:, :P, :], out.view(9, E + P, K)[:, E:, :], beta)
                 return out
             dw = _sink(w, put)
         if d_emb is not None and d_emb.dtype != emb.dtype:
@@ -685,3 +675,78 @@ class _L1MeanFn(torch.autograd.Function):
 
 def l1_mean(a, b):
     return _L1MeanFn.apply(a, b)
+
+
+
+class _Like(object):
+    """shape / dtype / device donor for an output allocation (no tensor kept alive)"""
+
+    def __init__(self, t):
+        self.shape, self.dtype, self.device = tuple(t.shape), t.dtype, t.device
+
+
+class _MaskSplitFn(torch.autograd.Function):
+    """x_fg = x * m, x_bg = x * (1 - m) (models.py:402-403) in one launch; the gradient dx = dfg * m + dbg * (1 - m) in another."""
+
+    @staticmethod
+    def forward(ctx, x, m):
+        fg, bg, mflat = H.mask_split_fwd(x, m)
+        ctx.save_for_backward(mflat)
+        ctx.like = _Like(x)
+        return fg, bg
+
+    @staticmethod
+    def backward(ctx, dfg, dbg):
+        (mflat,) = ctx.saved_tensors
+        return H.mask_split_bwd(dfg, dbg, mflat, ctx.like), None
+
+
+def mask_split(x, m):
+    return _MaskSplitFn.apply(x, m)
+
+
+class _VisConcatFn(torch.autograd.Function):
+    """models.py:433-442 + 467-468: per-part features times the visibility flag, concatenated (with the background feature)."""
+
+    @staticmethod
+    def forward(ctx, fea, vis, bg, P, z):
+        B = vis.shape[0]
+        out, visf = H.vis_concat_fwd(fea, vis, bg, B, P, z)
+        ctx.save_for_backward(visf)
+        ctx.cfg = (B, P, z, 0 if bg is None else bg.shape[1])
+        return out
+
+    @staticmethod
+    def backward(ctx, dall):
+        (visf,) = ctx.saved_tensors
+        B, P, z, zbg = ctx.cfg
+        dfea, dbg = H.vis_concat_bwd(dall, visf, B, P, z, zbg, zbg > 0 and ctx.needs_input_grad[2])
+        return dfea, None, dbg, None, None
+
+
+def vis_concat(fea, vis, bg, P, z):
+    return _VisConcatFn.apply(fea, vis, bg, P, z)
+
+
+class _Transpose12Fn(torch.autograd.Function):
+    """[B, A, C] -> [B, C, A] in one kernel; its gradient is the same op on the gradient, so it differentiates any number of
+    times (the WGAN-GP sweep differentiates the critic's backward pass once more)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return H.transpose12(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return _Transpose12Fn.apply(dy.contiguous()) if torch.is_grad_enabled() else H.transpose12(dy)
+
+
+def nchw_flatten(x_nchw_view, n):
+    """tf.reshape(output, [-1, n]) of the critic's logical NCHW tensor (wgan_gp.py:433).  When the data is physically NHWC (a
+    permuted view) this is one [B, HW, C] -> [B, C, HW] transpose kernel instead of a strided torch copy."""
+    if x_nchw_view.dim() == 4:
+        nhwc = x_nchw_view.permute(0, 2, 3, 1)
+        B, Hh, W, C = nhwc.shape
+        if nhwc.is_contiguous() and (Hh * W * C) % n == 0:
+            return _Transpose12Fn.apply(nhwc.reshape(B, Hh * W, C)).reshape(-1, n)
+    return x_nchw_view.reshape(-1, n)

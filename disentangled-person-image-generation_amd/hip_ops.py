@@ -1205,3 +1205,99 @@ def l1_mean(a, b, want_grad=False, scale=1.0):
     check(lib().dpig_l1_mean(ptr(a), ptr(b), n, ptr(out), ptr(da), float(scale), ptr(wsb), wsn, stream_ptr()),
           "l1_mean")
     return out, da
+
+
+# ---- graph wiring between the convolutions (csrc/dpig_glue.hip) ---------------------------------------------------------
+def mask_split_fwd(x, m):
+    """(x * m, x * (1 - m)) with m one value per pixel (models.py:402-403); x NHWC fp32 or bf16."""
+    _require_dev(x)
+    x, ldx = as_nhwc(x)
+    N, Hh, W, C = x.shape
+    m = m.reshape(-1).to(F32).contiguous()
+    if m.numel() != N * Hh * W:
+        raise RuntimeError("mask_split: one mask value per pixel expected")
+    fg, bg = torch.empty_like(x, memory_format=torch.contiguous_format), torch.empty_like(x, memory_format=torch.contiguous_format)
+    check(lib().dpig_mask_split_fwd(ptr(x), ldx, ptr(m), N * Hh * W, C, ptr(fg), C, ptr(bg), C, int(x.dtype == BF16), stream_ptr()),
+          "mask_split_fwd")
+    return fg, bg, m
+
+
+def mask_split_bwd(dfg, dbg, m, like):
+    """dx = dfg * m + dbg * (1 - m); either gradient may be None.  `like`: shape / dtype donor."""
+    N, Hh, W, C = like.shape
+    ldf = ldb = 0
+    if dfg is not None:
+        dfg, ldf = as_nhwc(dfg if dfg.dtype == like.dtype else dfg.to(like.dtype))
+    if dbg is not None:
+        dbg, ldb = as_nhwc(dbg if dbg.dtype == like.dtype else dbg.to(like.dtype))
+    dx = torch.empty((N, Hh, W, C), dtype=like.dtype, device=like.device)
+    check(lib().dpig_mask_split_bwd(ptr(dfg), ldf, ptr(dbg), ldb, ptr(m), N * Hh * W, C, ptr(dx), C, int(like.dtype == BF16),
+                                    stream_ptr()), "mask_split_bwd")
+    return dx
+
+
+def roi_boxes(bbox, bbox_num, img_H, img_W):
+    """models.py:405-413 -> (boxes [P*B, 4] fp32, box_ind [P*B] int32), part-major."""
+    if not bbox.is_cuda:
+        raise RuntimeError("dpig HIP ops need device tensors (got %s): there is no CPU fallback" % bbox.device)
+    if bbox.dtype not in (torch.int32, F32):
+        bbox = bbox.to(F32)
+    bbox = bbox.contiguous()
+    B, P_total, _ = bbox.shape
+    boxes = torch.empty((bbox_num * B, 4), dtype=F32, device=bbox.device)
+    ind = torch.empty((bbox_num * B,), dtype=torch.int32, device=bbox.device)
+    check(lib().dpig_roi_boxes(ptr(bbox), int(bbox.dtype == F32), B, P_total, bbox_num, float(img_H), float(img_W), ptr(boxes),
+                               ptr(ind), stream_ptr()), "roi_boxes")
+    return boxes, ind
+
+
+def vis_concat_fwd(fea, vis, bg, B, P, z):
+    fea = to_f32(fea).contiguous()
+    vis = vis.to(F32)
+    vis = vis if vis.stride(1) == 1 else vis.contiguous()
+    zbg = 0 if bg is None else bg.shape[1]
+    if bg is not None:
+        bg = to_f32(bg).contiguous()
+    out = torch.empty((B, P * z + zbg), dtype=F32, device=fea.device)
+    check(lib().dpig_vis_concat_fwd(ptr(fea), ptr(vis), vis.stride(0), ptr(bg), B, P, z, zbg, ptr(out), stream_ptr()), "vis_concat_fwd")
+    return out, vis
+
+
+def vis_concat_bwd(dall, vis, B, P, z, zbg, want_bg):
+    dall = dall.contiguous()
+    dfea = torch.empty((P * B, z), dtype=F32, device=dall.device)
+    dbg = torch.empty((B, zbg), dtype=F32, device=dall.device) if (want_bg and zbg) else None
+    check(lib().dpig_vis_concat_bwd(ptr(dall), ptr(vis), vis.stride(0), B, P, z, zbg, ptr(dfea), ptr(dbg), stream_ptr()), "vis_concat_bwd")
+    return dfea, dbg
+
+
+def emb_class_weights_fwd(w, E):
+    w = w.contiguous()
+    _, _, C, K = w.shape
+    wmat = torch.empty((E, 9 * K), dtype=F32, device=w.device)
+    check(lib().dpig_emb_class_weights_fwd(ptr(w), E, C, K, ptr(wmat), stream_ptr()), "emb_class_weights_fwd")
+    return wmat
+
+
+def emb_class_weights_bwd(dwc, E, out, beta):
+    """out [3,3,C,K] (contiguous): out[:, :, :E, :] = beta * out[:, :, :E, :] + transpose-of-the-class-sums(dwc [E, 9K])."""
+    _, _, C, K = out.shape
+    check(lib().dpig_emb_class_weights_bwd(ptr(dwc.contiguous()), E, C, K, ptr(out), float(beta), stream_ptr()), "emb_class_weights_bwd")
+
+
+def axpby3d(src, dst, beta):
+    """dst = beta * dst + src for 3-D views [outer, rows, cols] whose last axis is contiguous (any outer / row strides)."""
+    if src.dim() != 3 or tuple(src.shape) != tuple(dst.shape) or src.stride(2) != 1 or dst.stride(2) != 1 or src.dtype != F32 or dst.dtype != F32:
+        raise RuntimeError("axpby3d: [outer, rows, cols] fp32 views with a contiguous last axis expected")
+    o, r, c = src.shape
+    check(lib().dpig_axpby3d(ptr(src), src.stride(0), src.stride(1), ptr(dst), dst.stride(0), dst.stride(1), o, r, c, float(beta),
+                             stream_ptr()), "axpby3d")
+
+
+def transpose12(x):
+    """[B, A, C] -> [B, C, A] (contiguous in, contiguous out; fp32 or bf16)."""
+    x = x.contiguous()
+    B, Aa, C = x.shape
+    y = torch.empty((B, C, Aa), dtype=x.dtype, device=x.device)
+    check(lib().dpig_transpose12(ptr(x), ptr(y), B, Aa, C, x.element_size(), stream_ptr()), "transpose12")
+    return y

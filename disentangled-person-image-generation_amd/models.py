@@ -12,6 +12,7 @@ import numpy as np
 import torch
 
 from . import autograd as A
+from . import hip_ops as H
 from . import slim
 from .slim import fully_connected, variable_scope
 
@@ -45,13 +46,7 @@ def reshape(x, h, w, c, data_format):
 def _normalised_boxes(ROI_bboxs, bbox_num, img_H, img_W):
     """models.py:405-413: pixel (y1,x1,y2,x2) -> /img_H, /img_W (division by H, not H-1), stacked
     part-major ([part0: all images, part1: all images, ...]) like tf.concat(body_roi_list, axis=0)."""
-    b = ROI_bboxs[:, :bbox_num, :].to(torch.float32)
-    # scalar divisions only (no host->device constant upload: the step must be hipGraph-capturable)
-    b = torch.stack([b[..., 0] / img_H, b[..., 1] / img_W, b[..., 2] / img_H, b[..., 3] / img_W], dim=-1)
-    batch = b.shape[0]
-    boxes = b.permute(1, 0, 2).reshape(bbox_num * batch, 4).contiguous()
-    box_ind = torch.arange(batch, dtype=torch.int32, device=b.device).repeat(bbox_num)
-    return boxes, box_ind
+    return H.roi_boxes(ROI_bboxs, bbox_num, img_H, img_W)          # one launch (csrc/dpig_glue.hip)
 
 
 def _roi_tower(body_regions, z_num, repeat_num, hidden_num, data_format, activation_fn):
@@ -89,12 +84,16 @@ def GeneratorCNN_ID_Encoder_BodyROIVis(x, ROI_bboxs, ROI_vis, bbox_num, z_num, r
         boxes, box_ind = _normalised_boxes(ROI_bboxs, bbox_num, img_H, img_W)
         body_regions = A.crop_and_resize(x, boxes, box_ind, roi_size, roi_size)
         body_regions = _roi_tower(body_regions, z_num, repeat_num, hidden_num, data_format, activation_fn)
-        fea_list = _apply_vis(body_regions, ROI_vis, bbox_num, z_num)
         if keep_part_prob < 1.0:
+            fea_list = _apply_vis(body_regions, ROI_vis, bbox_num, z_num)
             for i in range(bbox_num):
                 keep = (torch.rand(batch_num, 1, device=x.device) < keep_part_prob).to(torch.float32)
                 fea_list[i] = fea_list[i] * keep
-        fea_all = torch.cat(fea_list, dim=-1)
+            fea_all = torch.cat(fea_list, dim=-1)
+        else:
+            # visibility multiply + concat (models.py:359-368, 387) as one launch; fea_list = views of the result
+            fea_all = A.vis_concat(body_regions, ROI_vis, None, bbox_num, z_num)
+            fea_list = [fea_all[:, i * z_num:(i + 1) * z_num] for i in range(bbox_num)]
         variables = slim.get_variables(vs)
     return fea_all, fea_list, variables
 
@@ -111,9 +110,7 @@ def GeneratorCNN_ID_Encoder_BodyROIVis_FgBgFeaTwoBranch(x, fg_mask, ROI_bboxs, R
         x = slim.res_block(x, hidden_num, 3, activation_fn=activation_fn, data_format=data_format)
 
         _tap("E.stem", x)
-        m = fg_mask.to(x.dtype)        # (bf16 storage mode: keep the product in the activation's type)
-        x_fg = x * m
-        x_bg = x * (1.0 - m)
+        x_fg, x_bg = A.mask_split(x, fg_mask)          # x * m, x * (1 - m): one launch (csrc/dpig_glue.hip)
 
         boxes, box_ind = _normalised_boxes(ROI_bboxs, bbox_num, img_H, img_W)
         body_regions = A.crop_and_resize(x_fg, boxes, box_ind, roi_size, roi_size)
@@ -122,8 +119,9 @@ def GeneratorCNN_ID_Encoder_BodyROIVis_FgBgFeaTwoBranch(x, fg_mask, ROI_bboxs, R
 
         # Share weights for different body regions
         body_regions = _roi_tower(body_regions, z_num, repeat_num, hidden_num, data_format, activation_fn)
-        fea_list = _apply_vis(body_regions, ROI_vis, bbox_num, z_num)
-        if keep_part_prob < 1.0:
+        fused_cat = keep_part_prob >= 1.0
+        if not fused_cat:
+            fea_list = _apply_vis(body_regions, ROI_vis, bbox_num, z_num)
             for i in range(bbox_num):
                 keep = (torch.rand(batch_num, 1, device=x.device) < keep_part_prob).to(torch.float32)
                 fea_list[i] = fea_list[i] * keep
@@ -138,8 +136,13 @@ def GeneratorCNN_ID_Encoder_BodyROIVis_FgBgFeaTwoBranch(x, fg_mask, ROI_bboxs, R
         x_bg = x_bg.reshape(x_bg.shape[0], -1)
         x_bg = fully_connected(x_bg, z_num * 4, activation_fn=None)
 
-        fea_list.append(x_bg)
-        fea_all = torch.cat(fea_list, dim=-1)
+        if fused_cat:
+            # visibility multiply (models.py:433-442) + tf.concat(fea_list, -1) (:467-468) as one launch; fea_list = views
+            fea_all = A.vis_concat(body_regions, ROI_vis, x_bg, bbox_num, z_num)
+            fea_list = [fea_all[:, i * z_num:(i + 1) * z_num] for i in range(bbox_num)] + [fea_all[:, bbox_num * z_num:]]
+        else:
+            fea_list.append(x_bg)
+            fea_all = torch.cat(fea_list, dim=-1)
         variables = slim.get_variables(vs)
     return fea_all, fea_list, conv_fea_list, variables
 

@@ -101,7 +101,7 @@ class WGAN_GP(object):
         output = post(output)
 
         # tf.reshape on the logical NCHW tensor: flatten order (c, h, w)
-        output = output.reshape(-1, 8 * 4 * 8 * dim)
+        output = A.nchw_flatten(output, 8 * 4 * 8 * dim)       # (one transpose kernel when the data is physically NHWC)
         output = lib.ops.linear.Linear(name + 'Discriminator.Output', 8 * 4 * 8 * dim, 1, output)
 
         lib.ops.conv2d.unset_weights_stdev()

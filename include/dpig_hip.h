@@ -402,6 +402,35 @@ int dpig_rmsprop_step(float* p, const float* g, float* ms, float* mom, int64_t n
                       float decay, float momentum, float eps, float grad_scale, void* stream);
 int dpig_clip(float* p, int64_t n, float lo, float hi, void* stream);
 
+/* ---- graph wiring between the convolutions (csrc/dpig_glue.hip): one launch each ---------------------------------------
+ * x_fg = x * m, x_bg = x * (1 - m) (models.py:402-403); x [rows][C] fp32 or bf16 (is_bf16) with row stride, m [rows] fp32.
+ * The gradient dx = dfg * m + dbg * (1 - m); either of dfg / dbg may be NULL. */
+int dpig_mask_split_fwd(const void* x, int ldx, const float* m, int64_t rows, int C, void* fg, int ldfg, void* bg, int ldbg,
+                        int is_bf16, void* stream);
+int dpig_mask_split_bwd(const void* dfg, int ldfg, const void* dbg, int ldbg, const float* m, int64_t rows, int C, void* dx,
+                        int ldx, int is_bf16, void* stream);
+/* models.py:405-413: bbox [B][P_total][4] pixel (y1, x1, y2, x2), int32 or fp32 (is_float) -> boxes [P*B][4] = (y1/H, x1/W,
+ * y2/H, x2/W), part-major (row p*B + b), and box_ind [P*B] = b: the arguments of tf.image.crop_and_resize. */
+int dpig_roi_boxes(const void* bbox, int is_float, int B, int P_total, int P, float img_H, float img_W, float* boxes,
+                   int32_t* box_ind, void* stream);
+/* models.py:433-442, 467-468: all[b][p*z + c] = fea[p*B + b][c] * vis[b][p] (p < P), all[b][P*z + c] = bg[b][c] (c < zbg; bg
+ * may be NULL with zbg = 0); the gradient scatters back the same way (dbg may be NULL). */
+int dpig_vis_concat_fwd(const float* fea, const float* vis, int ldvis, const float* bg, int B, int P, int z, int zbg, float* all,
+                        void* stream);
+int dpig_vis_concat_bwd(const float* dall, const float* vis, int ldvis, int B, int P, int z, int zbg, float* dfea, float* dbg,
+                        void* stream);
+/* Tiled-embedding collapse of the generator's first conv (trainer.py:588-590, models.py:520-528): w [3][3][C][K] HWIO, the
+ * first E input channels are the spatially constant embedding.  wmat[e][(cy*3 + cx)*K + k] = sum of the taps border class
+ * (cy, cx) of a SAME 3x3 conv sees; _bwd is the transpose into dw[.][.][e < E][.] (dw = beta * dw + ...). */
+int dpig_emb_class_weights_fwd(const float* w, int E, int C, int K, float* wmat, void* stream);
+int dpig_emb_class_weights_bwd(const float* dwc, int E, int C, int K, float* dw, float beta, void* stream);
+/* dst[o][r][c] = beta * dst[o][r][c] + src[o][r][c] with independent outer / row strides (elements). */
+int dpig_axpby3d(const float* src, int64_t s_outer, int64_t s_row, float* dst, int64_t d_outer, int64_t d_row, int outer, int rows,
+                 int cols, float beta, void* stream);
+/* y[b][c][a] = x[b][a][c] (2- or 4-byte elements): tf.reshape of the critic's logical NCHW tensor (wgan_gp.py:433) from the
+ * physically NHWC activation, and its gradient. */
+int dpig_transpose12(const void* x, void* y, int B, int A, int C, int elem_bytes, void* stream);
+
 /* ---- losses (trainer.py:238-245, 607, 623) --------------------------------------------------- */
 /* out[0] = mean_i sce(logits_i, label) ; dlogits_i = scale*(sigmoid(x_i)-label)/n (dlogits may be NULL) */
 int dpig_sce_mean(const float* logits, int n, float label, float* out, float* dlogits, float scale,

@@ -456,3 +456,74 @@ def test_gp_penalty_fused(dev):
     z = torch.zeros(2, 7, device=dev)                       # zero slope: no NaN
     p0, dg0, _ = H.gp_penalty(z, 10.0)
     assert float(p0) == 10.0 and float(dg0.abs().max()) == 0.0
+
+
+def test_glue_kernels_equal_the_elementwise_graph_they_replace(dev):
+    """csrc/dpig_glue.hip: mask split (models.py:402-403), ROI box normalisation (:405-413), visibility multiply + concat
+    (:433-442, 467-468), the tiled-embedding class sums and their transpose, the critic's NCHW flatten
+    (wgan_gp.py:433) -- each against the plain tensor expression of the reference graph, forward and gradient."""
+    import dpig_amd.hip_ops as H
+    import dpig_amd.autograd as A
+    g = torch.Generator().manual_seed(5)
+    # mask split, fp32 and bf16, odd channel count (scalar path) and vector path
+    for C, dt in ((128, torch.float32), (24, torch.bfloat16), (5, torch.float32)):
+        x = torch.randn((2, 6, 5, C), generator=g).to(dt).to(dev).requires_grad_(True)
+        m = (torch.rand((2, 6, 5, 1), generator=g) < 0.4).float().to(dev)
+        fg, bg = A.mask_split(x, m)
+        mm = m.to(dt)
+        assert torch.equal(fg, x.detach() * mm) and torch.equal(bg, x.detach() * (1.0 - mm))
+        dfg, dbg = torch.randn(fg.shape, generator=g).to(dt).to(dev), torch.randn(bg.shape, generator=g).to(dt).to(dev)
+        (dx,) = torch.autograd.grad([fg, bg], x, [dfg, dbg])
+        ref = (dfg.float() * m + dbg.float() * (1.0 - m)).to(dt)
+        assert torch.equal(dx, ref)
+        fg2, _ = A.mask_split(x, m)
+        (dx1,) = torch.autograd.grad(fg2, x, dfg)            # only one branch carries a gradient
+        assert torch.equal(dx1, (dfg.float() * m).to(dt))
+    # ROI boxes
+    bbox = torch.randint(0, 60, (3, 7, 4), generator=g, dtype=torch.int32).to(dev)
+    boxes, ind = H.roi_boxes(bbox, 5, 128.0, 64.0)
+    b = bbox[:, :5, :].float()
+    ref = torch.stack([b[..., 0] / 128.0, b[..., 1] / 64.0, b[..., 2] / 128.0, b[..., 3] / 64.0], dim=-1).permute(1, 0, 2).reshape(15, 4)
+    assert torch.equal(boxes, ref) and torch.equal(ind.cpu(), torch.arange(3, dtype=torch.int32).repeat(5))
+    assert torch.equal(H.roi_boxes(bbox.float(), 5, 128.0, 64.0)[0], ref)
+    # visibility multiply + concat
+    B, P, z = 3, 7, 32
+    fea = torch.randn((P * B, z), generator=g).to(dev).requires_grad_(True)
+    bgf = torch.randn((B, 4 * z), generator=g).to(dev).requires_grad_(True)
+    vis = (torch.rand((B, P), generator=g) < 0.7).float().to(dev)
+    out = A.vis_concat(fea, vis, bgf, P, z)
+    ref = torch.cat([fea.reshape(P, B, z)[p] * vis[:, p:p + 1] for p in range(P)] + [bgf], dim=-1)
+    assert torch.equal(out, ref)
+    dall = torch.randn(out.shape, generator=g).to(dev)
+    d1 = torch.autograd.grad(out, [fea, bgf], dall)
+    d2 = torch.autograd.grad(ref, [fea, bgf], dall)
+    assert torch.equal(d1[0], d2[0]) and torch.equal(d1[1], d2[1])
+    assert torch.equal(A.vis_concat(fea, vis, None, P, z), ref[:, :P * z])
+    # class sums of the filter taps and their transpose
+    E, Pc, K = 40, 18, 24
+    w = torch.randn((3, 3, E + Pc, K), generator=g).to(dev)
+    wmat = H.emb_class_weights_fwd(w, E)
+    vt = (slice(1, 3), slice(0, 3), slice(0, 2))
+    we = w[:, :, :E, :]
+    wy = torch.stack([we[vt[c]].sum(0) for c in range(3)])
+    wc = torch.stack([wy[:, vt[c]].sum(1) for c in range(3)], dim=1)
+    ref = wc.permute(2, 0, 1, 3).reshape(E, 9 * K)
+    assert (wmat - ref).abs().max().item() <= 1e-6 * ref.abs().max().item()
+    dwc = torch.randn((E, 9 * K), generator=g).to(dev)
+    outw = torch.full((3, 3, E + Pc, K), 2.0, device=dev)
+    H.emb_class_weights_bwd(dwc, E, outw, 1.0)
+    d = dwc.view(E, 3, 3, K).permute(1, 2, 0, 3)
+    dwy = torch.stack([d[1:].sum(0), d.sum(0), d[:2].sum(0)])
+    dwe = torch.stack([dwy[:, 1:].sum(1), dwy.sum(1), dwy[:, :2].sum(1)], dim=1)
+    assert (outw[:, :, :E, :] - (dwe + 2.0)).abs().max().item() <= 1e-5 and bool((outw[:, :, E:, :] == 2.0).all())
+    dwp = torch.randn((3, 3, 32, K), generator=g).to(dev)
+    H.axpby3d(dwp.view(9, 32, K)[:, :Pc, :], outw.view(9, E + Pc, K)[:, E:, :], 0.0)
+    assert torch.equal(outw[:, :, E:, :], dwp[:, :, :Pc, :])
+    # NCHW flatten of an NHWC tensor
+    for dt in (torch.float32, torch.bfloat16):
+        xn = torch.randn((4, 8, 4, 96), generator=g).to(dt).to(dev).requires_grad_(True)
+        y = A.nchw_flatten(xn.permute(0, 3, 1, 2), 8 * 4 * 96 // 2)
+        ref = xn.permute(0, 3, 1, 2).reshape(-1, 8 * 4 * 96 // 2)
+        assert torch.equal(y, ref)
+        dy = torch.randn(y.shape, generator=g).to(dt).to(dev)
+        assert torch.equal(torch.autograd.grad(y, xn, dy)[0], torch.autograd.grad(ref, xn, dy)[0])
