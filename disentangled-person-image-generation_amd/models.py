@@ -72,6 +72,29 @@ def _apply_vis(body_regions, ROI_vis, bbox_num, z_num):
     return fea_list
 
 
+def GeneratorCNN_ID_Encoder_BodyROI(x, ROI_bboxs, bbox_num, z_num, repeat_num, hidden_num, data_format, activation_fn=relu,
+                                    keep_part_prob=1.0, roi_size=48, reuse=False):
+    """Reference models.py:275-325: the ROI encoder without visibility flags (the DeepFashion stage-II trainers,
+    trainer_256.py:310-311, 604-605)."""
+    with variable_scope("G_encoder", reuse=reuse) as vs:
+        batch_num = x.shape[0]
+        img_H, img_W = float(x.shape[1]), float(x.shape[2])
+        x = slim.conv2d(x, hidden_num, 3, 1, activation_fn=activation_fn, data_format=data_format)
+        x = slim.res_block(x, hidden_num, 3, activation_fn=activation_fn, data_format=data_format)
+        boxes, box_ind = _normalised_boxes(ROI_bboxs, bbox_num, img_H, img_W)
+        body_regions = A.crop_and_resize(x, boxes, box_ind, roi_size, roi_size)
+        body_regions = _roi_tower(body_regions, z_num, repeat_num, hidden_num, data_format, activation_fn)
+        fea = body_regions.reshape(bbox_num, batch_num, z_num)           # tf.split(body_regions, bbox_num, axis=0)
+        fea_list = [fea[i] for i in range(bbox_num)]
+        if keep_part_prob < 1.0:
+            for i in range(bbox_num):
+                keep = (torch.rand(1, 1, device=x.device) < keep_part_prob).to(torch.float32)     # bernoulliSample([p]) tiled
+                fea_list[i] = fea_list[i] * keep
+        fea_all = torch.cat(fea_list, dim=-1)
+        variables = slim.get_variables(vs)
+    return fea_all, fea_list, variables
+
+
 def GeneratorCNN_ID_Encoder_BodyROIVis(x, ROI_bboxs, ROI_vis, bbox_num, z_num, repeat_num, hidden_num, data_format,
                                        activation_fn=relu, keep_part_prob=1.0, roi_size=48, reuse=False):
     """Reference models.py:328-388 (DeepFashion appearance encoder)."""

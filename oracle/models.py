@@ -163,6 +163,22 @@ def encoder_roi(P, x, ROI_bboxs, ROI_vis, bbox_num=7, z_num=32, repeat_num=7, hi
     return torch.cat(fea_list, dim=-1)
 
 
+def encoder_body_roi(P, x, ROI_bboxs, bbox_num=7, z_num=32, repeat_num=7, hidden_num=128, roi_size=48,
+                     scope="Encoder/G_encoder"):
+    """models.py:275-325 (`GeneratorCNN_ID_Encoder_BodyROI`: the ROI encoder WITHOUT the visibility multiply; the DeepFashion
+    stage-II trainers build it with repeat_num + 1 levels and the default 48 x 48 crops, trainer_256.py:310-311, 604-605)."""
+    sc = _Scope(scope)
+    act = O.relu
+    x = _conv(P, sc, x, hidden_num, 3, 1, act)
+    res = x
+    x = _conv(P, sc, x, hidden_num, 3, 1, act)
+    x = _conv(P, sc, x, hidden_num, 3, 1, act)
+    x = x + res
+    body = _crops(x, ROI_bboxs, bbox_num, roi_size)
+    body = _tower(P, sc, body, z_num, repeat_num, hidden_num, act)
+    return torch.cat(list(torch.split(body, x.shape[0], dim=0)), dim=-1)
+
+
 def generator_uae(P, x, pose, input_channel=3, z_num=64, repeat_num=5, hidden_num=128, scope="ID_AE/G",
                   taps=None):
     """models.py:518-576.  x = tiled embedding [B,H,W,E]."""
@@ -383,6 +399,16 @@ def stage2_losses(P, real, z, side="Fg", hidden=512):
     fake = gaussian_fc_res(P, z, real.shape[1], 4, hidden, scope="Gaussian_FC_%s/G_FC" % side)
     d_fake = fc_discriminator(P, fake, fake.shape[1], name="%s_FCDis_" % side)
     d_real = fc_discriminator(P, real, real.shape[1], name="%s_FCDis_" % side)
+    return -d_fake.mean(), d_fake.mean() - d_real.mean(), fake
+
+
+def stage2_256_losses(P, real, z, hidden=512):
+    """Model 102 (trainer_256.py:320-330): ONE Gaussian mapper under `Gaussian_FC`, the critic `FCDis_Discriminator.*` applied
+    to the pair [real; fake] in one call, wgan mode."""
+    fake = gaussian_fc_res(P, z, real.shape[1], 4, hidden, scope="Gaussian_FC/G_FC")
+    pair = torch.cat([real, fake], dim=0)
+    d = fc_discriminator(P, pair, pair.shape[1], name="FCDis_")
+    d_real, d_fake = torch.split(d, d.shape[0] // 2)
     return -d_fake.mean(), d_fake.mean() - d_real.mean(), fake
 
 

@@ -8,6 +8,7 @@ oracle.models.ParamStore(seed), numpy Generator streams), only expected outputs 
 
     python tests/golden/make_golden.py            (~5 min on 8 cores)
     python tests/golden/make_golden.py --small    the width-16 model (seconds): the fixture the CPU suite re-derives
+    python tests/golden/make_golden.py --stage2-256   stage2_df256_w16.npz: the DeepFashion stage-II models 102 / 103 / 104 (seconds)
     python tests/golden/make_golden.py --modes    modes_w32.npz: the four `_gan_loss` modes (wgan-gp incl. the critic's
                                                   gradients), weights after two TF-Adam iterations, model 101
                                                   (trainer_256.py) and the stage-II losses at width 32 (~2 min)
@@ -144,9 +145,61 @@ def mode_outputs(which=("losses", "adam", "df256", "stage2")):
     return out
 
 
+S2_W = 16                            # width of the DeepFashion stage-II fixture
+S2_POSE_SEED = 26
+
+
+def pose_rcv_256(Bp, seed):
+    """Seeded (row, col, visibility) keypoint triplets in 256 x 256 pixel coordinates, [Bp, 54]."""
+    g = torch.Generator().manual_seed(seed)
+    r = torch.randint(0, 256, (Bp, 18, 1), generator=g).double()
+    c = torch.randint(0, 256, (Bp, 18, 1), generator=g).double()
+    v = (torch.rand(Bp, 18, 1, generator=g, dtype=torch.float64) < 0.85).double()
+    return torch.cat([r, c, v], -1).reshape(Bp, 54)
+
+
+def stage2_256_outputs():
+    """DeepFashion 256 x 256 stage II (run_DF_train.sh:39-77) at width 16: model 102 (frozen `GeneratorCNN_ID_Encoder_BodyROI` ->
+    real embeddings, `Gaussian_FC` mapper, `FCDis_` critic on the pair, wgan losses), model 103 (pose auto-encoder loss with the
+    256-pixel normalisation) and model 104 (pose-embedding wgan losses).  Shared by the generator (--stage2-256) and
+    tests/test_oracle.py, which re-derives it."""
+    out = {"meta": np.array([BATCH_SEED, PARAM_SEED, Z_SEED, S2_POSE_SEED, B, S2_W])}
+    ob = OM.batch_to_torch(synthetic.make_batch(B, img_H=256, img_W=256, seed=BATCH_SEED))
+    P = OM.ParamStore(seed=PARAM_SEED)
+    with torch.no_grad():
+        embs = OM.encoder_body_roi(P, ob["x"], ob["part_bbox"], 7, 32, 7, S2_W, roi_size=48)
+    gz = torch.Generator().manual_seed(Z_SEED)
+    z = torch.randn(B, embs.shape[1], generator=gz, dtype=torch.float64) * 0.2
+    g_ref, d_ref, fake = OM.stage2_256_losses(P, embs, z)
+    out["m102/embs"] = embs.numpy()
+    out["m102/fake"] = fake.detach().numpy()
+    out["m102/g_loss"] = np.array(g_ref.item())
+    out["m102/d_loss"] = np.array(d_ref.item())
+    rcv = pose_rcv_256(6, S2_POSE_SEED)
+    P2 = OM.ParamStore(seed=PARAM_SEED + 1)
+    loss, zp, G_pose = OM.pose_ae_loss(P2, rcv, img_H=256, img_W=256)
+    out["m103/reconstruct_loss"] = np.array(loss.item())
+    out["m103/pose_embs"] = zp.detach().numpy()
+    out["m103/G_pose_rcv"] = G_pose.detach().numpy()
+    P3 = OM.ParamStore(seed=PARAM_SEED + 2)
+    zz = torch.randn(6, 32, generator=gz, dtype=torch.float64) * 0.2
+    g4, d4, fake4, real4 = OM.pose_gan_losses(P3, rcv, zz, img_H=256, img_W=256)
+    out["m104/g_loss"] = np.array(g4.item())
+    out["m104/d_loss"] = np.array(d4.item())
+    out["m104/fake"] = fake4.detach().numpy()
+    out["m104/real"] = real4.detach().numpy()
+    return out
+
+
 def main():
     torch.set_num_threads(os.cpu_count() or 1)
     t0 = time.time()
+    if "--stage2-256" in sys.argv:
+        out = stage2_256_outputs()
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "stage2_df256_w16.npz")
+        np.savez_compressed(path, **{k: (v.astype(np.float64) if v.dtype.kind == "f" else v) for k, v in out.items()})
+        print("wrote %s (%.0f KB) in %.1fs" % (path, os.path.getsize(path) / 1024.0, time.time() - t0))
+        return
     if "--modes" in sys.argv:
         out = mode_outputs()
         path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "modes_w32.npz")

@@ -374,3 +374,21 @@ def test_generated_crop_and_resize_shapes_incl_grad(shape, nbox, ch, cw, seed):
     dout = rnd(ref.shape, seed + 1)
     out.backward(T(dout))
     assert np.abs(it.grad.numpy() - naive.crop_and_resize_grad_image(dout, boxes, ind, img.shape)).max() < 1e-12
+
+
+def test_oracle_reproduces_stage2_df256_golden():
+    """tests/golden/stage2_df256_w16.npz (`make_golden.py --stage2-256`: the DeepFashion stage-II models 102 / 103 / 104 of
+    trainer_256.py:266-700) is re-derived from seeds by today's oracle."""
+    import importlib.util
+    import os
+    import numpy as np
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(here, "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    want = np.load(os.path.join(here, "golden", "stage2_df256_w16.npz"))
+    got = mg.stage2_256_outputs()
+    assert set(got.keys()) == set(want.keys())
+    for k in want.keys():
+        scale = max(float(np.abs(want[k]).max()), 1e-12)
+        assert float(np.abs(np.asarray(got[k], dtype=np.float64) - want[k]).max()) <= 1e-9 * scale, k

@@ -658,3 +658,180 @@ def test_inference_harness_against_oracle(dev):
     assert (out["G"].double().cpu() - torch.clamp((G + 1) * 127.5, 0, 255)).abs().max().item() < 1e-3 * 255
     assert _rel(out["G_dis_score"], score.reshape(B, -1).mean(1)) < 1e-3
     lib.delete_all_params(); slim.reset_scopes()
+
+
+# ---- DeepFashion 256 x 256 stage II (run_DF_train.sh:39-77; trainer_256.py:266-700) and BASELINE configs[4] --------------
+def _s2gold():
+    import importlib.util
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("make_golden", os.path.join(here, "golden", "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    gold = np.load(os.path.join(here, "golden", "stage2_df256_w16.npz"))
+    return mg, gold
+
+
+def _near(a, b, tol):
+    return abs(float(a) - float(b)) <= tol * max(abs(float(b)), 1e-3)
+
+
+def test_df256_stage2_appearance_gan_trainer(dev):
+    """Model 102 (trainer_256.py:266-400): frozen `GeneratorCNN_ID_Encoder_BodyROI` (repeat_num + 1 levels, 48 x 48 crops, no
+    visibility flags) -> real embeddings, `Gaussian_FC` mapper, `FCDis_` critic on the pair, wgan losses, RMSProp + clip, the
+    loop order -- against the committed golden fixture AND the oracle's parameter gradients."""
+    import dpig_amd.tflib as lib
+    from dpig_amd import slim, synthetic
+    from dpig_amd.trainer import Config
+    from dpig_amd.trainer_256 import DPIG_Encoder_subSampleAppNet_GAN_BodyROI_256
+    from oracle import models as OM
+    lib.delete_all_params(); slim.reset_scopes()
+    mg, gold = _s2gold()
+    bseed, pseed, zseed, _, B, W = [int(v) for v in gold["meta"]]
+    LR = 1e-3
+    batch_np = synthetic.make_batch(B, img_H=256, img_W=256, seed=bseed)
+    ob = OM.batch_to_torch(batch_np)
+    P = OM.ParamStore(seed=pseed)
+    with torch.no_grad():
+        embs_o = OM.encoder_body_roi(P, ob["x"], ob["part_bbox"], 7, 32, 7, W, roi_size=48)
+    gz = torch.Generator().manual_seed(zseed)
+    z = torch.randn(B, embs_o.shape[1], generator=gz, dtype=torch.float64) * 0.2
+    g_ref, d_ref, fake_o = OM.stage2_256_losses(P, embs_o, z)
+    gnames = [n for n in P.p if n.startswith("Gaussian_FC/")]
+    dnames = [n for n in P.p if "FCDis_Discriminator." in n]
+    gg = dict(zip(gnames, torch.autograd.grad(g_ref, [P.p[n] for n in gnames], retain_graph=True)))
+    dg = dict(zip(dnames, torch.autograd.grad(d_ref, [P.p[n] for n in dnames])))
+    _load(P, dev)
+    cfg = Config(batch_size=B, img_H=256, img_W=256, conv_hidden_num=W, g_lr=LR, d_lr=LR)
+    tr = DPIG_Encoder_subSampleAppNet_GAN_BodyROI_256(cfg, dev)
+    gb = synthetic.to_device(batch_np, dev)
+    tr.init_net(gb)
+    assert set(lib._params.keys()) == set(P.p.keys())
+    assert sorted(p.dpig_name for p in tr.G_flat.params) == sorted(gnames) and sorted(p.dpig_name for p in tr.D_flat.params) == sorted(dnames)
+    real, _ = tr.encode(gb)
+    assert tuple(real.shape) == (B, 224)
+    assert _rel(real, torch.from_numpy(gold["m102/embs"])) < 1e-3 and _rel(real, embs_o) < 1e-4
+    zz = z.float().to(dev)
+    with torch.no_grad():
+        fake, _ = tr.mapper(tr.dim, zz)
+    assert _rel(fake, torch.from_numpy(gold["m102/fake"])) < 1e-3
+    d_loss = tr.d_optim_embs(gb, z=zz)                        # critic first: the mapper still has the oracle's weights
+    assert _near(d_loss.item(), gold["m102/d_loss"], 1e-3) and _near(d_loss.item(), d_ref.item(), 1e-4)
+    for n in dnames:
+        assert _rel(lib._params[n]._dpig_grad, dg[n]) < 2e-3, n
+        p_new, _, _ = OM.tf_rmsprop_step(P.p[n].detach(), dg[n], torch.ones_like(dg[n]), torch.zeros_like(dg[n]), LR)
+        assert (lib._params[n].detach().double().cpu() - p_new.clamp(-0.01, 0.01)).abs().max().item() < 2e-5, n
+    with torch.no_grad():
+        for n in dnames:
+            lib._params[n].copy_(P.p[n].to(torch.float32))
+    g_loss = tr.g_optim_embs(gb, z=zz)
+    assert _near(g_loss.item(), gold["m102/g_loss"], 1e-3) and _near(g_loss.item(), g_ref.item(), 1e-4)
+    for n in gnames:
+        assert _rel(lib._params[n]._dpig_grad, gg[n]) < 2e-3, n
+    t_g, t_d = tr.g_opt.t, tr.d_opt.t
+    out = tr.train_step(gb)                 # step 0: five clipped critic updates, no mapper update (trainer_256.py:362-373)
+    assert "g_loss_embs" not in out and tr.d_opt.t == t_d + 5 and tr.g_opt.t == t_g
+    out = tr.train_step(gb)
+    assert "g_loss_embs" in out and tr.g_opt.t == t_g + 1 and tr.d_opt.t == t_d + 10
+    assert float(tr.D_flat.flat.abs().max()) <= 0.01 + 1e-9
+    lib.delete_all_params(); slim.reset_scopes()
+
+
+def test_df256_stage2_pose_trainers(dev):
+    """Models 103 / 104 (trainer_256.py:404-509, 511-700): the pose auto-encoder and the pose-embedding GAN with the 256-pixel
+    keypoint normalisation, against the golden fixture."""
+    import dpig_amd.tflib as lib
+    from dpig_amd import slim
+    from dpig_amd.trainer import Config
+    from dpig_amd.trainer_256 import DPIG_PoseRCV_AE_BodyROI_256, DPIG_subnetSamplePoseRCV_GAN_BodyROI_256
+    from oracle import models as OM
+    mg, gold = _s2gold()
+    _, pseed, zseed, poseseed, B, _ = [int(v) for v in gold["meta"]]
+    rcv = mg.pose_rcv_256(6, poseseed)
+    cfg = Config(batch_size=6, img_H=256, img_W=256, g_lr=1e-3, d_lr=1e-3)
+    # model 103
+    lib.delete_all_params(); slim.reset_scopes()
+    P2 = OM.ParamStore(seed=pseed + 1)
+    OM.pose_ae_loss(P2, rcv, img_H=256, img_W=256)
+    _load(P2, dev)
+    tr = DPIG_PoseRCV_AE_BodyROI_256(cfg, dev)
+    batch = {"pose_rcv": rcv.float().to(dev)}
+    tr.init_net(batch)
+    assert set(lib._params.keys()) == set(P2.p.keys())
+    o0 = tr.train_step(batch)
+    assert _near(o0["reconstruct_loss"], gold["m103/reconstruct_loss"], 1e-4)
+    o1 = tr.train_step(batch)
+    assert tr.g_opt.t == 1 and _rel(o1["G_pose_rcv"], torch.from_numpy(gold["m103/G_pose_rcv"])) < 1e-3
+    assert tuple(tr.G_pose(o1["G_pose_rcv"]).shape) == (6, 256, 256, 18)
+    # model 104
+    lib.delete_all_params(); slim.reset_scopes()
+    P3 = OM.ParamStore(seed=pseed + 2)
+    gz = torch.Generator().manual_seed(zseed)
+    torch.randn(B, 224, generator=gz, dtype=torch.float64)            # (the generator drew model 102's z first)
+    zz = torch.randn(6, 32, generator=gz, dtype=torch.float64) * 0.2
+    OM.pose_gan_losses(P3, rcv, zz, img_H=256, img_W=256)
+    _load(P3, dev)
+    tr = DPIG_subnetSamplePoseRCV_GAN_BodyROI_256(cfg, dev)
+    tr.init_net(batch)
+    assert set(lib._params.keys()) == set(P3.p.keys())
+    real, _ = tr.encode_pose(batch["pose_rcv"])
+    assert _rel(real, torch.from_numpy(gold["m104/real"])) < 1e-3
+    snap = [p.detach().clone() for p in tr.D_flat.params]
+    d_loss = tr.d_optim_embs(batch, z=zz.float().to(dev))
+    assert _near(d_loss.item(), gold["m104/d_loss"], 1e-3)
+    with torch.no_grad():
+        for p, s0 in zip(tr.D_flat.params, snap):
+            p.copy_(s0)
+    g_loss = tr.g_optim_embs(batch, z=zz.float().to(dev))
+    assert _near(g_loss.item(), gold["m104/g_loss"], 1e-3)
+    lib.delete_all_params(); slim.reset_scopes()
+
+
+def test_df256_wgan_gp_bf16_step(dev):
+    """BASELINE configs[4]'s per-GPU workload in small: model 101 (trainer_256.py:31-88) with MODE='wgan-gp' (LayerNorm
+    critic on the pair [x; G], 8 logit rows per image, gradient penalty through the double-backward sweep) in bf16 storage
+    mode.  d_loss for a pinned alpha against the fp64 oracle within bf16 storage rounding; a full step (5 critic iterations +
+    g_optim) stays finite and moves both parameter sets."""
+    import dpig_amd.hip_ops as H
+    import dpig_amd.tflib as lib
+    from dpig_amd import slim, synthetic
+    from dpig_amd.trainer import Config
+    from dpig_amd.trainer_256 import DPIG_Encoder_GAN_BodyROI_256
+    from oracle import models as OM
+    lib.delete_all_params(); slim.reset_scopes()
+    B, HID, ZN = 2, 32, 16
+    batch_np = synthetic.make_batch(B, img_H=256, img_W=256, seed=33)
+    ob = OM.batch_to_torch(batch_np)
+    P = OM.ParamStore(seed=14)
+    with torch.no_grad():
+        embs_o = OM.encoder_roi(P, ob["x"], ob["part_bbox"], ob["part_vis"], 7, 32, 7, HID, roi_size=64)
+        G_o, _ = OM.generator_uae(P, embs_o.reshape(B, 1, 1, -1).expand(B, 256, 256, embs_o.shape[1]), ob["pose"], 3, ZN, 5, HID)
+    g = torch.Generator().manual_seed(15)
+    alpha = torch.rand(B, generator=g, dtype=torch.float64)
+    D = lambda t: OM.dcgan_discriminator(P, t, "wgan-gp")          # noqa: E731
+    _, d_ref = OM.gan_losses("wgan-gp", D, ob["x"], G_o, alpha)
+    lib.set_device(dev)
+    for n, v in P.state_numpy().items():
+        lib.param(n, v, trainable=P.trainable[n])
+    tr = DPIG_Encoder_GAN_BodyROI_256(Config(batch_size=B, img_H=256, img_W=256, conv_hidden_num=HID, z_num=ZN, gan_mode='wgan-gp',
+                                             compute_dtype='bf16'), dev)
+    batch = synthetic.to_device(batch_np, dev)
+    try:
+        tr.init_net(batch)
+        assert H.get_compute() == "bf16" and set(lib._params.keys()) == set(P.p.keys())
+        assert (tr.d_opt.b1, tr.d_opt.b2) == (0.5, 0.9)
+        tr.gp_alpha = alpha.float().to(dev)
+        d0 = tr._d_optim_eager(batch, update=False)
+        print("df256 wgan-gp bf16: d_loss %.5f (oracle %.5f)" % (float(d0["d_loss"]), float(d_ref)))
+        assert abs(float(d0["d_loss"]) - float(d_ref)) < 8e-2 * max(abs(float(d_ref)), 1.0)
+        tr.gp_alpha = None
+        w_g, w_d = tr.G_flat.flat.detach().clone(), tr.D_flat.flat.detach().clone()
+        o = tr.train_step(batch, batch)                     # step 0: five critic iterations
+        assert tr.d_opt.t == 5 and torch.isfinite(o["d_loss"])
+        o = tr.train_step(batch, batch)
+        assert tr.g_opt.t == 1 and tr.d_opt.t == 10 and torch.isfinite(o["g_loss"]) and torch.isfinite(o["d_loss"])
+        assert float((tr.G_flat.flat - w_g).abs().max()) > 0 and float((tr.D_flat.flat - w_d).abs().max()) > 0
+        assert bool(torch.isfinite(tr.G_flat.grad).all()) and bool(torch.isfinite(tr.D_flat.grad).all())
+    finally:
+        H.set_compute("f32")
+        lib.delete_all_params(); slim.reset_scopes()
