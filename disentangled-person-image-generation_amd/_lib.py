@@ -29,6 +29,21 @@ class DpigConvDesc(ctypes.Structure):
     ]
 
 
+class DpigCriticDesc(ctypes.Structure):
+    _fields_ = [
+        ("B", ctypes.c_int32), ("H", ctypes.c_int32), ("W", ctypes.c_int32), ("Cin", ctypes.c_int32),
+        ("dim", ctypes.c_int32), ("lrelu_alpha", ctypes.c_float), ("ln_eps", ctypes.c_float), ("lam", ctypes.c_float),
+        ("compute", ctypes.c_int32),
+    ]
+
+
+class DpigCriticParams(ctypes.Structure):      # DpigCriticGrads has the same layout (non-const pointers)
+    _fields_ = [
+        ("w", ctypes.c_void_p * 4), ("b", ctypes.c_void_p * 4), ("ln_scale", ctypes.c_void_p * 3),
+        ("ln_offset", ctypes.c_void_p * 3), ("w_out", ctypes.c_void_p),
+    ]
+
+
 # every symbol include/dpig_hip.h declares: name -> (restype, argtypes)
 _vp, _i, _f, _i64, _sz = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_int64, ctypes.c_size_t
 _dp = ctypes.POINTER(DpigConvDesc)
@@ -105,6 +120,9 @@ SYMBOLS = {
     "dpig_ssim_gray_u8": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "dpig_gp_interpolate": (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp]),
     "dpig_gp_penalty": (_i, [_vp, _i, _i64, _f, _vp, _vp, _vp, _vp]),
+    "dpig_gp_double_backward_workspace_bytes": (_sz, [ctypes.POINTER(DpigCriticDesc)]),
+    "dpig_gp_double_backward": (_i, [ctypes.POINTER(DpigCriticDesc), ctypes.POINTER(DpigCriticParams), _vp, _vp, _vp, _f,
+                                     ctypes.POINTER(DpigCriticParams), _vp, _vp, _vp, _sz, _vp]),
     "dpig_upsample2x_fwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "dpig_upsample2x_bwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),
     "dpig_adam_step": (_i, [_vp, _vp, _vp, _vp, _i64, _vp, _f, _f, _f, _i, _f, _vp]),

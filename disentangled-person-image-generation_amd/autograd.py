@@ -538,6 +538,33 @@ def gp_penalty(g, lam):
     return _GPPenaltyFn.apply(g, lam)
 
 
+class _FusedGPFn(torch.autograd.Function):
+    """The whole penalty term of the DCGAN critic (trainer.py:222-236 over wgan_gp.py:407-440) through the library's single
+    entry point `dpig_gp_double_backward`: value and every parameter gradient in one call, no second-level autograd tape."""
+
+    @staticmethod
+    def forward(ctx, real, fake, alpha, lam, dim, keys, *params):
+        want = any(ctx.needs_input_grad[6:])
+        pd = {k: p.detach() for k, p in zip(keys, params)}
+        pen, _, grads = H.gp_double_backward(pd, real, fake, alpha, lam, dim=dim, grads=True if want else None)
+        ctx.grads = [grads[k] for k in keys] if want else None
+        ctx.params = params
+        return pen.reshape(())
+
+    @staticmethod
+    def backward(ctx, dout):
+        out = [None] * 6
+        for i, (p, g) in enumerate(zip(ctx.params, ctx.grads)):
+            out.append(_sink_small(p, g * dout) if ctx.needs_input_grad[6 + i] else None)
+        return tuple(out)
+
+
+def gp_fused(real, fake, alpha, lam, dim, named_params):
+    """named_params: ordered {critic variable name: parameter} with the keys of `hip_ops.CRITIC_KEYS`."""
+    keys = tuple(named_params.keys())
+    return _FusedGPFn.apply(real, fake, alpha, float(lam), int(dim), keys, *[named_params[k] for k in keys])
+
+
 _SYNC_BN_GROUP = [False, None]      # (enabled, process group)
 
 

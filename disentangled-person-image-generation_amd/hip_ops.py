@@ -1121,6 +1121,61 @@ def gp_penalty(g, lam):
     return pen, dg, slopes
 
 
+CRITIC_KEYS = (["Discriminator.%d.Filters" % i for i in range(1, 5)], ["Discriminator.%d.Biases" % i for i in range(1, 5)],
+               ["Discriminator.BN%d.scale" % i for i in range(2, 5)], ["Discriminator.BN%d.offset" % i for i in range(2, 5)],
+               "Discriminator.Output.W")
+
+
+def _critic_struct(tensors, prefix):
+    from ._lib import DpigCriticParams
+    s = DpigCriticParams()
+    ws, bs, sc, of, wo = CRITIC_KEYS
+    for i in range(4):
+        s.w[i] = ptr(tensors[prefix + ws[i]])
+        s.b[i] = ptr(tensors[prefix + bs[i]])
+    for i in range(3):
+        s.ln_scale[i] = ptr(tensors[prefix + sc[i]])
+        s.ln_offset[i] = ptr(tensors[prefix + of[i]])
+    s.w_out = ptr(tensors[prefix + wo])
+    return s
+
+
+def gp_double_backward(params, real, fake, alpha, lam=10.0, dim=64, grads=None, beta=0.0, prefix="", compute=None,
+                       lrelu_alpha=0.2, ln_eps=1e-5):
+    """trainer.py:222-236 for Discriminator = DCGANDiscriminator (wgan_gp.py:407-440) in one library call: the penalty value
+    [1], the per-sample slopes [B] and -- when `grads` (dict keyed like `params`, or True to allocate) is given -- d penalty /
+    d theta for every critic parameter (grads = beta * grads + ...).  `params`: dict name -> fp32 device tensor holding
+    `prefix + 'Discriminator.{1..4}.Filters' / '.Biases'`, `'Discriminator.BN{2..4}.scale' / '.offset'` and
+    `'Discriminator.Output.W'`; real / fake: NHWC images [B, H, W, Cin]; alpha: [B]."""
+    from ._lib import DpigCriticDesc
+    real, fake = to_f32(real).contiguous(), to_f32(fake).contiguous()
+    _require_gpu(real)
+    B, Hh, W, Cin = real.shape
+    keys = [prefix + k for grp in CRITIC_KEYS[:4] for k in grp] + [prefix + CRITIC_KEYS[4]]
+    for k in keys:
+        t = params[k]
+        if not (t.is_cuda and t.dtype == F32 and t.is_contiguous()):
+            raise RuntimeError("gp_double_backward: parameter %s must be a dense fp32 device tensor" % k)
+    d = DpigCriticDesc(B, Hh, W, Cin, int(dim), float(lrelu_alpha), float(ln_eps), float(lam),
+                       _COMPUTE[0] if compute is None else int(compute))
+    P = _critic_struct(params, prefix)
+    if grads is True:
+        grads = {k: torch.empty_like(params[k]) for k in keys}
+        beta = 0.0
+    G = _critic_struct(grads, prefix) if grads is not None else None
+    pen = torch.empty(1, dtype=F32, device=real.device)
+    slopes = torch.empty(B, dtype=F32, device=real.device)
+    nbytes = lib().dpig_gp_double_backward_workspace_bytes(ctypes.byref(d))
+    if nbytes == 0:
+        raise RuntimeError("gp_double_backward: %s" % lib().dpig_last_error().decode())
+    wsb, wsn = workspace.get(nbytes, real.device)
+    check(lib().dpig_gp_double_backward(ctypes.byref(d), ctypes.byref(P), ptr(real), ptr(fake),
+                                        ptr(alpha.contiguous().reshape(-1).float()), float(beta),
+                                        ctypes.byref(G) if G is not None else None, ptr(pen), ptr(slopes), ptr(wsb), wsn,
+                                        stream_ptr()), "gp_double_backward")
+    return pen, slopes, grads
+
+
 def upsample2x_fwd(x):
     if x.dtype == BF16:
         return _like_input(upsample2x_fwd(to_f32(x)), x)

@@ -272,7 +272,22 @@ class GradAllReduce(object):
             self.dist.broadcast(flat_params, src=0)
 
 
-def gradient_penalty(Discriminator, real_data, fake_data, LAMBDA=10., alpha=None):
+def critic_variables(name='', registry=None):
+    """The DCGAN critic's variables under `name` in creation order (wgan_gp.py:407-440), keyed WITHOUT the prefix: the operand
+    list of the fused penalty call.  None unless every one exists as a dense fp32 tensor (e.g. BatchNorm critics have no
+    LayerNorm variables; bf16 runs keep using the taped path)."""
+    reg = lib._params if registry is None else registry
+    out = {}
+    for grp in H.CRITIC_KEYS[:4]:
+        for k in grp:
+            out[k] = reg.get(name + k)
+    out[H.CRITIC_KEYS[4]] = reg.get(name + H.CRITIC_KEYS[4])
+    if any(v is None or v.dtype != torch.float32 for v in out.values()):
+        return None
+    return out
+
+
+def gradient_penalty(Discriminator, real_data, fake_data, LAMBDA=10., alpha=None, fused=None):
     """trainer.py:222-236 / wgan_gp.py:605-619: LAMBDA * mean_b (||grad_xhat D(xhat)||_2 - 1)^2 with
     xhat = real + alpha*(fake - real), alpha ~ U[0,1) per sample.  As written the reference only type-checks
     for flat [B,D] inputs (SURVEY C-3); this is the canonical form (per-sample alpha, L2 norm over all
@@ -282,6 +297,9 @@ def gradient_penalty(Discriminator, real_data, fake_data, LAMBDA=10., alpha=None
     B = real_data.shape[0]
     if alpha is None:
         alpha = torch.rand([B] + [1] * (real_data.dim() - 1), device=real_data.device)
+    if fused is not None:
+        # Discriminator == DCGANDiscriminator over NHWC images: one library call (`dpig_gp_double_backward`) instead of the tape
+        return A.gp_fused(real_data.detach(), fake_data.detach(), alpha.reshape(B), LAMBDA, fused["dim"], fused["params"])
     interpolates = H.gp_interpolate(real_data.detach(), fake_data.detach(), alpha.reshape(B)).requires_grad_(True)
     D_int = Discriminator(interpolates)
     with A.no_param_grads():      # d(sum D(xhat))/dtheta is not part of the loss: input gradient only
@@ -290,7 +308,7 @@ def gradient_penalty(Discriminator, real_data, fake_data, LAMBDA=10., alpha=None
     return A.gp_penalty(gradients, LAMBDA)
 
 
-def gan_loss(wgan_gp, disc_real, disc_fake, Discriminator=None, real_data=None, fake_data=None, alpha=None):
+def gan_loss(wgan_gp, disc_real, disc_fake, Discriminator=None, real_data=None, fake_data=None, alpha=None, fused_gp=None):
     """trainer.py:217-252 (`_gan_loss`), modes dcgan / wgan / wgan-gp / lsgan.  Returns (gen_cost, disc_cost);
     either input may be None when that side is not needed (TF prunes the unused branch)."""
     mode = wgan_gp.MODE
@@ -315,7 +333,7 @@ def gan_loss(wgan_gp, disc_real, disc_fake, Discriminator=None, real_data=None, 
             gen_cost = -A.logit_mean(disc_fake)
         if disc_fake is not None and disc_real is not None:
             disc_cost = A.logit_mean(disc_fake) - A.logit_mean(disc_real)
-            disc_cost = disc_cost + gradient_penalty(Discriminator, real_data, fake_data, wgan_gp.LAMBDA, alpha)
+            disc_cost = disc_cost + gradient_penalty(Discriminator, real_data, fake_data, wgan_gp.LAMBDA, alpha, fused=fused_gp)
     else:
         raise Exception()
     return gen_cost, disc_cost
@@ -408,6 +426,16 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
     def discriminate(self, img_nhwc):
         # tf.transpose(x, [0,3,1,2]) (trainer.py:601-602): a free view here
         return self.Discriminator_fn(img_nhwc.permute(0, 3, 1, 2), input_dim=3)
+
+    def _fused_gp(self):
+        """Operands of the one-call penalty (`dpig_gp_double_backward`) when this trainer's critic is the image DCGAN critic in
+        MODE 'wgan-gp' on fp32 tensors (config.fused_gp, default on); None -> the taped double backward."""
+        if self.wgan_gp.MODE != 'wgan-gp' or not getattr(self.config, "fused_gp", True) or H.get_compute() == "bf16":
+            return None
+        if getattr(self.config, "D_arch", "DCGAN") != 'DCGAN':
+            return None
+        params = critic_variables('')
+        return None if params is None else {"dim": 64, "params": params}
 
     def disc_pair(self, x, G, need_real=True):
         """(D_z_pos, D_z_neg).  Model 1 calls D separately on real and fake (trainer.py:601-602): two
@@ -674,7 +702,8 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
             G, _ = self.generate(embs, batch["pose"])
         D_z_pos, D_z_neg = self.disc_pair(batch["x"], G, need_real=True)
         _, d_loss = gan_loss(self.wgan_gp, D_z_pos, D_z_neg, Discriminator=self.discriminate,
-                             real_data=batch["x"], fake_data=G, alpha=getattr(self, "gp_alpha", None))   # (tests pin alpha)
+                             real_data=batch["x"], fake_data=G, alpha=getattr(self, "gp_alpha", None),   # (tests pin alpha)
+                             fused_gp=self._fused_gp())
         d_loss.backward()
         self.D_flat.finalize()
         if update:

@@ -375,6 +375,46 @@ int dpig_gp_interpolate(const float* real, const float* fake, const float* alpha
 int dpig_gp_penalty(const float* g, int B, int64_t D, float lambda, float* penalty, float* dg, float* slopes,
                     void* stream);
 
+/* ---- the whole gradient-penalty term of the DCGAN critic in ONE call (csrc/dpig_gp.hip) ------------------------------------
+ * Replaces, for Discriminator = WGAN_GP.DCGANDiscriminator in MODE 'wgan-gp' (wgan_gp.py:407-440: Conv5x5s2 -> LReLU ->
+ * [Conv5x5s2 -> LayerNorm -> LReLU] x3 -> reshape [-1, 8*4*8*dim] of the NCHW tensor -> Linear), the graph TF builds for
+ *     interpolates = real + alpha*(fake-real); gradients = tf.gradients(D(interpolates), [interpolates])[0]
+ *     gradient_penalty = LAMBDA * mean((||gradients||_2 - 1)^2)                               (trainer.py:222-236)
+ * AND the part of Optimizer.minimize(disc_cost) that differentiates it w.r.t. the critic's variables (tf.gradients of
+ * tf.gradients, i.e. the double backward), written out analytically: sweep 1 (forward + input gradient), dpig_gp_penalty,
+ * the adjoint of sweep 1's backward half (forward convs + wgrads + dpig_ln_bwd2) and the ordinary backward pass of the x-adjoints.
+ * All tensors NHWC fp32 (images [B][H][W][Cin]; filters HWIO [5][5][C][K]; LayerNorm scale/offset [C]; w_out [8*4*8*dim][1]).
+ *   penalty[0]  = the penalty value;  slopes[B] = ||gradients_b||_2
+ *   grads->X    = beta * grads->X + d penalty / d X   for every parameter (the output bias has no penalty gradient and is not
+ *                 in the struct); grads == NULL: value only (sweep 1).
+ * 256x256 inputs give 8 logit rows per image through the hard-coded reshape, exactly as the reference. */
+typedef struct DpigCriticDesc {
+    int32_t B, H, W, Cin;   /* interpolated images [B][H][W][Cin]; H, W multiples of 16                         */
+    int32_t dim;            /* DIM of wgan_gp.py:407: conv widths dim, 2dim, 4dim, 8dim                            */
+    float lrelu_alpha;      /* 0.2 (wgan_gp.py:23)                                                                 */
+    float ln_eps;           /* 1e-5 (layernorm.py:17)                                                              */
+    float lambda;           /* LAMBDA = 10 (wgan_gp.py:100)                                                        */
+    int32_t compute;        /* DPIG_COMPUTE_* of the convolutions                                                  */
+} DpigCriticDesc;
+typedef struct DpigCriticParams {
+    const float* w[4];          /* Discriminator.{1..4}.Filters                                                    */
+    const float* b[4];          /* Discriminator.{1..4}.Biases                                                     */
+    const float* ln_scale[3];   /* Discriminator.BN{2..4}.scale                                                    */
+    const float* ln_offset[3];  /* Discriminator.BN{2..4}.offset                                                   */
+    const float* w_out;         /* Discriminator.Output.W                                                          */
+} DpigCriticParams;
+typedef struct DpigCriticGrads {
+    float* w[4];
+    float* b[4];
+    float* ln_scale[3];
+    float* ln_offset[3];
+    float* w_out;
+} DpigCriticGrads;
+size_t dpig_gp_double_backward_workspace_bytes(const DpigCriticDesc* d);
+int dpig_gp_double_backward(const DpigCriticDesc* d, const DpigCriticParams* params, const float* real, const float* fake,
+                            const float* alpha, float beta, const DpigCriticGrads* grads, float* penalty, float* slopes,
+                            void* ws, size_t ws_bytes, void* stream);
+
 /* ---- nearest-neighbour 2x upsample (unfused form; utils.py:61-72) ---------------------------- */
 int dpig_upsample2x_fwd(const float* x, int N, int H, int W, int C, float* y, void* stream);
 int dpig_upsample2x_bwd(const float* dy, int N, int H, int W, int C, float* dx, void* stream);

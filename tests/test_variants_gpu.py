@@ -209,6 +209,62 @@ def test_wgan_gp_gradient_penalty_double_backward(dev, kind):
     lib.delete_all_params()
 
 
+@pytest.mark.parametrize("shape,dim", [((2, 128, 64, 3), 64), ((1, 256, 256, 3), 16)])
+def test_fused_gp_double_backward_entry_point(dev, shape, dim):
+    """`dpig_gp_double_backward` (one C-ABI call: forward + input gradient + penalty + the analytic second-order sweep,
+    trainer.py:222-236 over wgan_gp.py:407-440) against `oracle.models.gradient_penalty` differentiated by torch in fp64:
+    penalty value and every parameter gradient within 2e-5 of the tensor's max |ref|; value-only mode; beta accumulation;
+    256x256 inputs produce the reference's 8 logit rows per image."""
+    from dpig_amd import hip_ops as H
+    from oracle import models as OM
+    g = torch.Generator().manual_seed(5)
+    B = shape[0]
+    P = OM.ParamStore(seed=13)
+    real = torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1
+    fake = torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1
+    alpha = torch.rand(B, generator=g, dtype=torch.float64)
+    D_o = lambda t: OM.dcgan_discriminator(P, t, "wgan-gp", dim=dim)                  # noqa: E731
+    D_o(real[:1])                                    # creates the variables; then move biases / scales / offsets off their
+    names = [n for n in OM.d_var_names(P)]           # zero / one initial values so every term of the sweep is exercised
+    with torch.no_grad():
+        for n in names:
+            if not n.endswith(("Filters", "Output.W")):
+                P.p[n].add_(0.2 * (torch.rand(P.p[n].shape, generator=g, dtype=torch.float64) - 0.5))
+    gp_ref = OM.gradient_penalty(D_o, real, fake, alpha, 10.0)
+    refs = dict(zip(names, torch.autograd.grad(gp_ref, [P.p[n] for n in names], allow_unused=True)))
+    params = {n: P.p[n].detach().float().to(dev).contiguous() for n in names}
+    pen, slopes, grads = H.gp_double_backward(params, real.float().to(dev), fake.float().to(dev), alpha.float().to(dev), 10.0,
+                                              dim=dim, grads=True)
+    assert abs(pen.item() - gp_ref.item()) < 2e-5 * abs(gp_ref.item())
+    worst = 0.0
+    for n in names:
+        if n.endswith("Output.b"):
+            assert refs[n] is None or float(refs[n].abs().max()) == 0.0
+            continue
+        ref = refs[n]
+        if ref is None:                               # LayerNorm 4's offset only moves LeakyReLU masks: no gradient
+            assert n.endswith("BN4.offset") and float(grads[n].abs().max()) == 0.0
+            continue
+        scale = max(ref.abs().max().item(), 1e-12)
+        err = (grads[n].double().cpu() - ref).abs().max().item() / scale
+        worst = max(worst, err)
+        assert err < 2e-5, (n, err)
+    print("fused gp double backward %s: worst per-tensor error %.2e of max|ref|" % (shape, worst))
+    # value only
+    pen2, slopes2, none = H.gp_double_backward(params, real.float().to(dev), fake.float().to(dev), alpha.float().to(dev), 10.0,
+                                               dim=dim)
+    assert none is None and torch.equal(pen2, pen) and torch.equal(slopes2, slopes)
+    # grads = beta * grads + ...
+    acc = {n: torch.ones_like(t) for n, t in params.items()}
+    H.gp_double_backward(params, real.float().to(dev), fake.float().to(dev), alpha.float().to(dev), 10.0, dim=dim, grads=acc,
+                         beta=0.5)
+    for n in names:
+        if n.endswith("Output.b"):
+            continue
+        want = grads[n] + 0.5
+        assert (acc[n] - want).abs().max().item() <= 1e-6 * max(want.abs().max().item(), 1.0), n
+
+
 def test_stage1_step_in_wgan_gp_mode(dev):
     """The dormant MODE='wgan-gp' branch end to end (trainer.py:222-236, 131-135): LayerNorm critic,
     5 critic iterations per step with the gradient penalty, Adam(beta1=.5, beta2=.9); d_loss matches the
@@ -243,6 +299,21 @@ def test_stage1_step_in_wgan_gp_mode(dev):
     _, d_loss = gan_loss(tr.wgan_gp, D_pos, D_neg, Discriminator=tr.discriminate, real_data=gb["x"], fake_data=G,
                          alpha=alpha.float().to(dev))
     assert abs(d_loss.item() - d_ref.item()) < 1e-3 * abs(d_ref.item())
+    # the critic step through the one-call penalty (`dpig_gp_double_backward`, the default) and through the taped double
+    # backward: same loss, same flat critic gradient
+    tr.gp_alpha = alpha.float().to(dev)
+    assert tr._fused_gp() is not None
+    o1 = tr._d_optim_eager(gb, update=False)
+    g1 = tr.D_flat.grad.clone()
+    tr.config.fused_gp = False
+    assert tr._fused_gp() is None
+    o2 = tr._d_optim_eager(gb, update=False)
+    g2 = tr.D_flat.grad.clone()
+    tr.config.fused_gp = True
+    del tr.gp_alpha
+    assert abs(o1["d_loss"].item() - d_ref.item()) < 1e-3 * abs(d_ref.item())
+    assert abs(o1["d_loss"].item() - o2["d_loss"].item()) < 1e-5 * abs(d_ref.item())
+    assert (g1 - g2).abs().max().item() < 1e-4 * g2.abs().max().item()
     o = tr.train_step(gb, gb)
     assert tr.d_opt.t == 5 and torch.isfinite(o["d_loss"])
     o = tr.train_step(gb, gb)
