@@ -24,6 +24,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 PEAK_F32_MFMA_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+PEAK_BF16_MFMA_TFLOPS = 2500.0    # MI355X_MICROARCH.md: "~2.5 PF dense" (v_mfma_f32_32x32x16_bf16; measured 2495 TF)
 ALG_GFLOP_PER_IMG = 549.9         # stage-I Market G+D step, dense reference formulation
 
 
@@ -39,6 +40,9 @@ WORKLOADS = {
                          "Gaussian FC mappers / FC critics, MODE='wgan', 5 critic iterations per side)"),
     "df256": ("trainer_256", "DPIG_Encoder_GAN_BodyROI_256", {"img_H": 256, "img_W": 256}, 8,
               "DeepFashion 256x256 stage-I (trainer_256.py path), g_optim + d_optim per step"),
+    "df256-wgan-gp": ("trainer_256", "DPIG_Encoder_GAN_BodyROI_256", {"img_H": 256, "img_W": 256, "gan_mode": "wgan-gp"}, 8,
+                      "DeepFashion 256x256 stage-I with MODE='wgan-gp' (LayerNorm critic with 8 logit rows per image, gradient "
+                      "penalty, g_optim + 5 critic iterations per step): the per-GPU workload of BASELINE configs[4]"),
 }
 
 
@@ -99,17 +103,19 @@ def cpu_baseline(target_seconds=20.0):
 
 INFO_RUNS = [   # (key, BASELINE config it informs, bench.py arguments)
     ("df256_bf16", "configs[3]: DeepFashion 256x256 (trainer_256.py path) bs=8 bf16 on 1 MI355X",
-     ["--workload", "df256", "--dtype", "bf16", "--steps", "8", "--warmup", "2"]),
+     ["--workload", "df256", "--dtype", "bf16", "--steps", "20", "--warmup", "3"]),
     ("market128_stage2_bf16", "configs[2]: Market-1501 stage-II adversarial sampling bs=64 bf16 (this GPU's share of the job)",
-     ["--workload", "market128-stage2", "--dtype", "bf16", "--steps", "3", "--warmup", "1"]),
-    ("market128_bf16", "configs[1]'s graph in bf16", ["--workload", "market128", "--dtype", "bf16", "--steps", "10", "--warmup", "2"]),
+     ["--workload", "market128-stage2", "--dtype", "bf16", "--steps", "10", "--warmup", "2"]),
+    ("market128_bf16", "configs[1]'s graph in bf16", ["--workload", "market128", "--dtype", "bf16", "--steps", "30", "--warmup", "3"]),
     ("market128_split_bf16", "configs[1] (the headline workload) with the conv products on the bf16 pipe as two-term splits of the fp32 "
      "operands (DPIG_COMPUTE_BF16X3: fp32 tensors, <= 2e-5 max|ref| per kernel); the headline itself stays exact fp32",
-     ["--workload", "market128", "--dtype", "bf16x3", "--steps", "10", "--warmup", "2"]),
+     ["--workload", "market128", "--dtype", "bf16x3", "--steps", "30", "--warmup", "3"]),
     ("df256_split_bf16", "configs[3]'s graph (DeepFashion 256x256 bs=8) with fp32 tensors and split-bf16 conv products",
-     ["--workload", "df256", "--dtype", "bf16x3", "--steps", "4", "--warmup", "2"]),
+     ["--workload", "df256", "--dtype", "bf16x3", "--steps", "10", "--warmup", "2"]),
     ("market128_wgan_gp_f32", "configs[1] with MODE='wgan-gp' (LayerNorm critic, gradient penalty, 5 critic iterations per step)",
-     ["--workload", "market128-wgan-gp", "--steps", "5", "--warmup", "2"]),
+     ["--workload", "market128-wgan-gp", "--steps", "10", "--warmup", "2"]),
+    ("df256_wgan_gp_bf16", "configs[4]: DeepFashion 256x256 bs=8 per GPU, MODE='wgan-gp', bf16 -- one GPU's share of the 8-GPU job",
+     ["--workload", "df256-wgan-gp", "--dtype", "bf16", "--steps", "10", "--warmup", "2"]),
 ]
 
 
@@ -125,7 +131,8 @@ def info_lines():
             js = [l for l in r.stdout.splitlines() if l.startswith("{")]
             d = json.loads(js[-1])
             out[key] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"],
-                        "steps": d["steps"], "warmup": d["warmup"], "config": d["config"], "informs": informs}
+                        "steps": d["steps"], "warmup": d["warmup"], "config": d["config"], "informs": informs,
+                        "roofline": d.get("roofline")}
         except Exception as e:          # an information line must never take the headline down
             out[key] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     return out
@@ -191,8 +198,8 @@ def main():
     from dpig_amd.trainer import Config
     wl_mod, wl_cls, wl_cfg, wl_batch, wl_desc = WORKLOADS[args.workload]
     headline = args.workload == "market128" and args.dtype == "f32" and not args.host_input
-    if not headline:                          # information lines: no roofline / CPU legs, eager launches
-        args.no_roofline = args.no_cpu_baseline = True
+    if not headline:                          # information lines: no CPU leg
+        args.no_cpu_baseline = True
         args.no_graph = args.no_graph or args.workload in ("market128-stage2",)
 
     np.random.seed(0)                         # identical initial weights on every rank (+ broadcast)
@@ -253,7 +260,7 @@ def main():
     get_d = (lambda: next(feed_d)) if feed_d is not None else (lambda: batch_d)
     if args.workload == "market128-stage2":
         step_fn = lambda: tr.train_step(get_g())
-    elif args.workload == "market128-wgan-gp" and feed_d is None:
+    elif args.workload.endswith("wgan-gp") and feed_d is None:
         # every critic iteration of a step dequeues its own batch (trainer.py:340-345, 553-555): 5 distinct resident batches
         critic_batches = [batch_d] + [synthetic.to_device(synthetic.make_batch(B, img_H=cfg.img_H, img_W=cfg.img_W,
                                                                              seed=300 + 10 * rank + i), dev) for i in range(4)]
@@ -275,37 +282,85 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * B * args.steps / elapsed
 
+    # ---- N > 1: what the gradient exchange costs (rank-max like the headline) ---------------------------------------------
+    comm = None
+    if world > 1 and hasattr(tr, "G_flat") and hasattr(tr, "D_flat") and getattr(tr, "allreduce", None) is not None and tr.allreduce.enabled:
+        def rank_max(sec):
+            t = torch.tensor([sec], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return t.item()
+        # (a) the step's collectives alone, back to back on an otherwise idle GPU: G decoder slice, G encoder slice, D
+        eo = getattr(tr, "_enc_off", 0)
+        slices = [s for s in (tr.G_flat.grad[:eo], tr.G_flat.grad[eo:], tr.D_flat.grad) if s.numel()]
+        reps = 10
+        for _ in range(2):
+            tr.allreduce.finish(sum((tr.allreduce.start(s) for s in slices), []))
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            tr.allreduce.finish(sum((tr.allreduce.start(s) for s in slices), []))
+        sync()
+        ar_ms = rank_max(time.perf_counter() - t1) / reps * 1e3
+        # (b) the same K steps with the exchange switched off (every rank keeps its local gradient): the difference to the
+        #     timed region is the part of the exchange that the backward pass did not hide
+        tr.allreduce.enabled = False
+        for _ in range(min(args.warmup, 3)):
+            step_fn()
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            step_fn()
+        sync()
+        local_ms = rank_max(time.perf_counter() - t1) / args.steps * 1e3
+        tr.allreduce.enabled = True
+        nbytes = sum(s.numel() for s in slices) * (2 if tr.allreduce.compress else 4)
+        comm = {"allreduce_ms": round(ar_ms, 3), "exposed_ms": round(ms_per_step - local_ms, 3),
+                "ms_per_step_without_exchange": round(local_ms, 3), "bytes_per_step": nbytes,
+                "collectives_per_step": sum(-(-s.numel() // tr.allreduce.bucket) for s in slices),
+                "wire_dtype": "bf16" if tr.allreduce.compress else "f32",
+                "note": "allreduce_ms: the step's gradient all-reduces alone on an idle GPU; exposed_ms: timed step minus the "
+                        "same step with the exchange off (what the backward pass did not overlap)"}
+
     roofline = None
     if not args.no_roofline:
         # instrumented replay of the same step: HIP events around every conv-forward launch.  EVERY rank replays
         # (the steps contain the gradient all-reduce); rank 0's numbers are the ones reported.
         H.PROFILE = []
         nrep = max(1, min(3, args.steps))
-        graphs, tr._graphs = tr._graphs, None          # eager launches so that each one can be bracketed
+        graphs = getattr(tr, "_graphs", None)
+        tr._graphs = None                              # eager launches so that each one can be bracketed
         for _ in range(nrep):
-            tr.train_step(batch_g, batch_d)
+            step_fn()
         torch.cuda.synchronize()
         tr._graphs = graphs
         recs = [(r[0], r[1], r[2].elapsed_time(r[3]) * 1e-3) for r in H.PROFILE]
         H.PROFILE = None
-        fwd = [(f, t) for (k, f, t) in recs if k == "conv_fwd_mfma"]
-        nl = len(fwd)
-        flops = sum(f for f, _ in fwd)
-        secs = sum(t for _, t in fwd)
+        # dominant kernel class of this configuration: the conv-forward implicit GEMM on the pipe the dtype selects
+        dom, peak, kname, fmul = {
+            "f32": ("conv_fwd_mfma", PEAK_F32_MFMA_TFLOPS, "dpig::gather_gemm_kernel<false, true, false, 0> (conv fwd implicit GEMM, fp32 MFMA)", 1.0),
+            "bf16": ("conv_fwd_bf16", PEAK_BF16_MFMA_TFLOPS, "dpig::bq_kernel / bh_kernel / bg_kernel (conv fwd implicit GEMM on bf16 tensors, v_mfma_f32_32x32x16_bf16)", 1.0),
+            "bf16c": ("conv_fwd_mfma", PEAK_BF16_MFMA_TFLOPS, "conv fwd implicit GEMM, fp32 tensors rounded to bf16 on the way into LDS", 1.0),
+            "bf16x3": ("conv_fwd_mfma", PEAK_BF16_MFMA_TFLOPS, "conv fwd implicit GEMM, fp32 tensors as two-term bf16 splits: 3 bf16 MFMAs per product "
+                       "block (executed FLOPs = 3 x algorithmic)", 3.0),
+        }[args.dtype]
+        fwd = [(f, t) for (k, f, t) in recs if k == dom]
+        nl = max(len(fwd), 1)
+        flops = sum(f for f, _ in fwd) * fmul
+        secs = max(sum(t for _, t in fwd), 1e-12)
         achieved = flops / secs / 1e12
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-        if os.path.exists(tpath):
+        if headline and os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
                 traffic = tj.get("conv_fwd_hbm_bytes_per_launch")
                 traffic_src = "static: FETCH_SIZE / WRITE_SIZE passes of this command under rocprofv3 (%s), not re-measured in this run" % tj.get("source")
             except Exception:
                 traffic = None
-        roofline = {"bound": "mfma", "kernel": "dpig::gather_gemm_kernel<false, true, false, 0> (conv fwd implicit GEMM, fp32 MFMA)",
-                    "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / PEAK_F32_MFMA_TFLOPS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                    "launches_per_step": nl // nrep,
+        roofline = {"bound": "mfma", "kernel": kname,
+                    "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "launches_per_step": len(fwd) // nrep,
                     "flops_per_launch": flops / nl, "avg_launch_us": round(secs / nl * 1e6, 2),
                     "time_share_of_step": round(secs / nrep / (ms_per_step * 1e-3), 3)}
         by = {}
@@ -334,6 +389,8 @@ def main():
             "losses": {k: float(v) for k, v in out.items() if hasattr(v, "numel") and v.numel() == 1},
             "roofline": roofline, "cpu_baseline": cpu,
         }
+        if comm is not None:
+            line["allreduce_ms"], line["exposed_ms"], line["comm"] = comm["allreduce_ms"], comm["exposed_ms"], comm
         if headline and world == 1 and not args.no_info_lines:
             line["info_lines"] = info_lines()
         print(json.dumps(line), flush=True)

@@ -64,7 +64,9 @@ __device__ __forceinline__ void bg_epilogue(const BGParams& p, char* smem, f32x1
     const int col = n0 + c;
     const int rl0 = tid >> 4;
     // ---- batch-norm partial statistics of this row tile (as dpig_conv.hip's: per column the sum and the sum of squared
-    // deviations from the TILE's mean, from the fp32 accumulators + bias, before the output is rounded to bf16).  Only set by
+    // deviations from the TILE's mean) of the values AS STORED: accumulator + bias rounded to bf16, so that bn_apply / bn_bwd, which
+    // read the bf16 tensor, see exactly the mean and variance of what they normalise -- and the fallback that takes the
+    // statistics from the stored tensor (split-K plans, multi-run batches) agrees with this path.  Only set by
     // dpig_conv2d_fwd_bf16_stats: un-split bg_kernel launch, rows m0 .. m0 + 127 are pixels m0 .. (every thread takes part).
     if (p.stats) {
         const bool cok = col < p.Ncols;
@@ -80,7 +82,7 @@ __device__ __forceinline__ void bg_epilogue(const BGParams& p, char* smem, f32x1
             const int rl = rl0 + 16 * it;
             if (rl < nrows) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) sm[e] += Cs[rl * LDC + c + e] + b8[e];
+                for (int e = 0; e < 8; ++e) sm[e] += (float)(__bf16)(Cs[rl * LDC + c + e] + b8[e]);
             }
         }
 #pragma unroll
@@ -95,7 +97,7 @@ __device__ __forceinline__ void bg_epilogue(const BGParams& p, char* smem, f32x1
             const int rl = rl0 + 16 * it;
             if (rl < nrows) {
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { const float dv = Cs[rl * LDC + c + e] + b8[e] - tot[e] * inv; q8[e] += dv * dv; }
+                for (int e = 0; e < 8; ++e) { const float dv = (float)(__bf16)(Cs[rl * LDC + c + e] + b8[e]) - tot[e] * inv; q8[e] += dv * dv; }
             }
         }
 #pragma unroll

@@ -361,8 +361,9 @@ def conv2d_fwd(x, w, bias=None, stride=1, act=ACT_NONE, alpha=0.2, residual=None
                                            ptr(residual), ptr(out), ptr(out_act), ptr(y32),
                                            ctypes.byref(wrote) if wrote is not None else None, ptr(wsb), wsn, stream_ptr()),
                   "conv2d_fwd_x3")
-            if wrote is not None and wrote.value:
-                out._dpig_s32 = y32        # the epilogue left the output's split32 image: the next conv of the chain DMAs it
+            # the epilogue left the output's split32 image: the next conv of the chain DMAs it (a caller-supplied `out` must not
+            # keep an image of its previous contents otherwise)
+            tag_s32(out, y32 if (wrote is not None and wrote.value) else None)
         else:
             check(lib().dpig_conv2d_fwd(ctypes.byref(d), ptr(x), ptr(w), ptr(bias), ptr(residual), ptr(out),
                                         ptr(out_act), ptr(wsb), wsn, stream_ptr()), "conv2d_fwd")
@@ -385,7 +386,7 @@ def split32(t, reuse=1):
     (`reuse` = taps x column tiles) splits it in its k-loop instead -- unless the image already exists."""
     if not X3_PLANES[0] or t.dtype != torch.float32:
         return None
-    s32 = getattr(t, "_dpig_s32", None)
+    s32 = cached_s32(t)
     if s32 is not None:
         return s32
     ld = nhwc_ld(t)
@@ -397,10 +398,32 @@ def split32(t, reuse=1):
         return None
     s32 = torch.empty((N, Hh, W, nchunk, 64), dtype=BF16, device=t.device)
     check(lib().dpig_split32(ptr(t), ld, N * Hh * W, C, ptr(s32), stream_ptr()), "split32")
+    tag_s32(t, s32)
+    return s32
+
+
+def tag_s32(t, s32):
+    """Attach a split32 image to its tensor together with the tensor's identity at that moment (autograd version counter +
+    address): an in-place write (gradient accumulation, `copy_` into a static graph input) bumps the version and the image is
+    re-made instead of being DMA-ed stale.  `s32 = None` drops any image the tensor carried."""
     try:
-        t._dpig_s32 = s32
+        if s32 is None:
+            if hasattr(t, "_dpig_s32"):
+                del t._dpig_s32
+        else:
+            t._dpig_s32 = (s32, t._version, t.data_ptr())
     except Exception:
         pass
+
+
+def cached_s32(t):
+    ent = getattr(t, "_dpig_s32", None)
+    if ent is None:
+        return None
+    s32, ver, addr = ent
+    if ver != t._version or addr != t.data_ptr():
+        tag_s32(t, None)
+        return None
     return s32
 
 
@@ -445,12 +468,14 @@ def conv2d_fwd_stats(x, w, bias=None, stride=1, split_k=0):
     Ho, Wo = conv_out_hw(H, W, R, S, stride, False)
     d = _desc(N, H, W, C, K, R, S, stride, ldx, K, split_k=split_k)
     tiles = lib().dpig_conv2d_bn_stats_tiles(ctypes.byref(d))
-    if tiles <= 0:
+    if bias is not None:
+        bias = bias.contiguous()
+    # the stats epilogue stores 16-byte vectors: an operand at an odd offset (a bias that is a view, say) takes the plain conv and
+    # bn_fwd's own statistics passes instead of an EINVAL from the launch
+    if tiles <= 0 or not _al16(x, w, bias):
         return conv2d_fwd(x, w, bias, stride=stride, split_k=split_k), None
     out = torch.empty((N, Ho, Wo, K), dtype=torch.float32, device=x.device)
     stats = torch.empty((tiles, 2, K), dtype=torch.float32, device=x.device)
-    if bias is not None:
-        bias = bias.contiguous()
     with _Timed("conv_fwd_mfma", 2.0 * N * H * W // (stride * stride) * K * R * S * C, (N, H, W, C, K, R, stride, 0)):
         check(lib().dpig_conv2d_fwd_stats(ctypes.byref(d), ptr(x), ptr(w), ptr(bias), ptr(out), ptr(stats), stream_ptr()),
               "conv2d_fwd_stats")
@@ -496,8 +521,7 @@ def conv2d_dgrad(dy, w, in_shape, stride=1, accum=None, mask=None, act=ACT_NONE,
             check(lib().dpig_conv2d_dgrad_x3(ctypes.byref(d), ptr(dy), ptr(dy32), ptr(w), ptr(sh[0]), ptr(sh[2]), ptr(accum),
                                              ptr(mask), ptr(out), ptr(dx32), ctypes.byref(wrote) if wrote is not None else None,
                                              ptr(wsb), wsn, stream_ptr()), "conv2d_dgrad_x3")
-            if wrote is not None and wrote.value:
-                out._dpig_s32 = dx32
+            tag_s32(out, dx32 if (wrote is not None and wrote.value) else None)
         else:
             check(lib().dpig_conv2d_dgrad(ctypes.byref(d), ptr(dy), ptr(w), ptr(accum), ptr(mask), ptr(out), ptr(wsb),
                                           wsn, stream_ptr()), "conv2d_dgrad")
@@ -776,7 +800,7 @@ def act_bwd(dy, y, act, alpha=0.2, emit32=False):
         dz32 = torch.empty(tuple(dz.shape[:3]) + (cols // 32, 64), dtype=BF16, device=dz.device)
         check(lib().dpig_act_bwd_s32(ptr(dy), lddy, ptr(y), ldy, ptr(dz), cols, rows, cols, act, alpha, ptr(dz32), stream_ptr()),
               "act_bwd_s32")
-        dz._dpig_s32 = dz32
+        tag_s32(dz, dz32)
         return dz
     check(lib().dpig_act_bwd(ptr(dy), lddy, ptr(y), ldy, ptr(dz), cols, rows, cols, act, alpha, stream_ptr()),
           "act_bwd")

@@ -178,8 +178,15 @@ def load_optimizer_slots(flat, opt, values, ordinal=0):
     import numpy as np
     kind = "Adam" if isinstance(opt, TFAdam) else "RMSProp"
     sfx = "" if ordinal == 0 else "_%d" % ordinal
-    need = [("%s/%s" % (lib.tf_variable_name(p.dpig_name), kind), "%s/%s_1" % (lib.tf_variable_name(p.dpig_name), kind))
-            for p in flat.params]
+    def slot_names(p):
+        # TF-scoped keys (`<op>/<op>.Filters/Adam`); checkpoints written before the TF naming carry the bare registry name
+        # (`<op>.Filters/Adam`) -- the same fallback tfckpt.restore gives the weights
+        for base in (lib.tf_variable_name(p.dpig_name), p.dpig_name):
+            a, b = "%s/%s" % (base, kind), "%s/%s_1" % (base, kind)
+            if a in values and b in values:
+                return a, b
+        return "%s/%s" % (lib.tf_variable_name(p.dpig_name), kind), "%s/%s_1" % (lib.tf_variable_name(p.dpig_name), kind)
+    need = [slot_names(p) for p in flat.params]
     for p, (a, b) in zip(flat.params, need):
         if a not in values or b not in values or tuple(values[a].shape) != tuple(p.shape) or tuple(values[b].shape) != tuple(p.shape):
             return False
@@ -554,6 +561,11 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         snap = [(f.flat.clone(), f.m.clone(), f.v.clone()) for f in (self.G_flat, self.D_flat)]
         osnap = [(getattr(o, "state", None), o.t) for o in (self.g_opt, self.d_opt)]
         osnap = [(s.clone() if s is not None else None, t) for s, t in osnap]
+        # ... and so are the device RNG stream (the wgan-gp alpha, the stage-II samplers draw from it) and every non-trainable
+        # registry tensor (BatchNorm moving statistics when update_moving_stats is on)
+        rng = torch.cuda.get_rng_state(self.device)
+        trainable = set(id(p) for f in (self.G_flat, self.D_flat) for p in f.params)
+        bsnap = [(t, t.detach().clone()) for t in lib._params.values() if id(t) not in trainable and not t.requires_grad]
         with torch.cuda.stream(side):
             for _ in range(warmup):
                 self._g_optim_eager(self._static_g)
@@ -568,7 +580,10 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
                 if st is not None:
                     o.state.copy_(st)
                 o.t = t
-        del snap
+            for t, v in bsnap:
+                t.copy_(v)
+        torch.cuda.set_rng_state(rng, self.device)
+        del snap, bsnap
         torch.cuda.synchronize(self.device)
         self._graph_update = not (self.allreduce.enabled or self._split())   # fold all-reduce + Adam into the graph?
         gg, gd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()

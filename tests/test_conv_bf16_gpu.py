@@ -321,9 +321,9 @@ def test_bad_arguments(dev):
 
 @pytest.mark.parametrize("shape", [(3, 20, 20, 64, 128, 5, 2), (2, 17, 9, 32, 136, 3, 1)])
 def test_bf16_conv_epilogue_bn_statistics(dev, shape):
-    """dpig_conv2d_fwd_bf16_stats: the bf16-storage forward conv leaves the batch-norm partial statistics of its output (from
-    the fp32 accumulators + bias, before y is rounded to bf16); merged by dpig_bn_stats_finalize they give the batch mean and
-    rstd of the fp64 oracle conv on the bf16-ROUNDED operands, and bn_fwd(..., stats=) the normalised LeakyReLU output."""
+    """dpig_conv2d_fwd_bf16_stats: the bf16-storage forward conv leaves the batch-norm partial statistics of its output AS
+    STORED (accumulator + bias rounded to bf16); merged by dpig_bn_stats_finalize they give the batch mean and rstd of the
+    stored tensor -- the same numbers bn_fwd's own passes find -- and bn_fwd(..., stats=) the normalised LeakyReLU output."""
     import dpig_amd.hip_ops as H
     from oracle import ops as O
     N, Hh, W, C, K, k, s = shape
@@ -342,9 +342,22 @@ def test_bf16_conv_epilogue_bn_statistics(dev, shape):
     err = (y.float().cpu().double() - pre).abs()
     assert not bool((err > pre.abs() * 2.0 ** -8 + 1e-4 * float(pre.abs().max())).any())
     out, mean, rstd = H.bn_fwd(y, scale.float().to(dev), offset.float().to(dev), 1e-5, 2, 0.2, stats=st)
-    assert float((mean.cpu().double() - rows.mean(0)).abs().max()) <= 1e-5 * float(rows.mean(0).abs().max())
+    # the statistics describe the tensor AS STORED (bf16-rounded y): exactly what bn_apply / bn_bwd normalise ...
+    stored = y.float().cpu().double().reshape(-1, K)
+    assert float((mean.cpu().double() - stored.mean(0)).abs().max()) <= 2e-6 * float(stored.mean(0).abs().max())
+    st_rstd = 1.0 / torch.sqrt(stored.var(0, unbiased=False) + 1e-5)
+    assert float((rstd.cpu().double() - st_rstd).abs().max()) <= 2e-5 * float(st_rstd.abs().max())
+    # ... so the path without epilogue statistics (split-K plans, multi-run batches: bn_fwd's own passes over y) agrees
+    out_ns, mean_ns, rstd_ns = H.bn_fwd(y, scale.float().to(dev), offset.float().to(dev), 1e-5, 2, 0.2, stats=None)
+    assert float((mean_ns - mean).abs().max()) <= 2e-6 * float(mean.abs().max())
+    assert float((rstd_ns - rstd).abs().max()) <= 2e-5 * float(rstd.abs().max())
+    assert float((out_ns.float() - out.float()).abs().max()) <= 2.0 ** -7 * float(out.float().abs().max())
+    # ... and they are the oracle's batch statistics up to the rounding of y: values near 8 round with ulp 2^-4, i.e. a
+    # zero-mean error of std 0.018 per element, 0.018 / sqrt(rows) on a column mean (5 sigma over the K columns)
+    tol_mean = 5.0 * (2.0 ** -4 / 12 ** 0.5) / rows.shape[0] ** 0.5
+    assert float((mean.cpu().double() - rows.mean(0)).abs().max()) <= tol_mean
     ref_rstd = 1.0 / torch.sqrt(rows.var(0, unbiased=False) + 1e-5)
-    assert float((rstd.cpu().double() - ref_rstd).abs().max()) <= 1e-4 * float(ref_rstd.abs().max())
+    assert float((rstd.cpu().double() - ref_rstd).abs().max()) <= 1e-2 * float(ref_rstd.abs().max())
     ref = O.leaky_relu(O.batchnorm_train(pre, scale, offset), 0.2)
     assert out.dtype == torch.bfloat16
     assert float((out.float().cpu().double() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())      # bf16 y, bf16 result

@@ -447,13 +447,12 @@ def test_conv_split_bf16_filter_shadows(dev, shape):
             for planes in (False, True):                        # filter shadows alone; + the activation's split32 image (both by DMA)
                 H.X3_PLANES[0] = planes
                 for t in (x, dy):
-                    if hasattr(t, "_dpig_s32"):
-                        del t._dpig_s32
+                    H.tag_s32(t, None)
                 y1 = H.conv2d_fwd(x, w, b, stride=s, act=2, alpha=0.2, split_k=sk)
                 dx1 = H.conv2d_dgrad(dy, w, (N, Hh, W, C), stride=s, split_k=sk)
                 if planes and not (C % 8 or K % 8) and k > 1:
-                    assert hasattr(x, "_dpig_s32")              # the image was made (and is kept for the tensor's next consumer)
-                    s32 = x._dpig_s32.float()
+                    assert H.cached_s32(x) is not None          # the image was made (and is kept for the tensor's next consumer)
+                    s32 = H.cached_s32(x).float()
                     xp = torch.nn.functional.pad(x, (0, s32.shape[3] * 32 - C)).reshape(N, Hh, W, -1, 32)
                     assert torch.equal(s32[..., :32], xp.bfloat16().float()) and torch.equal(s32[..., 32:], (xp - s32[..., :32]).bfloat16().float())
                 assert torch.equal(y1, y0) and torch.equal(dx1, dx0), (sk, planes, float((y1 - y0).abs().max()), float((dx1 - dx0).abs().max()))
@@ -466,11 +465,17 @@ def test_conv_split_bf16_filter_shadows(dev, shape):
                     assert torch.equal(dw1, dw0), (sk, float((dw1 - dw0).abs().max()))
                     assert float((dbw - db0).abs().max()) <= 2e-5 * float(db0.abs().max())
                 for t in (y1, dx1):                            # an image the epilogue left equals the one dpig_split32 makes
-                    img = getattr(t, "_dpig_s32", None)
+                    img = H.cached_s32(t)
                     if img is not None:
                         assert planes
-                        del t._dpig_s32
+                        H.tag_s32(t, None)
                         assert torch.equal(H.split32(t, 99), img)
+                # an in-place write to the tensor invalidates its image (version counter): the next consumer re-splits
+                if planes and H.cached_s32(x) is not None:
+                    stale = H.cached_s32(x)
+                    x.mul_(1.0)
+                    assert H.cached_s32(x) is None and not hasattr(x, "_dpig_s32")
+                    assert torch.equal(H.split32(x, 99), stale)
             H.X3_PLANES[0] = planes_default
             sh.detach()
     finally:

@@ -32,17 +32,18 @@ def _alpha():
     return torch.rand(B, generator=torch.Generator().manual_seed(5))
 
 
-def _worker(rank, world, port, q, exchange):
+def _worker(rank, world, port, q, exchange, backend="gloo"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     sys.path.insert(0, ROOT)
-    torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ordinal = rank if backend == "nccl" else 0           # RCCL needs one device per rank; gloo ranks share cuda:0
+    torch.cuda.set_device(ordinal)
+    dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         from dpig_amd import synthetic
         from dpig_amd.trainer import Config, DPIG_Encoder_GAN_BodyROI_FgBg
-        dev = torch.device("cuda:0")
+        dev = torch.device("cuda", ordinal)
         half = B // world
         pick = lambda b: {k: v[rank * half:(rank + 1) * half] for k, v in b.items()}
         np.random.seed(0)
@@ -63,12 +64,14 @@ def _worker(rank, world, port, q, exchange):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("exchange", ["f32", "bf16"])
-def test_two_rank_step_equals_single_process_on_the_concatenated_batch(dev, exchange):
+@pytest.mark.parametrize("backend,exchange", [("gloo", "f32"), ("gloo", "bf16"), ("nccl", "f32"), ("nccl", "bf16")])
+def test_two_rank_step_equals_single_process_on_the_concatenated_batch(dev, backend, exchange):
+    if backend == "nccl" and torch.cuda.device_count() < 2:
+        pytest.skip("the RCCL variant needs two devices (the driver's 8-GPU node); the gloo variant covers the same code on one")
     world, port = 2, _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, exchange, backend)) for r in range(world)]
     for p in procs:
         p.start()
     res = dict(q.get(timeout=600) for _ in range(world))
@@ -99,13 +102,19 @@ def test_two_rank_step_equals_single_process_on_the_concatenated_batch(dev, exch
     g_loss = 0.5 * (res[0]["g_loss"] + res[1]["g_loss"])
     assert abs(d_loss - float(od["d_loss"])) < 2e-4 * max(1.0, abs(float(od["d_loss"])))
     assert abs(g_loss - float(og["g_loss"])) < 2e-4 * max(1.0, abs(float(og["g_loss"])))
-    # Adam's first step moves every weight by ~lr*sign(g): compare the updates where the gradient is not at the rounding
-    # floor (same criterion as tests/test_syncbn_gpu.py); the bf16 exchange rounds the summed gradient to 8 bits, which
-    # only flips signs of gradients that are ~0 relative to their neighbours
-    need = 0.97 if exchange == "f32" else 0.93
-    for name, new, old, ref in (("D", res[0]["D"], D0, tr.D_flat.flat.detach().cpu()),
-                                ("G", res[0]["G"], G0, tr.G_flat.flat.detach().cpu())):
+    # Adam's first step moves every weight by lr * g / (|g| + eps) ~ lr * sign(g): the two-rank update must equal the
+    # single-process one within 0.05 * lr on >= 99.5 % of the weights whose gradient is above the fp32 summation noise floor
+    # (|g| > 1e-4 of the side's largest gradient; below it the SIGN of g -- hence the whole +-lr update -- is decided by the
+    # order the partial sums are added in, on one GPU as much as on two).  The bf16 exchange rounds the summed gradient to 8
+    # significand bits, which cannot flip a sign: the same bar holds.
+    for name, new, old, flat in (("D", res[0]["D"], D0, tr.D_flat), ("G", res[0]["G"], G0, tr.G_flat)):
+        ref, grad = flat.flat.detach().cpu(), flat.grad.detach().cpu()
         close = ((new - old) - (ref - old)).abs() <= 0.05 * LR
-        assert close.float().mean() > need, (name, exchange, close.float().mean())
+        live = grad.abs() > 1e-4 * grad.abs().max()
+        frac_live, frac_all = close[live].float().mean().item(), close.float().mean().item()
+        print("ddp %s/%s %s: %.4f of the weights above the noise floor (%.1f %% of all) within 0.05 lr; %.4f of all"
+              % (backend, exchange, name, frac_live, 100.0 * live.float().mean().item(), frac_all))
+        assert frac_live >= 0.995, (name, exchange, frac_live)
+        assert frac_all > (0.97 if exchange == "f32" else 0.93), (name, exchange, frac_all)
     lib.delete_all_params()
     slim.reset_scopes()

@@ -200,8 +200,14 @@ def test_split_backward_equals_full_backward(dev):
     assert same(grads(), ref)
     # graphs: forced split -> two graphs for g_optim, optimizer launches stay eager
     w0, d0 = tr.G_flat.flat.clone(), tr.D_flat.flat.clone()
+    rng0 = torch.cuda.get_rng_state(dev)
+    buffers0 = {n: t.clone() for n, t in lib._params.items() if not t.requires_grad}
     tr.enable_graphs(gb, gb, warmup=1)
     assert tr._gg2 is not None and not tr._graph_update
+    # the warm-up steps leave no trace: weights, the device RNG stream and the non-trainable tensors are where they were
+    assert torch.equal(tr.G_flat.flat, w0) and torch.equal(tr.D_flat.flat, d0)
+    assert torch.equal(torch.cuda.get_rng_state(dev), rng0)
+    assert buffers0 and all(torch.equal(lib._params[n], v) for n, v in buffers0.items())
     for fl, s0 in zip((tr.G_flat, tr.D_flat), (w0, d0)):
         fl.flat.copy_(s0); fl.m.zero_(); fl.v.zero_()
     for opt in (tr.g_opt, tr.d_opt):
