@@ -65,6 +65,42 @@ def make_batch(batch_size, img_H=128, img_W=64, seed=1234, keypoint_num=18, part
     return {"x": x, "pose": pose, "mask_r6": mask, "part_bbox": part_bbox, "part_vis": part_vis}
 
 
+def make_batch_from_keypoints(batch_size, img_H=128, img_W=64, seed=1234, drop=0.15):
+    """A batch whose geometric inputs are DERIVED from one set of keypoints per person the way the reference's converter derives
+    them (datasets/convert_market.py:229-283, 578-638 restated in `dataprep`, pinned by tests/golden/prep_reference.npz): body
+    mask = closed union of discs along the limbs, 7 part boxes grown from the visible keypoints (sentinel [0,0,1,1] + vis 0 for
+    a part with none), pose map = the 49-offset disc per visible keypoint.  Same dict as `make_batch`, plus `keypoints`."""
+    from . import dataprep
+    rng = np.random.default_rng(seed)
+    B, H, W = batch_size, img_H, img_W
+    x = rng.uniform(-1.0, 1.0, size=(B, H, W, 3)).astype(np.float32)
+    pose = -np.ones((B, H, W, 18), dtype=np.float32)
+    mask = np.zeros((B, H, W, 1), dtype=np.float32)
+    bbox = np.zeros((B, 7, 4), dtype=np.int32)
+    vis = np.zeros((B, 7), dtype=np.float32)
+    kps = np.zeros((B, 18, 3), dtype=np.float64)
+    # a standing figure: (x, y) of the 18 MSCOCO keypoints as fractions of (W, H), jittered per person
+    base = np.array([(.50, .10), (.50, .20), (.36, .21), (.30, .36), (.28, .50), (.64, .21), (.70, .36), (.72, .50), (.42, .52),
+                     (.40, .72), (.40, .92), (.58, .52), (.60, .72), (.60, .92), (.54, .08), (.46, .08), (.58, .10), (.42, .10)])
+    for b in range(B):
+        j = base + rng.normal(0, 0.03, size=base.shape)
+        kps[b, :, 0] = np.clip(np.floor(j[:, 0] * W), 0, W - 1)
+        kps[b, :, 1] = np.clip(np.floor(j[:, 1] * H), 0, H - 1)
+        kps[b, :, 2] = rng.uniform(size=18) >= drop
+        if b % 4 == 3:
+            kps[b, [8, 9, 10, 11, 12, 13], 2] = 0       # a cropped figure without legs: parts 3, 6, 7 get the sentinel box
+        g = dataprep.model_inputs_from_keypoints(kps[b], H, W)
+        mask[b], bbox[b], vis[b] = g["mask_r6"], g["part_bbox"], g["part_vis"]
+        for k in range(18):
+            if kps[b, k, 2]:
+                r, c = int(kps[b, k, 1]), int(kps[b, k, 0])
+                for dr, dc in _STENCIL:
+                    rr, cc = r + dr, c + dc
+                    if 0 <= rr < H and 0 <= cc < W:
+                        pose[b, rr, cc, k] = 1.0
+    return {"x": x, "pose": pose, "mask_r6": mask, "part_bbox": bbox, "part_vis": vis, "keypoints": kps}
+
+
 def to_device(batch, device):
     import torch
     return {k: torch.as_tensor(v).to(device) for k, v in batch.items()}

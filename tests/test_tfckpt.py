@@ -5,6 +5,7 @@ independently of the writer is checked here against bytes laid out by hand from 
 import struct
 
 import numpy as np
+import torch
 import pytest
 
 from dpig_amd import tfckpt as C
@@ -247,6 +248,34 @@ def test_tf_variable_names_of_the_full_model_key_list():
     }
     for reg, tfn in cases.items():
         assert lib.tf_variable_name(reg) == tfn
+
+
+def test_full_model_checkpoint_key_list_fixture():
+    """tests/golden/ckpt_keys_model1.json is the variable list of the reference's stage-I Market model written down from its
+    graph-building code by tests/golden/make_ckpt_keys.py (a flat layer table, independent of this repo's model code).  The
+    names this repo gives the same variables -- creation order, shapes, TF scoping -- must be exactly that list (the oracle
+    builds them here on CPU at full width; tests/test_model_gpu.py checks registry == oracle and the saved key set)."""
+    import json
+    import os
+    import dpig_amd.tflib as lib
+    from dpig_amd import synthetic
+    from oracle import models as OM
+    fix = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ckpt_keys_model1.json")))
+    P = OM.ParamStore(seed=1)
+    ob = OM.batch_to_torch(synthetic.make_batch(1, seed=1))
+    with torch.no_grad():
+        _, G = OM.stage1_forward(P, ob)
+        OM.dcgan_discriminator(P, G, "dcgan")
+    g = [lib.tf_variable_name(n) for n in OM.g_var_names(P)]
+    d = [lib.tf_variable_name(n) for n in OM.d_var_names(P)]
+    assert g == fix["g_trainable"] and d == fix["d_trainable"]
+    for n, t in P.p.items():
+        assert list(t.shape) == fix["keys"][lib.tf_variable_name(n)], n
+    saved = set(lib.tf_variable_name(n) for n in P.p)
+    slots = {k for k in fix["keys"] if k.endswith(("/Adam", "/Adam_1"))}
+    extras = {"beta1_power", "beta2_power", "beta1_power_1", "beta2_power_1", "g_lr", "d_lr", "step"}
+    assert saved | slots | extras == set(fix["keys"])
+    assert slots == {n + s for n in g + d for s in ("/Adam", "/Adam_1")}
 
 
 def test_optimizer_slots_round_trip_under_tf_names(tmp_path):
