@@ -204,6 +204,70 @@ __global__ __launch_bounds__(256) void class_sum_partial_kernel(const T* __restr
                 (red[k][0][cl] + red[k][1][cl]) + (red[k][2][cl] + red[k][3][cl]);
     }
 }
+// The same partial sums with 16-byte loads: thread = (pixel slot, V consecutive channels), a slab = every nslab-th image row.
+// A row has ONE row class, so a pixel costs one add per channel (+ two selects for the row's first / last pixel) instead of nine
+// conditional adds; pixel slots are folded through LDS in slot order (fixed summation order).
+template <typename T, int V>
+__global__ __launch_bounds__(256) void class_sum_partial_vec_kernel(const T* __restrict__ a, int lda, int H, int W, int C,
+                                                                    float* __restrict__ partial) {
+    __shared__ float red[256 * V];
+    const int CV = C / V;                                  // threads per pixel (divides 256)
+    const int cv = threadIdx.x % CV, slot = threadIdx.x / CV, nslot = 256 / CV;
+    const int n = blockIdx.y, slab = blockIdx.z, nslab = gridDim.z;
+    float acc[9][V];
+#pragma unroll
+    for (int k = 0; k < 9; ++k)
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[k][e] = 0.f;
+    for (int y = slab; y < H; y += nslab) {
+        float l[V], m[V], r[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) { l[e] = 0.f; m[e] = 0.f; r[e] = 0.f; }
+        const T* rowp = a + ((long)n * H + y) * W * lda + cv * V;
+#pragma unroll 4
+        for (int x = slot; x < W; x += nslot) {
+            float v[V];
+            if constexpr (sizeof(T) == 2) {
+                const uint4 u = *reinterpret_cast<const uint4*>(rowp + (long)x * lda);
+                v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+                v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+                v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
+                v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+            } else {
+                const float4 u = *reinterpret_cast<const float4*>(rowp + (long)x * lda);
+                v[0] = u.x; v[1] = u.y; v[2] = u.z; v[3] = u.w;
+            }
+            const bool first = x == 0, last = x == W - 1;
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                l[e] += first ? v[e] : 0.f;
+                r[e] += last ? v[e] : 0.f;
+                m[e] += (first || last) ? 0.f : v[e];
+            }
+        }
+        const int cy = (y == 0) ? 0 : ((y == H - 1) ? 2 : 1);       // (block-uniform)
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (k == cy) {
+#pragma unroll
+                for (int e = 0; e < V; ++e) { acc[k * 3][e] += l[e]; acc[k * 3 + 1][e] += m[e]; acc[k * 3 + 2][e] += r[e]; }
+            }
+    }
+    for (int k = 0; k < 9; ++k) {
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < V; ++e) red[(slot * CV + cv) * V + e] = acc[k][e];
+        __syncthreads();
+        if (slot == 0) {
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                float s = 0.f;
+                for (int q = 0; q < nslot; ++q) s += red[(q * CV + cv) * V + e];
+                partial[(((long)n * nslab + slab) * 9 + k) * C + cv * V + e] = s;
+            }
+        }
+    }
+}
 __global__ __launch_bounds__(256) void class_sum_final_kernel(const float* __restrict__ partial, int nslab, int C,
                                                               long total, float* __restrict__ out) {
     // out[(n*9 + k)*C + c] = sum_slab partial[((n*nslab + slab)*9 + k)*C + c]
@@ -472,97 +536,181 @@ __device__ __forceinline__ void crop_range(float b1, float b2, int crop, int siz
     *lo = l < 0 ? 0 : l;
     *hi = h > crop - 1 ? crop - 1 : h;
 }
+// V consecutive channels (V = 4: one 16-byte fp32 / 8-byte bf16 access)
+template <int V> __device__ __forceinline__ void ld_vec(const float* p, float (&v)[V]) {
+    if constexpr (V == 4) { const float4 t = *reinterpret_cast<const float4*>(p); v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w; }
+    else { for (int e = 0; e < V; ++e) v[e] = p[e]; }
+}
+template <int V> __device__ __forceinline__ void ld_vec(const unsigned short* p, float (&v)[V]) {
+    if constexpr (V == 4) {
+        const uint2 t = *reinterpret_cast<const uint2*>(p);
+        v[0] = __uint_as_float(t.x << 16); v[1] = __uint_as_float(t.x & 0xffff0000u);
+        v[2] = __uint_as_float(t.y << 16); v[3] = __uint_as_float(t.y & 0xffff0000u);
+    } else { for (int e = 0; e < V; ++e) v[e] = __uint_as_float((unsigned)p[e] << 16); }
+}
+// Image columns a box can touch: samples lie in [min, max] * (W - 1) and reach pixels closer than 1.  Pass X only fills these
+// columns of tmp and pass Y only reads them (the rest of a [W]-wide row would be zeros: 3/4 of the traffic at the DeepFashion sizes).
+__device__ __forceinline__ void crop_cols(float x1, float x2, int W, int* lo, int* hi) {
+    const float a = fminf(x1, x2) * (float)(W - 1), b = fmaxf(x1, x2) * (float)(W - 1);
+    const int l = (int)floorf(a) - 1, h = (int)ceilf(b) + 1;
+    *lo = l < 0 ? 0 : l;
+    *hi = h > W - 1 ? W - 1 : h;
+}
+constexpr int CROP_MAXC = 128;      // largest crop side the row-table kernels take (reference: 48 / 64)
+// pass X, one workgroup per crop row (b, ii): the row's sample coordinates in_x[j] (and whether the sample lies inside the image)
+// are computed ONCE into LDS; a thread = (image column of the box's column range, channel group) then walks only the samples
+// crop_range() brackets -- no index arithmetic or divisions per sample.  Fixed summation order (j ascending).
 template <int V, typename T>
 __global__ __launch_bounds__(256) void crop_bwd_x_kernel(const T* __restrict__ dout, int W, int C,
                                                          const float* __restrict__ boxes, int nbox, int ch, int cw,
                                                          float* __restrict__ tmp) {
+    __shared__ float s_in[CROP_MAXC];
     const int CV = C / V;
-    const long total = (long)nbox * ch * W * CV;
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int c = (int)(i % CV) * V;
-        long t = i / CV;
-        const int x = (int)(t % W); t /= W;                  // t = b*ch + ii
-        const int b = (int)(t / ch);
-        const float x1 = boxes[b * 4 + 1], x2 = boxes[b * 4 + 3];
+    const long t = blockIdx.x;                                   // b*ch + ii
+    const int b = (int)(t / ch);
+    const float x1 = boxes[b * 4 + 1], x2 = boxes[b * 4 + 3];
+    for (int j = threadIdx.x; j < cw; j += 256) {
+        float in_x;
+        s_in[j] = crop_coord(x1, x2, j, cw, W, &in_x) ? in_x : -4.f;       // outside the image: weight <= 0 for every pixel
+    }
+    __syncthreads();
+    int xlo, xhi;
+    crop_cols(x1, x2, W, &xlo, &xhi);
+    const int ncol = xhi - xlo + 1;
+    const T* g = dout + (t * cw) * C;
+    for (int idx = threadIdx.x; idx < ncol * CV; idx += 256) {
+        const int xq = idx / CV, c = (idx - xq * CV) * V;
+        const int x = xlo + xq;
         int jlo, jhi;
         crop_range(x1, x2, cw, W, x, &jlo, &jhi);
         float acc[V];
 #pragma unroll
         for (int e = 0; e < V; ++e) acc[e] = 0.f;
-        const T* g = dout + (t * cw) * C + c;
         for (int j = jlo; j <= jhi; ++j) {
-            float in_x;
-            if (!crop_coord(x1, x2, j, cw, W, &in_x)) continue;
-            const float w = 1.f - fabsf(in_x - (float)x);
+            const float w = 1.f - fabsf(s_in[j] - (float)x);
             if (w <= 0.f) continue;
+            float gv[V];
+            ld_vec<V>(g + (long)j * C + c, gv);
 #pragma unroll
-            for (int e = 0; e < V; ++e) acc[e] += w * ld_elem(g, (long)j * C + e);
+            for (int e = 0; e < V; ++e) acc[e] += w * gv[e];
         }
         float* o = tmp + (t * W + x) * C + c;
+        if constexpr (V == 4) *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        else {
 #pragma unroll
-        for (int e = 0; e < V; ++e) o[e] = acc[e];
+            for (int e = 0; e < V; ++e) o[e] = acc[e];
+        }
     }
 }
-// pass Y: one thread per (image pixel, channel quad).  The boxes of the block's image(s) are first marked in an
-// LDS bitmask (atomicOr: order-free), then visited in increasing box order by every thread.
+// pass Y, one workgroup per image row (n, y): the (box, crop row, weight) triples that reach this row are listed ONCE in LDS in
+// (box, crop row) order -- the fixed summation order -- together with the box's column range; a thread = (pixel of the row,
+// channel group) adds the listed tmp rows whose column range holds its pixel.
+constexpr int CROP_MAXENT = 1024;
 template <int V, typename T>
 __global__ __launch_bounds__(256) void crop_bwd_y_kernel(const float* __restrict__ tmp, int N, int H, int W, int C,
                                                          const float* __restrict__ boxes,
                                                          const int* __restrict__ box_ind, int nbox, int ch,
                                                          T* __restrict__ dimg) {
-    __shared__ unsigned s_mask[32];
+    __shared__ int s_row[CROP_MAXENT];          // b*ch + ii
+    __shared__ float s_w[CROP_MAXENT];
+    __shared__ short s_lo[CROP_MAXENT], s_hi[CROP_MAXENT];
+    __shared__ int s_n;
     const int CV = C / V;
-    const long per_img = (long)H * W * CV;
-    const long total = (long)N * per_img;
-    const long i0 = (long)blockIdx.x * blockDim.x;
-    const long i = i0 + threadIdx.x;
-    const bool live = i < total;
-    const long ic = live ? i : total - 1;
-    const int c = (int)(ic % CV) * V;
-    long t = ic / CV;
-    const int x = (int)(t % W); t /= W;
-    const int y = (int)(t % H);
-    const int n = (int)(t / H);
-    const int n_lo = (int)(i0 / per_img);
-    const long ilast = (i0 + blockDim.x - 1 < total) ? i0 + blockDim.x - 1 : total - 1;
-    const int n_hi = (int)(ilast / per_img);
-    float acc[V];
-#pragma unroll
-    for (int e = 0; e < V; ++e) acc[e] = 0.f;
-    for (int base = 0; base < nbox; base += 1024) {
-        if (threadIdx.x < 32) s_mask[threadIdx.x] = 0u;
-        __syncthreads();
-        for (int b = base + threadIdx.x; b < nbox && b < base + 1024; b += blockDim.x) {
-            const int ind = box_ind[b];
-            if (ind >= n_lo && ind <= n_hi) atomicOr(&s_mask[(b - base) >> 5], 1u << ((b - base) & 31));
+    const int n = blockIdx.x / H, y = blockIdx.x - n * H;
+    // (blockIdx.y: which 256-thread slice of the row's W * C/V work items -- the gather is latency-bound, it wants many threads)
+    // list building, thread = box (boxes beyond 256: the per-thread path below): count this box's samples that reach row y, place the
+    // box's run after the runs of the boxes before it -- (box, crop row) order, the fixed summation order
+    __shared__ int s_cnt[256];
+    int my = 0, ilo = 0, ihi = -1, xlo = 0, xhi = -1;
+    float y1 = 0.f, y2 = 0.f;
+    if (threadIdx.x < nbox && nbox <= 256 && box_ind[threadIdx.x] == n) {
+        const int b = threadIdx.x;
+        y1 = boxes[b * 4 + 0]; y2 = boxes[b * 4 + 2];
+        crop_range(y1, y2, ch, H, y, &ilo, &ihi);
+        crop_cols(boxes[b * 4 + 1], boxes[b * 4 + 3], W, &xlo, &xhi);
+        for (int ii = ilo; ii <= ihi; ++ii) {
+            float in_y;
+            if (!crop_coord(y1, y2, ii, ch, H, &in_y)) continue;
+            if (1.f - fabsf(in_y - (float)y) > 0.f) ++my;
         }
-        __syncthreads();
-        for (int wd = 0; wd < 32; ++wd) {
-            unsigned m = s_mask[wd];
-            while (m) {
-                const int b = base + wd * 32 + (__ffs((int)m) - 1);
-                m &= m - 1;
+    }
+    s_cnt[threadIdx.x] = my;
+    __syncthreads();
+    if (nbox <= 256) {
+        int off = 0, tot = 0;
+        for (int b = 0; b < nbox; ++b) { const int cb = s_cnt[b]; if (b < (int)threadIdx.x) off += cb; tot += cb; }
+        if (threadIdx.x == 0) s_n = tot;
+        if (my > 0 && tot <= CROP_MAXENT) {
+            for (int ii = ilo; ii <= ihi; ++ii) {
+                float in_y;
+                if (!crop_coord(y1, y2, ii, ch, H, &in_y)) continue;
+                const float w = 1.f - fabsf(in_y - (float)y);
+                if (w <= 0.f) continue;
+                s_row[off] = threadIdx.x * ch + ii; s_w[off] = w; s_lo[off] = (short)xlo; s_hi[off] = (short)xhi;
+                ++off;
+            }
+        }
+    } else if (threadIdx.x == 0) {
+        s_n = CROP_MAXENT + 1;
+    }
+    __syncthreads();
+    const int cnt = s_n;
+    if (cnt > CROP_MAXENT) {
+        // more samples reach this row than the table holds (hundreds of boxes on one image): every thread walks the boxes itself,
+        // same order, same arithmetic
+        for (int idx = blockIdx.y * 256 + threadIdx.x; idx < W * CV; idx += gridDim.y * 256) {
+            const int x = idx / CV, c = (idx - x * CV) * V;
+            float acc[V];
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[e] = 0.f;
+            for (int b = 0; b < nbox; ++b) {
                 if (box_ind[b] != n) continue;
+                int xlo, xhi, ilo, ihi;
+                crop_cols(boxes[b * 4 + 1], boxes[b * 4 + 3], W, &xlo, &xhi);
+                if (x < xlo || x > xhi) continue;
                 const float y1 = boxes[b * 4 + 0], y2 = boxes[b * 4 + 2];
-                int ilo, ihi;
                 crop_range(y1, y2, ch, H, y, &ilo, &ihi);
-                const float* g = tmp + (((long)b * ch) * W + x) * C + c;
                 for (int ii = ilo; ii <= ihi; ++ii) {
                     float in_y;
                     if (!crop_coord(y1, y2, ii, ch, H, &in_y)) continue;
                     const float w = 1.f - fabsf(in_y - (float)y);
                     if (w <= 0.f) continue;
+                    float gv[V];
+                    ld_vec<V>(tmp + (((long)b * ch + ii) * W + x) * C + c, gv);
 #pragma unroll
-                    for (int e = 0; e < V; ++e) acc[e] += w * g[(long)ii * W * C + e];
+                    for (int e = 0; e < V; ++e) acc[e] += w * gv[e];
                 }
             }
-        }
-        __syncthreads();
-    }
-    if (live) {
-        T* o = dimg + (((long)n * H + y) * W + x) * C + c;
+            T* o = dimg + (((long)n * H + y) * W + x) * C + c;
 #pragma unroll
-        for (int e = 0; e < V; ++e) st_elem(o, e, acc[e]);
+            for (int e = 0; e < V; ++e) st_elem(o, e, acc[e]);
+        }
+        return;
+    }
+    for (int idx = blockIdx.y * 256 + threadIdx.x; idx < W * CV; idx += gridDim.y * 256) {
+        const int x = idx / CV, c = (idx - x * CV) * V;
+        float acc[V];
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] = 0.f;
+        for (int k = 0; k < cnt; ++k) {
+            if (x < s_lo[k] || x > s_hi[k]) continue;
+            float gv[V];
+            ld_vec<V>(tmp + ((long)s_row[k] * W + x) * C + c, gv);
+            const float w = s_w[k];
+#pragma unroll
+            for (int e = 0; e < V; ++e) acc[e] += w * gv[e];
+        }
+        T* o = dimg + (((long)n * H + y) * W + x) * C + c;
+        if constexpr (V == 4 && sizeof(T) == 4) *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        else if constexpr (V == 4) {
+            unsigned short h[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const __bf16 bb = (__bf16)acc[e]; h[e] = __builtin_bit_cast(unsigned short, bb); }
+            *reinterpret_cast<uint2*>(o) = make_uint2((unsigned)h[0] | ((unsigned)h[1] << 16), (unsigned)h[2] | ((unsigned)h[3] << 16));
+        } else {
+#pragma unroll
+            for (int e = 0; e < V; ++e) st_elem(o, e, acc[e]);
+        }
     }
 }
 
@@ -979,7 +1127,8 @@ extern "C" int dpig_colsum(const float* a, int lda, int64_t rows, int cols, floa
 static int class_slabs(int N, int H, int W) {
     int s = (H * W) / 256;
     if (s < 1) s = 1;
-    if (s > 32) s = 32;
+    if (s > 64) s = 64;
+    if (s > H) s = H;            // (the vector kernel deals whole image rows to slabs)
     return s;
 }
 extern "C" size_t dpig_border_class_sum_workspace_bytes(int N, int H, int W, int C) {
@@ -995,8 +1144,11 @@ static int border_class_sum_impl(const T* a, int lda, int N, int H, int W, int C
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nslab = class_slabs(N, H, W);
     float* partial = static_cast<float*>(ws);
-    hipLaunchKernelGGL(class_sum_partial_kernel<T>, dim3(cdivi(C, 64), N, nslab), dim3(256), 0, st, a, lda, H, W, C,
-                       partial);
+    constexpr int V = 16 / (int)sizeof(T);
+    if (C % V == 0 && lda % V == 0 && C / V <= 256 && 256 % (C / V) == 0 && aligned16(a))
+        hipLaunchKernelGGL((class_sum_partial_vec_kernel<T, V>), dim3(1, N, nslab), dim3(256), 0, st, a, lda, H, W, C, partial);
+    else
+        hipLaunchKernelGGL(class_sum_partial_kernel<T>, dim3(cdivi(C, 64), N, nslab), dim3(256), 0, st, a, lda, H, W, C, partial);
     const long total = (long)N * 9 * C;
     hipLaunchKernelGGL(class_sum_final_kernel, dim3(grid_for(total)), dim3(256), 0, st, partial, nslab, C, total, out);
     return check_launch("border_class_sum");
@@ -1274,15 +1426,17 @@ static int crop_resize_bwd_impl(const T* dout, int N, int H, int W, int C, const
     hipStream_t st = static_cast<hipStream_t>(stream);
     float* tmp = static_cast<float*>(ws);
     const bool v4 = (C % 4 == 0) && aligned16(dout) && aligned16(dimg) && aligned16(ws);
-    const long nx = (long)nbox * ch * W * (v4 ? C / 4 : C);
-    const long ny = (long)N * H * W * (v4 ? C / 4 : C);
-    if (ny > 256L * 0x7fffffffL) return fail(DPIG_EINVAL, "crop_resize_bwd: image too large");
-    const dim3 gy((unsigned)((ny + 255) / 256));
+    if (cw > CROP_MAXC || W > 32767 || (long)nbox * ch > 0x7fffffffL || (long)N * H > 0x7fffffffL)
+        return fail(DPIG_EINVAL, "crop_resize_bwd: crop wider than %d or image too large", CROP_MAXC);
+    const int per_row = W * (v4 ? C / 4 : C);
+    int ysplit = (per_row + 255) / 256;
+    if (ysplit > 64) ysplit = 64;
+    const dim3 gx((unsigned)((long)nbox * ch)), gy((unsigned)((long)N * H), (unsigned)ysplit);
     if (v4) {
-        hipLaunchKernelGGL((crop_bwd_x_kernel<4, T>), dim3(grid_for(nx)), dim3(256), 0, st, dout, W, C, boxes, nbox, ch, cw, tmp);
+        hipLaunchKernelGGL((crop_bwd_x_kernel<4, T>), gx, dim3(256), 0, st, dout, W, C, boxes, nbox, ch, cw, tmp);
         hipLaunchKernelGGL((crop_bwd_y_kernel<4, T>), gy, dim3(256), 0, st, tmp, N, H, W, C, boxes, box_ind, nbox, ch, dimg);
     } else {
-        hipLaunchKernelGGL((crop_bwd_x_kernel<1, T>), dim3(grid_for(nx)), dim3(256), 0, st, dout, W, C, boxes, nbox, ch, cw, tmp);
+        hipLaunchKernelGGL((crop_bwd_x_kernel<1, T>), gx, dim3(256), 0, st, dout, W, C, boxes, nbox, ch, cw, tmp);
         hipLaunchKernelGGL((crop_bwd_y_kernel<1, T>), gy, dim3(256), 0, st, tmp, N, H, W, C, boxes, box_ind, nbox, ch, dimg);
     }
     return check_launch("crop_resize_bwd");

@@ -506,6 +506,102 @@ __global__ __launch_bounds__(256) void fewc_dgrad_kernel(const FewCParams p, int
     }
 }
 
+// ---- the same gradient for K == 64 with lane = (pixel, 8-channel chunk): a wave takes 8 pixels of ONE row and ONE column parity,
+// so the set of taps that reach them is wave-uniform (stride 2: tap (ky, kx) reaches pixel (iy, ix) iff iy + pt - ky and
+// ix + pl - kx are even); per tap ONE fully coalesced wave load (8 neighbouring dy pixels x 128 bytes), the lane's three filter
+// rows come from LDS, partial sums stay in the lane over all taps and are folded across the 8 chunk lanes once per pixel.
+// Persistent workgroups (the 19 KB filter is staged once per workgroup).  HBM traffic: dy once + the image gradient.
+template <int R, int S, int ST, bool WB>
+__global__ __launch_bounds__(256) void fewc_dgrad_px_kernel(const FewCParams p, int nitems) {
+    extern __shared__ __attribute__((aligned(16))) float wl[];       // [R*S][8 chunks][3][8]
+    constexpr int K = 64, NCH = 8;
+    for (int i = threadIdx.x; i < R * S * 3 * K; i += 256) {
+        const int k = i % K, tc = i / K, c = tc % 3, t = tc / 3;
+        wl[((t * NCH + (k >> 3)) * 3 + c) * 8 + (k & 7)] = p.W[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int q = lane >> 3, ch = lane & 7;
+    const int halfW = (p.Wd + ST - 1) / ST;
+    const int segs = (halfW + 7) >> 3;
+    for (int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)); item < nitems; item += gridDim.x * 4) {
+        const int seg = item % segs;
+        const int t = item / segs;
+        const int px = t % ST;
+        const int row = t / ST;                            // n*H + iy
+        const int n = row / p.H, iy = row - n * p.H;
+        const int ix = (seg * 8 + q) * ST + px;
+        const bool valid = ix < p.Wd;
+        float a0 = 0.f, a1 = 0.f, a2 = 0.f;
+        // taps that reach this parity class: ky = ky0, ky0 + ST, ...; kx likewise (at most NT x NT of them).  Taps that fall off the
+        // filter or the dy image are gated to zero with a clamped address instead of a branch, so all NT*NT loads are issued together.
+        constexpr int NT = (R + ST - 1) / ST;
+        const int ky0 = (iy + p.pt) & (ST - 1), kx0 = (px + p.pl) & (ST - 1);
+        uint4 raw[NT * NT];
+        float gate[NT * NT];
+        int tapi[NT * NT];
+#pragma unroll
+        for (int a = 0; a < NT; ++a) {
+            const int ky = ky0 + a * ST;
+            const int ty = iy + p.pt - ky;                  // even by construction
+            const bool oky = ky < R && ty >= 0 && (ty >> 1) < p.Ho;
+            const long rbase = ((long)n * p.Ho + (oky ? (ty >> 1) : 0)) * p.Wo;
+#pragma unroll
+            for (int bq = 0; bq < NT; ++bq) {
+                const int kx = kx0 + bq * ST;
+                const int tx = ix + p.pl - kx;
+                const int ox = tx >> 1;
+                const bool ok = oky && valid && kx < S && tx >= 0 && ox < p.Wo;
+                const long go = (rbase + (ok ? ox : 0)) * p.ldy + ch * 8;
+                if constexpr (WB) raw[a * NT + bq] = *reinterpret_cast<const uint4*>(static_cast<const unsigned short*>(p.DY) + go);
+                else raw[a * NT + bq] = *reinterpret_cast<const uint4*>(static_cast<const float*>(p.DY) + go);   // (first 4 of 8)
+                gate[a * NT + bq] = ok ? 1.f : 0.f;
+                tapi[a * NT + bq] = ((ky < R ? ky : 0) * S + (kx < S ? kx : 0));
+                if constexpr (!WB) {
+                    // fp32 dy: second half of the 8 channels, consumed right away (keeps the register budget of the bf16 path)
+                    const float4 hi = *reinterpret_cast<const float4*>(static_cast<const float*>(p.DY) + go + 4);
+                    const float* w8 = wl + (tapi[a * NT + bq] * NCH + ch) * 24;
+                    const float g = gate[a * NT + bq];
+                    a0 += g * (hi.x * w8[4] + hi.y * w8[5] + hi.z * w8[6] + hi.w * w8[7]);
+                    a1 += g * (hi.x * w8[12] + hi.y * w8[13] + hi.z * w8[14] + hi.w * w8[15]);
+                    a2 += g * (hi.x * w8[20] + hi.y * w8[21] + hi.z * w8[22] + hi.w * w8[23]);
+                }
+            }
+        }
+#pragma unroll
+        for (int t9 = 0; t9 < NT * NT; ++t9) {
+            const float* w8 = wl + (tapi[t9] * NCH + ch) * 24;
+            const float g = gate[t9];
+            const uint4 u = raw[t9];
+            if constexpr (WB) {
+                float v[8];
+                v[0] = __uint_as_float(u.x << 16); v[1] = __uint_as_float(u.x & 0xffff0000u);
+                v[2] = __uint_as_float(u.y << 16); v[3] = __uint_as_float(u.y & 0xffff0000u);
+                v[4] = __uint_as_float(u.z << 16); v[5] = __uint_as_float(u.z & 0xffff0000u);
+                v[6] = __uint_as_float(u.w << 16); v[7] = __uint_as_float(u.w & 0xffff0000u);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float ve = v[e] * g;
+                    a0 += ve * w8[e]; a1 += ve * w8[8 + e]; a2 += ve * w8[16 + e];
+                }
+            } else {
+                const float v0 = __uint_as_float(u.x) * g, v1 = __uint_as_float(u.y) * g, v2 = __uint_as_float(u.z) * g, v3 = __uint_as_float(u.w) * g;
+                a0 += v0 * w8[0] + v1 * w8[1] + v2 * w8[2] + v3 * w8[3];
+                a1 += v0 * w8[8] + v1 * w8[9] + v2 * w8[10] + v3 * w8[11];
+                a2 += v0 * w8[16] + v1 * w8[17] + v2 * w8[18] + v3 * w8[19];
+            }
+        }
+#pragma unroll
+        for (int o = 1; o < 8; o <<= 1) {
+            a0 += __shfl_xor(a0, o, 64); a1 += __shfl_xor(a1, o, 64); a2 += __shfl_xor(a2, o, 64);
+        }
+        if (valid && ch == 0) {
+            float* o = p.DX + ((long)row * p.Wd + ix) * p.ldx;
+            o[0] = a0; o[1] = a1; o[2] = a2;
+        }
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------
 static bool eligible(const DpigConvDesc* d, int pt, int pl) {
     return d->K == TK && d->R == 3 && d->S == 3 && d->stride == 1 && !d->upsample2x && pt == 1 && pl == 1 &&
@@ -647,6 +743,19 @@ int fewc_dgrad_try(const DpigConvDesc* d, int pt, int pl, int Ho, int Wo, const 
     FewCParams p = {};
     fewc_fill(d, pt, pl, Ho, Wo, &p);
     p.DY = dy; p.W = w; p.DX = dx;
+    if (d->K == 64 && p.ldy % 8 == 0 && aligned16(dy)) {
+        const int halfW = (d->W + 1) / 2, segs = (halfW + 7) / 8;
+        const long nit = (long)d->N * d->H * 2 * segs;
+        if (nit < 0x7fffffffL) {
+            const int nitems = (int)nit;
+            const size_t lds = (size_t)25 * 3 * 64 * sizeof(float);
+            const int nblk = (nitems + 3) / 4 < 8 * kNumCU ? (nitems + 3) / 4 : 8 * kNumCU;
+            if (wide_bf16) hipLaunchKernelGGL((fewc_dgrad_px_kernel<5, 5, 2, true>), dim3(nblk), dim3(256), lds, st, p, nitems);
+            else hipLaunchKernelGGL((fewc_dgrad_px_kernel<5, 5, 2, false>), dim3(nblk), dim3(256), lds, st, p, nitems);
+            const int rc = check_launch("fewc_dgrad_px_kernel");
+            return rc ? rc : 1;
+        }
+    }
     const int nstrips = (d->W + XS - 1) / XS;
     const int nwaves = d->N * d->H * nstrips;
     if (wide_bf16) hipLaunchKernelGGL((fewc_dgrad_kernel<5, 5, 2, true>), dim3((nwaves + 3) / 4), dim3(256), 0, st, p, nstrips, nwaves);

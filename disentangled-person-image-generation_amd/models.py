@@ -246,7 +246,8 @@ def GeneratorCNN_ID_UAEAfterResidual(x, pose, input_channel, z_num, repeat_num, 
         if tiled:
             # x is a [B,E] embedding broadcast over H x W (trainer.py:588-590 embs_rep): the first conv
             # collapses exactly to a small GEMM + a thin conv over the pose channels
-            x = slim.conv2d_tiled_embedding(x[:, 0, 0, :], pose, hidden_num)
+            src = getattr(x, "_dpig_src", None)       # the [B,E] tensor the caller expanded (saves autograd's zero-fill + sum over [B,H,W,E])
+            x = slim.conv2d_tiled_embedding(src if src is not None else x[:, 0, 0, :], pose, hidden_num)
         else:
             if pose is not None:
                 x = torch.cat([x, pose], dim=3)

@@ -31,6 +31,7 @@ class DPIG_Encoder_GAN_BodyROI_256(DPIG_Encoder_GAN_BodyROI_FgBg):
     def generate(self, embs, pose):
         B = embs.shape[0]
         embs_rep = embs.reshape(B, 1, 1, -1).expand(B, self.img_H, self.img_W, embs.shape[1])
+        embs_rep._dpig_src = embs     # the builder's collapsed first conv reads the [B,E] source (no expand -> select round trip in autograd)
         with slim.variable_scope("ID_AE"):
             G, _, g_var = self.Generator_fn(embs_rep, pose, self.channel, self.z_num, self.repeat_num - 1,
                                             self.conv_hidden_num, self.data_format, activation_fn=slim.relu,

@@ -321,7 +321,9 @@ def test_checkpoint_resume_with_optimizer_slots(dev, tmp_path):
     import json
     import os
     fix = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ckpt_keys_model1.json")))
-    assert names == set(fix["keys"]), (sorted(names - set(fix["keys"]))[:5], sorted(set(fix["keys"]) - names)[:5])
+    ours = {"dpig_amd/adam_step", "dpig_amd/adam_step_1"}      # this repo's extension (exact integer step counts); a TF Saver ignores them
+    assert ours <= names
+    assert names - ours == set(fix["keys"]), (sorted(names - ours - set(fix["keys"]))[:5], sorted(set(fix["keys"]) - names)[:5])
     tr.train_step(gb, gb)
     want_g, want_d = tr.G_flat.flat.clone(), tr.D_flat.flat.clone()
     lib.delete_all_params()
