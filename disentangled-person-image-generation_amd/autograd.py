@@ -169,6 +169,15 @@ class _ConvFn(torch.autograd.Function):
         x, w, y = ctx.saved_tensors
         stride, act, alpha, up, has_b = ctx.cfg
         second = torch.is_grad_enabled()       # backward under create_graph=True
+        if up and not second and w.shape[0] == 1 and w.shape[1] == 1:
+            # act(conv1x1(upsample2x(x))): nearest upsampling commutes with the 1x1 conv, so its gradient lives on x's grid:
+            # one pass forms sum_{2x2} dy * act'(y) there, then plain 1x1 dgrad / wgrad (no 4-tap gathers of the 4x larger dy)
+            dzp = H.act_bwd_pool2x(dy, y, act, alpha)
+            dx = H.conv2d_dgrad(dzp, w, tuple(x.shape), stride=1) if ctx.needs_input_grad[0] else None
+            if _PARAM_GRADS_OFF[0]:
+                return dx, None, None, None, None, None, None, None, None
+            dw, db = _sink_wgrad_bias(w, ctx.b_ref, x, dzp, 1, False, ctx.needs_input_grad[1], has_b and ctx.needs_input_grad[2])
+            return dx, dw, db, None, None, None, None, None, None
         if second:
             dz = _ActBwdFn.apply(dy, y, act, alpha) if act != ACT_NONE else dy
         else:

@@ -194,6 +194,53 @@ __global__ __launch_bounds__(256) void emb_class_bwd_kernel(const float* __restr
     }
 }
 
+// ---- gradient of act(conv1x1(upsample2x(x))) w.r.t. the conv's LOW-resolution pre-image: the nearest-neighbour upsample commutes
+// with a 1x1 conv (models.py:569-570 computed at low resolution), so the backward pass needs sum_{2x2} dy * act'(y) per low-res
+// pixel -- one pass over dy / y instead of act_bwd + two 4-tap gathers over the high-resolution gradient.  dz [N,H,W,C] (dense),
+// dy / y [N,2H,2W,C] with row strides; VEC channels per thread (16 bytes).
+template <typename T, int VEC>
+__global__ __launch_bounds__(256) void act_bwd_pool2x_kernel(const T* __restrict__ dy, int lddy, const T* __restrict__ y, int ldy,
+                                                             T* __restrict__ dz, int N, int H, int W, int C, int act, float alpha) {
+    const int cv = C / VEC;
+    const long total = (long)N * H * W * cv;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % cv) * VEC;
+        long t = i / cv;
+        const int x = (int)(t % W); t /= W;
+        const int yy = (int)(t % H);
+        const long n = t / H;
+        float acc[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const long pix = (n * 2 * H + 2 * yy + (q >> 1)) * (2L * W) + 2 * x + (q & 1);
+            T g[VEC], a[VEC];
+            if (VEC * sizeof(T) == 16) *reinterpret_cast<uint4*>(g) = *reinterpret_cast<const uint4*>(dy + pix * lddy + c);
+            else g[0] = dy[pix * lddy + c];
+            if (act != DPIG_ACT_NONE) {
+                if (VEC * sizeof(T) == 16) *reinterpret_cast<uint4*>(a) = *reinterpret_cast<const uint4*>(y + pix * ldy + c);
+                else a[0] = y[pix * ldy + c];
+            }
+#pragma unroll
+            for (int e = 0; e < VEC; ++e) {
+                float gv, av = 1.f;
+                if constexpr (sizeof(T) == 2) { gv = glue_b2f(g[e]); if (act != DPIG_ACT_NONE) av = glue_b2f(a[e]); }
+                else { gv = g[e]; if (act != DPIG_ACT_NONE) av = a[e]; }
+                acc[e] += (act == DPIG_ACT_NONE) ? gv : gv * act_grad(av, act, alpha);
+            }
+        }
+        T o[VEC];
+#pragma unroll
+        for (int e = 0; e < VEC; ++e) {
+            if constexpr (sizeof(T) == 2) o[e] = glue_f2b(acc[e]); else o[e] = acc[e];
+        }
+        T* d = dz + (((n * H + yy) * W) + x) * C + c;
+        if (VEC * sizeof(T) == 16) *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(o);
+        else d[0] = o[0];
+    }
+}
+
 // ---- dst[r][c] = beta * dst[r][c] + src[r][c] on [outer][rows][cols] views with independent strides ---------------------
 __global__ __launch_bounds__(256) void axpby3d_kernel(const float* __restrict__ src, long s_outer, long s_row,
                                                       float* __restrict__ dst, long d_outer, long d_row, int outer, int rows,
@@ -313,6 +360,25 @@ extern "C" int dpig_emb_class_weights_bwd(const float* dwc, int E, int C, int K,
     const long n = (long)E * K;
     hipLaunchKernelGGL(emb_class_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), dwc, E, C, K, dw, beta);
     return check_launch("emb_class_weights_bwd");
+}
+
+extern "C" int dpig_act_bwd_pool2x(const void* dy, int lddy, const void* y, int ldy, void* dz, int N, int H, int W, int C, int act,
+                                   float alpha, int is_bf16, void* stream) {
+    if (!dy || !dz || (act != DPIG_ACT_NONE && !y) || N <= 0 || H <= 0 || W <= 0 || C <= 0 || lddy < C || (y && ldy < C))
+        return fail(DPIG_EINVAL, "act_bwd_pool2x: bad arguments");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int vec = is_bf16 ? 8 : 4;
+    const bool v = C % vec == 0 && lddy % vec == 0 && (!y || ldy % vec == 0) && aligned16(dy) && aligned16(dz) && (!y || aligned16(y));
+    const long work = (long)N * H * W * (v ? C / vec : C);
+    const dim3 grid(glue_blocks(work, 16));
+    if (is_bf16) {
+        if (v) hipLaunchKernelGGL((act_bwd_pool2x_kernel<glue_bf16, 8>), grid, dim3(256), 0, st, (const glue_bf16*)dy, lddy, (const glue_bf16*)y, ldy, (glue_bf16*)dz, N, H, W, C, act, alpha);
+        else hipLaunchKernelGGL((act_bwd_pool2x_kernel<glue_bf16, 1>), grid, dim3(256), 0, st, (const glue_bf16*)dy, lddy, (const glue_bf16*)y, ldy, (glue_bf16*)dz, N, H, W, C, act, alpha);
+    } else {
+        if (v) hipLaunchKernelGGL((act_bwd_pool2x_kernel<float, 4>), grid, dim3(256), 0, st, (const float*)dy, lddy, (const float*)y, ldy, (float*)dz, N, H, W, C, act, alpha);
+        else hipLaunchKernelGGL((act_bwd_pool2x_kernel<float, 1>), grid, dim3(256), 0, st, (const float*)dy, lddy, (const float*)y, ldy, (float*)dz, N, H, W, C, act, alpha);
+    }
+    return check_launch("act_bwd_pool2x");
 }
 
 extern "C" int dpig_axpby3d(const float* src, int64_t s_outer, int64_t s_row, float* dst, int64_t d_outer, int64_t d_row, int outer,

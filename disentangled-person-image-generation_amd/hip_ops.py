@@ -776,6 +776,25 @@ def act_fwd(x, act, alpha=0.2):
     return y
 
 
+def act_bwd_pool2x(dy, y, act, alpha=0.2):
+    """sum over 2x2 blocks of dy * act'(y): [N,2H,2W,C] -> [N,H,W,C], the gradient of act(conv1x1(upsample2x(.))) on the
+    low-resolution grid the conv runs on (dpig_act_bwd_pool2x).  fp32 or bf16 pairs."""
+    _require_dev(dy)
+    N, H2, W2, C = dy.shape
+    if H2 % 2 or W2 % 2:
+        raise RuntimeError("act_bwd_pool2x: odd spatial size")
+    lddy = nhwc_ld(dy)
+    ldy = nhwc_ld(y) if (y is not None and act != ACT_NONE) else C
+    same = y is None or act == ACT_NONE or y.dtype == dy.dtype
+    if lddy is None or ldy is None or not same:
+        dz = act_bwd(dy, y, act, alpha) if act != ACT_NONE else dy
+        return upsample2x_bwd(dz.contiguous())
+    dz = torch.empty((N, H2 // 2, W2 // 2, C), dtype=dy.dtype, device=dy.device)
+    check(lib().dpig_act_bwd_pool2x(ptr(dy), lddy, ptr(y) if act != ACT_NONE else None, ldy, ptr(dz), N, H2 // 2, W2 // 2, C, act,
+                                    float(alpha), int(dy.dtype == BF16), stream_ptr()), "act_bwd_pool2x")
+    return dz
+
+
 def act_bwd(dy, y, act, alpha=0.2, emit32=False):
     """dz = dy * act'(y) with y the activation output.  `emit32`: dz feeds conv kernels next ('bf16x3' mode: also leave its
     split32 image)."""

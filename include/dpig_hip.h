@@ -464,6 +464,12 @@ int dpig_vis_concat_bwd(const float* dall, const float* vis, int ldvis, int B, i
  * (cy, cx) of a SAME 3x3 conv sees; _bwd is the transpose into dw[.][.][e < E][.] (dw = beta * dw + ...). */
 int dpig_emb_class_weights_fwd(const float* w, int E, int C, int K, float* wmat, void* stream);
 int dpig_emb_class_weights_bwd(const float* dwc, int E, int C, int K, float* dw, float beta, void* stream);
+/* dz[N,H,W,C] = sum over the 2x2 block of dy[N,2H,2W,C] * act'(y[N,2H,2W,C]): the gradient of act(conv1x1(upsample2x(x)))
+ * (models.py:569-570, utils.py:61-72) pulled back to the low-resolution grid the 1x1 conv is computed on -- TF's ReluGrad +
+ * ResizeNearestNeighborGrad in one pass; its result feeds plain 1x1 dgrad / wgrad.  fp32 or bf16 (is_bf16) tensors; y may be
+ * NULL when act is DPIG_ACT_NONE. */
+int dpig_act_bwd_pool2x(const void* dy, int lddy, const void* y, int ldy, void* dz, int N, int H, int W, int C, int act, float alpha,
+                        int is_bf16, void* stream);
 /* dst[o][r][c] = beta * dst[o][r][c] + src[o][r][c] with independent outer / row strides (elements). */
 int dpig_axpby3d(const float* src, int64_t s_outer, int64_t s_row, float* dst, int64_t d_outer, int64_t d_row, int outer, int rows,
                  int cols, float beta, void* stream);

@@ -532,3 +532,28 @@ def test_glue_kernels_equal_the_elementwise_graph_they_replace(dev):
         assert torch.equal(y, ref)
         dy = torch.randn(y.shape, generator=g).to(dt).to(dev)
         assert torch.equal(torch.autograd.grad(y, xn, dy)[0], torch.autograd.grad(ref, xn, dy)[0])
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_act_bwd_pool2x_equals_masked_gradient_summed_over_2x2(dev, dtype):
+    """dpig_act_bwd_pool2x: the gradient of act(conv1x1(upsample2x(x))) on x's grid = 2x2 block sums of dy * act'(y)
+    (ReluGrad + ResizeNearestNeighborGrad of models.py:569-570 / utils.py:61-72 in one pass), dense and channel-sliced operands."""
+    import dpig_amd.hip_ops as H
+    g = torch.Generator().manual_seed(3)
+    N, Hh, W, C = 3, 6, 10, 24
+    td = torch.bfloat16 if dtype == "bf16" else torch.float32
+    wide = torch.randn(N, 2 * Hh, 2 * W, C + 8, generator=g).to(td).to(dev)
+    dy_dense = torch.randn(N, 2 * Hh, 2 * W, C, generator=g).to(td).to(dev)
+    y = torch.randn(N, 2 * Hh, 2 * W, C, generator=g).to(td).to(dev)
+    for dy in (dy_dense, wide[..., 8:]):                      # dense, and a channel slice of a wider buffer (decoder concat)
+        for act, alpha in ((0, 0.2), (1, 0.2), (2, 0.2)):
+            ref = dy.float()
+            if act == 1:
+                ref = ref * (y.float() > 0).float()
+            elif act == 2:
+                ref = ref * torch.where(y.float() > 0, torch.ones_like(ref), torch.full_like(ref, alpha))
+            ref = ref.reshape(N, Hh, 2, W, 2, C).sum(dim=(2, 4))
+            got = H.act_bwd_pool2x(dy, y, act, alpha)
+            assert got.dtype == td and got.shape == (N, Hh, W, C)
+            tol = 2.0 ** -7 if dtype == "bf16" else 1e-6
+            assert float((got.float() - ref).abs().max()) <= tol * float(ref.abs().max())
