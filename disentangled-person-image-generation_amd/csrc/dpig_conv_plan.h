@@ -52,7 +52,10 @@ static inline int choose_split(int tiles, int ktiles, int forced, int kdepth = 3
     const double kred = (double)kdepth * ktiles;
     double best = -1.0;
     int best_s = 1;
-    const int smax = ktiles / 2 > 0 ? (ktiles / 2 < 64 ? ktiles / 2 : 64) : 1;
+    // (a handful of tiles with a very deep reduction -- the fully connected layers, 20480 -> 128 on 16 rows -- is one k-tile chain per
+    // workgroup: latency-bound, so it may be cut into one piece per CU; the partial sums of so few tiles are a few MB)
+    const int cap = tiles <= 8 ? kNumCU : 64;
+    const int smax = ktiles / 2 > 0 ? (ktiles / 2 < cap ? ktiles / 2 : cap) : 1;
     for (int s = 1; s <= smax; ++s) {
         const int tps = cdiv(ktiles, s);
         const int sr = cdiv(ktiles, tps);                  // effective split count
