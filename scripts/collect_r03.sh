@@ -1,0 +1,12 @@
+#!/bin/bash
+# Round-3 evidence pass on the GPU box: kernel stats + PMC (matrix pipe) of the headline and the DeepFashion bf16 step, then the
+# driver's default bench line.  Outputs under gpurun_out/profiles_out/ (copied into profiles/ afterwards).
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+bash scripts/collect_stats.sh r03_market_f32
+bash scripts/collect_stats.sh r03_df256_bf16 --workload df256 --dtype bf16
+bash scripts/pmc_mfma_bench.sh r03_market_f32
+bash scripts/pmc_mfma_bench.sh r03_df256_bf16 --workload df256 --dtype bf16
+python bench.py > gpurun_out/profiles_out/r03_bench.json 2> gpurun_out/profiles_out/r03_bench.err
+tail -c 300 gpurun_out/profiles_out/r03_bench.err
+ls -la gpurun_out/profiles_out/ | tail -12
