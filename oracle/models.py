@@ -489,3 +489,62 @@ def pose_gan_losses(P, pose_rcv, z, img_H=128, img_W=64):
     D_z = fc_discriminator(P, torch.cat([real, fake], 0), 32, name="Pose_emb_")
     d_real, d_fake = torch.split(D_z, D_z.shape[0] // 2)
     return -d_fake.mean(), d_fake.mean() - d_real.mean(), fake, real
+
+
+# ---- tester.py pipelines (forward only), layer for layer ----------------------------------------------------------------------
+def tester_pipeline(P, kind, batch, rcv=None, pose_target=None, z_app=None, z_fg=None, z_bg=None, z_pose=None, sample_app=False,
+                    sample_fg=False, sample_bg=False, sample_pose=False, one_app_per_batch=False, hidden_num=128, z_num=64,
+                    repeat_num=5, img_H=128, img_W=64):
+    """The five pipelines of tester.py next to `DPIG_FourNetsFgBg_testOnly`:
+      'four_nets'          :75-135    BodyROI encoder, PoseAE z=100, `Gaussian_FC`
+      'sample_factor'      :479-571   Fg/Bg encoder, per-factor sampling, unsampled factors held at the first sample
+      'condition'          :657-686   Fg/Bg encoder + generator on a given pose map + critic
+      'condition_256'      :815-834   BodyROIVis(repeat+1, 64 x 64 crops) + generator(repeat-1), no critic
+      'sample_factor_256'  :985-1053  the same with the pose auto-encoder and `Gaussian_FC`
+    Returns dict(embs, pose_map, G, [G_pose_rcv], [score])."""
+    B = batch["x"].shape[0]
+    first = lambda t: t[:1].expand(B, *t.shape[1:])  # noqa: E731
+    out = {}
+    pose = kind in ("four_nets", "sample_factor", "sample_factor_256")
+    if pose:
+        norm = normalise_pose_rcv(rcv, 18, img_H, img_W)
+        pz = 100 if kind == "four_nets" else 32
+        pose_embs = pose_encoder_fc_res(P, norm, z_num=pz)
+        gaussian_fc_res(P, z_pose, pz, 4, 512, scope="PoseGaussian/G_FC")                      # in the graph, unused
+        coord, vis, _ = pose_decoder_fc_res(P, pose_embs)
+        if sample_pose:
+            G_pose_rcv = torch.cat([coord.reshape(B, 18, 2), vis.unsqueeze(-1)], -1)
+        else:
+            G_pose_rcv = norm.reshape(B, 18, 3) if kind == "four_nets" else first(norm.reshape(B, 18, 3))
+        out["G_pose_rcv"] = G_pose_rcv
+        out["reconstruct_loss"] = ((norm.reshape(B, 18, 3) - G_pose_rcv) ** 2).mean()
+        pose_map = O.tf_poseInflate(O.coord2channel_simple_rcv(G_pose_rcv.reshape(B, -1), 18, True, img_H, img_W), 18, 4, img_H, img_W)
+    else:
+        pose_map = pose_target
+    if kind in ("sample_factor", "condition"):
+        embs = encoder_fgbg(P, batch["x"], batch["mask_r6"], batch["part_bbox"], batch["part_vis"], 7, 32, repeat_num, hidden_num)
+    elif kind == "four_nets":
+        embs = encoder_body_roi(P, batch["x"], batch["part_bbox"], 7, 32, repeat_num, hidden_num, 48)
+    else:
+        embs = encoder_roi(P, batch["x"], batch["part_bbox"], batch["part_vis"], 7, 32, repeat_num + 1, hidden_num, 64)
+    if kind == "four_nets":
+        rnd = gaussian_fc_res(P, z_app, embs.shape[-1], 4, 512, scope="Gaussian_FC/G_FC")
+        if one_app_per_batch:
+            rnd = first(rnd)
+        embs = rnd if sample_app else embs
+    elif kind == "sample_factor":
+        fg_e, bg_e = embs[:, :224], embs[:, 224:]
+        app_fg = gaussian_fc_res(P, z_fg, 224, 4, 512, scope="Gaussian_FC_Fg/G_FC")
+        app_bg = gaussian_fc_res(P, z_bg, bg_e.shape[-1], 4, 256, scope="Gaussian_FC_Bg/G_FC")
+        embs = torch.cat([app_fg if sample_fg else first(fg_e), app_bg if sample_bg else first(bg_e)], -1)
+    elif kind == "sample_factor_256":
+        rnd = gaussian_fc_res(P, z_app, embs.shape[-1], 4, 512, scope="Gaussian_FC/G_FC")
+        embs = rnd if sample_app else first(embs)
+    out["embs"] = embs
+    embs_rep = embs.reshape(B, 1, 1, -1).expand(B, img_H, img_W, embs.shape[1])
+    gen_rep = repeat_num - 1 if kind.endswith("256") else repeat_num
+    G, _ = generator_uae(P, embs_rep, pose_map, 3, z_num, gen_rep, hidden_num)
+    out["G"], out["pose_map"] = G, pose_map
+    if not kind.endswith("256"):
+        out["score"] = dcgan_discriminator(P, G, "dcgan").reshape(B, -1).mean(1)
+    return out

@@ -731,6 +731,66 @@ def test_inference_harness_against_oracle(dev):
     lib.delete_all_params(); slim.reset_scopes()
 
 
+@pytest.mark.parametrize("kind,flags", [
+    ("four_nets", dict(sample_app=True, sample_pose=True, one_app_per_batch=True)),
+    ("four_nets", dict()),
+    ("sample_factor", dict(sample_fg=True, sample_bg=False, sample_pose=True)),
+    ("sample_factor", dict(sample_fg=False, sample_bg=True, sample_pose=False)),
+    ("condition", dict()),
+    ("condition_256", dict()),
+    ("sample_factor_256", dict(sample_app=True, sample_pose=True)),
+    ("sample_factor_256", dict()),
+])
+def test_remaining_tester_pipelines_against_oracle(dev, kind, flags):
+    """The other five pipelines of tester.py (:4-253, 419-613, 616-772, 775-914, 917-1138) against the oracle's layer-for-layer
+    graph of the same chain: embedding fed to the generator, decoded / held keypoints, rasterised pose map (bit-exact), the
+    generated image and the critic score; fixed noise for the Gaussian mappers."""
+    import dpig_amd.tflib as lib
+    from dpig_amd import slim, synthetic, tester
+    from dpig_amd.trainer import Config
+    from oracle import models as OM
+    lib.delete_all_params(); slim.reset_scopes()
+    is256 = kind.endswith("256")
+    Hh, W, rep = (256, 256, 6) if is256 else (128, 64, 5)
+    B, HID, ZN = 2, 8 if is256 else 16, 8
+    batch_np = synthetic.make_batch(B, img_H=Hh, img_W=W, seed=47)
+    ob = OM.batch_to_torch(batch_np)
+    g = torch.Generator().manual_seed(12)
+    rcv = torch.stack([torch.rand(B, 18, generator=g, dtype=torch.float64) * (Hh - 1), torch.rand(B, 18, generator=g, dtype=torch.float64) * (W - 1),
+                       (torch.rand(B, 18, generator=g, dtype=torch.float64) < 0.8).double()], -1).reshape(B, 54)
+    rcv = rcv.float().double()
+    n_app = 224 if kind in ("four_nets", "sample_factor_256") else 224
+    z = dict(z_app=torch.randn(B, n_app, generator=g, dtype=torch.float64) * 0.2, z_fg=torch.randn(B, 224, generator=g, dtype=torch.float64) * 0.2,
+             z_bg=torch.randn(B, 128, generator=g, dtype=torch.float64) * 0.2,
+             z_pose=torch.randn(B, 100 if kind == "four_nets" else 32, generator=g, dtype=torch.float64) * 0.2)
+    P = OM.ParamStore(seed=19)
+    with torch.no_grad():
+        ref = OM.tester_pipeline(P, kind, ob, rcv=rcv, pose_target=ob["pose"], hidden_num=HID, z_num=ZN, repeat_num=rep, img_H=Hh,
+                                 img_W=W, **z, **flags)
+    _load(P, dev)
+    cls = {"four_nets": tester.DPIG_FourNets_testOnly, "sample_factor": tester.DPIG_FourNetsFgBg_testOnlySampleFactor,
+           "condition": tester.DPIG_FourNetsFgBg_testOnlyCondition, "condition_256": tester.DPIG_ThreeNetsApp_testOnlyCondition_256,
+           "sample_factor_256": tester.DPIG_ThreeNetsApp_testOnlySampleFactor_256}[kind]
+    te = cls(Config(batch_size=B, conv_hidden_num=HID, z_num=ZN, img_H=Hh, img_W=W), dev, **flags)
+    gb = synthetic.to_device(batch_np, dev)
+    out = te.run(gb, pose_rcv=rcv.float().to(dev), pose_target=gb["pose"], **{k: v.float().to(dev) for k, v in z.items()})
+    assert set(lib._params.keys()) == set(P.p.keys()), (sorted(set(lib._params) ^ set(P.p))[:6])
+    assert _rel(out["embs"], ref["embs"]) < 1e-4
+    if "G_pose_rcv" in ref:
+        assert _rel(out["G_pose_rcv"][..., :2], ref["G_pose_rcv"][..., :2]) < 1e-4
+        assert torch.equal(out["G_pose_rcv"][..., 2].cpu().double(), ref["G_pose_rcv"][..., 2])
+        assert abs(float(out["reconstruct_loss"]) - float(ref["reconstruct_loss"])) <= 1e-5 * max(1.0, float(ref["reconstruct_loss"]))
+    assert torch.equal(out["pose_map"].cpu().double(), ref["pose_map"])
+    assert (out["G"].double().cpu() - torch.clamp((ref["G"] + 1) * 127.5, 0, 255)).abs().max().item() < 1e-3 * 255
+    if "score" in ref:
+        assert _rel(out["G_dis_score"], ref["score"]) < 1e-3
+    else:
+        assert "G_dis_score" not in out
+    out2 = te.run(gb, pose_rcv=rcv.float().to(dev), pose_target=gb["pose"], **{k: v.float().to(dev) for k, v in z.items()})
+    assert torch.equal(out2["G"], out["G"])               # second call reuses the variables
+    lib.delete_all_params(); slim.reset_scopes()
+
+
 # ---- DeepFashion 256 x 256 stage II (run_DF_train.sh:39-77; trainer_256.py:266-700) and BASELINE configs[4] --------------
 def _s2gold():
     import importlib.util
