@@ -164,6 +164,10 @@ def main():
                          "rasterised on the device (what tfrecord.batch_from_examples feeds); 'keypoints-serial' = the same upload on "
                          "the compute stream, no second queue; 'packed' / 'keypoints-packed' = prefetch with the batch packed "
                          "into one pinned buffer and moved by one copy")
+    ap.add_argument("--pose", default="keypoints", choices=["keypoints", "map"],
+                    help="keypoints (default): the resident batch holds pose_rcv, the [B,18,3] keypoints of the records, and the "
+                         "generator's first conv consumes them directly (the reference rasterises the target map inside the graph, "
+                         "trainer.py:556-560); map: the batch holds the rasterised [B,H,W,18] map (rounds 1-2)")
     ap.add_argument("--workload", default="market128", choices=sorted(WORKLOADS),
                     help="market128 = the BASELINE metric (configs[1]); the others are information lines for DESIGN.md")
     args = ap.parse_args()
@@ -208,6 +212,8 @@ def main():
     tr = getattr(importlib.import_module("dpig_amd." + wl_mod), wl_cls)(cfg, dev)
     batch_g = synthetic.to_device(synthetic.make_batch(B, img_H=cfg.img_H, img_W=cfg.img_W, seed=100 + 2 * rank), dev)
     batch_d = synthetic.to_device(synthetic.make_batch(B, img_H=cfg.img_H, img_W=cfg.img_W, seed=101 + 2 * rank), dev)
+    if args.pose == "keypoints" and not args.host_input and args.workload != "market128-stage2":
+        batch_g, batch_d = synthetic.keypoints_only(batch_g), synthetic.keypoints_only(batch_d)
     tr.init_net(batch_g)
     tr.step = 1                               # steady state: g_optim is only skipped at step 0
     if not args.no_graph:
@@ -264,6 +270,8 @@ def main():
         # every critic iteration of a step dequeues its own batch (trainer.py:340-345, 553-555): 5 distinct resident batches
         critic_batches = [batch_d] + [synthetic.to_device(synthetic.make_batch(B, img_H=cfg.img_H, img_W=cfg.img_W,
                                                                              seed=300 + 10 * rank + i), dev) for i in range(4)]
+        if args.pose == "keypoints":
+            critic_batches = [synthetic.keypoints_only(b) for b in critic_batches]
         step_fn = lambda: tr.train_step(get_g(), critic_batches)
     else:
         step_fn = lambda: tr.train_step(get_g(), get_d())
@@ -375,6 +383,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
 
+    POSE_DESC = ("pose input: keypoints (pose_rcv as the records hold them; the generator's first conv consumes them, no [B,H,W,18] map)"
+                 if "pose" not in batch_g else "pose input: rasterised target map resident in HBM")
     if rank == 0:
         line = {
             "metric": "training images/sec (G+D step) Market-1501 128x64 bs=16" if headline else
@@ -383,7 +393,7 @@ def main():
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "%s, bs=%d per GPU, %s" % (wl_desc, B, {"f32": "fp32", "bf16": "bf16 storage (activations, their gradients, filter shadows) + bf16 matrix pipe; fp32 accumulation, master weights, gradients and optimizer", "bf16c": "bf16 matrix pipe on fp32 tensors", "bf16x3": "fp32 tensors; conv products as three bf16 MFMAs on two-term bf16 splits of the fp32 operands (<= 2e-5 max|ref| per kernel, the exact path's test bar); everything else fp32"}[args.dtype]),
+            "config": {"workload": "%s, bs=%d per GPU, %s; %s" % (wl_desc, B, {"f32": "fp32", "bf16": "bf16 storage (activations, their gradients, filter shadows) + bf16 matrix pipe; fp32 accumulation, master weights, gradients and optimizer", "bf16c": "bf16 matrix pipe on fp32 tensors", "bf16x3": "fp32 tensors; conv products as three bf16 MFMAs on two-term bf16 splits of the fp32 operands (<= 2e-5 max|ref| per kernel, the exact path's test bar); everything else fp32"}[args.dtype], POSE_DESC),
                        "global_batch": world * B, "parallelism": "dp%d" % world},
             "achieved_alg_tflops": round(ALG_GFLOP_PER_IMG * value / 1e3, 2) if headline else None,
             "losses": {k: float(v) for k, v in out.items() if hasattr(v, "numel") and v.numel() == 1},

@@ -140,6 +140,8 @@ SYMBOLS = {
     "dpig_axpby3d": (_i, [_vp, _i64, _i64, _vp, _i64, _i64, _i, _i, _i, _f, _vp]),
     "dpig_transpose12": (_i, [_vp, _vp, _i, _i, _i, _i, _vp]),
     "dpig_act_bwd_pool2x": (_i, [_vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _i, _f, _i, _vp]),
+    "dpig_pose_stem_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _f, _vp, _i, _vp]),
+    "dpig_pose_stem_wgrad": (_i, [_vp, _i, _i, _i, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     "dpig_sce_mean": (_i, [_vp, _i, _f, _vp, _vp, _f, _vp]),
     "dpig_logit_mean": (_i, [_vp, _i, _i, _f, _vp, _vp, _f, _vp]),
     "dpig_l1_workspace_bytes": (_sz, [_i64]),

@@ -384,7 +384,77 @@ class _TiledEmbConvFn(torch.autograd.Function):
         return d_emb, None, dw, db
 
 
+class PoseKeypoints(object):
+    """Stand-in for the [B,H,W,P] pose target map when the batch carries the keypoints it is built from (trainer.py:556-560:
+    `coord2channel_simple_rcv(pose_rcv) -> tf_poseInflate`): the generator's first conv consumes the keypoints directly
+    (`_TiledEmbKeypointConvFn`), nothing else on the hot path reads the map.  `dense()` rasterises it on demand."""
+
+    def __init__(self, rcv, img_H, img_W, keypoint_num=18, is_normalized=False):
+        B = rcv.shape[0]
+        self.rcv = rcv.reshape(B, keypoint_num, 3)
+        self.shape = (B, img_H, img_W, keypoint_num)
+        self.is_normalized = is_normalized
+        self.device = rcv.device
+
+    def dim(self):
+        return 4
+
+    def dense(self):
+        from . import utils
+        B, Hh, W, K = self.shape
+        return utils.pose_target_from_rcv(self.rcv.reshape(B, -1).contiguous(), K, self.is_normalized, Hh, W)
+
+
+class _TiledEmbKeypointConvFn(torch.autograd.Function):
+    """`_TiledEmbConvFn` with the pose channels given as keypoints: their -1 background is one more border-class constant, their
+    discs a sparse sum (csrc/dpig_glue.hip::pose_stem_*): y = relu(conv3x3(concat([tile(emb), pose_map]), w) + b) without the map and
+    without the dense 18-channel conv; the filter gradient of the pose rows likewise (class sums of dz + a gather over the discs)."""
+
+    @staticmethod
+    def forward(ctx, emb, rcv, w, b, Hh, W, normalized):
+        E, K = emb.shape[1], w.shape[3]
+        P = w.shape[2] - E
+        wmat = H.emb_class_weights_fwd(w, E + P)                                       # [E + P, 9K]
+        e9 = H.linear_fwd(H.to_f32(emb), wmat[:E])                                     # [B, 9K]
+        cpos = H.colsum(wmat[E:])                                                      # [9K]: what the -1 background removes
+        y = H.pose_stem_fwd(rcv, normalized, e9.view(-1, 9, K), cpos.view(9, K), b, w, E, Hh, W, ACT_RELU, 0.2,
+                            bf16_out=H.get_compute() == "bf16" and K % 8 == 0)
+        ctx.save_for_backward(emb, rcv, w, wmat, y)
+        ctx.b_ref = b
+        ctx.cfg = (P, normalized)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        emb, rcv, w, wmat, y = ctx.saved_tensors
+        P, normalized = ctx.cfg
+        E, K = emb.shape[1], w.shape[3]
+        B = emb.shape[0]
+        dz = H.act_bwd(dy, y, ACT_RELU)
+        z9 = H.border_class_sum(dz)                                                    # [B, 9, K] fp32
+        db = None
+        if ctx.needs_input_grad[3]:
+            db = _sink(ctx.b_ref, lambda o, beta: H.colsum(z9.view(B * 9, K), out=o, beta=beta))
+        d_emb = H.linear_dgrad(z9.view(B, 9 * K), wmat[:E]) if ctx.needs_input_grad[0] else None
+        dw = None
+        if ctx.needs_input_grad[2]:
+            dwp = H.pose_stem_wgrad(rcv, normalized, z9, dz, P)                        # [9, P, K]
+            dwc = H.linear_wgrad(H.to_f32(emb), z9.view(B, 9 * K))                     # [E, 9K]
+
+            def put(out, beta):
+                if out is None:
+                    out = torch.empty((3, 3, E + P, K), dtype=torch.float32, device=dwc.device)
+                    beta = 0.0
+                H.emb_class_weights_bwd(dwc, E, out, beta)
+                H.axpby3d(dwp, out.view(9, E + P, K)[:, E:, :], beta)
+                return out
+            dw = _sink(w, put)
+        return d_emb, None, dw, db, None, None, None
+
+
 def tiled_emb_conv(emb, pose, w, b):
+    if isinstance(pose, PoseKeypoints):
+        return _TiledEmbKeypointConvFn.apply(emb, pose.rcv, w, b, pose.shape[1], pose.shape[2], pose.is_normalized)
     return _TiledEmbConvFn.apply(emb, pose, w, b)
 
 

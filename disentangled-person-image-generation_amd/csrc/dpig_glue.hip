@@ -194,6 +194,149 @@ __global__ __launch_bounds__(256) void emb_class_bwd_kernel(const float* __restr
     }
 }
 
+// ---- the generator's first conv fed with KEYPOINTS instead of the rasterised pose map (trainer.py:556-560 builds the map in the
+// graph from pose_rcv: coord2channel_simple_rcv + tf_poseInflate, utils.py:237-318).  A pose channel is -1 everywhere except a
+// radius-4 disc of 2 * min(v * hits, 1) - 1 around its keypoint, so its contribution to the SAME 3x3 conv is
+//     - sum_{valid taps} w[tap][k]            (a border-class constant like the tiled embedding's)
+//     + sum_{taps whose source pixel lies in the disc} 2 * min(v * hits, 1) * w[tap][k]      (non-zero within 5 pixels of the keypoint)
+// y = act(e9[b][class] + bias - cpos[class] + the sparse sum): the [B,H,W,18] tensor is never formed, the dense 18-channel conv
+// (5.4 GFLOP at Market, 123 us on the vector ALUs) becomes one write of y.  Same disc rule as pose_from_rcv_kernel<1>.
+__device__ __forceinline__ int stem_disc_half(int a) {
+    const int aa = a < 0 ? -a : a;
+    return aa == 0 ? 4 : (aa <= 2 ? 3 : (aa == 3 ? 2 : (aa == 4 ? 0 : -1)));
+}
+__device__ __forceinline__ void stem_keypoint(const float* __restrict__ rcv, int H, int W, int normalized, int* r, int* c, float* v) {
+    float R = rcv[0], C = rcv[1];
+    if (normalized) {
+        R = fminf(fmaxf((R + 1.f) / 2.0f * (float)H, 0.f), (float)(H - 1));
+        C = fminf(fmaxf((C + 1.f) / 2.0f * (float)W, 0.f), (float)(W - 1));
+    }
+    *r = (int)R; *c = (int)C; *v = rcv[2];
+}
+// amplitude above the -1 background of channel k at pixel (y, x): 0 outside the disc
+__device__ __forceinline__ float stem_amp(int r, int c, float v, int H, int W, int y, int x) {
+    if ((unsigned)r >= (unsigned)H || (unsigned)c >= (unsigned)W) return 0.f;
+    const int a = r - y, bb = c - x;
+    const int hw = stem_disc_half(a);
+    if (hw < 0 || bb < -hw || bb > hw) return 0.f;
+    const float hits = (a == 0 && bb == 0) ? 2.f : 1.f;
+    return 2.f * fminf(v * hits, 1.f);
+}
+constexpr int STEM_MAXK = 32;       // keypoints per image held in LDS
+// block = one image row; thread = (pixel, 4 output channels).  w: the whole filter [9][C][K] fp32, pose rows at channel E + k
+template <typename T>
+__global__ __launch_bounds__(256) void pose_stem_fwd_kernel(const float* __restrict__ rcv, int P, int normalized,
+                                                            const float* __restrict__ e9, const float* __restrict__ cpos,
+                                                            const float* __restrict__ bias, const float* __restrict__ w, int C, int E,
+                                                            int H, int W, int K, int act, float alpha, T* __restrict__ y) {
+    __shared__ int s_r[STEM_MAXK], s_c[STEM_MAXK];
+    __shared__ float s_v[STEM_MAXK];
+    __shared__ int s_near[STEM_MAXK], s_nn;
+    const int b = blockIdx.x / H, yy = blockIdx.x - b * H;
+    if (threadIdx.x < P) {
+        int r, c; float v;
+        stem_keypoint(rcv + ((long)b * P + threadIdx.x) * 3, H, W, normalized, &r, &c, &v);
+        s_r[threadIdx.x] = r; s_c[threadIdx.x] = c; s_v[threadIdx.x] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {              // keypoints whose disc (+1 for the 3x3 reach) touches this row
+        int n = 0;
+        for (int k = 0; k < P; ++k) {
+            const int dr = s_r[k] - yy;
+            if (s_v[k] != 0.f && dr >= -5 && dr <= 5 && (unsigned)s_r[k] < (unsigned)H && (unsigned)s_c[k] < (unsigned)W) s_near[n++] = k;
+        }
+        s_nn = n;
+    }
+    __syncthreads();
+    const int nn = s_nn;
+    const int KV = K >> 2;
+    const int cy = (yy == 0) ? 0 : ((yy == H - 1) ? 2 : 1);
+    for (int idx = threadIdx.x; idx < W * KV; idx += 256) {
+        const int x = idx / KV, c0 = (idx - x * KV) * 4;
+        const int cx = (x == 0) ? 0 : ((x == W - 1) ? 2 : 1);
+        const int cls = cy * 3 + cx;
+        const float4 e = *reinterpret_cast<const float4*>(e9 + ((long)b * 9 + cls) * K + c0);
+        const float4 cp = *reinterpret_cast<const float4*>(cpos + (long)cls * K + c0);
+        float4 a = make_float4(e.x - cp.x, e.y - cp.y, e.z - cp.z, e.w - cp.w);
+        if (bias) { const float4 bv = *reinterpret_cast<const float4*>(bias + c0); a.x += bv.x; a.y += bv.y; a.z += bv.z; a.w += bv.w; }
+        for (int q = 0; q < nn; ++q) {
+            const int k = s_near[q];
+            const int r = s_r[k], c = s_c[k];
+            if (c - x < -5 || c - x > 5) continue;
+            const float v = s_v[k];
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int sy = yy + ky - 1;
+                if ((unsigned)sy >= (unsigned)H) continue;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int sx = x + kx - 1;
+                    if ((unsigned)sx >= (unsigned)W) continue;
+                    const float amp = stem_amp(r, c, v, H, W, sy, sx);
+                    if (amp == 0.f) continue;
+                    const float4 wv = *reinterpret_cast<const float4*>(w + ((long)(ky * 3 + kx) * C + E + k) * K + c0);
+                    a.x += amp * wv.x; a.y += amp * wv.y; a.z += amp * wv.z; a.w += amp * wv.w;
+                }
+            }
+        }
+        a.x = act_apply(a.x, act, alpha); a.y = act_apply(a.y, act, alpha); a.z = act_apply(a.z, act, alpha); a.w = act_apply(a.w, act, alpha);
+        T* o = y + (((long)b * H + yy) * W + x) * K + c0;
+        if constexpr (sizeof(T) == 4) *reinterpret_cast<float4*>(o) = a;
+        else *reinterpret_cast<uint2*>(o) = make_uint2((unsigned)glue_f2b(a.x) | ((unsigned)glue_f2b(a.y) << 16), (unsigned)glue_f2b(a.z) | ((unsigned)glue_f2b(a.w) << 16));
+    }
+}
+// filter gradient of the pose rows: dwp[tap][k][:] = - sum_b sum_{classes that contain tap} z9[b][class][:]
+//                                                  + sum_b sum_{q in disc_k(b)} amp(q) * dz[b][q - tap + 1][:]
+// block = (k, tap), 1024 threads; thread = (term slot, 4 output channels): the B * 9 class terms and the B * 81 window positions are
+// dealt to the 1024 / (K/4) slots (the gather is a chain of dependent loads: it wants them spread), slots are folded through LDS in slot order.
+// z9 = border-class sums of dz.  Fixed summation order.
+template <typename T>
+__global__ __launch_bounds__(1024) void pose_stem_wgrad_kernel(const float* __restrict__ rcv, int B, int P, int normalized,
+                                                              const float* __restrict__ z9, const T* __restrict__ dz, int H, int W,
+                                                              int K, float* __restrict__ dwp) {
+    __shared__ float red[1024 * 4];
+    const int k = blockIdx.x, tap = blockIdx.y, ky = tap / 3, kx = tap - ky * 3;
+    const int KV = K >> 2;                                  // <= 256, divides 1024 (checked by the host)
+    const int cv = threadIdx.x % KV, slot = threadIdx.x / KV, nslot = 1024 / KV;
+    const int c0 = cv * 4;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int i = slot; i < B * 9; i += nslot) {
+        const int b = i / 9, cls = i - b * 9, cy = cls / 3, cx = cls - cy * 3;
+        // classes (cy, cx) whose valid taps contain (ky, kx): cy = 0 lacks ky = 0, cy = 2 lacks ky = 2 (same for columns)
+        if ((cy == 0 && ky == 0) || (cy == 2 && ky == 2) || (cx == 0 && kx == 0) || (cx == 2 && kx == 2)) continue;
+        const float4 z = *reinterpret_cast<const float4*>(z9 + ((long)b * 9 + cls) * K + c0);
+        acc.x -= z.x; acc.y -= z.y; acc.z -= z.z; acc.w -= z.w;
+    }
+    for (int i = slot; i < B * 81; i += nslot) {
+        const int b = i / 81, w81 = i - b * 81, a = w81 / 9 - 4, bb = w81 - (w81 / 9) * 9 - 4;
+        const int hw = stem_disc_half(a);
+        if (bb < -hw || bb > hw) continue;
+        int r, c; float v;
+        stem_keypoint(rcv + ((long)b * P + k) * 3, H, W, normalized, &r, &c, &v);
+        if (v == 0.f || (unsigned)r >= (unsigned)H || (unsigned)c >= (unsigned)W) continue;
+        const int sy = r - a, sx = c - bb;                  // source pixel in the disc
+        const int py = sy - ky + 1, px = sx - kx + 1;       // the output pixel that reads it through tap (ky, kx)
+        if ((unsigned)sy >= (unsigned)H || (unsigned)py >= (unsigned)H || (unsigned)sx >= (unsigned)W || (unsigned)px >= (unsigned)W) continue;
+        const float amp = 2.f * fminf(v * ((a == 0 && bb == 0) ? 2.f : 1.f), 1.f);
+        const T* g = dz + (((long)b * H + py) * W + px) * K + c0;
+        float g0, g1, g2, g3;
+        if constexpr (sizeof(T) == 4) { const float4 t = *reinterpret_cast<const float4*>(g); g0 = t.x; g1 = t.y; g2 = t.z; g3 = t.w; }
+        else { const uint2 t = *reinterpret_cast<const uint2*>(g); g0 = __uint_as_float(t.x << 16); g1 = __uint_as_float(t.x & 0xffff0000u);
+               g2 = __uint_as_float(t.y << 16); g3 = __uint_as_float(t.y & 0xffff0000u); }
+        acc.x += amp * g0; acc.y += amp * g1; acc.z += amp * g2; acc.w += amp * g3;
+    }
+    *reinterpret_cast<float4*>(&red[threadIdx.x * 4]) = acc;
+    __syncthreads();
+    if (slot == 0) {
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < nslot; ++q) {
+            const float4 t = *reinterpret_cast<const float4*>(&red[(q * KV + cv) * 4]);
+            s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        }
+        *reinterpret_cast<float4*>(dwp + ((long)tap * P + k) * K + c0) = s;
+    }
+}
+
 // ---- gradient of act(conv1x1(upsample2x(x))) w.r.t. the conv's LOW-resolution pre-image: the nearest-neighbour upsample commutes
 // with a 1x1 conv (models.py:569-570 computed at low resolution), so the backward pass needs sum_{2x2} dy * act'(y) per low-res
 // pixel -- one pass over dy / y instead of act_bwd + two 4-tap gathers over the high-resolution gradient.  dz [N,H,W,C] (dense),
@@ -360,6 +503,29 @@ extern "C" int dpig_emb_class_weights_bwd(const float* dwc, int E, int C, int K,
     const long n = (long)E * K;
     hipLaunchKernelGGL(emb_class_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), dwc, E, C, K, dw, beta);
     return check_launch("emb_class_weights_bwd");
+}
+
+extern "C" int dpig_pose_stem_fwd(const float* rcv, int B, int P, int normalized, const float* e9, const float* cpos, const float* bias,
+                                  const float* w, int C, int E, int H, int W, int K, int act, float alpha, void* y, int is_bf16, void* stream) {
+    if (!rcv || !e9 || !cpos || !w || !y || C != E + P || E < 0 || B <= 0 || P <= 0 || P > STEM_MAXK || H < 2 || W < 2 || K <= 0 || K % 4)
+        return fail(DPIG_EINVAL, "pose_stem_fwd: bad arguments (P <= %d, K %% 4 == 0)", STEM_MAXK);
+    if (!aligned16(e9) || !aligned16(cpos) || !aligned16(w) || !aligned16(y) || (bias && !aligned16(bias)))
+        return fail(DPIG_EINVAL, "pose_stem_fwd: operands must be 16-byte aligned");
+    if ((long)B * H > 0x7fffffffL) return fail(DPIG_EINVAL, "pose_stem_fwd: too many rows");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (is_bf16) hipLaunchKernelGGL((pose_stem_fwd_kernel<glue_bf16>), dim3(B * H), dim3(256), 0, st, rcv, P, normalized, e9, cpos, bias, w, C, E, H, W, K, act, alpha, (glue_bf16*)y);
+    else hipLaunchKernelGGL((pose_stem_fwd_kernel<float>), dim3(B * H), dim3(256), 0, st, rcv, P, normalized, e9, cpos, bias, w, C, E, H, W, K, act, alpha, (float*)y);
+    return check_launch("pose_stem_fwd");
+}
+extern "C" int dpig_pose_stem_wgrad(const float* rcv, int B, int P, int normalized, const float* z9, const void* dz, int H, int W, int K,
+                                    float* dwp, int is_bf16, void* stream) {
+    if (!rcv || !z9 || !dz || !dwp || B <= 0 || P <= 0 || H < 2 || W < 2 || K <= 0 || K % 4 || K > 1024 || 256 % (K / 4))
+        return fail(DPIG_EINVAL, "pose_stem_wgrad: bad arguments (K / 4 must divide 256)");
+    if (!aligned16(z9) || !aligned16(dz) || !aligned16(dwp)) return fail(DPIG_EINVAL, "pose_stem_wgrad: operands must be 16-byte aligned");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (is_bf16) hipLaunchKernelGGL((pose_stem_wgrad_kernel<glue_bf16>), dim3(P, 9), dim3(1024), 0, st, rcv, B, P, normalized, z9, (const glue_bf16*)dz, H, W, K, dwp);
+    else hipLaunchKernelGGL((pose_stem_wgrad_kernel<float>), dim3(P, 9), dim3(1024), 0, st, rcv, B, P, normalized, z9, (const float*)dz, H, W, K, dwp);
+    return check_launch("pose_stem_wgrad");
 }
 
 extern "C" int dpig_act_bwd_pool2x(const void* dy, int lddy, const void* y, int ldy, void* dz, int N, int H, int W, int C, int act,

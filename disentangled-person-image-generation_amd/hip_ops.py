@@ -776,6 +776,32 @@ def act_fwd(x, act, alpha=0.2):
     return y
 
 
+def pose_stem_fwd(rcv, normalized, e9, cpos, bias, w, E, H, W, act=ACT_RELU, alpha=0.2, bf16_out=False):
+    """y [B,H,W,K] = act(e9[b][class] - cpos[class] + bias + sparse disc terms): the generator's first conv fed with keypoints
+    (dpig_pose_stem_fwd).  rcv [B,P,3] fp32, e9 [B,9,K], cpos [9,K], w [3,3,E+P,K] fp32 (the whole filter)."""
+    _require_gpu(e9)
+    B, P = rcv.shape[0], rcv.shape[1]
+    K = e9.shape[-1]
+    rcv = rcv.contiguous().float()
+    y = torch.empty((B, H, W, K), dtype=BF16 if bf16_out else F32, device=e9.device)
+    check(lib().dpig_pose_stem_fwd(ptr(rcv), B, P, int(bool(normalized)), ptr(e9.contiguous()), ptr(cpos.contiguous()),
+                                   ptr(bias.contiguous() if bias is not None else None), ptr(w.contiguous()), w.shape[2], E, H, W, K, act,
+                                   float(alpha), ptr(y), int(bf16_out), stream_ptr()), "pose_stem_fwd")
+    return y
+
+
+def pose_stem_wgrad(rcv, normalized, z9, dz, P):
+    """dwp [9,P,K]: gradient of the pose rows of the stem filter (dpig_pose_stem_wgrad); z9 [B,9,K] fp32, dz [B,H,W,K] fp32 / bf16."""
+    _require_dev(dz)
+    B, H, W, K = dz.shape
+    dz = dz.contiguous()
+    rcv = rcv.contiguous().float()
+    dwp = torch.empty((9, P, K), dtype=F32, device=dz.device)
+    check(lib().dpig_pose_stem_wgrad(ptr(rcv), B, P, int(bool(normalized)), ptr(z9.contiguous()), ptr(dz), H, W, K, ptr(dwp),
+                                     int(dz.dtype == BF16), stream_ptr()), "pose_stem_wgrad")
+    return dwp
+
+
 def act_bwd_pool2x(dy, y, act, alpha=0.2):
     """sum over 2x2 blocks of dy * act'(y): [N,2H,2W,C] -> [N,H,W,C], the gradient of act(conv1x1(upsample2x(.))) on the
     low-resolution grid the conv runs on (dpig_act_bwd_pool2x).  fp32 or bf16 pairs."""

@@ -249,6 +249,8 @@ def GeneratorCNN_ID_UAEAfterResidual(x, pose, input_channel, z_num, repeat_num, 
             src = getattr(x, "_dpig_src", None)       # the [B,E] tensor the caller expanded (saves autograd's zero-fill + sum over [B,H,W,E])
             x = slim.conv2d_tiled_embedding(src if src is not None else x[:, 0, 0, :], pose, hidden_num)
         else:
+            if isinstance(pose, A.PoseKeypoints):      # only the collapsed first conv consumes keypoints: rasterise for the dense path
+                pose = pose.dense()
             if pose is not None:
                 x = torch.cat([x, pose], dim=3)
             x = slim.conv2d(x, hidden_num, 3, 1, activation_fn=activation_fn, data_format=data_format)

@@ -8,6 +8,7 @@ batch can feed the HIP path, the CPU oracle and the golden-vector generator.
   mask_r6   [B,H,W,1]  {0,1}: dilated union of the keypoint discs (~35 % ones)
   part_bbox [B,7,4]    int32 pixel (y1,x1,y2,x2), min side 8, or the invisible sentinel [0,0,1,1]
   part_vis  [B,7]      {0,1}, Bernoulli(0.9) (0 <=> sentinel box), convert_market.py:609-630
+  pose_rcv  [B,54]     the keypoints `pose` was built from: pixel (row, col, visibility) x 18 (a dropped keypoint is (0, 0, 0))
 """
 import numpy as np
 
@@ -34,6 +35,7 @@ def make_batch(batch_size, img_H=128, img_W=64, seed=1234, keypoint_num=18, part
     B, H, W = batch_size, img_H, img_W
     x = rng.uniform(-1.0, 1.0, size=(B, H, W, 3)).astype(np.float32)
     pose = -np.ones((B, H, W, keypoint_num), dtype=np.float32)
+    pose_rcv = np.zeros((B, keypoint_num, 3), dtype=np.float32)      # (row, col, visibility): what the records hold (trainer.py:556)
     mask = np.zeros((B, H, W, 1), dtype=np.float32)
     for b in range(B):
         # a crude "person": keypoints scattered around a vertical axis
@@ -43,6 +45,7 @@ def make_batch(batch_size, img_H=128, img_W=64, seed=1234, keypoint_num=18, part
                 continue
             r = int(np.clip(rng.uniform(0.08, 0.92) * H, 0, H - 1))
             c = int(np.clip(cx + rng.normal(0, 0.12) * W, 0, W - 1))
+            pose_rcv[b, k] = (r, c, 1.0)
             for dr, dc in _STENCIL:
                 rr, cc = r + dr, c + dc
                 if 0 <= rr < H and 0 <= cc < W:
@@ -62,7 +65,13 @@ def make_batch(batch_size, img_H=128, img_W=64, seed=1234, keypoint_num=18, part
             y1 = int(rng.integers(0, H - 1 - h + 1))
             x1 = int(rng.integers(0, W - 1 - w + 1))
             part_bbox[b, p] = [y1, x1, min(y1 + h, H - 1), min(x1 + w, W - 1)]
-    return {"x": x, "pose": pose, "mask_r6": mask, "part_bbox": part_bbox, "part_vis": part_vis}
+    return {"x": x, "pose": pose, "mask_r6": mask, "part_bbox": part_bbox, "part_vis": part_vis,
+            "pose_rcv": pose_rcv.reshape(B, keypoint_num * 3)}
+
+
+def keypoints_only(batch):
+    """The batch as the records deliver it: the keypoints `pose_rcv`, not the target map built from them (trainer.py:556-560)."""
+    return {k: v for k, v in batch.items() if k != "pose"}
 
 
 def make_batch_from_keypoints(batch_size, img_H=128, img_W=64, seed=1234, drop=0.15):

@@ -279,6 +279,15 @@ class GradAllReduce(object):
             self.dist.broadcast(flat_params, src=0)
 
 
+def pose_input(batch, img_H, img_W, keypoint_num=18):
+    """The generator's pose operand of a batch: the dense target map `batch['pose']` when the batch carries it, else the
+    keypoints `batch['pose_rcv']` ([B, 18*3] pixel (row, col, visibility) as the records hold them) wrapped so that the first
+    conv consumes them directly -- the map the reference builds in the graph (trainer.py:556-560) is never materialised."""
+    if "pose" in batch:
+        return batch["pose"]
+    return A.PoseKeypoints(batch["pose_rcv"], img_H, img_W, keypoint_num, is_normalized=False)
+
+
 def critic_variables(name='', registry=None):
     """The DCGAN critic's variables under `name` in creation order (wgan_gp.py:407-440), keyed WITHOUT the prefix: the operand
     list of the fused penalty call.  None unless every one exists as a dense fp32 tensor (e.g. BatchNorm critics have no
@@ -456,7 +465,7 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         H.set_compute(getattr(self.config, "compute_dtype", "f32"))
         with torch.no_grad():
             embs, enc_var = self.encode(batch)
-            G, g_var = self.generate(embs, batch["pose"])
+            G, g_var = self.generate(embs, pose_input(batch, self.img_H, self.img_W))
             self.discriminate(batch["x"])
         self.built = True
         self.restore_from_config()
@@ -655,7 +664,7 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         self.G_flat.zero_grad()
         self.D_flat.set_requires_grad(False)
         embs, _ = self.encode(batch)
-        G, _ = self.generate(embs, batch["pose"])
+        G, _ = self.generate(embs, pose_input(batch, self.img_H, self.img_W))
         _, D_z_neg = self.disc_pair(batch["x"], G, need_real=False)
         g_loss_only, _ = gan_loss(self.wgan_gp, None, D_z_neg)
         L1Loss = A.l1_mean(G, batch["x"])
@@ -715,7 +724,7 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         self.D_flat.zero_grad()
         with torch.no_grad():
             embs, _ = self.encode(batch)
-            G, _ = self.generate(embs, batch["pose"])
+            G, _ = self.generate(embs, pose_input(batch, self.img_H, self.img_W))
         D_z_pos, D_z_neg = self.disc_pair(batch["x"], G, need_real=True)
         _, d_loss = gan_loss(self.wgan_gp, D_z_pos, D_z_neg, Discriminator=self.discriminate,
                              real_data=batch["x"], fake_data=G, alpha=getattr(self, "gp_alpha", None),   # (tests pin alpha)

@@ -464,6 +464,19 @@ int dpig_vis_concat_bwd(const float* dall, const float* vis, int ldvis, int B, i
  * (cy, cx) of a SAME 3x3 conv sees; _bwd is the transpose into dw[.][.][e < E][.] (dw = beta * dw + ...). */
 int dpig_emb_class_weights_fwd(const float* w, int E, int C, int K, float* wmat, void* stream);
 int dpig_emb_class_weights_bwd(const float* dwc, int E, int C, int K, float* dw, float beta, void* stream);
+/* The generator's first conv (models.py:520-528 on concat(tile(emb), pose)) with the pose given as KEYPOINTS: the reference builds
+ * the [B,H,W,P] pose map inside the graph from pose_rcv (trainer.py:556-560: coord2channel_simple_rcv + tf_poseInflate,
+ * utils.py:237-318); a pose channel is -1 except a radius-4 disc, so its conv contribution is a border-class constant plus a sparse
+ * sum around the keypoint -- y is produced without the map and without the dense P-channel conv.
+ *   rcv [B][P][3] (row, col, visibility; normalised to [-1,1] if `normalized`), e9 [B][9][K] = emb @ class weights (dpig_linear_fwd on
+ *   dpig_emb_class_weights_fwd's first E rows), cpos [9][K] = column sums of that matrix's pose rows, w [3][3][C = E + P][K] = the filter
+ *   (its pose rows are channels E .. E + P - 1);
+ *   y [B,H,W,K] fp32 or bf16 = act(e9[class] - cpos[class] + bias + sparse).
+ * _wgrad: dwp [9][P][K] = gradient of the pose rows from z9 [B][9][K] (dpig_border_class_sum of dz) and dz [B,H,W,K]. */
+int dpig_pose_stem_fwd(const float* rcv, int B, int P, int normalized, const float* e9, const float* cpos, const float* bias,
+                       const float* w, int C, int E, int H, int W, int K, int act, float alpha, void* y, int is_bf16, void* stream);
+int dpig_pose_stem_wgrad(const float* rcv, int B, int P, int normalized, const float* z9, const void* dz, int H, int W, int K, float* dwp,
+                         int is_bf16, void* stream);
 /* dz[N,H,W,C] = sum over the 2x2 block of dy[N,2H,2W,C] * act'(y[N,2H,2W,C]): the gradient of act(conv1x1(upsample2x(x)))
  * (models.py:569-570, utils.py:61-72) pulled back to the low-resolution grid the 1x1 conv is computed on -- TF's ReluGrad +
  * ResizeNearestNeighborGrad in one pass; its result feeds plain 1x1 dgrad / wgrad.  fp32 or bf16 (is_bf16) tensors; y may be

@@ -137,7 +137,8 @@ _dims = st.tuples(st.integers(1, 32), st.sampled_from([3, 4, 6, 8, 12, 16, 24, 3
 @given(_dims)
 def test_workspace_plan_invariants(dims):
     """For any layer shape: the query is total (no crash, 0 for bad descriptors), forcing split_k=1 on the GEMM
-    kernels needs no workspace, and an automatic plan asks for a whole number of partial-sum slabs, at most 64."""
+    kernels needs no workspace, and an automatic plan asks for a whole number of partial-sum slabs, at most 64 (256 = one per CU
+    for problems of at most 8 tiles with a very deep reduction: the fully connected layers)."""
     from dpig_amd import _lib
     N, H, W, C, K, k, s, compute = dims
     h = _lib.lib()
@@ -153,9 +154,9 @@ def test_workspace_plan_invariants(dims):
         assert 0 <= auto < (1 << 40)
         if not thin and auto:
             if which == 1 and s == 2:                              # parity classes: slabs of the class sizes, same bound
-                assert auto <= 64 * slab[1]
+                assert auto <= 256 * slab[1]
             else:
-                assert auto % slab[which] == 0 and auto // slab[which] <= 64, (which, auto, slab[which])
+                assert auto % slab[which] == 0 and auto // slab[which] <= 256, (which, auto, slab[which])
         d.split_k = 1
         if not thin:
             assert h.dpig_conv2d_workspace_bytes(ctypes.byref(d), which) == 0

@@ -116,6 +116,34 @@ def test_forward_and_trunk_gradients_on_converter_style_inputs(dev):
     assert sorted(errs)[len(errs) // 2] < 2e-4, sorted(errs)[len(errs) // 2]
 
 
+def test_step_from_keypoints_equals_step_from_the_pose_map(dev):
+    """A batch that carries the keypoints `pose_rcv` instead of the target map (what the records hold; the reference rasterises
+    inside the graph, trainer.py:556-560) takes the same g_optim / d_optim: losses and the flat gradients equal those of the
+    map-fed step, the generated image equals the oracle's."""
+    import dpig_amd.tflib as lib
+    from dpig_amd import synthetic
+    tr, gb, P, ob, OM = _setup(dev)
+    kb = synthetic.keypoints_only(gb)
+    assert "pose" not in kb and kb["pose_rcv"].shape == (2, 54)
+    with torch.no_grad():
+        _, G_o = OM.stage1_forward(P, ob, hidden_num=HID, z_num=ZNUM)
+        embs, _ = tr.encode(kb)
+        from dpig_amd.trainer import pose_input
+        G, _ = tr.generate(embs, pose_input(kb, 128, 64))
+    assert _rel(G, G_o) < 1e-4
+    o_map = tr._g_optim_eager(gb, update=False)
+    g_map = tr.G_flat.grad.clone()
+    o_kp = tr._g_optim_eager(kb, update=False)
+    g_kp = tr.G_flat.grad.clone()
+    assert abs(o_map["g_loss"].item() - o_kp["g_loss"].item()) < 1e-5 * abs(o_map["g_loss"].item())
+    assert (g_map - g_kp).abs().max().item() < 2e-3 * g_map.abs().max().item()           # (kinks: module docstring)
+    assert ((g_map - g_kp).abs() <= 2e-4 * g_map.abs().max()).float().mean().item() > 0.995
+    d_map = tr._d_optim_eager(gb, update=False)
+    d_kp = tr._d_optim_eager(kb, update=False)
+    assert abs(d_map["d_loss"].item() - d_kp["d_loss"].item()) < 1e-5 * abs(d_map["d_loss"].item())
+    lib.delete_all_params()
+
+
 def test_trunk_gradients_linear_readout(dev):
     """d/dtheta of <G, r> for a fixed random r: every E+G kernel's backward, no D, no |.| kink."""
     import dpig_amd.tflib as lib

@@ -557,3 +557,50 @@ def test_act_bwd_pool2x_equals_masked_gradient_summed_over_2x2(dev, dtype):
             assert got.dtype == td and got.shape == (N, Hh, W, C)
             tol = 2.0 ** -7 if dtype == "bf16" else 1e-6
             assert float((got.float() - ref).abs().max()) <= tol * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_keypoint_fed_stem_conv_equals_the_dense_conv_on_the_rasterised_map(dev, dtype):
+    """autograd._TiledEmbKeypointConvFn (dpig_pose_stem_fwd / _wgrad): relu(conv3x3_SAME(concat([tile(emb), pose_map]), w) + b) and
+    its gradients w.r.t. emb, w, b from the KEYPOINTS (trainer.py:556-560 builds pose_map from pose_rcv in the graph; utils.py:237-318),
+    against the fp64 oracle's dense conv on the map `oracle.ops` rasterises from the same keypoints.  Keypoints in the corners, on the
+    borders, invisible, and two images with the same keypoint."""
+    import dpig_amd.hip_ops as H
+    from dpig_amd import autograd as A
+    from oracle import ops as O
+    g = torch.Generator().manual_seed(21)
+    B, Hh, W, E, P, K = 3, 24, 16, 20, 18, 32
+    r = torch.randint(0, Hh, (B, P), generator=g).double()
+    c = torch.randint(0, W, (B, P), generator=g).double()
+    v = (torch.rand(B, P, generator=g) < 0.8).double()
+    r[0, :4] = torch.tensor([0, 0, Hh - 1, Hh - 1]).double(); c[0, :4] = torch.tensor([0, W - 1, 0, W - 1]).double(); v[0, :4] = 1
+    r[1, :2] = torch.tensor([2.0, Hh - 3.0]); c[1, :2] = torch.tensor([0.0, W - 1.0]); v[1, :2] = 1
+    rcv = torch.stack([r, c, v], -1)
+    emb = (torch.randn(B, E, generator=g, dtype=torch.float64) * 0.5).requires_grad_(True)
+    w = (torch.randn(3, 3, E + P, K, generator=g, dtype=torch.float64) * 0.1).requires_grad_(True)
+    b = (torch.randn(K, generator=g, dtype=torch.float64) * 0.1).requires_grad_(True)
+    pose_map = O.tf_poseInflate(O.coord2channel_simple_rcv(rcv.reshape(B, -1), P, False, Hh, W), P, 4, Hh, W)
+    x = torch.cat([emb.reshape(B, 1, 1, E).expand(B, Hh, W, E), pose_map], -1)
+    y_ref = O.relu(O.conv2d_same(x, w, b, 1))
+    dy = torch.randn(y_ref.shape, generator=g, dtype=torch.float64)
+    d_emb, d_w, d_b = torch.autograd.grad((y_ref * dy).sum(), [emb, w, b])
+    H.set_compute(dtype)
+    try:
+        eg = emb.detach().float().to(dev).requires_grad_(True)
+        wg = w.detach().float().to(dev).requires_grad_(True)
+        bg = b.detach().float().to(dev).requires_grad_(True)
+        kp = A.PoseKeypoints(rcv.reshape(B, -1).float().to(dev), Hh, W, P, is_normalized=False)
+        y = A.tiled_emb_conv(eg, kp, wg, bg)
+        assert y.dtype == (torch.bfloat16 if dtype == "bf16" else torch.float32)
+        tol = 2.0 ** -7 if dtype == "bf16" else 2e-5
+        assert float((y.float().cpu().double() - y_ref).abs().max()) <= tol * float(y_ref.abs().max())
+        assert torch.equal(kp.dense().cpu().double(), pose_map)                      # the stand-in rasterises the same map on demand
+        dyg = dy.float().to(dev)
+        ge, gw, gb = torch.autograd.grad((y.float() * dyg).sum(), [eg, wg, bg])
+        gtol = 2e-2 if dtype == "bf16" else 1e-4
+        for got, ref, name in ((ge, d_emb, "emb"), (gw, d_w, "w"), (gb, d_b, "b")):
+            assert float((got.cpu().double() - ref).abs().max()) <= gtol * float(ref.abs().max()), name
+        # ... and the pose rows of the filter gradient on their own (the part the sparse gather produces)
+        assert float((gw[:, :, E:, :].cpu().double() - d_w[:, :, E:, :]).abs().max()) <= gtol * float(d_w[:, :, E:, :].abs().max())
+    finally:
+        H.set_compute("f32")
