@@ -40,6 +40,10 @@ WORKLOADS = {
                          "Gaussian FC mappers / FC critics, MODE='wgan', 5 critic iterations per side)"),
     "df256": ("trainer_256", "DPIG_Encoder_GAN_BodyROI_256", {"img_H": 256, "img_W": 256}, 8,
               "DeepFashion 256x256 stage-I (trainer_256.py path), g_optim + d_optim per step"),
+    "market128-sampling": ("tester", "DPIG_FourNetsFgBg_testOnly", {}, 32,
+                           "Market-1501 128x64 re-ID data generation (tester.py:256-417, batch 32 as tester.py:67): pose auto-encoder + "
+                           "Fg/Bg encoder + both Gaussian appearance mappers + generator + critic score + SSIM, forward only, "
+                           "appearance and pose sampled"),
     "df256-wgan-gp": ("trainer_256", "DPIG_Encoder_GAN_BodyROI_256", {"img_H": 256, "img_W": 256, "gan_mode": "wgan-gp"}, 8,
                       "DeepFashion 256x256 stage-I with MODE='wgan-gp' (LayerNorm critic with 8 logit rows per image, gradient "
                       "penalty, g_optim + 5 critic iterations per step): the per-GPU workload of BASELINE configs[4]"),
@@ -114,6 +118,8 @@ INFO_RUNS = [   # (key, BASELINE config it informs, bench.py arguments)
      ["--workload", "df256", "--dtype", "bf16x3", "--steps", "10", "--warmup", "2"]),
     ("market128_wgan_gp_f32", "configs[1] with MODE='wgan-gp' (LayerNorm critic, gradient penalty, 5 critic iterations per step)",
      ["--workload", "market128-wgan-gp", "--steps", "10", "--warmup", "2"]),
+    ("market128_sampling_bf16", "SURVEY 8(f-3): the inference / sampling harness at bf16 (generated images per second)",
+     ["--workload", "market128-sampling", "--dtype", "bf16", "--steps", "20", "--warmup", "3"]),
     ("df256_wgan_gp_bf16", "configs[4]: DeepFashion 256x256 bs=8 per GPU, MODE='wgan-gp', bf16 -- one GPU's share of the 8-GPU job",
      ["--workload", "df256-wgan-gp", "--dtype", "bf16", "--steps", "10", "--warmup", "2"]),
 ]
@@ -209,13 +215,21 @@ def main():
     np.random.seed(0)                         # identical initial weights on every rank (+ broadcast)
     B = args.batch or wl_batch
     cfg = Config(batch_size=B, compute_dtype=args.dtype, **wl_cfg)
-    tr = getattr(importlib.import_module("dpig_amd." + wl_mod), wl_cls)(cfg, dev)
+    sampling = args.workload == "market128-sampling"
+    if sampling:
+        args.no_graph = True
+        tr = getattr(importlib.import_module("dpig_amd." + wl_mod), wl_cls)(cfg, dev, sample_app=True, sample_pose=True)
+    else:
+        tr = getattr(importlib.import_module("dpig_amd." + wl_mod), wl_cls)(cfg, dev)
     batch_g = synthetic.to_device(synthetic.make_batch(B, img_H=cfg.img_H, img_W=cfg.img_W, seed=100 + 2 * rank), dev)
     batch_d = synthetic.to_device(synthetic.make_batch(B, img_H=cfg.img_H, img_W=cfg.img_W, seed=101 + 2 * rank), dev)
-    if args.pose == "keypoints" and not args.host_input and args.workload != "market128-stage2":
+    if args.pose == "keypoints" and not args.host_input and args.workload not in ("market128-stage2", "market128-sampling"):
         batch_g, batch_d = synthetic.keypoints_only(batch_g), synthetic.keypoints_only(batch_d)
-    tr.init_net(batch_g)
-    tr.step = 1                               # steady state: g_optim is only skipped at step 0
+    if sampling:
+        tr.run(batch_g, batch_g["pose_rcv"])  # builds the graph's variables (random init: there are no checkpoints here)
+    else:
+        tr.init_net(batch_g)
+        tr.step = 1                           # steady state: g_optim is only skipped at step 0
     if not args.no_graph:
         tr.enable_graphs(batch_g, batch_d)    # fwd+bwd+all-reduce+Adam of each optimizer op = one hipGraph
 
@@ -264,7 +278,9 @@ def main():
 
     get_g = (lambda: next(feed_g)) if feed_g is not None else (lambda: batch_g)
     get_d = (lambda: next(feed_d)) if feed_d is not None else (lambda: batch_d)
-    if args.workload == "market128-stage2":
+    if sampling:
+        step_fn = lambda: tr.run(batch_g, batch_g["pose_rcv"])
+    elif args.workload == "market128-stage2":
         step_fn = lambda: tr.train_step(get_g())
     elif args.workload.endswith("wgan-gp") and feed_d is None:
         # every critic iteration of a step dequeues its own batch (trainer.py:340-345, 553-555): 5 distinct resident batches
@@ -388,7 +404,8 @@ def main():
     if rank == 0:
         line = {
             "metric": "training images/sec (G+D step) Market-1501 128x64 bs=16" if headline else
-                      "training images/sec (%s, %s%s) [information line, not the BASELINE metric]" % (
+                      ("generated images/sec (%s, %s%s) [information line, not the BASELINE metric]" if sampling else
+                       "training images/sec (%s, %s%s) [information line, not the BASELINE metric]") % (
                           args.workload, args.dtype, ", inputs uploaded over PCIe every step (%s)" % args.host_input if args.host_input else ""),
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
@@ -396,7 +413,7 @@ def main():
             "config": {"workload": "%s, bs=%d per GPU, %s; %s" % (wl_desc, B, {"f32": "fp32", "bf16": "bf16 storage (activations, their gradients, filter shadows) + bf16 matrix pipe; fp32 accumulation, master weights, gradients and optimizer", "bf16c": "bf16 matrix pipe on fp32 tensors", "bf16x3": "fp32 tensors; conv products as three bf16 MFMAs on two-term bf16 splits of the fp32 operands (<= 2e-5 max|ref| per kernel, the exact path's test bar); everything else fp32"}[args.dtype], POSE_DESC),
                        "global_batch": world * B, "parallelism": "dp%d" % world},
             "achieved_alg_tflops": round(ALG_GFLOP_PER_IMG * value / 1e3, 2) if headline else None,
-            "losses": {k: float(v) for k, v in out.items() if hasattr(v, "numel") and v.numel() == 1},
+            "losses": {k: float(v) for k, v in out.items() if hasattr(v, "numel") and v.numel() == 1 and not sampling},
             "roofline": roofline, "cpu_baseline": cpu,
         }
         if comm is not None:
