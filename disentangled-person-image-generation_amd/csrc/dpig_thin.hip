@@ -16,6 +16,7 @@
 //
 // Roofline: HBM.  Algorithmic bytes = 4*(N*H*W*C + N*H*W*3) per call (+ filter), i.e. 135.8 MB at B=16.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include "dpig_common.h"
 #include "dpig_hip.h"
@@ -602,7 +603,184 @@ __global__ __launch_bounds__(256) void fewc_dgrad_px_kernel(const FewCParams p, 
     }
 }
 
+// ---- forward on the matrix pipe for a bf16 input (C % 32 == 0): the vector-ALU kernel above needs 108 FMAs per pixel and lane, twice its
+// HBM time.  Here D[16 x 16 px] += A[16 x 32 ch] * X[32 ch x 16 px] with v_mfma_f32_16x16x32_bf16 where the 16 rows of A are
+// (output channel o, column tap kx) pairs: row = 4 * o + kx (kx = 3: zero).  One UNSHIFTED pixel fragment therefore serves all three
+// column taps -- D holds, per pixel column c, the partial results P[o][kx][c] of filter row ky -- and the column shift is applied once
+// per output row at the end: y[o][c] = P[o][0][c - 1] + P[o][1][c] + P[o][2][c + 1], i.e. two lane shifts inside the 16-lane rows
+// (lane group o holds channel o, its accumulator registers 0..2 the three kx).  A wave owns a strip of 14 output columns (16 fragment
+// columns x0 - 1 .. x0 + 14) x RS output rows and walks the RS + 2 input rows once; every input fragment (16 px x 32 ch, one 16-byte
+// load per lane) feeds the three output rows it reaches (ky = 0, 1, 2).  The fp32 filter enters as two bf16 terms (hi + lo: 2 MFMAs) --
+// x is bf16 already, so the products are those of the fp32 filter to 2^-17.  Per pixel: x read once (HBM-bound), 1/3 of the LDS
+// fragment reads and MFMAs of the tap-by-tap formulation.
+typedef __bf16 thin_bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int T3_RS = 8, T3_OW = 14;
+template <int KC>        // KC = C / 32
+__global__ __launch_bounds__(256) void thin3_fwd_mfma_kernel(const ThinParams p, int nstrips_x, int nstrips_y, int nwaves) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short wq[];       // [hi|lo][3 ky][KC][4 k-groups][16 rows][8]
+    constexpr int FRAGS = 3 * KC * 4 * 16;
+    // stage the filter: zero the image (rows with kx = 3 / o = 3 stay zero), then stream W ([9][C][3] fp32, contiguous) with 16-byte
+    // loads and scatter each coefficient's two bf16 terms to its slot
+    for (int i = threadIdx.x; i < FRAGS * 2; i += 256) reinterpret_cast<uint4*>(wq)[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    const int nw4 = 9 * p.C * TK / 4;                       // (C % 32 == 0: a multiple of 4)
+    for (int q = threadIdx.x; q < nw4; q += 256) {
+        const float4 w4 = *reinterpret_cast<const float4*>(p.W + q * 4);
+        const float wv4[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = q * 4 + u;
+            const int o = j % TK, tc = j / TK, ch = tc % p.C, tap = tc / p.C;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int idx = ((((ky * KC + (ch >> 5)) * 4 + ((ch >> 3) & 3)) * 16) + (o * 4 + kx)) * 8 + (ch & 7);
+            const __bf16 hi = (__bf16)wv4[u];
+            const __bf16 lo = (__bf16)(wv4[u] - (float)hi);
+            wq[idx] = __builtin_bit_cast(unsigned short, hi);
+            wq[FRAGS * 8 + idx] = __builtin_bit_cast(unsigned short, lo);
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
+    if (wv >= nwaves) return;
+    const int sx = wv % nstrips_x;
+    const int t = wv / nstrips_x;
+    const int sy = t % nstrips_y, n = t / nstrips_y;
+    const int x0 = sx * T3_OW, y0 = sy * T3_RS;
+    const int col = lane & 15, kg = lane >> 4;
+    const int xx = x0 - 1 + col;                            // this lane's pixel column
+    const bool xok = (unsigned)xx < (unsigned)p.Wd;
+    const unsigned short* xb = static_cast<const unsigned short*>(p.X);
+    f32x4 acc[T3_RS];
+#pragma unroll
+    for (int i = 0; i < T3_RS; ++i) acc[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const thin_bf16x8 zero8 = __builtin_bit_cast(thin_bf16x8, make_uint4(0u, 0u, 0u, 0u));
+    const int abase = (kg * 16 + col) * 8;                  // this lane's slot inside a [4 k-groups][16 rows][8] fragment
+#pragma unroll
+    for (int ri = 0; ri < T3_RS + 2; ++ri) {
+        const int r = y0 - 1 + ri;                          // input row
+        const bool ok = xok && (unsigned)r < (unsigned)p.H;
+        const unsigned short* src = xb + ((((long)n * p.H + (ok ? r : 0)) * p.Wd + (ok ? xx : 0)) * p.ldx + kg * 8);
+        thin_bf16x8 bf[KC];
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+            const uint4 u = *reinterpret_cast<const uint4*>(src + kc * 32);
+            bf[kc] = ok ? __builtin_bit_cast(thin_bf16x8, u) : zero8;
+        }
+#pragma unroll
+        for (int kc = 0; kc < KC; ++kc) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int oi = ri - ky;                     // output row index within the strip: o = r + 1 - ky = y0 + (ri - ky)
+                if (oi < 0 || oi >= T3_RS) continue;        // (compile-time after unrolling)
+                const int fo = (ky * KC + kc) * 4 * 16 * 8 + abase;
+                const thin_bf16x8 ah = *reinterpret_cast<const thin_bf16x8*>(wq + fo);
+                const thin_bf16x8 al = *reinterpret_cast<const thin_bf16x8*>(wq + FRAGS * 8 + fo);
+                acc[oi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, bf[kc], acc[oi], 0, 0, 0);
+                acc[oi] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, bf[kc], acc[oi], 0, 0, 0);
+            }
+        }
+    }
+    // lane group kg = output channel; registers 0..2 = column taps: y[c] = P0[c - 1] + P1[c] + P2[c + 1] (lane shifts inside the 16-lane row)
+    const float bk = (p.bias && kg < TK) ? p.bias[kg] : 0.f;
+    const float slope = (p.act == DPIG_ACT_NONE) ? 1.f : ((p.act == DPIG_ACT_RELU) ? 0.f : p.alpha);
+    const bool writer = kg < TK && col >= 1 && col <= T3_OW && xx < p.Wd;
+#pragma unroll
+    for (int oi = 0; oi < T3_RS; ++oi) {
+        const float left = __shfl_up(acc[oi][0], 1, 16);        // P0 of the pixel one column to the left  (lanes of one 16-lane row)
+        const float right = __shfl_down(acc[oi][2], 1, 16);     // P2 of the pixel one column to the right
+        const int o = y0 + oi;
+        if (writer && o < p.H) {
+            const float v = (left + acc[oi][1]) + right + bk;
+            p.Y[(((long)n * p.H + o) * p.Wd + xx) * p.ldy + kg] = v > 0.f ? v : v * slope;
+        }
+    }
+}
+
+// ---- dgrad on the matrix pipe for a bf16 dx (C % 32 == 0): dx[p][c] = sum_{tap, o} dy[p - tap + 1][o] * w[tap][c][o] is a GEMM with a
+// reduction of only 27 (padded to 32): ONE v_mfma_f32_16x16x32_bf16 per (16 channels x 16 pixels).  A = the filter as [16 channels x 32 k]
+// tiles (k = 3 * tap + o) from LDS, B = the 27 dy values around each of 16 consecutive pixels of a row, gathered by the lanes themselves
+// (dy is the 3-channel fp32 image gradient: 12 bytes per pixel, cached).  Both operands are fp32 in memory, so each enters as two bf16
+// terms and a block is three MFMAs (hi*hi + hi*lo + lo*hi: relative error 2^-16, below dx's bf16 rounding).  The channel -> tile-row map is
+// chosen so that a lane's results of two consecutive tiles are 8 consecutive channels: one 16-byte store.  HBM-bound: dx written once.
+template <int CT>        // CT = C / 16 channel tiles
+__global__ __launch_bounds__(256) void thin3_dgrad_mfma_kernel(const ThinParams p, int groups_per_row, int nitems) {
+    extern __shared__ __attribute__((aligned(16))) unsigned short wd[];       // [hi|lo][CT tiles][4 k-groups][16 rows][8]
+    constexpr int FR = CT * 4 * 16;
+    for (int i = threadIdx.x; i < FR * 2; i += 256) reinterpret_cast<uint4*>(wd)[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    const int nw4 = 9 * p.C * TK / 4;
+    for (int q = threadIdx.x; q < nw4; q += 256) {
+        const float4 w4 = *reinterpret_cast<const float4*>(p.W + q * 4);
+        const float wv4[4] = {w4.x, w4.y, w4.z, w4.w};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = q * 4 + u;
+            const int o = j % TK, tc = j / TK, ch = tc % p.C, tap = tc / p.C;
+            const int k = tap * 3 + o;                      // reduction index, < 27
+            const int m = ch >> 5, within = ch & 31;
+            const int tile = 2 * m + ((within >> 2) & 1), row = (within >> 3) * 4 + (within & 3);
+            const int idx = (((tile * 4 + (k >> 3)) * 16) + row) * 8 + (k & 7);
+            const __bf16 hi = (__bf16)wv4[u];
+            const __bf16 lo = (__bf16)(wv4[u] - (float)hi);
+            wd[idx] = __builtin_bit_cast(unsigned short, hi);
+            wd[FR * 8 + idx] = __builtin_bit_cast(unsigned short, lo);
+        }
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int col = lane & 15, kg = lane >> 4;
+    const float* dy = p.DY;
+    unsigned short* dx = static_cast<unsigned short*>(p.DX);
+    const int abase = (kg * 16 + col) * 8;
+    for (int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)); item < nitems; item += gridDim.x * 4) {
+        const int gx = item % groups_per_row;
+        const int row = item / groups_per_row;              // n * H + y
+        const int y = row % p.H;
+        const int x = gx * 16 + col;
+        // B fragment: k = kg * 8 + e -> (tap, o); the source pixel of tap (ky, kx) is (y - ky + 1, x - kx + 1)
+        float v[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int k = kg * 8 + e;
+            const int tap = k / 3, o = k - tap * 3;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            const int sy = y - ky + 1, sx = x - kx + 1;
+            const bool ok = k < 27 && (unsigned)sy < (unsigned)p.H && (unsigned)sx < (unsigned)p.Wd;
+            v[e] = ok ? dy[((long)(row - y + sy) * p.Wd + sx) * p.ldy + o] : 0.f;
+        }
+        thin_bf16x8 bh, bl;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const __bf16 h = (__bf16)v[e];
+            bh[e] = h;
+            bl[e] = (__bf16)(v[e] - (float)h);
+        }
+        const bool xok = x < p.Wd;
+        unsigned short* orow = dx + ((long)row * p.Wd + (xok ? x : 0)) * p.ldx + kg * 8;
+#pragma unroll
+        for (int m = 0; m < CT / 2; ++m) {
+            f32x4 d0 = f32x4{0.f, 0.f, 0.f, 0.f}, d1 = f32x4{0.f, 0.f, 0.f, 0.f};
+            const thin_bf16x8 a0h = *reinterpret_cast<const thin_bf16x8*>(wd + (2 * m) * 4 * 16 * 8 + abase);
+            const thin_bf16x8 a0l = *reinterpret_cast<const thin_bf16x8*>(wd + FR * 8 + (2 * m) * 4 * 16 * 8 + abase);
+            const thin_bf16x8 a1h = *reinterpret_cast<const thin_bf16x8*>(wd + (2 * m + 1) * 4 * 16 * 8 + abase);
+            const thin_bf16x8 a1l = *reinterpret_cast<const thin_bf16x8*>(wd + FR * 8 + (2 * m + 1) * 4 * 16 * 8 + abase);
+            d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0h, bh, d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1h, bh, d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0h, bl, d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1h, bl, d1, 0, 0, 0);
+            d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0l, bh, d0, 0, 0, 0);
+            d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1l, bh, d1, 0, 0, 0);
+            // lane (pixel col, k-group kg): tile 2m rows kg*4.. = channels 32m + 8kg + 0..3, tile 2m+1 = channels 32m + 8kg + 4..7
+            if (xok)
+                *reinterpret_cast<uint4*>(orow + m * 32) = make_uint4(thin_pack2(d0[0], d0[1]), thin_pack2(d0[2], d0[3]),
+                                                                      thin_pack2(d1[0], d1[1]), thin_pack2(d1[2], d1[3]));
+        }
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------
+static int g_thin_mfma = []() { const char* e = getenv("DPIG_THIN_MFMA"); return e ? atoi(e) : 1; }();     // A/B switch
 static bool eligible(const DpigConvDesc* d, int pt, int pl) {
     return d->K == TK && d->R == 3 && d->S == 3 && d->stride == 1 && !d->upsample2x && pt == 1 && pl == 1 &&
            d->C % 4 == 0 && d->C >= 16 && d->C <= 256 && d->ldx % 4 == 0;
@@ -625,6 +803,20 @@ int thin_fwd_try(const DpigConvDesc* d, int pt, int pl, const void* x, const flo
     ThinParams p = {};
     if (!fill(d, &p, wide_bf16)) return 0;
     p.X = x; p.W = w; p.bias = bias; p.Y = y;
+    if (wide_bf16 && (d->C == 256 || d->C == 128 || d->C == 64) && d->ldx % 8 == 0 && aligned16(w) && g_thin_mfma) {
+        const int nsx = (d->W + T3_OW - 1) / T3_OW, nsy = (d->H + T3_RS - 1) / T3_RS;
+        const long nw = (long)d->N * nsx * nsy;
+        if (nw < 0x7fffffffL) {
+            const int kc = d->C / 32;
+            const size_t lds = (size_t)2 * 3 * kc * 4 * 16 * 8 * sizeof(unsigned short);
+            const dim3 grid((unsigned)((nw + 3) / 4));
+            if (kc == 8) hipLaunchKernelGGL((thin3_fwd_mfma_kernel<8>), grid, dim3(256), lds, st, p, nsx, nsy, (int)nw);
+            else if (kc == 4) hipLaunchKernelGGL((thin3_fwd_mfma_kernel<4>), grid, dim3(256), lds, st, p, nsx, nsy, (int)nw);
+            else hipLaunchKernelGGL((thin3_fwd_mfma_kernel<2>), grid, dim3(256), lds, st, p, nsx, nsy, (int)nw);
+            const int rcm = check_launch("thin3_fwd_mfma_kernel");
+            return rcm ? rcm : 1;
+        }
+    }
     if (wide_bf16) hipLaunchKernelGGL(thin3_fwd_kernel<true>, dim3((p.nwaves + 3) / 4), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(thin3_fwd_kernel<false>, dim3((p.nwaves + 3) / 4), dim3(256), 0, st, p);
     const int rc = check_launch("thin3_fwd_kernel");
@@ -637,6 +829,21 @@ int thin_dgrad_try(const DpigConvDesc* d, int pt, int pl, const float* dy, const
     ThinParams p = {};
     if (!fill(d, &p, wide_bf16)) return 0;
     p.DY = dy; p.W = w; p.DX = dx;
+    if (wide_bf16 && (d->C == 256 || d->C == 128 || d->C == 64) && d->ldx % 8 == 0 && aligned16(w) && g_thin_mfma) {
+        const int gpr = (d->W + 15) / 16;
+        const long nit = (long)d->N * d->H * gpr;
+        if (nit < 0x7fffffffL) {
+            const int ct = d->C / 16;
+            const size_t lds = (size_t)2 * ct * 4 * 16 * 8 * sizeof(unsigned short);
+            const long nb = (nit + 3) / 4;
+            const dim3 grid((unsigned)(nb < 4 * kNumCU ? nb : 4 * kNumCU));
+            if (ct == 16) hipLaunchKernelGGL((thin3_dgrad_mfma_kernel<16>), grid, dim3(256), lds, st, p, gpr, (int)nit);
+            else if (ct == 8) hipLaunchKernelGGL((thin3_dgrad_mfma_kernel<8>), grid, dim3(256), lds, st, p, gpr, (int)nit);
+            else hipLaunchKernelGGL((thin3_dgrad_mfma_kernel<4>), grid, dim3(256), lds, st, p, gpr, (int)nit);
+            const int rcm = check_launch("thin3_dgrad_mfma_kernel");
+            return rcm ? rcm : 1;
+        }
+    }
     if (wide_bf16) hipLaunchKernelGGL(thin3_dgrad_kernel<true>, dim3((p.nwaves + 3) / 4), dim3(256), 0, st, p);
     else hipLaunchKernelGGL(thin3_dgrad_kernel<false>, dim3((p.nwaves + 3) / 4), dim3(256), 0, st, p);
     const int rc = check_launch("thin3_dgrad_kernel");
