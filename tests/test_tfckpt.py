@@ -333,3 +333,94 @@ def test_optimizer_slots_round_trip_under_tf_names(tmp_path):
     finally:
         lib.delete_all_params()
         lib.set_device(None)
+
+
+@settings(max_examples=60, deadline=None)
+@given(st.binary(min_size=0, max_size=4096), st.integers(1, 64))
+def test_snappy_decoder_against_an_independent_compressor(data, repeat):
+    """The one piece of the checkpoint table format an independent implementation exists for in this image: snappy.  Blocks
+    produced by Apache Arrow's bundled Google snappy (`pyarrow.compress(codec='snappy')`: literals, 1/2/4-byte-offset copies,
+    overlapping copies from repetition) must decode to the original bytes with `tfckpt.snappy_decompress`."""
+    pa = pytest.importorskip("pyarrow")
+    if not pa.Codec.is_available("snappy"):
+        pytest.skip("pyarrow built without snappy")
+    raw = data * repeat
+    comp = pa.compress(raw, codec="snappy", asbytes=True)
+    assert C.snappy_decompress(comp) == raw
+    structured = (bytes(range(256)) * 3 + raw[:200] + b"\x00" * 5000 + raw[::-1][:300]) * 2      # long runs -> long-offset copies
+    assert C.snappy_decompress(pa.compress(structured, codec="snappy", asbytes=True)) == structured
+
+
+def _bundle_message_classes():
+    """BundleHeaderProto / BundleEntryProto (tensorflow/core/protobuf/tensor_bundle.proto) with TensorShapeProto
+    (framework/tensor_shape.proto) and VersionDef (framework/versions.proto), built in the protobuf runtime from their published field
+    numbers -- the index file's VALUES are these messages."""
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    f = descriptor_pb2.FileDescriptorProto(name="dpig_test_bundle.proto", package="dpigb", syntax="proto3")
+    T = descriptor_pb2.FieldDescriptorProto
+
+    def msg(name, parent=None):
+        m = (parent.nested_type if parent is not None else f.message_type).add()
+        m.name = name
+        return m
+
+    def field(m, name, num, typ, label=T.LABEL_OPTIONAL, type_name=None):
+        fd = m.field.add()
+        fd.name, fd.number, fd.type, fd.label = name, num, typ, label
+        if type_name:
+            fd.type_name = type_name
+
+    shape = msg("TensorShapeProto")
+    dim = msg("Dim", shape)
+    field(dim, "size", 1, T.TYPE_INT64)
+    field(dim, "name", 2, T.TYPE_STRING)
+    field(shape, "dim", 2, T.TYPE_MESSAGE, T.LABEL_REPEATED, ".dpigb.TensorShapeProto.Dim")
+    field(shape, "unknown_rank", 3, T.TYPE_BOOL)
+    ver = msg("VersionDef")
+    field(ver, "producer", 1, T.TYPE_INT32)
+    field(ver, "min_consumer", 2, T.TYPE_INT32)
+    hdr = msg("BundleHeaderProto")
+    field(hdr, "num_shards", 1, T.TYPE_INT32)
+    field(hdr, "endianness", 2, T.TYPE_INT32)                 # (enum LITTLE = 0, BIG = 1: same wire type)
+    field(hdr, "version", 3, T.TYPE_MESSAGE, type_name=".dpigb.VersionDef")
+    ent = msg("BundleEntryProto")
+    field(ent, "dtype", 1, T.TYPE_INT32)                      # (enum DataType)
+    field(ent, "shape", 2, T.TYPE_MESSAGE, type_name=".dpigb.TensorShapeProto")
+    field(ent, "shard_id", 3, T.TYPE_INT32)
+    field(ent, "offset", 4, T.TYPE_INT64)
+    field(ent, "size", 5, T.TYPE_INT64)
+    field(ent, "crc32c", 6, T.TYPE_FIXED32)
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(f)
+    get = getattr(message_factory, "GetMessageClass", None)
+    mk = (lambda n: get(pool.FindMessageTypeByName(n))) if get else (lambda n: message_factory.MessageFactory(pool).GetPrototype(pool.FindMessageTypeByName(n)))
+    return mk("dpigb.BundleHeaderProto"), mk("dpigb.BundleEntryProto")
+
+
+def test_bundle_protos_against_the_protobuf_runtime(tmp_path):
+    """The header / entry messages `save_checkpoint` writes into the index parse with the protobuf runtime to the values the
+    bundle format prescribes (DT_FLOAT = 1, DT_INT32 = 3, DT_INT64 = 9; offsets in write order; masked CRC32C of the bytes), and
+    entries the runtime serialises are read back by `_parse_entry`."""
+    pytest.importorskip("google.protobuf")
+    Header, Entry = _bundle_message_classes()
+    rng = np.random.RandomState(3)
+    tensors = {"a/w": rng.rand(3, 3, 4, 8).astype(np.float32), "a/b": rng.rand(8).astype(np.float32),
+               "step": np.array(7, dtype=np.int32), "big": np.arange(5, dtype=np.int64), "z/empty": np.zeros((0, 4), np.float32)}
+    prefix = str(tmp_path / "model.ckpt-1")
+    C.save_checkpoint(prefix, tensors)
+    items = C.read_table(prefix + ".index")
+    h = Header()
+    h.ParseFromString(items[0][1])
+    assert (h.num_shards, h.endianness, h.version.producer) == (1, 0, 1)
+    off = 0
+    dt = {np.dtype(np.float32): 1, np.dtype(np.int32): 3, np.dtype(np.int64): 9}
+    for key, val in items[1:]:
+        e = Entry()
+        e.ParseFromString(val)
+        a = tensors[key.decode()]
+        assert e.dtype == dt[a.dtype] and [d.size for d in e.shape.dim] == list(a.shape) and e.shard_id == 0
+        assert e.offset == off and e.size == a.nbytes and e.crc32c == masked_crc32c(a.tobytes())
+        off += a.nbytes
+        # ... and the other direction: what the runtime writes for the same entry is what the reader understands
+        back = C._parse_entry(e.SerializeToString())
+        assert (back["dtype"], back["shape"], back["offset"], back["size"], back["crc32c"]) == (e.dtype, list(a.shape), e.offset, e.size, e.crc32c)

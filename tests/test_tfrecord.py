@@ -165,3 +165,93 @@ def test_example_and_framing_round_trip_generated(examples):
                 assert list(g[k]) == v
             else:
                 assert np.array_equal(np.asarray(g[k]), v) and (len(v) == 0 or np.asarray(g[k]).dtype == v.dtype)
+
+
+def _example_message_classes():
+    """tf.train.Example built in the protobuf runtime from its published schema (tensorflow/core/example/feature.proto,
+    example.proto: BytesList / FloatList / Int64List { repeated value = 1 }, Feature oneof { bytes_list = 1, float_list = 2,
+    int64_list = 3 }, Features { map<string, Feature> feature = 1 }, Example { Features features = 1 }) -- an independent
+    implementation of the wire format (TensorFlow itself is not installed; its message definitions are these six)."""
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    f = descriptor_pb2.FileDescriptorProto(name="dpig_test_example.proto", package="dpigtest", syntax="proto3")
+    T = descriptor_pb2.FieldDescriptorProto
+
+    def msg(name):
+        m = f.message_type.add()
+        m.name = name
+        return m
+
+    def field(m, name, num, typ, label=T.LABEL_OPTIONAL, type_name=None, packed=None, oneof=None):
+        fd = m.field.add()
+        fd.name, fd.number, fd.type, fd.label = name, num, typ, label
+        if type_name:
+            fd.type_name = type_name
+        if packed is not None:
+            fd.options.packed = packed
+        if oneof is not None:
+            fd.oneof_index = oneof
+        return fd
+
+    field(msg("BytesList"), "value", 1, T.TYPE_BYTES, T.LABEL_REPEATED)
+    field(msg("FloatList"), "value", 1, T.TYPE_FLOAT, T.LABEL_REPEATED, packed=True)
+    field(msg("Int64List"), "value", 1, T.TYPE_INT64, T.LABEL_REPEATED, packed=True)
+    feat = msg("Feature")
+    feat.oneof_decl.add().name = "kind"
+    field(feat, "bytes_list", 1, T.TYPE_MESSAGE, type_name=".dpigtest.BytesList", oneof=0)
+    field(feat, "float_list", 2, T.TYPE_MESSAGE, type_name=".dpigtest.FloatList", oneof=0)
+    field(feat, "int64_list", 3, T.TYPE_MESSAGE, type_name=".dpigtest.Int64List", oneof=0)
+    feats = msg("Features")
+    entry = feats.nested_type.add()
+    entry.name = "FeatureEntry"
+    entry.options.map_entry = True
+    field(entry, "key", 1, T.TYPE_STRING)
+    field(entry, "value", 2, T.TYPE_MESSAGE, type_name=".dpigtest.Feature")
+    field(feats, "feature", 1, T.TYPE_MESSAGE, T.LABEL_REPEATED, type_name=".dpigtest.Features.FeatureEntry")
+    field(msg("Example"), "features", 1, T.TYPE_MESSAGE, type_name=".dpigtest.Features")
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(f)
+    get = getattr(message_factory, "GetMessageClass", None)
+    desc = pool.FindMessageTypeByName("dpigtest.Example")
+    return get(desc) if get else message_factory.MessageFactory(pool).GetPrototype(desc)
+
+
+def test_example_codec_against_the_protobuf_runtime():
+    """`parse_example` reads what the protobuf library serialises for tf.train.Example's schema and the library parses what
+    `encode_example` writes: the record payload format is pinned against an independent implementation (negative int64 = 10-byte
+    varints, packed float / int64 lists, empty lists, several byte strings, unicode keys)."""
+    pytest.importorskip("google.protobuf")
+    from dpig_amd import tfrecord as R
+    Example = _example_message_classes()
+    rng = np.random.RandomState(5)
+    want = {"image_raw_0": [rng.bytes(300)], "pose_peaks_0": rng.rand(128 * 64 * 18 // 64).astype(np.float32),
+            "part_bbox_0": np.array([0, 0, 1, 1, 5, 7, 120, 60, -1, -(2 ** 62), 2 ** 62, 300], dtype=np.int64),
+            "many": [b"a", b"", b"xyz" * 40], "empty_f": np.zeros(0, np.float32), "id_é": np.array([7], dtype=np.int64)}
+    ex = Example()
+    for k, v in want.items():
+        f = ex.features.feature[k]
+        if isinstance(v, list):
+            f.bytes_list.value.extend(v)
+        elif v.dtype.kind == "f":
+            f.float_list.value.extend(v.tolist())
+            if v.size == 0:
+                f.float_list.SetInParent()
+        else:
+            f.int64_list.value.extend(v.tolist())
+    got = R.parse_example(ex.SerializeToString())
+    assert set(got) == set(want)
+    for k, v in want.items():
+        if isinstance(v, list):
+            assert got[k] == v, k
+        else:
+            assert got[k].dtype == v.dtype and np.array_equal(got[k], v), k
+    back = Example()
+    back.ParseFromString(R.encode_example(want))
+    assert set(back.features.feature.keys()) == set(want)
+    for k, v in want.items():
+        f = back.features.feature[k]
+        if isinstance(v, list):
+            assert list(f.bytes_list.value) == v, k
+        elif v.dtype.kind == "f":
+            assert np.array_equal(np.array(f.float_list.value, dtype=np.float32), v), k
+        else:
+            assert list(f.int64_list.value) == v.tolist(), k
