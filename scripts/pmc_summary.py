@@ -27,7 +27,7 @@ with open(os.path.join(root, "profiles", tag + "_pmc_traffic.md"), "w") as fh:
              "`python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-roofline --no-graph` (5 eager steps incl. graph-free warm-up + init).\n"
              "read = 2 x FETCH_SIZE (gfx950: 128-B requests tallied at 64 B, MI355X_MICROARCH.md), write = WRITE_SIZE (uncalibrated).\n\n")
     fh.write("| kernel | launches | raw FETCH KB/launch | read MB/launch (corrected) | write MB/launch | total MB/launch |\n|---|---|---|---|---|---|\n")
-    for k, n, raw, rd, wr, tot in rows[:14]:
+    for k, n, raw, rd, wr, tot in rows[:16]:
         fh.write("| `%s` | %d | %.0f | %.2f | %.2f | %.2f |\n" % (short(k), n, raw / 1024.0, rd / 1e6, wr / 1e6, tot / 1e6))
 js = {}
 for k, n, raw, rd, wr, tot in rows:
@@ -35,5 +35,6 @@ for k, n, raw, rd, wr, tot in rows:
     if "gather_gemm_kernel<true, true, false, 0>" in k: js["conv_dgrad_hbm_bytes_per_launch"] = round(tot)
     if "wgrad_kernel<true, false, false, true, 0>" in k: js["conv_wgrad_hbm_bytes_per_launch"] = round(tot)
 js["source"] = "profiles/%s_pmc_traffic.md" % tag
-json.dump(js, open(os.path.join(root, "profiles", "roofline_traffic.json"), "w"), indent=1)
+if not os.environ.get("DPIG_KEEP_TRAFFIC_JSON") and "conv_fwd_hbm_bytes_per_launch" in js:      # (only the headline workload owns the file)
+    json.dump(js, open(os.path.join(root, "profiles", "roofline_traffic.json"), "w"), indent=1)
 print(js)
