@@ -779,6 +779,92 @@ __global__ __launch_bounds__(256) void thin3_dgrad_mfma_kernel(const ThinParams 
     }
 }
 
+// ---- forward of the 3-channel stems on the matrix pipe for a bf16 output (K % 32 == 0): y[p][k] = sum_{tap, c} x[s*p + tap - pad][c] * w[tap][c][k]
+// has a reduction of only R*S*3 (27 / 75): ceil(R*S*3 / 32) k-steps of v_mfma_f32_16x16x32_bf16 per (16 output channels x 16 pixels).
+// A = the filter as [16 channels x 32 k] tiles from LDS, B = the image window of 16 consecutive output pixels of a row, gathered by the
+// lanes (the fp32 image is 12 bytes per pixel, cached).  Image and filter are fp32: each enters as two bf16 terms, a block is three MFMAs
+// (hi*hi + hi*lo + lo*hi, relative error 2^-16: below y's bf16 rounding).  Channel -> tile-row map as in thin3_dgrad_mfma_kernel: two
+// tiles' results of a lane are 8 consecutive channels, one 16-byte store.  HBM-bound: y written once.
+template <int R, int S, int ST, int KT>        // KT = K / 16 output-channel tiles
+__global__ __launch_bounds__(256) void fewc_fwd_mfma_kernel(const FewCParams p, int groups_per_row, int nitems) {
+    constexpr int RED = R * S * 3, KS = (RED + 31) / 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned short wf[];       // [hi|lo][KT tiles][KS][4 k-groups][16 rows][8]
+    constexpr int FR = KT * KS * 4 * 16;
+    for (int i = threadIdx.x; i < FR * 2; i += 256) reinterpret_cast<uint4*>(wf)[i] = make_uint4(0u, 0u, 0u, 0u);
+    __syncthreads();
+    const int K = KT * 16;
+    for (int j = threadIdx.x; j < RED * K; j += 256) {                 // W: [R*S][3][K] fp32, k contiguous
+        const int k = j % K, red = j / K;                               // red = tap * 3 + c
+        const int m = k >> 5, within = k & 31;
+        const int tile = 2 * m + ((within >> 2) & 1), row = (within >> 3) * 4 + (within & 3);
+        const int idx = ((((tile * KS + (red >> 5)) * 4 + ((red >> 3) & 3)) * 16) + row) * 8 + (red & 7);
+        const float wv = p.W[j];
+        const __bf16 hi = (__bf16)wv;
+        const __bf16 lo = (__bf16)(wv - (float)hi);
+        wf[idx] = __builtin_bit_cast(unsigned short, hi);
+        wf[FR * 8 + idx] = __builtin_bit_cast(unsigned short, lo);
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int col = lane & 15, kg = lane >> 4;
+    unsigned short* yb = static_cast<unsigned short*>(p.Y);
+    const int abase = (kg * 16 + col) * 8;
+    const float slope = (p.act == DPIG_ACT_NONE) ? 1.f : ((p.act == DPIG_ACT_RELU) ? 0.f : p.alpha);
+    for (int item = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6)); item < nitems; item += gridDim.x * 4) {
+        const int gx = item % groups_per_row;
+        const int row = item / groups_per_row;              // n * Ho + oy
+        const int n = row / p.Ho, oy = row - n * p.Ho;
+        const int ox = gx * 16 + col;
+        thin_bf16x8 bh[KS], bl[KS];
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int red = ks * 32 + kg * 8 + e;
+                const int tap = red / 3, c = red - tap * 3;
+                const int ky = tap / S, kx = tap - ky * S;
+                const int iy = oy * ST - p.pt + ky, ix = ox * ST - p.pl + kx;
+                const bool ok = red < RED && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.Wd;
+                const float v = ok ? p.X[(((long)n * p.H + iy) * p.Wd + ix) * p.ldx + c] : 0.f;
+                const __bf16 h = (__bf16)v;
+                bh[ks][e] = h;
+                bl[ks][e] = (__bf16)(v - (float)h);
+            }
+        }
+        const bool xok = ox < p.Wo;
+        unsigned short* orow = yb + ((long)row * p.Wo + (xok ? ox : 0)) * p.ldy + kg * 8;
+#pragma unroll
+        for (int m = 0; m < KT / 2; ++m) {
+            f32x4 d0 = f32x4{0.f, 0.f, 0.f, 0.f}, d1 = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const int f0 = ((2 * m) * KS + ks) * 4 * 16 * 8 + abase, f1 = ((2 * m + 1) * KS + ks) * 4 * 16 * 8 + abase;
+                const thin_bf16x8 a0h = *reinterpret_cast<const thin_bf16x8*>(wf + f0);
+                const thin_bf16x8 a0l = *reinterpret_cast<const thin_bf16x8*>(wf + FR * 8 + f0);
+                const thin_bf16x8 a1h = *reinterpret_cast<const thin_bf16x8*>(wf + f1);
+                const thin_bf16x8 a1l = *reinterpret_cast<const thin_bf16x8*>(wf + FR * 8 + f1);
+                d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0h, bh[ks], d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1h, bh[ks], d1, 0, 0, 0);
+                d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0h, bl[ks], d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1h, bl[ks], d1, 0, 0, 0);
+                d0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a0l, bh[ks], d0, 0, 0, 0);
+                d1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a1l, bh[ks], d1, 0, 0, 0);
+            }
+            // lane (pixel col, k-group kg): tile 2m rows kg*4.. = channels 32m + 8kg + 0..3, tile 2m+1 = channels 32m + 8kg + 4..7
+            float v8[8] = {d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]};
+            if (p.bias) {
+                const float4 b0 = *reinterpret_cast<const float4*>(p.bias + m * 32 + kg * 8), b1 = *reinterpret_cast<const float4*>(p.bias + m * 32 + kg * 8 + 4);
+                v8[0] += b0.x; v8[1] += b0.y; v8[2] += b0.z; v8[3] += b0.w; v8[4] += b1.x; v8[5] += b1.y; v8[6] += b1.z; v8[7] += b1.w;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v8[e] = v8[e] > 0.f ? v8[e] : v8[e] * slope;
+            if (xok)
+                *reinterpret_cast<uint4*>(orow + m * 32) = make_uint4(thin_pack2(v8[0], v8[1]), thin_pack2(v8[2], v8[3]),
+                                                                      thin_pack2(v8[4], v8[5]), thin_pack2(v8[6], v8[7]));
+        }
+    }
+}
+
 // ---- host side ---------------------------------------------------------------------------------------------
 static int g_thin_mfma = []() { const char* e = getenv("DPIG_THIN_MFMA"); return e ? atoi(e) : 1; }();     // A/B switch
 static bool eligible(const DpigConvDesc* d, int pt, int pl) {
@@ -898,6 +984,22 @@ int fewc_fwd_try(const DpigConvDesc* d, int pt, int pl, int Ho, int Wo, const fl
     fewc_fill(d, pt, pl, Ho, Wo, &p);
     p.X = x; p.W = w; p.bias = bias; p.Y = y;
     const int R = kind == 1 ? 3 : 5;
+    if (wide_bf16 && g_thin_mfma && (d->K == 64 || d->K == 128) && d->ldy % 8 == 0) {
+        const int gpr = (Wo + 15) / 16;
+        const long nit = (long)d->N * Ho * gpr;
+        if (nit < 0x7fffffffL) {
+            const int ks = (R * R * 3 + 31) / 32, kt = d->K / 16;
+            const size_t ldsm = (size_t)2 * kt * ks * 4 * 16 * 8 * sizeof(unsigned short);
+            const long nb = (nit + 3) / 4;
+            const dim3 grid((unsigned)(nb < 4 * kNumCU ? nb : 4 * kNumCU));
+            if (kind == 1 && kt == 8) hipLaunchKernelGGL((fewc_fwd_mfma_kernel<3, 3, 1, 8>), grid, dim3(256), ldsm, st, p, gpr, (int)nit);
+            else if (kind == 1) hipLaunchKernelGGL((fewc_fwd_mfma_kernel<3, 3, 1, 4>), grid, dim3(256), ldsm, st, p, gpr, (int)nit);
+            else if (kt == 8) hipLaunchKernelGGL((fewc_fwd_mfma_kernel<5, 5, 2, 8>), grid, dim3(256), ldsm, st, p, gpr, (int)nit);
+            else hipLaunchKernelGGL((fewc_fwd_mfma_kernel<5, 5, 2, 4>), grid, dim3(256), ldsm, st, p, gpr, (int)nit);
+            const int rcm = check_launch("fewc_fwd_mfma_kernel");
+            return rcm ? rcm : 1;
+        }
+    }
     const size_t lds = ((size_t)R * R * 3 * d->K + (size_t)R * FC_MAXW * 3) * sizeof(float);
     if (kind == 1) {
         if (wide_bf16) hipLaunchKernelGGL((fewc_fwd_kernel<3, 3, 1, true>), dim3(p.nrows), dim3(256), lds, st, p);
