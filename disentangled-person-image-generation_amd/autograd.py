@@ -27,6 +27,27 @@ class no_param_grads(object):
         return False
 
 
+# A ReLU conv whose output feeds ONE residual block: the block's input-gradient dgrad applies that ReLU's mask in its epilogue
+# ((dgrad + skip gradient) * relu'(x0)) and tags the gradient, and the producing conv's backward then skips its own activation-gradient
+# pass.  ReLU masks are idempotent, so a gradient that lost its tag (autograd summed it with another consumer's) is simply masked again:
+# correctness never depends on the tag.  FUSE_INPUT_MASK[0] = False restores the separate pass (A/B, tests).
+FUSE_INPUT_MASK = [__import__('os').environ.get('DPIG_FUSE_INPUT_MASK', '1') != '0']
+
+
+def _mark_relu_output(y, act):
+    if act == ACT_RELU:
+        try:
+            y._dpig_relu_out = True
+        except Exception:
+            pass
+    return y
+
+
+def _premasked(dy, y):
+    """dy already carries relu'(y): it is the tagged input gradient of the residual block that consumed y."""
+    return FUSE_INPUT_MASK[0] and getattr(dy, "_dpig_masked_for", None) == y.data_ptr() and dy.shape == y.shape
+
+
 def _sink(p, fn):
     """Gradient delivery for a parameter.  If the optimizer registered a persistent gradient slice
     on the parameter (`p._dpig_grad`, a view into its flat gradient buffer -- see trainer.FlatParams)
@@ -180,6 +201,8 @@ class _ConvFn(torch.autograd.Function):
             return dx, dw, db, None, None, None, None, None, None
         if second:
             dz = _ActBwdFn.apply(dy, y, act, alpha) if act != ACT_NONE else dy
+        elif act == ACT_RELU and _premasked(dy, y):
+            dz = dy                                 # the consuming residual block's dgrad already applied relu'(y)
         else:
             dz = H.act_bwd(dy, y, act, alpha, emit32=True) if act != ACT_NONE else dy
         dx = dw = db = None
@@ -203,7 +226,7 @@ def conv2d(x, w, b=None, stride=1, act=ACT_NONE, alpha=0.2, upsample2x=False, bn
     if not bn_stats:
         if out is not None:
             return _ConvFn.apply(x, w, b, stride, act, alpha, upsample2x, None, _Out(out))
-        return _ConvFn.apply(x, w, b, stride, act, alpha, upsample2x)
+        return _mark_relu_output(_ConvFn.apply(x, w, b, stride, act, alpha, upsample2x), act)
     box = []
     y = _ConvFn.apply(x, w, b, stride, act, alpha, upsample2x, box)
     if box and box[0] is not None:
@@ -219,6 +242,7 @@ class _ResBlockFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x0, w1, b1, w2, b2, out=None):
+        ctx.x0_relu = bool(getattr(x0, "_dpig_relu_out", False))
         c1 = H.conv2d_fwd(x0, w1, b1, act=ACT_RELU, emit32=True)
         c2 = torch.empty_like(c1)
         out = torch.empty_like(c1) if out is None else out.t
@@ -237,7 +261,12 @@ class _ResBlockFn(torch.autograd.Function):
         dw1, db1 = _sink_wgrad_bias(w1, b1, x0, dz1, want_w=ctx.needs_input_grad[1], want_b=ctx.needs_input_grad[2])
         dx0 = None
         if ctx.needs_input_grad[0]:
-            dx0 = H.conv2d_dgrad(dz1, w1, tuple(x0.shape), accum=dout)
+            if ctx.x0_relu and FUSE_INPUT_MASK[0] and not torch.is_grad_enabled():
+                # x0 is a ReLU conv's output: hand its producer the gradient w.r.t. the PRE-activation (mask in this epilogue)
+                dx0 = H.conv2d_dgrad(dz1, w1, tuple(x0.shape), accum=dout, mask=x0, act=ACT_RELU)
+                dx0._dpig_masked_for = x0.data_ptr()
+            else:
+                dx0 = H.conv2d_dgrad(dz1, w1, tuple(x0.shape), accum=dout)
         return dx0, dw1, db1, dw2, db2, None
 
 
@@ -358,7 +387,7 @@ class _TiledEmbConvFn(torch.autograd.Function):
         emb, pose, w, wmat, y = ctx.saved_tensors
         E, K = emb.shape[1], w.shape[3]
         B = emb.shape[0]
-        dz = H.act_bwd(dy, y, ACT_RELU)
+        dz = dy.contiguous() if _premasked(dy, y) else H.act_bwd(dy, y, ACT_RELU)
         z9 = H.border_class_sum(dz)                                                    # [B, 9, K] fp32
         db = None
         if ctx.needs_input_grad[3]:            # every pixel belongs to exactly one class: the bias gradient is their sum
@@ -430,7 +459,7 @@ class _TiledEmbKeypointConvFn(torch.autograd.Function):
         P, normalized = ctx.cfg
         E, K = emb.shape[1], w.shape[3]
         B = emb.shape[0]
-        dz = H.act_bwd(dy, y, ACT_RELU)
+        dz = dy.contiguous() if _premasked(dy, y) else H.act_bwd(dy, y, ACT_RELU)
         z9 = H.border_class_sum(dz)                                                    # [B, 9, K] fp32
         db = None
         if ctx.needs_input_grad[3]:
@@ -454,8 +483,9 @@ class _TiledEmbKeypointConvFn(torch.autograd.Function):
 
 def tiled_emb_conv(emb, pose, w, b):
     if isinstance(pose, PoseKeypoints):
-        return _TiledEmbKeypointConvFn.apply(emb, pose.rcv, w, b, pose.shape[1], pose.shape[2], pose.is_normalized)
-    return _TiledEmbConvFn.apply(emb, pose, w, b)
+        return _mark_relu_output(_TiledEmbKeypointConvFn.apply(emb, pose.rcv, w, b, pose.shape[1], pose.shape[2], pose.is_normalized),
+                                 ACT_RELU)
+    return _mark_relu_output(_TiledEmbConvFn.apply(emb, pose, w, b), ACT_RELU)
 
 
 class _ActFn(torch.autograd.Function):

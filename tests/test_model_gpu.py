@@ -144,6 +144,40 @@ def test_step_from_keypoints_equals_step_from_the_pose_map(dev):
     lib.delete_all_params()
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_input_mask_fusion_is_bit_identical_and_active(dev, dtype):
+    """A ReLU conv feeding a residual block: the block's input-gradient dgrad applies the conv's ReLU mask in its epilogue and the
+    conv's backward skips its activation-gradient pass (autograd.FUSE_INPUT_MASK).  Masking in the epilogue or in a separate pass
+    multiplies the same stored values by 0 / 1: the flat gradients must be IDENTICAL with the fusion on and off, and the fused run
+    must launch fewer activation-gradient kernels."""
+    import dpig_amd.tflib as lib
+    from dpig_amd import autograd as A, hip_ops as H
+    tr, gb, P, ob, OM = _setup(dev)
+    tr.config.compute_dtype = dtype
+    calls = [0]
+    orig = H.act_bwd
+
+    def spy(*a, **k):
+        calls[0] += 1
+        return orig(*a, **k)
+    H.act_bwd = spy
+    try:
+        res = {}
+        for fuse in (False, True):
+            A.FUSE_INPUT_MASK[0] = fuse
+            calls[0] = 0
+            o = tr._g_optim_eager(gb, update=False)
+            res[fuse] = (tr.G_flat.grad.clone(), o["g_loss"].item(), calls[0])
+    finally:
+        H.act_bwd = orig
+        A.FUSE_INPUT_MASK[0] = True
+        H.set_compute("f32")
+    assert res[True][1] == res[False][1]
+    assert torch.equal(res[True][0], res[False][0])
+    assert res[True][2] <= res[False][2] - 10, (res[True][2], res[False][2])        # 3 towers x (stem + 4 stride-2 convs) at least
+    lib.delete_all_params()
+
+
 def test_trunk_gradients_linear_readout(dev):
     """d/dtheta of <G, r> for a fixed random r: every E+G kernel's backward, no D, no |.| kink."""
     import dpig_amd.tflib as lib
