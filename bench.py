@@ -307,43 +307,48 @@ def main():
     value = world * B * args.steps / elapsed
 
     # ---- N > 1: what the gradient exchange costs (rank-max like the headline) ---------------------------------------------
-    comm = None
+    comm, comm_error = None, None
     if world > 1 and hasattr(tr, "G_flat") and hasattr(tr, "D_flat") and getattr(tr, "allreduce", None) is not None and tr.allreduce.enabled:
-        def rank_max(sec):
-            t = torch.tensor([sec], dtype=torch.float64, device=dev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            return t.item()
-        # (a) the step's collectives alone, back to back on an otherwise idle GPU: G decoder slice, G encoder slice, D
-        eo = getattr(tr, "_enc_off", 0)
-        slices = [s for s in (tr.G_flat.grad[:eo], tr.G_flat.grad[eo:], tr.D_flat.grad) if s.numel()]
-        reps = 10
-        for _ in range(2):
-            tr.allreduce.finish(sum((tr.allreduce.start(s) for s in slices), []))
-        sync()
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            tr.allreduce.finish(sum((tr.allreduce.start(s) for s in slices), []))
-        sync()
-        ar_ms = rank_max(time.perf_counter() - t1) / reps * 1e3
-        # (b) the same K steps with the exchange switched off (every rank keeps its local gradient): the difference to the
-        #     timed region is the part of the exchange that the backward pass did not hide
-        tr.allreduce.enabled = False
-        for _ in range(min(args.warmup, 3)):
-            step_fn()
-        sync()
-        t1 = time.perf_counter()
-        for _ in range(args.steps):
-            step_fn()
-        sync()
-        local_ms = rank_max(time.perf_counter() - t1) / args.steps * 1e3
-        tr.allreduce.enabled = True
-        nbytes = sum(s.numel() for s in slices) * (2 if tr.allreduce.compress else 4)
-        comm = {"allreduce_ms": round(ar_ms, 3), "exposed_ms": round(ms_per_step - local_ms, 3),
-                "ms_per_step_without_exchange": round(local_ms, 3), "bytes_per_step": nbytes,
-                "collectives_per_step": sum(-(-s.numel() // tr.allreduce.bucket) for s in slices),
-                "wire_dtype": "bf16" if tr.allreduce.compress else "f32",
-                "note": "allreduce_ms: the step's gradient all-reduces alone on an idle GPU; exposed_ms: timed step minus the "
-                        "same step with the exchange off (what the backward pass did not overlap)"}
+        try:
+            def rank_max(sec):
+                t = torch.tensor([sec], dtype=torch.float64, device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                return t.item()
+            # (a) the step's collectives alone, back to back on an otherwise idle GPU: G decoder slice, G encoder slice, D
+            eo = getattr(tr, "_enc_off", 0)
+            slices = [s for s in (tr.G_flat.grad[:eo], tr.G_flat.grad[eo:], tr.D_flat.grad) if s.numel()]
+            reps = 10
+            for _ in range(2):
+                tr.allreduce.finish(sum((tr.allreduce.start(s) for s in slices), []))
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                tr.allreduce.finish(sum((tr.allreduce.start(s) for s in slices), []))
+            sync()
+            ar_ms = rank_max(time.perf_counter() - t1) / reps * 1e3
+            # (b) the same K steps with the exchange switched off (every rank keeps its local gradient): the difference to the
+            #     timed region is the part of the exchange that the backward pass did not hide
+            tr.allreduce.enabled = False
+            for _ in range(min(args.warmup, 3)):
+                step_fn()
+            sync()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step_fn()
+            sync()
+            local_ms = rank_max(time.perf_counter() - t1) / args.steps * 1e3
+            tr.allreduce.enabled = True
+            nbytes = sum(s.numel() for s in slices) * (2 if tr.allreduce.compress else 4)
+            comm = {"allreduce_ms": round(ar_ms, 3), "exposed_ms": round(ms_per_step - local_ms, 3),
+                    "ms_per_step_without_exchange": round(local_ms, 3), "bytes_per_step": nbytes,
+                    "collectives_per_step": sum(-(-s.numel() // tr.allreduce.bucket) for s in slices),
+                    "wire_dtype": "bf16" if tr.allreduce.compress else "f32",
+                    "note": "allreduce_ms: the step's gradient all-reduces alone on an idle GPU; exposed_ms: timed step minus the "
+                            "same step with the exchange off (what the backward pass did not overlap)"}
+        except Exception as e:      # a failure of this extra measurement must not take the bench line down (it is the same on every rank)
+            tr.allreduce.enabled = True
+            comm = None
+            comm_error = "%s: %s" % (type(e).__name__, str(e)[:200])
 
     roofline = None
     if not args.no_roofline:
@@ -418,6 +423,8 @@ def main():
         }
         if comm is not None:
             line["allreduce_ms"], line["exposed_ms"], line["comm"] = comm["allreduce_ms"], comm["exposed_ms"], comm
+        elif comm_error is not None:
+            line["comm"] = {"error": comm_error}
         if headline and world == 1 and not args.no_info_lines:
             line["info_lines"] = info_lines()
         print(json.dumps(line), flush=True)
