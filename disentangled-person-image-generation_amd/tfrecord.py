@@ -273,19 +273,23 @@ def decode_pair(example, which=0, img_H=128, img_W=64, part_indices=range(7)):
     }
 
 
-def batch_from_examples(examples, device, which=0, img_H=128, img_W=64, keypoint_num=18, part_indices=range(7)):
-    """Batch dict of device tensors with the keys of `synthetic.make_batch` / `synthetic.to_device`; the [B,H,W,18]
-    pose target is rasterised on the device from the (row, col, visibility) triplets (is_normalized=False,
-    trainer.py:556-560)."""
+def batch_from_examples(examples, device, which=0, img_H=128, img_W=64, keypoint_num=18, part_indices=range(7), dense_pose=True):
+    """Batch dict of device tensors with the keys of `synthetic.make_batch` / `synthetic.to_device`.  The pose arrives as the
+    records' (row, col, visibility) triplets `pose_rcv` (is_normalized=False, trainer.py:556-560); with `dense_pose` the
+    [B,H,W,18] target map is also rasterised on the device (`pose`) -- without it the trainers feed the keypoints straight to the
+    generator's first conv (trainer.pose_input)."""
     import torch
     from . import utils
     items = [decode_pair(e, which, img_H, img_W, part_indices) for e in examples]
     stack = lambda k: torch.from_numpy(np.stack([it[k] for it in items]))
     rcv = stack("pose_rcv").to(device)
-    return {
+    out = {
         "x": stack("x").to(device),
-        "pose": utils.pose_target_from_rcv(rcv, keypoint_num, False, img_H, img_W),
+        "pose_rcv": rcv.reshape(rcv.shape[0], -1).float(),
         "mask_r6": stack("mask_r6").to(device),
         "part_bbox": stack("part_bbox").to(device),
         "part_vis": stack("part_vis").to(device),
     }
+    if dense_pose:
+        out["pose"] = utils.pose_target_from_rcv(rcv, keypoint_num, False, img_H, img_W)
+    return out

@@ -139,6 +139,12 @@ def test_batch_from_records_feeds_the_trainer(dev):
     tr.step = 1
     out = tr.train_step(batch, T.batch_from_examples(exs, dev, which=1))
     assert all(np.isfinite(float(v)) for v in out.values() if hasattr(v, "numel") and v.numel() == 1)
+    # the same records without the rasterised map: the keypoints go straight to the generator's first conv (same losses)
+    kb = T.batch_from_examples(exs, dev, which=0, dense_pose=False)
+    assert "pose" not in kb and tuple(kb["pose_rcv"].shape) == (2, 54)
+    a = tr._g_optim_eager(batch, update=False)
+    b = tr._g_optim_eager(kb, update=False)
+    assert abs(float(a["g_loss"]) - float(b["g_loss"])) <= 1e-5 * abs(float(a["g_loss"]))
 
 
 from hypothesis import given, settings, strategies as st   # noqa: E402
