@@ -116,9 +116,11 @@ __device__ __forceinline__ void loop_barrier() {
 // v_permlane32_swap + per-pixel 16-byte stores is address-coalescer bound: 32 segments per instruction.)
 constexpr int WEP_ROW = 64 * 4 + 16;              // bytes per staged pixel row (+16: the 8 lanes of a store group hit 8 bank groups)
 constexpr int WEP_BYTES = 32 * WEP_ROW;           // per wave
+// `patch_w` > 0 (bhq_kernel): the wave's 128 rows are an 8-row x 16-column patch of one image; row_base is the pixel index of
+// its first pixel and patch_w the image width, so row r is pixel row_base + (r >> 4) * patch_w + (r & 15).
 template <bool HAS_RES, bool RES_POST, bool HAS_MASK, bool HAS_D2>
 __device__ __forceinline__ void q_epilogue_wave(const BGParams& p, f32x16 (&acc)[4][2], lds_char* W, int row_base, int cb0,
-                                                int lane, float slope) {
+                                                int lane, float slope, int patch_w = 0) {
     const int l31 = lane & 31, half = lane >> 5;
     const int c8 = (lane & 7) * 8, prow = lane >> 3;
     const int col = cb0 + c8;
@@ -145,7 +147,8 @@ __device__ __forceinline__ void q_epilogue_wave(const BGParams& p, f32x16 (&acc)
             const int px = 8 * i + prow;
             const f32x4 v0 = *(const lds_f4*)(W + px * WEP_ROW + c8 * 4);
             const f32x4 v1 = *(const lds_f4*)(W + px * WEP_ROW + c8 * 4 + 16);
-            const long r0 = row_base + mb * 32 + px;
+            const int rr = mb * 32 + px;
+            const long r0 = patch_w ? (long)row_base + (rr >> 4) * patch_w + (rr & 15) : (long)row_base + rr;
             if (!cok || r0 >= p.M) continue;
             float v[8] = {v0[0] + bv[0], v0[1] + bv[1], v0[2] + bv[2], v0[3] + bv[3], v1[0] + bv[4], v1[1] + bv[5], v1[2] + bv[6], v1[3] + bv[7]};
             float rv[8];
@@ -528,6 +531,224 @@ __global__ __launch_bounds__(512, 2) void bq_kernel(const BGParams p) {
 }
 
 // ================================================================================================
+// bhq_kernel: bq_kernel<2, 4> with bh_kernel's halo staging of the A operand (3 x 3 stride-1 windows: forward, and the stride-1 dgrad
+// = the same window with flipped taps).  The 128 rows of a wave row are an 8 x 16 patch of one image (a workgroup = a 16 x 16 region);
+// the patch WITH ITS HALO (10 x 18 pixels x 64 channels = 23 KB) is staged once per channel chunk and the nine taps read shifted
+// windows of it, so the k order is (chunk, tap) and only the 32-KB filter tile streams per k-tile: a wave issues 1 + 4 DMA pieces per
+// k-tile instead of 8 (the knock-out builds put the DMA stream at 21 % of the kernel), and the input is fetched once, not nine times.
+// LDS: A = [wave row][chunk parity][184 rows x 128 B] (92 KB), B as bq_kernel (64 KB).  The halo of chunk c + 1 is fetched during
+// chunk c, one piece per wave per k-tile: piece (tap * 8 + wave) mod 46 -- the 46 pieces are all issued by tap 5, taps 6..8 re-issue
+// pieces with the same data (a fixed count per phase keeps the counted waits simple).  Swizzle as bh_kernel: pixel (hy, hx) keeps its
+// 16-byte chunk c at slot c ^ ((hx >> 1) & 7).
+// ================================================================================================
+struct HQ {
+    static constexpr int P = 18, NPIX = 10 * 18, HROWS = 184, HALO_B = HROWS * ROWB, NPIECE = 23;
+    static constexpr int BSLOT = 64 * ROWB, B_OFF = 2 * 2 * HALO_B, SMEM = B_OFF + 4 * 2 * BSLOT;
+    static_assert(SMEM <= 163840 && 8 * WEP_BYTES <= SMEM, "LDS plan");
+};
+__global__ __launch_bounds__(512, 2) void bhq_kernel(const BGParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[HQ::SMEM];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 2, wc = wave & 3;
+    const int grp = wave >> 2;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    const int tile = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
+    const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+    const int n0 = nt * 256;
+    const int per_img = p.tiles_x * p.tiles_y;
+    const int img = mt / per_img;
+    const int trem = mt - img * per_img;
+    const int tyi = trem / p.tiles_x;
+    const int y0 = tyi * 16, x0 = (trem - tyi * p.tiles_x) * 16;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes);
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.B, p.b_bytes);
+    lds_char* const L = (lds_char*)smem;
+
+    // ---- halo DMA roles: in tap t this wave fetches piece id = (8 t + wave) mod 46 = (wave row j, piece q): halo pixels 8 q .. 8 q + 7
+    int h_voff[9], h_dst[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const int id = (8 * t + wave) % 46;
+        const int j = id / HQ::NPIECE, q = id - j * HQ::NPIECE;
+        const int hp = 8 * q + (lane >> 3);
+        const int hy = hp / HQ::P, hx = hp - hy * HQ::P;
+        const int y = y0 + 8 * j - 1 + hy, x = x0 - 1 + hx;
+        const bool ok = (hp < HQ::NPIX) & ((unsigned)y < (unsigned)p.Hs) & ((unsigned)x < (unsigned)p.Ws);
+        const int g = (lane & 7) ^ ((hx >> 1) & 7);
+        h_voff[t] = ok ? ((((img * p.Hs + y) * p.Ws + x) * p.lda) + g * 8) * 2 : (int)OOB;
+        h_dst[t] = (j * 2) * HQ::HALO_B + q * 8 * ROWB;
+    }
+    // ---- filter DMA roles (as bq_kernel<2, 4>): unit h, piece j: columns h*32 + 8*(wave & 3) .. +7 of wave column (wave >> 2) + 2j
+    const int prow = lane >> 3;
+    int b_voff[2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int tcol = ((wave >> 2) + 2 * j) * 64 + h * 32 + 8 * (wave & 3) + prow;
+            const int chunk = (lane & 7) ^ ((tcol >> 1) & 7);
+            const int nn = n0 + tcol;
+            b_voff[h][j] = (nn < p.Ncols) ? (nn * p.Cs + chunk * 8) * 2 : (int)OOB;
+        }
+    // ---- cursors.  k order (chunk, tap).  Staging cursor (filter tiles, two k-tiles ahead of the MFMAs) and compute cursor.
+    const int nkt = p.ktiles;
+    const int nch = p.cchunks;
+    const int cs2 = p.Cs * 2, nc2 = p.Ncols * cs2;
+    int st_left = nkt, st_ta = 0, st_tb = 0;
+    int st_kB = (p.w0 * p.Ncols * p.Cs) * 2;                           // tap (0, 0) of chunk 0
+    int st_dead = 0;
+    auto advance = [&]() {
+        --st_left;
+        if (st_left <= 0) {
+            st_dead = (int)OOB;
+        } else if (++st_tb == 3) {
+            st_tb = 0;
+            if (++st_ta == 3) {                                        // first tap of the next chunk
+                st_ta = 0;
+                st_kB += TK * 2 - (2 * p.wa + 2 * p.wb) * nc2;
+            } else {
+                st_kB += (p.wa - 2 * p.wb) * nc2;
+            }
+        } else {
+            st_kB += p.wb * nc2;
+        }
+    };
+    int dB = HQ::B_OFF + (wave >> 2) * (2 * HQ::BSLOT) + (8 * (wave & 3)) * ROWB;
+    int sB = HQ::BSLOT;
+    auto issueB = [&](int other, auto H) {
+        constexpr int h = decltype(H)::value;
+        const int d = (other ? dB + sB : dB) + h * 32 * ROWB;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) dma16l(rsB, b_voff[h][j] | st_dead, st_kB, L + (d + j * 4 * HQ::BSLOT));
+    };
+    auto issueH = [&](int t, int chunk) {                              // piece of tap slot t (a literal) for the halo of `chunk`
+        const int dead = chunk < nch ? 0 : (int)OOB;
+        dma16l(rsA, h_voff[t] | dead, chunk * (TK * 2), L + (h_dst[t] + (chunk & 1) * HQ::HALO_B));
+    };
+
+    // ---- fragment addresses ---------------------------------------------------------------------------------------------
+    const int fsw = (l31 >> 1) & 7;
+    int fb[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) fb[ks] = HQ::B_OFF + wc * (2 * HQ::BSLOT) + l31 * ROWB + (((2 * ks + half) ^ fsw) * 16);
+    const int f_tx = l31 & 15, f_tyl = l31 >> 4;
+    int fa[4];
+    auto set_fa = [&](int ta, int tb, int chunk) {                     // A fragment addresses of tap (ta, tb) of `chunk`'s halo
+        const int dyy = 1 + p.oy0 + ta * p.oys, dxx = 1 + p.ox0 + tb * p.oxs;
+        const int hx = f_tx + dxx;
+        const int sw = (hx >> 1) & 7;
+        const int base = (wr * 2 + (chunk & 1)) * HQ::HALO_B + ((dyy + f_tyl) * HQ::P + hx) * ROWB;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) fa[ks] = base + (((2 * ks + half) ^ sw) << 4);
+    };
+    auto lds16 = [&](int off) -> bf16x8 { return *(const __attribute__((address_space(3))) bf16x8*)(L + off); };
+    bf16x8 fA[2][4], fB0[4], fB1[4];
+    auto rdA = [&](auto MH) {
+        constexpr int mh = decltype(MH)::value;
+#pragma unroll
+        for (int mbi = 0; mbi < 2; ++mbi)
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) fA[mbi][ks] = lds16(fa[ks] + (mh * 4 + mbi * 2) * HQ::P * ROWB);
+    };
+    auto rdB = [&](auto NBK, bf16x8 (&f)[4]) {
+        constexpr int nb = decltype(NBK)::value;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) f[ks] = lds16(fb[ks] + nb * 32 * ROWB);
+    };
+    auto mma = [&](auto MH, auto NBK, const bf16x8 (&fbv)[4]) {
+        constexpr int mh = decltype(MH)::value, nb = decltype(NBK)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int mbi = 0; mbi < 2; ++mbi)
+                acc[2 * mh + mbi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fbv[ks], fA[mbi][ks], acc[2 * mh + mbi][nb], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+
+    // ---- prologue: the halo of chunk 0 (6 pieces per wave: all 46 + 2 repeats), filter tiles 0 and 1 ----------------------------
+#pragma unroll
+    for (int t = 0; t < 6; ++t) issueH(t, 0);
+    issueB(0, I0{});
+    issueB(0, I1{});
+    advance();
+    issueB(1, I0{});
+    issueB(1, I1{});
+    wait_vm<4>();                                    // halo 0 + filter tile 0 home (tile 1 may be in flight)
+    q_barrier();
+    if (grp == 1) q_barrier();                       // stagger: this group runs one barrier behind
+    for (int c = 0; c < nch; ++c) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+            set_fa(tap / 3, tap % 3, c);
+            // PA: rows mh0 x all 64 columns
+            rdB(I0{}, fB0);
+            rdB(I1{}, fB1);
+            __builtin_amdgcn_sched_barrier(0);
+            rdA(I0{});
+            __builtin_amdgcn_sched_barrier(0);
+            issueH(tap, c + 1);                      // next chunk's halo: one piece per k-tile
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            q_barrier();
+            mma(I0{}, I0{}, fB0);
+            mma(I0{}, I1{}, fB1);
+            q_barrier();
+            // PB: rows mh1
+            rdA(I1{});
+            __builtin_amdgcn_sched_barrier(0);
+            advance();
+            issueB(0, I0{});                         // filter tile t + 2 into the slot tile t was read from
+            issueB(0, I1{});
+            wait_vm<4>();                            // everything but those four pieces: filter tile t + 1 and this k-tile's halo piece
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            q_barrier();
+            mma(I1{}, I0{}, fB0);
+            mma(I1{}, I1{}, fB1);
+            q_barrier();
+            // next k-tile: the other filter slot
+            dB += sB;
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) fb[ks] += sB;
+            sB = -sB;
+        }
+    }
+    if (grp == 0) q_barrier();
+    wait_vm<0>();
+    __syncthreads();
+
+    // ---- epilogue: the wave-private transposing epilogue of bq_kernel; rows are patch pixels -----------------------------------
+    const bool hr = p.res != nullptr, hm = p.mask != nullptr, h2 = p.D2 != nullptr, rpost = p.res_post != 0;
+    const int kind = (!hr && !hm && !h2) ? 1 : ((hr && !rpost && !hm && !h2) ? 2 : ((!hr && hm && !h2) ? 3 : ((hr && rpost && !hm && h2) ? 4 : 5)));
+    const float slope = (p.act == DPIG_ACT_NONE) ? 1.f : ((p.act == DPIG_ACT_RELU) ? 0.f : p.alpha);
+    const int row_base = (img * p.Hs + y0 + 8 * wr) * p.Ws + x0, cb0 = n0 + wc * 64;
+    lds_char* W = L + wave * WEP_BYTES;
+    switch (kind) {
+        case 1: q_epilogue_wave<false, false, false, false>(p, acc, W, row_base, cb0, lane, slope, p.Ws); break;
+        case 2: q_epilogue_wave<true, false, false, false>(p, acc, W, row_base, cb0, lane, slope, p.Ws); break;
+        case 3: q_epilogue_wave<false, false, true, false>(p, acc, W, row_base, cb0, lane, slope, p.Ws); break;
+        case 4: q_epilogue_wave<true, true, false, true>(p, acc, W, row_base, cb0, lane, slope, p.Ws); break;
+        default: q_epilogue_wave<true, false, true, false>(p, acc, W, row_base, cb0, lane, slope, p.Ws); break;
+    }
+}
+
+// ================================================================================================
 // host side
 // ================================================================================================
 static int g_q_mode = -1;      // 0 off, 1 automatic, 2 whenever the layer is legal for the kernel (tests)
@@ -542,6 +763,19 @@ static void q_init() {
     g_q_variant = v ? atoi(v) : 0;
     const char* m = getenv("DPIG_BF16_Q_MINEFF");
     if (m) g_q_mineff = atof(m);
+}
+
+static int g_q_halo = []() { const char* e = getenv("DPIG_BF16_QH"); return e ? atoi(e) : 1; }();     // halo-staged variant (A/B switch)
+// 3 x 3 stride-1 window (forward / flipped-tap dgrad) on whole 16 x 16 regions with one of the five fused epilogues
+static bool bhq_eligible(const BGParams& p) {
+    if (p.ntaps != 9 || p.tap_nb != 3 || p.sr != 1 || !p.identity_rows || p.replicate || p.res_cls || p.stats) return false;
+    if (p.Hr != p.Hs || p.Wr != p.Ws || p.oys * p.oys != 1 || p.oxs * p.oxs != 1) return false;
+    if (1 + p.oy0 < 0 || 1 + p.oy0 + 2 * p.oys < 0 || 1 + p.oy0 > 2 || 1 + p.oy0 + 2 * p.oys > 2) return false;
+    if (1 + p.ox0 < 0 || 1 + p.ox0 + 2 * p.oxs < 0 || 1 + p.ox0 > 2 || 1 + p.ox0 + 2 * p.oxs > 2) return false;
+    if ((p.Hs & 15) || (p.Ws & 15) || (p.Cs % TK) || p.M % (p.Hs * p.Ws)) return false;
+    const bool hr = p.res != nullptr, hm = p.mask != nullptr, h2 = p.D2 != nullptr, rpost = p.res_post != 0;
+    const bool known = (!hr && !hm && !h2) || (hr && !rpost && !hm && !h2) || (!hr && hm && !h2) || (hr && rpost && !hm && h2) || (hr && !rpost && hm && !h2);
+    return known;
 }
 
 // Fraction of the launched MFMA work that is real when the tiles of bm x bn run `slots` at a time in whole rounds.
@@ -578,6 +812,14 @@ int bq_try(BGParams& p, hipStream_t st) {
     q.nsplit = 1;
     q.tiles_per_split = ktiles;
     dim3 grid(q.mtiles * q.ntiles, 1, 1), block(512);
+    if (variant == 1 && g_q_halo && bhq_eligible(p)) {
+        q.tiles_x = p.Ws / 16; q.tiles_y = p.Hs / 16;
+        q.mtiles = (p.M / (p.Hs * p.Ws)) * q.tiles_x * q.tiles_y;
+        dim3 hgrid(q.mtiles * q.ntiles, 1, 1);
+        hipLaunchKernelGGL(bhq_kernel, hgrid, block, 0, st, q);
+        const int rch = check_launch("bhq_kernel");
+        return rch ? rch : 1;
+    }
     if (variant == 1) hipLaunchKernelGGL((bq_kernel<2, 4>), grid, block, 0, st, q);
     else hipLaunchKernelGGL((bq_kernel<4, 2>), grid, block, 0, st, q);
     const int rc = check_launch("bq_kernel");

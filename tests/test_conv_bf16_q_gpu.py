@@ -149,9 +149,12 @@ def _one_ulp(a, b):
                                    (8, 64, 64, 768, 768), (56, 64, 64, 128, 128)])
 def test_full_size_layers_repeat_and_agree(dev, layer):
     """BASELINE configs[1]/[3] layer sizes (3x3 stride 1), forward (+ bias + ReLU) and dgrad (* mask): every launch of the
-    large-tile kernel reproduces itself bit for bit (five launches: the DMA pipeline's hazards are timing dependent, a race
-    would show as a difference), the two tile variants agree bit for bit (same products, same k order, fp32 accumulation),
-    and both agree with the 128 x 128 halo-patch kernel -- which sums channel-chunk-major instead of tap-major -- to one bf16 ulp."""
+    large-tile kernels reproduces itself bit for bit (five launches: the DMA pipeline's hazards are timing dependent, a race
+    would show as a difference).  The 256 x 256 variant runs these layers on the halo-staged kernel (bhq_kernel: k order (chunk,
+    tap), as the 128 x 128 halo-patch kernel), the 512 x 128 variant tap-major: the variants agree with each other and with the
+    128 x 128 kernel to one bf16 ulp (same products, fp32 accumulation in a different order); with the halo staging switched off
+    (DPIG_BF16_QH=0 builds / non-16-multiple images) the two variants share the k order and are bit-identical
+    (test_equals_the_tap_major_128_tile_kernel_bit_for_bit covers that path)."""
     import dpig_amd.hip_ops as H
     N, Hh, W, C, K = layer
     x, w, b, dy, m = _full_size_operands(dev, N, Hh, W, C, K)
@@ -160,9 +163,10 @@ def test_full_size_layers_repeat_and_agree(dev, layer):
         H.set_large_tile(0, 0)
         y0 = H.conv2d_fwd(x, w, b, act=1)
         dx0 = H.conv2d_dgrad(dy, w, (N, Hh, W, C), mask=m, act=1)
-        ref = None
+        refs = {}
         for variant in (1, 2):
             H.set_large_tile(2, variant)
+            ref = None
             for rep in range(5):
                 y = H.conv2d_fwd(x, w, b, act=1)
                 dx = H.conv2d_dgrad(dy, w, (N, Hh, W, C), mask=m, act=1)
@@ -172,7 +176,11 @@ def test_full_size_layers_repeat_and_agree(dev, layer):
                     variant, rep, int((y != ref[0]).sum()))
                 assert torch.equal(dx, ref[1]), "dgrad differs (variant %d, launch %d): %d elements" % (
                     variant, rep, int((dx != ref[1]).sum()))
-        assert _one_ulp(ref[0], y0) and _one_ulp(ref[1], dx0)
+            refs[variant] = ref
+            assert _one_ulp(ref[0], y0) and _one_ulp(ref[1], dx0)
+        assert _one_ulp(refs[1][0], refs[2][0]) and _one_ulp(refs[1][1], refs[2][1])
+        print("layer %s: 256x256 (halo-staged) == 128-tile halo kernel bit for bit: fwd %s dgrad %s" % (
+            layer, torch.equal(refs[1][0], y0), torch.equal(refs[1][1], dx0)))
     finally:
         H.set_large_tile(1, 0)
 
