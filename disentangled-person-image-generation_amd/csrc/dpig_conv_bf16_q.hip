@@ -537,8 +537,8 @@ __global__ __launch_bounds__(512, 2) void bq_kernel(const BGParams p) {
 // windows of it, so the k order is (chunk, tap) and only the 32-KB filter tile streams per k-tile: a wave issues 1 + 4 DMA pieces per
 // k-tile instead of 8 (the knock-out builds put the DMA stream at 21 % of the kernel), and the input is fetched once, not nine times.
 // LDS: A = [wave row][chunk parity][184 rows x 128 B] (92 KB), B as bq_kernel (64 KB).  The halo of chunk c + 1 is fetched during
-// chunk c, one piece per wave per k-tile: piece (tap * 8 + wave) mod 46 -- the 46 pieces are all issued by tap 5, taps 6..8 re-issue
-// pieces with the same data (a fixed count per phase keeps the counted waits simple).  Swizzle as bh_kernel: pixel (hy, hx) keeps its
+// chunk c, one piece per wave per k-tile of taps 0..5: piece tap * 8 + wave (< 46).  The per-phase wait is "everything but the four
+// filter pieces just issued", so it does not care whether a halo piece was issued in the phase before.  Swizzle as bh_kernel: pixel (hy, hx) keeps its
 // 16-byte chunk c at slot c ^ ((hx >> 1) & 7).
 // ================================================================================================
 struct HQ {
@@ -576,10 +576,10 @@ __global__ __launch_bounds__(512, 2) void bhq_kernel(const BGParams p) {
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.B, p.b_bytes);
     lds_char* const L = (lds_char*)smem;
 
-    // ---- halo DMA roles: in tap t this wave fetches piece id = (8 t + wave) mod 46 = (wave row j, piece q): halo pixels 8 q .. 8 q + 7
-    int h_voff[9], h_dst[9];
+    // ---- halo DMA roles: in tap t < 6 this wave fetches piece id = 8 t + wave (< 46) = (wave row j, piece q): halo pixels 8 q .. 8 q + 7
+    int h_voff[6], h_dst[6];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) {
+    for (int t = 0; t < 6; ++t) {
         const int id = (8 * t + wave) % 46;
         const int j = id / HQ::NPIECE, q = id - j * HQ::NPIECE;
         const int hp = 8 * q + (lane >> 3);
@@ -634,6 +634,7 @@ __global__ __launch_bounds__(512, 2) void bhq_kernel(const BGParams p) {
         for (int j = 0; j < 2; ++j) dma16l(rsB, b_voff[h][j] | st_dead, st_kB, L + (d + j * 4 * HQ::BSLOT));
     };
     auto issueH = [&](int t, int chunk) {                              // piece of tap slot t (a literal) for the halo of `chunk`
+        if (8 * t + wave >= 2 * HQ::NPIECE) return;                    // (wave-uniform) 46 pieces: taps 0..4 all waves, tap 5 waves 0..5
         const int dead = chunk < nch ? 0 : (int)OOB;
         dma16l(rsA, h_voff[t] | dead, chunk * (TK * 2), L + (h_dst[t] + (chunk & 1) * HQ::HALO_B));
     };
@@ -681,7 +682,7 @@ __global__ __launch_bounds__(512, 2) void bhq_kernel(const BGParams p) {
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
 
-    // ---- prologue: the halo of chunk 0 (6 pieces per wave: all 46 + 2 repeats), filter tiles 0 and 1 ----------------------------
+    // ---- prologue: the halo of chunk 0 (46 pieces over the 8 waves), filter tiles 0 and 1 ----------------------------
 #pragma unroll
     for (int t = 0; t < 6; ++t) issueH(t, 0);
     issueB(0, I0{});
@@ -702,7 +703,7 @@ __global__ __launch_bounds__(512, 2) void bhq_kernel(const BGParams p) {
             __builtin_amdgcn_sched_barrier(0);
             rdA(I0{});
             __builtin_amdgcn_sched_barrier(0);
-            issueH(tap, c + 1);                      // next chunk's halo: one piece per k-tile
+            if (tap < 6) issueH(tap, c + 1);         // next chunk's halo: one piece per wave in taps 0..5
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             q_barrier();
@@ -795,7 +796,8 @@ int bq_try(BGParams& p, hipStream_t st) {
     // Selection (automatic mode), from the A/B of scripts/bench_conv_bf16q.py (profiles/r03_conv_bf16_tile_ab.txt): a full
     // CU runs the 256 x 256 kernel ~1.15x and the 512 x 128 kernel ~1.04x as fast as two 128 x 128 workgroups; what decides
     // is how well each tile grid fills whole rounds of the chip (256 slots here, 512 there).
-    const double e1 = q_eff(p.M, p.Ncols, 256, 256, kNumCU) * 1.15, e2 = q_eff(p.M, p.Ncols, 512, 128, kNumCU) * 1.04;
+    const bool halo = g_q_halo && bhq_eligible(p);       // (the halo-staged 256 x 256 kernel: another ~5 %)
+    const double e1 = q_eff(p.M, p.Ncols, 256, 256, kNumCU) * (halo ? 1.21 : 1.15), e2 = q_eff(p.M, p.Ncols, 512, 128, kNumCU) * 1.04;
     int variant = g_q_variant ? g_q_variant : (e2 > e1 ? 2 : 1);
     if (g_q_mode == 1) {
         if (p.nsplit > 1) return 0;                      // the split-K plan of the 128 x 128 family wins on small layers
@@ -812,7 +814,7 @@ int bq_try(BGParams& p, hipStream_t st) {
     q.nsplit = 1;
     q.tiles_per_split = ktiles;
     dim3 grid(q.mtiles * q.ntiles, 1, 1), block(512);
-    if (variant == 1 && g_q_halo && bhq_eligible(p)) {
+    if (variant == 1 && halo) {
         q.tiles_x = p.Ws / 16; q.tiles_y = p.Hs / 16;
         q.mtiles = (p.M / (p.Hs * p.Ws)) * q.tiles_x * q.tiles_y;
         dim3 hgrid(q.mtiles * q.ntiles, 1, 1);
