@@ -546,6 +546,7 @@ struct HQ {
     static constexpr int BSLOT = 64 * ROWB, B_OFF = 2 * 2 * HALO_B, SMEM = B_OFF + 4 * 2 * BSLOT;
     static_assert(SMEM <= 163840 && 8 * WEP_BYTES <= SMEM, "LDS plan");
 };
+template <bool SLACK>
 __global__ __launch_bounds__(512, 2) void bhq_kernel(const BGParams p) {
     __shared__ __attribute__((aligned(16))) char smem[HQ::SMEM];
     const int tid = threadIdx.x;
@@ -716,7 +717,10 @@ __global__ __launch_bounds__(512, 2) void bhq_kernel(const BGParams p) {
             advance();
             issueB(0, I0{});                         // filter tile t + 2 into the slot tile t was read from
             issueB(0, I1{});
-            wait_vm<4>();                            // everything but those four pieces: filter tile t + 1 and this k-tile's halo piece
+            // filter tile t + 1 must be home; this k-tile's halo piece (issued in PA, needed only by the next chunk) may stay in flight
+            if (SLACK && tap < 5) wait_vm<5>();
+            else if (SLACK && tap == 5 && wave < 6) wait_vm<5>();
+            else wait_vm<4>();
             __builtin_amdgcn_sched_barrier(0);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             q_barrier();
@@ -818,7 +822,8 @@ int bq_try(BGParams& p, hipStream_t st) {
         q.tiles_x = p.Ws / 16; q.tiles_y = p.Hs / 16;
         q.mtiles = (p.M / (p.Hs * p.Ws)) * q.tiles_x * q.tiles_y;
         dim3 hgrid(q.mtiles * q.ntiles, 1, 1);
-        hipLaunchKernelGGL(bhq_kernel, hgrid, block, 0, st, q);
+        if (g_q_halo == 2) hipLaunchKernelGGL(bhq_kernel<true>, hgrid, block, 0, st, q);
+        else hipLaunchKernelGGL(bhq_kernel<false>, hgrid, block, 0, st, q);
         const int rch = check_launch("bhq_kernel");
         return rch ? rch : 1;
     }
