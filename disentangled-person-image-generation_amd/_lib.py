@@ -184,7 +184,7 @@ def stream_ptr():
 
 
 class _Workspace:
-    """Grow-only scratch buffer per device; the C ABI never allocates (SURVEY 8b ownership row)."""
+    """Grow-only scratch buffer per device and stream; the C ABI never allocates (SURVEY 8b ownership row)."""
 
     def __init__(self):
         self.buf = {}
@@ -199,7 +199,8 @@ class _Workspace:
     def get(self, nbytes, device):
         if nbytes == 0:
             return None, 0
-        key = (device.type, device.index)
+        # one buffer per (device, stream): launches on different streams (autograd.side_branch) may run concurrently
+        key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
         b = self.buf.get(key)
         if b is None or b.numel() < nbytes:
             if b is not None and self.pinned:

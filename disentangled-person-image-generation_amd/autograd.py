@@ -32,6 +32,48 @@ class no_param_grads(object):
 # pass.  ReLU masks are idempotent, so a gradient that lost its tag (autograd summed it with another consumer's) is simply masked again:
 # correctness never depends on the tag.  FUSE_INPUT_MASK[0] = False restores the separate pass (A/B, tests).
 FUSE_INPUT_MASK = [__import__('os').environ.get('DPIG_FUSE_INPUT_MASK', '1') != '0']
+# Independent towers of one graph on two HIP streams (models.py: the Fg / ROI tower beside the Bg tower of the two-branch
+# encoder).  The deep levels of either tower are launches of a few dozen workgroups; side by side they fill the CUs the other
+# leaves idle.  Results do not change (no atomics anywhere; every launch has its own per-stream workspace, _lib._Workspace).
+TWO_STREAM = [__import__('os').environ.get('DPIG_TWO_STREAM', '1') != '0']
+_SIDE_STREAMS = {}
+
+
+class side_branch(object):
+    """`with side_branch(x) as sb:` runs the block on this device's side stream, ordered after everything launched so far on the
+    current stream; `sb.join(t, ...)` afterwards makes the current stream wait for the block and returns the tensors for use on it.
+    Inactive (a plain block on the current stream) when TWO_STREAM is off or x is not on a GPU.  Backward: autograd replays each
+    node on the stream it was recorded on and orders gradients that cross streams by events; the block's first node (the consumer of
+    a current-stream tensor) runs last in backward, so the current stream's wait for ITS input gradient covers every launch of the
+    block's backward, including gradients our kernels write straight into the flat buffer."""
+
+    def __init__(self, x):
+        self.active = bool(TWO_STREAM[0]) and x.is_cuda
+        if self.active:
+            key = (x.device.index,)
+            if key not in _SIDE_STREAMS:
+                _SIDE_STREAMS[key] = torch.cuda.Stream(device=x.device)
+            self.side = _SIDE_STREAMS[key]
+            self.main = torch.cuda.current_stream(x.device)
+            self.ctx = torch.cuda.stream(self.side)
+
+    def __enter__(self):
+        if self.active:
+            self.side.wait_stream(self.main)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.active:
+            self.ctx.__exit__(*exc)
+        return False
+
+    def join(self, *tensors):
+        if self.active:
+            self.main.wait_stream(self.side)
+            for t in tensors:
+                t.record_stream(self.main)          # allocated on the side stream, read on this one
+        return tensors[0] if len(tensors) == 1 else tensors
 
 
 def _mark_relu_output(y, act):
@@ -63,6 +105,42 @@ def _sink(p, fn):
     return None
 
 
+# Filter gradients on their own stream: inside `with wgrad_overlap():` (the trainers' backward passes) every conv wgrad that sinks into
+# the flat gradient buffer is launched on one side stream, after the stream that produced dz; nothing in the backward chain waits for
+# it, so it runs beside the following layers' dgrads and fills their tails.  All contributions to one parameter stay in launch order
+# (one wgrad stream); leaving the block makes the current stream wait for the wgrad stream (finalize / all-reduce / Adam come after).
+WGRAD_STREAM = [__import__('os').environ.get('DPIG_WGRAD_STREAM', '0') != '0']
+_WG = {"on": False, "used": False, "streams": {}}
+
+
+class wgrad_overlap(object):
+    def __enter__(self):
+        self.prev = _WG["on"]
+        _WG["on"] = bool(WGRAD_STREAM[0])
+        return self
+
+    def __exit__(self, *exc):
+        _WG["on"] = self.prev
+        if not self.prev and _WG["used"]:
+            for dev, st in _WG["streams"].items():
+                torch.cuda.current_stream(dev).wait_stream(st)
+            _WG["used"] = False
+        return False
+
+
+def _wgrad_stream(x, dz):
+    """The wgrad stream, ordered after the current one (dz has just been produced on it); x / dz stay allocated for it."""
+    dev = x.device
+    st = _WG["streams"].get(dev)
+    if st is None:
+        st = _WG["streams"][dev] = torch.cuda.Stream(device=dev)
+    st.wait_stream(torch.cuda.current_stream(dev))
+    x.record_stream(st)
+    dz.record_stream(st)
+    _WG["used"] = True
+    return st
+
+
 def _sink_wgrad_bias(w, b, x, dz, stride=1, upsample2x=False, want_w=True, want_b=True):
     """Filter gradient (+ bias gradient in the same launch when both go to flat sinks)."""
     dw = db = None
@@ -70,8 +148,13 @@ def _sink_wgrad_bias(w, b, x, dz, stride=1, upsample2x=False, want_w=True, want_
     bbuf = getattr(b, "_dpig_grad", None) if (want_b and b is not None) else None
     if wbuf is not None and bbuf is not None:
         wt, bt = w._dpig_touched, b._dpig_touched
-        H.conv2d_wgrad(x, dz, tuple(w.shape), stride=stride, upsample2x=upsample2x, out=wbuf,
-                       beta=1.0 if wt[0] else 0.0, db=bbuf, db_beta=1.0 if bt[0] else 0.0)
+        if _WG["on"] and x.is_cuda and not torch.is_grad_enabled():
+            with torch.cuda.stream(_wgrad_stream(x, dz)):
+                H.conv2d_wgrad(x, dz, tuple(w.shape), stride=stride, upsample2x=upsample2x, out=wbuf,
+                               beta=1.0 if wt[0] else 0.0, db=bbuf, db_beta=1.0 if bt[0] else 0.0)
+        else:
+            H.conv2d_wgrad(x, dz, tuple(w.shape), stride=stride, upsample2x=upsample2x, out=wbuf,
+                           beta=1.0 if wt[0] else 0.0, db=bbuf, db_beta=1.0 if bt[0] else 0.0)
         wt[0] = True
         bt[0] = True
         return None, None

@@ -136,14 +136,16 @@ def GeneratorCNN_ID_Encoder_BodyROIVis_FgBgFeaTwoBranch(x, fg_mask, ROI_bboxs, R
         x_fg, x_bg = A.mask_split(x, fg_mask)          # x * m, x * (1 - m): one launch (csrc/dpig_glue.hip)
 
         boxes, box_ind = _normalised_boxes(ROI_bboxs, bbox_num, img_H, img_W)
-        body_regions = A.crop_and_resize(x_fg, boxes, box_ind, roi_size, roi_size)
-        conv_fea_list = [body_regions, x_bg]
-        _tap("E.rois", body_regions)
+        with A.side_branch(x_fg) as fg_branch:          # the ROI tower beside the background branch (A.TWO_STREAM)
+            body_regions = A.crop_and_resize(x_fg, boxes, box_ind, roi_size, roi_size)
+            conv_fea_list = [body_regions, x_bg]
+            _tap("E.rois", body_regions)
 
-        # Share weights for different body regions
-        body_regions = _roi_tower(body_regions, z_num, repeat_num, hidden_num, data_format, activation_fn)
+            # Share weights for different body regions
+            body_regions = _roi_tower(body_regions, z_num, repeat_num, hidden_num, data_format, activation_fn)
         fused_cat = keep_part_prob >= 1.0
         if not fused_cat:
+            body_regions = fg_branch.join(body_regions)
             fea_list = _apply_vis(body_regions, ROI_vis, bbox_num, z_num)
             for i in range(bbox_num):
                 keep = (torch.rand(batch_num, 1, device=x.device) < keep_part_prob).to(torch.float32)
@@ -160,6 +162,7 @@ def GeneratorCNN_ID_Encoder_BodyROIVis_FgBgFeaTwoBranch(x, fg_mask, ROI_bboxs, R
         x_bg = fully_connected(x_bg, z_num * 4, activation_fn=None)
 
         if fused_cat:
+            body_regions = fg_branch.join(body_regions)
             # visibility multiply (models.py:433-442) + tf.concat(fea_list, -1) (:467-468) as one launch; fea_list = views
             fea_all = A.vis_concat(body_regions, ROI_vis, x_bg, bbox_num, z_num)
             fea_list = [fea_all[:, i * z_num:(i + 1) * z_num] for i in range(bbox_num)] + [fea_all[:, bbox_num * z_num:]]

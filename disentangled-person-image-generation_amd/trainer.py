@@ -687,7 +687,8 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         """Stage 1: critic (dgrad only) + generator, down to the embedding; the decoder slice of the flat gradient
         is complete afterwards."""
         dec = self.G_flat.params[:self._n_dec]
-        res = torch.autograd.grad(g_loss, [embs] + dec, allow_unused=True)
+        with A.wgrad_overlap():
+            res = torch.autograd.grad(g_loss, [embs] + dec, allow_unused=True)
         self._sunk_or_copy(dec, res[1:])
         self.D_flat.set_requires_grad(True)
         self.G_flat.finalize(0, self._n_dec)
@@ -696,7 +697,8 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
     def _g_backward_encoder(self, embs, d_embs):
         """Stage 2: the encoder, from the embedding gradient."""
         enc = self.G_flat.params[self._n_dec:]
-        res = torch.autograd.grad(embs, enc, grad_outputs=d_embs, allow_unused=True)
+        with A.wgrad_overlap():
+            res = torch.autograd.grad(embs, enc, grad_outputs=d_embs, allow_unused=True)
         self._sunk_or_copy(enc, res)
         self.G_flat.finalize(self._n_dec, None)
 
@@ -711,7 +713,8 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
                 h += self.allreduce.start(self.G_flat.grad[self._enc_off:])
                 self.g_opt.step(self.allreduce.finish(h))
         else:
-            g_loss.backward()
+            with A.wgrad_overlap():
+                g_loss.backward()
             self.D_flat.set_requires_grad(True)
             self.G_flat.finalize()
             if update:
@@ -729,7 +732,8 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         _, d_loss = gan_loss(self.wgan_gp, D_z_pos, D_z_neg, Discriminator=self.discriminate,
                              real_data=batch["x"], fake_data=G, alpha=getattr(self, "gp_alpha", None),   # (tests pin alpha)
                              fused_gp=self._fused_gp())
-        d_loss.backward()
+        with A.wgrad_overlap():
+            d_loss.backward()
         self.D_flat.finalize()
         if update:
             self.d_opt.step(self.allreduce(self.D_flat.grad))

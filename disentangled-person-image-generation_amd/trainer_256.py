@@ -10,6 +10,7 @@ Stage II (run_DF_train.sh:39-77), at the end of this file: model 102 `DPIG_Encod
 auto-encoder) and model 104 `DPIG_subnetSamplePoseRCV_GAN_BodyROI_256` (:511-700, the pose-embedding GAN)."""
 import torch
 
+from . import autograd as A
 from . import hip_ops as H
 from . import models
 from . import slim
@@ -113,7 +114,8 @@ class DPIG_Encoder_subSampleAppNet_GAN_BodyROI_256(object):
         fake, _ = self.mapper(self.dim, z)
         _, D_neg = self.critic_pair(real, fake)
         g_loss, _ = gan_loss(self.wgan_gp_encoder, None, D_neg)
-        g_loss.backward()
+        with A.wgrad_overlap():
+            g_loss.backward()
         self.D_flat.set_requires_grad(True)
         self.G_flat.finalize()
         self.g_opt.step(self.allreduce(self.G_flat.grad))
@@ -126,7 +128,8 @@ class DPIG_Encoder_subSampleAppNet_GAN_BodyROI_256(object):
             fake, _ = self.mapper(self.dim, z)
         D_pos, D_neg = self.critic_pair(real, fake)
         _, d_loss = gan_loss(self.wgan_gp_encoder, D_pos, D_neg)
-        d_loss.backward()
+        with A.wgrad_overlap():
+            d_loss.backward()
         self.D_flat.finalize()
         self.d_opt.step(self.allreduce(self.D_flat.grad))
         if self.wgan_gp_encoder.MODE == 'wgan':

@@ -18,6 +18,7 @@ Every critic update re-runs the (conv-heavy) encoder forward, which is where the
 """
 import torch
 
+from . import autograd as A
 from . import models
 from . import slim
 from . import tflib as lib
@@ -98,7 +99,8 @@ class DPIG_Encoder_subSampleAppNetFgBg_GAN_BodyROI(object):
         df.set_requires_grad(False)
         app, _ = self.mapper(side, self.dims[side], z=z)
         g_loss, _ = gan_loss(self.sides[side]["wg"], None, self.critic(side, app))
-        g_loss.backward()
+        with A.wgrad_overlap():
+            g_loss.backward()
         df.set_requires_grad(True)
         gf.finalize()
         self.opts[side][0].step(self.allreduce(gf.grad))
@@ -114,7 +116,8 @@ class DPIG_Encoder_subSampleAppNetFgBg_GAN_BodyROI(object):
         real = real.contiguous()
         _, d_loss = gan_loss(self.sides[side]["wg"], self.critic(side, real), self.critic(side, app),
                              Discriminator=lambda t: self.critic(side, t), real_data=real, fake_data=app)
-        d_loss.backward()
+        with A.wgrad_overlap():
+            d_loss.backward()
         df.finalize()
         self.opts[side][1].step(self.allreduce(df.grad))
         if self.sides[side]["wg"].MODE == 'wgan':
@@ -210,7 +213,8 @@ class DPIG_PoseRCV_AE_BodyROI(object):
         self.G_flat.zero_grad()
         norm, _, G_pose_rcv, _ = self.autoencode(batch["pose_rcv"])
         loss = self.reconstruct_loss(norm, G_pose_rcv)
-        (loss * 20).backward()
+        with A.wgrad_overlap():
+            (loss * 20).backward()
         self.G_flat.finalize()
         self.g_opt.step(self.allreduce(self.G_flat.grad))
         return {"reconstruct_loss": loss.detach(), "G_pose_rcv": G_pose_rcv.detach()}
@@ -298,7 +302,8 @@ class DPIG_subnetSamplePoseRCV_GAN_BodyROI(DPIG_PoseRCV_AE_BodyROI):
         fake, _ = self.mapper(z)
         _, D_neg = self.critic_pair(real, fake)
         g_loss, _ = gan_loss(self.wgan_gp_encoder, None, D_neg)
-        g_loss.backward()
+        with A.wgrad_overlap():
+            g_loss.backward()
         self.D_flat.set_requires_grad(True)
         self.G_flat.finalize()
         self.g_opt.step(self.allreduce(self.G_flat.grad))
@@ -311,7 +316,8 @@ class DPIG_subnetSamplePoseRCV_GAN_BodyROI(DPIG_PoseRCV_AE_BodyROI):
             fake, _ = self.mapper(z)
         D_pos, D_neg = self.critic_pair(real, fake)
         _, d_loss = gan_loss(self.wgan_gp_encoder, D_pos, D_neg)
-        d_loss.backward()
+        with A.wgrad_overlap():
+            d_loss.backward()
         self.D_flat.finalize()
         self.d_opt.step(self.allreduce(self.D_flat.grad))
         if self.wgan_gp_encoder.MODE == 'wgan':

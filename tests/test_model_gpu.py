@@ -178,6 +178,41 @@ def test_input_mask_fusion_is_bit_identical_and_active(dev, dtype):
     lib.delete_all_params()
 
 
+@pytest.mark.parametrize("dtype,graphs", [("f32", False), ("bf16", False), ("f32", True)])
+def test_two_stream_towers_are_bit_identical(dev, dtype, graphs):
+    """The ROI tower on a side stream beside the background branch (autograd.side_branch, models.py two-branch encoder): same
+    kernels, same operands, a workspace per stream -- losses and every gradient / weight must be IDENTICAL to the one-stream run,
+    eagerly (g_optim gradients, then a d_optim update) and through hipGraph replay (weights after two full steps)."""
+    import dpig_amd.tflib as lib
+    from dpig_amd import autograd as A, hip_ops as H
+    res = {}
+    defaults = (A.TWO_STREAM[0], A.WGRAD_STREAM[0])
+    try:
+        for two in (False, True):
+            A.TWO_STREAM[0] = two
+            A.WGRAD_STREAM[0] = two                  # ... and the filter gradients on their own stream (autograd.wgrad_overlap)
+            tr, gb, P, ob, OM = _setup(dev)
+            tr.config.compute_dtype = dtype
+            if graphs:
+                tr.enable_graphs(gb, gb)
+                tr.step = 1
+                outs = [tr.train_step(gb, gb) for _ in range(2)]
+                torch.cuda.synchronize()
+                res[two] = (tr.G_flat.flat.clone(), tr.D_flat.flat.clone(), outs[-1]["g_loss"].item(), outs[-1]["d_loss"].item())
+            else:
+                o = tr._g_optim_eager(gb, update=False)
+                g = tr.G_flat.grad.clone()
+                od = tr._d_optim_eager(gb, update=True)
+                torch.cuda.synchronize()
+                res[two] = (g, tr.D_flat.flat.clone(), o["g_loss"].item(), od["d_loss"].item())
+            lib.delete_all_params()
+    finally:
+        A.TWO_STREAM[0], A.WGRAD_STREAM[0] = defaults
+        H.set_compute("f32")
+    assert res[True][2] == res[False][2] and res[True][3] == res[False][3]
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+
+
 def test_trunk_gradients_linear_readout(dev):
     """d/dtheta of <G, r> for a fixed random r: every E+G kernel's backward, no D, no |.| kink."""
     import dpig_amd.tflib as lib
