@@ -36,6 +36,8 @@ FUSE_INPUT_MASK = [__import__('os').environ.get('DPIG_FUSE_INPUT_MASK', '1') != 
 # encoder).  The deep levels of either tower are launches of a few dozen workgroups; side by side they fill the CUs the other
 # leaves idle.  Results do not change (no atomics anywhere; every launch has its own per-stream workspace, _lib._Workspace).
 TWO_STREAM = [__import__('os').environ.get('DPIG_TWO_STREAM', '1') != '0']
+# d_optim in MODE 'dcgan': the critic's pass over the real images (forward AND backward) on a side stream beside the generator's forward
+D_OVERLAP = [__import__('os').environ.get('DPIG_D_OVERLAP', '1') != '0']
 _SIDE_STREAMS = {}
 
 
@@ -47,10 +49,10 @@ class side_branch(object):
     a current-stream tensor) runs last in backward, so the current stream's wait for ITS input gradient covers every launch of the
     block's backward, including gradients our kernels write straight into the flat buffer."""
 
-    def __init__(self, x):
-        self.active = bool(TWO_STREAM[0]) and x.is_cuda
+    def __init__(self, x, key="tower", enabled=None):
+        self.active = bool(TWO_STREAM[0] if enabled is None else enabled) and x.is_cuda
         if self.active:
-            key = (x.device.index,)
+            key = (x.device.index, key)
             if key not in _SIDE_STREAMS:
                 _SIDE_STREAMS[key] = torch.cuda.Stream(device=x.device)
             self.side = _SIDE_STREAMS[key]

@@ -725,6 +725,9 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         """sess.run(d_optim): fwd E,G (no grad), D(x), D(G); d_loss; bwd D; Adam(D)."""
         H.set_compute(getattr(self.config, "compute_dtype", "f32"))
         self.D_flat.zero_grad()
+        if (A.D_OVERLAP[0] and self.wgan_gp.MODE == 'dcgan' and batch["x"].is_cuda
+                and type(self).disc_pair is DPIG_Encoder_GAN_BodyROI_FgBg.disc_pair):
+            return self._d_optim_overlapped(batch, update)
         with torch.no_grad():
             embs, _ = self.encode(batch)
             G, _ = self.generate(embs, pose_input(batch, self.img_H, self.img_W))
@@ -738,6 +741,27 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         if update:
             self.d_opt.step(self.allreduce(self.D_flat.grad))
         return {"d_loss": d_loss.detach()}
+
+    def _d_optim_overlapped(self, batch, update):
+        """MODE 'dcgan', separate critic passes (trainer.py:601-602): d_loss = (sce(D(G), 0) + sce(D(x), 1)) / 2 is a sum of a term that
+        needs the generator and one that does not.  The real-image term -- critic forward AND backward -- runs on a side stream beside
+        the encoder / generator forward; the fake term follows on the current stream and accumulates into the same gradient slices
+        (two-term sums: the order of the two contributions does not change a bit)."""
+        with A.side_branch(batch["x"], key="critic", enabled=True) as sb:
+            l_real = A.sce_mean(self.discriminate(batch["x"]), 1.0)
+            (l_real / 2.).backward()
+            l_real = l_real.detach()
+        with torch.no_grad():
+            embs, _ = self.encode(batch)
+            G, _ = self.generate(embs, pose_input(batch, self.img_H, self.img_W))
+        l_real = sb.join(l_real)
+        l_fake = A.sce_mean(self.discriminate(G), 0.0)
+        (l_fake / 2.).backward()
+        d_loss = (l_fake.detach() + l_real) / 2.
+        self.D_flat.finalize()
+        if update:
+            self.d_opt.step(self.allreduce(self.D_flat.grad))
+        return {"d_loss": d_loss}
 
     def train_step(self, batch_g, batch_d):
         """One iteration of the reference loop (trainer.py:336-347, 362-363).  `batch_d` is one batch, or a sequence of

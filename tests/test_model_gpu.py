@@ -186,11 +186,12 @@ def test_two_stream_towers_are_bit_identical(dev, dtype, graphs):
     import dpig_amd.tflib as lib
     from dpig_amd import autograd as A, hip_ops as H
     res = {}
-    defaults = (A.TWO_STREAM[0], A.WGRAD_STREAM[0])
+    defaults = (A.TWO_STREAM[0], A.WGRAD_STREAM[0], A.D_OVERLAP[0])
     try:
         for two in (False, True):
             A.TWO_STREAM[0] = two
             A.WGRAD_STREAM[0] = two                  # ... and the filter gradients on their own stream (autograd.wgrad_overlap)
+            A.D_OVERLAP[0] = two                     # ... and the critic's real-image pass beside the generator forward (d_optim)
             tr, gb, P, ob, OM = _setup(dev)
             tr.config.compute_dtype = dtype
             if graphs:
@@ -207,7 +208,7 @@ def test_two_stream_towers_are_bit_identical(dev, dtype, graphs):
                 res[two] = (g, tr.D_flat.flat.clone(), o["g_loss"].item(), od["d_loss"].item())
             lib.delete_all_params()
     finally:
-        A.TWO_STREAM[0], A.WGRAD_STREAM[0] = defaults
+        A.TWO_STREAM[0], A.WGRAD_STREAM[0], A.D_OVERLAP[0] = defaults
         H.set_compute("f32")
     assert res[True][2] == res[False][2] and res[True][3] == res[False][3]
     assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
