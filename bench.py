@@ -359,14 +359,14 @@ def main():
         graphs = getattr(tr, "_graphs", None)
         tr._graphs = None                              # eager launches so that each one can be bracketed
         from dpig_amd import autograd as _A
-        two_stream = _A.TWO_STREAM[0]
-        _A.TWO_STREAM[0] = False                       # ... and on ONE stream, so that every launch is timed alone (the timed steps
-        try:                                           # above run the encoder's two towers side by side, autograd.side_branch)
+        side = (_A.TWO_STREAM[0], _A.D_OVERLAP[0])
+        _A.TWO_STREAM[0] = _A.D_OVERLAP[0] = False     # ... and on ONE stream, so that every launch is timed alone (the timed steps
+        try:                                           # above run independent towers / critic passes side by side)
             for _ in range(nrep):
                 step_fn()
             torch.cuda.synchronize()
         finally:
-            _A.TWO_STREAM[0] = two_stream
+            _A.TWO_STREAM[0], _A.D_OVERLAP[0] = side
         tr._graphs = graphs
         recs = [(r[0], r[1], r[2].elapsed_time(r[3]) * 1e-3) for r in H.PROFILE]
         H.PROFILE = None
@@ -399,7 +399,7 @@ def main():
                     "flops_per_launch": flops / nl, "avg_launch_us": round(secs / nl * 1e6, 2),
                     "time_share_of_step": round(secs / nrep / (ms_per_step * 1e-3), 3),
                     "timing": "HIP events around every launch of an eager replay of the same step on ONE stream (each launch alone on "
-                              "the GPU); the timed steps overlap the encoder's two towers on two streams"}
+                              "the GPU); the timed steps overlap the encoder's two towers, and the critic's real-image pass with the generator forward, on side streams"}
         by = {}
         for k, f, t in recs:
             a = by.setdefault(k, [0, 0.0, 0.0])
