@@ -134,3 +134,39 @@ def test_packed_batch_layout_round_trip():
     assert all(out[k].dtype == b[k].dtype and torch.equal(out[k], b[k]) for k in b)
     assert L.matches(b) and not L.matches({k: v for k, v in b.items() if k != "vis"})
     assert not L.matches(dict(b, x=b["x"].double()))
+
+
+def test_side_branch_and_wgrad_overlap_are_plain_blocks_without_a_gpu():
+    """autograd.side_branch / wgrad_overlap (independent sub-graphs on side HIP streams) must be inert for host tensors: same
+    objects out, no stream API touched, switches restored."""
+    import torch
+    from dpig_amd import autograd as A
+    x = torch.randn(3, 4)
+    with A.side_branch(x) as sb:
+        assert not sb.active
+        y = x * 2
+    assert sb.join(y) is y
+    a, b = sb.join(y, x)
+    assert a is y and b is x
+    with A.side_branch(x, key="critic", enabled=True) as sb2:
+        assert not sb2.active                              # enabled, but not a GPU tensor
+    on = A._WG["on"]
+    with A.wgrad_overlap():
+        assert A._WG["on"] == bool(A.WGRAD_STREAM[0])
+        with A.wgrad_overlap():                            # nested: the outer block owns the join
+            pass
+    assert A._WG["on"] == on and not A._WG["used"]
+
+
+def test_workspace_is_per_device_and_stream_key():
+    """_lib._Workspace: grow-only, one buffer per key; a pinned (graph-captured) buffer that must grow is retired, not freed."""
+    import torch
+    from dpig_amd._lib import _Workspace
+    ws = _Workspace()
+    dev = torch.device("cpu")
+    assert ws.get(0, dev) == (None, 0)
+    b1, n1 = ws.get(100, dev)
+    assert n1 >= 100 and ws.get(50, dev)[0] is b1                     # re-used while it is large enough
+    ws.pin()
+    b2, n2 = ws.get(n1 + 1, dev)
+    assert b2 is not b1 and n2 > n1 and any(r is b1 for r in ws.retired)
