@@ -68,6 +68,38 @@ def batchnorm_train(x, scale, offset, eps=1e-5):
     return (x - mean) / torch.sqrt(var + eps) * scale + offset
 
 
+def batchnorm_inference_blend(x, scale, offset, moving_mean, moving_variance, eps=1e-5):
+    """`_fused_batch_norm_inference` (tflib/ops/batchnorm.py:31-37): each item's own moments over (H, W), blended 1/B : (B-1)/B with
+    the moving statistics, then tf.nn.batch_normalization with eps inside the sqrt.  x is NHWC here (the reference passes NCHW)."""
+    bs = float(x.shape[0])
+    mean = x.mean(dim=(1, 2), keepdim=True)
+    var = ((x - mean) ** 2).mean(dim=(1, 2), keepdim=True)
+    mean = (1. / bs) * mean + ((bs - 1.) / bs) * moving_mean
+    var = (1. / bs) * var + ((bs - 1.) / bs) * moving_variance
+    return (x - mean) / torch.sqrt(var + eps) * scale + offset
+
+
+def batchnorm_moving_update(x, moving_mean, moving_variance, stats_iter):
+    """`_force_updates` (tflib/ops/batchnorm.py:57-68): running averages with weight 1/(stats_iter+1) of the batch moments that
+    tf.nn.fused_batch_norm RETURNS in training mode -- the mean, and the variance with Bessel's correction n/(n-1), n = N*H*W
+    (the normalisation itself uses the biased variance).  x NHWC; returns the new (moving_mean, moving_variance)."""
+    C = x.shape[-1]
+    xf = x.reshape(-1, C)
+    n = xf.shape[0]
+    bm = xf.mean(0)
+    bv = ((xf - bm) ** 2).sum(0) / (n - 1)
+    it = float(stats_iter)
+    return (it / (it + 1)) * moving_mean + (1 / (it + 1)) * bm, (it / (it + 1)) * moving_variance + (1 / (it + 1)) * bv
+
+
+def batchnorm_unfused(x, axes, scale, offset, eps=1e-5):
+    """The non-fused branch (tflib/ops/batchnorm.py:74-87): tf.nn.moments over `axes` with keep_dims, parameters shaped like the kept
+    dims (batch dim forced to 1 when 0 is not in axes), tf.nn.batch_normalization.  x in the caller's own layout."""
+    mean = x.mean(dim=tuple(axes), keepdim=True)
+    var = ((x - mean) ** 2).mean(dim=tuple(axes), keepdim=True)
+    return (x - mean) / torch.sqrt(var + eps) * scale + offset
+
+
 def layernorm(x, scale, offset, eps=1e-5):
     """tflib/ops/layernorm.py:6-20 with norm_axes [1,2,3]: per-sample moments over (C,H,W),
     per-channel scale/offset.  x NHWC."""

@@ -54,6 +54,43 @@ def test_adjoint_identities_and_linearity(dev, layer):
     assert torch.equal(H.conv2d_wgrad(x, dy, (k, k, C, K), stride=s, upsample2x=up), dw)
 
 
+# the decoder 3x3 layers of SURVEY 8(d)'s target list at the FULL Market batch (B = 16): (name, H, W, C)
+DECODER_LAYERS = [("dec4", 128, 64, 256), ("dec3", 64, 32, 512), ("dec2", 32, 16, 768), ("dec1", 16, 8, 1024), ("dec0", 8, 4, 768)]
+
+
+@pytest.mark.parametrize("layer", DECODER_LAYERS, ids=[l[0] for l in DECODER_LAYERS])
+def test_full_batch_decoder_layers_against_the_fp64_oracle(dev, layer):
+    """B = 16 decoder convs (implicit GEMMs 131072x256x2304 ... 512x768x6912) against oracle.ops.conv2d_same evaluated in fp64 on the host,
+    forward (+ bias + ReLU in the epilogue), dgrad and wgrad + bias gradient (the oracle's own autograd).  Operands are fp32-representable,
+    so the only difference is the kernels' fp32 accumulation: bars 1e-4 of max|ref| (k <= 9216 terms), 2e-4 for the filter gradient
+    (k = up to 131072 pixels)."""
+    import dpig_amd.hip_ops as H
+    from oracle import ops as O
+    _, Hh, W, C = layer
+    N = 16
+    g = torch.Generator().manual_seed(Hh * 7 + C)
+    x = (torch.rand((N, Hh, W, C), generator=g) * 2 - 1)
+    w = (torch.rand((3, 3, C, C), generator=g) * 2 - 1) * (1.5 / (9 * C) ** 0.5)
+    b = torch.rand((C,), generator=g) - 0.5
+    dy = (torch.rand((N, Hh, W, C), generator=g) * 2 - 1)
+    xd, wd, bd = x.double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    ref = O.conv2d_same(xd, wd, bd, 1)
+    rdx, rdw, rdb = torch.autograd.grad(ref, [xd, wd, bd], dy.double())
+    xg, wg, bg, dyg = x.to(dev), w.to(dev), b.to(dev), dy.to(dev)
+
+    def close(got, want, tol):
+        err = (got.double().cpu() - want).abs().max().item()
+        assert err <= tol * want.abs().max().item(), (err, want.abs().max().item())
+    close(H.conv2d_fwd(xg, wg, bg), ref.detach(), 1e-4)
+    close(H.conv2d_fwd(xg, wg, bg, act=1), torch.relu(ref.detach()), 1e-4)
+    close(H.conv2d_dgrad(dyg, wg, (N, Hh, W, C)), rdx, 1e-4)
+    dw = torch.empty((3, 3, C, C), device=dev)
+    db = torch.empty((C,), device=dev)
+    H.conv2d_wgrad(xg, dyg, (3, 3, C, C), out=dw, db=db)
+    close(dw, rdw, 2e-4)
+    close(db, rdb, 2e-4)
+
+
 def test_constant_input_gives_border_classes(dev):
     """SAME 3x3 conv of an all-ones image: every output pixel equals the sum of the filter taps that fall inside the
     image, i.e. one of 9 values per output channel (what the tiled-embedding collapse relies on)."""

@@ -604,3 +604,31 @@ def test_keypoint_fed_stem_conv_equals_the_dense_conv_on_the_rasterised_map(dev,
         assert float((gw[:, :, E:, :].cpu().double() - d_w[:, :, E:, :]).abs().max()) <= gtol * float(d_w[:, :, E:, :].abs().max())
     finally:
         H.set_compute("f32")
+
+
+def test_batchnorm_training_flag_updates_the_moving_statistics(dev):
+    """Batchnorm(..., is_training=True, stats_iter=k) (tflib/ops/batchnorm.py:51-68; off the hot path, where is_training is None): the output
+    is the training-mode normalisation and the moving statistics become the 1/(k+1) running averages of the batch mean and of the
+    Bessel-corrected batch variance (what tf.nn.fused_batch_norm returns); update_moving_stats=False and is_training=None leave them alone."""
+    import dpig_amd.tflib as lib
+    import dpig_amd.tflib.ops  # noqa
+    from oracle import ops as O
+    lib.delete_all_params()
+    lib.set_device(dev)
+    x = _rand((4, 9, 7, 12), 3)                                       # NHWC
+    xg = x.float().to(dev).permute(0, 3, 1, 2)
+    mm0, mv0 = _rand((12,), 4), _rand((12,), 5, 0.5, 1.5)
+    lib.param('M.moving_mean', mm0.float().numpy(), trainable=False)
+    lib.param('M.moving_variance', mv0.float().numpy(), trainable=False)
+    y = lib.ops.batchnorm.Batchnorm('M', [0, 2, 3], xg, is_training=True, stats_iter=3)
+    one, zero = torch.ones(12, dtype=torch.float64), torch.zeros(12, dtype=torch.float64)
+    _close(y.permute(0, 2, 3, 1), O.batchnorm_train(x, one, zero), 1e-4)
+    rm, rv = O.batchnorm_moving_update(x, mm0, mv0, 3)
+    _close(lib.param('M.moving_mean'), rm, 1e-5)
+    _close(lib.param('M.moving_variance'), rv, 1e-5)
+    before = (lib.param('M.moving_mean').clone(), lib.param('M.moving_variance').clone())
+    lib.ops.batchnorm.Batchnorm('M', [0, 2, 3], xg, is_training=True, stats_iter=4, update_moving_stats=False)
+    lib.ops.batchnorm.Batchnorm('M', [0, 2, 3], xg)                   # the hot path's call: statistics created, never updated
+    assert torch.equal(lib.param('M.moving_mean'), before[0]) and torch.equal(lib.param('M.moving_variance'), before[1])
+    lib.delete_all_params()
+

@@ -392,3 +392,71 @@ def test_oracle_reproduces_stage2_df256_golden():
     for k in want.keys():
         scale = max(float(np.abs(want[k]).max()), 1e-12)
         assert float(np.abs(np.asarray(got[k], dtype=np.float64) - want[k]).max()) <= 1e-9 * scale, k
+
+
+def test_batchnorm_side_branches_against_numpy_loops():
+    """The oracle's restatements of the reference Batchnorm's non-training branches (batchnorm.py:31-37, 57-68, 74-87) against
+    explicit numpy loops over channels / items."""
+    from oracle import ops as O
+    rng = np.random.RandomState(3)
+    x = rng.randn(3, 5, 4, 6)
+    sc, of, mm, mv = rng.rand(6) + 0.5, rng.randn(6), rng.randn(6), rng.rand(6) + 0.2
+    t = lambda a: torch.from_numpy(np.asarray(a, dtype=np.float64))
+    got = O.batchnorm_inference_blend(t(x), t(sc), t(of), t(mm), t(mv)).numpy()
+    ref = np.empty_like(x)
+    for n in range(3):
+        for c in range(6):
+            m = x[n, :, :, c].mean() / 3. + (2. / 3.) * mm[c]
+            v = x[n, :, :, c].var() / 3. + (2. / 3.) * mv[c]
+            ref[n, :, :, c] = (x[n, :, :, c] - m) / np.sqrt(v + 1e-5) * sc[c] + of[c]
+    assert np.abs(got - ref).max() < 1e-12
+    nm, nv = O.batchnorm_moving_update(t(x), t(mm), t(mv), 4)
+    for c in range(6):
+        col = x[..., c].ravel()
+        assert abs(float(nm[c]) - (0.8 * mm[c] + 0.2 * col.mean())) < 1e-12
+        assert abs(float(nv[c]) - (0.8 * mv[c] + 0.2 * col.var(ddof=1))) < 1e-12
+    y = rng.randn(4, 6, 5)                                  # [N, C, L], moments over the batch only: per-(c, l) parameters
+    s2, o2 = rng.rand(1, 6, 5) + 0.5, rng.randn(1, 6, 5)
+    got = O.batchnorm_unfused(t(y), [0], t(s2), t(o2)).numpy()
+    ref = (y - y.mean(0, keepdims=True)) / np.sqrt(y.var(0, keepdims=True) + 1e-5) * s2 + o2
+    assert np.abs(got - ref).max() < 1e-12
+
+
+def test_tflib_batchnorm_inference_and_unfused_branches_match_the_oracle():
+    """tflib.ops.batchnorm.Batchnorm off the hot path (every reference call site passes is_training=None): the inference blend
+    (is_training=False) and the unfused branch are tensor plumbing on the caller's device -- checked here on the host against the
+    oracle, incl. the parameter shapes the reference creates."""
+    import dpig_amd.tflib as lib
+    import dpig_amd.tflib.ops  # noqa
+    from oracle import ops as O
+    lib.delete_all_params()
+    lib.set_device("cpu")
+    try:
+        g = torch.Generator().manual_seed(7)
+        x = torch.randn(3, 6, 5, 4, generator=g)                             # NCHW
+        lib.param('B.moving_mean', torch.randn(6, generator=g).numpy(), trainable=False)
+        lib.param('B.moving_variance', (torch.rand(6, generator=g) + 0.2).numpy(), trainable=False)
+        lib.param('B.scale', (torch.rand(6, generator=g) + 0.5).numpy())
+        lib.param('B.offset', torch.randn(6, generator=g).numpy())
+        y = lib.ops.batchnorm.Batchnorm('B', [0, 2, 3], x, is_training=False, stats_iter=0)
+        d = lambda n: lib.param(n).detach().double()
+        ref = O.batchnorm_inference_blend(x.double().permute(0, 2, 3, 1), d('B.scale'), d('B.offset'), d('B.moving_mean'), d('B.moving_variance'))
+        assert tuple(y.shape) == (3, 6, 5, 4)
+        assert (y.permute(0, 2, 3, 1).double() - ref).abs().max() < 1e-5
+        assert torch.equal(lib.param('B.moving_mean'), d('B.moving_mean').float())          # the inference branch never updates
+        x3 = torch.randn(4, 6, 5, generator=g)
+        y3 = lib.ops.batchnorm.Batchnorm('B3', [0, 2], x3, is_training=False, stats_iter=0)  # [N, C, L] through the same branch
+        ref3 = O.batchnorm_inference_blend(x3.double().permute(0, 2, 1).unsqueeze(2), d('B3.scale'), d('B3.offset'), d('B3.moving_mean'),
+                                           d('B3.moving_variance'))
+        assert tuple(y3.shape) == (4, 6, 5) and (y3.permute(0, 2, 1).unsqueeze(2).double() - ref3).abs().max() < 1e-5
+        z = lib.ops.batchnorm.Batchnorm('U', [0], x3, fused=False)                           # unfused: moments over the batch only
+        assert tuple(lib.param('U.scale').shape) == (1, 6, 5) and tuple(lib.param('U.offset').shape) == (1, 6, 5)
+        refz = O.batchnorm_unfused(x3.double(), [0], d('U.scale'), d('U.offset'))
+        assert (z.double() - refz).abs().max() < 1e-5
+        z2 = lib.ops.batchnorm.Batchnorm('U2', [1, 2], x3, fused=False)                      # no batch axis: shared parameters (the warning)
+        assert tuple(lib.param('U2.scale').shape) == (1, 1, 1)
+        assert (z2.double() - O.batchnorm_unfused(x3.double(), [1, 2], d('U2.scale'), d('U2.offset'))).abs().max() < 1e-5
+    finally:
+        lib.delete_all_params()
+        lib.set_device(None)
+
