@@ -89,6 +89,8 @@ SYMBOLS = {
     "dpig_border_class_sum_bf16": (_i, [_vp, _i, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "dpig_conv2d_bn_stats_tiles": (_i, [_dp]),
     "dpig_conv2d_fwd_stats": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dpig_conv2d_bn_stats_tiles_ws": (_i, [_dp]),
+    "dpig_conv2d_fwd_stats_ws": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dpig_bn_stats_finalize": (_i, [_vp, _i, _i64, _i, _i, _f, _vp, _vp, _vp]),
     "dpig_conv2d_bf16_bn_stats_tiles": (_i, [_dp]),
     "dpig_conv2d_fwd_bf16_stats": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -1215,6 +1215,76 @@ __device__ __forceinline__ void gather_gemm_reduce_body(const GGParams& p) {
     }
 }
 
+// split-K second pass of a forward conv that carries batch-norm statistics: one workgroup per 128 x 128 output tile sums the
+// partials in split order (the same sums as gather_gemm_reduce_body), runs the float4 epilogue, and leaves the tile's column sums and
+// centred squares exactly as gather_gemm_body's statistics section does for an un-split launch (same thread <-> element map).
+__global__ __launch_bounds__(256) void gather_gemm_reduce_stats_kernel(const GGParams p) {
+    __shared__ __attribute__((aligned(16))) float red[8 * BN];
+    const int tid = threadIdx.x;
+    const int mt = blockIdx.x / p.ntiles, nt = blockIdx.x - mt * p.ntiles;
+    const int m0 = mt * BM, n0 = nt * BN;
+    const int c = (tid & 31) * 4, col = n0 + c, rl0 = tid >> 5;
+    const bool cok = col < p.Ncols;
+    const int nrows = min(BM, p.M - m0);
+    const int n4 = p.Ncols >> 2;
+    const long total4 = ((long)p.M * p.Ncols) >> 2;
+    const float4* p4 = reinterpret_cast<const float4*>(p.partial);
+    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p.bias && cok) bv = *reinterpret_cast<const float4*>(p.bias + col);
+    float4 val[16];
+    float4 sm = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int rl = rl0 + 8 * it;
+        val[it] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (rl < nrows && cok) {
+            const long i = (long)(m0 + rl) * n4 + (col >> 2);
+            float4 v = p4[i];
+            for (int sp = 1; sp < p.nsplit; ++sp) {
+                const float4 t = p4[(long)sp * total4 + i];
+                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            }
+            epi_vec4(p, m0 + rl, col, v, bv);
+            v.x += bv.x; v.y += bv.y; v.z += bv.z; v.w += bv.w;
+            val[it] = v;
+            sm.x += v.x; sm.y += v.y; sm.z += v.z; sm.w += v.w;
+        }
+    }
+    *reinterpret_cast<float4*>(&red[rl0 * BN + c]) = sm;
+    __syncthreads();
+    float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const float4 t = *reinterpret_cast<const float4*>(&red[g * BN + c]);
+        tot.x += t.x; tot.y += t.y; tot.z += t.z; tot.w += t.w;
+    }
+    const float inv = 1.0f / (float)nrows;
+    const float4 mean = make_float4(tot.x * inv, tot.y * inv, tot.z * inv, tot.w * inv);
+    __syncthreads();
+    float4 q = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int it = 0; it < 16; ++it) {
+        const int rl = rl0 + 8 * it;
+        if (rl < nrows && cok) {
+            const float dx = val[it].x - mean.x, dy = val[it].y - mean.y, dz = val[it].z - mean.z, dw = val[it].w - mean.w;
+            q.x += dx * dx; q.y += dy * dy; q.z += dz * dz; q.w += dw * dw;
+        }
+    }
+    *reinterpret_cast<float4*>(&red[rl0 * BN + c]) = q;
+    __syncthreads();
+    if (rl0 == 0 && cok) {
+        float4 qt = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const float4 t = *reinterpret_cast<const float4*>(&red[g * BN + c]);
+            qt.x += t.x; qt.y += t.y; qt.z += t.z; qt.w += t.w;
+        }
+        float* o = p.stats + (long)mt * 2 * p.Ncols + col;
+        *reinterpret_cast<float4*>(o) = tot;
+        *reinterpret_cast<float4*>(o + p.Ncols) = qt;
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // wgrad: dw[(tap, ci), co] = sum over output pixels m of x[src(m,tap), ci] * dy[m, co]
 struct WGParams {
@@ -1874,8 +1944,10 @@ static int launch_gg(GGParams& p, bool b_rowk, int nimg, long filter_elems, hipS
     if (pipe && (!vec || narrow)) return fail(DPIG_EINVAL, "internal: bf16 loop selected for an ineligible problem");
     if (!p.vec_epi || narrow || p.replicate) p.D32 = nullptr;      // the float4 epilogue (in the kernel, or in the split-K
                                                                    // reduction pass) is what writes the image
-    if (p.stats && (p.nsplit != 1 || !p.vec_epi || narrow || !aligned16(p.stats)))
-        return fail(DPIG_EINVAL, "conv fwd with BN statistics needs an un-split plan, 16-byte aligned operands and more than 32 output channels");
+    if (p.stats && (!p.vec_epi || narrow || !aligned16(p.stats) || (p.nsplit != 1 && (!p.identity_rows || p.replicate))))
+        return fail(DPIG_EINVAL, "conv fwd with BN statistics needs 16-byte aligned operands and more than 32 output channels");
+    float* const split_stats = (p.stats && p.nsplit > 1) ? p.stats : nullptr;      // split-K: the reduction pass leaves the statistics
+    if (split_stats) p.stats = nullptr;
 #define DPIG_GG(BR, VE, NA) hipLaunchKernelGGL((gather_gemm_kernel<BR, VE, NA>), grid, block, 0, st, p)
     if (pipe == 1) {
         if (b_rowk) hipLaunchKernelGGL((gather_gemm_kernel<true, true, false, 1>), grid, block, 0, st, p);
@@ -1899,7 +1971,11 @@ static int launch_gg(GGParams& p, bool b_rowk, int nimg, long filter_elems, hipS
 #undef DPIG_GG
     rc = check_launch("gather_gemm_kernel");
     if (rc) return rc;
-    if (p.nsplit > 1) {
+    if (split_stats) {
+        p.stats = split_stats;
+        hipLaunchKernelGGL(gather_gemm_reduce_stats_kernel, dim3(p.mtiles * p.ntiles), dim3(256), 0, st, p);
+        rc = check_launch("gather_gemm_reduce_stats_kernel");
+    } else if (p.nsplit > 1) {
         hipLaunchKernelGGL(gather_gemm_reduce_kernel, dim3(reduce_blocks(p)), dim3(256), 0, st, p);
         rc = check_launch("gather_gemm_reduce_kernel");
     }
@@ -2137,21 +2213,32 @@ extern "C" int dpig_conv2d_dgrad_x3(const DpigConvDesc* d, const float* dy, cons
 // stats[tile][0][K] = sum, stats[tile][1][K] = sum of squared deviations from the tile's mean.  The tile count is 0 when this
 // problem's plan cannot carry them (split-K, <= 32 output channels, the upsample fusion, a batch served in several runs):
 // the caller then runs dpig_bn_fwd's own statistics passes.
-extern "C" int dpig_conv2d_bn_stats_tiles(const DpigConvDesc* d) {
+static int bn_stats_tiles(const DpigConvDesc* d, bool allow_split) {
     int pt, pl, Ho, Wo;
     if (resolve_desc(d, &pt, &pl, &Ho, &Wo)) return 0;
     if (d->upsample2x || d->K <= 32 || d->K % 4 || d->ldy % 4 || d->act != DPIG_ACT_NONE || images_per_launch(d, 4) < d->N) return 0;
     const int bk = gg_bk(d, d->ldx, d->C, d->K);
     Shape s = fwd_shape(d, Ho, Wo, bk);
     Plan pln = plan_split(cdiv(s.M, BM) * cdiv(s.Ncols, BN), s.ktiles, d->split_k, 32, split_pen(d));
-    return pln.nsplit == 1 ? (int)cdiv(s.M, BM) : 0;
+    return (pln.nsplit == 1 || allow_split) ? (int)cdiv(s.M, BM) : 0;
 }
+extern "C" int dpig_conv2d_bn_stats_tiles(const DpigConvDesc* d) { return bn_stats_tiles(d, false); }
+// ... with a workspace (dpig_conv2d_workspace_bytes(d, 0)) the split-K plans carry the statistics too: their reduction pass leaves them
+extern "C" int dpig_conv2d_bn_stats_tiles_ws(const DpigConvDesc* d) { return bn_stats_tiles(d, true); }
 extern "C" int dpig_conv2d_fwd_stats(const DpigConvDesc* d, const float* x, const float* w, const float* bias, float* y,
                                      float* stats, void* stream) {
     if (!stats) return fail(DPIG_EINVAL, "conv fwd with BN statistics: null statistics buffer");
     if (dpig_conv2d_bn_stats_tiles(d) <= 0)
         return fail(DPIG_EINVAL, "conv fwd with BN statistics: this problem's plan cannot carry them (dpig_conv2d_bn_stats_tiles == 0)");
     return conv2d_fwd_one(d, x, w, bias, nullptr, y, nullptr, nullptr, 0, stream, stats);
+}
+
+extern "C" int dpig_conv2d_fwd_stats_ws(const DpigConvDesc* d, const float* x, const float* w, const float* bias, float* y,
+                                        float* stats, void* ws, size_t ws_bytes, void* stream) {
+    if (!stats) return fail(DPIG_EINVAL, "conv fwd with BN statistics: null statistics buffer");
+    if (dpig_conv2d_bn_stats_tiles_ws(d) <= 0)
+        return fail(DPIG_EINVAL, "conv fwd with BN statistics: this problem cannot carry them (dpig_conv2d_bn_stats_tiles_ws == 0)");
+    return conv2d_fwd_one(d, x, w, bias, nullptr, y, nullptr, ws, ws_bytes, stream, stats);
 }
 
 extern "C" int dpig_conv2d_dgrad(const DpigConvDesc* d, const float* dy, const float* w, const float* accum,

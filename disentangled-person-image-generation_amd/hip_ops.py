@@ -437,7 +437,8 @@ def _image_room(N, Hh, W, C, device):
 def conv2d_fwd_stats(x, w, bias=None, stride=1, split_k=0):
     """y = conv_SAME(x, w) + bias together with the batch-norm partial statistics of y, left by the conv's epilogue
     (dpig_conv2d_fwd_stats): returns (y, stats) with stats = (float tensor [tiles, 2, K], rows per tile), or (y, None) when
-    this problem's plan cannot carry them (split-K, thin layers, bf16 storage) -- `bn_fwd(y, ..., stats=stats)` accepts both."""
+    this problem cannot carry them (thin layers, the upsample fusion, a batch served in several launches; bf16 storage: split-K plans too)
+    -- `bn_fwd(y, ..., stats=stats)` accepts both."""
     if _STORE_BF16[0] or x.dtype == BF16:
         _require_dev(x)
         N, H, W, C = x.shape
@@ -467,7 +468,7 @@ def conv2d_fwd_stats(x, w, bias=None, stride=1, split_k=0):
         raise RuntimeError("conv2d: filter expects %d input channels, tensor has %d" % (Cw, C))
     Ho, Wo = conv_out_hw(H, W, R, S, stride, False)
     d = _desc(N, H, W, C, K, R, S, stride, ldx, K, split_k=split_k)
-    tiles = lib().dpig_conv2d_bn_stats_tiles(ctypes.byref(d))
+    tiles = lib().dpig_conv2d_bn_stats_tiles_ws(ctypes.byref(d))          # (split-K plans included: their reduction pass leaves them)
     if bias is not None:
         bias = bias.contiguous()
     # the stats epilogue stores 16-byte vectors: an operand at an odd offset (a bias that is a view, say) takes the plain conv and
@@ -476,9 +477,10 @@ def conv2d_fwd_stats(x, w, bias=None, stride=1, split_k=0):
         return conv2d_fwd(x, w, bias, stride=stride, split_k=split_k), None
     out = torch.empty((N, Ho, Wo, K), dtype=torch.float32, device=x.device)
     stats = torch.empty((tiles, 2, K), dtype=torch.float32, device=x.device)
+    wsb, wsn = _ws(d, 0, x.device)
     with _Timed("conv_fwd_mfma", 2.0 * N * H * W // (stride * stride) * K * R * S * C, (N, H, W, C, K, R, stride, 0)):
-        check(lib().dpig_conv2d_fwd_stats(ctypes.byref(d), ptr(x), ptr(w), ptr(bias), ptr(out), ptr(stats), stream_ptr()),
-              "conv2d_fwd_stats")
+        check(lib().dpig_conv2d_fwd_stats_ws(ctypes.byref(d), ptr(x), ptr(w), ptr(bias), ptr(out), ptr(stats), ptr(wsb), wsn,
+                                             stream_ptr()), "conv2d_fwd_stats")
     return out, (stats, 128)
 
 

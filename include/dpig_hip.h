@@ -258,6 +258,11 @@ int dpig_border_class_sum_bf16(const uint16_t* a, int lda, int N, int H, int W, 
 int dpig_conv2d_bn_stats_tiles(const DpigConvDesc* d);
 int dpig_conv2d_fwd_stats(const DpigConvDesc* d, const float* x, const float* w, const float* bias, float* y, float* stats,
                           void* stream);
+/* ... with a workspace (dpig_conv2d_workspace_bytes(d, 0)): split-K plans carry the statistics too -- the reduction pass that sums the
+ * partials leaves the tile statistics (same layout, same values as an un-split launch of the same tile would leave). */
+int dpig_conv2d_bn_stats_tiles_ws(const DpigConvDesc* d);
+int dpig_conv2d_fwd_stats_ws(const DpigConvDesc* d, const float* x, const float* w, const float* bias, float* y, float* stats,
+                             void* ws, size_t ws_bytes, void* stream);
 /* the same for bf16 activations (statistics from the fp32 accumulators + bias, before y is rounded to bf16) */
 int dpig_conv2d_bf16_bn_stats_tiles(const DpigConvDesc* d);
 int dpig_conv2d_fwd_bf16_stats(const DpigConvDesc* d, const uint16_t* x, const uint16_t* w_t, const float* bias, uint16_t* y,

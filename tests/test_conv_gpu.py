@@ -586,6 +586,8 @@ def test_round2_entry_points_refuse_bad_arguments(dev):
     assert lib().dpig_conv2d_bn_stats_tiles(ctypes.byref(d)) == 0            # 1 row tile: the heuristic plan is split-K
     assert lib().dpig_conv2d_fwd_stats(ctypes.byref(d), ptr(x), ptr(w), None, ptr(y), ptr(st), stream_ptr()) != 0
     assert b"statistics" in lib().dpig_last_error()
+    assert lib().dpig_conv2d_bn_stats_tiles_ws(ctypes.byref(d)) == 1         # ... with a workspace the split plan carries them
+    assert lib().dpig_conv2d_fwd_stats_ws(ctypes.byref(d), ptr(x), ptr(w), None, ptr(y), ptr(st), None, 0, stream_ptr()) != 0   # no workspace
     d1 = H._desc(1, 8, 8, 64, 64, 3, 3, 1, 64, 64, split_k=1)
     assert lib().dpig_conv2d_bn_stats_tiles(ctypes.byref(d1)) == 1
     assert lib().dpig_conv2d_fwd_stats(ctypes.byref(d1), ptr(x), ptr(w), None, ptr(y), None, stream_ptr()) != 0

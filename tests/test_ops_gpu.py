@@ -50,7 +50,7 @@ def test_conv_epilogue_bn_statistics(dev, shape, compute):
     (dpig_conv2d_fwd_stats -> dpig_bn_stats_finalize -> dpig_bn_apply): conv + bias, batch mean, rstd and the normalised
     LeakyReLU output against the fp64 oracle conv -> batchnorm_train chain; a large offset in the bias makes a one-pass
     E[x^2]-E[x]^2 lose ~4 digits (the per-tile centred sums do not); ragged last row tile; bit-for-bit repeatable.
-    With the heuristic split-K plan (few row tiles) the statistics are not offered and bn_fwd runs its own passes."""
+    Split-K plans (the heuristic one on few row tiles, forced 2 / 3 way) carry them too: their reduction pass leaves them."""
     import dpig_amd.hip_ops as H
     from oracle import ops as O
     N, Hh, W, C, K, k, s = shape
@@ -77,9 +77,18 @@ def test_conv_epilogue_bn_statistics(dev, shape, compute):
         assert float((rstd2 - rstd).abs().max()) <= 1e-5 * float(rstd.abs().max())
         y_b, st_b = H.conv2d_fwd_stats(xg, wg, bg, stride=s, split_k=1)
         assert torch.equal(y_b, y) and torch.equal(st_b[0], st[0])
-        y_h, st_h = H.conv2d_fwd_stats(xg, wg, bg, stride=s)            # heuristic plan: split-K on these few tiles
-        if st_h is None:
-            _close(y_h, pre)
+        # split-K plans (the heuristic one on these few tiles, and forced 2 / 3 way): the reduction pass that sums the partials leaves
+        # the same per-tile statistics of the values it stores
+        for sk in (0, 2, 3):
+            y_s, st_s = H.conv2d_fwd_stats(xg, wg, bg, stride=s, split_k=sk)
+            assert st_s is not None and st_s[0].shape == st[0].shape
+            _close(y_s, pre)
+            out_s, mean_s, rstd_s = H.bn_fwd(y_s, scale.float().to(dev), offset.float().to(dev), 1e-5, 2, 0.2, stats=st_s)
+            _close(mean_s, rows.mean(0), 1e-6)
+            _close(rstd_s, 1.0 / torch.sqrt(rows.var(0, unbiased=False) + 1e-5), 2e-5 if compute == "f32" else 1e-4)
+            _close(out_s, ref, 2e-5 if compute == "f32" else 1e-4)
+            y_s2, st_s2 = H.conv2d_fwd_stats(xg, wg, bg, stride=s, split_k=sk)
+            assert torch.equal(y_s2, y_s) and torch.equal(st_s2[0], st_s[0])
     finally:
         H.set_compute("f32")
 
