@@ -1,0 +1,318 @@
+// bhq32_probe: stand-alone prototype of the NEXT bf16 conv kernel -- the halo-staged eight-wave schedule
+// of bhq_kernel (csrc/dpig_conv_bf16_q.hip) at BK = 32, for the 3x3 stride-1 layers with 128 output channels (the encoder's
+// res blocks: 8 x 256 x 256 x 128 -> 128 at DeepFashion, 0.87 PF today on bq_kernel<4, 2>).  NOT part of the library: it was written
+// at the end of round 3 without GPU minutes left and has never run; it builds (scripts/ubench/build.sh), checks itself against a
+// naive kernel and prints effective TFLOP/s:      ./bhq32_probe [N H W C]      (defaults 8 256 256 128)
+//
+// Geometry.  Workgroup = 8 waves as 4 (pixel rows) x 2 (channel columns); a wave owns 128 pixels (an 8 x 16 patch) x 64 channels
+// = 4 x 2 accumulators of v_mfma_f32_32x32x16_bf16; the workgroup's output tile is a 32 x 16-pixel patch x 128 channels.
+// k order (32-channel chunk, tap).  LDS rows are 64 B (32 bf16):
+//   * input: per chunk, per wave row, the 10 x 18 halo of its patch at a row pitch of 20 pixels (so that the linear pixel index and
+//     hx agree mod 4), 13 DMA pieces of 16 pixels, two chunk slots: 2 x 4 x 13 KB = 104 KB; the nine taps read shifted windows;
+//     16-byte slot s of pixel hx holds channel granule s ^ ((hx >> 2) & 3)  (ds_read_b128 of 16 consecutive pixels: conflict-free);
+//   * filter: [128 columns][32 k] = 8 KB per k-tile, FOUR slots (prefetch distance 3: a k-tile of 16 MFMAs per wave is too short
+//     for a distance of 2), slot s of column n holds granule s ^ ((n >> 2) & 3); one DMA piece per wave per k-tile.
+// A k-tile is ONE phase: { 8 + 4 fragment reads ; DMA issue (filter tile t + 3, one halo piece of the next chunk in taps 0..6) ;
+// counted vmcnt ; lgkmcnt(0) ; barrier ; 16 MFMAs ; barrier }, wave groups 0-3 / 4-7 one barrier out of phase (ping-pong), the
+// same 12 reads and <= 2 DMA pieces per 16 MFMAs as bhq_kernel.  Counted waits: with the issue order (filter, halo) per k-tile the
+// pieces younger than filter tile t + 1 are {3, 4, 5, 5, 5, 5, 5, 4, 3}[tap]; halo pieces are issued by every wave in taps 0..6
+// (ids >= 52 are dead: out-of-range source, scratch destination) so that the counts are compile-time.
+// LDS: 104 KB + 32 KB + 1 KB scratch = 137 KB, one workgroup per CU.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <vector>
+#include <type_traits>
+#include "dpig_bf16_common.h"
+
+using namespace dpig::bfk;
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __attribute__((address_space(3))) char lds_char;
+
+struct P32 {
+    const bf16_t* A;      // x [N][H][W][C]
+    const bf16_t* B;      // filter [9][Ncols][C]  (the library's transposed shadow)
+    const float* bias;    // [Ncols]
+    bf16_t* D;            // y [N][H][W][Ncols] = relu(conv + bias)
+    int N, H, W, C, Ncols;
+    int tiles_x, tiles_y, mtiles, ntiles, nch;
+    unsigned a_bytes, b_bytes;
+};
+
+constexpr int RB = 64;                          // bytes per LDS row (32 bf16)
+constexpr int HP = 20;                          // halo row pitch in pixels
+constexpr int NPX = 10 * HP;                    // 200 halo pixel slots per wave row
+constexpr int NPIECE = 13;                      // pieces of 16 pixels per wave row
+constexpr int WR_B = NPIECE * 16 * RB;          // 13312 B per wave row per chunk slot
+constexpr int HSLOT = 4 * WR_B;                 // 53248
+constexpr int B_OFF = 2 * HSLOT;                // 106496
+constexpr int BSL = 128 * RB;                   // 8192
+constexpr int PAD_OFF = B_OFF + 4 * BSL;        // 139264: 1 KB scratch for dead DMA pieces
+constexpr int SMEM32 = PAD_OFF + 1024;          // 140288
+
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void dma16l(__amdgpu_buffer_rsrc_t rs, int voff, int soff, lds_char* lds_dst) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_void*)lds_dst, 16, voff, soff, 0, 0);
+}
+__device__ __forceinline__ void q_barrier() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+__device__ __forceinline__ unsigned short f2bf(float f) {           // round to nearest even
+    unsigned u = __float_as_uint(f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (unsigned short)(u >> 16);
+}
+
+__global__ __launch_bounds__(512, 2) void bhq32_kernel(const P32 p) {
+    __shared__ __attribute__((aligned(16))) char smem[SMEM32];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int grp = wave >> 2;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    const int tile = blockIdx.x;
+    const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+    const int n0 = nt * 128;
+    const int per_img = p.tiles_x * p.tiles_y;
+    const int img = mt / per_img;
+    const int trem = mt - img * per_img;
+    const int tyi = trem / p.tiles_x;
+    const int y0 = tyi * 32, x0 = (trem - tyi * p.tiles_x) * 16;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes);
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.B, p.b_bytes);
+    lds_char* const L = (lds_char*)smem;
+
+    // ---- halo DMA roles: in tap slot t <= 6 this wave fetches piece id = 8 t + wave; id < 52: (wave row j, piece q) = halo pixel
+    //      slots 16 q .. 16 q + 15 of wave row j; lane -> (pixel slot 16 q + lane / 4, 16-byte slot lane % 4)
+    int h_voff[7], h_dst[7];
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+        const int id = 8 * t + wave;
+        const bool live = id < 4 * NPIECE;
+        const int j = live ? id / NPIECE : 0, q = live ? id - j * NPIECE : 0;
+        const int hp = 16 * q + (lane >> 2);
+        const int hy = hp / HP, hx = hp - hy * HP;
+        const int y = y0 + 8 * j - 1 + hy, x = x0 - 1 + hx;
+        const bool ok = live & (hp < NPX) & (hx < 18) & ((unsigned)y < (unsigned)p.H) & ((unsigned)x < (unsigned)p.W);
+        const int g = (lane & 3) ^ ((hx >> 2) & 3);
+        h_voff[t] = ok ? ((((img * p.H + y) * p.W + x) * p.C) + g * 8) * 2 : (int)OOB;
+        h_dst[t] = live ? (j * WR_B + q * 1024) : -1;
+    }
+    // ---- filter DMA role: columns 16 wave .. 16 wave + 15 of the 128; lane -> (column 16 wave + lane / 4, slot lane % 4)
+    int b_voff;
+    {
+        const int n = 16 * wave + (lane >> 2);
+        const int g = (lane & 3) ^ ((n >> 2) & 3);
+        b_voff = (n0 + n < p.Ncols) ? ((n0 + n) * p.C + g * 8) * 2 : (int)OOB;
+    }
+    const int nch = p.nch, nkt = 9 * nch;
+    const int tapB = p.Ncols * p.C * 2;                      // bytes between two taps of the filter
+    auto issueB = [&](int t) {                               // filter k-tile t (chunk t / 9, tap t % 9) into slot t % 4
+        const int c = t / 9, tap = t - 9 * c;
+        const int dead = t < nkt ? 0 : (int)OOB;
+        dma16l(rsB, b_voff | dead, tap * tapB + c * 64, L + (B_OFF + (t & 3) * BSL + wave * 1024));
+    };
+    auto issueH = [&](int t, int chunk) {                    // halo piece of tap slot t (a literal) for `chunk`
+        const int dead = chunk < nch ? 0 : (int)OOB;
+        const int dst = h_dst[t] >= 0 ? (chunk & 1) * HSLOT + h_dst[t] : PAD_OFF;
+        dma16l(rsA, h_voff[t] | dead, chunk * 64, L + dst);
+    };
+
+    // ---- fragment addresses
+    const int f_tx = l31 & 15, f_tyl = l31 >> 4;
+    const int bn = wc * 64 + l31;                             // (+ 32 nb) column inside the 128
+    int fb[2][2];                                             // [nb][ks], slot 0
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int n = bn + 32 * nb;
+            fb[nb][ks] = B_OFF + n * RB + (((2 * ks + half) ^ ((n >> 2) & 3)) << 4);
+        }
+    auto lds16 = [&](int off) -> bf16x8 { return *(const __attribute__((address_space(3))) bf16x8*)(L + off); };
+    bf16x8 fA[4][2], fB[2][2];
+    auto rdA = [&](int ta, int tb, int chunk) {               // tap (ta, tb) literals
+        const int hx = f_tx + tb;
+        const int sw = (hx >> 2) & 3;
+        const int base = (chunk & 1) * HSLOT + wr * WR_B + ((ta + f_tyl) * HP + hx) * RB;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fA[mb][ks] = lds16(base + (2 * mb) * HP * RB + (((2 * ks + half) ^ sw) << 4));
+    };
+    auto rdB = [&](int slot) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fB[nb][ks] = lds16(fb[nb][ks] + slot * BSL);
+    };
+    auto mma = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fB[nb][ks], fA[mb][ks], acc[mb][nb], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // ---- prologue: halo of chunk 0 (7 pieces per wave, dead ones included), filter tiles 0, 1, 2
+#pragma unroll
+    for (int t = 0; t < 7; ++t) issueH(t, 0);
+    issueB(0);
+    issueB(1);
+    issueB(2);
+    wait_vm<2>();                                    // halo 0 + filter tile 0 home
+    q_barrier();
+    if (grp == 1) q_barrier();                       // stagger: this group runs one barrier behind
+    int t = 0;
+    for (int c = 0; c < nch; ++c) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap, ++t) {
+            rdB(t & 3);
+            __builtin_amdgcn_sched_barrier(0);
+            rdA(tap / 3, tap % 3, c);
+            __builtin_amdgcn_sched_barrier(0);
+            issueB(t + 3);                           // into the slot tile t - 1 was read from (both groups are past those reads)
+            if (tap < 7) issueH(tap, c + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // filter tile t + 1 must be home: the pieces younger than it (issue order: filter, halo per k-tile)
+            if (tap == 0 || tap == 8) wait_vm<3>();
+            else if (tap == 1 || tap == 7) wait_vm<4>();
+            else wait_vm<5>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            q_barrier();
+            mma();
+            q_barrier();
+        }
+    }
+    if (grp == 0) q_barrier();
+    wait_vm<0>();
+    __syncthreads();
+
+    // ---- epilogue (probe quality: straight from the registers; D^T accumulators: lane (l31, half) holds pixel l31 of block mb and
+    //      channels 8 q + 4 half + 0..3 of block nb): bias + ReLU, 8-byte bf16 stores
+#pragma unroll
+    for (int mb = 0; mb < 4; ++mb) {
+        const int y = y0 + 8 * wr + 2 * mb + f_tyl, x = x0 + f_tx;
+        const long pix = ((long)img * p.H + y) * p.W + x;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int ch = n0 + wc * 64 + nb * 32 + 8 * q + 4 * half;
+                if (ch < p.Ncols) {
+                    unsigned short o[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = f2bf(fmaxf(acc[mb][nb][4 * q + e] + p.bias[ch + e], 0.f));
+                    uint2 v;
+                    v.x = (unsigned)o[0] | ((unsigned)o[1] << 16);
+                    v.y = (unsigned)o[2] | ((unsigned)o[3] << 16);
+                    *reinterpret_cast<uint2*>(p.D + pix * p.Ncols + ch) = v;
+                }
+            }
+    }
+}
+
+__device__ __forceinline__ float bf2f(unsigned short b) { return __uint_as_float(((unsigned)b) << 16); }
+__global__ void ref_kernel(const P32 p, float* out) {          // one thread per (pixel, channel), fp32 accumulation
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)p.N * p.H * p.W * p.Ncols;
+    if (i >= total) return;
+    const int ch = (int)(i % p.Ncols);
+    const long pix = i / p.Ncols;
+    const int x = (int)(pix % p.W), y = (int)((pix / p.W) % p.H), n = (int)(pix / ((long)p.W * p.H));
+    float s = 0.f;
+    for (int ta = 0; ta < 3; ++ta)
+        for (int tb = 0; tb < 3; ++tb) {
+            const int yy = y + ta - 1, xx = x + tb - 1;
+            if ((unsigned)yy >= (unsigned)p.H || (unsigned)xx >= (unsigned)p.W) continue;
+            const bf16_t* a = p.A + (((long)n * p.H + yy) * p.W + xx) * p.C;
+            const bf16_t* b = p.B + ((long)(ta * 3 + tb) * p.Ncols + ch) * p.C;
+            for (int c = 0; c < p.C; ++c) s += bf2f(a[c]) * bf2f(b[c]);
+        }
+    out[i] = fmaxf(s + p.bias[ch], 0.f);
+}
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
+
+unsigned short host_bf(float f) { unsigned u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (unsigned short)(u >> 16); }
+
+}  // namespace
+
+int main(int argc, char** argv) {
+    int N = 8, H = 256, W = 256, C = 128;
+    if (argc >= 5) { N = atoi(argv[1]); H = atoi(argv[2]); W = atoi(argv[3]); C = atoi(argv[4]); }
+    const int K = 128;
+    if (H % 32 || W % 16 || C % 32) { fprintf(stderr, "H %% 32, W %% 16, C %% 32 required\n"); return 1; }
+    const size_t nx = (size_t)N * H * W * C, nw = (size_t)9 * K * C, ny = (size_t)N * H * W * K;
+    std::vector<unsigned short> hx(nx), hw(nw);
+    std::vector<float> hb(K);
+    unsigned s = 12345u;
+    auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 32768.0f - 1.0f; };
+    for (auto& v : hx) v = host_bf(rnd());
+    for (auto& v : hw) v = host_bf(rnd() * 0.05f);
+    for (auto& v : hb) v = rnd() * 0.5f;
+    bf16_t *dx, *dw, *dy; float *db, *dref;
+    CK(hipMalloc(&dx, nx * 2)); CK(hipMalloc(&dw, nw * 2)); CK(hipMalloc(&dy, ny * 2)); CK(hipMalloc(&db, K * 4)); CK(hipMalloc(&dref, ny * 4));
+    CK(hipMemcpy(dx, hx.data(), nx * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(dw, hw.data(), nw * 2, hipMemcpyHostToDevice));
+    CK(hipMemcpy(db, hb.data(), K * 4, hipMemcpyHostToDevice));
+    CK(hipMemset(dy, 0xff, ny * 2));
+    P32 p = {};
+    p.A = dx; p.B = dw; p.bias = db; p.D = dy; p.N = N; p.H = H; p.W = W; p.C = C; p.Ncols = K;
+    p.tiles_x = W / 16; p.tiles_y = H / 32; p.mtiles = N * p.tiles_x * p.tiles_y; p.ntiles = (K + 127) / 128; p.nch = C / 32;
+    p.a_bytes = (unsigned)(nx * 2); p.b_bytes = (unsigned)(nw * 2);
+    if (nx * 2 >= (1ull << 31)) { fprintf(stderr, "x beyond one buffer descriptor\n"); return 1; }
+    dim3 grid(p.mtiles * p.ntiles), block(512);
+    hipLaunchKernelGGL(bhq32_kernel, grid, block, 0, 0, p);
+    CK(hipGetLastError()); CK(hipDeviceSynchronize());
+    hipLaunchKernelGGL(ref_kernel, dim3((unsigned)((ny + 255) / 256)), dim3(256), 0, 0, p, dref);
+    CK(hipGetLastError()); CK(hipDeviceSynchronize());
+    std::vector<unsigned short> gy(ny); std::vector<float> gr(ny);
+    CK(hipMemcpy(gy.data(), dy, ny * 2, hipMemcpyDeviceToHost));
+    CK(hipMemcpy(gr.data(), dref, ny * 4, hipMemcpyDeviceToHost));
+    double maxerr = 0, maxref = 0; size_t bad = 0, worst = 0;
+    for (size_t i = 0; i < ny; ++i) {
+        unsigned u = ((unsigned)gy[i]) << 16; float g; memcpy(&g, &u, 4);
+        const double e = fabs((double)g - gr[i]);
+        if (e > maxerr) { maxerr = e; worst = i; }
+        if (fabs(gr[i]) > maxref) maxref = fabs(gr[i]);
+        if (e > 0.02 * fabs(gr[i]) + 0.02) ++bad;               // bf16 output rounding: 2^-8 relative
+    }
+    printf("check: max |err| %.4g (max |ref| %.4g) at element %zu, %zu of %zu outside the bf16 rounding bar -> %s\n", maxerr, maxref, worst, bad, ny,
+           bad == 0 ? "OK" : "MISMATCH");
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    const int it = 20;
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(bhq32_kernel, grid, block, 0, 0, p);
+    CK(hipEventRecord(e0));
+    for (int i = 0; i < it; ++i) hipLaunchKernelGGL(bhq32_kernel, grid, block, 0, 0, p);
+    CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    const double fl = 2.0 * N * H * W * (double)K * 9 * C;
+    printf("bhq32 %dx%dx%dx%d -> %d: %.1f us per launch, %.1f TFLOP/s (library today on this layer: ~870-940)\n", N, H, W, C, K, ms / it * 1e3,
+           fl / (ms / it * 1e-3) / 1e12);
+    return bad == 0 ? 0 : 2;
+}
