@@ -3,6 +3,8 @@
 // res blocks: 8 x 256 x 256 x 128 -> 128 at DeepFashion, 0.87 PF today on bq_kernel<4, 2>).  NOT part of the library: it was written
 // at the end of round 3 without GPU minutes left and has never run; it builds (scripts/ubench/build.sh), checks itself against a
 // naive kernel and prints effective TFLOP/s:      ./bhq32_probe [N H W C]      (defaults 8 256 256 128)
+// Its index math is checked on the host: scripts/ubench/check_bhq32_indexing.py (LDS images vs fragment addresses, bank conflicts, the
+// wait table) and scripts/ubench/emulate_bhq32.py (the whole data path in numpy == a direct 3x3 convolution, exactly).
 //
 // Geometry.  Workgroup = 8 waves as 4 (pixel rows) x 2 (channel columns); a wave owns 128 pixels (an 8 x 16 patch) x 64 channels
 // = 4 x 2 accumulators of v_mfma_f32_32x32x16_bf16; the workgroup's output tile is a 32 x 16-pixel patch x 128 channels.
