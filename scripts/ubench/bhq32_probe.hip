@@ -2,7 +2,7 @@
 // of bhq_kernel (csrc/dpig_conv_bf16_q.hip) at BK = 32, for the 3x3 stride-1 layers with 128 output channels (the encoder's
 // res blocks: 8 x 256 x 256 x 128 -> 128 at DeepFashion, 0.87 PF today on bq_kernel<4, 2>).  NOT part of the library: it was written
 // at the end of round 3 without GPU minutes left and has never run; it builds (scripts/ubench/build.sh), checks itself against a
-// naive kernel and prints effective TFLOP/s:      ./bhq32_probe [N H W C]      (defaults 8 256 256 128)
+// naive kernel and prints effective TFLOP/s:      ./bhq32_probe [N H W C]      (defaults 8 256 256 128; BHQ32_DGRAD=1: the dgrad's taps)
 // Its index math is checked on the host: scripts/ubench/check_bhq32_indexing.py (LDS images vs fragment addresses, bank conflicts, the
 // wait table) and scripts/ubench/emulate_bhq32.py (the whole data path in numpy == a direct 3x3 convolution, exactly).
 //
@@ -44,6 +44,9 @@ struct P32 {
     int N, H, W, C, Ncols;
     int tiles_x, tiles_y, mtiles, ntiles, nch;
     unsigned a_bytes, b_bytes;
+    // affine tap family of the library (BGParams): tap (ta, tb) reads the source at offset (oy0 + ta * oys, ox0 + tb * oxs) and filter
+    // slab w0 + ta * wa + tb * wb.  Forward: (-1, 1, -1, 1; 0, 3, 1); stride-1 dgrad (A = dy, B = the [tap][Cin][Cout] shadow): (1, -1, 1, -1; 0, 3, 1)
+    int oy0, oys, ox0, oxs, w0, wa, wb;
 };
 
 constexpr int RB = 64;                          // bytes per LDS row (32 bf16)
@@ -130,8 +133,9 @@ __global__ __launch_bounds__(512, 2) void bhq32_kernel(const P32 p) {
     const int tapB = p.Ncols * p.C * 2;                      // bytes between two taps of the filter
     auto issueB = [&](int t) {                               // filter k-tile t (chunk t / 9, tap t % 9) into slot t % 4
         const int c = t / 9, tap = t - 9 * c;
+        const int ta = tap / 3, tb = tap - 3 * ta;
         const int dead = t < nkt ? 0 : (int)OOB;
-        dma16l(rsB, b_voff | dead, tap * tapB + c * 64, L + (B_OFF + (t & 3) * BSL + wave * 1024));
+        dma16l(rsB, b_voff | dead, (p.w0 + ta * p.wa + tb * p.wb) * tapB + c * 64, L + (B_OFF + (t & 3) * BSL + wave * 1024));
     };
     auto issueH = [&](int t, int chunk) {                    // halo piece of tap slot t (a literal) for `chunk`
         const int dead = chunk < nch ? 0 : (int)OOB;
@@ -152,10 +156,11 @@ __global__ __launch_bounds__(512, 2) void bhq32_kernel(const P32 p) {
         }
     auto lds16 = [&](int off) -> bf16x8 { return *(const __attribute__((address_space(3))) bf16x8*)(L + off); };
     bf16x8 fA[4][2], fB[2][2];
-    auto rdA = [&](int ta, int tb, int chunk) {               // tap (ta, tb) literals
-        const int hx = f_tx + tb;
+    auto rdA = [&](int ta, int tb, int chunk) {               // tap (ta, tb) literals; halo coordinates are image coordinates + 1
+        const int dyy = 1 + p.oy0 + ta * p.oys, dxx = 1 + p.ox0 + tb * p.oxs;
+        const int hx = f_tx + dxx;
         const int sw = (hx >> 2) & 3;
-        const int base = (chunk & 1) * HSLOT + wr * WR_B + ((ta + f_tyl) * HP + hx) * RB;
+        const int base = (chunk & 1) * HSLOT + wr * WR_B + ((dyy + f_tyl) * HP + hx) * RB;
 #pragma unroll
         for (int mb = 0; mb < 4; ++mb)
 #pragma unroll
@@ -249,10 +254,10 @@ __global__ void ref_kernel(const P32 p, float* out) {          // one thread per
     float s = 0.f;
     for (int ta = 0; ta < 3; ++ta)
         for (int tb = 0; tb < 3; ++tb) {
-            const int yy = y + ta - 1, xx = x + tb - 1;
+            const int yy = y + p.oy0 + ta * p.oys, xx = x + p.ox0 + tb * p.oxs;
             if ((unsigned)yy >= (unsigned)p.H || (unsigned)xx >= (unsigned)p.W) continue;
             const bf16_t* a = p.A + (((long)n * p.H + yy) * p.W + xx) * p.C;
-            const bf16_t* b = p.B + ((long)(ta * 3 + tb) * p.Ncols + ch) * p.C;
+            const bf16_t* b = p.B + ((long)(p.w0 + ta * p.wa + tb * p.wb) * p.Ncols + ch) * p.C;
             for (int c = 0; c < p.C; ++c) s += bf2f(a[c]) * bf2f(b[c]);
         }
     out[i] = fmaxf(s + p.bias[ch], 0.f);
@@ -288,6 +293,8 @@ int main(int argc, char** argv) {
     p.tiles_x = W / 16; p.tiles_y = H / 32; p.mtiles = N * p.tiles_x * p.tiles_y; p.ntiles = (K + 127) / 128; p.nch = C / 32;
     p.a_bytes = (unsigned)(nx * 2); p.b_bytes = (unsigned)(nw * 2);
     if (nx * 2 >= (1ull << 31)) { fprintf(stderr, "x beyond one buffer descriptor\n"); return 1; }
+    p.oy0 = -1; p.oys = 1; p.ox0 = -1; p.oxs = 1; p.w0 = 0; p.wa = 3; p.wb = 1;
+    if (getenv("BHQ32_DGRAD")) { p.oy0 = 1; p.oys = -1; p.ox0 = 1; p.oxs = -1; }      // the stride-1 dgrad's tap family (same data, mirrored windows)
     dim3 grid(p.mtiles * p.ntiles), block(512);
     hipLaunchKernelGGL(bhq32_kernel, grid, block, 0, 0, p);
     CK(hipGetLastError()); CK(hipDeviceSynchronize());

@@ -9,7 +9,8 @@ RB = 64; HP = 20; NPX = 200; NPIECE = 13; WR_B = NPIECE * 16 * RB; HSLOT = 4 * W
 PAD_OFF = B_OFF + 4 * BSL; SMEM = PAD_OFF + 1024
 
 
-def run(N, H, W, C, K=128, seed=0):
+def run(N, H, W, C, K=128, seed=0, taps=(-1, 1, -1, 1, 0, 3, 1)):
+    oy0, oys, ox0, oxs, w0, wa, wb = taps      # the library's affine tap family: forward (-1, 1, -1, 1; 0, 3, 1), stride-1 dgrad (1, -1, 1, -1; 0, 3, 1)
     rng = np.random.RandomState(seed)
     x = rng.randint(-4, 5, size=(N, H, W, C)).astype(np.float64)
     w = rng.randint(-3, 4, size=(9, K, C)).astype(np.float64)          # [tap][column][channel]: the transposed shadow
@@ -52,7 +53,8 @@ def run(N, H, W, C, K=128, seed=0):
                 n = 16 * wave + (lane >> 2)
                 g = (lane & 3) ^ ((n >> 2) & 3)
                 ok = n0 + n < K and t < 9 * nch
-                off = ((tap * K + n0 + n) * C + c * 32 + g * 8) if ok else None
+                slab = w0 + (tap // 3) * wa + (tap % 3) * wb
+                off = ((slab * K + n0 + n) * C + c * 32 + g * 8) if ok else None
                 lds[B_OFF + (t & 3) * BSL + wave * 1024 + lane * 16] = gather(wf, off)
 
         for t in range(7):
@@ -71,9 +73,10 @@ def run(N, H, W, C, K=128, seed=0):
                     for lane in range(64):
                         l31, half = lane & 31, lane >> 5
                         tx, tyl = l31 & 15, l31 >> 4
-                        hx = tx + tb
+                        dyy, dxx = 1 + oy0 + ta * oys, 1 + ox0 + tb * oxs
+                        hx = tx + dxx
                         sw = (hx >> 2) & 3
-                        base = (c & 1) * HSLOT + wr * WR_B + ((ta + tyl) * HP + hx) * RB
+                        base = (c & 1) * HSLOT + wr * WR_B + ((dyy + tyl) * HP + hx) * RB
                         for mb in range(4):
                             for ks in range(2):
                                 frA[wave, lane, mb, ks] = lds[base + (2 * mb) * HP * RB + (((2 * ks + half) ^ sw) << 4)]
@@ -117,13 +120,14 @@ def run(N, H, W, C, K=128, seed=0):
     xp = np.pad(x, ((0, 0), (1, 1), (1, 1), (0, 0)))
     for ta in range(3):
         for tb in range(3):
-            ref += xp[:, ta:ta + H, tb:tb + W, :] @ w[ta * 3 + tb].T
+            sy, sx = 1 + oy0 + ta * oys, 1 + ox0 + tb * oxs
+            ref += xp[:, sy:sy + H, sx:sx + W, :] @ w[w0 + ta * wa + tb * wb].T
     assert not np.isnan(y).any(), "unwritten outputs"
     err = np.abs(y - ref).max()
-    print("N %d H %d W %d C %d: max |err| %.3g %s" % (N, H, W, C, err, "OK" if err == 0 else "MISMATCH"))
+    print("N %d H %d W %d C %d taps %s: max |err| %.3g %s" % (N, H, W, C, taps, err, "OK" if err == 0 else "MISMATCH"))
     return err == 0
 
 
 if __name__ == "__main__":
-    ok = run(1, 32, 16, 32) and run(1, 64, 32, 64, seed=1) and run(2, 32, 32, 96, seed=2)
+    ok = run(1, 32, 16, 32) and run(1, 64, 32, 64, seed=1) and run(2, 32, 32, 96, seed=2) and run(1, 64, 32, 64, seed=3, taps=(1, -1, 1, -1, 0, 3, 1))
     raise SystemExit(0 if ok else 1)
