@@ -20,6 +20,16 @@
 // pieces younger than filter tile t + 1 are {3, 4, 5, 5, 5, 5, 5, 4, 3}[tap]; halo pieces are issued by every wave in taps 0..6
 // (ids >= 52 are dead: out-of-range source, scratch destination) so that the counts are compile-time.
 // LDS: 104 KB + 32 KB + 1 KB scratch = 137 KB, one workgroup per CU.
+//
+// Port plan (csrc/dpig_conv_bf16_q.hip), once the probe passes its self-check and beats bq_kernel<4, 2> on the GPU:
+//   1. kernel: P32 -> BGParams (A, B, Hs, Ws, lda, Cs, Ncols, oy0 .. wb, a_bytes, b_bytes, tiles_x = Ws / 16, tiles_y = Hs / 32, cchunks = Cs / 32);
+//      the wave tile (8 x 16 pixels x 64 channels, D^T accumulators acc[4][2]) is bhq_kernel's, so the epilogue is its switch over
+//      q_epilogue_wave<...>(p, acc, L + wave * WEP_BYTES, row_base = (img * Hs + y0 + 8 * wr) * Ws + x0, cb0 = n0 + wc * 64, lane, slope, p.Ws)
+//      behind `wait_vm<0>(); __syncthreads();` (8 * WEP_BYTES = 68 KB fits the 137 KB);
+//   2. eligibility: bhq_eligible's conditions with Hs % 32 == 0 and Cs % 32 == 0; selection in bq_try: where variant 2 (512 x 128) is
+//      chosen today and the layer is eligible (the model's factor for it: measure);  A/B switch DPIG_BF16_QH32;
+//   3. tests: tests/test_conv_bf16_q_gpu.py -- every fused epilogue, forward and dgrad, against the 128-tile kernels (one-ulp bar: the
+//      k order (32-chunk, tap) differs from theirs) and the fp64 oracle on rounded operands; full-size layer in test_fullsize_gpu.py.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
