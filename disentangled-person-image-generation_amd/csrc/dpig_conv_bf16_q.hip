@@ -754,6 +754,177 @@ __global__ __launch_bounds__(512, 2) void bhq_kernel(const BGParams p) {
 }
 
 // ================================================================================================
+// bhq32_kernel (EXPERIMENTAL, off unless DPIG_BF16_QH32=1; written at the end of round 3 without GPU minutes left -- it builds, its index
+// math is emulated on the host (scripts/ubench/check_bhq32_indexing.py, emulate_bhq32.py: the data path equals a direct convolution), it
+// has not run): the halo-staged schedule at BK = 32 for the 128-column layers that bq_kernel<4, 2> serves today without halo staging.
+// 8 waves as 4 (8 x 16-pixel patches) x 2 (64 channels): a 32 x 16-pixel patch x 128 channels per workgroup; LDS rows of 64 B; per
+// 32-channel chunk the 10 x 18 halo of every wave row at a pitch of 20 pixels (13 pieces of 16 pixels, two chunk slots = 104 KB), 16-byte
+// slot s of pixel hx holds granule s ^ ((hx >> 2) & 3); filter tiles [128 columns][32 k] = 8 KB in FOUR slots (prefetch distance 3), one
+// piece per wave per k-tile; a k-tile is one phase {12 fragment reads; filter piece of tile t + 3, halo piece of the next chunk in taps
+// 0..6; counted vmcnt {3, 4, 5, 5, 5, 5, 5, 4, 3}[tap]; barrier; 16 MFMAs; barrier}, groups staggered by one barrier.  The wave tile
+// and the D^T accumulators are bhq_kernel's, so the epilogue is the same.  See scripts/ubench/bhq32_probe.hip for the stand-alone form.
+// ================================================================================================
+struct H32 {
+    static constexpr int RB = 64, HP = 20, NPX = 10 * HP, NPIECE = 13, WR_B = NPIECE * 16 * RB, HSLOT = 4 * WR_B;
+    static constexpr int B_OFF = 2 * HSLOT, BSL = 128 * RB, PAD_OFF = B_OFF + 4 * BSL, SMEM = PAD_OFF + 1024;
+    static_assert(SMEM <= 163840 && 8 * WEP_BYTES <= SMEM, "LDS plan");
+};
+__global__ __launch_bounds__(512, 2) void bhq32_kernel(const BGParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[H32::SMEM];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave >> 1, wc = wave & 1;
+    const int grp = wave >> 2;
+    const int l31 = lane & 31, half = lane >> 5;
+
+    const int tile = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
+    const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
+    const int n0 = nt * 128;
+    const int per_img = p.tiles_x * p.tiles_y;
+    const int img = mt / per_img;
+    const int trem = mt - img * per_img;
+    const int tyi = trem / p.tiles_x;
+    const int y0 = tyi * 32, x0 = (trem - tyi * p.tiles_x) * 16;
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes);
+    const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.B, p.b_bytes);
+    lds_char* const L = (lds_char*)smem;
+
+    // halo DMA roles: in tap slot t <= 6 this wave fetches piece id = 8 t + wave (ids >= 52 are dead: out-of-range source, scratch
+    // destination, so that every wave issues the same number of pieces); lane -> (pixel slot 16 q + lane / 4, 16-byte slot lane % 4)
+    int h_voff[7], h_dst[7];
+#pragma unroll
+    for (int t = 0; t < 7; ++t) {
+        const int id = 8 * t + wave;
+        const bool live = id < 4 * H32::NPIECE;
+        const int j = live ? id / H32::NPIECE : 0, q = live ? id - j * H32::NPIECE : 0;
+        const int hp = 16 * q + (lane >> 2);
+        const int hy = hp / H32::HP, hx = hp - hy * H32::HP;
+        const int y = y0 + 8 * j - 1 + hy, x = x0 - 1 + hx;
+        const bool ok = live & (hp < H32::NPX) & (hx < 18) & ((unsigned)y < (unsigned)p.Hs) & ((unsigned)x < (unsigned)p.Ws);
+        const int g = (lane & 3) ^ ((hx >> 2) & 3);
+        h_voff[t] = ok ? ((((img * p.Hs + y) * p.Ws + x) * p.lda) + g * 8) * 2 : (int)OOB;
+        h_dst[t] = live ? (j * H32::WR_B + q * 1024) : -1;
+    }
+    int b_voff;                                              // filter DMA role: columns 16 wave .. 16 wave + 15 of the 128
+    {
+        const int n = 16 * wave + (lane >> 2);
+        const int g = (lane & 3) ^ ((n >> 2) & 3);
+        b_voff = (n0 + n < p.Ncols) ? ((n0 + n) * p.Cs + g * 8) * 2 : (int)OOB;
+    }
+    const int nch = p.Cs >> 5, nkt = 9 * nch;
+    const int tapB = p.Ncols * p.Cs * 2;                     // bytes between two filter slabs
+    auto issueB = [&](int t) {                               // filter k-tile t (chunk t / 9, tap t % 9) into slot t % 4
+        const int c = t / 9, tap = t - 9 * c;
+        const int ta = tap / 3, tb = tap - 3 * ta;
+        const int dead = t < nkt ? 0 : (int)OOB;
+        dma16l(rsB, b_voff | dead, (p.w0 + ta * p.wa + tb * p.wb) * tapB + c * 64, L + (H32::B_OFF + (t & 3) * H32::BSL + wave * 1024));
+    };
+    auto issueH = [&](int t, int chunk) {                    // halo piece of tap slot t (a literal) for `chunk`
+        const int dead = chunk < nch ? 0 : (int)OOB;
+        const int dst = h_dst[t] >= 0 ? (chunk & 1) * H32::HSLOT + h_dst[t] : H32::PAD_OFF;
+        dma16l(rsA, h_voff[t] | dead, chunk * 64, L + dst);
+    };
+
+    const int f_tx = l31 & 15, f_tyl = l31 >> 4;
+    int fb[2][2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const int n = wc * 64 + 32 * nb + l31;
+            fb[nb][ks] = H32::B_OFF + n * H32::RB + (((2 * ks + half) ^ ((n >> 2) & 3)) << 4);
+        }
+    auto lds16 = [&](int off) -> bf16x8 { return *(const __attribute__((address_space(3))) bf16x8*)(L + off); };
+    bf16x8 fA[4][2], fB[2][2];
+    auto rdA = [&](int ta, int tb, int chunk) {              // tap (ta, tb) literals; halo coordinates = image coordinates + 1
+        const int dyy = 1 + p.oy0 + ta * p.oys, dxx = 1 + p.ox0 + tb * p.oxs;
+        const int hx = f_tx + dxx;
+        const int sw = (hx >> 2) & 3;
+        const int base = (chunk & 1) * H32::HSLOT + wr * H32::WR_B + ((dyy + f_tyl) * H32::HP + hx) * H32::RB;
+#pragma unroll
+        for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fA[mb][ks] = lds16(base + (2 * mb) * H32::HP * H32::RB + (((2 * ks + half) ^ sw) << 4));
+    };
+    auto rdB = [&](int slot) {
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) fB[nb][ks] = lds16(fb[nb][ks] + slot * H32::BSL);
+    };
+    auto mma = [&]() {
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int mb = 0; mb < 4; ++mb)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fB[nb][ks], fA[mb][ks], acc[mb][nb], 0, 0, 0);
+        __builtin_amdgcn_s_setprio(0);
+    };
+
+    // prologue: halo of chunk 0 (7 pieces per wave, dead ones included), filter tiles 0, 1, 2
+#pragma unroll
+    for (int t = 0; t < 7; ++t) issueH(t, 0);
+    issueB(0);
+    issueB(1);
+    issueB(2);
+    wait_vm<2>();                                    // halo 0 + filter tile 0 home
+    q_barrier();
+    if (grp == 1) q_barrier();                       // stagger: this group runs one barrier behind
+    int t = 0;
+    for (int c = 0; c < nch; ++c) {
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap, ++t) {
+            rdB(t & 3);
+            __builtin_amdgcn_sched_barrier(0);
+            rdA(tap / 3, tap % 3, c);
+            __builtin_amdgcn_sched_barrier(0);
+            issueB(t + 3);                           // into the slot tile t - 1 was read from (both groups are past those reads)
+            if (tap < 7) issueH(tap, c + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            // filter tile t + 1 must be home: the pieces younger than it (issue order per k-tile: filter, halo)
+            if (tap == 0 || tap == 8) wait_vm<3>();
+            else if (tap == 1 || tap == 7) wait_vm<4>();
+            else wait_vm<5>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            q_barrier();
+            mma();
+            q_barrier();
+        }
+    }
+    if (grp == 0) q_barrier();
+    wait_vm<0>();
+    __syncthreads();
+
+    // epilogue: bhq_kernel's (the wave tile and the accumulator layout are the same)
+    const bool hr = p.res != nullptr, hm = p.mask != nullptr, h2 = p.D2 != nullptr, rpost = p.res_post != 0;
+    const int kind = (!hr && !hm && !h2) ? 1 : ((hr && !rpost && !hm && !h2) ? 2 : ((!hr && hm && !h2) ? 3 : ((hr && rpost && !hm && h2) ? 4 : 5)));
+    const float slope = (p.act == DPIG_ACT_NONE) ? 1.f : ((p.act == DPIG_ACT_RELU) ? 0.f : p.alpha);
+    const int row_base = (img * p.Hs + y0 + 8 * wr) * p.Ws + x0, cb0 = n0 + wc * 64;
+    lds_char* W = L + wave * WEP_BYTES;
+    switch (kind) {
+        case 1: q_epilogue_wave<false, false, false, false>(p, acc, W, row_base, cb0, lane, slope, p.Ws); break;
+        case 2: q_epilogue_wave<true, false, false, false>(p, acc, W, row_base, cb0, lane, slope, p.Ws); break;
+        case 3: q_epilogue_wave<false, false, true, false>(p, acc, W, row_base, cb0, lane, slope, p.Ws); break;
+        case 4: q_epilogue_wave<true, true, false, true>(p, acc, W, row_base, cb0, lane, slope, p.Ws); break;
+        default: q_epilogue_wave<true, false, true, false>(p, acc, W, row_base, cb0, lane, slope, p.Ws); break;
+    }
+}
+
+// ================================================================================================
 // host side
 // ================================================================================================
 static int g_q_mode = -1;      // 0 off, 1 automatic, 2 whenever the layer is legal for the kernel (tests)
@@ -782,6 +953,9 @@ static bool bhq_eligible(const BGParams& p) {
     const bool known = (!hr && !hm && !h2) || (hr && !rpost && !hm && !h2) || (!hr && hm && !h2) || (hr && rpost && !hm && h2) || (hr && !rpost && hm && !h2);
     return known;
 }
+
+static int g_q_halo32 = []() { const char* e = getenv("DPIG_BF16_QH32"); return e ? atoi(e) : 0; }();   // EXPERIMENTAL (see bhq32_kernel): off
+static bool bhq32_eligible(const BGParams& p) { return bhq_eligible(p) && !(p.Hs & 31); }
 
 // Fraction of the launched MFMA work that is real when the tiles of bm x bn run `slots` at a time in whole rounds.
 static double q_eff(long M, long N, int bm, int bn, int slots) {
@@ -825,6 +999,14 @@ int bq_try(BGParams& p, hipStream_t st) {
         if (g_q_halo == 2) hipLaunchKernelGGL(bhq_kernel<true>, hgrid, block, 0, st, q);
         else hipLaunchKernelGGL(bhq_kernel<false>, hgrid, block, 0, st, q);
         const int rch = check_launch("bhq_kernel");
+        return rch ? rch : 1;
+    }
+    if (variant == 2 && g_q_halo32 && bhq32_eligible(p)) {
+        q.tiles_x = p.Ws / 16; q.tiles_y = p.Hs / 32;
+        q.mtiles = (p.M / (p.Hs * p.Ws)) * q.tiles_x * q.tiles_y;
+        dim3 hgrid(q.mtiles * q.ntiles, 1, 1);
+        hipLaunchKernelGGL(bhq32_kernel, hgrid, block, 0, st, q);
+        const int rch = check_launch("bhq32_kernel");
         return rch ? rch : 1;
     }
     if (variant == 1) hipLaunchKernelGGL((bq_kernel<2, 4>), grid, block, 0, st, q);
