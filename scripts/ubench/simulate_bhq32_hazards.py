@@ -1,0 +1,126 @@
+"""Randomised ordering check of bhq32_kernel's k-loop (csrc/dpig_conv_bf16_q.hip, scripts/ubench/bhq32_probe.hip): eight waves run the
+kernel's instruction stream (fragment reads, LDS-DMA issues, counted vmcnt waits, the two barriers per k-tile, groups staggered by
+one barrier) under a random scheduler; every DMA piece lands at a random later time, in issue order per wave (the only guarantee
+vmcnt gives).  A fragment read must find the piece of ITS k-tile / chunk in the LDS region it reads, and never a region with a DMA
+still in flight: that is the RAW / WAR argument of the kernel's header, executed.     python scripts/ubench/simulate_bhq32_hazards.py"""
+import random
+import sys
+
+NP = 13
+WAIT = [3, 4, 5, 5, 5, 5, 5, 4, 3]
+
+
+def program(wave, nch):
+    """Instruction list of one wave: ('dma', region, tag) / ('wait', n) / ('bar',) / ('read', [regions], tag_kind, tag)."""
+    grp = wave >> 2
+    wr, wc = wave >> 1, wave & 1
+    nkt = 9 * nch
+    prog = []
+
+    def issueH(t, chunk):
+        idp = 8 * t + wave
+        region = ("H", chunk & 1, idp // NP, idp % NP) if idp < 4 * NP else ("PAD", wave)
+        prog.append(("dma", region, chunk if chunk < nch else "dead"))
+
+    def issueB(t):
+        prog.append(("dma", ("B", t & 3, wave), t if t < nkt else "dead"))
+
+    for t in range(7):
+        issueH(t, 0)
+    for t in range(3):
+        issueB(t)
+    prog.append(("wait", 2))
+    prog.append(("bar",))
+    if grp == 1:
+        prog.append(("bar",))
+    t = 0
+    for c in range(nch):
+        for tap in range(9):
+            prog.append(("read", [("B", t & 3, 4 * wc + k) for k in range(4)], t))
+            prog.append(("read", [("H", c & 1, wr, q) for q in range(NP)], c))
+            issueB(t + 3)
+            if tap < 7:
+                issueH(tap, c + 1)
+            prog.append(("wait", WAIT[tap]))
+            prog.append(("bar",))
+            prog.append(("mfma",))
+            prog.append(("bar",))
+            t += 1
+    if grp == 0:
+        prog.append(("bar",))
+    prog.append(("wait", 0))
+    return prog
+
+
+def run(nch, seed, lazy=0.5):
+    rng = random.Random(seed)
+    progs = [program(w, nch) for w in range(8)]
+    pc = [0] * 8
+    fifo = [[] for _ in range(8)]          # per wave: DMA ops in flight, in issue order
+    lds = {}                               # region -> tag of the data it holds
+    pending = {}                           # region -> number of DMA ops in flight to it
+    at_bar = [False] * 8
+    steps = 0
+    while any(pc[w] < len(progs[w]) for w in range(8)) or any(fifo):
+        steps += 1
+        choices = []
+        for w in range(8):
+            if fifo[w]:
+                choices.append(("land", w))
+            if pc[w] < len(progs[w]) and not at_bar[w]:
+                ins = progs[w][pc[w]]
+                if ins[0] == "wait" and len(fifo[w]) > ins[1]:
+                    continue                                   # blocked on vmcnt
+                choices.append(("exec", w))
+        if not choices:
+            if all(at_bar[w] or pc[w] >= len(progs[w]) for w in range(8)) and any(at_bar):
+                if not all(at_bar[w] for w in range(8) if pc[w] < len(progs[w])) or any(pc[w] >= len(progs[w]) for w in range(8)):
+                    raise AssertionError("barrier deadlock")
+            raise AssertionError("stuck")
+        # landings are made rare (`lazy`), so that pieces stay in flight as long as the waits allow: the adversarial memory system
+        execs = [ch for ch in choices if ch[0] == "exec"]
+        lands = [ch for ch in choices if ch[0] == "land"]
+        if execs and (not lands or rng.random() > lazy):
+            kind, w = rng.choice(execs)
+        else:
+            kind, w = rng.choice(lands)
+        if kind == "land":
+            region, tag = fifo[w].pop(0)
+            pending[region] -= 1
+            lds[region] = tag
+            continue
+        ins = progs[w][pc[w]]
+        if ins[0] == "dma":
+            fifo[w].append((ins[1], ins[2]))
+            pending[ins[1]] = pending.get(ins[1], 0) + 1
+        elif ins[0] == "read":
+            for region in ins[1]:
+                assert pending.get(region, 0) == 0, ("read of a region with a DMA in flight", w, region, ins[2])
+                assert lds.get(region) == ins[2], ("stale / overwritten data", w, region, lds.get(region), "wanted", ins[2])
+        elif ins[0] == "bar":
+            at_bar[w] = True
+            if all(at_bar):
+                at_bar = [False] * 8
+                for v in range(8):
+                    pc[v] += 1
+                continue
+            continue                                           # pc advances when the barrier releases
+        pc[w] += 1
+    return steps
+
+
+if __name__ == "__main__":
+    n = 0
+    for nch in (1, 2, 3, 4):
+        for seed in range(150):
+            run(nch, seed, lazy=(0.98, 0.5, 0.1, 0.02)[seed % 4])
+            n += 1
+    print("bhq32 k-loop: %d random schedules (1..4 chunks), every fragment read saw the data of its own k-tile / chunk with no DMA in flight" % n)
+    # the check has teeth: a too-lax wait (one more piece allowed in flight) must be caught
+    WAIT[4] += 1
+    try:
+        for seed in range(300):
+            run(3, seed, lazy=0.02)
+        print("WARNING: the relaxed wait was not caught"); sys.exit(1)
+    except AssertionError as e:
+        print("relaxed wait caught as expected:", e.args[0][0])
