@@ -753,8 +753,9 @@ __global__ __launch_bounds__(512, 2) void bhq_kernel(const BGParams p) {
     }
 }
 
+#ifdef DPIG_EXPERIMENTAL_BHQ32
 // ================================================================================================
-// bhq32_kernel (EXPERIMENTAL, off unless DPIG_BF16_QH32=1; written at the end of round 3 without GPU minutes left -- it builds, its index
+// bhq32_kernel (EXPERIMENTAL: compiled only with -DDPIG_EXPERIMENTAL_BHQ32, and then off unless DPIG_BF16_QH32=1; written at the end of round 3 without GPU minutes left -- it builds, its index
 // math is emulated on the host (scripts/ubench/check_bhq32_indexing.py, emulate_bhq32.py: the data path equals a direct convolution), it
 // has not run): the halo-staged schedule at BK = 32 for the 128-column layers that bq_kernel<4, 2> serves today without halo staging.
 // 8 waves as 4 (8 x 16-pixel patches) x 2 (64 channels): a 32 x 16-pixel patch x 128 channels per workgroup; LDS rows of 64 B; per
@@ -924,6 +925,8 @@ __global__ __launch_bounds__(512, 2) void bhq32_kernel(const BGParams p) {
     }
 }
 
+#endif  // DPIG_EXPERIMENTAL_BHQ32
+
 // ================================================================================================
 // host side
 // ================================================================================================
@@ -954,8 +957,10 @@ static bool bhq_eligible(const BGParams& p) {
     return known;
 }
 
+#ifdef DPIG_EXPERIMENTAL_BHQ32
 static int g_q_halo32 = []() { const char* e = getenv("DPIG_BF16_QH32"); return e ? atoi(e) : 0; }();   // EXPERIMENTAL (see bhq32_kernel): off
 static bool bhq32_eligible(const BGParams& p) { return bhq_eligible(p) && !(p.Hs & 31); }
+#endif
 
 // Fraction of the launched MFMA work that is real when the tiles of bm x bn run `slots` at a time in whole rounds.
 static double q_eff(long M, long N, int bm, int bn, int slots) {
@@ -1001,6 +1006,7 @@ int bq_try(BGParams& p, hipStream_t st) {
         const int rch = check_launch("bhq_kernel");
         return rch ? rch : 1;
     }
+#ifdef DPIG_EXPERIMENTAL_BHQ32
     if (variant == 2 && g_q_halo32 && bhq32_eligible(p)) {
         q.tiles_x = p.Ws / 16; q.tiles_y = p.Hs / 32;
         q.mtiles = (p.M / (p.Hs * p.Ws)) * q.tiles_x * q.tiles_y;
@@ -1009,6 +1015,7 @@ int bq_try(BGParams& p, hipStream_t st) {
         const int rch = check_launch("bhq32_kernel");
         return rch ? rch : 1;
     }
+#endif
     if (variant == 1) hipLaunchKernelGGL((bq_kernel<2, 4>), grid, block, 0, st, q);
     else hipLaunchKernelGGL((bq_kernel<4, 2>), grid, block, 0, st, q);
     const int rc = check_launch("bq_kernel");

@@ -1,6 +1,7 @@
 """First GPU check of the EXPERIMENTAL bhq32_kernel (csrc/dpig_conv_bf16_q.hip; off by default, never run when it was written):
 
-    DPIG_BF16_QH32=1 timeout 120 python scripts/check_bhq32.py          # (a shorter timeout than gpurun's: a hang must not cost a strike)
+    bash scripts/build_experimental.sh                                   # the library with -DDPIG_EXPERIMENTAL_BHQ32 -> scripts/ubench/libdpig_exp.so
+    DPIG_LIB_PATH=scripts/ubench/libdpig_exp.so DPIG_BF16_QH32=1 timeout 120 python scripts/check_bhq32.py   # (own timeout: a hang must not cost a strike)
 
 Forward (+ bias + ReLU, + residual) and the stride-1 dgrad (* mask) of 128-column 3x3 layers with the 512 x 128 variant forced -- which the
 switch routes to bhq32_kernel where the layer is eligible -- against the 128 x 128 kernels (large tiles off) on the same operands: the k
