@@ -145,7 +145,7 @@ def GeneratorCNN_ID_Encoder_BodyROIVis_FgBgFeaTwoBranch(x, fg_mask, ROI_bboxs, R
             body_regions = _roi_tower(body_regions, z_num, repeat_num, hidden_num, data_format, activation_fn)
         fused_cat = keep_part_prob >= 1.0
         if not fused_cat:
-            body_regions = fg_branch.join(body_regions)
+            body_regions, _ = fg_branch.join(body_regions, conv_fea_list[0])     # (the crops are handed to the caller too)
             fea_list = _apply_vis(body_regions, ROI_vis, bbox_num, z_num)
             for i in range(bbox_num):
                 keep = (torch.rand(batch_num, 1, device=x.device) < keep_part_prob).to(torch.float32)
@@ -162,7 +162,7 @@ def GeneratorCNN_ID_Encoder_BodyROIVis_FgBgFeaTwoBranch(x, fg_mask, ROI_bboxs, R
         x_bg = fully_connected(x_bg, z_num * 4, activation_fn=None)
 
         if fused_cat:
-            body_regions = fg_branch.join(body_regions)
+            body_regions, _ = fg_branch.join(body_regions, conv_fea_list[0])     # (the crops are handed to the caller too)
             # visibility multiply (models.py:433-442) + tf.concat(fea_list, -1) (:467-468) as one launch; fea_list = views
             fea_all = A.vis_concat(body_regions, ROI_vis, x_bg, bbox_num, z_num)
             fea_list = [fea_all[:, i * z_num:(i + 1) * z_num] for i in range(bbox_num)] + [fea_all[:, bbox_num * z_num:]]
