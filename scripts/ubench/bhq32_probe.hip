@@ -5,7 +5,7 @@
 // naive kernel and prints effective TFLOP/s:      ./bhq32_probe [N H W C]      (defaults 8 256 256 128; BHQ32_DGRAD=1: the dgrad's taps)
 // Its index math is checked on the host: scripts/ubench/check_bhq32_indexing.py (LDS images vs fragment addresses, bank conflicts, the
 // wait table), scripts/ubench/emulate_bhq32.py (the whole data path in numpy == a direct 3x3 convolution, exactly) and
-// scripts/ubench/simulate_bhq32_hazards.py (the k-loop's reads / DMA issues / counted waits / barriers under random schedules with
+// scripts/ubench/simulate_kloop_hazards.py (the k-loop's reads / DMA issues / counted waits / barriers under random schedules with
 // adversarially early and late DMA landings: every read sees its own k-tile's data; a wait relaxed by one piece is caught).
 //
 // Geometry.  Workgroup = 8 waves as 4 (pixel rows) x 2 (channel columns); a wave owns 128 pixels (an 8 x 16 patch) x 64 channels

@@ -1,8 +1,8 @@
-"""Randomised ordering check of bhq32_kernel's k-loop (csrc/dpig_conv_bf16_q.hip, scripts/ubench/bhq32_probe.hip): eight waves run the
-kernel's instruction stream (fragment reads, LDS-DMA issues, counted vmcnt waits, the two barriers per k-tile, groups staggered by
+"""Randomised ordering check of the k-loops of bhq_kernel (the shipped halo-staged 256 x 256 kernel) and bhq32_kernel (the experimental
+BK = 32 variant; csrc/dpig_conv_bf16_q.hip, scripts/ubench/bhq32_probe.hip): eight waves run the kernel's instruction stream (fragment reads, LDS-DMA issues, counted vmcnt waits, the two barriers per k-tile, groups staggered by
 one barrier) under a random scheduler; every DMA piece lands at a random later time, in issue order per wave (the only guarantee
 vmcnt gives).  A fragment read must find the piece of ITS k-tile / chunk in the LDS region it reads, and never a region with a DMA
-still in flight: that is the RAW / WAR argument of the kernel's header, executed.     python scripts/ubench/simulate_bhq32_hazards.py"""
+still in flight: that is the RAW / WAR argument of the kernels' headers, executed.     python scripts/ubench/simulate_kloop_hazards.py"""
 import random
 import sys
 
@@ -52,9 +52,54 @@ def program(wave, nch):
     return prog
 
 
-def run(nch, seed, lazy=0.5):
+def program_bhq(wave, nch, pb_wait=4, slack=False):
+    """bhq_kernel: waves as 2 (pixel rows) x 4 (channel columns); per k-tile two phases PA / PB of 16 MFMAs; halo of a 64-channel chunk =
+    2 wave rows x 23 pieces, fetched as piece 8 t + wave (< 46) in PA of taps 0..5; filter tile = 4 wave columns x 2 units x 4 pieces in two
+    slots, tile t + 2 issued in PB(t) into the slot tile t was read from; PB waits with 4 pieces in flight."""
+    grp = wave >> 2
+    wr, wc = wave >> 2, wave & 3
+    nkt = 9 * nch
+    prog = []
+
+    def issueH(t, chunk):
+        idp = 8 * t + wave
+        if idp < 46:
+            prog.append(("dma", ("H", chunk & 1, idp // 23, idp % 23), chunk if chunk < nch else "dead"))
+
+    def issueB(t, h):                                        # unit h of filter tile t: this wave's two pieces
+        for j in range(2):
+            prog.append(("dma", ("B", t & 1, (wave >> 2) + 2 * j, h, wave & 3), t if t < nkt else "dead"))
+
+    for t in range(6):
+        issueH(t, 0)
+    issueB(0, 0); issueB(0, 1); issueB(1, 0); issueB(1, 1)
+    prog.append(("wait", 4))
+    prog.append(("bar",))
+    if grp == 1:
+        prog.append(("bar",))
+    t = 0
+    for c in range(nch):
+        for tap in range(9):
+            prog.append(("read", [("B", t & 1, wc, h, k) for h in range(2) for k in range(4)], t))
+            prog.append(("read", [("H", c & 1, wr, q) for q in range(23)], c))                  # rows of M-half 0
+            if tap < 6:
+                issueH(tap, c + 1)
+            prog.append(("bar",)); prog.append(("mfma",)); prog.append(("bar",))
+            prog.append(("read", [("H", c & 1, wr, q) for q in range(23)], c))                  # rows of M-half 1
+            issueB(t + 2, 0); issueB(t + 2, 1)
+            # the <true> build (DPIG_BF16_QH=2): the halo piece issued in this k-tile's PA may stay in flight
+            prog.append(("wait", pb_wait + (1 if slack and (tap < 5 or (tap == 5 and wave < 6)) else 0)))
+            prog.append(("bar",)); prog.append(("mfma",)); prog.append(("bar",))
+            t += 1
+    if grp == 0:
+        prog.append(("bar",))
+    prog.append(("wait", 0))
+    return prog
+
+
+def run(nch, seed, lazy=0.5, make=None):
     rng = random.Random(seed)
-    progs = [program(w, nch) for w in range(8)]
+    progs = [(make or program)(w, nch) for w in range(8)]
     pc = [0] * 8
     fifo = [[] for _ in range(8)]          # per wave: DMA ops in flight, in issue order
     lds = {}                               # region -> tag of the data it holds
@@ -116,6 +161,21 @@ if __name__ == "__main__":
             run(nch, seed, lazy=(0.98, 0.5, 0.1, 0.02)[seed % 4])
             n += 1
     print("bhq32 k-loop: %d random schedules (1..4 chunks), every fragment read saw the data of its own k-tile / chunk with no DMA in flight" % n)
+    n = 0
+    for nch in (1, 2, 3, 4):
+        for seed in range(150):
+            run(nch, seed, lazy=(0.98, 0.5, 0.1, 0.02)[seed % 4], make=program_bhq)
+            n += 1
+    for seed in range(200):
+        run(3, seed, lazy=(0.98, 0.1, 0.02)[seed % 3], make=lambda w, c: program_bhq(w, c, slack=True))
+        n += 1
+    print("bhq   k-loop: %d random schedules (1..4 chunks, incl. the relaxed-wait build), every fragment read saw the data of its own k-tile / chunk with no DMA in flight" % n)
+    try:
+        for seed in range(300):
+            run(3, seed, lazy=0.02, make=lambda w, c: program_bhq(w, c, pb_wait=5))
+        print("WARNING: bhq's relaxed wait was not caught"); sys.exit(1)
+    except AssertionError as e:
+        print("bhq: a PB wait relaxed by one piece is caught as expected:", e.args[0][0])
     # the check has teeth: a too-lax wait (one more piece allowed in flight) must be caught
     WAIT[4] += 1
     try:
