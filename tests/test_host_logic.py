@@ -170,3 +170,25 @@ def test_workspace_is_per_device_and_stream_key():
     ws.pin()
     b2, n2 = ws.get(n1 + 1, dev)
     assert b2 is not b1 and n2 > n1 and any(r is b1 for r in ws.retired)
+
+
+def test_halo_staged_kloop_ordering_model():
+    """The k-loop of bhq_kernel (csrc/dpig_conv_bf16_q.hip) as an executable ordering model (scripts/ubench/simulate_kloop_hazards.py):
+    the eight waves' fragment reads, LDS-DMA issues, counted vmcnt waits and barriers under random schedules with early and late DMA
+    landings -- every read must see its own k-tile's / chunk's data with no DMA in flight to that LDS region; a wait relaxed by one piece
+    must be caught (the model has teeth).  A regression guard for edits of the schedule; the kernel itself is tested on the GPU."""
+    import importlib.util
+    import os
+    import pytest
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "scripts", "ubench", "simulate_kloop_hazards.py")
+    spec = importlib.util.spec_from_file_location("simulate_kloop_hazards", path)
+    sim = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sim)
+    for nch in (1, 2, 3):
+        for seed in range(16):
+            lazy = (0.98, 0.5, 0.1, 0.02)[seed % 4]
+            sim.run(nch, seed, lazy=lazy, make=sim.program_bhq)
+            sim.run(nch, seed, lazy=lazy, make=lambda w, c: sim.program_bhq(w, c, slack=True))
+    with pytest.raises(AssertionError):
+        for seed in range(200):
+            sim.run(3, seed, lazy=0.02, make=lambda w, c: sim.program_bhq(w, c, pb_wait=5))
