@@ -1,4 +1,4 @@
-"""Randomised ordering check of the k-loops of bhq_kernel (the shipped halo-staged 256 x 256 kernel) and bhq32_kernel (the experimental
+"""Randomised ordering check of the k-loops of bq_kernel<2,4> / <4,2>, bhq_kernel (the shipped large-tile kernels) and bhq32_kernel (the experimental
 BK = 32 variant; csrc/dpig_conv_bf16_q.hip, scripts/ubench/bhq32_probe.hip): eight waves run the kernel's instruction stream (fragment reads, LDS-DMA issues, counted vmcnt waits, the two barriers per k-tile, groups staggered by
 one barrier) under a random scheduler; every DMA piece lands at a random later time, in issue order per wave (the only guarantee
 vmcnt gives).  A fragment read must find the piece of ITS k-tile / chunk in the LDS region it reads, and never a region with a DMA
@@ -97,6 +97,46 @@ def program_bhq(wave, nch, pb_wait=4, slack=False):
     return prog
 
 
+def program_bq(wave, nkt, WM=2, WN=4, relax=0):
+    """bq_kernel<WM, WN> (256 x 256 / 512 x 128, operands gathered per tap): A = [wave row][2 slots][units UA0 / UA1 of 64 rows, 8 pieces each],
+    B = [wave column][2 slots][units UB0 / UB1 of 32 columns, 4 pieces each]; PA(t) stages UA1(t + 1) into the other slot, PB(t) stages
+    UA0, UB0, UB1 of (t + 2) into the current one; both phases wait with 2 (NA + NB) pieces in flight.  `nkt` k-tiles."""
+    NA, NB = WM, WN // 2
+    VMC = 2 * (NA + NB) + relax
+    grp = wave >> 2
+    wr, wc = wave // WN, wave % WN
+    prog = []
+
+    def issueA(t, h):
+        for j in range(NA):
+            prog.append(("dma", ("A", t & 1, j, h, wave), t if t < nkt else "dead"))
+
+    def issueB(t, h):
+        for j in range(NB):
+            prog.append(("dma", ("B", t & 1, (wave >> 2) + 2 * j, h, wave & 3), t if t < nkt else "dead"))
+
+    issueA(0, 0); issueB(0, 0); issueB(0, 1); issueA(0, 1)
+    issueA(1, 0); issueB(1, 0); issueB(1, 1)
+    prog.append(("wait", NA + 2 * NB))
+    prog.append(("bar",))
+    if grp == 1:
+        prog.append(("bar",))
+    for t in range(nkt):
+        prog.append(("read", [("B", t & 1, wc, h, k) for h in range(2) for k in range(4)], t))
+        prog.append(("read", [("A", t & 1, wr, 0, k) for k in range(8)], t))
+        issueA(t + 1, 1)
+        prog.append(("wait", VMC))
+        prog.append(("bar",)); prog.append(("mfma",)); prog.append(("bar",))
+        prog.append(("read", [("A", t & 1, wr, 1, k) for k in range(8)], t))
+        issueA(t + 2, 0); issueB(t + 2, 0); issueB(t + 2, 1)
+        prog.append(("wait", VMC))
+        prog.append(("bar",)); prog.append(("mfma",)); prog.append(("bar",))
+    if grp == 0:
+        prog.append(("bar",))
+    prog.append(("wait", 0))
+    return prog
+
+
 def run(nch, seed, lazy=0.5, make=None):
     rng = random.Random(seed)
     progs = [(make or program)(w, nch) for w in range(8)]
@@ -176,6 +216,19 @@ if __name__ == "__main__":
         print("WARNING: bhq's relaxed wait was not caught"); sys.exit(1)
     except AssertionError as e:
         print("bhq: a PB wait relaxed by one piece is caught as expected:", e.args[0][0])
+    n = 0
+    for (WM, WN) in ((2, 4), (4, 2)):
+        for nkt in (2, 3, 9, 18):
+            for seed in range(60):
+                run(nkt, seed, lazy=(0.98, 0.5, 0.1, 0.02)[seed % 4], make=lambda w, k: program_bq(w, k, WM, WN))
+                n += 1
+    print("bq<2,4> / bq<4,2> k-loops: %d random schedules (2..18 k-tiles), every fragment read saw its own k-tile's data with no DMA in flight" % n)
+    try:
+        for seed in range(300):
+            run(9, seed, lazy=0.02, make=lambda w, k: program_bq(w, k, 2, 4, relax=1))
+        print("WARNING: bq's relaxed wait was not caught"); sys.exit(1)
+    except AssertionError as e:
+        print("bq: a wait relaxed by one piece is caught as expected:", e.args[0][0])
     # the check has teeth: a too-lax wait (one more piece allowed in flight) must be caught
     WAIT[4] += 1
     try:
