@@ -4,6 +4,7 @@ boxes `part_bbox` and their visibility `part_vis`) can be produced fr
 
     valid_peaks      datasets/convert_market.py:339-376  `_get_valid_peaks`  (the best-scoring person's keypoints)
     part_bbox7       datasets/convert_market.py:578-638  `get_part_bbox7`    (7 region proposals + visibility)
+    part_bbox37      datasets/convert_DF.py:522-655      `get_part_bbox`     (DeepFashion: 37 proposals, whole-body rule, lifted nose)
     pose_mask_raster datasets/convert_market.py:229-276  `_getPoseMask`      (radius-4 discs along the 23 limbs)
     pose_mask        ... + :277-283 the 5x5 morphological closing (skimage `dilation` then `erosion`)
 
@@ -70,6 +71,40 @@ def part_bbox7(peaks, radius=7, img_H=128, img_W=64, radius_single=10):
         r = radius if len(pts) > 1 else radius_single
         bbox[k] = (max(0, ys.min() - r), max(0, xs.min() - r), min(img_H - 1, ys.max() + r), min(img_W - 1, xs.max() + r))
         vis[k] = 1
+    return bbox, vis
+
+
+# DeepFashion converter (datasets/convert_DF.py:522-570): 37 keypoint groups -- the 7 of PARTS7 (arm groups as that file lists them),
+# torso corners, 8 limb segments, the whole body, the 18 single keypoints, the right and the left side
+PARTS37 = (PARTS7[:3] + ((5, 6, 7), (2, 3, 4), (11, 12, 13), (8, 9, 10)) +
+           ((2, 5, 8, 11), (5, 6), (6, 7), (2, 3), (3, 4), (11, 12), (12, 13), (8, 9), (9, 10), tuple(range(18))) +
+           tuple((i,) for i in range(18)) + ((2, 3, 4, 8, 9, 10), (5, 6, 7, 11, 12, 13)))
+
+
+def part_bbox37(peaks, img_H=256, img_W=256):
+    """datasets/convert_DF.py:522-655 `get_part_bbox`: the DeepFashion records' 37 region proposals (trainer_256.py:34-41 feeds the first 7
+    to the appearance encoder).  A person counts as a whole body when both lower legs (groups 13 and 15: left / right knee-ankle) have a
+    visible keypoint: margins (10, 20 for a single keypoint) then, (20, 40) for upper-body crops; the nose is lifted by 10 / 25 pixels
+    (not above the top edge) before the boxes are taken, so head boxes include the hair.  Otherwise the rules of `part_bbox7`.
+    Returns (bbox [37, 4] as (y1, x1, y2, x2), vis [37])."""
+    vis = np.array([1 if any(len(peaks[i]) for i in part) else 0 for part in PARTS37], dtype=np.int64)
+    whole = bool(vis[13] and vis[15])
+    r, r_single, lift = (10, 20, 10) if whole else (20, 40, 25)
+    bbox = np.zeros((len(PARTS37), 4), dtype=np.float64)
+    for k, part in enumerate(PARTS37):
+        xs, ys = [], []
+        for i in part:
+            if len(peaks[i]):
+                x, y = peaks[i][0][0], peaks[i][0][1]
+                if i == 0:
+                    y = max(0, y - lift)
+                xs.append(x)
+                ys.append(y)
+        if not xs:
+            bbox[k] = (0, 0, 1, 1)
+            continue
+        m = r if len(xs) > 1 else r_single
+        bbox[k] = (max(0, min(ys) - m), max(0, min(xs) - m), min(img_H - 1, max(ys) + m), min(img_W - 1, max(xs) + m))
     return bbox, vis
 
 

@@ -1,7 +1,8 @@
 """Generate tests/golden/prep_reference.npz -- body masks, part boxes and peak selection produced BY THE REFERENCE'S OWN CODE.
 
 The converter that writes the TFRecords (datasets/convert_market.py) needs TensorFlow / skimage / python 2 as a module, but
-five of its functions are plain python + numpy:
+five of its functions (and `get_part_bbox` of datasets/convert_DF.py:522-655, the DeepFashion records' 37 region proposals) are plain
+python + numpy:
 
     _get_valid_peaks   :339-376   pick the best-scoring person's keypoints out of OpenPose's candidates
     get_part_bbox7     :578-638   the 7 body-part boxes + visibility the Fg encoder crops (models.py:405-415)
@@ -68,6 +69,38 @@ def keypoint_cases():
     return kp
 
 
+REF_DF = "/root/reference/datasets/convert_DF.py"
+
+
+def reference_df_part_bbox():
+    """`get_part_bbox` of the DeepFashion converter (datasets/convert_DF.py:522-655): 37 region proposals; its image dumps sit behind
+    `idx is not None` and are never reached."""
+    tree = ast.parse(open(REF_DF).read(), REF_DF)
+    defs = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "get_part_bbox"]
+    assert len(defs) == 1
+    ns = {"np": _NumpyWithFloatAlias(), "xrange": range}
+    exec(compile(ast.Module(body=defs, type_ignores=[]), REF_DF, "exec"), ns)
+    return ns["get_part_bbox"]
+
+
+def df_keypoint_cases():
+    """[n, 18, 3] on the 256x256 DeepFashion canvas: whole bodies, upper-body crops (no lower legs), sparse detections, corner cases."""
+    rng = np.random.RandomState(4242)
+    n = 32
+    kp = np.zeros((n, 18, 3), dtype=np.float64)
+    kp[:, :, 0] = rng.randint(0, 256, size=(n, 18))
+    kp[:, :, 1] = rng.randint(0, 256, size=(n, 18))
+    kp[:, :, 2] = rng.uniform(size=(n, 18)) < 0.85
+    kp[8:16, [9, 10, 12, 13], 2] = 0                      # upper-body crops: knees and ankles missing -> the wide margins
+    kp[16:24, :, 2] = rng.uniform(size=(8, 18)) < 0.3     # sparse
+    kp[0, :, 2] = 1
+    kp[1, :, 2] = 0                                       # nothing visible: 37 sentinels
+    kp[2, :, 2] = 1; kp[2, 0, :2] = (100, 4)              # nose near the top edge: the lift is clipped at 0
+    kp[3, :, 2] = 0; kp[3, 0, :] = (128, 200, 1)          # the nose alone: single-keypoint margin 40, lifted by 25
+    kp[4, :, 2] = 1; kp[4, :, 0] = 255; kp[4, :, 1] = 255
+    return kp
+
+
 def to_peaks(kp):
     return [[(float(x), float(y), 1.0, i)] if p else [] for i, (x, y, p) in enumerate(kp)]
 
@@ -120,6 +153,16 @@ def main():
         assert set(np.unique(m).tolist()) <= {0.0, 1.0}
         masks.append(m.astype(np.uint8))
     fix = {"keypoints": kp, "part_bbox": np.stack(bbox), "part_vis": np.stack(vis), "mask_raster_bits": np.packbits(np.stack(masks), axis=-1)}
+    get_part_bbox = reference_df_part_bbox()
+    dkp = df_keypoint_cases()
+    dbox, dvis = [], []
+    for person in dkp:
+        b, v = get_part_bbox(to_peaks(person))
+        dbox.append(np.array(b, dtype=np.float64))
+        dvis.append(np.array(v, dtype=np.int64))
+    fix["df_keypoints"] = dkp
+    fix["df_part_bbox"] = np.stack(dbox)
+    fix["df_part_vis"] = np.stack(dvis)
     for i, (all_peaks, subsets) in enumerate(valid_peak_cases()):
         got = f["_get_valid_peaks"](all_peaks, subsets)
         flat = np.array([list(p) + [k] for k, c in enumerate(all_peaks) for p in c], dtype=np.float64).reshape(-1, 5)

@@ -1,6 +1,6 @@
 """Input builders (`dataprep`: body mask, part boxes, peak selection) against outputs of the REFERENCE'S OWN functions
 (tests/golden/prep_reference.npz, produced by tests/golden/make_prep_golden.py executing datasets/convert_market.py:229-376,
-578-638 from the reference's text), and the synthetic generators against the conventions those outputs show."""
+578-638 and datasets/convert_DF.py:522-655 from the reference's text), and the synthetic generators against the conventions those outputs show."""
 import os
 import sys
 
@@ -23,6 +23,23 @@ def test_part_boxes_and_visibility_equal_the_reference_builder():
     assert np.all(b[v == 0] == np.array([0, 0, 1, 1]))
     assert np.all(b[..., 0] >= 0) and np.all(b[..., 2] <= 127) and np.all(b[..., 1] >= 0) and np.all(b[..., 3] <= 63)
     assert np.all(b[v == 1][:, 2] >= b[v == 1][:, 0]) and np.all(b[v == 1][:, 3] >= b[v == 1][:, 1])
+
+
+def test_deepfashion_part_boxes_equal_the_reference_builder():
+    """datasets/convert_DF.py:522-655 `get_part_bbox` (37 proposals per person; trainer_256.py:34-41 uses the first 7): whole-body rule,
+    lifted nose, single-keypoint margins -- `dataprep.part_bbox37` against the reference function's own outputs."""
+    from dpig_amd import dataprep
+    kp = FIX["df_keypoints"]
+    whole = 0
+    for i in range(kp.shape[0]):
+        bbox, vis = dataprep.part_bbox37(dataprep.peaks_from_array(kp[i]))
+        assert np.array_equal(bbox, FIX["df_part_bbox"][i]), i
+        assert np.array_equal(vis, FIX["df_part_vis"][i]), i
+        whole += int(vis[13] and vis[15])
+    assert 0 < whole < kp.shape[0]                              # both margin regimes are in the fixture
+    b, v = FIX["df_part_bbox"], FIX["df_part_vis"]
+    assert b.shape[1:] == (37, 4) and np.all(b[v == 0] == np.array([0, 0, 1, 1]))
+    assert np.all(b >= 0) and np.all(b[..., 2] <= 255) and np.all(b[..., 3] <= 255)
 
 
 def test_body_mask_rasterisation_equals_the_reference_builder():
