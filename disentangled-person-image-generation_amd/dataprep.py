@@ -2,7 +2,7 @@
 offline converter (datasets/convert_market.py), restated so that inputs for the hot path (pose mask `mask_r6`, the 7 body-part
 boxes `part_bbox` and their visibility `part_vis`) can be produced from keypoints without the converter:
 
-    valid_peaks      datasets/convert_market.py:339-376  `_get_valid_peaks`  (the best-scoring person's keypoints)
+    valid_peaks      datasets/convert_market.py:339-376, utils.py:459-490, datasets/convert_DF.py:302-338  `_get_valid_peaks` (three variants)
     part_bbox7       datasets/convert_market.py:578-638  `get_part_bbox7`    (7 region proposals + visibility)
     part_bbox37      datasets/convert_DF.py:522-655      `get_part_bbox`     (DeepFashion: 37 proposals, whole-body rule, lifted nose)
     pose_mask_raster datasets/convert_market.py:229-276  `_getPoseMask`      (radius-4 discs along the 23 limbs)
@@ -29,27 +29,36 @@ def peaks_from_array(kp):
     return [[(float(x), float(y), 1.0, i)] if p else [] for i, (x, y, p) in enumerate(np.asarray(kp, dtype=np.float64))]
 
 
-def valid_peaks(all_peaks, subsets):
-    """convert_market.py:339-376: keep, per keypoint, the candidate that belongs to the person (row of `subsets`) with the
-    highest total score (`subset[-2]`); None when there is no person."""
+def valid_peaks(all_peaks, subsets, variant="market"):
+    """`_get_valid_peaks`: keep, per keypoint, the candidate that belongs to the person (row of `subsets`) with the highest total score
+    (`subset[-2]`; only scores above -1 count, the first maximum wins); of several matching candidates the LAST one.  The reference
+    holds three variants of this function that differ in what comes back:
+        "market"  datasets/convert_market.py:339-376  the selection; with no person: ALL candidates, untouched (":367 Avoid to return None")
+        "utils"   utils.py:459-490                    the selection; with no person: None
+        "df"      datasets/convert_DF.py:302-338      computes the selection and returns ALL candidates, untouched (:333); no person: None
+    and None whenever anything raises (a bare except), e.g. `subsets` without rows."""
+    if variant not in ("market", "utils", "df"):
+        raise ValueError("variant must be 'market', 'utils' or 'df'")
     subsets = np.asarray(subsets)
-    if subsets.ndim != 2 or subsets.shape[0] == 0:
-        return None
-    scores = subsets[:, -2]
+    if subsets.ndim != 2:
+        return None                                        # (`subset[-2]` of a scalar raises in the reference)
+    scores = subsets[:, -2].tolist() if subsets.shape[0] else []
     best = -1
     best_score = -1
-    for i, s in enumerate(scores.tolist()):          # first maximum wins, and only scores above -1 count (:349-351)
-        if s > best_score:
-            best, best_score = i, s
+    for i, sc in enumerate(scores):
+        if sc > best_score:
+            best, best_score = i, sc
     if best < 0:
-        return None
+        return all_peaks if variant == "market" else None
+    if variant == "df":
+        return all_peaks
     ids = subsets[best, :18].tolist()
     out = []
     for cands in all_peaks:
         keep = None
         for p in cands:
             if p[-1] in ids:
-                keep = p                               # the LAST matching candidate (:363-365)
+                keep = p
         out.append([keep] if keep is not None and len(keep) > 0 else [])
     return out
 

@@ -36,7 +36,7 @@ class _NumpyWithFloatAlias(object):
         return getattr(np, name)
 
 
-def reference_functions():
+def reference_functions(REF=REF, WANTED=WANTED):
     tree = ast.parse(open(REF).read(), REF)
     defs = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in WANTED]
     assert sorted(d.name for d in defs) == sorted(WANTED), [d.name for d in defs]
@@ -81,6 +81,18 @@ def reference_df_part_bbox():
     ns = {"np": _NumpyWithFloatAlias(), "xrange": range}
     exec(compile(ast.Module(body=defs, type_ignores=[]), REF_DF, "exec"), ns)
     return ns["get_part_bbox"]
+
+
+def reference_valid_peaks(path):
+    """The `_get_valid_peaks` of another file of the reference (utils.py:459-490, datasets/convert_DF.py:302-338: same selection,
+    different return conventions)."""
+    import sys
+    tree = ast.parse(open(path).read(), path)
+    defs = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "_get_valid_peaks"]
+    assert len(defs) == 1
+    ns = {"np": np, "sys": sys}
+    exec(compile(ast.Module(body=defs, type_ignores=[]), path, "exec"), ns)
+    return ns["_get_valid_peaks"]
 
 
 def df_keypoint_cases():
@@ -160,15 +172,35 @@ def main():
         b, v = get_part_bbox(to_peaks(person))
         dbox.append(np.array(b, dtype=np.float64))
         dvis.append(np.array(v, dtype=np.int64))
+    # the DeepFashion converter's own copy of the mask builder (datasets/convert_DF.py:197-247), on its 256 x 256 canvas
+    fdf = reference_functions(REF_DF, ("_getPoseMask", "_getSparseKeypoint", "_sparse2dense"))
+    dmasks = []
+    for person in dkp[:8]:
+        m = np.asarray(fdf["_getPoseMask"](to_peaks(person), 256, 256, radius=4, mode="Solid"), dtype=np.float64).reshape(256, 256)
+        assert set(np.unique(m).tolist()) <= {0.0, 1.0}
+        dmasks.append(m.astype(np.uint8))
+    fix["df_mask_raster_bits"] = np.packbits(np.stack(dmasks), axis=-1)
     fix["df_keypoints"] = dkp
     fix["df_part_bbox"] = np.stack(dbox)
     fix["df_part_vis"] = np.stack(dvis)
-    for i, (all_peaks, subsets) in enumerate(valid_peak_cases()):
-        got = f["_get_valid_peaks"](all_peaks, subsets)
+    variants = {"market": f["_get_valid_peaks"], "utils": reference_valid_peaks("/root/reference/utils.py"),
+                "df": reference_valid_peaks(REF_DF)}
+    cases = valid_peak_cases()
+    empty_scores = (cases[1][0], cases[1][1].copy())
+    empty_scores[1][:, 18] = -3.0                      # two people, neither with a score above -1: "no person"
+    cases += [empty_scores, (cases[2][0], np.zeros((0, 20)))]
+    for i, (all_peaks, subsets) in enumerate(cases):
         flat = np.array([list(p) + [k] for k, c in enumerate(all_peaks) for p in c], dtype=np.float64).reshape(-1, 5)
         fix["vp%d_candidates" % i] = flat              # (x, y, score, id, keypoint)
         fix["vp%d_subsets" % i] = subsets
-        fix["vp%d_selected" % i] = encode_peaks(got)
+        for v, fn in variants.items():                 # what each of the reference's three variants returns: 0 None, 1 a selection, 2 all_peaks itself
+            got = fn(all_peaks, subsets)
+            kind = 0 if got is None else (2 if got is all_peaks else 1)
+            fix["vp%d_%s_kind" % (i, v)] = np.array(kind)
+            if kind == 1:
+                fix["vp%d_%s_selected" % (i, v)] = encode_peaks(got)
+        if int(fix["vp%d_market_kind" % i]) == 1:
+            fix["vp%d_selected" % i] = fix["vp%d_market_selected" % i]
     path = os.path.join(HERE, "prep_reference.npz")
     np.savez_compressed(path, **fix)
     print("wrote", path, {k: v.shape for k, v in fix.items()})

@@ -50,20 +50,43 @@ def test_body_mask_rasterisation_equals_the_reference_builder():
     for i in range(kp.shape[0]):
         got = dataprep.pose_mask_raster(dataprep.peaks_from_array(kp[i]), 128, 64, radius=4)
         assert np.array_equal(got, ref[i]), i
+    # the DeepFashion converter's copy of the builder (datasets/convert_DF.py:197-247) on its 256 x 256 canvas
+    dkp = FIX["df_keypoints"]
+    dref = np.unpackbits(FIX["df_mask_raster_bits"], axis=-1)[..., :256].astype(np.float64)
+    assert dref.shape == (8, 256, 256) and dref[1].sum() == 0 and dref[0].sum() > 0
+    for i in range(dref.shape[0]):
+        assert np.array_equal(dataprep.pose_mask_raster(dataprep.peaks_from_array(dkp[i]), 256, 256, radius=4), dref[i]), i
 
 
 def test_valid_peak_selection_equals_the_reference_builder():
+    """`_get_valid_peaks` exists three times in the reference (datasets/convert_market.py:339-376, utils.py:459-490,
+    datasets/convert_DF.py:302-338) with the same selection and different return conventions (no person: all candidates / None; the
+    DeepFashion copy returns all candidates even after selecting): every variant against its own function's output, for 1 - 3 people,
+    for people whose scores are all below -1 and for an empty person table."""
     from dpig_amd import dataprep
-    for i in range(3):
-        cand, subsets, want = FIX["vp%d_candidates" % i], FIX["vp%d_subsets" % i], FIX["vp%d_selected" % i]
+    n = 0
+    while "vp%d_candidates" % n in FIX.files:
+        n += 1
+    assert n == 5
+    kinds = set()
+    for i in range(n):
+        cand, subsets = FIX["vp%d_candidates" % i], FIX["vp%d_subsets" % i]
         all_peaks = [[tuple(r[:3]) + (int(r[3]),) for r in cand if int(r[4]) == k] for k in range(18)]
-        got = dataprep.valid_peaks(all_peaks, subsets)
-        enc = np.zeros((18, 5))
-        for k, p in enumerate(got):
-            if len(p):
-                enc[k, :4], enc[k, 4] = p[0], 1
-        assert np.array_equal(enc, want), i
-    assert dataprep.valid_peaks([[] for _ in range(18)], np.zeros((0, 20))) is None
+        for v in ("market", "utils", "df"):
+            kind = int(FIX["vp%d_%s_kind" % (i, v)])
+            kinds.add((v, kind))
+            got = dataprep.valid_peaks(all_peaks, subsets, v)
+            if kind == 0:
+                assert got is None, (i, v)
+            elif kind == 2:
+                assert got is all_peaks, (i, v)
+            else:
+                enc = np.zeros((18, 5))
+                for k, p in enumerate(got):
+                    if len(p):
+                        enc[k, :4], enc[k, 4] = p[0], 1
+                assert np.array_equal(enc, FIX["vp%d_%s_selected" % (i, v)]), (i, v)
+    assert kinds == {("market", 1), ("market", 2), ("utils", 1), ("utils", 0), ("df", 2), ("df", 0)}
 
 
 def test_closing_is_scipy_grey_closing_with_ignored_borders():
