@@ -1,4 +1,4 @@
-"""Randomised ordering check of the k-loops of bq_kernel<2,4> / <4,2>, bhq_kernel (the shipped large-tile kernels) and bhq32_kernel (the experimental
+"""Randomised ordering check of the k-loops of bq_kernel<2,4> / <4,2>, bhq_kernel, bwq_kernel<2,4> / <4,2> (the shipped large-tile kernels) and bhq32_kernel (the experimental
 BK = 32 variant; csrc/dpig_conv_bf16_q.hip, scripts/ubench/bhq32_probe.hip): eight waves run the kernel's instruction stream (fragment reads, LDS-DMA issues, counted vmcnt waits, the two barriers per k-tile, groups staggered by
 one barrier) under a random scheduler; every DMA piece lands at a random later time, in issue order per wave (the only guarantee
 vmcnt gives).  A fragment read must find the piece of ITS k-tile / chunk in the LDS region it reads, and never a region with a DMA
@@ -137,6 +137,40 @@ def program_bq(wave, nkt, WM=2, WN=4, relax=0):
     return prog
 
 
+def program_bwq(wave, nkt, WM=2, WN=4, relax=0):
+    """bwq_kernel<WM, WN> (wgrad, csrc/dpig_conv_bf16_wq.hip): k = pixels, 64 per k-tile; units are cut along k: X01 = pixels 0..31 and
+    X23 = pixels 32..63 of every x block (WM items) and dy block (WN / 2 blocks of 128 co), 8 pieces of 4 pixel rows per block and unit.
+    PA(t) reads X01(t) and stages X23(t + 1) into the other slot, PB(t) reads X23(t) and stages X01(t + 2) into its own."""
+    NA, NB = WM, WN // 2
+    VMC = 2 * (NA + NB) + relax
+    grp = wave >> 2
+    wr, wc = wave // WN, wave % WN
+    prog = []
+
+    def issue(t, u):
+        tag = t if t < nkt else "dead"
+        for j in range(NA):
+            prog.append(("dma", ("X", t & 1, j, u, wave), tag))
+        for j in range(NB):
+            prog.append(("dma", ("Y", t & 1, j, u, wave), tag))
+
+    issue(0, 0); issue(0, 1); issue(1, 0)
+    prog.append(("wait", NA + NB))
+    prog.append(("bar",))
+    if grp == 1:
+        prog.append(("bar",))
+    for t in range(nkt):
+        for u in range(2):
+            prog.append(("read", [("X", t & 1, wr, u, k) for k in range(8)] + [("Y", t & 1, wc // 2, u, k) for k in range(8)], t))
+            issue(t + 1, 1) if u == 0 else issue(t + 2, 0)
+            prog.append(("wait", VMC))
+            prog.append(("bar",)); prog.append(("mfma",)); prog.append(("bar",))
+    if grp == 0:
+        prog.append(("bar",))
+    prog.append(("wait", 0))
+    return prog
+
+
 def run(nch, seed, lazy=0.5, make=None):
     rng = random.Random(seed)
     progs = [(make or program)(w, nch) for w in range(8)]
@@ -229,6 +263,19 @@ if __name__ == "__main__":
         print("WARNING: bq's relaxed wait was not caught"); sys.exit(1)
     except AssertionError as e:
         print("bq: a wait relaxed by one piece is caught as expected:", e.args[0][0])
+    n = 0
+    for (WM, WN) in ((2, 4), (4, 2)):
+        for nkt in (2, 3, 16):
+            for seed in range(60):
+                run(nkt, seed, lazy=(0.98, 0.5, 0.1, 0.02)[seed % 4], make=lambda w, k: program_bwq(w, k, WM, WN))
+                n += 1
+    print("bwq<2,4> / bwq<4,2> (wgrad) k-loops: %d random schedules, every fragment read saw its own k-tile's data with no DMA in flight" % n)
+    try:
+        for seed in range(300):
+            run(9, seed, lazy=0.02, make=lambda w, k: program_bwq(w, k, 2, 4, relax=1))
+        print("WARNING: bwq's relaxed wait was not caught"); sys.exit(1)
+    except AssertionError as e:
+        print("bwq: a wait relaxed by one piece is caught as expected:", e.args[0][0])
     # the check has teeth: a too-lax wait (one more piece allowed in flight) must be caught
     WAIT[4] += 1
     try:

@@ -173,7 +173,7 @@ def test_workspace_is_per_device_and_stream_key():
 
 
 def test_halo_staged_kloop_ordering_model():
-    """The k-loops of bhq_kernel and bq_kernel<2,4> / <4,2> (csrc/dpig_conv_bf16_q.hip) as executable ordering models (scripts/ubench/simulate_kloop_hazards.py):
+    """The k-loops of bhq_kernel, bq_kernel<2,4> / <4,2> (csrc/dpig_conv_bf16_q.hip) and bwq_kernel (dpig_conv_bf16_wq.hip) as executable ordering models (scripts/ubench/simulate_kloop_hazards.py):
     the eight waves' fragment reads, LDS-DMA issues, counted vmcnt waits and barriers under random schedules with early and late DMA
     landings -- every read must see its own k-tile's / chunk's data with no DMA in flight to that LDS region; a wait relaxed by one piece
     must be caught (the model has teeth).  A regression guard for edits of the schedule; the kernel itself is tested on the GPU."""
@@ -199,3 +199,10 @@ def test_halo_staged_kloop_ordering_model():
     with pytest.raises(AssertionError):
         for seed in range(200):
             sim.run(9, seed, lazy=0.02, make=lambda w, k: sim.program_bq(w, k, 2, 4, relax=1))
+    for (WM, WN) in ((2, 4), (4, 2)):                                        # bwq_kernel<2,4> / <4,2> (wgrad: units cut along k)
+        for nkt in (2, 3, 9):
+            for seed in range(8):
+                sim.run(nkt, seed, lazy=(0.98, 0.5, 0.1, 0.02)[seed % 4], make=lambda w, k: sim.program_bwq(w, k, WM, WN))
+    with pytest.raises(AssertionError):
+        for seed in range(200):
+            sim.run(9, seed, lazy=0.02, make=lambda w, k: sim.program_bwq(w, k, 2, 4, relax=1))
