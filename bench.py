@@ -428,6 +428,7 @@ def main():
             "achieved_alg_tflops": round(ALG_GFLOP_PER_IMG * value / 1e3, 2) if headline else None,
             "losses": {k: float(v) for k, v in out.items() if hasattr(v, "numel") and v.numel() == 1 and not sampling},
             "roofline": roofline, "cpu_baseline": cpu,
+            "build_mode": __graft_entry__.BUILD_MODE,      # "compiled": this process rebuilt the library; "reused": the shipped .so was fresh
         }
         if comm is not None:
             line["allreduce_ms"], line["exposed_ms"], line["comm"] = comm["allreduce_ms"], comm["exposed_ms"], comm

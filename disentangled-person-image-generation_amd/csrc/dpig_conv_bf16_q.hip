@@ -753,17 +753,18 @@ __global__ __launch_bounds__(512, 2) void bhq_kernel(const BGParams p) {
     }
 }
 
-#ifdef DPIG_EXPERIMENTAL_BHQ32
 // ================================================================================================
-// bhq32_kernel (EXPERIMENTAL: compiled only with -DDPIG_EXPERIMENTAL_BHQ32, and then off unless DPIG_BF16_QH32=1; written at the end of round 3 without GPU minutes left -- it builds, its index
-// math is emulated on the host (scripts/ubench/check_bhq32_indexing.py, emulate_bhq32.py: the data path equals a direct convolution), it
-// has not run): the halo-staged schedule at BK = 32 for the 128-column layers that bq_kernel<4, 2> serves today without halo staging.
+// bhq32_kernel: the halo-staged schedule at BK = 32 for the 128-column layers (C -> 128 at full resolution: the encoder stems / residual
+// blocks of models.py:396-400, 420-426) that bq_kernel<4, 2> serves without halo staging.
 // 8 waves as 4 (8 x 16-pixel patches) x 2 (64 channels): a 32 x 16-pixel patch x 128 channels per workgroup; LDS rows of 64 B; per
 // 32-channel chunk the 10 x 18 halo of every wave row at a pitch of 20 pixels (13 pieces of 16 pixels, two chunk slots = 104 KB), 16-byte
 // slot s of pixel hx holds granule s ^ ((hx >> 2) & 3); filter tiles [128 columns][32 k] = 8 KB in FOUR slots (prefetch distance 3), one
 // piece per wave per k-tile; a k-tile is one phase {12 fragment reads; filter piece of tile t + 3, halo piece of the next chunk in taps
 // 0..6; counted vmcnt {3, 4, 5, 5, 5, 5, 5, 4, 3}[tap]; barrier; 16 MFMAs; barrier}, groups staggered by one barrier.  The wave tile
-// and the D^T accumulators are bhq_kernel's, so the epilogue is the same.  See scripts/ubench/bhq32_probe.hip for the stand-alone form.
+// and the D^T accumulators are bhq_kernel's, so the epilogue is the same.  scripts/ubench/bhq32_probe.hip is the stand-alone form
+// (self-check against a direct convolution); its index math is also emulated on the host (scripts/ubench/emulate_bhq32.py).
+// Measured (round 4, profiles/r04_bhq32_first_run.txt): 8 x 256 x 256 x 128 -> 128 forward 914 -> 1021 TFLOP/s, dgrad 676 -> 843 against
+// the 128 x 128 halo kernel on the same box; DPIG_BF16_QH32=0 is the A/B switch.
 // ================================================================================================
 struct H32 {
     static constexpr int RB = 64, HP = 20, NPX = 10 * HP, NPIECE = 13, WR_B = NPIECE * 16 * RB, HSLOT = 4 * WR_B;
@@ -925,8 +926,6 @@ __global__ __launch_bounds__(512, 2) void bhq32_kernel(const BGParams p) {
     }
 }
 
-#endif  // DPIG_EXPERIMENTAL_BHQ32
-
 // ================================================================================================
 // host side
 // ================================================================================================
@@ -957,10 +956,8 @@ static bool bhq_eligible(const BGParams& p) {
     return known;
 }
 
-#ifdef DPIG_EXPERIMENTAL_BHQ32
-static int g_q_halo32 = []() { const char* e = getenv("DPIG_BF16_QH32"); return e ? atoi(e) : 0; }();   // EXPERIMENTAL (see bhq32_kernel): off
+static int g_q_halo32 = []() { const char* e = getenv("DPIG_BF16_QH32"); return e ? atoi(e) : 1; }();   // halo-staged 512 x 128 variant (A/B switch)
 static bool bhq32_eligible(const BGParams& p) { return bhq_eligible(p) && !(p.Hs & 31); }
-#endif
 
 // Fraction of the launched MFMA work that is real when the tiles of bm x bn run `slots` at a time in whole rounds.
 static double q_eff(long M, long N, int bm, int bn, int slots) {
@@ -980,7 +977,9 @@ int bq_try(BGParams& p, hipStream_t st) {
     // CU runs the 256 x 256 kernel ~1.15x and the 512 x 128 kernel ~1.04x as fast as two 128 x 128 workgroups; what decides
     // is how well each tile grid fills whole rounds of the chip (256 slots here, 512 there).
     const bool halo = g_q_halo && bhq_eligible(p);       // (the halo-staged 256 x 256 kernel: another ~5 %)
-    const double e1 = q_eff(p.M, p.Ncols, 256, 256, kNumCU) * (halo ? 1.21 : 1.15), e2 = q_eff(p.M, p.Ncols, 512, 128, kNumCU) * 1.04;
+    const bool halo32 = g_q_halo32 && bhq32_eligible(p);   // (the halo-staged 512 x 128 kernel: ~1.12x the 128 x 128 halo kernel)
+    const double e1 = q_eff(p.M, p.Ncols, 256, 256, kNumCU) * (halo ? 1.21 : 1.15);
+    const double e2 = q_eff(p.M, p.Ncols, 512, 128, kNumCU) * (halo32 ? 1.12 : 1.04);
     int variant = g_q_variant ? g_q_variant : (e2 > e1 ? 2 : 1);
     if (g_q_mode == 1) {
         if (p.nsplit > 1) return 0;                      // the split-K plan of the 128 x 128 family wins on small layers
@@ -1006,8 +1005,7 @@ int bq_try(BGParams& p, hipStream_t st) {
         const int rch = check_launch("bhq_kernel");
         return rch ? rch : 1;
     }
-#ifdef DPIG_EXPERIMENTAL_BHQ32
-    if (variant == 2 && g_q_halo32 && bhq32_eligible(p)) {
+    if (variant == 2 && halo32) {
         q.tiles_x = p.Ws / 16; q.tiles_y = p.Hs / 32;
         q.mtiles = (p.M / (p.Hs * p.Ws)) * q.tiles_x * q.tiles_y;
         dim3 hgrid(q.mtiles * q.ntiles, 1, 1);
@@ -1015,7 +1013,6 @@ int bq_try(BGParams& p, hipStream_t st) {
         const int rch = check_launch("bhq32_kernel");
         return rch ? rch : 1;
     }
-#endif
     if (variant == 1) hipLaunchKernelGGL((bq_kernel<2, 4>), grid, block, 0, st, q);
     else hipLaunchKernelGGL((bq_kernel<4, 2>), grid, block, 0, st, q);
     const int rc = check_launch("bq_kernel");

@@ -1,7 +1,6 @@
-"""First GPU check of the EXPERIMENTAL bhq32_kernel (csrc/dpig_conv_bf16_q.hip; off by default, never run when it was written):
+"""GPU check + timing of bhq32_kernel (csrc/dpig_conv_bf16_q.hip), the halo-staged 512 x 128 kernel of the 128-column 3x3 layers:
 
-    bash scripts/build_experimental.sh                                   # the library with -DDPIG_EXPERIMENTAL_BHQ32 -> scripts/ubench/libdpig_exp.so
-    DPIG_LIB_PATH=scripts/ubench/libdpig_exp.so DPIG_BF16_QH32=1 timeout 120 python scripts/check_bhq32.py   # (own timeout: a hang must not cost a strike)
+    timeout 120 python scripts/check_bhq32.py        # (own timeout: a hang must not cost a strike)
 
 Forward (+ bias + ReLU, + residual) and the stride-1 dgrad (* mask) of 128-column 3x3 layers with the 512 x 128 variant forced -- which the
 switch routes to bhq32_kernel where the layer is eligible -- against the 128 x 128 kernels (large tiles off) on the same operands: the k
@@ -10,7 +9,6 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import dpig_amd.hip_ops as H
-assert os.environ.get("DPIG_BF16_QH32") == "1", "set DPIG_BF16_QH32=1"
 dev = torch.device("cuda:0"); BF = torch.bfloat16
 
 

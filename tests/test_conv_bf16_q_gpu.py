@@ -128,6 +128,63 @@ def test_upsampled_1x1(dev, large_tile):
     _close_bf16(got, ref)
 
 
+# ---- bhq32_kernel: the halo-staged 512 x 128 kernel (32 x 16-pixel patches, 32-channel k-tiles) -------------------------------
+# (N, H, W, C, K): H a multiple of 32, W of 16, C of 64 -- what routes the forced 512 x 128 variant to it
+BHQ32_SHAPES = [
+    (2, 32, 16, 64, 128),      # one patch per image, two 32-channel chunks (the next chunk's halo is staged exactly once)
+    (1, 64, 48, 128, 128),     # 2 x 3 patches: interior halos on every side
+    (3, 32, 32, 192, 104),     # 104 columns: a partial column tile (dead filter rows), 6 chunks
+    (1, 32, 16, 64, 264),      # three column tiles, the last one with 8 live columns
+]
+
+
+@pytest.mark.parametrize("shape", BHQ32_SHAPES)
+def test_halo_staged_512x128_kernel_against_oracle(dev, shape):
+    """Forward (every fused epilogue of the family) and the stride-1 dgrad of 3x3 layers on bhq32_kernel against the fp64 oracle on
+    the bf16-rounded operands, and launch-after-launch repeatability (the counted-vmcnt pipeline's hazards are timing dependent)."""
+    import dpig_amd.hip_ops as H
+    from oracle import ops as O
+    N, Hh, W, C, K = shape
+    x = _rand((N, Hh, W, C), 21)
+    w = _rand((3, 3, C, K), 22, 0.2)
+    b = _rand((K,), 23)
+    res = _rand((N, Hh, W, K), 24)
+    dy = _rand((N, Hh, W, K), 26)
+    acc, m = _rand((N, Hh, W, C), 27), _rand((N, Hh, W, C), 28)
+    xd, wd, bd, rd = x.float().to(dev).to(BF), w.float().to(dev), b.float().to(dev), res.float().to(dev).to(BF)
+    dyd, ad, md = dy.float().to(dev).to(BF), acc.float().to(dev).to(BF), m.float().to(dev).to(BF)
+    xr = _r(x).requires_grad_(True)
+    conv0 = O.conv2d_same(xr, _r(w), None, 1)
+    conv = conv0.detach() + b.float().double()
+    conv0.backward(_r(dy))
+    try:
+        H.set_large_tile(2, 2)
+        y1 = H.conv2d_fwd(xd, wd, bd, act=1)
+        _close_bf16(y1, O.relu(conv))
+        _close_bf16(H.conv2d_fwd(xd, wd, None), conv0.detach())
+        _close_bf16(H.conv2d_fwd(xd, wd, bd, act=2, alpha=0.2, residual=rd), O.leaky_relu(conv + _r(res), 0.2))
+        out, out_act = torch.empty((N, Hh, W, K), dtype=BF, device=dev), torch.empty((N, Hh, W, K), dtype=BF, device=dev)
+        H.conv2d_fwd(xd, wd, bd, act=1, residual=rd, res_after_act=True, out=out, out_act=out_act)
+        _close_bf16(out_act, O.relu(conv))
+        assert torch.equal(out.cpu(), (out_act.float() + rd.float()).to(BF).cpu())
+        dx1 = H.conv2d_dgrad(dyd, wd, (N, Hh, W, C), mask=md, act=1)
+        _close_bf16(dx1, xr.grad * (_r(m) > 0))
+        _close_bf16(H.conv2d_dgrad(dyd, wd, (N, Hh, W, C)), xr.grad)
+        _close_bf16(H.conv2d_dgrad(dyd, wd, (N, Hh, W, C), accum=ad, mask=md, act=2, alpha=0.2),
+                    (xr.grad + _r(acc)) * torch.where(_r(m) > 0, 1.0, 0.2))
+        # channel slices of wider buffers on both sides
+        xbig = torch.zeros((N, Hh, W, C + 64), dtype=BF, device=dev)
+        xbig[..., 64:] = xd
+        ybig = torch.full((N, Hh, W, K + 64), 7.0, dtype=BF, device=dev)
+        H.conv2d_fwd(xbig[..., 64:], wd, bd, act=1, out=ybig[..., :K])
+        assert torch.equal(ybig[..., :K], y1) and (ybig[..., K:] == 7.0).all()
+        for _ in range(4):
+            assert torch.equal(H.conv2d_fwd(xd, wd, bd, act=1), y1)
+            assert torch.equal(H.conv2d_dgrad(dyd, wd, (N, Hh, W, C), mask=md, act=1), dx1)
+    finally:
+        H.set_large_tile(1, 0)
+
+
 def _full_size_operands(dev, N, Hh, W, C, K):
     g = torch.Generator(device="cpu").manual_seed(11)
     x = (torch.rand((N, Hh, W, C), generator=g) * 2 - 1).to(dev).to(BF)
