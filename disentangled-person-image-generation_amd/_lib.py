@@ -101,11 +101,15 @@ SYMBOLS = {
     "dpig_bn_apply": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _i, _vp]),
     "dpig_bn_bwd_sums": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _sz, _vp]),
     "dpig_bn_bwd_apply": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _vp, _i, _f, _f, _vp, _i, _vp]),
-    "dpig_ln_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _i, _f, _vp, _vp, _vp, _vp]),
+    "dpig_ln_fwd_workspace_bytes": (_sz, [_i, _i, _i]),
+    "dpig_ln_fwd": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dpig_ln_fwd_bf16": (_i, [_vp, _i, _i, _i, _vp, _vp, _f, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dpig_ln_workspace_bytes": (_sz, [_i, _i, _i]),
     "dpig_ln_bwd": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dpig_ln_bwd_bf16": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dpig_ln_bwd2_workspace_bytes": (_sz, [_i, _i, _i]),
     "dpig_ln_bwd2": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dpig_ln_bwd2_bf16": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _i, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dpig_linear_workspace_bytes": (_sz, [_i, _i, _i, _i]),
     "dpig_linear_fwd": (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _sz, _vp]),
     "dpig_linear_dgrad": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _sz, _vp]),
@@ -121,8 +125,10 @@ SYMBOLS = {
     "dpig_ssim_workspace_bytes": (_sz, [_i, _i, _i]),
     "dpig_ssim_gray_u8": (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _sz, _vp]),
     "dpig_gp_interpolate": (_i, [_vp, _vp, _vp, _i, _i64, _vp, _vp]),
-    "dpig_gp_penalty": (_i, [_vp, _i, _i64, _f, _vp, _vp, _vp, _vp]),
+    "dpig_gp_penalty_workspace_bytes": (_sz, [_i, _i64]),
+    "dpig_gp_penalty": (_i, [_vp, _i, _i64, _f, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dpig_gp_double_backward_workspace_bytes": (_sz, [ctypes.POINTER(DpigCriticDesc)]),
+    "dpig_gp_double_backward_slot": (_i, [ctypes.POINTER(DpigCriticDesc), _i, _i, ctypes.POINTER(_sz), ctypes.POINTER(_sz)]),
     "dpig_gp_double_backward": (_i, [ctypes.POINTER(DpigCriticDesc), ctypes.POINTER(DpigCriticParams), _vp, _vp, _vp, _f,
                                      ctypes.POINTER(DpigCriticParams), _vp, _vp, _vp, _sz, _vp]),
     "dpig_upsample2x_fwd": (_i, [_vp, _i, _i, _i, _i, _vp, _vp]),

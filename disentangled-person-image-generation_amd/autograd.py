@@ -219,6 +219,22 @@ class _ConvDgradFn(torch.autograd.Function):
         return d_dz, d_w, None, None, None
 
 
+class _CastFn(torch.autograd.Function):
+    """fp32 <-> bf16 storage conversion that stays on the tape (its gradient is the opposite conversion), for backward passes that are
+    differentiated once more: a raw conversion kernel would cut the second-order graph behind it."""
+
+    @staticmethod
+    def forward(ctx, x, to_bf16):
+        ctx.to_bf16 = to_bf16
+        return H.to_bf16(x) if to_bf16 else H.to_f32(x)
+
+    @staticmethod
+    def backward(ctx, d):
+        if torch.is_grad_enabled():
+            return _CastFn.apply(d, not ctx.to_bf16), None
+        return (H.to_f32(d) if ctx.to_bf16 else H.to_bf16(d)), None
+
+
 class _LinearDgradFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dz, w):
@@ -241,7 +257,7 @@ class _LNBwdFn(torch.autograd.Function):
     def forward(ctx, dy, x, y, scale, mean, rstd, act, alpha):
         ctx.save_for_backward(dy, x, y, scale, mean, rstd)
         ctx.cfg = (act, alpha)
-        dx, _, _ = H.ln_bwd(dy, x, y, scale, mean, rstd, act, alpha)
+        dx, _, _ = H.ln_bwd(dy, x, y, scale, mean, rstd, act, alpha, want_params=False)
         return dx
 
     @staticmethod
@@ -647,7 +663,10 @@ class _LinearFn(torch.autograd.Function):
         if has_b and ctx.needs_input_grad[2] and not _PARAM_GRADS_OFF[0]:
             db = _sink(ctx.b_ref, lambda o, beta: H.colsum(dz, out=o, beta=beta))
         if dx is not None and dx.dtype != x.dtype:
-            dx = H.to_bf16(dx) if x.dtype == H.BF16 else H.to_f32(dx)
+            if torch.is_grad_enabled():        # (on the tape: the penalty's gradient w.r.t. `w` flows back through this conversion)
+                dx = _CastFn.apply(dx, x.dtype == H.BF16)
+            else:
+                dx = H.to_bf16(dx) if x.dtype == H.BF16 else H.to_f32(dx)
         return dx, dw, db, None, None
 
 

@@ -320,9 +320,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// layer norm: one 1024-thread workgroup per sample (N <= a few dozen, L = P*C <= ~1M)
-// ---------------------------------------------------------------------------------------------
+// (the LayerNorm family and the WGAN-GP penalty reduction live in dpig_norm.hip)
+// sum over a 1024-thread workgroup (the loss kernels below); the result is the same in every thread
 __device__ __forceinline__ float block_sum_1024(float v, float* red) {
     v = wave_sum(v);
     const int w = threadIdx.x >> 6, l = threadIdx.x & 63;
@@ -336,123 +335,6 @@ __device__ __forceinline__ float block_sum_1024(float v, float* red) {
     }
     __syncthreads();
     return red[16];
-}
-
-__global__ __launch_bounds__(1024) void ln_fwd_kernel(const float* __restrict__ x, int P, int C,
-                                                      const float* __restrict__ scale,
-                                                      const float* __restrict__ offset, float eps, int act,
-                                                      float alpha, float* __restrict__ y,
-                                                      float* __restrict__ save_mean,
-                                                      float* __restrict__ save_rstd) {
-    __shared__ float red[17];
-    const long L = (long)P * C;
-    const float* xs = x + (long)blockIdx.x * L;
-    float* ys = y + (long)blockIdx.x * L;
-    float s = 0.f;
-    for (long i = threadIdx.x; i < L; i += 1024) s += xs[i];
-    const float mean = block_sum_1024(s, red) / (float)L;
-    float q = 0.f;
-    for (long i = threadIdx.x; i < L; i += 1024) { const float d = xs[i] - mean; q += d * d; }
-    const float var = block_sum_1024(q, red) / (float)L;
-    const float rstd = 1.0f / sqrtf(var + eps);
-    if (threadIdx.x == 0) { save_mean[blockIdx.x] = mean; save_rstd[blockIdx.x] = rstd; }
-    for (long i = threadIdx.x; i < L; i += 1024) {
-        const int c = (int)(i % C);
-        ys[i] = act_apply((xs[i] - mean) * rstd * scale[c] + offset[c], act, alpha);
-    }
-}
-
-__global__ __launch_bounds__(1024) void ln_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
-                                                      const float* __restrict__ y, int P, int C,
-                                                      const float* __restrict__ scale,
-                                                      const float* __restrict__ mean,
-                                                      const float* __restrict__ rstd, int act, float alpha,
-                                                      float* __restrict__ dx) {
-    __shared__ float red[17];
-    const long L = (long)P * C;
-    const long base = (long)blockIdx.x * L;
-    const float mu = mean[blockIdx.x], rs = rstd[blockIdx.x];
-    float s1 = 0.f, s2 = 0.f;
-    for (long i = threadIdx.x; i < L; i += 1024) {
-        const int c = (int)(i % C);
-        float dz = dy[base + i];
-        if (act != DPIG_ACT_NONE) dz *= act_grad(y[base + i], act, alpha);
-        const float g = dz * scale[c];
-        s1 += g;
-        s2 += g * (x[base + i] - mu) * rs;
-    }
-    const float S1 = block_sum_1024(s1, red) / (float)L;
-    const float S2 = block_sum_1024(s2, red) / (float)L;
-    for (long i = threadIdx.x; i < L; i += 1024) {
-        const int c = (int)(i % C);
-        float dz = dy[base + i];
-        if (act != DPIG_ACT_NONE) dz *= act_grad(y[base + i], act, alpha);
-        const float xh = (x[base + i] - mu) * rs;
-        dx[base + i] = rs * (dz * scale[c] - S1 - xh * S2);
-    }
-}
-
-// Second-order LayerNorm: the backward of ln_bwd_kernel (needed by the WGAN-GP penalty, whose loss is a
-// function of dD/dx -- trainer.py:233-236; SURVEY Appendix E "down-sweep").  With g = dz*gamma,
-// dx = r*(g - mean(g) - xh*mean(g*xh)) and upstream u = dP/d(dx):
-//   dP/dg_i  = r*(u_i - mean(u) - xh_i*mean(u*xh))
-//   dP/dxh_i = -r*(mean(g*xh)*u_i + mean(u*xh)*g_i),   dP/dr = sum_i u_i*(g_i - mean(g) - xh_i*mean(g*xh))
-//   dP/dx_j  = r*(q_j - mean(q) - xh_j*mean(q*xh)) - (dP/dr)*r^2*xh_j/L          (q = dP/dxh)
-// gs = dP/dg * dz is written for the per-channel gamma gradient (column sum over samples).
-__global__ __launch_bounds__(1024) void ln_bwd2_kernel(const float* __restrict__ u, const float* __restrict__ dy,
-                                                       const float* __restrict__ x, const float* __restrict__ y,
-                                                       int P, int C, const float* __restrict__ scale,
-                                                       const float* __restrict__ mean,
-                                                       const float* __restrict__ rstd, int act, float alpha,
-                                                       float* __restrict__ d_dy, float* __restrict__ d_x,
-                                                       float* __restrict__ gs) {
-    __shared__ float red[17];
-    const long L = (long)P * C;
-    const long base = (long)blockIdx.x * L;
-    const float mu = mean[blockIdx.x], r = rstd[blockIdx.x];
-    const float invL = 1.0f / (float)L;
-    float su = 0.f, sux = 0.f, sg = 0.f, sgx = 0.f;
-    for (long i = threadIdx.x; i < L; i += 1024) {
-        const int c = (int)(i % C);
-        float dz = dy[base + i];
-        if (act != DPIG_ACT_NONE) dz *= act_grad(y[base + i], act, alpha);
-        const float g = dz * scale[c];
-        const float xh = (x[base + i] - mu) * r;
-        const float uu = u[base + i];
-        su += uu; sux += uu * xh; sg += g; sgx += g * xh;
-    }
-    const float mu_u = block_sum_1024(su, red) * invL;
-    const float cc = block_sum_1024(sux, red) * invL;
-    const float a = block_sum_1024(sg, red) * invL;
-    const float b = block_sum_1024(sgx, red) * invL;
-    float s1 = 0.f, sq = 0.f, sqx = 0.f;
-    for (long i = threadIdx.x; i < L; i += 1024) {
-        const int c = (int)(i % C);
-        float dz = dy[base + i];
-        if (act != DPIG_ACT_NONE) dz *= act_grad(y[base + i], act, alpha);
-        const float g = dz * scale[c];
-        const float xh = (x[base + i] - mu) * r;
-        const float uu = u[base + i];
-        const float q = -r * (b * uu + cc * g);
-        s1 += uu * (g - a - xh * b);
-        sq += q; sqx += q * xh;
-    }
-    const float U1 = block_sum_1024(s1, red);
-    const float mq = block_sum_1024(sq, red) * invL;
-    const float mqx = block_sum_1024(sqx, red) * invL;
-    for (long i = threadIdx.x; i < L; i += 1024) {
-        const int c = (int)(i % C);
-        const float ag = (act != DPIG_ACT_NONE) ? act_grad(y[base + i], act, alpha) : 1.f;
-        const float dz = dy[base + i] * ag;
-        const float g = dz * scale[c];
-        const float xh = (x[base + i] - mu) * r;
-        const float uu = u[base + i];
-        const float dg = r * (uu - mu_u - xh * cc);
-        const float q = -r * (b * uu + cc * g);
-        d_dy[base + i] = dg * scale[c] * ag;
-        d_x[base + i] = r * (q - mq - xh * mqx) - U1 * r * r * xh * invL;
-        gs[base + i] = dg * dz;
-    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -872,27 +754,6 @@ __global__ __launch_bounds__(256) void gp_interpolate_kernel(const float* __rest
         xhat[i] = r + a * (fake[i] - r);
     }
 }
-// one workgroup per sample: slope = ||g_b||, then dg_b = coef * g_b with coef = lambda*2*(slope-1)/(B*slope)
-__global__ __launch_bounds__(256) void gp_penalty_kernel(const float* __restrict__ g, int B, long D, float lambda,
-                                                         float* __restrict__ dg, float* __restrict__ slopes) {
-    __shared__ float red[4];
-    const int b = blockIdx.x;
-    const float* gb = g + (long)b * D;
-    float s = 0.f;
-    for (long i = threadIdx.x; i < D; i += 256) { const float v = gb[i]; s += v * v; }
-    s = block_reduce_256(s, red, 0);
-    const float slope = sqrtf(s);
-    if (threadIdx.x == 0) slopes[b] = slope;
-    const float coef = slope > 0.f ? lambda * 2.f * (slope - 1.f) / ((float)B * slope) : 0.f;
-    float* db = dg + (long)b * D;
-    for (long i = threadIdx.x; i < D; i += 256) db[i] = coef * gb[i];
-}
-__global__ void gp_final_kernel(const float* __restrict__ slopes, int B, float lambda, float* __restrict__ penalty) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    float s = 0.f;
-    for (int b = 0; b < B; ++b) { const float d = slopes[b] - 1.f; s += d * d; }       // fixed order
-    penalty[0] = lambda * s / (float)B;
-}
 
 // ---------------------------------------------------------------------------------------------
 // nearest-neighbour 2x upsample (align_corners=False -> exact 2x2 replication) and its gradient
@@ -1309,57 +1170,6 @@ extern "C" int dpig_bn_bwd_apply(const float* dy, int lddy, const float* x, int 
     return check_launch("bn_bwd_apply");
 }
 
-extern "C" int dpig_ln_fwd(const float* x, int N, int P, int C, const float* scale, const float* offset, float eps,
-                           int act, float alpha, float* y, float* save_mean, float* save_rstd, void* stream) {
-    if (!x || !scale || !offset || !y || !save_mean || !save_rstd) return fail(DPIG_EINVAL, "ln_fwd: null pointer");
-    if (N <= 0 || P <= 0 || C <= 0) return fail(DPIG_EINVAL, "ln_fwd: empty");
-    hipLaunchKernelGGL(ln_fwd_kernel, dim3(N), dim3(1024), 0, static_cast<hipStream_t>(stream), x, P, C, scale, offset,
-                       eps, act, alpha, y, save_mean, save_rstd);
-    return check_launch("ln_fwd");
-}
-extern "C" size_t dpig_ln_workspace_bytes(int N, int P, int C) {
-    return (size_t)slabs_for((long)N * P) * 2 * C * sizeof(float);
-}
-extern "C" int dpig_ln_bwd(const float* dy, const float* x, const float* y, int N, int P, int C, const float* scale,
-                           const float* save_mean, const float* save_rstd, int act, float alpha, float* dx,
-                           float* dscale, float* doffset, void* ws, size_t ws_bytes, void* stream) {
-    if (!dy || !x || !scale || !save_mean || !save_rstd || !dx || !dscale || !doffset)
-        return fail(DPIG_EINVAL, "ln_bwd: null pointer");
-    if (act != DPIG_ACT_NONE && !y) return fail(DPIG_EINVAL, "ln_bwd: activation output required");
-    if (!ws || ws_bytes < dpig_ln_workspace_bytes(N, P, C)) return fail(DPIG_ENOMEM, "ln_bwd: workspace too small");
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    const long rows = (long)N * P;
-    const int nslab = slabs_for(rows);
-    float* partial = static_cast<float*>(ws);
-    hipLaunchKernelGGL((col_partial_kernel<3>), dim3(cdivi(C, 64), nslab), dim3(256), 0, st, dy, C, x, C, y, C,
-                       save_mean, save_rstd, rows, C, P, act, alpha, partial);
-    hipLaunchKernelGGL((col_final_kernel<0>), dim3(cdivi(C, 64)), dim3(256), 0, st, partial, nslab, 2, C, doffset,
-                       dscale, 1.0f, 0.f, 0.f);
-    hipLaunchKernelGGL(ln_bwd_kernel, dim3(N), dim3(1024), 0, st, dy, x, y, P, C, scale, save_mean, save_rstd, act,
-                       alpha, dx);
-    return check_launch("ln_bwd");
-}
-
-extern "C" size_t dpig_ln_bwd2_workspace_bytes(int N, int P, int C) {
-    return (size_t)N * P * C * sizeof(float) + dpig_colsum_workspace_bytes((int64_t)N * P, C);
-}
-extern "C" int dpig_ln_bwd2(const float* u, const float* dy, const float* x, const float* y, int N, int P, int C,
-                            const float* scale, const float* save_mean, const float* save_rstd, int act, float alpha,
-                            float* d_dy, float* d_x, float* d_scale, void* ws, size_t ws_bytes, void* stream) {
-    if (!u || !dy || !x || !scale || !save_mean || !save_rstd || !d_dy || !d_x || !d_scale)
-        return fail(DPIG_EINVAL, "ln_bwd2: null pointer");
-    if (act != DPIG_ACT_NONE && !y) return fail(DPIG_EINVAL, "ln_bwd2: activation output required");
-    if (!ws || ws_bytes < dpig_ln_bwd2_workspace_bytes(N, P, C)) return fail(DPIG_ENOMEM, "ln_bwd2: workspace too small");
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    float* gs = static_cast<float*>(ws);
-    hipLaunchKernelGGL(ln_bwd2_kernel, dim3(N), dim3(1024), 0, st, u, dy, x, y, P, C, scale, save_mean, save_rstd, act,
-                       alpha, d_dy, d_x, gs);
-    int rc = check_launch("ln_bwd2");
-    if (rc) return rc;
-    const size_t off = (size_t)N * P * C * sizeof(float);
-    return dpig_colsum(gs, C, (int64_t)N * P, C, d_scale, 0.f, static_cast<char*>(ws) + off, ws_bytes - off, stream);
-}
-
 // ---- fully connected layers ride on the conv kernels (a [M,K] matrix is an M x 1 x 1 x K image) -
 static DpigConvDesc linear_desc(int M, int Kin, int Nout, int act, float alpha) {
     DpigConvDesc d = {};
@@ -1507,16 +1317,6 @@ extern "C" int dpig_gp_interpolate(const float* real, const float* fake, const f
                        real, fake, alpha, (long)D, (long)B * D, xhat);
     return check_launch("gp_interpolate");
 }
-extern "C" int dpig_gp_penalty(const float* g, int B, int64_t D, float lambda, float* penalty, float* dg, float* slopes,
-                               void* stream) {
-    if (!g || !penalty || !dg || !slopes) return fail(DPIG_EINVAL, "gp_penalty: null pointer");
-    if (B <= 0 || D <= 0) return fail(DPIG_EINVAL, "gp_penalty: empty");
-    hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(gp_penalty_kernel, dim3(B), dim3(256), 0, st, g, B, (long)D, lambda, dg, slopes);
-    hipLaunchKernelGGL(gp_final_kernel, dim3(1), dim3(64), 0, st, slopes, B, lambda, penalty);
-    return check_launch("gp_penalty");
-}
-
 extern "C" int dpig_upsample2x_fwd(const float* x, int N, int H, int W, int C, float* y, void* stream) {
     if (!x || !y) return fail(DPIG_EINVAL, "upsample2x: null pointer");
     hipLaunchKernelGGL(upsample2x_fwd_kernel, dim3(grid_for((long)N * H * W * C * 4)), dim3(256), 0,

@@ -93,7 +93,7 @@ def as_nhwc(t):
     return t, ld
 
 
-COMPUTE_F32, COMPUTE_BF16, COMPUTE_BF16X3 = 0, 1, 2
+COMPUTE_F32, COMPUTE_BF16, COMPUTE_BF16X3, COMPUTE_BF16_STORE = 0, 1, 2, 3
 _COMPUTE = [COMPUTE_F32]      # DpigConvDesc.compute of the fp32-tensor entry points
 _STORE_BF16 = [False]         # 'bf16' mode: activations stored as bf16
 
@@ -986,60 +986,58 @@ def bn_sync_bwd(dy, x, y, scale, mean, rstd, act, alpha, allreduce, world):
     return dx, sums[:C], sums[C:]
 
 
+def _ln_same_type(*ts):
+    """LayerNorm operands as one storage type: all bf16 when the first one is (and 16-byte channel vectors exist), else all fp32."""
+    ts = [t for t in ts]
+    bf = ts[0].dtype == BF16
+    return bf, [None if t is None else ((to_bf16(t) if bf else to_f32(t)).contiguous()) for t in ts]
+
+
 def ln_fwd(x, scale, offset, eps=1e-5, act=ACT_NONE, alpha=0.2):
-    """Layer norm over (H,W,C) per sample; x NHWC dense."""
-    if x.dtype == BF16:
-        y, mean, rstd = ln_fwd(to_f32(x), scale, offset, eps, act, alpha)
-        return to_bf16(y), mean, rstd
-    _require_gpu(x)
+    """Layer norm over (H,W,C) per sample; x NHWC dense, fp32 or bf16 (read / written directly: dpig_ln_fwd_bf16)."""
+    _require_dev(x)
     x = x.contiguous()
     N, C = x.shape[0], x.shape[-1]
     P = x.numel() // (N * C)
     y = torch.empty_like(x)
     mean = torch.empty(N, dtype=torch.float32, device=x.device)
     rstd = torch.empty(N, dtype=torch.float32, device=x.device)
-    check(lib().dpig_ln_fwd(ptr(x), N, P, C, ptr(scale.contiguous()), ptr(offset.contiguous()), eps, act, alpha,
-                            ptr(y), ptr(mean), ptr(rstd), stream_ptr()), "ln_fwd")
+    wsb, wsn = workspace.get(lib().dpig_ln_fwd_workspace_bytes(N, P, C), x.device)
+    fn = lib().dpig_ln_fwd_bf16 if x.dtype == BF16 else lib().dpig_ln_fwd
+    check(fn(ptr(x), N, P, C, ptr(scale.contiguous()), ptr(offset.contiguous()), eps, act, alpha, ptr(y), ptr(mean), ptr(rstd),
+             ptr(wsb), wsn, stream_ptr()), "ln_fwd")
     return y, mean, rstd
 
 
-def ln_bwd(dy, x, y, scale, mean, rstd, act=ACT_NONE, alpha=0.2):
-    if BF16 in (dy.dtype, x.dtype) or (y is not None and y.dtype == BF16):
-        dx, dscale, doffset = ln_bwd(to_f32(dy), to_f32(x), to_f32(y), scale, mean, rstd, act, alpha)
-        return _like_input(dx, x), dscale, doffset
-    _require_gpu(dy)
-    dy = dy.contiguous()
-    x = x.contiguous()
-    if y is not None:
-        y = y.contiguous()
+def ln_bwd(dy, x, y, scale, mean, rstd, act=ACT_NONE, alpha=0.2, want_params=True):
+    """(dx, dscale, doffset); the parameter gradients are skipped (None) with want_params=False."""
+    _require_dev(dy)
+    bf, (x, dy, y) = _ln_same_type(x, dy, y)
     N, C = x.shape[0], x.shape[-1]
     P = x.numel() // (N * C)
     dx = torch.empty_like(x)
-    dscale = torch.empty(C, dtype=torch.float32, device=x.device)
-    doffset = torch.empty(C, dtype=torch.float32, device=x.device)
+    dscale = torch.empty(C, dtype=torch.float32, device=x.device) if want_params else None
+    doffset = torch.empty(C, dtype=torch.float32, device=x.device) if want_params else None
     wsb, wsn = workspace.get(lib().dpig_ln_workspace_bytes(N, P, C), x.device)
-    check(lib().dpig_ln_bwd(ptr(dy), ptr(x), ptr(y), N, P, C, ptr(scale.contiguous()), ptr(mean), ptr(rstd), act,
-                            alpha, ptr(dx), ptr(dscale), ptr(doffset), ptr(wsb), wsn, stream_ptr()), "ln_bwd")
+    fn = lib().dpig_ln_bwd_bf16 if bf else lib().dpig_ln_bwd
+    check(fn(ptr(dy), ptr(x), ptr(y), N, P, C, ptr(scale.contiguous()), ptr(mean), ptr(rstd), act, alpha, ptr(dx), ptr(dscale),
+             ptr(doffset), ptr(wsb), wsn, stream_ptr()), "ln_bwd")
     return dx, dscale, doffset
 
 
 def ln_bwd2(u, dy, x, y, scale, mean, rstd, act=ACT_NONE, alpha=0.2):
     """Second-order LayerNorm: gradients of ln_bwd's dx w.r.t. (dy, x, scale) given u = dP/d(dx)."""
-    if BF16 in (u.dtype, dy.dtype, x.dtype) or (y is not None and y.dtype == BF16):
-        d_dy, d_x, d_scale = ln_bwd2(to_f32(u), to_f32(dy), to_f32(x), to_f32(y), scale, mean, rstd, act, alpha)
-        return _like_input(d_dy, x), _like_input(d_x, x), d_scale
-    _require_gpu(u)
-    u = u.contiguous(); dy = dy.contiguous(); x = x.contiguous()
-    if y is not None:
-        y = y.contiguous()
+    _require_dev(u)
+    bf, (x, u, dy, y) = _ln_same_type(x, u, dy, y)
     N, C = x.shape[0], x.shape[-1]
     P = x.numel() // (N * C)
     d_dy = torch.empty_like(x)
     d_x = torch.empty_like(x)
     d_scale = torch.empty(C, dtype=torch.float32, device=x.device)
     wsb, wsn = workspace.get(lib().dpig_ln_bwd2_workspace_bytes(N, P, C), x.device)
-    check(lib().dpig_ln_bwd2(ptr(u), ptr(dy), ptr(x), ptr(y), N, P, C, ptr(scale.contiguous()), ptr(mean), ptr(rstd),
-                             act, alpha, ptr(d_dy), ptr(d_x), ptr(d_scale), ptr(wsb), wsn, stream_ptr()), "ln_bwd2")
+    fn = lib().dpig_ln_bwd2_bf16 if bf else lib().dpig_ln_bwd2
+    check(fn(ptr(u), ptr(dy), ptr(x), ptr(y), N, P, C, ptr(scale.contiguous()), ptr(mean), ptr(rstd), act, alpha, ptr(d_dy), ptr(d_x),
+             ptr(d_scale), ptr(wsb), wsn, stream_ptr()), "ln_bwd2")
     return d_dy, d_x, d_scale
 
 
@@ -1187,7 +1185,8 @@ def gp_penalty(g, lam):
     pen = torch.empty(1, dtype=torch.float32, device=g.device)
     dg = torch.empty_like(g)
     slopes = torch.empty(B, dtype=torch.float32, device=g.device)
-    check(lib().dpig_gp_penalty(ptr(g), B, g.numel() // B, float(lam), ptr(pen), ptr(dg), ptr(slopes), stream_ptr()),
+    wsb, wsn = workspace.get(lib().dpig_gp_penalty_workspace_bytes(B, g.numel() // B), g.device)
+    check(lib().dpig_gp_penalty(ptr(g), B, g.numel() // B, float(lam), ptr(pen), ptr(dg), ptr(slopes), ptr(wsb), wsn, stream_ptr()),
           "gp_penalty")
     return pen, dg, slopes
 
@@ -1217,7 +1216,9 @@ def gp_double_backward(params, real, fake, alpha, lam=10.0, dim=64, grads=None, 
     [1], the per-sample slopes [B] and -- when `grads` (dict keyed like `params`, or True to allocate) is given -- d penalty /
     d theta for every critic parameter (grads = beta * grads + ...).  `params`: dict name -> fp32 device tensor holding
     `prefix + 'Discriminator.{1..4}.Filters' / '.Biases'`, `'Discriminator.BN{2..4}.scale' / '.offset'` and
-    `'Discriminator.Output.W'`; real / fake: NHWC images [B, H, W, Cin]; alpha: [B]."""
+    `'Discriminator.Output.W'`; real / fake: NHWC images [B, H, W, Cin]; alpha: [B].  `compute`: a DPIG_COMPUTE_* value; None = the
+    current mode -- in 'bf16' storage mode COMPUTE_BF16_STORE: the critic's activations inside the call are bf16 tensors on the
+    bf16-storage kernels (images, parameters and gradients stay fp32)."""
     from ._lib import DpigCriticDesc
     real, fake = to_f32(real).contiguous(), to_f32(fake).contiguous()
     _require_gpu(real)
@@ -1228,7 +1229,7 @@ def gp_double_backward(params, real, fake, alpha, lam=10.0, dim=64, grads=None, 
         if not (t.is_cuda and t.dtype == F32 and t.is_contiguous()):
             raise RuntimeError("gp_double_backward: parameter %s must be a dense fp32 device tensor" % k)
     d = DpigCriticDesc(B, Hh, W, Cin, int(dim), float(lrelu_alpha), float(ln_eps), float(lam),
-                       _COMPUTE[0] if compute is None else int(compute))
+                       (COMPUTE_BF16_STORE if _STORE_BF16[0] else _COMPUTE[0]) if compute is None else int(compute))
     P = _critic_struct(params, prefix)
     if grads is True:
         grads = {k: torch.empty_like(params[k]) for k in keys}
@@ -1245,6 +1246,35 @@ def gp_double_backward(params, real, fake, alpha, lam=10.0, dim=64, grads=None, 
                                         ctypes.byref(G) if G is not None else None, ptr(pen), ptr(slopes), ptr(wsb), wsn,
                                         stream_ptr()), "gp_double_backward")
     return pen, slopes, grads
+
+
+GP_SLOTS = ("Z", "A", "DA", "DZ", "V", "UB", "ZB", "T", "F", "ZS")
+
+
+def gp_double_backward_tensors(shape, dim=64, compute=None, device=None):
+    """Copies of the tensors the LAST `gp_double_backward` call of this shape / mode left in the workspace (dpig_gp_double_backward_slot):
+    {'xhat', 'gin', 'u0'} fp32 images and {'Z2'..'ZS3'}: level tensors [B, H_l, W_l, C_l], fp32 or bf16 by mode.  Inspection / tests."""
+    from ._lib import DpigCriticDesc
+    B, Hh, W, Cin = shape
+    comp = (COMPUTE_BF16_STORE if _STORE_BF16[0] else _COMPUTE[0]) if compute is None else int(compute)
+    d = DpigCriticDesc(B, Hh, W, Cin, int(dim), 0.2, 1e-5, 10.0, comp)
+    device = torch.device("cuda", torch.cuda.current_device()) if device is None else device
+    nbytes = lib().dpig_gp_double_backward_workspace_bytes(ctypes.byref(d))
+    wsb, _ = workspace.get(nbytes, device)
+    out = {}
+    off, nb = ctypes.c_size_t(), ctypes.c_size_t()
+    dt = BF16 if comp == COMPUTE_BF16_STORE else F32
+    hs, ws_, cs = [Hh], [W], [Cin]
+    for l in range(1, 5):
+        hs.append((hs[-1] + 1) // 2); ws_.append((ws_[-1] + 1) // 2); cs.append(dim << (l - 1))
+    for i, nm in enumerate(("xhat", "gin", "u0")):
+        check(lib().dpig_gp_double_backward_slot(ctypes.byref(d), 0, i, ctypes.byref(off), ctypes.byref(nb)), "gp_slot")
+        out[nm] = wsb[off.value:off.value + nb.value].view(F32).reshape(B, Hh, W, Cin).clone()
+    for l in range(1, 5):
+        for i, nm in enumerate(GP_SLOTS):
+            check(lib().dpig_gp_double_backward_slot(ctypes.byref(d), l, i, ctypes.byref(off), ctypes.byref(nb)), "gp_slot")
+            out["%s%d" % (nm, l)] = wsb[off.value:off.value + nb.value].view(dt).reshape(B, hs[l], ws_[l], cs[l]).clone()
+    return out
 
 
 def upsample2x_fwd(x):

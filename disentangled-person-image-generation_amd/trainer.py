@@ -291,7 +291,7 @@ def pose_input(batch, img_H, img_W, keypoint_num=18):
 def critic_variables(name='', registry=None):
     """The DCGAN critic's variables under `name` in creation order (wgan_gp.py:407-440), keyed WITHOUT the prefix: the operand
     list of the fused penalty call.  None unless every one exists as a dense fp32 tensor (e.g. BatchNorm critics have no
-    LayerNorm variables; bf16 runs keep using the taped path)."""
+    LayerNorm variables)."""
     reg = lib._params if registry is None else registry
     out = {}
     for grp in H.CRITIC_KEYS[:4]:
@@ -446,8 +446,9 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
 
     def _fused_gp(self):
         """Operands of the one-call penalty (`dpig_gp_double_backward`) when this trainer's critic is the image DCGAN critic in
-        MODE 'wgan-gp' on fp32 tensors (config.fused_gp, default on); None -> the taped double backward."""
-        if self.wgan_gp.MODE != 'wgan-gp' or not getattr(self.config, "fused_gp", True) or H.get_compute() == "bf16":
+        MODE 'wgan-gp' (config.fused_gp, default on; in 'bf16' storage mode the call keeps its activations in bf16:
+        DPIG_COMPUTE_BF16_STORE); None -> the taped double backward."""
+        if self.wgan_gp.MODE != 'wgan-gp' or not getattr(self.config, "fused_gp", True):
             return None
         if getattr(self.config, "D_arch", "DCGAN") != 'DCGAN':
             return None

@@ -51,7 +51,7 @@ extern "C" {
 #define DPIG_ACT_RELU 1
 #define DPIG_ACT_LRELU 2
 
-#define DPIG_VERSION 270
+#define DPIG_VERSION 280
 
 /* Convolution problem, always described from the FORWARD op's point of view. */
 typedef struct DpigConvDesc {
@@ -91,6 +91,9 @@ typedef struct DpigConvDesc {
                                 /* MFMAs (hi*lo + lo*hi + hi*hi) into the fp32 accumulator: the fp32 accuracy     */
                                 /* class (<= 2e-5 max|ref|, the exact path's own test bar) at bf16-pipe speed.    */
                                 /* Applies where DPIG_COMPUTE_BF16 does; other shapes run the exact fp32 kernels. */
+#define DPIG_COMPUTE_BF16_STORE 3 /* DpigCriticDesc.compute only (dpig_gp_double_backward): the critic's activations are stored */
+                                /* as bfloat16 inside the workspace and every op runs on the bf16-STORAGE kernels below         */
+                                /* (dpig_conv2d_*_bf16, dpig_ln_*_bf16, ...): BASELINE configs[2]-[4]'s mode.                     */
 
 int dpig_version(void);
 const char* dpig_last_error(void);
@@ -300,13 +303,24 @@ int dpig_bn_bwd_apply(const float* dy, int lddy, const float* x, int ldx, const 
                       void* stream);
 
 /* ---- layer norm over (H,W,C) per sample, per-channel scale/offset (layernorm.py:6-20) -------- */
-/* x,y: [N, P, C] with P = H*W pixels, dense (ld == C). save_mean/save_rstd: [N]. */
+/* x,y: [N, P, C] with P = H*W pixels, dense (ld == C). save_mean/save_rstd: [N].  A sample is cut into chunks, one workgroup
+ * each (csrc/dpig_norm.hip): every entry point takes a small workspace for the per-chunk partial sums.  The _bf16 forms read /
+ * write bf16 tensors directly ('bf16' storage mode) with the same fp32 arithmetic; parameters, statistics and parameter
+ * gradients are fp32 in both. */
+size_t dpig_ln_fwd_workspace_bytes(int N, int P, int C);
 int dpig_ln_fwd(const float* x, int N, int P, int C, const float* scale, const float* offset, float eps,
-                int act, float alpha, float* y, float* save_mean, float* save_rstd, void* stream);
+                int act, float alpha, float* y, float* save_mean, float* save_rstd, void* ws, size_t ws_bytes, void* stream);
+int dpig_ln_fwd_bf16(const uint16_t* x, int N, int P, int C, const float* scale, const float* offset, float eps,
+                     int act, float alpha, uint16_t* y, float* save_mean, float* save_rstd, void* ws, size_t ws_bytes,
+                     void* stream);
+/* dscale / doffset may both be NULL (input gradient only: the first sweep of the gradient penalty). */
 size_t dpig_ln_workspace_bytes(int N, int P, int C);
 int dpig_ln_bwd(const float* dy, const float* x, const float* y, int N, int P, int C, const float* scale,
                 const float* save_mean, const float* save_rstd, int act, float alpha, float* dx,
                 float* dscale, float* doffset, void* ws, size_t ws_bytes, void* stream);
+int dpig_ln_bwd_bf16(const uint16_t* dy, const uint16_t* x, const uint16_t* y, int N, int P, int C, const float* scale,
+                     const float* save_mean, const float* save_rstd, int act, float alpha, uint16_t* dx,
+                     float* dscale, float* doffset, void* ws, size_t ws_bytes, void* stream);
 
 /* Second-order LayerNorm (gradient of dpig_ln_bwd's dx w.r.t. dy, x and scale), the piece of the WGAN-GP
  * double backward (trainer.py:222-236) that does not reduce to the first-order kernels: with
@@ -315,6 +329,9 @@ size_t dpig_ln_bwd2_workspace_bytes(int N, int P, int C);
 int dpig_ln_bwd2(const float* u, const float* dy, const float* x, const float* y, int N, int P, int C,
                  const float* scale, const float* save_mean, const float* save_rstd, int act, float alpha,
                  float* d_dy, float* d_x, float* d_scale, void* ws, size_t ws_bytes, void* stream);
+int dpig_ln_bwd2_bf16(const uint16_t* u, const uint16_t* dy, const uint16_t* x, const uint16_t* y, int N, int P, int C,
+                      const float* scale, const float* save_mean, const float* save_rstd, int act, float alpha,
+                      uint16_t* d_dy, uint16_t* d_x, float* d_scale, void* ws, size_t ws_bytes, void* stream);
 
 /* ---- fully connected (linear.py:132-146, slim.fully_connected) ------------------------------- */
 /* y[M,Nout] = act(x[M,Kin] @ w[Kin,Nout] + bias) */
@@ -374,11 +391,13 @@ int dpig_ssim_gray_u8(const float* a, const float* b, int B, int H, int W, float
  * dpig_gp_penalty: given g = grad_xhat D(xhat) [B, D]:  slope_b = ||g[b,:]||_2,
  *     *penalty = lambda * mean_b (slope_b - 1)^2   and   dg[b,:] = lambda * 2 (slope_b - 1) / (B * slope_b) * g[b,:]
  *   (the derivative of the penalty w.r.t. g: the seed of the double-backward sweep through the critic), in one
- *   pass over g + a [B]-sized finalisation; slopes: [B] scratch/output.  A zero slope yields dg = 0. */
+ *   pass over g (chunked over the chip: per-chunk sums of squares in `ws`, merged in chunk order) + a [B]-sized finalisation;
+ *   slopes: [B] output.  A zero slope yields dg = 0. */
 int dpig_gp_interpolate(const float* real, const float* fake, const float* alpha, int B, int64_t D, float* xhat,
                         void* stream);
+size_t dpig_gp_penalty_workspace_bytes(int B, int64_t D);
 int dpig_gp_penalty(const float* g, int B, int64_t D, float lambda, float* penalty, float* dg, float* slopes,
-                    void* stream);
+                    void* ws, size_t ws_bytes, void* stream);
 
 /* ---- the whole gradient-penalty term of the DCGAN critic in ONE call (csrc/dpig_gp.hip) ------------------------------------
  * Replaces, for Discriminator = WGAN_GP.DCGANDiscriminator in MODE 'wgan-gp' (wgan_gp.py:407-440: Conv5x5s2 -> LReLU ->
@@ -388,7 +407,10 @@ int dpig_gp_penalty(const float* g, int B, int64_t D, float lambda, float* penal
  * AND the part of Optimizer.minimize(disc_cost) that differentiates it w.r.t. the critic's variables (tf.gradients of
  * tf.gradients, i.e. the double backward), written out analytically: sweep 1 (forward + input gradient), dpig_gp_penalty,
  * the adjoint of sweep 1's backward half (forward convs + wgrads + dpig_ln_bwd2) and the ordinary backward pass of the x-adjoints.
- * All tensors NHWC fp32 (images [B][H][W][Cin]; filters HWIO [5][5][C][K]; LayerNorm scale/offset [C]; w_out [8*4*8*dim][1]).
+ * Interface tensors are fp32: images NHWC [B][H][W][Cin]; filters HWIO [5][5][C][K]; LayerNorm scale/offset [C]; w_out
+ * [8*4*8*dim][1]; every gradient.  desc->compute = DPIG_COMPUTE_BF16_STORE keeps the critic's own activations (and their
+ * adjoints) as bfloat16 inside the workspace and runs the bf16-storage kernels with fp32 accumulation (Cin = 3, dim in {32, 64,
+ * 128, 256}); the other modes keep them fp32.
  *   penalty[0]  = the penalty value;  slopes[B] = ||gradients_b||_2
  *   grads->X    = beta * grads->X + d penalty / d X   for every parameter (the output bias has no penalty gradient and is not
  *                 in the struct); grads == NULL: value only (sweep 1).
@@ -399,7 +421,7 @@ typedef struct DpigCriticDesc {
     float lrelu_alpha;      /* 0.2 (wgan_gp.py:23)                                                                 */
     float ln_eps;           /* 1e-5 (layernorm.py:17)                                                              */
     float lambda;           /* LAMBDA = 10 (wgan_gp.py:100)                                                        */
-    int32_t compute;        /* DPIG_COMPUTE_* of the convolutions                                                  */
+    int32_t compute;        /* DPIG_COMPUTE_* of the convolutions; DPIG_COMPUTE_BF16_STORE: bf16 activations       */
 } DpigCriticDesc;
 typedef struct DpigCriticParams {
     const float* w[4];          /* Discriminator.{1..4}.Filters                                                    */
@@ -416,6 +438,13 @@ typedef struct DpigCriticGrads {
     float* w_out;
 } DpigCriticGrads;
 size_t dpig_gp_double_backward_workspace_bytes(const DpigCriticDesc* d);
+/* Inspection: byte offset / size, inside the workspace of a finished call, of one tensor of the three sweeps.  level 0: the fp32
+ * images, slot 0 xhat, 1 g = dD/dxhat, 2 u0 = dpenalty/dg.  level 1..4 (NHWC [B][H_l][W_l][C_l]; fp32, or bfloat16 with
+ * DPIG_COMPUTE_BF16_STORE), slot 0 z (conv output; levels 2-4), 1 a (activation), 2 da and 3 dz (input-gradient sweep), 4 v and 5 ub
+ * (adjoints of the up-sweep before / after the norm), 6 zb (second-order x-adjoint of the norm), 7 t (what the down-sweep receives
+ * from the level above), 8 f (its first-order LayerNorm gradient), 9 zs (zb + f, what flows further down; level 4: use zb).  No slot
+ * is written twice, so every link of the chain can be checked against its inputs (tests/test_variants_gpu.py). */
+int dpig_gp_double_backward_slot(const DpigCriticDesc* d, int level, int slot, size_t* offset, size_t* bytes);
 int dpig_gp_double_backward(const DpigCriticDesc* d, const DpigCriticParams* params, const float* real, const float* fake,
                             const float* alpha, float beta, const DpigCriticGrads* grads, float* penalty, float* slopes,
                             void* ws, size_t ws_bytes, void* stream);

@@ -460,3 +460,43 @@ def test_tflib_batchnorm_inference_and_unfused_branches_match_the_oracle():
         lib.delete_all_params()
         lib.set_device(None)
 
+
+
+def test_gp_sweeps_equal_double_backward():
+    """oracle/gp_sweeps.py (the gradient penalty as three explicit sweeps, SURVEY Appendix E -- the form csrc/dpig_gp.hip evaluates) against
+    torch's double backward of `oracle.models.gradient_penalty` (trainer.py:222-236 over wgan_gp.py:407-440): value and every parameter
+    gradient to fp64 round-off, at Market 128x64 and at 256x256 (8 logit rows per image).  With bf16 stores the same sweeps give
+    the emulation the GPU's 'bf16' storage mode is held against; how far bf16 storage alone moves the result is printed."""
+    import torch
+    from oracle import gp_sweeps as GS
+    from oracle import models as OM
+    for shape, dim in (((2, 128, 64, 3), 8), ((1, 256, 256, 3), 4)):
+        g = torch.Generator().manual_seed(21)
+        B = shape[0]
+        P = OM.ParamStore(seed=23)
+        real = torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1
+        fake = torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1
+        alpha = torch.rand(B, generator=g, dtype=torch.float64)
+        D_o = lambda t: OM.dcgan_discriminator(P, t, "wgan-gp", dim=dim)                  # noqa: E731
+        D_o(real[:1])
+        names = OM.d_var_names(P)
+        with torch.no_grad():
+            for n in names:
+                if not n.endswith(("Filters", "Output.W")):
+                    P.p[n].add_(0.2 * (torch.rand(P.p[n].shape, generator=g, dtype=torch.float64) - 0.5))
+        gp_ref = OM.gradient_penalty(D_o, real, fake, alpha, 10.0)
+        refs = dict(zip(names, torch.autograd.grad(gp_ref, [P.p[n] for n in names], allow_unused=True)))
+        pen, grads = GS.gp_sweeps(P.p, real, fake, alpha, 10.0, dim=dim)
+        assert abs(pen.item() - gp_ref.item()) < 1e-11 * abs(gp_ref.item())
+        for n in names:
+            if n.endswith("Output.b"):
+                continue
+            if refs[n] is None:
+                assert float(grads[n].abs().max()) == 0.0
+                continue
+            assert (grads[n] - refs[n]).abs().max().item() < 1e-10 * max(refs[n].abs().max().item(), 1e-30), n
+        pen16, g16 = GS.gp_sweeps(P.p, real, fake, alpha, 10.0, dim=dim, store=GS.bf16_round)
+        worst = max((g16[n] - refs[n]).norm().item() / refs[n].norm().item() for n in names if refs[n] is not None and not n.endswith("Output.b"))
+        print("bf16 storage of the sweeps' tensors alone moves the penalty by %.1e (rel) and a parameter gradient by up to %.1e (rel L2)"
+              % (abs(pen16.item() - gp_ref.item()) / abs(gp_ref.item()), worst))
+        assert worst < 0.2
