@@ -111,14 +111,29 @@ def _sink(p, fn):
 # the flat gradient buffer is launched on one side stream, after the stream that produced dz; nothing in the backward chain waits for
 # it, so it runs beside the following layers' dgrads and fills their tails.  All contributions to one parameter stay in launch order
 # (one wgrad stream); leaving the block makes the current stream wait for the wgrad stream (finalize / all-reduce / Adam come after).
-WGRAD_STREAM = [__import__('os').environ.get('DPIG_WGRAD_STREAM', '0') != '0']
-_WG = {"on": False, "used": False, "streams": {}}
+# DPIG_WGRAD_STREAM: 0 = off, 1 = every wgrad, 2 = only the wgrads of SMALL layers (fewer than WGRAD_SMALL_GF GFLOP: launches that do not
+# fill the chip -- the deep levels of the towers / the low-resolution decoder stages -- and therefore gain from running beside the next
+# layer's dgrad; full-size kernels side by side lose their XCD-local L2 reuse, measured round 3).
+WGRAD_STREAM = [int(__import__('os').environ.get('DPIG_WGRAD_STREAM', '0'))]
+WGRAD_SMALL_GF = [float(__import__('os').environ.get('DPIG_WGRAD_SMALL_GF', '40'))]
+_WG = {"on": 0, "used": False, "streams": {}}
+
+
+def _wgrad_on_side_stream(x, dz, w, stride):
+    if not _WG["on"] or not x.is_cuda or torch.is_grad_enabled():
+        return False
+    if any(torch.cuda.current_stream(x.device) == st for st in _SIDE_STREAMS.values()):
+        return False            # (a third stream forked from a side stream inside a hipGraph capture crashed hipStreamEndCapture on this ROCm)
+    if _WG["on"] == 1:
+        return True
+    gf = 2.0 * dz.shape[0] * dz.shape[1] * dz.shape[2] * dz.shape[3] * w.shape[0] * w.shape[1] * w.shape[2] * 1e-9
+    return gf < WGRAD_SMALL_GF[0]
 
 
 class wgrad_overlap(object):
     def __enter__(self):
         self.prev = _WG["on"]
-        _WG["on"] = bool(WGRAD_STREAM[0])
+        _WG["on"] = int(WGRAD_STREAM[0])
         return self
 
     def __exit__(self, *exc):
@@ -150,7 +165,7 @@ def _sink_wgrad_bias(w, b, x, dz, stride=1, upsample2x=False, want_w=True, want_
     bbuf = getattr(b, "_dpig_grad", None) if (want_b and b is not None) else None
     if wbuf is not None and bbuf is not None:
         wt, bt = w._dpig_touched, b._dpig_touched
-        if _WG["on"] and x.is_cuda and not torch.is_grad_enabled():
+        if _wgrad_on_side_stream(x, dz, w, stride):
             with torch.cuda.stream(_wgrad_stream(x, dz)):
                 H.conv2d_wgrad(x, dz, tuple(w.shape), stride=stride, upsample2x=upsample2x, out=wbuf,
                                beta=1.0 if wt[0] else 0.0, db=bbuf, db_beta=1.0 if bt[0] else 0.0)
