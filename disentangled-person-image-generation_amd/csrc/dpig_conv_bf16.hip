@@ -1367,17 +1367,30 @@ static bool wgrad_is_s1(const DpigConvDesc* d, int pt, int pl, int Ho, int Wo) {
            (xe * 2 + (long)(pt * d->W + pl) * d->ldx * 2 < 0x7fffffffL);
 }
 
+// A 3 x 3 stride-1 SAME conv on a 1 x 1 map IS the 1 x 1 conv with the filter's centre slab (contiguous in HWIO): the filter gradient
+// runs as that, the other eight slabs receive beta * dw.
+static bool wgrad_centre_tap_only(const DpigConvDesc* d) {
+    return d->H == 1 && d->W == 1 && d->R == 3 && d->S == 3 && d->stride == 1 && !d->upsample2x && (d->pad_t < 0 || d->pad_t == 1) &&
+           (d->pad_l < 0 || d->pad_l == 1);
+}
+static DpigConvDesc centre_tap_desc(const DpigConvDesc* d) {
+    DpigConvDesc c = *d;
+    c.R = c.S = 1; c.pad_t = c.pad_l = 0;
+    return c;
+}
+
 static size_t bf16_workspace_bytes_one(const DpigConvDesc* d, int which) {
     int pt, pl, Ho, Wo;
     if (resolve_desc(d, &pt, &pl, &Ho, &Wo) || !shape_ok(d)) return 0;
+    const TapWindow tw = live_taps(d, pt, pl, Ho, Wo);
     if (which == 0) {
         const long M = d->upsample2x ? (long)d->N * d->H * d->W : (long)d->N * Ho * Wo;
-        Plan pln = plan_split(cdiv(M, TM) * cdiv(d->K, TN), d->R * d->S * cdiv(d->C, gtk()), d->split_k, gtk(), kSplitPenalty);
+        Plan pln = plan_split(cdiv(M, TM) * cdiv(d->K, TN), tw.na * tw.nb * cdiv(d->C, gtk()), d->split_k, gtk(), kSplitPenalty);
         return pln.nsplit > 1 ? (size_t)pln.nsplit * M * d->K * sizeof(float) : 0;
     } else if (which == 1) {
         if (d->upsample2x || d->stride == 1) {
             const long M = (long)d->N * d->H * d->W;
-            const int ntaps = d->upsample2x ? 4 : d->R * d->S;
+            const int ntaps = d->upsample2x ? 4 : tw.na * tw.nb;
             Plan pln = plan_split(cdiv(M, TM) * cdiv(d->C, TN), ntaps * cdiv(d->K, gtk()), d->split_k, gtk(), kSplitPenalty);
             return pln.nsplit > 1 ? (size_t)pln.nsplit * M * d->C * sizeof(float) : 0;
         }
@@ -1385,6 +1398,7 @@ static size_t bf16_workspace_bytes_one(const DpigConvDesc* d, int which) {
         plan_s2(d, pt, pl, &sp);
         return sp.total;
     } else if (which == 2) {
+        if (wgrad_centre_tap_only(d)) { DpigConvDesc c = centre_tap_desc(d); return bf16_workspace_bytes_one(&c, 2); }
         const long Npix = (long)d->N * Ho * Wo * (d->upsample2x ? 4 : 1);
         const int tiles = (d->upsample2x ? 1 : d->R * d->S) * cdiv(d->C, TM) * cdiv(d->K, TN);
         Plan pln = plan_split(tiles, cdiv(Npix, TK), d->split_k, TK, kSplitPenalty);
@@ -1522,8 +1536,9 @@ static int fwd_bf16_one(const DpigConvDesc* d, const uint16_t* x, const uint16_t
     p.dpy = 0; p.dpx = 0; p.ldd = d->ldy; p.ldres = d->ldres; p.ldmask = 0;
     p.identity_rows = d->upsample2x ? 0 : 1;
     p.act = d->act; p.alpha = d->alpha;
-    p.ntaps = d->R * d->S;
-    p.tap_nb = d->S; p.oy0 = -pt; p.oys = 1; p.ox0 = -pl; p.oxs = 1; p.w0 = 0; p.wa = d->S; p.wb = 1;
+    const TapWindow tw = live_taps(d, pt, pl, Ho, Wo);           // (the whole filter except on maps smaller than it: dpig_conv_plan.h)
+    p.ntaps = tw.na * tw.nb;
+    p.tap_nb = tw.nb; p.oy0 = -pt + tw.a0; p.oys = 1; p.ox0 = -pl + tw.b0; p.oxs = 1; p.w0 = tw.a0 * d->S + tw.b0; p.wa = d->S; p.wb = 1;
     Plan pln = plan_split(cdiv(p.M, TM) * cdiv(p.Ncols, TN), p.ntaps * cdiv(p.Cs, gtk()), d->split_k, gtk(), kSplitPenalty);
     p.nsplit = pln.nsplit; p.tiles_per_split = pln.tiles_per_split;
     if (p.nsplit > 1 && (!ws || ws_bytes < (size_t)p.nsplit * p.M * p.Ncols * sizeof(float)))
@@ -1558,8 +1573,9 @@ static int dgrad_bf16_one(const DpigConvDesc* d, const uint16_t* dy, const uint1
         p.M = d->N * d->H * d->W; p.Hr = d->H; p.Wr = d->W;
         p.Hs = Ho; p.Ws = Wo; p.sr = 1;
         p.dr = 1; p.identity_rows = 1;
-        p.ntaps = d->R * d->S;
-        p.tap_nb = d->S; p.oy0 = pt; p.oys = -1; p.ox0 = pl; p.oxs = -1; p.w0 = 0; p.wa = d->S; p.wb = 1;
+        const TapWindow tw = live_taps(d, pt, pl, Ho, Wo);       // (stride 1: the taps live in the forward pass are the ones live here)
+        p.ntaps = tw.na * tw.nb;
+        p.tap_nb = tw.nb; p.oy0 = pt - tw.a0; p.oys = -1; p.ox0 = pl - tw.b0; p.oxs = -1; p.w0 = tw.a0 * d->S + tw.b0; p.wa = d->S; p.wb = 1;
     } else {
         S2Plan sp;
         plan_s2(d, pt, pl, &sp);
@@ -1599,6 +1615,20 @@ static int wgrad_bf16_one(const DpigConvDesc* d, const uint16_t* x, const uint16
     if (!aligned16(x) || !aligned16(dy) || !aligned16(dw) || (ws && !aligned16(ws)))
         return fail(DPIG_EALIGN, "bf16 wgrad: pointers must be 16-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (wgrad_centre_tap_only(d)) {
+        const long slab = (long)d->C * d->K;
+        if (beta == 0.f) {
+            rc = (int)hipMemsetAsync(dw, 0, 4 * slab * sizeof(float), st);
+            if (!rc) rc = (int)hipMemsetAsync(dw + 5 * slab, 0, 4 * slab * sizeof(float), st);
+            if (rc) return fail(DPIG_ELAUNCH, "wgrad: clearing the padding-only taps failed");
+        } else if (beta != 1.f) {
+            rc = dpig_axpby3d(dw, 0, 0, dw, 0, 0, 1, 1, (int)(4 * slab), beta - 1.f, stream);          // dw = (beta - 1) dw + dw
+            if (!rc) rc = dpig_axpby3d(dw + 5 * slab, 0, 0, dw + 5 * slab, 0, 0, 1, 1, (int)(4 * slab), beta - 1.f, stream);
+            if (rc) return rc;
+        }
+        const DpigConvDesc c = centre_tap_desc(d);
+        return wgrad_bf16_one(&c, x, dy, dw + 4 * slab, beta, db, beta_b, ws, ws_bytes, stream);
+    }
     BWParams p = {};
     p.X = x; p.DY = dy; p.DW = dw; p.partial = static_cast<float*>(ws);
     p.H = d->H; p.W = d->W; p.ldx = d->ldx; p.C = d->C; p.K = d->K; p.ldy = d->ldy;

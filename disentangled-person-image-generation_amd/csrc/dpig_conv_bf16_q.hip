@@ -559,11 +559,10 @@ __global__ __launch_bounds__(512, 2) void bhq_kernel(const BGParams p) {
     const int tile = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
     const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
     const int n0 = nt * 256;
-    const int per_img = p.tiles_x * p.tiles_y;
-    const int img = mt / per_img;
-    const int trem = mt - img * per_img;
-    const int tyi = trem / p.tiles_x;
-    const int y0 = tyi * 16, x0 = (trem - tyi * p.tiles_x) * 16;
+    // the images of the batch are one tall stack of N * Hs pixel rows; a tile is 16 of them (two wave rows of 8, each inside ONE image
+    // because Hs % 8 == 0) x 16 columns: tiles need not align with images, only the halo's validity is image-local
+    const int tyi = mt / p.tiles_x;
+    const int g0 = tyi * 16, x0 = (mt - tyi * p.tiles_x) * 16;
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -585,10 +584,11 @@ __global__ __launch_bounds__(512, 2) void bhq_kernel(const BGParams p) {
         const int j = id / HQ::NPIECE, q = id - j * HQ::NPIECE;
         const int hp = 8 * q + (lane >> 3);
         const int hy = hp / HQ::P, hx = hp - hy * HQ::P;
-        const int y = y0 + 8 * j - 1 + hy, x = x0 - 1 + hx;
+        const int gj = g0 + 8 * j, yj = gj % p.Hs;               // this wave row's first pixel row: global, and inside its image
+        const int y = yj - 1 + hy, x = x0 - 1 + hx;
         const bool ok = (hp < HQ::NPIX) & ((unsigned)y < (unsigned)p.Hs) & ((unsigned)x < (unsigned)p.Ws);
         const int g = (lane & 7) ^ ((hx >> 1) & 7);
-        h_voff[t] = ok ? ((((img * p.Hs + y) * p.Ws + x) * p.lda) + g * 8) * 2 : (int)OOB;
+        h_voff[t] = ok ? (((((gj - 1 + hy) * p.Ws) + x) * p.lda) + g * 8) * 2 : (int)OOB;
         h_dst[t] = (j * 2) * HQ::HALO_B + q * 8 * ROWB;
     }
     // ---- filter DMA roles (as bq_kernel<2, 4>): unit h, piece j: columns h*32 + 8*(wave & 3) .. +7 of wave column (wave >> 2) + 2j
@@ -742,7 +742,7 @@ __global__ __launch_bounds__(512, 2) void bhq_kernel(const BGParams p) {
     const bool hr = p.res != nullptr, hm = p.mask != nullptr, h2 = p.D2 != nullptr, rpost = p.res_post != 0;
     const int kind = (!hr && !hm && !h2) ? 1 : ((hr && !rpost && !hm && !h2) ? 2 : ((!hr && hm && !h2) ? 3 : ((hr && rpost && !hm && h2) ? 4 : 5)));
     const float slope = (p.act == DPIG_ACT_NONE) ? 1.f : ((p.act == DPIG_ACT_RELU) ? 0.f : p.alpha);
-    const int row_base = (img * p.Hs + y0 + 8 * wr) * p.Ws + x0, cb0 = n0 + wc * 64;
+    const int row_base = (g0 + 8 * wr) * p.Ws + x0, cb0 = n0 + wc * 64;
     lds_char* W = L + wave * WEP_BYTES;
     switch (kind) {
         case 1: q_epilogue_wave<false, false, false, false>(p, acc, W, row_base, cb0, lane, slope, p.Ws); break;
@@ -783,11 +783,8 @@ __global__ __launch_bounds__(512, 2) void bhq32_kernel(const BGParams p) {
     const int tile = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
     const int mt = tile / p.ntiles, nt = tile - mt * p.ntiles;
     const int n0 = nt * 128;
-    const int per_img = p.tiles_x * p.tiles_y;
-    const int img = mt / per_img;
-    const int trem = mt - img * per_img;
-    const int tyi = trem / p.tiles_x;
-    const int y0 = tyi * 32, x0 = (trem - tyi * p.tiles_x) * 16;
+    const int tyi = mt / p.tiles_x;                              // (tall-stack tiling as in bhq_kernel: 32 pixel rows = four wave rows of 8)
+    const int g0 = tyi * 32, x0 = (mt - tyi * p.tiles_x) * 16;
 
     f32x16 acc[4][2];
 #pragma unroll
@@ -811,10 +808,11 @@ __global__ __launch_bounds__(512, 2) void bhq32_kernel(const BGParams p) {
         const int j = live ? id / H32::NPIECE : 0, q = live ? id - j * H32::NPIECE : 0;
         const int hp = 16 * q + (lane >> 2);
         const int hy = hp / H32::HP, hx = hp - hy * H32::HP;
-        const int y = y0 + 8 * j - 1 + hy, x = x0 - 1 + hx;
+        const int gj = g0 + 8 * j, yj = gj % p.Hs;
+        const int y = yj - 1 + hy, x = x0 - 1 + hx;
         const bool ok = live & (hp < H32::NPX) & (hx < 18) & ((unsigned)y < (unsigned)p.Hs) & ((unsigned)x < (unsigned)p.Ws);
         const int g = (lane & 3) ^ ((hx >> 2) & 3);
-        h_voff[t] = ok ? ((((img * p.Hs + y) * p.Ws + x) * p.lda) + g * 8) * 2 : (int)OOB;
+        h_voff[t] = ok ? (((((gj - 1 + hy) * p.Ws) + x) * p.lda) + g * 8) * 2 : (int)OOB;
         h_dst[t] = live ? (j * H32::WR_B + q * 1024) : -1;
     }
     int b_voff;                                              // filter DMA role: columns 16 wave .. 16 wave + 15 of the 128
@@ -915,7 +913,7 @@ __global__ __launch_bounds__(512, 2) void bhq32_kernel(const BGParams p) {
     const bool hr = p.res != nullptr, hm = p.mask != nullptr, h2 = p.D2 != nullptr, rpost = p.res_post != 0;
     const int kind = (!hr && !hm && !h2) ? 1 : ((hr && !rpost && !hm && !h2) ? 2 : ((!hr && hm && !h2) ? 3 : ((hr && rpost && !hm && h2) ? 4 : 5)));
     const float slope = (p.act == DPIG_ACT_NONE) ? 1.f : ((p.act == DPIG_ACT_RELU) ? 0.f : p.alpha);
-    const int row_base = (img * p.Hs + y0 + 8 * wr) * p.Ws + x0, cb0 = n0 + wc * 64;
+    const int row_base = (g0 + 8 * wr) * p.Ws + x0, cb0 = n0 + wc * 64;
     lds_char* W = L + wave * WEP_BYTES;
     switch (kind) {
         case 1: q_epilogue_wave<false, false, false, false>(p, acc, W, row_base, cb0, lane, slope, p.Ws); break;
@@ -950,14 +948,14 @@ static bool bhq_eligible(const BGParams& p) {
     if (p.Hr != p.Hs || p.Wr != p.Ws || p.oys * p.oys != 1 || p.oxs * p.oxs != 1) return false;
     if (1 + p.oy0 < 0 || 1 + p.oy0 + 2 * p.oys < 0 || 1 + p.oy0 > 2 || 1 + p.oy0 + 2 * p.oys > 2) return false;
     if (1 + p.ox0 < 0 || 1 + p.ox0 + 2 * p.oxs < 0 || 1 + p.ox0 > 2 || 1 + p.ox0 + 2 * p.oxs > 2) return false;
-    if ((p.Hs & 15) || (p.Ws & 15) || (p.Cs % TK) || p.M % (p.Hs * p.Ws)) return false;
+    if ((p.Hs & 7) || (p.Ws & 15) || (p.Cs % TK) || p.M % (p.Hs * p.Ws) || ((p.M / p.Ws) & 15)) return false;   // 8-row wave patches inside images; 16-row tiles over the stack
     const bool hr = p.res != nullptr, hm = p.mask != nullptr, h2 = p.D2 != nullptr, rpost = p.res_post != 0;
     const bool known = (!hr && !hm && !h2) || (hr && !rpost && !hm && !h2) || (!hr && hm && !h2) || (hr && rpost && !hm && h2) || (hr && !rpost && hm && !h2);
     return known;
 }
 
 static int g_q_halo32 = []() { const char* e = getenv("DPIG_BF16_QH32"); return e ? atoi(e) : 1; }();   // halo-staged 512 x 128 variant (A/B switch)
-static bool bhq32_eligible(const BGParams& p) { return bhq_eligible(p) && !(p.Hs & 31); }
+static bool bhq32_eligible(const BGParams& p) { return bhq_eligible(p) && !((p.M / p.Ws) & 31); }
 
 // Fraction of the launched MFMA work that is real when the tiles of bm x bn run `slots` at a time in whole rounds.
 static double q_eff(long M, long N, int bm, int bn, int slots) {
@@ -997,8 +995,8 @@ int bq_try(BGParams& p, hipStream_t st) {
     q.tiles_per_split = ktiles;
     dim3 grid(q.mtiles * q.ntiles, 1, 1), block(512);
     if (variant == 1 && halo) {
-        q.tiles_x = p.Ws / 16; q.tiles_y = p.Hs / 16;
-        q.mtiles = (p.M / (p.Hs * p.Ws)) * q.tiles_x * q.tiles_y;
+        q.tiles_x = p.Ws / 16; q.tiles_y = (p.M / p.Ws) / 16;             // tiles over the stack of all images' pixel rows
+        q.mtiles = q.tiles_x * q.tiles_y;
         dim3 hgrid(q.mtiles * q.ntiles, 1, 1);
         if (g_q_halo == 2) hipLaunchKernelGGL(bhq_kernel<true>, hgrid, block, 0, st, q);
         else hipLaunchKernelGGL(bhq_kernel<false>, hgrid, block, 0, st, q);
@@ -1006,8 +1004,8 @@ int bq_try(BGParams& p, hipStream_t st) {
         return rch ? rch : 1;
     }
     if (variant == 2 && halo32) {
-        q.tiles_x = p.Ws / 16; q.tiles_y = p.Hs / 32;
-        q.mtiles = (p.M / (p.Hs * p.Ws)) * q.tiles_x * q.tiles_y;
+        q.tiles_x = p.Ws / 16; q.tiles_y = (p.M / p.Ws) / 32;
+        q.mtiles = q.tiles_x * q.tiles_y;
         dim3 hgrid(q.mtiles * q.ntiles, 1, 1);
         hipLaunchKernelGGL(bhq32_kernel, hgrid, block, 0, st, q);
         const int rch = check_launch("bhq32_kernel");

@@ -41,6 +41,29 @@ static inline int resolve_desc(const DpigConvDesc* d, int* pt, int* pl, int* Ho,
     return DPIG_OK;
 }
 
+// Filter taps that touch at least one REAL input pixel for some output position: a contiguous window [a0, a0 + na) x [b0, b0 + nb) of
+// the R x S filter.  Every tap outside it multiplies padding only -- on the 1 x 1 maps at the bottom of the DeepFashion ROI tower
+// (models.py:420-431 at trainer_256.py:40-41: repeat_num 7) eight of a 3 x 3 filter's nine taps, on its 2 x 2 -> 1 x 1 stride-2 conv
+// five -- so the kernels' tap loops run over the window only (the affine tap family of the parameter blocks addresses a sub-rectangle
+// of the filter directly); results are identical.  Forward: tap row a is live iff 0 <= oy s - pt + a < H for some output row oy.
+struct TapWindow { int a0, na, b0, nb; };
+static inline void live_range(int in, int out, int k, int s, int pad, int* lo, int* n) {
+    int first = -1, last = -1;
+    for (int a = 0; a < k; ++a) {
+        bool live = false;
+        for (int o = 0; o < out && !live; ++o) live = (o * s - pad + a >= 0) && (o * s - pad + a < in);
+        if (live) { if (first < 0) first = a; last = a; }
+    }
+    if (first < 0) { first = 0; last = 0; }
+    *lo = first; *n = last - first + 1;
+}
+static inline TapWindow live_taps(const DpigConvDesc* d, int pt, int pl, int Ho, int Wo) {
+    TapWindow t;
+    live_range(d->H, Ho, d->R, d->stride, pt, &t.a0, &t.na);
+    live_range(d->W, Wo, d->S, d->stride, pl, &t.b0, &t.nb);
+    return t;
+}
+
 // Split-K plan.  The grid is tiles x splits workgroups of which 2 per CU are resident (512 slots):
 // pick the split count that best fills whole "rounds" of 512 slots, charged with the HBM round trip
 // of the fp32 partial sums (~pen*s/K relative to the MFMA time of a K-deep reduction: pen = 120 for the fp32

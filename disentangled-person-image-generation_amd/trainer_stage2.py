@@ -124,16 +124,95 @@ class DPIG_Encoder_subSampleAppNetFgBg_GAN_BodyROI(object):
             clip_disc_weights(df)
         return d_loss.detach()
 
+    def enable_graphs(self, batch, warmup=2):
+        """hipGraph replay of the step's optimizer ops (the launch-bound part of this trainer: ten frozen-encoder forwards of ~300 launches
+        each plus the FC mappers / critics): one captured graph per (side, op) -- `d_optim_embs` = encoder forward + mapper forward + critic
+        forward / backward + RMSProp + clip, `g_optim_embs` = mapper + critic forward / backward + RMSProp -- replayed in the loop order of
+        trainer.py:821-845.  The batch lives in static buffers (`_feed` copies a new one in); the samplers' noise comes from the device
+        generator, which torch advances per replay.  Weights, optimizer slots and the generator state are put back after the warm-up, so
+        enabling graphs does not move the training trajectory."""
+        from ._lib import workspace
+        dev = self.device
+        self._static = {k: v.clone() for k, v in batch.items()}
+        snap = [(f.flat.clone(), f.m.clone(), f.v.clone()) for pair in self.flats.values() for f in pair]
+        osnap = [(o, o.t, o.state.clone() if hasattr(o, "state") else None) for pair in self.opts.values() for o in pair]
+        rng = torch.cuda.get_rng_state(dev)
+        side_stream = torch.cuda.Stream(device=dev)
+        side_stream.wait_stream(torch.cuda.current_stream(dev))
+        step0, self._graphs = self.step, None
+        with torch.cuda.stream(side_stream):
+            self.step = 1
+            for _ in range(warmup):
+                self._train_step_eager(self._static)
+        torch.cuda.current_stream(dev).wait_stream(side_stream)
+        torch.cuda.synchronize(dev)
+        self.step = step0
+        with torch.no_grad():
+            for f, (w, m, v) in zip([f for pair in self.flats.values() for f in pair], snap):
+                f.flat.copy_(w); f.m.copy_(m); f.v.copy_(v)
+            for o, t, st in osnap:
+                o.t = t
+                if st is not None:
+                    o.state.copy_(st)
+        torch.cuda.set_rng_state(rng, dev)
+        torch.cuda.synchronize(dev)
+        graphs, pool = {}, None
+        for side in ("fg", "bg"):
+            for op in ("g", "d"):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
+                    out = self.g_optim_embs(side) if op == "g" else self.d_optim_embs(side, self._static)
+                pool = g.pool()
+                graphs[(side, op)] = (g, out)
+                o = self.opts[side][0 if op == "g" else 1]
+                o.t -= 1                      # capturing recorded one step() without executing it
+        self._graphs = graphs
+        workspace.pin()
+
+    def _feed(self, batch):
+        for k, v in batch.items():
+            if self._static[k].data_ptr() != v.data_ptr():
+                self._static[k].copy_(v, non_blocking=True)
+
     def train_step(self, batch):
-        """trainer.py:821-845."""
-        out = {}
+        """trainer.py:821-845.  `batch`: one batch, or a sequence -- every `sess.run(d_optim_embs)` of the reference dequeues a fresh
+        batch (trainer.py:553-555, 832-841), so the ten critic updates of a step see ten batches (a single one is reused for all)."""
+        if getattr(self, "_graphs", None) is None:
+            return self._train_step_eager(batch)
+        many = isinstance(batch, (list, tuple))
+        out, k = {}, 0
+        for side in ("fg", "bg"):
+            wg = self.sides[side]["wg"]
+            if self.step > 0:
+                g, o = self._graphs[(side, "g")]
+                g.replay()
+                self.opts[side][0].t += 1
+                out["g_loss_embs_" + side] = o
+            iters = 1 if wg.MODE in ('dcgan', 'lsgan') else wg.CRITIC_ITERS
+            for _ in range(iters):
+                self._feed(batch[k % len(batch)] if many else batch)
+                k += 1
+                g, o = self._graphs[(side, "d")]
+                g.replay()
+                self.opts[side][1].t += 1
+                out["d_loss_embs_" + side] = o
+        if self.step % self.config.lr_update_step == self.config.lr_update_step - 1:
+            self.g_lr.mul_(0.5)
+            self.d_lr.mul_(0.5)
+        self.step += 1
+        return out
+
+    def _train_step_eager(self, batch):
+        many = isinstance(batch, (list, tuple))
+        out, k = {}, 0
         for side in ("fg", "bg"):
             wg = self.sides[side]["wg"]
             if self.step > 0:
                 out["g_loss_embs_" + side] = self.g_optim_embs(side)
             iters = 1 if wg.MODE in ('dcgan', 'lsgan') else wg.CRITIC_ITERS
             for _ in range(iters):
-                out["d_loss_embs_" + side] = self.d_optim_embs(side, batch)
+                out["d_loss_embs_" + side] = self.d_optim_embs(side, batch[k % len(batch)] if many else batch)
+                k += 1
         if self.step % self.config.lr_update_step == self.config.lr_update_step - 1:
             self.g_lr.mul_(0.5)
             self.d_lr.mul_(0.5)

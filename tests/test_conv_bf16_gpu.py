@@ -363,3 +363,38 @@ def test_bf16_conv_epilogue_bn_statistics(dev, shape):
     assert float((out.float().cpu().double() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())      # bf16 y, bf16 result
     y2, st2 = H.conv2d_fwd_stats(xg, wg, bg, stride=s, split_k=1)
     assert torch.equal(y2, y) and torch.equal(st2[0], st[0])
+
+
+@pytest.mark.parametrize("shape", [(56, 1, 1, 896, 896, 3, 1), (56, 2, 2, 768, 896, 3, 2), (7, 1, 1, 64, 72, 5, 1), (5, 1, 3, 64, 64, 3, 1),
+                                   (9, 2, 1, 96, 64, 3, 2)])
+def test_maps_smaller_than_the_filter_run_their_live_taps_only(dev, shape):
+    """The bottom of the DeepFashion ROI tower (models.py:420-431 with repeat_num 7, trainer_256.py:40-41): 3x3 convs on 1 x 1 maps and the
+    2 x 2 -> 1 x 1 stride-2 conv.  Taps that only ever see padding are skipped (dpig_conv_plan.h::live_taps; the 1 x 1-map filter
+    gradient runs as the centre slab's 1 x 1 conv): forward (+ bias + ReLU), dgrad (* mask) and wgrad (+ bias gradient; beta 0 / 1 / 0.5,
+    untouched slabs = beta * dw) against the DENSE fp64 oracle conv on the bf16-rounded operands."""
+    import dpig_amd.hip_ops as H
+    from oracle import ops as O
+    N, Hh, W, C, K, k, s = shape
+    x = _rand((N, Hh, W, C), 31)
+    w = _rand((k, k, C, K), 32, 0.1)
+    b = _rand((K,), 33)
+    xr = _r(x).requires_grad_(True)
+    wr = _r(w).requires_grad_(True)
+    y0 = O.conv2d_same(xr, wr, None, s)
+    dy = _rand(tuple(y0.shape), 34)
+    y0.backward(_r(dy))
+    xd, wd, bd, dyd = x.float().to(dev).to(BF), w.float().to(dev), b.float().to(dev), dy.float().to(dev).to(BF)
+    _close_bf16(H.conv2d_fwd(xd, wd, bd, stride=s, act=1), O.relu(y0.detach() + b.double()))
+    if s == 1:
+        m = _rand((N, Hh, W, C), 35)
+        _close_bf16(H.conv2d_dgrad(dyd, wd, (N, Hh, W, C), stride=s, mask=m.float().to(dev).to(BF), act=1), xr.grad * (_r(m) > 0))
+    else:
+        _close_bf16(H.conv2d_dgrad(dyd, wd, (N, Hh, W, C), stride=s), xr.grad)
+    for beta in (0.0, 1.0, 0.5):
+        dw = torch.full((k, k, C, K), 2.0, device=dev)
+        db = torch.full((K,), 3.0, device=dev)
+        H.conv2d_wgrad(xd, dyd, (k, k, C, K), stride=s, out=dw, beta=beta, db=db, db_beta=beta)
+        ref = wr.grad + 2.0 * beta
+        assert (dw.double().cpu() - ref).abs().max().item() <= 2e-5 * max(ref.abs().max().item(), 1e-6), beta
+        refb = _r(dy).sum((0, 1, 2)) + 3.0 * beta
+        assert (db.double().cpu() - refb).abs().max().item() <= 2e-5 * max(refb.abs().max().item(), 1e-6), beta

@@ -128,19 +128,24 @@ def test_upsampled_1x1(dev, large_tile):
     _close_bf16(got, ref)
 
 
-# ---- bhq32_kernel: the halo-staged 512 x 128 kernel (32 x 16-pixel patches, 32-channel k-tiles) -------------------------------
-# (N, H, W, C, K): H a multiple of 32, W of 16, C of 64 -- what routes the forced 512 x 128 variant to it
-BHQ32_SHAPES = [
-    (2, 32, 16, 64, 128),      # one patch per image, two 32-channel chunks (the next chunk's halo is staged exactly once)
-    (1, 64, 48, 128, 128),     # 2 x 3 patches: interior halos on every side
-    (3, 32, 32, 192, 104),     # 104 columns: a partial column tile (dead filter rows), 6 chunks
-    (1, 32, 16, 64, 264),      # three column tiles, the last one with 8 live columns
+# ---- the halo-staged kernels: bhq_kernel (256 x 256: 16 x 16-pixel patches) and bhq32_kernel (512 x 128: 32 x 16-pixel patches, 32-channel
+# k-tiles).  Tiles run over the STACK of all images' pixel rows (wave rows of 8 pixel rows stay inside one image: H % 8 == 0), so a
+# tile may straddle two images; (variant, (N, H, W, C, K)): W a multiple of 16, C of 64, N * H a multiple of 16 / 32
+HALO_SHAPES = [
+    (2, (2, 32, 16, 64, 128)),      # one patch per image, two 32-channel chunks (the next chunk's halo is staged exactly once)
+    (2, (1, 64, 48, 128, 128)),     # 2 x 3 patches: interior halos on every side
+    (2, (3, 32, 32, 192, 104)),     # 104 columns: a partial column tile (dead filter rows), 6 chunks
+    (2, (1, 32, 16, 64, 264)),      # three column tiles, the last one with 8 live columns
+    (2, (4, 24, 16, 64, 128)),      # 24-row images: every tile straddles two images (rows 0-23 | 0-7, 8-23 | 0-15, ...)
+    (2, (4, 48, 48, 128, 128)),     # the Market ROI-tower level (48 x 48 crops): tiles 1 and 2 of every three straddle
+    (1, (4, 24, 16, 64, 256)),      # bhq_kernel, 16-row tiles over 24-row images
+    (1, (2, 40, 32, 128, 192)),     # bhq_kernel, 40 = 2.5 tiles per image, a partial column tile
 ]
 
 
-@pytest.mark.parametrize("shape", BHQ32_SHAPES)
-def test_halo_staged_512x128_kernel_against_oracle(dev, shape):
-    """Forward (every fused epilogue of the family) and the stride-1 dgrad of 3x3 layers on bhq32_kernel against the fp64 oracle on
+@pytest.mark.parametrize("variant,shape", HALO_SHAPES)
+def test_halo_staged_kernels_against_oracle(dev, variant, shape):
+    """Forward (every fused epilogue of the family) and the stride-1 dgrad of 3x3 layers on bhq_kernel / bhq32_kernel against the fp64 oracle on
     the bf16-rounded operands, and launch-after-launch repeatability (the counted-vmcnt pipeline's hazards are timing dependent)."""
     import dpig_amd.hip_ops as H
     from oracle import ops as O
@@ -158,7 +163,7 @@ def test_halo_staged_512x128_kernel_against_oracle(dev, shape):
     conv = conv0.detach() + b.float().double()
     conv0.backward(_r(dy))
     try:
-        H.set_large_tile(2, 2)
+        H.set_large_tile(2, variant)
         y1 = H.conv2d_fwd(xd, wd, bd, act=1)
         _close_bf16(y1, O.relu(conv))
         _close_bf16(H.conv2d_fwd(xd, wd, None), conv0.detach())

@@ -83,6 +83,54 @@ def test_stage2_mapper_critic_wgan(dev):
     lib.delete_all_params()
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_stage2_hipgraph_replay_matches_eager(dev, dtype):
+    """Model 3 (trainer.py:715-868) with its optimizer ops replayed as hipGraphs (`enable_graphs`: one graph per (side, op), the loop order
+    of trainer.py:821-845) against the same trainer launched eagerly: same weights, same device-generator state, three steps (the first
+    without mapper updates, a sequence of distinct batches for the critic updates) -- losses and every mapper / critic weight identical
+    (the captured samplers draw from the generator at the offsets eager execution uses); enabling graphs does not move the weights."""
+    import dpig_amd.hip_ops as H
+    import dpig_amd.tflib as lib
+    from dpig_amd import slim, synthetic
+    from dpig_amd.trainer import Config
+    from dpig_amd.trainer_stage2 import DPIG_Encoder_subSampleAppNetFgBg_GAN_BodyROI
+    B, HID = 4, 16
+    batches = [synthetic.to_device(synthetic.make_batch(B, seed=40 + i), dev) for i in range(3)]
+    res = {}
+    try:
+        for mode in ("eager", "graph"):
+            lib.delete_all_params(); slim.reset_scopes(); lib.set_device(dev)
+            import numpy as np
+            np.random.seed(3)
+            tr = DPIG_Encoder_subSampleAppNetFgBg_GAN_BodyROI(Config(batch_size=B, conv_hidden_num=HID, g_lr=1e-3, d_lr=1e-3,
+                                                                     compute_dtype=dtype), dev)
+            tr.init_net(batches[0])
+            w0 = [f.flat.clone() for pair in tr.flats.values() for f in pair]
+            if mode == "graph":
+                tr.enable_graphs(batches[0])
+                assert tr._graphs is not None
+                for a, f in zip(w0, [f for pair in tr.flats.values() for f in pair]):
+                    assert torch.equal(a, f.flat), "enable_graphs moved the weights"
+            torch.cuda.manual_seed(1234)
+            outs = []
+            for step in range(3):
+                o = tr.train_step(batches)
+                outs.append({k: float(v) for k, v in o.items()})
+            res[mode] = (outs, [f.flat.clone() for pair in tr.flats.values() for f in pair],
+                         [(o.t) for pair in tr.opts.values() for o in pair])
+        assert res["eager"][2] == res["graph"][2]
+        for oe, og in zip(res["eager"][0], res["graph"][0]):
+            assert oe.keys() == og.keys()
+            for k in oe:
+                assert oe[k] == og[k], (k, oe[k], og[k])
+        for a, b in zip(res["eager"][1], res["graph"][1]):
+            assert torch.equal(a, b)
+        assert float((res["graph"][1][0] - w0[0]).abs().max()) > 0
+    finally:
+        H.set_compute("f32")
+        lib.delete_all_params(); slim.reset_scopes()
+
+
 def test_stage1_256_graph(dev):
     """Model 101 at 256x256, width 8: activations, the 8-rows-per-image logits (F8), losses, one step."""
     import dpig_amd.tflib as lib
