@@ -97,6 +97,10 @@ SYMBOLS = {
     "dpig_bn_workspace_bytes": (_sz, [_i64, _i]),
     "dpig_bn_fwd": (_i, [_vp, _i, _i64, _i, _vp, _vp, _f, _i, _f, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "dpig_bn_bwd": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp, _vp, _vp, _i, _f, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "dpig_bn_bf16_workspace_bytes": (_sz, [_i64, _i]),
+    "dpig_bn_fwd_bf16": (_i, [_vp, _i, _i64, _i, _vp, _vp, _f, _i, _f, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
+    "dpig_bn_apply_bf16": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _i, _vp]),
+    "dpig_bn_bwd_bf16": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp, _vp, _vp, _i, _f, _vp, _i, _vp, _vp, _vp, _sz, _vp]),
     "dpig_bn_sqdev": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _sz, _vp]),
     "dpig_bn_apply": (_i, [_vp, _i, _i64, _i, _vp, _vp, _vp, _vp, _i, _f, _vp, _i, _vp]),
     "dpig_bn_bwd_sums": (_i, [_vp, _i, _vp, _i, _vp, _i, _i64, _i, _vp, _vp, _i, _f, _vp, _vp, _vp, _sz, _vp]),

@@ -428,6 +428,184 @@ __global__ void gp_final_kernel(const float* __restrict__ slopes, int B, float l
     penalty[0] = lambda * s / (float)B;
 }
 
+// ---- training-mode batch norm on bf16 tensors (tflib/ops/batchnorm.py:30: tf.nn.fused_batch_norm; statistics over N, H, W per channel) ------
+// The 'bf16' storage mode used to bracket the fp32 kernels of dpig_misc.hip with conversion passes (3 tensors in, 1 out per call: 36
+// conversion launches per DeepFashion step).  These read / write the bf16 tensors directly: 8 channels (16 bytes) per thread, fp32
+// arithmetic, the same two-pass statistics (mean, then centred squares) and the same fixed summation order idea (row slabs, then slabs).
+// MODE 0: s0 = sum a;  1: s0 = sum (a - mean[c])^2;  2: dz = a * act'(y), s0 = sum dz, s1 = sum dz * (x - mean[c]) * rstd[c]
+template <int MODE>
+__global__ __launch_bounds__(NT) void bn16_partial_kernel(const bf16_t* __restrict__ a, int lda, const bf16_t* __restrict__ x, int ldx,
+                                                          const bf16_t* __restrict__ y, int ldy, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, long rows, int C, int act, float alpha,
+                                                          float* __restrict__ partial) {
+    constexpr int NOUT = MODE == 2 ? 2 : 1;
+    __shared__ float red[NOUT][16][128 + 4];
+    const int cg = threadIdx.x & 15, rg = threadIdx.x >> 4;
+    const int c0 = blockIdx.x * 128 + cg * 8;
+    float s0[8], s1[8], mu[8], rs[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s0[e] = 0.f; s1[e] = 0.f; mu[e] = 0.f; rs[e] = 0.f; }
+    if (c0 < C) {
+        if (MODE >= 1) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mu[e] = mean[c0 + e];
+        }
+        if (MODE == 2) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) rs[e] = rstd[c0 + e];
+        }
+        for (long r = (long)blockIdx.y * 16 + rg; r < rows; r += (long)gridDim.y * 16) {
+            float v[8];
+            ldv<8>(a, r * lda + c0, v);
+            if (MODE == 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s0[e] += v[e];
+            } else if (MODE == 1) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { const float d = v[e] - mu[e]; s0[e] += d * d; }
+            } else {
+                float xv[8], yv[8];
+                ldv<8>(x, r * ldx + c0, xv);
+                if (act != DPIG_ACT_NONE) ldv<8>(y, r * ldy + c0, yv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float dz = (act != DPIG_ACT_NONE) ? v[e] * act_grad(yv[e], act, alpha) : v[e];
+                    s0[e] += dz;
+                    s1[e] += dz * (xv[e] - mu[e]) * rs[e];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        red[0][rg][cg * 8 + e] = s0[e];
+        if (NOUT == 2) red[NOUT - 1][rg][cg * 8 + e] = s1[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128 && blockIdx.x * 128 + (int)threadIdx.x < C) {
+#pragma unroll
+        for (int o = 0; o < NOUT; ++o) {
+            float t = 0.f;
+#pragma unroll
+            for (int g16 = 0; g16 < 16; ++g16) t += red[o][g16][threadIdx.x];
+            partial[((long)blockIdx.y * NOUT + o) * C + blockIdx.x * 128 + threadIdx.x] = t;
+        }
+    }
+}
+// FIN 0: out_o[c] = scale * sum_slab partial[slab][o][c];  FIN 1: out_0[c] = 1 / sqrt(scale * sum + eps).  A block = 64 channels x 4 slab
+// groups (group g takes slabs g, g + 4, ...; the four group sums are added in group order: deterministic)
+template <int FIN>
+__global__ __launch_bounds__(NT) void bn16_final_kernel(const float* __restrict__ partial, int nslab, int nout, int C, float* __restrict__ out0,
+                                                        float* __restrict__ out1, float scale, float eps) {
+    __shared__ float red[2][4][64];
+    const int cl = threadIdx.x & 63, gq = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
+    for (int o = 0; o < nout; ++o) {
+        float sum = 0.f;
+        if (c < C)
+            for (int b = gq; b < nslab; b += 4) sum += partial[((long)b * nout + o) * C + c];
+        red[o][gq][cl] = sum;
+    }
+    __syncthreads();
+    if (gq != 0 || c >= C) return;
+    for (int o = 0; o < nout; ++o) {
+        const float t = (red[o][0][cl] + red[o][1][cl]) + (red[o][2][cl] + red[o][3][cl]);
+        float* out = o == 0 ? out0 : out1;
+        if (FIN == 1) out[c] = 1.0f / sqrtf(t * scale + eps);
+        else out[c] = t * scale;
+    }
+}
+// y = act((x - mean) * rstd * scale + offset).  FIXED (C / 8 divides the block size, every model width): a thread keeps its 8 channels for
+// all its rows, the per-channel constants live in registers; otherwise they are fetched per element group.
+template <bool FIXED>
+__global__ __launch_bounds__(NT) void bn16_apply_kernel(const bf16_t* __restrict__ x, int ldx, long rows, int C, const float* __restrict__ scale,
+                                                        const float* __restrict__ offset, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, int act, float alpha, bf16_t* __restrict__ y, int ldy) {
+    const int c8 = C >> 3;
+    if (FIXED) {
+        const int c0 = (threadIdx.x % c8) * 8, rpb = NT / c8;
+        float ka[8], kb[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { ka[e] = rstd[c0 + e] * scale[c0 + e]; kb[e] = offset[c0 + e] - mean[c0 + e] * ka[e]; }
+        for (long r = (long)blockIdx.x * rpb + threadIdx.x / c8; r < rows; r += (long)gridDim.x * rpb) {
+            float v[8], o[8];
+            ldv<8>(x, r * ldx + c0, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = act_apply(v[e] * ka[e] + kb[e], act, alpha);
+            stv<8>(y, r * ldy + c0, o);
+        }
+        return;
+    }
+    const long total = rows * c8;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const long r = i / c8;
+        const int c0 = (int)(i - r * c8) * 8;
+        float v[8], o[8];
+        ldv<8>(x, r * ldx + c0, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float ka = rstd[c0 + e] * scale[c0 + e];
+            o[e] = act_apply(v[e] * ka + (offset[c0 + e] - mean[c0 + e] * ka), act, alpha);
+        }
+        stv<8>(y, r * ldy + c0, o);
+    }
+}
+template <bool FIXED>
+__global__ __launch_bounds__(NT) void bn16_bwd_apply_kernel(const bf16_t* __restrict__ dy, int lddy, const bf16_t* __restrict__ x, int ldx,
+                                                            const bf16_t* __restrict__ y, int ldy, long rows, int C,
+                                                            const float* __restrict__ scale, const float* __restrict__ mean,
+                                                            const float* __restrict__ rstd, const float* __restrict__ dscale,
+                                                            const float* __restrict__ doffset, int act, float alpha, float inv,
+                                                            bf16_t* __restrict__ dx, int lddx) {
+    const int c8 = C >> 3;
+    auto one = [&](long r, int c0, const float (&mu)[8], const float (&rs)[8], const float (&k1)[8], const float (&k2)[8], const float (&k3)[8]) {
+        float d[8], xv[8], yv[8], o[8];
+        ldv<8>(dy, r * lddy + c0, d);
+        ldv<8>(x, r * ldx + c0, xv);
+        if (act != DPIG_ACT_NONE) ldv<8>(y, r * ldy + c0, yv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float dz = (act != DPIG_ACT_NONE) ? d[e] * act_grad(yv[e], act, alpha) : d[e];
+            const float xh = (xv[e] - mu[e]) * rs[e];
+            o[e] = k1[e] * (dz - k2[e] - xh * k3[e]);
+        }
+        stv<8>(dx, r * lddx + c0, o);
+    };
+    auto consts = [&](int c0, float (&mu)[8], float (&rs)[8], float (&k1)[8], float (&k2)[8], float (&k3)[8]) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            mu[e] = mean[c0 + e]; rs[e] = rstd[c0 + e];
+            k1[e] = scale[c0 + e] * rs[e]; k2[e] = doffset[c0 + e] * inv; k3[e] = dscale[c0 + e] * inv;
+        }
+    };
+    float mu[8], rs[8], k1[8], k2[8], k3[8];
+    if (FIXED) {
+        const int c0 = (threadIdx.x % c8) * 8, rpb = NT / c8;
+        consts(c0, mu, rs, k1, k2, k3);
+        for (long r = (long)blockIdx.x * rpb + threadIdx.x / c8; r < rows; r += (long)gridDim.x * rpb) one(r, c0, mu, rs, k1, k2, k3);
+        return;
+    }
+    const long total = rows * c8;
+    for (long i = (long)blockIdx.x * NT + threadIdx.x; i < total; i += (long)gridDim.x * NT) {
+        const long r = i / c8;
+        const int c0 = (int)(i - r * c8) * 8;
+        consts(c0, mu, rs, k1, k2, k3);
+        one(r, c0, mu, rs, k1, k2, k3);
+    }
+}
+static int bn16_slabs(long rows) {
+    long s = rows / 128;
+    return (int)(s < 1 ? 1 : (s > 256 ? 256 : s));
+}
+static int bn16_grid(long n) {
+    long b = (n + NT - 1) / NT;
+    return (int)(b < 1 ? 1 : (b > 8 * kNumCU ? 8 * kNumCU : b));
+}
+static int bn16_check(const void* a, int lda, int C) {
+    if (C % 8 || lda % 8 || lda < C || !aligned16(a)) return fail(DPIG_EALIGN, "bf16 batch norm: 16-byte channel vectors (C, strides multiples of 8)");
+    return DPIG_OK;
+}
+
 // ---- host side ------------------------------------------------------------------------------------------------------------------
 static Geo make_geo(int N, long L, int C) {
     Geo g;
@@ -621,4 +799,69 @@ extern "C" int dpig_gp_penalty(const float* g, int B, int64_t D, float lambda, f
     }
     hipLaunchKernelGGL(gp_final_kernel, dim3(1), dim3(64), 0, st, slopes, B, lambda, penalty);
     return check_launch("gp_penalty");
+}
+
+// ---- batch norm on bf16 tensors --------------------------------------------------------------------------------------------------------
+extern "C" size_t dpig_bn_bf16_workspace_bytes(int64_t rows, int C) {
+    if (rows <= 0 || C <= 0) return 0;
+    return up256((size_t)bn16_slabs(rows) * 2 * C * sizeof(float));
+}
+extern "C" int dpig_bn_apply_bf16(const uint16_t* x, int ldx, int64_t rows, int C, const float* scale, const float* offset, const float* mean,
+                                  const float* rstd, int act, float alpha, uint16_t* y, int ldy, void* stream) {
+    if (!x || !scale || !offset || !mean || !rstd || !y || rows <= 0 || C <= 0) return fail(DPIG_EINVAL, "bn_apply_bf16: bad arguments");
+    int rc = bn16_check(x, ldx, C);
+    if (!rc) rc = bn16_check(y, ldy, C);
+    if (rc) return rc;
+    const dim3 grid(bn16_grid(rows * (C / 8)));
+    if (NT % (C / 8) == 0) hipLaunchKernelGGL((bn16_apply_kernel<true>), grid, dim3(NT), 0, static_cast<hipStream_t>(stream), x, ldx, (long)rows, C,
+                                              scale, offset, mean, rstd, act, alpha, y, ldy);
+    else hipLaunchKernelGGL((bn16_apply_kernel<false>), grid, dim3(NT), 0, static_cast<hipStream_t>(stream), x, ldx, (long)rows, C, scale, offset,
+                            mean, rstd, act, alpha, y, ldy);
+    return check_launch("bn_apply_bf16");
+}
+extern "C" int dpig_bn_fwd_bf16(const uint16_t* x, int ldx, int64_t rows, int C, const float* scale, const float* offset, float eps, int act,
+                                float alpha, uint16_t* y, int ldy, float* save_mean, float* save_rstd, void* ws, size_t ws_bytes,
+                                void* stream) {
+    if (!x || !scale || !offset || !y || !save_mean || !save_rstd || rows <= 0 || C <= 0) return fail(DPIG_EINVAL, "bn_fwd_bf16: bad arguments");
+    int rc = bn16_check(x, ldx, C);
+    if (rc) return rc;
+    if (!ws || ws_bytes < dpig_bn_bf16_workspace_bytes(rows, C)) return fail(DPIG_ENOMEM, "bn_fwd_bf16: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nslab = bn16_slabs(rows);
+    float* partial = static_cast<float*>(ws);
+    const dim3 g1((C + 127) / 128, nslab), g2((C + 63) / 64);
+    hipLaunchKernelGGL((bn16_partial_kernel<0>), g1, dim3(NT), 0, st, x, ldx, (const bf16_t*)nullptr, 0, (const bf16_t*)nullptr, 0,
+                       (const float*)nullptr, (const float*)nullptr, (long)rows, C, 0, 0.f, partial);
+    hipLaunchKernelGGL((bn16_final_kernel<0>), g2, dim3(NT), 0, st, partial, nslab, 1, C, save_mean, (float*)nullptr, 1.0f / (float)rows, 0.f);
+    hipLaunchKernelGGL((bn16_partial_kernel<1>), g1, dim3(NT), 0, st, x, ldx, (const bf16_t*)nullptr, 0, (const bf16_t*)nullptr, 0,
+                       (const float*)save_mean, (const float*)nullptr, (long)rows, C, 0, 0.f, partial);
+    hipLaunchKernelGGL((bn16_final_kernel<1>), g2, dim3(NT), 0, st, partial, nslab, 1, C, save_rstd, (float*)nullptr, 1.0f / (float)rows, eps);
+    rc = check_launch("bn_fwd_bf16");
+    if (rc) return rc;
+    return dpig_bn_apply_bf16(x, ldx, rows, C, scale, offset, save_mean, save_rstd, act, alpha, y, ldy, stream);
+}
+extern "C" int dpig_bn_bwd_bf16(const uint16_t* dy, int lddy, const uint16_t* x, int ldx, const uint16_t* y, int ldy, int64_t rows, int C,
+                                const float* scale, const float* save_mean, const float* save_rstd, int act, float alpha, uint16_t* dx,
+                                int lddx, float* dscale, float* doffset, void* ws, size_t ws_bytes, void* stream) {
+    if (!dy || !x || !scale || !save_mean || !save_rstd || !dx || !dscale || !doffset || rows <= 0 || C <= 0)
+        return fail(DPIG_EINVAL, "bn_bwd_bf16: bad arguments");
+    if (act != DPIG_ACT_NONE && !y) return fail(DPIG_EINVAL, "bn_bwd_bf16: activation output required");
+    int rc = bn16_check(dy, lddy, C);
+    if (!rc) rc = bn16_check(x, ldx, C);
+    if (!rc && act != DPIG_ACT_NONE) rc = bn16_check(y, ldy, C);
+    if (!rc) rc = bn16_check(dx, lddx, C);
+    if (rc) return rc;
+    if (!ws || ws_bytes < dpig_bn_bf16_workspace_bytes(rows, C)) return fail(DPIG_ENOMEM, "bn_bwd_bf16: workspace too small");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int nslab = bn16_slabs(rows);
+    float* partial = static_cast<float*>(ws);
+    hipLaunchKernelGGL((bn16_partial_kernel<2>), dim3((C + 127) / 128, nslab), dim3(NT), 0, st, dy, lddy, x, ldx, y, ldy, save_mean, save_rstd,
+                       (long)rows, C, act, alpha, partial);
+    hipLaunchKernelGGL((bn16_final_kernel<0>), dim3((C + 63) / 64), dim3(NT), 0, st, partial, nslab, 2, C, doffset, dscale, 1.0f, 0.f);
+    const dim3 grid(bn16_grid(rows * (C / 8)));
+    if (NT % (C / 8) == 0) hipLaunchKernelGGL((bn16_bwd_apply_kernel<true>), grid, dim3(NT), 0, st, dy, lddy, x, ldx, y, ldy, (long)rows, C, scale,
+                                              save_mean, save_rstd, dscale, doffset, act, alpha, 1.0f / (float)rows, dx, lddx);
+    else hipLaunchKernelGGL((bn16_bwd_apply_kernel<false>), grid, dim3(NT), 0, st, dy, lddy, x, ldx, y, ldy, (long)rows, C, scale, save_mean,
+                            save_rstd, dscale, doffset, act, alpha, 1.0f / (float)rows, dx, lddx);
+    return check_launch("bn_bwd_bf16");
 }

@@ -891,10 +891,33 @@ def pad_channels_bf16(x, cols_out):
     return out
 
 
+BN_BF16_NATIVE = [os.environ.get('DPIG_BN_BF16_NATIVE', '1') != '0']     # A/B switch: 0 = fp32 batch-norm kernels between conversion passes
+
+
 def bn_fwd(x, scale, offset, eps=1e-5, act=ACT_NONE, alpha=0.2, stats=None):
     """Training-mode batch norm over all but the last axis (+ fused activation).  `stats` = what `conv2d_fwd_stats` returned
     for x: the statistics passes are replaced by one merge of the producing conv's per-tile partials."""
     if x.dtype == BF16:
+        _require_dev(x)
+        xb, rows, C, ldx = _rows_ld(x)
+        if BN_BF16_NATIVE[0] and C % 8 == 0 and ldx % 8 == 0 and _al16(xb):       # bf16 tensors read / written directly (dpig_bn_*_bf16): no conversion passes
+            y = torch.empty(xb.shape, dtype=BF16, device=x.device)
+            mean = torch.empty(C, dtype=torch.float32, device=x.device)
+            rstd = torch.empty(C, dtype=torch.float32, device=x.device)
+            sc, of = scale.contiguous(), offset.contiguous()
+            if stats is not None:
+                st, rpt = stats
+                if st.shape[2] != C or st.shape[0] != (rows + rpt - 1) // rpt:
+                    raise RuntimeError("bn_fwd: the statistics do not belong to this tensor")
+                check(lib().dpig_bn_stats_finalize(ptr(st), st.shape[0], rows, rpt, C, eps, ptr(mean), ptr(rstd), stream_ptr()),
+                      "bn_stats_finalize")
+                check(lib().dpig_bn_apply_bf16(ptr(xb), ldx, rows, C, ptr(sc), ptr(of), ptr(mean), ptr(rstd), act, alpha, ptr(y), C,
+                                               stream_ptr()), "bn_apply_bf16")
+                return y, mean, rstd
+            wsb, wsn = workspace.get(lib().dpig_bn_bf16_workspace_bytes(rows, C), x.device)
+            check(lib().dpig_bn_fwd_bf16(ptr(xb), ldx, rows, C, ptr(sc), ptr(of), eps, act, alpha, ptr(y), C, ptr(mean), ptr(rstd),
+                                         ptr(wsb), wsn, stream_ptr()), "bn_fwd_bf16")
+            return y, mean, rstd
         y, mean, rstd = bn_fwd(to_f32(x), scale, offset, eps, act, alpha, stats=stats)
         return to_bf16(y), mean, rstd
     _require_gpu(x)
@@ -919,6 +942,20 @@ def bn_fwd(x, scale, offset, eps=1e-5, act=ACT_NONE, alpha=0.2, stats=None):
 
 def bn_bwd(dy, x, y, scale, mean, rstd, act=ACT_NONE, alpha=0.2):
     if BF16 in (dy.dtype, x.dtype) or (y is not None and y.dtype == BF16):
+        if BN_BF16_NATIVE[0] and x.dtype == BF16 and x.shape[-1] % 8 == 0:
+            dyb, rows, C, lddy = _rows_ld(to_bf16(dy))
+            xb, _, _, ldx = _rows_ld(x)
+            yb, ldy = None, C
+            if y is not None:
+                yb, _, _, ldy = _rows_ld(to_bf16(y))
+            if lddy % 8 == 0 and ldx % 8 == 0 and ldy % 8 == 0 and _al16(dyb, xb, yb):
+                dx = torch.empty(xb.shape, dtype=BF16, device=x.device)
+                dscale = torch.empty(C, dtype=torch.float32, device=x.device)
+                doffset = torch.empty(C, dtype=torch.float32, device=x.device)
+                wsb, wsn = workspace.get(lib().dpig_bn_bf16_workspace_bytes(rows, C), x.device)
+                check(lib().dpig_bn_bwd_bf16(ptr(dyb), lddy, ptr(xb), ldx, ptr(yb), ldy, rows, C, ptr(scale.contiguous()), ptr(mean), ptr(rstd),
+                                             act, alpha, ptr(dx), C, ptr(dscale), ptr(doffset), ptr(wsb), wsn, stream_ptr()), "bn_bwd_bf16")
+                return dx, dscale, doffset
         dx, dscale, doffset = bn_bwd(to_f32(dy), to_f32(x), to_f32(y), scale, mean, rstd, act, alpha)
         return _like_input(dx, x), dscale, doffset
     _require_gpu(dy)
@@ -1042,8 +1079,8 @@ def ln_bwd2(u, dy, x, y, scale, mean, rstd, act=ACT_NONE, alpha=0.2):
 
 
 def linear_fwd(x, w, bias=None, act=ACT_NONE, alpha=0.2):
-    if x.dtype == BF16:        # FC layers: fp32 kernels on fp32 weights; the output follows the input's storage type
-        return _like_input(linear_fwd(to_f32(x), w, bias, act, alpha), x)
+    if x.dtype == BF16:        # FC layers: fp32 kernels on fp32 weights; FC-net tensors stay fp32 (a conv that consumes one converts it)
+        return linear_fwd(to_f32(x), w, bias, act, alpha)
     _require_gpu(x)
     x = x.contiguous()
     w = w.contiguous()

@@ -285,6 +285,18 @@ int dpig_bn_bwd(const float* dy, int lddy, const float* x, int ldx, const float*
                 float alpha, float* dx, int lddx, float* dscale, float* doffset, void* ws,
                 size_t ws_bytes, void* stream);
 
+/* The same op on bf16 tensors ('bf16' storage mode): x / y / dy / dx bfloat16 [rows, C] with row strides (C and strides multiples of
+ * 8, 16-byte aligned), fp32 arithmetic, statistics and parameter gradients.  dpig_bn_apply_bf16 normalises with given statistics
+ * (those a conv epilogue left: dpig_conv2d_fwd_bf16_stats + dpig_bn_stats_finalize). */
+size_t dpig_bn_bf16_workspace_bytes(int64_t rows, int C);
+int dpig_bn_fwd_bf16(const uint16_t* x, int ldx, int64_t rows, int C, const float* scale, const float* offset, float eps, int act,
+                     float alpha, uint16_t* y, int ldy, float* save_mean, float* save_rstd, void* ws, size_t ws_bytes, void* stream);
+int dpig_bn_apply_bf16(const uint16_t* x, int ldx, int64_t rows, int C, const float* scale, const float* offset, const float* mean,
+                       const float* rstd, int act, float alpha, uint16_t* y, int ldy, void* stream);
+int dpig_bn_bwd_bf16(const uint16_t* dy, int lddy, const uint16_t* x, int ldx, const uint16_t* y, int ldy, int64_t rows, int C,
+                     const float* scale, const float* save_mean, const float* save_rstd, int act, float alpha, uint16_t* dx, int lddx,
+                     float* dscale, float* doffset, void* ws, size_t ws_bytes, void* stream);
+
 /* Staged form of the same op for synchronised batch statistics across data-parallel ranks: the
  * caller sum-all-reduces the [C] vectors between the stages.
  *   fwd: dpig_colsum(x) -> mean = sum/n_total; dpig_bn_sqdev(x, mean) -> rstd = rsqrt(sq/n_total + eps);

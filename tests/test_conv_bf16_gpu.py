@@ -398,3 +398,39 @@ def test_maps_smaller_than_the_filter_run_their_live_taps_only(dev, shape):
         assert (dw.double().cpu() - ref).abs().max().item() <= 2e-5 * max(ref.abs().max().item(), 1e-6), beta
         refb = _r(dy).sum((0, 1, 2)) + 3.0 * beta
         assert (db.double().cpu() - refb).abs().max().item() <= 2e-5 * max(refb.abs().max().item(), 1e-6), beta
+
+
+@pytest.mark.parametrize("shape", [(16, 64, 64, 128), (3, 9, 7, 72), (2, 4, 4, 512)])
+def test_batchnorm_on_bf16_tensors(dev, shape):
+    """Training-mode batch norm (tflib/ops/batchnorm.py:30) + fused LeakyReLU on bf16 tensors without conversion passes
+    (dpig_bn_fwd_bf16 / _bwd_bf16): forward, statistics, dx, dscale, doffset against the fp64 oracle evaluated on the bf16 operands;
+    outputs within one bf16 rounding, fp32 results at the fp32 kernels' bar."""
+    import dpig_amd.hip_ops as H
+    from oracle import ops as O
+    C = shape[-1]
+    x = (_rand(shape, 41) * 2 - 0.3)
+    sc = _rand((C,), 42) * 0.5 + 1.0
+    of = _rand((C,), 43)
+    dy = _rand(shape, 44)
+    xr = _r(x).requires_grad_(True)
+    scr, ofr = sc.float().double().requires_grad_(True), of.float().double().requires_grad_(True)
+    y = O.leaky_relu(O.batchnorm_train(xr, scr, ofr), 0.2)
+    xd = x.float().to(dev).to(BF)
+    yg, mean, rstd = H.bn_fwd(xd, sc.float().to(dev), of.float().to(dev), 1e-5, 2, 0.2)
+    assert yg.dtype == BF
+    _close_bf16(yg, y.detach())
+    m_ref = xr.detach().mean(dim=(0, 1, 2))
+    assert (mean.double().cpu() - m_ref).abs().max().item() < 1e-5 * max(m_ref.abs().max().item(), 1.0)
+    # backward from the kernel's own (rounded) activation, as the trainer runs it
+    yq = yg.double().cpu()
+    dyq = _r(dy)
+    dz = dyq * torch.where(yq > 0, 1.0, 0.2)
+    xh = (xr.detach() - m_ref) * rstd.double().cpu()
+    n = xr.numel() // C
+    dsc_ref, dof_ref = (dz * xh).sum(dim=(0, 1, 2)), dz.sum(dim=(0, 1, 2))
+    dx_ref = scr.detach() * rstd.double().cpu() * (dz - dof_ref / n - xh * dsc_ref / n)
+    dx, dsc, dof = H.bn_bwd(dy.float().to(dev).to(BF), xd, yg, sc.float().to(dev), mean, rstd, 2, 0.2)
+    assert dx.dtype == BF
+    _close_bf16(dx, dx_ref)
+    assert (dsc.double().cpu() - dsc_ref).abs().max().item() < 5e-5 * max(dsc_ref.abs().max().item(), 1e-6)
+    assert (dof.double().cpu() - dof_ref).abs().max().item() < 5e-5 * max(dof_ref.abs().max().item(), 1e-6)
