@@ -316,9 +316,14 @@ def main():
                 t = torch.tensor([sec], dtype=torch.float64, device=dev)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 return t.item()
-            # (a) the step's collectives alone, back to back on an otherwise idle GPU: G decoder slice, G encoder slice, D
-            eo = getattr(tr, "_enc_off", 0)
-            slices = [s for s in (tr.G_flat.grad[:eo], tr.G_flat.grad[eo:], tr.D_flat.grad) if s.numel()]
+            # (a) the step's collectives alone, back to back on an otherwise idle GPU: one slice per backward stage of the generator
+            #     side (generator, background tower, ROI tower, stem: trainer._backward_stages) + the critic's
+            if hasattr(tr, "_stages"):
+                slices = [tr._stage_slice(st) for st in tr._stages] + [tr.D_flat.grad]
+            else:
+                eo = getattr(tr, "_enc_off", 0)
+                slices = [tr.G_flat.grad[:eo], tr.G_flat.grad[eo:], tr.D_flat.grad]
+            slices = [s for s in slices if s.numel()]
             reps = 10
             for _ in range(2):
                 tr.allreduce.finish(sum((tr.allreduce.start(s) for s in slices), []))

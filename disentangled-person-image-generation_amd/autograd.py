@@ -14,17 +14,25 @@ from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU
 # sweep would also deliver d(sum D(xhat))/dtheta into the critic's gradient slices -- a term d_loss does not contain.
 _PARAM_GRADS_OFF = [False]
 
+# Stage boundaries of the data-parallel backward (trainer: the gradient exchange of a finished stage runs under the next stage's
+# kernels).  A trainer sets CUTS to a dict around its forward pass; the model builders record the tensors at which the backward
+# graph can be cut and (MARKS) how many `Conv` / `fully_connected` scopes their variable scope had opened at that point -- which
+# variables, by TF-slim name, belong to which stage (models.encoder_stage_of).
+CUTS = None
+MARKS = {}
 
-class no_param_grads(object):
-    """Context: backward passes run inside deliver no parameter gradients (input gradients only)."""
 
-    def __enter__(self):
-        self.saved = _PARAM_GRADS_OFF[0]
-        _PARAM_GRADS_OFF[0] = True
+class _CutFn(torch.autograd.Function):
+    """Identity that gives a cut tensor a backward node of its own: two outputs of ONE node (mask_split's x_fg / x_bg) would otherwise
+    share their capture point, and a partial backward towards one of them would still run every branch that reaches the node."""
 
-    def __exit__(self, *exc):
-        _PARAM_GRADS_OFF[0] = self.saved
-        return False
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
 
 
 # A ReLU conv whose output feeds ONE residual block: the block's input-gradient dgrad applies that ReLU's mask in its epilogue
@@ -76,6 +84,15 @@ class side_branch(object):
             for t in tensors:
                 t.record_stream(self.main)          # allocated on the side stream, read on this one
         return tensors[0] if len(tensors) == 1 else tensors
+
+
+def join_side_streams(device):
+    """Make the current stream wait for every side stream of `device`: after a PARTIAL backward pass (torch.autograd.grad towards a
+    tensor produced inside a side_branch) the returned gradients may have been written on a side stream."""
+    cur = torch.cuda.current_stream(device)
+    for (idx, _), st in _SIDE_STREAMS.items():
+        if idx == device.index:
+            cur.wait_stream(st)
 
 
 def _mark_relu_output(y, act):

@@ -27,6 +27,42 @@ def _tap(name, t):
         TAPS[name] = t.detach()
 
 
+def _cut(name, *tensors):
+    """Backward-stage boundary (autograd.CUTS / MARKS): the tensors, and the scope counters reached so far."""
+    path = slim._path()
+    if name == "E.towers_in":
+        A.MARKS.pop("E.bg_begin", None)                   # (a two-tower builder sets it again further down)
+    A.MARKS[name] = (path, slim._counters.get(path + "/Conv", 0), slim._counters.get(path + "/fully_connected", 0))
+    if A.CUTS is not None and tensors:
+        tensors = tuple(A._CutFn.apply(t) for t in tensors)      # (own backward node per cut tensor, see autograd._CutFn)
+        A.CUTS[name] = tensors
+    return tensors[0] if len(tensors) == 1 else tensors
+
+
+def encoder_stage_of(param_name):
+    """'stem' | 'roi' | 'bg' for a variable of the encoders below, from its TF-slim name (`<scope>/Conv_k/weights`, ...) and the scope
+    counters recorded at the stage boundaries; None for any other variable."""
+    if "E.towers_in" not in A.MARKS:
+        return None
+    path, conv_t, fc_t = A.MARKS["E.towers_in"]
+    if not param_name.startswith(path + "/"):
+        return None
+    leaf = param_name[len(path) + 1:].split("/")[0]
+    base, _, k = leaf.partition("_")
+    if base == "fully" :                                  # fully_connected[_k]
+        base, k = "fully_connected", leaf[len("fully_connected"):].lstrip("_")
+    k = int(k) if k else 0
+
+    def before(mark):
+        _, c, f = A.MARKS[mark]
+        return k < (c if base == "Conv" else f)
+    if before("E.towers_in"):
+        return "stem"
+    if "E.bg_begin" in A.MARKS and not before("E.bg_begin"):
+        return "bg"
+    return "roi"
+
+
 def relu(x):
     return slim.relu(x)
 
@@ -103,6 +139,7 @@ def GeneratorCNN_ID_Encoder_BodyROIVis(x, ROI_bboxs, ROI_vis, bbox_num, z_num, r
         img_H, img_W = float(x.shape[1]), float(x.shape[2])
         x = slim.conv2d(x, hidden_num, 3, 1, activation_fn=activation_fn, data_format=data_format)
         x = slim.res_block(x, hidden_num, 3, activation_fn=activation_fn, data_format=data_format)
+        x = _cut("E.towers_in", x)                     # backward stage boundary: [ROI tower] | [stem]
 
         boxes, box_ind = _normalised_boxes(ROI_bboxs, bbox_num, img_H, img_W)
         body_regions = A.crop_and_resize(x, boxes, box_ind, roi_size, roi_size)
@@ -134,6 +171,7 @@ def GeneratorCNN_ID_Encoder_BodyROIVis_FgBgFeaTwoBranch(x, fg_mask, ROI_bboxs, R
 
         _tap("E.stem", x)
         x_fg, x_bg = A.mask_split(x, fg_mask)          # x * m, x * (1 - m): one launch (csrc/dpig_glue.hip)
+        x_fg, x_bg = _cut("E.towers_in", x_fg, x_bg)  # backward stage boundaries: [Bg tower] | [ROI tower] | [stem]
 
         boxes, box_ind = _normalised_boxes(ROI_bboxs, bbox_num, img_H, img_W)
         with A.side_branch(x_fg) as fg_branch:          # the ROI tower beside the background branch (A.TWO_STREAM)
@@ -152,6 +190,7 @@ def GeneratorCNN_ID_Encoder_BodyROIVis_FgBgFeaTwoBranch(x, fg_mask, ROI_bboxs, R
                 fea_list[i] = fea_list[i] * keep
 
         # Background branch
+        _cut("E.bg_begin")
         for idx in range(repeat_num):
             channel_num = hidden_num * (idx + 1)
             x_bg = slim.res_block(x_bg, channel_num, 3, activation_fn=activation_fn, data_format=data_format)

@@ -373,9 +373,10 @@ class Config(object):
         self.sync_bn = False             # data parallel: D's BatchNorm statistics over all ranks
         self.grad_exchange = None        # None: 'bf16' in 'bf16' mode, fp32 otherwise.  'bf16' = the gradient all-reduce moves
                                          # bf16 (half the xGMI bytes; fp32 gradients and optimizer unchanged); 'f32' forces fp32
-        self.split_backward = None       # None: in data-parallel runs only.  The generator-side backward runs in two
-                                         # stages (decoder+critic, then encoder) so that the decoder half of the
-                                         # gradient all-reduce overlaps the encoder's backward pass
+        self.split_backward = None       # None: in data-parallel runs only.  The generator-side backward runs in stages
+                                         # (critic + generator, background tower, ROI tower, encoder stem) so that the
+                                         # all-reduce of each finished stage's gradient slice overlaps the next stage's
+                                         # backward pass; gradients are bit-identical to one backward pass
         self.compute_dtype = 'f32'       # 'f32' is the reference's arithmetic.  'bf16' (BASELINE configs 3-5):
                                          # activations / their gradients / filter shadows stored as bf16, bf16 matrix
                                          # pipe, fp32 accumulation, master weights, gradients and optimizer.  'bf16c':
@@ -478,6 +479,7 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         self._n_dec = sum(1 for p in self.G_flat.params if id(p) in dec_ids)        # decoder params come first
         assert all(id(p) in dec_ids for p in self.G_flat.params[:self._n_dec])
         self._enc_off = self.G_flat.offsets[self._n_dec] if self._n_dec < len(self.G_flat.params) else self.G_flat.numel
+        self._stages = self._backward_stages()
         self.g_opt, self.d_opt = get_optimizers(self.wgan_gp, self.G_flat, self.D_flat, self.g_lr, self.d_lr)
         gx = getattr(self.config, "grad_exchange", None)
         if gx is None:
@@ -601,15 +603,25 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         # thread_local: a process-group watchdog thread polling events must not invalidate the capture
         self._gg2 = None
         if self._split():
-            # two graphs for g_optim: [forward + critic/decoder backward] and [encoder backward]; the all-reduce of
-            # the decoder slice is launched between the two replays and overlaps the second one
-            with torch.cuda.graph(gg, capture_error_mode="thread_local"):
-                g_loss, embs, out_g = self._g_forward(self._static_g)
-                d_embs = self._g_backward_decoder(g_loss, embs)
-            self._gg2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self._gg2, pool=gg.pool(), capture_error_mode="thread_local"):
-                self._g_backward_encoder(embs, d_embs)
-            self._keep = (g_loss, embs, d_embs)
+            # one graph per backward stage of g_optim: [forward + critic / generator backward], then the encoder's stages (background
+            # tower, ROI tower, stem); the all-reduce of a finished stage's gradient slice is launched between two replays and runs
+            # under the next stage's kernels (collectives stay out of the captures)
+            A.CUTS = {}
+            try:
+                with torch.cuda.graph(gg, capture_error_mode="thread_local"):
+                    g_loss, embs, out_g = self._g_forward(self._static_g)
+                    d_embs = self._g_backward_decoder(g_loss, embs)
+                cuts = A.CUTS
+            finally:
+                A.CUTS = None
+            ctx = {"embs": embs, "d_embs": d_embs, "cuts": cuts}
+            self._gg2 = []
+            for st in self._stages[1:]:
+                gs = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gs, pool=gg.pool(), capture_error_mode="thread_local"):
+                    self._g_backward_stage(st[0], ctx)
+                self._gg2.append((gs, st))
+            self._keep = (g_loss, ctx)
             del g_loss, embs, d_embs
         else:
             with torch.cuda.graph(gg, capture_error_mode="thread_local"):
@@ -634,9 +646,10 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         self._feed(self._static_g, batch)
         self._graphs[0].replay()
         if self._gg2 is not None:
-            h = self.allreduce.start(self.G_flat.grad[:self._enc_off])
-            self._gg2.replay()
-            h += self.allreduce.start(self.G_flat.grad[self._enc_off:])
+            h = self.allreduce.start(self._stage_slice(self._stages[0]))
+            for gs, st in self._gg2:
+                gs.replay()
+                h += self.allreduce.start(self._stage_slice(st))
             self.g_opt.step(self.allreduce.finish(h))
         elif self._graph_update:
             self.g_opt.t += 1
@@ -695,25 +708,85 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         self.G_flat.finalize(0, self._n_dec)
         return res[0]
 
-    def _g_backward_encoder(self, embs, d_embs):
-        """Stage 2: the encoder, from the embedding gradient."""
-        enc = self.G_flat.params[self._n_dec:]
+    def _backward_stages(self):
+        """The generator-side backward as stages in completion order, each a contiguous slice of the flat gradient buffer:
+        [generator] -> [background tower] -> [ROI tower] -> [encoder stem] (the towers share only the stem, models.py:390-471; a
+        single-tower encoder has no background stage).  [(name, first param index, one past the last)]; the encoder is cut at the
+        tensors the builders record (autograd.CUTS) into the variables their TF-slim names assign to each part."""
+        n0, params = self._n_dec, self.G_flat.params
+        kinds = [models.encoder_stage_of(p.dpig_name) for p in params[n0:]]
+        stages = [("generator", 0, n0)]
+        if not kinds or any(k is None for k in kinds):
+            return stages + ([("encoder", n0, len(params))] if kinds else [])
+        runs = []
+        for i, k in enumerate(kinds):                      # creation order: stem, ROI tower, background tower -- contiguous runs
+            if runs and runs[-1][0] == k:
+                runs[-1][2] = n0 + i + 1
+            else:
+                runs.append([k, n0 + i, n0 + i + 1])
+        if sorted(r[0] for r in runs) != sorted(set(kinds)):
+            return stages + [("encoder", n0, len(params))]     # (not contiguous: one encoder stage)
+        by = {r[0]: (r[1], r[2]) for r in runs}
+        for k in ("bg", "roi", "stem"):
+            if k in by:
+                stages.append((k, by[k][0], by[k][1]))
+        return stages
+
+    def _stage_slice(self, st):
+        """The flat-gradient slice of a stage (the 16-byte alignment gaps between tensors ride along: they are zero)."""
+        _, lo, hi = st
+        off = self.G_flat.offsets
+        return self.G_flat.grad[off[lo]:(off[hi] if hi < len(off) else self.G_flat.numel)]
+
+    def _g_backward_stage(self, name, ctx):
+        """One encoder stage of the backward pass; `ctx` carries the cut tensors and the gradients that have reached them."""
+        _, lo, hi = next(s for s in self._stages if s[0] == name)
+        ps = self.G_flat.params[lo:hi]
+        cuts = ctx["cuts"].get("E.towers_in")
         with A.wgrad_overlap():
-            res = torch.autograd.grad(embs, enc, grad_outputs=d_embs, allow_unused=True)
-        self._sunk_or_copy(enc, res)
-        self.G_flat.finalize(self._n_dec, None)
+            if name == "encoder" or cuts is None:          # no finer cut available: the whole encoder from the embedding gradient
+                res = torch.autograd.grad(ctx["embs"], ps, grad_outputs=ctx["d_embs"], allow_unused=True)
+                self._sunk_or_copy(ps, res)
+            elif name in ("bg", "roi"):
+                t = cuts[1] if name == "bg" else cuts[0]
+                last_tower = name == "roi" or not any(s[0] == "roi" for s in self._stages)
+                res = torch.autograd.grad(ctx["embs"], [t] + ps, grad_outputs=ctx["d_embs"], allow_unused=True, retain_graph=not last_tower)
+                ctx["d_" + name] = res[0]
+                self._sunk_or_copy(ps, res[1:])
+            else:                                          # stem: from the towers' input gradients
+                outs = [c for c, g in zip(cuts, (ctx.get("d_roi"), ctx.get("d_bg"))) if g is not None]
+                gouts = [g for g in (ctx.get("d_roi"), ctx.get("d_bg")) if g is not None]
+                res = torch.autograd.grad(outs, ps, grad_outputs=gouts, allow_unused=True)
+                self._sunk_or_copy(ps, res)
+        if self.device.type == "cuda":
+            A.join_side_streams(self.device)               # (a tower's backward runs on its side stream: autograd.side_branch)
+        self.G_flat.finalize(lo, hi)
+
+    def _g_backward_encoder(self, embs, d_embs, cuts=None, between=None):
+        """Stages 2..: the encoder, from the embedding gradient; `between(stage)` is called after each finished stage (the
+        data-parallel exchange of its gradient slice starts there)."""
+        ctx = {"embs": embs, "d_embs": d_embs, "cuts": cuts or {}}
+        for st in self._stages[1:]:
+            self._g_backward_stage(st[0], ctx)
+            if between is not None:
+                between(st)
 
     def _g_optim_eager(self, batch, update=True):
         """sess.run(g_optim): fwd E,G,D(fake); g_loss = sce(D(G),1) + 20*L1; bwd D(dgrad only),G,E; Adam."""
-        g_loss, embs, out = self._g_forward(batch)
         if self._split():
+            A.CUTS = {}
+            try:
+                g_loss, embs, out = self._g_forward(batch)
+                cuts = A.CUTS
+            finally:
+                A.CUTS = None
             d_embs = self._g_backward_decoder(g_loss, embs)
-            h = self.allreduce.start(self.G_flat.grad[:self._enc_off]) if update else []
-            self._g_backward_encoder(embs, d_embs)
+            h = self.allreduce.start(self._stage_slice(self._stages[0])) if update else []
+            self._g_backward_encoder(embs, d_embs, cuts, between=(lambda st: h.extend(self.allreduce.start(self._stage_slice(st)))) if update else None)
             if update:
-                h += self.allreduce.start(self.G_flat.grad[self._enc_off:])
                 self.g_opt.step(self.allreduce.finish(h))
         else:
+            g_loss, embs, out = self._g_forward(batch)
             with A.wgrad_overlap():
                 g_loss.backward()
             self.D_flat.set_requires_grad(True)
