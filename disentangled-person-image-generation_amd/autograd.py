@@ -106,7 +106,10 @@ def _mark_relu_output(y, act):
 
 def _premasked(dy, y):
     """dy already carries relu'(y): it is the tagged input gradient of the residual block that consumed y."""
-    return FUSE_INPUT_MASK[0] and getattr(dy, "_dpig_masked_for", None) == y.data_ptr() and dy.shape == y.shape
+    tag = getattr(dy, "_dpig_masked_for", None)
+    # the tag is (data pointer of y, version of dy when it was tagged): an in-place accumulation of another consumer's gradient into
+    # the tagged tensor (autograd's InputBuffer may add in place) bumps the version and voids the tag
+    return FUSE_INPUT_MASK[0] and tag is not None and tag == (y.data_ptr(), dy._version) and dy.shape == y.shape
 
 
 def _sink(p, fn):
@@ -397,7 +400,7 @@ class _ResBlockFn(torch.autograd.Function):
             if ctx.x0_relu and FUSE_INPUT_MASK[0] and not torch.is_grad_enabled():
                 # x0 is a ReLU conv's output: hand its producer the gradient w.r.t. the PRE-activation (mask in this epilogue)
                 dx0 = H.conv2d_dgrad(dz1, w1, tuple(x0.shape), accum=dout, mask=x0, act=ACT_RELU)
-                dx0._dpig_masked_for = x0.data_ptr()
+                dx0._dpig_masked_for = (x0.data_ptr(), dx0._version)
             else:
                 dx0 = H.conv2d_dgrad(dz1, w1, tuple(x0.shape), accum=dout)
         return dx0, dw1, db1, dw2, db2, None
@@ -614,8 +617,16 @@ class _TiledEmbKeypointConvFn(torch.autograd.Function):
         return d_emb, None, dw, db, None, None, None
 
 
+def _keypoint_stem_ok(pose, w):
+    """What dpig_pose_stem_fwd / _wgrad take: at most 32 keypoints, output channels in quads whose count divides 256."""
+    K, P = w.shape[3], pose.shape[3]
+    return P <= 32 and K % 4 == 0 and 256 % (K // 4) == 0 and w.data_ptr() % 16 == 0
+
+
 def tiled_emb_conv(emb, pose, w, b):
     if isinstance(pose, PoseKeypoints):
+        if not _keypoint_stem_ok(pose, w):                  # (e.g. conv_hidden_num = 96): the dense map and the dense conv
+            return _mark_relu_output(_TiledEmbConvFn.apply(emb, pose.dense(), w, b), ACT_RELU)
         return _mark_relu_output(_TiledEmbKeypointConvFn.apply(emb, pose.rcv, w, b, pose.shape[1], pose.shape[2], pose.is_normalized),
                                  ACT_RELU)
     return _mark_relu_output(_TiledEmbConvFn.apply(emb, pose, w, b), ACT_RELU)

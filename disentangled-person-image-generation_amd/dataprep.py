@@ -36,10 +36,12 @@ def valid_peaks(all_peaks, subsets, variant="market"):
         "market"  datasets/convert_market.py:339-376  the selection; with no person: ALL candidates, untouched (":367 Avoid to return None")
         "utils"   utils.py:459-490                    the selection; with no person: None
         "df"      datasets/convert_DF.py:302-338      computes the selection and returns ALL candidates, untouched (:333); no person: None
-    and None whenever anything raises (a bare except), e.g. `subsets` without rows."""
+    and None whenever anything raises (a bare except), e.g. a 1-D `subsets` of scalars."""
     if variant not in ("market", "utils", "df"):
         raise ValueError("variant must be 'market', 'utils' or 'df'")
     subsets = np.asarray(subsets)
+    if subsets.size == 0:                                  # OpenPose found nobody (an empty array of any rank): `subsets.tolist()` is [],
+        return all_peaks if variant == "market" else None  # no loop iteration runs -- "market" hands back all candidates (:367)
     if subsets.ndim != 2:
         return None                                        # (`subset[-2]` of a scalar raises in the reference)
     scores = subsets[:, -2].tolist() if subsets.shape[0] else []
@@ -170,7 +172,8 @@ def pose_mask(peaks, height, width, radius=4):
 def model_inputs_from_keypoints(kp, img_H=128, img_W=64):
     """One person's geometric inputs as the records hold them: kp [18, 3] (x, y, present) ->
     dict(mask_r6 [H, W, 1] float32 in {0, 1}, part_bbox [7, 4] int64 (y1, x1, y2, x2), part_vis [7] int64)
-    (the record fields `pose_mask_r4`-style mask, `part_bbox`, `part_vis` read at trainer.py:553-560)."""
+    (the record fields `pose_mask_r6`, `part_bbox`, `part_vis` read at trainer.py:553-560).  The record key says r6 but the converter
+    fills it with `_getPoseMask(..., radius=7)` (convert_market.py:480, 499, 555-556): radius 7 here too."""
     peaks = peaks_from_array(kp)
     bbox, vis = part_bbox7(peaks, img_H=img_H, img_W=img_W)
-    return {"mask_r6": pose_mask(peaks, img_H, img_W).astype(np.float32)[..., None], "part_bbox": bbox.astype(np.int64), "part_vis": vis}
+    return {"mask_r6": pose_mask(peaks, img_H, img_W, radius=7).astype(np.float32)[..., None], "part_bbox": bbox.astype(np.int64), "part_vis": vis}

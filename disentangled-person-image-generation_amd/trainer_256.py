@@ -137,13 +137,17 @@ class DPIG_Encoder_subSampleAppNet_GAN_BodyROI_256(object):
         return d_loss.detach()
 
     def train_step(self, batch):
-        """trainer_256.py:362-373."""
+        """trainer_256.py:362-373.  `batch`: one batch, or a sequence -- every `sess.run(g_optim_embs / d_optim_embs)` of the reference
+        dequeues a fresh batch, so the mapper update and the five critic updates of a step see six batches (a single one is reused)."""
+        many = isinstance(batch, (list, tuple))
+        nxt = iter(range(10 ** 9))
+        pick = (lambda: batch[next(nxt) % len(batch)]) if many else (lambda: batch)
         out = {}
         if self.step > 0:
-            out["g_loss_embs"] = self.g_optim_embs(batch)
+            out["g_loss_embs"] = self.g_optim_embs(pick())
         iters = 1 if self.wgan_gp_encoder.MODE in ('dcgan', 'lsgan') else self.wgan_gp_encoder.CRITIC_ITERS
         for _ in range(iters):
-            out["d_loss_embs"] = self.d_optim_embs(batch)
+            out["d_loss_embs"] = self.d_optim_embs(pick())
         if self.step % self.config.lr_update_step == self.config.lr_update_step - 1:
             self.g_lr.mul_(0.5)
             self.d_lr.mul_(0.5)

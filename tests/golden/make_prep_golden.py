@@ -154,7 +154,7 @@ def encode_peaks(peaks):
 def main():
     f = reference_functions()
     kp = keypoint_cases()
-    bbox, vis, masks = [], [], []
+    bbox, vis, masks, masks7 = [], [], [], []
     for person in kp:
         peaks = to_peaks(person)
         b, v = f["get_part_bbox7"](peaks)
@@ -164,7 +164,13 @@ def main():
         m = np.asarray(m, dtype=np.float64).reshape(128, 64)
         assert set(np.unique(m).tolist()) <= {0.0, 1.0}
         masks.append(m.astype(np.uint8))
-    fix = {"keypoints": kp, "part_bbox": np.stack(bbox), "part_vis": np.stack(vis), "mask_raster_bits": np.packbits(np.stack(masks), axis=-1)}
+        # radius 7: what the converter stores under the record key `pose_mask_r6_*` (convert_market.py:480, 499, 555-556), the mask the
+        # Fg/Bg encoder consumes (trainer.py:581)
+        m7 = np.asarray(f["_getPoseMask"](peaks, 128, 64, radius=7, mode="Solid"), dtype=np.float64).reshape(128, 64)
+        assert set(np.unique(m7).tolist()) <= {0.0, 1.0}
+        masks7.append(m7.astype(np.uint8))
+    fix = {"keypoints": kp, "part_bbox": np.stack(bbox), "part_vis": np.stack(vis), "mask_raster_bits": np.packbits(np.stack(masks), axis=-1),
+           "mask_raster_r7_bits": np.packbits(np.stack(masks7), axis=-1)}
     get_part_bbox = reference_df_part_bbox()
     dkp = df_keypoint_cases()
     dbox, dvis = [], []

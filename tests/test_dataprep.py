@@ -50,6 +50,13 @@ def test_body_mask_rasterisation_equals_the_reference_builder():
     for i in range(kp.shape[0]):
         got = dataprep.pose_mask_raster(dataprep.peaks_from_array(kp[i]), 128, 64, radius=4)
         assert np.array_equal(got, ref[i]), i
+    # radius 7 = the record field `pose_mask_r6_*` (convert_market.py:480, 555-556), what model_inputs_from_keypoints builds
+    ref7 = np.unpackbits(FIX["mask_raster_r7_bits"], axis=-1)[..., :64].astype(np.float64)
+    assert ref7.sum() > ref.sum()
+    for i in range(kp.shape[0]):
+        assert np.array_equal(dataprep.pose_mask_raster(dataprep.peaks_from_array(kp[i]), 128, 64, radius=7), ref7[i]), i
+    m = dataprep.model_inputs_from_keypoints(kp[0])["mask_r6"][..., 0]
+    assert np.array_equal(m, dataprep.close5(ref7[0]).astype(np.float32))
     # the DeepFashion converter's copy of the builder (datasets/convert_DF.py:197-247) on its 256 x 256 canvas
     dkp = FIX["df_keypoints"]
     dref = np.unpackbits(FIX["df_mask_raster_bits"], axis=-1)[..., :256].astype(np.float64)
@@ -128,3 +135,15 @@ def test_synthetic_batches_follow_the_builder_conventions():
                 if k in members:
                     y1, x1, y2, x2 = kb["part_bbox"][bi, part]
                     assert y1 <= y <= y2 and x1 <= x <= x2
+
+
+def test_no_person_found_is_an_empty_subsets_array_of_any_rank():
+    """OpenPose returns an empty 1-D array when it finds nobody: the Market converter's `_get_valid_peaks` runs no loop iteration and
+    hands back every candidate (convert_market.py:367 "Avoid to return None"); the utils / DeepFashion variants return None."""
+    from dpig_amd import dataprep
+    peaks = [[(3.0, 4.0, 0.9, 0)], []] + [[] for _ in range(16)]
+    for empty in (np.zeros((0,)), np.zeros((0, 20)), []):
+        assert dataprep.valid_peaks(peaks, empty, "market") is peaks
+        assert dataprep.valid_peaks(peaks, empty, "utils") is None
+        assert dataprep.valid_peaks(peaks, empty, "df") is None
+    assert dataprep.valid_peaks(peaks, np.float64(3.0), "market") is None      # a scalar: `subset[-2]` raises in the reference

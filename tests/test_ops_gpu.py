@@ -93,6 +93,20 @@ def test_conv_epilogue_bn_statistics(dev, shape, compute):
         H.set_compute("f32")
 
 
+def test_keypoint_fed_stem_falls_back_to_the_dense_conv_for_widths_the_kernel_does_not_take(dev):
+    """conv_hidden_num = 96: K / 4 = 24 lanes per pixel does not divide 256, dpig_pose_stem_wgrad would refuse it at the first backward
+    pass -- `tiled_emb_conv` rasterises the map and runs the dense path instead (same oracle bar, forward and gradients)."""
+    from dpig_amd import autograd as A
+
+    class W(object):
+        shape = (3, 3, 38, 96)
+        def data_ptr(self): return 0
+    class P(object):
+        shape = (3, 24, 16, 18)
+    assert not A._keypoint_stem_ok(P(), W())
+    test_keypoint_fed_stem_conv_equals_the_dense_conv_on_the_rasterised_map(dev, "f32", K=96)
+
+
 def test_discriminator_uses_conv_epilogue_bn_statistics(dev):
     """DCGANDiscriminator (wgan_gp.py:407-440) in BatchNorm mode asks its convs for the statistics; on a batch large enough
     for un-split plans the fused path must give the logits (and input gradient) of the path with separate statistics passes."""
@@ -569,7 +583,7 @@ def test_act_bwd_pool2x_equals_masked_gradient_summed_over_2x2(dev, dtype):
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
-def test_keypoint_fed_stem_conv_equals_the_dense_conv_on_the_rasterised_map(dev, dtype):
+def test_keypoint_fed_stem_conv_equals_the_dense_conv_on_the_rasterised_map(dev, dtype, K=32):
     """autograd._TiledEmbKeypointConvFn (dpig_pose_stem_fwd / _wgrad): relu(conv3x3_SAME(concat([tile(emb), pose_map]), w) + b) and
     its gradients w.r.t. emb, w, b from the KEYPOINTS (trainer.py:556-560 builds pose_map from pose_rcv in the graph; utils.py:237-318),
     against the fp64 oracle's dense conv on the map `oracle.ops` rasterises from the same keypoints.  Keypoints in the corners, on the
@@ -578,7 +592,7 @@ def test_keypoint_fed_stem_conv_equals_the_dense_conv_on_the_rasterised_map(dev,
     from dpig_amd import autograd as A
     from oracle import ops as O
     g = torch.Generator().manual_seed(21)
-    B, Hh, W, E, P, K = 3, 24, 16, 20, 18, 32
+    B, Hh, W, E, P = 3, 24, 16, 20, 18
     r = torch.randint(0, Hh, (B, P), generator=g).double()
     c = torch.randint(0, W, (B, P), generator=g).double()
     v = (torch.rand(B, P, generator=g) < 0.8).double()
