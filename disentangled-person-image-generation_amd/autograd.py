@@ -14,12 +14,97 @@ from ._lib import ACT_LRELU, ACT_NONE, ACT_RELU
 # sweep would also deliver d(sum D(xhat))/dtheta into the critic's gradient slices -- a term d_loss does not contain.
 _PARAM_GRADS_OFF = [False]
 
+
+class no_param_grads(object):
+    """Context: backward passes run inside deliver no parameter gradients (input gradients only)."""
+
+    def __enter__(self):
+        self.saved = _PARAM_GRADS_OFF[0]
+        _PARAM_GRADS_OFF[0] = True
+
+    def __exit__(self, *exc):
+        _PARAM_GRADS_OFF[0] = self.saved
+        return False
+
+
 # Stage boundaries of the data-parallel backward (trainer: the gradient exchange of a finished stage runs under the next stage's
 # kernels).  A trainer sets CUTS to a dict around its forward pass; the model builders record the tensors at which the backward
 # graph can be cut and (MARKS) how many `Conv` / `fully_connected` scopes their variable scope had opened at that point -- which
 # variables, by TF-slim name, belong to which stage (models.encoder_stage_of).
 CUTS = None
 MARKS = {}
+
+
+# ---- hipGraph capture around collectives --------------------------------------------------------------------------------------------
+# A collective cannot ride inside a captured graph here (the gloo / RCCL process groups launch from their own machinery), yet the
+# cross-rank batch-norm statistics need three of them in the MIDDLE of the critic's forward and backward passes.  `SegmentedCapture`
+# captures a function as a CHAIN of graphs: wherever the function reaches an `eager_island(fn)` -- also from the autograd engine's
+# worker thread, inside a backward pass -- the running capture ends, `fn` is executed (and remembered), and a new capture begins in
+# the same memory pool.  A replay alternates graph launches and the remembered calls.  Outside a capture `eager_island(fn)` is `fn()`.
+_SEG = [None]
+
+
+def eager_island(fn):
+    seg = _SEG[0]
+    return fn() if seg is None else seg.island(fn)
+
+
+class SegmentedCapture(object):
+    def __init__(self, device, pool=None, stream=None):
+        self.device = torch.device(device)
+        self.pool = pool
+        self.stream = stream if stream is not None else torch.cuda.Stream(device=self.device)
+        self.items = []              # ("graph", CUDAGraph) | ("call", fn)
+        self.cur = None
+
+    def _begin(self):
+        self.cur = torch.cuda.CUDAGraph()
+        # relaxed: a segment may end on another thread than it began (islands reached from the autograd engine's device thread)
+        if self.pool is not None:
+            self.cur.capture_begin(pool=self.pool, capture_error_mode="relaxed")
+        else:
+            self.cur.capture_begin(capture_error_mode="relaxed")
+
+    def _end(self):
+        self.cur.capture_end()
+        self.pool = self.cur.pool()
+        self.items.append(("graph", self.cur))
+        self.cur = None
+
+    def island(self, fn):
+        self._end()
+        out = fn()
+        self.items.append(("call", fn))
+        self._begin()
+        return out
+
+    def capture(self, fn):
+        import gc
+        gc.collect()
+        torch.cuda.synchronize(self.device)
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(self.stream):
+            self._begin()
+            _SEG[0] = self
+            try:
+                out = fn()
+            finally:
+                _SEG[0] = None
+                if self.cur is not None:
+                    self._end()
+        torch.cuda.current_stream(self.device).wait_stream(self.stream)
+        return out
+
+    def replay(self):
+        for kind, x in self.items:
+            if kind == "graph":
+                x.replay()
+            else:
+                x()
+
+    @property
+    def segments(self):
+        return sum(1 for k, _ in self.items if k == "graph")
 
 
 class _CutFn(torch.autograd.Function):
@@ -750,7 +835,7 @@ class _SyncBatchNormFn(torch.autograd.Function):
     def forward(ctx, x, scale, offset, eps, act, alpha, group):
         import torch.distributed as dist
         world = dist.get_world_size(group)
-        ar = lambda t: dist.all_reduce(t, group=group)
+        ar = lambda t: eager_island(lambda: dist.all_reduce(t, group=group))     # (between two captured graphs under SegmentedCapture)
         y, mean, rstd = H.bn_sync_fwd(x, scale, offset, eps, act, alpha, ar, world)
         ctx.save_for_backward(x, scale, mean, rstd, y if act != ACT_NONE else None)
         ctx.cfg = (act, alpha, group, world)
@@ -762,7 +847,7 @@ class _SyncBatchNormFn(torch.autograd.Function):
         import torch.distributed as dist
         x, scale, mean, rstd, y = ctx.saved_tensors
         act, alpha, group, world = ctx.cfg
-        ar = lambda t: dist.all_reduce(t, group=group)
+        ar = lambda t: eager_island(lambda: dist.all_reduce(t, group=group))
         dx, dscale, doffset = H.bn_sync_bwd(dy, x, y, scale, mean, rstd, act, alpha, ar, world)
         # every rank back-propagates its LOCAL mean loss, i.e. world x its share of the global mean loss; the
         # trainer then averages parameter gradients over ranks.  dx is consistent with that convention as it is;

@@ -489,9 +489,6 @@ __device__ __forceinline__ void gg_mainloop_split(const GGParams& p, char* lds, 
         cur_tb = tap - cur_ta * p.tap_nb;
     }
     float4 ra[4], rb[4];
-#ifdef DPIG_KO_SPLITB
-    bool ko_first = true;
-#endif
     const int dma_wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     // The register-staged operand(s) and the DMA'd filter tile of the SAME k-tile are requested at different moments (below),
     // so each keeps its own (tap, channel-chunk) cursor.
@@ -519,14 +516,8 @@ __device__ __forceinline__ void gg_mainloop_split(const GGParams& p, char* lds, 
                             ((unsigned)(a_ix0[i] + t_ox) < (unsigned)p.Ws);
             ra[i] = gload4<true>(rsA, a_rowoff[i] + t_sA, ok, t_ck, p.Cs);
             if (B_DMA) continue;
-#ifdef DPIG_KO_SPLITB   // knock-out experiment: the filter operand costs nothing after the first tile (results wrong)
-            if (ko_first) {
-#endif
             if (B_ROWK) rb[i] = gload4<true>(rsB, b_off[i] + t_sB, live & b_ok[i] & t_kok, t_ck, p.Cs);
             else rb[i] = gload4<true>(rsB, b_off[i] + t_sB, live & b_ok[i] & (c0 + kgrp * 4 + i < p.Cs), 0, 4);
-#ifdef DPIG_KO_SPLITB
-            }
-#endif
         }
     };
     auto dma_b = [&](bool live, int bufn) {                 // B_DMA: four 1-KB pieces of the filter tile straight into LDS
@@ -548,14 +539,8 @@ __device__ __forceinline__ void gg_mainloop_split(const GGParams& p, char* lds, 
         for (int i = 0; i < 4; ++i) {
             const int r = (tid >> 3) + 32 * i;
             split_store4(As + r * ROWB + kq * 8, ra[i].x, ra[i].y, ra[i].z, ra[i].w);
-#ifdef DPIG_KO_SPLITB
-            if (ko_first)
-#endif
             if (B_ROWK && !B_DMA) split_store4(Bs + r * ROWB + kq * 8, rb[i].x, rb[i].y, rb[i].z, rb[i].w);
         }
-#ifdef DPIG_KO_SPLITB
-        if (ko_first)
-#endif
         if (!B_ROWK) {      // register transpose of the 4(k) x 4(n) patch -> 4 rows n of 4 consecutive k
             char* d = Bs + (nq * 4) * ROWB + split_tslot(kgrp, nq) * 8;
             split_store4(d + 0 * ROWB, rb[0].x, rb[1].x, rb[2].x, rb[3].x);
@@ -573,10 +558,6 @@ __device__ __forceinline__ void gg_mainloop_split(const GGParams& p, char* lds, 
     if (B_DMA) dma_b(true, 0);
     load_regs(true);
     store_tile(0);
-#ifdef DPIG_KO_SPLITB
-    store_tile(1);
-    ko_first = false;
-#endif
     if (B_DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (B_DMA) dma_b(kt_begin + 1 < kt_end, 1);

@@ -210,9 +210,6 @@ __device__ __forceinline__ void bg_body(const BGParams& p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wrow = (wave >> 1) * 64, wcol = (wave & 1) * 64;
     const int l31 = lane & 31, half = lane >> 5;
-#ifdef DPIG_KO_DMA
-    int ko_n = 0;
-#endif
 #ifdef DPIG_TRACE
     const bool trace_on = ((int)blockIdx.x < 256) && (blockIdx.z == 0) && (lane == 0);
     int trace_n = 0;
@@ -316,15 +313,10 @@ __device__ __forceinline__ void bg_body(const BGParams& p) {
     auto load_frag = [&](int stage, int ks, bf16x8 (&a)[2], bf16x8 (&b)[2]) {
         const char* ab = fa_base + stage * STAGE_B;
         const char* bb = fb_base + stage * STAGE_B;
-#ifdef DPIG_KO_LDS      // knock-out experiment (scripts/ubench/knockout.sh): half the fragment reads, wrong results
-        a[0] = *reinterpret_cast<const bf16x8*>(ab + so[ks]); a[1] = a[0];
-        b[0] = *reinterpret_cast<const bf16x8*>(bb + so[ks]); b[1] = b[0];
-#else
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) a[mb] = *reinterpret_cast<const bf16x8*>(ab + mb * 32 * ROWB + so[ks]);
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) b[nb] = *reinterpret_cast<const bf16x8*>(bb + nb * 32 * ROWB + so[ks]);
-#endif
     };
     // One k-tile: the first fragments are requested right behind the barrier, the DMA of the NEXT tile (address
     // arithmetic + 8 LDS-DMA instructions) is issued under their latency, the fragments of k-step ks+1 are read under the
@@ -333,33 +325,23 @@ __device__ __forceinline__ void bg_body(const BGParams& p) {
         BF_STAMP(1);
         load_frag(stage, 0, fa[0], fb[0]);
         __builtin_amdgcn_sched_barrier(0);
-#ifdef DPIG_KO_DMA      // knock-out: only the first tiles are fetched
-        if (more && ko_n++ < 1) issue(stage ^ 1);
-#else
         if (more) issue(stage ^ 1);
-#endif
         BF_STAMP(2);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             if (ks + 1 < 4) load_frag(stage, ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
             __builtin_amdgcn_sched_barrier(0);
-#ifdef DPIG_KO_MFMA     // knock-out: one MFMA instead of four per k-step
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][0] + fa[ks & 1][1], fb[ks & 1][0] + fb[ks & 1][1], acc[0][0], 0, 0, 0);
-#else
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb)
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][mb], fb[ks & 1][nb], acc[mb][nb], 0, 0, 0);
-#endif
             __builtin_amdgcn_sched_barrier(0);
         }
         BF_STAMP(3);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         BF_STAMP(4);
-#ifndef DPIG_KO_BAR     // knock-out: no workgroup barrier per k-tile (races)
         __syncthreads();
-#endif
     };
 
     BF_STAMP(0);
@@ -1367,18 +1349,9 @@ static bool wgrad_is_s1(const DpigConvDesc* d, int pt, int pl, int Ho, int Wo) {
            (xe * 2 + (long)(pt * d->W + pl) * d->ldx * 2 < 0x7fffffffL);
 }
 
-// A 3 x 3 stride-1 SAME conv on a 1 x 1 map IS the 1 x 1 conv with the filter's centre slab (contiguous in HWIO): the filter gradient
-// runs as that, the other eight slabs receive beta * dw.
-static bool wgrad_centre_tap_only(const DpigConvDesc* d) {
-    return d->H == 1 && d->W == 1 && d->R == 3 && d->S == 3 && d->stride == 1 && !d->upsample2x && (d->pad_t < 0 || d->pad_t == 1) &&
-           (d->pad_l < 0 || d->pad_l == 1);
-}
-static DpigConvDesc centre_tap_desc(const DpigConvDesc* d) {
-    DpigConvDesc c = *d;
-    c.R = c.S = 1; c.pad_t = c.pad_l = 0;
-    return c;
-}
-
+// (The filter gradient keeps all taps on such maps: with beta = 0 -- every first touch of a step -- the padding-only slabs have to be
+// written anyway, and the dense launch does that at the same cost as clearing them: measured 11 us dense vs 17 us centre slab + two
+// clears on the 1 x 1 level.)
 static size_t bf16_workspace_bytes_one(const DpigConvDesc* d, int which) {
     int pt, pl, Ho, Wo;
     if (resolve_desc(d, &pt, &pl, &Ho, &Wo) || !shape_ok(d)) return 0;
@@ -1398,7 +1371,6 @@ static size_t bf16_workspace_bytes_one(const DpigConvDesc* d, int which) {
         plan_s2(d, pt, pl, &sp);
         return sp.total;
     } else if (which == 2) {
-        if (wgrad_centre_tap_only(d)) { DpigConvDesc c = centre_tap_desc(d); return bf16_workspace_bytes_one(&c, 2); }
         const long Npix = (long)d->N * Ho * Wo * (d->upsample2x ? 4 : 1);
         const int tiles = (d->upsample2x ? 1 : d->R * d->S) * cdiv(d->C, TM) * cdiv(d->K, TN);
         Plan pln = plan_split(tiles, cdiv(Npix, TK), d->split_k, TK, kSplitPenalty);
@@ -1615,20 +1587,6 @@ static int wgrad_bf16_one(const DpigConvDesc* d, const uint16_t* x, const uint16
     if (!aligned16(x) || !aligned16(dy) || !aligned16(dw) || (ws && !aligned16(ws)))
         return fail(DPIG_EALIGN, "bf16 wgrad: pointers must be 16-byte aligned");
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (wgrad_centre_tap_only(d)) {
-        const long slab = (long)d->C * d->K;
-        if (beta == 0.f) {
-            rc = (int)hipMemsetAsync(dw, 0, 4 * slab * sizeof(float), st);
-            if (!rc) rc = (int)hipMemsetAsync(dw + 5 * slab, 0, 4 * slab * sizeof(float), st);
-            if (rc) return fail(DPIG_ELAUNCH, "wgrad: clearing the padding-only taps failed");
-        } else if (beta != 1.f) {
-            rc = dpig_axpby3d(dw, 0, 0, dw, 0, 0, 1, 1, (int)(4 * slab), beta - 1.f, stream);          // dw = (beta - 1) dw + dw
-            if (!rc) rc = dpig_axpby3d(dw + 5 * slab, 0, 0, dw + 5 * slab, 0, 0, 1, 1, (int)(4 * slab), beta - 1.f, stream);
-            if (rc) return rc;
-        }
-        const DpigConvDesc c = centre_tap_desc(d);
-        return wgrad_bf16_one(&c, x, dy, dw + 4 * slab, beta, db, beta_b, ws, ws_bytes, stream);
-    }
     BWParams p = {};
     p.X = x; p.DY = dy; p.DW = dw; p.partial = static_cast<float*>(ws);
     p.H = d->H; p.W = d->W; p.ldx = d->ldx; p.C = d->C; p.K = d->K; p.ldy = d->ldy;

@@ -76,14 +76,11 @@ struct QGeom {
 
 template <int N>
 __device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-// Knock-out builds (scripts/ubench/knockout_q.sh; dev aid, never in the shipped library, results wrong by construction):
-// DPIG_QKO_WAIT no counted vmcnt in the loop, _DMA no LDS-DMA in the loop, _LDS no fragment reads in the loop, _BAR no
-// barriers in the loop, _MFMA one MFMA per phase, _EPI no epilogue, _PRIO no s_setprio.
+// (the round-3 knock-out builds -- one ingredient of the loop compiled out at a time -- are recorded in profiles/r03_q_knockout.md;
+// their #ifdefs have been removed from the loops)
 template <int N>
 __device__ __forceinline__ void loop_wait_vm() {
-#if !defined(DPIG_QKO_WAIT) && !defined(DPIG_QKO_DMA)
     wait_vm<N>();
-#endif
 }
 
 typedef __attribute__((address_space(3))) char lds_char;
@@ -97,11 +94,7 @@ __device__ __forceinline__ void q_barrier() {
     __builtin_amdgcn_sched_barrier(0);
 }
 __device__ __forceinline__ void loop_barrier() {
-#ifdef DPIG_QKO_BAR
-    __builtin_amdgcn_sched_barrier(0);
-#else
     q_barrier();
-#endif
 }
 
 // ---- wave-private epilogue ---------------------------------------------------------------------------------------------
@@ -175,11 +168,7 @@ __device__ __forceinline__ void q_epilogue_wave(const BGParams& p, f32x16 (&acc)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += rv[e];
             }
-#ifdef DPIG_QKO_STORE
-            { const uint4 o = pack8(v); if (o.x == 0x12345678u && o.y == 0x9abcdef0u) *reinterpret_cast<uint4*>(p.D + r0 * p.ldd + col) = o; }
-#else
             *reinterpret_cast<uint4*>(p.D + r0 * p.ldd + col) = pack8(v);
-#endif
         }
     }
 }
@@ -340,35 +329,19 @@ __global__ __launch_bounds__(512, 2) void bq_kernel(const BGParams p) {
     auto mma = [&](auto MH, auto NBK, const bf16x8 (&fbv)[4]) {
         constexpr int mh = decltype(MH)::value, nb = decltype(NBK)::value;
         __builtin_amdgcn_sched_barrier(0);
-#ifndef DPIG_QKO_PRIO
         __builtin_amdgcn_s_setprio(1);
-#endif
-#ifdef DPIG_QKO_MFMA
-        acc[2 * mh][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fbv[0], fA[0][0], acc[2 * mh][nb], 0, 0, 0);
-#else
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
             for (int mbi = 0; mbi < 2; ++mbi)
                 acc[2 * mh + mbi][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fbv[ks], fA[mbi][ks], acc[2 * mh + mbi][nb], 0, 0, 0);
-#endif
-#ifndef DPIG_QKO_PRIO
         __builtin_amdgcn_s_setprio(0);
-#endif
     };
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
 
-#ifdef DPIG_QKO_LDS
-#define LRD(x) do { } while (0)
-#else
 #define LRD(x) x
-#endif
-#ifdef DPIG_QKO_DMA
-#define LDMA(x) do { } while (0)
-#else
 #define LDMA(x) x
-#endif
     QT_DECL
     // ---- prologue: k-tile 0 complete + {UA0, UB0, UB1} of k-tile 1 in flight ------------------------------------------
     enter_tap();
@@ -382,9 +355,6 @@ __global__ __launch_bounds__(512, 2) void bq_kernel(const BGParams p) {
     issueB(1, I1{});
     wait_vm<G::NA + 2 * G::NB>();
     q_barrier();
-#ifdef DPIG_QKO_LDS
-    rdB(I0{}, fB0); rdB(I1{}, fB1); rdA(I0{});
-#endif
     if (grp == 1) q_barrier();                       // stagger: this group runs one barrier behind
     for (int t = 0; t < nkt; ++t) {
         // PA: rows mh0 x all 64 columns
@@ -445,22 +415,10 @@ __global__ __launch_bounds__(512, 2) void bq_kernel(const BGParams p) {
 #endif
 
     // ---- epilogue: four passes, pass mb stages rows wr*128 + mb*32 .. +31 of every wave row ---------------------------
-#ifdef DPIG_QKO_EPI
-    if (p.M > 0) {      // keep the accumulators live, store nothing
-        float z = 0.f;
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) z += acc[i][j][0] + acc[i][j][15];
-        if (z == 1.2345e-30f) p.D[0] = 0;
-        return;
-    }
-#endif
     const bool lean = p.identity_rows && !p.res_cls && !p.replicate && p.nsplit == 1;
     const bool hr = p.res != nullptr, hm = p.mask != nullptr, h2 = p.D2 != nullptr, rpost = p.res_post != 0;
     const int kind = !lean ? 0 : ((!hr && !hm && !h2) ? 1 : ((hr && !rpost && !hm && !h2) ? 2 : ((!hr && hm && !h2) ? 3 : ((hr && rpost && !hm && h2) ? 4 : ((hr && !rpost && hm && !h2) ? 5 : 0)))));
     const float slope = (p.act == DPIG_ACT_NONE) ? 1.f : ((p.act == DPIG_ACT_RELU) ? 0.f : p.alpha);
-#ifndef DPIG_QKO_REGEPI
     if (kind) {                                                       // (workgroup-uniform) the flag combinations the models produce
         const int row_base = m0 + wr * 128, cb0 = n0 + wc * 64;
         lds_char* W = (lds_char*)smem + wave * WEP_BYTES;             // this wave's own staging rows
@@ -472,7 +430,6 @@ __global__ __launch_bounds__(512, 2) void bq_kernel(const BGParams p) {
             default: q_epilogue_wave<true, false, true, false>(p, acc, W, row_base, cb0, lane, slope); break;    // (dgrad + accum) * mask
         }
     } else
-#endif
     {
         // every other combination (class-indexed residual, 2 x 2 replication, split-K partials, ...): four passes through LDS,
         // pass mb stages the mb-th 32-pixel block of every wave as fp32 rows, then epi8 on 8 consecutive columns per thread

@@ -557,6 +557,25 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         return prefix
 
     # ---- hipGraph capture of the two optimizer ops ----------------------------------------------
+    def _sync_bn_active(self):
+        return bool(A._SYNC_BN_GROUP[0]) and self.allreduce.enabled
+
+    def _capture(self, fn, pool=None):
+        """(replayable, fn's result): one hipGraph -- or, with cross-rank batch-norm statistics, a chain of graphs with the statistics'
+        all-reduces between them (autograd.SegmentedCapture: the critic's BatchNorm layers are `eager_island`s)."""
+        if getattr(self, "_cap_stream", None) is None:
+            # ONE capture stream for every graph of this trainer: a later graph's backward pass replays nodes on the stream they
+            # were recorded on (an earlier capture's), which must be the stream being captured
+            self._cap_stream = torch.cuda.Stream(device=self.device)
+        if self._sync_bn_active():
+            seg = A.SegmentedCapture(self.device, pool=pool, stream=self._cap_stream)
+            out = seg.capture(fn)
+            return seg, out
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, pool=pool, stream=self._cap_stream, capture_error_mode="thread_local"):
+            out = fn()
+        return g, out
+
     def enable_graphs(self, batch_g, batch_d, warmup=2):
         """Capture g_optim and d_optim into hipGraphs.  Shapes are static, parameters/gradients/Adam state
         live at fixed addresses and the Adam step counter is on the device, so a replay is the whole host
@@ -599,8 +618,7 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         del snap, bsnap
         torch.cuda.synchronize(self.device)
         self._graph_update = not (self.allreduce.enabled or self._split())   # fold all-reduce + Adam into the graph?
-        gg, gd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        # thread_local: a process-group watchdog thread polling events must not invalidate the capture
+        # (capture_error_mode thread_local: a process-group watchdog thread polling events must not invalidate the capture)
         self._gg2 = None
         if self._split():
             # one graph per backward stage of g_optim: [forward + critic / generator backward], then the encoder's stages (background
@@ -608,9 +626,10 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
             # under the next stage's kernels (collectives stay out of the captures)
             A.CUTS = {}
             try:
-                with torch.cuda.graph(gg, capture_error_mode="thread_local"):
+                def stage0():
                     g_loss, embs, out_g = self._g_forward(self._static_g)
-                    d_embs = self._g_backward_decoder(g_loss, embs)
+                    return g_loss, embs, out_g, self._g_backward_decoder(g_loss, embs)
+                gg, (g_loss, embs, out_g, d_embs) = self._capture(stage0)
                 cuts = A.CUTS
             finally:
                 A.CUTS = None
@@ -618,16 +637,16 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
             self._gg2 = []
             for st in self._stages[1:]:
                 gs = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gs, pool=gg.pool(), capture_error_mode="thread_local"):
+                with torch.cuda.graph(gs, pool=gg.pool if isinstance(gg, A.SegmentedCapture) else gg.pool(), stream=self._cap_stream,
+                                      capture_error_mode="thread_local"):
                     self._g_backward_stage(st[0], ctx)
                 self._gg2.append((gs, st))
             self._keep = (g_loss, ctx)
             del g_loss, embs, d_embs
         else:
-            with torch.cuda.graph(gg, capture_error_mode="thread_local"):
-                out_g = self._g_optim_eager(self._static_g, update=self._graph_update)
-        with torch.cuda.graph(gd, pool=gg.pool(), capture_error_mode="thread_local"):
-            out_d = self._d_optim_eager(self._static_d, update=self._graph_update)
+            gg, out_g = self._capture(lambda: self._g_optim_eager(self._static_g, update=self._graph_update))
+        gd, out_d = self._capture(lambda: self._d_optim_eager(self._static_d, update=self._graph_update),
+                                  pool=gg.pool if isinstance(gg, A.SegmentedCapture) else gg.pool())
         self._graphs = (gg, out_g, gd, out_d)
         from ._lib import workspace
         workspace.pin()            # the graphs hold the workspace address: a later, larger request must not free it
@@ -799,8 +818,8 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         """sess.run(d_optim): fwd E,G (no grad), D(x), D(G); d_loss; bwd D; Adam(D)."""
         H.set_compute(getattr(self.config, "compute_dtype", "f32"))
         self.D_flat.zero_grad()
-        if (A.D_OVERLAP[0] and self.wgan_gp.MODE == 'dcgan' and batch["x"].is_cuda
-                and type(self).disc_pair is DPIG_Encoder_GAN_BodyROI_FgBg.disc_pair):
+        if (A.D_OVERLAP[0] and self.wgan_gp.MODE == 'dcgan' and batch["x"].is_cuda and not self._sync_bn_active()
+                and type(self).disc_pair is DPIG_Encoder_GAN_BodyROI_FgBg.disc_pair):        # (SyncBN's collectives cannot sit inside a forked stream of a capture)
             return self._d_optim_overlapped(batch, update)
         with torch.no_grad():
             embs, _ = self.encode(batch)

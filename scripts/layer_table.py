@@ -10,11 +10,11 @@ DT = os.environ.get('DPIG_DTYPE', 'f32')
 if os.environ.get('DPIG_WORKLOAD', 'market128') == 'df256':      # DPIG_WORKLOAD=df256 DPIG_DTYPE=bf16 python scripts/layer_table.py
     B = 8
     tr = DPIG_Encoder_GAN_BodyROI_256(Config(batch_size=B, img_H=256, img_W=256, compute_dtype=DT), dev)
-    mk = lambda seed: synthetic.to_device(synthetic.make_batch(B, img_H=256, img_W=256, seed=seed), dev)
+    mk = lambda seed: synthetic.keypoints_only(synthetic.to_device(synthetic.make_batch(B, img_H=256, img_W=256, seed=seed), dev))   # (bench.py's default: keypoint-fed stem)
 else:
     B = 16
     tr = DPIG_Encoder_GAN_BodyROI_FgBg(Config(batch_size=B, compute_dtype=DT), dev)
-    mk = lambda seed: synthetic.to_device(synthetic.make_batch(B, seed=seed), dev)
+    mk = lambda seed: synthetic.keypoints_only(synthetic.to_device(synthetic.make_batch(B, seed=seed), dev))
 b0, b1 = mk(1), mk(2)
 tr.init_net(b0); tr.step = 1
 for _ in range(2): tr.train_step(b0, b1)

@@ -369,9 +369,9 @@ def test_bf16_conv_epilogue_bn_statistics(dev, shape):
                                    (9, 2, 1, 96, 64, 3, 2)])
 def test_maps_smaller_than_the_filter_run_their_live_taps_only(dev, shape):
     """The bottom of the DeepFashion ROI tower (models.py:420-431 with repeat_num 7, trainer_256.py:40-41): 3x3 convs on 1 x 1 maps and the
-    2 x 2 -> 1 x 1 stride-2 conv.  Taps that only ever see padding are skipped (dpig_conv_plan.h::live_taps; the 1 x 1-map filter
-    gradient runs as the centre slab's 1 x 1 conv): forward (+ bias + ReLU), dgrad (* mask) and wgrad (+ bias gradient; beta 0 / 1 / 0.5,
-    untouched slabs = beta * dw) against the DENSE fp64 oracle conv on the bf16-rounded operands."""
+    2 x 2 -> 1 x 1 stride-2 conv.  Taps that only ever see padding are skipped in forward and dgrad (dpig_conv_plan.h::live_taps):
+    forward (+ bias + ReLU), dgrad (* mask), and the (dense) wgrad (+ bias gradient; beta 0 / 1 / 0.5) against the DENSE fp64 oracle
+    conv on the bf16-rounded operands."""
     import dpig_amd.hip_ops as H
     from oracle import ops as O
     N, Hh, W, C, K, k, s = shape

@@ -88,6 +88,8 @@ def test_sync_batchnorm_op_matches_full_batch():
 def _train_worker(rank, world, port, q):
     _setup(rank, world, port)
     try:
+        import faulthandler
+        faulthandler.enable()
         from dpig_amd import synthetic
         from dpig_amd.trainer import Config, DPIG_Encoder_GAN_BodyROI_FgBg
         dev = torch.device("cuda:0")
@@ -107,6 +109,10 @@ def _train_worker(rank, world, port, q):
                    D=tr.D_flat.flat.detach().cpu().numpy().copy(), G=tr.G_flat.flat.detach().cpu().numpy().copy())
         q.put((rank, res))
         dist.barrier()
+    except Exception:
+        import traceback
+        traceback.print_exc()
+        raise
     finally:
         dist.destroy_process_group()
 
@@ -119,7 +125,7 @@ def test_two_rank_step_with_sync_bn_matches_single_process(dev):
     procs = [ctx.Process(target=_train_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
-    res = dict(q.get(timeout=600) for _ in range(world))
+    res = dict(q.get(timeout=300) for _ in range(world))
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -156,3 +162,73 @@ def test_two_rank_step_with_sync_bn_matches_single_process(dev):
         lr = 2e-5
         close = (upd - upd_ref).abs() <= 0.05 * lr
         assert close.float().mean() > 0.97, (name, close.float().mean())
+
+
+def _segmented_worker(q):
+    """One process, a world-size-1 gloo group and the cross-rank batch-norm op FORCED (its three all-reduces per layer and pass are
+    then identity collectives): the trainer's optimizer ops captured as chains of hipGraphs with the collectives between them."""
+    import faulthandler
+    faulthandler.enable()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(_free_port())
+    sys.path.insert(0, ROOT)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=0, world_size=1)
+    try:
+        from dpig_amd import autograd as A
+        from dpig_amd import synthetic
+        from dpig_amd.trainer import Config, DPIG_Encoder_GAN_BodyROI_FgBg
+        dev = torch.device("cuda:0")
+        A.batchnorm = lambda x, scale, offset, eps=1e-5, act=0, alpha=0.2, stats=None: A._SyncBatchNormFn.apply(x, scale, offset, eps, act, alpha, None)
+        out = {}
+        for split in (False, True):
+            import dpig_amd.tflib as lib
+            from dpig_amd import slim
+            lib.delete_all_params(); slim.reset_scopes()
+            np.random.seed(0)
+            B = 2
+            tr = DPIG_Encoder_GAN_BodyROI_FgBg(Config(batch_size=B, conv_hidden_num=16, z_num=8, sync_bn=True, split_backward=split), dev)
+            bg = synthetic.to_device(synthetic.make_batch(B, seed=21), dev)
+            bd = synthetic.to_device(synthetic.make_batch(B, seed=22), dev)
+            tr.init_net(bg)
+            tr.step = 1
+            tr._sync_bn_active = lambda: True
+            snap = [(f.flat.clone(), f.m.clone(), f.v.clone()) for f in (tr.G_flat, tr.D_flat)]
+            e = tr.train_step(bg, bd)
+            torch.cuda.synchronize()
+            eager = (float(e["g_loss"]), float(e["d_loss"]), tr.G_flat.flat.clone(), tr.D_flat.flat.clone())
+            with torch.no_grad():
+                for f, (w, m, v) in zip((tr.G_flat, tr.D_flat), snap):
+                    f.flat.copy_(w); f.m.copy_(m); f.v.copy_(v)
+                for o in (tr.g_opt, tr.d_opt):
+                    o.state.zero_(); o.t = 0
+            tr.step = 1
+            tr.enable_graphs(bg, bd, warmup=1)
+            gg, gd = tr._graphs[0], tr._graphs[2]
+            r = tr.train_step(bg, bd)
+            torch.cuda.synchronize()
+            out[split] = dict(kind=type(gg).__name__, segments=(gg.segments, gd.segments), stages=0 if tr._gg2 is None else len(tr._gg2),
+                              same=bool(float(r["g_loss"]) == eager[0] and float(r["d_loss"]) == eager[1] and
+                                        torch.equal(tr.G_flat.flat, eager[2]) and torch.equal(tr.D_flat.flat, eager[3])))
+        q.put(out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_optimizer_ops_with_collectives_inside_replay_as_chains_of_graphs():
+    """autograd.SegmentedCapture: with cross-rank batch-norm statistics an optimizer op cannot be ONE hipGraph (the statistics' all-reduces
+    sit in the middle of the critic's forward and backward passes).  It is captured as a chain of graphs with the collectives between
+    them -- also where the collective is reached from the autograd engine's thread inside a backward pass.  g_optim: critic forward
+    (3 BN layers x 2 statistics) + backward (3 x 1) = 9 all-reduces -> 10 graphs; d_optim: two critic passes -> 19; with the staged
+    data-parallel backward the encoder's three stages follow as graphs of their own.  A replayed step equals the eager step bit for bit."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    p = ctx.Process(target=_segmented_worker, args=(q,))
+    p.start()
+    out = q.get(timeout=240)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    for split in (False, True):
+        o = out[split]
+        assert o["kind"] == "SegmentedCapture" and o["segments"] == (10, 19), o
+        assert o["stages"] == (3 if split else 0) and o["same"], o
