@@ -288,6 +288,13 @@ def _sink_wgrad_bias(w, b, x, dz, stride=1, upsample2x=False, want_w=True, want_
     return dw, db
 
 
+def _first_touch_out(p):
+    """The flat-gradient slice of `p` when a kernel may write its gradient there directly (registered and not yet touched this step);
+    `_sink_small` then only marks it."""
+    buf = getattr(p, "_dpig_grad", None)
+    return buf if (buf is not None and not p._dpig_touched[0]) else None
+
+
 def _sink_small(p, g):
     """Same contract as _sink for tiny per-channel gradients that a kernel already produced."""
     buf = getattr(p, "_dpig_grad", None)
@@ -296,7 +303,7 @@ def _sink_small(p, g):
     touched = p._dpig_touched
     if touched[0]:
         buf.add_(g.view_as(buf))
-    else:
+    elif g.data_ptr() != buf.data_ptr():           # (the kernel may have written the slice itself: _first_touch_out)
         buf.copy_(g.view_as(buf))
     touched[0] = True
     return None
@@ -817,8 +824,11 @@ class _BatchNormFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, scale, mean, rstd, y = ctx.saved_tensors
         act, alpha = ctx.cfg
-        dx, dscale, doffset = H.bn_bwd(dy, x, y, scale, mean, rstd, act, alpha)
-        if _PARAM_GRADS_OFF[0]:
+        off = _PARAM_GRADS_OFF[0]
+        dx, dscale, doffset = H.bn_bwd(dy, x, y, scale, mean, rstd, act, alpha,
+                                       dscale_out=None if off or not ctx.needs_input_grad[1] else _first_touch_out(scale),
+                                       doffset_out=None if off or not ctx.needs_input_grad[2] else _first_touch_out(ctx.offset_ref))
+        if off:
             return dx, None, None, None, None, None, None
         ds = _sink_small(scale, dscale) if ctx.needs_input_grad[1] else None
         do = _sink_small(ctx.offset_ref, doffset) if ctx.needs_input_grad[2] else None
@@ -942,7 +952,9 @@ class _LayerNormFn(torch.autograd.Function):
                 return dx, None, None, None, None, None
             _, dscale, doffset = H.ln_bwd(dy.detach(), x, y, scale, mean, rstd, act, alpha)
         else:
-            dx, dscale, doffset = H.ln_bwd(dy, x, y, scale, mean, rstd, act, alpha)
+            dx, dscale, doffset = H.ln_bwd(dy, x, y, scale, mean, rstd, act, alpha,
+                                           dscale_out=_first_touch_out(scale) if ctx.needs_input_grad[1] else None,
+                                           doffset_out=_first_touch_out(ctx.offset_ref) if ctx.needs_input_grad[2] else None)
         ds = _sink_small(scale, dscale) if ctx.needs_input_grad[1] else None
         do = _sink_small(ctx.offset_ref, doffset) if ctx.needs_input_grad[2] else None
         return dx, ds, do, None, None, None

@@ -90,21 +90,23 @@ struct Geo {          // a sample of L elements in nch chunks of CH (the last on
 };
 __device__ __forceinline__ int chan(const Geo& g, long i) { return g.cmask ? (int)(i & g.cmask) : (int)(i % g.C); }
 
-// mean / biased variance of sample n from its chunks' (sum, M2): exact pairwise merge in chunk order
+// mean / biased variance of sample n from its chunks' (sum, M2): exact pairwise merge in chunk order.  fp32 with one reciprocal per
+// chunk (every thread of every workgroup of the sample runs this loop: fp64 divisions here cost 35 us per launch at 64 chunks); all chunks
+// but the last hold CH elements, so the running count is j * CH.
 __device__ __forceinline__ void merge_stats(const float* __restrict__ part, const Geo& g, int n, float* mean, float* var) {
     const float* p = part + (long)n * g.nch * 2;
-    double cnt = 0.0, mu = 0.0, m2 = 0.0;
+    float cnt = 0.f, mu = 0.f, m2 = 0.f;
     for (int j = 0; j < g.nch; ++j) {
         const long left = g.L - (long)j * g.CH;
-        const double nb = (double)(left < g.CH ? left : g.CH);
-        const double mb = (double)p[2 * j] / nb, qb = (double)p[2 * j + 1];
-        const double tot = cnt + nb, d = mb - mu;
-        mu += d * (nb / tot);
-        m2 += qb + d * d * (cnt * nb / tot);
+        const float nb = (float)(left < g.CH ? left : g.CH);
+        const float tot = cnt + nb, rtot = 1.0f / tot;
+        const float mb = p[2 * j] * (1.0f / nb), d = mb - mu;
+        mu += d * (nb * rtot);
+        m2 += p[2 * j + 1] + d * d * (cnt * nb * rtot);
         cnt = tot;
     }
-    *mean = (float)mu;
-    *var = (float)(m2 / cnt);
+    *mean = mu;
+    *var = m2 / cnt;
 }
 template <int NS>
 __device__ __forceinline__ void merge_sums(const float* __restrict__ part, const Geo& g, int n, float (&s)[NS]) {
@@ -229,53 +231,70 @@ __global__ __launch_bounds__(NT) void ln_bwd_apply_kernel(const T* __restrict__ 
 }
 
 // per-channel parameter gradients: doffset[c] = sum dz, dscale[c] = sum dz * xh over all samples and pixels.
-// partial [slab][2][C]; a workgroup = 64 channels x 4 row groups, rows strided by the slab count (fixed order).
-template <typename T>
+// partial [slab][2][C]; a workgroup = 128 channels (V per thread) x row groups, rows strided by the slab count (fixed order).
+template <typename T, int V>
 __global__ __launch_bounds__(NT) void ln_param_partial_kernel(const T* __restrict__ dy, const T* __restrict__ x, const T* __restrict__ y,
                                                               const float* __restrict__ mean, const float* __restrict__ rstd, long rows,
                                                               int C, int P, int act, float alpha, float* __restrict__ partial) {
-    __shared__ float red[2][4][64];
-    const int cl = threadIdx.x & 63, rg = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
-    float s0 = 0.f, s1 = 0.f;
-    if (c < C) {
-        for (long r = (long)blockIdx.y * 4 + rg; r < rows; r += (long)gridDim.y * 4) {
+    constexpr int LPR = 128 / V, RG = NT / LPR;            // lanes per row of 128 channels, row groups
+    __shared__ float red[2][RG][128 + 4];
+    const int cg = threadIdx.x % LPR, rg = threadIdx.x / LPR;
+    const int c0 = blockIdx.x * 128 + cg * V;
+    float s0[V], s1[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) { s0[e] = 0.f; s1[e] = 0.f; }
+    if (c0 < C) {
+        for (long r = (long)blockIdx.y * RG + rg; r < rows; r += (long)gridDim.y * RG) {
             const long n = r / P;
-            float d[1], xv[1], yv[1];
-            ldv<1>(dy, r * C + c, d);
-            ldv<1>(x, r * C + c, xv);
-            float dz = d[0];
-            if (act != DPIG_ACT_NONE) { ldv<1>(y, r * C + c, yv); dz *= act_grad(yv[0], act, alpha); }
-            s0 += dz;
-            s1 += dz * (xv[0] - mean[n]) * rstd[n];
+            const float mu = mean[n], rs = rstd[n];
+            float d[V], xv[V], yv[V];
+            ldv<V>(dy, r * C + c0, d);
+            ldv<V>(x, r * C + c0, xv);
+            if (act != DPIG_ACT_NONE) ldv<V>(y, r * C + c0, yv);
+#pragma unroll
+            for (int e = 0; e < V; ++e) {
+                if (V > 1 || c0 + e < C) {
+                    const float dz = (act != DPIG_ACT_NONE) ? d[e] * act_grad(yv[e], act, alpha) : d[e];
+                    s0[e] += dz;
+                    s1[e] += dz * (xv[e] - mu) * rs;
+                }
+            }
         }
     }
-    red[0][rg][cl] = s0;
-    red[1][rg][cl] = s1;
-    __syncthreads();
-    if (rg == 0 && c < C) {
 #pragma unroll
-        for (int o = 0; o < 2; ++o)
-            partial[((long)blockIdx.y * 2 + o) * C + c] = (red[o][0][cl] + red[o][1][cl]) + (red[o][2][cl] + red[o][3][cl]);
+    for (int e = 0; e < V; ++e) { red[0][rg][cg * V + e] = s0[e]; red[1][rg][cg * V + e] = s1[e]; }
+    __syncthreads();
+    if (threadIdx.x < 128 && blockIdx.x * 128 + (int)threadIdx.x < C) {
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+            float t = 0.f;
+#pragma unroll
+            for (int q = 0; q < RG; ++q) t += red[o][q][threadIdx.x];
+            partial[((long)blockIdx.y * 2 + o) * C + blockIdx.x * 128 + threadIdx.x] = t;
+        }
     }
 }
-// out_o[c] = sum over slabs of partial[slab][o][c], o = 0 -> out0, 1 -> out1 (fixed order)
+// out_o[c] = sum over slabs of partial[slab][o][c], o = 0 -> out0, 1 -> out1.  16 channels x 16 slab groups per workgroup (a short
+// dependent-load chain per thread), the group sums added in group order: deterministic.
 __global__ __launch_bounds__(NT) void ln_param_final_kernel(const float* __restrict__ partial, int nslab, int C, float* __restrict__ out0,
                                                             float* __restrict__ out1) {
-    __shared__ float red[2][4][64];
-    const int cl = threadIdx.x & 63, gq = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    __shared__ float red[2][16][16];
+    const int cl = threadIdx.x & 15, gq = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
 #pragma unroll
     for (int o = 0; o < 2; ++o) {
-        float s = 0.f;
+        float sum = 0.f;
         if (c < C)
-            for (int b = gq; b < nslab; b += 4) s += partial[((long)b * 2 + o) * C + c];
-        red[o][gq][cl] = s;
+            for (int b = gq; b < nslab; b += 16) sum += partial[((long)b * 2 + o) * C + c];
+        red[o][gq][cl] = sum;
     }
     __syncthreads();
     if (gq != 0 || c >= C) return;
-    out0[c] = (red[0][0][cl] + red[0][1][cl]) + (red[0][2][cl] + red[0][3][cl]);
-    out1[c] = (red[1][0][cl] + red[1][1][cl]) + (red[1][2][cl] + red[1][3][cl]);
+    float t0 = 0.f, t1 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) { t0 += red[0][q][cl]; t1 += red[1][q][cl]; }
+    out0[c] = t0;
+    out1[c] = t1;
 }
 
 // ---- second order: the backward of ln_bwd.  With g = dz * gamma, dx = r (g - mean(g) - xh mean(g xh)) and
@@ -492,24 +511,26 @@ __global__ __launch_bounds__(NT) void bn16_partial_kernel(const bf16_t* __restri
         }
     }
 }
-// FIN 0: out_o[c] = scale * sum_slab partial[slab][o][c];  FIN 1: out_0[c] = 1 / sqrt(scale * sum + eps).  A block = 64 channels x 4 slab
-// groups (group g takes slabs g, g + 4, ...; the four group sums are added in group order: deterministic)
+// FIN 0: out_o[c] = scale * sum_slab partial[slab][o][c];  FIN 1: out_0[c] = 1 / sqrt(scale * sum + eps).  A block = 16 channels x 16 slab
+// groups (group g takes slabs g, g + 16, ...; the group sums are added in group order: deterministic)
 template <int FIN>
 __global__ __launch_bounds__(NT) void bn16_final_kernel(const float* __restrict__ partial, int nslab, int nout, int C, float* __restrict__ out0,
                                                         float* __restrict__ out1, float scale, float eps) {
-    __shared__ float red[2][4][64];
-    const int cl = threadIdx.x & 63, gq = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    __shared__ float red[2][16][16];
+    const int cl = threadIdx.x & 15, gq = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     for (int o = 0; o < nout; ++o) {
         float sum = 0.f;
         if (c < C)
-            for (int b = gq; b < nslab; b += 4) sum += partial[((long)b * nout + o) * C + c];
+            for (int b = gq; b < nslab; b += 16) sum += partial[((long)b * nout + o) * C + c];
         red[o][gq][cl] = sum;
     }
     __syncthreads();
     if (gq != 0 || c >= C) return;
     for (int o = 0; o < nout; ++o) {
-        const float t = (red[o][0][cl] + red[o][1][cl]) + (red[o][2][cl] + red[o][3][cl]);
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += red[o][q][cl];
         float* out = o == 0 ? out0 : out1;
         if (FIN == 1) out[c] = 1.0f / sqrtf(t * scale + eps);
         else out[c] = t * scale;
@@ -674,9 +695,14 @@ static int ln_bwd_impl(const T* dy, const T* x, const T* y, int N, int P, int C,
     float* ppart = reinterpret_cast<float*>(static_cast<char*>(ws) + up256((size_t)N * g.nch * 2 * sizeof(float)));
     if (dscale) {
         const int nslab = param_slabs(rows);
-        hipLaunchKernelGGL((ln_param_partial_kernel<T>), dim3((C + 63) / 64, nslab), dim3(NT), 0, st, dy, x, y, save_mean, save_rstd, rows, C,
-                           P, act, alpha, ppart);
-        hipLaunchKernelGGL(ln_param_final_kernel, dim3((C + 63) / 64), dim3(NT), 0, st, ppart, nslab, C, doffset, dscale);
+        constexpr int VP = vec_width<T>();
+        if (C % VP == 0 && aligned16(dy) && aligned16(x) && (act == DPIG_ACT_NONE || aligned16(y)))
+            hipLaunchKernelGGL((ln_param_partial_kernel<T, VP>), dim3((C + 127) / 128, nslab), dim3(NT), 0, st, dy, x, y, save_mean, save_rstd,
+                               rows, C, P, act, alpha, ppart);
+        else
+            hipLaunchKernelGGL((ln_param_partial_kernel<T, 1>), dim3((C + 127) / 128, nslab), dim3(NT), 0, st, dy, x, y, save_mean, save_rstd,
+                               rows, C, P, act, alpha, ppart);
+        hipLaunchKernelGGL(ln_param_final_kernel, dim3((C + 15) / 16), dim3(NT), 0, st, ppart, nslab, C, doffset, dscale);
     }
     constexpr int V = vec_width<T>();
     const dim3 grid(N * g.nch), block(NT);
@@ -829,7 +855,7 @@ extern "C" int dpig_bn_fwd_bf16(const uint16_t* x, int ldx, int64_t rows, int C,
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int nslab = bn16_slabs(rows);
     float* partial = static_cast<float*>(ws);
-    const dim3 g1((C + 127) / 128, nslab), g2((C + 63) / 64);
+    const dim3 g1((C + 127) / 128, nslab), g2((C + 15) / 16);
     hipLaunchKernelGGL((bn16_partial_kernel<0>), g1, dim3(NT), 0, st, x, ldx, (const bf16_t*)nullptr, 0, (const bf16_t*)nullptr, 0,
                        (const float*)nullptr, (const float*)nullptr, (long)rows, C, 0, 0.f, partial);
     hipLaunchKernelGGL((bn16_final_kernel<0>), g2, dim3(NT), 0, st, partial, nslab, 1, C, save_mean, (float*)nullptr, 1.0f / (float)rows, 0.f);
@@ -857,7 +883,7 @@ extern "C" int dpig_bn_bwd_bf16(const uint16_t* dy, int lddy, const uint16_t* x,
     float* partial = static_cast<float*>(ws);
     hipLaunchKernelGGL((bn16_partial_kernel<2>), dim3((C + 127) / 128, nslab), dim3(NT), 0, st, dy, lddy, x, ldx, y, ldy, save_mean, save_rstd,
                        (long)rows, C, act, alpha, partial);
-    hipLaunchKernelGGL((bn16_final_kernel<0>), dim3((C + 63) / 64), dim3(NT), 0, st, partial, nslab, 2, C, doffset, dscale, 1.0f, 0.f);
+    hipLaunchKernelGGL((bn16_final_kernel<0>), dim3((C + 15) / 16), dim3(NT), 0, st, partial, nslab, 2, C, doffset, dscale, 1.0f, 0.f);
     const dim3 grid(bn16_grid(rows * (C / 8)));
     if (NT % (C / 8) == 0) hipLaunchKernelGGL((bn16_bwd_apply_kernel<true>), grid, dim3(NT), 0, st, dy, lddy, x, ldx, y, ldy, (long)rows, C, scale,
                                               save_mean, save_rstd, dscale, doffset, act, alpha, 1.0f / (float)rows, dx, lddx);

@@ -940,7 +940,14 @@ def bn_fwd(x, scale, offset, eps=1e-5, act=ACT_NONE, alpha=0.2, stats=None):
     return y, mean, rstd
 
 
-def bn_bwd(dy, x, y, scale, mean, rstd, act=ACT_NONE, alpha=0.2):
+def _param_out(buf, C, device):
+    """The [C] fp32 output of a parameter-gradient kernel: the caller's buffer (a slice of a flat gradient buffer) or a new tensor."""
+    if buf is not None and buf.dtype == F32 and buf.numel() == C and buf.is_contiguous() and buf.is_cuda:
+        return buf.view(C)
+    return torch.empty(C, dtype=torch.float32, device=device)
+
+
+def bn_bwd(dy, x, y, scale, mean, rstd, act=ACT_NONE, alpha=0.2, dscale_out=None, doffset_out=None):
     if BF16 in (dy.dtype, x.dtype) or (y is not None and y.dtype == BF16):
         if BN_BF16_NATIVE[0] and x.dtype == BF16 and x.shape[-1] % 8 == 0:
             dyb, rows, C, lddy = _rows_ld(to_bf16(dy))
@@ -950,13 +957,12 @@ def bn_bwd(dy, x, y, scale, mean, rstd, act=ACT_NONE, alpha=0.2):
                 yb, _, _, ldy = _rows_ld(to_bf16(y))
             if lddy % 8 == 0 and ldx % 8 == 0 and ldy % 8 == 0 and _al16(dyb, xb, yb):
                 dx = torch.empty(xb.shape, dtype=BF16, device=x.device)
-                dscale = torch.empty(C, dtype=torch.float32, device=x.device)
-                doffset = torch.empty(C, dtype=torch.float32, device=x.device)
+                dscale, doffset = _param_out(dscale_out, C, x.device), _param_out(doffset_out, C, x.device)
                 wsb, wsn = workspace.get(lib().dpig_bn_bf16_workspace_bytes(rows, C), x.device)
                 check(lib().dpig_bn_bwd_bf16(ptr(dyb), lddy, ptr(xb), ldx, ptr(yb), ldy, rows, C, ptr(scale.contiguous()), ptr(mean), ptr(rstd),
                                              act, alpha, ptr(dx), C, ptr(dscale), ptr(doffset), ptr(wsb), wsn, stream_ptr()), "bn_bwd_bf16")
                 return dx, dscale, doffset
-        dx, dscale, doffset = bn_bwd(to_f32(dy), to_f32(x), to_f32(y), scale, mean, rstd, act, alpha)
+        dx, dscale, doffset = bn_bwd(to_f32(dy), to_f32(x), to_f32(y), scale, mean, rstd, act, alpha, dscale_out, doffset_out)
         return _like_input(dx, x), dscale, doffset
     _require_gpu(dy)
     dy, rows, C, lddy = _rows_ld(dy)
@@ -965,8 +971,7 @@ def bn_bwd(dy, x, y, scale, mean, rstd, act=ACT_NONE, alpha=0.2):
     if y is not None:
         y, _, _, ldy = _rows_ld(y)
     dx = torch.empty(x.shape, dtype=torch.float32, device=x.device)
-    dscale = torch.empty(C, dtype=torch.float32, device=x.device)
-    doffset = torch.empty(C, dtype=torch.float32, device=x.device)
+    dscale, doffset = _param_out(dscale_out, C, x.device), _param_out(doffset_out, C, x.device)
     wsb, wsn = workspace.get(lib().dpig_bn_workspace_bytes(rows, C), x.device)
     check(lib().dpig_bn_bwd(ptr(dy), lddy, ptr(x), ldx, ptr(y), ldy, rows, C, ptr(scale.contiguous()), ptr(mean),
                             ptr(rstd), act, alpha, ptr(dx), C, ptr(dscale), ptr(doffset), ptr(wsb), wsn,
@@ -1046,15 +1051,15 @@ def ln_fwd(x, scale, offset, eps=1e-5, act=ACT_NONE, alpha=0.2):
     return y, mean, rstd
 
 
-def ln_bwd(dy, x, y, scale, mean, rstd, act=ACT_NONE, alpha=0.2, want_params=True):
+def ln_bwd(dy, x, y, scale, mean, rstd, act=ACT_NONE, alpha=0.2, want_params=True, dscale_out=None, doffset_out=None):
     """(dx, dscale, doffset); the parameter gradients are skipped (None) with want_params=False."""
     _require_dev(dy)
     bf, (x, dy, y) = _ln_same_type(x, dy, y)
     N, C = x.shape[0], x.shape[-1]
     P = x.numel() // (N * C)
     dx = torch.empty_like(x)
-    dscale = torch.empty(C, dtype=torch.float32, device=x.device) if want_params else None
-    doffset = torch.empty(C, dtype=torch.float32, device=x.device) if want_params else None
+    dscale = _param_out(dscale_out, C, x.device) if want_params else None
+    doffset = _param_out(doffset_out, C, x.device) if want_params else None
     wsb, wsn = workspace.get(lib().dpig_ln_workspace_bytes(N, P, C), x.device)
     fn = lib().dpig_ln_bwd_bf16 if bf else lib().dpig_ln_bwd
     check(fn(ptr(dy), ptr(x), ptr(y), N, P, C, ptr(scale.contiguous()), ptr(mean), ptr(rstd), act, alpha, ptr(dx), ptr(dscale),

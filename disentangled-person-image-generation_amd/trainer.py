@@ -654,6 +654,11 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
             self.g_opt.t -= 1          # capturing recorded one step() each without executing it
             self.d_opt.t -= 1
 
+    def static_batches(self):
+        """(g_optim's, d_optim's) input buffers of the captured graphs: a producer that writes the next batch INTO them (a prefetcher's
+        device slot, bench.py's resident synthetic batches) and passes them back to `train_step` feeds the replay without a copy."""
+        return self._static_g, self._static_d
+
     def _feed(self, static, batch):
         for k, v in batch.items():
             if static[k].data_ptr() != v.data_ptr():

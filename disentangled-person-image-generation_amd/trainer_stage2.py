@@ -169,6 +169,10 @@ class DPIG_Encoder_subSampleAppNetFgBg_GAN_BodyROI(object):
         self._graphs = graphs
         workspace.pin()
 
+    def static_batch(self):
+        """The captured graphs' input buffers: a producer that fills them and passes them to `train_step` feeds the replay without a copy."""
+        return self._static
+
     def _feed(self, batch):
         for k, v in batch.items():
             if self._static[k].data_ptr() != v.data_ptr():
