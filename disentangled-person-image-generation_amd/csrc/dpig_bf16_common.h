@@ -49,6 +49,7 @@ struct BGParams {
     unsigned a_bytes, b_bytes;
     unsigned mul_hrwr, shr_hrwr, mul_wr, shr_wr;
     int tiles_x, tiles_y;  // bh_kernel: 2-D output patches per image
+    int halo128;           // host hint for the tile-family choice: the 128 x 128 family would run this layer on its halo-patch kernel
 };
 
 __device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned shr) {

@@ -1281,11 +1281,12 @@ static int launch_bg(BGParams& p, int nimg, long filter_elems, hipStream_t st) {
     int tx = 0, ty = 0;
     if (p.stats && (p.nsplit != 1 || !p.identity_rows || p.replicate || !aligned16(p.stats)))
         return fail(DPIG_EINVAL, "bf16 conv fwd with BN statistics needs an un-split plan");
+    const int twl = p.stats ? 0 : halo_plan(p, nimg, &tx, &ty);
     {
+        p.halo128 = twl != 0;
         const int q = bq_try(p, st);             // large layers: 8-wave 256 x 256 / 512 x 128 tiles (dpig_conv_bf16_q.hip)
         if (q) return q < 0 ? q : DPIG_OK;
     }
-    const int twl = p.stats ? 0 : halo_plan(p, nimg, &tx, &ty);
     if (twl) {
         p.tiles_x = tx; p.tiles_y = ty;
         p.mtiles = nimg * tx * ty;

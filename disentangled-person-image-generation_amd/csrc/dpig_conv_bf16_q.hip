@@ -899,6 +899,7 @@ static void q_init() {
 }
 
 static int g_q_halo = []() { const char* e = getenv("DPIG_BF16_QH"); return e ? atoi(e) : 1; }();     // halo-staged variant (A/B switch)
+static int g_q_nohalo_bonus = []() { const char* e = getenv("DPIG_BF16_Q_NOHALO"); return e ? atoi(e) : 1; }();   // (A/B switch of the hint below)
 // 3 x 3 stride-1 window (forward / flipped-tap dgrad) on whole 16 x 16 regions with one of the five fused epilogues
 static bool bhq_eligible(const BGParams& p) {
     if (p.ntaps != 9 || p.tap_nb != 3 || p.sr != 1 || !p.identity_rows || p.replicate || p.res_cls || p.stats) return false;
@@ -938,7 +939,9 @@ int bq_try(BGParams& p, hipStream_t st) {
     int variant = g_q_variant ? g_q_variant : (e2 > e1 ? 2 : 1);
     if (g_q_mode == 1) {
         if (p.nsplit > 1) return 0;                      // the split-K plan of the 128 x 128 family wins on small layers
-        const double e0 = q_eff(p.M, p.Ncols, 128, 128, 2 * kNumCU);
+        // the 128 x 128 family's tap-major kernel (layers its halo-patch kernel does not take: 12 x 12 / 6 x 6 maps, stride 2, 5 x 5) runs at
+        // ~0.7 of the halo-patch kernel's rate (profiles/r03_conv_bf16_tile_ab.txt: 24 x 24 C256 736 vs 1148 TFLOP/s on the 256 x 256 tile)
+        const double e0 = q_eff(p.M, p.Ncols, 128, 128, 2 * kNumCU) * ((p.halo128 || !g_q_nohalo_bonus) ? 1.0 : 0.72);
         if ((variant == 1 ? e1 : e2) < e0 * g_q_mineff) return 0;
         if (variant == 2 && p.Ncols <= 128 && q_eff(p.M, p.Ncols, 512, 128, kNumCU) < 0.95) return 0;   // 128-column layers: only on full rounds
     }
