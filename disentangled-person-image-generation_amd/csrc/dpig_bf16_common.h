@@ -2,6 +2,7 @@
 // the 8-wave 256 x 256 / 512 x 128 "8-phase" kernels): operand types, the gather-GEMM parameter block, LDS-DMA and
 // bf16 pack / unpack helpers, and the fused epilogue on 8 consecutive columns of one GEMM row.
 #pragma once
+#include <cstdlib>
 #include "dpig_common.h"
 
 namespace dpig {
@@ -22,7 +23,11 @@ constexpr int STATS_RED_BYTES = 16 * TN * 4;                 // scratch of the B
 constexpr int SMEM_BYTES = TM * LDC * 4 + STATS_RED_BYTES;   // 67584 (>= 2 stages = 65536) + 8192; 2 workgroups per CU = 148 KB of 160 KB
 constexpr unsigned OOB = 0x7fffffffu;
 // split-K partial sums cost relatively more than on the fp32 pipe (the products are ~8x faster, HBM is not)
-constexpr double kSplitPenalty = 700.0;
+static inline double split_penalty_bf16() {
+    static const double v = getenv("DPIG_BF16_SPLIT_PEN") ? atof(getenv("DPIG_BF16_SPLIT_PEN")) : 700.0;
+    return v;
+}
+#define kSplitPenalty split_penalty_bf16()
 
 struct BGParams {
     const bf16_t* A;      // gathered source activation (x for fwd, dy for dgrad)

@@ -1879,7 +1879,8 @@ static int gg_bk(const DpigConvDesc* d, int lda, int Cs, int Ncols) {
 // faster than the exact fp32 one while the fp32 partials cost the same, so splitting pays later there.
 static double split_pen(const DpigConvDesc* d) {
     static const double x3 = getenv("DPIG_X3_SPLIT_PEN") ? atof(getenv("DPIG_X3_SPLIT_PEN")) : 120.0;
-    return d->compute == DPIG_COMPUTE_BF16X3 ? x3 : 120.0;
+    static const double f32 = getenv("DPIG_F32_SPLIT_PEN") ? atof(getenv("DPIG_F32_SPLIT_PEN")) : 120.0;
+    return d->compute == DPIG_COMPUTE_BF16X3 ? x3 : f32;
 }
 // matrix pipe of the GEMM loop (the PIPE template argument): the bf16 and split-bf16 loops need the same shape; the split
 // loop keeps the fp32 loop's k-tile, so every plan / workspace size of the exact path holds for it
