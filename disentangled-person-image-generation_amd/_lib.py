@@ -62,6 +62,7 @@ SYMBOLS = {
     "dpig_conv2d_wgrad_bf16": (_i, [_dp, _vp, _vp, _vp, _f, _vp, _f, _vp, _sz, _vp]),
     "dpig_conv_bf16_set_large_tile": (_i, [_i, _i]),
     "dpig_conv_bf16_set_large_tile_wgrad": (_i, [_i, _i]),
+    "dpig_conv_bf16_set_wave8": (_i, [_i]),
     "dpig_conv2d_fwd_thin_bf16": (_i, [_dp, _vp, _vp, _vp, _vp, _vp]),
     "dpig_conv2d_dgrad_thin_bf16": (_i, [_dp, _vp, _vp, _vp, _vp]),
     "dpig_conv2d_wgrad_thin_bf16": (_i, [_dp, _vp, _vp, _vp, _f, _vp, _f, _vp, _sz, _vp]),

@@ -47,16 +47,19 @@ namespace bfk {
 // ---- epilogue shared by the k-loop variants: accumulators -> LDS (fp32) -> 16-byte row-contiguous global accesses ----
 // `rowof(rl)` maps tile row rl (0..127) to the GEMM row it holds, or -1 when the tile row is padding: m0 + rl for the
 // linear row tiles of bg_kernel, the NHW pixel index of the 2-D patch position for the halo tiles of bh_kernel.
-template <typename RowOf>
-__device__ __forceinline__ void bg_epilogue(const BGParams& p, char* smem, f32x16 (&acc)[2][2], int m0, int n0, int split,
+// NB = 32-column blocks of a wave's sub-tile (2: four waves of 64 x 64; 1: eight waves of 64 x 32), RG = row groups of the
+// workgroup's store pass (threads / 16).
+template <int NB, int RG, typename RowOf>
+__device__ __forceinline__ void bg_epilogue(const BGParams& p, char* smem, f32x16 (&acc)[2][NB], int m0, int n0, int split,
                                             int tid, int wrow, int wcol, int l31, int half, RowOf rowof) {
+    constexpr int NIT = TM / RG;                 // rows a thread stores
     float* Cs = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
         for (int r = 0; r < 16; ++r)
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
+            for (int nb = 0; nb < NB; ++nb)
                 Cs[(wrow + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * LDC + wcol + nb * 32 + l31] = acc[mb][nb][r];
     __syncthreads();
 
@@ -68,7 +71,7 @@ __device__ __forceinline__ void bg_epilogue(const BGParams& p, char* smem, f32x1
     // read the bf16 tensor, see exactly the mean and variance of what they normalise -- and the fallback that takes the
     // statistics from the stored tensor (split-K plans, multi-run batches) agrees with this path.  Only set by
     // dpig_conv2d_fwd_bf16_stats: un-split bg_kernel launch, rows m0 .. m0 + 127 are pixels m0 .. (every thread takes part).
-    if (p.stats) {
+    if (RG == 16 && p.stats) {                       // (the host launches the statistics epilogue on the four-wave kernel only)
         const bool cok = col < p.Ncols;
         const int nrows = min(TM, p.M - m0);
         float b8[8];
@@ -118,10 +121,10 @@ __device__ __forceinline__ void bg_epilogue(const BGParams& p, char* smem, f32x1
     if (p.nsplit > 1) {
         float* pp = p.partial + ((long)split * p.M + m0 + rl0) * p.Ncols + col;
 #pragma unroll 4
-        for (int it = 0; it < 8; ++it) {
-            if (m0 + rl0 + 16 * it < p.M) {
-                *reinterpret_cast<float4*>(pp + (long)(16 * it) * p.Ncols) = *reinterpret_cast<const float4*>(&Cs[(rl0 + 16 * it) * LDC + c]);
-                *reinterpret_cast<float4*>(pp + (long)(16 * it) * p.Ncols + 4) = *reinterpret_cast<const float4*>(&Cs[(rl0 + 16 * it) * LDC + c + 4]);
+        for (int it = 0; it < NIT; ++it) {
+            if (m0 + rl0 + RG * it < p.M) {
+                *reinterpret_cast<float4*>(pp + (long)(RG * it) * p.Ncols) = *reinterpret_cast<const float4*>(&Cs[(rl0 + RG * it) * LDC + c]);
+                *reinterpret_cast<float4*>(pp + (long)(RG * it) * p.Ncols + 4) = *reinterpret_cast<const float4*>(&Cs[(rl0 + RG * it) * LDC + c + 4]);
             }
         }
         return;
@@ -145,15 +148,15 @@ __device__ __forceinline__ void bg_epilogue(const BGParams& p, char* smem, f32x1
         const float slope = (p.act == DPIG_ACT_NONE) ? 1.f : ((p.act == DPIG_ACT_RELU) ? 0.f : p.alpha);
         auto run = [&](auto HAS_RES, auto RES_POST, auto HAS_MASK, auto HAS_D2) {
 #pragma unroll 2
-            for (int it = 0; it < 8; ++it) {
-                const long r0 = rowof(rl0 + 16 * it);
+            for (int it = 0; it < NIT; ++it) {
+                const long r0 = rowof(rl0 + RG * it);
                 if (r0 < 0) continue;
                 bf16_t* dp = p.D + r0 * p.ldd + col;
                 const bf16_t* rp = HAS_RES ? p.res + r0 * p.ldres + col : nullptr;
                 const bf16_t* mp = HAS_MASK ? p.mask + r0 * p.ldmask + col : nullptr;
                 bf16_t* d2 = HAS_D2 ? p.D2 + r0 * p.ldd2 + col : nullptr;
                 float v[8], rv[8];
-                load_c(rl0 + 16 * it, v);
+                load_c(rl0 + RG * it, v);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) v[e] += bv[e];
                 if (HAS_RES) unpack8(*reinterpret_cast<const uint4*>(rp), rv);
@@ -190,8 +193,8 @@ __device__ __forceinline__ void bg_epilogue(const BGParams& p, char* smem, f32x1
         if (hr && rpost && !hm && h2) { run(T{}, T{}, F{}, T{}); return; }          // res-block tail
     }
 #pragma unroll 2
-    for (int it = 0; it < 8; ++it) {
-        const int rl = rl0 + 16 * it;
+    for (int it = 0; it < NIT; ++it) {
+        const int rl = rl0 + RG * it;
         const int row = rowof(rl);
         if (row < 0) continue;
         float v[8];
@@ -202,13 +205,20 @@ __device__ __forceinline__ void bg_epilogue(const BGParams& p, char* smem, f32x1
 
 // ------------------------------------------------------------------------------------------------
 // gather-GEMM: D[M x Ncols] = gather(A)[M x K] * B^T, K = taps x channels
+// NW = waves of the workgroup: 4 (sub-tiles 64 x 64) or 8 (64 x 32: each wave issues HALF the LDS-DMA pieces of a k-tile -- their issue
+// cost, not their bytes, is what bounds this loop (profiles/r02_bf16_kloop_timeline_knockout.md) -- for 1.5x the fragment reads).  The
+// k order of every output element is the same, so the two give identical bits.
+template <int NW>
 __device__ __forceinline__ void bg_body(const BGParams& p) {
+    constexpr int NB = NW == 4 ? 2 : 1;          // 32-column blocks per wave
+    constexpr int RPR = 8 * NW;                  // tile rows one DMA round of the workgroup fills
+    constexpr int NJ = TM / RPR;                 // DMA rounds per operand tile
     __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];     // the ONLY LDS object (two would make hipcc
                                                                        // drain the DMA queue before every ds_read)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wrow = (wave >> 1) * 64, wcol = (wave & 1) * 64;
+    const int wrow = NW == 4 ? (wave >> 1) * 64 : (wave >> 2) * 64, wcol = NW == 4 ? (wave & 1) * 64 : (wave & 3) * 32;
     const int l31 = lane & 31, half = lane >> 5;
 #ifdef DPIG_TRACE
     const bool trace_on = ((int)blockIdx.x < 256) && (blockIdx.z == 0) && (lane == 0);
@@ -222,28 +232,28 @@ __device__ __forceinline__ void bg_body(const BGParams& p) {
     const int kt_begin = split * p.tiles_per_split;
     const int kt_end = min(p.ktiles, kt_begin + p.tiles_per_split);
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NB];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     const __amdgpu_buffer_rsrc_t rsA = make_rsrc(p.A, p.a_bytes);
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.B, p.b_bytes);
 
-    // ---- DMA roles: instruction j of this wave fills tile rows 32j + 8*wave .. +7; lane -> (row, slot) -------------
+    // ---- DMA roles: instruction j of this wave fills tile rows RPR j + 8*wave .. +7 (RPR = 32 / 64); lane -> (row, slot) ----
     // Per-lane work is kept OUT of the k-tile loop (the loop is issue-bound: 16 MFMAs of 32 cycles per k-tile leave ~500
     // cycles for everything else): the halo test and the tap's pixel shift are folded into a per-lane offset once per
     // TAP (a_voff, OOB when the tap falls outside the image for this row); the channel chunk of a k-tile is a SCALAR
     // offset of the DMA instruction, as is the whole filter-slab offset of the B operand.
-    const int lrow = 8 * wave + (lane >> 3);                   // (+ 32 j)
+    const int lrow = 8 * wave + (lane >> 3);                   // (+ RPR j)
     const int chunk = (lane & 7) ^ ((lrow >> 1) & 7);          // the row's 16-byte chunk this lane fetches
-    int a_base[4], a_iy0[4], a_ix0[4], a_voff[4], b_voff[4];
+    int a_base[NJ], a_iy0[NJ], a_ix0[NJ], a_voff[NJ], b_voff[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int m = m0 + lrow + 32 * j;
+    for (int j = 0; j < NJ; ++j) {
+        const int m = m0 + lrow + RPR * j;
         const bool ok = m < p.M;
         const int mm = ok ? m : 0;
         const int n = fast_div(mm, p.mul_hrwr, p.shr_hrwr);
@@ -253,7 +263,7 @@ __device__ __forceinline__ void bg_body(const BGParams& p) {
         a_iy0[j] = ok ? r * p.sr : -(1 << 24);                 // a row beyond M fails every bounds test
         a_ix0[j] = c * p.sr;
         a_base[j] = ((((n * p.Hs + r * p.sr) * p.Ws + c * p.sr) * p.lda) + chunk * 8) * 2;
-        const int nn = n0 + lrow + 32 * j;
+        const int nn = n0 + lrow + RPR * j;
         b_voff[j] = (nn < p.Ncols) ? (nn * p.Cs + chunk * 8) * 2 : (int)OOB;
     }
     const bool ktail = (p.Cs & (TK - 1)) != 0;                 // the last channel chunk of a tap is partial (uniform)
@@ -268,7 +278,7 @@ __device__ __forceinline__ void bg_body(const BGParams& p) {
         const int t_oy = p.oy0 + cur_ta * p.oys, t_ox = p.ox0 + cur_tb * p.oxs;
         const int shift = ((t_oy * p.Ws + t_ox) * p.lda) * 2;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NJ; ++j) {
             // bitwise & on purpose: && would become exec-mask branches
             const bool ok = ((unsigned)(a_iy0[j] + t_oy) < (unsigned)p.Hs) & ((unsigned)(a_ix0[j] + t_ox) < (unsigned)p.Ws);
             a_voff[j] = ok ? a_base[j] + shift : (int)OOB;
@@ -282,15 +292,15 @@ __device__ __forceinline__ void bg_body(const BGParams& p) {
         if (ktail) {
             const bool kok = c0 + chunk * 8 < p.Cs;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                dma16(rsA, kok ? a_voff[j] : (int)OOB, c0 * 2, dst + 32 * j * ROWB);
-                dma16(rsB, kok ? b_voff[j] : (int)OOB, tap_sB + c0 * 2, dst + TILE_B + 32 * j * ROWB);
+            for (int j = 0; j < NJ; ++j) {
+                dma16(rsA, kok ? a_voff[j] : (int)OOB, c0 * 2, dst + RPR * j * ROWB);
+                dma16(rsB, kok ? b_voff[j] : (int)OOB, tap_sB + c0 * 2, dst + TILE_B + RPR * j * ROWB);
             }
         } else {
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                dma16(rsA, a_voff[j], c0 * 2, dst + 32 * j * ROWB);
-                dma16(rsB, b_voff[j], tap_sB + c0 * 2, dst + TILE_B + 32 * j * ROWB);
+            for (int j = 0; j < NJ; ++j) {
+                dma16(rsA, a_voff[j], c0 * 2, dst + RPR * j * ROWB);
+                dma16(rsB, b_voff[j], tap_sB + c0 * 2, dst + TILE_B + RPR * j * ROWB);
             }
         }
         cur_c0 += TK;
@@ -309,14 +319,14 @@ __device__ __forceinline__ void bg_body(const BGParams& p) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) so[ks] = ((2 * ks + half) ^ fsw) * 16;
 
-    bf16x8 fa[2][2], fb[2][2];                     // [k-step parity][32-row / 32-col block]
-    auto load_frag = [&](int stage, int ks, bf16x8 (&a)[2], bf16x8 (&b)[2]) {
+    bf16x8 fa[2][2], fb[2][NB];                    // [k-step parity][32-row / 32-col block]
+    auto load_frag = [&](int stage, int ks, bf16x8 (&a)[2], bf16x8 (&b)[NB]) {
         const char* ab = fa_base + stage * STAGE_B;
         const char* bb = fb_base + stage * STAGE_B;
 #pragma unroll
         for (int mb = 0; mb < 2; ++mb) a[mb] = *reinterpret_cast<const bf16x8*>(ab + mb * 32 * ROWB + so[ks]);
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) b[nb] = *reinterpret_cast<const bf16x8*>(bb + nb * 32 * ROWB + so[ks]);
+        for (int nb = 0; nb < NB; ++nb) b[nb] = *reinterpret_cast<const bf16x8*>(bb + nb * 32 * ROWB + so[ks]);
     };
     // One k-tile: the first fragments are requested right behind the barrier, the DMA of the NEXT tile (address
     // arithmetic + 8 LDS-DMA instructions) is issued under their latency, the fragments of k-step ks+1 are read under the
@@ -334,7 +344,7 @@ __device__ __forceinline__ void bg_body(const BGParams& p) {
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
+                for (int nb = 0; nb < NB; ++nb)
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][mb], fb[ks & 1][nb], acc[mb][nb], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -359,18 +369,24 @@ __device__ __forceinline__ void bg_body(const BGParams& p) {
     }
 
     BF_STAMP(5);
-    bg_epilogue(p, smem, acc, m0, n0, split, tid, wrow, wcol, l31, half,
-                [&](int rl) { return (m0 + rl < p.M) ? m0 + rl : -1; });
+    bg_epilogue<NB, 4 * NW>(p, smem, acc, m0, n0, split, tid, wrow, wcol, l31, half,
+                            [&](int rl) { return (m0 + rl < p.M) ? m0 + rl : -1; });
     BF_STAMP(6);
 }
 
-__global__ __launch_bounds__(256, 2) void bg_kernel(const BGParams p) { bg_body(p); }
+__global__ __launch_bounds__(256, 2) void bg_kernel(const BGParams p) { bg_body<4>(p); }
+__global__ __launch_bounds__(512, 2) void bg8_kernel(const BGParams p) { bg_body<8>(p); }
 
 struct BGMulti { BGParams q[4]; };
 __global__ __launch_bounds__(256, 2) void bg_multi_kernel(const BGMulti m) {
     const BGParams& p = m.q[blockIdx.y];
     if ((int)blockIdx.x >= p.mtiles * p.ntiles || (int)blockIdx.z >= p.nsplit) return;
-    bg_body(p);
+    bg_body<4>(p);
+}
+__global__ __launch_bounds__(512, 2) void bg8_multi_kernel(const BGMulti m) {
+    const BGParams& p = m.q[blockIdx.y];
+    if ((int)blockIdx.x >= p.mtiles * p.ntiles || (int)blockIdx.z >= p.nsplit) return;
+    bg_body<8>(p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -386,8 +402,11 @@ __global__ __launch_bounds__(256, 2) void bg_multi_kernel(const BGMulti m) {
 // Bank conflicts: pixel (hy, hx) of the halo keeps its 16-byte chunk c at slot c ^ ((hx >> 1) + (TW / 2) hy) & 7: the 16
 // lanes of a ds_read_b128 group (consecutive hx of one or two patch rows) then hit 16 different 16-byte bank groups
 // for every tap shift.
-template <int TWL>   // log2 of the patch width: 4 (8 rows x 16) or 3 (16 rows x 8)
-__global__ __launch_bounds__(256, 2) void bh_kernel(const BGParams p) {
+template <int TWL, int NW>   // log2 of the patch width: 4 (8 rows x 16) or 3 (16 rows x 8); waves: 4 (64 x 64 sub-tiles) or 8 (64 x 32, as bg_body)
+__device__ __forceinline__ void bh_body(const BGParams& p) {
+    constexpr int NB = NW == 4 ? 2 : 1;          // 32-column blocks per wave
+    constexpr int RPR = 8 * NW, NJ = TM / RPR;   // filter DMA: tile rows per round of the workgroup, rounds
+    constexpr int NQ = 24 / NW;                  // halo DMA pieces per wave (23 pieces in all)
     constexpr int TW = 1 << TWL, TH = TM / TW, P = TW + 2, NPIX = (TH + 2) * P;       // 180 halo pixels
     constexpr int HROWS = 184, HALO_B = HROWS * ROWB;                                 // 23 DMA pieces of 8 pixels
     constexpr int HSMEM = 2 * HALO_B + 2 * TILE_B;                                    // 79872
@@ -398,7 +417,7 @@ __global__ __launch_bounds__(256, 2) void bh_kernel(const BGParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wrow = (wave >> 1) * 64, wcol = (wave & 1) * 64;
+    const int wrow = NW == 4 ? (wave >> 1) * 64 : (wave >> 2) * 64, wcol = NW == 4 ? (wave & 1) * 64 : (wave & 3) * 32;
     const int l31 = lane & 31, half = lane >> 5;
 
     const int tile = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
@@ -410,11 +429,11 @@ __global__ __launch_bounds__(256, 2) void bh_kernel(const BGParams p) {
     const int tyi = trem / p.tiles_x;
     const int y0 = tyi * TH, x0 = (trem - tyi * p.tiles_x) * TW;
 
-    f32x16 acc[2][2];
+    f32x16 acc[2][NB];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < NB; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -422,11 +441,11 @@ __global__ __launch_bounds__(256, 2) void bh_kernel(const BGParams p) {
     const __amdgpu_buffer_rsrc_t rsB = make_rsrc(p.B, p.b_bytes);
     const bool ktail = (p.Cs & (TK - 1)) != 0;
 
-    // ---- halo DMA roles: piece i = wave + 4 q (q = 0..5, i < 23) covers halo pixels 8 i .. 8 i + 7; lane -> (pixel, slot)
-    int h_voff[6], h_gran[6];
+    // ---- halo DMA roles: piece i = wave + NW q (q < NQ, i < 23) covers halo pixels 8 i .. 8 i + 7; lane -> (pixel, slot)
+    int h_voff[NQ], h_gran[NQ];
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        const int hp = 8 * (wave + 4 * q) + (lane >> 3);
+    for (int q = 0; q < NQ; ++q) {
+        const int hp = 8 * (wave + NW * q) + (lane >> 3);
         const int hy = hp / P, hx = hp - hy * P;
         const int y = y0 - 1 + hy, x = x0 - 1 + hx;
         const bool ok = (hp < NPIX) & ((unsigned)y < (unsigned)p.Hs) & ((unsigned)x < (unsigned)p.Ws);
@@ -434,19 +453,19 @@ __global__ __launch_bounds__(256, 2) void bh_kernel(const BGParams p) {
         h_gran[q] = g;
         h_voff[q] = ok ? ((((img * p.Hs + y) * p.Ws + x) * p.lda) + g * 8) * 2 : (int)OOB;
     }
-    auto issue_halo = [&](int q, int buf, int c0) {            // piece (wave + 4 q) of the chunk starting at channel c0
-        if (wave + 4 * q >= 23) return;                        // (wave-uniform)
+    auto issue_halo = [&](int q, int buf, int c0) {            // piece (wave + NW q) of the chunk starting at channel c0
+        if (wave + NW * q >= 23) return;                       // (wave-uniform)
         int v = h_voff[q];
         if (ktail) v = (c0 + h_gran[q] * 8 < p.Cs) ? v : (int)OOB;
-        dma16(rsA, v, c0 * 2, smem + buf * HALO_B + (wave + 4 * q) * 8 * ROWB);
+        dma16(rsA, v, c0 * 2, smem + buf * HALO_B + (wave + NW * q) * 8 * ROWB);
     };
-    // ---- filter DMA roles (as bg_kernel): instruction j fills tile rows 32 j + 8 wave .. +7 ------------------------
+    // ---- filter DMA roles (as bg_kernel): instruction j fills tile rows RPR j + 8 wave .. +7 -----------------------
     const int lrow = 8 * wave + (lane >> 3);
     const int chunk = (lane & 7) ^ ((lrow >> 1) & 7);
-    int b_voff[4];
+    int b_voff[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int nn = n0 + lrow + 32 * j;
+    for (int j = 0; j < NJ; ++j) {
+        const int nn = n0 + lrow + RPR * j;
         b_voff[j] = (nn < p.Ncols) ? (nn * p.Cs + chunk * 8) * 2 : (int)OOB;
     }
     auto issue_b = [&](int stage, int tap, int c0) {
@@ -455,7 +474,7 @@ __global__ __launch_bounds__(256, 2) void bh_kernel(const BGParams p) {
         char* dst = bbuf + stage * TILE_B + (8 * wave) * ROWB;
         const bool kok = !ktail | (c0 + chunk * 8 < p.Cs);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) dma16(rsB, kok ? b_voff[j] : (int)OOB, sB, dst + 32 * j * ROWB);
+        for (int j = 0; j < NJ; ++j) dma16(rsB, kok ? b_voff[j] : (int)OOB, sB, dst + RPR * j * ROWB);
     };
 
     // ---- fragment addressing ---------------------------------------------------------------------------------------
@@ -472,7 +491,7 @@ __global__ __launch_bounds__(256, 2) void bh_kernel(const BGParams p) {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) sob[ks] = ((2 * ks + half) ^ fsw) * 16;
 
-    bf16x8 fa[2][2], fb[2][2];
+    bf16x8 fa[2][2], fb[2][NB];
     const int nch = p.cchunks;
     const int ktiles = 9 * nch;
     // one k-tile = (chunk c, tap): A fragments from the resident halo of chunk c shifted by the tap, B from bbuf[stage]
@@ -490,11 +509,11 @@ __global__ __launch_bounds__(256, 2) void bh_kernel(const BGParams p) {
             abase[mb] = hb + (hy * P + hx) * ROWB;
             sw[mb] = ((hx >> 1) + (TW / 2) * hy) & 7;
         }
-        auto load_frag = [&](int ks, bf16x8 (&a)[2], bf16x8 (&b)[2]) {
+        auto load_frag = [&](int ks, bf16x8 (&a)[2], bf16x8 (&b)[NB]) {
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb) a[mb] = *reinterpret_cast<const bf16x8*>(abase[mb] + (((2 * ks + half) ^ sw[mb]) << 4));
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) b[nb] = *reinterpret_cast<const bf16x8*>(bb + nb * 32 * ROWB + sob[ks]);
+            for (int nb = 0; nb < NB; ++nb) b[nb] = *reinterpret_cast<const bf16x8*>(bb + nb * 32 * ROWB + sob[ks]);
         };
         load_frag(0, fa[0], fb[0]);
         __builtin_amdgcn_sched_barrier(0);
@@ -502,7 +521,7 @@ __global__ __launch_bounds__(256, 2) void bh_kernel(const BGParams p) {
             const int kn = kt + 1, cn = kn / 9;
             issue_b(stage ^ 1, kn - cn * 9, cn * TK);
         }
-        if (tap < 6 && c + 1 < nch) issue_halo(tap, (c + 1) & 1, (c + 1) * TK);
+        if (tap < NQ && c + 1 < nch) issue_halo(tap, (c + 1) & 1, (c + 1) * TK);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             if (ks + 1 < 4) load_frag(ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
@@ -510,7 +529,7 @@ __global__ __launch_bounds__(256, 2) void bh_kernel(const BGParams p) {
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
+                for (int nb = 0; nb < NB; ++nb)
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][mb], fb[ks & 1][nb], acc[mb][nb], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -519,7 +538,7 @@ __global__ __launch_bounds__(256, 2) void bh_kernel(const BGParams p) {
     };
 
 #pragma unroll
-    for (int q = 0; q < 6; ++q) issue_halo(q, 0, 0);
+    for (int q = 0; q < NQ; ++q) issue_halo(q, 0, 0);
     issue_b(0, 0, 0);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -530,11 +549,13 @@ __global__ __launch_bounds__(256, 2) void bh_kernel(const BGParams p) {
     }
     if (kt < ktiles) ktile(kt, 0);
 
-    bg_epilogue(p, smem, acc, 0, n0, 0, tid, wrow, wcol, l31, half, [&](int rl) {
+    bg_epilogue<NB, 4 * NW>(p, smem, acc, 0, n0, 0, tid, wrow, wcol, l31, half, [&](int rl) {
         const int y = y0 + (rl >> TWL), x = x0 + (rl & (TW - 1));
         return (y < p.Hs && x < p.Ws) ? (img * p.Hs + y) * p.Ws + x : -1;
     });
 }
+template <int TWL> __global__ __launch_bounds__(256, 2) void bh_kernel(const BGParams p) { bh_body<TWL, 4>(p); }
+template <int TWL> __global__ __launch_bounds__(512, 2) void bh8_kernel(const BGParams p) { bh_body<TWL, 8>(p); }
 
 // split-K second pass: sum the fp32 partials in split order (deterministic), run the fused epilogue, write bf16
 __device__ __forceinline__ void bg_reduce_body(const BGParams& p) {
@@ -578,13 +599,17 @@ constexpr int WTILE_B = TK * WROWB;       // 16 KB
 constexpr int WSTAGE_B = 2 * WTILE_B;
 constexpr int WSMEM_BYTES = 2 * WSTAGE_B; // 64 KB = the [128][128] fp32 staging of the epilogue
 
-template <bool S1>   // S1: stride-1 SAME layer -- output pixel m pairs with input pixel m + const
-__global__ __launch_bounds__(256, 2) void bw_kernel(const BWParams p) {
+// NW = 4 waves of 64 x 64 or 8 waves of 64 x 32 (as bg_body: half the DMA instructions and halo tests per wave; same k order, same bits)
+template <bool S1, int NW>   // S1: stride-1 SAME layer -- output pixel m pairs with input pixel m + const
+__device__ __forceinline__ void bw_body(const BWParams& p) {
+    constexpr int NB = NW == 4 ? 2 : 1;          // 32-column blocks per wave
+    constexpr int PPR = 4 * NW;                  // pixel rows one DMA round of the workgroup fills
+    constexpr int NJ = TK / PPR;                 // DMA rounds per operand tile
     __shared__ __attribute__((aligned(16))) char smem[WSMEM_BYTES];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wrow = (wave >> 1) * 64, wcol = (wave & 1) * 64;
+    const int wrow = NW == 4 ? (wave >> 1) * 64 : (wave >> 2) * 64, wcol = NW == 4 ? (wave & 1) * 64 : (wave & 3) * 32;
     const int l31 = lane & 31, half = lane >> 5;
 
     const int mtiles = p.ntaps * p.cblocks;
@@ -602,30 +627,29 @@ __global__ __launch_bounds__(256, 2) void bw_kernel(const BWParams p) {
     const int kt_end = min(p.ktiles, kt_begin + p.tiles_per_split);
     const bool do_bias = (p.DB != nullptr) && (mt == 0);
 
-    f32x16 acc[2][2];
-    f32x16 accb[2];                         // bias gradient: ones x dy on the matrix pipe (rows all equal)
+    f32x16 acc[2][NB];
+    f32x16 accb[NB];                        // bias gradient: ones x dy on the matrix pipe (rows all equal)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        acc[0][0][r] = 0.f; acc[0][1][r] = 0.f; acc[1][0][r] = 0.f; acc[1][1][r] = 0.f;
-        accb[0][r] = 0.f; accb[1][r] = 0.f;
-    }
+    for (int r = 0; r < 16; ++r)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) { acc[0][nb][r] = 0.f; acc[1][nb][r] = 0.f; accb[nb][r] = 0.f; }
     // S1: the x descriptor starts `padpix` pixels BEFORE the tensor so that the scalar pixel offset m + tap shift + padpix is
     // never negative; lanes whose tap falls outside the image carry voffset = OOB and are never dereferenced
     const int padpix = S1 ? p.pad_t * p.W + p.pad_l : 0;
     const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.X - (long)padpix * p.ldx, p.x_bytes + (unsigned)(padpix * p.ldx * 2));
     const __amdgpu_buffer_rsrc_t rsY = make_rsrc(p.DY, p.y_bytes);
 
-    // ---- DMA roles: instruction j of this wave fills pixel rows 16j + 4*wave .. +3 (1 KB); lane -> (pixel, slot) ---
+    // ---- DMA roles: instruction j of this wave fills pixel rows PPR j + 4*wave .. +3 (1 KB; PPR = 16 / 32); lane -> (pixel, slot) ---
     // dy: per-lane constant offset + SCALAR k-tile offset; pixels >= Npix lie beyond the descriptor (zeros for free).
     // x (S1): likewise, plus the halo test on an incrementally advanced (oy, ox); other layers (stride 2, the upsampled
     // 1x1) compute the source pixel per row.
-    const int prow = 4 * wave + (lane >> 4);                   // (+ 16 j); (prow & 3) == lane >> 4
+    const int prow = 4 * wave + (lane >> 4);                   // (+ PPR j); (prow & 3) == lane >> 4
     const int gran = (lane & 15) ^ ((lane >> 4) << 2);         // the 8-channel granule this lane fetches
     const bool cx_ok = ci0 + gran * 8 < p.C, cy_ok = co0 + gran * 8 < p.K;
-    int s_oy[4], s_ox[4], s_n[4], y_voff[4], x_voff[4];
+    int s_oy[NJ], s_ox[NJ], s_n[NJ], y_voff[NJ], x_voff[NJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int r = prow + 16 * j;
+    for (int j = 0; j < NJ; ++j) {
+        const int r = prow + PPR * j;
         const int m = kt_begin * TK + r;
         const int n = fast_div(m, p.mul_howo, p.shr_howo);
         const int rem = m - n * p.HoWo;
@@ -641,19 +665,19 @@ __global__ __launch_bounds__(256, 2) void bw_kernel(const BWParams p) {
         const int sy = (kt * TK * p.ldy) * 2;
         const int sx = S1 ? ((kt * TK + oyoff * p.W + oxoff + padpix) * p.ldx) * 2 : 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int r = prow + 16 * j;
+        for (int j = 0; j < NJ; ++j) {
+            const int r = prow + PPR * j;
             if (S1) {
                 const bool ok = (r < left) & ((unsigned)(s_oy[j] + oyoff) < (unsigned)p.H) & ((unsigned)(s_ox[j] + oxoff) < (unsigned)p.W);
-                dma16(rsX, ok ? x_voff[j] : (int)OOB, sx, dst + 16 * j * WROWB);
+                dma16(rsX, ok ? x_voff[j] : (int)OOB, sx, dst + PPR * j * WROWB);
             } else {
                 const int py = s_oy[j] * p.s + oyoff, px = s_ox[j] * p.s + oxoff;
                 const int iy = py >> p.shift, ix = px >> p.shift;
                 const bool ok = (r < left) & cx_ok & (py >= 0) & (px >= 0) & (iy < p.H) & (ix < p.W);
                 const int xo = ((((s_n[j] * p.H + iy) * p.W + ix) * p.ldx) + ci0 + gran * 8) * 2;
-                dma16(rsX, ok ? xo : (int)OOB, 0, dst + 16 * j * WROWB);
+                dma16(rsX, ok ? xo : (int)OOB, 0, dst + PPR * j * WROWB);
             }
-            dma16(rsY, y_voff[j], sy, dst + WTILE_B + 16 * j * WROWB);
+            dma16(rsY, y_voff[j], sy, dst + WTILE_B + PPR * j * WROWB);
             // advance this row's pixel by one k-tile (64 pixels)
             s_ox[j] += p.d64_ox;
             const bool c1 = s_ox[j] >= p.Wo;
@@ -673,13 +697,16 @@ __global__ __launch_bounds__(256, 2) void bw_kernel(const BWParams p) {
     const int pq = q >> 2;                                     // pixel (0..3) whose address this lane supplies
     // per-lane base addresses (operand tile offset, stage, k-step and the +4 pixel step are compile-time immediates)
     const char* pa[2];
-    const char* pb[2];
+    const char* pb[NB];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
         const int ca = wrow + b * 32 + cgrp * 16 + (q & 3) * 4;       // first of this lane's 4 address channels
-        const int cb = wcol + b * 32 + cgrp * 16 + (q & 3) * 4;
         // granule = chan / 8, swizzled by the pixel row: every pixel read below is 4 t + pq, so (pixel & 3) == pq
         pa[b] = smem + (half * 8 + pq) * WROWB + (((ca >> 3) ^ (pq << 2)) * 16) + (ca & 7) * 2;
+    }
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        const int cb = wcol + b * 32 + cgrp * 16 + (q & 3) * 4;
         pb[b] = smem + WTILE_B + (half * 8 + pq) * WROWB + (((cb >> 3) ^ (pq << 2)) * 16) + (cb & 7) * 2;
     }
     auto tr_read = [&](const char* a) -> s16x4 {
@@ -691,18 +718,20 @@ __global__ __launch_bounds__(256, 2) void bw_kernel(const BWParams p) {
     // front of the first tr read that follows a DMA in program order -- with the DMA issued last that wait is the one
     // the tile's own barrier needed anyway, and the DMA stays in flight under the 16 MFMAs.
     auto ktile = [&](int kt, int stage, bool more) {
-        bf16x8 fa[4][2], fb[4][2];
+        bf16x8 fa[4][2], fb[4][NB];
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {                       // k-step ks: pixels 16 ks + 8 half .. + 7 of the tile
+            const int o = stage * WSTAGE_B + ks * 16 * WROWB;
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                const int o = stage * WSTAGE_B + ks * 16 * WROWB;
                 const s16x4 a0 = tr_read(pa[b] + o), a1 = tr_read(pa[b] + o + 4 * WROWB);
-                const s16x4 b0 = tr_read(pb[b] + o), b1 = tr_read(pb[b] + o + 4 * WROWB);
                 const s16x8 av = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-                const s16x8 bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
                 fa[ks][b] = __builtin_bit_cast(bf16x8, av);
-                fb[ks][b] = __builtin_bit_cast(bf16x8, bv);
+                if (b < NB) {
+                    const s16x4 b0 = tr_read(pb[b] + o), b1 = tr_read(pb[b] + o + 4 * WROWB);
+                    const s16x8 bv = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+                    fb[ks][b] = __builtin_bit_cast(bf16x8, bv);
+                }
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -713,13 +742,13 @@ __global__ __launch_bounds__(256, 2) void bw_kernel(const BWParams p) {
 #pragma unroll
             for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb)
+                for (int nb = 0; nb < NB; ++nb)
                     acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks][mb], fb[ks][nb], acc[mb][nb], 0, 0, 0);
             if (do_bias) {                                     // workgroup-uniform
                 const s16x8 one8 = {0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80, 0x3f80};
                 const bf16x8 ones = __builtin_bit_cast(bf16x8, one8);
-                accb[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, fb[ks][0], accb[0], 0, 0, 0);
-                accb[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, fb[ks][1], accb[1], 0, 0, 0);
+#pragma unroll
+                for (int nb = 0; nb < NB; ++nb) accb[nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ones, fb[ks][nb], accb[nb], 0, 0, 0);
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -744,7 +773,7 @@ __global__ __launch_bounds__(256, 2) void bw_kernel(const BWParams p) {
     if (do_bias && wrow == 0 && l31 < 32 && half == 0) {
         // row 0 of the ones x dy product: accumulator register 0 of lanes 0..31 (half 0) holds (row 0, column l31)
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
+        for (int nb = 0; nb < NB; ++nb) {
             const int co = co0 + wcol + nb * 32 + l31;
             if (co < p.K) {
                 const float v = accb[nb][0];
@@ -758,7 +787,7 @@ __global__ __launch_bounds__(256, 2) void bw_kernel(const BWParams p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r)
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb)
+            for (int nb = 0; nb < NB; ++nb)
                 Cs[(wrow + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * TN + wcol + nb * 32 + l31] = acc[mb][nb][r];
     __syncthreads();
     float* dst = (p.nsplit > 1) ? p.partial + (long)split * wsize : p.DW;
@@ -767,8 +796,8 @@ __global__ __launch_bounds__(256, 2) void bw_kernel(const BWParams p) {
     const int co = co0 + c;
     if (co < p.K) {
 #pragma unroll 4
-        for (int it = 0; it < 16; ++it) {
-            const int rl = (tid >> 5) + 8 * it;
+        for (int it = 0; it < 64 / NW; ++it) {
+            const int rl = (tid >> 5) + 2 * NW * it;
             const int ci = ci0 + rl;
             if (ci >= p.C) continue;
             float4 v = *reinterpret_cast<const float4*>(&Cs[rl * TN + c]);
@@ -781,6 +810,8 @@ __global__ __launch_bounds__(256, 2) void bw_kernel(const BWParams p) {
         }
     }
 }
+template <bool S1> __global__ __launch_bounds__(256, 2) void bw_kernel(const BWParams p) { bw_body<S1, 4>(p); }
+template <bool S1> __global__ __launch_bounds__(512, 2) void bw8_kernel(const BWParams p) { bw_body<S1, 8>(p); }
 
 // ------------------------------------------------------------------------------------------------
 // Split-bf16 filter gradient with BOTH operands from their split32 images (dpig_split32: [pixel][32-channel chunk][32 hi |
@@ -1275,6 +1306,17 @@ static int halo_plan(const BGParams& p, int nimg, int* tx, int* ty) {
     return best;
 }
 
+// Eight-wave forms of bg_kernel (bit 0), bw_kernel (bit 1) and bh_kernel (bit 2) (DPIG_BF16_G8 / dpig_conv_bf16_set_wave8; default 3):
+// same tiles, plans and bits.  Measured (profiles/r04_ab_wave8_layers.txt): forward / dgrad -2 % over the 128-tile layers of the three
+// graphs (-12..-24 % on the stride-2 dgrads' four-class launch, never worse than +4 %); Market bf16 step +1.0 % (bit 0) and +1.5 %
+// (bits 0 + 1), DeepFashion +0.5 %, stage II +0.2 %.  The halo-patch kernel issues 5 pieces per 16 MFMAs already and does not gain (-0.4 %
+// on DeepFashion): off by default.
+static int g_wave8 = -1;
+static int wave8_mode() {
+    if (g_wave8 < 0) { const char* e = getenv("DPIG_BF16_G8"); g_wave8 = e ? (atoi(e) & 7) : 3; }
+    return g_wave8;
+}
+
 static int launch_bg(BGParams& p, int nimg, long filter_elems, hipStream_t st) {
     int rc = prepare_bg(p, nimg, filter_elems);
     if (rc) return rc;
@@ -1292,12 +1334,16 @@ static int launch_bg(BGParams& p, int nimg, long filter_elems, hipStream_t st) {
         p.mtiles = nimg * tx * ty;
         p.nsplit = 1; p.tiles_per_split = p.ktiles;
         dim3 hgrid(p.mtiles * p.ntiles), hblock(256);
-        if (twl == 4) hipLaunchKernelGGL((bh_kernel<4>), hgrid, hblock, 0, st, p);
+        if (wave8_mode() & 4) {
+            if (twl == 4) hipLaunchKernelGGL((bh8_kernel<4>), hgrid, dim3(512), 0, st, p);
+            else hipLaunchKernelGGL((bh8_kernel<3>), hgrid, dim3(512), 0, st, p);
+        } else if (twl == 4) hipLaunchKernelGGL((bh_kernel<4>), hgrid, hblock, 0, st, p);
         else hipLaunchKernelGGL((bh_kernel<3>), hgrid, hblock, 0, st, p);
         return check_launch("bh_kernel");
     }
-    dim3 grid(p.mtiles * p.ntiles, 1, p.nsplit), block(256);
-    hipLaunchKernelGGL(bg_kernel, grid, block, 0, st, p);
+    dim3 grid(p.mtiles * p.ntiles, 1, p.nsplit);
+    if ((wave8_mode() & 1) && !p.stats) hipLaunchKernelGGL(bg8_kernel, grid, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL(bg_kernel, grid, dim3(256), 0, st, p);
     rc = check_launch("bg_kernel");
     if (rc) return rc;
     if (p.nsplit > 1) {
@@ -1317,8 +1363,9 @@ static int launch_bg_multi(BGParams* q, int n, int nimg, long filter_elems, hipS
         if (q[i].nsplit > 1 && reduce_blocks(q[i]) > max_red) max_red = reduce_blocks(q[i]);
         m.q[i] = q[i];
     }
-    dim3 grid(max_tiles, n, max_split), block(256);
-    hipLaunchKernelGGL(bg_multi_kernel, grid, block, 0, st, m);
+    dim3 grid(max_tiles, n, max_split);
+    if (wave8_mode() & 1) hipLaunchKernelGGL(bg8_multi_kernel, grid, dim3(512), 0, st, m);
+    else hipLaunchKernelGGL(bg_multi_kernel, grid, dim3(256), 0, st, m);
     int rc = check_launch("bg_multi_kernel");
     if (rc) return rc;
     if (max_red > 0) {
@@ -1335,6 +1382,12 @@ static void plan_s2(const DpigConvDesc* d, int pt, int pl, S2Plan* sp) { plan_dg
 
 using namespace dpig;
 using namespace dpig::bfk;
+
+extern "C" int dpig_conv_bf16_set_wave8(int mode) {
+    if (mode < 0 || mode > 7) return fail(DPIG_EINVAL, "wave8 mode out of range");
+    g_wave8 = mode;
+    return DPIG_OK;
+}
 
 extern "C" int dpig_conv2d_bf16_supported(const DpigConvDesc* d, int which) {
     int pt, pl, Ho, Wo;
@@ -1632,7 +1685,10 @@ static int wgrad_bf16_one(const DpigConvDesc* d, const uint16_t* x, const uint16
         if (rc < 0) return rc;
         rc = DPIG_OK;
     } else {
-        if (s1) hipLaunchKernelGGL((bw_kernel<true>), grid, block, 0, st, p);
+        if (wave8_mode() & 2) {
+            if (s1) hipLaunchKernelGGL((bw8_kernel<true>), grid, dim3(512), 0, st, p);
+            else hipLaunchKernelGGL((bw8_kernel<false>), grid, dim3(512), 0, st, p);
+        } else if (s1) hipLaunchKernelGGL((bw_kernel<true>), grid, block, 0, st, p);
         else hipLaunchKernelGGL((bw_kernel<false>), grid, block, 0, st, p);
         rc = check_launch("bw_kernel");
         if (rc) return rc;

@@ -571,6 +571,11 @@ def set_large_tile(mode=1, variant=0):
     check(lib().dpig_conv_bf16_set_large_tile(int(mode), int(variant)), "conv_bf16_set_large_tile")
 
 
+def set_wave8(mode):
+    """Eight-wave forms of the 128 x 128 bf16 kernels (dpig_conv_bf16_set_wave8): bit 0 forward / dgrad, bit 1 filter gradient; identical results."""
+    check(lib().dpig_conv_bf16_set_wave8(int(mode)), "conv_bf16_set_wave8")
+
+
 def set_large_tile_wgrad(mode=1, variant=0):
     """The same switch for the bf16-storage filter gradient (dpig_conv_bf16_set_large_tile_wgrad)."""
     check(lib().dpig_conv_bf16_set_large_tile_wgrad(int(mode), int(variant)), "conv_bf16_set_large_tile_wgrad")

@@ -51,7 +51,7 @@ extern "C" {
 #define DPIG_ACT_RELU 1
 #define DPIG_ACT_LRELU 2
 
-#define DPIG_VERSION 280
+#define DPIG_VERSION 281
 
 /* Convolution problem, always described from the FORWARD op's point of view. */
 typedef struct DpigConvDesc {
@@ -161,6 +161,10 @@ int dpig_conv_bf16_set_large_tile(int mode, int variant);
 /* The same switch for dpig_conv2d_wgrad_bf16 (csrc/dpig_conv_bf16_wq.hip: stride-1 SAME layers; variant 1 = 2 (tap, 128-ci)
  * items x 256 co per workgroup, 2 = 4 items x 128 co; environment DPIG_BF16_WQ).  The workspace query follows the setting. */
 int dpig_conv_bf16_set_large_tile_wgrad(int mode, int variant);
+/* The 128 x 128 kernels with eight waves per workgroup instead of four (csrc/dpig_conv_bf16.hip: 64 x 32 sub-tiles, half the LDS-DMA
+ * instructions per wave): bit 0 = forward / dgrad (bg8_kernel, bg8_multi_kernel), bit 1 = filter gradient (bw8_kernel), bit 2 = the
+ * halo-patch kernel (bh8_kernel); environment DPIG_BF16_G8.  Same plans, same bits. */
+int dpig_conv_bf16_set_wave8(int mode);
 /* The thin layers of 'bf16' mode on the vector-ALU kernels (csrc/dpig_thin.hip) with their WIDE tensor stored as bf16;
  * the 3-channel image side, the fp32 HWIO filter and the filter gradient stay fp32:
  *   K == 3 (3x3 s1, the generator's image conv models.py:573):        x / dx bf16 [.., C],   y / dy fp32 [.., 3]

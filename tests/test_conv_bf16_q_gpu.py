@@ -343,3 +343,56 @@ def test_wgrad_full_size_repeats_and_agrees(dev, layer):
             assert (ref[1] - db0).abs().max().item() <= 2e-5 * db0.abs().max().item()
     finally:
         H.set_large_tile_wgrad(1, 0)
+
+
+# ---- the eight-wave form of the 128 x 128 kernel (csrc/dpig_conv_bf16.hip bg8_kernel / bg8_multi_kernel) --------------------------
+WAVE8_SHAPES = FWD_SHAPES + [
+    (16, 8, 4, 640, 640, 3, 1),     # Market G level 5: 512 rows, 90 k-tiles -> split-K plan
+    (16, 16, 8, 512, 384, 3, 2),    # stride 2 (the dgrad runs its four parity classes in one launch)
+    (2, 12, 10, 72, 200, 3, 1),     # channel tail (72 = 64 + 8) and a partial column tile
+    (16, 64, 64, 64, 128, 3, 1),    # 512 patches of 8 x 16: the halo-patch kernel (bh8_kernel<4>)
+    (36, 48, 40, 72, 128, 3, 1),    # 16 x 8 patches (bh8_kernel<3>), channel tail in the halo
+]
+
+
+@pytest.mark.parametrize("shape", WAVE8_SHAPES)
+def test_eight_wave_128_tile_kernel(dev, shape):
+    """Same tile, plan and k order as the four-wave kernels, so the results must be the same bits -- forward with a fused epilogue,
+    dgrad with the activation mask (stride 2: bg8_multi_kernel; halo patches: bh8_kernel), filter + bias gradient (bw8_kernel), with
+    and without split-K -- and
+    forward and filter gradient must meet the oracle."""
+    import dpig_amd.hip_ops as H
+    from oracle import ops as O
+    N, Hh, W, C, K, k, s = shape
+    x = _rand((N, Hh, W, C), 1)
+    w = _rand((k, k, C, K), 2, 0.2)
+    b = _rand((K,), 3)
+    xd, wd, bd = x.float().to(dev).to(BF), w.float().to(dev), b.float().to(dev)
+    Ho, Wo = -(-Hh // s), -(-W // s)
+    dy = _rand((N, Ho, Wo, K), 5).float().to(dev).to(BF)
+    m = _rand((N, Hh, W, C), 6).float().to(dev).to(BF)
+    try:
+        H.set_large_tile(0, 0)
+        H.set_large_tile_wgrad(0, 0)
+        out = {}
+        for mode in (0, 7):
+            H.set_wave8(mode)
+            for rep in range(3):
+                y = H.conv2d_fwd(xd, wd, bd, stride=s, act=2, alpha=0.2)
+                dx = H.conv2d_dgrad(dy, wd, (N, Hh, W, C), stride=s, mask=m, act=1)
+                db = torch.empty(K, device=dev)
+                dw = H.conv2d_wgrad(xd, dy, (k, k, C, K), stride=s, db=db)
+                if rep == 0:
+                    out[mode] = (y, dx, dw, db)
+                assert all(torch.equal(t0, t1) for t0, t1 in zip((y, dx, dw, db), out[mode])), "launch %d differs (mode %d)" % (rep, mode)
+        for name, t0, t1 in zip(("forward", "dgrad", "wgrad", "bias gradient"), out[0], out[7]):
+            assert torch.equal(t0, t1), "%s: %d elements differ" % (name, int((t0 != t1).sum()))
+        wref = torch.autograd.functional.vjp(lambda ww: O.conv2d_same(_r(x), ww, None, s), w.double() * 0, dy.double().cpu())[1]
+        err = (out[7][2].double().cpu() - wref).abs().max().item()
+        assert err <= 2e-5 * max(wref.abs().max().item(), 1e-6) + 1e-6, "wgrad off the oracle by %.3e (scale %.3e)" % (err, wref.abs().max().item())
+        ref = O.leaky_relu(O.conv2d_same(_r(x), _r(w), b.float().double(), s), 0.2)
+        _close_bf16(out[7][0], ref)
+    finally:
+        H.set_wave8(3)
+        H.set_large_tile(1, 0)
+        H.set_large_tile_wgrad(1, 0)
