@@ -384,7 +384,7 @@ def main():
         # dominant kernel class of this configuration: the conv-forward implicit GEMM on the pipe the dtype selects
         dom, peak, kname, fmul = {
             "f32": ("conv_fwd_mfma", PEAK_F32_MFMA_TFLOPS, "dpig::gather_gemm_kernel<false, true, false, 0> (conv fwd implicit GEMM, fp32 MFMA)", 1.0),
-            "bf16": ("conv_fwd_bf16", PEAK_BF16_MFMA_TFLOPS, "dpig::bhq_kernel / bhq32_kernel / bq_kernel / bh_kernel / bg_kernel (conv fwd implicit GEMM on bf16 tensors, v_mfma_f32_32x32x16_bf16)", 1.0),
+            "bf16": ("conv_fwd_bf16", PEAK_BF16_MFMA_TFLOPS, "dpig::bhq_kernel / bhq32_kernel / bq_kernel / bh_kernel / bg8_kernel (conv fwd implicit GEMM on bf16 tensors, v_mfma_f32_32x32x16_bf16)", 1.0),
             "bf16c": ("conv_fwd_mfma", PEAK_BF16_MFMA_TFLOPS, "conv fwd implicit GEMM, fp32 tensors rounded to bf16 on the way into LDS", 1.0),
             "bf16x3": ("conv_fwd_mfma", PEAK_BF16_MFMA_TFLOPS, "conv fwd implicit GEMM, fp32 tensors as two-term bf16 splits: 3 bf16 MFMAs per product "
                        "block (executed FLOPs = 3 x algorithmic)", 3.0),
