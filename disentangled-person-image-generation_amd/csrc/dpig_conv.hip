@@ -78,6 +78,7 @@ struct GGParams {
     int tap_nb, oy0, oys, ox0, oxs, w0, wa, wb;
     unsigned a_bytes, b_bytes;   // byte extents of A and B for the buffer descriptors
     int vec_epi;          // 1: every epilogue operand is 16-byte addressable (float4 path)
+    int red_lanes;        // split-K second pass: lanes sharing one float4 of the result (1, or 16 for few-tile many-split plans)
     int vec_a;            // 1: the gathered operand alone is 16-byte loadable (thin-N layers: B is not)
     unsigned mul_hrwr, shr_hrwr, mul_wr, shr_wr;   // magic numbers: row / (Hr*Wr) and rem / Wr without v_rcp sequences
 };
@@ -1162,12 +1163,45 @@ __global__ __launch_bounds__(256) void gather_gemm_reduce_multi_kernel(const GGM
     const GGParams& p = m.q[blockIdx.y];
     if (p.nsplit > 1) gather_gemm_reduce_body(p);
 }
+// A handful of output tiles cut into up to one split per CU (the fully connected layers: 16 .. 112 rows, reductions of 4096 .. 20480) leaves
+// the pass few threads with a long chain of dependent loads each (256 splits four at a time: ~19 us for a 16 x 64 result).  Such passes
+// give every float4 of the result to 16 lanes: lane j sums splits j, j + 16, ..., the 16 partial sums are combined in a fixed butterfly.
+static inline int reduce_lanes(int nsplit, long total4) {
+    static const bool off = getenv("DPIG_REDUCE_LANES") && atoi(getenv("DPIG_REDUCE_LANES")) <= 1;      // (A/B switch)
+    return (!off && nsplit >= 32 && total4 <= 32768) ? 16 : 1;
+}
+
 __device__ __forceinline__ void gather_gemm_reduce_body(const GGParams& p) {
     const long total = (long)p.M * p.Ncols;
     if (p.vec_epi) {
         const int n4 = p.Ncols >> 2;
         const long total4 = total >> 2;
         const float4* p4 = reinterpret_cast<const float4*>(p.partial);
+        if (p.red_lanes > 1) {
+            const int sub = threadIdx.x & 15;
+            const long ngroups = ((long)gridDim.x * blockDim.x) >> 4;
+            for (long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 4; i < total4; i += ngroups) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 4
+                for (int s = sub; s < p.nsplit; s += 16) {
+                    const float4 t = p4[(long)s * total4 + i];
+                    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+                }
+#pragma unroll
+                for (int o = 8; o >= 1; o >>= 1) {
+                    v.x += __shfl_xor(v.x, o, 16); v.y += __shfl_xor(v.y, o, 16);
+                    v.z += __shfl_xor(v.z, o, 16); v.w += __shfl_xor(v.w, o, 16);
+                }
+                if (sub == 0) {
+                    const int row = (int)(i / n4);
+                    const int col = (int)(i - (long)row * n4) * 4;
+                    float4 bv = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (p.bias) bv = *reinterpret_cast<const float4*>(p.bias + col);
+                    epi_vec4(p, row, col, v, bv);
+                }
+            }
+            return;
+        }
         for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total4; i += (long)gridDim.x * blockDim.x) {
             float4 v = p4[i];
 #pragma unroll 4
@@ -1904,6 +1938,7 @@ static int prepare_gg(GGParams& p, int nimg, long filter_elems, bool* vec, bool*
                 (!p.bias || aligned16(p.bias)) && (!p.res || (p.ldres % 4 == 0 && aligned16(p.res))) &&
                 (!p.mask || (p.ldmask % 4 == 0 && aligned16(p.mask))) &&
                 (!p.D2 || (p.ldd2 % 4 == 0 && aligned16(p.D2))) && (!p.partial || aligned16(p.partial));
+    p.red_lanes = p.vec_epi ? reduce_lanes(p.nsplit, (long)p.M * p.Ncols / 4) : 1;
     *narrow = p.Ncols <= 32;
     p.mtiles = cdiv(p.M, BM);
     p.ntiles = cdiv(p.Ncols, *narrow ? 32 : BN);
@@ -1915,7 +1950,8 @@ static int prepare_gg(GGParams& p, int nimg, long filter_elems, bool* vec, bool*
 }
 static int reduce_blocks(const GGParams& p) {
     const long total = (long)p.M * p.Ncols;
-    int blocks = cdiv(p.vec_epi ? total / 4 : total, 256);
+    const long threads = p.vec_epi ? (total / 4) * p.red_lanes : total;
+    const int blocks = cdiv(threads, 256);
     return blocks > 8 * kNumCU ? 8 * kNumCU : blocks;
 }
 static int launch_gg(GGParams& p, bool b_rowk, int nimg, long filter_elems, hipStream_t st, int pipe = 0) {
