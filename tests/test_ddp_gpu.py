@@ -100,8 +100,11 @@ def test_two_rank_step_equals_single_process_on_the_concatenated_batch(dev, back
     # each rank reports the mean over its half: their average is the batch-4 mean
     d_loss = 0.5 * (res[0]["d_loss"] + res[1]["d_loss"])
     g_loss = 0.5 * (res[0]["g_loss"] + res[1]["g_loss"])
-    assert abs(d_loss - float(od["d_loss"])) < 2e-4 * max(1.0, abs(float(od["d_loss"])))
-    assert abs(g_loss - float(og["g_loss"])) < 2e-4 * max(1.0, abs(float(og["g_loss"])))
+    # (the critic loss is taken AFTER the generator's update: with the bf16 exchange the weights whose summed gradient sits at the
+    # rounding noise floor move by +-lr the other way, and the penalty-dominated loss of a random-init critic (~340) sees that)
+    tol = 2e-4 if exchange == "f32" else 1e-3
+    assert abs(d_loss - float(od["d_loss"])) < tol * max(1.0, abs(float(od["d_loss"])))
+    assert abs(g_loss - float(og["g_loss"])) < tol * max(1.0, abs(float(og["g_loss"])))
     # Adam's first step moves every weight by lr * g / (|g| + eps) ~ lr * sign(g): the two-rank update must equal the
     # single-process one within 0.05 * lr on >= 99.5 % of the weights whose gradient is above the fp32 summation noise floor
     # (|g| > 1e-4 of the side's largest gradient; below it the SIGN of g -- hence the whole +-lr update -- is decided by the
