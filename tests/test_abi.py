@@ -58,6 +58,20 @@ def test_same_pad_and_version(lib):
         assert lib.same_pad(inp, k, s) == (eo, ep)
 
 
+def test_kernel_family_switches_validate_their_arguments(lib):
+    """The process-wide kernel-choice setters are host state only: callable without a device, out-of-range values are DPIG_EINVAL
+    with a message, valid ones leave the defaults' results unchanged (same plans, same bits: the GPU tests compare them)."""
+    h = lib.lib()
+    for fn, bad, good in ((h.dpig_conv_bf16_set_wave8, (-1, 8), (0, 7, 3)),):
+        for v in bad:
+            assert fn(v) != 0
+            assert b"wave8" in h.dpig_last_error()
+        for v in good:
+            assert fn(v) == 0
+    assert h.dpig_conv_bf16_set_large_tile(3, 0) != 0 and h.dpig_conv_bf16_set_large_tile(1, 3) != 0
+    assert h.dpig_conv_bf16_set_large_tile(1, 0) == 0 and h.dpig_conv_bf16_set_large_tile_wgrad(1, 0) == 0
+
+
 def _desc(lib, **kw):
     d = lib.DpigConvDesc()
     base = dict(N=16, H=8, W=4, C=768, K=768, R=3, S=3, stride=1, pad_t=-1, pad_l=-1, ldx=768, ldy=768)
