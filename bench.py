@@ -57,20 +57,18 @@ def cpu_baseline(target_seconds=20.0):
     from oracle import models as OM
     import torch.nn.functional as F
     ncpu = os.cpu_count() or 1
-    # torch-CPU conv throughput collapses when the thread pool oversubscribes the cores this process
-    # may actually use (a 256-thread pool took 266 s for one bs=1 step on the GPU box; 8 threads take
-    # 13 s here), so pick the pool size by a <1 s probe on a dec4-shaped conv and report it as `cores`.
-    xp = torch.randn(1, 256, 128, 64)
-    wp = torch.randn(256, 256, 3, 3)
-    best, cores = 0.0, 1
-    for nt in sorted(set(min(ncpu, c) for c in (4, 8, 16, 32, 64, 128))):
-        torch.set_num_threads(nt)
-        F.conv2d(xp, wp, padding=1)
-        t0 = time.time()
-        F.conv2d(xp, wp, padding=1)
-        rate = 1.0 / max(time.time() - t0, 1e-6)
-        if rate > best * 1.1:
-            best, cores = rate, nt
+    # Pool size = the PHYSICAL cores this process may run on (round 4's probe-picked pool gave 0.37 .. 0.90 img/s from box to box:
+    # torch-CPU conv throughput collapses when the pool oversubscribes the cores, and two SMT threads of a core share its FMA units).
+    try:
+        import psutil
+        phys = psutil.cpu_count(logical=False) or ncpu
+    except Exception:
+        phys = max(1, ncpu // 2)
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except Exception:
+        avail = ncpu
+    cores = max(1, min(phys, avail, 64))          # (beyond 64 threads the bs=4 convs have too few rows per thread to scale)
     torch.set_num_threads(cores)
 
     P = OM.ParamStore(seed=1, dtype=torch.float32)
@@ -93,7 +91,7 @@ def cpu_baseline(target_seconds=20.0):
     one_step(ob1)              # bs=1 probe that sizes the sample
     t1 = time.time() - t0
     B = 4                      # BASELINE configs[0]: the reference's CPU-runnable case is bs=4
-    reps = int(max(1, min(8, round(target_seconds / max(4 * t1, 1e-3)))))
+    reps = int(max(3, min(8, round(target_seconds / max(4 * t1, 1e-3)))))     # >= 3 timed steps
     ob = OM.batch_to_torch(synthetic.make_batch(B, seed=8), dtype=torch.float32)
     t0 = time.time()
     for _ in range(reps):
@@ -101,8 +99,8 @@ def cpu_baseline(target_seconds=20.0):
     t = time.time() - t0
     return {"value": round(B * reps / t, 4), "unit": "images/sec", "cores": cores, "kind": "port",
             "sample": "%d G+D steps of the oracle graph (torch-CPU fp32: g_loss fwd+bwd + TF-Adam update, d_loss fwd+bwd + "
-                      "TF-Adam update) at bs=%d on %d threads (the pool size a probe found fastest) of %d logical CPUs: "
-                      "%.1f s" % (reps, B, cores, ncpu, t)}
+                      "TF-Adam update) at bs=%d on %d threads (= physical cores available to the process, capped at 64) of %d "
+                      "logical CPUs: %.1f s" % (reps, B, cores, ncpu, t)}
 
 
 INFO_RUNS = [   # (key, BASELINE config it informs, bench.py arguments)
@@ -122,6 +120,16 @@ INFO_RUNS = [   # (key, BASELINE config it informs, bench.py arguments)
      ["--workload", "market128-sampling", "--dtype", "bf16", "--steps", "20", "--warmup", "3"]),
     ("df256_wgan_gp_bf16", "configs[4]: DeepFashion 256x256 bs=8 per GPU, MODE='wgan-gp', bf16 -- one GPU's share of the 8-GPU job",
      ["--workload", "df256-wgan-gp", "--dtype", "bf16", "--steps", "10", "--warmup", "2"]),
+    ("df256_wgan_gp_bf16_bs4", "configs[4] at its OWN per-GPU batch: global 32 over 8 GPUs = 4 per GPU (SURVEY 8e) -- half the rows per layer of the "
+     "bs=8 line above", ["--workload", "df256-wgan-gp", "--dtype", "bf16", "--batch", "4", "--steps", "10", "--warmup", "2"]),
+    ("market128_host_input_f32", "SURVEY 8(f-1): the headline step with both batches starting every step in pinned HOST memory as the records' "
+     "keypoints + image + mask + boxes, packed into one buffer, uploaded one step ahead on a copy stream (prefetch.DevicePrefetcher)",
+     ["--workload", "market128", "--host-input", "keypoints-packed", "--steps", "20", "--warmup", "5"]),
+    ("market128_tfrecord_f32", "SURVEY 8(f-1): the headline step fed from serialized tf.train.Example records (the reference's schema, "
+     "datasets/market1501.py:79-141): tfrecord.RecordFeeder decodes on 4 host threads -> DevicePrefetcher -> step",
+     ["--workload", "market128", "--host-input", "tfrecord", "--steps", "20", "--warmup", "5"]),
+    ("market128_tfrecord_bf16", "the same record-fed pipeline at bf16 (a 5x shorter step for the host decode to keep up with)",
+     ["--workload", "market128", "--dtype", "bf16", "--host-input", "tfrecord", "--steps", "30", "--warmup", "5"]),
 ]
 
 
@@ -138,7 +146,7 @@ def info_lines():
             d = json.loads(js[-1])
             out[key] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"],
                         "steps": d["steps"], "warmup": d["warmup"], "config": d["config"], "informs": informs,
-                        "roofline": d.get("roofline")}
+                        "input_feed": d.get("input_feed"), "roofline": d.get("roofline")}
         except Exception as e:          # an information line must never take the headline down
             out[key] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
     return out
@@ -162,14 +170,18 @@ def main():
     ap.add_argument("--no-info-lines", action="store_true",
                     help="headline run only: skip the information lines (df256 / stage-II / Market in bf16, Market wgan-gp) that "
                          "are measured in sub-processes after the headline and embedded under `info_lines`")
-    ap.add_argument("--host-input", nargs="?", const="prefetch", default=None, choices=["prefetch", "serial", "keypoints", "keypoints-serial", "keypoints-packed", "packed"],
+    ap.add_argument("--host-input", nargs="?", const="prefetch", default=None, choices=["prefetch", "serial", "keypoints", "keypoints-serial", "keypoints-packed", "packed", "tfrecord"],
                     help="information line: both batches start every step in pinned HOST memory, so the timed region "
                          "includes their PCIe upload (the BASELINE value is quoted with inputs resident in HBM). "
                          "'prefetch' uploads on a copy stream one step ahead (dpig_amd.prefetch), 'serial' on the compute stream, "
                          "'keypoints' = prefetch of the 18 (row, col, visibility) triplets instead of the dense pose maps, "
                          "rasterised on the device (what tfrecord.batch_from_examples feeds); 'keypoints-serial' = the same upload on "
                          "the compute stream, no second queue; 'packed' / 'keypoints-packed' = prefetch with the batch packed "
-                         "into one pinned buffer and moved by one copy")
+                         "into one pinned buffer and moved by one copy; 'tfrecord' = the batches are DECODED every step from serialized "
+                         "tf.train.Example records (tfrecord.RecordFeeder, 4 host threads) and uploaded packed, one step ahead")
+    ap.add_argument("--copy-input", action="store_true",
+                    help="resident batches are separate device tensors copied into the graphs' static inputs every step (rounds 1-3's "
+                         "methodology; the default since round 4 hands the graphs' own input buffers to the step: no per-step copy)")
     ap.add_argument("--pose", default="keypoints", choices=["keypoints", "map"],
                     help="keypoints (default): the resident batch holds pose_rcv, the [B,18,3] keypoints of the records, and the "
                          "generator's first conv consumes them directly (the reference rasterises the target map inside the graph, "
@@ -222,7 +234,8 @@ def main():
         tr = getattr(importlib.import_module("dpig_amd." + wl_mod), wl_cls)(cfg, dev)
     batch_g = synthetic.to_device(synthetic.make_batch(B, img_H=cfg.img_H, img_W=cfg.img_W, seed=100 + 2 * rank), dev)
     batch_d = synthetic.to_device(synthetic.make_batch(B, img_H=cfg.img_H, img_W=cfg.img_W, seed=101 + 2 * rank), dev)
-    if args.pose == "keypoints" and not args.host_input and args.workload not in ("market128-stage2", "market128-sampling"):
+    kp_host = bool(args.host_input) and (args.host_input == "tfrecord" or args.host_input.startswith("keypoints"))
+    if args.pose == "keypoints" and (not args.host_input or kp_host) and args.workload not in ("market128-stage2", "market128-sampling"):
         batch_g, batch_d = synthetic.keypoints_only(batch_g), synthetic.keypoints_only(batch_d)
     if sampling:
         tr.run(batch_g, batch_g["pose_rcv"])  # builds the graph's variables (random init: there are no checkpoints here)
@@ -232,17 +245,43 @@ def main():
     if not args.no_graph:
         if args.workload == "market128-stage2":
             tr.enable_graphs(batch_g)         # one hipGraph per (side, optimizer op): frozen-encoder forward + mapper / critic update
-            batch_g = tr.static_batch()       # (the resident batch is the graphs' input buffer)
+            if not args.copy_input:
+                batch_g = tr.static_batch()   # (the resident batch is the graphs' input buffer)
         else:
             tr.enable_graphs(batch_g, batch_d)    # fwd+bwd+all-reduce+Adam of each optimizer op = one hipGraph
-            if not args.host_input and hasattr(tr, "static_batches"):
+            if not args.host_input and not args.copy_input and hasattr(tr, "static_batches"):
                 # the resident batches ARE the graphs' input buffers (what a device-side producer fills): no per-step device copy
                 batch_g, batch_d = tr.static_batches()
 
     if args.host_input == "serial" and args.no_graph:
         raise SystemExit("--host-input needs the hipGraph path (the eager path takes device batches)")
     feed_g = feed_d = None
-    if args.host_input:                       # the replayed graphs read their own static buffers; _feed copies into them
+    feeders = []
+    if args.host_input == "tfrecord":
+        # serialized records of the reference's schema (datasets/market1501.py:79-141; raw image bytes) built once from synthetic
+        # batches; EVERY step decodes 2 x B of them on host threads (tfrecord.RecordFeeder), packs, uploads one step ahead
+        from dpig_amd import tfrecord as T
+        from dpig_amd.prefetch import DevicePrefetcher
+
+        def records(seed):
+            nb = synthetic.make_batch(4 * B, img_H=cfg.img_H, img_W=cfg.img_W, seed=seed)
+            out = []
+            for i in range(4 * B):
+                ex = {"image_format": [b"raw"], "image_height": np.array([cfg.img_H]), "image_width": np.array([cfg.img_W])}
+                rcv = np.asarray(nb["pose_rcv"][i])
+                for sfx in ("0", "1"):
+                    img = np.clip(np.rint(np.asarray(nb["x"][i]) * 127.5 + 127.5), 0, 255).astype(np.uint8)
+                    ex.update({"image_raw_" + sfx: [img.tobytes()], "pose_peaks_%s_rcv" % sfx: rcv.reshape(-1).astype(np.float32),
+                               "pose_mask_r6_" + sfx: np.asarray(nb["mask_r6"][i]).reshape(-1).astype(np.int64),
+                               "part_bbox_" + sfx: np.asarray(nb["part_bbox"][i]).reshape(-1).astype(np.int64),
+                               "part_vis_" + sfx: np.asarray(nb["part_vis"][i]).reshape(-1).astype(np.int64)})
+                out.append(T.encode_example(ex))
+            return out
+        for seed in (400 + 2 * rank, 401 + 2 * rank):
+            feeders.append(T.RecordFeeder(records(seed), B, which=0, img_H=cfg.img_H, img_W=cfg.img_W, workers=4, depth=4, pin=True))
+        feed_g = DevicePrefetcher(feeders[0], dev, packed=True)
+        feed_d = DevicePrefetcher(feeders[1], dev, packed=True)
+    elif args.host_input:                     # the replayed graphs read their own static buffers; _feed copies into them
         batch_g = {k: v.cpu().pin_memory() for k, v in batch_g.items()}
         batch_d = {k: v.cpu().pin_memory() for k, v in batch_d.items()}
         if args.host_input != "serial":
@@ -258,7 +297,10 @@ def main():
                     b["pose_rcv"] = torch.from_numpy(rcv.reshape(B, 54).astype(np.float32)).pin_memory()
                     return b
 
-                def rasterised(feed):
+                def rasterised(feed):             # --pose map: the graphs consume the dense target map, rasterised on the device
+                    if "pose" not in tr.static_batches()[0]:
+                        yield from feed               # (default: the keypoints feed the generator's first conv directly)
+                        return
                     for b in feed:
                         b = dict(b)
                         b["pose"] = utils.pose_target_from_rcv(b.pop("pose_rcv"), 18, False, cfg.img_H, cfg.img_W)
@@ -380,6 +422,7 @@ def main():
             _A.TWO_STREAM[0], _A.D_OVERLAP[0] = side
         tr._graphs = graphs
         recs = [(r[0], r[1], r[2].elapsed_time(r[3]) * 1e-3) for r in H.PROFILE]
+        labels = [(r[0], r[4]) for r in H.PROFILE if len(r) > 4]
         H.PROFILE = None
         # dominant kernel class of this configuration: the conv-forward implicit GEMM on the pipe the dtype selects
         dom, peak, kname, fmul = {
@@ -394,18 +437,33 @@ def main():
         flops = sum(f for f, _ in fwd) * fmul
         secs = max(sum(t for _, t in fwd), 1e-12)
         achieved = flops / secs / 1e12
+        # ALGORITHMIC bytes of the same launches: each operand once -- input map + filter + output map at the storage width
+        esz = 2 if args.dtype == "bf16" else 4
+        def alg_bytes_of(classes):
+            a = [esz * (n * h * w * c + (n * 4 * h * w * kk if up else n * (-(-h // st)) * (-(-w // st)) * kk) + r * r * c * kk)
+                 for (k, (n, h, w, c, kk, r, st, up)) in labels if k in classes]
+            return sum(a) / max(len(a), 1)
+        alg_bytes = alg_bytes_of((dom,))
+        # HBM bytes per launch of that kernel class from the FETCH_SIZE / WRITE_SIZE passes of THIS command under rocprofv3
+        # (scripts/pmc_traffic.sh -> profiles/roofline_traffic.json; separate --pmc passes, FETCH_SIZE doubled per the guide's gfx950 note)
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
-        if headline and os.path.exists(tpath):
+        if os.path.exists(tpath):
             try:
-                tj = json.load(open(tpath))
-                traffic = tj.get("conv_fwd_hbm_bytes_per_launch")
-                traffic_src = "static: FETCH_SIZE / WRITE_SIZE passes of this command under rocprofv3 (%s), not re-measured in this run" % tj.get("source")
+                ent = json.load(open(tpath)).get("entries", {}).get("%s/%s" % (args.workload, args.dtype))
+                if ent and B == wl_batch:
+                    traffic = ent.get("hbm_bytes_per_launch")
+                    alg_bytes = alg_bytes_of(tuple(ent.get("classes", [dom])))      # (the bf16 kernels serve forward AND dgrad launches)
+                    traffic_src = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at %s (%s), averaged over the launches of %s "
+                                   "[classes %s]; a per-round static figure, not re-measured inside this run"
+                                   % (ent.get("head", "?"), ent.get("source"), ", ".join(ent.get("kernels", [])), "+".join(ent.get("classes", []))))
             except Exception:
                 traffic = None
         roofline = {"bound": "mfma", "kernel": kname,
                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": int(alg_bytes),
+                    "traffic_over_algorithmic": round(traffic / alg_bytes, 2) if (traffic and alg_bytes) else None,
                     "launches_per_step": len(fwd) // nrep,
                     "flops_per_launch": flops / nl, "avg_launch_us": round(secs / nl * 1e6, 2),
                     "time_share_of_step": round(secs / nrep / (ms_per_step * 1e-3), 3),
@@ -438,6 +496,7 @@ def main():
                        "global_batch": world * B, "parallelism": "dp%d" % world},
             "achieved_alg_tflops": round(ALG_GFLOP_PER_IMG * value / 1e3, 2) if headline else None,
             "losses": {k: float(v) for k, v in out.items() if hasattr(v, "numel") and v.numel() == 1 and not sampling},
+            "input_feed": ("host:%s" % args.host_input) if args.host_input else ("copy" if (args.copy_input or args.no_graph) else "static"),
             "roofline": roofline, "cpu_baseline": cpu,
             "build_mode": __graft_entry__.BUILD_MODE,      # "compiled": this process rebuilt the library; "reused": the shipped .so was fresh
         }

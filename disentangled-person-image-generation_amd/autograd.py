@@ -88,10 +88,17 @@ class SegmentedCapture(object):
             _SEG[0] = self
             try:
                 out = fn()
-            finally:
+            except BaseException:
                 _SEG[0] = None
                 if self.cur is not None:
-                    self._end()
+                    try:                                  # a broken capture cannot always be ended: keep the ORIGINAL error
+                        self._end()
+                    except Exception:
+                        self.cur = None
+                raise
+            _SEG[0] = None
+            if self.cur is not None:
+                self._end()
         torch.cuda.current_stream(self.device).wait_stream(self.stream)
         return out
 
@@ -174,9 +181,12 @@ class side_branch(object):
 def join_side_streams(device):
     """Make the current stream wait for every side stream of `device`: after a PARTIAL backward pass (torch.autograd.grad towards a
     tensor produced inside a side_branch) the returned gradients may have been written on a side stream."""
+    device = torch.device(device)
+    # a bare 'cuda' device has index None while the side streams are keyed by the tensors' (always concrete) device index
+    want = device.index if device.index is not None else torch.cuda.current_device()
     cur = torch.cuda.current_stream(device)
     for (idx, _), st in _SIDE_STREAMS.items():
-        if idx == device.index:
+        if idx == want:
             cur.wait_stream(st)
 
 

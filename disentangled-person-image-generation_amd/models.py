@@ -39,26 +39,34 @@ def _cut(name, *tensors):
     return tensors[0] if len(tensors) == 1 else tensors
 
 
-def encoder_stage_of(param_name):
+def encoder_stage_of(param_name, marks=None):
     """'stem' | 'roi' | 'bg' for a variable of the encoders below, from its TF-slim name (`<scope>/Conv_k/weights`, ...) and the scope
-    counters recorded at the stage boundaries; None for any other variable."""
-    if "E.towers_in" not in A.MARKS:
+    counters recorded at the stage boundaries (`marks`: a snapshot of autograd.MARKS taken right after the build forward; default the
+    live dict); None for any other variable -- another scope, a leaf that is neither `Conv[_k]` nor `fully_connected[_k]`, a
+    non-numeric suffix -- so that the caller falls back to ONE 'encoder' stage instead of misfiling the variable."""
+    marks = A.MARKS if marks is None else marks
+    if "E.towers_in" not in marks:
         return None
-    path, conv_t, fc_t = A.MARKS["E.towers_in"]
+    path, conv_t, fc_t = marks["E.towers_in"]
     if not param_name.startswith(path + "/"):
         return None
     leaf = param_name[len(path) + 1:].split("/")[0]
-    base, _, k = leaf.partition("_")
-    if base == "fully" :                                  # fully_connected[_k]
-        base, k = "fully_connected", leaf[len("fully_connected"):].lstrip("_")
-    k = int(k) if k else 0
+    for base in ("Conv", "fully_connected"):
+        if leaf == base:
+            k = 0
+            break
+        if leaf.startswith(base + "_") and leaf[len(base) + 1:].isdigit():
+            k = int(leaf[len(base) + 1:])
+            break
+    else:
+        return None
 
     def before(mark):
-        _, c, f = A.MARKS[mark]
+        _, c, f = marks[mark]
         return k < (c if base == "Conv" else f)
     if before("E.towers_in"):
         return "stem"
-    if "E.bg_begin" in A.MARKS and not before("E.bg_begin"):
+    if "E.bg_begin" in marks and not before("E.bg_begin"):
         return "bg"
     return "roi"
 

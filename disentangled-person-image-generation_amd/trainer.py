@@ -738,7 +738,9 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
         single-tower encoder has no background stage).  [(name, first param index, one past the last)]; the encoder is cut at the
         tensors the builders record (autograd.CUTS) into the variables their TF-slim names assign to each part."""
         n0, params = self._n_dec, self.G_flat.params
-        kinds = [models.encoder_stage_of(p.dpig_name) for p in params[n0:]]
+        # (the scope counters are a process-global that every encoder build overwrites: take THIS trainer's, right after its own build)
+        self._marks = dict(A.MARKS)
+        kinds = [models.encoder_stage_of(p.dpig_name, self._marks) for p in params[n0:]]
         stages = [("generator", 0, n0)]
         if not kinds or any(k is None for k in kinds):
             return stages + ([("encoder", n0, len(params))] if kinds else [])

@@ -137,6 +137,7 @@ class DPIG_Encoder_subSampleAppNetFgBg_GAN_BodyROI(object):
         snap = [(f.flat.clone(), f.m.clone(), f.v.clone()) for pair in self.flats.values() for f in pair]
         osnap = [(o, o.t, o.state.clone() if hasattr(o, "state") else None) for pair in self.opts.values() for o in pair]
         rng = torch.cuda.get_rng_state(dev)
+        lrs = (self.g_lr.clone(), self.d_lr.clone())          # (the eager step halves them in place at the lr_update_step boundary)
         side_stream = torch.cuda.Stream(device=dev)
         side_stream.wait_stream(torch.cuda.current_stream(dev))
         step0, self._graphs = self.step, None
@@ -154,6 +155,7 @@ class DPIG_Encoder_subSampleAppNetFgBg_GAN_BodyROI(object):
                 o.t = t
                 if st is not None:
                     o.state.copy_(st)
+            self.g_lr.copy_(lrs[0]); self.d_lr.copy_(lrs[1])
         torch.cuda.set_rng_state(rng, dev)
         torch.cuda.synchronize(dev)
         graphs, pool = {}, None
@@ -175,8 +177,12 @@ class DPIG_Encoder_subSampleAppNetFgBg_GAN_BodyROI(object):
 
     def _feed(self, batch):
         for k, v in batch.items():
-            if self._static[k].data_ptr() != v.data_ptr():
-                self._static[k].copy_(v, non_blocking=True)
+            st = self._static.get(k)
+            if st is None or tuple(st.shape) != tuple(v.shape) or st.dtype != v.dtype:
+                raise RuntimeError("train_step: batch field %r (%s) does not match the captured graphs' input (%s)" % (
+                    k, tuple(v.shape), None if st is None else tuple(st.shape)))
+            if st.data_ptr() != v.data_ptr():
+                st.copy_(v, non_blocking=True)
 
     def train_step(self, batch):
         """trainer.py:821-845.  `batch`: one batch, or a sequence -- every `sess.run(d_optim_embs)` of the reference dequeues a fresh

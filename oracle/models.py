@@ -412,14 +412,15 @@ def stage2_256_losses(P, real, z, hidden=512):
     return -d_fake.mean(), d_fake.mean() - d_real.mean(), fake
 
 
-def stage1_256_forward(P, batch, hidden_num=128, z_num=64, repeat_num=6):
-    """trainer_256.py:31-66: E = BodyROIVis(repeat_num+1, roi 64); G with repeat_num-1 levels; D on [x; G]."""
+def stage1_256_forward(P, batch, hidden_num=128, z_num=64, repeat_num=6, taps=None):
+    """trainer_256.py:31-66: E = BodyROIVis(repeat_num+1, roi 64); G with repeat_num-1 levels; D on [x; G].
+    `taps` (a dict) additionally receives the generator's G.stem / G.z / G.dec* activations and the critic's pre-norm maps."""
     x = batch["x"]
     B, H, W, _ = x.shape
     embs = encoder_roi(P, x, batch["part_bbox"], batch["part_vis"], 7, 32, repeat_num + 1, hidden_num, roi_size=64)
     embs_rep = embs.reshape(B, 1, 1, -1).expand(B, H, W, embs.shape[1])
-    G, _ = generator_uae(P, embs_rep, batch["pose"], 3, z_num, repeat_num - 1, hidden_num)
-    D_z = dcgan_discriminator(P, torch.cat([x, G], dim=0), "dcgan")
+    G, _ = generator_uae(P, embs_rep, batch["pose"], 3, z_num, repeat_num - 1, hidden_num, taps=taps)
+    D_z = dcgan_discriminator(P, torch.cat([x, G], dim=0), "dcgan", taps=taps)
     D_pos, D_neg = torch.split(D_z, D_z.shape[0] // 2)
     g_only, d_loss = gan_loss("dcgan", D_pos, D_neg)
     l1 = (G - x).abs().mean()

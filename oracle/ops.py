@@ -35,6 +35,91 @@ def conv2d_same(x, w, b=None, stride=1):
     return y
 
 
+# ---- the same conv evaluated at SAMPLED positions (full-size layers: a dense fp64 conv of a 256x256 batch takes minutes on the
+# host, a few thousand output positions take seconds).  Same definitions as conv2d_same / its autograd gradients -- pinned against
+# them on small dense problems by tests/test_oracle.py::test_sampled_conv_equals_dense -- restricted to the requested elements.
+# Elements are gathered in the tensors' own dtype (a 537-MB fp32 batch is not copied to fp64) and all arithmetic is float64.
+def _sampled_patches(x, kh, kw, stride, n, oy, ox, upsample2x):
+    """[P, kh, kw, C] input windows behind output positions (n, oy, ox) of conv2d_same (zero where the window is padding)."""
+    N, H, W, C = x.shape
+    if upsample2x:                       # 1x1 conv on the nearest-2x upsampled map (models.py:569-570): source pixel (oy//2, ox//2)
+        assert kh == 1 and kw == 1 and stride == 1
+        return x[n, oy // 2, ox // 2].double().reshape(-1, 1, 1, C)
+    _, pt, _ = same_pad(H, kh, stride)
+    _, pl, _ = same_pad(W, kw, stride)
+    P = n.shape[0]
+    out = torch.zeros((P, kh, kw, C), dtype=torch.float64)
+    for r in range(kh):
+        iy = oy * stride + r - pt
+        for s in range(kw):
+            ix = ox * stride + s - pl
+            ok = (iy >= 0) & (iy < H) & (ix >= 0) & (ix < W)
+            out[ok, r, s] = x[n[ok], iy[ok], ix[ok]].double()
+    return out
+
+
+def conv2d_same_sampled(x, w, b, stride, n, oy, ox, upsample2x=False):
+    """conv2d_same(x, w, b, stride)[n, oy, ox, :] for index vectors (n, oy, ox): [P, Cout].  With upsample2x the conv is the 1x1
+    conv of the nearest-2x upsampled x (utils.py:61-72 + models.py:570) and (oy, ox) index the upsampled grid."""
+    kh, kw, C, K = w.shape
+    pat = _sampled_patches(x, kh, kw, stride, n, oy, ox, upsample2x)
+    y = pat.reshape(pat.shape[0], -1) @ w.double().reshape(kh * kw * C, K)
+    return y if b is None else y + b.double()
+
+
+def conv2d_same_dgrad_sampled(dy, w, in_shape, stride, n, iy, ix, upsample2x=False):
+    """(d conv2d_same / d x)^T dy at input positions (n, iy, ix): [P, Cin].  dy is the full output gradient [N, Ho, Wo, K]."""
+    kh, kw, C, K = w.shape
+    N, H, W, _ = in_shape
+    P = n.shape[0]
+    out = torch.zeros((P, C), dtype=torch.float64)
+    w = w.double()
+    if upsample2x:                       # every low-resolution pixel feeds its 2 x 2 replicas
+        for a in range(2):
+            for b2 in range(2):
+                out += dy[n, 2 * iy + a, 2 * ix + b2].double() @ w[0, 0].t()
+        return out
+    Ho, pt, _ = same_pad(H, kh, stride)
+    Wo, pl, _ = same_pad(W, kw, stride)
+    for r in range(kh):
+        ty = iy + pt - r                 # oy * stride = iy + pt - r
+        for s in range(kw):
+            tx = ix + pl - s
+            ok = (ty >= 0) & (tx >= 0) & (ty % stride == 0) & (tx % stride == 0) & (ty // stride < Ho) & (tx // stride < Wo)
+            if bool(ok.any()):
+                out[ok] += dy[n[ok], ty[ok] // stride, tx[ok] // stride].double() @ w[r, s].t()
+    return out
+
+
+def conv2d_same_wgrad_sampled(x, dy, wshape, stride, taps, ci, co, upsample2x=False):
+    """(d conv2d_same / d w)^T dy for the filter taps `taps` (list of (r, s)) and the channel index vectors ci, co:
+    [len(taps), len(ci), len(co)], each element the FULL sum over the batch's pixels."""
+    kh, kw, C, K = wshape
+    N, H, W, _ = x.shape
+    dys = dy[..., co].double()
+    out = []
+    if upsample2x:
+        assert kh == 1 and kw == 1 and taps == [(0, 0)]
+        pooled = dys[:, 0::2, 0::2] + dys[:, 0::2, 1::2] + dys[:, 1::2, 0::2] + dys[:, 1::2, 1::2]
+        return (x[..., ci].double().reshape(-1, len(ci)).t() @ pooled.reshape(-1, len(co)))[None]
+    Ho, pt, _ = same_pad(H, kh, stride)
+    Wo, pl, _ = same_pad(W, kw, stride)
+    xs = x[..., ci].double()
+    for (r, s) in taps:
+        # output rows oy whose source row oy * stride + r - pt lies inside the image (same for columns)
+        oy = [o for o in range(Ho) if 0 <= o * stride + r - pt < H]
+        ox = [o for o in range(Wo) if 0 <= o * stride + s - pl < W]
+        if not oy or not ox:
+            out.append(torch.zeros((len(ci), len(co)), dtype=torch.float64))
+            continue
+        ys = slice(oy[0] * stride + r - pt, oy[-1] * stride + r - pt + 1, stride)
+        xsl = slice(ox[0] * stride + s - pl, ox[-1] * stride + s - pl + 1, stride)
+        a = xs[:, ys, xsl].reshape(-1, len(ci))
+        g = dys[:, oy[0]:oy[-1] + 1, ox[0]:ox[-1] + 1].reshape(-1, len(co))
+        out.append(a.t() @ g)
+    return torch.stack(out)
+
+
 def conv2d_transpose_same(x, w, b=None, stride=2):
     """tf.nn.conv2d_transpose(x, w, out=[N,2H,2W,Cout], strides 2, 'SAME') + bias
     (tflib/ops/deconv2d.py:89-112).  w is (k,k,Cout,Cin).  Defined as the gradient of

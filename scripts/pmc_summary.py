@@ -29,12 +29,30 @@ with open(os.path.join(root, "profiles", tag + "_pmc_traffic.md"), "w") as fh:
     fh.write("| kernel | launches | raw FETCH KB/launch | read MB/launch (corrected) | write MB/launch | total MB/launch |\n|---|---|---|---|---|---|\n")
     for k, n, raw, rd, wr, tot in rows[:16]:
         fh.write("| `%s` | %d | %.0f | %.2f | %.2f | %.2f |\n" % (short(k), n, raw / 1024.0, rd / 1e6, wr / 1e6, tot / 1e6))
-js = {}
-for k, n, raw, rd, wr, tot in rows:
-    if "gather_gemm_kernel<false, true, false, 0>" in k: js["conv_fwd_hbm_bytes_per_launch"] = round(tot)
-    if "gather_gemm_kernel<true, true, false, 0>" in k: js["conv_dgrad_hbm_bytes_per_launch"] = round(tot)
-    if "wgrad_kernel<true, false, false, true, 0>" in k: js["conv_wgrad_hbm_bytes_per_launch"] = round(tot)
-js["source"] = "profiles/%s_pmc_traffic.md" % tag
-if not os.environ.get("DPIG_KEEP_TRAFFIC_JSON") and "conv_fwd_hbm_bytes_per_launch" in js:      # (only the headline workload owns the file)
-    json.dump(js, open(os.path.join(root, "profiles", "roofline_traffic.json"), "w"), indent=1)
-print(js)
+# profiles/roofline_traffic.json: {"entries": {"<workload>/<dtype>": {hbm_bytes_per_launch of the dominant kernel class, ...}}} -- what
+# bench.py reports as roofline.traffic for that workload (DPIG_TRAFFIC_KEY names the entry; the dtype picks the kernel family)
+key = os.environ.get("DPIG_TRAFFIC_KEY", "market128/f32")
+dtype = key.split("/")[1]
+FAMILY = {"f32": (["gather_gemm_kernel<false, true, false, 0>"], ["conv_fwd_mfma"]),
+          "bf16": (["bhq_kernel", "bhq32_kernel", "bq_kernel", "bh_kernel", "bg8_kernel", "bg_kernel", "bg8_multi_kernel", "bg_multi_kernel"],
+                   ["conv_fwd_bf16", "conv_dgrad_bf16"])}
+pats, classes = FAMILY.get(dtype, FAMILY["f32"])
+def base(n):                      # "dpig::bfk::bq_kernel<2, 4>" -> "bq_kernel"
+    n = short(n)
+    n = n[:n.index("<")] if "<" in n else n
+    return n.split("::")[-1]
+sel = [r for r in rows if (base(r[0]) in pats if dtype != "f32" else any(p_ in r[0] for p_ in pats))]
+path = os.path.join(root, "profiles", "roofline_traffic.json")
+try:
+    js = json.load(open(path))
+except Exception:
+    js = {}
+if "entries" not in js:
+    js = {"entries": {}}
+if sel:
+    nl = sum(r[1] for r in sel)
+    head = os.popen("git -C %s rev-parse --short HEAD 2>/dev/null" % root).read().strip() or os.environ.get("DPIG_HEAD", "?")
+    js["entries"][key] = {"hbm_bytes_per_launch": round(sum(r[1] * r[5] for r in sel) / nl), "launches": nl, "classes": classes,
+                          "kernels": sorted(set(short(r[0]) for r in sel)), "source": "profiles/%s_pmc_traffic.md" % tag, "head": head}
+    json.dump(js, open(path, "w"), indent=1)
+print(key, js["entries"].get(key))

@@ -186,3 +186,137 @@ def test_bf16_storage_full_size_layers(dev, layer):
     assert torch.equal(H.conv2d_fwd(xb, w, None, stride=s, upsample2x=up), yb)
     assert torch.equal(H.conv2d_dgrad(dyb, w, (N, Hh, W, C), stride=s, upsample2x=up), dxb)
     assert torch.equal(H.conv2d_wgrad(xb, dyb, (k, k, C, K), stride=s, upsample2x=up), dw)
+
+
+# ---- sampled fp64 oracle at FULL size (VERDICT r4 "missing" 3) ----------------------------------------------------------------
+# Every kernel family that serves a DeepFashion / stage-II shape is compared with oracle.ops.conv2d_same -- not with another HIP
+# kernel: the oracle is evaluated in fp64 on >= 4096 sampled output positions (forward), input positions (dgrad) and on sampled
+# (tap, ci, co) filter elements with their FULL pixel sums (wgrad); oracle.ops.conv2d_same*_sampled are pinned to the dense
+# conv2d_same and its autograd gradients by tests/test_oracle.py::test_sampled_conv_equals_dense.  Operands are bf16-representable,
+# so ONE reference serves the fp32 kernels (bar: fp32 accumulation, 1e-4 / 2e-4 of max|ref| as for the Market decoder layers above)
+# and the bf16-storage kernels (bar: one rounding of the result, 2^-8 |ref| + 5e-5 max|ref|; filter gradients are fp32).
+SAMPLED_LAYERS = BF16_LAYERS + [
+    ("df dec2 3x3 768ch @64x64 (384 tiles of 256x256)", 8, 64, 64, 768, 768, 3, 1, False),
+    ("df dec1 3x3 1024ch @32x32", 8, 32, 32, 1024, 1024, 3, 1, False),
+    ("df dec0 3x3 768ch @16x16", 8, 16, 16, 768, 768, 3, 1, False),
+    ("df roi tower N=56 8x8x512", 56, 8, 8, 512, 512, 3, 1, False),
+    ("df image conv 256->3 @256x256", 8, 256, 256, 256, 3, 3, 1, False),
+    ("df stem 3->128 @256x256", 8, 256, 256, 3, 128, 3, 1, False),
+    ("df critic stem 5x5 s2 3->64 on the [x;G] pair", 16, 256, 256, 3, 64, 5, 2, False),
+    ("stage-II roi tower N=448 6x6x512", 448, 6, 6, 512, 512, 3, 1, False),
+]
+# (id, arithmetic, forward/dgrad tile family (mode, variant), wgrad tile family, eight-wave bits)
+SAMPLED_VARIANTS = [
+    ("f32", "f32", None, None, None),                        # gather_gemm_kernel / wgrad_kernel / thin3_* / fewc_* on fp32 tensors
+    ("bf16-auto", "bf16", (1, 0), (1, 0), 3),                 # what the trainers run: bhq / bhq32 / bq / bh / bg8, bwq / bw8, thin bf16
+    ("bf16-128tile", "bf16", (0, 0), (0, 0), 3),              # bh_kernel / bg8_kernel, bw8_kernel
+    ("bf16-128tile-4wave", "bf16", (0, 0), (0, 0), 0),        # bh_kernel / bg_kernel, bw_kernel
+    ("bf16-256x256", "bf16", (2, 1), (2, 1), 3),              # bhq_kernel where eligible else bq_kernel<2,4>; bwq_kernel<2,4>
+    ("bf16-512x128", "bf16", (2, 2), (2, 2), 3),              # bhq32_kernel where eligible else bq_kernel<4,2>; bwq_kernel<4,2>
+]
+
+
+def _sample_positions(N, Hh, W, count, gen):
+    """`count` positions: uniformly random + every corner / border class of the first and the last image."""
+    n = torch.randint(0, N, (count,), generator=gen)
+    y = torch.randint(0, Hh, (count,), generator=gen)
+    x = torch.randint(0, W, (count,), generator=gen)
+    edge_y = torch.tensor([0, 0, 0, Hh // 2, Hh - 1, Hh - 1, Hh - 1, Hh // 2, min(1, Hh - 1), max(Hh - 2, 0)])
+    edge_x = torch.tensor([0, W // 2, W - 1, W - 1, W - 1, W // 2, 0, 0, min(1, W - 1), max(W - 2, 0)])
+    k = edge_y.numel()
+    for j, img in enumerate((0, N - 1)):
+        n[j * k:(j + 1) * k], y[j * k:(j + 1) * k], x[j * k:(j + 1) * k] = img, edge_y, edge_x
+    return n, y, x
+
+
+_SAMPLED_CACHE = {}
+
+
+def _sampled_reference(layer, dev):
+    """Operands (bf16-representable fp32, on the device and on the host), sample indices and the oracle's fp64 values -- once per
+    layer, shared by the variants (the parametrisation iterates variants fastest)."""
+    from oracle import ops as O
+    name, N, Hh, W, C, K, k, s, up = layer
+    if name in _SAMPLED_CACHE:
+        return _SAMPLED_CACHE[name]
+    _SAMPLED_CACHE.clear()                                   # one layer's tensors at a time (the largest is 537 MB per operand)
+    gd = torch.Generator(device=dev).manual_seed(11)
+    g = torch.Generator().manual_seed(11)
+    bf = lambda t: t.bfloat16().float()
+    Ho, Wo = (2 * Hh, 2 * W) if up else (O.same_pad(Hh, k, s)[0], O.same_pad(W, k, s)[0])
+    xd = bf(torch.rand((N, Hh, W, C), device=dev, generator=gd) * 2 - 1)
+    wd = bf((torch.rand((k, k, C, K), device=dev, generator=gd) * 2 - 1) * (1.5 / (k * k * C) ** 0.5))
+    bd = bf(torch.rand((K,), device=dev, generator=gd) - 0.5)
+    dyd = bf(torch.rand((N, Ho, Wo, K), device=dev, generator=gd) * 2 - 1)
+    x, w, b, dy = xd.cpu(), wd.cpu(), bd.cpu(), dyd.cpu()
+    P = 4096
+    on, oy, ox = _sample_positions(N, Ho, Wo, P, g)
+    inn, iy, ix = _sample_positions(N, Hh, W, P, g)
+    taps = [(r, c) for r in range(k) for c in range(k)]
+    ci = torch.randperm(C, generator=g)[:min(C, 48)]
+    co = torch.randperm(K, generator=g)[:min(K, 48)]
+    ref = dict(
+        y=O.conv2d_same_sampled(x, w, b, s, on, oy, ox, upsample2x=up),
+        dx=O.conv2d_same_dgrad_sampled(dy, w, (N, Hh, W, C), s, inn, iy, ix, upsample2x=up),
+        dw=O.conv2d_same_wgrad_sampled(x, dy, (k, k, C, K), s, taps, ci, co, upsample2x=up),
+        db=dy.double().sum(dim=(0, 1, 2)))
+    del x, dy
+    out = (xd, wd, bd, dyd, (on, oy, ox), (inn, iy, ix), (taps, ci, co), ref)
+    _SAMPLED_CACHE[name] = out
+    return out
+
+
+FOUR_WAVE_LAYERS = ("df dec3 3x3 512ch @128x128", "df roi down 3x3 s2", "df critic 5x5 s2 on the [x;G] pair", "stage-II roi tower N=448 12x12x384")
+
+
+@pytest.mark.parametrize("variant", SAMPLED_VARIANTS, ids=[v[0] for v in SAMPLED_VARIANTS])
+@pytest.mark.parametrize("layer", SAMPLED_LAYERS, ids=[l[0] for l in SAMPLED_LAYERS])
+def test_sampled_oracle_full_size(dev, layer, variant):
+    import dpig_amd.hip_ops as H
+    name, N, Hh, W, C, K, k, s, up = layer
+    vid, arith, ftile, wtile, wave8 = variant
+    thin = C == 3 or K == 3
+    if thin and vid not in ("f32", "bf16-auto"):
+        pytest.skip("the vector-ALU / 16x16x32 thin kernels have no tile families")
+    if vid == "bf16-128tile-4wave" and name not in FOUR_WAVE_LAYERS:
+        pytest.skip("the four-wave 128-tile kernels are sampled on four layers (same tiles, plan and k order as the eight-wave forms)")
+    x, w, b, dy, (on, oy, ox), (inn, iy, ix), (taps, ci, co), ref = _sampled_reference(layer, dev)
+    BF = torch.bfloat16
+    store = lambda t: t.to(BF) if (arith == "bf16" and t.shape[-1] % 8 == 0) else t
+    xg, dyg, wg, bg = store(x), store(dy), w, b
+    if arith == "bf16":
+        H.set_compute("bf16")
+        H.set_large_tile(*ftile)
+        H.set_large_tile_wgrad(*wtile)
+        H.set_wave8(wave8)
+    try:
+        y = H.conv2d_fwd(xg, wg, bg, stride=s, upsample2x=up)
+        dx = H.conv2d_dgrad(dyg, wg, (N, Hh, W, C), stride=s, upsample2x=up)
+        dw = torch.empty((k, k, C, K), device=dev)
+        db = torch.empty((K,), device=dev)
+        H.conv2d_wgrad(xg, dyg, (k, k, C, K), stride=s, upsample2x=up, out=dw, db=db)
+    finally:
+        if arith == "bf16":
+            H.set_compute("f32")
+            H.set_large_tile(1, 0)
+            H.set_large_tile_wgrad(1, 0)
+            H.set_wave8(3)
+
+    def check(got, want, tol32, what):
+        want = want.double()
+        scale = max(want.abs().max().item(), 1e-30)
+        err = (got.double().cpu() - want).abs()
+        bound = torch.full_like(want, tol32 * scale) if got.dtype == torch.float32 else want.abs() * 2.0 ** -8 + 5e-5 * scale
+        bad = err > bound
+        assert not bool(bad.any()), "%s [%s, %s]: %d of %d sampled elements off, worst %.3e of max|ref| %.3e" % (
+            what, name, vid, int(bad.sum()), bad.numel(), float(err.max()), scale)
+    check(y[on.to(dev), oy.to(dev), ox.to(dev)], ref["y"], 1e-4, "forward")
+    check(dx[inn.to(dev), iy.to(dev), ix.to(dev)], ref["dx"], 1e-4, "dgrad")
+    tr = torch.tensor([t[0] for t in taps], device=dev)
+    tc = torch.tensor([t[1] for t in taps], device=dev)
+    check(dw[tr, tc][:, ci.to(dev)][:, :, co.to(dev)], ref["dw"], 2e-4, "wgrad")
+    check(db, ref["db"], 2e-4, "bias gradient")
+
+
+def teardown_module(module):
+    _SAMPLED_CACHE.clear()

@@ -206,3 +206,21 @@ def test_halo_staged_kloop_ordering_model():
     with pytest.raises(AssertionError):
         for seed in range(200):
             sim.run(9, seed, lazy=0.02, make=lambda w, k: sim.program_bwq(w, k, 2, 4, relax=1))
+
+
+def test_encoder_stage_of_files_only_variables_it_can_parse():
+    """`models.encoder_stage_of`: TF-slim leaves `Conv[_k]` / `fully_connected[_k]` of the marked scope are filed by the scope
+    counters; anything else -- another scope, an unknown layer kind, a non-numeric suffix -- is None (the trainer then keeps ONE
+    'encoder' stage) instead of raising or being compared against the wrong counter; a snapshot of the marks is honoured."""
+    from dpig_amd import models
+    marks = {"E.towers_in": ("Encoder/G_encoder", 3, 0), "E.bg_begin": ("Encoder/G_encoder", 17, 1)}
+    f = lambda n: models.encoder_stage_of(n, marks)            # noqa: E731
+    assert f("Encoder/G_encoder/Conv/weights") == "stem" and f("Encoder/G_encoder/Conv_2/biases") == "stem"
+    assert f("Encoder/G_encoder/Conv_3/weights") == "roi" and f("Encoder/G_encoder/Conv_16/weights") == "roi"
+    assert f("Encoder/G_encoder/fully_connected/weights") == "roi"
+    assert f("Encoder/G_encoder/Conv_17/weights") == "bg" and f("Encoder/G_encoder/fully_connected_1/biases") == "bg"
+    assert f("Encoder/G_encoder/Conv_x/weights") is None         # non-numeric suffix: used to raise ValueError
+    assert f("Encoder/G_encoder/LayerNorm/gamma") is None        # unknown layer kind: used to be filed by the FC counter
+    assert f("Encoder/G_encoder/fully_connectedX/weights") is None
+    assert f("ID_AE/G/Conv_3/weights") is None
+    assert models.encoder_stage_of("Encoder/G_encoder/Conv/weights", {}) is None

@@ -500,3 +500,36 @@ def test_gp_sweeps_equal_double_backward():
         print("bf16 storage of the sweeps' tensors alone moves the penalty by %.1e (rel) and a parameter gradient by up to %.1e (rel L2)"
               % (abs(pen16.item() - gp_ref.item()) / abs(gp_ref.item()), worst))
         assert worst < 0.2
+
+
+# ---- the sampled forms used at BASELINE full sizes (tests/test_fullsize_gpu.py::test_sampled_oracle_*) ---------------------
+@pytest.mark.parametrize("shape", [(2, 8, 6, 3, 5, 3, 1, False), (2, 8, 6, 4, 5, 3, 2, False), (1, 9, 7, 3, 4, 5, 2, False),
+                                   (2, 5, 5, 2, 3, 1, 1, False), (1, 7, 9, 3, 2, 3, 2, False), (2, 4, 3, 5, 4, 1, 1, True),
+                                   (3, 2, 2, 4, 4, 3, 1, False), (2, 12, 10, 3, 4, 5, 1, False)])
+def test_sampled_conv_equals_dense(shape):
+    """conv2d_same_sampled / _dgrad_sampled / _wgrad_sampled are conv2d_same and its autograd gradients restricted to the requested
+    elements -- EVERY element here (all positions, all taps, all channels), so a wrong pad / stride / border rule cannot hide."""
+    N, H, W, C, K, k, s, up = shape
+    x = T(rnd((N, H, W, C), 1)).requires_grad_(True)
+    w = T(rnd((k, k, C, K), 2)).requires_grad_(True)
+    b = T(rnd((K,), 3))
+    y = O.conv2d_same(O.upsample2x(x) if up else x, w, b, s)
+    dy = T(rnd(tuple(y.shape), 4))
+    dx, dw = torch.autograd.grad(y, [x, w], dy)
+    Ho, Wo = y.shape[1], y.shape[2]
+    n, oy, ox = [t.reshape(-1) for t in torch.meshgrid(torch.arange(N), torch.arange(Ho), torch.arange(Wo), indexing="ij")]
+    got = O.conv2d_same_sampled(x.detach(), w.detach(), b, s, n, oy, ox, upsample2x=up)
+    np.testing.assert_allclose(got.numpy(), y.detach().reshape(-1, K).numpy(), rtol=1e-12, atol=1e-13)
+    n, iy, ix = [t.reshape(-1) for t in torch.meshgrid(torch.arange(N), torch.arange(H), torch.arange(W), indexing="ij")]
+    got = O.conv2d_same_dgrad_sampled(dy, w.detach(), (N, H, W, C), s, n, iy, ix, upsample2x=up)
+    np.testing.assert_allclose(got.numpy(), dx.reshape(-1, C).numpy(), rtol=1e-12, atol=1e-13)
+    taps = [(r, c) for r in range(k) for c in range(k)]
+    got = O.conv2d_same_wgrad_sampled(x.detach(), dy, (k, k, C, K), s, taps, torch.arange(C), torch.arange(K), upsample2x=up)
+    np.testing.assert_allclose(got.reshape(k, k, C, K).numpy(), dw.numpy(), rtol=1e-12, atol=1e-13)
+    # a strict subset in scrambled order picks the same numbers
+    sel = torch.tensor([len(n) - 1, 0, len(n) // 2])
+    sub = O.conv2d_same_dgrad_sampled(dy, w.detach(), (N, H, W, C), s, n[sel], iy[sel], ix[sel], upsample2x=up)
+    np.testing.assert_allclose(sub.numpy(), dx.reshape(-1, C)[sel].numpy(), rtol=1e-12, atol=1e-13)
+    ci, co = torch.tensor([C - 1, 0]), torch.tensor([0, K - 1, 1])
+    sub = O.conv2d_same_wgrad_sampled(x.detach(), dy, (k, k, C, K), s, taps[-1:], ci, co, upsample2x=up)
+    np.testing.assert_allclose(sub[0].numpy(), dw[taps[-1][0], taps[-1][1]][ci][:, co].numpy(), rtol=1e-12, atol=1e-13)

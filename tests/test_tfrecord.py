@@ -261,3 +261,44 @@ def test_example_codec_against_the_protobuf_runtime():
             assert np.array_equal(np.array(f.float_list.value, dtype=np.float32), v), k
         else:
             assert list(f.int64_list.value) == v.tolist(), k
+
+
+def test_packed_varints_vectorised_equals_scalar_decoder():
+    """`_packed_varints` (one numpy pass over a packed Int64List) against the byte-by-byte `_varint` loop: 1- to 10-byte
+    varints, negatives (two's complement, 10 bytes), the 0 / 1 mask fast path, empty input, truncation."""
+    rng = np.random.default_rng(9)
+    vals = np.concatenate([rng.integers(0, 2, 300), rng.integers(-5, 300, 200), rng.integers(-2 ** 62, 2 ** 62, 100),
+                           np.array([0, 127, 128, 16383, 16384, -1, 2 ** 63 - 1, -2 ** 63])]).astype(np.int64)
+    rng.shuffle(vals)
+    blob = b"".join(T._enc_varint(int(v) & (2 ** 64 - 1)) for v in vals)
+    got = T._packed_varints(memoryview(blob))
+    want, pos = [], 0
+    while pos < len(blob):
+        x, pos = T._varint(blob, pos)
+        want.append(T._signed64(x))
+    assert got.dtype == np.int64 and got.tolist() == want == vals.tolist()
+    mask = rng.integers(0, 2, 8192).astype(np.int64)
+    assert np.array_equal(T._packed_varints(bytes(mask.astype(np.uint8))), mask)           # single-byte fast path
+    assert T._packed_varints(b"").size == 0
+    with pytest.raises(ValueError):
+        T._packed_varints(bytes([0x80, 0x80]))                                             # no terminator
+    back = T.parse_example(T.encode_example({"m": vals}))
+    assert np.array_equal(back["m"], vals)
+
+
+def test_record_feeder_yields_the_batches_in_record_order():
+    rng = np.random.default_rng(10)
+    recs = [_pair_example(rng, nparts=7) for _ in range(5)]
+    payloads = [r[0] for r in recs]
+    feeder = T.RecordFeeder(payloads, batch_size=2, which=1, workers=3, depth=3, pin=False)
+    try:
+        seen = [next(feeder) for _ in range(6)]                  # 12 records = 2.4 passes over the 5
+    finally:
+        feeder.close()
+    for j, b in enumerate(seen):
+        for i in range(2):
+            t = recs[(2 * j + i) % 5][1]["1"]
+            assert np.array_equal(b["x"][i].numpy(), (t["img"].astype(np.float32) - 127.5) / 127.5)
+            assert np.array_equal(b["pose_rcv"][i].numpy(), t["rcv"].reshape(-1))
+            assert np.array_equal(b["mask_r6"][i, ..., 0].numpy(), t["mask"].reshape(128, 64).astype(np.float32))
+            assert np.array_equal(b["part_bbox"][i].numpy(), t["bbox"][:7]) and tuple(b["pose_rcv"].shape) == (2, 54)

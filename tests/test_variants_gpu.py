@@ -1129,3 +1129,46 @@ def test_df256_wgan_gp_bf16_step(dev):
     finally:
         H.set_compute("f32")
         lib.delete_all_params(); slim.reset_scopes()
+
+
+def test_stage2_graph_warmup_leaves_the_learning_rates_alone(dev):
+    """`enable_graphs` warms up with real eager steps at step 1; with lr_update_step = 2 those steps halve g_lr / d_lr in
+    place -- the warm-up must put them back like the weights and optimizer slots; `_feed` refuses a batch the graphs were not captured for."""
+    import dpig_amd.hip_ops as H
+    import dpig_amd.tflib as lib
+    import numpy as np
+    from dpig_amd import slim, synthetic
+    from dpig_amd.trainer import Config
+    from dpig_amd.trainer_stage2 import DPIG_Encoder_subSampleAppNetFgBg_GAN_BodyROI
+    try:
+        lib.delete_all_params(); slim.reset_scopes(); lib.set_device(dev)
+        np.random.seed(3)
+        batch = synthetic.to_device(synthetic.make_batch(2, seed=40), dev)
+        tr = DPIG_Encoder_subSampleAppNetFgBg_GAN_BodyROI(Config(batch_size=2, conv_hidden_num=16, g_lr=1e-3, d_lr=2e-3, lr_update_step=2), dev)
+        tr.init_net(batch)
+        tr.enable_graphs(batch)
+        assert float(tr.g_lr) == pytest.approx(1e-3) and float(tr.d_lr) == pytest.approx(2e-3)
+        bad = dict(batch)
+        bad["x"] = batch["x"][:1]
+        with pytest.raises(RuntimeError):
+            tr.train_step(bad)
+        with pytest.raises(RuntimeError):
+            tr.train_step(dict(batch, extra=batch["x"]))
+    finally:
+        H.set_compute("f32")
+        lib.delete_all_params(); slim.reset_scopes()
+
+
+def test_join_side_streams_accepts_an_unindexed_device(dev):
+    """the side streams are keyed by the tensors' concrete device index; a trainer built with torch.device('cuda') (index None)
+    must still have its current stream wait for them."""
+    from dpig_amd import autograd as A
+    x = torch.ones(1 << 20, device=dev)
+    with A.side_branch(x, key="t", enabled=True) as sb:
+        y = x * 2
+        for _ in range(50):
+            y = y + 1
+    assert any(idx == dev.index for (idx, _) in A._SIDE_STREAMS)
+    A.join_side_streams(torch.device("cuda"))            # index None
+    A.join_side_streams("cuda")
+    assert float(y[0]) == 52.0
