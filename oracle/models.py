@@ -71,13 +71,29 @@ class _Scope(object):
         return "%s/%s" % (self.path, default if n == 0 else "%s_%d" % (default, n))
 
 
-def _conv(P, sc, x, cout, k, stride, act):
+# Emulation of the library's bf16 STORAGE mode (DESIGN: "a tensor is stored bf16 iff its channel count is a multiple of 8"; conv
+# filters are read from bf16 shadows; accumulation, biases, FC layers and norms are fp32).  STORE = None: the reference's arithmetic.
+# STORE = f (e.g. lambda t: t.bfloat16().to(t.dtype)): every activation the library keeps in bf16 is passed through f where the
+# library rounds it -- conv outputs after their fused activation, residual sums, ROI crops, the masked fg / bg images, the reshaped
+# FC output that enters the decoder -- and every filter of a bf16 matrix-pipe conv (Cin, Cout >= 32, multiples of 8).  Used by
+# tests/test_variants_gpu.py::test_stage1_bf16_storage_mode to hold the bf16 model to a bound that follows from the storage format
+# instead of an empirical one.
+STORE = None
+
+
+def _st(x):
+    return STORE(x) if (STORE is not None and x.dim() == 4 and x.shape[-1] % 8 == 0) else x
+
+
+def _conv(P, sc, x, cout, k, stride, act, round_w=True):
     name = sc.uniq("Conv")
     cin = x.shape[-1]
     w = P.get(name + "/weights", (k, k, cin, cout), "xavier", fan=(k * k * cin, k * k * cout))
     b = P.get(name + "/biases", (cout,), "zeros")
+    if STORE is not None and round_w and cin >= 32 and cout >= 32 and cin % 8 == 0 and cout % 8 == 0:
+        w = STORE(w)
     y = O.conv2d_same(x, w, b, stride)
-    return act(y) if act is not None else y
+    return _st(act(y) if act is not None else y)
 
 
 def _fc(P, sc, x, cout, act):
@@ -95,7 +111,7 @@ def _tower(P, sc, x, z_out, repeat_num, hidden_num, act):
         res = x
         x = _conv(P, sc, x, channel_num, 3, 1, act)
         x = _conv(P, sc, x, channel_num, 3, 1, act)
-        x = x + res
+        x = _st(x + res)
         if idx < repeat_num - 1:
             x = _conv(P, sc, x, hidden_num * (idx + 2), 3, 2, act)
     x = x.reshape(x.shape[0], -1)            # NHWC flatten order (h, w, c)
@@ -112,7 +128,7 @@ def _crops(x, ROI_bboxs, bbox_num, roi_size):
         y2 = bbox[:, 2:3] / float(H)
         x2 = bbox[:, 3:4] / float(W)
         nb = torch.cat([y1, x1, y2, x2], dim=-1)
-        rois.append(O.crop_and_resize(x, nb, torch.arange(B), roi_size, roi_size))
+        rois.append(_st(O.crop_and_resize(x, nb, torch.arange(B), roi_size, roi_size)))
     return torch.cat(rois, dim=0)
 
 
@@ -126,12 +142,12 @@ def encoder_fgbg(P, x, fg_mask, ROI_bboxs, ROI_vis, bbox_num=7, z_num=32, repeat
     res = x
     x = _conv(P, sc, x, hidden_num, 3, 1, act)
     x = _conv(P, sc, x, hidden_num, 3, 1, act)
-    x = x + res
+    x = _st(x + res)
     if taps is not None:
         taps["E.stem"] = x
     m = fg_mask.to(x.dtype)
-    x_fg = x * m
-    x_bg = x * (1.0 - m)
+    x_fg = _st(x * m)
+    x_bg = _st(x * (1.0 - m))
     body = _crops(x_fg, ROI_bboxs, bbox_num, roi_size)
     if taps is not None:
         taps["E.rois"] = body
@@ -154,7 +170,7 @@ def encoder_roi(P, x, ROI_bboxs, ROI_vis, bbox_num=7, z_num=32, repeat_num=7, hi
     res = x
     x = _conv(P, sc, x, hidden_num, 3, 1, act)
     x = _conv(P, sc, x, hidden_num, 3, 1, act)
-    x = x + res
+    x = _st(x + res)
     body = _crops(x, ROI_bboxs, bbox_num, roi_size)
     body = _tower(P, sc, body, z_num, repeat_num, hidden_num, act)
     fea_list = list(torch.split(body, B, dim=0))
@@ -173,7 +189,7 @@ def encoder_body_roi(P, x, ROI_bboxs, bbox_num=7, z_num=32, repeat_num=7, hidden
     res = x
     x = _conv(P, sc, x, hidden_num, 3, 1, act)
     x = _conv(P, sc, x, hidden_num, 3, 1, act)
-    x = x + res
+    x = _st(x + res)
     body = _crops(x, ROI_bboxs, bbox_num, roi_size)
     body = _tower(P, sc, body, z_num, repeat_num, hidden_num, act)
     return torch.cat(list(torch.split(body, x.shape[0], dim=0)), dim=-1)
@@ -187,7 +203,7 @@ def generator_uae(P, x, pose, input_channel=3, z_num=64, repeat_num=5, hidden_nu
     if pose is not None:
         x = torch.cat([x, pose], dim=3)
     enc = []
-    x = _conv(P, sc, x, hidden_num, 3, 1, act)
+    x = _conv(P, sc, x, hidden_num, 3, 1, act, round_w=False)     # (tiled-embedding collapse: fp32 filter sums)
     if taps is not None:
         taps["G.stem"] = x
     for idx in range(repeat_num):
@@ -195,7 +211,7 @@ def generator_uae(P, x, pose, input_channel=3, z_num=64, repeat_num=5, hidden_nu
         res = x
         x = _conv(P, sc, x, channel_num, 3, 1, act)
         x = _conv(P, sc, x, channel_num, 3, 1, act)
-        x = x + res
+        x = _st(x + res)
         enc.append(x)
         if idx < repeat_num - 1:
             x = _conv(P, sc, x, hidden_num * (idx + 2), 3, 2, act)
@@ -205,14 +221,14 @@ def generator_uae(P, x, pose, input_channel=3, z_num=64, repeat_num=5, hidden_nu
     if taps is not None:
         taps["G.z"] = z
     x = _fc(P, sc, z, x_shape[1] * x_shape[2] * hidden_num, None)
-    x = x.reshape(-1, x_shape[1], x_shape[2], hidden_num)
+    x = _st(x.reshape(-1, x_shape[1], x_shape[2], hidden_num))
     for idx in range(repeat_num):
         x = torch.cat([x, enc[repeat_num - 1 - idx]], dim=-1)
         res = x
         channel_num = x.shape[-1]
         x = _conv(P, sc, x, channel_num, 3, 1, act)
         x = _conv(P, sc, x, channel_num, 3, 1, act)
-        x = x + res
+        x = _st(x + res)
         if taps is not None:
             taps["G.dec%d" % idx] = x
         if idx < repeat_num - 1:
@@ -228,6 +244,8 @@ def dcgan_discriminator(P, img_nhwc, mode="dcgan", dim=64, name="", taps=None):
     def conv(nm, x, cin, cout):
         w = P.get(nm + ".Filters", (5, 5, cin, cout), "stdev", stdev=0.02)
         b = P.get(nm + ".Biases", (cout,), "zeros")
+        if STORE is not None and cin >= 32:              # (bf16-storage emulation: layers 2-4 read bf16 filter shadows)
+            w = STORE(w)
         return O.conv2d_same(x, w, b, 2)
 
     def norm(nm, x):
@@ -242,13 +260,13 @@ def dcgan_discriminator(P, img_nhwc, mode="dcgan", dim=64, name="", taps=None):
 
     pre = name + "Discriminator."
     z1 = conv(pre + "1", img_nhwc, img_nhwc.shape[-1], dim)
-    o = O.leaky_relu(z1)
-    z2 = norm(pre + "BN2", conv(pre + "2", o, dim, 2 * dim))
-    o = O.leaky_relu(z2)
-    z3 = norm(pre + "BN3", conv(pre + "3", o, 2 * dim, 4 * dim))
-    o = O.leaky_relu(z3)
-    z4 = norm(pre + "BN4", conv(pre + "4", o, 4 * dim, 8 * dim))
-    o = O.leaky_relu(z4)
+    o = _st(O.leaky_relu(z1))
+    z2 = norm(pre + "BN2", _st(conv(pre + "2", o, dim, 2 * dim)))
+    o = _st(O.leaky_relu(z2))
+    z3 = norm(pre + "BN3", _st(conv(pre + "3", o, 2 * dim, 4 * dim)))
+    o = _st(O.leaky_relu(z3))
+    z4 = norm(pre + "BN4", _st(conv(pre + "4", o, 4 * dim, 8 * dim)))
+    o = _st(O.leaky_relu(z4))
     if taps is not None:
         taps.update({"D.1pre": z1, "D.2pre": z2, "D.3pre": z3, "D.4pre": z4, "D.4": o})
     o = o.permute(0, 3, 1, 2).reshape(-1, 8 * 4 * 8 * dim)

@@ -3,6 +3,8 @@ stage-II embedding GAN pieces (GaussianFCRes mapper + FC critic, wgan mode, RMSP
 trainer.py:715-868), the DeepFashion 256x256 stage-I graph (trainer_256.py:31-88: deeper ROI encoder,
 D on the concatenated pair with joint BatchNorm statistics, 8 logit rows per image), and the
 LayerNorm discriminator that MODE='wgan-gp' selects (wgan_gp.py:34-40)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -760,15 +762,68 @@ def test_stage1_bf16_storage_mode(dev, model):
             G, _ = tr.generate(embs, batch["pose"])
         assert G.dtype == torch.float32                         # the 3-channel image stays fp32
         rel = lambda a, b: (a.double().cpu() - b.double()).abs().max().item() / max(b.abs().max().item(), 1e-12)
-        e_embs, e_G = rel(embs, embs_o), rel(G, G_o)
-        print("bf16 storage (%s): embedding rel err %.3e, G rel err %.3e" % (model, e_embs, e_G))
-        assert 1e-5 < e_embs < 6e-2
-        assert e_G < 8e-2
+        # The bound comes from the storage FORMAT, not from this library: the oracle graph is re-run with every
+        # tensor the library keeps in bf16 rounded where the library rounds it (oracle.models.STORE), once exactly and once with the
+        # stored values perturbed by 1e-6 relative before rounding -- the size of an fp32-vs-fp64 accumulation difference, which flips
+        # roundings that sit on a bf16 boundary.  What those flips move (the format's own noise floor, ~6e-3 of max|ref| through the
+        # ~50 stored tensors of the graph) is the unit: the library must stay within 3 x of it from the emulated-storage oracle.
+        bf = lambda t: t.bfloat16().to(t.dtype)
+        gn = torch.Generator().manual_seed(5)
+        jit = lambda t: bf(t * (1 + 2e-6 * (torch.rand(t.shape, generator=gn, dtype=t.dtype) - 0.5)))
+
+        def oracle_eg(store):
+            OM.STORE = store
+            try:
+                with torch.no_grad():
+                    if model == "market":
+                        return OM.stage1_forward(P, ob, hidden_num=HID, z_num=ZN)
+                    r = OM.stage1_256_forward(P, ob, HID, ZN, 6)
+                    return r["embs"], r["G"]
+            finally:
+                OM.STORE = None
+        embs_s, G_s = oracle_eg(bf)
+        embs_j, G_j = oracle_eg(jit)
+        floor_e, floor_G = rel(embs_j, embs_s), rel(G_j, G_s)
+        e_embs, e_G = rel(embs, embs_s), rel(G, G_s)
+        msg = ("bf16 storage (%s): vs emulated-storage oracle: embedding %.3e (format floor %.3e), G %.3e (floor %.3e); vs exact oracle %.3e / %.3e"
+               % (model, e_embs, floor_e, e_G, floor_G, rel(embs, embs_o), rel(G, G_o)))
+        print(msg)
+        assert 1e-5 < e_embs <= 3 * max(floor_e, 2.0 ** -8), msg
+        assert e_G <= 3 * max(floor_G, 2.0 ** -8), msg
         tr.step = 1
         w0 = tr.G_flat.flat.detach().clone()
         sh0 = tr.G_flat.shadows.buf.detach().clone()
         d0 = tr._d_optim_eager(batch, update=False)         # (before the generator moves: the oracle's weights)
-        assert abs(float(d0["d_loss"]) - float(dl_o)) < 8e-2 * abs(float(dl_o))
+
+        # the critic alone, on the LIBRARY's own generator output (the generator's deviation is bounded above): emulated-storage
+        # oracle critic, same 3 x its own flip floor (batch norm over 2-4 images makes it the touchiest part of the graph)
+        def oracle_dloss(store):
+            OM.STORE = store
+            try:
+                with torch.no_grad():
+                    Gc = G.double().cpu()
+                    if model == "market":
+                        dr, df_ = OM.dcgan_discriminator(P, ob["x"], "dcgan"), OM.dcgan_discriminator(P, Gc, "dcgan")
+                    else:
+                        dz = OM.dcgan_discriminator(P, torch.cat([ob["x"], Gc], dim=0), "dcgan")
+                        dr, df_ = torch.split(dz, dz.shape[0] // 2)
+                    return float(OM.gan_loss("dcgan", dr, df_)[1])
+            finally:
+                OM.STORE = None
+        dl_s, dl_j = oracle_dloss(bf), oracle_dloss(jit)
+        floor_d = abs(dl_j - dl_s) / abs(dl_s)
+        e_d = abs(float(d0["d_loss"]) - dl_s) / abs(dl_s)
+        msg_d = "bf16 storage (%s): d_loss vs emulated-storage critic %.3e (floor %.3e); vs exact oracle %.3e" % (
+            model, e_d, floor_d, abs(float(d0["d_loss"]) - float(dl_o)) / abs(float(dl_o)))
+        print(msg_d)
+        try:
+            root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            os.makedirs(os.path.join(root, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(root, "gpurun_out", "bf16_model_bars.txt"), "a") as fh:
+                fh.write(msg + "\n" + msg_d + "\n")
+        except Exception:
+            pass
+        assert e_d <= 3 * max(floor_d, 2.0 ** -7), msg_d
         out = tr.train_step(batch, batch)
         assert abs(float(out["g_loss"]) - float(gl_o)) < 5e-2 * abs(float(gl_o))
         assert all(np.isfinite(float(v)) for v in out.values() if hasattr(v, "numel") and v.numel() == 1)
