@@ -225,7 +225,16 @@ def main():
 
     np.random.seed(0)                         # identical initial weights on every rank (+ broadcast)
     B = args.batch or wl_batch
-    cfg = Config(batch_size=B, compute_dtype=args.dtype, **wl_cfg)
+    cfg_kw = dict(wl_cfg)
+    # A/B switches of the data-parallel path for scripts/run_scale.sh (defaults: wire format follows the dtype, staged backward
+    # in data-parallel runs, per-rank batch-norm statistics)
+    if os.environ.get("DPIG_GRAD_EXCHANGE") in ("f32", "bf16"):
+        cfg_kw["grad_exchange"] = os.environ["DPIG_GRAD_EXCHANGE"]
+    if os.environ.get("DPIG_SPLIT_BACKWARD") in ("0", "1"):
+        cfg_kw["split_backward"] = os.environ["DPIG_SPLIT_BACKWARD"] == "1"
+    if os.environ.get("DPIG_SYNC_BN") == "1":
+        cfg_kw["sync_bn"] = True
+    cfg = Config(batch_size=B, compute_dtype=args.dtype, **cfg_kw)
     sampling = args.workload == "market128-sampling"
     if sampling:
         args.no_graph = True

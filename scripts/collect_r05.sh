@@ -1,0 +1,61 @@
+#!/bin/bash
+# Round-5 evidence pass on the GPU box (stages selected by arguments so that one gpurun call can do a bounded subset):
+#   tests      pytest -m gpu (log -> gpurun_out/pytest_gpu.log)
+#   traffic    HBM-traffic PMC passes (FETCH_SIZE / WRITE_SIZE, own passes) of the headline + the bf16 workloads -> profiles/r05_*_pmc_traffic.md,
+#              profiles/roofline_traffic.json (what bench.py reports as roofline.traffic)
+#   stats      rocprofv3 --kernel-trace --stats of the headline (one stream), Market bf16, DeepFashion bf16, stage-II bf16
+#   pmc        matrix-pipe counters of the DeepFashion bf16 step AT HEAD with rocm-smi clock / power samples taken during the pass
+#   layers     per-layer tables (Market bf16, DeepFashion bf16, Market fp32)
+#   crash      scripts/diag_syncbn_graph_2rank.py (two ranks, SyncBN, captured graphs)
+#   bench      the driver's command, every information line
+R=${GRAFT_REPO_ROOT:-/root/repo}
+cd $R
+mkdir -p gpurun_out/profiles_out
+for stage in "$@"; do
+case $stage in
+tests)
+  timeout 1500 python -m pytest tests -m gpu -x -q -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; echo "pytest rc $?"; tail -5 gpurun_out/pytest_gpu.log ;;
+newtests)
+  timeout 1200 python -m pytest tests/test_fullsize_gpu.py tests/test_golden_gpu.py tests/test_tfrecord.py "tests/test_variants_gpu.py::test_stage1_bf16_storage_mode" \
+     "tests/test_variants_gpu.py::test_stage2_graph_warmup_leaves_the_learning_rates_alone" "tests/test_variants_gpu.py::test_join_side_streams_accepts_an_unindexed_device" \
+     -m gpu -x -q -p no:cacheprovider --durations=15 > gpurun_out/pytest_new.log 2>&1; echo "pytest(new) rc $?"; tail -25 gpurun_out/pytest_new.log ;;
+traffic)
+  DPIG_TWO_STREAM=0 DPIG_D_OVERLAP=0 bash scripts/pmc_traffic.sh r05_market_f32 market128/f32
+  DPIG_TWO_STREAM=0 DPIG_D_OVERLAP=0 bash scripts/pmc_traffic.sh r05_market_bf16 market128/bf16 --workload market128 --dtype bf16
+  DPIG_TWO_STREAM=0 DPIG_D_OVERLAP=0 bash scripts/pmc_traffic.sh r05_df256_bf16 df256/bf16 --workload df256 --dtype bf16
+  DPIG_TWO_STREAM=0 DPIG_D_OVERLAP=0 bash scripts/pmc_traffic.sh r05_stage2_bf16 market128-stage2/bf16 --workload market128-stage2 --dtype bf16
+  DPIG_TWO_STREAM=0 DPIG_D_OVERLAP=0 bash scripts/pmc_traffic.sh r05_df256_wgan_gp_bf16 df256-wgan-gp/bf16 --workload df256-wgan-gp --dtype bf16
+  cat profiles/roofline_traffic.json ;;
+stats)
+  DPIG_TWO_STREAM=0 DPIG_D_OVERLAP=0 bash scripts/collect_stats.sh r05_market_f32
+  bash scripts/collect_stats.sh r05_market_bf16 --workload market128 --dtype bf16
+  bash scripts/collect_stats.sh r05_df256_bf16 --workload df256 --dtype bf16
+  bash scripts/collect_stats.sh r05_stage2_bf16 --workload market128-stage2 --dtype bf16 ;;
+pmc)
+  # clock / power while the counter pass runs (one sample per second): MfmaUtil and achieved-of-peak can only be reconciled with the
+  # clock the part actually sustained
+  ( for i in $(seq 1 120); do rocm-smi --showclocks --showpower --json 2>/dev/null | tr -d '\n'; echo; sleep 1; done ) > gpurun_out/profiles_out/r05_df256_bf16_smi.jsonl &
+  SMI=$!
+  DPIG_TWO_STREAM=0 DPIG_D_OVERLAP=0 bash scripts/pmc_mfma_bench.sh r05_df256_bf16 --workload df256 --dtype bf16
+  kill $SMI 2>/dev/null
+  python scripts/smi_summary.py gpurun_out/profiles_out/r05_df256_bf16_smi.jsonl >> profiles/r05_df256_bf16_pmc_mfma.md; cp profiles/r05_df256_bf16_pmc_mfma.md gpurun_out/profiles_out/ ;;
+layers)
+  DPIG_WORKLOAD=market128 DPIG_DTYPE=bf16 DPIG_TWO_STREAM=0 DPIG_D_OVERLAP=0 timeout 300 python scripts/layer_table.py > gpurun_out/profiles_out/r05_layer_market_bf16.txt 2>&1
+  DPIG_WORKLOAD=df256 DPIG_DTYPE=bf16 DPIG_TWO_STREAM=0 DPIG_D_OVERLAP=0 timeout 300 python scripts/layer_table.py > gpurun_out/profiles_out/r05_layer_df256_bf16.txt 2>&1
+  DPIG_WORKLOAD=market128 DPIG_DTYPE=f32 DPIG_TWO_STREAM=0 DPIG_D_OVERLAP=0 timeout 300 python scripts/layer_table.py > gpurun_out/profiles_out/r05_layer_market_f32.txt 2>&1
+  head -3 gpurun_out/profiles_out/r05_layer_*.txt ;;
+crash)
+  timeout 600 python scripts/diag_syncbn_graph_2rank.py ${CRASH_ATTEMPTS:-8} graphs > gpurun_out/crash_graphs.log 2>&1; tail -60 gpurun_out/crash_graphs.log ;;
+bench)
+  python bench.py --gpus 1 --steps 20 --warmup 5 > gpurun_out/profiles_out/r05_bench.json 2> gpurun_out/profiles_out/r05_bench.err
+  tail -c 300 gpurun_out/profiles_out/r05_bench.err; python - <<'PY'
+import json
+d = json.loads([l for l in open("gpurun_out/profiles_out/r05_bench.json") if l.startswith("{")][-1])
+print("headline", d["value"], d["ms_per_step"], d["roofline"]["frac"], d["roofline"]["traffic"], d["cpu_baseline"])
+for k, v in d.get("info_lines", {}).items():
+    print(" ", k, v.get("value"), v.get("ms_per_step"), (v.get("roofline") or {}).get("frac"), (v.get("roofline") or {}).get("traffic"), v.get("error"))
+PY
+  ;;
+esac
+done
+ls gpurun_out/profiles_out | tail -30
