@@ -1,0 +1,448 @@
+// Winograd F(2x2, 3x3) convolution on the fp32 matrix pipe (gfx950), fp32 in / fp32 products / fp32 accumulate.
+//
+// The exact direct-conv family (dpig_conv.hip) sits at 0.77 of the fp32 MFMA peak (the pipe is ~97 % busy at the clock the part
+// sustains), so the only lever left on the BASELINE metric in its own arithmetic type is fewer executed multiplies.  For a 3 x 3
+// stride-1 SAME conv (89 % of the step's FLOPs: models.py:396-400, 425-427, 458-460, 534-535, 564-565 of the reference) Winograd's
+// minimal filtering computes every 2 x 2 output tile from a 4 x 4 input patch with 16 multiplies per (input channel, output channel)
+// instead of 36:
+//        Y = A^T [ (G g G^T) o (B^T d B) ] A        (o = element-wise product, summed over input channels)
+// i.e. 16 independent GEMMs  M_p[tile, k] = sum_c V_p[tile, c] U_p[c, k],  p = (xi, nu) in 4 x 4, on 1/4 of the rows: 2.25x fewer
+// MFMA FLOPs.  Everything is fused in ONE kernel so that neither the 4x-expanded input transform V nor the 4x-expanded product M
+// ever exists in HBM:
+//   * a workgroup owns 64 tiles (256 output pixels) x 64 output channels and ALL 16 positions: four waves (2 tile halves x 2 channel
+//     halves), each holding 16 accumulator blocks of v_mfma_f32_32x32x2_f32 (32 output channels x 32 tiles per position) = 256
+//     accumulator registers -> one wave per SIMD, one workgroup per CU (__launch_bounds__(256, 1));
+//   * the reduction runs over input channels in chunks of 8: per chunk a thread loads the 3 x 4 input pixels its half of the row
+//     transform needs (buffer loads with out-of-range offsets as the zero padding), applies B^T . B in registers (64 adds) and writes
+//     16-byte rows of V_p into LDS; the transformed filter U_p arrives by LDS-DMA from a precomputed image (dpig_wino_filter_transform:
+//     once per optimizer step, like the bf16 filter shadows) that already HAS the LDS layout, bank swizzle included;
+//   * per chunk a wave issues 64 MFMAs (4096 cycles of pipe time) against 32 ds_read_b128, 12 global loads, 8 DMA pieces, 64 VALU and
+//     8 ds_write_b128: the loop is matrix-bound with a wide margin, which is what lets a one-wave-per-SIMD kernel work;
+//   * output transform A^T . A is pure per-lane register arithmetic (a lane holds the same (tile, channel) element of all 16
+//     positions), then the 2 x 2 pixels go through LDS into the family's fused row-contiguous epilogue (bias, activation, residual
+//     before / after the activation with the second output, dgrad's (. + accum) * act'(mask)).
+// dgrad of a 3 x 3 stride-1 SAME conv is the same conv with the filter rotated by 180 degrees and its channel roles swapped: the
+// same kernel on a second transformed image (U' from w[2-r][2-s][c][k] read as [k][c]).  wgrad stays on the direct kernels.
+//
+// LDS image of one chunk of one operand (V or U): [position 16][row 64][8 floats]; row = tile (V) or output channel (U); the two
+// 16-byte halves of a row are swapped when (row >> 3) & 1 so that the 16-lane groups of ds_read_b128 cover all 64 banks.  Within a
+// chunk the channel order is free as long as both operands agree: MFMA k-step s multiplies channels {s, 4 + s}.
+//
+// Accuracy: products and sums are fp32; the transforms add +-1 / +-1/2 combinations of 4 inputs / 3 filter taps, so results differ
+// from the direct kernel by a few fp32 ulps of the largest intermediate (measured against the fp64 oracle in tests/test_wino_gpu.py).
+#include <stdlib.h>
+#include "dpig_common.h"
+#include "dpig_conv_plan.h"
+
+namespace dpig {
+namespace wino {
+
+constexpr int TB = 64;                        // 2 x 2 output tiles per workgroup
+constexpr int KB = 64;                        // output channels per workgroup
+constexpr int CH = 8;                         // reduction channels per chunk
+constexpr int ROWB = CH * 4;                  // bytes of one (position, row)
+constexpr int PLANE = 64 * ROWB;              // one position: 2 KB
+constexpr int OPB = 16 * PLANE;               // one operand, one chunk: 32 KB
+constexpr int SMEM = 4 * OPB;                 // V[2] | U[2]
+constexpr int EP_ROW = KB * 4 + 16;           // epilogue staging: bytes per pixel row (+16: conflict-free 16-byte stores)
+constexpr unsigned OOB = 0x7fffffffu;
+static_assert(256 * EP_ROW <= SMEM, "epilogue staging fits the loop's LDS");
+
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((address_space(3))) void lds_void;
+
+struct WParams {
+    const float* X;       // gathered activation (x forward, dy for dgrad), NHWC with channel stride ldx
+    const float* U;       // transformed filter image [Kout / 64][Cin / 8][16][64][8]
+    float* D;             // destination, NHWC with channel stride ldd
+    float* D2;            // optional second output (activation before a post-activation residual add)
+    const float* bias;    // [Kout] or null
+    const float* res;     // residual / accumulate tensor (destination-shaped) or null
+    const float* mask;    // activation-output tensor for act' (destination-shaped) or null
+    int N, H, W, Cin, Kout;
+    int ldx, ldd, ldres, ldmask, ldd2;
+    int T, THW, TW;       // tiles in the batch, per image, per tile row
+    int nch;              // Cin / 8
+    int mtiles, ntiles;
+    int act; float alpha; int res_post;
+    unsigned x_bytes, u_bytes;
+    unsigned mul_thw, shr_thw, mul_tw, shr_tw;
+};
+
+__device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned shr) {
+    return mul ? (int)(__umulhi((unsigned)n, mul) >> shr) : n;
+}
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+template <int N>
+__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// Fused epilogue on 4 consecutive channels of one output pixel (the fp32 family's epi_vec4 without its split-K / replicate / class forms)
+__device__ __forceinline__ void epi4(const WParams& p, long pix, int col, f32x4 v, f32x4 bv) {
+    v += bv;
+    f32x4 rv = {0.f, 0.f, 0.f, 0.f};
+    if (p.res) rv = *reinterpret_cast<const f32x4*>(p.res + pix * p.ldres + col);
+    if (p.res && !p.res_post) v += rv;
+    if (p.mask) {
+        const f32x4 mv = *reinterpret_cast<const f32x4*>(p.mask + pix * p.ldmask + col);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] *= act_grad(mv[e], p.act, p.alpha);
+    } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], p.act, p.alpha);
+    }
+    if (p.D2) *reinterpret_cast<f32x4*>(p.D2 + pix * p.ldd2 + col) = v;
+    if (p.res && p.res_post) v += rv;
+    *reinterpret_cast<f32x4*>(p.D + pix * p.ldd + col) = v;
+}
+
+__global__ __launch_bounds__(256, 1) void wino_kernel(const WParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[SMEM];
+    lds_char* const L = (lds_char*)smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+
+    // tile order: the row blocks of one 64-channel column block are consecutive, so the workgroups an XCD receives (xcd_remap hands
+    // every XCD one contiguous range) stream ONE slice of the transformed filter through their L2
+    const int tile = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
+    const int nt = tile / p.mtiles, mt = tile - nt * p.mtiles;
+    const int t0 = mt * TB, n0 = nt * KB;
+
+    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.X, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t rsU = make_rsrc(p.U, p.u_bytes);
+
+    // ---- input-transform role: tile tl = 32 (wave & 1) + lane / 2, channel quad q = lane & 1, transform rows xi = 2 xh, 2 xh + 1 --------
+    const int tl = 32 * (wave & 1) + (lane >> 1), q = lane & 1, xh = wave >> 1;
+    int voff[3][4];
+    {
+        const int t = t0 + tl;
+        const bool tok = t < p.T;
+        const int tt = tok ? t : 0;
+        const int n = fast_div(tt, p.mul_thw, p.shr_thw);
+        const int rem = tt - n * p.THW;
+        const int ty = fast_div(rem, p.mul_tw, p.shr_tw);
+        const int tx = rem - ty * p.TW;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int iy = 2 * ty - 1 + xh + i;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ix = 2 * tx - 1 + j;
+                const bool ok = tok & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+                voff[i][j] = ok ? ((((n * p.H + iy) * p.W + ix) * p.ldx) + q * 4) * 4 : (int)OOB;
+            }
+        }
+    }
+    const int v_wr = tl * ROWB + ((q ^ ((tl >> 3) & 1)) << 4);       // this thread's 16 bytes of a V row (half-swap swizzle)
+    f32x4 d[3][4];
+    auto loadV = [&](int chunk) {
+        const int so = chunk < p.nch ? chunk * ROWB : 0;
+        const int dead = chunk < p.nch ? 0 : (int)OOB;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                d[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, voff[i][j] | dead, so, 0));
+    };
+    // B^T d B for transform rows 2 xh, 2 xh + 1 (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]); d[i] = patch row xh + i
+    auto transformV = [&](int buf) {
+        f32x4 r0[4], r1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (xh == 0) { r0[j] = d[0][j] - d[2][j]; r1[j] = d[1][j] + d[2][j]; }      // xi 0: d0 - d2, xi 1: d1 + d2
+            else { r0[j] = d[1][j] - d[0][j]; r1[j] = d[0][j] - d[2][j]; }              // xi 2: d2 - d1, xi 3: d1 - d3 (rows 1, 2, 3 loaded)
+        }
+        lds_char* const base = L + buf * OPB + (8 * xh) * PLANE + v_wr;
+        typedef __attribute__((address_space(3))) f32x4 lds_f4;
+        *(lds_f4*)(base + 0 * PLANE) = r0[0] - r0[2];
+        *(lds_f4*)(base + 1 * PLANE) = r0[1] + r0[2];
+        *(lds_f4*)(base + 2 * PLANE) = r0[2] - r0[1];
+        *(lds_f4*)(base + 3 * PLANE) = r0[1] - r0[3];
+        *(lds_f4*)(base + 4 * PLANE) = r1[0] - r1[2];
+        *(lds_f4*)(base + 5 * PLANE) = r1[1] + r1[2];
+        *(lds_f4*)(base + 6 * PLANE) = r1[2] - r1[1];
+        *(lds_f4*)(base + 7 * PLANE) = r1[1] - r1[3];
+    };
+    // ---- filter DMA role: the chunk's 32-KB image is 32 pieces of 1 KB; wave w moves pieces 8 w .. 8 w + 7 ---------------------------
+    const int u_base = (nt * p.nch) * OPB;                           // byte offset of this column block's first chunk
+    auto dmaU = [&](int chunk, int buf) {
+        const int dead = chunk < p.nch ? 0 : (int)OOB;
+        const int so = u_base + (chunk < p.nch ? chunk : 0) * OPB + wave * 8192;
+#pragma unroll
+        for (int i = 0; i < 8; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (lds_void*)(L + 2 * OPB + buf * OPB + wave * 8192 + i * 1024), 16,
+                                                     (lane * 16 + i * 1024) | dead, so, 0, 0);
+    };
+
+    // ---- MFMA role: wave = (tile half wr, channel half wc); fragment = 16 bytes of row l31 (+ 32 half-block), slot half ^ swizzle ------
+    const int wr = wave >> 1, wc = wave & 1;
+    const int f_row_v = 32 * wr + l31, f_row_u = 32 * wc + l31;
+    const int fv = f_row_v * ROWB + ((half ^ ((f_row_v >> 3) & 1)) << 4);
+    const int fu = 2 * OPB + f_row_u * ROWB + ((half ^ ((f_row_u >> 3) & 1)) << 4);
+    f32x16 acc[16];
+#pragma unroll
+    for (int pp = 0; pp < 16; ++pp)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[pp][r] = 0.f;
+    typedef const __attribute__((address_space(3))) f32x4 lds_cf4;
+
+    // ---- prologue: chunk 0 staged, chunk 1's input patch in registers ---------------------------------------------------------------
+    dmaU(0, 0);
+    loadV(0);
+    transformV(0);
+    loadV(1);
+    wait_vm<12>();                                   // the filter pieces of chunk 0 are older than the 12 loads just issued
+    __syncthreads();
+    for (int c = 0; c < p.nch; ++c) {
+        const int buf = c & 1;
+        dmaU(c + 1, buf ^ 1);                        // (that slot was last read in iteration c - 1; every wave is past its barrier)
+        __builtin_amdgcn_sched_barrier(0);
+        lds_char* const Vb = L + buf * OPB + fv;
+        lds_char* const Ub = L + buf * OPB + fu;
+#pragma unroll
+        for (int pp = 0; pp < 8; ++pp) {
+            const f32x4 fa = *(lds_cf4*)(Ub + pp * PLANE);
+            const f32x4 fb = *(lds_cf4*)(Vb + pp * PLANE);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], fb[s], acc[pp], 0, 0, 0);
+        }
+        transformV(buf ^ 1);                         // chunk c + 1 (loaded an iteration ago) -> the other V slot
+        loadV(c + 2);
+#pragma unroll
+        for (int pp = 8; pp < 16; ++pp) {
+            const f32x4 fa = *(lds_cf4*)(Ub + pp * PLANE);
+            const f32x4 fb = *(lds_cf4*)(Vb + pp * PLANE);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], fb[s], acc[pp], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        wait_vm<12>();                               // filter pieces of chunk c + 1 home (only the 12 loads of chunk c + 2 are younger)
+        __syncthreads();                             // + this wave's V rows written, every wave done reading slot `buf`
+    }
+    wait_vm<0>();
+    __syncthreads();
+
+    // ---- output transform: Y = A^T M A per lane (A^T = [1 1 1 0; 0 1 -1 -1]); lane = (tile l31 of half wr, channels 8 g + 4 half + e) ----
+    // staging rows: [pixel (i, j) of the 2 x 2][tile 0..63] so that the 8 lanes of a store group write 8 consecutive rows
+    typedef __attribute__((address_space(3))) f32x4 lds_f4;
+    const int strow = 32 * wr + l31;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 y[2][2];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int r = 4 * g + e;
+            float t[2][4];
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) {
+                t[0][nu] = acc[0 + nu][r] + acc[4 + nu][r] + acc[8 + nu][r];
+                t[1][nu] = acc[4 + nu][r] - acc[8 + nu][r] - acc[12 + nu][r];
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                y[i][0][e] = t[i][0] + t[i][1] + t[i][2];
+                y[i][1][e] = t[i][1] - t[i][2] - t[i][3];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                *(lds_f4*)(L + ((2 * i + j) * 64 + strow) * EP_ROW + (32 * wc + 8 * g + 4 * half) * 4) = y[i][j];
+    }
+    __syncthreads();
+    // ---- fused epilogue: thread = (16-byte channel group cg, staged row tid / 16 + 16 it) -------------------------------------------
+    const int cg = tid & 15, col = n0 + 4 * cg;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+        const int row = (tid >> 4) + 16 * it;                        // (2 i + j) * 64 + tile
+        const int tloc = row & 63, ij = row >> 6;
+        const int t = t0 + tloc;
+        if (t >= p.T) continue;
+        const int n = fast_div(t, p.mul_thw, p.shr_thw);
+        const int rem = t - n * p.THW;
+        const int ty = fast_div(rem, p.mul_tw, p.shr_tw);
+        const int tx = rem - ty * p.TW;
+        const long pix = ((long)n * p.H + (2 * ty + (ij >> 1))) * p.W + (2 * tx + (ij & 1));
+        const f32x4 v = *(lds_cf4*)(L + row * EP_ROW + cg * 16);
+        epi4(p, pix, col, v, bv);
+    }
+}
+
+// ---- filter transform: U = G g G^T (G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1]) of every (input channel, output channel) pair, written
+// in the kernel's LDS image order.  `dgrad`: the transposed conv's filter g'[r][s][k][c] = w[2 - r][2 - s][c][k] (input channels = the
+// forward conv's output channels).  w is HWIO [3][3][C][K].
+// One workgroup per (64-channel column block kb, 8-channel chunk): the 512 transforms are staged in LDS in image order and leave as one
+// contiguous 32-KB run of 16-byte stores.  Reads follow the filter's fastest axis (forward: output channels, dgrad: input channels).
+template <bool DGRAD>
+__global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int C, int K) {
+    __shared__ __attribute__((aligned(16))) float img[16 * 512];
+    const int cin = DGRAD ? K : C;
+    const int nch = cin / CH;
+    const int kb = blockIdx.x / nch, chunk = blockIdx.x - kb * nch;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        // (m, cc) = (output channel within the block, reduction channel within the chunk); the lanes run along w's fastest axis
+        const int m = DGRAD ? (tid >> 3) + 32 * j : (tid & 63);
+        const int cc = DGRAD ? (tid & 7) : (tid >> 6) + 4 * j;
+        const int ko = kb * 64 + m, ci = chunk * CH + cc;
+        float g[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+                g[r][s] = DGRAD ? w[(((2 - r) * 3 + (2 - s)) * (long)C + ko) * K + ci] : w[((r * 3 + s) * (long)C + ci) * K + ko];
+        float t[4][3];
+#pragma unroll
+        for (int s = 0; s < 3; ++s) {
+            t[0][s] = g[0][s];
+            t[1][s] = 0.5f * (g[0][s] + g[1][s] + g[2][s]);
+            t[2][s] = 0.5f * (g[0][s] - g[1][s] + g[2][s]);
+            t[3][s] = g[2][s];
+        }
+        float* const o = img + m * 8 + (((cc >> 2) ^ ((m >> 3) & 1)) << 2) + (cc & 3);
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi) {
+            o[(xi * 4 + 0) * 512] = t[xi][0];
+            o[(xi * 4 + 1) * 512] = 0.5f * (t[xi][0] + t[xi][1] + t[xi][2]);
+            o[(xi * 4 + 2) * 512] = 0.5f * (t[xi][0] - t[xi][1] + t[xi][2]);
+            o[(xi * 4 + 3) * 512] = t[xi][2];
+        }
+    }
+    __syncthreads();
+    f32x4* const dst = reinterpret_cast<f32x4*>(U + (long)blockIdx.x * (16 * 512));
+    const f32x4* const src = reinterpret_cast<const f32x4*>(img);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dst[tid + 256 * i] = src[tid + 256 * i];
+}
+
+static int g_mode = -1;            // 0 never, 1 where the cost model says it pays (default), 2 wherever legal (tests)
+static void init_mode() {
+    if (g_mode >= 0) return;
+    const char* e = getenv("DPIG_WINO");
+    g_mode = e ? atoi(e) : 1;
+}
+
+// geometry both entry points share: 3 x 3, stride 1, SAME, even image, 16-byte addressable channel vectors
+static bool shape_ok(const DpigConvDesc* d, int cin, int kout, int ld_in, int ld_out) {
+    if (d->R != 3 || d->S != 3 || d->stride != 1 || d->upsample2x || d->res_class || d->split_k > 1) return false;
+    if ((d->H & 1) || (d->W & 1) || d->H < 2 || d->W < 2) return false;
+    if (cin % CH || kout % KB || (ld_in & 3) || (ld_out & 3)) return false;
+    if (d->pad_t >= 0 && d->pad_t != 1) return false;
+    if (d->pad_l >= 0 && d->pad_l != 1) return false;
+    const long lim = 0x7f000000L;
+    if ((long)d->N * d->H * d->W * ld_in * 4 >= lim || (long)d->N * d->H * d->W * ld_out * 4 >= lim) return false;
+    if ((long)16 * cin * kout * 4 >= lim) return false;
+    return true;
+}
+// Does the fused Winograd kernel beat the direct kernel on this layer?  One workgroup per CU, whole rounds of 256: a round lasts
+// nch x 64 MFMAs x 64 cycles + ~20 k cycles of prologue / output transform / epilogue; the direct family delivers ~115 TFLOP/s on
+// layers that fill the chip and less on the small ones (profiles/r04_market_f32_kernel_stats.md).
+static bool pays(const DpigConvDesc* d, int cin, int kout) {
+    init_mode();
+    if (g_mode == 0) return false;
+    if (g_mode == 2) return true;
+    const long T = (long)d->N * (d->H / 2) * (d->W / 2);
+    const long wgs = (long)cdiv(T, TB) * (kout / KB);
+    const long rounds = (wgs + kNumCU - 1) / kNumCU;
+    const double wino_cycles = (double)rounds * ((double)(cin / CH) * 4096.0 / 0.85 + 20000.0);
+    const double direct_flops = 2.0 * d->N * d->H * d->W * 9.0 * cin * kout;
+    const double direct_cycles = direct_flops / (115e12 / 2.1e9);         // cycles at the ~2.1 GHz these kernels sustain
+    return wino_cycles < 0.9 * direct_cycles;
+}
+
+static int launch(const DpigConvDesc* d, const float* in, const float* U, const float* bias, const float* res, const float* mask,
+                  float* out, float* out2, int cin, int kout, int ld_in, int ld_out, int act, hipStream_t st) {
+    if (!aligned16(in) || !aligned16(U) || !aligned16(out) || (bias && !aligned16(bias)) || (res && (!aligned16(res) || (d->ldres & 3))) ||
+        (mask && (!aligned16(mask) || (d->ldmask & 3))) || (out2 && (!aligned16(out2) || (d->ldy2 & 3))))
+        return fail(DPIG_EINVAL, "winograd conv: operands must be 16-byte addressable");
+    WParams p = {};
+    p.X = in; p.U = U; p.D = out; p.D2 = out2; p.bias = bias; p.res = res; p.mask = mask;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = cin; p.Kout = kout;
+    p.ldx = ld_in; p.ldd = ld_out; p.ldres = d->ldres; p.ldmask = d->ldmask; p.ldd2 = d->ldy2;
+    p.TW = d->W / 2; p.THW = (d->H / 2) * p.TW; p.T = d->N * p.THW;
+    p.nch = cin / CH;
+    p.mtiles = cdiv(p.T, TB); p.ntiles = kout / KB;
+    p.act = act; p.alpha = d->alpha; p.res_post = d->res_after_act;
+    p.x_bytes = (unsigned)((long)d->N * d->H * d->W * ld_in * 4);
+    p.u_bytes = (unsigned)((long)16 * cin * kout * 4);
+    find_divisor(p.THW, &p.mul_thw, &p.shr_thw);
+    find_divisor(p.TW, &p.mul_tw, &p.shr_tw);
+    hipLaunchKernelGGL(wino_kernel, dim3(p.mtiles * p.ntiles), dim3(256), 0, st, p);
+    return check_launch("wino_kernel");
+}
+
+}  // namespace wino
+}  // namespace dpig
+
+using namespace dpig;
+
+// Elements (floats) of one transformed filter image of a [3][3][C][K] filter; 0 when the shape has no Winograd form.
+extern "C" size_t dpig_wino_filter_elems(int C, int K) {
+    if (C <= 0 || K <= 0 || C % 64 || K % 64) return 0;
+    return (size_t)16 * C * K;
+}
+
+// u_fwd / u_dgrad (either may be null): transformed images for dpig_conv2d_fwd_wino / dpig_conv2d_dgrad_wino of the HWIO filter w.
+extern "C" int dpig_wino_filter_transform(const float* w, int C, int K, float* u_fwd, float* u_dgrad, void* stream) {
+    if (!w || !dpig_wino_filter_elems(C, K)) return fail(DPIG_EINVAL, "winograd filter transform: C and K must be positive multiples of 64");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int blocks = (C / 64) * (K / wino::CH);                 // = (K / 64) * (C / 8): the same count in both directions
+    if (u_fwd) hipLaunchKernelGGL(wino::wino_filter_kernel<false>, dim3(blocks), dim3(256), 0, st, w, u_fwd, C, K);
+    if (u_dgrad) hipLaunchKernelGGL(wino::wino_filter_kernel<true>, dim3(blocks), dim3(256), 0, st, w, u_dgrad, C, K);
+    return check_launch("wino_filter_kernel");
+}
+
+// 1: dpig_conv2d_fwd_wino (which = 0) / dpig_conv2d_dgrad_wino (which = 1) accepts this descriptor AND is expected to beat the
+// direct kernel (DPIG_WINO=2 / dpig_conv_wino_set_mode(2): wherever legal); 0 otherwise.  No device work.
+extern "C" int dpig_conv2d_wino_eligible(const DpigConvDesc* d, int which) {
+    if (!d || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->K <= 0 || d->compute != DPIG_COMPUTE_F32) return 0;
+    const bool dg = which == 1;
+    const int cin = dg ? d->K : d->C, kout = dg ? d->C : d->K;
+    const int ld_in = dg ? d->ldy : d->ldx, ld_out = dg ? d->ldx : d->ldy;
+    if (d->C % 64 || d->K % 64) return 0;                       // (one transformed image serves both directions)
+    if (!wino::shape_ok(d, cin, kout, ld_in, ld_out)) return 0;
+    return wino::pays(d, cin, kout) ? 1 : 0;
+}
+
+extern "C" int dpig_conv_wino_set_mode(int mode) {
+    if (mode < 0 || mode > 2) return fail(DPIG_EINVAL, "winograd mode out of range");
+    wino::g_mode = mode;
+    return DPIG_OK;
+}
+
+// y = act(conv3x3_SAME(x, w) + bias + residual)  (or act(..) + residual with res_after_act, y_act receiving the activation) through
+// the transformed filter image u_fwd of dpig_wino_filter_transform.  Same descriptor and epilogue semantics as dpig_conv2d_fwd.
+extern "C" int dpig_conv2d_fwd_wino(const DpigConvDesc* d, const float* x, const float* u_fwd, const float* bias, const float* residual,
+                                    float* y, float* y_act, void* stream) {
+    int pt, pl, Ho, Wo;
+    int rc = resolve_desc(d, &pt, &pl, &Ho, &Wo);
+    if (rc) return rc;
+    if (!x || !u_fwd || !y) return fail(DPIG_EINVAL, "null tensor pointer");
+    if (!wino::shape_ok(d, d->C, d->K, d->ldx, d->ldy) || d->C % 64) return fail(DPIG_EINVAL, "winograd conv: unsupported shape");
+    if (residual && d->ldres < d->K) return fail(DPIG_EINVAL, "ldres < K");
+    if (y_act && d->ldy2 < d->K) return fail(DPIG_EINVAL, "ldy2 < K");
+    return wino::launch(d, x, u_fwd, bias, residual, nullptr, y, y_act, d->C, d->K, d->ldx, d->ldy, d->act, static_cast<hipStream_t>(stream));
+}
+
+// dx = (conv_backward_data(dy, w) + accum) * act'(mask) through u_dgrad.  Same semantics as dpig_conv2d_dgrad.
+extern "C" int dpig_conv2d_dgrad_wino(const DpigConvDesc* d, const float* dy, const float* u_dgrad, const float* accum, const float* mask,
+                                      float* dx, void* stream) {
+    int pt, pl, Ho, Wo;
+    int rc = resolve_desc(d, &pt, &pl, &Ho, &Wo);
+    if (rc) return rc;
+    if (!dy || !u_dgrad || !dx) return fail(DPIG_EINVAL, "null tensor pointer");
+    if (!wino::shape_ok(d, d->K, d->C, d->ldy, d->ldx) || d->K % 64) return fail(DPIG_EINVAL, "winograd conv: unsupported shape");
+    if (accum && d->ldres < d->C) return fail(DPIG_EINVAL, "ldres < C");
+    if (mask && d->ldmask < d->C) return fail(DPIG_EINVAL, "ldmask < C");
+    DpigConvDesc e = *d;
+    e.res_after_act = 0; e.ldy2 = 0;
+    return wino::launch(&e, dy, u_dgrad, nullptr, accum, mask, dx, nullptr, d->K, d->C, d->ldy, d->ldx, mask ? d->act : DPIG_ACT_NONE,
+                        static_cast<hipStream_t>(stream));
+}
