@@ -63,6 +63,12 @@ SYMBOLS = {
     "dpig_conv_bf16_set_large_tile": (_i, [_i, _i]),
     "dpig_conv_bf16_set_large_tile_wgrad": (_i, [_i, _i]),
     "dpig_conv_bf16_set_wave8": (_i, [_i]),
+    "dpig_wino_filter_elems": (_sz, [_i, _i]),
+    "dpig_wino_filter_transform": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "dpig_conv2d_wino_eligible": (_i, [_dp, _i]),
+    "dpig_conv_wino_set_mode": (_i, [_i]),
+    "dpig_conv2d_fwd_wino": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "dpig_conv2d_dgrad_wino": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "dpig_conv2d_fwd_thin_bf16": (_i, [_dp, _vp, _vp, _vp, _vp, _vp]),
     "dpig_conv2d_dgrad_thin_bf16": (_i, [_dp, _vp, _vp, _vp, _vp]),
     "dpig_conv2d_wgrad_thin_bf16": (_i, [_dp, _vp, _vp, _vp, _f, _vp, _f, _vp, _sz, _vp]),

@@ -116,6 +116,11 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const WParams p) {
 
     // ---- input-transform role: tile tl = 32 (wave & 1) + lane / 2, channel quad q = lane & 1, transform rows xi = 2 xh, 2 xh + 1 --------
     const int tl = 32 * (wave & 1) + (lane >> 1), q = lane & 1, xh = wave >> 1;
+    // patch rows (a, b, c) this thread loads: transform rows 2 xh, 2 xh + 1 are  a - c  and  sgn * b + c  with
+    //   xh = 0: (a, b, c) = patch rows (0, 1, 2), sgn = +1   [xi 0: d0 - d2,  xi 1: d1 + d2]
+    //   xh = 1: (a, b, c) = patch rows (2, 3, 1), sgn = -1   [xi 2: d2 - d1,  xi 3: d1 - d3]        (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1])
+    // -- one instruction stream for both wave pairs, no branch in the loop
+    const float sgn = xh ? -1.f : 1.f;
     int voff[3][4];
     {
         const int t = t0 + tl;
@@ -127,7 +132,8 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const WParams p) {
         const int tx = rem - ty * p.TW;
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
-            const int iy = 2 * ty - 1 + xh + i;
+            const int prow = xh ? (i == 0 ? 2 : (i == 1 ? 3 : 1)) : i;
+            const int iy = 2 * ty - 1 + prow;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int ix = 2 * tx - 1 + j;
@@ -138,43 +144,56 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const WParams p) {
     }
     const int v_wr = tl * ROWB + ((q ^ ((tl >> 3) & 1)) << 4);       // this thread's 16 bytes of a V row (half-swap swizzle)
     f32x4 d[3][4];
-    auto loadV = [&](int chunk) {
+    auto loadVrow = [&](int chunk, int i) {                          // patch row slot i (literal) of `chunk`
         const int so = chunk < p.nch ? chunk * ROWB : 0;
         const int dead = chunk < p.nch ? 0 : (int)OOB;
 #pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                d[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, voff[i][j] | dead, so, 0));
+        for (int j = 0; j < 4; ++j)
+            d[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, voff[i][j] | dead, so, 0));
     };
-    // B^T d B for transform rows 2 xh, 2 xh + 1 (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]); d[i] = patch row xh + i
-    auto transformV = [&](int buf) {
-        f32x4 r0[4], r1[4];
+    auto loadV = [&](int chunk) {
+        loadVrow(chunk, 0);
+        loadVrow(chunk, 1);
+        loadVrow(chunk, 2);
+    };
+    // B^T d B in three stages so that the k-loop can place them between MFMA groups: rows, then the four columns of either row
+    f32x4 r0[4], r1[4];
+    typedef __attribute__((address_space(3))) f32x4 lds_f4;
+    auto rowsV = [&](int which) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            if (xh == 0) { r0[j] = d[0][j] - d[2][j]; r1[j] = d[1][j] + d[2][j]; }      // xi 0: d0 - d2, xi 1: d1 + d2
-            else { r0[j] = d[1][j] - d[0][j]; r1[j] = d[0][j] - d[2][j]; }              // xi 2: d2 - d1, xi 3: d1 - d3 (rows 1, 2, 3 loaded)
+            if (which == 0) r0[j] = d[0][j] - d[2][j];
+            else r1[j] = sgn * d[1][j] + d[2][j];
         }
-        lds_char* const base = L + buf * OPB + (8 * xh) * PLANE + v_wr;
-        typedef __attribute__((address_space(3))) f32x4 lds_f4;
-        *(lds_f4*)(base + 0 * PLANE) = r0[0] - r0[2];
-        *(lds_f4*)(base + 1 * PLANE) = r0[1] + r0[2];
-        *(lds_f4*)(base + 2 * PLANE) = r0[2] - r0[1];
-        *(lds_f4*)(base + 3 * PLANE) = r0[1] - r0[3];
-        *(lds_f4*)(base + 4 * PLANE) = r1[0] - r1[2];
-        *(lds_f4*)(base + 5 * PLANE) = r1[1] + r1[2];
-        *(lds_f4*)(base + 6 * PLANE) = r1[2] - r1[1];
-        *(lds_f4*)(base + 7 * PLANE) = r1[1] - r1[3];
+    };
+    auto colsV = [&](int buf, int which, int pair) {                 // positions 8 xh + 4 which + 2 pair, + 1
+        const f32x4* r = which ? r1 : r0;
+        lds_char* const base = L + buf * OPB + (8 * xh + 4 * which) * PLANE + v_wr;
+        if (pair == 0) {
+            *(lds_f4*)(base + 0 * PLANE) = r[0] - r[2];
+            *(lds_f4*)(base + 1 * PLANE) = r[1] + r[2];
+        } else {
+            *(lds_f4*)(base + 2 * PLANE) = r[2] - r[1];
+            *(lds_f4*)(base + 3 * PLANE) = r[1] - r[3];
+        }
+    };
+    auto transformV = [&](int buf) {
+        rowsV(0); rowsV(1);
+        colsV(buf, 0, 0); colsV(buf, 0, 1); colsV(buf, 1, 0); colsV(buf, 1, 1);
     };
     // ---- filter DMA role: the chunk's 32-KB image is 32 pieces of 1 KB; wave w moves pieces 8 w .. 8 w + 7 ---------------------------
     const int u_base = (nt * p.nch) * OPB;                           // byte offset of this column block's first chunk
-    auto dmaU = [&](int chunk, int buf) {
+    auto dmaUhalf = [&](int chunk, int buf, int h4) {                // pieces 4 h4 .. 4 h4 + 3 of this wave's eight
         const int dead = chunk < p.nch ? 0 : (int)OOB;
         const int so = u_base + (chunk < p.nch ? chunk : 0) * OPB + wave * 8192;
 #pragma unroll
-        for (int i = 0; i < 8; ++i)
+        for (int i = 4 * h4; i < 4 * h4 + 4; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (lds_void*)(L + 2 * OPB + buf * OPB + wave * 8192 + i * 1024), 16,
                                                      (lane * 16 + i * 1024) | dead, so, 0, 0);
+    };
+    auto dmaU = [&](int chunk, int buf) {
+        dmaUhalf(chunk, buf, 0);
+        dmaUhalf(chunk, buf, 1);
     };
 
     // ---- MFMA role: wave = (tile half wr, channel half wc); fragment = 16 bytes of row l31 (+ 32 half-block), slot half ^ swizzle ------
@@ -196,29 +215,33 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const WParams p) {
     loadV(1);
     wait_vm<12>();                                   // the filter pieces of chunk 0 are older than the 12 loads just issued
     __syncthreads();
+    // One chunk = 16 steps (positions), each {fragments of the NEXT position, 4 MFMAs on this position's accumulator block (256 cycles of
+    // pipe time), a slice of the staging work for chunk c + 1 / c + 2}; sched_barrier pins the slices between the MFMA groups -- with one
+    // wave per SIMD nothing else hides them.  Slices: steps 0-1 filter DMA of chunk c + 1 (4 pieces each), 2-3 the row transform of the
+    // patch held in registers (chunk c + 1), 4-7 its column transform + the eight 16-byte LDS stores, 8-10 the patch loads of chunk c + 2.
     for (int c = 0; c < p.nch; ++c) {
         const int buf = c & 1;
-        dmaU(c + 1, buf ^ 1);                        // (that slot was last read in iteration c - 1; every wave is past its barrier)
-        __builtin_amdgcn_sched_barrier(0);
         lds_char* const Vb = L + buf * OPB + fv;
         lds_char* const Ub = L + buf * OPB + fu;
+        f32x4 fa[2], fb[2];
+        fa[0] = *(lds_cf4*)(Ub);
+        fb[0] = *(lds_cf4*)(Vb);
 #pragma unroll
-        for (int pp = 0; pp < 8; ++pp) {
-            const f32x4 fa = *(lds_cf4*)(Ub + pp * PLANE);
-            const f32x4 fb = *(lds_cf4*)(Vb + pp * PLANE);
+        for (int pp = 0; pp < 16; ++pp) {
+            if (pp < 15) {
+                fa[(pp + 1) & 1] = *(lds_cf4*)(Ub + (pp + 1) * PLANE);
+                fb[(pp + 1) & 1] = *(lds_cf4*)(Vb + (pp + 1) * PLANE);
+            }
 #pragma unroll
-            for (int s = 0; s < 4; ++s) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], fb[s], acc[pp], 0, 0, 0);
+            for (int s = 0; s < 4; ++s) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[pp & 1][s], fb[pp & 1][s], acc[pp], 0, 0, 0);
+            if (pp == 0) dmaUhalf(c + 1, buf ^ 1, 0);    // (that slot was last read in iteration c - 1; every wave is past its barrier)
+            if (pp == 1) dmaUhalf(c + 1, buf ^ 1, 1);
+            if (pp == 2) rowsV(0);
+            if (pp == 3) rowsV(1);
+            if (pp >= 4 && pp < 8) colsV(buf ^ 1, (pp - 4) >> 1, (pp - 4) & 1);
+            if (pp >= 8 && pp < 11) loadVrow(c + 2, pp - 8);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        transformV(buf ^ 1);                         // chunk c + 1 (loaded an iteration ago) -> the other V slot
-        loadV(c + 2);
-#pragma unroll
-        for (int pp = 8; pp < 16; ++pp) {
-            const f32x4 fa = *(lds_cf4*)(Ub + pp * PLANE);
-            const f32x4 fb = *(lds_cf4*)(Vb + pp * PLANE);
-#pragma unroll
-            for (int s = 0; s < 4; ++s) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s], fb[s], acc[pp], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
         wait_vm<12>();                               // filter pieces of chunk c + 1 home (only the 12 loads of chunk c + 2 are younger)
         __syncthreads();                             // + this wave's V rows written, every wave done reading slot `buf`
     }

@@ -12,6 +12,9 @@ Arithmetic modes (`set_compute`):
            Ops whose kernels exist in fp32 only (thin 3-channel convs, norms, FC layers, crops) convert at their
            boundary (`to_f32` / `to_bf16` kernels); a tensor is stored as bf16 iff its channel count is a multiple of 8;
   'bf16c'  round 1's intermediate mode: fp32 tensors, conv operands rounded to bf16 on their way into LDS;
+  'f32w'   'f32' with the 3x3 stride-1 convs evaluated by Winograd's F(2x2,3x3) minimal filtering on the fp32 matrix pipe
+           (csrc/dpig_conv_wino.hip: fp32 tensors, fp32 products, fp32 accumulation, 2.25x fewer multiplies; forward and dgrad
+           where the library's cost model says it pays, everything else -- and every filter gradient -- on the 'f32' kernels);
   'bf16x3' fp32 tensors, fp32 accuracy class on the bf16 pipe: conv operands are split into two bf16 terms on their way
            into LDS and every product block is three bf16 MFMAs (DPIG_COMPUTE_BF16X3, include/dpig_hip.h).  An opt-in
            mode, held to the exact path's kernel bar (2e-5 max|ref|); 'f32' stays the exact-products default.
@@ -96,17 +99,21 @@ def as_nhwc(t):
 COMPUTE_F32, COMPUTE_BF16, COMPUTE_BF16X3, COMPUTE_BF16_STORE = 0, 1, 2, 3
 _COMPUTE = [COMPUTE_F32]      # DpigConvDesc.compute of the fp32-tensor entry points
 _STORE_BF16 = [False]         # 'bf16' mode: activations stored as bf16
+_WINO = [False]               # 'f32w' mode: 3x3 stride-1 convs through the Winograd F(2x2,3x3) kernel where it pays
 
 
 def set_compute(dtype):
     """Arithmetic of every subsequent launch (module docstring): 'f32' | 'bf16' (storage) | 'bf16c' (fp32 tensors,
     bf16 matrix pipe) | 'bf16x3' (fp32 tensors, split-bf16 products)."""
-    mode = {"f32": "f32", "fp32": "f32", "bf16": "bf16", "bf16c": "bf16c", "bf16x3": "bf16x3"}[dtype]
+    mode = {"f32": "f32", "fp32": "f32", "bf16": "bf16", "bf16c": "bf16c", "bf16x3": "bf16x3", "f32w": "f32w"}[dtype]
     _COMPUTE[0] = {"bf16c": COMPUTE_BF16, "bf16x3": COMPUTE_BF16X3}.get(mode, COMPUTE_F32)
     _STORE_BF16[0] = mode == "bf16"
+    _WINO[0] = mode == "f32w"
 
 
 def get_compute():
+    if _WINO[0]:
+        return "f32w"
     return "bf16" if _STORE_BF16[0] else {COMPUTE_BF16: "bf16c", COMPUTE_BF16X3: "bf16x3"}.get(_COMPUTE[0], "f32")
 
 
@@ -263,6 +270,61 @@ class FilterShadows(object):
                     delattr(p, a)
 
 
+def wino_images(w, want_fwd=True, want_dgrad=True):
+    """(u_fwd, u_dgrad) transformed images of an HWIO [3,3,C,K] filter for dpig_conv2d_fwd_wino / _dgrad_wino
+    (dpig_wino_filter_transform), or None when the filter has no Winograd form.  Parameters owned by a trainer carry persistent
+    images refreshed after every optimizer step (`w._dpig_wino`, WinoFilters); any other tensor gets them made on the spot."""
+    im = getattr(w, "_dpig_wino", None)
+    if im is not None:
+        return im
+    if w.dim() != 4 or w.shape[0] != 3 or w.shape[1] != 3 or w.dtype != F32 or not w.is_cuda:
+        return None
+    C, K = int(w.shape[2]), int(w.shape[3])
+    n = lib().dpig_wino_filter_elems(C, K)
+    if n == 0:
+        return None
+    w = w.contiguous()
+    uf = torch.empty(n, dtype=F32, device=w.device) if want_fwd else None
+    ud = torch.empty(n, dtype=F32, device=w.device) if want_dgrad else None
+    check(lib().dpig_wino_filter_transform(ptr(w), C, K, ptr(uf), ptr(ud), stream_ptr()), "wino_filter_transform")
+    return uf, ud
+
+
+class WinoFilters(object):
+    """Persistent Winograd images (forward + dgrad) of every 3x3 filter in `params` that has them, in ONE allocation, attached to the
+    parameters as `_dpig_wino`; `refresh()` re-derives them from the fp32 masters (after every optimizer step, like FilterShadows)."""
+
+    def __init__(self, params):
+        self.params = [p for p in params if p.dim() == 4 and tuple(p.shape[:2]) == (3, 3) and
+                       lib().dpig_wino_filter_elems(int(p.shape[2]), int(p.shape[3])) > 0]
+        if not self.params:
+            return
+        total = sum(2 * lib().dpig_wino_filter_elems(int(p.shape[2]), int(p.shape[3])) for p in self.params)
+        self.buf = torch.empty(total, dtype=F32, device=self.params[0].device)
+        off = 0
+        for p in self.params:
+            n = lib().dpig_wino_filter_elems(int(p.shape[2]), int(p.shape[3]))
+            p._dpig_wino = (self.buf[off:off + n], self.buf[off + n:off + 2 * n])
+            off += 2 * n
+        self.refresh()
+
+    def refresh(self):
+        for p in self.params:
+            uf, ud = p._dpig_wino
+            check(lib().dpig_wino_filter_transform(ptr(p.data), int(p.shape[2]), int(p.shape[3]), ptr(uf), ptr(ud), stream_ptr()),
+                  "wino_filter_transform")
+
+    def detach(self):
+        for p in self.params:
+            if hasattr(p, "_dpig_wino"):
+                delattr(p, "_dpig_wino")
+
+
+def set_wino_mode(mode):
+    """dpig_conv_wino_set_mode: 0 never, 1 the library's cost model (default), 2 wherever the layer has a Winograd form (tests)."""
+    check(lib().dpig_conv_wino_set_mode(int(mode)), "conv_wino_set_mode")
+
+
 def _bf16_conv_ok(C, K, *lds):
     return C % 8 == 0 and K % 8 == 0 and C >= 32 and K >= 32 and all(ld % 8 == 0 for ld in lds)
 
@@ -349,6 +411,15 @@ def conv2d_fwd(x, w, bias=None, stride=1, act=ACT_NONE, alpha=0.2, residual=None
             raise RuntimeError("conv2d: bad out_act tensor")
     d = _desc(N, H, W, C, K, R, S, stride, ldx, ldy, ldres=ldres, act=act, alpha=alpha, upsample2x=upsample2x,
               split_k=split_k, res_after_act=res_after_act, ldy2=ldy2, res_class=res_class)
+    if _WINO[0] and R == 3 and S == 3 and stride == 1 and split_k == 0 and lib().dpig_conv2d_wino_eligible(ctypes.byref(d), 0) \
+            and _al16(x, out, residual, out_act, bias):
+        im = wino_images(w, want_dgrad=False)
+        if im is not None:
+            # executed FLOPs: 16 multiplies per (2x2 tile, ci, co) instead of 36 -- what the roofline of this launch is priced on
+            with _Timed("conv_fwd_wino", 2.0 * N * (H // 2) * (W // 2) * 16 * K * C, (N, H, W, C, K, R, stride, 0)):
+                check(lib().dpig_conv2d_fwd_wino(ctypes.byref(d), ptr(x), ptr(im[0]), ptr(bias), ptr(residual), ptr(out), ptr(out_act),
+                                                 stream_ptr()), "conv2d_fwd_wino")
+            return out
     wsb, wsn = _ws(d, 0, x.device)
     mfma = (C % 4 == 0 and K % 4 == 0 and ldx % 4 == 0 and C >= 32 and K >= 32)
     with _Timed("conv_fwd_mfma" if mfma else "conv_fwd_thin", 2.0 * N * H * W // (stride * stride) * K * R * S * C,
@@ -511,6 +582,14 @@ def conv2d_dgrad(dy, w, in_shape, stride=1, accum=None, mask=None, act=ACT_NONE,
         mask, ldmask = as_nhwc(mask)
     d = _desc(N, H, W, C, K, R, S, stride, ldx, ldy, ldres=ldres, ldmask=ldmask, act=act, alpha=alpha,
               upsample2x=upsample2x, split_k=split_k)
+    if _WINO[0] and R == 3 and S == 3 and stride == 1 and split_k == 0 and lib().dpig_conv2d_wino_eligible(ctypes.byref(d), 1) \
+            and _al16(dy, out, accum, mask):
+        im = wino_images(w, want_fwd=False)
+        if im is not None:
+            with _Timed("conv_dgrad_wino", 2.0 * N * (H // 2) * (W // 2) * 16 * K * C, (N, H, W, C, K, R, stride, 0)):
+                check(lib().dpig_conv2d_dgrad_wino(ctypes.byref(d), ptr(dy), ptr(im[1]), ptr(accum), ptr(mask), ptr(out), stream_ptr()),
+                      "conv2d_dgrad_wino")
+            return out
     wsb, wsn = _ws(d, 1, dy.device)
     mfma = (C % 4 == 0 and K % 4 == 0 and ldy % 4 == 0 and C >= 32 and K >= 32)
     with _Timed("conv_dgrad_mfma" if mfma else "conv_dgrad_thin",

@@ -56,10 +56,17 @@ class FlatParams(object):
         optimizer step from the fp32 masters this object owns.  split=True ('bf16x3' mode): the two-term shadows."""
         self.shadows = H.FilterShadows(self.params, flat=self.flat, split=split)
 
+    def enable_wino(self):
+        """'f32w' mode: persistent Winograd images of the 3x3 filters (hip_ops.WinoFilters), refreshed after every optimizer step."""
+        self.wino = H.WinoFilters(self.params)
+
     def refresh_shadows(self):
         sh = getattr(self, "shadows", None)
         if sh is not None:
             sh.refresh()
+        wn = getattr(self, "wino", None)
+        if wn is not None:
+            wn.refresh()
 
     def zero_grad(self):
         """No memset: the first kernel that touches a slice overwrites it (beta = 0)."""
@@ -491,6 +498,8 @@ class DPIG_Encoder_GAN_BodyROI_FgBg(object):
             split = self.config.compute_dtype == "bf16x3"
             self.G_flat.enable_bf16_shadows(split)
             self.D_flat.enable_bf16_shadows(split)
+        if getattr(self.config, "compute_dtype", "f32") == "f32w":
+            self.G_flat.enable_wino()                    # (the critic has no 3x3 convs)
         lib.ops.batchnorm.set_sync(bool(getattr(self.config, "sync_bn", False)) and self.allreduce.enabled)
         if getattr(self.config, "ckpt_path", None):
             self.restore_counters(self.config.ckpt_path)

@@ -165,6 +165,32 @@ int dpig_conv_bf16_set_large_tile_wgrad(int mode, int variant);
  * instructions per wave): bit 0 = forward / dgrad (bg8_kernel, bg8_multi_kernel), bit 1 = filter gradient (bw8_kernel), bit 2 = the
  * halo-patch kernel (bh8_kernel); environment DPIG_BF16_G8.  Same plans, same bits. */
 int dpig_conv_bf16_set_wave8(int mode);
+/* ---- Winograd F(2x2, 3x3) on the fp32 matrix pipe (csrc/dpig_conv_wino.hip) -------------------------------------------------
+ * The 3 x 3 stride-1 SAME convs of slim.conv2d (reference models.py:396-400, 425-427, 458-460, 534-535, 564-565: 89 % of a stage-I
+ * step's FLOPs) with 2.25x fewer multiplies: fp32 tensors, fp32 products, fp32 accumulation -- the arithmetic TYPE of
+ * dpig_conv2d_fwd / _dgrad, a different (mathematically equivalent) evaluation order, so results agree with the direct kernels to a few
+ * fp32 ulps of the largest intermediate instead of bit for bit (tests/test_wino_gpu.py holds both to the same bar against the fp64
+ * oracle).  Input transform, 16 position GEMMs, output transform and the fused epilogue are ONE kernel; the filter's transform is made
+ * once per optimizer step:
+ *   dpig_wino_filter_elems      floats of one transformed image of a [3][3][C][K] filter (16 C K), 0 if C or K is not a multiple of 64
+ *   dpig_wino_filter_transform  u_fwd / u_dgrad (either may be NULL) <- HWIO filter w; u_dgrad is the image of the 180-degree rotated,
+ *                               channel-transposed filter that makes conv_backward_data the same kernel
+ *   dpig_conv2d_wino_eligible   1 if the descriptor (which = 0 forward, 1 dgrad) has a Winograd form (3x3, stride 1, even H and W,
+ *                               C and K multiples of 64, 16-byte channel vectors, no class residual) AND the cost model expects it to
+ *                               beat the direct kernel (small maps that cannot fill 256 CUs with 64-tile x 64-channel workgroups
+ *                               stay direct); dpig_conv_wino_set_mode / DPIG_WINO: 0 never, 1 cost model (default), 2 wherever legal
+ *   dpig_conv2d_fwd_wino        dpig_conv2d_fwd's semantics (bias, activation, residual before / after it, second output y_act)
+ *   dpig_conv2d_dgrad_wino      dpig_conv2d_dgrad's semantics ((. + accum) * act'(mask))
+ * wgrad has no Winograd form here (dpig_conv2d_wgrad).  No workspace. */
+size_t dpig_wino_filter_elems(int C, int K);
+int dpig_wino_filter_transform(const float* w, int C, int K, float* u_fwd, float* u_dgrad, void* stream);
+int dpig_conv2d_wino_eligible(const DpigConvDesc* d, int which);
+int dpig_conv_wino_set_mode(int mode);
+int dpig_conv2d_fwd_wino(const DpigConvDesc* d, const float* x, const float* u_fwd, const float* bias, const float* residual,
+                         float* y, float* y_act, void* stream);
+int dpig_conv2d_dgrad_wino(const DpigConvDesc* d, const float* dy, const float* u_dgrad, const float* accum, const float* mask,
+                           float* dx, void* stream);
+
 /* The thin layers of 'bf16' mode on the vector-ALU kernels (csrc/dpig_thin.hip) with their WIDE tensor stored as bf16;
  * the 3-channel image side, the fp32 HWIO filter and the filter gradient stay fp32:
  *   K == 3 (3x3 s1, the generator's image conv models.py:573):        x / dx bf16 [.., C],   y / dy fp32 [.., 3]

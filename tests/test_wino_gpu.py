@@ -1,0 +1,232 @@
+"""GPU parity of the Winograd F(2x2, 3x3) fp32 kernel (csrc/dpig_conv_wino.hip) through dpig_conv2d_fwd_wino / _dgrad_wino and the
+'f32w' mode of hip_ops: same fp64 oracle (oracle.ops.conv2d_same + its autograd gradients), same 2e-5 of max|ref| bar as the direct
+fp32 kernels of tests/test_conv_gpu.py -- the arithmetic type is the same, only the evaluation order differs -- on shapes that hit every
+structural edge: a partial last row block, tiles that straddle images, exactly one block, several channel blocks / chunks, image
+borders on every side, channel slices of wider buffers, and every fused epilogue of the family."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _rand(shape, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g, dtype=torch.float64) * 2 - 1) * scale
+
+
+def _close(got, ref, tol=2e-5):
+    ref = ref.double()
+    err = (got.double().cpu() - ref).abs().max().item()
+    scale = max(ref.abs().max().item(), 1e-12)
+    assert err <= tol * scale, "max err %.3e vs max|ref| %.3e (%.2e relative)" % (err, scale, err / scale)
+    return err / scale
+
+
+@pytest.fixture
+def wino():
+    import dpig_amd.hip_ops as H
+    H.set_compute("f32w")
+    H.set_wino_mode(2)                  # wherever legal: the cost model would keep these small layers on the direct kernel
+    yield H
+    H.set_wino_mode(1)
+    H.set_compute("f32")
+
+
+# (N, H, W, C, K)
+SHAPES = [
+    (2, 8, 6, 64, 64),        # 24 tiles: one partial block, one chunk-block
+    (1, 16, 16, 128, 64),     # exactly 64 tiles
+    (3, 10, 14, 64, 128),     # 105 tiles: blocks straddle images, partial last block, two channel blocks
+    (2, 4, 4, 192, 64),       # 2 x 2 tiles per image: every tile touches two borders; 24 chunks
+    (5, 2, 2, 64, 64),        # one tile per image: all four borders
+    (1, 32, 24, 64, 192),     # 192 tiles x 3 channel blocks
+]
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_forward_and_dgrad_against_oracle(dev, wino, shape):
+    H = wino
+    from oracle import ops as O
+    N, Hh, W, C, K = shape
+    x = _rand((N, Hh, W, C), 1).requires_grad_(True)
+    w = _rand((3, 3, C, K), 2, 1.5 / (9 * C) ** 0.5)
+    b = _rand((K,), 3)
+    ref = O.conv2d_same(x, w, b, 1)
+    dy = _rand(tuple(ref.shape), 4)
+    (rdx,) = torch.autograd.grad(ref, x, dy)
+    xd, wd, bd, dyd = x.detach().float().to(dev), w.float().to(dev), b.float().to(dev), dy.float().to(dev)
+    H.PROFILE = []
+    try:
+        y = H.conv2d_fwd(xd, wd, bd)
+        dx = H.conv2d_dgrad(dyd, wd, (N, Hh, W, C))
+        kinds = [r[0] for r in H.PROFILE]
+    finally:
+        H.PROFILE = None
+    assert kinds == ["conv_fwd_wino", "conv_dgrad_wino"], kinds          # the Winograd kernel ran, not a silent direct fall-back
+    # operands are fp32-rounded on the device: compare with the oracle on the same rounded values
+    ref32 = O.conv2d_same(xd.cpu().double().requires_grad_(True), wd.cpu().double(), bd.cpu().double(), 1)
+    _close(y, ref32.detach())
+    xr = xd.cpu().double().requires_grad_(True)
+    (rdx32,) = torch.autograd.grad(O.conv2d_same(xr, wd.cpu().double(), None, 1), xr, dyd.cpu().double())
+    _close(dx, rdx32)
+    # and the direct kernels agree with it to the same bar (two evaluation orders of one fp32 sum)
+    H.set_compute("f32")
+    try:
+        yd = H.conv2d_fwd(xd, wd, bd)
+    finally:
+        H.set_compute("f32w")
+    assert float((y - yd).abs().max()) <= 4e-5 * float(yd.abs().max())
+    assert torch.equal(H.conv2d_fwd(xd, wd, bd), y)                       # repeatable
+
+
+def test_fused_epilogues_and_channel_slices(dev, wino):
+    H = wino
+    from oracle import ops as O
+    N, Hh, W, C, K = 3, 10, 14, 64, 128
+    x, w, b = _rand((N, Hh, W, C), 1), _rand((3, 3, C, K), 2, 0.1), _rand((K,), 3)
+    res = _rand((N, Hh, W, K), 4)
+    f = lambda t: t.float().to(dev)
+    r = lambda t: t.float().double()
+    xd, wd, bd, rd = f(x), f(w), f(b), f(res)
+    xr = r(x).requires_grad_(True)
+    conv0 = O.conv2d_same(xr, r(w), None, 1)
+    conv = conv0.detach() + r(b)
+    _close(H.conv2d_fwd(xd, wd, None), conv0.detach())
+    _close(H.conv2d_fwd(xd, wd, bd, act=1), O.relu(conv))
+    _close(H.conv2d_fwd(xd, wd, bd, act=2, alpha=0.2), O.leaky_relu(conv, 0.2))
+    _close(H.conv2d_fwd(xd, wd, bd, act=1, residual=rd), O.relu(conv + r(res)))
+    out, out_act = torch.empty((N, Hh, W, K), device=dev), torch.empty((N, Hh, W, K), device=dev)
+    H.conv2d_fwd(xd, wd, bd, act=1, residual=rd, res_after_act=True, out=out, out_act=out_act)
+    _close(out_act, O.relu(conv))
+    _close(out, O.relu(conv) + r(res))
+    _close(H.conv2d_fwd(xd, wd, bd, act=1, residual=rd, res_after_act=True), O.relu(conv) + r(res))
+    # channel slices of wider buffers on both sides (how the decoder's concats are realised)
+    xbig = torch.zeros((N, Hh, W, C + 64), device=dev)
+    xbig[..., 64:] = xd
+    ybig = torch.full((N, Hh, W, K + 64), 7.0, device=dev)
+    H.conv2d_fwd(xbig[..., 64:], wd, bd, act=1, out=ybig[..., :K])
+    _close(ybig[..., :K], O.relu(conv))
+    assert bool((ybig[..., K:] == 7.0).all())
+    # dgrad: plain, * mask, (+ accum) * mask, + accum
+    dy = _rand((N, Hh, W, K), 6)
+    conv0.backward(r(dy))
+    dyd = f(dy)
+    acc, m = _rand((N, Hh, W, C), 7), _rand((N, Hh, W, C), 8)
+    ad, md = f(acc), f(m)
+    H.PROFILE = []
+    try:
+        _close(H.conv2d_dgrad(dyd, wd, (N, Hh, W, C)), xr.grad)
+        _close(H.conv2d_dgrad(dyd, wd, (N, Hh, W, C), mask=md, act=1), xr.grad * (r(m) > 0))
+        _close(H.conv2d_dgrad(dyd, wd, (N, Hh, W, C), accum=ad, mask=md, act=2, alpha=0.2), (xr.grad + r(acc)) * torch.where(r(m) > 0, 1.0, 0.2))
+        _close(H.conv2d_dgrad(dyd, wd, (N, Hh, W, C), accum=ad), xr.grad + r(acc))
+        assert all(k[0] == "conv_dgrad_wino" for k in H.PROFILE) and len(H.PROFILE) == 4
+    finally:
+        H.PROFILE = None
+
+
+def test_layers_without_a_winograd_form_stay_on_the_direct_kernels(dev, wino):
+    """stride 2, 5x5, 1x1, odd maps, channel counts that are not multiples of 64, the class-indexed residual: `conv2d_wino_eligible` says
+    no and the call runs the direct kernel (same results as 'f32' mode, bit for bit)."""
+    H = wino
+    cases = [(2, 8, 6, 64, 64, 3, 2), (2, 8, 6, 64, 64, 5, 1), (2, 8, 6, 64, 64, 1, 1), (2, 7, 6, 64, 64, 3, 1), (2, 8, 6, 96, 64, 3, 1),
+             (2, 8, 6, 64, 32, 3, 1)]
+    for N, Hh, W, C, K, k, s in cases:
+        x, w = _rand((N, Hh, W, C), 1).float().to(dev), _rand((k, k, C, K), 2, 0.1).float().to(dev)
+        H.PROFILE = []
+        try:
+            y = H.conv2d_fwd(x, w, None, stride=s)
+            kinds = [r[0] for r in H.PROFILE]
+        finally:
+            H.PROFILE = None
+        assert kinds == ["conv_fwd_mfma"], (kinds, (N, Hh, W, C, K, k, s))
+        H.set_compute("f32")
+        try:
+            assert torch.equal(H.conv2d_fwd(x, w, None, stride=s), y)
+        finally:
+            H.set_compute("f32w")
+
+
+FULL = [("dec4", 16, 128, 64, 256), ("dec3", 16, 64, 32, 512), ("dec2", 16, 32, 16, 768), ("roi b1", 112, 24, 24, 256)]
+
+
+@pytest.mark.parametrize("layer", FULL, ids=[l[0] for l in FULL])
+def test_full_size_layers_against_the_sampled_oracle(dev, layer):
+    """BASELINE configs[1] layer sizes under the DEFAULT selection (cost model): 4096 sampled output / input positions against
+    oracle.ops.conv2d_same*_sampled in fp64, forward + bias + ReLU and dgrad."""
+    import dpig_amd.hip_ops as H
+    from oracle import ops as O
+    _, N, Hh, W, C = layer
+    g = torch.Generator(device=dev).manual_seed(5)
+    x = torch.rand((N, Hh, W, C), device=dev, generator=g) * 2 - 1
+    w = (torch.rand((3, 3, C, C), device=dev, generator=g) * 2 - 1) * (1.5 / (9 * C) ** 0.5)
+    b = torch.rand((C,), device=dev, generator=g) - 0.5
+    dy = torch.rand((N, Hh, W, C), device=dev, generator=g) * 2 - 1
+    gc = torch.Generator().manual_seed(6)
+    P = 4096
+    n, oy, ox = torch.randint(0, N, (P,), generator=gc), torch.randint(0, Hh, (P,), generator=gc), torch.randint(0, W, (P,), generator=gc)
+    oy[:64], ox[64:128] = 0, 0
+    oy[128:192], ox[192:256] = Hh - 1, W - 1
+    xc, wc, bc, dyc = x.cpu(), w.cpu(), b.cpu(), dy.cpu()
+    ref_y = torch.relu(O.conv2d_same_sampled(xc, wc, bc, 1, n, oy, ox))
+    ref_dx = O.conv2d_same_dgrad_sampled(dyc, wc, (N, Hh, W, C), 1, n, oy, ox)
+    H.set_compute("f32w")
+    H.PROFILE = []
+    try:
+        y = H.conv2d_fwd(x, w, b, act=1)
+        dx = H.conv2d_dgrad(dy, w, (N, Hh, W, C))
+        kinds = [r[0] for r in H.PROFILE]
+    finally:
+        H.PROFILE = None
+        H.set_compute("f32")
+    assert kinds == ["conv_fwd_wino", "conv_dgrad_wino"], kinds
+    idx = (n.to(dev), oy.to(dev), ox.to(dev))
+    _close(y[idx], ref_y, 1e-4)
+    _close(dx[idx], ref_dx, 1e-4)
+
+
+def test_stage1_step_in_winograd_mode_equals_the_exact_mode(dev):
+    """Config(compute_dtype='f32w'): one g_optim + d_optim of the stage-I trainer (width 64, so that the 3x3 layers have Winograd forms)
+    against the same step in 'f32' mode: losses to 1e-5, generator output to 1e-4 of its range, and the Winograd images follow the
+    masters through the optimizer step."""
+    import numpy as np
+    import dpig_amd.hip_ops as H
+    import dpig_amd.tflib as lib
+    from dpig_amd import slim, synthetic
+    from dpig_amd.trainer import Config, DPIG_Encoder_GAN_BodyROI_FgBg
+    res = {}
+    H.set_wino_mode(2)
+    try:
+        for mode in ("f32", "f32w"):
+            lib.delete_all_params(); slim.reset_scopes()
+            np.random.seed(0)
+            B = 2
+            tr = DPIG_Encoder_GAN_BodyROI_FgBg(Config(batch_size=B, conv_hidden_num=64, z_num=16, compute_dtype=mode, g_lr=1e-3, d_lr=1e-3), dev)
+            bg = synthetic.to_device(synthetic.make_batch(B, seed=21), dev)
+            bd = synthetic.to_device(synthetic.make_batch(B, seed=22), dev)
+            tr.init_net(bg)
+            tr.step = 1
+            if mode == "f32w":
+                assert len(tr.G_flat.wino.params) > 20
+                p0 = tr.G_flat.wino.params[0]
+                u0 = p0._dpig_wino[0].clone()
+            H.PROFILE = []
+            out = tr.train_step(bg, bd)
+            kinds = set(r[0] for r in H.PROFILE)
+            H.PROFILE = None
+            if mode == "f32w":
+                assert "conv_fwd_wino" in kinds and "conv_dgrad_wino" in kinds
+                assert not torch.equal(p0._dpig_wino[0], u0)                 # refreshed after Adam moved the filter
+                assert torch.equal(p0._dpig_wino[0], H.wino_images(p0.data.clone())[0])
+            else:
+                assert "conv_fwd_wino" not in kinds
+            res[mode] = ({k: float(v) for k, v in out.items() if hasattr(v, "numel") and v.numel() == 1}, out["G"].clone(),
+                         tr.G_flat.grad.clone())
+        for k in ("g_loss", "d_loss", "L1Loss"):
+            assert abs(res["f32w"][0][k] - res["f32"][0][k]) <= 1e-5 * abs(res["f32"][0][k]), (k, res["f32w"][0][k], res["f32"][0][k])
+        Gd = (res["f32w"][1] - res["f32"][1]).abs().max().item()
+        assert Gd <= 1e-4 * res["f32"][1].abs().max().item(), Gd
+    finally:
+        H.PROFILE = None
+        H.set_wino_mode(1)
+        H.set_compute("f32")
+        lib.delete_all_params(); slim.reset_scopes()
