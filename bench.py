@@ -161,12 +161,14 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly (no hipGraph replay)")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "bf16c", "bf16x3"],
+    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "bf16c", "bf16x3", "f32w"],
                     help="f32 = the BASELINE metric's arithmetic.  bf16 (information lines; BASELINE configs 3-5): activations, "
                          "their gradients and the filter shadows stored as bf16, bf16 matrix pipe, fp32 accumulation / master "
                          "weights / gradients / optimizer.  bf16c: round 1's intermediate mode (fp32 tensors, bf16 pipe).  bf16x3 "
                          "(information line): fp32 tensors, conv operands split into two bf16 terms, three bf16 MFMAs per product "
-                         "block -- the exact kernels' own 2e-5 accuracy bar on the bf16 pipe")
+                         "block -- the exact kernels' own 2e-5 accuracy bar on the bf16 pipe.  f32w (information line): f32 with the 3x3 "
+                         "stride-1 convs (forward + dgrad) evaluated by Winograd F(2x2,3x3) on the fp32 matrix pipe: fp32 tensors, fp32 "
+                         "products, fp32 accumulation, 2.25x fewer multiplies (csrc/dpig_conv_wino.hip)")
     ap.add_argument("--no-info-lines", action="store_true",
                     help="headline run only: skip the information lines (df256 / stage-II / Market in bf16, Market wgan-gp) that "
                          "are measured in sub-processes after the headline and embedded under `info_lines`")
@@ -440,6 +442,8 @@ def main():
             "bf16c": ("conv_fwd_mfma", PEAK_BF16_MFMA_TFLOPS, "conv fwd implicit GEMM, fp32 tensors rounded to bf16 on the way into LDS", 1.0),
             "bf16x3": ("conv_fwd_mfma", PEAK_BF16_MFMA_TFLOPS, "conv fwd implicit GEMM, fp32 tensors as two-term bf16 splits: 3 bf16 MFMAs per product "
                        "block (executed FLOPs = 3 x algorithmic)", 3.0),
+            "f32w": ("conv_fwd_wino", PEAK_F32_MFMA_TFLOPS, "dpig::wino::wino_kernel (3x3 stride-1 conv fwd as Winograd F(2x2,3x3): 16 position GEMMs on "
+                     "v_mfma_f32_32x32x2_f32, transforms fused; FLOPs = the 16/36 of the direct count that are executed)", 1.0),
         }[args.dtype]
         fwd = [(f, t) for (k, f, t) in recs if k == dom]
         nl = max(len(fwd), 1)
@@ -501,7 +505,7 @@ def main():
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
-            "config": {"workload": "%s, bs=%d per GPU, %s; %s" % (wl_desc, B, {"f32": "fp32", "bf16": "bf16 storage (activations, their gradients, filter shadows) + bf16 matrix pipe; fp32 accumulation, master weights, gradients and optimizer", "bf16c": "bf16 matrix pipe on fp32 tensors", "bf16x3": "fp32 tensors; conv products as three bf16 MFMAs on two-term bf16 splits of the fp32 operands (<= 2e-5 max|ref| per kernel, the exact path's test bar); everything else fp32"}[args.dtype], POSE_DESC),
+            "config": {"workload": "%s, bs=%d per GPU, %s; %s" % (wl_desc, B, {"f32": "fp32", "f32w": "fp32 (tensors, products, accumulation); 3x3 stride-1 convs forward + dgrad by Winograd F(2x2,3x3) where the cost model says it pays", "bf16": "bf16 storage (activations, their gradients, filter shadows) + bf16 matrix pipe; fp32 accumulation, master weights, gradients and optimizer", "bf16c": "bf16 matrix pipe on fp32 tensors", "bf16x3": "fp32 tensors; conv products as three bf16 MFMAs on two-term bf16 splits of the fp32 operands (<= 2e-5 max|ref| per kernel, the exact path's test bar); everything else fp32"}[args.dtype], POSE_DESC),
                        "global_batch": world * B, "parallelism": "dp%d" % world},
             "achieved_alg_tflops": round(ALG_GFLOP_PER_IMG * value / 1e3, 2) if headline else None,
             "losses": {k: float(v) for k, v in out.items() if hasattr(v, "numel") and v.numel() == 1 and not sampling},

@@ -9,18 +9,21 @@
 // i.e. 16 independent GEMMs  M_p[tile, k] = sum_c V_p[tile, c] U_p[c, k],  p = (xi, nu) in 4 x 4, on 1/4 of the rows: 2.25x fewer
 // MFMA FLOPs.  Everything is fused in ONE kernel so that neither the 4x-expanded input transform V nor the 4x-expanded product M
 // ever exists in HBM:
-//   * a workgroup owns 64 tiles (256 output pixels) x 64 output channels and ALL 16 positions: four waves (2 tile halves x 2 channel
-//     halves), each holding 16 accumulator blocks of v_mfma_f32_32x32x2_f32 (32 output channels x 32 tiles per position) = 256
-//     accumulator registers -> one wave per SIMD, one workgroup per CU (__launch_bounds__(256, 1));
-//   * the reduction runs over input channels in chunks of 8: per chunk a thread loads the 3 x 4 input pixels its half of the row
-//     transform needs (buffer loads with out-of-range offsets as the zero padding), applies B^T . B in registers (64 adds) and writes
+//   * a workgroup owns 64 tiles (256 output pixels) x 64 output channels and ALL 16 positions: eight waves = 2 position halves x 2 tile
+//     halves x 2 channel halves, each holding 8 accumulator blocks of v_mfma_f32_32x32x2_f32 (32 output channels x 32 tiles per
+//     position) = 128 accumulator registers -> two waves per SIMD (the two position halves of one block: one stages while the other
+//     feeds the matrix pipe), one workgroup per CU.  (The first form, four waves with all 16 positions = 256 accumulators each and one
+//     wave per SIMD, ran the k-loop at ~70 % of the pipe: nothing hides a lone wave's own issue stalls; scripts/trace_wino.py.)
+//   * the reduction runs over input channels in chunks of 8: per chunk a thread loads the 2 x 4 input pixels its row of the row
+//     transform needs (buffer loads with out-of-range offsets as the zero padding), applies B^T . B in registers and writes four
 //     16-byte rows of V_p into LDS; the transformed filter U_p arrives by LDS-DMA from a precomputed image (dpig_wino_filter_transform:
 //     once per optimizer step, like the bf16 filter shadows) that already HAS the LDS layout, bank swizzle included;
-//   * per chunk a wave issues 64 MFMAs (4096 cycles of pipe time) against 32 ds_read_b128, 12 global loads, 8 DMA pieces, 64 VALU and
-//     8 ds_write_b128: the loop is matrix-bound with a wide margin, which is what lets a one-wave-per-SIMD kernel work;
-//   * output transform A^T . A is pure per-lane register arithmetic (a lane holds the same (tile, channel) element of all 16
-//     positions), then the 2 x 2 pixels go through LDS into the family's fused row-contiguous epilogue (bias, activation, residual
-//     before / after the activation with the second output, dgrad's (. + accum) * act'(mask)).
+//   * per chunk a wave issues 32 MFMAs (2048 cycles of pipe time; 4096 per SIMD) against 16 ds_read_b128, 8 global loads, 4 DMA pieces,
+//     ~32 VALU and 4 ds_write_b128: the loop is matrix-bound with a wide margin;
+//   * the output transform A^T . A is per-lane register arithmetic on each wave's eight positions (a lane holds the same (tile, channel)
+//     element of all of them); the two position halves' partial 2 x 2 pixels meet in LDS on their way into the family's fused
+//     row-contiguous epilogue (bias, activation, residual before / after the activation with the second output, dgrad's
+//     (. + accum) * act'(mask)).
 // dgrad of a 3 x 3 stride-1 SAME conv is the same conv with the filter rotated by 180 degrees and its channel roles swapped: the
 // same kernel on a second transformed image (U' from w[2-r][2-s][c][k] read as [k][c]).  wgrad stays on the direct kernels.
 //
@@ -43,10 +46,10 @@ constexpr int CH = 8;                         // reduction channels per chunk
 constexpr int ROWB = CH * 4;                  // bytes of one (position, row)
 constexpr int PLANE = 64 * ROWB;              // one position: 2 KB
 constexpr int OPB = 16 * PLANE;               // one operand, one chunk: 32 KB
-constexpr int SMEM = 4 * OPB;                 // V[2] | U[2]
 constexpr int EP_ROW = KB * 4 + 16;           // epilogue staging: bytes per pixel row (+16: conflict-free 16-byte stores)
+constexpr int SMEM = 2 * 256 * EP_ROW;        // the loop's V[2] | U[2] (128 KB) or the epilogue's two staging images (136 KB)
 constexpr unsigned OOB = 0x7fffffffu;
-static_assert(256 * EP_ROW <= SMEM, "epilogue staging fits the loop's LDS");
+static_assert(4 * OPB <= SMEM && SMEM <= 163840, "LDS plan");
 
 typedef __attribute__((address_space(3))) char lds_char;
 typedef __attribute__((address_space(3))) void lds_void;
@@ -67,6 +70,7 @@ struct WParams {
     int act; float alpha; int res_post;
     unsigned x_bytes, u_bytes;
     unsigned mul_thw, shr_thw, mul_tw, shr_tw;
+    unsigned long long* trace;   // dev aid (dpig_debug_wino_trace): 8 s_memtime stamps per workgroup, or null
 };
 
 __device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned shr) {
@@ -97,7 +101,7 @@ __device__ __forceinline__ void epi4(const WParams& p, long pix, int col, f32x4 
     *reinterpret_cast<f32x4*>(p.D + pix * p.ldd + col) = v;
 }
 
-__global__ __launch_bounds__(256, 1) void wino_kernel(const WParams p) {
+__global__ __launch_bounds__(512, 2) void wino_kernel(const WParams p) {
     __shared__ __attribute__((aligned(16))) char smem[SMEM];
     lds_char* const L = (lds_char*)smem;
     const int tid = threadIdx.x;
@@ -110,18 +114,20 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const WParams p) {
     const int tile = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
     const int nt = tile / p.mtiles, mt = tile - nt * p.mtiles;
     const int t0 = mt * TB, n0 = nt * KB;
+    auto stamp = [&](int slot) {
+        if (p.trace && tid == 0) p.trace[(long)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
 
     const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.X, p.x_bytes);
     const __amdgpu_buffer_rsrc_t rsU = make_rsrc(p.U, p.u_bytes);
 
-    // ---- input-transform role: tile tl = 32 (wave & 1) + lane / 2, channel quad q = lane & 1, transform rows xi = 2 xh, 2 xh + 1 --------
-    const int tl = 32 * (wave & 1) + (lane >> 1), q = lane & 1, xh = wave >> 1;
-    // patch rows (a, b, c) this thread loads: transform rows 2 xh, 2 xh + 1 are  a - c  and  sgn * b + c  with
-    //   xh = 0: (a, b, c) = patch rows (0, 1, 2), sgn = +1   [xi 0: d0 - d2,  xi 1: d1 + d2]
-    //   xh = 1: (a, b, c) = patch rows (2, 3, 1), sgn = -1   [xi 2: d2 - d1,  xi 3: d1 - d3]        (B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1])
-    // -- one instruction stream for both wave pairs, no branch in the loop
-    const float sgn = xh ? -1.f : 1.f;
-    int voff[3][4];
+    // ---- input-transform role: tile tl = 32 (wave & 1) + lane / 2, channel quad q = lane & 1, transform row xi = wave / 2 ---------------
+    // B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1]: row xi of B^T d is  A + sgn * C  of two patch rows (A, C):
+    //   xi 0: (0, 2) -   xi 1: (1, 2) +   xi 2: (2, 1) -   xi 3: (1, 3) -        -- one instruction stream for all eight waves
+    const int tl = 32 * (wave & 1) + (lane >> 1), q = lane & 1, xi = wave >> 1;
+    const float sgn = xi == 1 ? 1.f : -1.f;
+    int voff[2][4];
     {
         const int t = t0 + tl;
         const bool tok = t < p.T;
@@ -131,8 +137,8 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const WParams p) {
         const int ty = fast_div(rem, p.mul_tw, p.shr_tw);
         const int tx = rem - ty * p.TW;
 #pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const int prow = xh ? (i == 0 ? 2 : (i == 1 ? 3 : 1)) : i;
+        for (int i = 0; i < 2; ++i) {
+            const int prow = i == 0 ? (xi == 0 ? 0 : (xi == 2 ? 2 : 1)) : (xi == 2 ? 1 : (xi == 3 ? 3 : 2));
             const int iy = 2 * ty - 1 + prow;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -142,8 +148,8 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const WParams p) {
             }
         }
     }
-    const int v_wr = tl * ROWB + ((q ^ ((tl >> 3) & 1)) << 4);       // this thread's 16 bytes of a V row (half-swap swizzle)
-    f32x4 d[3][4];
+    const int v_wr = (4 * xi) * PLANE + tl * ROWB + ((q ^ ((tl >> 3) & 1)) << 4);   // this thread's 16 bytes of V rows 4 xi .. 4 xi + 3
+    f32x4 d[2][4];
     auto loadVrow = [&](int chunk, int i) {                          // patch row slot i (literal) of `chunk`
         const int so = chunk < p.nch ? chunk * ROWB : 0;
         const int dead = chunk < p.nch ? 0 : (int)OOB;
@@ -151,24 +157,14 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const WParams p) {
         for (int j = 0; j < 4; ++j)
             d[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, voff[i][j] | dead, so, 0));
     };
-    auto loadV = [&](int chunk) {
-        loadVrow(chunk, 0);
-        loadVrow(chunk, 1);
-        loadVrow(chunk, 2);
-    };
-    // B^T d B in three stages so that the k-loop can place them between MFMA groups: rows, then the four columns of either row
-    f32x4 r0[4], r1[4];
+    f32x4 r[4];
     typedef __attribute__((address_space(3))) f32x4 lds_f4;
-    auto rowsV = [&](int which) {
+    auto rowV = [&]() {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (which == 0) r0[j] = d[0][j] - d[2][j];
-            else r1[j] = sgn * d[1][j] + d[2][j];
-        }
+        for (int j = 0; j < 4; ++j) r[j] = sgn * d[1][j] + d[0][j];
     };
-    auto colsV = [&](int buf, int which, int pair) {                 // positions 8 xh + 4 which + 2 pair, + 1
-        const f32x4* r = which ? r1 : r0;
-        lds_char* const base = L + buf * OPB + (8 * xh + 4 * which) * PLANE + v_wr;
+    auto colsV = [&](int buf, int pair) {                            // positions 4 xi + 2 pair, + 1
+        lds_char* const base = L + buf * OPB + v_wr;
         if (pair == 0) {
             *(lds_f4*)(base + 0 * PLANE) = r[0] - r[2];
             *(lds_f4*)(base + 1 * PLANE) = r[1] + r[2];
@@ -177,48 +173,46 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const WParams p) {
             *(lds_f4*)(base + 3 * PLANE) = r[1] - r[3];
         }
     };
-    auto transformV = [&](int buf) {
-        rowsV(0); rowsV(1);
-        colsV(buf, 0, 0); colsV(buf, 0, 1); colsV(buf, 1, 0); colsV(buf, 1, 1);
-    };
-    // ---- filter DMA role: the chunk's 32-KB image is 32 pieces of 1 KB; wave w moves pieces 8 w .. 8 w + 7 ---------------------------
+    // ---- filter DMA role: the chunk's 32-KB image is 32 pieces of 1 KB; wave w moves pieces 4 w .. 4 w + 3 ---------------------------
     const int u_base = (nt * p.nch) * OPB;                           // byte offset of this column block's first chunk
-    auto dmaUhalf = [&](int chunk, int buf, int h4) {                // pieces 4 h4 .. 4 h4 + 3 of this wave's eight
+    auto dmaU = [&](int chunk, int buf) {
         const int dead = chunk < p.nch ? 0 : (int)OOB;
-        const int so = u_base + (chunk < p.nch ? chunk : 0) * OPB + wave * 8192;
+        const int so = u_base + (chunk < p.nch ? chunk : 0) * OPB + wave * 4096;
 #pragma unroll
-        for (int i = 4 * h4; i < 4 * h4 + 4; ++i)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (lds_void*)(L + 2 * OPB + buf * OPB + wave * 8192 + i * 1024), 16,
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (lds_void*)(L + 2 * OPB + buf * OPB + wave * 4096 + i * 1024), 16,
                                                      (lane * 16 + i * 1024) | dead, so, 0, 0);
     };
-    auto dmaU = [&](int chunk, int buf) {
-        dmaUhalf(chunk, buf, 0);
-        dmaUhalf(chunk, buf, 1);
-    };
 
-    // ---- MFMA role: wave = (tile half wr, channel half wc); fragment = 16 bytes of row l31 (+ 32 half-block), slot half ^ swizzle ------
-    const int wr = wave >> 1, wc = wave & 1;
+    // ---- MFMA role: wave = (position half ph, tile half wr, channel half wc): positions 8 ph .. 8 ph + 7 of a 32-tile x 32-channel block;
+    // waves w and w + 4 share a SIMD (the two position halves of one block).  Fragment = 16 bytes of row l31, slot half ^ swizzle ------
+    const int ph = wave >> 2, wr = (wave >> 1) & 1, wc = wave & 1;
     const int f_row_v = 32 * wr + l31, f_row_u = 32 * wc + l31;
-    const int fv = f_row_v * ROWB + ((half ^ ((f_row_v >> 3) & 1)) << 4);
-    const int fu = 2 * OPB + f_row_u * ROWB + ((half ^ ((f_row_u >> 3) & 1)) << 4);
-    f32x16 acc[16];
+    const int fv = (8 * ph) * PLANE + f_row_v * ROWB + ((half ^ ((f_row_v >> 3) & 1)) << 4);
+    const int fu = 2 * OPB + (8 * ph) * PLANE + f_row_u * ROWB + ((half ^ ((f_row_u >> 3) & 1)) << 4);
+    f32x16 acc[8];
 #pragma unroll
-    for (int pp = 0; pp < 16; ++pp)
+    for (int pp = 0; pp < 8; ++pp)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[pp][r] = 0.f;
+        for (int e = 0; e < 16; ++e) acc[pp][e] = 0.f;
     typedef const __attribute__((address_space(3))) f32x4 lds_cf4;
 
-    // ---- prologue: chunk 0 staged, chunk 1's input patch in registers ---------------------------------------------------------------
+    // ---- prologue: chunk 0 staged, chunk 1's input patch rows in registers ------------------------------------------------------------
     dmaU(0, 0);
-    loadV(0);
-    transformV(0);
-    loadV(1);
-    wait_vm<12>();                                   // the filter pieces of chunk 0 are older than the 12 loads just issued
+    loadVrow(0, 0);
+    loadVrow(0, 1);
+    rowV();
+    colsV(0, 0);
+    colsV(0, 1);
+    loadVrow(1, 0);
+    loadVrow(1, 1);
+    wait_vm<8>();                                    // the filter pieces of chunk 0 are older than the 8 loads just issued
     __syncthreads();
-    // One chunk = 16 steps (positions), each {fragments of the NEXT position, 4 MFMAs on this position's accumulator block (256 cycles of
-    // pipe time), a slice of the staging work for chunk c + 1 / c + 2}; sched_barrier pins the slices between the MFMA groups -- with one
-    // wave per SIMD nothing else hides them.  Slices: steps 0-1 filter DMA of chunk c + 1 (4 pieces each), 2-3 the row transform of the
-    // patch held in registers (chunk c + 1), 4-7 its column transform + the eight 16-byte LDS stores, 8-10 the patch loads of chunk c + 2.
+    stamp(1);
+    // One chunk = 8 steps (this wave's positions), each {fragments of the NEXT position, 4 MFMAs on this position's accumulator block
+    // (256 cycles of pipe time), a slice of the staging work for chunk c + 1 / c + 2}; the SIMD's other wave (the other position half)
+    // fills the matrix pipe while this one stages.  Slices: step 0 the filter DMA of chunk c + 1 (4 pieces), 1 the row transform of the
+    // patch rows held in registers (chunk c + 1), 2-3 its column transform + four 16-byte LDS stores, 4-5 the patch loads of chunk c + 2.
     for (int c = 0; c < p.nch; ++c) {
         const int buf = c & 1;
         lds_char* const Vb = L + buf * OPB + fv;
@@ -227,74 +221,84 @@ __global__ __launch_bounds__(256, 1) void wino_kernel(const WParams p) {
         fa[0] = *(lds_cf4*)(Ub);
         fb[0] = *(lds_cf4*)(Vb);
 #pragma unroll
-        for (int pp = 0; pp < 16; ++pp) {
-            if (pp < 15) {
+        for (int pp = 0; pp < 8; ++pp) {
+            if (pp < 7) {
                 fa[(pp + 1) & 1] = *(lds_cf4*)(Ub + (pp + 1) * PLANE);
                 fb[(pp + 1) & 1] = *(lds_cf4*)(Vb + (pp + 1) * PLANE);
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[pp & 1][s], fb[pp & 1][s], acc[pp], 0, 0, 0);
-            if (pp == 0) dmaUhalf(c + 1, buf ^ 1, 0);    // (that slot was last read in iteration c - 1; every wave is past its barrier)
-            if (pp == 1) dmaUhalf(c + 1, buf ^ 1, 1);
-            if (pp == 2) rowsV(0);
-            if (pp == 3) rowsV(1);
-            if (pp >= 4 && pp < 8) colsV(buf ^ 1, (pp - 4) >> 1, (pp - 4) & 1);
-            if (pp >= 8 && pp < 11) loadVrow(c + 2, pp - 8);
+            if (pp == 0) dmaU(c + 1, buf ^ 1);       // (that slot was last read in iteration c - 1; every wave is past its barrier)
+            if (pp == 1) rowV();
+            if (pp == 2) colsV(buf ^ 1, 0);
+            if (pp == 3) colsV(buf ^ 1, 1);
+            if (pp == 4) loadVrow(c + 2, 0);
+            if (pp == 5) loadVrow(c + 2, 1);
             __builtin_amdgcn_sched_barrier(0);
         }
-        wait_vm<12>();                               // filter pieces of chunk c + 1 home (only the 12 loads of chunk c + 2 are younger)
+        wait_vm<8>();                                // filter pieces of chunk c + 1 home (only the 8 loads of chunk c + 2 are younger)
         __syncthreads();                             // + this wave's V rows written, every wave done reading slot `buf`
     }
     wait_vm<0>();
     __syncthreads();
+    stamp(2);
 
-    // ---- output transform: Y = A^T M A per lane (A^T = [1 1 1 0; 0 1 -1 -1]); lane = (tile l31 of half wr, channels 8 g + 4 half + e) ----
-    // staging rows: [pixel (i, j) of the 2 x 2][tile 0..63] so that the 8 lanes of a store group write 8 consecutive rows
-    typedef __attribute__((address_space(3))) f32x4 lds_f4;
+    // ---- output transform: Y = A^T M A (A^T = [1 1 1 0; 0 1 -1 -1]).  A lane holds element (tile l31 of half wr, channel 8 g + 4 half + e)
+    // of ITS eight positions = transform rows xi = 2 ph, 2 ph + 1: the column transform s[xi][j] is local, the row transform
+    // y[0][j] = s0 + s1 + s2, y[1][j] = s1 - s2 - s3 splits into the two position halves' partial sums
+    //     ph 0: (s0 + s1, s1)          ph 1: (s2, -s2 - s3)
+    // which go to two staging images [ph][pixel (i, j) of the 2 x 2][tile 0..63][64 channels]; the epilogue adds them.
+    const float c0 = ph ? 0.f : 1.f, c1 = ph ? -1.f : 0.f, c2 = ph ? -1.f : 1.f;
     const int strow = 32 * wr + l31;
+    lds_char* const ST = L + ph * (256 * EP_ROW);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
         f32x4 y[2][2];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const int r = 4 * g + e;
-            float t[2][4];
+            const int rr = 4 * g + e;
+            float sx[2][2];
 #pragma unroll
-            for (int nu = 0; nu < 4; ++nu) {
-                t[0][nu] = acc[0 + nu][r] + acc[4 + nu][r] + acc[8 + nu][r];
-                t[1][nu] = acc[4 + nu][r] - acc[8 + nu][r] - acc[12 + nu][r];
+            for (int x2 = 0; x2 < 2; ++x2) {
+                sx[x2][0] = acc[4 * x2 + 0][rr] + acc[4 * x2 + 1][rr] + acc[4 * x2 + 2][rr];
+                sx[x2][1] = acc[4 * x2 + 1][rr] - acc[4 * x2 + 2][rr] - acc[4 * x2 + 3][rr];
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                y[i][0][e] = t[i][0] + t[i][1] + t[i][2];
-                y[i][1][e] = t[i][1] - t[i][2] - t[i][3];
+            for (int j = 0; j < 2; ++j) {
+                y[0][j][e] = sx[0][j] + c0 * sx[1][j];
+                y[1][j][e] = c1 * sx[0][j] + c2 * sx[1][j];
             }
         }
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 2; ++j)
-                *(lds_f4*)(L + ((2 * i + j) * 64 + strow) * EP_ROW + (32 * wc + 8 * g + 4 * half) * 4) = y[i][j];
+                *(lds_f4*)(ST + ((2 * i + j) * 64 + strow) * EP_ROW + (32 * wc + 8 * g + 4 * half) * 4) = y[i][j];
     }
     __syncthreads();
-    // ---- fused epilogue: thread = (16-byte channel group cg, staged row tid / 16 + 16 it) -------------------------------------------
+    stamp(3);
+    // ---- fused epilogue: thread = (16-byte channel group cg, staged row tid / 16 + 32 it); a thread's rows are 2 tiles x 4 pixels -------
     const int cg = tid & 15, col = n0 + 4 * cg;
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
-#pragma unroll 4
-    for (int it = 0; it < 16; ++it) {
-        const int row = (tid >> 4) + 16 * it;                        // (2 i + j) * 64 + tile
-        const int tloc = row & 63, ij = row >> 6;
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+        const int tloc = (tid >> 4) + 32 * k2;
         const int t = t0 + tloc;
         if (t >= p.T) continue;
         const int n = fast_div(t, p.mul_thw, p.shr_thw);
         const int rem = t - n * p.THW;
         const int ty = fast_div(rem, p.mul_tw, p.shr_tw);
         const int tx = rem - ty * p.TW;
-        const long pix = ((long)n * p.H + (2 * ty + (ij >> 1))) * p.W + (2 * tx + (ij & 1));
-        const f32x4 v = *(lds_cf4*)(L + row * EP_ROW + cg * 16);
-        epi4(p, pix, col, v, bv);
+        const long pix0 = ((long)n * p.H + 2 * ty) * p.W + 2 * tx;
+#pragma unroll
+        for (int ij = 0; ij < 4; ++ij) {
+            const int row = ij * 64 + tloc;
+            const f32x4 v = *(lds_cf4*)(L + row * EP_ROW + cg * 16) + *(lds_cf4*)(L + 256 * EP_ROW + row * EP_ROW + cg * 16);
+            epi4(p, pix0 + (ij >> 1) * p.W + (ij & 1), col, v, bv);
+        }
     }
+    stamp(4);
 }
 
 // ---- filter transform: U = G g G^T (G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1]) of every (input channel, output channel) pair, written
@@ -345,6 +349,7 @@ __global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restric
     for (int i = 0; i < 8; ++i) dst[tid + 256 * i] = src[tid + 256 * i];
 }
 
+static unsigned long long* g_trace = nullptr;
 static int g_mode = -1;            // 0 never, 1 where the cost model says it pays (default), 2 wherever legal (tests)
 static void init_mode() {
     if (g_mode >= 0) return;
@@ -397,7 +402,8 @@ static int launch(const DpigConvDesc* d, const float* in, const float* U, const 
     p.u_bytes = (unsigned)((long)16 * cin * kout * 4);
     find_divisor(p.THW, &p.mul_thw, &p.shr_thw);
     find_divisor(p.TW, &p.mul_tw, &p.shr_tw);
-    hipLaunchKernelGGL(wino_kernel, dim3(p.mtiles * p.ntiles), dim3(256), 0, st, p);
+    p.trace = g_trace;
+    hipLaunchKernelGGL(wino_kernel, dim3(p.mtiles * p.ntiles), dim3(512), 0, st, p);
     return check_launch("wino_kernel");
 }
 
@@ -432,6 +438,13 @@ extern "C" int dpig_conv2d_wino_eligible(const DpigConvDesc* d, int which) {
     if (d->C % 64 || d->K % 64) return 0;                       // (one transformed image serves both directions)
     if (!wino::shape_ok(d, cin, kout, ld_in, ld_out)) return 0;
     return wino::pays(d, cin, kout) ? 1 : 0;
+}
+
+// dev aid (scripts/trace_wino.py; not in include/dpig_hip.h): every subsequent Winograd launch writes 8 s_memtime stamps per workgroup
+// (start, prologue done, k-loop done, output transform staged, end) to `buf` (device memory, >= 64 bytes x workgroups); null turns it off.
+extern "C" int dpig_debug_wino_trace(unsigned long long* buf) {
+    wino::g_trace = buf;
+    return DPIG_OK;
 }
 
 extern "C" int dpig_conv_wino_set_mode(int mode) {
