@@ -301,6 +301,217 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WParams p) {
     stamp(4);
 }
 
+// ================================================================================================
+// Filter gradient: F(3x3, 2x2).  dW[r][s][c][k] = sum over tiles of sum_{i,j in 2x2} d[r + i][s + j][c] dy[i][j][k]  (d = the tile's 4 x 4
+// input patch) is, per tile, a 3 x 3-output correlation with a 2 x 2 "filter" dy: minimal filtering gives
+//        dW = A'^T [ sum_tiles (B'^T d B') o (G' dy G'^T) ] A'
+//   B'^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 -1 0 1]   G' = [1 0; 1/2 1/2; 1/2 -1/2; 0 1]   A'^T = [1 1 1 0; 0 1 -1 0; 0 1 1 1]
+// i.e. again 16 position GEMMs  dU_p[c, k] = sum_t V'_p[t, c] Y'_p[t, k]  with the TILES as the reduction axis: 16 multiplies per
+// (tile, c, k) instead of 36.  A workgroup owns a 64 x 64 block of (c, k), all 16 positions (eight waves: 2 position halves x 2 x 2
+// 32 x 32 sub-blocks, 128 accumulator registers each) and a contiguous range of tiles, which it walks in chunks of 8: per chunk every
+// thread loads one row pair of one tile's input patch (8 x 16 bytes) and the tile's 2 x 2 dy pixels (4 x 16 bytes), transforms both in
+// registers and writes 16-byte rows [position][tile][channel] into LDS; the MFMA fragments are 4-byte LDS reads (the reduction index of
+// v_mfma_f32_32x32x2_f32 runs across lanes).  At the end each wave applies A'^T . A' to its own position half in registers and writes
+// its nine 32 x 32 tap blocks as ONE of 2 S partial filter gradients [3][3][C][K]; wino_wgrad_reduce_kernel sums them in fixed order
+// (deterministic) into dw (+ beta dw).  The bias gradient is not part of this kernel (dpig_colsum).
+// ================================================================================================
+struct WGParams {
+    const float* X;       // forward input, NHWC, channel stride ldx
+    const float* DY;      // output gradient, NHWC, channel stride ldy
+    float* part;          // [2 * nsplit][3][3][C][K]
+    int N, H, W, C, K, ldx, ldy;
+    int T, THW, TW;
+    int nchunks, cps;     // 8-tile chunks in the batch, chunks per split
+    int cblocks, kblocks, nsplit;
+    unsigned x_bytes, y_bytes;
+    unsigned mul_thw, shr_thw, mul_tw, shr_tw;
+};
+
+__global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WGParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[4 * OPB];
+    lds_char* const L = (lds_char*)smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    // block order: the (c, k) blocks of one tile range are consecutive, so the workgroups of an XCD read one range of x / dy
+    const int bid = xcd_remap(blockIdx.x, p.cblocks * p.kblocks * p.nsplit);
+    const int nb = p.cblocks * p.kblocks;
+    const int sp = bid / nb, blk = bid - sp * nb;
+    const int cb = blk / p.kblocks, kb = blk - cb * p.kblocks;
+    const int ch0 = sp * p.cps, ch1 = min(ch0 + p.cps, p.nchunks);
+    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.X, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t rsY = make_rsrc(p.DY, p.y_bytes);
+
+    // ---- transform roles: tile slot tl = (tid / 16) % 8, channel quad cq = tid % 16, transform row xi = wave / 2 ----------------------
+    const int cq = tid & 15, tl = (tid >> 4) & 7, xi = wave >> 1;
+    // B'^T row xi of the patch = A + sgn C:  xi 0: (0, 2) -   xi 1: (1, 2) +   xi 2: (2, 1) -   xi 3: (3, 1) -
+    const float sgn = xi == 1 ? 1.f : -1.f;
+    const int rowA = xi == 0 ? 0 : (xi == 1 ? 1 : (xi == 2 ? 2 : 3)), rowC = xi < 2 ? 2 : 1;
+    // G' row xi of the 2 x 2 dy = ga y0 + gb y1:  (1, 0), (1/2, 1/2), (1/2, -1/2), (0, 1)
+    const float ga = xi == 0 ? 1.f : (xi == 3 ? 0.f : 0.5f), gb = xi == 0 ? 0.f : (xi == 1 ? 0.5f : (xi == 2 ? -0.5f : 1.f));
+    const int xcol = (cb * 64 + cq * 4) * 4, ycol = (kb * 64 + cq * 4) * 4;      // byte offsets of this thread's channel quads
+    int xoff[2][4], yoff[2][2];
+    auto tile_offsets = [&](int chunk) {                             // offsets of tile 8 chunk + tl (all out of range past the batch)
+        const int t = chunk * 8 + tl;
+        const bool tok = (chunk < ch1) & (t < p.T);
+        const int tt = tok ? t : 0;
+        const int n = fast_div(tt, p.mul_thw, p.shr_thw);
+        const int rem = tt - n * p.THW;
+        const int ty = fast_div(rem, p.mul_tw, p.shr_tw);
+        const int tx = rem - ty * p.TW;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int iy = 2 * ty - 1 + (i == 0 ? rowA : rowC);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ix = 2 * tx - 1 + j;
+                const bool ok = tok & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
+                xoff[i][j] = ok ? (((n * p.H + iy) * p.W + ix) * p.ldx) * 4 + xcol : (int)OOB;
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                yoff[i][j] = tok ? (((n * p.H + 2 * ty + i) * p.W + 2 * tx + j) * p.ldy) * 4 + ycol : (int)OOB;
+        }
+    };
+    f32x4 d[2][4], y[2][2];
+    auto loadX = [&](int i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) d[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, xoff[i][j], 0, 0));
+    };
+    auto loadY = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) y[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsY, yoff[i][j], 0, 0));
+    };
+    typedef __attribute__((address_space(3))) f32x4 lds_f4;
+    const int wr_off = (4 * xi) * PLANE + tl * 256 + cq * 16;        // [position 4 xi + nu][tile tl][channel quad cq]
+    f32x4 r[4], ry[2];
+    auto rowX = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = sgn * d[1][j] + d[0][j];
+    };
+    auto colsX = [&](int buf, int pair) {
+        lds_char* const base = L + buf * OPB + wr_off;
+        if (pair == 0) {
+            *(lds_f4*)(base + 0 * PLANE) = r[0] - r[2];
+            *(lds_f4*)(base + 1 * PLANE) = r[1] + r[2];
+        } else {
+            *(lds_f4*)(base + 2 * PLANE) = r[2] - r[1];
+            *(lds_f4*)(base + 3 * PLANE) = r[3] - r[1];
+        }
+    };
+    auto rowY = [&]() {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ry[j] = ga * y[0][j] + gb * y[1][j];
+    };
+    auto colsY = [&](int buf, int pair) {
+        lds_char* const base = L + 2 * OPB + buf * OPB + wr_off;
+        if (pair == 0) {
+            *(lds_f4*)(base + 0 * PLANE) = ry[0];
+            *(lds_f4*)(base + 1 * PLANE) = 0.5f * (ry[0] + ry[1]);
+        } else {
+            *(lds_f4*)(base + 2 * PLANE) = 0.5f * (ry[0] - ry[1]);
+            *(lds_f4*)(base + 3 * PLANE) = ry[1];
+        }
+    };
+
+    // ---- MFMA role: wave = (position half ph, channel half cr of the 64 c, half kc of the 64 k); A = V'[tile][c], B = Y'[tile][k] ------
+    const int ph = wave >> 2, cr = (wave >> 1) & 1, kc = wave & 1;
+    const int fa_off = (8 * ph) * PLANE + half * 256 + (32 * cr + l31) * 4;
+    const int fb_off = 2 * OPB + (8 * ph) * PLANE + half * 256 + (32 * kc + l31) * 4;
+    f32x16 acc[8];
+#pragma unroll
+    for (int pp = 0; pp < 8; ++pp)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[pp][e] = 0.f;
+    typedef const __attribute__((address_space(3))) float lds_cf;
+
+    // ---- prologue: chunk ch0 staged, chunk ch0 + 1 in registers ------------------------------------------------------------------------
+    tile_offsets(ch0);
+    loadX(0); loadX(1); loadY();
+    rowX(); colsX(0, 0); colsX(0, 1);
+    rowY(); colsY(0, 0); colsY(0, 1);
+    tile_offsets(ch0 + 1);
+    loadX(0); loadX(1); loadY();
+    __syncthreads();
+    for (int c = ch0; c < ch1; ++c) {
+        const int buf = (c - ch0) & 1;
+        lds_char* const Ab = L + buf * OPB + fa_off;
+        lds_char* const Bb = L + buf * OPB + fb_off;
+        float fa[2][4], fb[2][4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            fa[0][s] = *(lds_cf*)(Ab + s * 512);
+            fb[0][s] = *(lds_cf*)(Bb + s * 512);
+        }
+#pragma unroll
+        for (int pp = 0; pp < 8; ++pp) {
+            if (pp < 7) {
+#pragma unroll
+                for (int s = 0; s < 4; ++s) {
+                    fa[(pp + 1) & 1][s] = *(lds_cf*)(Ab + (pp + 1) * PLANE + s * 512);
+                    fb[(pp + 1) & 1][s] = *(lds_cf*)(Bb + (pp + 1) * PLANE + s * 512);
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[pp & 1][s], fb[pp & 1][s], acc[pp], 0, 0, 0);
+            // staging slices: chunk c + 1 (in registers) -> the other slot, then the loads of chunk c + 2
+            if (pp == 0) rowX();
+            if (pp == 1) colsX(buf ^ 1, 0);
+            if (pp == 2) colsX(buf ^ 1, 1);
+            if (pp == 3) { rowY(); colsY(buf ^ 1, 0); }
+            if (pp == 4) { colsY(buf ^ 1, 1); tile_offsets(c + 2); }
+            if (pp == 5) loadX(0);
+            if (pp == 6) loadX(1);
+            if (pp == 7) loadY();
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();
+    }
+
+    // ---- output transform A'^T dU A' on this wave's position half (transform rows xi = 2 ph, 2 ph + 1), straight to its partial slab.
+    // Column transform (over nu) per row: s0 = M0 + M1 + M2, s1 = M1 - M2, s2 = M1 + M2 + M3; row transform w0 = S0 + S1 + S2,
+    // w1 = S1 - S2, w2 = S1 + S2 + S3 splits into  ph 0: (S0 + S1, S1, S1)   ph 1: (S2, -S2, S2 + S3).
+    float* const slab = p.part + (long)(2 * sp + ph) * 9 * p.C * p.K;
+    const int kcol = kb * 64 + 32 * kc + l31;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+        const int crow = cb * 64 + 32 * cr + 8 * (e >> 2) + 4 * half + (e & 3);
+        float sx[2][3];
+#pragma unroll
+        for (int x2 = 0; x2 < 2; ++x2) {
+            const float m0 = acc[4 * x2 + 0][e], m1 = acc[4 * x2 + 1][e], m2 = acc[4 * x2 + 2][e], m3 = acc[4 * x2 + 3][e];
+            sx[x2][0] = m0 + m1 + m2;
+            sx[x2][1] = m1 - m2;
+            sx[x2][2] = m1 + m2 + m3;
+        }
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3) {
+            const float a = sx[0][s3], b = sx[1][s3];
+            const float w0 = ph ? a : a + b, w1 = ph ? -a : b, w2 = ph ? a + b : b;
+            slab[((long)(0 * 3 + s3) * p.C + crow) * p.K + kcol] = w0;
+            slab[((long)(1 * 3 + s3) * p.C + crow) * p.K + kcol] = w1;
+            slab[((long)(2 * 3 + s3) * p.C + crow) * p.K + kcol] = w2;
+        }
+    }
+}
+
+// dw = beta dw + sum of the nparts partial gradients (fixed order: deterministic)
+__global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, long n4, int nparts,
+                                                                 float beta) {
+    const f32x4* p4 = reinterpret_cast<const f32x4*>(part);
+    f32x4* o4 = reinterpret_cast<f32x4*>(dw);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int s = 0; s < nparts; ++s) v += p4[(long)s * n4 + i];
+        if (beta != 0.f) v += beta * o4[i];
+        o4[i] = v;
+    }
+}
+
 // ---- filter transform: U = G g G^T (G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1]) of every (input channel, output channel) pair, written
 // in the kernel's LDS image order.  `dgrad`: the transposed conv's filter g'[r][s][k][c] = w[2 - r][2 - s][c][k] (input channels = the
 // forward conv's output channels).  w is HWIO [3][3][C][K].
@@ -369,9 +580,10 @@ static bool shape_ok(const DpigConvDesc* d, int cin, int kout, int ld_in, int ld
     if ((long)16 * cin * kout * 4 >= lim) return false;
     return true;
 }
-// Does the fused Winograd kernel beat the direct kernel on this layer?  One workgroup per CU, whole rounds of 256: a round lasts
-// nch x 64 MFMAs x 64 cycles + ~20 k cycles of prologue / output transform / epilogue; the direct family delivers ~115 TFLOP/s on
-// layers that fill the chip and less on the small ones (profiles/r04_market_f32_kernel_stats.md).
+// Does the fused Winograd kernel beat the direct kernel on this layer?  One workgroup per CU, whole rounds of 256: a workgroup's life is
+// ~5050 cycles per 8-channel chunk (64 MFMAs per SIMD = 4096 of them) + ~16 k cycles of prologue / output transform / epilogue
+// (scripts/trace_wino.py); the direct family delivers ~115 TFLOP/s = 50 k FLOP per cycle at the same 2.3 GHz on layers that fill the chip
+// (profiles/r05_wino_layers.txt: the model's choice agrees with the measured faster kernel on all 14 Market layer shapes).
 static bool pays(const DpigConvDesc* d, int cin, int kout) {
     init_mode();
     if (g_mode == 0) return false;
@@ -379,10 +591,9 @@ static bool pays(const DpigConvDesc* d, int cin, int kout) {
     const long T = (long)d->N * (d->H / 2) * (d->W / 2);
     const long wgs = (long)cdiv(T, TB) * (kout / KB);
     const long rounds = (wgs + kNumCU - 1) / kNumCU;
-    const double wino_cycles = (double)rounds * ((double)(cin / CH) * 4096.0 / 0.85 + 20000.0);
-    const double direct_flops = 2.0 * d->N * d->H * d->W * 9.0 * cin * kout;
-    const double direct_cycles = direct_flops / (115e12 / 2.1e9);         // cycles at the ~2.1 GHz these kernels sustain
-    return wino_cycles < 0.9 * direct_cycles;
+    const double wino_cycles = (double)rounds * ((double)(cin / CH) * 5050.0 + 16000.0);
+    const double direct_cycles = 2.0 * d->N * d->H * d->W * 9.0 * cin * kout / 50000.0;
+    return wino_cycles < 0.95 * direct_cycles;
 }
 
 static int launch(const DpigConvDesc* d, const float* in, const float* U, const float* bias, const float* res, const float* mask,
@@ -407,10 +618,98 @@ static int launch(const DpigConvDesc* d, const float* in, const float* U, const 
     return check_launch("wino_kernel");
 }
 
+// ---- filter-gradient plan: splits over the tile axis so that (C / 64)(K / 64) S workgroups fill whole rounds of the chip -----------
+struct WGPlan { int nsplit, cps, nchunks; };
+static WGPlan wgrad_plan(const DpigConvDesc* d) {
+    WGPlan pl;
+    const long T = (long)d->N * (d->H / 2) * (d->W / 2);
+    pl.nchunks = cdiv(T, 8);
+    const int blocks = (d->C / 64) * (d->K / 64);
+    int best = 1;
+    double best_score = -1.0;
+    for (int s = 1; s <= 256; ++s) {
+        if (pl.nchunks / s < 16 && s > 1) break;                   // at least 16 chunks (128 tiles) per workgroup
+        const long wgs = (long)blocks * s;
+        const long rounds = (wgs + kNumCU - 1) / kNumCU;
+        const double cps = (double)cdiv(pl.nchunks, s);
+        const double cost = rounds * (cps * 5800.0 + 30000.0) + 2.0 * s * 600.0;      // + the partial slabs' round trip
+        const double score = 1.0 / cost;
+        if (score > best_score) { best_score = score; best = s; }
+    }
+    pl.nsplit = best;
+    pl.cps = cdiv(pl.nchunks, best);
+    pl.nsplit = cdiv(pl.nchunks, pl.cps);
+    return pl;
+}
+static bool wgrad_shape_ok(const DpigConvDesc* d) {
+    if (d->R != 3 || d->S != 3 || d->stride != 1 || d->upsample2x) return false;
+    if ((d->H & 1) || (d->W & 1) || d->H < 2 || d->W < 2 || d->C % 64 || d->K % 64 || (d->ldx & 3) || (d->ldy & 3)) return false;
+    if (d->pad_t >= 0 && d->pad_t != 1) return false;
+    if (d->pad_l >= 0 && d->pad_l != 1) return false;
+    const long lim = 0x7f000000L;
+    return (long)d->N * d->H * d->W * d->ldx * 4 < lim && (long)d->N * d->H * d->W * d->ldy * 4 < lim;
+}
+static bool wgrad_pays(const DpigConvDesc* d) {
+    init_mode();
+    if (g_mode == 0) return false;
+    if (g_mode == 2) return true;
+    const WGPlan pl = wgrad_plan(d);
+    const long wgs = (long)(d->C / 64) * (d->K / 64) * pl.nsplit;
+    const long rounds = (wgs + kNumCU - 1) / kNumCU;
+    // ~5800 cycles per 8-tile chunk (4-byte fragment reads) + ~30 k fixed, + the partial slabs' write / read and the bias-gradient pass
+    const double wino_cycles = rounds * ((double)pl.cps * 5800.0 + 30000.0) + 2.0 * pl.nsplit * 600.0 + 40000.0;
+    const double direct_cycles = 2.0 * d->N * d->H * d->W * 9.0 * d->C * d->K / 50000.0;
+    return wino_cycles < 0.95 * direct_cycles;
+}
+
 }  // namespace wino
 }  // namespace dpig
 
 using namespace dpig;
+
+// 1: dpig_conv2d_wgrad_wino accepts the descriptor and is expected to beat dpig_conv2d_wgrad (mode switch as dpig_conv2d_wino_eligible).
+extern "C" int dpig_conv2d_wgrad_wino_eligible(const DpigConvDesc* d) {
+    if (!d || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->K <= 0 || d->compute != DPIG_COMPUTE_F32) return 0;
+    if (!wino::wgrad_shape_ok(d)) return 0;
+    return wino::wgrad_pays(d) ? 1 : 0;
+}
+extern "C" size_t dpig_conv2d_wgrad_wino_workspace_bytes(const DpigConvDesc* d) {
+    if (!d || !wino::wgrad_shape_ok(d)) return 0;
+    const wino::WGPlan pl = wino::wgrad_plan(d);
+    return (size_t)2 * pl.nsplit * 9 * d->C * d->K * sizeof(float);
+}
+// dw[3][3][C][K] = beta dw + conv_backward_filter(x, dy) by F(3x3, 2x2) minimal filtering (fp32 tensors, products and sums; deterministic).
+// The bias gradient is NOT produced here (dpig_colsum over dy).
+extern "C" int dpig_conv2d_wgrad_wino(const DpigConvDesc* d, const float* x, const float* dy, float* dw, float beta, void* ws, size_t ws_bytes,
+                                      void* stream) {
+    int pt, pl_, Ho, Wo;
+    int rc = resolve_desc(d, &pt, &pl_, &Ho, &Wo);
+    if (rc) return rc;
+    if (!x || !dy || !dw) return fail(DPIG_EINVAL, "null tensor pointer");
+    if (!wino::wgrad_shape_ok(d)) return fail(DPIG_EINVAL, "winograd wgrad: unsupported shape");
+    if (!aligned16(x) || !aligned16(dy) || !aligned16(dw) || !aligned16(ws)) return fail(DPIG_EINVAL, "winograd wgrad: operands must be 16-byte aligned");
+    const wino::WGPlan pl = wino::wgrad_plan(d);
+    const size_t need = (size_t)2 * pl.nsplit * 9 * d->C * d->K * sizeof(float);
+    if (!ws || ws_bytes < need) return fail(DPIG_ENOMEM, "winograd wgrad workspace too small: have %zu, need %zu", ws_bytes, need);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    wino::WGParams p = {};
+    p.X = x; p.DY = dy; p.part = static_cast<float*>(ws);
+    p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->C; p.K = d->K; p.ldx = d->ldx; p.ldy = d->ldy;
+    p.TW = d->W / 2; p.THW = (d->H / 2) * p.TW; p.T = d->N * p.THW;
+    p.nchunks = pl.nchunks; p.cps = pl.cps; p.nsplit = pl.nsplit;
+    p.cblocks = d->C / 64; p.kblocks = d->K / 64;
+    p.x_bytes = (unsigned)((long)d->N * d->H * d->W * d->ldx * 4);
+    p.y_bytes = (unsigned)((long)d->N * d->H * d->W * d->ldy * 4);
+    find_divisor(p.THW, &p.mul_thw, &p.shr_thw);
+    find_divisor(p.TW, &p.mul_tw, &p.shr_tw);
+    hipLaunchKernelGGL(wino::wino_wgrad_kernel, dim3(p.cblocks * p.kblocks * p.nsplit), dim3(512), 0, st, p);
+    rc = check_launch("wino_wgrad_kernel");
+    if (rc) return rc;
+    const long n4 = (long)9 * d->C * d->K / 4;
+    const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+    hipLaunchKernelGGL(wino::wino_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.part, dw, n4, 2 * pl.nsplit, beta);
+    return check_launch("wino_wgrad_reduce_kernel");
+}
 
 // Elements (floats) of one transformed filter image of a [3][3][C][K] filter; 0 when the shape has no Winograd form.
 extern "C" size_t dpig_wino_filter_elems(int C, int K) {

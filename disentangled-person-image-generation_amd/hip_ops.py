@@ -625,6 +625,16 @@ def conv2d_wgrad(x, dy, wshape, stride=1, upsample2x=False, out=None, beta=0.0, 
         out = torch.empty(tuple(wshape), dtype=torch.float32, device=x.device)
         beta = 0.0
     d = _desc(N, H, W, C, K, R, S, stride, ldx, ldy, upsample2x=upsample2x, split_k=split_k)
+    if _WINO[0] and R == 3 and S == 3 and stride == 1 and split_k == 0 and out.is_contiguous() and _al16(x, dy, out) \
+            and lib().dpig_conv2d_wgrad_wino_eligible(ctypes.byref(d)):
+        nbytes = lib().dpig_conv2d_wgrad_wino_workspace_bytes(ctypes.byref(d))
+        wsb, wsn = workspace.get(nbytes, x.device)
+        with _Timed("conv_wgrad_wino", 2.0 * N * (H // 2) * (W // 2) * 16 * K * C, (N, H, W, C, K, R, stride, 0)):
+            check(lib().dpig_conv2d_wgrad_wino(ctypes.byref(d), ptr(x), ptr(dy), ptr(out), float(beta), ptr(wsb), wsn, stream_ptr()),
+                  "conv2d_wgrad_wino")
+        if db is not None:                      # (the direct kernel forms the bias gradient inside its launch; here it is its own pass)
+            colsum(dy, out=db, beta=db_beta)
+        return out
     wsb, wsn = _ws(d, 2, x.device)
     mfma = (C % 4 == 0 and K % 4 == 0 and C >= 32 and K >= 32)
     with _Timed("conv_wgrad_mfma" if mfma else "conv_wgrad_thin",

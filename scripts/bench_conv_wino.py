@@ -28,9 +28,9 @@ def timeit(fn, reps=8):
     return e0.elapsed_time(e1) / reps * 1e-3
 
 
-print("%-28s %10s | %9s %9s %6s | %9s %9s %6s | max diff" % ("layer", "GF", "fwd dir", "fwd wino", "x", "dg dir", "dg wino", "x"))
+print("%-28s %10s | %9s %9s %6s | %9s %9s %6s | %9s %9s %6s | max diff" % ("layer", "GF", "fwd dir", "fwd wino", "x", "dg dir", "dg wino", "x", "wg dir", "wg wino", "x"))
 g = torch.Generator(device=dev).manual_seed(0)
-tot = [0.0, 0.0, 0.0, 0.0]
+tot = [0.0] * 6
 for name, N, Hh, W, C in layers:
     x = torch.rand((N, Hh, W, C), device=dev, generator=g) * 2 - 1
     w = (torch.rand((3, 3, C, C), device=dev, generator=g) * 2 - 1) * (1.5 / (9 * C) ** 0.5)
@@ -41,6 +41,9 @@ for name, N, Hh, W, C in layers:
     yd = H.conv2d_fwd(x, w, b, act=1)
     t_fd = timeit(lambda: H.conv2d_fwd(x, w, b, act=1))
     t_dd = timeit(lambda: H.conv2d_dgrad(dy, w, (N, Hh, W, C)))
+    dwb, dbb = torch.empty_like(w), torch.empty_like(b)
+    t_wd = timeit(lambda: H.conv2d_wgrad(x, dy, (3, 3, C, C), out=dwb, db=dbb))
+    dwd = dwb.clone()
     H.set_compute("f32w")
     H.set_wino_mode(2)
     im = H.wino_images(w)
@@ -48,13 +51,16 @@ for name, N, Hh, W, C in layers:
     yw = H.conv2d_fwd(x, w, b, act=1)
     t_fw = timeit(lambda: H.conv2d_fwd(x, w, b, act=1))
     t_dw = timeit(lambda: H.conv2d_dgrad(dy, w, (N, Hh, W, C)))
+    t_ww = timeit(lambda: H.conv2d_wgrad(x, dy, (3, 3, C, C), out=dwb, db=dbb))
+    wdiff = float((dwb - dwd).abs().max() / dwd.abs().max())
     H.set_wino_mode(1)
+    wpays = bool(H.lib().dpig_conv2d_wgrad_wino_eligible(__import__("ctypes").byref(H._desc(N, Hh, W, C, C, 3, 3, 1, C, C))))
     pays = bool(H.lib().dpig_conv2d_wino_eligible(__import__("ctypes").byref(H._desc(N, Hh, W, C, C, 3, 3, 1, C, C)), 0))
     H.set_compute("f32")
     diff = float((yw - yd).abs().max() / yd.abs().max())
-    for i, t in enumerate((t_fd, t_fw, t_dd, t_dw)):
+    for i, t in enumerate((t_fd, t_fw, t_dd, t_dw, t_wd, t_ww)):
         tot[i] += t
-    print("%-28s %10.1f | %7.1f TF %7.1f TF %5.2fx | %7.1f TF %7.1f TF %5.2fx | %.2e  model:%s" % (
-        name, flops / 1e9, flops / t_fd / 1e12, flops / t_fw / 1e12, t_fd / t_fw, flops / t_dd / 1e12, flops / t_dw / 1e12, t_dd / t_dw, diff,
-        "wino" if pays else "direct"))
-print("sum of launches [ms]: fwd direct %.3f wino %.3f | dgrad direct %.3f wino %.3f" % tuple(t * 1e3 for t in tot))
+    print("%-28s %10.1f | %7.1f TF %7.1f TF %5.2fx | %7.1f TF %7.1f TF %5.2fx | %7.1f TF %7.1f TF %5.2fx | %.1e %.1e  model:%s/%s" % (
+        name, flops / 1e9, flops / t_fd / 1e12, flops / t_fw / 1e12, t_fd / t_fw, flops / t_dd / 1e12, flops / t_dw / 1e12, t_dd / t_dw,
+        flops / t_wd / 1e12, flops / t_ww / 1e12, t_wd / t_ww, diff, wdiff, "wino" if pays else "direct", "wino" if wpays else "direct"))
+print("sum of launches [ms]: fwd direct %.3f wino %.3f | dgrad direct %.3f wino %.3f | wgrad (+ bias gradient) direct %.3f wino %.3f" % tuple(t * 1e3 for t in tot))

@@ -59,10 +59,20 @@ def test_forward_and_dgrad_against_oracle(dev, wino, shape):
     try:
         y = H.conv2d_fwd(xd, wd, bd)
         dx = H.conv2d_dgrad(dyd, wd, (N, Hh, W, C))
+        dw = torch.full((3, 3, C, K), 7.0, device=dev)
+        db = torch.empty((K,), device=dev)
+        H.conv2d_wgrad(xd, dyd, (3, 3, C, K), out=dw, db=db)
+        dw2 = H.conv2d_wgrad(xd, dyd, (3, 3, C, K), out=dw.clone(), beta=1.0)      # accumulation into an existing gradient
         kinds = [r[0] for r in H.PROFILE]
     finally:
         H.PROFILE = None
-    assert kinds == ["conv_fwd_wino", "conv_dgrad_wino"], kinds          # the Winograd kernel ran, not a silent direct fall-back
+    assert kinds == ["conv_fwd_wino", "conv_dgrad_wino", "conv_wgrad_wino", "conv_wgrad_wino"], kinds   # no silent direct fall-back
+    xr2, wr2 = xd.cpu().double(), wd.cpu().double().requires_grad_(True)
+    (rdw,) = torch.autograd.grad(O.conv2d_same(xr2, wr2, None, 1), wr2, dyd.cpu().double())
+    _close(dw, rdw)
+    _close(dw2, 2 * rdw)
+    _close(db, dyd.cpu().double().sum(dim=(0, 1, 2)))
+    assert torch.equal(H.conv2d_wgrad(xd, dyd, (3, 3, C, K)), dw)          # repeatable (fixed summation order)
     # operands are fp32-rounded on the device: compare with the oracle on the same rounded values
     ref32 = O.conv2d_same(xd.cpu().double().requires_grad_(True), wd.cpu().double(), bd.cpu().double(), 1)
     _close(y, ref32.detach())
@@ -169,19 +179,24 @@ def test_full_size_layers_against_the_sampled_oracle(dev, layer):
     xc, wc, bc, dyc = x.cpu(), w.cpu(), b.cpu(), dy.cpu()
     ref_y = torch.relu(O.conv2d_same_sampled(xc, wc, bc, 1, n, oy, ox))
     ref_dx = O.conv2d_same_dgrad_sampled(dyc, wc, (N, Hh, W, C), 1, n, oy, ox)
+    taps = [(r, c) for r in range(3) for c in range(3)]
+    ci, co = torch.randperm(C, generator=gc)[:48], torch.randperm(C, generator=gc)[:48]
+    ref_dw = O.conv2d_same_wgrad_sampled(xc, dyc, (3, 3, C, C), 1, taps, ci, co)
     H.set_compute("f32w")
     H.PROFILE = []
     try:
         y = H.conv2d_fwd(x, w, b, act=1)
         dx = H.conv2d_dgrad(dy, w, (N, Hh, W, C))
+        dw = H.conv2d_wgrad(x, dy, (3, 3, C, C))
         kinds = [r[0] for r in H.PROFILE]
     finally:
         H.PROFILE = None
         H.set_compute("f32")
-    assert kinds == ["conv_fwd_wino", "conv_dgrad_wino"], kinds
+    assert kinds == ["conv_fwd_wino", "conv_dgrad_wino", "conv_wgrad_wino"], kinds
     idx = (n.to(dev), oy.to(dev), ox.to(dev))
     _close(y[idx], ref_y, 1e-4)
     _close(dx[idx], ref_dx, 1e-4)
+    _close(dw.reshape(9, C, C)[:, ci.to(dev)][:, :, co.to(dev)], ref_dw, 2e-4)
 
 
 def test_stage1_step_in_winograd_mode_equals_the_exact_mode(dev):
@@ -214,7 +229,7 @@ def test_stage1_step_in_winograd_mode_equals_the_exact_mode(dev):
             kinds = set(r[0] for r in H.PROFILE)
             H.PROFILE = None
             if mode == "f32w":
-                assert "conv_fwd_wino" in kinds and "conv_dgrad_wino" in kinds
+                assert "conv_fwd_wino" in kinds and "conv_dgrad_wino" in kinds and "conv_wgrad_wino" in kinds
                 assert not torch.equal(p0._dpig_wino[0], u0)                 # refreshed after Adam moved the filter
                 assert torch.equal(p0._dpig_wino[0], H.wino_images(p0.data.clone())[0])
             else:
