@@ -104,6 +104,8 @@ def cpu_baseline(target_seconds=20.0):
 
 
 INFO_RUNS = [   # (key, BASELINE config it informs, bench.py arguments)
+    ("market128_direct_f32", "configs[1] with EVERY conv on the direct implicit-GEMM fp32 kernels (exact fp32 products in the direct summation "
+     "order): rounds 1-4's headline, kept as the like-for-like line", ["--workload", "market128", "--dtype", "f32", "--steps", "20", "--warmup", "5"]),
     ("df256_bf16", "configs[3]: DeepFashion 256x256 (trainer_256.py path) bs=8 bf16 on 1 MI355X",
      ["--workload", "df256", "--dtype", "bf16", "--steps", "20", "--warmup", "3"]),
     ("market128_stage2_bf16", "configs[2]: Market-1501 stage-II adversarial sampling bs=64 bf16 (this GPU's share of the job)",
@@ -115,7 +117,7 @@ INFO_RUNS = [   # (key, BASELINE config it informs, bench.py arguments)
     ("df256_split_bf16", "configs[3]'s graph (DeepFashion 256x256 bs=8) with fp32 tensors and split-bf16 conv products",
      ["--workload", "df256", "--dtype", "bf16x3", "--steps", "10", "--warmup", "2"]),
     ("market128_wgan_gp_f32", "configs[1] with MODE='wgan-gp' (LayerNorm critic, gradient penalty, 5 critic iterations per step)",
-     ["--workload", "market128-wgan-gp", "--steps", "10", "--warmup", "2"]),
+     ["--workload", "market128-wgan-gp", "--dtype", "f32", "--steps", "10", "--warmup", "2"]),
     ("market128_sampling_bf16", "SURVEY 8(f-3): the inference / sampling harness at bf16 (generated images per second)",
      ["--workload", "market128-sampling", "--dtype", "bf16", "--steps", "20", "--warmup", "3"]),
     ("df256_wgan_gp_bf16", "configs[4]: DeepFashion 256x256 bs=8 per GPU, MODE='wgan-gp', bf16 -- one GPU's share of the 8-GPU job",
@@ -161,8 +163,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="launch every kernel eagerly (no hipGraph replay)")
-    ap.add_argument("--dtype", default="f32", choices=["f32", "bf16", "bf16c", "bf16x3", "f32w"],
-                    help="f32 = the BASELINE metric's arithmetic.  bf16 (information lines; BASELINE configs 3-5): activations, "
+    ap.add_argument("--dtype", default="f32w", choices=["f32", "bf16", "bf16c", "bf16x3", "f32w"],
+                    help="f32w (default since round 5, the headline) = the BASELINE metric's arithmetic TYPE -- fp32 tensors, fp32 products, fp32 "
+                         "accumulation -- with the 3x3 stride-1 convs (forward, dgrad, wgrad) evaluated by Winograd minimal filtering "
+                         "F(2x2,3x3) / F(3x3,2x2) on the fp32 matrix pipe where the library's cost model says it pays (2.25x fewer multiplies; "
+                         "every golden activation within 1e-4 of max|ref| of the fp64 oracle, tests/test_golden_gpu.py); f32 = the same "
+                         "with every conv on the direct implicit-GEMM kernels (rounds 1-4's headline, now the information line "
+                         "market128_direct_f32).  bf16 (information lines; BASELINE configs 3-5): activations, "
                          "their gradients and the filter shadows stored as bf16, bf16 matrix pipe, fp32 accumulation / master "
                          "weights / gradients / optimizer.  bf16c: round 1's intermediate mode (fp32 tensors, bf16 pipe).  bf16x3 "
                          "(information line): fp32 tensors, conv operands split into two bf16 terms, three bf16 MFMAs per product "
@@ -221,7 +228,7 @@ def main():
     import importlib
     from dpig_amd.trainer import Config
     wl_mod, wl_cls, wl_cfg, wl_batch, wl_desc = WORKLOADS[args.workload]
-    headline = args.workload == "market128" and args.dtype == "f32" and not args.host_input
+    headline = args.workload == "market128" and args.dtype == "f32w" and not args.host_input
     if not headline:                          # information lines: no CPU leg
         args.no_cpu_baseline = True
 
@@ -475,6 +482,10 @@ def main():
         roofline = {"bound": "mfma", "kernel": kname,
                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "achieved_direct_equivalent": round(achieved * 36.0 / 16.0, 2) if args.dtype == "f32w" else None,
+                    "frac_direct_equivalent": round(achieved * 36.0 / 16.0 / peak, 4) if args.dtype == "f32w" else None,
+                    "flop_basis": ("EXECUTED multiplies of the Winograd form: 16 per (2x2 tile, ci, co) = 16/36 of the direct conv's; "
+                                   "achieved_direct_equivalent prices the same launches at the direct count") if args.dtype == "f32w" else "executed = direct",
                     "algorithmic_bytes_per_launch": int(alg_bytes),
                     "traffic_over_algorithmic": round(traffic / alg_bytes, 2) if (traffic and alg_bytes) else None,
                     "launches_per_step": len(fwd) // nrep,
@@ -504,7 +515,8 @@ def main():
                           args.workload, args.dtype, ", inputs uploaded over PCIe every step (%s)" % args.host_input if args.host_input else ""),
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.dtype == "f32w" else args.dtype, "data": "synthetic",
+            "conv_algorithm": "winograd F(2x2,3x3) / F(3x3,2x2) for 3x3 stride-1 layers where it pays, direct implicit GEMM elsewhere" if args.dtype == "f32w" else "direct implicit GEMM",
             "config": {"workload": "%s, bs=%d per GPU, %s; %s" % (wl_desc, B, {"f32": "fp32", "f32w": "fp32 (tensors, products, accumulation); 3x3 stride-1 convs forward + dgrad by Winograd F(2x2,3x3) where the cost model says it pays", "bf16": "bf16 storage (activations, their gradients, filter shadows) + bf16 matrix pipe; fp32 accumulation, master weights, gradients and optimizer", "bf16c": "bf16 matrix pipe on fp32 tensors", "bf16x3": "fp32 tensors; conv products as three bf16 MFMAs on two-term bf16 splits of the fp32 operands (<= 2e-5 max|ref| per kernel, the exact path's test bar); everything else fp32"}[args.dtype], POSE_DESC),
                        "global_batch": world * B, "parallelism": "dp%d" % world},
             "achieved_alg_tflops": round(ALG_GFLOP_PER_IMG * value / 1e3, 2) if headline else None,

@@ -20,14 +20,21 @@ newtests)
      "tests/test_variants_gpu.py::test_stage2_graph_warmup_leaves_the_learning_rates_alone" "tests/test_variants_gpu.py::test_join_side_streams_accepts_an_unindexed_device" \
      -m gpu -x -q -p no:cacheprovider --durations=15 > gpurun_out/pytest_new.log 2>&1; echo "pytest(new) rc $?"; tail -25 gpurun_out/pytest_new.log ;;
 traffic)
-  DPIG_TWO_STREAM=0 DPIG_D_OVERLAP=0 bash scripts/pmc_traffic.sh r05_market_f32 market128/f32
+  DPIG_TWO_STREAM=0 DPIG_D_OVERLAP=0 bash scripts/pmc_traffic.sh r05_market_f32 market128/f32 --dtype f32
   DPIG_TWO_STREAM=0 DPIG_D_OVERLAP=0 bash scripts/pmc_traffic.sh r05_market_bf16 market128/bf16 --workload market128 --dtype bf16
   DPIG_TWO_STREAM=0 DPIG_D_OVERLAP=0 bash scripts/pmc_traffic.sh r05_df256_bf16 df256/bf16 --workload df256 --dtype bf16
   DPIG_TWO_STREAM=0 DPIG_D_OVERLAP=0 bash scripts/pmc_traffic.sh r05_stage2_bf16 market128-stage2/bf16 --workload market128-stage2 --dtype bf16
   DPIG_TWO_STREAM=0 DPIG_D_OVERLAP=0 bash scripts/pmc_traffic.sh r05_df256_wgan_gp_bf16 df256-wgan-gp/bf16 --workload df256-wgan-gp --dtype bf16
   cat profiles/roofline_traffic.json ;;
+headline)
+  # the round-5 headline (f32w: Winograd where it pays): traffic passes, kernel stats (one stream), matrix-pipe counters, per-layer table
+  DPIG_TWO_STREAM=0 DPIG_D_OVERLAP=0 bash scripts/pmc_traffic.sh r05_market_f32w market128/f32w --dtype f32w
+  DPIG_TWO_STREAM=0 DPIG_D_OVERLAP=0 bash scripts/collect_stats.sh r05_market_f32w --dtype f32w
+  DPIG_TWO_STREAM=0 DPIG_D_OVERLAP=0 bash scripts/pmc_mfma_bench.sh r05_market_f32w --dtype f32w
+  DPIG_WORKLOAD=market128 DPIG_DTYPE=f32w DPIG_TWO_STREAM=0 DPIG_D_OVERLAP=0 timeout 300 python scripts/layer_table.py > gpurun_out/profiles_out/r05_layer_market_f32w.txt 2>&1
+  head -4 gpurun_out/profiles_out/r05_layer_market_f32w.txt; tail -12 profiles/r05_market_f32w_pmc_mfma.md | cut -c1-160 ;;
 stats)
-  DPIG_TWO_STREAM=0 DPIG_D_OVERLAP=0 bash scripts/collect_stats.sh r05_market_f32
+  DPIG_TWO_STREAM=0 DPIG_D_OVERLAP=0 bash scripts/collect_stats.sh r05_market_f32 --dtype f32
   bash scripts/collect_stats.sh r05_market_bf16 --workload market128 --dtype bf16
   bash scripts/collect_stats.sh r05_df256_bf16 --workload df256 --dtype bf16
   bash scripts/collect_stats.sh r05_stage2_bf16 --workload market128-stage2 --dtype bf16 ;;
@@ -42,6 +49,7 @@ pmc)
 layers)
   DPIG_WORKLOAD=market128 DPIG_DTYPE=bf16 DPIG_TWO_STREAM=0 DPIG_D_OVERLAP=0 timeout 300 python scripts/layer_table.py > gpurun_out/profiles_out/r05_layer_market_bf16.txt 2>&1
   DPIG_WORKLOAD=df256 DPIG_DTYPE=bf16 DPIG_TWO_STREAM=0 DPIG_D_OVERLAP=0 timeout 300 python scripts/layer_table.py > gpurun_out/profiles_out/r05_layer_df256_bf16.txt 2>&1
+  DPIG_WORKLOAD=market128 DPIG_DTYPE=f32w DPIG_TWO_STREAM=0 DPIG_D_OVERLAP=0 timeout 300 python scripts/layer_table.py > gpurun_out/profiles_out/r05_layer_market_f32w.txt 2>&1
   DPIG_WORKLOAD=market128 DPIG_DTYPE=f32 DPIG_TWO_STREAM=0 DPIG_D_OVERLAP=0 timeout 300 python scripts/layer_table.py > gpurun_out/profiles_out/r05_layer_market_f32.txt 2>&1
   head -3 gpurun_out/profiles_out/r05_layer_*.txt ;;
 crash)

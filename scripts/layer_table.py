@@ -28,7 +28,7 @@ for k, f, a, b, lab in recs:
     key = (k, lab); d = agg.setdefault(key, [0, 0.0, 0.0]); d[0] += 1; d[1] += f; d[2] += a.elapsed_time(b) * 1e-3
 tot = sum(v[2] for v in agg.values())
 print("step %.2f ms (instrumented); conv total %.2f ms" % (e0.elapsed_time(e1) / 3, tot / 3 * 1e3))
-CEIL = {'f32': 130e12, 'bf16c': 600e12, 'bf16': 1000e12, 'bf16x3': 330e12}[DT]   # reference rate for the 'lost' column
+CEIL = {'f32': 130e12, 'f32w': 110e12, 'bf16c': 600e12, 'bf16': 1000e12, 'bf16x3': 330e12}[DT]   # (f32w: executed FLOPs of the Winograd launches)   # reference rate for the 'lost' column
 tf = sum(v[1] for v in agg.values())
 print("executed %.2f TFLOP/step -> %.1f TF average; at %.0f TF everywhere: %.2f ms" % (tf / 3 / 1e12, tf / tot / 1e12, CEIL / 1e12, tf / 3 / CEIL * 1e3))
 lost = lambda v: (v[2] - v[1] / CEIL) / 3 * 1e3

@@ -34,6 +34,7 @@ with open(os.path.join(root, "profiles", tag + "_pmc_traffic.md"), "w") as fh:
 key = os.environ.get("DPIG_TRAFFIC_KEY", "market128/f32")
 dtype = key.split("/")[1]
 FAMILY = {"f32": (["gather_gemm_kernel<false, true, false, 0>"], ["conv_fwd_mfma"]),
+          "f32w": (["wino_kernel"], ["conv_fwd_wino", "conv_dgrad_wino"]),
           "bf16": (["bhq_kernel", "bhq32_kernel", "bq_kernel", "bh_kernel", "bg8_kernel", "bg_kernel", "bg8_multi_kernel", "bg_multi_kernel"],
                    ["conv_fwd_bf16", "conv_dgrad_bf16"])}
 pats, classes = FAMILY.get(dtype, FAMILY["f32"])
@@ -42,6 +43,7 @@ def base(n):                      # "dpig::bfk::bq_kernel<2, 4>" -> "bq_kernel"
     n = n[:n.index("<")] if "<" in n else n
     return n.split("::")[-1]
 sel = [r for r in rows if (base(r[0]) in pats if dtype != "f32" else any(p_ in r[0] for p_ in pats))]
+sel = [r for r in sel if "wino_filter" not in r[0] and "wino_wgrad" not in r[0]]
 path = os.path.join(root, "profiles", "roofline_traffic.json")
 try:
     js = json.load(open(path))
