@@ -34,6 +34,7 @@
 // Accuracy: products and sums are fp32; the transforms add +-1 / +-1/2 combinations of 4 inputs / 3 filter taps, so results differ
 // from the direct kernel by a few fp32 ulps of the largest intermediate (measured against the fp64 oracle in tests/test_wino_gpu.py).
 #include <stdlib.h>
+#include <type_traits>
 #include "dpig_common.h"
 #include "dpig_conv_plan.h"
 
@@ -69,7 +70,7 @@ struct WParams {
     int mtiles, ntiles;
     int act; float alpha; int res_post;
     unsigned x_bytes, u_bytes;
-    unsigned mul_thw, shr_thw, mul_tw, shr_tw;
+    unsigned mul_thw, shr_thw, mul_tw, shr_tw, mul_th, shr_th;
     unsigned long long* trace;   // dev aid (dpig_debug_wino_trace): 8 s_memtime stamps per workgroup, or null
 };
 
@@ -149,19 +150,22 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WParams p) {
         }
     }
     const int v_wr = (4 * xi) * PLANE + tl * ROWB + ((q ^ ((tl >> 3) & 1)) << 4);   // this thread's 16 bytes of V rows 4 xi .. 4 xi + 3
-    f32x4 d[2][4];
-    auto loadVrow = [&](int chunk, int i) {                          // patch row slot i (literal) of `chunk`
+    // TWO register sets of patch rows: the loads of chunk c + 3 are issued while chunk c is multiplied (set = chunk parity), 1.6 chunks
+    // (~8000 cycles) ahead of their transform.  A patch pixel's 128-byte line holds 4 chunks, so every fourth chunk's loads go to HBM;
+    // with one set (issued ~2500 cycles ahead) that stall cost ~590 of a chunk's 5050 cycles (profiles/r05_wino_knockout.txt).
+    f32x4 d[2][2][4];
+    auto loadVrow = [&](int chunk, int i, int set) {                 // patch row slot i of `chunk` into set `set` (literals)
         const int so = chunk < p.nch ? chunk * ROWB : 0;
         const int dead = chunk < p.nch ? 0 : (int)OOB;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
-            d[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, voff[i][j] | dead, so, 0));
+            d[set][i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, voff[i][j] | dead, so, 0));
     };
     f32x4 r[4];
     typedef __attribute__((address_space(3))) f32x4 lds_f4;
-    auto rowV = [&]() {
+    auto rowV = [&](int set) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r[j] = sgn * d[1][j] + d[0][j];
+        for (int j = 0; j < 4; ++j) r[j] = sgn * d[set][1][j] + d[set][0][j];
     };
     auto colsV = [&](int buf, int pair) {                            // positions 4 xi + 2 pair, + 1
         lds_char* const base = L + buf * OPB + v_wr;
@@ -197,24 +201,27 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WParams p) {
         for (int e = 0; e < 16; ++e) acc[pp][e] = 0.f;
     typedef const __attribute__((address_space(3))) f32x4 lds_cf4;
 
-    // ---- prologue: chunk 0 staged, chunk 1's input patch rows in registers ------------------------------------------------------------
+    // ---- prologue: chunk 0 staged, the patch rows of chunks 1 and 2 in flight ----------------------------------------------------------
     dmaU(0, 0);
-    loadVrow(0, 0);
-    loadVrow(0, 1);
-    rowV();
+    loadVrow(0, 0, 0);
+    loadVrow(0, 1, 0);
+    loadVrow(1, 0, 1);
+    loadVrow(1, 1, 1);
+    rowV(0);
     colsV(0, 0);
     colsV(0, 1);
-    loadVrow(1, 0);
-    loadVrow(1, 1);
-    wait_vm<8>();                                    // the filter pieces of chunk 0 are older than the 8 loads just issued
+    loadVrow(2, 0, 0);
+    loadVrow(2, 1, 0);
+    wait_vm<16>();                                   // the filter pieces of chunk 0 are older than the 16 loads of chunks 1 and 2
     __syncthreads();
     stamp(1);
     // One chunk = 8 steps (this wave's positions), each {fragments of the NEXT position, 4 MFMAs on this position's accumulator block
-    // (256 cycles of pipe time), a slice of the staging work for chunk c + 1 / c + 2}; the SIMD's other wave (the other position half)
-    // fills the matrix pipe while this one stages.  Slices: step 0 the filter DMA of chunk c + 1 (4 pieces), 1 the row transform of the
-    // patch rows held in registers (chunk c + 1), 2-3 its column transform + four 16-byte LDS stores, 4-5 the patch loads of chunk c + 2.
-    for (int c = 0; c < p.nch; ++c) {
-        const int buf = c & 1;
+    // (256 cycles of pipe time), a slice of the staging work}; the SIMD's other wave (the other position half) fills the matrix pipe
+    // while this one stages.  Slices: step 0 the filter DMA of chunk c + 1 (4 pieces), 1 the row transform of chunk c + 1's patch rows
+    // (register set (c + 1) & 1), 2-3 its column transform + four 16-byte LDS stores, 4-5 the patch loads of chunk c + 3 into the set
+    // just consumed.  The body is instantiated for both parities of c (static register sets and LDS slots).
+    auto body = [&](int c, auto PAR) {
+        constexpr int buf = decltype(PAR)::value, oth = buf ^ 1;
         lds_char* const Vb = L + buf * OPB + fv;
         lds_char* const Ub = L + buf * OPB + fu;
         f32x4 fa[2], fb[2];
@@ -227,17 +234,21 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WParams p) {
                 fb[(pp + 1) & 1] = *(lds_cf4*)(Vb + (pp + 1) * PLANE);
             }
 #pragma unroll
-            for (int s = 0; s < 4; ++s) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[pp & 1][s], fb[pp & 1][s], acc[pp], 0, 0, 0);
-            if (pp == 0) dmaU(c + 1, buf ^ 1);       // (that slot was last read in iteration c - 1; every wave is past its barrier)
-            if (pp == 1) rowV();
-            if (pp == 2) colsV(buf ^ 1, 0);
-            if (pp == 3) colsV(buf ^ 1, 1);
-            if (pp == 4) loadVrow(c + 2, 0);
-            if (pp == 5) loadVrow(c + 2, 1);
+            for (int s4 = 0; s4 < 4; ++s4) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[pp & 1][s4], fb[pp & 1][s4], acc[pp], 0, 0, 0);
+            if (pp == 0) dmaU(c + 1, oth);           // (that slot was last read in iteration c - 1; every wave is past its barrier)
+            if (pp == 1) rowV(oth);
+            if (pp == 2) colsV(oth, 0);
+            if (pp == 3) colsV(oth, 1);
+            if (pp == 4) loadVrow(c + 3, 0, oth);
+            if (pp == 5) loadVrow(c + 3, 1, oth);
             __builtin_amdgcn_sched_barrier(0);
         }
-        wait_vm<8>();                                // filter pieces of chunk c + 1 home (only the 8 loads of chunk c + 2 are younger)
+        wait_vm<8>();                                // filter pieces of chunk c + 1 home (only the 8 loads of chunk c + 3 are younger)
         __syncthreads();                             // + this wave's V rows written, every wave done reading slot `buf`
+    };
+    for (int c = 0; c < p.nch; c += 2) {
+        body(c, std::integral_constant<int, 0>{});
+        if (c + 1 < p.nch) body(c + 1, std::integral_constant<int, 1>{});
     }
     wait_vm<0>();
     __syncthreads();
@@ -291,6 +302,219 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WParams p) {
         const int ty = fast_div(rem, p.mul_tw, p.shr_tw);
         const int tx = rem - ty * p.TW;
         const long pix0 = ((long)n * p.H + 2 * ty) * p.W + 2 * tx;
+#pragma unroll
+        for (int ij = 0; ij < 4; ++ij) {
+            const int row = ij * 64 + tloc;
+            const f32x4 v = *(lds_cf4*)(L + row * EP_ROW + cg * 16) + *(lds_cf4*)(L + 256 * EP_ROW + row * EP_ROW + cg * 16);
+            epi4(p, pix0 + (ij >> 1) * p.W + (ij & 1), col, v, bv);
+        }
+    }
+    stamp(4);
+}
+
+// ================================================================================================
+// wino_block_kernel: the same kernel for layers whose tiles can be cut into blocks of 4 (wide) x 16 (tall) on the STACK of all images'
+// tile rows (W % 8 == 0, N * H % 32 == 0: every big layer of the graphs).  What changes is how the input patches arrive.  In
+// wino_kernel every thread fetches its own 2 x 4 patch pixels from L2 (32 bytes of a 128-byte line per lane pair): each pixel of the
+// workgroup's region is requested ~6 times (4 overlapping patches x the row pairs of the 4 transform rows) as 32 distinct lines per wave
+// instruction -- the texture path, not the matrix pipe, paced the loop (knock-out builds, profiles/r05_wino_knockout.txt: 5030 cycles
+// per chunk with the loads, 4430 without, 4096 = the MFMAs).  Here the block's 34 x 10 raw pixels of a chunk (340 x 32 bytes) are
+// gathered ONCE by LDS-DMA (11 pieces per workgroup instead of 64 load instructions), two chunks ahead, and the transform threads read
+// their patch pixels from LDS.  Rows that belong to a neighbouring image in the stack (a tile row at an image border needs zero
+// padding where the stack holds the other image's pixels) are read from a 32-byte zero slot instead -- an address select per thread,
+// made once; out-of-image columns and rows beyond the stack are out-of-range DMA lanes (zeros).  Output pixels of the block need no
+// division either: the stack's pixel row of tile row R is 2 R + i.
+// ================================================================================================
+constexpr int RAW_PIECES = 11, RAWB = RAW_PIECES * 1024;             // 340 pixels x 32 B in 11 DMA pieces
+constexpr int RAW_OFF = 4 * OPB, ZERO_OFF = RAW_OFF + 2 * RAWB, SMEM_BLOCK = ZERO_OFF + 64;
+static_assert(SMEM_BLOCK <= 163840 && SMEM <= SMEM_BLOCK, "LDS plan");
+
+__global__ __launch_bounds__(512, 2) void wino_block_kernel(const WParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[SMEM_BLOCK];
+    lds_char* const L = (lds_char*)smem;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int tile = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
+    const int nt = tile / p.mtiles, mt = tile - nt * p.mtiles;
+    const int n0 = nt * KB;
+    const int bcols = p.TW >> 2;
+    const int brow = mt / bcols, bcol = mt - brow * bcols;
+    const int R0 = 16 * brow, C0 = 4 * bcol;                         // first stacked tile row / tile column of the block
+    auto stamp = [&](int slot) {
+        if (p.trace && tid == 0) p.trace[(long)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memtime();
+    };
+    stamp(0);
+    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.X, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t rsU = make_rsrc(p.U, p.u_bytes);
+    typedef __attribute__((address_space(3))) f32x4 lds_f4;
+    typedef const __attribute__((address_space(3))) f32x4 lds_cf4;
+    if (tid < 4) *(lds_f4*)(L + ZERO_OFF + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- raw-gather role: piece ids wave and wave + 8 (< 11); lane slot s = 64 id + lane = (raw pixel s / 2, 16-byte half s & 1) -------
+    int g_voff[2];
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        const int s = (wave + 8 * k) * 64 + lane;
+        const int idx = s >> 1, hq = s & 1;
+        const int row = idx / 10, colr = idx - row * 10;
+        const int g = 2 * R0 - 1 + row, x = 2 * C0 - 1 + colr;       // stacked pixel row, column
+        const bool ok = (wave + 8 * k < RAW_PIECES) & (idx < 340) & ((unsigned)g < (unsigned)(p.N * p.H)) & ((unsigned)x < (unsigned)p.W);
+        g_voff[k] = ok ? ((g * p.W + x) * p.ldx + hq * 4) * 4 : (int)OOB;
+    }
+    auto dmaRaw = [&](int chunk, int slot) {
+        const int dead = chunk < p.nch ? 0 : (int)OOB;
+        const int so = chunk < p.nch ? chunk * ROWB : 0;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void*)(L + RAW_OFF + slot * RAWB + wave * 1024), 16, g_voff[0] | dead, so, 0, 0);
+        if (wave + 8 < RAW_PIECES)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void*)(L + RAW_OFF + slot * RAWB + (wave + 8) * 1024), 16, g_voff[1] | dead, so, 0, 0);
+    };
+    // ---- input-transform role: tile tl = 32 (wave & 1) + lane / 2 = (block row tl / 4, block column tl % 4), quad q, transform row xi ---
+    const int tl = 32 * (wave & 1) + (lane >> 1), q = lane & 1, xi = wave >> 1;
+    const float sgn = xi == 1 ? 1.f : -1.f;
+    const int bty = tl >> 2, btx = tl & 3;
+    int roff[2][4];                                                   // LDS byte offsets (within a raw slot, or the zero slot) of the 2 x 4 patch pixels
+    {
+        const int R = R0 + bty;
+        const int n = fast_div(R, p.mul_th, p.shr_th);
+        const int ty = R - n * (p.H >> 1);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int prow = i == 0 ? (xi == 0 ? 0 : (xi == 2 ? 2 : 1)) : (xi == 2 ? 1 : (xi == 3 ? 3 : 2));
+            const int y = 2 * ty - 1 + prow;
+            const bool ok = (unsigned)y < (unsigned)p.H;             // else: the stack holds the neighbouring image there -> zero padding
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                roff[i][j] = ok ? ((2 * bty + prow) * 10 + 2 * btx + j) * 32 + q * 16 : -1;
+        }
+    }
+    const int v_wr = (4 * xi) * PLANE + tl * ROWB + ((q ^ ((tl >> 3) & 1)) << 4);
+    f32x4 d[2][4], r[4];
+    auto readRaw = [&](int slot) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                d[i][j] = *(lds_cf4*)(L + (roff[i][j] >= 0 ? RAW_OFF + slot * RAWB + roff[i][j] : ZERO_OFF + q * 16));
+    };
+    auto rowV = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) r[j] = sgn * d[1][j] + d[0][j];
+    };
+    auto colsV = [&](int buf, int pair) {
+        lds_char* const base = L + buf * OPB + v_wr;
+        if (pair == 0) {
+            *(lds_f4*)(base + 0 * PLANE) = r[0] - r[2];
+            *(lds_f4*)(base + 1 * PLANE) = r[1] + r[2];
+        } else {
+            *(lds_f4*)(base + 2 * PLANE) = r[2] - r[1];
+            *(lds_f4*)(base + 3 * PLANE) = r[1] - r[3];
+        }
+    };
+    const int u_base = (nt * p.nch) * OPB;
+    auto dmaU = [&](int chunk, int buf) {
+        const int dead = chunk < p.nch ? 0 : (int)OOB;
+        const int so = u_base + (chunk < p.nch ? chunk : 0) * OPB + wave * 4096;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (lds_void*)(L + 2 * OPB + buf * OPB + wave * 4096 + i * 1024), 16,
+                                                     (lane * 16 + i * 1024) | dead, so, 0, 0);
+    };
+    // ---- MFMA role (as wino_kernel) ---------------------------------------------------------------------------------------------------
+    const int ph = wave >> 2, wr = (wave >> 1) & 1, wc = wave & 1;
+    const int f_row_v = 32 * wr + l31, f_row_u = 32 * wc + l31;
+    const int fv = (8 * ph) * PLANE + f_row_v * ROWB + ((half ^ ((f_row_v >> 3) & 1)) << 4);
+    const int fu = 2 * OPB + (8 * ph) * PLANE + f_row_u * ROWB + ((half ^ ((f_row_u >> 3) & 1)) << 4);
+    f32x16 acc[8];
+#pragma unroll
+    for (int pp = 0; pp < 8; ++pp)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[pp][e] = 0.f;
+
+    // ---- prologue: filter chunk 0 and the raw pixels of chunks 0 and 1 gathered; chunk 0 transformed ------------------------------------
+    dmaU(0, 0);
+    dmaRaw(0, 0);
+    dmaRaw(1, 1);
+    wait_vm<0>();
+    __syncthreads();
+    readRaw(0);
+    rowV();
+    colsV(0, 0);
+    colsV(0, 1);
+    __syncthreads();                                 // V slot 0 complete, raw slot 0 free
+    stamp(1);
+    // chunk c: step 0 {filter DMA of chunk c + 1, raw gather of chunk c + 2 into the raw slot chunk c was transformed from}, step 1 the
+    // eight 16-byte LDS reads of chunk c + 1's patch pixels, 2 the row transform, 3-4 the column transform + four LDS stores.
+    auto body = [&](int c, auto PAR) {
+        constexpr int buf = decltype(PAR)::value, oth = buf ^ 1;
+        lds_char* const Vb = L + buf * OPB + fv;
+        lds_char* const Ub = L + buf * OPB + fu;
+        f32x4 fa[2], fb[2];
+        fa[0] = *(lds_cf4*)(Ub);
+        fb[0] = *(lds_cf4*)(Vb);
+#pragma unroll
+        for (int pp = 0; pp < 8; ++pp) {
+            if (pp < 7) {
+                fa[(pp + 1) & 1] = *(lds_cf4*)(Ub + (pp + 1) * PLANE);
+                fb[(pp + 1) & 1] = *(lds_cf4*)(Vb + (pp + 1) * PLANE);
+            }
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[pp & 1][s4], fb[pp & 1][s4], acc[pp], 0, 0, 0);
+            if (pp == 0) { dmaU(c + 1, oth); dmaRaw(c + 2, buf); }
+            if (pp == 1) readRaw(oth);
+            if (pp == 2) rowV();
+            if (pp == 3) colsV(oth, 0);
+            if (pp == 4) colsV(oth, 1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        wait_vm<0>();                                // this wave's DMA pieces (issued seven steps ago) are home
+        __syncthreads();
+    };
+    for (int c = 0; c < p.nch; c += 2) {
+        body(c, std::integral_constant<int, 0>{});
+        if (c + 1 < p.nch) body(c + 1, std::integral_constant<int, 1>{});
+    }
+    stamp(2);
+
+    // ---- output transform + staging (as wino_kernel) -----------------------------------------------------------------------------------
+    const float c0 = ph ? 0.f : 1.f, c1 = ph ? -1.f : 0.f, c2 = ph ? -1.f : 1.f;
+    const int strow = 32 * wr + l31;
+    lds_char* const ST = L + ph * (256 * EP_ROW);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        f32x4 y[2][2];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int rr = 4 * g + e;
+            float sx[2][2];
+#pragma unroll
+            for (int x2 = 0; x2 < 2; ++x2) {
+                sx[x2][0] = acc[4 * x2 + 0][rr] + acc[4 * x2 + 1][rr] + acc[4 * x2 + 2][rr];
+                sx[x2][1] = acc[4 * x2 + 1][rr] - acc[4 * x2 + 2][rr] - acc[4 * x2 + 3][rr];
+            }
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                y[0][j][e] = sx[0][j] + c0 * sx[1][j];
+                y[1][j][e] = c1 * sx[0][j] + c2 * sx[1][j];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                *(lds_f4*)(ST + ((2 * i + j) * 64 + strow) * EP_ROW + (32 * wc + 8 * g + 4 * half) * 4) = y[i][j];
+    }
+    __syncthreads();
+    stamp(3);
+    // ---- fused epilogue: the stack's pixel of tile (block row, block column), sub-pixel (i, j) is (2 R + i) W + 2 (C0 + btx) + j ---------
+    const int cg = tid & 15, col = n0 + 4 * cg;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+        const int tloc = (tid >> 4) + 32 * k2;
+        const long pix0 = (long)(2 * (R0 + (tloc >> 2))) * p.W + 2 * (C0 + (tloc & 3));
 #pragma unroll
         for (int ij = 0; ij < 4; ++ij) {
             const int row = ij * 64 + tloc;
@@ -613,7 +837,14 @@ static int launch(const DpigConvDesc* d, const float* in, const float* U, const 
     p.u_bytes = (unsigned)((long)16 * cin * kout * 4);
     find_divisor(p.THW, &p.mul_thw, &p.shr_thw);
     find_divisor(p.TW, &p.mul_tw, &p.shr_tw);
+    find_divisor(d->H / 2, &p.mul_th, &p.shr_th);
     p.trace = g_trace;
+    // blocks of 4 x 16 tiles on the stack of all images' tile rows: the raw-gather form (DPIG_WINO_BLOCK=0: A/B switch)
+    static const bool block_on = !(getenv("DPIG_WINO_BLOCK") && atoi(getenv("DPIG_WINO_BLOCK")) == 0);
+    if (block_on && (p.TW & 3) == 0 && ((d->N * (d->H / 2)) & 15) == 0) {
+        hipLaunchKernelGGL(wino_block_kernel, dim3(p.mtiles * p.ntiles), dim3(512), 0, st, p);
+        return check_launch("wino_block_kernel");
+    }
     hipLaunchKernelGGL(wino_kernel, dim3(p.mtiles * p.ntiles), dim3(512), 0, st, p);
     return check_launch("wino_kernel");
 }

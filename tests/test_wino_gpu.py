@@ -39,7 +39,10 @@ SHAPES = [
     (3, 10, 14, 64, 128),     # 105 tiles: blocks straddle images, partial last block, two channel blocks
     (2, 4, 4, 192, 64),       # 2 x 2 tiles per image: every tile touches two borders; 24 chunks
     (5, 2, 2, 64, 64),        # one tile per image: all four borders
-    (1, 32, 24, 64, 192),     # 192 tiles x 3 channel blocks
+    (1, 32, 24, 64, 192),     # 192 tiles x 3 channel blocks; raw-gather blocks of 4 x 16 tiles (wino_block_kernel): 3 block columns
+    (2, 16, 8, 64, 64),       # one 4 x 16 block that straddles two images: zero padding where the stack holds the other image
+    (4, 8, 16, 64, 128),      # four images in every block column (tile rows 4 | 4 | 4 | 4), two block columns
+    (3, 32, 16, 128, 64),     # 3 x 2 blocks, 16 chunks
 ]
 
 
@@ -89,10 +92,11 @@ def test_forward_and_dgrad_against_oracle(dev, wino, shape):
     assert torch.equal(H.conv2d_fwd(xd, wd, bd), y)                       # repeatable
 
 
-def test_fused_epilogues_and_channel_slices(dev, wino):
+@pytest.mark.parametrize("geom", [(3, 10, 14), (2, 16, 8)], ids=["generic", "block"])
+def test_fused_epilogues_and_channel_slices(dev, wino, geom):
     H = wino
     from oracle import ops as O
-    N, Hh, W, C, K = 3, 10, 14, 64, 128
+    (N, Hh, W), C, K = geom, 64, 128
     x, w, b = _rand((N, Hh, W, C), 1), _rand((3, 3, C, K), 2, 0.1), _rand((K,), 3)
     res = _rand((N, Hh, W, K), 4)
     f = lambda t: t.float().to(dev)
