@@ -63,6 +63,8 @@ struct WParams {
     const float* bias;    // [Kout] or null
     const float* res;     // residual / accumulate tensor (destination-shaped) or null
     const float* mask;    // activation-output tensor for act' (destination-shaped) or null
+    float* partial;       // nsplit > 1: [nsplit][N * H * W][Kout] pre-epilogue partial sums (one per input-channel range)
+    int nsplit, cps;      // input-channel splits, chunks per split
     int N, H, W, Cin, Kout;
     int ldx, ldd, ldres, ldmask, ldd2;
     int T, THW, TW;       // tiles in the batch, per image, per tile row
@@ -112,9 +114,11 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WParams p) {
 
     // tile order: the row blocks of one 64-channel column block are consecutive, so the workgroups an XCD receives (xcd_remap hands
     // every XCD one contiguous range) stream ONE slice of the transformed filter through their L2
-    const int tile = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
+    const int bid = xcd_remap(blockIdx.x, p.mtiles * p.ntiles * p.nsplit);
+    const int sp = bid / (p.mtiles * p.ntiles), tile = bid - sp * (p.mtiles * p.ntiles);
     const int nt = tile / p.mtiles, mt = tile - nt * p.mtiles;
     const int t0 = mt * TB, n0 = nt * KB;
+    const int cb = sp * p.cps, ce = min(cb + p.cps, p.nch);          // this workgroup's chunks (input-channel range of a split plan)
     auto stamp = [&](int slot) {
         if (p.trace && tid == 0) p.trace[(long)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memtime();
     };
@@ -155,8 +159,8 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WParams p) {
     // with one set (issued ~2500 cycles ahead) that stall cost ~590 of a chunk's 5050 cycles (profiles/r05_wino_knockout.txt).
     f32x4 d[2][2][4];
     auto loadVrow = [&](int chunk, int i, int set) {                 // patch row slot i of `chunk` into set `set` (literals)
-        const int so = chunk < p.nch ? chunk * ROWB : 0;
-        const int dead = chunk < p.nch ? 0 : (int)OOB;
+        const int so = chunk < ce ? chunk * ROWB : 0;
+        const int dead = chunk < ce ? 0 : (int)OOB;
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             d[set][i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, voff[i][j] | dead, so, 0));
@@ -180,8 +184,8 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WParams p) {
     // ---- filter DMA role: the chunk's 32-KB image is 32 pieces of 1 KB; wave w moves pieces 4 w .. 4 w + 3 ---------------------------
     const int u_base = (nt * p.nch) * OPB;                           // byte offset of this column block's first chunk
     auto dmaU = [&](int chunk, int buf) {
-        const int dead = chunk < p.nch ? 0 : (int)OOB;
-        const int so = u_base + (chunk < p.nch ? chunk : 0) * OPB + wave * 4096;
+        const int dead = chunk < ce ? 0 : (int)OOB;
+        const int so = u_base + (chunk < ce ? chunk : 0) * OPB + wave * 4096;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (lds_void*)(L + 2 * OPB + buf * OPB + wave * 4096 + i * 1024), 16,
@@ -202,16 +206,16 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WParams p) {
     typedef const __attribute__((address_space(3))) f32x4 lds_cf4;
 
     // ---- prologue: chunk 0 staged, the patch rows of chunks 1 and 2 in flight ----------------------------------------------------------
-    dmaU(0, 0);
-    loadVrow(0, 0, 0);
-    loadVrow(0, 1, 0);
-    loadVrow(1, 0, 1);
-    loadVrow(1, 1, 1);
+    dmaU(cb, 0);
+    loadVrow(cb, 0, 0);
+    loadVrow(cb, 1, 0);
+    loadVrow(cb + 1, 0, 1);
+    loadVrow(cb + 1, 1, 1);
     rowV(0);
     colsV(0, 0);
     colsV(0, 1);
-    loadVrow(2, 0, 0);
-    loadVrow(2, 1, 0);
+    loadVrow(cb + 2, 0, 0);
+    loadVrow(cb + 2, 1, 0);
     wait_vm<16>();                                   // the filter pieces of chunk 0 are older than the 16 loads of chunks 1 and 2
     __syncthreads();
     stamp(1);
@@ -246,9 +250,9 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WParams p) {
         wait_vm<8>();                                // filter pieces of chunk c + 1 home (only the 8 loads of chunk c + 3 are younger)
         __syncthreads();                             // + this wave's V rows written, every wave done reading slot `buf`
     };
-    for (int c = 0; c < p.nch; c += 2) {
+    for (int c = cb; c < ce; c += 2) {           // (the parity of the body is the chunk's position in the range, not its index)
         body(c, std::integral_constant<int, 0>{});
-        if (c + 1 < p.nch) body(c + 1, std::integral_constant<int, 1>{});
+        if (c + 1 < ce) body(c + 1, std::integral_constant<int, 1>{});
     }
     wait_vm<0>();
     __syncthreads();
@@ -306,7 +310,9 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WParams p) {
         for (int ij = 0; ij < 4; ++ij) {
             const int row = ij * 64 + tloc;
             const f32x4 v = *(lds_cf4*)(L + row * EP_ROW + cg * 16) + *(lds_cf4*)(L + 256 * EP_ROW + row * EP_ROW + cg * 16);
-            epi4(p, pix0 + (ij >> 1) * p.W + (ij & 1), col, v, bv);
+            const long pix = pix0 + (ij >> 1) * p.W + (ij & 1);
+            if (p.nsplit > 1) *reinterpret_cast<f32x4*>(p.partial + ((long)sp * p.N * p.H * p.W + pix) * p.Kout + col) = v;
+            else epi4(p, pix, col, v, bv);
         }
     }
     stamp(4);
@@ -336,9 +342,11 @@ __global__ __launch_bounds__(512, 2) void wino_block_kernel(const WParams p) {
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
-    const int tile = xcd_remap(blockIdx.x, p.mtiles * p.ntiles);
+    const int bid = xcd_remap(blockIdx.x, p.mtiles * p.ntiles * p.nsplit);
+    const int sp = bid / (p.mtiles * p.ntiles), tile = bid - sp * (p.mtiles * p.ntiles);
     const int nt = tile / p.mtiles, mt = tile - nt * p.mtiles;
     const int n0 = nt * KB;
+    const int cb = sp * p.cps, ce = min(cb + p.cps, p.nch);
     const int bcols = p.TW >> 2;
     const int brow = mt / bcols, bcol = mt - brow * bcols;
     const int R0 = 16 * brow, C0 = 4 * bcol;                         // first stacked tile row / tile column of the block
@@ -364,8 +372,8 @@ __global__ __launch_bounds__(512, 2) void wino_block_kernel(const WParams p) {
         g_voff[k] = ok ? ((g * p.W + x) * p.ldx + hq * 4) * 4 : (int)OOB;
     }
     auto dmaRaw = [&](int chunk, int slot) {
-        const int dead = chunk < p.nch ? 0 : (int)OOB;
-        const int so = chunk < p.nch ? chunk * ROWB : 0;
+        const int dead = chunk < ce ? 0 : (int)OOB;
+        const int so = chunk < ce ? chunk * ROWB : 0;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void*)(L + RAW_OFF + slot * RAWB + wave * 1024), 16, g_voff[0] | dead, so, 0, 0);
         if (wave + 8 < RAW_PIECES)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void*)(L + RAW_OFF + slot * RAWB + (wave + 8) * 1024), 16, g_voff[1] | dead, so, 0, 0);
@@ -414,8 +422,8 @@ __global__ __launch_bounds__(512, 2) void wino_block_kernel(const WParams p) {
     };
     const int u_base = (nt * p.nch) * OPB;
     auto dmaU = [&](int chunk, int buf) {
-        const int dead = chunk < p.nch ? 0 : (int)OOB;
-        const int so = u_base + (chunk < p.nch ? chunk : 0) * OPB + wave * 4096;
+        const int dead = chunk < ce ? 0 : (int)OOB;
+        const int so = u_base + (chunk < ce ? chunk : 0) * OPB + wave * 4096;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rsU, (lds_void*)(L + 2 * OPB + buf * OPB + wave * 4096 + i * 1024), 16,
@@ -433,9 +441,9 @@ __global__ __launch_bounds__(512, 2) void wino_block_kernel(const WParams p) {
         for (int e = 0; e < 16; ++e) acc[pp][e] = 0.f;
 
     // ---- prologue: filter chunk 0 and the raw pixels of chunks 0 and 1 gathered; chunk 0 transformed ------------------------------------
-    dmaU(0, 0);
-    dmaRaw(0, 0);
-    dmaRaw(1, 1);
+    dmaU(cb, 0);
+    dmaRaw(cb, 0);
+    dmaRaw(cb + 1, 1);
     wait_vm<0>();
     __syncthreads();
     readRaw(0);
@@ -471,9 +479,9 @@ __global__ __launch_bounds__(512, 2) void wino_block_kernel(const WParams p) {
         wait_vm<0>();                                // this wave's DMA pieces (issued seven steps ago) are home
         __syncthreads();
     };
-    for (int c = 0; c < p.nch; c += 2) {
+    for (int c = cb; c < ce; c += 2) {
         body(c, std::integral_constant<int, 0>{});
-        if (c + 1 < p.nch) body(c + 1, std::integral_constant<int, 1>{});
+        if (c + 1 < ce) body(c + 1, std::integral_constant<int, 1>{});
     }
     stamp(2);
 
@@ -519,7 +527,9 @@ __global__ __launch_bounds__(512, 2) void wino_block_kernel(const WParams p) {
         for (int ij = 0; ij < 4; ++ij) {
             const int row = ij * 64 + tloc;
             const f32x4 v = *(lds_cf4*)(L + row * EP_ROW + cg * 16) + *(lds_cf4*)(L + 256 * EP_ROW + row * EP_ROW + cg * 16);
-            epi4(p, pix0 + (ij >> 1) * p.W + (ij & 1), col, v, bv);
+            const long pix = pix0 + (ij >> 1) * p.W + (ij & 1);
+            if (p.nsplit > 1) *reinterpret_cast<f32x4*>(p.partial + ((long)sp * p.N * p.H * p.W + pix) * p.Kout + col) = v;
+            else epi4(p, pix, col, v, bv);
         }
     }
     stamp(4);
@@ -736,6 +746,21 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __r
     }
 }
 
+// Second pass of a split plan: sum the nsplit partial outputs in split order (deterministic) and run the fused epilogue.
+__global__ __launch_bounds__(256) void wino_reduce_kernel(const WParams p) {
+    const int k4 = p.Kout >> 2;
+    const long total = (long)p.N * p.H * p.W * k4, slab = (long)p.N * p.H * p.W * p.Kout;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long pix = i / k4;
+        const int col = (int)(i - pix * k4) * 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int s = 0; s < p.nsplit; ++s) v += *reinterpret_cast<const f32x4*>(p.partial + s * slab + pix * p.Kout + col);
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
+        epi4(p, pix, col, v, bv);
+    }
+}
+
 // ---- filter transform: U = G g G^T (G = [1 0 0; 1/2 1/2 1/2; 1/2 -1/2 1/2; 0 0 1]) of every (input channel, output channel) pair, written
 // in the kernel's LDS image order.  `dgrad`: the transposed conv's filter g'[r][s][k][c] = w[2 - r][2 - s][c][k] (input channels = the
 // forward conv's output channels).  w is HWIO [3][3][C][K].
@@ -808,20 +833,36 @@ static bool shape_ok(const DpigConvDesc* d, int cin, int kout, int ld_in, int ld
 // ~5050 cycles per 8-channel chunk (64 MFMAs per SIMD = 4096 of them) + ~16 k cycles of prologue / output transform / epilogue
 // (scripts/trace_wino.py); the direct family delivers ~115 TFLOP/s = 50 k FLOP per cycle at the same 2.3 GHz on layers that fill the chip
 // (profiles/r05_wino_layers.txt: the model's choice agrees with the measured faster kernel on all 14 Market layer shapes).
+// Split plan: with fewer workgroups than CUs (or a fractional last round) the reduction over input channels is cut into `nsplit` ranges,
+// each workgroup leaves a pre-epilogue partial output and wino_reduce_kernel sums them in split order and runs the epilogue
+// (deterministic).  Cost in cycles at 2.3 GHz: rounds x (chunks per split x 4800 + 16 k) + the partials' write + read at ~4 TB/s.
+struct FPlan { int nsplit, cps; double cycles; };
+static FPlan fwd_plan(const DpigConvDesc* d, int cin, int kout) {
+    const long T = (long)d->N * (d->H / 2) * (d->W / 2);
+    const long wgs1 = (long)cdiv(T, TB) * (kout / KB);
+    const int nch = cin / CH;
+    FPlan best = {1, nch, 0.0};
+    static const int force = getenv("DPIG_WINO_SPLIT") ? atoi(getenv("DPIG_WINO_SPLIT")) : 0;       // (A/B switch: 1 = never split)
+    for (int s = 1; s <= 16; ++s) {
+        const int cps = cdiv(nch, s);
+        if (s > 1 && (cps < 6 || cdiv(nch, cps) != s || force == 1)) continue;
+        const long rounds = (wgs1 * s + kNumCU - 1) / kNumCU;
+        double cyc = (double)rounds * ((double)cps * 4800.0 + 16000.0);
+        if (s > 1) cyc += 8000.0 + 2.0 * s * (double)d->N * d->H * d->W * kout * 4.0 / 1740.0;     // 4 TB/s = 1740 B per cycle
+        if (best.cycles == 0.0 || cyc < best.cycles * 0.97) best = {s, cps, cyc};
+    }
+    return best;
+}
 static bool pays(const DpigConvDesc* d, int cin, int kout) {
     init_mode();
     if (g_mode == 0) return false;
     if (g_mode == 2) return true;
-    const long T = (long)d->N * (d->H / 2) * (d->W / 2);
-    const long wgs = (long)cdiv(T, TB) * (kout / KB);
-    const long rounds = (wgs + kNumCU - 1) / kNumCU;
-    const double wino_cycles = (double)rounds * ((double)(cin / CH) * 5050.0 + 16000.0);
     const double direct_cycles = 2.0 * d->N * d->H * d->W * 9.0 * cin * kout / 50000.0;
-    return wino_cycles < 0.95 * direct_cycles;
+    return fwd_plan(d, cin, kout).cycles < 0.95 * direct_cycles;
 }
 
 static int launch(const DpigConvDesc* d, const float* in, const float* U, const float* bias, const float* res, const float* mask,
-                  float* out, float* out2, int cin, int kout, int ld_in, int ld_out, int act, hipStream_t st) {
+                  float* out, float* out2, int cin, int kout, int ld_in, int ld_out, int act, void* ws, size_t ws_bytes, hipStream_t st) {
     if (!aligned16(in) || !aligned16(U) || !aligned16(out) || (bias && !aligned16(bias)) || (res && (!aligned16(res) || (d->ldres & 3))) ||
         (mask && (!aligned16(mask) || (d->ldmask & 3))) || (out2 && (!aligned16(out2) || (d->ldy2 & 3))))
         return fail(DPIG_EINVAL, "winograd conv: operands must be 16-byte addressable");
@@ -839,14 +880,29 @@ static int launch(const DpigConvDesc* d, const float* in, const float* U, const 
     find_divisor(p.TW, &p.mul_tw, &p.shr_tw);
     find_divisor(d->H / 2, &p.mul_th, &p.shr_th);
     p.trace = g_trace;
+    const FPlan pl = fwd_plan(d, cin, kout);
+    p.nsplit = pl.nsplit; p.cps = pl.cps;
+    if (p.nsplit > 1) {
+        const size_t need = (size_t)p.nsplit * d->N * d->H * d->W * kout * sizeof(float);
+        if (!ws || ws_bytes < need || !aligned16(ws)) return fail(DPIG_ENOMEM, "winograd conv workspace too small: have %zu, need %zu", ws_bytes, need);
+        p.partial = static_cast<float*>(ws);
+    }
+    const dim3 grid(p.mtiles * p.ntiles * p.nsplit);
     // blocks of 4 x 16 tiles on the stack of all images' tile rows: the raw-gather form (DPIG_WINO_BLOCK=0: A/B switch)
     static const bool block_on = !(getenv("DPIG_WINO_BLOCK") && atoi(getenv("DPIG_WINO_BLOCK")) == 0);
+    int rc;
     if (block_on && (p.TW & 3) == 0 && ((d->N * (d->H / 2)) & 15) == 0) {
-        hipLaunchKernelGGL(wino_block_kernel, dim3(p.mtiles * p.ntiles), dim3(512), 0, st, p);
-        return check_launch("wino_block_kernel");
+        hipLaunchKernelGGL(wino_block_kernel, grid, dim3(512), 0, st, p);
+        rc = check_launch("wino_block_kernel");
+    } else {
+        hipLaunchKernelGGL(wino_kernel, grid, dim3(512), 0, st, p);
+        rc = check_launch("wino_kernel");
     }
-    hipLaunchKernelGGL(wino_kernel, dim3(p.mtiles * p.ntiles), dim3(512), 0, st, p);
-    return check_launch("wino_kernel");
+    if (rc || p.nsplit == 1) return rc;
+    const long total = (long)d->N * d->H * d->W * (kout / 4);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(wino_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+    return check_launch("wino_reduce_kernel");
 }
 
 // ---- filter-gradient plan: splits over the tile axis so that (C / 64)(K / 64) S workgroups fill whole rounds of the chip -----------
@@ -985,8 +1041,18 @@ extern "C" int dpig_conv_wino_set_mode(int mode) {
 
 // y = act(conv3x3_SAME(x, w) + bias + residual)  (or act(..) + residual with res_after_act, y_act receiving the activation) through
 // the transformed filter image u_fwd of dpig_wino_filter_transform.  Same descriptor and epilogue semantics as dpig_conv2d_fwd.
+// Workspace of dpig_conv2d_fwd_wino (which = 0) / dpig_conv2d_dgrad_wino (which = 1): the partial outputs of a split plan, 0 for most layers.
+extern "C" size_t dpig_conv2d_wino_workspace_bytes(const DpigConvDesc* d, int which) {
+    if (!d || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->K <= 0) return 0;
+    const bool dg = which == 1;
+    const int cin = dg ? d->K : d->C, kout = dg ? d->C : d->K;
+    if (d->C % 64 || d->K % 64 || !wino::shape_ok(d, cin, kout, dg ? d->ldy : d->ldx, dg ? d->ldx : d->ldy)) return 0;
+    const wino::FPlan pl = wino::fwd_plan(d, cin, kout);
+    return pl.nsplit > 1 ? (size_t)pl.nsplit * d->N * d->H * d->W * kout * sizeof(float) : 0;
+}
+
 extern "C" int dpig_conv2d_fwd_wino(const DpigConvDesc* d, const float* x, const float* u_fwd, const float* bias, const float* residual,
-                                    float* y, float* y_act, void* stream) {
+                                    float* y, float* y_act, void* ws, size_t ws_bytes, void* stream) {
     int pt, pl, Ho, Wo;
     int rc = resolve_desc(d, &pt, &pl, &Ho, &Wo);
     if (rc) return rc;
@@ -994,12 +1060,13 @@ extern "C" int dpig_conv2d_fwd_wino(const DpigConvDesc* d, const float* x, const
     if (!wino::shape_ok(d, d->C, d->K, d->ldx, d->ldy) || d->C % 64) return fail(DPIG_EINVAL, "winograd conv: unsupported shape");
     if (residual && d->ldres < d->K) return fail(DPIG_EINVAL, "ldres < K");
     if (y_act && d->ldy2 < d->K) return fail(DPIG_EINVAL, "ldy2 < K");
-    return wino::launch(d, x, u_fwd, bias, residual, nullptr, y, y_act, d->C, d->K, d->ldx, d->ldy, d->act, static_cast<hipStream_t>(stream));
+    return wino::launch(d, x, u_fwd, bias, residual, nullptr, y, y_act, d->C, d->K, d->ldx, d->ldy, d->act, ws, ws_bytes,
+                        static_cast<hipStream_t>(stream));
 }
 
 // dx = (conv_backward_data(dy, w) + accum) * act'(mask) through u_dgrad.  Same semantics as dpig_conv2d_dgrad.
 extern "C" int dpig_conv2d_dgrad_wino(const DpigConvDesc* d, const float* dy, const float* u_dgrad, const float* accum, const float* mask,
-                                      float* dx, void* stream) {
+                                      float* dx, void* ws, size_t ws_bytes, void* stream) {
     int pt, pl, Ho, Wo;
     int rc = resolve_desc(d, &pt, &pl, &Ho, &Wo);
     if (rc) return rc;
@@ -1010,5 +1077,5 @@ extern "C" int dpig_conv2d_dgrad_wino(const DpigConvDesc* d, const float* dy, co
     DpigConvDesc e = *d;
     e.res_after_act = 0; e.ldy2 = 0;
     return wino::launch(&e, dy, u_dgrad, nullptr, accum, mask, dx, nullptr, d->K, d->C, d->ldy, d->ldx, mask ? d->act : DPIG_ACT_NONE,
-                        static_cast<hipStream_t>(stream));
+                        ws, ws_bytes, static_cast<hipStream_t>(stream));
 }

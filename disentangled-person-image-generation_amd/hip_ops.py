@@ -416,9 +416,10 @@ def conv2d_fwd(x, w, bias=None, stride=1, act=ACT_NONE, alpha=0.2, residual=None
         im = wino_images(w, want_dgrad=False)
         if im is not None:
             # executed FLOPs: 16 multiplies per (2x2 tile, ci, co) instead of 36 -- what the roofline of this launch is priced on
+            wsb, wsn = workspace.get(lib().dpig_conv2d_wino_workspace_bytes(ctypes.byref(d), 0), x.device)
             with _Timed("conv_fwd_wino", 2.0 * N * (H // 2) * (W // 2) * 16 * K * C, (N, H, W, C, K, R, stride, 0)):
                 check(lib().dpig_conv2d_fwd_wino(ctypes.byref(d), ptr(x), ptr(im[0]), ptr(bias), ptr(residual), ptr(out), ptr(out_act),
-                                                 stream_ptr()), "conv2d_fwd_wino")
+                                                 ptr(wsb), wsn, stream_ptr()), "conv2d_fwd_wino")
             return out
     wsb, wsn = _ws(d, 0, x.device)
     mfma = (C % 4 == 0 and K % 4 == 0 and ldx % 4 == 0 and C >= 32 and K >= 32)
@@ -586,9 +587,10 @@ def conv2d_dgrad(dy, w, in_shape, stride=1, accum=None, mask=None, act=ACT_NONE,
             and _al16(dy, out, accum, mask):
         im = wino_images(w, want_fwd=False)
         if im is not None:
+            wsb, wsn = workspace.get(lib().dpig_conv2d_wino_workspace_bytes(ctypes.byref(d), 1), dy.device)
             with _Timed("conv_dgrad_wino", 2.0 * N * (H // 2) * (W // 2) * 16 * K * C, (N, H, W, C, K, R, stride, 0)):
-                check(lib().dpig_conv2d_dgrad_wino(ctypes.byref(d), ptr(dy), ptr(im[1]), ptr(accum), ptr(mask), ptr(out), stream_ptr()),
-                      "conv2d_dgrad_wino")
+                check(lib().dpig_conv2d_dgrad_wino(ctypes.byref(d), ptr(dy), ptr(im[1]), ptr(accum), ptr(mask), ptr(out), ptr(wsb), wsn,
+                                                   stream_ptr()), "conv2d_dgrad_wino")
             return out
     wsb, wsn = _ws(d, 1, dy.device)
     mfma = (C % 4 == 0 and K % 4 == 0 and ldy % 4 == 0 and C >= 32 and K >= 32)

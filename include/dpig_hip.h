@@ -181,15 +181,17 @@ int dpig_conv_bf16_set_wave8(int mode);
  *                               stay direct); dpig_conv_wino_set_mode / DPIG_WINO: 0 never, 1 cost model (default), 2 wherever legal
  *   dpig_conv2d_fwd_wino        dpig_conv2d_fwd's semantics (bias, activation, residual before / after it, second output y_act)
  *   dpig_conv2d_dgrad_wino      dpig_conv2d_dgrad's semantics ((. + accum) * act'(mask))
- * No workspace for these two. */
+ * Workspace (dpig_conv2d_wino_workspace_bytes; 0 for layers that fill the chip): layers with fewer workgroups than CUs, or a fractional
+ * last round, cut the reduction over input channels into ranges whose partial outputs a second kernel sums in fixed order. */
 size_t dpig_wino_filter_elems(int C, int K);
 int dpig_wino_filter_transform(const float* w, int C, int K, float* u_fwd, float* u_dgrad, void* stream);
 int dpig_conv2d_wino_eligible(const DpigConvDesc* d, int which);
 int dpig_conv_wino_set_mode(int mode);
+size_t dpig_conv2d_wino_workspace_bytes(const DpigConvDesc* d, int which);
 int dpig_conv2d_fwd_wino(const DpigConvDesc* d, const float* x, const float* u_fwd, const float* bias, const float* residual,
-                         float* y, float* y_act, void* stream);
+                         float* y, float* y_act, void* ws, size_t ws_bytes, void* stream);
 int dpig_conv2d_dgrad_wino(const DpigConvDesc* d, const float* dy, const float* u_dgrad, const float* accum, const float* mask,
-                           float* dx, void* stream);
+                           float* dx, void* ws, size_t ws_bytes, void* stream);
 /* The filter gradient by F(3x3, 2x2) minimal filtering: dw[3][3][C][K] = beta dw + conv_backward_filter(x, dy), 16 multiplies per
  * (2x2 tile, c, k) instead of 36; input and output-gradient transforms, the 16 position GEMMs over the tile axis and the output
  * transform are one kernel, split over tile ranges into 2 S partial gradients that a second kernel sums in fixed order

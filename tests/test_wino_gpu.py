@@ -70,6 +70,10 @@ def test_forward_and_dgrad_against_oracle(dev, wino, shape):
     finally:
         H.PROFILE = None
     assert kinds == ["conv_fwd_wino", "conv_dgrad_wino", "conv_wgrad_wino", "conv_wgrad_wino"], kinds   # no silent direct fall-back
+    if shape in ((2, 4, 4, 192, 64), (3, 32, 16, 128, 64)):       # few workgroups, >= 16 chunks: these run as input-channel SPLIT plans
+        import ctypes
+        dsc = H._desc(N, Hh, W, C, K, 3, 3, 1, C, K)
+        assert H.lib().dpig_conv2d_wino_workspace_bytes(ctypes.byref(dsc), 0) >= 2 * N * Hh * W * K * 4
     xr2, wr2 = xd.cpu().double(), wd.cpu().double().requires_grad_(True)
     (rdw,) = torch.autograd.grad(O.conv2d_same(xr2, wr2, None, 1), wr2, dyd.cpu().double())
     _close(dw, rdw)
@@ -205,7 +209,7 @@ def test_full_size_layers_against_the_sampled_oracle(dev, layer):
 
 def test_stage1_step_in_winograd_mode_equals_the_exact_mode(dev):
     """Config(compute_dtype='f32w'): one g_optim + d_optim of the stage-I trainer (width 64, so that the 3x3 layers have Winograd forms)
-    against the same step in 'f32' mode: losses to 1e-5, generator output to 1e-4 of its range, and the Winograd images follow the
+    against the same step in 'f32' mode: losses to 1e-5 (the batch-norm critic's to 2e-4), generator output to 1e-4 of its range, and the Winograd images follow the
     masters through the optimizer step."""
     import numpy as np
     import dpig_amd.hip_ops as H
@@ -240,8 +244,10 @@ def test_stage1_step_in_winograd_mode_equals_the_exact_mode(dev):
                 assert "conv_fwd_wino" not in kinds
             res[mode] = ({k: float(v) for k, v in out.items() if hasattr(v, "numel") and v.numel() == 1}, out["G"].clone(),
                          tr.G_flat.grad.clone())
-        for k in ("g_loss", "d_loss", "L1Loss"):
-            assert abs(res["f32w"][0][k] - res["f32"][0][k]) <= 1e-5 * abs(res["f32"][0][k]), (k, res["f32w"][0][k], res["f32"][0][k])
+        # (d_loss is evaluated AFTER the generator's update, through a batch-norm critic on 2 images: it amplifies the two fp32
+        # summation orders' 1e-6 differences most -- 2e-5 at full width, scripts/diag_wino_traj.py)
+        for k, tol in (("g_loss", 1e-5), ("L1Loss", 1e-5), ("d_loss", 2e-4)):
+            assert abs(res["f32w"][0][k] - res["f32"][0][k]) <= tol * abs(res["f32"][0][k]), (k, res["f32w"][0][k], res["f32"][0][k])
         Gd = (res["f32w"][1] - res["f32"][1]).abs().max().item()
         assert Gd <= 1e-4 * res["f32"][1].abs().max().item(), Gd
     finally:
