@@ -585,6 +585,19 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WGParams p) {
     // G' row xi of the 2 x 2 dy = ga y0 + gb y1:  (1, 0), (1/2, 1/2), (1/2, -1/2), (0, 1)
     const float ga = xi == 0 ? 1.f : (xi == 3 ? 0.f : 0.5f), gb = xi == 0 ? 0.f : (xi == 1 ? 0.5f : (xi == 2 ? -0.5f : 1.f));
     const int xcol = (cb * 64 + cq * 4) * 4, ycol = (kb * 64 + cq * 4) * 4;      // byte offsets of this thread's channel quads
+    // Per-chunk addressing, kept cheap (it runs between the MFMAs of every chunk): offsets = one base per operand + per-thread constants;
+    // the base by 24-bit multiplies (full rate; v_mul_lo_u32 / v_mad_u64_u32 are quarter rate and an `ok ? product : OOB` select made the
+    // compiler branch on exec); validity = 2 row tests + 2 column tests.  The stack's pixel row of tile row (n, ty) is n H + 2 ty.
+    const int ldx4 = p.ldx * 4, ldy4 = p.ldy * 4;
+    const int rsx = p.W * ldx4, rsy = p.W * ldy4;                   // bytes per pixel row
+    int cx[2][4], cy[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) cx[i][j] = (i == 0 ? rowA : rowC) * rsx + j * ldx4;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) cy[i][j] = i * rsy + j * ldy4;
+    }
     int xoff[2][4], yoff[2][2];
     auto tile_offsets = [&](int chunk) {                             // offsets of tile 8 chunk + tl (all out of range past the batch)
         const int t = chunk * 8 + tl;
@@ -594,18 +607,17 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WGParams p) {
         const int rem = tt - n * p.THW;
         const int ty = fast_div(rem, p.mul_tw, p.shr_tw);
         const int tx = rem - ty * p.TW;
+        const int r2 = __mul24(n, p.H) + 2 * ty;
+        const int xb = __mul24(r2 - 1, rsx) + __mul24(2 * tx - 1, ldx4) + xcol;
+        const int yb = __mul24(r2, rsy) + __mul24(2 * tx, ldy4) + ycol;
+        const bool rok[2] = {tok && (unsigned)(2 * ty - 1 + rowA) < (unsigned)p.H, tok && (unsigned)(2 * ty - 1 + rowC) < (unsigned)p.H};
+        const bool cok[4] = {tx > 0, true, true, tx < p.TW - 1};
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            const int iy = 2 * ty - 1 + (i == 0 ? rowA : rowC);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int ix = 2 * tx - 1 + j;
-                const bool ok = tok & ((unsigned)iy < (unsigned)p.H) & ((unsigned)ix < (unsigned)p.W);
-                xoff[i][j] = ok ? (((n * p.H + iy) * p.W + ix) * p.ldx) * 4 + xcol : (int)OOB;
-            }
+            for (int j = 0; j < 4; ++j) xoff[i][j] = (rok[i] && cok[j]) ? xb + cx[i][j] : (int)OOB;
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-                yoff[i][j] = tok ? (((n * p.H + 2 * ty + i) * p.W + 2 * tx + j) * p.ldy) * 4 + ycol : (int)OOB;
+            for (int j = 0; j < 2; ++j) yoff[i][j] = tok ? yb + cy[i][j] : (int)OOB;
         }
     };
     f32x4 d[2][4], y[2][2];
@@ -691,15 +703,17 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WGParams p) {
             }
 #pragma unroll
             for (int s = 0; s < 4; ++s) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[pp & 1][s], fb[pp & 1][s], acc[pp], 0, 0, 0);
-            // staging slices: chunk c + 1 (in registers) -> the other slot, then the loads of chunk c + 2
-            if (pp == 0) rowX();
-            if (pp == 1) colsX(buf ^ 1, 0);
-            if (pp == 2) colsX(buf ^ 1, 1);
-            if (pp == 3) { rowY(); colsY(buf ^ 1, 0); }
-            if (pp == 4) { colsY(buf ^ 1, 1); tile_offsets(c + 2); }
-            if (pp == 5) loadX(0);
-            if (pp == 6) loadX(1);
-            if (pp == 7) loadY();
+            // staging slices.  The row transforms of chunk c + 1 come FIRST: they free the load registers, so the loads of chunk c + 2 can
+            // follow at once and have seven steps (~5000 cycles) to land before the next chunk's step 0 needs them -- issued at the END
+            // of the chunk (two steps ahead of their use) an L2 hit's latency was exposed every chunk: a knock-out build without the
+            // loads ran 293 instead of 219 TFLOP/s on dec3 (build/ko/run_wg.sh; an L2 prefetch four chunks ahead changed nothing:
+            // the lines were L2-resident already, the other (c, k) blocks of the XCD read them too).
+            if (pp == 0) { tile_offsets(c + 2); rowX(); rowY(); }
+            if (pp == 1) { loadX(0); loadX(1); loadY(); }
+            if (pp == 2) colsX(buf ^ 1, 0);
+            if (pp == 3) colsX(buf ^ 1, 1);
+            if (pp == 4) colsY(buf ^ 1, 0);
+            if (pp == 5) colsY(buf ^ 1, 1);
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
