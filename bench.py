@@ -106,6 +106,8 @@ def cpu_baseline(target_seconds=20.0):
 INFO_RUNS = [   # (key, BASELINE config it informs, bench.py arguments)
     ("market128_direct_f32", "configs[1] with EVERY conv on the direct implicit-GEMM fp32 kernels (exact fp32 products in the direct summation "
      "order): rounds 1-4's headline, kept as the like-for-like line", ["--workload", "market128", "--dtype", "f32", "--steps", "20", "--warmup", "5"]),
+    ("df256_f32", "configs[3]'s graph (DeepFashion 256x256, trainer_256.py path, bs=8) in the headline's arithmetic: fp32 with Winograd where it pays",
+     ["--workload", "df256", "--dtype", "f32w", "--steps", "10", "--warmup", "2"]),
     ("df256_bf16", "configs[3]: DeepFashion 256x256 (trainer_256.py path) bs=8 bf16 on 1 MI355X",
      ["--workload", "df256", "--dtype", "bf16", "--steps", "20", "--warmup", "3"]),
     ("market128_stage2_bf16", "configs[2]: Market-1501 stage-II adversarial sampling bs=64 bf16 (this GPU's share of the job)",

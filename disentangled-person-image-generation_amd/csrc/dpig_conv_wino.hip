@@ -871,7 +871,11 @@ static bool pays(const DpigConvDesc* d, int cin, int kout) {
     init_mode();
     if (g_mode == 0) return false;
     if (g_mode == 2) return true;
-    const double direct_cycles = 2.0 * d->N * d->H * d->W * 9.0 * cin * kout / 50000.0;
+    // the direct family: ~115 TFLOP/s = 50 k FLOP per cycle on layers with >= 512 of its 128 x 128 tiles, down to ~65 % of that on the
+    // smallest maps (8 x 4 C640: 75 TFLOP/s measured; its split-K plans pay partial-sum passes too)
+    const long dtiles = (long)cdiv((long)d->N * d->H * d->W, 128) * cdiv(kout, 128);
+    const double drate = 50000.0 * (dtiles >= 512 ? 1.0 : 0.65 + 0.35 * (double)dtiles / 512.0);
+    const double direct_cycles = 2.0 * d->N * d->H * d->W * 9.0 * cin * kout / drate;
     return fwd_plan(d, cin, kout).cycles < 0.95 * direct_cycles;
 }
 
