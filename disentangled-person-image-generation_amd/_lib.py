@@ -72,7 +72,7 @@ SYMBOLS = {
     "dpig_conv2d_dgrad_wino": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dpig_conv2d_wgrad_wino_eligible": (_i, [_dp]),
     "dpig_conv2d_wgrad_wino_workspace_bytes": (_sz, [_dp]),
-    "dpig_conv2d_wgrad_wino": (_i, [_dp, _vp, _vp, _vp, _f, _vp, _sz, _vp]),
+    "dpig_conv2d_wgrad_wino": (_i, [_dp, _vp, _vp, _vp, _f, _vp, _f, _vp, _sz, _vp]),
     "dpig_conv2d_fwd_thin_bf16": (_i, [_dp, _vp, _vp, _vp, _vp, _vp]),
     "dpig_conv2d_dgrad_thin_bf16": (_i, [_dp, _vp, _vp, _vp, _vp]),
     "dpig_conv2d_wgrad_thin_bf16": (_i, [_dp, _vp, _vp, _vp, _f, _vp, _f, _vp, _sz, _vp]),

@@ -547,12 +547,15 @@ __global__ __launch_bounds__(512, 2) void wino_block_kernel(const WParams p) {
 // registers and writes 16-byte rows [position][tile][channel] into LDS; the MFMA fragments are 4-byte LDS reads (the reduction index of
 // v_mfma_f32_32x32x2_f32 runs across lanes).  At the end each wave applies A'^T . A' to its own position half in registers and writes
 // its nine 32 x 32 tap blocks as ONE of 2 S partial filter gradients [3][3][C][K]; wino_wgrad_reduce_kernel sums them in fixed order
-// (deterministic) into dw (+ beta dw).  The bias gradient is not part of this kernel (dpig_colsum).
+// (deterministic) into dw (+ beta dw).  The bias gradient db[k] = sum over pixels of dy rides along: the 2 x 2 dy pixels of the tiles
+// partition the map, so the workgroups of channel block 0 add up what their transform threads load anyway (transform row 0's copy)
+// and leave one [K] partial per split; the reduce kernel sums those in split order too.
 // ================================================================================================
 struct WGParams {
     const float* X;       // forward input, NHWC, channel stride ldx
     const float* DY;      // output gradient, NHWC, channel stride ldy
     float* part;          // [2 * nsplit][3][3][C][K]
+    float* bias_part;     // [nsplit][K] after the filter slabs, or null: no bias gradient asked
     int N, H, W, C, K, ldx, ldy;
     int T, THW, TW;
     int nchunks, cps;     // 8-tile chunks in the batch, chunks per split
@@ -634,6 +637,8 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WGParams p) {
     typedef __attribute__((address_space(3))) f32x4 lds_f4;
     const int wr_off = (4 * xi) * PLANE + tl * 256 + cq * 16;        // [position 4 xi + nu][tile tl][channel quad cq]
     f32x4 r[4], ry[2];
+    const bool sum_bias = p.bias_part != nullptr && cb == 0 && xi == 0;      // (wave-uniform)
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     auto rowX = [&]() {
 #pragma unroll
         for (int j = 0; j < 4; ++j) r[j] = sgn * d[1][j] + d[0][j];
@@ -651,6 +656,7 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WGParams p) {
     auto rowY = [&]() {
 #pragma unroll
         for (int j = 0; j < 2; ++j) ry[j] = ga * y[0][j] + gb * y[1][j];
+        if (sum_bias) bsum += (y[0][0] + y[0][1]) + (y[1][0] + y[1][1]);     // (tiles past the range loaded zeros)
     };
     auto colsY = [&](int buf, int pair) {
         lds_char* const base = L + 2 * OPB + buf * OPB + wr_off;
@@ -722,6 +728,17 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WGParams p) {
     // ---- output transform A'^T dU A' on this wave's position half (transform rows xi = 2 ph, 2 ph + 1), straight to its partial slab.
     // Column transform (over nu) per row: s0 = M0 + M1 + M2, s1 = M1 - M2, s2 = M1 + M2 + M3; row transform w0 = S0 + S1 + S2,
     // w1 = S1 - S2, w2 = S1 + S2 + S3 splits into  ph 0: (S0 + S1, S1, S1)   ph 1: (S2, -S2, S2 + S3).
+    if (p.bias_part != nullptr && cb == 0) {         // (workgroup-uniform) bias partial: 8 tile slots x 16 channel quads -> 64 channels
+        typedef __attribute__((address_space(3))) float lds_f;
+        if (xi == 0) *(lds_f4*)(L + tl * 256 + cq * 16) = bsum;
+        __syncthreads();
+        if (tid < 64) {
+            float t = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t += *(lds_f*)(L + i * 256 + tid * 4);
+            p.bias_part[(long)sp * p.K + kb * 64 + tid] = t;
+        }
+    }
     float* const slab = p.part + (long)(2 * sp + ph) * 9 * p.C * p.K;
     const int kcol = kb * 64 + 32 * kc + l31;
 #pragma unroll
@@ -747,16 +764,27 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WGParams p) {
 }
 
 // dw = beta dw + sum of the nparts partial gradients (fixed order: deterministic)
+// (+ the bias gradient: db = beta_b db + sum of the nparts / 2 partial [K] rows, when db is given)
 __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, long n4, int nparts,
-                                                                 float beta) {
+                                                                 float beta, const float* __restrict__ bias_part, float* __restrict__ db,
+                                                                 int K, float beta_b) {
     const f32x4* p4 = reinterpret_cast<const f32x4*>(part);
     f32x4* o4 = reinterpret_cast<f32x4*>(dw);
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x) {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+    const long total = n4 + (db ? K : 0);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        if (i < n4) {
+            f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll 4
-        for (int s = 0; s < nparts; ++s) v += p4[(long)s * n4 + i];
-        if (beta != 0.f) v += beta * o4[i];
-        o4[i] = v;
+            for (int s = 0; s < nparts; ++s) v += p4[(long)s * n4 + i];
+            if (beta != 0.f) v += beta * o4[i];
+            o4[i] = v;
+        } else {
+            const int k = (int)(i - n4);
+            float t = 0.f;
+            for (int s = 0; s < nparts / 2; ++s) t += bias_part[(long)s * K + k];
+            if (beta_b != 0.f) t += beta_b * db[k];
+            db[k] = t;
+        }
     }
 }
 
@@ -961,8 +989,8 @@ static bool wgrad_pays(const DpigConvDesc* d) {
     const WGPlan pl = wgrad_plan(d);
     const long wgs = (long)(d->C / 64) * (d->K / 64) * pl.nsplit;
     const long rounds = (wgs + kNumCU - 1) / kNumCU;
-    // ~5800 cycles per 8-tile chunk (4-byte fragment reads) + ~30 k fixed, + the partial slabs' write / read and the bias-gradient pass
-    const double wino_cycles = rounds * ((double)pl.cps * 5800.0 + 30000.0) + 2.0 * pl.nsplit * 600.0 + 40000.0;
+    // ~5800 cycles per 8-tile chunk (4-byte fragment reads) + ~30 k fixed, + the partial slabs' write / read and the reduction launch
+    const double wino_cycles = rounds * ((double)pl.cps * 5800.0 + 30000.0) + 2.0 * pl.nsplit * 600.0 + 15000.0;
     const double direct_cycles = 2.0 * d->N * d->H * d->W * 9.0 * d->C * d->K / 50000.0;
     return wino_cycles < 0.95 * direct_cycles;
 }
@@ -981,12 +1009,13 @@ extern "C" int dpig_conv2d_wgrad_wino_eligible(const DpigConvDesc* d) {
 extern "C" size_t dpig_conv2d_wgrad_wino_workspace_bytes(const DpigConvDesc* d) {
     if (!d || !wino::wgrad_shape_ok(d)) return 0;
     const wino::WGPlan pl = wino::wgrad_plan(d);
-    return (size_t)2 * pl.nsplit * 9 * d->C * d->K * sizeof(float);
+    return ((size_t)2 * pl.nsplit * 9 * d->C * d->K + (size_t)pl.nsplit * d->K) * sizeof(float);
 }
-// dw[3][3][C][K] = beta dw + conv_backward_filter(x, dy) by F(3x3, 2x2) minimal filtering (fp32 tensors, products and sums; deterministic).
-// The bias gradient is NOT produced here (dpig_colsum over dy).
-extern "C" int dpig_conv2d_wgrad_wino(const DpigConvDesc* d, const float* x, const float* dy, float* dw, float beta, void* ws, size_t ws_bytes,
-                                      void* stream) {
+// dw[3][3][C][K] = beta dw + conv_backward_filter(x, dy) by F(3x3, 2x2) minimal filtering (fp32 tensors, products and sums; deterministic);
+// with db ([K], may be null) the same two launches also leave the bias gradient db = beta_b db + sum over pixels of dy, as
+// dpig_conv2d_wgrad does.
+extern "C" int dpig_conv2d_wgrad_wino(const DpigConvDesc* d, const float* x, const float* dy, float* dw, float beta, float* db, float beta_b,
+                                      void* ws, size_t ws_bytes, void* stream) {
     int pt, pl_, Ho, Wo;
     int rc = resolve_desc(d, &pt, &pl_, &Ho, &Wo);
     if (rc) return rc;
@@ -994,11 +1023,13 @@ extern "C" int dpig_conv2d_wgrad_wino(const DpigConvDesc* d, const float* x, con
     if (!wino::wgrad_shape_ok(d)) return fail(DPIG_EINVAL, "winograd wgrad: unsupported shape");
     if (!aligned16(x) || !aligned16(dy) || !aligned16(dw) || !aligned16(ws)) return fail(DPIG_EINVAL, "winograd wgrad: operands must be 16-byte aligned");
     const wino::WGPlan pl = wino::wgrad_plan(d);
-    const size_t need = (size_t)2 * pl.nsplit * 9 * d->C * d->K * sizeof(float);
+    const size_t slabs = (size_t)2 * pl.nsplit * 9 * d->C * d->K;
+    const size_t need = (slabs + (size_t)pl.nsplit * d->K) * sizeof(float);
     if (!ws || ws_bytes < need) return fail(DPIG_ENOMEM, "winograd wgrad workspace too small: have %zu, need %zu", ws_bytes, need);
     hipStream_t st = static_cast<hipStream_t>(stream);
     wino::WGParams p = {};
     p.X = x; p.DY = dy; p.part = static_cast<float*>(ws);
+    p.bias_part = db ? p.part + slabs : nullptr;
     p.N = d->N; p.H = d->H; p.W = d->W; p.C = d->C; p.K = d->K; p.ldx = d->ldx; p.ldy = d->ldy;
     p.TW = d->W / 2; p.THW = (d->H / 2) * p.TW; p.T = d->N * p.THW;
     p.nchunks = pl.nchunks; p.cps = pl.cps; p.nsplit = pl.nsplit;
@@ -1012,7 +1043,8 @@ extern "C" int dpig_conv2d_wgrad_wino(const DpigConvDesc* d, const float* x, con
     if (rc) return rc;
     const long n4 = (long)9 * d->C * d->K / 4;
     const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
-    hipLaunchKernelGGL(wino::wino_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.part, dw, n4, 2 * pl.nsplit, beta);
+    hipLaunchKernelGGL(wino::wino_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.part, dw, n4, 2 * pl.nsplit, beta,
+                       p.bias_part, db, d->K, beta_b);
     return check_launch("wino_wgrad_reduce_kernel");
 }
 

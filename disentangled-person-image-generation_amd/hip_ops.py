@@ -547,6 +547,12 @@ def conv2d_fwd_stats(x, w, bias=None, stride=1, split_k=0):
     # bn_fwd's own statistics passes instead of an EINVAL from the launch
     if tiles <= 0 or not _al16(x, w, bias):
         return conv2d_fwd(x, w, bias, stride=stride, split_k=split_k), None
+    # a split plan's statistics come from its reduction pass, one workgroup per output tile summing every split in turn: below ~128
+    # tiles that pass is latency-bound on a handful of CUs and loses to the all-CU plain reduction followed by bn_fwd's own
+    # statistics passes (16 x 8 C256->512 5x5/2 at batch 16: 111 us against 66 us, scripts/bench_critic_convs.py) -- policy here,
+    # the entry point itself still takes any plan (a forced split_k keeps the fused path)
+    if split_k == 0 and tiles * ((K + 127) // 128) < 128 and lib().dpig_conv2d_bn_stats_tiles(ctypes.byref(d)) <= 0:
+        return conv2d_fwd(x, w, bias, stride=stride), None
     out = torch.empty((N, Ho, Wo, K), dtype=torch.float32, device=x.device)
     stats = torch.empty((tiles, 2, K), dtype=torch.float32, device=x.device)
     wsb, wsn = _ws(d, 0, x.device)
@@ -632,10 +638,8 @@ def conv2d_wgrad(x, dy, wshape, stride=1, upsample2x=False, out=None, beta=0.0, 
         nbytes = lib().dpig_conv2d_wgrad_wino_workspace_bytes(ctypes.byref(d))
         wsb, wsn = workspace.get(nbytes, x.device)
         with _Timed("conv_wgrad_wino", 2.0 * N * (H // 2) * (W // 2) * 16 * K * C, (N, H, W, C, K, R, stride, 0)):
-            check(lib().dpig_conv2d_wgrad_wino(ctypes.byref(d), ptr(x), ptr(dy), ptr(out), float(beta), ptr(wsb), wsn, stream_ptr()),
-                  "conv2d_wgrad_wino")
-        if db is not None:                      # (the direct kernel forms the bias gradient inside its launch; here it is its own pass)
-            colsum(dy, out=db, beta=db_beta)
+            check(lib().dpig_conv2d_wgrad_wino(ctypes.byref(d), ptr(x), ptr(dy), ptr(out), float(beta), ptr(db), float(db_beta),
+                                               ptr(wsb), wsn, stream_ptr()), "conv2d_wgrad_wino")
         return out
     wsb, wsn = _ws(d, 2, x.device)
     mfma = (C % 4 == 0 and K % 4 == 0 and C >= 32 and K >= 32)

@@ -195,12 +195,12 @@ int dpig_conv2d_dgrad_wino(const DpigConvDesc* d, const float* dy, const float* 
 /* The filter gradient by F(3x3, 2x2) minimal filtering: dw[3][3][C][K] = beta dw + conv_backward_filter(x, dy), 16 multiplies per
  * (2x2 tile, c, k) instead of 36; input and output-gradient transforms, the 16 position GEMMs over the tile axis and the output
  * transform are one kernel, split over tile ranges into 2 S partial gradients that a second kernel sums in fixed order
- * (deterministic).  Same shape rules as above.  The bias gradient is not produced (dpig_colsum over dy).  Workspace:
- * dpig_conv2d_wgrad_wino_workspace_bytes.  dpig_conv2d_wgrad_wino_eligible: shape has the form AND the cost model prefers it. */
+ * (deterministic).  Same shape rules as above.  With db ([K]; may be null) the same launches leave the bias gradient
+ * db = beta_b db + sum over pixels of dy, as dpig_conv2d_wgrad does.  Workspace: dpig_conv2d_wgrad_wino_workspace_bytes.  dpig_conv2d_wgrad_wino_eligible: shape has the form AND the cost model prefers it. */
 int dpig_conv2d_wgrad_wino_eligible(const DpigConvDesc* d);
 size_t dpig_conv2d_wgrad_wino_workspace_bytes(const DpigConvDesc* d);
-int dpig_conv2d_wgrad_wino(const DpigConvDesc* d, const float* x, const float* dy, float* dw, float beta, void* ws, size_t ws_bytes,
-                           void* stream);
+int dpig_conv2d_wgrad_wino(const DpigConvDesc* d, const float* x, const float* dy, float* dw, float beta, float* db, float beta_b,
+                           void* ws, size_t ws_bytes, void* stream);
 
 /* The thin layers of 'bf16' mode on the vector-ALU kernels (csrc/dpig_thin.hip) with their WIDE tensor stored as bf16;
  * the 3-channel image side, the fp32 HWIO filter and the filter gradient stay fp32:

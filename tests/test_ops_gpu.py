@@ -81,6 +81,9 @@ def test_conv_epilogue_bn_statistics(dev, shape, compute):
         # the same per-tile statistics of the values it stores
         for sk in (0, 2, 3):
             y_s, st_s = H.conv2d_fwd_stats(xg, wg, bg, stride=s, split_k=sk)
+            if sk == 0 and st_s is None:            # host policy: a heuristic split over few tiles takes bn_fwd's own passes
+                _close(y_s, pre)
+                continue
             assert st_s is not None and st_s[0].shape == st[0].shape
             _close(y_s, pre)
             out_s, mean_s, rstd_s = H.bn_fwd(y_s, scale.float().to(dev), offset.float().to(dev), 1e-5, 2, 0.2, stats=st_s)

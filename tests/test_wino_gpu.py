@@ -78,7 +78,10 @@ def test_forward_and_dgrad_against_oracle(dev, wino, shape):
     (rdw,) = torch.autograd.grad(O.conv2d_same(xr2, wr2, None, 1), wr2, dyd.cpu().double())
     _close(dw, rdw)
     _close(dw2, 2 * rdw)
-    _close(db, dyd.cpu().double().sum(dim=(0, 1, 2)))
+    _close(db, dyd.cpu().double().sum(dim=(0, 1, 2)))                       # (formed inside the same two launches)
+    db2 = db.clone()
+    H.conv2d_wgrad(xd, dyd, (3, 3, C, K), out=dw.clone(), db=db2, db_beta=1.0)
+    _close(db2, 2 * dyd.cpu().double().sum(dim=(0, 1, 2)))
     assert torch.equal(H.conv2d_wgrad(xd, dyd, (3, 3, C, K)), dw)          # repeatable (fixed summation order)
     # operands are fp32-rounded on the device: compare with the oracle on the same rounded values
     ref32 = O.conv2d_same(xd.cpu().double().requires_grad_(True), wd.cpu().double(), bd.cpu().double(), 1)
