@@ -65,6 +65,8 @@ SYMBOLS = {
     "dpig_conv_bf16_set_wave8": (_i, [_i]),
     "dpig_wino_filter_elems": (_sz, [_i, _i]),
     "dpig_wino_filter_transform": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "dpig_wino_filter_jobs_plan": (_i, [_vp, _i]),
+    "dpig_wino_filter_transform_jobs": (_i, [_vp, _i, _i, _vp]),
     "dpig_conv2d_wino_eligible": (_i, [_dp, _i]),
     "dpig_conv_wino_set_mode": (_i, [_i]),
     "dpig_conv2d_wino_workspace_bytes": (_sz, [_dp, _i]),

@@ -809,11 +809,10 @@ __global__ __launch_bounds__(256) void wino_reduce_kernel(const WParams p) {
 // One workgroup per (64-channel column block kb, 8-channel chunk): the 512 transforms are staged in LDS in image order and leave as one
 // contiguous 32-KB run of 16-byte stores.  Reads follow the filter's fastest axis (forward: output channels, dgrad: input channels).
 template <bool DGRAD>
-__global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int C, int K) {
-    __shared__ __attribute__((aligned(16))) float img[16 * 512];
+__device__ __forceinline__ void filter_body(const float* __restrict__ w, float* __restrict__ U, int C, int K, int blk, float* img) {
     const int cin = DGRAD ? K : C;
     const int nch = cin / CH;
-    const int kb = blockIdx.x / nch, chunk = blockIdx.x - kb * nch;
+    const int kb = blk / nch, chunk = blk - kb * nch;
     const int tid = threadIdx.x;
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
@@ -845,10 +844,36 @@ __global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restric
         }
     }
     __syncthreads();
-    f32x4* const dst = reinterpret_cast<f32x4*>(U + (long)blockIdx.x * (16 * 512));
+    f32x4* const dst = reinterpret_cast<f32x4*>(U + (long)blk * (16 * 512));
     const f32x4* const src = reinterpret_cast<const f32x4*>(img);
 #pragma unroll
     for (int i = 0; i < 8; ++i) dst[tid + 256 * i] = src[tid + 256 * i];
+}
+template <bool DGRAD>
+__global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int C, int K) {
+    __shared__ __attribute__((aligned(16))) float img[16 * 512];
+    filter_body<DGRAD>(w, U, C, K, blockIdx.x, img);
+}
+// Every filter of a parameter set in ONE launch (a model has ~90 of them; one launch pair each was 1.7 ms of a 46-ms step, all launch
+// latency): blocks [0, total) write the forward images, [total, 2 total) the dgrad images; a block finds its job by bisection over
+// the jobs' first_block.
+__global__ __launch_bounds__(256) void wino_filter_jobs_kernel(const DpigWinoFilterJob* __restrict__ jobs, int njobs, int total) {
+    __shared__ __attribute__((aligned(16))) float img[16 * 512];
+    const int dir = (int)blockIdx.x >= total;
+    const int b = (int)blockIdx.x - dir * total;
+    // job = the last one whose first_block <= b: every thread tests a few jobs and the workgroup counts the hits -- ONE round of
+    // independent loads (a bisection's chain of eight dependent loads was most of this kernel's time: 618 us for the Market model)
+    int cnt = 0;
+    for (int i0 = 0; i0 < njobs; i0 += 256) {
+        const int i = i0 + (int)threadIdx.x;
+        cnt += __syncthreads_count(i < njobs && jobs[i].first_block <= b);
+    }
+    const DpigWinoFilterJob j = jobs[cnt - 1];                    // (first_block of job 0 is 0: cnt >= 1)
+    if (dir) {
+        if (j.u_dgrad) filter_body<true>(j.w, j.u_dgrad, j.C, j.K, b - j.first_block, img);
+    } else {
+        if (j.u_fwd) filter_body<false>(j.w, j.u_fwd, j.C, j.K, b - j.first_block, img);
+    }
 }
 
 static unsigned long long* g_trace = nullptr;
@@ -1062,6 +1087,28 @@ extern "C" int dpig_wino_filter_transform(const float* w, int C, int K, float* u
     if (u_fwd) hipLaunchKernelGGL(wino::wino_filter_kernel<false>, dim3(blocks), dim3(256), 0, st, w, u_fwd, C, K);
     if (u_dgrad) hipLaunchKernelGGL(wino::wino_filter_kernel<true>, dim3(blocks), dim3(256), 0, st, w, u_dgrad, C, K);
     return check_launch("wino_filter_kernel");
+}
+
+// The same for a whole parameter set in one launch.  dpig_wino_filter_jobs_plan (host) fills first_block of every job and returns the
+// block total (0: a job without a Winograd form, or a null filter); the planned array, copied to device memory, feeds
+// dpig_wino_filter_transform_jobs.
+extern "C" int dpig_wino_filter_jobs_plan(DpigWinoFilterJob* jobs, int njobs) {
+    if (!jobs || njobs <= 0) return 0;
+    long total = 0;
+    for (int i = 0; i < njobs; ++i) {
+        if (!jobs[i].w || !dpig_wino_filter_elems(jobs[i].C, jobs[i].K)) return 0;
+        jobs[i].first_block = (int)total;
+        jobs[i].reserved = 0;
+        total += (long)(jobs[i].C / 64) * (jobs[i].K / wino::CH);
+        if (total > 0x3fffffffL) return 0;
+    }
+    return (int)total;
+}
+extern "C" int dpig_wino_filter_transform_jobs(const DpigWinoFilterJob* jobs_dev, int njobs, int total_blocks, void* stream) {
+    if (!jobs_dev || njobs <= 0 || total_blocks <= 0) return fail(DPIG_EINVAL, "winograd filter jobs: empty or unplanned job list");
+    hipLaunchKernelGGL(wino::wino_filter_jobs_kernel, dim3(2 * (unsigned)total_blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       jobs_dev, njobs, total_blocks);
+    return check_launch("wino_filter_jobs_kernel");
 }
 
 // 1: dpig_conv2d_fwd_wino (which = 0) / dpig_conv2d_dgrad_wino (which = 1) accepts this descriptor AND is expected to beat the

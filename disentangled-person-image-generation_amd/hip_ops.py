@@ -290,6 +290,12 @@ def wino_images(w, want_fwd=True, want_dgrad=True):
     return uf, ud
 
 
+class WinoFilterJob(ctypes.Structure):
+    """DpigWinoFilterJob (include/dpig_hip.h)."""
+    _fields_ = [("w", ctypes.c_void_p), ("u_fwd", ctypes.c_void_p), ("u_dgrad", ctypes.c_void_p), ("C", ctypes.c_int32), ("K", ctypes.c_int32),
+                ("first_block", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
 class WinoFilters(object):
     """Persistent Winograd images (forward + dgrad) of every 3x3 filter in `params` that has them, in ONE allocation, attached to the
     parameters as `_dpig_wino`; `refresh()` re-derives them from the fp32 masters (after every optimizer step, like FilterShadows)."""
@@ -306,9 +312,25 @@ class WinoFilters(object):
             n = lib().dpig_wino_filter_elems(int(p.shape[2]), int(p.shape[3]))
             p._dpig_wino = (self.buf[off:off + n], self.buf[off + n:off + 2 * n])
             off += 2 * n
+        # one launch per refresh for the whole set (dpig_wino_filter_transform_jobs): the job table lives in device memory and names the
+        # masters where they are NOW -- a parameter whose storage moves afterwards (p.data = ...) falls back to per-filter launches
+        jobs = (WinoFilterJob * len(self.params))()
+        for j, p in zip(jobs, self.params):
+            j.w, j.u_fwd, j.u_dgrad = p.data.data_ptr(), p._dpig_wino[0].data_ptr(), p._dpig_wino[1].data_ptr()
+            j.C, j.K = int(p.shape[2]), int(p.shape[3])
+        self.total = lib().dpig_wino_filter_jobs_plan(ctypes.byref(jobs), len(jobs))
+        if self.total <= 0:
+            raise RuntimeError("dpig_wino_filter_jobs_plan refused the filter set")
+        self.masters = [p.data.data_ptr() for p in self.params]
+        self.jobs = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(self.params[0].device)
         self.refresh()
 
     def refresh(self):
+        if not getattr(self, "params", None):
+            return
+        if [p.data.data_ptr() for p in self.params] == self.masters:
+            check(lib().dpig_wino_filter_transform_jobs(ptr(self.jobs), len(self.params), self.total, stream_ptr()), "wino_filter_transform_jobs")
+            return
         for p in self.params:
             uf, ud = p._dpig_wino
             check(lib().dpig_wino_filter_transform(ptr(p.data), int(p.shape[2]), int(p.shape[3]), ptr(uf), ptr(ud), stream_ptr()),

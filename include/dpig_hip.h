@@ -185,6 +185,18 @@ int dpig_conv_bf16_set_wave8(int mode);
  * last round, cut the reduction over input channels into ranges whose partial outputs a second kernel sums in fixed order. */
 size_t dpig_wino_filter_elems(int C, int K);
 int dpig_wino_filter_transform(const float* w, int C, int K, float* u_fwd, float* u_dgrad, void* stream);
+/* A whole parameter set's images in ONE launch (after every optimizer step): describe each filter in a job, let
+ * dpig_wino_filter_jobs_plan (host only) fill first_block and return the block total (0: a job has no Winograd form), copy the array to
+ * device memory once, then dpig_wino_filter_transform_jobs(jobs_dev, njobs, total, stream) per refresh.  u_fwd / u_dgrad may be null. */
+typedef struct DpigWinoFilterJob {
+    const float* w;            /* HWIO [3][3][C][K] master */
+    float* u_fwd;              /* dpig_wino_filter_elems(C, K) floats each */
+    float* u_dgrad;
+    int32_t C, K;
+    int32_t first_block, reserved;
+} DpigWinoFilterJob;
+int dpig_wino_filter_jobs_plan(DpigWinoFilterJob* jobs, int njobs);
+int dpig_wino_filter_transform_jobs(const DpigWinoFilterJob* jobs_dev, int njobs, int total_blocks, void* stream);
 int dpig_conv2d_wino_eligible(const DpigConvDesc* d, int which);
 int dpig_conv_wino_set_mode(int mode);
 size_t dpig_conv2d_wino_workspace_bytes(const DpigConvDesc* d, int which);

@@ -167,6 +167,33 @@ def test_layers_without_a_winograd_form_stay_on_the_direct_kernels(dev, wino):
             H.set_compute("f32w")
 
 
+def test_one_launch_filter_refresh_equals_the_per_filter_transforms(dev, wino):
+    """WinoFilters.refresh: dpig_wino_filter_transform_jobs writes, for a set of filters of different sizes (and the 5x5 / thin ones it
+    must skip), exactly the images dpig_wino_filter_transform writes one filter at a time; a master whose storage moved takes the
+    per-filter path and still ends up right."""
+    H = wino
+    shapes = [(3, 3, 64, 64), (3, 3, 128, 64), (5, 5, 64, 64), (3, 3, 64, 192), (3, 3, 256, 256), (3, 3, 64, 3), (3, 3, 192, 128)]
+    params = [torch.nn.Parameter(_rand(sh, 10 + i, 0.1).float().to(dev)) for i, sh in enumerate(shapes)]
+    wf = H.WinoFilters(params)
+    assert len(wf.params) == 5 and wf.total == sum((p.shape[2] // 64) * (p.shape[3] // 8) for p in wf.params)
+    for p in wf.params:
+        uf, ud = H.wino_images(p.data.clone())
+        assert torch.equal(p._dpig_wino[0], uf) and torch.equal(p._dpig_wino[1], ud)
+    with torch.no_grad():
+        for p in wf.params:
+            p.data.mul_(1.5)                                  # in place: the job table still names the masters
+    wf.refresh()
+    for p in wf.params:
+        uf, ud = H.wino_images(p.data.clone())
+        assert torch.equal(p._dpig_wino[0], uf) and torch.equal(p._dpig_wino[1], ud)
+    params[1].data = params[1].data.clone() * 2.0             # storage moved: per-filter launches
+    wf.refresh()
+    for p in wf.params:
+        uf, ud = H.wino_images(p.data.clone())
+        assert torch.equal(p._dpig_wino[0], uf) and torch.equal(p._dpig_wino[1], ud)
+    wf.detach()
+
+
 FULL = [("dec4", 16, 128, 64, 256), ("dec3", 16, 64, 32, 512), ("dec2", 16, 32, 16, 768), ("roi b1", 112, 24, 24, 256)]
 
 
