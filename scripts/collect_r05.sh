@@ -29,6 +29,7 @@ traffic)
 headline)
   # the round-5 headline (f32w: Winograd where it pays): traffic passes, kernel stats (one stream), matrix-pipe counters, per-layer table
   DPIG_TWO_STREAM=0 DPIG_D_OVERLAP=0 bash scripts/pmc_traffic.sh r05_market_f32w market128/f32w --dtype f32w
+  DPIG_TWO_STREAM=0 DPIG_D_OVERLAP=0 bash scripts/pmc_traffic.sh r05_df256_f32w df256/f32w --workload df256 --dtype f32w
   DPIG_TWO_STREAM=0 DPIG_D_OVERLAP=0 bash scripts/collect_stats.sh r05_market_f32w --dtype f32w
   DPIG_TWO_STREAM=0 DPIG_D_OVERLAP=0 bash scripts/pmc_mfma_bench.sh r05_market_f32w --dtype f32w
   DPIG_WORKLOAD=market128 DPIG_DTYPE=f32w DPIG_TWO_STREAM=0 DPIG_D_OVERLAP=0 timeout 300 python scripts/layer_table.py > gpurun_out/profiles_out/r05_layer_market_f32w.txt 2>&1

@@ -194,12 +194,14 @@ def test_one_launch_filter_refresh_equals_the_per_filter_transforms(dev, wino):
     wf.detach()
 
 
-FULL = [("dec4", 16, 128, 64, 256), ("dec3", 16, 64, 32, 512), ("dec2", 16, 32, 16, 768), ("roi b1", 112, 24, 24, 256)]
+FULL = [("dec4", 16, 128, 64, 256), ("dec3", 16, 64, 32, 512), ("dec2", 16, 32, 16, 768), ("roi b1", 112, 24, 24, 256),
+        # DeepFashion 256 x 256 at batch 8 (trainer_256.py sizes; bench.py's df256_f32 line runs them by Winograd too)
+        ("df enc1", 8, 256, 256, 128), ("df dec3", 8, 64, 64, 768)]
 
 
 @pytest.mark.parametrize("layer", FULL, ids=[l[0] for l in FULL])
 def test_full_size_layers_against_the_sampled_oracle(dev, layer):
-    """BASELINE configs[1] layer sizes under the DEFAULT selection (cost model): 4096 sampled output / input positions against
+    """BASELINE configs[1] (and two DeepFashion) layer sizes under the DEFAULT selection (cost model): 4096 sampled output / input positions against
     oracle.ops.conv2d_same*_sampled in fp64, forward + bias + ReLU and dgrad."""
     import dpig_amd.hip_ops as H
     from oracle import ops as O
