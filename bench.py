@@ -451,7 +451,7 @@ def main():
             "bf16c": ("conv_fwd_mfma", PEAK_BF16_MFMA_TFLOPS, "conv fwd implicit GEMM, fp32 tensors rounded to bf16 on the way into LDS", 1.0),
             "bf16x3": ("conv_fwd_mfma", PEAK_BF16_MFMA_TFLOPS, "conv fwd implicit GEMM, fp32 tensors as two-term bf16 splits: 3 bf16 MFMAs per product "
                        "block (executed FLOPs = 3 x algorithmic)", 3.0),
-            "f32w": ("conv_fwd_wino", PEAK_F32_MFMA_TFLOPS, "dpig::wino::wino_kernel (3x3 stride-1 conv fwd as Winograd F(2x2,3x3): 16 position GEMMs on "
+            "f32w": ("conv_fwd_wino", PEAK_F32_MFMA_TFLOPS, "dpig::wino::wino_block_kernel / wino_kernel (3x3 stride-1 conv fwd as Winograd F(2x2,3x3): 16 position GEMMs on "
                      "v_mfma_f32_32x32x2_f32, transforms fused; FLOPs = the 16/36 of the direct count that are executed)", 1.0),
         }[args.dtype]
         fwd = [(f, t) for (k, f, t) in recs if k == dom]

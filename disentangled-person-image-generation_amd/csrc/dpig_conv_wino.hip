@@ -73,6 +73,7 @@ struct WParams {
     int act; float alpha; int res_post;
     unsigned x_bytes, u_bytes;
     unsigned mul_thw, shr_thw, mul_tw, shr_tw, mul_th, shr_th;
+    int xmajor;           // workgroup order: 1 activation-major, 0 filter-major
     unsigned long long* trace;   // dev aid (dpig_debug_wino_trace): 8 s_memtime stamps per workgroup, or null
 };
 
@@ -112,11 +113,13 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
 
-    // tile order: the row blocks of one 64-channel column block are consecutive, so the workgroups an XCD receives (xcd_remap hands
-    // every XCD one contiguous range) stream ONE slice of the transformed filter through their L2
+    // tile order (xcd_remap hands every XCD one contiguous range of it).  Filter-major: the row blocks of one 64-channel column block
+    // are consecutive, an XCD streams ONE slice of the transformed filter through its L2 and the column blocks' XCDs each fetch the
+    // activation (min(8, K / 64) times in all).  Activation-major (p.xmajor): the column blocks of one row block are consecutive, the
+    // activation is fetched once and every XCD streams the whole filter image.  The host picks the order that moves fewer bytes.
     const int bid = xcd_remap(blockIdx.x, p.mtiles * p.ntiles * p.nsplit);
     const int sp = bid / (p.mtiles * p.ntiles), tile = bid - sp * (p.mtiles * p.ntiles);
-    const int nt = tile / p.mtiles, mt = tile - nt * p.mtiles;
+    const int nt = p.xmajor ? tile % p.ntiles : tile / p.mtiles, mt = p.xmajor ? tile / p.ntiles : tile - nt * p.mtiles;
     const int t0 = mt * TB, n0 = nt * KB;
     const int cb = sp * p.cps, ce = min(cb + p.cps, p.nch);          // this workgroup's chunks (input-channel range of a split plan)
     auto stamp = [&](int slot) {
@@ -344,7 +347,7 @@ __global__ __launch_bounds__(512, 2) void wino_block_kernel(const WParams p) {
     const int l31 = lane & 31, half = lane >> 5;
     const int bid = xcd_remap(blockIdx.x, p.mtiles * p.ntiles * p.nsplit);
     const int sp = bid / (p.mtiles * p.ntiles), tile = bid - sp * (p.mtiles * p.ntiles);
-    const int nt = tile / p.mtiles, mt = tile - nt * p.mtiles;
+    const int nt = p.xmajor ? tile % p.ntiles : tile / p.mtiles, mt = p.xmajor ? tile / p.ntiles : tile - nt * p.mtiles;
     const int n0 = nt * KB;
     const int cb = sp * p.cps, ce = min(cb + p.cps, p.nch);
     const int bcols = p.TW >> 2;
@@ -953,6 +956,14 @@ static int launch(const DpigConvDesc* d, const float* in, const float* U, const 
     p.trace = g_trace;
     const FPlan pl = fwd_plan(d, cin, kout);
     p.nsplit = pl.nsplit; p.cps = pl.cps;
+    {   // workgroup order by HBM bytes: every XCD has its own L2, so whichever operand the XCDs do NOT partition is fetched by each
+        // of the XCDs that work on the launch (DPIG_WINO_XMAJOR=0 / 1 pins the order: measurements)
+        const double xb = (double)d->N * d->H * d->W * cin * 4.0, ub = 16.0 * cin * kout * 4.0;
+        const double filter_major = xb * (p.ntiles < kNumXCD ? p.ntiles : kNumXCD) + ub;
+        const double act_major = xb + ub * (p.mtiles < kNumXCD ? p.mtiles : kNumXCD);
+        static const char* pin = getenv("DPIG_WINO_XMAJOR");
+        p.xmajor = pin ? (atoi(pin) != 0) : (act_major < filter_major);
+    }
     if (p.nsplit > 1) {
         const size_t need = (size_t)p.nsplit * d->N * d->H * d->W * kout * sizeof(float);
         if (!ws || ws_bytes < need || !aligned16(ws)) return fail(DPIG_ENOMEM, "winograd conv workspace too small: have %zu, need %zu", ws_bytes, need);
