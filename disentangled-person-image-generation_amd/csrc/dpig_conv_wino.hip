@@ -855,15 +855,18 @@ __device__ __forceinline__ void filter_body(const float* __restrict__ w, float* 
 template <bool DGRAD>
 __global__ __launch_bounds__(256) void wino_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int C, int K) {
     __shared__ __attribute__((aligned(16))) float img[16 * 512];
-    filter_body<DGRAD>(w, U, C, K, blockIdx.x, img);
+    filter_body<DGRAD>(w, U, C, K, xcd_remap(blockIdx.x, gridDim.x), img);
 }
 // Every filter of a parameter set in ONE launch (a model has ~90 of them; one launch pair each was 1.7 ms of a 46-ms step, all launch
 // latency): blocks [0, total) write the forward images, [total, 2 total) the dgrad images; a block finds its job by bisection over
 // the jobs' first_block.
 __global__ __launch_bounds__(256) void wino_filter_jobs_kernel(const DpigWinoFilterJob* __restrict__ jobs, int njobs, int total) {
     __shared__ __attribute__((aligned(16))) float img[16 * 512];
-    const int dir = (int)blockIdx.x >= total;
-    const int b = (int)blockIdx.x - dir * total;
+    // (consecutive blocks of the dgrad direction read neighbouring 32-byte pieces of the same filter rows: on ONE XCD they share the
+    // lines through its L2 -- dealt round-robin over the XCDs every piece was its own HBM fetch, 2.4 GB read for 0.45 GB of filters)
+    const int lb = xcd_remap(blockIdx.x, 2 * total);
+    const int dir = lb >= total;
+    const int b = lb - dir * total;
     // job = the last one whose first_block <= b: every thread tests a few jobs and the workgroup counts the hits -- ONE round of
     // independent loads (a bisection's chain of eight dependent loads was most of this kernel's time: 618 us for the Market model)
     int cnt = 0;
