@@ -175,9 +175,7 @@ def main():
                          "their gradients and the filter shadows stored as bf16, bf16 matrix pipe, fp32 accumulation / master "
                          "weights / gradients / optimizer.  bf16c: round 1's intermediate mode (fp32 tensors, bf16 pipe).  bf16x3 "
                          "(information line): fp32 tensors, conv operands split into two bf16 terms, three bf16 MFMAs per product "
-                         "block -- the exact kernels' own 2e-5 accuracy bar on the bf16 pipe.  f32w (information line): f32 with the 3x3 "
-                         "stride-1 convs (forward + dgrad) evaluated by Winograd F(2x2,3x3) on the fp32 matrix pipe: fp32 tensors, fp32 "
-                         "products, fp32 accumulation, 2.25x fewer multiplies (csrc/dpig_conv_wino.hip)")
+                         "block -- the exact kernels' own 2e-5 accuracy bar on the bf16 pipe.")
     ap.add_argument("--no-info-lines", action="store_true",
                     help="headline run only: skip the information lines (df256 / stage-II / Market in bf16, Market wgan-gp) that "
                          "are measured in sub-processes after the headline and embedded under `info_lines`")
@@ -519,7 +517,7 @@ def main():
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.dtype == "f32w" else args.dtype, "data": "synthetic",
             "conv_algorithm": "winograd F(2x2,3x3) / F(3x3,2x2) for 3x3 stride-1 layers where it pays, direct implicit GEMM elsewhere" if args.dtype == "f32w" else "direct implicit GEMM",
-            "config": {"workload": "%s, bs=%d per GPU, %s; %s" % (wl_desc, B, {"f32": "fp32", "f32w": "fp32 (tensors, products, accumulation); 3x3 stride-1 convs forward + dgrad by Winograd F(2x2,3x3) where the cost model says it pays", "bf16": "bf16 storage (activations, their gradients, filter shadows) + bf16 matrix pipe; fp32 accumulation, master weights, gradients and optimizer", "bf16c": "bf16 matrix pipe on fp32 tensors", "bf16x3": "fp32 tensors; conv products as three bf16 MFMAs on two-term bf16 splits of the fp32 operands (<= 2e-5 max|ref| per kernel, the exact path's test bar); everything else fp32"}[args.dtype], POSE_DESC),
+            "config": {"workload": "%s, bs=%d per GPU, %s; %s" % (wl_desc, B, {"f32": "fp32", "f32w": "fp32 (tensors, products, accumulation); 3x3 stride-1 convs (forward, dgrad, filter gradient) by Winograd F(2x2,3x3) / F(3x3,2x2) where the cost model says it pays", "bf16": "bf16 storage (activations, their gradients, filter shadows) + bf16 matrix pipe; fp32 accumulation, master weights, gradients and optimizer", "bf16c": "bf16 matrix pipe on fp32 tensors", "bf16x3": "fp32 tensors; conv products as three bf16 MFMAs on two-term bf16 splits of the fp32 operands (<= 2e-5 max|ref| per kernel, the exact path's test bar); everything else fp32"}[args.dtype], POSE_DESC),
                        "global_batch": world * B, "parallelism": "dp%d" % world},
             "achieved_alg_tflops": round(ALG_GFLOP_PER_IMG * value / 1e3, 2) if headline else None,
             "losses": {k: float(v) for k, v in out.items() if hasattr(v, "numel") and v.numel() == 1 and not sampling},

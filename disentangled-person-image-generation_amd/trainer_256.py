@@ -106,6 +106,8 @@ class DPIG_Encoder_subSampleAppNet_GAN_BodyROI_256(object):
         self.allreduce.broadcast(self.D_flat.flat)
         if getattr(self.config, "compute_dtype", "f32") in ("bf16", "bf16x3"):
             self.encoder_shadows = H.FilterShadows(self.Encoder_var, split=self.config.compute_dtype == "bf16x3")
+        if getattr(self.config, "compute_dtype", "f32") == "f32w":
+            self.encoder_wino = H.WinoFilters(self.Encoder_var)      # frozen: Winograd images made once
 
     def g_optim_embs(self, batch, z=None):
         self.G_flat.zero_grad()

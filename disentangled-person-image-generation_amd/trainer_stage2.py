@@ -91,6 +91,8 @@ class DPIG_Encoder_subSampleAppNetFgBg_GAN_BodyROI(object):
         if getattr(self.config, "compute_dtype", "f32") in ("bf16", "bf16x3"):
             # the frozen encoder's filters: bf16 shadows made once (the FC mappers / critics run on fp32 weights)
             self.encoder_shadows = H.FilterShadows(self.Encoder_var, split=self.config.compute_dtype == "bf16x3")
+        if getattr(self.config, "compute_dtype", "f32") == "f32w":
+            self.encoder_wino = H.WinoFilters(self.Encoder_var)      # frozen: Winograd images made once
 
     # ---- optimizer ops -------------------------------------------------------------------------------
     def g_optim_embs(self, side, z=None):
