@@ -167,6 +167,19 @@ def test_layers_without_a_winograd_form_stay_on_the_direct_kernels(dev, wino):
             H.set_compute("f32w")
 
 
+@pytest.mark.parametrize("order", ["0", "1"], ids=["filter-major", "activation-major"])
+def test_both_workgroup_orders_against_the_oracle(dev, order):
+    """The forward / dgrad kernels walk their workgroups filter-major or activation-major, picked per launch by HBM bytes
+    (WParams.xmajor); DPIG_WINO_XMAJOR pins the order for a whole process.  The oracle and epilogue tests above, every shape, in a
+    sub-process under each order."""
+    import os, subprocess, sys
+    env = dict(os.environ, DPIG_WINO_XMAJOR=order)
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-m", "gpu", "-p", "no:cacheprovider",
+                        "-k", "test_forward_and_dgrad_against_oracle or test_fused_epilogues_and_channel_slices"],
+                       env=env, capture_output=True, text=True, timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and " passed" in r.stdout, r.stdout[-3000:] + r.stderr[-2000:]
+
+
 def test_one_launch_filter_refresh_equals_the_per_filter_transforms(dev, wino):
     """WinoFilters.refresh: dpig_wino_filter_transform_jobs writes, for a set of filters of different sizes (and the 5x5 / thin ones it
     must skip), exactly the images dpig_wino_filter_transform writes one filter at a time; a master whose storage moved takes the
