@@ -105,6 +105,65 @@ __device__ __forceinline__ void epi4(const WParams& p, long pix, int col, f32x4 
     *reinterpret_cast<f32x4*>(p.D + pix * p.ldd + col) = v;
 }
 
+typedef const __attribute__((address_space(3))) f32x4 lds_cf4_t;
+// A workgroup's fused epilogue: thread = (16-byte channel group cg = tid % 16, staged rows tid / 16 + 32 k2 of the four 2 x 2 sub-pixel
+// images), i.e. the four pixels of two tiles; pix0[k2] = the tile's top-left output pixel (ok[k2]: the tile exists).  All 16 LDS reads
+// go first (one wait instead of eight read -> wait -> store round trips), then ONE of three workgroup-uniform paths: the partial slab
+// of a split plan, the plain bias + activation (most launches; the activation a compile-time constant), or the family's general
+// form.  (With the reads inside the per-pixel loop and every activation / residual / mask test inside it too, this phase took 6.4 k
+// cycles of a C = 128 workgroup's 92 k -- scripts/trace_wino.py.)
+__device__ __forceinline__ void wino_epilogue(const WParams& p, const lds_char* const L, int tid, int n0, int sp, const long (&pix0)[2],
+                                              const bool (&ok)[2]) {
+    const int cg = tid & 15, col = n0 + 4 * cg;
+    f32x4 v[8];
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2)
+#pragma unroll
+        for (int ij = 0; ij < 4; ++ij) {
+            const int row = ij * 64 + (tid >> 4) + 32 * k2;
+            v[4 * k2 + ij] = *(lds_cf4_t*)(L + row * EP_ROW + cg * 16) + *(lds_cf4_t*)(L + 256 * EP_ROW + row * EP_ROW + cg * 16);
+        }
+    if (p.nsplit > 1) {
+        float* const base = p.partial + (long)sp * p.N * p.H * p.W * p.Kout + col;
+#pragma unroll
+        for (int k2 = 0; k2 < 2; ++k2) {
+            if (!ok[k2]) continue;
+#pragma unroll
+            for (int ij = 0; ij < 4; ++ij)
+                *reinterpret_cast<f32x4*>(base + (pix0[k2] + (ij >> 1) * p.W + (ij & 1)) * p.Kout) = v[4 * k2 + ij];
+        }
+        return;
+    }
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
+    if (!p.res && !p.mask && !p.D2) {
+        float* const base = p.D + col;
+        auto plain = [&](auto ACT) {
+#pragma unroll
+            for (int k2 = 0; k2 < 2; ++k2) {
+                if (!ok[k2]) continue;
+#pragma unroll
+                for (int ij = 0; ij < 4; ++ij) {
+                    f32x4 o = v[4 * k2 + ij] + bv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = act_apply(o[e], decltype(ACT)::value, p.alpha);
+                    *reinterpret_cast<f32x4*>(base + (pix0[k2] + (ij >> 1) * p.W + (ij & 1)) * p.ldd) = o;
+                }
+            }
+        };
+        if (p.act == DPIG_ACT_RELU) plain(std::integral_constant<int, DPIG_ACT_RELU>{});
+        else if (p.act == DPIG_ACT_LRELU) plain(std::integral_constant<int, DPIG_ACT_LRELU>{});
+        else plain(std::integral_constant<int, DPIG_ACT_NONE>{});
+        return;
+    }
+#pragma unroll
+    for (int k2 = 0; k2 < 2; ++k2) {
+        if (!ok[k2]) continue;
+#pragma unroll
+        for (int ij = 0; ij < 4; ++ij) epi4(p, pix0[k2] + (ij >> 1) * p.W + (ij & 1), col, v[4 * k2 + ij], bv);
+    }
+}
+
 __global__ __launch_bounds__(512, 2) void wino_kernel(const WParams p) {
     __shared__ __attribute__((aligned(16))) char smem[SMEM];
     lds_char* const L = (lds_char*)smem;
@@ -295,29 +354,21 @@ __global__ __launch_bounds__(512, 2) void wino_kernel(const WParams p) {
     }
     __syncthreads();
     stamp(3);
-    // ---- fused epilogue: thread = (16-byte channel group cg, staged row tid / 16 + 32 it); a thread's rows are 2 tiles x 4 pixels -------
-    const int cg = tid & 15, col = n0 + 4 * cg;
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
+    // ---- fused epilogue: a thread's staged rows are the 4 pixels of tiles t0 + tid / 16 and + 32 ----------------------------------------
+    long pix0[2];
+    bool ok[2];
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) {
-        const int tloc = (tid >> 4) + 32 * k2;
-        const int t = t0 + tloc;
-        if (t >= p.T) continue;
-        const int n = fast_div(t, p.mul_thw, p.shr_thw);
-        const int rem = t - n * p.THW;
+        const int t = t0 + (tid >> 4) + 32 * k2;
+        ok[k2] = t < p.T;
+        const int tt = ok[k2] ? t : 0;
+        const int n = fast_div(tt, p.mul_thw, p.shr_thw);
+        const int rem = tt - n * p.THW;
         const int ty = fast_div(rem, p.mul_tw, p.shr_tw);
         const int tx = rem - ty * p.TW;
-        const long pix0 = ((long)n * p.H + 2 * ty) * p.W + 2 * tx;
-#pragma unroll
-        for (int ij = 0; ij < 4; ++ij) {
-            const int row = ij * 64 + tloc;
-            const f32x4 v = *(lds_cf4*)(L + row * EP_ROW + cg * 16) + *(lds_cf4*)(L + 256 * EP_ROW + row * EP_ROW + cg * 16);
-            const long pix = pix0 + (ij >> 1) * p.W + (ij & 1);
-            if (p.nsplit > 1) *reinterpret_cast<f32x4*>(p.partial + ((long)sp * p.N * p.H * p.W + pix) * p.Kout + col) = v;
-            else epi4(p, pix, col, v, bv);
-        }
+        pix0[k2] = ((long)n * p.H + 2 * ty) * p.W + 2 * tx;
     }
+    wino_epilogue(p, L, tid, n0, sp, pix0, ok);
     stamp(4);
 }
 
@@ -519,22 +570,14 @@ __global__ __launch_bounds__(512, 2) void wino_block_kernel(const WParams p) {
     __syncthreads();
     stamp(3);
     // ---- fused epilogue: the stack's pixel of tile (block row, block column), sub-pixel (i, j) is (2 R + i) W + 2 (C0 + btx) + j ---------
-    const int cg = tid & 15, col = n0 + 4 * cg;
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
+    long pix0[2];
+    const bool ok[2] = {true, true};
 #pragma unroll
     for (int k2 = 0; k2 < 2; ++k2) {
         const int tloc = (tid >> 4) + 32 * k2;
-        const long pix0 = (long)(2 * (R0 + (tloc >> 2))) * p.W + 2 * (C0 + (tloc & 3));
-#pragma unroll
-        for (int ij = 0; ij < 4; ++ij) {
-            const int row = ij * 64 + tloc;
-            const f32x4 v = *(lds_cf4*)(L + row * EP_ROW + cg * 16) + *(lds_cf4*)(L + 256 * EP_ROW + row * EP_ROW + cg * 16);
-            const long pix = pix0 + (ij >> 1) * p.W + (ij & 1);
-            if (p.nsplit > 1) *reinterpret_cast<f32x4*>(p.partial + ((long)sp * p.N * p.H * p.W + pix) * p.Kout + col) = v;
-            else epi4(p, pix, col, v, bv);
-        }
+        pix0[k2] = (long)(2 * (R0 + (tloc >> 2))) * p.W + 2 * (C0 + (tloc & 3));
     }
+    wino_epilogue(p, L, tid, n0, sp, pix0, ok);
     stamp(4);
 }
 
