@@ -389,14 +389,13 @@ constexpr int RAW_PIECES = 11, RAWB = RAW_PIECES * 1024;             // 340 pixe
 constexpr int RAW_OFF = 4 * OPB, ZERO_OFF = RAW_OFF + 2 * RAWB, SMEM_BLOCK = ZERO_OFF + 64;
 static_assert(SMEM_BLOCK <= 163840 && SMEM <= SMEM_BLOCK, "LDS plan");
 
-__global__ __launch_bounds__(512, 2) void wino_block_kernel(const WParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[SMEM_BLOCK];
-    lds_char* const L = (lds_char*)smem;
+// one workgroup's work item vb (a virtual block index: what the block index is to a launch with one workgroup per item)
+__device__ __forceinline__ void wino_block_body(const WParams& p, lds_char* const L, const int vb) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
-    const int bid = xcd_remap(blockIdx.x, p.mtiles * p.ntiles * p.nsplit);
+    const int bid = xcd_remap(vb, p.mtiles * p.ntiles * p.nsplit);
     const int sp = bid / (p.mtiles * p.ntiles), tile = bid - sp * (p.mtiles * p.ntiles);
     const int nt = p.xmajor ? tile % p.ntiles : tile / p.mtiles, mt = p.xmajor ? tile / p.ntiles : tile - nt * p.mtiles;
     const int n0 = nt * KB;
@@ -405,7 +404,7 @@ __global__ __launch_bounds__(512, 2) void wino_block_kernel(const WParams p) {
     const int brow = mt / bcols, bcol = mt - brow * bcols;
     const int R0 = 16 * brow, C0 = 4 * bcol;                         // first stacked tile row / tile column of the block
     auto stamp = [&](int slot) {
-        if (p.trace && tid == 0) p.trace[(long)blockIdx.x * 8 + slot] = __builtin_amdgcn_s_memtime();
+        if (p.trace && tid == 0) p.trace[(long)vb * 8 + slot] = __builtin_amdgcn_s_memtime();
     };
     stamp(0);
     const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.X, p.x_bytes);
@@ -579,6 +578,20 @@ __global__ __launch_bounds__(512, 2) void wino_block_kernel(const WParams p) {
     }
     wino_epilogue(p, L, tid, n0, sp, pix0, ok);
     stamp(4);
+}
+
+// Persistent launch: the host starts one workgroup per CU (or one per item when there are fewer) and every workgroup walks the items
+// vb = blockIdx.x, + gridDim.x, ... (gridDim.x a multiple of the XCD count keeps an item's XCD what xcd_remap assumes).  With one
+// 136-KB workgroup per CU nothing else can be resident while the dispatcher retires a workgroup and starts the next: that gap
+// (~6 us per round) was the difference between 4 rounds x 87.7 k cycles = 146 us and the 178 us a C = 128 layer took.
+__global__ __launch_bounds__(512, 2) void wino_block_kernel(const WParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[SMEM_BLOCK];
+    lds_char* const L = (lds_char*)smem;
+    const int total = p.mtiles * p.ntiles * p.nsplit;
+    for (int vb = blockIdx.x; vb < total; vb += gridDim.x) {
+        wino_block_body(p, L, vb);
+        __syncthreads();                              // the epilogue's staging reads are done before the next item's DMA lands
+    }
 }
 
 // ================================================================================================
@@ -1020,7 +1033,10 @@ static int launch(const DpigConvDesc* d, const float* in, const float* U, const 
     static const bool block_on = !(getenv("DPIG_WINO_BLOCK") && atoi(getenv("DPIG_WINO_BLOCK")) == 0);
     int rc;
     if (block_on && (p.TW & 3) == 0 && ((d->N * (d->H / 2)) & 15) == 0) {
-        hipLaunchKernelGGL(wino_block_kernel, grid, dim3(512), 0, st, p);
+        static const char* pers = getenv("DPIG_WINO_PERSIST");      // 0: one workgroup per item (measurements)
+        const unsigned items = grid.x;
+        const dim3 pgrid((pers && atoi(pers) == 0) || items <= (unsigned)kNumCU ? items : (unsigned)kNumCU);
+        hipLaunchKernelGGL(wino_block_kernel, pgrid, dim3(512), 0, st, p);
         rc = check_launch("wino_block_kernel");
     } else {
         hipLaunchKernelGGL(wino_kernel, grid, dim3(512), 0, st, p);
