@@ -404,7 +404,12 @@ __device__ __forceinline__ void wino_block_body(const WParams& p, lds_char* cons
     const int brow = mt / bcols, bcol = mt - brow * bcols;
     const int R0 = 16 * brow, C0 = 4 * bcol;                         // first stacked tile row / tile column of the block
     auto stamp = [&](int slot) {
-        if (p.trace && tid == 0) p.trace[(long)vb * 8 + slot] = __builtin_amdgcn_s_memtime();
+        if (p.trace && tid == 0) {
+            p.trace[(long)vb * 8 + slot] = __builtin_amdgcn_s_memtime();
+            // (s_memtime counts per XCD: the item's start and end also on the 100-MHz clock all XCDs share, for ramp / tail analysis)
+            if (slot == 0) p.trace[(long)vb * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+            if (slot == 4) p.trace[(long)vb * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+        }
     };
     stamp(0);
     const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.X, p.x_bytes);
