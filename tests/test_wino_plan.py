@@ -1,0 +1,100 @@
+"""Host-side planning of the Winograd family (no device work: eligibility = shape rules AND cost model, workspace = the split plan):
+the choices measured on the GPU (profiles/r05_wino_layers.txt: on every Market layer shape the model picks the faster kernel) are pinned
+here so that a change to the model's constants shows up on the CPU suite."""
+import ctypes
+
+import pytest
+
+MARKET = [  # (name, N, H, W, C): BASELINE configs[1] layer shapes at bs = 16 (ROI tower: 7 parts x 16 images)
+    ("enc0", 16, 128, 64, 128), ("roi b0", 112, 48, 48, 128), ("enc1", 16, 64, 32, 256), ("roi b1", 112, 24, 24, 256),
+    ("enc2", 16, 32, 16, 384), ("roi b2", 112, 12, 12, 384), ("enc3", 16, 16, 8, 512), ("roi b3", 112, 6, 6, 512),
+    ("enc4", 16, 8, 4, 640), ("dec0", 16, 8, 4, 768), ("dec1", 16, 16, 8, 1024), ("dec2", 16, 32, 16, 768),
+    ("dec3", 16, 64, 32, 512), ("dec4", 16, 128, 64, 256)]
+WGRAD_DIRECT = {"enc4", "dec0"}          # 8 x 4 maps: 512 tiles cannot feed the tile-reduction kernel; the direct wgrad is faster (measured)
+
+
+@pytest.fixture(scope="module")
+def H():
+    import __graft_entry__
+    __graft_entry__.build()
+    import dpig_amd.hip_ops as H
+    return H
+
+
+def _desc(H, N, Hh, W, C, K, R=3, stride=1):
+    return H._desc(N, Hh, W, C, K, R, R, stride, C, K)
+
+
+def test_cost_model_choices_on_the_market_layers(H):
+    lib = H.lib()
+    lib.dpig_conv_wino_set_mode(1)
+    for name, N, Hh, W, C in MARKET:
+        d = _desc(H, N, Hh, W, C, C)
+        assert lib.dpig_conv2d_wino_eligible(ctypes.byref(d), 0) == 1, name
+        assert lib.dpig_conv2d_wino_eligible(ctypes.byref(d), 1) == 1, name
+        assert lib.dpig_conv2d_wgrad_wino_eligible(ctypes.byref(d)) == (0 if name in WGRAD_DIRECT else 1), name
+
+
+def test_shapes_without_a_winograd_form_are_refused_in_every_mode(H):
+    lib = H.lib()
+    try:
+        for mode in (1, 2):
+            lib.dpig_conv_wino_set_mode(mode)
+            for d in (_desc(H, 16, 64, 32, 256, 384, stride=2), _desc(H, 16, 64, 32, 256, 256, R=5), _desc(H, 16, 64, 32, 256, 256, R=1),
+                      _desc(H, 16, 63, 32, 256, 256), _desc(H, 16, 64, 32, 96, 256), _desc(H, 16, 64, 32, 256, 32)):
+                assert lib.dpig_conv2d_wino_eligible(ctypes.byref(d), 0) == 0
+                assert lib.dpig_conv2d_wino_eligible(ctypes.byref(d), 1) == 0
+                assert lib.dpig_conv2d_wgrad_wino_eligible(ctypes.byref(d)) == 0
+                assert lib.dpig_conv2d_wino_workspace_bytes(ctypes.byref(d), 0) == 0
+        lib.dpig_conv_wino_set_mode(0)                         # family off: nothing is eligible
+        d = _desc(H, 16, 64, 32, 512, 512)
+        assert lib.dpig_conv2d_wino_eligible(ctypes.byref(d), 0) == 0 and lib.dpig_conv2d_wgrad_wino_eligible(ctypes.byref(d)) == 0
+    finally:
+        lib.dpig_conv_wino_set_mode(1)
+    assert lib.dpig_conv_wino_set_mode(3) != 0 and lib.dpig_conv_wino_set_mode(-1) != 0
+
+
+def test_workspace_sizes_follow_the_split_plans(H):
+    """Forward / dgrad: 0 for layers whose 64-tile x 64-channel grid fills whole rounds of the 256 CUs, else s partial outputs
+    (2 <= s <= 16, every range >= 6 chunks of 8 input channels).  Filter gradient: 2 S slabs of [3][3][C][K] + S rows of [K]."""
+    lib = H.lib()
+    lib.dpig_conv_wino_set_mode(1)
+    for name, N, Hh, W, C in MARKET:
+        d = _desc(H, N, Hh, W, C, C)
+        out_bytes = N * Hh * W * C * 4
+        items = -(-(N * (Hh // 2) * (W // 2)) // 64) * (C // 64)
+        for which in (0, 1):
+            ws = lib.dpig_conv2d_wino_workspace_bytes(ctypes.byref(d), which)
+            assert ws % out_bytes == 0, name
+            s = ws // out_bytes
+            assert s == 0 or (2 <= s <= 16 and (C // 8) // s >= 6), (name, s)
+            if items % 256 == 0:
+                assert s == 0, (name, items)                  # whole rounds already
+            if items < 128:
+                assert s >= 2, (name, items)                  # fewer workgroups than half the chip: the plan splits
+        wsg = lib.dpig_conv2d_wgrad_wino_workspace_bytes(ctypes.byref(d))
+        per_split = (2 * 9 * C * C + C) * 4
+        assert wsg > 0 and wsg % per_split == 0, name
+        S = wsg // per_split
+        chunks = -(-(N * (Hh // 2) * (W // 2)) // 8)
+        assert 1 <= S <= 256 and (S == 1 or chunks // S >= 16), (name, S)
+
+
+def test_filter_job_planning(H):
+    """dpig_wino_filter_jobs_plan: first_block = the running sum of (C / 64)(K / 8); a filter without the form makes the whole plan fail."""
+    lib = H.lib()
+    shapes = [(64, 64), (128, 64), (256, 256), (64, 192)]
+    jobs = (H.WinoFilterJob * len(shapes))()
+    for j, (C, K) in zip(jobs, shapes):
+        j.w, j.u_fwd, j.u_dgrad, j.C, j.K = 4096, 8192, 12288, C, K
+    total = lib.dpig_wino_filter_jobs_plan(ctypes.byref(jobs), len(jobs))
+    blocks = [(C // 64) * (K // 8) for C, K in shapes]
+    assert total == sum(blocks)
+    assert [j.first_block for j in jobs] == [sum(blocks[:i]) for i in range(len(blocks))]
+    jobs[2].C = 96
+    assert lib.dpig_wino_filter_jobs_plan(ctypes.byref(jobs), len(jobs)) == 0
+    jobs[2].C = 256
+    jobs[1].w = None
+    assert lib.dpig_wino_filter_jobs_plan(ctypes.byref(jobs), len(jobs)) == 0
+    assert lib.dpig_wino_filter_jobs_plan(None, 0) == 0
+    assert lib.dpig_wino_filter_transform_jobs(None, 0, 0, None) != 0          # refused before any launch
