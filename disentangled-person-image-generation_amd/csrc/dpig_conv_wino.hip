@@ -606,13 +606,14 @@ __global__ __launch_bounds__(512, 2) void wino_block_kernel(const WParams p) {
 //   B'^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 -1 0 1]   G' = [1 0; 1/2 1/2; 1/2 -1/2; 0 1]   A'^T = [1 1 1 0; 0 1 -1 0; 0 1 1 1]
 // i.e. again 16 position GEMMs  dU_p[c, k] = sum_t V'_p[t, c] Y'_p[t, k]  with the TILES as the reduction axis: 16 multiplies per
 // (tile, c, k) instead of 36.  A workgroup owns a 64 x 64 block of (c, k), all 16 positions (eight waves: 2 position halves x 2 x 2
-// 32 x 32 sub-blocks, 128 accumulator registers each) and a contiguous range of tiles, which it walks in chunks of 8: per chunk every
-// thread loads one row pair of one tile's input patch (8 x 16 bytes) and the tile's 2 x 2 dy pixels (4 x 16 bytes), transforms both in
-// registers and writes 16-byte rows [position][tile][channel] into LDS; the MFMA fragments are 4-byte LDS reads (the reduction index of
-// v_mfma_f32_32x32x2_f32 runs across lanes).  At the end each wave applies A'^T . A' to its own position half in registers and writes
+// 32 x 32 sub-blocks, 128 accumulator registers each) and a contiguous range of tiles, which it walks in chunks of 8: per chunk a wave
+// takes one tile, a thread loads one row of its input patch (4 x 16 bytes; the second row its transform row combines comes from a
+// neighbouring lane by ds_bpermute) and the tile's 2 x 2 dy pixels (4 x 16 bytes), transforms both in registers and writes 16-byte
+// rows [position][tile][channel] into LDS; the MFMA fragments are 4-byte LDS reads (the reduction index of v_mfma_f32_32x32x2_f32 runs
+// across lanes).  At the end each wave applies A'^T . A' to its own position half in registers and writes
 // its nine 32 x 32 tap blocks as ONE of 2 S partial filter gradients [3][3][C][K]; wino_wgrad_reduce_kernel sums them in fixed order
 // (deterministic) into dw (+ beta dw).  The bias gradient db[k] = sum over pixels of dy rides along: the 2 x 2 dy pixels of the tiles
-// partition the map, so the workgroups of channel block 0 add up what their transform threads load anyway (transform row 0's copy)
+// partition the map, so the workgroups of channel block 0 add up what their transform threads load anyway (the lanes of transform row 0 deliver)
 // and leave one [K] partial per split; the reduce kernel sums those in split order too.
 // ================================================================================================
 struct WGParams {
@@ -644,28 +645,25 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WGParams p) {
     const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.X, p.x_bytes);
     const __amdgpu_buffer_rsrc_t rsY = make_rsrc(p.DY, p.y_bytes);
 
-    // ---- transform roles: tile slot tl = (tid / 16) % 8, channel quad cq = tid % 16, transform row xi = wave / 2 ----------------------
-    const int cq = tid & 15, tl = (tid >> 4) & 7, xi = wave >> 1;
-    // B'^T row xi of the patch = A + sgn C:  xi 0: (0, 2) -   xi 1: (1, 2) +   xi 2: (2, 1) -   xi 3: (3, 1) -
+    // ---- transform roles: tile slot tl = wave, channel quad cq = lane % 16, transform row xi = lane / 16 ------------------------------
+    // The loop is short of L1 request bandwidth, not of arithmetic (knock-out builds: without the global loads it runs 302 instead of
+    // 238 TFLOP/s effective on dec3, without a quarter of the LDS fragment reads not a bit faster), so the requests are what is
+    // economised: a thread loads ONE patch row (its own transform row's first operand, 4 pixels) and takes the second operand of
+    // B'^T from the lane that loaded it (ds_bpermute: 16 LDS-crossbar moves, no memory) -- 4 patch loads instead of 8 -- and the
+    // wave's four transform rows ask for the SAME 2 x 2 dy pixels of the wave's one tile, which the texture unit serves as 2 lines
+    // per instruction instead of 8.  Per workgroup and chunk: 64 load instructions / 320 line requests instead of 96 / 768.
+    const int cq = lane & 15, xi = lane >> 4, tl = wave;
+    // B'^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 -1 0 1]: row xi = (own patch row xi) + sgn (patch row 2 for xi < 2, else patch row 1)
     const float sgn = xi == 1 ? 1.f : -1.f;
-    const int rowA = xi == 0 ? 0 : (xi == 1 ? 1 : (xi == 2 ? 2 : 3)), rowC = xi < 2 ? 2 : 1;
+    const int peer = (((xi < 2) ? 2 : 1) * 16 + cq) * 4;            // ds_bpermute address of the lane that holds the other row
     // G' row xi of the 2 x 2 dy = ga y0 + gb y1:  (1, 0), (1/2, 1/2), (1/2, -1/2), (0, 1)
     const float ga = xi == 0 ? 1.f : (xi == 3 ? 0.f : 0.5f), gb = xi == 0 ? 0.f : (xi == 1 ? 0.5f : (xi == 2 ? -0.5f : 1.f));
     const int xcol = (cb * 64 + cq * 4) * 4, ycol = (kb * 64 + cq * 4) * 4;      // byte offsets of this thread's channel quads
-    // Per-chunk addressing, kept cheap (it runs between the MFMAs of every chunk): offsets = one base per operand + per-thread constants;
-    // the base by 24-bit multiplies (full rate; v_mul_lo_u32 / v_mad_u64_u32 are quarter rate and an `ok ? product : OOB` select made the
-    // compiler branch on exec); validity = 2 row tests + 2 column tests.  The stack's pixel row of tile row (n, ty) is n H + 2 ty.
+    // Per-chunk addressing: the wave's tile is wave-uniform (scalar divisions), a lane adds its patch row and channel quad; 24-bit
+    // multiplies (full rate).  The stack's pixel row of tile row (n, ty) is n H + 2 ty.
     const int ldx4 = p.ldx * 4, ldy4 = p.ldy * 4;
     const int rsx = p.W * ldx4, rsy = p.W * ldy4;                   // bytes per pixel row
-    int cx[2][4], cy[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) cx[i][j] = (i == 0 ? rowA : rowC) * rsx + j * ldx4;
-#pragma unroll
-        for (int j = 0; j < 2; ++j) cy[i][j] = i * rsy + j * ldy4;
-    }
-    int xoff[2][4], yoff[2][2];
+    int xoff[4], yoff[2][2];
     auto tile_offsets = [&](int chunk) {                             // offsets of tile 8 chunk + tl (all out of range past the batch)
         const int t = chunk * 8 + tl;
         const bool tok = (chunk < ch1) & (t < p.T);
@@ -675,22 +673,22 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WGParams p) {
         const int ty = fast_div(rem, p.mul_tw, p.shr_tw);
         const int tx = rem - ty * p.TW;
         const int r2 = __mul24(n, p.H) + 2 * ty;
-        const int xb = __mul24(r2 - 1, rsx) + __mul24(2 * tx - 1, ldx4) + xcol;
+        const bool rok = tok && (unsigned)(2 * ty - 1 + xi) < (unsigned)p.H;
+        const int xb = __mul24(r2 - 1 + xi, rsx) + __mul24(2 * tx - 1, ldx4) + xcol;
         const int yb = __mul24(r2, rsy) + __mul24(2 * tx, ldy4) + ycol;
-        const bool rok[2] = {tok && (unsigned)(2 * ty - 1 + rowA) < (unsigned)p.H, tok && (unsigned)(2 * ty - 1 + rowC) < (unsigned)p.H};
-        const bool cok[4] = {tx > 0, true, true, tx < p.TW - 1};
+        xoff[0] = (rok && tx > 0) ? xb : (int)OOB;
+        xoff[1] = rok ? xb + ldx4 : (int)OOB;
+        xoff[2] = rok ? xb + 2 * ldx4 : (int)OOB;
+        xoff[3] = (rok && tx < p.TW - 1) ? xb + 3 * ldx4 : (int)OOB;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 4; ++j) xoff[i][j] = (rok[i] && cok[j]) ? xb + cx[i][j] : (int)OOB;
-#pragma unroll
-            for (int j = 0; j < 2; ++j) yoff[i][j] = tok ? yb + cy[i][j] : (int)OOB;
-        }
+            for (int j = 0; j < 2; ++j) yoff[i][j] = tok ? yb + i * rsy + j * ldy4 : (int)OOB;
     };
-    f32x4 d[2][4], y[2][2];
-    auto loadX = [&](int i) {
+    f32x4 d[4], y[2][2];
+    auto loadX = [&]() {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) d[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, xoff[i][j], 0, 0));
+        for (int j = 0; j < 4; ++j) d[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, xoff[j], 0, 0));
     };
     auto loadY = [&]() {
 #pragma unroll
@@ -701,11 +699,17 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WGParams p) {
     typedef __attribute__((address_space(3))) f32x4 lds_f4;
     const int wr_off = (4 * xi) * PLANE + tl * 256 + cq * 16;        // [position 4 xi + nu][tile tl][channel quad cq]
     f32x4 r[4], ry[2];
-    const bool sum_bias = p.bias_part != nullptr && cb == 0 && xi == 0;      // (wave-uniform)
+    const bool sum_bias = p.bias_part != nullptr && cb == 0;         // (workgroup-uniform; the lanes of transform row 0 deliver the sums)
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     auto rowX = [&]() {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) r[j] = sgn * d[1][j] + d[0][j];
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float own = d[j][e];               // (a named scalar: bit-casting the vector element in place made clang move element 0 four times)
+                const float o = __int_as_float(__builtin_amdgcn_ds_bpermute(peer, __float_as_int(own)));
+                r[j][e] = sgn * o + own;
+            }
     };
     auto colsX = [&](int buf, int pair) {
         lds_char* const base = L + buf * OPB + wr_off;
@@ -746,11 +750,11 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WGParams p) {
 
     // ---- prologue: chunk ch0 staged, chunk ch0 + 1 in registers ------------------------------------------------------------------------
     tile_offsets(ch0);
-    loadX(0); loadX(1); loadY();
+    loadX(); loadY();
     rowX(); colsX(0, 0); colsX(0, 1);
     rowY(); colsY(0, 0); colsY(0, 1);
     tile_offsets(ch0 + 1);
-    loadX(0); loadX(1); loadY();
+    loadX(); loadY();
     __syncthreads();
     for (int c = ch0; c < ch1; ++c) {
         const int buf = (c - ch0) & 1;
@@ -779,7 +783,7 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WGParams p) {
             // loads ran 293 instead of 219 TFLOP/s on dec3 (build/ko/run_wg.sh; an L2 prefetch four chunks ahead changed nothing:
             // the lines were L2-resident already, the other (c, k) blocks of the XCD read them too).
             if (pp == 0) { tile_offsets(c + 2); rowX(); rowY(); }
-            if (pp == 1) { loadX(0); loadX(1); loadY(); }
+            if (pp == 1) { loadX(); loadY(); }
             if (pp == 2) colsX(buf ^ 1, 0);
             if (pp == 3) colsX(buf ^ 1, 1);
             if (pp == 4) colsY(buf ^ 1, 0);
@@ -794,7 +798,7 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WGParams p) {
     // w1 = S1 - S2, w2 = S1 + S2 + S3 splits into  ph 0: (S0 + S1, S1, S1)   ph 1: (S2, -S2, S2 + S3).
     if (p.bias_part != nullptr && cb == 0) {         // (workgroup-uniform) bias partial: 8 tile slots x 16 channel quads -> 64 channels
         typedef __attribute__((address_space(3))) float lds_f;
-        if (xi == 0) *(lds_f4*)(L + tl * 256 + cq * 16) = bsum;
+        if (xi == 0) *(lds_f4*)(L + tl * 256 + cq * 16) = bsum;       // (every lane summed; one transform row's lanes deliver)
         __syncthreads();
         if (tid < 64) {
             float t = 0.f;
