@@ -1098,7 +1098,10 @@ static bool wgrad_pays(const DpigConvDesc* d) {
     const long rounds = (wgs + kNumCU - 1) / kNumCU;
     // ~5800 cycles per 8-tile chunk (4-byte fragment reads) + ~30 k fixed, + the partial slabs' write / read and the reduction launch
     const double wino_cycles = rounds * ((double)pl.cps * 5800.0 + 30000.0) + 2.0 * pl.nsplit * 600.0 + 15000.0;
-    const double direct_cycles = 2.0 * d->N * d->H * d->W * 9.0 * d->C * d->K / 50000.0;
+    // (the direct filter gradient reaches ~115 TFLOP/s = 50 k FLOP per cycle on layers with long pixel reductions, ~0.7 of that below
+    // ~1000 pixels: 8 x 4 C768 runs 75 against this kernel's 88, 8 x 4 C640 88 against 64 -- profiles/r05_wino_layers.txt)
+    const double rate = 50000.0 * ((long)d->N * d->H * d->W < 1024 ? 0.7 : 1.0);
+    const double direct_cycles = 2.0 * d->N * d->H * d->W * 9.0 * d->C * d->K / rate;
     return wino_cycles < 0.95 * direct_cycles;
 }
 

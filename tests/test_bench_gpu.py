@@ -29,6 +29,11 @@ def test_bench_single_gpu_line(dev):
     rf = j["roofline"]
     assert rf["bound"] == "mfma" and rf["unit"] == "TFLOP/s" and 0 < rf["frac"] < 1
     assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    # the headline runs the 3x3 stride-1 convs by Winograd: FLOPs are the EXECUTED ones, the direct-equivalent rate is carried beside them
+    assert "winograd" in j["conv_algorithm"] and "EXECUTED" in rf["flop_basis"]
+    assert abs(rf["frac_direct_equivalent"] - rf["frac"] * 36.0 / 16.0) < 2e-3
+    assert rf["per_kernel_class"]["conv_fwd_wino"]["launches_per_step"] > 0 and rf["per_kernel_class"]["conv_wgrad_wino"]["launches_per_step"] > 0
+    assert rf["traffic"] is None or rf["traffic_over_algorithmic"] > 0.5
 
 
 def test_bench_two_ranks(dev):
