@@ -8,7 +8,7 @@ g_optim on one synthetic batch + d_optim on another, Market-1501 128x64, bs=16 p
 (BASELINE configs[1]); inputs are resident in HBM before the timed region.  Weak scaling: the
 per-GPU batch is fixed, gradients are all-reduced over RCCL each optimizer call.
 
-Prints ONE JSON line on rank 0 with the driver's contract plus
+Prints ONE compact JSON line (< 4 KB, the last line of stdout) on rank 0 with the driver's contract plus
   roofline     -- the dominant kernel (conv forward implicit GEMM), executed FLOPs per launch over its
                   mean launch duration, HIP events on the launch stream, same steps as the timed ones
   cpu_baseline -- the CPU oracle ("port" of the reference graph, torch-CPU fp32) timed on the host
@@ -97,10 +97,9 @@ def cpu_baseline(target_seconds=20.0):
     for _ in range(reps):
         one_step(ob)
     t = time.time() - t0
+    # one oracle step = g_loss fwd+bwd + TF-Adam update, d_loss fwd+bwd + TF-Adam update; threads = physical cores available, capped at 64
     return {"value": round(B * reps / t, 4), "unit": "images/sec", "cores": cores, "kind": "port",
-            "sample": "%d G+D steps of the oracle graph (torch-CPU fp32: g_loss fwd+bwd + TF-Adam update, d_loss fwd+bwd + "
-                      "TF-Adam update) at bs=%d on %d threads (= physical cores available to the process, capped at 64) of %d "
-                      "logical CPUs: %.1f s" % (reps, B, cores, ncpu, t)}
+            "sample": "%d oracle G+D steps (torch-CPU fp32) at bs=%d on %d threads of %d logical CPUs: %.1f s" % (reps, B, cores, ncpu, t)}
 
 
 INFO_RUNS = [   # (key, BASELINE config it informs, bench.py arguments)
@@ -126,6 +125,8 @@ INFO_RUNS = [   # (key, BASELINE config it informs, bench.py arguments)
      ["--workload", "df256-wgan-gp", "--dtype", "bf16", "--steps", "10", "--warmup", "2"]),
     ("df256_wgan_gp_bf16_bs4", "configs[4] at its OWN per-GPU batch: global 32 over 8 GPUs = 4 per GPU (SURVEY 8e) -- half the rows per layer of the "
      "bs=8 line above", ["--workload", "df256-wgan-gp", "--dtype", "bf16", "--batch", "4", "--steps", "10", "--warmup", "2"]),
+    ("market128_bs2_f32", "SURVEY 8(d)'s strong-scaling point: global B=16 over 8 GPUs = 2 images per GPU (small-batch CU fill of the headline graph)",
+     ["--workload", "market128", "--dtype", "f32w", "--batch", "2", "--steps", "20", "--warmup", "5"]),
     ("market128_host_input_f32", "SURVEY 8(f-1): the headline step with both batches starting every step in pinned HOST memory as the records' "
      "keypoints + image + mask + boxes, packed into one buffer, uploaded one step ahead on a copy stream (prefetch.DevicePrefetcher)",
      ["--workload", "market128", "--host-input", "keypoints-packed", "--steps", "20", "--warmup", "5"]),
@@ -137,22 +138,55 @@ INFO_RUNS = [   # (key, BASELINE config it informs, bench.py arguments)
 ]
 
 
+INFO_FILE = os.environ.get("DPIG_BENCH_INFO_FILE", os.path.join("gpurun_out", "bench_info.jsonl"))
+
+
+def csrc_sha():
+    """sha1 over the kernel sources + the C header: what a profiles/roofline_traffic.json entry was measured on."""
+    import glob
+    import hashlib
+    h = hashlib.sha1()
+    pkg = os.path.join(ROOT, "disentangled-person-image-generation_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(pkg, "*.hip")) + glob.glob(os.path.join(pkg, "*.h")) + [os.path.join(ROOT, "include", "dpig_hip.h")]):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:12]
+
+
 def info_lines():
-    """The other BASELINE configurations that fit one GPU, each measured by this same script in a sub-process (fresh
-    parameter registry, same kernels) AFTER the headline's timed region: {key: {value, unit, ms_per_step, config, informs}}."""
+    """The other BASELINE configurations that fit one GPU, each measured by this same script in a sub-process (fresh parameter
+    registry, same kernels) AFTER the headline's timed region.  Every sub-process's full record goes to INFO_FILE (one JSON object per
+    line, with the configuration it informs) and to stderr; the headline object only carries {key: [images/sec, ms/step, roofline.frac]}
+    (round 5 nested the full records and the 36-KB line no longer parsed)."""
     import subprocess
     out = {}
+    path = os.path.join(ROOT, INFO_FILE)
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        fh = open(path, "w")
+    except OSError:
+        fh = None
+    only = [k for k in os.environ.get("DPIG_BENCH_INFO_ONLY", "").split(",") if k]      # (tests: a bounded subset)
     for key, informs, extra in INFO_RUNS:
+        if only and key not in only:
+            continue
         try:
             r = subprocess.run([sys.executable, os.path.abspath(__file__), "--gpus", "1", "--no-info-lines"] + extra,
                                capture_output=True, text=True, timeout=300)
             js = [l for l in r.stdout.splitlines() if l.startswith("{")]
             d = json.loads(js[-1])
-            out[key] = {"value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "dtype": d["dtype"],
-                        "steps": d["steps"], "warmup": d["warmup"], "config": d["config"], "informs": informs,
-                        "input_feed": d.get("input_feed"), "roofline": d.get("roofline")}
+            d["key"], d["informs"] = key, informs
+            out[key] = [d["value"], d["ms_per_step"], (d.get("roofline") or {}).get("frac")]
         except Exception as e:          # an information line must never take the headline down
-            out[key] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+            d = {"key": key, "error": "%s: %s" % (type(e).__name__, str(e)[:200])}
+            out[key] = None
+        txt = json.dumps(d)
+        print("[info] " + txt, file=sys.stderr, flush=True)
+        if fh is not None:
+            fh.write(txt + "\n")
+            fh.flush()
+    if fh is not None:
+        fh.close()
     return out
 
 
@@ -178,7 +212,7 @@ def main():
                          "block -- the exact kernels' own 2e-5 accuracy bar on the bf16 pipe.")
     ap.add_argument("--no-info-lines", action="store_true",
                     help="headline run only: skip the information lines (df256 / stage-II / Market in bf16, Market wgan-gp) that "
-                         "are measured in sub-processes after the headline and embedded under `info_lines`")
+                         "are measured in sub-processes after the headline; full records -> gpurun_out/bench_info.jsonl + stderr, summary under `info`")
     ap.add_argument("--host-input", nargs="?", const="prefetch", default=None, choices=["prefetch", "serial", "keypoints", "keypoints-serial", "keypoints-packed", "packed", "tfrecord"],
                     help="information line: both batches start every step in pinned HOST memory, so the timed region "
                          "includes their PCIe upload (the BASELINE value is quoted with inputs resident in HBM). "
@@ -413,9 +447,9 @@ def main():
             comm = {"allreduce_ms": round(ar_ms, 3), "exposed_ms": round(ms_per_step - local_ms, 3),
                     "ms_per_step_without_exchange": round(local_ms, 3), "bytes_per_step": nbytes,
                     "collectives_per_step": sum(-(-s.numel() // tr.allreduce.bucket) for s in slices),
-                    "wire_dtype": "bf16" if tr.allreduce.compress else "f32",
-                    "note": "allreduce_ms: the step's gradient all-reduces alone on an idle GPU; exposed_ms: timed step minus the "
-                            "same step with the exchange off (what the backward pass did not overlap)"}
+                    "wire_dtype": "bf16" if tr.allreduce.compress else "f32"}
+            # allreduce_ms: the step's gradient all-reduces alone on an idle GPU; exposed_ms: timed step minus the same step with the
+            # exchange off (what the backward pass did not overlap)
         except Exception as e:      # a failure of this extra measurement must not take the bench line down (it is the same on every rank)
             tr.allreduce.enabled = True
             comm = None
@@ -444,13 +478,13 @@ def main():
         H.PROFILE = None
         # dominant kernel class of this configuration: the conv-forward implicit GEMM on the pipe the dtype selects
         dom, peak, kname, fmul = {
-            "f32": ("conv_fwd_mfma", PEAK_F32_MFMA_TFLOPS, "dpig::gather_gemm_kernel<false, true, false, 0> (conv fwd implicit GEMM, fp32 MFMA)", 1.0),
-            "bf16": ("conv_fwd_bf16", PEAK_BF16_MFMA_TFLOPS, "dpig::bhq_kernel / bhq32_kernel / bq_kernel / bh_kernel / bg8_kernel (conv fwd implicit GEMM on bf16 tensors, v_mfma_f32_32x32x16_bf16)", 1.0),
+            "f32": ("conv_fwd_mfma", PEAK_F32_MFMA_TFLOPS, "dpig::gather_gemm_kernel<false,true,false,0> (conv fwd implicit GEMM, v_mfma_f32_32x32x2_f32)", 1.0),
+            "bf16": ("conv_fwd_bf16", PEAK_BF16_MFMA_TFLOPS, "dpig::bfk::{bhq,bhq32,bq,bh,bg8,sk}_kernel (conv fwd implicit GEMM on bf16 tensors, v_mfma_f32_32x32x16_bf16)", 1.0),
             "bf16c": ("conv_fwd_mfma", PEAK_BF16_MFMA_TFLOPS, "conv fwd implicit GEMM, fp32 tensors rounded to bf16 on the way into LDS", 1.0),
-            "bf16x3": ("conv_fwd_mfma", PEAK_BF16_MFMA_TFLOPS, "conv fwd implicit GEMM, fp32 tensors as two-term bf16 splits: 3 bf16 MFMAs per product "
-                       "block (executed FLOPs = 3 x algorithmic)", 3.0),
-            "f32w": ("conv_fwd_wino", PEAK_F32_MFMA_TFLOPS, "dpig::wino::wino_block_kernel / wino_kernel (3x3 stride-1 conv fwd as Winograd F(2x2,3x3): 16 position GEMMs on "
-                     "v_mfma_f32_32x32x2_f32, transforms fused; FLOPs = the 16/36 of the direct count that are executed)", 1.0),
+            # fp32 tensors as two-term bf16 splits: 3 bf16 MFMAs per product block (executed FLOPs = 3 x algorithmic)
+            "bf16x3": ("conv_fwd_mfma", PEAK_BF16_MFMA_TFLOPS, "conv fwd implicit GEMM, two-term bf16 splits of fp32 operands (3 MFMAs per product block)", 3.0),
+            # 3x3 stride-1 conv fwd as Winograd F(2x2,3x3): 16 position GEMMs, transforms fused; FLOPs = the executed 16/36 of the direct count
+            "f32w": ("conv_fwd_wino", PEAK_F32_MFMA_TFLOPS, "dpig::wino::wino_block_kernel / wino_kernel (Winograd F(2x2,3x3) conv fwd, v_mfma_f32_32x32x2_f32)", 1.0),
         }[args.dtype]
         fwd = [(f, t) for (k, f, t) in recs if k == dom]
         nl = max(len(fwd), 1)
@@ -466,72 +500,87 @@ def main():
         alg_bytes = alg_bytes_of((dom,))
         # HBM bytes per launch of that kernel class from the FETCH_SIZE / WRITE_SIZE passes of THIS command under rocprofv3
         # (scripts/pmc_traffic.sh -> profiles/roofline_traffic.json; separate --pmc passes, FETCH_SIZE doubled per the guide's gfx950 note)
-        traffic, traffic_src = None, None
+        traffic, traffic_head, traffic_stale = None, None, None
         tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
         if os.path.exists(tpath):
             try:
                 ent = json.load(open(tpath)).get("entries", {}).get("%s/%s" % (args.workload, args.dtype))
                 if ent and B == wl_batch:
-                    traffic = ent.get("hbm_bytes_per_launch")
-                    alg_bytes = alg_bytes_of(tuple(ent.get("classes", [dom])))      # (the bf16 kernels serve forward AND dgrad launches)
-                    traffic_src = ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at %s (%s), averaged over the launches of %s "
-                                   "[classes %s]; a per-round static figure, not re-measured inside this run"
-                                   % (ent.get("head", "?"), ent.get("source"), ", ".join(ent.get("kernels", [])), "+".join(ent.get("classes", []))))
+                    traffic_head = ent.get("head")
+                    # a figure measured on other kernel sources than the ones this run executes is not "this run": report null
+                    traffic_stale = ent.get("csrc_sha") != csrc_sha()
+                    if not traffic_stale:
+                        traffic = ent.get("hbm_bytes_per_launch")
+                        alg_bytes = alg_bytes_of(tuple(ent.get("classes", [dom])))      # (the bf16 kernels serve forward AND dgrad launches)
             except Exception:
                 traffic = None
         roofline = {"bound": "mfma", "kernel": kname,
                     "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_source": traffic_src,
-                    "achieved_direct_equivalent": round(achieved * 36.0 / 16.0, 2) if args.dtype == "f32w" else None,
-                    "frac_direct_equivalent": round(achieved * 36.0 / 16.0 / peak, 4) if args.dtype == "f32w" else None,
-                    "flop_basis": ("EXECUTED multiplies of the Winograd form: 16 per (2x2 tile, ci, co) = 16/36 of the direct conv's; "
-                                   "achieved_direct_equivalent prices the same launches at the direct count") if args.dtype == "f32w" else "executed = direct",
+                    "frac": round(achieved / peak, 4), "traffic": traffic, "traffic_head": traffic_head, "traffic_stale": traffic_stale,
                     "algorithmic_bytes_per_launch": int(alg_bytes),
                     "traffic_over_algorithmic": round(traffic / alg_bytes, 2) if (traffic and alg_bytes) else None,
                     "launches_per_step": len(fwd) // nrep,
-                    "flops_per_launch": flops / nl, "avg_launch_us": round(secs / nl * 1e6, 2),
+                    "flops_per_launch": round(flops / nl), "avg_launch_us": round(secs / nl * 1e6, 2),
                     "time_share_of_step": round(secs / nrep / (ms_per_step * 1e-3), 3),
-                    "timing": "HIP events around every launch of an eager replay of the same step on ONE stream (each launch alone on "
-                              "the GPU); the timed steps overlap the encoder's two towers, and the critic's real-image pass with the generator forward, on side streams"}
+                    "flop_basis": "executed (16/36 of direct)" if args.dtype == "f32w" else "executed = direct"}
+        if args.dtype == "f32w":
+            roofline["achieved_direct_equivalent"] = round(achieved * 36.0 / 16.0, 2)
+            roofline["frac_direct_equivalent"] = round(achieved * 36.0 / 16.0 / peak, 4)
         by = {}
         for k, f, t in recs:
             a = by.setdefault(k, [0, 0.0, 0.0])
             a[0] += 1; a[1] += f; a[2] += t
-        roofline["per_kernel_class"] = {k: {"launches_per_step": v[0] // nrep, "ms_per_step": round(v[2] / nrep * 1e3, 3),
-                                            "tflops": round(v[1] / v[2] / 1e12, 2) if v[2] > 0 and v[1] > 0 else None}
+        roofline["per_kernel_class_fields"] = "launches/step, ms/step, TFLOP/s"
+        roofline["per_kernel_class"] = {k: [v[0] // nrep, round(v[2] / nrep * 1e3, 3), round(v[1] / v[2] / 1e12, 1) if v[2] > 0 and v[1] > 0 else None]
                                         for k, v in sorted(by.items())}
+        # whole-step matrix-pipe utilisation on executed FLOPs: every FLOP-carrying launch of the step over the timed step
+        tot_flops = sum(v[1] for v in by.values()) * fmul / nrep
+        roofline["step_executed_tflop"] = round(tot_flops / 1e12, 3)
+        roofline["step_frac"] = round(tot_flops / (ms_per_step * 1e-3) / 1e12 / peak, 4)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         cpu = cpu_baseline()
 
-    POSE_DESC = ("pose input: keypoints (pose_rcv as the records hold them; the generator's first conv consumes them, no [B,H,W,18] map)"
-                 if "pose" not in batch_g else "pose input: rasterised target map resident in HBM")
+    MODE_DESC = {"f32": "fp32 direct", "f32w": "fp32, Winograd on 3x3 s1 where the cost model picks it", "bf16": "bf16 storage + bf16 MFMA, fp32 accumulate/master/optimizer",
+                 "bf16c": "fp32 tensors, bf16 MFMA", "bf16x3": "fp32 tensors, split-bf16 products"}[args.dtype]
+    rccl_ranks_seen = None
+    if world > 1:
+        # what the collective library actually connected: every rank contributes one bit, summed by a real all-reduce on the device
+        t = torch.zeros(world, dtype=torch.float32, device=dev)
+        t[rank] = 1.0
+        dist.all_reduce(t)
+        rccl_ranks_seen = int((t > 0.5).sum().item())
     if rank == 0:
         line = {
             "metric": "training images/sec (G+D step) Market-1501 128x64 bs=16" if headline else
-                      ("generated images/sec (%s, %s%s) [information line, not the BASELINE metric]" if sampling else
-                       "training images/sec (%s, %s%s) [information line, not the BASELINE metric]") % (
-                          args.workload, args.dtype, ", inputs uploaded over PCIe every step (%s)" % args.host_input if args.host_input else ""),
+                      ("generated images/sec (%s, %s%s) [information line]" if sampling else "training images/sec (%s, %s%s) [information line]") % (
+                          args.workload, args.dtype, ", host input %s" % args.host_input if args.host_input else ""),
             "value": round(value, 2), "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.dtype == "f32w" else args.dtype, "data": "synthetic",
-            "conv_algorithm": "winograd F(2x2,3x3) / F(3x3,2x2) for 3x3 stride-1 layers where it pays, direct implicit GEMM elsewhere" if args.dtype == "f32w" else "direct implicit GEMM",
-            "config": {"workload": "%s, bs=%d per GPU, %s; %s" % (wl_desc, B, {"f32": "fp32", "f32w": "fp32 (tensors, products, accumulation); 3x3 stride-1 convs (forward, dgrad, filter gradient) by Winograd F(2x2,3x3) / F(3x3,2x2) where the cost model says it pays", "bf16": "bf16 storage (activations, their gradients, filter shadows) + bf16 matrix pipe; fp32 accumulation, master weights, gradients and optimizer", "bf16c": "bf16 matrix pipe on fp32 tensors", "bf16x3": "fp32 tensors; conv products as three bf16 MFMAs on two-term bf16 splits of the fp32 operands (<= 2e-5 max|ref| per kernel, the exact path's test bar); everything else fp32"}[args.dtype], POSE_DESC),
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.dtype == "f32w" else args.dtype, "compute_mode": args.dtype, "data": "synthetic",
+            "conv_algorithm": "winograd F(2x2,3x3)/F(3x3,2x2) on 3x3 s1 + direct implicit GEMM" if args.dtype == "f32w" else "direct implicit GEMM",
+            "config": {"workload": "%s bs=%d/GPU (%s; pose as %s)" % (args.workload, B, MODE_DESC, "map" if "pose" in batch_g else "keypoints"),
                        "global_batch": world * B, "parallelism": "dp%d" % world},
             "achieved_alg_tflops": round(ALG_GFLOP_PER_IMG * value / 1e3, 2) if headline else None,
-            "losses": {k: float(v) for k, v in out.items() if hasattr(v, "numel") and v.numel() == 1 and not sampling},
+            "losses": {k: round(float(v), 5) for k, v in out.items() if hasattr(v, "numel") and v.numel() == 1 and not sampling},
             "input_feed": ("host:%s" % args.host_input) if args.host_input else ("copy" if (args.copy_input or args.no_graph) else "static"),
             "roofline": roofline, "cpu_baseline": cpu,
             "build_mode": __graft_entry__.BUILD_MODE,      # "compiled": this process rebuilt the library; "reused": the shipped .so was fresh
         }
+        if world > 1:
+            line["rccl_ranks_seen"] = rccl_ranks_seen
+            line["dist_backend"] = dist.get_backend()
         if comm is not None:
             line["allreduce_ms"], line["exposed_ms"], line["comm"] = comm["allreduce_ms"], comm["exposed_ms"], comm
         elif comm_error is not None:
             line["comm"] = {"error": comm_error}
         if headline and world == 1 and not args.no_info_lines:
-            line["info_lines"] = info_lines()
-        print(json.dumps(line), flush=True)
+            line["info_fields"] = "images/sec, ms/step, roofline.frac"
+            line["info"] = info_lines()
+            line["info_file"] = INFO_FILE
+        # ONE compact line, the last of stdout (the driver stores a bounded tail and parses the last line)
+        print(json.dumps(line, separators=(",", ":")), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

@@ -69,6 +69,7 @@ SYMBOLS = {
     "dpig_wino_filter_transform_jobs": (_i, [_vp, _i, _i, _vp]),
     "dpig_conv2d_wino_eligible": (_i, [_dp, _i]),
     "dpig_conv_wino_set_mode": (_i, [_i]),
+    "dpig_conv_wino_get_mode": (_i, []),
     "dpig_conv2d_wino_workspace_bytes": (_sz, [_dp, _i]),
     "dpig_conv2d_fwd_wino": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dpig_conv2d_dgrad_wino": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),

@@ -25,7 +25,8 @@
 //     row-contiguous epilogue (bias, activation, residual before / after the activation with the second output, dgrad's
 //     (. + accum) * act'(mask)).
 // dgrad of a 3 x 3 stride-1 SAME conv is the same conv with the filter rotated by 180 degrees and its channel roles swapped: the
-// same kernel on a second transformed image (U' from w[2-r][2-s][c][k] read as [k][c]).  wgrad stays on the direct kernels.
+// same kernel on a second transformed image (U' from w[2-r][2-s][c][k] read as [k][c]).  The filter gradient has its own kernel further
+// down, wino_wgrad_kernel = F(3x3, 2x2) with the tiles as reduction axis (dpig_conv2d_wgrad_wino; own eligibility + cost model).
 //
 // LDS image of one chunk of one operand (V or U): [position 16][row 64][8 floats]; row = tile (V) or output channel (U); the two
 // 16-byte halves of a row are swapped when (row >> 3) & 1 so that the 16-lane groups of ds_read_b128 cover all 64 banks.  Within a
@@ -1087,6 +1088,9 @@ static bool wgrad_shape_ok(const DpigConvDesc* d) {
     if (d->pad_t >= 0 && d->pad_t != 1) return false;
     if (d->pad_l >= 0 && d->pad_l != 1) return false;
     const long lim = 0x7f000000L;
+    // wino_wgrad_kernel forms its byte offsets with 24-bit multiplies (__mul24): a row pitch or a row count of 2^23 or more would wrap silently
+    const long m24 = 1L << 23;
+    if ((long)d->W * d->ldx * 4 >= m24 || (long)d->W * d->ldy * 4 >= m24 || (long)d->N * d->H >= m24) return false;
     return (long)d->N * d->H * d->W * d->ldx * 4 < lim && (long)d->N * d->H * d->W * d->ldy * 4 < lim;
 }
 static bool wgrad_pays(const DpigConvDesc* d) {
@@ -1219,6 +1223,11 @@ extern "C" int dpig_conv_wino_set_mode(int mode) {
     if (mode < 0 || mode > 2) return fail(DPIG_EINVAL, "winograd mode out of range");
     wino::g_mode = mode;
     return DPIG_OK;
+}
+
+extern "C" int dpig_conv_wino_get_mode(void) {
+    wino::init_mode();
+    return wino::g_mode;
 }
 
 // y = act(conv3x3_SAME(x, w) + bias + residual)  (or act(..) + residual with res_after_act, y_act receiving the activation) through

@@ -12,9 +12,11 @@ Arithmetic modes (`set_compute`):
            Ops whose kernels exist in fp32 only (thin 3-channel convs, norms, FC layers, crops) convert at their
            boundary (`to_f32` / `to_bf16` kernels); a tensor is stored as bf16 iff its channel count is a multiple of 8;
   'bf16c'  round 1's intermediate mode: fp32 tensors, conv operands rounded to bf16 on their way into LDS;
-  'f32w'   'f32' with the 3x3 stride-1 convs evaluated by Winograd's F(2x2,3x3) minimal filtering on the fp32 matrix pipe
-           (csrc/dpig_conv_wino.hip: fp32 tensors, fp32 products, fp32 accumulation, 2.25x fewer multiplies; forward and dgrad
-           where the library's cost model says it pays, everything else -- and every filter gradient -- on the 'f32' kernels);
+  'f32w'   'f32' with the 3x3 stride-1 convs evaluated by Winograd minimal filtering on the fp32 matrix pipe
+           (csrc/dpig_conv_wino.hip: fp32 tensors, fp32 products, fp32 accumulation, 2.25x fewer multiplies): forward and dgrad by
+           F(2x2,3x3), the filter gradient by F(3x3,2x2) (`conv2d_wgrad` -> dpig_conv2d_wgrad_wino), each where the layer has the form
+           (3x3, stride 1, even H and W, C and K multiples of 64) AND the library's cost model says it pays; everything else on the
+           'f32' kernels.  bench.py's headline mode since round 5;
   'bf16x3' fp32 tensors, fp32 accuracy class on the bf16 pipe: conv operands are split into two bf16 terms on their way
            into LDS and every product block is three bf16 MFMAs (DPIG_COMPUTE_BF16X3, include/dpig_hip.h).  An opt-in
            mode, held to the exact path's kernel bar (2e-5 max|ref|); 'f32' stays the exact-products default.
@@ -195,6 +197,23 @@ def filter_shadows(w, want_plain=True, want_t=True):
     return plain, trans
 
 
+# Every live owner of images DERIVED from fp32 master filters (bf16 shadows, split shadows, Winograd images).  Anything that writes
+# parameter values outside the optimizers (tfckpt.restore, tester loading into a live trainer) calls refresh_all_derived(): the
+# kernels of 'bf16' / 'bf16x3' / 'f32w' read the images, not the masters.
+import weakref
+_DERIVED = weakref.WeakSet()
+
+
+def refresh_all_derived():
+    """Re-derive every registered image set from its masters.  Returns how many sets were refreshed."""
+    n = 0
+    for o in list(_DERIVED):
+        if getattr(o, "params", None):
+            o.refresh()
+            n += 1
+    return n
+
+
 class FilterShadows(object):
     """Persistent bf16 shadows (plain HWIO + per-tap transposed) of every conv filter in `params` that the bf16 kernels
     accept, in ONE allocation; attached to the parameters as `_dpig_shadow`.  `refresh()` re-derives them from the fp32
@@ -237,6 +256,7 @@ class FilterShadows(object):
         if flat is not None:
             self.flat, self.ntiles = flat, tiles
             self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
+        _DERIVED.add(self)
         self.refresh()
 
     def refresh(self):
@@ -323,6 +343,7 @@ class WinoFilters(object):
             raise RuntimeError("dpig_wino_filter_jobs_plan refused the filter set")
         self.masters = [p.data.data_ptr() for p in self.params]
         self.jobs = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(self.params[0].device)
+        _DERIVED.add(self)
         self.refresh()
 
     def refresh(self):
@@ -342,9 +363,17 @@ class WinoFilters(object):
                 delattr(p, "_dpig_wino")
 
 
+def get_wino_mode():
+    """dpig_conv_wino_get_mode: the mode in force (DPIG_WINO in the environment unless set_wino_mode changed it)."""
+    return int(lib().dpig_conv_wino_get_mode())
+
+
 def set_wino_mode(mode):
-    """dpig_conv_wino_set_mode: 0 never, 1 the library's cost model (default), 2 wherever the layer has a Winograd form (tests)."""
+    """dpig_conv_wino_set_mode: 0 never, 1 the library's cost model (default), 2 wherever the layer has a Winograd form (tests).
+    Returns the PREVIOUS mode, so that callers restore what was in force (e.g. a process started with the DPIG_WINO=0 kill switch)."""
+    prev = get_wino_mode()
     check(lib().dpig_conv_wino_set_mode(int(mode)), "conv_wino_set_mode")
+    return prev
 
 
 def _bf16_conv_ok(C, K, *lds):

@@ -380,6 +380,11 @@ def restore(prefix, scopes=None, strict=True, verify=True):
             p = lib._params[n]
             v = np.array(values[key[n]], dtype=np.float32, order="C")
             p.data.copy_(torch.from_numpy(v.reshape(-1)).to(p.device).reshape(p.shape))
+    if names and any(lib._params[n].is_cuda for n in names):
+        # the 'bf16' / 'bf16x3' / 'f32w' kernels read images DERIVED from the masters (bf16 shadows, Winograd images): a restore into a
+        # live trainer must re-derive them, or forward / dgrad would run on the filters from before the restore
+        from . import hip_ops
+        hip_ops.refresh_all_derived()
     return names
 
 

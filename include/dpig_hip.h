@@ -199,6 +199,7 @@ int dpig_wino_filter_jobs_plan(DpigWinoFilterJob* jobs, int njobs);
 int dpig_wino_filter_transform_jobs(const DpigWinoFilterJob* jobs_dev, int njobs, int total_blocks, void* stream);
 int dpig_conv2d_wino_eligible(const DpigConvDesc* d, int which);
 int dpig_conv_wino_set_mode(int mode);
+int dpig_conv_wino_get_mode(void);        /* the mode in force: DPIG_WINO from the environment (default 1) until _set_mode changes it */
 size_t dpig_conv2d_wino_workspace_bytes(const DpigConvDesc* d, int which);
 int dpig_conv2d_fwd_wino(const DpigConvDesc* d, const float* x, const float* u_fwd, const float* bias, const float* residual,
                          float* y, float* y_act, void* ws, size_t ws_bytes, void* stream);

@@ -26,9 +26,9 @@ def _close(got, ref, tol=2e-5):
 def wino():
     import dpig_amd.hip_ops as H
     H.set_compute("f32w")
-    H.set_wino_mode(2)                  # wherever legal: the cost model would keep these small layers on the direct kernel
+    prev = H.set_wino_mode(2)           # wherever legal: the cost model would keep these small layers on the direct kernel
     yield H
-    H.set_wino_mode(1)
+    H.set_wino_mode(prev)
     H.set_compute("f32")
 
 
@@ -262,7 +262,7 @@ def test_stage1_step_in_winograd_mode_equals_the_exact_mode(dev):
     from dpig_amd import slim, synthetic
     from dpig_amd.trainer import Config, DPIG_Encoder_GAN_BodyROI_FgBg
     res = {}
-    H.set_wino_mode(2)
+    prev_wino = H.set_wino_mode(2)
     try:
         for mode in ("f32", "f32w"):
             lib.delete_all_params(); slim.reset_scopes()
@@ -297,6 +297,6 @@ def test_stage1_step_in_winograd_mode_equals_the_exact_mode(dev):
         assert Gd <= 1e-4 * res["f32"][1].abs().max().item(), Gd
     finally:
         H.PROFILE = None
-        H.set_wino_mode(1)
+        H.set_wino_mode(prev_wino)
         H.set_compute("f32")
         lib.delete_all_params(); slim.reset_scopes()

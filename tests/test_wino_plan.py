@@ -54,6 +54,27 @@ def test_shapes_without_a_winograd_form_are_refused_in_every_mode(H):
     assert lib.dpig_conv_wino_set_mode(3) != 0 and lib.dpig_conv_wino_set_mode(-1) != 0
 
 
+def test_wgrad_refuses_shapes_beyond_its_24_bit_offset_arithmetic(H):
+    """wino_wgrad_kernel forms byte offsets with 24-bit multiplies: a row pitch W * ld * 4 or a row count N * H of 2^23 or more passes the
+    total-bytes bound but would address wrongly -- the eligibility test (and the entry point) refuse it.  Forward / dgrad use full
+    32-bit multiplies and keep accepting the same descriptor."""
+    lib = H.lib()
+    prev = lib.dpig_conv_wino_get_mode()
+    try:
+        lib.dpig_conv_wino_set_mode(2)
+        ok = H._desc(1, 2, 1024, 64, 64, 3, 3, 1, 1024, 64)          # pitch 1024 * 1024 * 4 = 2^22
+        assert lib.dpig_conv2d_wgrad_wino_eligible(ctypes.byref(ok)) == 1
+        wide_x = H._desc(1, 2, 1024, 64, 64, 3, 3, 1, 2048, 64)      # x pitch 2^23
+        wide_y = H._desc(1, 2, 1024, 64, 64, 3, 3, 1, 64, 2048)      # dy pitch 2^23
+        for d in (wide_x, wide_y):
+            assert lib.dpig_conv2d_wgrad_wino_eligible(ctypes.byref(d)) == 0
+            assert lib.dpig_conv2d_wgrad_wino_workspace_bytes(ctypes.byref(d)) == 0
+        assert lib.dpig_conv2d_wino_eligible(ctypes.byref(wide_x), 0) == 1
+    finally:
+        lib.dpig_conv_wino_set_mode(prev)
+    assert lib.dpig_conv_wino_get_mode() == prev
+
+
 def test_workspace_sizes_follow_the_split_plans(H):
     """Forward / dgrad: 0 for layers whose 64-tile x 64-channel grid fills whole rounds of the 256 CUs, else s partial outputs
     (2 <= s <= 16, every range >= 6 chunks of 8 input channels).  Filter gradient: 2 S slabs of [3][3][C][K] + S rows of [K]."""
