@@ -15,7 +15,8 @@
 //                    that consumes memory it was told to overwrite (beta = 0 first-touch contracts) shows up as NaN; unset = no fill
 //   DPIG_GUARD_LOG   1 = one line per allocation on stderr
 //
-// Frees synchronise the device first (an unmap under a running kernel would itself fault).  Build: __graft_entry__.build_guard().
+// Frees synchronise the device first (an unmap under a running kernel would itself fault) and keep the address range reserved
+// (never reused: use-after-free faults too).  Build: __graft_entry__.build_guard().
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -107,7 +108,10 @@ extern "C" void dpig_guard_free(void* ptr, ssize_t size, int device, hipStream_t
     char* lo = (char*)r.base + g_gran;
     GCHECK(hipMemUnmap(lo, r.mapped));
     GCHECK(hipMemRelease(r.handle));
-    GCHECK(hipMemAddressFree(r.base, r.reserved));
+    // The address range is deliberately NOT returned (no hipMemAddressFree): on this stack (ROCm 7.2, gfx950) a range that is freed and
+    // handed out again by a later hipMemAddressReserve reads and writes wrong data (scripts/ubench/vmm_probe.cpp: 34-40 of 40 rounds
+    // wrong with the address free, 0 of 40 without it).  A 48-bit address space does not run out in a test process, and a side effect
+    // worth having: a freed tensor's addresses stay unmapped for good, so a kernel launched with a stale pointer faults as well.
 }
 
 extern "C" long dpig_guard_live_bytes() { return g_bytes; }

@@ -37,6 +37,9 @@ def _worker(rank, world, port, q, exchange, backend="gloo"):
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     sys.path.insert(0, ROOT)
+    if os.environ.get("DPIG_GUARD") in ("hi", "lo"):      # guard-page run of the suite (tests/conftest.py): the ranks' allocations too
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import conftest  # noqa: F401  (installs the allocator at import)
     ordinal = rank if backend == "nccl" else 0           # RCCL needs one device per rank; gloo ranks share cuda:0
     torch.cuda.set_device(ordinal)
     dist.init_process_group(backend, rank=rank, world_size=world)

@@ -28,6 +28,9 @@ def _setup(rank, world, port):
     os.environ["MASTER_PORT"] = str(port)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     sys.path.insert(0, ROOT)
+    if os.environ.get("DPIG_GUARD") in ("hi", "lo"):      # guard-page run of the suite (tests/conftest.py): the ranks' allocations too
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import conftest  # noqa: F401  (installs the allocator at import)
     torch.cuda.set_device(0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
 
