@@ -500,7 +500,7 @@ def main():
         alg_bytes = alg_bytes_of((dom,))
         # HBM bytes per launch of that kernel class from the FETCH_SIZE / WRITE_SIZE passes of THIS command under rocprofv3
         # (scripts/pmc_traffic.sh -> profiles/roofline_traffic.json; separate --pmc passes, FETCH_SIZE doubled per the guide's gfx950 note)
-        traffic, traffic_head, traffic_stale = None, None, None
+        traffic, traffic_head, traffic_stale, wg_traffic, wg_alg = None, None, None, None, None
         tpath = os.path.join(ROOT, "profiles", "roofline_traffic.json")
         if os.path.exists(tpath):
             try:
@@ -512,6 +512,9 @@ def main():
                     if not traffic_stale:
                         traffic = ent.get("hbm_bytes_per_launch")
                         alg_bytes = alg_bytes_of(tuple(ent.get("classes", [dom])))      # (the bf16 kernels serve forward AND dgrad launches)
+                        if ent.get("wgrad"):          # the Winograd filter-gradient class beside it: x + dy + the [3][3][C][K] gradient once
+                            wg_traffic = ent["wgrad"].get("hbm_bytes_per_launch")
+                            wg_alg = alg_bytes_of(tuple(ent["wgrad"].get("classes", ["conv_wgrad_wino"])))
             except Exception:
                 traffic = None
         roofline = {"bound": "mfma", "kernel": kname,
@@ -523,6 +526,8 @@ def main():
                     "flops_per_launch": round(flops / nl), "avg_launch_us": round(secs / nl * 1e6, 2),
                     "time_share_of_step": round(secs / nrep / (ms_per_step * 1e-3), 3),
                     "flop_basis": "executed (16/36 of direct)" if args.dtype == "f32w" else "executed = direct"}
+        if wg_traffic:
+            roofline["wgrad_traffic"], roofline["wgrad_algorithmic_bytes_per_launch"] = wg_traffic, int(wg_alg)
         if args.dtype == "f32w":
             roofline["achieved_direct_equivalent"] = round(achieved * 36.0 / 16.0, 2)
             roofline["frac_direct_equivalent"] = round(achieved * 36.0 / 16.0 / peak, 4)

@@ -53,8 +53,19 @@ if "entries" not in js:
     js = {"entries": {}}
 if sel:
     nl = sum(r[1] for r in sel)
-    head = os.popen("git -C %s rev-parse --short HEAD 2>/dev/null" % root).read().strip() or os.environ.get("DPIG_HEAD", "?")
-    js["entries"][key] = {"hbm_bytes_per_launch": round(sum(r[1] * r[5] for r in sel) / nl), "launches": nl, "classes": classes,
-                          "kernels": sorted(set(short(r[0]) for r in sel)), "source": "profiles/%s_pmc_traffic.md" % tag, "head": head}
+    head = os.environ.get("DPIG_HEAD") or os.popen("git -C %s rev-parse --short HEAD 2>/dev/null" % root).read().strip() or "?"
+    # the kernel sources this figure was measured on: bench.py reports the entry only while csrc/ hashes to the same value
+    sys.path.insert(0, root)
+    import bench as _bench
+    ent = {"hbm_bytes_per_launch": round(sum(r[1] * r[5] for r in sel) / nl), "launches": nl, "classes": classes,
+           "kernels": sorted(set(short(r[0]) for r in sel)), "source": "profiles/%s_pmc_traffic.md" % tag, "head": head,
+           "csrc_sha": _bench.csrc_sha()}
+    if dtype == "f32w":           # the Winograd filter gradient beside the forward / dgrad class
+        wg = [r for r in rows if base(r[0]) == "wino_wgrad_kernel"]
+        if wg:
+            nw = sum(r[1] for r in wg)
+            ent["wgrad"] = {"hbm_bytes_per_launch": round(sum(r[1] * r[5] for r in wg) / nw), "launches": nw, "classes": ["conv_wgrad_wino"],
+                            "kernels": ["dpig::wino::wino_wgrad_kernel"]}
+    js["entries"][key] = ent
     json.dump(js, open(path, "w"), indent=1)
 print(key, js["entries"].get(key))

@@ -5,6 +5,8 @@
 #
 #   bash scripts/run_scale.sh            # curve + sweeps (~15 min on an 8-GPU node)
 #   bash scripts/run_scale.sh curve      # the 1/2/4/8 curve only (fp32 headline + Market bf16)
+#   bash scripts/run_scale.sh --dry      # rehearsal on ONE GPU: every branch of this script with N clamped to 2 ranks sharing the device
+#                                        # over gloo, 2 steps each -- so that a typo does not burn the node's minutes
 #
 # What to read in each line: value (whole-job img/s), ms_per_step, allreduce_ms (the step's gradient slices all-reduced back to back on
 # an idle GPU), exposed_ms (timed step minus the same step with the exchange off = what the staged backward did not hide), comm{}.
@@ -12,14 +14,18 @@
 set -u
 R=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd "$R"
-OUT=gpurun_out/scale; mkdir -p $OUT
+DRY=0; if [ "${1:-}" = "--dry" ]; then DRY=1; shift; fi
+OUT=gpurun_out/scale; [ $DRY -eq 1 ] && OUT=gpurun_out/scale_dry; mkdir -p $OUT
 export HSA_ENABLE_IPC_MODE_LEGACY=0            # dmabuf IPC: without it RCCL fails with hipIpcGetMemHandle: invalid argument on this driver
 NGPU=$(python -c "import torch; print(torch.cuda.device_count())")
 STEPS=${STEPS:-30}; WARM=${WARM:-5}; PORT=29540
+if [ $DRY -eq 1 ]; then STEPS=2; WARM=1; export DPIG_DIST_BACKEND=gloo; fi     # (gloo: the ranks share the one device; RCCL needs one device per rank)
 run() {   # run <tag> <ngpus> [env assignments ...] -- [bench args ...]
   local tag=$1 n=$2; shift 2
   local envs=(); while [ "$#" -gt 0 ] && [ "$1" != "--" ]; do envs+=("$1"); shift; done; [ "$#" -gt 0 ] && shift
-  if [ "$n" -gt "$NGPU" ]; then echo "skip $tag: needs $n GPUs, node has $NGPU"; return; fi
+  local want=$n
+  if [ $DRY -eq 1 ] && [ "$n" -gt 2 ]; then n=2; fi
+  if [ $DRY -eq 0 ] && [ "$n" -gt "$NGPU" ]; then echo "skip $tag: needs $n GPUs, node has $NGPU"; return; fi
   PORT=$((PORT + 1))
   echo "== $tag: N=$n ${envs[*]:-} $*"
   if [ "$n" -eq 1 ]; then
@@ -32,7 +38,11 @@ run() {   # run <tag> <ngpus> [env assignments ...] -- [bench args ...]
 import json, sys
 try:
     d = json.load(open(sys.argv[1]))
-    print("   %s: %.1f img/s, %.2f ms/step, allreduce %s ms, exposed %s ms" % (sys.argv[2], d["value"], d["ms_per_step"], d.get("allreduce_ms"), d.get("exposed_ms")))
+    seen = d.get("rccl_ranks_seen")
+    # the collective library's own count of the ranks (a device all-reduce of one-hot rows, bench.py) must be the N that was launched
+    flag = "" if (d["n_gpus"] == 1 or seen == d["n_gpus"]) else "  **RANKS SEEN %s != n_gpus %s**" % (seen, d["n_gpus"])
+    print("   %s: N=%d (%s) %.1f img/s, %.2f ms/step, allreduce %s ms, exposed %s ms%s" % (
+        sys.argv[2], d["n_gpus"], d.get("dist_backend", "-"), d["value"], d["ms_per_step"], d.get("allreduce_ms"), d.get("exposed_ms"), flag))
 except Exception as e:
     print("   %s: NO RESULT (%s) -- see the .err file" % (sys.argv[2], e))
 PY
@@ -41,6 +51,11 @@ PY
 for n in 1 2 4 8; do
   run f32_n$n $n --
   run bf16_n$n $n -- --dtype bf16
+done
+# ---- 1b. SURVEY 8(d)'s strong-scaling information points: the reference's global batch 16 over the node = 2 images per GPU at N = 8
+#          (one-GPU twin: bench.py's market128_bs2_f32 information line), and configs[4]'s own per-GPU batch of 4 ----
+for n in 1 8; do
+  run f32_strong_bs2_n$n $n -- --batch 2
 done
 [ "${1:-all}" = "curve" ] && exit 0
 # ---- 2. configs[2] / configs[4] at their OWN per-GPU batches: stage-II global 64 = 8 per GPU, DeepFashion wgan-gp global 32 = 4 per GPU ----
@@ -65,10 +80,10 @@ run f32_n8_nosplit 8 DPIG_SPLIT_BACKWARD=0 --
 # ---- 5. cross-rank batch-norm statistics (eager islands between captured graphs) at N = 2 and 8 ----
 run f32_n2_syncbn 2 DPIG_SYNC_BN=1 --
 run f32_n8_syncbn 8 DPIG_SYNC_BN=1 --
-python - <<'PY'
-import glob, json, os
+python - "$OUT" <<'PY'
+import glob, json, os, sys
 rows = {}
-for p in sorted(glob.glob("gpurun_out/scale/*.json")):
+for p in sorted(glob.glob(os.path.join(sys.argv[1], "*.json"))):
     try:
         rows[os.path.basename(p)[:-5]] = json.load(open(p))
     except Exception:
@@ -77,5 +92,8 @@ for fam in ("f32", "bf16"):
     base = rows.get("%s_n1" % fam)
     if base:
         print("weak-scaling efficiency (%s): " % fam + ", ".join(
-            "N=%d %.3f" % (n, rows["%s_n%d" % (fam, n)]["value"] / (n * base["value"])) for n in (2, 4, 8) if "%s_n%d" % (fam, n) in rows))
+            "N=%d %.3f" % (rows["%s_n%d" % (fam, n)]["n_gpus"], rows["%s_n%d" % (fam, n)]["value"] / (rows["%s_n%d" % (fam, n)]["n_gpus"] * base["value"]))
+            for n in (2, 4, 8) if "%s_n%d" % (fam, n) in rows))
+bad = [k for k, d in rows.items() if d.get("n_gpus", 1) > 1 and d.get("rccl_ranks_seen") != d.get("n_gpus")]
+print("runs: %d with a result%s" % (len(rows), ("; RANK-COUNT MISMATCH in " + ", ".join(bad)) if bad else "; every multi-rank run saw all its ranks"))
 PY

@@ -424,3 +424,46 @@ def test_bundle_protos_against_the_protobuf_runtime(tmp_path):
         # ... and the other direction: what the runtime writes for the same entry is what the reader understands
         back = C._parse_entry(e.SerializeToString())
         assert (back["dtype"], back["shape"], back["offset"], back["size"], back["crc32c"]) == (e.dtype, list(a.shape), e.offset, e.size, e.crc32c)
+
+
+def test_writer_against_the_independent_reader(tmp_path):
+    """tfckpt.save_checkpoint's files read back by tests/bundle_reader_independent.py -- a reader that shares no code with the module
+    (own varint, CRC-32C table, protobuf walk, block parser): names, shapes, dtypes, bytes, every block and tensor checksum.  Enough
+    variables that the table has several data blocks (prefix-compressed keys across restart points, a multi-entry index block)."""
+    import bundle_reader_independent as R
+    rs = np.random.RandomState(3)
+    tensors = {"step": np.array(77, dtype=np.int32), "g_lr": np.array(2e-5, dtype=np.float32)}
+    for i in range(180):
+        scope = "Encoder/G_encoder/Conv_%d" % i if i % 3 else "Discriminator.%d/Discriminator.%d.Filters" % (i, i)
+        tensors[scope + "/weights"] = rs.randn(3, 3, 1 + i % 5, 2 + i % 7).astype(np.float32)
+        tensors[scope + "/biases"] = rs.randn(2 + i % 7).astype(np.float32)
+    tensors["beta1_power"] = np.array(0.9 ** 5, dtype=np.float32)
+    tensors["big/weights"] = rs.randn(20480, 16).astype(np.float32)
+    prefix = str(tmp_path / "model.ckpt-77")
+    C.save_checkpoint(prefix, tensors)
+    got, header = R.read_bundle(prefix)
+    assert header.get(1) == 1                                        # num_shards
+    assert set(got) == set(tensors)
+    for k, v in tensors.items():
+        assert got[k].dtype == v.dtype and got[k].shape == v.shape and np.array_equal(got[k], v), k
+    # several data blocks (the bundle's block size holds this whole index in one): the same keys through write_table with small
+    # blocks -- prefix-compressed keys across restart points, a multi-entry index block -- read by the independent table reader
+    items = sorted((k.encode(), ("value of %s" % k).encode() * (1 + len(k) % 3)) for k in tensors)
+    small = str(tmp_path / "small.index")
+    C.write_table(small, items, block_size=512)
+    raw_small = open(small, "rb").read()
+    foot = raw_small[-48:]
+    p = 0
+    _, p = R.varint(foot, p); _, p = R.varint(foot, p)
+    io, p = R.varint(foot, p); isz, p = R.varint(foot, p)
+    assert len(R.entries(R.block(raw_small, io, isz))) >= 10
+    assert R.read_index(small) == dict(items)
+    raw = open(prefix + ".index", "rb").read()
+    # ... and the independent CRC agrees with the module's on arbitrary bytes
+    blob = rs.bytes(1000)
+    assert R.masked(blob) == masked_crc32c(blob)
+    # a flipped byte in a data block is caught by the independent reader too
+    bad = bytearray(raw); bad[10] ^= 1
+    open(prefix + ".index", "wb").write(bytes(bad))
+    with pytest.raises(ValueError):
+        R.read_bundle(prefix)
