@@ -611,8 +611,8 @@ __global__ __launch_bounds__(512, 2) void wino_block_kernel(const WParams p) {
 // takes one tile, a thread loads one row of its input patch (4 x 16 bytes; the second row its transform row combines comes from a
 // neighbouring lane by ds_bpermute) and the tile's 2 x 2 dy pixels (4 x 16 bytes), transforms both in registers and writes 16-byte
 // rows [position][tile][channel] into LDS; the MFMA fragments are 4-byte LDS reads (the reduction index of v_mfma_f32_32x32x2_f32 runs
-// across lanes).  At the end each wave applies A'^T . A' to its own position half in registers and writes
-// its nine 32 x 32 tap blocks as ONE of 2 S partial filter gradients [3][3][C][K]; wino_wgrad_reduce_kernel sums them in fixed order
+// across lanes).  At the end each wave applies A'^T . A' to its own position half in registers (nine 32 x 32 tap blocks), the workgroup's two position halves meet in LDS, and the block leaves ONE of S partial filter gradients
+// [3][3][C][K]; wino_wgrad_reduce_kernel sums them in fixed order
 // (deterministic) into dw (+ beta dw).  The bias gradient db[k] = sum over pixels of dy rides along: the 2 x 2 dy pixels of the tiles
 // partition the map, so the workgroups of channel block 0 add up what their transform threads load anyway (the lanes of transform row 0 deliver)
 // and leave one [K] partial per split; the reduce kernel sums those in split order too.
@@ -620,7 +620,7 @@ __global__ __launch_bounds__(512, 2) void wino_block_kernel(const WParams p) {
 struct WGParams {
     const float* X;       // forward input, NHWC, channel stride ldx
     const float* DY;      // output gradient, NHWC, channel stride ldy
-    float* part;          // [2 * nsplit][3][3][C][K]
+    float* part;          // [nsplit][3][3][C][K]
     float* bias_part;     // [nsplit][K] after the filter slabs, or null: no bias gradient asked
     int N, H, W, C, K, ldx, ldy;
     int T, THW, TW;
@@ -808,32 +808,61 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WGParams p) {
             p.bias_part[(long)sp * p.K + kb * 64 + tid] = t;
         }
     }
-    float* const slab = p.part + (long)(2 * sp + ph) * 9 * p.C * p.K;
+    // The two position halves of a (c, k) block sit in DIFFERENT waves of this workgroup (ph 0: transform rows 0, 1; ph 1: rows 2, 3) and
+    // each holds a partial value of all nine taps.  They meet here, through the LDS the loop no longer needs, so that the workgroup
+    // leaves ONE partial gradient per split instead of two (round 5 wrote 2 S slabs: twice the stores and twice the bytes the reduce
+    // pass reads).  Two rounds of 8 accumulator elements: in round 0 the ph 1 waves hand theirs over and the ph 0 waves add + store, in
+    // round 1 the roles swap (balanced stores).  own + partner is one fp32 addition, commutative: the bits do not depend on the round.
+    float* const slab = p.part + (long)sp * 9 * p.C * p.K;
     const int kcol = kb * 64 + 32 * kc + l31;
+    typedef __attribute__((address_space(3))) float lds_f;
+    lds_f* const XL = (lds_f*)L + ((wave & 3) * 72) * 64 + lane;             // [wave pair][8 elements x 9 taps][lane]
 #pragma unroll
-    for (int e = 0; e < 16; ++e) {
-        const int crow = cb * 64 + 32 * cr + 8 * (e >> 2) + 4 * half + (e & 3);
-        float sx[2][3];
+    for (int rnd = 0; rnd < 2; ++rnd) {
+        const bool sender = (ph != rnd);
+        float wv[8][9];
 #pragma unroll
-        for (int x2 = 0; x2 < 2; ++x2) {
-            const float m0 = acc[4 * x2 + 0][e], m1 = acc[4 * x2 + 1][e], m2 = acc[4 * x2 + 2][e], m3 = acc[4 * x2 + 3][e];
-            sx[x2][0] = m0 + m1 + m2;
-            sx[x2][1] = m1 - m2;
-            sx[x2][2] = m1 + m2 + m3;
+        for (int e8 = 0; e8 < 8; ++e8) {
+            const int e = 8 * rnd + e8;
+            float sx[2][3];
+#pragma unroll
+            for (int x2 = 0; x2 < 2; ++x2) {
+                const float m0 = acc[4 * x2 + 0][e], m1 = acc[4 * x2 + 1][e], m2 = acc[4 * x2 + 2][e], m3 = acc[4 * x2 + 3][e];
+                sx[x2][0] = m0 + m1 + m2;
+                sx[x2][1] = m1 - m2;
+                sx[x2][2] = m1 + m2 + m3;
+            }
+#pragma unroll
+            for (int s3 = 0; s3 < 3; ++s3) {
+                const float a = sx[0][s3], b = sx[1][s3];
+                wv[e8][0 * 3 + s3] = ph ? a : a + b;
+                wv[e8][1 * 3 + s3] = ph ? -a : b;
+                wv[e8][2 * 3 + s3] = ph ? a + b : b;
+            }
         }
+        __syncthreads();                 // the LDS is free: the loop's last reads / the bias rows / the previous round's readers are done
+        if (sender) {
 #pragma unroll
-        for (int s3 = 0; s3 < 3; ++s3) {
-            const float a = sx[0][s3], b = sx[1][s3];
-            const float w0 = ph ? a : a + b, w1 = ph ? -a : b, w2 = ph ? a + b : b;
-            slab[((long)(0 * 3 + s3) * p.C + crow) * p.K + kcol] = w0;
-            slab[((long)(1 * 3 + s3) * p.C + crow) * p.K + kcol] = w1;
-            slab[((long)(2 * 3 + s3) * p.C + crow) * p.K + kcol] = w2;
+            for (int e8 = 0; e8 < 8; ++e8)
+#pragma unroll
+                for (int t = 0; t < 9; ++t) XL[(e8 * 9 + t) * 64] = wv[e8][t];
+        }
+        __syncthreads();
+        if (!sender) {
+#pragma unroll
+            for (int e8 = 0; e8 < 8; ++e8) {
+                const int e = 8 * rnd + e8;
+                const int crow = cb * 64 + 32 * cr + 8 * (e >> 2) + 4 * half + (e & 3);
+#pragma unroll
+                for (int t = 0; t < 9; ++t)
+                    slab[((long)t * p.C + crow) * p.K + kcol] = wv[e8][t] + XL[(e8 * 9 + t) * 64];
+            }
         }
     }
 }
 
 // dw = beta dw + sum of the nparts partial gradients (fixed order: deterministic)
-// (+ the bias gradient: db = beta_b db + sum of the nparts / 2 partial [K] rows, when db is given)
+// (+ the bias gradient: db = beta_b db + sum of the nparts partial [K] rows, when db is given)
 __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw, long n4, int nparts,
                                                                  float beta, const float* __restrict__ bias_part, float* __restrict__ db,
                                                                  int K, float beta_b) {
@@ -850,7 +879,7 @@ __global__ __launch_bounds__(256) void wino_wgrad_reduce_kernel(const float* __r
         } else {
             const int k = (int)(i - n4);
             float t = 0.f;
-            for (int s = 0; s < nparts / 2; ++s) t += bias_part[(long)s * K + k];
+            for (int s = 0; s < nparts; ++s) t += bias_part[(long)s * K + k];
             if (beta_b != 0.f) t += beta_b * db[k];
             db[k] = t;
         }
@@ -1123,7 +1152,7 @@ extern "C" int dpig_conv2d_wgrad_wino_eligible(const DpigConvDesc* d) {
 extern "C" size_t dpig_conv2d_wgrad_wino_workspace_bytes(const DpigConvDesc* d) {
     if (!d || !wino::wgrad_shape_ok(d)) return 0;
     const wino::WGPlan pl = wino::wgrad_plan(d);
-    return ((size_t)2 * pl.nsplit * 9 * d->C * d->K + (size_t)pl.nsplit * d->K) * sizeof(float);
+    return ((size_t)pl.nsplit * 9 * d->C * d->K + (size_t)pl.nsplit * d->K) * sizeof(float);
 }
 // dw[3][3][C][K] = beta dw + conv_backward_filter(x, dy) by F(3x3, 2x2) minimal filtering (fp32 tensors, products and sums; deterministic);
 // with db ([K], may be null) the same two launches also leave the bias gradient db = beta_b db + sum over pixels of dy, as
@@ -1137,7 +1166,7 @@ extern "C" int dpig_conv2d_wgrad_wino(const DpigConvDesc* d, const float* x, con
     if (!wino::wgrad_shape_ok(d)) return fail(DPIG_EINVAL, "winograd wgrad: unsupported shape");
     if (!aligned16(x) || !aligned16(dy) || !aligned16(dw) || !aligned16(ws)) return fail(DPIG_EINVAL, "winograd wgrad: operands must be 16-byte aligned");
     const wino::WGPlan pl = wino::wgrad_plan(d);
-    const size_t slabs = (size_t)2 * pl.nsplit * 9 * d->C * d->K;
+    const size_t slabs = (size_t)pl.nsplit * 9 * d->C * d->K;
     const size_t need = (slabs + (size_t)pl.nsplit * d->K) * sizeof(float);
     if (!ws || ws_bytes < need) return fail(DPIG_ENOMEM, "winograd wgrad workspace too small: have %zu, need %zu", ws_bytes, need);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -1157,7 +1186,7 @@ extern "C" int dpig_conv2d_wgrad_wino(const DpigConvDesc* d, const float* x, con
     if (rc) return rc;
     const long n4 = (long)9 * d->C * d->K / 4;
     const int blocks = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
-    hipLaunchKernelGGL(wino::wino_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.part, dw, n4, 2 * pl.nsplit, beta,
+    hipLaunchKernelGGL(wino::wino_wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, st, p.part, dw, n4, pl.nsplit, beta,
                        p.bias_part, db, d->K, beta_b);
     return check_launch("wino_wgrad_reduce_kernel");
 }

@@ -95,7 +95,15 @@ class DPIG_Encoder_subSampleAppNetFgBg_GAN_BodyROI(object):
             self.encoder_wino = H.WinoFilters(self.Encoder_var)      # frozen: Winograd images made once
 
     # ---- optimizer ops -------------------------------------------------------------------------------
-    def g_optim_embs(self, side, z=None):
+    def _update(self, side, which):
+        """Gradient exchange + optimizer step (+ the wgan weight clip) of one side's mapper (which = 0) or critic (1).  Data parallel:
+        kept OUT of the captured graphs (the collective library's calls are not capturable on every backend; `enable_graphs`)."""
+        f = self.flats[side][which]
+        self.opts[side][which].step(self.allreduce(f.grad))
+        if which == 1 and self.sides[side]["wg"].MODE == 'wgan':
+            clip_disc_weights(f)
+
+    def g_optim_embs(self, side, z=None, update=True):
         gf, df = self.flats[side]
         gf.zero_grad()
         df.set_requires_grad(False)
@@ -105,10 +113,11 @@ class DPIG_Encoder_subSampleAppNetFgBg_GAN_BodyROI(object):
             g_loss.backward()
         df.set_requires_grad(True)
         gf.finalize()
-        self.opts[side][0].step(self.allreduce(gf.grad))
+        if update:
+            self._update(side, 0)
         return g_loss.detach()
 
-    def d_optim_embs(self, side, batch, z=None):
+    def d_optim_embs(self, side, batch, z=None, update=True):
         gf, df = self.flats[side]
         df.zero_grad()
         fg, bg, _ = self.encode(batch)
@@ -121,9 +130,8 @@ class DPIG_Encoder_subSampleAppNetFgBg_GAN_BodyROI(object):
         with A.wgrad_overlap():
             d_loss.backward()
         df.finalize()
-        self.opts[side][1].step(self.allreduce(df.grad))
-        if self.sides[side]["wg"].MODE == 'wgan':
-            clip_disc_weights(df)
+        if update:
+            self._update(side, 1)
         return d_loss.detach()
 
     def enable_graphs(self, batch, warmup=2):
@@ -132,7 +140,9 @@ class DPIG_Encoder_subSampleAppNetFgBg_GAN_BodyROI(object):
         forward / backward + RMSProp + clip, `g_optim_embs` = mapper + critic forward / backward + RMSProp -- replayed in the loop order of
         trainer.py:821-845.  The batch lives in static buffers (`_feed` copies a new one in); the samplers' noise comes from the device
         generator, which torch advances per replay.  Weights, optimizer slots and the generator state are put back after the warm-up, so
-        enabling graphs does not move the training trajectory."""
+        enabling graphs does not move the training trajectory.  Data parallel (world > 1): a graph ends with the backward pass; the
+        gradient all-reduce, the optimizer step and the clip follow eagerly on the same stream, as in the stage-I trainer (found by
+        `scripts/run_scale.sh --dry`: with the exchange inside the capture the two-rank launch died in `capture_end`)."""
         from ._lib import workspace
         dev = self.device
         self._static = {k: v.clone() for k, v in batch.items()}
@@ -161,15 +171,17 @@ class DPIG_Encoder_subSampleAppNetFgBg_GAN_BodyROI(object):
         torch.cuda.set_rng_state(rng, dev)
         torch.cuda.synchronize(dev)
         graphs, pool = {}, None
+        self._graph_update = fold = not self.allreduce.enabled       # exchange + optimizer step inside the graph?
         for side in ("fg", "bg"):
             for op in ("g", "d"):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g, pool=pool, capture_error_mode="thread_local"):
-                    out = self.g_optim_embs(side) if op == "g" else self.d_optim_embs(side, self._static)
+                    out = self.g_optim_embs(side, update=fold) if op == "g" else self.d_optim_embs(side, self._static, update=fold)
                 pool = g.pool()
                 graphs[(side, op)] = (g, out)
-                o = self.opts[side][0 if op == "g" else 1]
-                o.t -= 1                      # capturing recorded one step() without executing it
+                if fold:
+                    o = self.opts[side][0 if op == "g" else 1]
+                    o.t -= 1                  # capturing recorded one step() without executing it
         self._graphs = graphs
         workspace.pin()
 
@@ -198,7 +210,10 @@ class DPIG_Encoder_subSampleAppNetFgBg_GAN_BodyROI(object):
             if self.step > 0:
                 g, o = self._graphs[(side, "g")]
                 g.replay()
-                self.opts[side][0].t += 1
+                if self._graph_update:
+                    self.opts[side][0].t += 1
+                else:
+                    self._update(side, 0)
                 out["g_loss_embs_" + side] = o
             iters = 1 if wg.MODE in ('dcgan', 'lsgan') else wg.CRITIC_ITERS
             for _ in range(iters):
@@ -206,7 +221,10 @@ class DPIG_Encoder_subSampleAppNetFgBg_GAN_BodyROI(object):
                 k += 1
                 g, o = self._graphs[(side, "d")]
                 g.replay()
-                self.opts[side][1].t += 1
+                if self._graph_update:
+                    self.opts[side][1].t += 1
+                else:
+                    self._update(side, 1)
                 out["d_loss_embs_" + side] = o
         if self.step % self.config.lr_update_step == self.config.lr_update_step - 1:
             self.g_lr.mul_(0.5)

@@ -207,7 +207,7 @@ int dpig_conv2d_dgrad_wino(const DpigConvDesc* d, const float* dy, const float* 
                            float* dx, void* ws, size_t ws_bytes, void* stream);
 /* The filter gradient by F(3x3, 2x2) minimal filtering: dw[3][3][C][K] = beta dw + conv_backward_filter(x, dy), 16 multiplies per
  * (2x2 tile, c, k) instead of 36; input and output-gradient transforms, the 16 position GEMMs over the tile axis and the output
- * transform are one kernel, split over tile ranges into 2 S partial gradients that a second kernel sums in fixed order
+ * transform are one kernel, split over tile ranges into S partial gradients that a second kernel sums in fixed order
  * (deterministic).  Same shape rules as above.  With db ([K]; may be null) the same launches leave the bias gradient
  * db = beta_b db + sum over pixels of dy, as dpig_conv2d_wgrad does.  Workspace: dpig_conv2d_wgrad_wino_workspace_bytes.  dpig_conv2d_wgrad_wino_eligible: shape has the form AND the cost model prefers it. */
 int dpig_conv2d_wgrad_wino_eligible(const DpigConvDesc* d);

@@ -124,3 +124,69 @@ def test_two_rank_step_equals_single_process_on_the_concatenated_batch(dev, back
         assert frac_all > (0.97 if exchange == "f32" else 0.93), (name, exchange, frac_all)
     lib.delete_all_params()
     slim.reset_scopes()
+
+
+def _stage2_worker(rank, world, port, q):
+    """Stage-II trainer (model 3: frozen encoder + FC mappers / critics, MODE 'wgan') on two ranks: two eager steps, then the same two
+    steps replayed from captured graphs.  Under data parallelism the graphs end with the backward pass; the gradient exchange, the
+    optimizer step and the weight clip follow eagerly (trainer_stage2._update)."""
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    sys.path.insert(0, ROOT)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import dpig_amd.tflib as lib
+        from dpig_amd import slim, synthetic
+        from dpig_amd.trainer import Config
+        from dpig_amd.trainer_stage2 import DPIG_Encoder_subSampleAppNetFgBg_GAN_BodyROI
+        dev = torch.device("cuda:0")
+        half = B // world
+        out = {}
+        for mode in ("eager", "graphs"):
+            lib.delete_all_params(); slim.reset_scopes()
+            np.random.seed(0)
+            torch.manual_seed(100 + rank); torch.cuda.manual_seed(100 + rank)        # (the samplers' noise: per rank, same in both modes)
+            tr = DPIG_Encoder_subSampleAppNetFgBg_GAN_BodyROI(Config(batch_size=half, conv_hidden_num=16, g_lr=1e-3, d_lr=1e-3), dev)
+            b = synthetic.to_device({k: v[rank * half:(rank + 1) * half] for k, v in synthetic.make_batch(B, seed=21).items()}, dev)
+            tr.init_net(b)
+            assert tr.allreduce.enabled
+            tr.step = 1
+            if mode == "graphs":
+                tr.enable_graphs(b, warmup=1)
+                assert tr._graph_update is False                     # exchange + update stay outside the captures
+                b = tr.static_batch()
+            losses = []
+            for _ in range(2):
+                o = tr.train_step(b)
+                losses.append({k: float(v) for k, v in o.items()})
+            torch.cuda.synchronize()
+            out[mode] = (losses, {s: [f.flat.detach().cpu().numpy().copy() for f in tr.flats[s]] for s in ("fg", "bg")})
+        q.put((rank, out))
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+def test_stage2_two_rank_captured_steps_equal_eager(dev):
+    """Found by `scripts/run_scale.sh --dry` (round 6): the stage-II trainer captured its gradient all-reduce inside the hipGraphs and a
+    two-rank launch died in capture_end -- configs[2] (8 x MI355X) would have failed on the 8-GPU day.  Replayed steps must equal the
+    eager ones bit for bit on both ranks, and the replicas must stay identical."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_stage2_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(world):
+        (le, we), (lg, wg) = res[r]["eager"], res[r]["graphs"]
+        assert le == lg, (le, lg)
+        for s in ("fg", "bg"):
+            assert all(np.array_equal(a, b_) for a, b_ in zip(we[s], wg[s]))
+    for s in ("fg", "bg"):
+        assert all(np.array_equal(a, b_) for a, b_ in zip(res[0]["graphs"][1][s], res[1]["graphs"][1][s]))
