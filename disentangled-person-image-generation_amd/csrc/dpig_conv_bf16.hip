@@ -119,12 +119,16 @@ __device__ __forceinline__ void bg_epilogue(const BGParams& p, char* smem, f32x1
     }
     if (col >= p.Ncols) return;
     if (p.nsplit > 1) {
-        float* pp = p.partial + ((long)split * p.M + m0 + rl0) * p.Ncols + col;
+        // pre-epilogue partial sums [split][GEMM row][column]; the row of tile row rl comes from rowof (m0 + rl for the linear tiles, the
+        // pixel index of the patch position for the halo tiles): bg_reduce_kernel is the second pass of both
+        float* const pbase = p.partial + (long)split * p.M * p.Ncols + col;
 #pragma unroll 4
         for (int it = 0; it < NIT; ++it) {
-            if (m0 + rl0 + RG * it < p.M) {
-                *reinterpret_cast<float4*>(pp + (long)(RG * it) * p.Ncols) = *reinterpret_cast<const float4*>(&Cs[(rl0 + RG * it) * LDC + c]);
-                *reinterpret_cast<float4*>(pp + (long)(RG * it) * p.Ncols + 4) = *reinterpret_cast<const float4*>(&Cs[(rl0 + RG * it) * LDC + c + 4]);
+            const long r0 = rowof(rl0 + RG * it);
+            if (r0 >= 0) {
+                float* pp = pbase + r0 * p.Ncols;
+                *reinterpret_cast<float4*>(pp) = *reinterpret_cast<const float4*>(&Cs[(rl0 + RG * it) * LDC + c]);
+                *reinterpret_cast<float4*>(pp + 4) = *reinterpret_cast<const float4*>(&Cs[(rl0 + RG * it) * LDC + c + 4]);
             }
         }
         return;
@@ -208,12 +212,18 @@ __device__ __forceinline__ void bg_epilogue(const BGParams& p, char* smem, f32x1
 // NW = waves of the workgroup: 4 (sub-tiles 64 x 64) or 8 (64 x 32: each wave issues HALF the LDS-DMA pieces of a k-tile -- their issue
 // cost, not their bytes, is what bounds this loop (profiles/r02_bf16_kloop_timeline_knockout.md) -- for 1.5x the fragment reads).  The
 // k order of every output element is the same, so the two give identical bits.
-template <int NW>
+// ST = LDS stages of the k-loop.  2 (rounds 2-5): the DMA of k-tile t + 1 flies under the MFMAs of k-tile t and is waited for in full
+// before the barrier -- fine with two workgroups per CU, whose loops interleave.  4 (round 6, bg8d_kernel): THREE k-tiles in flight,
+// counted waits (s_waitcnt vmcnt(2 P): only k-tile t's own pieces must have landed), raw barriers, one 128-KB workgroup per CU -- for
+// the small layers whose split plans give the chip ONE round of <= 256 workgroups: alone on its CU a two-stage loop exposes the whole
+// L2 -> LDS latency every k-tile (32 x 16 C384: 0.83 us per k-tile against 0.21 us of MFMAs).  Same k order per output element: same bits.
+template <int NW, int ST = 2>
 __device__ __forceinline__ void bg_body(const BGParams& p) {
     constexpr int NB = NW == 4 ? 2 : 1;          // 32-column blocks per wave
     constexpr int RPR = 8 * NW;                  // tile rows one DMA round of the workgroup fills
     constexpr int NJ = TM / RPR;                 // DMA rounds per operand tile
-    __shared__ __attribute__((aligned(16))) char smem[SMEM_BYTES];     // the ONLY LDS object (two would make hipcc
+    constexpr int SMEM_ST = ST * STAGE_B > SMEM_BYTES ? ST * STAGE_B : SMEM_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[SMEM_ST];        // the ONLY LDS object (two would make hipcc
                                                                        // drain the DMA queue before every ds_read)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -286,6 +296,14 @@ __device__ __forceinline__ void bg_body(const BGParams& p) {
         tap_sB = ((p.w0 + cur_ta * p.wa + cur_tb * p.wb) * p.Ncols * p.Cs) * 2;
     };
     enter_tap();
+    auto issue_dummy = [&](int stage) {      // (ST > 2) past the last k-tile: the same DMA instructions with out-of-range offsets -- zero fill of a
+        char* dst = smem + stage * STAGE_B + (8 * wave) * ROWB;           // free stage -- so that the counted waits stay uniform
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+            dma16(rsA, (int)OOB, 0, dst + RPR * j * ROWB);
+            dma16(rsB, (int)OOB, 0, dst + TILE_B + RPR * j * ROWB);
+        }
+    };
     auto issue = [&](int stage) {
         const int c0 = cur_c0;
         char* dst = smem + stage * STAGE_B + (8 * wave) * ROWB;
@@ -355,17 +373,62 @@ __device__ __forceinline__ void bg_body(const BGParams& p) {
     };
 
     BF_STAMP(0);
-    if (kt_begin < kt_end) {
-        issue(0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        int kt = kt_begin;
-        // two k-tiles per trip so that the LDS stage is a compile-time constant
-        for (; kt + 1 < kt_end; kt += 2) {
-            ktile(0, true);
-            ktile(1, kt + 2 < kt_end);
+    if constexpr (ST == 2) {
+        if (kt_begin < kt_end) {
+            issue(0);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+            int kt = kt_begin;
+            // two k-tiles per trip so that the LDS stage is a compile-time constant
+            for (; kt + 1 < kt_end; kt += 2) {
+                ktile(0, true);
+                ktile(1, kt + 2 < kt_end);
+            }
+            if (kt < kt_end) ktile(0, false);
         }
-        if (kt < kt_end) ktile(0, false);
+    } else if (kt_begin < kt_end) {
+        // ---- ST-stage ring: k-tiles t + 1 .. t + ST - 1 in flight under k-tile t ------------------------------------------------------
+        constexpr int P = 2 * NJ;                          // DMA instructions of one k-tile per wave
+        int nissued = kt_begin;                            // next k-tile to issue
+        auto issue_next = [&](int stage) {
+            if (nissued < kt_end) issue(stage); else issue_dummy(stage);
+            ++nissued;
+        };
+#pragma unroll
+        for (int i = 0; i < ST - 1; ++i) issue_next(i);
+        // one k-tile: wait for ITS pieces only (the ST - 2 younger k-tiles stay in flight), raw barrier (every wave's pieces of k-tile t
+        // are in LDS; every wave has finished reading k-tile t - 1, whose stage the next issue overwrites), issue k-tile t + ST - 1,
+        // fragments + MFMAs of k-tile t.  __syncthreads() would drain the DMA queue (it waits for vmcnt(0)).
+        auto ktile_deep = [&](auto STAGE) {
+            constexpr int stage = decltype(STAGE)::value;
+            asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(P * (ST - 2)) : "memory");
+            load_frag(stage, 0, fa[0], fb[0]);
+            __builtin_amdgcn_sched_barrier(0);
+            issue_next((stage + ST - 1) % ST);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks + 1 < 4) load_frag(stage, ks + 1, fa[(ks + 1) & 1], fb[(ks + 1) & 1]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+                    for (int nb = 0; nb < NB; ++nb)
+                        acc[mb][nb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[ks & 1][mb], fb[ks & 1][nb], acc[mb][nb], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        int kt = kt_begin;
+        for (; kt + ST <= kt_end; kt += ST) {
+            ktile_deep(std::integral_constant<int, 0>{});
+            ktile_deep(std::integral_constant<int, 1>{});
+            ktile_deep(std::integral_constant<int, 2 % ST>{});
+            ktile_deep(std::integral_constant<int, 3 % ST>{});
+        }
+        const int rem = kt_end - kt;                       // 0 .. ST - 1 k-tiles left: stages 0, 1, 2 in order
+        if (rem > 0) ktile_deep(std::integral_constant<int, 0>{});
+        if (rem > 1) ktile_deep(std::integral_constant<int, 1>{});
+        if (rem > 2) ktile_deep(std::integral_constant<int, 2 % ST>{});
+        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");    // the dummy pieces too: the epilogue reuses the LDS
     }
 
     BF_STAMP(5);
@@ -376,6 +439,7 @@ __device__ __forceinline__ void bg_body(const BGParams& p) {
 
 __global__ __launch_bounds__(256, 2) void bg_kernel(const BGParams p) { bg_body<4>(p); }
 __global__ __launch_bounds__(512, 2) void bg8_kernel(const BGParams p) { bg_body<8>(p); }
+__global__ __launch_bounds__(512, 1) void bg8d_kernel(const BGParams p) { bg_body<8, 4>(p); }       // deep ring, one workgroup per CU
 
 struct BGMulti { BGParams q[4]; };
 __global__ __launch_bounds__(256, 2) void bg_multi_kernel(const BGMulti m) {
@@ -387,6 +451,12 @@ __global__ __launch_bounds__(512, 2) void bg8_multi_kernel(const BGMulti m) {
     const BGParams& p = m.q[blockIdx.y];
     if ((int)blockIdx.x >= p.mtiles * p.ntiles || (int)blockIdx.z >= p.nsplit) return;
     bg_body<8>(p);
+}
+
+__global__ __launch_bounds__(512, 1) void bg8d_multi_kernel(const BGMulti m) {                      // the deep ring for a multi-problem launch
+    const BGParams& p = m.q[blockIdx.y];
+    if ((int)blockIdx.x >= p.mtiles * p.ntiles || (int)blockIdx.z >= p.nsplit) return;
+    bg_body<8, 4>(p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -492,7 +562,12 @@ __device__ __forceinline__ void bh_body(const BGParams& p) {
     for (int ks = 0; ks < 4; ++ks) sob[ks] = ((2 * ks + half) ^ fsw) * 16;
 
     bf16x8 fa[2][2], fb[2][NB];
-    const int nch = p.cchunks;
+    // split plan (round 6): blockIdx.z owns the channel chunks [c_begin, nch) of a range of tiles_per_split chunks -- a layer with fewer
+    // patches than the chip has slots (32 x 16 C384, 16 x 8 C512, DeepFashion's 32 x 32 C512 / 16 x 16 C768) keeps the halo staging
+    // (167 instead of 288 KB of L2 -> LDS traffic per chunk) instead of falling back to the tap-major kernel for its split-K
+    const int split = blockIdx.z;
+    const int c_begin = split * p.tiles_per_split;
+    const int nch = min(p.cchunks, c_begin + p.tiles_per_split);
     const int ktiles = 9 * nch;
     // one k-tile = (chunk c, tap): A fragments from the resident halo of chunk c shifted by the tap, B from bbuf[stage]
     auto ktile = [&](int kt, int stage) {
@@ -538,18 +613,18 @@ __device__ __forceinline__ void bh_body(const BGParams& p) {
     };
 
 #pragma unroll
-    for (int q = 0; q < NQ; ++q) issue_halo(q, 0, 0);
-    issue_b(0, 0, 0);
+    for (int q = 0; q < NQ; ++q) issue_halo(q, c_begin & 1, c_begin * TK);
+    issue_b(0, 0, c_begin * TK);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    int kt = 0;
+    int kt = 9 * c_begin;
     for (; kt + 1 < ktiles; kt += 2) {
         ktile(kt, 0);
         ktile(kt + 1, 1);
     }
     if (kt < ktiles) ktile(kt, 0);
 
-    bg_epilogue<NB, 4 * NW>(p, smem, acc, 0, n0, 0, tid, wrow, wcol, l31, half, [&](int rl) {
+    bg_epilogue<NB, 4 * NW>(p, smem, acc, 0, n0, split, tid, wrow, wcol, l31, half, [&](int rl) {
         const int y = y0 + (rl >> TWL), x = x0 + (rl & (TW - 1));
         return (y < p.Hs && x < p.Ws) ? (img * p.Hs + y) * p.Ws + x : -1;
     });
@@ -1302,7 +1377,16 @@ static int halo_plan(const BGParams& p, int nimg, int* tx, int* ty) {
     }
     if (best_u < 0.74) return 0;
     const long tiles = (long)nimg * (*tx) * (*ty) * cdiv(p.Ncols, TN);
-    if (tiles < 2 * kNumCU) return 0;                          // small layers: bg_kernel with split-K fills the chip
+    if (tiles < 2 * kNumCU) {
+        // fewer patches than resident slots: with DPIG_BF16_HALO_SPLIT=1 the halo kernel splits the reduction over ranges of channel chunks
+        // (the plan's nsplit, capped by the chunk count).  Built and measured in round 6 (scripts/bench_halo_split.py,
+        // profiles/r06_bf16_small_layer_ab.txt): bit-identical, and NOT faster -- 16 x 8 C512 34.9 -> 34.3 us, 32 x 32 C512 65.6 -> 63.9,
+        // 16 x 16 C768 48.4 -> 49.8 -- these launches are bound by their fixed costs, not by L2 -> LDS bytes.  Off by default: the
+        // tap-major kernel (with its four-stage ring, bg8d_kernel) keeps these layers.
+        static int hsplit = -1;
+        if (hsplit < 0) { const char* e = getenv("DPIG_BF16_HALO_SPLIT"); hsplit = (e && !strcmp(e, "1")) ? 1 : 0; }
+        if (!hsplit || p.nsplit < 2 || p.cchunks < 2) return 0;
+    }
     return best;
 }
 
@@ -1332,17 +1416,35 @@ static int launch_bg(BGParams& p, int nimg, long filter_elems, hipStream_t st) {
     if (twl) {
         p.tiles_x = tx; p.tiles_y = ty;
         p.mtiles = nimg * tx * ty;
-        p.nsplit = 1; p.tiles_per_split = p.ktiles;
-        dim3 hgrid(p.mtiles * p.ntiles), hblock(256);
+        if ((long)p.mtiles * p.ntiles >= 2 * kNumCU || p.nsplit < 2) {
+            p.nsplit = 1; p.tiles_per_split = p.cchunks;
+        } else {                                               // channel-chunk ranges (tiles_per_split counts CHUNKS for this kernel)
+            const int want = p.nsplit < p.cchunks ? p.nsplit : p.cchunks;
+            p.tiles_per_split = cdiv(p.cchunks, want);
+            p.nsplit = cdiv(p.cchunks, p.tiles_per_split);     // <= the plan's nsplit: the workspace sized for the plan holds the partials
+        }
+        dim3 hgrid(p.mtiles * p.ntiles, 1, p.nsplit), hblock(256);
         if (wave8_mode() & 4) {
             if (twl == 4) hipLaunchKernelGGL((bh8_kernel<4>), hgrid, dim3(512), 0, st, p);
             else hipLaunchKernelGGL((bh8_kernel<3>), hgrid, dim3(512), 0, st, p);
         } else if (twl == 4) hipLaunchKernelGGL((bh_kernel<4>), hgrid, hblock, 0, st, p);
         else hipLaunchKernelGGL((bh_kernel<3>), hgrid, hblock, 0, st, p);
-        return check_launch("bh_kernel");
+        rc = check_launch("bh_kernel");
+        if (rc == DPIG_OK && p.nsplit > 1) {
+            hipLaunchKernelGGL(bg_reduce_kernel, dim3(reduce_blocks(p)), dim3(256), 0, st, p);
+            rc = check_launch("bg_reduce_kernel");
+        }
+        return rc;
     }
     dim3 grid(p.mtiles * p.ntiles, 1, p.nsplit);
-    if ((wave8_mode() & 1) && !p.stats) hipLaunchKernelGGL(bg8_kernel, grid, dim3(512), 0, st, p);
+    // one round of at most one workgroup per CU (what the split plans give the small layers): the four-stage ring (bg8d_kernel) keeps
+    // three k-tiles in flight where the two-stage loop, alone on its CU, waits out every DMA.  DPIG_BF16_DEEP=0: off (A/B measurements).
+    static int deep = -1;
+    if (deep < 0) { const char* e = getenv("DPIG_BF16_DEEP"); deep = (e && !strcmp(e, "0")) ? 0 : 1; }
+    const long wgs = (long)p.mtiles * p.ntiles * p.nsplit;
+    if (deep && (wave8_mode() & 1) && !p.stats && wgs <= kNumCU && p.ktiles / p.nsplit >= 4)
+        hipLaunchKernelGGL(bg8d_kernel, grid, dim3(512), 0, st, p);
+    else if ((wave8_mode() & 1) && !p.stats) hipLaunchKernelGGL(bg8_kernel, grid, dim3(512), 0, st, p);
     else hipLaunchKernelGGL(bg_kernel, grid, dim3(256), 0, st, p);
     rc = check_launch("bg_kernel");
     if (rc) return rc;
@@ -1364,7 +1466,16 @@ static int launch_bg_multi(BGParams* q, int n, int nimg, long filter_elems, hipS
         m.q[i] = q[i];
     }
     dim3 grid(max_tiles, n, max_split);
-    if (wave8_mode() & 1) hipLaunchKernelGGL(bg8_multi_kernel, grid, dim3(512), 0, st, m);
+    static int deep = -1;
+    if (deep < 0) { const char* e = getenv("DPIG_BF16_DEEP"); deep = (e && !strcmp(e, "0")) ? 0 : 1; }
+    long live = 0;                                   // workgroups that do not exit at once
+    int min_kt = 1 << 30;
+    for (int i = 0; i < n; ++i) {
+        live += (long)q[i].mtiles * q[i].ntiles * q[i].nsplit;
+        if (q[i].ktiles / q[i].nsplit < min_kt) min_kt = q[i].ktiles / q[i].nsplit;
+    }
+    if (deep && (wave8_mode() & 1) && live <= kNumCU && min_kt >= 4) hipLaunchKernelGGL(bg8d_multi_kernel, grid, dim3(512), 0, st, m);
+    else if (wave8_mode() & 1) hipLaunchKernelGGL(bg8_multi_kernel, grid, dim3(512), 0, st, m);
     else hipLaunchKernelGGL(bg_multi_kernel, grid, dim3(256), 0, st, m);
     int rc = check_launch("bg_multi_kernel");
     if (rc) return rc;
