@@ -35,7 +35,8 @@ key = os.environ.get("DPIG_TRAFFIC_KEY", "market128/f32")
 dtype = key.split("/")[1]
 FAMILY = {"f32": (["gather_gemm_kernel<false, true, false, 0>"], ["conv_fwd_mfma"]),
           "f32w": (["wino_block_kernel", "wino_kernel"], ["conv_fwd_wino", "conv_dgrad_wino"]),
-          "bf16": (["bhq_kernel", "bhq32_kernel", "bq_kernel", "bh_kernel", "bg8_kernel", "bg_kernel", "bg8_multi_kernel", "bg_multi_kernel"],
+          "bf16": (["bhq_kernel", "bhq32_kernel", "bq_kernel", "bh_kernel", "bg8_kernel", "bg8d_kernel", "bg_kernel", "bg8_multi_kernel", "bg8d_multi_kernel",
+                    "bg_multi_kernel"],
                    ["conv_fwd_bf16", "conv_dgrad_bf16"])}
 pats, classes = FAMILY.get(dtype, FAMILY["f32"])
 def base(n):                      # "dpig::bfk::bq_kernel<2, 4>" -> "bq_kernel"
