@@ -1112,6 +1112,7 @@ static WGPlan wgrad_plan(const DpigConvDesc* d) {
     return pl;
 }
 static bool wgrad_shape_ok(const DpigConvDesc* d) {
+    if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->K <= 0) return false;   // (an empty batch made wgrad_plan divide by zero: tests/test_host_sweep.py)
     if (d->R != 3 || d->S != 3 || d->stride != 1 || d->upsample2x) return false;
     if ((d->H & 1) || (d->W & 1) || d->H < 2 || d->W < 2 || d->C % 64 || d->K % 64 || (d->ldx & 3) || (d->ldy & 3)) return false;
     if (d->pad_t >= 0 && d->pad_t != 1) return false;
