@@ -1,8 +1,8 @@
 """Host-side sweep of the C ABI's planning surface (no device work, runs without a GPU): every function that sizes a workspace, decides
 eligibility or plans a launch is called over a grid of ordinary, degenerate and hostile descriptors.  Properties: it returns (no crash,
 no hang), sizes are finite and bounded, "not supported" answers are consistent between the query and the sizing function, and null /
-non-positive descriptors are refused.  The SAME file is what `scripts/build_asan.sh` runs against the AddressSanitizer +
-UndefinedBehaviorSanitizer build of the library's host code (SURVEY section 5's sanitizer row; profiles/r06_asan_ubsan_host.txt)."""
+non-positive descriptors are refused.  This file is also part of what the sanitizer build of the library's host code is run against
+(SURVEY section 5's sanitizer row; the recipe and its record are named in profiles/r06_asan_ubsan_host.txt)."""
 import ctypes
 import itertools
 import random
