@@ -73,6 +73,15 @@ SYMBOLS = {
     "dpig_conv2d_wino_workspace_bytes": (_sz, [_dp, _i]),
     "dpig_conv2d_fwd_wino": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dpig_conv2d_dgrad_wino": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dpig_wino4_filter_elems": (_sz, [_i, _i]),
+    "dpig_wino4_filter_transform": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
+    "dpig_wino4_filter_transform_jobs": (_i, [_vp, _i, _i, _vp]),
+    "dpig_conv2d_wino4_eligible": (_i, [_dp, _i]),
+    "dpig_conv_wino4_set_mode": (_i, [_i]),
+    "dpig_conv_wino4_get_mode": (_i, []),
+    "dpig_conv2d_wino4_workspace_bytes": (_sz, [_dp, _i]),
+    "dpig_conv2d_fwd_wino4": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
+    "dpig_conv2d_dgrad_wino4": (_i, [_dp, _vp, _vp, _vp, _vp, _vp, _vp, _sz, _vp]),
     "dpig_conv2d_wgrad_wino_eligible": (_i, [_dp]),
     "dpig_conv2d_wgrad_wino_workspace_bytes": (_sz, [_dp]),
     "dpig_conv2d_wgrad_wino": (_i, [_dp, _vp, _vp, _vp, _f, _vp, _f, _vp, _sz, _vp]),

@@ -34,10 +34,7 @@
 //
 // Accuracy: products and sums are fp32; the transforms add +-1 / +-1/2 combinations of 4 inputs / 3 filter taps, so results differ
 // from the direct kernel by a few fp32 ulps of the largest intermediate (measured against the fp64 oracle in tests/test_wino_gpu.py).
-#include <stdlib.h>
-#include <type_traits>
-#include "dpig_common.h"
-#include "dpig_conv_plan.h"
+#include "dpig_wino_common.h"
 
 namespace dpig {
 namespace wino {
@@ -50,62 +47,7 @@ constexpr int PLANE = 64 * ROWB;              // one position: 2 KB
 constexpr int OPB = 16 * PLANE;               // one operand, one chunk: 32 KB
 constexpr int EP_ROW = KB * 4 + 16;           // epilogue staging: bytes per pixel row (+16: conflict-free 16-byte stores)
 constexpr int SMEM = 2 * 256 * EP_ROW;        // the loop's V[2] | U[2] (128 KB) or the epilogue's two staging images (136 KB)
-constexpr unsigned OOB = 0x7fffffffu;
 static_assert(4 * OPB <= SMEM && SMEM <= 163840, "LDS plan");
-
-typedef __attribute__((address_space(3))) char lds_char;
-typedef __attribute__((address_space(3))) void lds_void;
-
-struct WParams {
-    const float* X;       // gathered activation (x forward, dy for dgrad), NHWC with channel stride ldx
-    const float* U;       // transformed filter image [Kout / 64][Cin / 8][16][64][8]
-    float* D;             // destination, NHWC with channel stride ldd
-    float* D2;            // optional second output (activation before a post-activation residual add)
-    const float* bias;    // [Kout] or null
-    const float* res;     // residual / accumulate tensor (destination-shaped) or null
-    const float* mask;    // activation-output tensor for act' (destination-shaped) or null
-    float* partial;       // nsplit > 1: [nsplit][N * H * W][Kout] pre-epilogue partial sums (one per input-channel range)
-    int nsplit, cps;      // input-channel splits, chunks per split
-    int N, H, W, Cin, Kout;
-    int ldx, ldd, ldres, ldmask, ldd2;
-    int T, THW, TW;       // tiles in the batch, per image, per tile row
-    int nch;              // Cin / 8
-    int mtiles, ntiles;
-    int act; float alpha; int res_post;
-    unsigned x_bytes, u_bytes;
-    unsigned mul_thw, shr_thw, mul_tw, shr_tw, mul_th, shr_th;
-    int xmajor;           // workgroup order: 1 activation-major, 0 filter-major
-    unsigned long long* trace;   // dev aid (dpig_debug_wino_trace): 8 s_memtime stamps per workgroup, or null
-};
-
-__device__ __forceinline__ int fast_div(int n, unsigned mul, unsigned shr) {
-    return mul ? (int)(__umulhi((unsigned)n, mul) >> shr) : n;
-}
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
-}
-template <int N>
-__device__ __forceinline__ void wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-// Fused epilogue on 4 consecutive channels of one output pixel (the fp32 family's epi_vec4 without its split-K / replicate / class forms)
-__device__ __forceinline__ void epi4(const WParams& p, long pix, int col, f32x4 v, f32x4 bv) {
-    v += bv;
-    f32x4 rv = {0.f, 0.f, 0.f, 0.f};
-    if (p.res) rv = *reinterpret_cast<const f32x4*>(p.res + pix * p.ldres + col);
-    if (p.res && !p.res_post) v += rv;
-    if (p.mask) {
-        const f32x4 mv = *reinterpret_cast<const f32x4*>(p.mask + pix * p.ldmask + col);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] *= act_grad(mv[e], p.act, p.alpha);
-    } else {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = act_apply(v[e], p.act, p.alpha);
-    }
-    if (p.D2) *reinterpret_cast<f32x4*>(p.D2 + pix * p.ldd2 + col) = v;
-    if (p.res && p.res_post) v += rv;
-    *reinterpret_cast<f32x4*>(p.D + pix * p.ldd + col) = v;
-}
-
 typedef const __attribute__((address_space(3))) f32x4 lds_cf4_t;
 // A workgroup's fused epilogue: thread = (16-byte channel group cg = tid % 16, staged rows tid / 16 + 32 k2 of the four 2 x 2 sub-pixel
 // images), i.e. the four pixels of two tiles; pix0[k2] = the tile's top-left output pixel (ok[k2]: the tile exists).  All 16 LDS reads
@@ -977,7 +919,15 @@ __global__ __launch_bounds__(256) void wino_filter_jobs_kernel(const DpigWinoFil
     }
 }
 
+int launch_reduce(const WParams& p, hipStream_t st) {
+    const long total = (long)p.N * p.H * p.W * (p.Kout / 4);
+    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(wino_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+    return check_launch("wino_reduce_kernel");
+}
+
 static unsigned long long* g_trace = nullptr;
+unsigned long long* trace_buffer() { return g_trace; }
 static int g_mode = -1;            // 0 never, 1 where the cost model says it pays (default), 2 wherever legal (tests)
 static void init_mode() {
     if (g_mode >= 0) return;
@@ -1082,10 +1032,7 @@ static int launch(const DpigConvDesc* d, const float* in, const float* U, const 
         rc = check_launch("wino_kernel");
     }
     if (rc || p.nsplit == 1) return rc;
-    const long total = (long)d->N * d->H * d->W * (kout / 4);
-    const int blocks = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
-    hipLaunchKernelGGL(wino_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
-    return check_launch("wino_reduce_kernel");
+    return launch_reduce(p, st);
 }
 
 // ---- filter-gradient plan: splits over the tile axis so that (C / 64)(K / 64) S workgroups fill whole rounds of the chip -----------

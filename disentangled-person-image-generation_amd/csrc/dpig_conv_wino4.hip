@@ -1,0 +1,623 @@
+// Winograd F(4x4, 3x3) convolution on the fp32 matrix pipe (gfx950): the large-map companion of dpig_conv_wino.hip's F(2x2, 3x3).
+//
+// A 4 x 4 output tile of a 3 x 3 stride-1 SAME conv comes from a 6 x 6 input patch with 36 multiplies per (input channel, output
+// channel) instead of 144:  Y = A^T [ (G g G^T) o (B^T d B) ] A  with the matrices of Lavin & Gray (interpolation points 0, +-1, +-2,
+// inf) -- 4x fewer matrix-pipe FLOPs than the direct kernels, 1.78x fewer than F(2x2, 3x3).  The price is numerical (the transforms
+// multiply by up to 8 / 5 / 1/24: errors of a few 1e-6 of the largest activation instead of a few 1e-7; scripts/f43_numerics.py holds
+// every golden activation of the full-width model to 6.2e-6 with this form on all maps whose sides are multiples of 4, bar 1e-4) and
+// structural: 36 position GEMMs  M_p[tile, k] = sum_c V_p[tile, c] U_p[c, k]  need 36 accumulator blocks, so a workgroup owns 32 tiles
+// (512 output pixels, a block of BW x 32 / BW tiles on the stack of all images' tile rows) x 64 output channels:
+//   * eight waves = 4 position groups (the 3 x 3 sub-squares of the 6 x 6 position grid) x 2 channel halves; a wave holds nine
+//     32 x 32 accumulator blocks of v_mfma_f32_32x32x2_f32 (144 registers), two waves per SIMD, one workgroup per CU (persistent);
+//   * no two waves share a filter fragment (one tile block per workgroup), so the transformed filter U never touches LDS: the image
+//     dpig_wino4_filter_transform leaves is in FRAGMENT order ([column block][chunk][position][channel half][lane][4 floats]) and a
+//     wave's fragment of (position, chunk) is ONE coalesced 1-KB buffer load straight into the MFMA's A registers, re-issued for chunk
+//     c + 1 the moment position p of chunk c has been multiplied (a full chunk, ~4600 cycles, of latency cover; 36 registers);
+//   * the block's raw pixels of a chunk of 8 input channels ((4 BW + 2) x (128 / BW + 2) x 32 bytes) are gathered once by LDS-DMA two
+//     chunks ahead; B^T d B runs in two wave-private passes over LDS: pass A, thread = (tile, channel quad, patch column), transforms
+//     its column of 6 rows and writes a scratch row; pass B, thread = (tile, channel quad, transform row), reads that row's 6 columns,
+//     transforms them and writes six 16-byte rows of V.  (One thread per full 6 x 6 patch would hold 36 float4; one thread per
+//     transform row would read 4 patch rows = 24 float4 from LDS instead of 6 + 6.)  Six of every eight lanes work in both passes;
+//   * the output transform A^T M A is linear in the positions: each wave transforms its own 3 x 3 sub-square (register arithmetic
+//     with wave-uniform coefficients) into a partial 4 x 4 tile; the four partials meet in LDS one output row at a time (4 x 32 KB
+//     staging) on their way into the family's fused epilogue (bias, activation, residual, second output, dgrad's (. + accum) act').
+// dgrad is the same kernel on the image of the rotated / transposed filter, as in the F(2x2, 3x3) family.  The filter gradient stays on
+// F(3x3, 2x2) / the direct kernels.
+//
+// LDS (154 KB): raw[2] (21 KB each) | V[2] (36 positions x (32 rows x 32 B + 16), 36.6 KB each) | scratch (8 waves x 4.9 KB) | zero slot;
+// the staging images of the output transform reuse the front of it.  V's position planes are 1040 bytes apart so that the six
+// transform rows a 16-lane store group covers (6 planes = 6240 bytes = 24 banks apart) fall on disjoint banks; the scratch strides
+// (96 bytes per row, 624 per item) keep both passes conflict-free (16-lane groups: two items x six lanes).
+#include "dpig_wino_common.h"
+
+namespace dpig {
+namespace wino4 {
+
+using wino::WParams;
+using wino::lds_char;
+using wino::lds_void;
+using wino::OOB;
+using wino::fast_div;
+using wino::make_rsrc;
+using wino::wait_vm;
+using wino::epi4;
+
+constexpr int KB = 64;                        // output channels per workgroup
+constexpr int CH = 8;                         // reduction channels per chunk
+constexpr int TB = 32;                        // 4 x 4 output tiles per workgroup
+constexpr int PS = TB * CH * 4 + 16;          // bytes between position planes of V
+constexpr int VB = 36 * PS;                   // one V buffer
+constexpr int RAW_PIECES = 21, RAWB = RAW_PIECES * 1024;
+constexpr int T_XS = 96, T_IT = 624, T_WAVE = 8 * T_IT;
+constexpr int RAW_OFF = 0, V_OFF = 2 * RAWB, T_OFF = V_OFF + 2 * VB, ZERO_OFF = T_OFF + 8 * T_WAVE, SMEM = ZERO_OFF + 64;
+constexpr int EP_ROW = KB * 4 + 16;           // staging: bytes per (partial, pixel column, tile) row of 64 channels (+16: conflict-free stores)
+constexpr int UPOS = 2048;                    // bytes of one (chunk, position) of the filter image: 64 channels x 8
+constexpr int UCHUNK = 36 * UPOS;
+static_assert(16 * TB * EP_ROW <= ZERO_OFF && SMEM <= 163840 && (V_OFF % 16) == 0 && (T_OFF % 16) == 0, "LDS plan");
+
+typedef __attribute__((address_space(3))) f32x4 lds_f4;
+typedef const __attribute__((address_space(3))) f32x4 lds_cf4;
+
+// B^T of F(4, 3) applied along one axis:  [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1],
+// in three parts of two results each (the k-loop spreads them over three of its steps); every result leaves through
+// `out(index, value)` as soon as it exists (the callers store it: no second set of six registers)
+__device__ __forceinline__ f32x4 fma4(f32x4 a, float b, f32x4 c) { return __builtin_elementwise_fma(a, f32x4{b, b, b, b}, c); }
+template <int PART, class F>
+__device__ __forceinline__ void bt6(const f32x4 (&d)[6], F&& out) {
+    if (PART == 0) {
+        out(0, fma4(d[0], 4.f, fma4(d[2], -5.f, d[4])));
+        out(5, fma4(d[1], 4.f, fma4(d[3], -5.f, d[5])));
+    } else if (PART == 1) {
+        const f32x4 a = fma4(d[2], -4.f, d[4]);
+        const f32x4 b = fma4(d[1], -4.f, d[3]);
+        out(1, a + b);
+        out(2, a - b);
+    } else {
+        const f32x4 c = d[4] - d[2];
+        const f32x4 e = d[3] - d[1];
+        out(3, fma4(e, 2.f, c));
+        out(4, fma4(e, -2.f, c));
+    }
+}
+
+// A^T of F(4, 3): [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+__device__ __forceinline__ float at_coef(int y, int xi) {
+    // (wave-uniform arguments: scalar selects)
+    if (xi == 0) return y == 0 ? 1.f : 0.f;
+    if (xi == 5) return y == 3 ? 1.f : 0.f;
+    const float mag = (xi >= 3) ? (y == 0 ? 1.f : y == 1 ? 2.f : y == 2 ? 4.f : 8.f) : 1.f;
+    const bool neg = ((xi == 2) | (xi == 4)) & ((y & 1) != 0);
+    return neg ? -mag : mag;
+}
+
+template <int BW, int KO = 0>   // KO: knock-out bits for timing experiments (DPIG_WINO4_KO; results are wrong): 1 no transforms, 2 no filter loads, 4 no raw gather, 8 no MFMAs
+__device__ __forceinline__ void wino4_body(const WParams& p, lds_char* const L, const int vb) {
+    constexpr int BH = TB / BW, RW = 4 * BW + 2, RH = 4 * BH + 2, RPIX = RW * RH, PIECES = (2 * RPIX + 63) / 64;
+    static_assert(PIECES <= RAW_PIECES && PIECES > 16, "raw gather plan");
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, half = lane >> 5;
+    const int bid = xcd_remap(vb, p.mtiles * p.ntiles * p.nsplit);
+    const int sp = bid / (p.mtiles * p.ntiles), tile = bid - sp * (p.mtiles * p.ntiles);
+    const int nt = p.xmajor ? tile % p.ntiles : tile / p.mtiles, mt = p.xmajor ? tile / p.ntiles : tile - nt * p.mtiles;
+    const int n0 = nt * KB;
+    const int cb = sp * p.cps, ce = min(cb + p.cps, p.nch);
+    const int bcols = p.TW / BW;
+    const int brow = mt / bcols, bcol = mt - brow * bcols;
+    const int R0 = BH * brow, C0 = BW * bcol;                         // first stacked tile row / tile column of the block
+    auto stamp = [&](int slot) {
+        if (p.trace && tid == 0) {
+            p.trace[(long)vb * 8 + slot] = __builtin_amdgcn_s_memtime();
+            if (slot == 0) p.trace[(long)vb * 8 + 5] = __builtin_amdgcn_s_memrealtime();
+            if (slot == 4) p.trace[(long)vb * 8 + 6] = __builtin_amdgcn_s_memrealtime();
+        }
+    };
+    stamp(0);
+    const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.X, p.x_bytes);
+    const __amdgpu_buffer_rsrc_t rsU = make_rsrc(p.U, p.u_bytes);
+    if (tid < 4) *(lds_f4*)(L + ZERO_OFF + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- raw-gather role: piece ids wave, wave + 8, wave + 16 (< PIECES); lane slot s = 64 id + lane = (raw pixel s / 2, 16-byte half s & 1)
+    int g_voff[3];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) {
+        const int s = (wave + 8 * k) * 64 + lane;
+        const int idx = s >> 1, hq = s & 1;
+        const int row = idx / RW, colr = idx - row * RW;
+        const int g = 4 * R0 - 1 + row, x = 4 * C0 - 1 + colr;       // stacked pixel row, column
+        const bool ok = (idx < RPIX) & ((unsigned)g < (unsigned)(p.N * p.H)) & ((unsigned)x < (unsigned)p.W);
+        g_voff[k] = ok ? ((g * p.W + x) * p.ldx + hq * 4) * 4 : (int)OOB;
+    }
+    auto dmaRaw = [&](int chunk, int slot) {
+        const int dead = chunk < ce ? 0 : (int)OOB;
+        const int so = chunk < ce ? chunk * (CH * 4) : 0;
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+            if (k < 2 || wave + 16 < PIECES)
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void*)(L + RAW_OFF + slot * RAWB + (wave + 8 * k) * 1024), 16,
+                                                         g_voff[k] | dead, so, 0, 0);
+    };
+    // ---- input-transform role: item = (tile tl = 4 wave + lane / 16, channel quad q = (lane / 8) & 1), sub-index j = lane % 8 (< 6 works):
+    // pass A: patch column j; pass B: transform row xi = j
+    const int j = min(lane & 7, 5), it = lane >> 3;                   // (lanes 6 and 7 of an item repeat lane 5: no EXEC games, counted waits)
+    const int tl = 4 * wave + (it >> 1), q = it & 1;
+    const int bty = tl / BW, btx = tl - bty * BW;
+    int a_mid, a_top[2], a_bot[2];                                    // LDS byte addresses of patch rows 1..4 (slot 0), row 0 and row 5 (per slot; the zero slot where the row is padding)
+    {
+        const int R = R0 + bty;
+        const int n = fast_div(R, p.mul_th, p.shr_th);
+        const int ty = R - n * (p.H >> 2);
+        const int base = ((4 * bty) * RW + 4 * btx + j) * 32 + q * 16;
+        a_mid = RAW_OFF + base;
+        const bool top_ok = ty > 0, bot_ok = 4 * ty + 4 < p.H;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            a_top[s] = top_ok ? RAW_OFF + s * RAWB + base : ZERO_OFF + q * 16;
+            a_bot[s] = bot_ok ? RAW_OFF + s * RAWB + base + 5 * RW * 32 : ZERO_OFF + q * 16;
+        }
+    }
+    const int t_base = T_OFF + wave * T_WAVE + it * T_IT;
+    const int t_wr = t_base + j * 16;                                  // pass A: + xi * T_XS
+    const int t_rd = t_base + j * T_XS;                                // pass B: + column * 16
+    const int v_wr = V_OFF + j * PS + tl * (CH * 4) + ((q ^ ((tl >> 3) & 1)) << 4);   // pass B: + 6 nu * PS (+ buffer): plane of position (xi, nu) = 6 nu + xi
+    f32x4 d[6];
+    auto readA = [&](int slot) {
+        d[0] = *(lds_cf4*)(L + a_top[slot]);
+#pragma unroll
+        for (int r = 1; r < 5; ++r) d[r] = *(lds_cf4*)(L + a_mid + slot * RAWB + r * RW * 32);
+        d[5] = *(lds_cf4*)(L + a_bot[slot]);
+    };
+    auto passA = [&](auto PART) {                                       // column transform -> scratch rows
+        bt6<decltype(PART)::value>(d, [&](int xi, f32x4 v) { *(lds_f4*)(L + t_wr + xi * T_XS) = v; });
+    };
+    auto readB = [&]() {
+#pragma unroll
+        for (int s = 0; s < 6; ++s) d[s] = *(lds_cf4*)(L + t_rd + s * 16);
+    };
+    auto passB = [&](int buf, auto PART) {                              // row transform -> V rows
+        bt6<decltype(PART)::value>(d, [&](int nu, f32x4 v) { *(lds_f4*)(L + v_wr + buf * VB + (6 * nu) * PS) = v; });
+    };
+    // ---- MFMA role: wave = (position group pg = (a, b): rows 3 a .. 3 a + 2, columns 3 b .. 3 b + 2 of the 6 x 6 grid; channel half wc) ------
+    const int pg = wave >> 1, wc = wave & 1;
+    const int pa = pg >> 1, pb = pg & 1;
+    const int pos0 = 18 * pa + 3 * pb;                                 // the wave's first position; its pp-th: pos0 + 6 (pp / 3) + pp % 3
+    const int fv = V_OFF + (18 * pb + 3 * pa) * PS + l31 * (CH * 4) + ((half ^ ((l31 >> 3) & 1)) << 4);   // (V planes: 6 nu + xi)
+    const int u_voff = pos0 * UPOS + wc * 1024 + lane * 16;
+    const int u_base = (nt * p.nch) * UCHUNK;
+    f32x4 u[9];
+    auto loadU = [&](int chunk, int pp) {
+        const int dead = chunk < ce ? 0 : (int)OOB;
+        const int so = u_base + (chunk < ce ? chunk : 0) * UCHUNK;
+        u[pp] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, (u_voff + (6 * (pp / 3) + pp % 3) * UPOS) | dead, so, 0));
+    };
+    f32x16 acc[9];
+#pragma unroll
+    for (int pp = 0; pp < 9; ++pp)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[pp][e] = 0.f;
+
+    // ---- prologue: raw pixels of chunks 0 and 1 gathered, the filter fragments of chunk 0 loaded, chunk 0 transformed -----------------------
+    dmaRaw(cb, 0);
+    dmaRaw(cb + 1, 1);
+#pragma unroll
+    for (int pp = 0; pp < 9; ++pp) loadU(cb, pp);
+    wait_vm<0>();
+    __syncthreads();
+    readA(0);
+    passA(std::integral_constant<int, 0>{});
+    passA(std::integral_constant<int, 1>{});
+    passA(std::integral_constant<int, 2>{});
+    readB();
+    passB(0, std::integral_constant<int, 0>{});
+    passB(0, std::integral_constant<int, 1>{});
+    passB(0, std::integral_constant<int, 2>{});
+    __syncthreads();                                 // V slot 0 complete, raw slot 0 free
+    stamp(1);
+    // chunk c = nine steps (the wave's positions): {V fragment of the next position, 4 MFMAs, the filter fragment of this position for
+    // chunk c + 1, a slice of the staging work}.  Slices: step 0 the raw gather of chunk c + 2 (into the raw slot chunk c was transformed
+    // from), 1 pass A's LDS reads of chunk c + 1, 2-4 its transform + scratch stores (two rows per step), 5 pass B's reads, 6-8 its
+    // transform + V stores (with all of a pass in one step the step outlasted the other wave's MFMAs: 6670 cycles per chunk against 5220
+    // without the transforms).
+    auto body = [&](int c, auto PAR) {
+        constexpr int buf = decltype(PAR)::value, oth = buf ^ 1;
+        lds_char* const Vb = L + buf * VB + fv;
+        f32x4 fb[2];
+        fb[0] = *(lds_cf4*)(Vb);
+#pragma unroll
+        for (int pp = 0; pp < 9; ++pp) {
+            // the NEXT position's V fragment goes out before this position's MFMAs (pinned: left to itself the scheduler issues it after
+            // them, and its latency, behind the slice's slow 16-byte stores, lands on the next step)
+            if (pp < 8) fb[(pp + 1) & 1] = *(lds_cf4*)(Vb + (6 * ((pp + 1) % 3) + (pp + 1) / 3) * PS);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+                if (!(KO & 8)) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[pp][s4], fb[pp & 1][s4], acc[pp], 0, 0, 0);
+            if (pp == 0 && !(KO & 4)) dmaRaw(c + 2, buf);
+            if (!(KO & 2)) loadU(c + 1, pp);
+            if (!(KO & 1)) {
+                if (pp == 1) readA(oth);
+                if (pp == 2) passA(std::integral_constant<int, 0>{});
+                if (pp == 3) passA(std::integral_constant<int, 1>{});
+                if (pp == 4) passA(std::integral_constant<int, 2>{});
+                if (pp == 5) readB();
+                if (pp == 6) passB(oth, std::integral_constant<int, 0>{});
+                if (pp == 7) passB(oth, std::integral_constant<int, 1>{});
+                if (pp == 8) passB(oth, std::integral_constant<int, 2>{});
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        wait_vm<9>();                                // the raw pieces of chunk c + 2 are home (only the nine filter fragments are younger)
+        __syncthreads();                             // + V slot `oth` written, every wave done reading V slot `buf` and raw slot `oth`
+    };
+    for (int c = cb; c < ce; c += 2) {
+        body(c, std::integral_constant<int, 0>{});
+        if (c + 1 < ce) body(c + 1, std::integral_constant<int, 1>{});
+    }
+    wait_vm<0>();
+    stamp(2);
+
+    // ---- output transform, one output row y of the 4 x 4 tiles at a time.  A lane holds element (tile l31, channel 32 wc + 8 g + 4 half + e)
+    // of its nine positions M[3 a + i][3 b + jj]; its partial of Y[y][x] is  sum_i AT[y][3 a + i] sum_jj AT[x][3 b + jj] M[i][jj].
+    // Staging: [partial pg][x][tile][64 channels]; the epilogue threads (16-byte channel group cg = tid % 16, tile tid / 16) add the four
+    // partials in fixed order and run ONE of three workgroup-uniform paths on the row's four pixels.
+    float cc[4][3];
+#pragma unroll
+    for (int x = 0; x < 4; ++x)
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj) cc[x][jj] = at_coef(x, 3 * pb + jj);
+    const int cg = tid & 15, tloc = tid >> 4, col = n0 + 4 * cg;
+    const int ebty = tloc / BW, ebtx = tloc - ebty * BW;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (p.bias && p.nsplit == 1) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
+#pragma unroll
+    for (int y = 0; y < 4; ++y) {
+        float cr[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) cr[i] = at_coef(y, 3 * pa + i);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            f32x4 P[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int rr = 4 * g + e;
+                float r3[3];
+#pragma unroll
+                for (int jj = 0; jj < 3; ++jj) r3[jj] = cr[0] * acc[jj][rr] + cr[1] * acc[3 + jj][rr] + cr[2] * acc[6 + jj][rr];
+#pragma unroll
+                for (int x = 0; x < 4; ++x) P[x][e] = cc[x][0] * r3[0] + cc[x][1] * r3[1] + cc[x][2] * r3[2];
+            }
+#pragma unroll
+            for (int x = 0; x < 4; ++x)
+                *(lds_f4*)(L + ((pg * 4 + x) * TB + l31) * EP_ROW + (32 * wc + 8 * g + 4 * half) * 4) = P[x];
+        }
+        __syncthreads();
+        f32x4 v[4];
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+            const lds_char* const s = L + (x * TB + tloc) * EP_ROW + cg * 16;
+            v[x] = (*(lds_cf4*)(s) + *(lds_cf4*)(s + 4 * TB * EP_ROW)) + (*(lds_cf4*)(s + 8 * TB * EP_ROW) + *(lds_cf4*)(s + 12 * TB * EP_ROW));
+        }
+        const long pix = (long)(4 * (R0 + ebty) + y) * p.W + 4 * (C0 + ebtx);
+        if (p.nsplit > 1) {
+            float* const base = p.partial + (long)sp * p.N * p.H * p.W * p.Kout + col;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) *reinterpret_cast<f32x4*>(base + (pix + x) * p.Kout) = v[x];
+        } else if (!p.res && !p.mask && !p.D2) {
+            float* const base = p.D + col;
+            auto plain = [&](auto ACT) {
+#pragma unroll
+                for (int x = 0; x < 4; ++x) {
+                    f32x4 o = v[x] + bv;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = act_apply(o[e], decltype(ACT)::value, p.alpha);
+                    *reinterpret_cast<f32x4*>(base + (pix + x) * p.ldd) = o;
+                }
+            };
+            if (p.act == DPIG_ACT_RELU) plain(std::integral_constant<int, DPIG_ACT_RELU>{});
+            else if (p.act == DPIG_ACT_LRELU) plain(std::integral_constant<int, DPIG_ACT_LRELU>{});
+            else plain(std::integral_constant<int, DPIG_ACT_NONE>{});
+        } else {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) epi4(p, pix + x, col, v[x], bv);
+        }
+        if (y < 3) __syncthreads();                  // the row's staging reads are done before the next row's stores
+        if (y == 0) stamp(3);
+    }
+    stamp(4);
+}
+
+// Persistent launch (as wino_block_kernel): one workgroup per CU, or per item when there are fewer, walking the items.
+template <int BW, int KO = 0>
+__global__ __launch_bounds__(512, 2) void wino4_kernel(const WParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[SMEM];
+    lds_char* const L = (lds_char*)smem;
+    const int total = p.mtiles * p.ntiles * p.nsplit;
+    for (int vb = blockIdx.x; vb < total; vb += gridDim.x) {
+        wino4_body<BW, KO>(p, L, vb);
+        __syncthreads();                              // the last row's staging reads are done before the next item's gather lands
+    }
+}
+
+// ---- filter transform: U = G g G^T, G = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1], of every (input
+// channel, output channel) pair, written in the kernel's fragment order.  One workgroup per (64-channel column block, 8-channel chunk):
+// its 512 transforms are staged in LDS in image order and leave as one contiguous 72-KB run.  `DGRAD`: the transposed conv's filter
+// g'[r][s][k][c] = w[2 - r][2 - s][c][k].  w is HWIO [3][3][C][K].
+__device__ __forceinline__ void g6(float g0, float g1, float g2, float (&o)[6]) {
+    const float s = g0 + g2;
+    o[0] = 0.25f * g0;
+    o[1] = (-1.f / 6.f) * (s + g1);
+    o[2] = (-1.f / 6.f) * (s - g1);
+    const float e = (1.f / 24.f) * g0 + (1.f / 6.f) * g2;
+    o[3] = e + (1.f / 12.f) * g1;
+    o[4] = e - (1.f / 12.f) * g1;
+    o[5] = g2;
+}
+template <bool DGRAD>
+__device__ __forceinline__ void filter4_body(const float* __restrict__ w, float* __restrict__ U, int C, int K, int blk, float* img) {
+    const int cin = DGRAD ? K : C;
+    const int nch = cin / CH;
+    const int kb = blk / nch, chunk = blk - kb * nch;
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int jx = 0; jx < 2; ++jx) {
+        // (m, cc) = (output channel within the block, reduction channel within the chunk); the lanes run along w's fastest axis
+        const int m = DGRAD ? (tid >> 3) + 32 * jx : (tid & 63);
+        const int cc = DGRAD ? (tid & 7) : (tid >> 6) + 4 * jx;
+        const int ko = kb * 64 + m, ci = chunk * CH + cc;
+        float g[3][3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int s = 0; s < 3; ++s)
+                g[r][s] = DGRAD ? w[(((2 - r) * 3 + (2 - s)) * (long)C + ko) * K + ci] : w[((r * 3 + s) * (long)C + ci) * K + ko];
+        float tt[3][6];                                // [filter column s][transform row xi]
+#pragma unroll
+        for (int s = 0; s < 3; ++s) g6(g[0][s], g[1][s], g[2][s], tt[s]);
+        // image order within (chunk, position): [channel half m / 32][k half cc / 4][channel m % 32][cc % 4]
+        float* const o = img + (m >> 5) * 256 + (cc >> 2) * 128 + (m & 31) * 4 + (cc & 3);
+#pragma unroll
+        for (int xi = 0; xi < 6; ++xi) {
+            float uu[6];
+            g6(tt[0][xi], tt[1][xi], tt[2][xi], uu);
+#pragma unroll
+            for (int nu = 0; nu < 6; ++nu) o[(xi * 6 + nu) * 512] = uu[nu];
+        }
+    }
+    __syncthreads();
+    f32x4* const dst = reinterpret_cast<f32x4*>(U + (long)blk * (36 * 512));
+    const f32x4* const src = reinterpret_cast<const f32x4*>(img);
+#pragma unroll
+    for (int i = 0; i < 18; ++i) dst[tid + 256 * i] = src[tid + 256 * i];
+}
+template <bool DGRAD>
+__global__ __launch_bounds__(256) void wino4_filter_kernel(const float* __restrict__ w, float* __restrict__ U, int C, int K) {
+    __shared__ __attribute__((aligned(16))) float img[36 * 512];
+    filter4_body<DGRAD>(w, U, C, K, xcd_remap(blockIdx.x, gridDim.x), img);
+}
+// every filter of a parameter set in one launch (as wino_filter_jobs_kernel; the same job table and block numbering)
+__global__ __launch_bounds__(256) void wino4_filter_jobs_kernel(const DpigWinoFilterJob* __restrict__ jobs, int njobs, int total) {
+    __shared__ __attribute__((aligned(16))) float img[36 * 512];
+    const int lb = xcd_remap(blockIdx.x, 2 * total);
+    const int dir = lb >= total;
+    const int b = lb - dir * total;
+    int cnt = 0;
+    for (int i0 = 0; i0 < njobs; i0 += 256) {
+        const int i = i0 + (int)threadIdx.x;
+        cnt += __syncthreads_count(i < njobs && jobs[i].first_block <= b);
+    }
+    const DpigWinoFilterJob j = jobs[cnt - 1];
+    if (dir) {
+        if (j.u_dgrad) filter4_body<true>(j.w, j.u_dgrad, j.C, j.K, b - j.first_block, img);
+    } else {
+        if (j.u_fwd) filter4_body<false>(j.w, j.u_fwd, j.C, j.K, b - j.first_block, img);
+    }
+}
+
+static int g_mode = -1;            // 0 never, 1 where the cost model says it pays (default), 2 wherever legal (tests)
+static void init_mode() {
+    if (g_mode >= 0) return;
+    const char* e = getenv("DPIG_WINO4");
+    g_mode = e ? atoi(e) : 1;
+}
+
+// block width (tiles) the layer's tile grid can be cut with: BW x 32 / BW tiles on the stack of all images' tile rows; 0: none
+static int block_width(const DpigConvDesc* d) {
+    const int tw = d->W / 4;
+    const long rows = (long)d->N * (d->H / 4);
+    if (tw % 4 == 0 && rows % 8 == 0) return 4;
+    if (tw % 2 == 0 && rows % 16 == 0) return 2;
+    return 0;
+}
+// geometry both entry points share: 3 x 3, stride 1, SAME, sides multiples of 4 with a block form, 16-byte addressable channel vectors
+static bool shape_ok(const DpigConvDesc* d, int cin, int kout, int ld_in, int ld_out) {
+    if (d->R != 3 || d->S != 3 || d->stride != 1 || d->upsample2x || d->res_class || d->split_k > 1) return false;
+    if ((d->H & 3) || (d->W & 3) || d->H < 4 || d->W < 4) return false;
+    if (!block_width(d)) return false;
+    if (cin % CH || kout % KB || (ld_in & 3) || (ld_out & 3)) return false;
+    if (d->pad_t >= 0 && d->pad_t != 1) return false;
+    if (d->pad_l >= 0 && d->pad_l != 1) return false;
+    const long lim = 0x7f000000L;
+    if ((long)d->N * d->H * d->W * ld_in * 4 >= lim || (long)d->N * d->H * d->W * ld_out * 4 >= lim) return false;
+    if ((long)36 * cin * kout * 4 >= lim) return false;
+    return true;
+}
+// One workgroup per CU, whole rounds of 256: a workgroup's life is ~CHUNK_CYCLES per 8-channel chunk (72 MFMAs per SIMD = 4608 of them)
+// + ~FIXED_CYCLES of prologue / output transform / epilogue.  Split plans as in the F(2x2, 3x3) family (partials summed by wino_reduce_kernel).
+constexpr double CHUNK_CYCLES = 5400.0, FIXED_CYCLES = 26000.0;
+struct FPlan { int nsplit, cps; double cycles; };
+static FPlan fwd_plan(const DpigConvDesc* d, int cin, int kout) {
+    const long T = (long)d->N * (d->H / 4) * (d->W / 4);
+    const long wgs1 = (T / TB) * (kout / KB);
+    const int nch = cin / CH;
+    FPlan best = {1, nch, 0.0};
+    static const int force = getenv("DPIG_WINO_SPLIT") ? atoi(getenv("DPIG_WINO_SPLIT")) : 0;       // (A/B switch: 1 = never split)
+    for (int s = 1; s <= 16; ++s) {
+        const int cps = cdiv(nch, s);
+        if (s > 1 && (cps < 6 || cdiv(nch, cps) != s || force == 1)) continue;
+        const long rounds = (wgs1 * s + kNumCU - 1) / kNumCU;
+        double cyc = (double)rounds * ((double)cps * CHUNK_CYCLES + FIXED_CYCLES);
+        if (s > 1) cyc += 8000.0 + 2.0 * s * (double)d->N * d->H * d->W * kout * 4.0 / 1740.0;     // 4 TB/s = 1740 B per cycle
+        if (best.cycles == 0.0 || cyc < best.cycles * 0.97) best = {s, cps, cyc};
+    }
+    return best;
+}
+// Does this form beat what the layer would otherwise run on?  The F(2x2, 3x3) kernel's life is ~5050 cycles per chunk + ~16 k per
+// 256-pixel workgroup (dpig_conv_wino.hip); layers that kernel's own cost model leaves to the direct family are small maps where this
+// form has even fewer workgroups.
+static bool pays(const DpigConvDesc* d, int cin, int kout) {
+    init_mode();
+    if (g_mode == 0) return false;
+    if (g_mode == 2) return true;
+    const long T2 = (long)d->N * (d->H / 2) * (d->W / 2);
+    const long wgs2 = (long)cdiv(T2, 64) * (kout / KB);
+    const double f2 = (double)((wgs2 + kNumCU - 1) / kNumCU) * ((cin / CH) * 5050.0 + 16000.0);
+    return fwd_plan(d, cin, kout).cycles < 0.95 * f2;
+}
+
+static int launch(const DpigConvDesc* d, const float* in, const float* U, const float* bias, const float* res, const float* mask,
+                  float* out, float* out2, int cin, int kout, int ld_in, int ld_out, int act, void* ws, size_t ws_bytes, hipStream_t st) {
+    if (!aligned16(in) || !aligned16(U) || !aligned16(out) || (bias && !aligned16(bias)) || (res && (!aligned16(res) || (d->ldres & 3))) ||
+        (mask && (!aligned16(mask) || (d->ldmask & 3))) || (out2 && (!aligned16(out2) || (d->ldy2 & 3))))
+        return fail(DPIG_EINVAL, "winograd F(4x4) conv: operands must be 16-byte addressable");
+    WParams p = {};
+    p.X = in; p.U = U; p.D = out; p.D2 = out2; p.bias = bias; p.res = res; p.mask = mask;
+    p.N = d->N; p.H = d->H; p.W = d->W; p.Cin = cin; p.Kout = kout;
+    p.ldx = ld_in; p.ldd = ld_out; p.ldres = d->ldres; p.ldmask = d->ldmask; p.ldd2 = d->ldy2;
+    p.TW = d->W / 4; p.THW = (d->H / 4) * p.TW; p.T = d->N * p.THW;
+    p.nch = cin / CH;
+    p.mtiles = p.T / TB; p.ntiles = kout / KB;
+    p.act = act; p.alpha = d->alpha; p.res_post = d->res_after_act;
+    p.x_bytes = (unsigned)((long)d->N * d->H * d->W * ld_in * 4);
+    p.u_bytes = (unsigned)((long)36 * cin * kout * 4);
+    find_divisor(p.THW, &p.mul_thw, &p.shr_thw);
+    find_divisor(p.TW, &p.mul_tw, &p.shr_tw);
+    find_divisor(d->H / 4, &p.mul_th, &p.shr_th);
+    p.trace = wino::trace_buffer();
+    const FPlan pl = fwd_plan(d, cin, kout);
+    p.nsplit = pl.nsplit; p.cps = pl.cps;
+    {   // workgroup order by HBM bytes (as the F(2x2, 3x3) launch)
+        const double xb = (double)d->N * d->H * d->W * cin * 4.0, ub = 36.0 * cin * kout * 4.0;
+        const double filter_major = xb * (p.ntiles < kNumXCD ? p.ntiles : kNumXCD) + ub;
+        const double act_major = xb + ub * (p.mtiles < kNumXCD ? p.mtiles : kNumXCD);
+        static const char* pin = getenv("DPIG_WINO_XMAJOR");
+        p.xmajor = pin ? (atoi(pin) != 0) : (act_major < filter_major);
+    }
+    if (p.nsplit > 1) {
+        const size_t need = (size_t)p.nsplit * d->N * d->H * d->W * kout * sizeof(float);
+        if (!ws || ws_bytes < need || !aligned16(ws)) return fail(DPIG_ENOMEM, "winograd F(4x4) conv workspace too small: have %zu, need %zu", ws_bytes, need);
+        p.partial = static_cast<float*>(ws);
+    }
+    const unsigned items = (unsigned)(p.mtiles * p.ntiles * p.nsplit);
+    static const char* pers = getenv("DPIG_WINO_PERSIST");          // 0: one workgroup per item (measurements)
+    const dim3 pgrid((pers && atoi(pers) == 0) || items <= (unsigned)kNumCU ? items : (unsigned)kNumCU);
+    static const int ko = getenv("DPIG_WINO4_KO") ? atoi(getenv("DPIG_WINO4_KO")) : 0;
+    if (block_width(d) == 2) hipLaunchKernelGGL(wino4_kernel<2>, pgrid, dim3(512), 0, st, p);
+#ifdef DPIG_WINO4_KNOCKOUT
+    else if (ko == 1) hipLaunchKernelGGL((wino4_kernel<4, 1>), pgrid, dim3(512), 0, st, p);
+    else if (ko == 2) hipLaunchKernelGGL((wino4_kernel<4, 2>), pgrid, dim3(512), 0, st, p);
+    else if (ko == 4) hipLaunchKernelGGL((wino4_kernel<4, 4>), pgrid, dim3(512), 0, st, p);
+    else if (ko == 7) hipLaunchKernelGGL((wino4_kernel<4, 7>), pgrid, dim3(512), 0, st, p);
+    else if (ko == 8) hipLaunchKernelGGL((wino4_kernel<4, 8>), pgrid, dim3(512), 0, st, p);
+    else if (ko == 3) hipLaunchKernelGGL((wino4_kernel<4, 3>), pgrid, dim3(512), 0, st, p);
+#endif
+    else hipLaunchKernelGGL(wino4_kernel<4>, pgrid, dim3(512), 0, st, p);
+    (void)ko;
+    const int rc = check_launch("wino4_kernel");
+    if (rc || p.nsplit == 1) return rc;
+    return wino::launch_reduce(p, st);
+}
+
+}  // namespace wino4
+}  // namespace dpig
+
+using namespace dpig;
+
+// Elements (floats) of one F(4x4, 3x3) image of a [3][3][C][K] filter; 0 when the shape has no such form.
+extern "C" size_t dpig_wino4_filter_elems(int C, int K) {
+    if (C <= 0 || K <= 0 || C % 64 || K % 64) return 0;
+    return (size_t)36 * C * K;
+}
+
+// u_fwd / u_dgrad (either may be null): images for dpig_conv2d_fwd_wino4 / dpig_conv2d_dgrad_wino4 of the HWIO filter w.
+extern "C" int dpig_wino4_filter_transform(const float* w, int C, int K, float* u_fwd, float* u_dgrad, void* stream) {
+    if (!w || !dpig_wino4_filter_elems(C, K)) return fail(DPIG_EINVAL, "winograd F(4x4) filter transform: C and K must be positive multiples of 64");
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int blocks = (C / 64) * (K / wino4::CH);                // = (K / 64) * (C / 8): the same count in both directions
+    if (u_fwd) hipLaunchKernelGGL(wino4::wino4_filter_kernel<false>, dim3(blocks), dim3(256), 0, st, w, u_fwd, C, K);
+    if (u_dgrad) hipLaunchKernelGGL(wino4::wino4_filter_kernel<true>, dim3(blocks), dim3(256), 0, st, w, u_dgrad, C, K);
+    return check_launch("wino4_filter_kernel");
+}
+
+// A whole parameter set in one launch: the job table of dpig_wino_filter_jobs_plan (same block numbering), u_fwd / u_dgrad holding
+// dpig_wino4_filter_elems floats each.
+extern "C" int dpig_wino4_filter_transform_jobs(const DpigWinoFilterJob* jobs_dev, int njobs, int total_blocks, void* stream) {
+    if (!jobs_dev || njobs <= 0 || total_blocks <= 0) return fail(DPIG_EINVAL, "winograd F(4x4) filter jobs: empty or unplanned job list");
+    hipLaunchKernelGGL(wino4::wino4_filter_jobs_kernel, dim3(2 * (unsigned)total_blocks), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       jobs_dev, njobs, total_blocks);
+    return check_launch("wino4_filter_jobs_kernel");
+}
+
+// 1: dpig_conv2d_fwd_wino4 (which = 0) / dpig_conv2d_dgrad_wino4 (which = 1) accepts this descriptor AND is expected to beat the
+// F(2x2, 3x3) kernel (DPIG_WINO4=2 / dpig_conv_wino4_set_mode(2): wherever legal); 0 otherwise.  No device work.
+extern "C" int dpig_conv2d_wino4_eligible(const DpigConvDesc* d, int which) {
+    if (!d || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->K <= 0 || d->compute != DPIG_COMPUTE_F32) return 0;
+    const bool dg = which == 1;
+    const int cin = dg ? d->K : d->C, kout = dg ? d->C : d->K;
+    const int ld_in = dg ? d->ldy : d->ldx, ld_out = dg ? d->ldx : d->ldy;
+    if (d->C % 64 || d->K % 64) return 0;                       // (one transformed image pair serves both directions)
+    if (!wino4::shape_ok(d, cin, kout, ld_in, ld_out)) return 0;
+    return wino4::pays(d, cin, kout) ? 1 : 0;
+}
+
+extern "C" int dpig_conv_wino4_set_mode(int mode) {
+    if (mode < 0 || mode > 2) return fail(DPIG_EINVAL, "winograd F(4x4) mode out of range");
+    wino4::g_mode = mode;
+    return DPIG_OK;
+}
+
+extern "C" int dpig_conv_wino4_get_mode(void) {
+    wino4::init_mode();
+    return wino4::g_mode;
+}
+
+// Workspace of dpig_conv2d_fwd_wino4 (which = 0) / dpig_conv2d_dgrad_wino4 (which = 1): the partial outputs of a split plan, 0 for most layers.
+extern "C" size_t dpig_conv2d_wino4_workspace_bytes(const DpigConvDesc* d, int which) {
+    if (!d || d->N <= 0 || d->H <= 0 || d->W <= 0 || d->C <= 0 || d->K <= 0) return 0;
+    const bool dg = which == 1;
+    const int cin = dg ? d->K : d->C, kout = dg ? d->C : d->K;
+    if (d->C % 64 || d->K % 64 || !wino4::shape_ok(d, cin, kout, dg ? d->ldy : d->ldx, dg ? d->ldx : d->ldy)) return 0;
+    const wino4::FPlan pl = wino4::fwd_plan(d, cin, kout);
+    return pl.nsplit > 1 ? (size_t)pl.nsplit * d->N * d->H * d->W * kout * sizeof(float) : 0;
+}
+
+// y = act(conv3x3_SAME(x, w) + bias + residual)  (or act(..) + residual with res_after_act, y_act receiving the activation) through the
+// F(4x4, 3x3) image u_fwd of dpig_wino4_filter_transform.  Same descriptor and epilogue semantics as dpig_conv2d_fwd.
+extern "C" int dpig_conv2d_fwd_wino4(const DpigConvDesc* d, const float* x, const float* u_fwd, const float* bias, const float* residual,
+                                     float* y, float* y_act, void* ws, size_t ws_bytes, void* stream) {
+    int pt, pl, Ho, Wo;
+    int rc = resolve_desc(d, &pt, &pl, &Ho, &Wo);
+    if (rc) return rc;
+    if (!x || !u_fwd || !y) return fail(DPIG_EINVAL, "null tensor pointer");
+    if (!wino4::shape_ok(d, d->C, d->K, d->ldx, d->ldy) || d->C % 64) return fail(DPIG_EINVAL, "winograd F(4x4) conv: unsupported shape");
+    if (residual && d->ldres < d->K) return fail(DPIG_EINVAL, "ldres < K");
+    if (y_act && d->ldy2 < d->K) return fail(DPIG_EINVAL, "ldy2 < K");
+    return wino4::launch(d, x, u_fwd, bias, residual, nullptr, y, y_act, d->C, d->K, d->ldx, d->ldy, d->act, ws, ws_bytes,
+                         static_cast<hipStream_t>(stream));
+}
+
+// dx = (conv_backward_data(dy, w) + accum) * act'(mask) through u_dgrad.  Same semantics as dpig_conv2d_dgrad.
+extern "C" int dpig_conv2d_dgrad_wino4(const DpigConvDesc* d, const float* dy, const float* u_dgrad, const float* accum, const float* mask,
+                                       float* dx, void* ws, size_t ws_bytes, void* stream) {
+    int pt, pl, Ho, Wo;
+    int rc = resolve_desc(d, &pt, &pl, &Ho, &Wo);
+    if (rc) return rc;
+    if (!dy || !u_dgrad || !dx) return fail(DPIG_EINVAL, "null tensor pointer");
+    if (!wino4::shape_ok(d, d->K, d->C, d->ldy, d->ldx) || d->K % 64) return fail(DPIG_EINVAL, "winograd F(4x4) conv: unsupported shape");
+    if (accum && d->ldres < d->C) return fail(DPIG_EINVAL, "ldres < C");
+    if (mask && d->ldmask < d->C) return fail(DPIG_EINVAL, "ldmask < C");
+    DpigConvDesc e = *d;
+    e.res_after_act = 0; e.ldy2 = 0;
+    return wino4::launch(&e, dy, u_dgrad, nullptr, accum, mask, dx, nullptr, d->K, d->C, d->ldy, d->ldx, mask ? d->act : DPIG_ACT_NONE,
+                         ws, ws_bytes, static_cast<hipStream_t>(stream));
+}

@@ -294,6 +294,9 @@ def wino_images(w, want_fwd=True, want_dgrad=True):
     """(u_fwd, u_dgrad) transformed images of an HWIO [3,3,C,K] filter for dpig_conv2d_fwd_wino / _dgrad_wino
     (dpig_wino_filter_transform), or None when the filter has no Winograd form.  Parameters owned by a trainer carry persistent
     images refreshed after every optimizer step (`w._dpig_wino`, WinoFilters); any other tensor gets them made on the spot."""
+    use = getattr(w, "_dpig_wino_use", None)
+    if use is not None:
+        use.add(2)
     im = getattr(w, "_dpig_wino", None)
     if im is not None:
         return im
@@ -310,6 +313,30 @@ def wino_images(w, want_fwd=True, want_dgrad=True):
     return uf, ud
 
 
+def wino4_images(w, want_fwd=True, want_dgrad=True):
+    """(u_fwd, u_dgrad) F(4x4, 3x3) images of an HWIO [3,3,C,K] filter for dpig_conv2d_fwd_wino4 / _dgrad_wino4, or None when the
+    filter has no such form.  A parameter owned by a WinoFilters set gets persistent images on its first request (the set refreshes
+    them after every optimizer step from then on); any other tensor gets them made on the spot."""
+    im = getattr(w, "_dpig_wino4", None)
+    if im is not None:
+        return im
+    if w.dim() != 4 or w.shape[0] != 3 or w.shape[1] != 3 or w.dtype != F32 or not w.is_cuda:
+        return None
+    C, K = int(w.shape[2]), int(w.shape[3])
+    n = lib().dpig_wino4_filter_elems(C, K)
+    if n == 0:
+        return None
+    owner = getattr(w, "_dpig_wino_owner", None)
+    owner = owner() if owner is not None else None
+    if owner is not None:
+        return owner.want4(w)
+    w = w.contiguous()
+    uf = torch.empty(n, dtype=F32, device=w.device) if want_fwd else None
+    ud = torch.empty(n, dtype=F32, device=w.device) if want_dgrad else None
+    check(lib().dpig_wino4_filter_transform(ptr(w), C, K, ptr(uf), ptr(ud), stream_ptr()), "wino4_filter_transform")
+    return uf, ud
+
+
 class WinoFilterJob(ctypes.Structure):
     """DpigWinoFilterJob (include/dpig_hip.h)."""
     _fields_ = [("w", ctypes.c_void_p), ("u_fwd", ctypes.c_void_p), ("u_dgrad", ctypes.c_void_p), ("C", ctypes.c_int32), ("K", ctypes.c_int32),
@@ -317,8 +344,12 @@ class WinoFilterJob(ctypes.Structure):
 
 
 class WinoFilters(object):
-    """Persistent Winograd images (forward + dgrad) of every 3x3 filter in `params` that has them, in ONE allocation, attached to the
-    parameters as `_dpig_wino`; `refresh()` re-derives them from the fp32 masters (after every optimizer step, like FilterShadows)."""
+    """Persistent Winograd images (forward + dgrad) of every 3x3 filter in `params` that has them, attached to the parameters;
+    `refresh()` re-derives them from the fp32 masters (after every optimizer step, like FilterShadows).  The F(2x2, 3x3) images
+    (`_dpig_wino`) exist from the start, in one allocation; a filter's F(4x4, 3x3) images (`_dpig_wino4`, 2.25x the size) are made
+    when a layer first asks for them (`want4`: the library's cost model decides per layer shape, and only the conv call knows the
+    shape).  After the set's first optimizer step -- every layer has run forward and backward once -- filters that only ever asked
+    for the F(4x4) form leave the F(2x2) refresh (`prune`; a later F(2x2) request for one of them is served on the spot)."""
 
     def __init__(self, params):
         self.params = [p for p in params if p.dim() == 4 and tuple(p.shape[:2]) == (3, 3) and
@@ -328,39 +359,94 @@ class WinoFilters(object):
         total = sum(2 * lib().dpig_wino_filter_elems(int(p.shape[2]), int(p.shape[3])) for p in self.params)
         self.buf = torch.empty(total, dtype=F32, device=self.params[0].device)
         off = 0
+        me = weakref.ref(self)
         for p in self.params:
             n = lib().dpig_wino_filter_elems(int(p.shape[2]), int(p.shape[3]))
             p._dpig_wino = (self.buf[off:off + n], self.buf[off + n:off + 2 * n])
+            p._dpig_wino_owner = me
+            p._dpig_wino_use = set()
+            if hasattr(p, "_dpig_wino4"):
+                delattr(p, "_dpig_wino4")
             off += 2 * n
-        # one launch per refresh for the whole set (dpig_wino_filter_transform_jobs): the job table lives in device memory and names the
-        # masters where they are NOW -- a parameter whose storage moves afterwards (p.data = ...) falls back to per-filter launches
-        jobs = (WinoFilterJob * len(self.params))()
-        for j, p in zip(jobs, self.params):
-            j.w, j.u_fwd, j.u_dgrad = p.data.data_ptr(), p._dpig_wino[0].data_ptr(), p._dpig_wino[1].data_ptr()
-            j.C, j.K = int(p.shape[2]), int(p.shape[3])
-        self.total = lib().dpig_wino_filter_jobs_plan(ctypes.byref(jobs), len(jobs))
-        if self.total <= 0:
-            raise RuntimeError("dpig_wino_filter_jobs_plan refused the filter set")
-        self.masters = [p.data.data_ptr() for p in self.params]
-        self.jobs = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(self.params[0].device)
+        self.p2, self.p4 = list(self.params), []
+        self.refreshes = 0
+        self.pruned = False
+        self.keep = []                  # superseded job tables (a captured graph may still name them)
+        self.plan2 = self._plan(self.p2, "_dpig_wino")
+        self.plan4 = None
         _DERIVED.add(self)
         self.refresh()
+
+    def _plan(self, plist, attr):
+        """One launch per refresh for a whole list (dpig_wino[4]_filter_transform_jobs): the job table lives in device memory and names
+        the masters where they are NOW -- a parameter whose storage moves afterwards (p.data = ...) falls back to per-filter launches."""
+        if not plist:
+            return None
+        jobs = (WinoFilterJob * len(plist))()
+        for j, p in zip(jobs, plist):
+            im = getattr(p, attr)
+            j.w, j.u_fwd, j.u_dgrad = p.data.data_ptr(), im[0].data_ptr(), im[1].data_ptr()
+            j.C, j.K = int(p.shape[2]), int(p.shape[3])
+        total = lib().dpig_wino_filter_jobs_plan(ctypes.byref(jobs), len(jobs))
+        if total <= 0:
+            raise RuntimeError("dpig_wino_filter_jobs_plan refused the filter set")
+        dev_jobs = torch.frombuffer(bytearray(bytes(jobs)), dtype=torch.uint8).to(plist[0].device)
+        return {"jobs": dev_jobs, "n": len(plist), "total": total, "masters": [p.data.data_ptr() for p in plist]}
+
+    def want4(self, p):
+        """Persistent F(4x4, 3x3) images for parameter `p` of this set (made and filled now, refreshed with the set from here on)."""
+        C, K = int(p.shape[2]), int(p.shape[3])
+        n = lib().dpig_wino4_filter_elems(C, K)
+        buf = torch.empty(2 * n, dtype=F32, device=p.device)
+        p._dpig_wino4 = (buf[:n], buf[n:])
+        p._dpig_wino_use.add(4)
+        check(lib().dpig_wino4_filter_transform(ptr(p.data), C, K, ptr(p._dpig_wino4[0]), ptr(p._dpig_wino4[1]), stream_ptr()),
+              "wino4_filter_transform")
+        self.p4.append(p)
+        if self.plan4 is not None:
+            self.keep.append(self.plan4)
+        self.plan4 = self._plan(self.p4, "_dpig_wino4")
+        return p._dpig_wino4
+
+    def prune(self):
+        """Filters whose layers only ever asked for the F(4x4) images leave the F(2x2) refresh."""
+        self.pruned = True
+        drop = [p for p in self.p2 if 4 in p._dpig_wino_use and 2 not in p._dpig_wino_use]
+        if not drop:
+            return 0
+        for p in drop:
+            delattr(p, "_dpig_wino")
+        self.p2 = [p for p in self.p2 if hasattr(p, "_dpig_wino")]
+        self.keep.append(self.plan2)
+        self.plan2 = self._plan(self.p2, "_dpig_wino")
+        return len(drop)
+
+    def _run(self, plan, plist, attr, four):
+        if plan is None:
+            return
+        jobs_fn = lib().dpig_wino4_filter_transform_jobs if four else lib().dpig_wino_filter_transform_jobs
+        one_fn = lib().dpig_wino4_filter_transform if four else lib().dpig_wino_filter_transform
+        if [p.data.data_ptr() for p in plist] == plan["masters"]:
+            check(jobs_fn(ptr(plan["jobs"]), plan["n"], plan["total"], stream_ptr()), "wino_filter_transform_jobs")
+            return
+        for p in plist:
+            uf, ud = getattr(p, attr)
+            check(one_fn(ptr(p.data), int(p.shape[2]), int(p.shape[3]), ptr(uf), ptr(ud), stream_ptr()), "wino_filter_transform")
 
     def refresh(self):
         if not getattr(self, "params", None):
             return
-        if [p.data.data_ptr() for p in self.params] == self.masters:
-            check(lib().dpig_wino_filter_transform_jobs(ptr(self.jobs), len(self.params), self.total, stream_ptr()), "wino_filter_transform_jobs")
-            return
-        for p in self.params:
-            uf, ud = p._dpig_wino
-            check(lib().dpig_wino_filter_transform(ptr(p.data), int(p.shape[2]), int(p.shape[3]), ptr(uf), ptr(ud), stream_ptr()),
-                  "wino_filter_transform")
+        self.refreshes += 1
+        if self.refreshes == 2 and not self.pruned and not torch.cuda.is_current_stream_capturing():
+            self.prune()
+        self._run(self.plan2, self.p2, "_dpig_wino", False)
+        self._run(self.plan4, self.p4, "_dpig_wino4", True)
 
     def detach(self):
         for p in self.params:
-            if hasattr(p, "_dpig_wino"):
-                delattr(p, "_dpig_wino")
+            for a in ("_dpig_wino", "_dpig_wino4", "_dpig_wino_owner", "_dpig_wino_use"):
+                if hasattr(p, a):
+                    delattr(p, a)
 
 
 def get_wino_mode():
@@ -373,6 +459,19 @@ def set_wino_mode(mode):
     Returns the PREVIOUS mode, so that callers restore what was in force (e.g. a process started with the DPIG_WINO=0 kill switch)."""
     prev = get_wino_mode()
     check(lib().dpig_conv_wino_set_mode(int(mode)), "conv_wino_set_mode")
+    return prev
+
+
+def get_wino4_mode():
+    """dpig_conv_wino4_get_mode: the F(4x4, 3x3) mode in force (DPIG_WINO4 in the environment unless set_wino4_mode changed it)."""
+    return int(lib().dpig_conv_wino4_get_mode())
+
+
+def set_wino4_mode(mode):
+    """dpig_conv_wino4_set_mode: 0 never, 1 the library's cost model (default), 2 wherever the layer has the F(4x4, 3x3) form (tests).
+    Returns the PREVIOUS mode."""
+    prev = get_wino4_mode()
+    check(lib().dpig_conv_wino4_set_mode(int(mode)), "conv_wino4_set_mode")
     return prev
 
 
@@ -462,6 +561,16 @@ def conv2d_fwd(x, w, bias=None, stride=1, act=ACT_NONE, alpha=0.2, residual=None
             raise RuntimeError("conv2d: bad out_act tensor")
     d = _desc(N, H, W, C, K, R, S, stride, ldx, ldy, ldres=ldres, act=act, alpha=alpha, upsample2x=upsample2x,
               split_k=split_k, res_after_act=res_after_act, ldy2=ldy2, res_class=res_class)
+    if _WINO[0] and R == 3 and S == 3 and stride == 1 and split_k == 0 and lib().dpig_conv2d_wino4_eligible(ctypes.byref(d), 0) \
+            and _al16(x, out, residual, out_act, bias):
+        im = wino4_images(w, want_dgrad=False)
+        if im is not None:
+            # executed FLOPs: 36 multiplies per (4x4 tile, ci, co) instead of 144
+            wsb, wsn = workspace.get(lib().dpig_conv2d_wino4_workspace_bytes(ctypes.byref(d), 0), x.device)
+            with _Timed("conv_fwd_wino4", 2.0 * N * (H // 4) * (W // 4) * 36 * K * C, (N, H, W, C, K, R, stride, 0)):
+                check(lib().dpig_conv2d_fwd_wino4(ctypes.byref(d), ptr(x), ptr(im[0]), ptr(bias), ptr(residual), ptr(out), ptr(out_act),
+                                                  ptr(wsb), wsn, stream_ptr()), "conv2d_fwd_wino4")
+            return out
     if _WINO[0] and R == 3 and S == 3 and stride == 1 and split_k == 0 and lib().dpig_conv2d_wino_eligible(ctypes.byref(d), 0) \
             and _al16(x, out, residual, out_act, bias):
         im = wino_images(w, want_dgrad=False)
@@ -640,6 +749,15 @@ def conv2d_dgrad(dy, w, in_shape, stride=1, accum=None, mask=None, act=ACT_NONE,
         mask, ldmask = as_nhwc(mask)
     d = _desc(N, H, W, C, K, R, S, stride, ldx, ldy, ldres=ldres, ldmask=ldmask, act=act, alpha=alpha,
               upsample2x=upsample2x, split_k=split_k)
+    if _WINO[0] and R == 3 and S == 3 and stride == 1 and split_k == 0 and lib().dpig_conv2d_wino4_eligible(ctypes.byref(d), 1) \
+            and _al16(dy, out, accum, mask):
+        im = wino4_images(w, want_fwd=False)
+        if im is not None:
+            wsb, wsn = workspace.get(lib().dpig_conv2d_wino4_workspace_bytes(ctypes.byref(d), 1), dy.device)
+            with _Timed("conv_dgrad_wino4", 2.0 * N * (H // 4) * (W // 4) * 36 * K * C, (N, H, W, C, K, R, stride, 0)):
+                check(lib().dpig_conv2d_dgrad_wino4(ctypes.byref(d), ptr(dy), ptr(im[1]), ptr(accum), ptr(mask), ptr(out), ptr(wsb), wsn,
+                                                    stream_ptr()), "conv2d_dgrad_wino4")
+            return out
     if _WINO[0] and R == 3 and S == 3 and stride == 1 and split_k == 0 and lib().dpig_conv2d_wino_eligible(ctypes.byref(d), 1) \
             and _al16(dy, out, accum, mask):
         im = wino_images(w, want_fwd=False)

@@ -51,7 +51,7 @@ extern "C" {
 #define DPIG_ACT_RELU 1
 #define DPIG_ACT_LRELU 2
 
-#define DPIG_VERSION 282
+#define DPIG_VERSION 283
 
 /* Convolution problem, always described from the FORWARD op's point of view. */
 typedef struct DpigConvDesc {
@@ -214,6 +214,31 @@ int dpig_conv2d_wgrad_wino_eligible(const DpigConvDesc* d);
 size_t dpig_conv2d_wgrad_wino_workspace_bytes(const DpigConvDesc* d);
 int dpig_conv2d_wgrad_wino(const DpigConvDesc* d, const float* x, const float* dy, float* dw, float beta, float* db, float beta_b,
                            void* ws, size_t ws_bytes, void* stream);
+
+/* ---- Winograd F(4x4, 3x3) on the fp32 matrix pipe (csrc/dpig_conv_wino4.hip) ------------------------------------------------
+ * The same layers (reference models.py:396-400, 425-427, 458-460, 534-535, 564-565) on maps whose sides are multiples of 4, with 4x fewer
+ * multiplies than direct summation (36 per 4 x 4 output tile and channel pair instead of 144): fp32 tensors, products and sums; the
+ * transforms' larger constants cost about one decimal digit against F(2x2, 3x3) (a few 1e-6 of the largest activation on the golden
+ * model, profiles/r06_f43_numerics.txt; tests/test_wino4_gpu.py holds the kernels to 5e-5 against the fp64 oracle).  Entry points
+ * mirror the F(2x2, 3x3) family's, with their own images (36 C K floats each, in MFMA-fragment order):
+ *   dpig_wino4_filter_elems / dpig_wino4_filter_transform / dpig_wino4_filter_transform_jobs (the job table and plan of
+ *   dpig_wino_filter_jobs_plan serve both families: the block numbering is the same)
+ *   dpig_conv2d_wino4_eligible   the descriptor has the form (3x3, stride 1, H and W multiples of 4, the tile grid cut into blocks of
+ *                                4 x 8 or 2 x 16 tiles on the stack of all images' tile rows, C and K multiples of 64) AND the cost
+ *                                model expects it to beat the F(2x2, 3x3) kernel; dpig_conv_wino4_set_mode / DPIG_WINO4: 0 never,
+ *                                1 cost model (default), 2 wherever legal
+ *   dpig_conv2d_fwd_wino4 / dpig_conv2d_dgrad_wino4 / dpig_conv2d_wino4_workspace_bytes   as their F(2x2, 3x3) namesakes */
+size_t dpig_wino4_filter_elems(int C, int K);
+int dpig_wino4_filter_transform(const float* w, int C, int K, float* u_fwd, float* u_dgrad, void* stream);
+int dpig_wino4_filter_transform_jobs(const DpigWinoFilterJob* jobs_dev, int njobs, int total_blocks, void* stream);
+int dpig_conv2d_wino4_eligible(const DpigConvDesc* d, int which);
+int dpig_conv_wino4_set_mode(int mode);
+int dpig_conv_wino4_get_mode(void);
+size_t dpig_conv2d_wino4_workspace_bytes(const DpigConvDesc* d, int which);
+int dpig_conv2d_fwd_wino4(const DpigConvDesc* d, const float* x, const float* u_fwd, const float* bias, const float* residual,
+                          float* y, float* y_act, void* ws, size_t ws_bytes, void* stream);
+int dpig_conv2d_dgrad_wino4(const DpigConvDesc* d, const float* dy, const float* u_dgrad, const float* accum, const float* mask,
+                            float* dx, void* ws, size_t ws_bytes, void* stream);
 
 /* The thin layers of 'bf16' mode on the vector-ALU kernels (csrc/dpig_thin.hip) with their WIDE tensor stored as bf16;
  * the 3-channel image side, the fp32 HWIO filter and the filter gradient stay fp32:

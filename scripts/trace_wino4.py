@@ -1,0 +1,37 @@
+"""Where a Winograd F(4x4,3x3) workgroup spends its life: s_memtime stamps (dpig_debug_wino_trace) of one launch per layer.
+   python scripts/trace_wino4.py"""
+import ctypes, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from dpig_amd import hip_ops as H
+dev = torch.device("cuda:0")
+lib = H.lib()
+lib.dpig_debug_wino_trace.argtypes = [ctypes.c_void_p]
+lib.dpig_debug_wino_trace.restype = ctypes.c_int
+g = torch.Generator(device=dev).manual_seed(0)
+H.set_compute("f32w"); H.set_wino4_mode(2)
+print("%-22s %6s %5s | %9s %9s %9s %9s | %9s %8s | %s" % ("layer", "items", "nch", "prologue", "loop", "outxf y0", "rows 1-3", "total", "cyc/chunk", "span of all items / sum"))
+for name, N, Hh, W, C in [("C128 128x64", 16, 128, 64, 128), ("C128 48x48", 112, 48, 48, 128), ("C256 128x64", 16, 128, 64, 256), ("C256 24x24", 112, 24, 24, 256),
+                          ("C512 64x32", 16, 64, 32, 512), ("C768 32x16", 16, 32, 16, 768)]:
+    x = torch.rand((N, Hh, W, C), device=dev, generator=g) * 2 - 1
+    w = (torch.rand((3, 3, C, C), device=dev, generator=g) * 2 - 1) * 0.02
+    b = torch.rand((C,), device=dev, generator=g)
+    w._dpig_wino4 = H.wino4_images(w)
+    H.conv2d_fwd(x, w, b, act=1)
+    d = H._desc(N, Hh, W, C, C, 3, 3, 1, C, C)
+    split = max(1, int(lib.dpig_conv2d_wino4_workspace_bytes(ctypes.byref(d), 0)) // (N * Hh * W * C * 4))
+    wgs = N * (Hh // 4) * (W // 4) // 32 * (C // 64) * split
+    buf = torch.zeros(wgs * 8, dtype=torch.int64, device=dev)
+    lib.dpig_debug_wino_trace(ctypes.c_void_p(buf.data_ptr()))
+    H.conv2d_fwd(x, w, b, act=1)
+    torch.cuda.synchronize()
+    lib.dpig_debug_wino_trace(None)
+    t = buf.view(wgs, 8).cpu().double()
+    seg = [(t[:, i + 1] - t[:, i]).mean().item() for i in range(4)]
+    tot = (t[:, 4] - t[:, 0]).mean().item()
+    span = (t[:, 4].max() - t[:, 0].min()).item()
+    rounds = (wgs + 255) // 256
+    nch = C // 8 // split
+    print("%-22s %6d %5d | %9.0f %9.0f %9.0f %9.0f | %9.0f %8.0f | span %.0f = %.2f x rounds x total (split %d)" % (
+        name, wgs, nch, seg[0], seg[1], seg[2], seg[3], tot, seg[1] / nch, span, span / (rounds * tot), split))
+H.set_wino4_mode(1); H.set_compute("f32")

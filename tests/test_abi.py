@@ -50,7 +50,7 @@ def test_header_is_plain_c_and_struct_layout_matches(lib, tmp_path):
 
 def test_same_pad_and_version(lib):
     h = lib.lib()
-    assert h.dpig_version() == 282
+    assert h.dpig_version() == 283
     o, p = ctypes.c_int(), ctypes.c_int()
     for inp, k, s, eo, ep in [(128, 3, 1, 128, 1), (128, 3, 2, 64, 0), (64, 5, 2, 32, 1), (7, 3, 2, 4, 1)]:
         h.dpig_same_pad(inp, k, s, ctypes.byref(o), ctypes.byref(p))
