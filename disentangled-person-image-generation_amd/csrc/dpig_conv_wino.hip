@@ -971,16 +971,28 @@ static FPlan fwd_plan(const DpigConvDesc* d, int cin, int kout) {
     }
     return best;
 }
-static bool pays(const DpigConvDesc* d, int cin, int kout) {
-    init_mode();
-    if (g_mode == 0) return false;
-    if (g_mode == 2) return true;
+static double direct_cycles_of(const DpigConvDesc* d, int cin, int kout) {
     // the direct family: ~115 TFLOP/s = 50 k FLOP per cycle on layers with >= 512 of its 128 x 128 tiles, down to ~65 % of that on the
     // smallest maps (8 x 4 C640: 75 TFLOP/s measured; its split-K plans pay partial-sum passes too)
     const long dtiles = (long)cdiv((long)d->N * d->H * d->W, 128) * cdiv(kout, 128);
     const double drate = 50000.0 * (dtiles >= 512 ? 1.0 : 0.65 + 0.35 * (double)dtiles / 512.0);
-    const double direct_cycles = 2.0 * d->N * d->H * d->W * 9.0 * cin * kout / drate;
-    return fwd_plan(d, cin, kout).cycles < 0.95 * direct_cycles;
+    return 2.0 * d->N * d->H * d->W * 9.0 * cin * kout / drate;
+}
+static bool pays(const DpigConvDesc* d, int cin, int kout) {
+    init_mode();
+    if (g_mode == 0) return false;
+    if (g_mode == 2) return true;
+    return fwd_plan(d, cin, kout).cycles < 0.95 * direct_cycles_of(d, cin, kout);
+}
+// what the layer costs WITHOUT the F(4x4, 3x3) form, in this file's cost model: the F(2x2, 3x3) plan where this family would take it
+// (mode and shape permitting), the direct family otherwise (dpig_conv_wino4.hip's cost model compares against it)
+double alt_cycles(const DpigConvDesc* d, int cin, int kout, int ld_in, int ld_out) {
+    init_mode();
+    const double direct = direct_cycles_of(d, cin, kout);
+    if (g_mode == 0 || !shape_ok(d, cin, kout, ld_in, ld_out)) return direct;
+    const double f2 = fwd_plan(d, cin, kout).cycles;
+    if (g_mode == 2) return f2;
+    return f2 < 0.95 * direct ? f2 : direct;
 }
 
 static int launch(const DpigConvDesc* d, const float* in, const float* U, const float* bias, const float* res, const float* mask,

@@ -73,22 +73,64 @@ __device__ __forceinline__ void bt6(const f32x4 (&d)[6], F&& out) {
         out(1, a + b);
         out(2, a - b);
     } else {
-        const f32x4 c = d[4] - d[2];
-        const f32x4 e = d[3] - d[1];
+        const f32x4 c = fma4(d[2], -1.f, d[4]);
+        const f32x4 e = fma4(d[1], -1.f, d[3]);
         out(3, fma4(e, 2.f, c));
         out(4, fma4(e, -2.f, c));
     }
 }
 
-// A^T of F(4, 3): [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
-__device__ __forceinline__ float at_coef(int y, int xi) {
-    // (wave-uniform arguments: scalar selects)
-    if (xi == 0) return y == 0 ? 1.f : 0.f;
-    if (xi == 5) return y == 3 ? 1.f : 0.f;
-    const float mag = (xi >= 3) ? (y == 0 ? 1.f : y == 1 ? 2.f : y == 2 ? 4.f : 8.f) : 1.f;
-    const bool neg = ((xi == 2) | (xi == 4)) & ((y & 1) != 0);
-    return neg ? -mag : mag;
+// A^T of F(4, 3): [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1].  The output transform of one position group (rows
+// 3 PA .. 3 PA + 2, columns 3 PB .. 3 PB + 2 of the 6 x 6 grid) for output row Y, on PAIRS of accumulator elements (v_pk_* instructions)
+// with the coefficients as compile-time integers: zeros vanish, +-1 are adds (the generic form, 84 multiply-adds per element with
+// wave-uniform coefficients, was 1344 vector instructions per wave and most of the phase's ~19 k cycles).
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int ATI[4][6] = {{1, 1, 1, 1, 1, 0}, {0, 1, -1, 2, -2, 0}, {0, 1, 1, 4, 4, 0}, {0, 1, -1, 8, -8, 1}};
+template <int K>
+__device__ __forceinline__ void mac2(f32x2& v, bool& have, f32x2 a) {
+    if constexpr (K != 0) {
+        if (!have) {
+            v = (K == 1) ? a : (float)K * a;
+            have = true;
+        } else if constexpr (K == 1) v += a;
+        else if constexpr (K == -1) v -= a;
+        else v = __builtin_elementwise_fma(a, f32x2{(float)K, (float)K}, v);
+    }
 }
+template <int K0, int K1, int K2>
+__device__ __forceinline__ f32x2 lin3(f32x2 a0, f32x2 a1, f32x2 a2) {
+    f32x2 v = {0.f, 0.f};
+    bool have = false;
+    mac2<K0>(v, have, a0);
+    mac2<K1>(v, have, a1);
+    mac2<K2>(v, have, a2);
+    return v;
+}
+// partial of output row Y, columns 0..3, for accumulator elements 4 g .. 4 g + 3 of the wave's nine positions: P[x] (16 bytes along channels)
+template <int PA, int PB, int Y>
+__device__ __forceinline__ void out_row_group(const f32x16 (&acc)[9], int g, f32x4 (&P)[4]) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int e0 = 4 * g + 2 * h;
+        f32x2 r[3];
+#pragma unroll
+        for (int jj = 0; jj < 3; ++jj)
+            r[jj] = lin3<ATI[Y][3 * PA], ATI[Y][3 * PA + 1], ATI[Y][3 * PA + 2]>(f32x2{acc[jj][e0], acc[jj][e0 + 1]}, f32x2{acc[3 + jj][e0], acc[3 + jj][e0 + 1]},
+                                                                            f32x2{acc[6 + jj][e0], acc[6 + jj][e0 + 1]});
+        const f32x2 p0 = lin3<ATI[0][3 * PB], ATI[0][3 * PB + 1], ATI[0][3 * PB + 2]>(r[0], r[1], r[2]);
+        const f32x2 p1 = lin3<ATI[1][3 * PB], ATI[1][3 * PB + 1], ATI[1][3 * PB + 2]>(r[0], r[1], r[2]);
+        const f32x2 p2 = lin3<ATI[2][3 * PB], ATI[2][3 * PB + 1], ATI[2][3 * PB + 2]>(r[0], r[1], r[2]);
+        const f32x2 p3 = lin3<ATI[3][3 * PB], ATI[3][3 * PB + 1], ATI[3][3 * PB + 2]>(r[0], r[1], r[2]);
+        P[0][2 * h] = p0[0]; P[0][2 * h + 1] = p0[1];
+        P[1][2 * h] = p1[0]; P[1][2 * h + 1] = p1[1];
+        P[2][2 * h] = p2[0]; P[2][2 * h + 1] = p2[1];
+        P[3][2 * h] = p3[0]; P[3][2 * h + 1] = p3[1];
+    }
+}
+
+// workgroup barrier that orders LDS traffic only (__syncthreads() also waits for the global stores in flight -- on this target vmcnt
+// counts stores -- which put a store round trip on every output row: the staging is all these barriers protect)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int BW, int KO = 0>   // KO: knock-out bits for timing experiments (DPIG_WINO4_KO; results are wrong): 1 no transforms, 2 no filter loads, 4 no raw gather, 8 no MFMAs
 __device__ __forceinline__ void wino4_body(const WParams& p, lds_char* const L, const int vb) {
@@ -129,14 +171,15 @@ __device__ __forceinline__ void wino4_body(const WParams& p, lds_char* const L, 
         const bool ok = (idx < RPIX) & ((unsigned)g < (unsigned)(p.N * p.H)) & ((unsigned)x < (unsigned)p.W);
         g_voff[k] = ok ? ((g * p.W + x) * p.ldx + hq * 4) * 4 : (int)OOB;
     }
+    // (a chunk index past the workgroup's range -- the loop's look-ahead at its end -- re-reads the last chunk: the data is staged and
+    // never multiplied; no per-load select on the vector ALU)
     auto dmaRaw = [&](int chunk, int slot) {
-        const int dead = chunk < ce ? 0 : (int)OOB;
-        const int so = chunk < ce ? chunk * (CH * 4) : 0;
+        const int so = min(chunk, ce - 1) * (CH * 4);
 #pragma unroll
         for (int k = 0; k < 3; ++k)
             if (k < 2 || wave + 16 < PIECES)
                 __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void*)(L + RAW_OFF + slot * RAWB + (wave + 8 * k) * 1024), 16,
-                                                         g_voff[k] | dead, so, 0, 0);
+                                                         g_voff[k], so, 0, 0);
     };
     // ---- input-transform role: item = (tile tl = 4 wave + lane / 16, channel quad q = (lane / 8) & 1), sub-index j = lane % 8 (< 6 works):
     // pass A: patch column j; pass B: transform row xi = j
@@ -187,9 +230,8 @@ __device__ __forceinline__ void wino4_body(const WParams& p, lds_char* const L, 
     const int u_base = (nt * p.nch) * UCHUNK;
     f32x4 u[9];
     auto loadU = [&](int chunk, int pp) {
-        const int dead = chunk < ce ? 0 : (int)OOB;
-        const int so = u_base + (chunk < ce ? chunk : 0) * UCHUNK;
-        u[pp] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, (u_voff + (6 * (pp / 3) + pp % 3) * UPOS) | dead, so, 0));
+        const int so = u_base + min(chunk, ce - 1) * UCHUNK;
+        u[pp] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsU, u_voff + (6 * (pp / 3) + pp % 3) * UPOS, so, 0));
     };
     f32x16 acc[9];
 #pragma unroll
@@ -204,6 +246,7 @@ __device__ __forceinline__ void wino4_body(const WParams& p, lds_char* const L, 
     for (int pp = 0; pp < 9; ++pp) loadU(cb, pp);
     wait_vm<0>();
     __syncthreads();
+    if (!(KO & 32)) stamp(7);
     readA(0);
     passA(std::integral_constant<int, 0>{});
     passA(std::integral_constant<int, 1>{});
@@ -213,7 +256,7 @@ __device__ __forceinline__ void wino4_body(const WParams& p, lds_char* const L, 
     passB(0, std::integral_constant<int, 1>{});
     passB(0, std::integral_constant<int, 2>{});
     __syncthreads();                                 // V slot 0 complete, raw slot 0 free
-    stamp(1);
+    if (!(KO & 32)) stamp(1);
     // chunk c = nine steps (the wave's positions): {V fragment of the next position, 4 MFMAs, the filter fragment of this position for
     // chunk c + 1, a slice of the staging work}.  Slices: step 0 the raw gather of chunk c + 2 (into the raw slot chunk c was transformed
     // from), 1 pass A's LDS reads of chunk c + 1, 2-4 its transform + scratch stores (two rows per step), 5 pass B's reads, 6-8 its
@@ -230,9 +273,11 @@ __device__ __forceinline__ void wino4_body(const WParams& p, lds_char* const L, 
             // them, and its latency, behind the slice's slow 16-byte stores, lands on the next step)
             if (pp < 8) fb[(pp + 1) & 1] = *(lds_cf4*)(Vb + (6 * ((pp + 1) % 3) + (pp + 1) / 3) * PS);
             __builtin_amdgcn_sched_barrier(0);
+            if (KO & 16) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4)
                 if (!(KO & 8)) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[pp][s4], fb[pp & 1][s4], acc[pp], 0, 0, 0);
+            if (KO & 16) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(0); }
             if (pp == 0 && !(KO & 4)) dmaRaw(c + 2, buf);
             if (!(KO & 2)) loadU(c + 1, pp);
             if (!(KO & 1)) {
@@ -255,43 +300,38 @@ __device__ __forceinline__ void wino4_body(const WParams& p, lds_char* const L, 
         if (c + 1 < ce) body(c + 1, std::integral_constant<int, 1>{});
     }
     wait_vm<0>();
-    stamp(2);
+    if (!(KO & 32)) stamp(2);
 
     // ---- output transform, one output row y of the 4 x 4 tiles at a time.  A lane holds element (tile l31, channel 32 wc + 8 g + 4 half + e)
     // of its nine positions M[3 a + i][3 b + jj]; its partial of Y[y][x] is  sum_i AT[y][3 a + i] sum_jj AT[x][3 b + jj] M[i][jj].
     // Staging: [partial pg][x][tile][64 channels]; the epilogue threads (16-byte channel group cg = tid % 16, tile tid / 16) add the four
     // partials in fixed order and run ONE of three workgroup-uniform paths on the row's four pixels.
-    float cc[4][3];
-#pragma unroll
-    for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int jj = 0; jj < 3; ++jj) cc[x][jj] = at_coef(x, 3 * pb + jj);
     const int cg = tid & 15, tloc = tid >> 4, col = n0 + 4 * cg;
     const int ebty = tloc / BW, ebtx = tloc - ebty * BW;
     f32x4 bv = {0.f, 0.f, 0.f, 0.f};
     if (p.bias && p.nsplit == 1) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
+    auto out_row = [&](auto Yc) {
+        constexpr int y = decltype(Yc)::value;
+        if ((KO & 32) && y == 1) stamp(1);
+        auto stage = [&](auto PAc, auto PBc) {
 #pragma unroll
-    for (int y = 0; y < 4; ++y) {
-        float cr[3];
+            for (int g = 0; g < 4; ++g) {
+                f32x4 P[4];
+                out_row_group<decltype(PAc)::value, decltype(PBc)::value, decltype(Yc)::value>(acc, g, P);
 #pragma unroll
-        for (int i = 0; i < 3; ++i) cr[i] = at_coef(y, 3 * pa + i);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 P[4];
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int rr = 4 * g + e;
-                float r3[3];
-#pragma unroll
-                for (int jj = 0; jj < 3; ++jj) r3[jj] = cr[0] * acc[jj][rr] + cr[1] * acc[3 + jj][rr] + cr[2] * acc[6 + jj][rr];
-#pragma unroll
-                for (int x = 0; x < 4; ++x) P[x][e] = cc[x][0] * r3[0] + cc[x][1] * r3[1] + cc[x][2] * r3[2];
+                for (int x = 0; x < 4; ++x)
+                    *(lds_f4*)(L + ((pg * 4 + x) * TB + l31) * EP_ROW + (32 * wc + 8 * g + 4 * half) * 4) = P[x];
             }
-#pragma unroll
-            for (int x = 0; x < 4; ++x)
-                *(lds_f4*)(L + ((pg * 4 + x) * TB + l31) * EP_ROW + (32 * wc + 8 * g + 4 * half) * 4) = P[x];
-        }
-        __syncthreads();
+        };
+        typedef std::integral_constant<int, 0> I0;
+        typedef std::integral_constant<int, 1> I1;
+        if (pg == 0) stage(I0{}, I0{});
+        else if (pg == 1) stage(I0{}, I1{});
+        else if (pg == 2) stage(I1{}, I0{});
+        else stage(I1{}, I1{});
+        if ((KO & 32) && y == 1) stamp(2);
+        lds_barrier();
+        if ((KO & 32) && y == 1) stamp(3);
         f32x4 v[4];
 #pragma unroll
         for (int x = 0; x < 4; ++x) {
@@ -321,10 +361,16 @@ __device__ __forceinline__ void wino4_body(const WParams& p, lds_char* const L, 
 #pragma unroll
             for (int x = 0; x < 4; ++x) epi4(p, pix + x, col, v[x], bv);
         }
-        if (y < 3) __syncthreads();                  // the row's staging reads are done before the next row's stores
-        if (y == 0) stamp(3);
-    }
-    stamp(4);
+        if ((KO & 32) && y == 1) stamp(7);
+        if (y < 3) lds_barrier();                    // the row's staging reads are done before the next row's stores
+        if (!(KO & 32) && y == 0) stamp(3);
+        if ((KO & 32) && y == 1) stamp(4);
+    };
+    out_row(std::integral_constant<int, 0>{});
+    out_row(std::integral_constant<int, 1>{});
+    out_row(std::integral_constant<int, 2>{});
+    out_row(std::integral_constant<int, 3>{});
+    if (!(KO & 32)) stamp(4);
 }
 
 // Persistent launch (as wino_block_kernel): one workgroup per CU, or per item when there are fewer, walking the items.
@@ -335,7 +381,7 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(const WParams p) {
     const int total = p.mtiles * p.ntiles * p.nsplit;
     for (int vb = blockIdx.x; vb < total; vb += gridDim.x) {
         wino4_body<BW, KO>(p, L, vb);
-        __syncthreads();                              // the last row's staging reads are done before the next item's gather lands
+        lds_barrier();                                // the last row's staging reads are done before the next item's gather lands
     }
 }
 
@@ -442,9 +488,10 @@ static bool shape_ok(const DpigConvDesc* d, int cin, int kout, int ld_in, int ld
     if ((long)36 * cin * kout * 4 >= lim) return false;
     return true;
 }
-// One workgroup per CU, whole rounds of 256: a workgroup's life is ~CHUNK_CYCLES per 8-channel chunk (72 MFMAs per SIMD = 4608 of them)
-// + ~FIXED_CYCLES of prologue / output transform / epilogue.  Split plans as in the F(2x2, 3x3) family (partials summed by wino_reduce_kernel).
-constexpr double CHUNK_CYCLES = 5400.0, FIXED_CYCLES = 26000.0;
+// One workgroup per CU, whole rounds of 256: a workgroup's life is ~6200 cycles per 8-channel chunk (72 MFMAs per SIMD = 4608 of them)
+// + ~34 k cycles of prologue (first gather + transform, ~12 k) and output transform / epilogue (~21 k) -- scripts/trace_wino4.py.
+// Split plans as in the F(2x2, 3x3) family (partials summed by wino_reduce_kernel).
+constexpr double CHUNK_CYCLES = 6200.0, FIXED_CYCLES = 34000.0;
 struct FPlan { int nsplit, cps; double cycles; };
 static FPlan fwd_plan(const DpigConvDesc* d, int cin, int kout) {
     const long T = (long)d->N * (d->H / 4) * (d->W / 4);
@@ -462,17 +509,12 @@ static FPlan fwd_plan(const DpigConvDesc* d, int cin, int kout) {
     }
     return best;
 }
-// Does this form beat what the layer would otherwise run on?  The F(2x2, 3x3) kernel's life is ~5050 cycles per chunk + ~16 k per
-// 256-pixel workgroup (dpig_conv_wino.hip); layers that kernel's own cost model leaves to the direct family are small maps where this
-// form has even fewer workgroups.
-static bool pays(const DpigConvDesc* d, int cin, int kout) {
+// Does this form beat what the layer would otherwise run on (the F(2x2, 3x3) plan, or the direct family where that one does not pay)?
+static bool pays(const DpigConvDesc* d, int cin, int kout, int ld_in, int ld_out) {
     init_mode();
     if (g_mode == 0) return false;
     if (g_mode == 2) return true;
-    const long T2 = (long)d->N * (d->H / 2) * (d->W / 2);
-    const long wgs2 = (long)cdiv(T2, 64) * (kout / KB);
-    const double f2 = (double)((wgs2 + kNumCU - 1) / kNumCU) * ((cin / CH) * 5050.0 + 16000.0);
-    return fwd_plan(d, cin, kout).cycles < 0.95 * f2;
+    return fwd_plan(d, cin, kout).cycles < 0.97 * wino::alt_cycles(d, cin, kout, ld_in, ld_out);
 }
 
 static int launch(const DpigConvDesc* d, const float* in, const float* U, const float* bias, const float* res, const float* mask,
@@ -520,6 +562,8 @@ static int launch(const DpigConvDesc* d, const float* in, const float* U, const 
     else if (ko == 7) hipLaunchKernelGGL((wino4_kernel<4, 7>), pgrid, dim3(512), 0, st, p);
     else if (ko == 8) hipLaunchKernelGGL((wino4_kernel<4, 8>), pgrid, dim3(512), 0, st, p);
     else if (ko == 3) hipLaunchKernelGGL((wino4_kernel<4, 3>), pgrid, dim3(512), 0, st, p);
+    else if (ko == 16) hipLaunchKernelGGL((wino4_kernel<4, 16>), pgrid, dim3(512), 0, st, p);
+    else if (ko == 32) hipLaunchKernelGGL((wino4_kernel<4, 32>), pgrid, dim3(512), 0, st, p);
 #endif
     else hipLaunchKernelGGL(wino4_kernel<4>, pgrid, dim3(512), 0, st, p);
     (void)ko;
@@ -567,7 +611,7 @@ extern "C" int dpig_conv2d_wino4_eligible(const DpigConvDesc* d, int which) {
     const int ld_in = dg ? d->ldy : d->ldx, ld_out = dg ? d->ldx : d->ldy;
     if (d->C % 64 || d->K % 64) return 0;                       // (one transformed image pair serves both directions)
     if (!wino4::shape_ok(d, cin, kout, ld_in, ld_out)) return 0;
-    return wino4::pays(d, cin, kout) ? 1 : 0;
+    return wino4::pays(d, cin, kout, ld_in, ld_out) ? 1 : 0;
 }
 
 extern "C" int dpig_conv_wino4_set_mode(int mode) {

@@ -67,6 +67,8 @@ __device__ __forceinline__ void epi4(const WParams& p, long pix, int col, f32x4 
 
 // second pass of a split plan (dpig_conv_wino.hip): sums the nsplit partial outputs in split order and runs the fused epilogue
 int launch_reduce(const WParams& p, hipStream_t st);
+// cost (cycles, this family's cost model) of the layer without the F(4x4, 3x3) form: the F(2x2, 3x3) plan or the direct family
+double alt_cycles(const DpigConvDesc* d, int cin, int kout, int ld_in, int ld_out);
 // dev aid: the stamp buffer dpig_debug_wino_trace installed, or null
 unsigned long long* trace_buffer();
 

@@ -8,8 +8,8 @@ cp $PKG/libdpig_hip.so /tmp/libdpig_hip.so.keep
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -I include -I $PKG/csrc -DDPIG_WINO4_KNOCKOUT -c $PKG/csrc/dpig_conv_wino4.hip -o /tmp/wino4_ko.o
 objs=$(ls build/obj/*.o | grep -v dpig_conv_wino4.o)
 hipcc --offload-arch=gfx950 -shared -fPIC -o $PKG/libdpig_hip.so $objs /tmp/wino4_ko.o
-for ko in 0 1 2 4 3 7 8; do
+for ko in ${KOS:-0 1 2 4 3 7 8}; do
     echo "== DPIG_WINO4_KO=$ko  (1 no transforms, 2 no filter loads, 4 no raw gather, 8 no MFMAs)"
-    DPIG_WINO4_KO=$ko python scripts/trace_wino4.py 2>&1 | grep -v amdgpu.ids | cut -c1-110
+    DPIG_WINO4_KO=$ko python scripts/trace_wino4.py 2>&1 | grep -v amdgpu.ids 
 done
 cp /tmp/libdpig_hip.so.keep $PKG/libdpig_hip.so

@@ -34,7 +34,7 @@ with open(os.path.join(root, "profiles", tag + "_pmc_traffic.md"), "w") as fh:
 key = os.environ.get("DPIG_TRAFFIC_KEY", "market128/f32")
 dtype = key.split("/")[1]
 FAMILY = {"f32": (["gather_gemm_kernel<false, true, false, 0>"], ["conv_fwd_mfma"]),
-          "f32w": (["wino_block_kernel", "wino_kernel"], ["conv_fwd_wino", "conv_dgrad_wino"]),
+          "f32w": (["wino4_kernel"], ["conv_fwd_wino4", "conv_dgrad_wino4"]),      # (the dominant class since the F(4x4,3x3) kernel: bench.py picks it by time)
           "bf16": (["bhq_kernel", "bhq32_kernel", "bq_kernel", "bh_kernel", "bg8_kernel", "bg8d_kernel", "bg_kernel", "bg8_multi_kernel", "bg8d_multi_kernel",
                     "bg_multi_kernel"],
                    ["conv_fwd_bf16", "conv_dgrad_bf16"])}

@@ -10,7 +10,7 @@ lib.dpig_debug_wino_trace.argtypes = [ctypes.c_void_p]
 lib.dpig_debug_wino_trace.restype = ctypes.c_int
 g = torch.Generator(device=dev).manual_seed(0)
 H.set_compute("f32w"); H.set_wino4_mode(2)
-print("%-22s %6s %5s | %9s %9s %9s %9s | %9s %8s | %s" % ("layer", "items", "nch", "prologue", "loop", "outxf y0", "rows 1-3", "total", "cyc/chunk", "span of all items / sum"))
+print("%-22s %6s %5s | %8s %9s %9s %9s %9s | %9s %8s" % ("layer", "items", "nch", "arrive", "prologue", "loop", "outxf y0", "rows 1-3", "total", "cyc/chunk"))
 for name, N, Hh, W, C in [("C128 128x64", 16, 128, 64, 128), ("C128 48x48", 112, 48, 48, 128), ("C256 128x64", 16, 128, 64, 256), ("C256 24x24", 112, 24, 24, 256),
                           ("C512 64x32", 16, 64, 32, 512), ("C768 32x16", 16, 32, 16, 768)]:
     x = torch.rand((N, Hh, W, C), device=dev, generator=g) * 2 - 1
@@ -32,6 +32,10 @@ for name, N, Hh, W, C in [("C128 128x64", 16, 128, 64, 128), ("C128 48x48", 112,
     span = (t[:, 4].max() - t[:, 0].min()).item()
     rounds = (wgs + 255) // 256
     nch = C // 8 // split
-    print("%-22s %6d %5d | %9.0f %9.0f %9.0f %9.0f | %9.0f %8.0f | span %.0f = %.2f x rounds x total (split %d)" % (
-        name, wgs, nch, seg[0], seg[1], seg[2], seg[3], tot, seg[1] / nch, span, span / (rounds * tot), split))
+    if os.environ.get("DPIG_WINO4_KO") == "32":      # epilogue stamp mode: row 1 of the output phase
+        m = lambda a, b: (t[:, b] - t[:, a]).mean().item()
+        print("%-22s row 1: transform + staging stores %6.0f | barrier %6.0f | sums + epilogue + store issue %6.0f | barrier %6.0f" % (name, m(1, 2), m(2, 3), m(3, 7), m(7, 4)))
+        continue
+    arrive = (t[:, 7] - t[:, 0]).mean().item()
+    print("%-22s %6d %5d | %8.0f %9.0f %9.0f %9.0f %9.0f | %9.0f %8.0f  (split %d)" % (name, wgs, nch, arrive, seg[0], seg[1], seg[2], seg[3], tot, seg[1] / nch, split))
 H.set_wino4_mode(1); H.set_compute("f32")

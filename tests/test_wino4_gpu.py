@@ -170,3 +170,55 @@ def test_filter_images_follow_the_optimizer(dev, wino4):
     finally:
         H.set_wino4_mode(prev)
     wf.detach()
+
+
+def test_stage1_step_with_the_large_maps_on_f4_equals_the_exact_mode(dev):
+    """Config(compute_dtype='f32w') with the F(4x4, 3x3) kernel wherever the layer has the form: one train step of the stage-I trainer
+    (width 64) against the same step in 'f32' mode -- losses to 5e-5 (the batch-norm critic's, evaluated after the generator's update,
+    to 1e-3), generator output to 1e-4 of its range; after a second step (not compared: Adam's first updates are sign-like, so the two
+    arithmetic orders' 1e-6 gradient differences move individual weights by the learning rate) the F(4x4) images still follow the
+    masters and filters that only use them have left the F(2x2) refresh."""
+    import numpy as np
+    import dpig_amd.hip_ops as H
+    import dpig_amd.tflib as lib
+    from dpig_amd import slim, synthetic
+    from dpig_amd.trainer import Config, DPIG_Encoder_GAN_BodyROI_FgBg
+    res = {}
+    prev_wino, prev4 = H.set_wino_mode(2), H.set_wino4_mode(2)
+    try:
+        for mode in ("f32", "f32w"):
+            lib.delete_all_params(); slim.reset_scopes()
+            np.random.seed(0)
+            B = 2
+            tr = DPIG_Encoder_GAN_BodyROI_FgBg(Config(batch_size=B, conv_hidden_num=64, z_num=16, compute_dtype=mode, g_lr=1e-3, d_lr=1e-3), dev)
+            bg = synthetic.to_device(synthetic.make_batch(B, seed=21), dev)
+            bd = synthetic.to_device(synthetic.make_batch(B, seed=22), dev)
+            tr.init_net(bg)
+            tr.step = 1
+            H.PROFILE = []
+            out = tr.train_step(bg, bd)
+            kinds = set(r[0] for r in H.PROFILE)
+            H.PROFILE = None
+            res[mode] = ({k: float(v) for k, v in out.items() if hasattr(v, "numel") and v.numel() == 1}, out["G"].clone())
+            tr.train_step(bg, bd)
+            if mode == "f32w":
+                assert "conv_fwd_wino4" in kinds and "conv_dgrad_wino4" in kinds and "conv_wgrad_wino" in kinds, kinds
+                wf = tr.G_flat.wino
+                assert len(wf.p4) > 5 and wf.pruned and len(wf.p2) < len(wf.params)
+                for p in wf.p4[:3]:                                            # refreshed after Adam moved the filters
+                    fresh = H.wino4_images(p.data.clone())
+                    assert torch.equal(p._dpig_wino4[0], fresh[0]) and torch.equal(p._dpig_wino4[1], fresh[1])
+                for p in wf.p2[:3]:
+                    assert torch.equal(p._dpig_wino[0], H.wino_images(p.data.clone())[0])
+            else:
+                assert "conv_fwd_wino4" not in kinds
+        for k, tol in (("g_loss", 5e-5), ("L1Loss", 5e-5), ("d_loss", 1e-3)):
+            assert abs(res["f32w"][0][k] - res["f32"][0][k]) <= tol * abs(res["f32"][0][k]), (k, res["f32w"][0][k], res["f32"][0][k])
+        Gd = (res["f32w"][1] - res["f32"][1]).abs().max().item()
+        assert Gd <= 1e-4 * res["f32"][1].abs().max().item(), Gd
+    finally:
+        H.PROFILE = None
+        H.set_wino4_mode(prev4)
+        H.set_wino_mode(prev_wino)
+        H.set_compute("f32")
+        lib.delete_all_params(); slim.reset_scopes()

@@ -27,7 +27,9 @@ def wino():
     import dpig_amd.hip_ops as H
     H.set_compute("f32w")
     prev = H.set_wino_mode(2)           # wherever legal: the cost model would keep these small layers on the direct kernel
+    prev4 = H.set_wino4_mode(0)         # (this file is about the F(2x2, 3x3) kernels: tests/test_wino4_gpu.py holds the F(4x4, 3x3) ones)
     yield H
+    H.set_wino4_mode(prev4)
     H.set_wino_mode(prev)
     H.set_compute("f32")
 
@@ -188,7 +190,7 @@ def test_one_launch_filter_refresh_equals_the_per_filter_transforms(dev, wino):
     shapes = [(3, 3, 64, 64), (3, 3, 128, 64), (5, 5, 64, 64), (3, 3, 64, 192), (3, 3, 256, 256), (3, 3, 64, 3), (3, 3, 192, 128)]
     params = [torch.nn.Parameter(_rand(sh, 10 + i, 0.1).float().to(dev)) for i, sh in enumerate(shapes)]
     wf = H.WinoFilters(params)
-    assert len(wf.params) == 5 and wf.total == sum((p.shape[2] // 64) * (p.shape[3] // 8) for p in wf.params)
+    assert len(wf.params) == 5 and wf.plan2["total"] == sum((p.shape[2] // 64) * (p.shape[3] // 8) for p in wf.params)
     for p in wf.params:
         uf, ud = H.wino_images(p.data.clone())
         assert torch.equal(p._dpig_wino[0], uf) and torch.equal(p._dpig_wino[1], ud)
@@ -212,10 +214,12 @@ FULL = [("dec4", 16, 128, 64, 256), ("dec3", 16, 64, 32, 512), ("dec2", 16, 32, 
         ("df enc1", 8, 256, 256, 128), ("df dec3", 8, 64, 64, 768)]
 
 
+@pytest.mark.parametrize("form", ["f4", "f2"])
 @pytest.mark.parametrize("layer", FULL, ids=[l[0] for l in FULL])
-def test_full_size_layers_against_the_sampled_oracle(dev, layer):
-    """BASELINE configs[1] (and two DeepFashion) layer sizes under the DEFAULT selection (cost model): 4096 sampled output / input positions against
-    oracle.ops.conv2d_same*_sampled in fp64, forward + bias + ReLU and dgrad."""
+def test_full_size_layers_against_the_sampled_oracle(dev, layer, form):
+    """BASELINE configs[1] (and two DeepFashion) layer sizes under the DEFAULT selection (cost model: every one of these layers runs the
+    F(4x4, 3x3) forward / dgrad kernel; "f2": with that form switched off, the F(2x2, 3x3) kernel): 4096 sampled output / input
+    positions against oracle.ops.conv2d_same*_sampled in fp64, forward + bias + ReLU and dgrad."""
     import dpig_amd.hip_ops as H
     from oracle import ops as O
     _, N, Hh, W, C = layer
@@ -236,6 +240,7 @@ def test_full_size_layers_against_the_sampled_oracle(dev, layer):
     ci, co = torch.randperm(C, generator=gc)[:48], torch.randperm(C, generator=gc)[:48]
     ref_dw = O.conv2d_same_wgrad_sampled(xc, dyc, (3, 3, C, C), 1, taps, ci, co)
     H.set_compute("f32w")
+    prev4 = H.set_wino4_mode(0) if form == "f2" else H.get_wino4_mode()
     H.PROFILE = []
     try:
         y = H.conv2d_fwd(x, w, b, act=1)
@@ -244,8 +249,10 @@ def test_full_size_layers_against_the_sampled_oracle(dev, layer):
         kinds = [r[0] for r in H.PROFILE]
     finally:
         H.PROFILE = None
+        H.set_wino4_mode(prev4)
         H.set_compute("f32")
-    assert kinds == ["conv_fwd_wino", "conv_dgrad_wino", "conv_wgrad_wino"], kinds
+    sfx = "4" if form == "f4" else ""
+    assert kinds == ["conv_fwd_wino" + sfx, "conv_dgrad_wino" + sfx, "conv_wgrad_wino"], kinds
     idx = (n.to(dev), oy.to(dev), ox.to(dev))
     _close(y[idx], ref_y, 1e-4)
     _close(dx[idx], ref_dx, 1e-4)
@@ -263,6 +270,7 @@ def test_stage1_step_in_winograd_mode_equals_the_exact_mode(dev):
     from dpig_amd.trainer import Config, DPIG_Encoder_GAN_BodyROI_FgBg
     res = {}
     prev_wino = H.set_wino_mode(2)
+    prev4 = H.set_wino4_mode(0)          # (the F(2x2, 3x3) kernels' step test; the F(4x4, 3x3) twin is in tests/test_wino4_gpu.py)
     try:
         for mode in ("f32", "f32w"):
             lib.delete_all_params(); slim.reset_scopes()
@@ -297,6 +305,7 @@ def test_stage1_step_in_winograd_mode_equals_the_exact_mode(dev):
         assert Gd <= 1e-4 * res["f32"][1].abs().max().item(), Gd
     finally:
         H.PROFILE = None
+        H.set_wino4_mode(prev4)
         H.set_wino_mode(prev_wino)
         H.set_compute("f32")
         lib.delete_all_params(); slim.reset_scopes()
