@@ -133,10 +133,15 @@ __device__ __forceinline__ void out_row_group(const f32x16 (&acc)[9], int g, f32
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 template <int BW, int KO = 0>   // KO: knock-out bits for timing experiments (DPIG_WINO4_KO; results are wrong): 1 no transforms, 2 no filter loads, 4 no raw gather, 8 no MFMAs
-__device__ __forceinline__ void wino4_body(const WParams& p, lds_char* const L, const int vb) {
+__device__ __forceinline__ void wino4_body(const WParams& p, lds_char* const L, const int vb, const int vb_next) {
     constexpr int BH = TB / BW, RW = 4 * BW + 2, RH = 4 * BH + 2, RPIX = RW * RH, PIECES = (2 * RPIX + 63) / 64;
     static_assert(PIECES <= RAW_PIECES && PIECES > 16, "raw gather plan");
-    const int tid = threadIdx.x;
+    // (the thread index passes through an empty asm: everything derived from it is recomputed per item, a few dozen instructions.  Hoisted
+    // out of the persistent loop those values were spilled across the k-loop -- the register file is full -- and every item began with
+    // five scratch reloads, each behind a wait for ALL memory operations in flight, the previous item's output stores included:
+    // 3-4 k cycles per item)
+    int tid = threadIdx.x;
+    asm volatile("" : "+v"(tid));
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, half = lane >> 5;
@@ -240,28 +245,36 @@ __device__ __forceinline__ void wino4_body(const WParams& p, lds_char* const L, 
         for (int e = 0; e < 16; ++e) acc[pp][e] = 0.f;
 
     // ---- prologue: raw pixels of chunks 0 and 1 gathered, the filter fragments of chunk 0 loaded, chunk 0 transformed -----------------------
+    if (KO & 128) stamp(1);
+    // Only the first raw gather is waited for before chunk 0 is transformed; the filter fragments (72 KB per workgroup, most of the
+    // prologue's bytes: their ISSUE alone, 120 one-KB loads through the CU's one address pipe, took ~3 k cycles in front of that wait)
+    // go out between the passes of the transform, whose LDS round trips would otherwise idle.
     dmaRaw(cb, 0);
     dmaRaw(cb + 1, 1);
-#pragma unroll
-    for (int pp = 0; pp < 9; ++pp) loadU(cb, pp);
-    wait_vm<0>();
+    if (KO & 128) stamp(2);
+    wait_vm<2>();                                    // (2 or 3 pieces of chunk 1's gather are younger than chunk 0's)
+    if (KO & 128) stamp(3);
     __syncthreads();
     if (!(KO & 32)) stamp(7);
     readA(0);
+    loadU(cb, 0); loadU(cb, 1); loadU(cb, 2);
     passA(std::integral_constant<int, 0>{});
     passA(std::integral_constant<int, 1>{});
+    loadU(cb, 3); loadU(cb, 4); loadU(cb, 5);
     passA(std::integral_constant<int, 2>{});
     readB();
+    loadU(cb, 6); loadU(cb, 7); loadU(cb, 8);
     passB(0, std::integral_constant<int, 0>{});
     passB(0, std::integral_constant<int, 1>{});
     passB(0, std::integral_constant<int, 2>{});
-    __syncthreads();                                 // V slot 0 complete, raw slot 0 free
-    if (!(KO & 32)) stamp(1);
+    wait_vm<9>();                                    // the second gather is home (the fragment loads may still fly: the MFMAs wait for theirs)
+    __syncthreads();                                 // V slot 0 complete, raw slots 0 (free) and 1 (filled) visible
+    if (!(KO & 32) && !(KO & 128)) stamp(1);
+    if (KO & 128) stamp(4);
     // chunk c = nine steps (the wave's positions): {V fragment of the next position, 4 MFMAs, the filter fragment of this position for
     // chunk c + 1, a slice of the staging work}.  Slices: step 0 the raw gather of chunk c + 2 (into the raw slot chunk c was transformed
     // from), 1 pass A's LDS reads of chunk c + 1, 2-4 its transform + scratch stores (two rows per step), 5 pass B's reads, 6-8 its
-    // transform + V stores (with all of a pass in one step the step outlasted the other wave's MFMAs: 6670 cycles per chunk against 5220
-    // without the transforms).
+    // transform + V stores.
     auto body = [&](int c, auto PAR) {
         constexpr int buf = decltype(PAR)::value, oth = buf ^ 1;
         lds_char* const Vb = L + buf * VB + fv;
@@ -269,17 +282,13 @@ __device__ __forceinline__ void wino4_body(const WParams& p, lds_char* const L, 
         fb[0] = *(lds_cf4*)(Vb);
 #pragma unroll
         for (int pp = 0; pp < 9; ++pp) {
-            // the NEXT position's V fragment goes out before this position's MFMAs (pinned: left to itself the scheduler issues it after
-            // them, and its latency, behind the slice's slow 16-byte stores, lands on the next step)
+            // Order within a step (each boundary pinned): the NEXT position's V fragment read, the staging slice, this position's four
+            // MFMAs, the filter fragment's reload (+ the raw gather).  Measured per chunk (scripts/ko_wino4.sh): slice after the MFMAs
+            // 6200 cycles, slice before them 5815, "one MFMA, four slice instructions" enforced 6070, priority flips around the MFMAs
+            // +130, fragment read after the slice +90; left to itself the scheduler issues the fragment read after the MFMAs and its
+            // latency, behind the slice's slow 16-byte stores, lands on the next step.
             if (pp < 8) fb[(pp + 1) & 1] = *(lds_cf4*)(Vb + (6 * ((pp + 1) % 3) + (pp + 1) / 3) * PS);
             __builtin_amdgcn_sched_barrier(0);
-            if (KO & 16) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-            for (int s4 = 0; s4 < 4; ++s4)
-                if (!(KO & 8)) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[pp][s4], fb[pp & 1][s4], acc[pp], 0, 0, 0);
-            if (KO & 16) { __builtin_amdgcn_sched_barrier(0); __builtin_amdgcn_s_setprio(0); }
-            if (pp == 0 && !(KO & 4)) dmaRaw(c + 2, buf);
-            if (!(KO & 2)) loadU(c + 1, pp);
             if (!(KO & 1)) {
                 if (pp == 1) readA(oth);
                 if (pp == 2) passA(std::integral_constant<int, 0>{});
@@ -291,6 +300,12 @@ __device__ __forceinline__ void wino4_body(const WParams& p, lds_char* const L, 
                 if (pp == 8) passB(oth, std::integral_constant<int, 2>{});
             }
             __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4)
+                if (!(KO & 8)) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(u[pp][s4], fb[pp & 1][s4], acc[pp], 0, 0, 0);
+            if (pp == 0 && !(KO & 4)) dmaRaw(c + 2, buf);
+            if (!(KO & 2)) loadU(c + 1, pp);
+            __builtin_amdgcn_sched_barrier(0);
         }
         wait_vm<9>();                                // the raw pieces of chunk c + 2 are home (only the nine filter fragments are younger)
         __syncthreads();                             // + V slot `oth` written, every wave done reading V slot `buf` and raw slot `oth`
@@ -300,18 +315,22 @@ __device__ __forceinline__ void wino4_body(const WParams& p, lds_char* const L, 
         if (c + 1 < ce) body(c + 1, std::integral_constant<int, 1>{});
     }
     wait_vm<0>();
-    if (!(KO & 32)) stamp(2);
-
+    if (!(KO & 32) && !(KO & 128)) stamp(2);
     // ---- output transform, one output row y of the 4 x 4 tiles at a time.  A lane holds element (tile l31, channel 32 wc + 8 g + 4 half + e)
     // of its nine positions M[3 a + i][3 b + jj]; its partial of Y[y][x] is  sum_i AT[y][3 a + i] sum_jj AT[x][3 b + jj] M[i][jj].
     // Staging: [partial pg][x][tile][64 channels]; the epilogue threads (16-byte channel group cg = tid % 16, tile tid / 16) add the four
     // partials in fixed order and run ONE of three workgroup-uniform paths on the row's four pixels.
-    const int cg = tid & 15, tloc = tid >> 4, col = n0 + 4 * cg;
-    const int ebty = tloc / BW, ebtx = tloc - ebty * BW;
-    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
-    if (p.bias && p.nsplit == 1) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
     auto out_row = [&](auto Yc) {
         constexpr int y = decltype(Yc)::value;
+        // (the row's lane roles and addresses are made here, from the thread index through an empty asm: kept across the rows they were
+        // spilled, and every reload waited for the previous row's output stores -- vmcnt counts stores)
+        int tid2 = threadIdx.x;
+        asm volatile("" : "+v"(tid2));
+        // (and the accumulators: two rows of a position group can share sub-expressions -- rows 1 and 3 of the groups that hold grid rows
+        // 0-2 are identical -- and values kept from one row for another do not fit either)
+        asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]));
+        const int cg = tid2 & 15, tloc = tid2 >> 4, col = n0 + 4 * cg;
+        const int ebty = tloc / BW, ebtx = tloc - ebty * BW;
         if ((KO & 32) && y == 1) stamp(1);
         auto stage = [&](auto PAc, auto PBc) {
 #pragma unroll
@@ -339,6 +358,8 @@ __device__ __forceinline__ void wino4_body(const WParams& p, lds_char* const L, 
             v[x] = (*(lds_cf4*)(s) + *(lds_cf4*)(s + 4 * TB * EP_ROW)) + (*(lds_cf4*)(s + 8 * TB * EP_ROW) + *(lds_cf4*)(s + 12 * TB * EP_ROW));
         }
         const long pix = (long)(4 * (R0 + ebty) + y) * p.W + 4 * (C0 + ebtx);
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias && p.nsplit == 1) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
         if (p.nsplit > 1) {
             float* const base = p.partial + (long)sp * p.N * p.H * p.W * p.Kout + col;
 #pragma unroll
@@ -363,14 +384,14 @@ __device__ __forceinline__ void wino4_body(const WParams& p, lds_char* const L, 
         }
         if ((KO & 32) && y == 1) stamp(7);
         if (y < 3) lds_barrier();                    // the row's staging reads are done before the next row's stores
-        if (!(KO & 32) && y == 0) stamp(3);
+        if (!(KO & 32) && !(KO & 128) && y == 0) stamp(3);
         if ((KO & 32) && y == 1) stamp(4);
     };
     out_row(std::integral_constant<int, 0>{});
     out_row(std::integral_constant<int, 1>{});
     out_row(std::integral_constant<int, 2>{});
     out_row(std::integral_constant<int, 3>{});
-    if (!(KO & 32)) stamp(4);
+    if (!(KO & 32) && !(KO & 128)) stamp(4);
 }
 
 // Persistent launch (as wino_block_kernel): one workgroup per CU, or per item when there are fewer, walking the items.
@@ -380,7 +401,7 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(const WParams p) {
     lds_char* const L = (lds_char*)smem;
     const int total = p.mtiles * p.ntiles * p.nsplit;
     for (int vb = blockIdx.x; vb < total; vb += gridDim.x) {
-        wino4_body<BW, KO>(p, L, vb);
+        wino4_body<BW, KO>(p, L, vb, vb + (int)gridDim.x < total ? vb + (int)gridDim.x : -1);
         lds_barrier();                                // the last row's staging reads are done before the next item's gather lands
     }
 }
@@ -488,10 +509,10 @@ static bool shape_ok(const DpigConvDesc* d, int cin, int kout, int ld_in, int ld
     if ((long)36 * cin * kout * 4 >= lim) return false;
     return true;
 }
-// One workgroup per CU, whole rounds of 256: a workgroup's life is ~6200 cycles per 8-channel chunk (72 MFMAs per SIMD = 4608 of them)
-// + ~34 k cycles of prologue (first gather + transform, ~12 k) and output transform / epilogue (~21 k) -- scripts/trace_wino4.py.
+// One workgroup per CU, whole rounds of 256: a workgroup's life is ~5800 cycles per 8-channel chunk (72 MFMAs per SIMD = 4608 of them)
+// + ~25 k cycles of prologue (first gather + transform, ~7.5 k) and output transform / epilogue (~17 k) -- scripts/trace_wino4.py.
 // Split plans as in the F(2x2, 3x3) family (partials summed by wino_reduce_kernel).
-constexpr double CHUNK_CYCLES = 6200.0, FIXED_CYCLES = 34000.0;
+constexpr double CHUNK_CYCLES = 5800.0, FIXED_CYCLES = 25000.0;
 struct FPlan { int nsplit, cps; double cycles; };
 static FPlan fwd_plan(const DpigConvDesc* d, int cin, int kout) {
     const long T = (long)d->N * (d->H / 4) * (d->W / 4);
@@ -562,8 +583,8 @@ static int launch(const DpigConvDesc* d, const float* in, const float* U, const 
     else if (ko == 7) hipLaunchKernelGGL((wino4_kernel<4, 7>), pgrid, dim3(512), 0, st, p);
     else if (ko == 8) hipLaunchKernelGGL((wino4_kernel<4, 8>), pgrid, dim3(512), 0, st, p);
     else if (ko == 3) hipLaunchKernelGGL((wino4_kernel<4, 3>), pgrid, dim3(512), 0, st, p);
-    else if (ko == 16) hipLaunchKernelGGL((wino4_kernel<4, 16>), pgrid, dim3(512), 0, st, p);
     else if (ko == 32) hipLaunchKernelGGL((wino4_kernel<4, 32>), pgrid, dim3(512), 0, st, p);
+    else if (ko == 192) hipLaunchKernelGGL((wino4_kernel<4, 192>), pgrid, dim3(512), 0, st, p);
 #endif
     else hipLaunchKernelGGL(wino4_kernel<4>, pgrid, dim3(512), 0, st, p);
     (void)ko;

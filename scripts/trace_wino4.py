@@ -36,6 +36,11 @@ for name, N, Hh, W, C in [("C128 128x64", 16, 128, 64, 128), ("C128 48x48", 112,
         m = lambda a, b: (t[:, b] - t[:, a]).mean().item()
         print("%-22s row 1: transform + staging stores %6.0f | barrier %6.0f | sums + epilogue + store issue %6.0f | barrier %6.0f" % (name, m(1, 2), m(2, 3), m(3, 7), m(7, 4)))
         continue
+    if os.environ.get("DPIG_WINO4_KO") == "192":     # prologue stamp mode
+        m = lambda a, b: (t[:, b] - t[:, a]).mean().item()
+        print("%-22s prologue: setup %6.0f | issue of 6 gathers + 9 fragment loads %6.0f | own loads home %6.0f | barrier %6.0f | transform + barrier %6.0f" % (
+            name, m(0, 1), m(1, 2), m(2, 3), m(3, 7), m(7, 4)))
+        continue
     arrive = (t[:, 7] - t[:, 0]).mean().item()
     print("%-22s %6d %5d | %8.0f %9.0f %9.0f %9.0f %9.0f | %9.0f %8.0f  (split %d)" % (name, wgs, nch, arrive, seg[0], seg[1], seg[2], seg[3], tot, seg[1] / nch, split))
 H.set_wino4_mode(1); H.set_compute("f32")
