@@ -202,8 +202,9 @@ def main():
     ap.add_argument("--dtype", default="f32w", choices=["f32", "bf16", "bf16c", "bf16x3", "f32w"],
                     help="f32w (default since round 5, the headline) = the BASELINE metric's arithmetic TYPE -- fp32 tensors, fp32 products, fp32 "
                          "accumulation -- with the 3x3 stride-1 convs (forward, dgrad, wgrad) evaluated by Winograd minimal filtering "
-                         "F(2x2,3x3) / F(3x3,2x2) on the fp32 matrix pipe where the library's cost model says it pays (2.25x fewer multiplies; "
-                         "every golden activation within 1e-4 of max|ref| of the fp64 oracle, tests/test_golden_gpu.py); f32 = the same "
+                         "F(4x4,3x3) (maps with a 4x4-tile block form: 4x fewer multiplies) / F(2x2,3x3) / F(3x3,2x2) (2.25x fewer) on the fp32 "
+                         "matrix pipe where the library's cost model says it pays "
+                         "(every golden activation within 1e-4 of max|ref| of the fp64 oracle, tests/test_golden_gpu.py); f32 = the same "
                          "with every conv on the direct implicit-GEMM kernels (rounds 1-4's headline, now the information line "
                          "market128_direct_f32).  bf16 (information lines; BASELINE configs 3-5): activations, "
                          "their gradients and the filter shadows stored as bf16, bf16 matrix pipe, fp32 accumulation / master "

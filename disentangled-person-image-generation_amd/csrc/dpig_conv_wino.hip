@@ -333,6 +333,7 @@ constexpr int RAW_OFF = 4 * OPB, ZERO_OFF = RAW_OFF + 2 * RAWB, SMEM_BLOCK = ZER
 static_assert(SMEM_BLOCK <= 163840 && SMEM <= SMEM_BLOCK, "LDS plan");
 
 // one workgroup's work item vb (a virtual block index: what the block index is to a launch with one workgroup per item)
+template <bool SLICE_FIRST>
 __device__ __forceinline__ void wino_block_body(const WParams& p, lds_char* const L, const int vb) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -468,13 +469,23 @@ __device__ __forceinline__ void wino_block_body(const WParams& p, lds_char* cons
                 fa[(pp + 1) & 1] = *(lds_cf4*)(Ub + (pp + 1) * PLANE);
                 fb[(pp + 1) & 1] = *(lds_cf4*)(Vb + (pp + 1) * PLANE);
             }
+            if (SLICE_FIRST) {
+                __builtin_amdgcn_sched_barrier(0);
+                if (pp == 1) readRaw(oth);
+                if (pp == 2) rowV();
+                if (pp == 3) colsV(oth, 0);
+                if (pp == 4) colsV(oth, 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int s4 = 0; s4 < 4; ++s4) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[pp & 1][s4], fb[pp & 1][s4], acc[pp], 0, 0, 0);
             if (pp == 0) { dmaU(c + 1, oth); dmaRaw(c + 2, buf); }
-            if (pp == 1) readRaw(oth);
-            if (pp == 2) rowV();
-            if (pp == 3) colsV(oth, 0);
-            if (pp == 4) colsV(oth, 1);
+            if (!SLICE_FIRST) {
+                if (pp == 1) readRaw(oth);
+                if (pp == 2) rowV();
+                if (pp == 3) colsV(oth, 0);
+                if (pp == 4) colsV(oth, 1);
+            }
             __builtin_amdgcn_sched_barrier(0);
         }
         wait_vm<0>();                                // this wave's DMA pieces (issued seven steps ago) are home
@@ -532,12 +543,13 @@ __device__ __forceinline__ void wino_block_body(const WParams& p, lds_char* cons
 // vb = blockIdx.x, + gridDim.x, ... (gridDim.x a multiple of the XCD count keeps an item's XCD what xcd_remap assumes).  With one
 // 136-KB workgroup per CU nothing else can be resident while the dispatcher retires a workgroup and starts the next: that gap
 // (~6 us per round) was the difference between 4 rounds x 87.7 k cycles = 146 us and the 178 us a C = 128 layer took.
+template <bool SLICE_FIRST>
 __global__ __launch_bounds__(512, 2) void wino_block_kernel(const WParams p) {
     __shared__ __attribute__((aligned(16))) char smem[SMEM_BLOCK];
     lds_char* const L = (lds_char*)smem;
     const int total = p.mtiles * p.ntiles * p.nsplit;
     for (int vb = blockIdx.x; vb < total; vb += gridDim.x) {
-        wino_block_body(p, L, vb);
+        wino_block_body<SLICE_FIRST>(p, L, vb);
         __syncthreads();                              // the epilogue's staging reads are done before the next item's DMA lands
     }
 }
@@ -572,6 +584,7 @@ struct WGParams {
     unsigned mul_thw, shr_thw, mul_tw, shr_tw;
 };
 
+template <bool SLICE_FIRST>
 __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WGParams p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * OPB];
     lds_char* const L = (lds_char*)smem;
@@ -718,6 +731,19 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WGParams p) {
                     fb[(pp + 1) & 1][s] = *(lds_cf*)(Bb + (pp + 1) * PLANE + s * 512);
                 }
             }
+            auto slice = [&]() {
+                if (pp == 0) { tile_offsets(c + 2); rowX(); rowY(); }
+                if (pp == 1) { loadX(); loadY(); }
+                if (pp == 2) colsX(buf ^ 1, 0);
+                if (pp == 3) colsX(buf ^ 1, 1);
+                if (pp == 4) colsY(buf ^ 1, 0);
+                if (pp == 5) colsY(buf ^ 1, 1);
+            };
+            if (SLICE_FIRST) {                       // (the order the F(4x4, 3x3) kernel measured 6 % faster: fragment reads, slice, MFMAs)
+                __builtin_amdgcn_sched_barrier(0);
+                slice();
+                __builtin_amdgcn_sched_barrier(0);
+            }
 #pragma unroll
             for (int s = 0; s < 4; ++s) acc[pp] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[pp & 1][s], fb[pp & 1][s], acc[pp], 0, 0, 0);
             // staging slices.  The row transforms of chunk c + 1 come FIRST: they free the load registers, so the loads of chunk c + 2 can
@@ -725,12 +751,7 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WGParams p) {
             // of the chunk (two steps ahead of their use) an L2 hit's latency was exposed every chunk: a knock-out build without the
             // loads ran 293 instead of 219 TFLOP/s on dec3 (build/ko/run_wg.sh; an L2 prefetch four chunks ahead changed nothing:
             // the lines were L2-resident already, the other (c, k) blocks of the XCD read them too).
-            if (pp == 0) { tile_offsets(c + 2); rowX(); rowY(); }
-            if (pp == 1) { loadX(); loadY(); }
-            if (pp == 2) colsX(buf ^ 1, 0);
-            if (pp == 3) colsX(buf ^ 1, 1);
-            if (pp == 4) colsY(buf ^ 1, 0);
-            if (pp == 5) colsY(buf ^ 1, 1);
+            if (!SLICE_FIRST) slice();
             __builtin_amdgcn_sched_barrier(0);
         }
         __syncthreads();
@@ -1037,7 +1058,9 @@ static int launch(const DpigConvDesc* d, const float* in, const float* U, const 
         static const char* pers = getenv("DPIG_WINO_PERSIST");      // 0: one workgroup per item (measurements)
         const unsigned items = grid.x;
         const dim3 pgrid((pers && atoi(pers) == 0) || items <= (unsigned)kNumCU ? items : (unsigned)kNumCU);
-        hipLaunchKernelGGL(wino_block_kernel, pgrid, dim3(512), 0, st, p);
+        static const bool slice_first = getenv("DPIG_WINO_ORDER") && atoi(getenv("DPIG_WINO_ORDER")) == 1;      // (A/B switch)
+        if (slice_first) hipLaunchKernelGGL(wino_block_kernel<true>, pgrid, dim3(512), 0, st, p);
+        else hipLaunchKernelGGL(wino_block_kernel<false>, pgrid, dim3(512), 0, st, p);
         rc = check_launch("wino_block_kernel");
     } else {
         hipLaunchKernelGGL(wino_kernel, grid, dim3(512), 0, st, p);
@@ -1141,7 +1164,9 @@ extern "C" int dpig_conv2d_wgrad_wino(const DpigConvDesc* d, const float* x, con
     p.y_bytes = (unsigned)((long)d->N * d->H * d->W * d->ldy * 4);
     find_divisor(p.THW, &p.mul_thw, &p.shr_thw);
     find_divisor(p.TW, &p.mul_tw, &p.shr_tw);
-    hipLaunchKernelGGL(wino::wino_wgrad_kernel, dim3(p.cblocks * p.kblocks * p.nsplit), dim3(512), 0, st, p);
+    static const bool slice_first = getenv("DPIG_WINO_WG_ORDER") && atoi(getenv("DPIG_WINO_WG_ORDER")) == 1;      // (A/B switch)
+    if (slice_first) hipLaunchKernelGGL(wino::wino_wgrad_kernel<true>, dim3(p.cblocks * p.kblocks * p.nsplit), dim3(512), 0, st, p);
+    else hipLaunchKernelGGL(wino::wino_wgrad_kernel<false>, dim3(p.cblocks * p.kblocks * p.nsplit), dim3(512), 0, st, p);
     rc = check_launch("wino_wgrad_kernel");
     if (rc) return rc;
     const long n4 = (long)9 * d->C * d->K / 4;

@@ -5,6 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from dpig_amd import hip_ops as H
 dev = torch.device("cuda:0")
+H.set_wino4_mode(0)              # this script compares the direct kernels with F(2x2,3x3) / F(3x3,2x2); scripts/bench_conv_wino4.py holds F(4x4,3x3)
 MARKET = [("E.res / enc0 128x64 C128", 16, 128, 64, 128), ("roi b0 48x48 C128", 112, 48, 48, 128), ("enc1 64x32 C256", 16, 64, 32, 256),
           ("roi b1 24x24 C256", 112, 24, 24, 256), ("enc2 32x16 C384", 16, 32, 16, 384), ("roi b2 12x12 C384", 112, 12, 12, 384),
           ("enc3 16x8 C512", 16, 16, 8, 512), ("roi b3 6x6 C512", 112, 6, 6, 512), ("enc4 8x4 C640", 16, 8, 4, 640),
