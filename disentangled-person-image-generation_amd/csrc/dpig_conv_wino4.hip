@@ -61,7 +61,22 @@ typedef const __attribute__((address_space(3))) f32x4 lds_cf4;
 // B^T of F(4, 3) applied along one axis:  [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1],
 // in three parts of two results each (the k-loop spreads them over three of its steps); every result leaves through
 // `out(index, value)` as soon as it exists (the callers store it: no second set of six registers)
-__device__ __forceinline__ f32x4 fma4(f32x4 a, float b, f32x4 c) { return __builtin_elementwise_fma(a, f32x4{b, b, b, b}, c); }
+// (written on register pairs; the compiler packs or unpacks them -- v_pk_fma_f32 / v_fma_f32 -- as its MFMA co-issue heuristic decides)
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 fma4(f32x4 a, float b, f32x4 c) {
+    const f32x2_t bb = {b, b};
+    const f32x2_t lo = __builtin_elementwise_fma(f32x2_t{a[0], a[1]}, bb, f32x2_t{c[0], c[1]});
+    const f32x2_t hi = __builtin_elementwise_fma(f32x2_t{a[2], a[3]}, bb, f32x2_t{c[2], c[3]});
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+__device__ __forceinline__ f32x4 add4(f32x4 a, f32x4 c) {
+    const f32x2_t lo = f32x2_t{a[0], a[1]} + f32x2_t{c[0], c[1]}, hi = f32x2_t{a[2], a[3]} + f32x2_t{c[2], c[3]};
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+__device__ __forceinline__ f32x4 sub4(f32x4 a, f32x4 c) {
+    const f32x2_t lo = f32x2_t{a[0], a[1]} - f32x2_t{c[0], c[1]}, hi = f32x2_t{a[2], a[3]} - f32x2_t{c[2], c[3]};
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
 template <int PART, class F>
 __device__ __forceinline__ void bt6(const f32x4 (&d)[6], F&& out) {
     if (PART == 0) {
@@ -70,11 +85,11 @@ __device__ __forceinline__ void bt6(const f32x4 (&d)[6], F&& out) {
     } else if (PART == 1) {
         const f32x4 a = fma4(d[2], -4.f, d[4]);
         const f32x4 b = fma4(d[1], -4.f, d[3]);
-        out(1, a + b);
-        out(2, a - b);
+        out(1, add4(a, b));
+        out(2, sub4(a, b));
     } else {
-        const f32x4 c = fma4(d[2], -1.f, d[4]);
-        const f32x4 e = fma4(d[1], -1.f, d[3]);
+        const f32x4 c = sub4(d[4], d[2]);
+        const f32x4 e = sub4(d[3], d[1]);
         out(3, fma4(e, 2.f, c));
         out(4, fma4(e, -2.f, c));
     }
@@ -132,22 +147,33 @@ __device__ __forceinline__ void out_row_group(const f32x16 (&acc)[9], int g, f32
 // counts stores -- which put a store round trip on every output row: the staging is all these barriers protect)
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int BW, int KO = 0>   // KO: knock-out bits for timing experiments (DPIG_WINO4_KO; results are wrong): 1 no transforms, 2 no filter loads, 4 no raw gather, 8 no MFMAs
-__device__ __forceinline__ void wino4_body(const WParams& p, lds_char* const L, const int vb, const int vb_next) {
+// (KO: knock-out bits for timing experiments -- DPIG_WINO4_KO; results are wrong: 1 no transforms, 2 no filter loads, 4 no raw gather, 8 no MFMAs)
+__device__ __forceinline__ int lane_id() { return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+// a zero the compiler cannot hoist (hoisted out of the persistent loop, the zero vector was spilled and reloaded per output row)
+__device__ __forceinline__ f32x4 fresh_zero4() {
+    float z;
+    asm volatile("v_mov_b32 %0, 0" : "=v"(z));
+    return f32x4{z, z, z, z};
+}
+
+template <int BW, int KO = 0>
+__device__ __forceinline__ void wino4_body(const WParams& p, lds_char* const L, const int vb, const int wave) {
     constexpr int BH = TB / BW, RW = 4 * BW + 2, RH = 4 * BH + 2, RPIX = RW * RH, PIECES = (2 * RPIX + 63) / 64;
     static_assert(PIECES <= RAW_PIECES && PIECES > 16, "raw gather plan");
     // (the thread index passes through an empty asm: everything derived from it is recomputed per item, a few dozen instructions.  Hoisted
     // out of the persistent loop those values were spilled across the k-loop -- the register file is full -- and every item began with
     // five scratch reloads, each behind a wait for ALL memory operations in flight, the previous item's output stores included:
     // 3-4 k cycles per item)
-    int tid = threadIdx.x;
-    asm volatile("" : "+v"(tid));
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int lane = lane_id();
+    asm volatile("" : "+v"(lane));
+    const int tid = wave * 64 + lane;                 // (the wave's index is a scalar made once per kernel: no register holds threadIdx.x)
     const int l31 = lane & 31, half = lane >> 5;
     const int bid = xcd_remap(vb, p.mtiles * p.ntiles * p.nsplit);
     const int sp = bid / (p.mtiles * p.ntiles), tile = bid - sp * (p.mtiles * p.ntiles);
-    const int nt = p.xmajor ? tile % p.ntiles : tile / p.mtiles, mt = p.xmajor ? tile / p.ntiles : tile - nt * p.mtiles;
+    // (both orders by integer arithmetic: as a boolean the choice was kept in a vector register -- the scalar file is full -- spilled, and
+    // reloaded at the top of every item behind a wait for the previous item's stores)
+    const int nt_f = tile / p.mtiles, mt_f = tile - nt_f * p.mtiles, mt_x = tile / p.ntiles, nt_x = tile - mt_x * p.ntiles;
+    const int nt = nt_f + p.xmajor * (nt_x - nt_f), mt = mt_f + p.xmajor * (mt_x - mt_f);
     const int n0 = nt * KB;
     const int cb = sp * p.cps, ce = min(cb + p.cps, p.nch);
     const int bcols = p.TW / BW;
@@ -163,7 +189,7 @@ __device__ __forceinline__ void wino4_body(const WParams& p, lds_char* const L, 
     stamp(0);
     const __amdgpu_buffer_rsrc_t rsX = make_rsrc(p.X, p.x_bytes);
     const __amdgpu_buffer_rsrc_t rsU = make_rsrc(p.U, p.u_bytes);
-    if (tid < 4) *(lds_f4*)(L + ZERO_OFF + tid * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (tid < 4) *(lds_f4*)(L + ZERO_OFF + tid * 16) = fresh_zero4();
 
     // ---- raw-gather role: piece ids wave, wave + 8, wave + 16 (< PIECES); lane slot s = 64 id + lane = (raw pixel s / 2, 16-byte half s & 1)
     int g_voff[3];
@@ -324,13 +350,15 @@ __device__ __forceinline__ void wino4_body(const WParams& p, lds_char* const L, 
         constexpr int y = decltype(Yc)::value;
         // (the row's lane roles and addresses are made here, from the thread index through an empty asm: kept across the rows they were
         // spilled, and every reload waited for the previous row's output stores -- vmcnt counts stores)
-        int tid2 = threadIdx.x;
-        asm volatile("" : "+v"(tid2));
+        int lane2 = lane_id();
+        asm volatile("" : "+v"(lane2));
+        const int tid2 = wave * 64 + lane2;
         // (and the accumulators: two rows of a position group can share sub-expressions -- rows 1 and 3 of the groups that hold grid rows
         // 0-2 are identical -- and values kept from one row for another do not fit either)
         asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]));
         const int cg = tid2 & 15, tloc = tid2 >> 4, col = n0 + 4 * cg;
         const int ebty = tloc / BW, ebtx = tloc - ebty * BW;
+        const long pix = (long)(4 * (R0 + ebty) + y) * p.W + 4 * (C0 + ebtx);
         if ((KO & 32) && y == 1) stamp(1);
         auto stage = [&](auto PAc, auto PBc) {
 #pragma unroll
@@ -340,6 +368,7 @@ __device__ __forceinline__ void wino4_body(const WParams& p, lds_char* const L, 
 #pragma unroll
                 for (int x = 0; x < 4; ++x)
                     *(lds_f4*)(L + ((pg * 4 + x) * TB + l31) * EP_ROW + (32 * wc + 8 * g + 4 * half) * 4) = P[x];
+                __builtin_amdgcn_sched_barrier(0);   // (one channel group at a time)
             }
         };
         typedef std::integral_constant<int, 0> I0;
@@ -348,6 +377,19 @@ __device__ __forceinline__ void wino4_body(const WParams& p, lds_char* const L, 
         else if (pg == 1) stage(I0{}, I1{});
         else if (pg == 2) stage(I1{}, I0{});
         else stage(I1{}, I1{});
+        // the general epilogue's operands (residual / accumulate tensor, activation mask) of this row's four pixels are asked for HERE,
+        // between the staging stores and the barrier: loaded where they are used, behind this row's own LDS reads, the masked dgrad ran
+        // 14 % behind the plain one (a memory round trip per row, plus the previous row's output stores: one counter); asked for before
+        // the transform they do not fit beside the accumulators (the allocator spilled all eight)
+        const bool general = p.nsplit == 1 && (p.res || p.mask || p.D2);
+        f32x4 rv[4], mv[4];
+        if (general) {
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {            // (left unset where the launch has no such operand: never read then)
+                if (p.res) rv[x] = *reinterpret_cast<const f32x4*>(p.res + (pix + x) * p.ldres + col);
+                if (p.mask) mv[x] = *reinterpret_cast<const f32x4*>(p.mask + (pix + x) * p.ldmask + col);
+            }
+        }
         if ((KO & 32) && y == 1) stamp(2);
         lds_barrier();
         if ((KO & 32) && y == 1) stamp(3);
@@ -356,9 +398,9 @@ __device__ __forceinline__ void wino4_body(const WParams& p, lds_char* const L, 
         for (int x = 0; x < 4; ++x) {
             const lds_char* const s = L + (x * TB + tloc) * EP_ROW + cg * 16;
             v[x] = (*(lds_cf4*)(s) + *(lds_cf4*)(s + 4 * TB * EP_ROW)) + (*(lds_cf4*)(s + 8 * TB * EP_ROW) + *(lds_cf4*)(s + 12 * TB * EP_ROW));
+            if (x == 1) __builtin_amdgcn_sched_barrier(0);      // (eight reads in flight, not sixteen: beside the accumulators and the general path's operands 64 registers of read data spill)
         }
-        const long pix = (long)(4 * (R0 + ebty) + y) * p.W + 4 * (C0 + ebtx);
-        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        f32x4 bv = fresh_zero4();
         if (p.bias && p.nsplit == 1) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
         if (p.nsplit > 1) {
             float* const base = p.partial + (long)sp * p.N * p.H * p.W * p.Kout + col;
@@ -380,7 +422,20 @@ __device__ __forceinline__ void wino4_body(const WParams& p, lds_char* const L, 
             else plain(std::integral_constant<int, DPIG_ACT_NONE>{});
         } else {
 #pragma unroll
-            for (int x = 0; x < 4; ++x) epi4(p, pix + x, col, v[x], bv);
+            for (int x = 0; x < 4; ++x) {            // (epi4 of dpig_wino_common.h on the operands loaded above)
+                f32x4 o = v[x] + bv;
+                if (p.res && !p.res_post) o += rv[x];
+                if (p.mask) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] *= act_grad(mv[x][e], p.act, p.alpha);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[e] = act_apply(o[e], p.act, p.alpha);
+                }
+                if (p.D2) *reinterpret_cast<f32x4*>(p.D2 + (pix + x) * p.ldd2 + col) = o;
+                if (p.res && p.res_post) o += rv[x];
+                *reinterpret_cast<f32x4*>(p.D + (pix + x) * p.ldd + col) = o;
+            }
         }
         if ((KO & 32) && y == 1) stamp(7);
         if (y < 3) lds_barrier();                    // the row's staging reads are done before the next row's stores
@@ -400,8 +455,9 @@ __global__ __launch_bounds__(512, 2) void wino4_kernel(const WParams p) {
     __shared__ __attribute__((aligned(16))) char smem[SMEM];
     lds_char* const L = (lds_char*)smem;
     const int total = p.mtiles * p.ntiles * p.nsplit;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int vb = blockIdx.x; vb < total; vb += gridDim.x) {
-        wino4_body<BW, KO>(p, L, vb, vb + (int)gridDim.x < total ? vb + (int)gridDim.x : -1);
+        wino4_body<BW, KO>(p, L, vb, wave);
         lds_barrier();                                // the last row's staging reads are done before the next item's gather lands
     }
 }

@@ -58,11 +58,13 @@ for name, N, Hh, W, C in layers:
     y4 = H.conv2d_fwd(x, w, b, act=1)
     t_f4 = timeit(lambda: H.conv2d_fwd(x, w, b, act=1))
     t_d4 = timeit(lambda: H.conv2d_dgrad(dy, w, (N, Hh, W, C)))
+    t_d4m = timeit(lambda: H.conv2d_dgrad(dy, w, (N, Hh, W, C), mask=x, act=1))          # the form most dgrads of the step have: * act'(mask)
+    t_f4r = timeit(lambda: H.conv2d_fwd(x, w, b, act=1, residual=dy))                    # forward with a residual (the encoder's blocks)
     H.set_compute("f32")
     for i, t in enumerate((t_f2, t_f4, t_d2, t_d4)):
         tot[i] += t
     print("%-28s %9.1f | %6.1f TF %6.1f TF %6.1f TF %5.2fx | %6.1f TF %6.1f TF %5.2fx | %6.1f %6.1f | %.1e %.1e | %s" % (
         name, flops / 1e9, flops / t_fd / 1e12, flops / t_f2 / 1e12, flops / t_f4 / 1e12, t_f2 / t_f4, flops / t_d2 / 1e12, flops / t_d4 / 1e12,
         t_d2 / t_d4, flops / 4 / t_f4 / 1e12, flops / 4 / t_d4 / 1e12, float((y2 - yd).abs().max() / yd.abs().max()),
-        float((y4 - yd).abs().max() / yd.abs().max()), "F4" if pays else "F2"))
+        float((y4 - yd).abs().max() / yd.abs().max()), "F4" if pays else "F2") + " | dgrad*mask %.1f TF, fwd+res %.1f TF" % (flops / t_d4m / 1e12, flops / t_f4r / 1e12))
 print("sum of launches on layers with the form [ms]: fwd F2 %.3f F4 %.3f | dgrad F2 %.3f F4 %.3f" % tuple(t * 1e3 for t in tot))
