@@ -565,10 +565,10 @@ static bool shape_ok(const DpigConvDesc* d, int cin, int kout, int ld_in, int ld
     if ((long)36 * cin * kout * 4 >= lim) return false;
     return true;
 }
-// One workgroup per CU, whole rounds of 256: a workgroup's life is ~5800 cycles per 8-channel chunk (72 MFMAs per SIMD = 4608 of them)
-// + ~25 k cycles of prologue (first gather + transform, ~7.5 k) and output transform / epilogue (~17 k) -- scripts/trace_wino4.py.
+// One workgroup per CU, whole rounds of 256: a workgroup's life is ~5900 cycles per 8-channel chunk (72 MFMAs per SIMD = 4608 of them)
+// + ~26 k cycles of prologue (first gather + transform, ~7.5 k) and output transform / epilogue (~18 k) -- scripts/trace_wino4.py.
 // Split plans as in the F(2x2, 3x3) family (partials summed by wino_reduce_kernel).
-constexpr double CHUNK_CYCLES = 5800.0, FIXED_CYCLES = 25000.0;
+constexpr double CHUNK_CYCLES = 5900.0, FIXED_CYCLES = 26000.0;
 struct FPlan { int nsplit, cps; double cycles; };
 static FPlan fwd_plan(const DpigConvDesc* d, int cin, int kout) {
     const long T = (long)d->N * (d->H / 4) * (d->W / 4);

@@ -437,7 +437,9 @@ class WinoFilters(object):
         if not getattr(self, "params", None):
             return
         self.refreshes += 1
-        if self.refreshes == 2 and not self.pruned and not torch.cuda.is_current_stream_capturing():
+        # (the first refresh after the set's layers have run: a refresh that comes before any of them -- a checkpoint restore -- decides nothing)
+        if self.refreshes >= 2 and not self.pruned and any(p._dpig_wino_use for p in self.params) \
+                and not torch.cuda.is_current_stream_capturing():
             self.prune()
         self._run(self.plan2, self.p2, "_dpig_wino", False)
         self._run(self.plan4, self.p4, "_dpig_wino4", True)

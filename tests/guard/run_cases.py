@@ -18,7 +18,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 faulthandler.enable(all_threads=True)
 
 
-def model_case(trainer_mod, cls, steps=2, batch=2, prep=None, **cfg):
+def model_case(trainer_mod, cls, steps=2, batch=2, prep=None, wino4=None, **cfg):
     def run(dev):
         import importlib
         import numpy as np
@@ -29,6 +29,7 @@ def model_case(trainer_mod, cls, steps=2, batch=2, prep=None, **cfg):
         lib.delete_all_params(); slim.reset_scopes()
         np.random.seed(0)
         prev = H.set_wino_mode(2)
+        prev4 = H.set_wino4_mode(wino4) if wino4 is not None else H.get_wino4_mode()     # (2: the F(4x4,3x3) kernel wherever the layer has the form)
         try:
             c = Config(batch_size=batch, **cfg)
             tr = getattr(importlib.import_module("dpig_amd." + trainer_mod), cls)(c, dev)
@@ -44,6 +45,7 @@ def model_case(trainer_mod, cls, steps=2, batch=2, prep=None, **cfg):
             assert all(v == v for v in vals), out          # (NaN check: with DPIG_GUARD_FILL=255 fresh memory is NaN)
         finally:
             H.set_wino_mode(prev)
+            H.set_wino4_mode(prev4)
             H.set_compute("f32")
             lib.delete_all_params(); slim.reset_scopes()
     return run
@@ -56,8 +58,9 @@ def conv_case(N, Hh, W, C, K, R, stride, mode="f32", up=False, slack=0):
         import torch
         import dpig_amd.hip_ops as H
         from dpig_amd import autograd as A
-        H.set_compute(mode)
+        H.set_compute("f32w" if mode == "f32w4" else mode)
         prev = H.set_wino_mode(2)
+        prev4 = H.set_wino4_mode(2 if mode == "f32w4" else 0)       # "f32w4": F(4x4,3x3); "f32w": F(2x2,3x3)
         try:
             g = torch.Generator().manual_seed(N * 1000 + C * 7 + K)
             dt = torch.bfloat16 if (mode == "bf16" and C % 8 == 0) else torch.float32
@@ -71,6 +74,7 @@ def conv_case(N, Hh, W, C, K, R, stride, mode="f32", up=False, slack=0):
             assert torch.isfinite(y.float()).all() and torch.isfinite(w.grad).all() and torch.isfinite(x.grad.float()).all()
         finally:
             H.set_wino_mode(prev)
+            H.set_wino4_mode(prev4)
             H.set_compute("f32")
     return run
 
@@ -92,6 +96,7 @@ def build_cases():
     cases.append(("step market w16 bf16 wgan-gp", model_case("trainer", M, conv_hidden_num=16, z_num=8, compute_dtype="bf16", gan_mode="wgan-gp")))
     cases.append(("step market w16 bf16x3", model_case("trainer", M, conv_hidden_num=16, z_num=8, compute_dtype="bf16x3")))
     cases.append(("step market w64 f32w", model_case("trainer", M, conv_hidden_num=64, z_num=16, compute_dtype="f32w")))
+    cases.append(("step market w64 f32w F(4x4)", model_case("trainer", M, wino4=2, conv_hidden_num=64, z_num=16, compute_dtype="f32w")))
     cases.append(("step market w64 bf16", model_case("trainer", M, conv_hidden_num=64, z_num=16, compute_dtype="bf16")))
     cases.append(("step market w24 f32 B=1", model_case("trainer", M, batch=1, conv_hidden_num=24, z_num=8)))
     cases.append(("step market w16 f32 B=3", model_case("trainer", M, batch=3, conv_hidden_num=16, z_num=8)))
@@ -126,6 +131,10 @@ def build_cases():
     for (N, Hh, W, C, K) in ((1, 2, 2, 64, 64), (2, 4, 2, 64, 128), (1, 6, 6, 128, 64)):       # Winograd forms
         for slack in (0, 64):
             cases.append(("conv f32w N%d %dx%d C%d K%d slack%d" % (N, Hh, W, C, K, slack), conv_case(N, Hh, W, C, K, 3, 1, "f32w", slack=slack)))
+    # F(4x4,3x3) forms: one 4 x 8 block, a 2 x 16 block holding eight images, block rows that straddle images, a split plan
+    for (N, Hh, W, C, K) in ((1, 32, 16, 64, 64), (8, 8, 8, 64, 128), (2, 16, 16, 128, 64), (2, 16, 16, 448, 64)):
+        for slack in (0, 64):
+            cases.append(("conv f32w F(4x4) N%d %dx%d C%d K%d slack%d" % (N, Hh, W, C, K, slack), conv_case(N, Hh, W, C, K, 3, 1, "f32w4", slack=slack)))
     for (N, Hh, W, C, K) in ((1, 1, 1, 20, 6), (2, 3, 3, 72, 24), (1, 4, 2, 64, 16)):           # upsample-fused 1x1 / 3x3
         cases.append(("conv f32 up2x N%d %dx%d C%d K%d" % (N, Hh, W, C, K), conv_case(N, Hh, W, C, K, 1, 1, "f32", up=True)))
     return cases
