@@ -61,7 +61,11 @@ typedef const __attribute__((address_space(3))) f32x4 lds_cf4;
 // B^T of F(4, 3) applied along one axis:  [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1],
 // in three parts of two results each (the k-loop spreads them over three of its steps); every result leaves through
 // `out(index, value)` as soon as it exists (the callers store it: no second set of six registers)
-// (written on register pairs; the compiler packs or unpacks them -- v_pk_fma_f32 / v_fma_f32 -- as its MFMA co-issue heuristic decides)
+// (written on register pairs; the compiler's post-RA peephole unpacks most of them -- v_pk_fma_f32 -> 2 x v_fma_f32 -- in the shadow of
+// the MFMAs.  Forced packed through inline asm (48 instead of 84 vector instructions per chunk) the k-loop takes the SAME 5890 cycles:
+// fp32 vector arithmetic costs matrix-pipe time by its lane-operations, not its instruction count -- the fp32 MFMA and packed fp32
+// vector peaks are the same 157 TFLOP/s.  scripts/ko_wino4.sh: the transforms' arithmetic is 970 of the loop's 1100 cycles over the
+// bare MFMAs, their LDS reads and stores 60, filter loads + raw gather 75)
 typedef float f32x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ f32x4 fma4(f32x4 a, float b, f32x4 c) {
     const f32x2_t bb = {b, b};
@@ -243,6 +247,12 @@ __device__ __forceinline__ void wino4_body(const WParams& p, lds_char* const L, 
         d[5] = *(lds_cf4*)(L + a_bot[slot]);
     };
     auto passA = [&](auto PART) {                                       // column transform -> scratch rows
+        if (KO & 16) {                               // (knock-out: the stores without the arithmetic)
+            constexpr int P = decltype(PART)::value;
+            *(lds_f4*)(L + t_wr + (P == 0 ? 0 : P == 1 ? 1 : 3) * T_XS) = d[0];
+            *(lds_f4*)(L + t_wr + (P == 0 ? 5 : P == 1 ? 2 : 4) * T_XS) = d[1];
+            return;
+        }
         bt6<decltype(PART)::value>(d, [&](int xi, f32x4 v) { *(lds_f4*)(L + t_wr + xi * T_XS) = v; });
     };
     auto readB = [&]() {
@@ -250,6 +260,12 @@ __device__ __forceinline__ void wino4_body(const WParams& p, lds_char* const L, 
         for (int s = 0; s < 6; ++s) d[s] = *(lds_cf4*)(L + t_rd + s * 16);
     };
     auto passB = [&](int buf, auto PART) {                              // row transform -> V rows
+        if (KO & 16) {
+            constexpr int P = decltype(PART)::value;
+            *(lds_f4*)(L + v_wr + buf * VB + (6 * (P == 0 ? 0 : P == 1 ? 1 : 3)) * PS) = d[0];
+            *(lds_f4*)(L + v_wr + buf * VB + (6 * (P == 0 ? 5 : P == 1 ? 2 : 4)) * PS) = d[1];
+            return;
+        }
         bt6<decltype(PART)::value>(d, [&](int nu, f32x4 v) { *(lds_f4*)(L + v_wr + buf * VB + (6 * nu) * PS) = v; });
     };
     // ---- MFMA role: wave = (position group pg = (a, b): rows 3 a .. 3 a + 2, columns 3 b .. 3 b + 2 of the 6 x 6 grid; channel half wc) ------
@@ -639,6 +655,7 @@ static int launch(const DpigConvDesc* d, const float* in, const float* U, const 
     else if (ko == 7) hipLaunchKernelGGL((wino4_kernel<4, 7>), pgrid, dim3(512), 0, st, p);
     else if (ko == 8) hipLaunchKernelGGL((wino4_kernel<4, 8>), pgrid, dim3(512), 0, st, p);
     else if (ko == 3) hipLaunchKernelGGL((wino4_kernel<4, 3>), pgrid, dim3(512), 0, st, p);
+    else if (ko == 16) hipLaunchKernelGGL((wino4_kernel<4, 16>), pgrid, dim3(512), 0, st, p);
     else if (ko == 32) hipLaunchKernelGGL((wino4_kernel<4, 32>), pgrid, dim3(512), 0, st, p);
     else if (ko == 192) hipLaunchKernelGGL((wino4_kernel<4, 192>), pgrid, dim3(512), 0, st, p);
 #endif
