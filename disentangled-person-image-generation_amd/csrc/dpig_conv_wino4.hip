@@ -6,7 +6,7 @@
 // multiply by up to 8 / 5 / 1/24: errors of a few 1e-6 of the largest activation instead of a few 1e-7; scripts/f43_numerics.py holds
 // every golden activation of the full-width model to 6.2e-6 with this form on all maps whose sides are multiples of 4, bar 1e-4) and
 // structural: 36 position GEMMs  M_p[tile, k] = sum_c V_p[tile, c] U_p[c, k]  need 36 accumulator blocks, so a workgroup owns 32 tiles
-// (512 output pixels, a block of BW x 32 / BW tiles on the stack of all images' tile rows) x 64 output channels:
+// (512 output pixels, a block of BW x 32 / BW tiles, BW = 4, 2 or 3, on the stack of all images' tile rows) x 64 output channels:
 //   * eight waves = 4 position groups (the 3 x 3 sub-squares of the 6 x 6 position grid) x 2 channel halves; a wave holds nine
 //     32 x 32 accumulator blocks of v_mfma_f32_32x32x2_f32 (144 registers), two waves per SIMD, one workgroup per CU (persistent);
 //   * no two waves share a filter fragment (one tile block per workgroup), so the transformed filter U never touches LDS: the image
@@ -162,7 +162,10 @@ __device__ __forceinline__ f32x4 fresh_zero4() {
 
 template <int BW, int KO = 0>
 __device__ __forceinline__ void wino4_body(const WParams& p, lds_char* const L, const int vb, const int wave) {
-    constexpr int BH = TB / BW, RW = 4 * BW + 2, RH = 4 * BH + 2, RPIX = RW * RH, PIECES = (2 * RPIX + 63) / 64;
+    // (BW = 3 -- maps with three, six, nine .. tile columns, 12 x 12 say -- uses 30 of the 32 tile slots: the MFMA rows of slots 30, 31 and
+    // of tile rows past the end of the stack (a partial last block) hold whatever the transform made of out-of-range pixels, and the
+    // output phase leaves them out)
+    constexpr int BH = TB / BW, TBV = BW * BH, RW = 4 * BW + 2, RH = 4 * BH + 2, RPIX = RW * RH, PIECES = (2 * RPIX + 63) / 64;
     static_assert(PIECES <= RAW_PIECES && PIECES > 16, "raw gather plan");
     // (the thread index passes through an empty asm: everything derived from it is recomputed per item, a few dozen instructions.  Hoisted
     // out of the persistent loop those values were spilled across the k-loop -- the register file is full -- and every item began with
@@ -220,7 +223,8 @@ __device__ __forceinline__ void wino4_body(const WParams& p, lds_char* const L, 
     // pass A: patch column j; pass B: transform row xi = j
     const int j = min(lane & 7, 5), it = lane >> 3;                   // (lanes 6 and 7 of an item repeat lane 5: no EXEC games, counted waits)
     const int tl = 4 * wave + (it >> 1), q = it & 1;
-    const int bty = tl / BW, btx = tl - bty * BW;
+    const int tlv = min(tl, TBV - 1);                                 // (unused slots repeat the last tile's patch: reads stay inside the raw slot)
+    const int bty = tlv / BW, btx = tlv - bty * BW;
     int a_mid, a_top[2], a_bot[2];                                    // LDS byte addresses of patch rows 1..4 (slot 0), row 0 and row 5 (per slot; the zero slot where the row is padding)
     {
         const int R = R0 + bty;
@@ -374,7 +378,8 @@ __device__ __forceinline__ void wino4_body(const WParams& p, lds_char* const L, 
         asm volatile("" : "+v"(acc[0]), "+v"(acc[1]), "+v"(acc[2]), "+v"(acc[3]), "+v"(acc[4]), "+v"(acc[5]), "+v"(acc[6]), "+v"(acc[7]), "+v"(acc[8]));
         const int cg = tid2 & 15, tloc = tid2 >> 4, col = n0 + 4 * cg;
         const int ebty = tloc / BW, ebtx = tloc - ebty * BW;
-        const long pix = (long)(4 * (R0 + ebty) + y) * p.W + 4 * (C0 + ebtx);
+        const bool live = (tloc < TBV) & (4 * (R0 + ebty) < p.N * p.H);         // a tile slot in use, on a tile row of the stack
+        const long pix = live ? (long)(4 * (R0 + ebty) + y) * p.W + 4 * (C0 + ebtx) : 0;
         if ((KO & 32) && y == 1) stamp(1);
         auto stage = [&](auto PAc, auto PBc) {
 #pragma unroll
@@ -399,7 +404,7 @@ __device__ __forceinline__ void wino4_body(const WParams& p, lds_char* const L, 
         // the transform they do not fit beside the accumulators (the allocator spilled all eight)
         const bool general = p.nsplit == 1 && (p.res || p.mask || p.D2);
         f32x4 rv[4], mv[4];
-        if (general) {
+        if (general && live) {
 #pragma unroll
             for (int x = 0; x < 4; ++x) {            // (left unset where the launch has no such operand: never read then)
                 if (p.res) rv[x] = *reinterpret_cast<const f32x4*>(p.res + (pix + x) * p.ldres + col);
@@ -418,7 +423,9 @@ __device__ __forceinline__ void wino4_body(const WParams& p, lds_char* const L, 
         }
         f32x4 bv = fresh_zero4();
         if (p.bias && p.nsplit == 1) bv = *reinterpret_cast<const f32x4*>(p.bias + col);
-        if (p.nsplit > 1) {
+        if (!live) {
+            // (nothing to store: an unused tile slot, or a tile row past the end of the stack)
+        } else if (p.nsplit > 1) {
             float* const base = p.partial + (long)sp * p.N * p.H * p.W * p.Kout + col;
 #pragma unroll
             for (int x = 0; x < 4; ++x) *reinterpret_cast<f32x4*>(base + (pix + x) * p.Kout) = v[x];
@@ -566,7 +573,17 @@ static int block_width(const DpigConvDesc* d) {
     const long rows = (long)d->N * (d->H / 4);
     if (tw % 4 == 0 && rows % 8 == 0) return 4;
     if (tw % 2 == 0 && rows % 16 == 0) return 2;
+    if (tw % 3 == 0) return 3;                 // 3 x 10 tiles (30 of the 32 slots), a partial last block where the stack's rows are no multiple of 10
+    if (tw % 4 == 0) return 4;                 // the even widths with a partial last block
+    if (tw % 2 == 0) return 2;
     return 0;
+}
+// row blocks x column blocks of the tile grid
+static long tile_blocks(const DpigConvDesc* d) {
+    const int bw = block_width(d);
+    if (!bw) return 0;
+    const long rows = (long)d->N * (d->H / 4);
+    return cdiv(rows, TB / bw) * ((d->W / 4) / bw);
 }
 // geometry both entry points share: 3 x 3, stride 1, SAME, sides multiples of 4 with a block form, 16-byte addressable channel vectors
 static bool shape_ok(const DpigConvDesc* d, int cin, int kout, int ld_in, int ld_out) {
@@ -587,8 +604,7 @@ static bool shape_ok(const DpigConvDesc* d, int cin, int kout, int ld_in, int ld
 constexpr double CHUNK_CYCLES = 5900.0, FIXED_CYCLES = 26000.0;
 struct FPlan { int nsplit, cps; double cycles; };
 static FPlan fwd_plan(const DpigConvDesc* d, int cin, int kout) {
-    const long T = (long)d->N * (d->H / 4) * (d->W / 4);
-    const long wgs1 = (T / TB) * (kout / KB);
+    const long wgs1 = tile_blocks(d) * (kout / KB);
     const int nch = cin / CH;
     FPlan best = {1, nch, 0.0};
     static const int force = getenv("DPIG_WINO_SPLIT") ? atoi(getenv("DPIG_WINO_SPLIT")) : 0;       // (A/B switch: 1 = never split)
@@ -621,7 +637,7 @@ static int launch(const DpigConvDesc* d, const float* in, const float* U, const 
     p.ldx = ld_in; p.ldd = ld_out; p.ldres = d->ldres; p.ldmask = d->ldmask; p.ldd2 = d->ldy2;
     p.TW = d->W / 4; p.THW = (d->H / 4) * p.TW; p.T = d->N * p.THW;
     p.nch = cin / CH;
-    p.mtiles = p.T / TB; p.ntiles = kout / KB;
+    p.mtiles = (int)tile_blocks(d); p.ntiles = kout / KB;
     p.act = act; p.alpha = d->alpha; p.res_post = d->res_after_act;
     p.x_bytes = (unsigned)((long)d->N * d->H * d->W * ld_in * 4);
     p.u_bytes = (unsigned)((long)36 * cin * kout * 4);
@@ -648,6 +664,7 @@ static int launch(const DpigConvDesc* d, const float* in, const float* U, const 
     const dim3 pgrid((pers && atoi(pers) == 0) || items <= (unsigned)kNumCU ? items : (unsigned)kNumCU);
     static const int ko = getenv("DPIG_WINO4_KO") ? atoi(getenv("DPIG_WINO4_KO")) : 0;
     if (block_width(d) == 2) hipLaunchKernelGGL(wino4_kernel<2>, pgrid, dim3(512), 0, st, p);
+    else if (block_width(d) == 3) hipLaunchKernelGGL(wino4_kernel<3>, pgrid, dim3(512), 0, st, p);
 #ifdef DPIG_WINO4_KNOCKOUT
     else if (ko == 1) hipLaunchKernelGGL((wino4_kernel<4, 1>), pgrid, dim3(512), 0, st, p);
     else if (ko == 2) hipLaunchKernelGGL((wino4_kernel<4, 2>), pgrid, dim3(512), 0, st, p);

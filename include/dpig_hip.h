@@ -224,7 +224,8 @@ int dpig_conv2d_wgrad_wino(const DpigConvDesc* d, const float* x, const float* d
  *   dpig_wino4_filter_elems / dpig_wino4_filter_transform / dpig_wino4_filter_transform_jobs (the job table and plan of
  *   dpig_wino_filter_jobs_plan serve both families: the block numbering is the same)
  *   dpig_conv2d_wino4_eligible   the descriptor has the form (3x3, stride 1, H and W multiples of 4, the tile grid cut into blocks of
- *                                4 x 8 or 2 x 16 tiles on the stack of all images' tile rows, C and K multiples of 64) AND the cost
+ *                                4 x 8, 2 x 16 or 3 x 10 tiles on the stack of all images' tile rows -- W / 4 even or a multiple of 3;
+ *                                the last block may be partial --, C and K multiples of 64) AND the cost
  *                                model expects it to beat the F(2x2, 3x3) kernel; dpig_conv_wino4_set_mode / DPIG_WINO4: 0 never,
  *                                1 cost model (default), 2 wherever legal
  *   dpig_conv2d_fwd_wino4 / dpig_conv2d_dgrad_wino4 / dpig_conv2d_wino4_workspace_bytes   as their F(2x2, 3x3) namesakes */

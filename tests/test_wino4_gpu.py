@@ -2,7 +2,7 @@
 the 'f32w' mode of hip_ops, against the fp64 oracle (oracle.ops.conv2d_same + its autograd gradient).  Bar: 5e-5 of max|ref| -- the
 form's transforms multiply by constants up to 8 (inputs), 1/24 (filters) and 8 (outputs), one decimal digit more rounding than
 F(2x2, 3x3)'s 2e-5 (profiles/r06_f43_numerics.txt: 1.3e-5 on a single layer of random data).  Shapes hit every structural edge:
-both block forms (4 x 8 and 2 x 16 tiles), blocks that straddle images (zero padding where the stack holds the other image), one
+all three block forms (4 x 8, 2 x 16 and 3 x 10 tiles; partial last blocks), blocks that straddle images (zero padding where the stack holds the other image), one
 block column / several, one and several channel blocks and chunks, split plans, channel slices and every fused epilogue."""
 import ctypes
 
@@ -48,7 +48,12 @@ SHAPES = [
     (1, 64, 24, 64, 192),     # W / 4 = 6 tile columns: block form 2 x 16, three block columns, three channel blocks
     (3, 32, 48, 128, 128),    # 12 tile columns = 3 blocks of 4; 24 tile rows = 3 block rows straddling image borders
     (2, 16, 16, 448, 64),     # 56 chunks on 2 workgroups: an input-channel split plan
-    (7, 24, 24, 64, 64),      # the ROI tower's form: 6 x 6 tiles per image, blocks of 2 x 16 over 42 tile rows... (42 % 16 != 0: no block form)
+    (7, 24, 24, 64, 64),      # 6 x 6 tiles per image, 42 tile rows (no multiple of 16): the 3-wide form, 3 x 10 tiles in 30 of the 32 slots, partial last block
+    (5, 12, 12, 64, 128),     # the ROI tower's 12 x 12 level: three tile columns, blocks of 10 tile rows over 3.3 images each
+    (3, 8, 16, 64, 64),       # 4 tile columns, 6 tile rows: one partial 4 x 8 block
+    (1, 4, 8, 64, 64),        # 2 tile columns, ONE tile row: a 2 x 16 block with a single live row
+    (2, 12, 36, 64, 64),      # 9 tile columns: three 3-wide block columns
+    (2, 6, 6, 64, 64),        # sides no multiples of 4: no F(4x4) form, stays on F(2x2, 3x3)
 ]
 
 
@@ -69,7 +74,7 @@ def test_forward_and_dgrad_against_oracle(dev, wino4, shape):
     dy = _rand(tuple(ref.shape), 4)
     xd, wd, bd, dyd = x.detach().float().to(dev), w.float().to(dev), b.float().to(dev), dy.float().to(dev)
     form = _has_form(H, N, Hh, W, C, K)
-    assert form == (shape != (7, 24, 24, 64, 64))
+    assert form == (shape != (2, 6, 6, 64, 64))
     H.PROFILE = []
     try:
         y = H.conv2d_fwd(xd, wd, bd)
@@ -94,7 +99,7 @@ def test_forward_and_dgrad_against_oracle(dev, wino4, shape):
     assert torch.equal(H.conv2d_dgrad(dyd, wd, (N, Hh, W, C)), dx)
 
 
-@pytest.mark.parametrize("geom", [(2, 16, 16), (8, 8, 8)], ids=["block4x8", "block2x16"])
+@pytest.mark.parametrize("geom", [(2, 16, 16), (8, 8, 8), (5, 12, 12)], ids=["block4x8", "block2x16", "block3x10"])
 def test_fused_epilogues_and_channel_slices(dev, wino4, geom):
     H = wino4
     from oracle import ops as O
