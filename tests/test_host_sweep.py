@@ -55,6 +55,13 @@ def test_planning_surface_over_a_descriptor_grid(H):
                 assert el in (0, 1) and 0 <= ws < TB
                 if d.R != 3 or d.stride != 1 or d.C % 64 or d.K % 64 or d.H % 2 or d.W % 2 or d.upsample2x:
                     assert el == 0 and ws == 0
+                el4 = lib.dpig_conv2d_wino4_eligible(r, which)                    # the F(4x4, 3x3) form: sides multiples of 4, a block form
+                ws4 = lib.dpig_conv2d_wino4_workspace_bytes(r, which)
+                assert el4 in (0, 1) and 0 <= ws4 < TB
+                tw = d.W // 4
+                if d.R != 3 or d.stride != 1 or d.C % 64 or d.K % 64 or d.H % 4 or d.W % 4 or d.upsample2x or (tw % 2 and tw % 3):
+                    assert el4 == 0 and ws4 == 0
+                assert compute == H.COMPUTE_F32 or el4 == 0
             el = lib.dpig_conv2d_wgrad_wino_eligible(r)
             ws = lib.dpig_conv2d_wgrad_wino_workspace_bytes(r)
             assert el in (0, 1) and 0 <= ws < TB and (compute == H.COMPUTE_F32 or el == 0)
@@ -77,6 +84,10 @@ def test_hostile_descriptors_are_refused_not_dereferenced(H):
         assert lib.dpig_conv2d_wino_eligible(r, 0) in (0, 1) and lib.dpig_conv2d_wgrad_wino_eligible(r) in (0, 1)
         lib.dpig_conv2d_wino_workspace_bytes(r, 0)
         lib.dpig_conv2d_wgrad_wino_workspace_bytes(r)
+        assert lib.dpig_conv2d_wino4_eligible(r, 0) in (0, 1) and lib.dpig_conv2d_wino4_eligible(r, 1) in (0, 1)
+        lib.dpig_conv2d_wino4_workspace_bytes(r, 0)
+        assert lib.dpig_conv2d_fwd_wino4(r, None, None, None, None, None, None, None, 0, None) != 0
+        assert lib.dpig_conv2d_dgrad_wino4(r, None, None, None, None, None, None, 0, None) != 0
         # the launching entry points refuse such a descriptor (or their null tensors) BEFORE touching the device: non-zero status, a message
         rc = lib.dpig_conv2d_fwd(r, None, None, None, None, None, None, None, 0, None)
         assert rc != 0 and lib.dpig_last_error()
@@ -85,6 +96,7 @@ def test_hostile_descriptors_are_refused_not_dereferenced(H):
     null = ctypes.POINTER(type(good))()
     assert lib.dpig_conv2d_workspace_bytes(null, 0) == 0 and lib.dpig_conv2d_bf16_workspace_bytes(null, 0) == 0
     assert lib.dpig_conv2d_wino_eligible(null, 0) == 0 and lib.dpig_conv2d_wgrad_wino_eligible(null) == 0
+    assert lib.dpig_conv2d_wino4_eligible(null, 0) == 0 and lib.dpig_conv2d_wino4_workspace_bytes(null, 0) == 0
     assert lib.dpig_conv2d_fwd(null, None, None, None, None, None, None, None, 0, None) != 0
 
 
@@ -103,6 +115,7 @@ def test_scalar_sizing_functions_over_a_grid(H):
     for C, K in itertools.product((0, -64, 3, 64, 96, 128, 1024), repeat=2):
         n = lib.dpig_wino_filter_elems(C, K)
         assert n == (16 * C * K if (C > 0 and K > 0 and C % 64 == 0 and K % 64 == 0) else 0)
+        assert lib.dpig_wino4_filter_elems(C, K) == (36 * C * K if (C > 0 and K > 0 and C % 64 == 0 and K % 64 == 0) else 0)
     for inp, k, s in itertools.product((1, 2, 3, 63, 64, 128), (1, 3, 5), (1, 2)):
         out, pad = ctypes.c_int(), ctypes.c_int()
         assert lib.dpig_same_pad(inp, k, s, ctypes.byref(out), ctypes.byref(pad)) == 0

@@ -35,6 +35,40 @@ def test_cost_model_choices_on_the_market_layers(H):
         assert lib.dpig_conv2d_wgrad_wino_eligible(ctypes.byref(d)) == (0 if name in WGRAD_DIRECT else 1), name
 
 
+F4_CHOICE = {"enc0", "roi b0", "enc1", "roi b1", "enc2", "roi b2", "dec1", "dec2", "dec3", "dec4"}      # measured faster on each (profiles/r06_wino4_layers.txt)
+F4_NO_FORM = {"roi b3", "enc4", "dec0"}          # 6 x 6: sides no multiples of 4; 8 x 4: one tile column
+
+
+def test_f4_cost_model_choices_on_the_market_layers(H):
+    """The F(4x4, 3x3) kernel's selection on the Market layer shapes: the form where it measured faster than F(2x2, 3x3), the 3-wide
+    block form on the 12 x 12 level, F(2x2) on 16 x 8 C512 (a cost-model call: 1.15x stand-alone, cancelled by its image refresh) and on
+    the maps without a form; mode 0 switches it off, mode 2 takes every layer with the form."""
+    lib = H.lib()
+    lib.dpig_conv_wino_set_mode(1)
+    try:
+        lib.dpig_conv_wino4_set_mode(1)
+        for name, N, Hh, W, C in MARKET:
+            d = _desc(H, N, Hh, W, C, C)
+            for which in (0, 1):
+                assert lib.dpig_conv2d_wino4_eligible(ctypes.byref(d), which) == (1 if name in F4_CHOICE else 0), (name, which)
+        lib.dpig_conv_wino4_set_mode(2)
+        for name, N, Hh, W, C in MARKET:
+            d = _desc(H, N, Hh, W, C, C)
+            assert lib.dpig_conv2d_wino4_eligible(ctypes.byref(d), 0) == (0 if name in F4_NO_FORM else 1), name
+        # split plans: 32 x 16 C384 has 96 items for 256 CUs -> two input-channel ranges, their partial outputs in the workspace
+        d = _desc(H, 16, 32, 16, 384, 384)
+        assert lib.dpig_conv2d_wino4_workspace_bytes(ctypes.byref(d), 0) == 2 * 16 * 32 * 16 * 384 * 4
+        d = _desc(H, 16, 128, 64, 256, 256)
+        assert lib.dpig_conv2d_wino4_workspace_bytes(ctypes.byref(d), 0) == 0
+        lib.dpig_conv_wino4_set_mode(0)
+        for name, N, Hh, W, C in MARKET:
+            d = _desc(H, N, Hh, W, C, C)
+            assert lib.dpig_conv2d_wino4_eligible(ctypes.byref(d), 0) == 0
+        assert lib.dpig_conv_wino4_set_mode(3) != 0 and lib.dpig_conv_wino4_set_mode(-1) != 0
+    finally:
+        lib.dpig_conv_wino4_set_mode(1)
+
+
 def test_shapes_without_a_winograd_form_are_refused_in_every_mode(H):
     lib = H.lib()
     try:
