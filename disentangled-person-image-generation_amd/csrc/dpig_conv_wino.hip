@@ -584,9 +584,9 @@ struct WGParams {
     unsigned mul_thw, shr_thw, mul_tw, shr_tw;
 };
 
-template <bool SLICE_FIRST>
+template <bool SLICE_FIRST, int KO = 0, bool XCH = true>      // XCH: the x row transform's partner row through LDS instead of ds_bpermute; KO (builds with -DDPIG_WINO4_KNOCKOUT only; results are wrong): 1 no x arithmetic, 2 no dy arithmetic, 4 no ds_bpermute
 __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WGParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[4 * OPB];
+    __shared__ __attribute__((aligned(16))) char smem[4 * OPB + 8 * 4096];      // + a 4-KB exchange area per wave (row transform of x)
     lds_char* const L = (lds_char*)smem;
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -663,13 +663,30 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WGParams p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float own = d[j][e];               // (a named scalar: bit-casting the vector element in place made clang move element 0 four times)
-                const float o = __int_as_float(__builtin_amdgcn_ds_bpermute(peer, __float_as_int(own)));
-                r[j][e] = sgn * o + own;
+                const float o = (KO & 4) ? own : __int_as_float(__builtin_amdgcn_ds_bpermute(peer, __float_as_int(own)));
+                r[j][e] = (KO & 1) ? o : sgn * o + own;
             }
+    };
+    // the same through the wave's exchange area: four 16-byte stores of the own row, four 16-byte reads of the partner's (the LDS runs a
+    // wave's operations in order: no wait between them) instead of sixteen ds_bpermute_b32 -- knock-out builds put 6 % of the kernel on
+    // those sixteen (scripts/ko_wgrad.sh)
+    const int xch_wr = 4 * OPB + wave * 4096 + lane * 16, xch_rd = 4 * OPB + wave * 4096 + (((xi < 2) ? 2 : 1) * 16 + cq) * 16;
+    typedef const __attribute__((address_space(3))) f32x4 lds_cf4x;
+    auto rowX2 = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *(lds_f4*)(L + xch_wr + j * 1024) = d[j];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const f32x4 o = *(lds_cf4x*)(L + xch_rd + j * 1024);
+            r[j] = sgn * o + d[j];
+        }
     };
     auto colsX = [&](int buf, int pair) {
         lds_char* const base = L + buf * OPB + wr_off;
-        if (pair == 0) {
+        if (KO & 1) {
+            *(lds_f4*)(base + (2 * pair) * PLANE) = r[2 * pair];
+            *(lds_f4*)(base + (2 * pair + 1) * PLANE) = r[2 * pair + 1];
+        } else if (pair == 0) {
             *(lds_f4*)(base + 0 * PLANE) = r[0] - r[2];
             *(lds_f4*)(base + 1 * PLANE) = r[1] + r[2];
         } else {
@@ -678,13 +695,17 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WGParams p) {
         }
     };
     auto rowY = [&]() {
+        if (KO & 2) { ry[0] = y[0][0]; ry[1] = y[1][1]; return; }
 #pragma unroll
         for (int j = 0; j < 2; ++j) ry[j] = ga * y[0][j] + gb * y[1][j];
         if (sum_bias) bsum += (y[0][0] + y[0][1]) + (y[1][0] + y[1][1]);     // (tiles past the range loaded zeros)
     };
     auto colsY = [&](int buf, int pair) {
         lds_char* const base = L + 2 * OPB + buf * OPB + wr_off;
-        if (pair == 0) {
+        if (KO & 2) {
+            *(lds_f4*)(base + (2 * pair) * PLANE) = ry[0];
+            *(lds_f4*)(base + (2 * pair + 1) * PLANE) = ry[1];
+        } else if (pair == 0) {
             *(lds_f4*)(base + 0 * PLANE) = ry[0];
             *(lds_f4*)(base + 1 * PLANE) = 0.5f * (ry[0] + ry[1]);
         } else {
@@ -707,7 +728,8 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WGParams p) {
     // ---- prologue: chunk ch0 staged, chunk ch0 + 1 in registers ------------------------------------------------------------------------
     tile_offsets(ch0);
     loadX(); loadY();
-    rowX(); colsX(0, 0); colsX(0, 1);
+    if (XCH) rowX2(); else rowX();
+    colsX(0, 0); colsX(0, 1);
     rowY(); colsY(0, 0); colsY(0, 1);
     tile_offsets(ch0 + 1);
     loadX(); loadY();
@@ -732,7 +754,7 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WGParams p) {
                 }
             }
             auto slice = [&]() {
-                if (pp == 0) { tile_offsets(c + 2); rowX(); rowY(); }
+                if (pp == 0) { tile_offsets(c + 2); if (XCH) rowX2(); else rowX(); rowY(); }
                 if (pp == 1) { loadX(); loadY(); }
                 if (pp == 2) colsX(buf ^ 1, 0);
                 if (pp == 3) colsX(buf ^ 1, 1);
@@ -1165,7 +1187,17 @@ extern "C" int dpig_conv2d_wgrad_wino(const DpigConvDesc* d, const float* x, con
     find_divisor(p.THW, &p.mul_thw, &p.shr_thw);
     find_divisor(p.TW, &p.mul_tw, &p.shr_tw);
     static const bool slice_first = getenv("DPIG_WINO_WG_ORDER") && atoi(getenv("DPIG_WINO_WG_ORDER")) == 1;      // (A/B switch)
-    if (slice_first) hipLaunchKernelGGL(wino::wino_wgrad_kernel<true>, dim3(p.cblocks * p.kblocks * p.nsplit), dim3(512), 0, st, p);
+#ifdef DPIG_WINO4_KNOCKOUT
+    static const int wg_ko = getenv("DPIG_WINO_WG_KO") ? atoi(getenv("DPIG_WINO_WG_KO")) : 0;
+    if (wg_ko == 1) hipLaunchKernelGGL((wino::wino_wgrad_kernel<false, 1>), dim3(p.cblocks * p.kblocks * p.nsplit), dim3(512), 0, st, p);
+    else if (wg_ko == 2) hipLaunchKernelGGL((wino::wino_wgrad_kernel<false, 2>), dim3(p.cblocks * p.kblocks * p.nsplit), dim3(512), 0, st, p);
+    else if (wg_ko == 3) hipLaunchKernelGGL((wino::wino_wgrad_kernel<false, 3>), dim3(p.cblocks * p.kblocks * p.nsplit), dim3(512), 0, st, p);
+    else if (wg_ko == 7) hipLaunchKernelGGL((wino::wino_wgrad_kernel<false, 7>), dim3(p.cblocks * p.kblocks * p.nsplit), dim3(512), 0, st, p);
+    else
+#endif
+    static const bool no_xch = getenv("DPIG_WINO_WG_XCH") && atoi(getenv("DPIG_WINO_WG_XCH")) == 0;       // (A/B switch: the ds_bpermute form)
+    if (no_xch) hipLaunchKernelGGL((wino::wino_wgrad_kernel<false, 0, false>), dim3(p.cblocks * p.kblocks * p.nsplit), dim3(512), 0, st, p);
+    else if (slice_first) hipLaunchKernelGGL(wino::wino_wgrad_kernel<true>, dim3(p.cblocks * p.kblocks * p.nsplit), dim3(512), 0, st, p);
     else hipLaunchKernelGGL(wino::wino_wgrad_kernel<false>, dim3(p.cblocks * p.kblocks * p.nsplit), dim3(512), 0, st, p);
     rc = check_launch("wino_wgrad_kernel");
     if (rc) return rc;
