@@ -132,7 +132,9 @@ def build_cases():
         for slack in (0, 64):
             cases.append(("conv f32w N%d %dx%d C%d K%d slack%d" % (N, Hh, W, C, K, slack), conv_case(N, Hh, W, C, K, 3, 1, "f32w", slack=slack)))
     # F(4x4,3x3) forms: one 4 x 8 block, a 2 x 16 block holding eight images, block rows that straddle images, a split plan
-    for (N, Hh, W, C, K) in ((1, 32, 16, 64, 64), (8, 8, 8, 64, 128), (2, 16, 16, 128, 64), (2, 16, 16, 448, 64)):
+    # (+ the 3-wide form with its unused tile slots and partial last block, a partial 4 x 8 block, a 2 x 16 block with one live tile row)
+    for (N, Hh, W, C, K) in ((1, 32, 16, 64, 64), (8, 8, 8, 64, 128), (2, 16, 16, 128, 64), (2, 16, 16, 448, 64),
+                             (5, 12, 12, 64, 128), (7, 24, 24, 64, 64), (3, 8, 16, 64, 64), (1, 4, 8, 64, 64)):
         for slack in (0, 64):
             cases.append(("conv f32w F(4x4) N%d %dx%d C%d K%d slack%d" % (N, Hh, W, C, K, slack), conv_case(N, Hh, W, C, K, 3, 1, "f32w4", slack=slack)))
     for (N, Hh, W, C, K) in ((1, 1, 1, 20, 6), (2, 3, 3, 72, 24), (1, 4, 2, 64, 16)):           # upsample-fused 1x1 / 3x3
