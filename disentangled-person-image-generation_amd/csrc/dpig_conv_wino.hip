@@ -584,7 +584,7 @@ struct WGParams {
     unsigned mul_thw, shr_thw, mul_tw, shr_tw;
 };
 
-template <bool SLICE_FIRST, int KO = 0, bool XCH = true>      // XCH: the x row transform's partner row through LDS instead of ds_bpermute; KO (builds with -DDPIG_WINO4_KNOCKOUT only; results are wrong): 1 no x arithmetic, 2 no dy arithmetic, 4 no ds_bpermute
+template <bool SLICE_FIRST, int KO = 0, bool XCH = true>      // XCH: the x row transform's partner row through LDS instead of ds_bpermute; KO (builds with -DDPIG_WINO4_KNOCKOUT only; results are wrong): 1 no x arithmetic, 2 no dy arithmetic, 4 no ds_bpermute, 8 no per-chunk address arithmetic
 __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WGParams p) {
     __shared__ __attribute__((aligned(16))) char smem[4 * OPB + 8 * 4096];      // + a 4-KB exchange area per wave (row transform of x)
     lds_char* const L = (lds_char*)smem;
@@ -619,8 +619,18 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WGParams p) {
     // multiplies (full rate).  The stack's pixel row of tile row (n, ty) is n H + 2 ty.
     const int ldx4 = p.ldx * 4, ldy4 = p.ldy * 4;
     const int rsx = p.W * ldx4, rsy = p.W * ldy4;                   // bytes per pixel row
-    int xoff[4], yoff[2][2];
-    auto tile_offsets = [&](int chunk) {                             // offsets of tile 8 chunk + tl (all out of range past the batch)
+    // Addresses = (scalar part of the wave's tile, per chunk, in the loads' scalar offset) + (a lane's patch row and channel quad, made
+    // once).  The x descriptor starts one pixel row and one pixel BEFORE the tensor so that the scalar part (tile's pixel row 2 ty - 1,
+    // column 2 tx - 1) is never negative; nothing is read there: a lane whose patch row or column lies outside the image gets an
+    // out-of-range vector offset (zero fill).  Per chunk that is three vector selects instead of ~30 vector instructions of address
+    // arithmetic -- knock-out builds put 4.5 % of the kernel on them
+    // (scripts/ko_wgrad.sh; every vector instruction of this loop costs matrix-pipe time).
+    const __amdgpu_buffer_rsrc_t rsX1 = make_rsrc(reinterpret_cast<const char*>(p.X) - (rsx + ldx4), p.x_bytes + (unsigned)(rsx + ldx4));
+    const int vx_lane = xi * rsx + xcol;                             // + j ldx4 in the scalar offset
+    int sx, sy;                                                      // scalar parts of the current tile (x: row r2 - 1 / column 2 tx - 1 folded into the descriptor)
+    int xv;                                                          // this lane's vector offset for the x loads, or out of range
+    bool x_left, x_right, y_ok;                                      // wave-uniform: patch column 0 / 3 inside the image, tile inside the range
+    auto tile_offsets = [&](int chunk) {                             // the tile 8 chunk + tl
         const int t = chunk * 8 + tl;
         const bool tok = (chunk < ch1) & (t < p.T);
         const int tt = tok ? t : 0;
@@ -628,29 +638,28 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WGParams p) {
         const int rem = tt - n * p.THW;
         const int ty = fast_div(rem, p.mul_tw, p.shr_tw);
         const int tx = rem - ty * p.TW;
-        const int r2 = __mul24(n, p.H) + 2 * ty;
-        const bool rok = tok && (unsigned)(2 * ty - 1 + xi) < (unsigned)p.H;
-        const int xb = __mul24(r2 - 1 + xi, rsx) + __mul24(2 * tx - 1, ldx4) + xcol;
-        const int yb = __mul24(r2, rsy) + __mul24(2 * tx, ldy4) + ycol;
-        xoff[0] = (rok && tx > 0) ? xb : (int)OOB;
-        xoff[1] = rok ? xb + ldx4 : (int)OOB;
-        xoff[2] = rok ? xb + 2 * ldx4 : (int)OOB;
-        xoff[3] = (rok && tx < p.TW - 1) ? xb + 3 * ldx4 : (int)OOB;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j) yoff[i][j] = tok ? yb + i * rsy + j * ldy4 : (int)OOB;
+        const int r2 = n * p.H + 2 * ty;
+        sx = r2 * rsx + 2 * tx * ldx4;
+        sy = r2 * rsy + 2 * tx * ldy4;
+        const bool dead = !tok | ((ty == 0) & (xi == 0)) | ((2 * ty + 2 == p.H) & (xi == 3));
+        xv = dead ? (int)OOB : vx_lane;
+        x_left = tok & (tx > 0);
+        x_right = tok & (tx < p.TW - 1);
+        y_ok = tok;
     };
     f32x4 d[4], y[2][2];
-    auto loadX = [&]() {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) d[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX, xoff[j], 0, 0));
+    auto loadX = [&]() {                             // (the edge columns by an out-of-range vector offset too: no load is ever conditional)
+        d[0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX1, x_left ? xv : (int)OOB, sx, 0));
+        d[1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX1, xv, sx + ldx4, 0));
+        d[2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX1, xv, sx + 2 * ldx4, 0));
+        d[3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsX1, x_right ? xv : (int)OOB, sx + 3 * ldx4, 0));
     };
     auto loadY = [&]() {
+        const int yv = y_ok ? ycol : (int)OOB;
 #pragma unroll
         for (int i = 0; i < 2; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j) y[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsY, yoff[i][j], 0, 0));
+            for (int j = 0; j < 2; ++j) y[i][j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rsY, yv, sy + i * rsy + j * ldy4, 0));
     };
     typedef __attribute__((address_space(3))) f32x4 lds_f4;
     const int wr_off = (4 * xi) * PLANE + tl * 256 + cq * 16;        // [position 4 xi + nu][tile tl][channel quad cq]
@@ -754,7 +763,7 @@ __global__ __launch_bounds__(512, 2) void wino_wgrad_kernel(const WGParams p) {
                 }
             }
             auto slice = [&]() {
-                if (pp == 0) { tile_offsets(c + 2); if (XCH) rowX2(); else rowX(); rowY(); }
+                if (pp == 0) { if (!(KO & 8)) tile_offsets(c + 2); if (XCH) rowX2(); else rowX(); rowY(); }
                 if (pp == 1) { loadX(); loadY(); }
                 if (pp == 2) colsX(buf ^ 1, 0);
                 if (pp == 3) colsX(buf ^ 1, 1);
@@ -1187,15 +1196,17 @@ extern "C" int dpig_conv2d_wgrad_wino(const DpigConvDesc* d, const float* x, con
     find_divisor(p.THW, &p.mul_thw, &p.shr_thw);
     find_divisor(p.TW, &p.mul_tw, &p.shr_tw);
     static const bool slice_first = getenv("DPIG_WINO_WG_ORDER") && atoi(getenv("DPIG_WINO_WG_ORDER")) == 1;      // (A/B switch)
+    static const bool no_xch = getenv("DPIG_WINO_WG_XCH") && atoi(getenv("DPIG_WINO_WG_XCH")) == 0;       // (A/B switch: the ds_bpermute form)
 #ifdef DPIG_WINO4_KNOCKOUT
     static const int wg_ko = getenv("DPIG_WINO_WG_KO") ? atoi(getenv("DPIG_WINO_WG_KO")) : 0;
     if (wg_ko == 1) hipLaunchKernelGGL((wino::wino_wgrad_kernel<false, 1>), dim3(p.cblocks * p.kblocks * p.nsplit), dim3(512), 0, st, p);
     else if (wg_ko == 2) hipLaunchKernelGGL((wino::wino_wgrad_kernel<false, 2>), dim3(p.cblocks * p.kblocks * p.nsplit), dim3(512), 0, st, p);
     else if (wg_ko == 3) hipLaunchKernelGGL((wino::wino_wgrad_kernel<false, 3>), dim3(p.cblocks * p.kblocks * p.nsplit), dim3(512), 0, st, p);
     else if (wg_ko == 7) hipLaunchKernelGGL((wino::wino_wgrad_kernel<false, 7>), dim3(p.cblocks * p.kblocks * p.nsplit), dim3(512), 0, st, p);
+    else if (wg_ko == 8) hipLaunchKernelGGL((wino::wino_wgrad_kernel<false, 8>), dim3(p.cblocks * p.kblocks * p.nsplit), dim3(512), 0, st, p);
+    else if (wg_ko == 15) hipLaunchKernelGGL((wino::wino_wgrad_kernel<false, 15>), dim3(p.cblocks * p.kblocks * p.nsplit), dim3(512), 0, st, p);
     else
 #endif
-    static const bool no_xch = getenv("DPIG_WINO_WG_XCH") && atoi(getenv("DPIG_WINO_WG_XCH")) == 0;       // (A/B switch: the ds_bpermute form)
     if (no_xch) hipLaunchKernelGGL((wino::wino_wgrad_kernel<false, 0, false>), dim3(p.cblocks * p.kblocks * p.nsplit), dim3(512), 0, st, p);
     else if (slice_first) hipLaunchKernelGGL(wino::wino_wgrad_kernel<true>, dim3(p.cblocks * p.kblocks * p.nsplit), dim3(512), 0, st, p);
     else hipLaunchKernelGGL(wino::wino_wgrad_kernel<false>, dim3(p.cblocks * p.kblocks * p.nsplit), dim3(512), 0, st, p);
